@@ -1,0 +1,218 @@
+"""oracle/oracle.py -- TEST INFRASTRUCTURE ONLY: ctypes access to the checker libraries.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module
+(the product path under 7-zip-zstd_amd/ never does).
+
+  port : oracle/libgc_oracle.so        -- this repo's plain-C restatement (zstd_frame_dec.c) + corpus generators
+  ref  : oracle/_ref/lib*_ref.so       -- the reference's own C codecs compiled from /root/reference by oracle/Makefile
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_SZ = C.c_size_t
+_VP = C.c_void_p
+
+
+def build(verbose=False):
+    """Compile the restatement and, if /root/reference is present, the reference libraries."""
+    r = subprocess.run(["make", "-C", HERE, "-j8", "all"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("oracle build failed:\n" + r.stdout + r.stderr)
+    if verbose:
+        print(r.stdout)
+
+
+def _load(path):
+    if not os.path.exists(path):
+        return None
+    return C.CDLL(path)
+
+
+_port = None
+_ref = {}
+
+
+def port():
+    global _port
+    if _port is None:
+        p = os.path.join(HERE, "libgc_oracle.so")
+        if not os.path.exists(p):
+            build()
+        _port = C.CDLL(p)
+        _port.gco_zstd_decompress.argtypes = [_VP, _SZ, _VP, _SZ, C.POINTER(_SZ)]
+        _port.gco_zstd_decompress.restype = C.c_int
+        _port.gco_last_diag.restype = C.POINTER(_Diag)
+        _port.gco_xxh64.argtypes = [_VP, _SZ, C.c_uint64]
+        _port.gco_xxh64.restype = C.c_uint64
+        for name in ("gc_corpus_text_zipf", "gc_corpus_webtext", "gc_corpus_silesia_like"):
+            getattr(_port, name).argtypes = [_VP, _SZ, C.c_uint64]
+        _port.gc_corpus_lz7zip.argtypes = [_VP, _SZ, C.c_uint, C.c_uint32]
+    return _port
+
+
+class _Diag(C.Structure):
+    _fields_ = [("code", C.c_int), ("line", C.c_int), ("src_pos", _SZ), ("dst_pos", _SZ),
+                ("frames", C.c_uint), ("blocks", C.c_uint)]
+
+
+def ref(name):
+    """name in {'zstd','flzma2','brotli'}; returns CDLL or None when the prebuilt .so is absent."""
+    if name not in _ref:
+        lib = _load(os.path.join(HERE, "_ref", "lib%s_ref.so" % name))
+        if lib is not None:
+            if name == "zstd":
+                lib.ref_zstd_compress.argtypes = [_VP, _SZ, _VP, _SZ, C.c_int, C.c_int]
+                lib.ref_zstd_compress_pieces.argtypes = [_VP, _SZ, _VP, _SZ, C.c_int, _SZ]
+                lib.ref_zstd_decompress.argtypes = [_VP, _SZ, _VP, _SZ]
+                lib.ref_zstd_compress_bound.argtypes = [_SZ]
+                lib.ref_zstd_compress_sequences.argtypes = [_VP, _SZ, _VP, _VP, _VP, _SZ, _VP, _SZ, C.c_int]
+                for f in ("ref_zstd_compress", "ref_zstd_compress_pieces", "ref_zstd_decompress",
+                          "ref_zstd_compress_bound", "ref_zstd_compress_sequences"):
+                    getattr(lib, f).restype = _SZ
+            elif name == "flzma2":
+                lib.ref_fl2_compress.argtypes = [_VP, _SZ, _VP, _SZ, C.c_int, C.c_uint, C.POINTER(C.c_ubyte)]
+                lib.ref_fl2_compress.restype = _SZ
+                lib.ref_lzma2_decode.argtypes = [_VP, _SZ, _VP, _SZ, C.c_ubyte]
+                lib.ref_lzma2_decode.restype = _SZ
+            elif name == "brotli":
+                lib.ref_brotli_compress.argtypes = [_VP, _SZ, _VP, _SZ, C.c_int, C.c_int]
+                lib.ref_brotli_decompress.argtypes = [_VP, _SZ, _VP, _SZ]
+                lib.ref_brotlimt_compress.argtypes = [_VP, _SZ, _VP, _SZ, C.c_int, C.c_int]
+                lib.ref_brotlimt_decompress.argtypes = [_VP, _SZ, _VP, _SZ, C.c_int]
+                for f in ("ref_brotli_compress", "ref_brotli_decompress", "ref_brotlimt_compress",
+                          "ref_brotlimt_decompress"):
+                    getattr(lib, f).restype = _SZ
+        _ref[name] = lib
+    return _ref[name]
+
+
+_BAD = (1 << 64) - 1
+
+
+def _buf(x):
+    a = np.ascontiguousarray(np.frombuffer(x, dtype=np.uint8) if not isinstance(x, np.ndarray) else x, dtype=np.uint8)
+    return a, a.ctypes.data
+
+
+# ----------------------------------------------------------------------------- corpora
+def corpus(kind, n, seed=20260921):
+    out = np.empty(n, dtype=np.uint8)
+    p = port()
+    if kind == "text-zipf":
+        p.gc_corpus_text_zipf(out.ctypes.data, n, seed)
+    elif kind == "web-text":
+        p.gc_corpus_webtext(out.ctypes.data, n, seed)
+    elif kind == "lz-7zip":
+        p.gc_corpus_lz7zip(out.ctypes.data, n, 24, seed & 0xFFFFFFFF if seed != 20260921 else 0)
+    elif kind == "silesia-like":
+        p.gc_corpus_silesia_like(out.ctypes.data, n, seed)
+    elif kind == "random":
+        out[:] = np.random.default_rng(seed).integers(0, 256, n, dtype=np.uint8)
+    elif kind == "zeros":
+        out[:] = 0
+    else:
+        raise ValueError(kind)
+    return out
+
+
+# ----------------------------------------------------------------------------- zstd
+def port_zstd_decompress(comp, cap):
+    a, ap = _buf(comp)
+    out = np.empty(max(cap, 1), dtype=np.uint8)
+    n = _SZ(0)
+    rc = port().gco_zstd_decompress(out.ctypes.data, cap, ap, a.size, C.byref(n))
+    if rc != 0:
+        d = port().gco_last_diag().contents
+        raise ValueError("port zstd decode failed: code=%d line=%d src_pos=%d dst_pos=%d frames=%d blocks=%d"
+                         % (d.code, d.line, d.src_pos, d.dst_pos, d.frames, d.blocks))
+    return out[:n.value]
+
+
+def ref_zstd_decompress(comp, cap):
+    a, ap = _buf(comp)
+    out = np.empty(max(cap, 1), dtype=np.uint8)
+    r = ref("zstd").ref_zstd_decompress(out.ctypes.data, cap, ap, a.size)
+    if r == _BAD:
+        raise ValueError("reference zstd decoder rejected the stream")
+    return out[:r]
+
+
+def ref_zstd_compress(data, level=3, workers=0, piece=0):
+    a, ap = _buf(data)
+    lib = ref("zstd")
+    npieces = 1 if not piece else (a.size + piece - 1) // piece + 1
+    cap = lib.ref_zstd_compress_bound(a.size) + 64 * npieces + 64
+    out = np.empty(cap, dtype=np.uint8)
+    if piece:
+        r = lib.ref_zstd_compress_pieces(out.ctypes.data, cap, ap, a.size, level, piece)
+    else:
+        r = lib.ref_zstd_compress(out.ctypes.data, cap, ap, a.size, level, workers)
+    if r == _BAD:
+        raise RuntimeError("reference zstd compress failed")
+    return out[:r].copy()
+
+
+def ref_zstd_compress_sequences(data, offs, lls, mls, level=3):
+    a, ap = _buf(data)
+    lib = ref("zstd")
+    cap = lib.ref_zstd_compress_bound(a.size) + 1024
+    out = np.empty(cap, dtype=np.uint8)
+    o = np.ascontiguousarray(offs, dtype=np.uint32); l = np.ascontiguousarray(lls, dtype=np.uint32)
+    m = np.ascontiguousarray(mls, dtype=np.uint32)
+    r = lib.ref_zstd_compress_sequences(out.ctypes.data, cap, o.ctypes.data, l.ctypes.data, m.ctypes.data,
+                                        o.size, ap, a.size, level)
+    if r == _BAD:
+        raise RuntimeError("reference ZSTD_compressSequences rejected the sequences")
+    return out[:r].copy()
+
+
+# ----------------------------------------------------------------------------- flzma2 / brotli
+def ref_fl2_compress(data, level=5, threads=1):
+    a, ap = _buf(data)
+    cap = a.size + a.size // 8 + 4096
+    out = np.empty(cap, dtype=np.uint8)
+    prop = C.c_ubyte(0)
+    r = ref("flzma2").ref_fl2_compress(out.ctypes.data, cap, ap, a.size, level, threads, C.byref(prop))
+    if r == _BAD:
+        raise RuntimeError("reference FL2 compress failed")
+    return out[:r].copy(), prop.value
+
+
+def ref_lzma2_decode(comp, cap, prop):
+    a, ap = _buf(comp)
+    out = np.empty(max(cap, 1), dtype=np.uint8)
+    r = ref("flzma2").ref_lzma2_decode(out.ctypes.data, cap, ap, a.size, prop)
+    if r >= _BAD - 1:
+        raise ValueError("reference LZMA2 decoder rejected the stream (%d)" % (r - (1 << 64)))
+    return out[:r]
+
+
+def ref_brotlimt_compress(data, level=6, threads=1):
+    a, ap = _buf(data)
+    cap = a.size + a.size // 4 + 4096
+    out = np.empty(cap, dtype=np.uint8)
+    r = ref("brotli").ref_brotlimt_compress(out.ctypes.data, cap, ap, a.size, level, threads)
+    if r == _BAD:
+        raise RuntimeError("reference brotli-mt compress failed")
+    return out[:r].copy()
+
+
+def ref_brotlimt_decompress(comp, cap, threads=1):
+    a, ap = _buf(comp)
+    out = np.empty(max(cap, 1), dtype=np.uint8)
+    r = ref("brotli").ref_brotlimt_decompress(out.ctypes.data, cap, ap, a.size, threads)
+    if r == _BAD:
+        raise ValueError("reference brotli-mt decoder rejected the stream")
+    return out[:r]
+
+
+def ref_brotli_decompress(comp, cap):
+    a, ap = _buf(comp)
+    out = np.empty(max(cap, 1), dtype=np.uint8)
+    r = ref("brotli").ref_brotli_decompress(out.ctypes.data, cap, ap, a.size)
+    if r == _BAD:
+        raise ValueError("reference brotli decoder rejected the stream")
+    return out[:r]

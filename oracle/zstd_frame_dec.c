@@ -1,0 +1,483 @@
+/* oracle/zstd_frame_dec.c -- TEST INFRASTRUCTURE ONLY (never linked into the product path).
+ *
+ * Plain-C restatement of the zstd *decoder* the reference uses as the judge of every ZSTD
+ * encoder (RFC 8878 semantics, as implemented by the reference under /root/reference):
+ *
+ *   frame / block walking ............ C/zstd/zstd_decompress.c:953 (ZSTD_decompressFrame),
+ *                                      :1070 (multi-frame loop), frame header :440-560
+ *   literals section ................. C/zstd/zstd_decompress_block.c:135 (ZSTD_decodeLiteralsBlock)
+ *   Huffman table description ........ C/zstd/entropy_common.c:239 (HUF_readStats), FSE weights
+ *                                      C/zstd/fse_decompress.c:175-230 (2 interleaved states)
+ *   Huffman stream decode ............ C/zstd/huf_decompress.c (X1 single-symbol tables, 1 / 4 streams)
+ *   NCount parsing ................... C/zstd/entropy_common.c:42 (FSE_readNCount_body)
+ *   FSE decode table ................. C/zstd/zstd_decompress_block.c:484 (ZSTD_buildFSETable_body)
+ *   sequence section ................. C/zstd/zstd_decompress_block.c:697 (ZSTD_decodeSeqHeaders),
+ *                                      :1216 (ZSTD_decodeSequence), repcode rules :1250-1290
+ *   predefined tables / code bases ... C/zstd/zstd_internal.h:119-164
+ *   concatenated + skippable frames .. CPP/7zip/Compress/ZstdDecoder.cpp:145-158
+ *
+ * Why it exists: the reference pins *decoded bytes* only; an encoder is right
+ * iff this decoder (and the reference's own, oracle/_ref/libzstd_ref.so) regenerates the input
+ * bit-exactly.  This file travels as source to the GPU box; the reference library travels as a
+ * prebuilt .so.  Parity pin: tests/test_oracle.py checks this decoder against the reference's
+ * golden fixture tests/regr-arc/test.txt.zstd (sha256 aeda0f81..., regression.test:31-89, copied
+ * byte-for-byte to tests/golden/) and against frames produced by the reference encoder at
+ * levels 1..19 on every corpus.
+ *
+ * Pure byte/integer arithmetic; no dependency on anything but libc.
+ */
+#include <stddef.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdlib.h>
+
+#define GCO_OK            0
+#define GCO_ERR_TRUNC    -1   /* input ends early */
+#define GCO_ERR_MAGIC    -2
+#define GCO_ERR_CORRUPT  -3
+#define GCO_ERR_DSTSIZE  -4
+#define GCO_ERR_UNSUP    -5   /* dictionary id etc. */
+#define GCO_ERR_CHECKSUM -6
+
+typedef struct {
+    int      code;       /* GCO_* */
+    int      line;       /* source line that raised it (debug aid for encoder bring-up) */
+    size_t   src_pos;    /* byte offset in the compressed input of the frame/block at fault */
+    size_t   dst_pos;    /* bytes regenerated so far */
+    unsigned frames, blocks;
+} gco_diag_t;
+
+static gco_diag_t g_diag;
+#define FAIL(c) do { g_diag.code = (c); g_diag.line = __LINE__; return (c); } while (0)
+
+/* ------------------------------------------------------------------ XXH64 (content checksum) */
+#define P1 11400714785074694791ULL
+#define P2 14029467366897019727ULL
+#define P3 1609587929392839161ULL
+#define P4 9650029242287828579ULL
+#define P5 2870177450012600261ULL
+static uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+static uint64_t rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+static uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static uint64_t xxr(uint64_t acc, uint64_t in) { acc += in * P2; acc = rotl64(acc, 31); return acc * P1; }
+static uint64_t xxm(uint64_t acc, uint64_t v) { v = xxr(0, v); acc ^= v; return acc * P1 + P4; }
+uint64_t gco_xxh64(const void* data, size_t len, uint64_t seed)
+{
+    const uint8_t* p = (const uint8_t*)data; const uint8_t* e = p + len; uint64_t h;
+    if (len >= 32) {
+        uint64_t v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
+        do { v1 = xxr(v1, rd64(p)); v2 = xxr(v2, rd64(p + 8)); v3 = xxr(v3, rd64(p + 16)); v4 = xxr(v4, rd64(p + 24)); p += 32; } while (p + 32 <= e);
+        h = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+        h = xxm(h, v1); h = xxm(h, v2); h = xxm(h, v3); h = xxm(h, v4);
+    } else h = seed + P5;
+    h += (uint64_t)len;
+    while (p + 8 <= e) { h ^= xxr(0, rd64(p)); h = rotl64(h, 27) * P1 + P4; p += 8; }
+    if (p + 4 <= e) { h ^= (uint64_t)rd32(p) * P1; h = rotl64(h, 23) * P2 + P3; p += 4; }
+    while (p < e) { h ^= (*p) * P5; h = rotl64(h, 11) * P1; p++; }
+    h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+    return h;
+}
+
+/* ------------------------------------------------------------------ bit readers */
+static int hibit(uint32_t v) { int r = 0; while (v >>= 1) r++; return r; }
+
+/* forward (LSB-first) reader used by FSE NCount headers */
+typedef struct { const uint8_t* p; size_t n; size_t bit; } fbits_t;
+static uint32_t fb_read(fbits_t* b, int nb)
+{
+    uint32_t v = 0; int i;
+    for (i = 0; i < nb; i++) {
+        size_t byte = b->bit >> 3;
+        uint32_t bitv = byte < b->n ? (b->p[byte] >> (b->bit & 7)) & 1u : 0u;
+        v |= bitv << i; b->bit++;
+    }
+    return v;
+}
+
+/* backward reader: stream ends with a 1-bit end mark in its last byte; bits are consumed from
+ * the mark downwards.  `off` = number of unread bits (may go negative: zero-extended reads). */
+typedef struct { const uint8_t* p; int64_t off; } bbits_t;
+static int bb_init(bbits_t* b, const uint8_t* p, size_t n)
+{
+    if (n == 0 || p[n - 1] == 0) return -1;
+    b->p = p; b->off = (int64_t)n * 8 - (8 - hibit(p[n - 1]));
+    return 0;
+}
+static uint64_t bb_read(bbits_t* b, int nb)
+{   /* returns the next nb bits (nb <= 32), MSB-of-field = earliest consumed bit */
+    uint64_t v = 0; int i;
+    b->off -= nb;
+    for (i = nb - 1; i >= 0; i--) {
+        int64_t pos = b->off + i;
+        uint64_t bit = pos >= 0 ? (b->p[pos >> 3] >> (pos & 7)) & 1u : 0u;
+        v = (v << 1) | bit;
+    }
+    return v;
+}
+
+/* ------------------------------------------------------------------ FSE */
+#define FSE_MAX_AL 9
+#define FSE_MAX_SYM 256
+typedef struct { uint8_t sym[1 << FSE_MAX_AL]; uint8_t nb[1 << FSE_MAX_AL]; uint16_t base[1 << FSE_MAX_AL]; int al; } fse_dt;
+
+/* entropy_common.c:42 -- returns bytes consumed or <0 */
+static int fse_read_ncount(const uint8_t* p, size_t n, int maxAL, int maxSym, int16_t* norm, int* nsym, int* alOut)
+{
+    fbits_t b = { p, n, 0 };
+    int al = 5 + (int)fb_read(&b, 4), remaining, s = 0;
+    if (al > maxAL) return -1;
+    remaining = 1 << al;
+    memset(norm, 0, sizeof(int16_t) * (maxSym + 1));
+    while (remaining > 0 && s <= maxSym) {
+        int bits = hibit((uint32_t)remaining + 1) + 1;
+        uint32_t val = fb_read(&b, bits);
+        uint32_t lower = (1u << (bits - 1)) - 1;
+        uint32_t thr = (1u << bits) - 1 - ((uint32_t)remaining + 1);
+        int proba;
+        if ((val & lower) < thr) { b.bit--; val &= lower; }
+        else if (val > lower) val -= thr;
+        proba = (int)val - 1;
+        remaining -= proba < 0 ? -proba : proba;
+        norm[s++] = (int16_t)proba;
+        if (proba == 0) {
+            uint32_t rep = fb_read(&b, 2);
+            for (;;) {
+                uint32_t i;
+                for (i = 0; i < rep && s <= maxSym; i++) norm[s++] = 0;
+                if (rep == 3) rep = fb_read(&b, 2); else break;
+            }
+        }
+    }
+    if (remaining != 0 || s > maxSym + 1) return -1;
+    if (((b.bit + 7) >> 3) > n) return -1;
+    *nsym = s; *alOut = al;
+    return (int)((b.bit + 7) >> 3);
+}
+
+/* zstd_decompress_block.c:484 */
+static int fse_build_dt(fse_dt* dt, const int16_t* norm, int nsym, int al)
+{
+    int size = 1 << al, high = size - 1, s, i, pos = 0;
+    int step = (size >> 1) + (size >> 3) + 3, mask = size - 1;
+    uint16_t next[FSE_MAX_SYM];
+    dt->al = al;
+    for (s = 0; s < nsym; s++) {
+        if (norm[s] == -1) { dt->sym[high--] = (uint8_t)s; next[s] = 1; }
+        else next[s] = (uint16_t)norm[s];
+    }
+    for (s = 0; s < nsym; s++) {
+        for (i = 0; i < norm[s]; i++) {
+            dt->sym[pos] = (uint8_t)s;
+            do { pos = (pos + step) & mask; } while (pos > high);
+        }
+    }
+    if (pos != 0) return -1;
+    for (i = 0; i < size; i++) {
+        uint8_t sy = dt->sym[i];
+        uint16_t ns = next[sy]++;
+        dt->nb[i] = (uint8_t)(al - hibit(ns));
+        dt->base[i] = (uint16_t)(((uint32_t)ns << dt->nb[i]) - size);
+    }
+    return 0;
+}
+static void fse_build_rle(fse_dt* dt, uint8_t sym) { dt->al = 0; dt->sym[0] = sym; dt->nb[0] = 0; dt->base[0] = 0; }
+
+/* ------------------------------------------------------------------ Huffman */
+#define HUF_MAX_BITS 11
+typedef struct { uint8_t sym[1 << HUF_MAX_BITS]; uint8_t nb[1 << HUF_MAX_BITS]; int maxBits; int valid; } huf_dt;
+
+/* FSE-compressed weights: fse_decompress.c:175-230 (two interleaved states, stream drained) */
+static int huf_read_fse_weights(const uint8_t* p, size_t n, uint8_t* w, int maxW)
+{
+    int16_t norm[256]; int nsym, al, hdr, cnt = 0;
+    fse_dt dt; bbits_t b; uint32_t s1, s2;
+    hdr = fse_read_ncount(p, n, 6, 255, norm, &nsym, &al);
+    if (hdr < 0) return -1;
+    if (fse_build_dt(&dt, norm, nsym, al)) return -1;
+    if (bb_init(&b, p + hdr, n - hdr)) return -1;
+    s1 = (uint32_t)bb_read(&b, al); s2 = (uint32_t)bb_read(&b, al);
+    if (b.off < 0) return -1;
+    for (;;) {
+        if (cnt >= maxW) return -1;
+        w[cnt++] = dt.sym[s1];
+        s1 = dt.base[s1] + (uint32_t)bb_read(&b, dt.nb[s1]);
+        if (b.off < 0) { if (cnt >= maxW) return -1; w[cnt++] = dt.sym[s2]; break; }
+        if (cnt >= maxW) return -1;
+        w[cnt++] = dt.sym[s2];
+        s2 = dt.base[s2] + (uint32_t)bb_read(&b, dt.nb[s2]);
+        if (b.off < 0) { if (cnt >= maxW) return -1; w[cnt++] = dt.sym[s1]; break; }
+    }
+    return cnt;
+}
+
+/* entropy_common.c:239 HUF_readStats + huf_decompress.c X1 table fill; returns bytes consumed */
+static int huf_read_table(huf_dt* dt, const uint8_t* p, size_t n)
+{
+    uint8_t w[256]; int nw, i, consumed; uint32_t total = 0, rest; int maxBits, last;
+    uint32_t rankStart[HUF_MAX_BITS + 2], rankCount[HUF_MAX_BITS + 2];
+    if (n < 1) return -1;
+    if (p[0] >= 128) {
+        nw = p[0] - 127; consumed = 1 + (nw + 1) / 2;
+        if ((size_t)consumed > n) return -1;
+        for (i = 0; i < nw; i++) w[i] = (i & 1) ? (p[1 + i / 2] & 15) : (p[1 + i / 2] >> 4);
+    } else {
+        consumed = 1 + p[0];
+        if ((size_t)consumed > n) return -1;
+        nw = huf_read_fse_weights(p + 1, p[0], w, 255);
+        if (nw < 0) return -1;
+    }
+    for (i = 0; i < nw; i++) { if (w[i] > HUF_MAX_BITS) return -1; if (w[i]) total += 1u << (w[i] - 1); }
+    if (total == 0) return -1;
+    maxBits = hibit(total) + 1;
+    if (maxBits > HUF_MAX_BITS) return -1;
+    rest = (1u << maxBits) - total;
+    if (rest & (rest - 1)) return -1;           /* must be a power of two */
+    last = hibit(rest) + 1;
+    w[nw++] = (uint8_t)last;
+    memset(rankCount, 0, sizeof(rankCount));
+    for (i = 0; i < nw; i++) rankCount[w[i]]++;
+    if (rankCount[1] < 2 || (rankCount[1] & 1)) return -1;
+    { uint32_t next = 0; int r; for (r = 1; r <= maxBits; r++) { rankStart[r] = next; next += rankCount[r] << (r - 1); } }
+    for (i = 0; i < nw; i++) {
+        if (w[i]) {
+            uint32_t len = 1u << (w[i] - 1), st = rankStart[w[i]], k;
+            for (k = 0; k < len; k++) { dt->sym[st + k] = (uint8_t)i; dt->nb[st + k] = (uint8_t)(maxBits + 1 - w[i]); }
+            rankStart[w[i]] += len;
+        }
+    }
+    dt->maxBits = maxBits; dt->valid = 1;
+    return consumed;
+}
+
+static int huf_decode_stream(const huf_dt* dt, const uint8_t* p, size_t n, uint8_t* out, size_t count)
+{
+    bbits_t b; size_t i; uint32_t window; int mb = dt->maxBits;
+    if (bb_init(&b, p, n)) return -1;
+    window = (uint32_t)bb_read(&b, mb);
+    for (i = 0; i < count; i++) {
+        int nb = dt->nb[window];
+        out[i] = dt->sym[window];
+        window = ((window << nb) & ((1u << mb) - 1)) | (uint32_t)bb_read(&b, nb);
+    }
+    /* exactly consumed: we pre-read mb bits beyond the consumed symbols */
+    if (b.off != -(int64_t)mb) return -1;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ sequence code tables (zstd_internal.h:119-164) */
+static const uint32_t LL_base[36] = { 0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,22,24,28,32,40,48,64,0x80,0x100,0x200,0x400,0x800,0x1000,0x2000,0x4000,0x8000,0x10000 };
+static const uint8_t  LL_bits[36] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16 };
+static const uint32_t ML_base[53] = { 3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,37,39,41,43,47,51,59,67,83,99,0x83,0x103,0x203,0x403,0x803,0x1003,0x2003,0x4003,0x8003,0x10003 };
+static const uint8_t  ML_bits[53] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,4,5,7,8,9,10,11,12,13,14,15,16 };
+static const int16_t LL_defaultNorm[36] = { 4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1,2,2,2,2,2,2,2,2,2,3,2,1,1,1,1,1,-1,-1,-1,-1 };
+static const int16_t ML_defaultNorm[53] = { 1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1 };
+static const int16_t OF_defaultNorm[29] = { 1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1 };
+
+typedef struct {
+    huf_dt huf;
+    fse_dt ll, of, ml;
+    int ll_valid, of_valid, ml_valid;
+    uint32_t rep[3];
+} frame_ctx;
+
+/* one table of the sequences header (zstd_decompress_block.c:620 ZSTD_buildSeqTable) */
+static int seq_table(fse_dt* dt, int* valid, int mode, const uint8_t** pp, const uint8_t* end,
+                     const int16_t* defNorm, int defSyms, int defAL, int maxAL, int maxSym)
+{
+    const uint8_t* p = *pp;
+    switch (mode) {
+    case 0: if (fse_build_dt(dt, defNorm, defSyms, defAL)) return -1; *valid = 1; return 0;
+    case 1: if (p >= end) return -1; if (*p > maxSym) return -1; fse_build_rle(dt, *p); *pp = p + 1; *valid = 1; return 0;
+    case 2: {
+        int16_t norm[64]; int nsym, al, used;
+        used = fse_read_ncount(p, (size_t)(end - p), maxAL, maxSym, norm, &nsym, &al);
+        if (used < 0) return -1;
+        if (fse_build_dt(dt, norm, nsym, al)) return -1;
+        *pp = p + used; *valid = 1; return 0; }
+    default: return *valid ? 0 : -1;   /* repeat */
+    }
+}
+
+static int decode_block(frame_ctx* fc, const uint8_t* src, size_t n, uint8_t* dstBase, size_t dstPos,
+                        size_t dstCap, size_t windowStart, size_t* produced)
+{
+    const uint8_t* p = src; const uint8_t* end = src + n;
+    static uint8_t lit[1 << 17];
+    size_t litSize = 0;
+    /* ---- literals section (zstd_decompress_block.c:135) */
+    {
+        int type, fmt; size_t hsz, regen, comp = 0; int streams = 1;
+        if (n < 1) FAIL(GCO_ERR_CORRUPT);
+        type = p[0] & 3; fmt = (p[0] >> 2) & 3;
+        if (type < 2) {
+            if (fmt == 0 || fmt == 2) { hsz = 1; regen = p[0] >> 3; }
+            else if (fmt == 1) { if (n < 2) FAIL(GCO_ERR_CORRUPT); hsz = 2; regen = (p[0] | (p[1] << 8)) >> 4; }
+            else { if (n < 3) FAIL(GCO_ERR_CORRUPT); hsz = 3; regen = (p[0] | (p[1] << 8) | ((uint32_t)p[2] << 16)) >> 4; }
+            if (regen > (1 << 17)) FAIL(GCO_ERR_CORRUPT);
+            p += hsz;
+            if (type == 0) { if ((size_t)(end - p) < regen) FAIL(GCO_ERR_CORRUPT); memcpy(lit, p, regen); p += regen; }
+            else { if (p >= end) FAIL(GCO_ERR_CORRUPT); memset(lit, *p, regen); p += 1; }
+            litSize = regen;
+        } else {
+            uint64_t h = 0; int i;
+            if (fmt == 0 || fmt == 1) { hsz = 3; streams = fmt == 0 ? 1 : 4; }
+            else if (fmt == 2) { hsz = 4; streams = 4; } else { hsz = 5; streams = 4; }
+            if (n < hsz) FAIL(GCO_ERR_CORRUPT);
+            for (i = 0; i < (int)hsz; i++) h |= (uint64_t)p[i] << (8 * i);
+            if (hsz == 3) { regen = (h >> 4) & 0x3FF; comp = (h >> 14) & 0x3FF; }
+            else if (hsz == 4) { regen = (h >> 4) & 0x3FFF; comp = (h >> 18) & 0x3FFF; }
+            else { regen = (h >> 4) & 0x3FFFF; comp = (h >> 22) & 0x3FFFF; }
+            if (regen > (1 << 17)) FAIL(GCO_ERR_CORRUPT);
+            p += hsz;
+            if ((size_t)(end - p) < comp) FAIL(GCO_ERR_CORRUPT);
+            {
+                const uint8_t* q = p; const uint8_t* qe = p + comp;
+                if (type == 2) { int used = huf_read_table(&fc->huf, q, comp); if (used < 0) FAIL(GCO_ERR_CORRUPT); q += used; }
+                else if (!fc->huf.valid) FAIL(GCO_ERR_CORRUPT);
+                if (streams == 1) { if (huf_decode_stream(&fc->huf, q, (size_t)(qe - q), lit, regen)) FAIL(GCO_ERR_CORRUPT); }
+                else {
+                    size_t s1, s2, s3, s4, seg = (regen + 3) / 4, tot;
+                    if (qe - q < 6) FAIL(GCO_ERR_CORRUPT);
+                    s1 = q[0] | (q[1] << 8); s2 = q[2] | (q[3] << 8); s3 = q[4] | (q[5] << 8); q += 6;
+                    tot = s1 + s2 + s3;
+                    if (tot > (size_t)(qe - q)) FAIL(GCO_ERR_CORRUPT);
+                    s4 = (size_t)(qe - q) - tot;
+                    if (seg * 3 > regen) FAIL(GCO_ERR_CORRUPT);
+                    if (huf_decode_stream(&fc->huf, q, s1, lit, seg)) FAIL(GCO_ERR_CORRUPT);
+                    if (huf_decode_stream(&fc->huf, q + s1, s2, lit + seg, seg)) FAIL(GCO_ERR_CORRUPT);
+                    if (huf_decode_stream(&fc->huf, q + s1 + s2, s3, lit + 2 * seg, seg)) FAIL(GCO_ERR_CORRUPT);
+                    if (huf_decode_stream(&fc->huf, q + tot, s4, lit + 3 * seg, regen - 3 * seg)) FAIL(GCO_ERR_CORRUPT);
+                }
+            }
+            p += comp; litSize = regen;
+        }
+    }
+    /* ---- sequences section (zstd_decompress_block.c:697) */
+    {
+        size_t nbSeq, litPos = 0, out = dstPos;
+        int modes; bbits_t b; uint32_t sLL, sOF, sML; size_t i;
+        if (p >= end) FAIL(GCO_ERR_CORRUPT);
+        nbSeq = *p++;
+        if (nbSeq >= 128) {
+            if (nbSeq == 255) { if (end - p < 2) FAIL(GCO_ERR_CORRUPT); nbSeq = (size_t)p[0] + ((size_t)p[1] << 8) + 0x7F00; p += 2; }
+            else { if (p >= end) FAIL(GCO_ERR_CORRUPT); nbSeq = ((nbSeq - 128) << 8) + *p++; }
+        }
+        if (nbSeq == 0) {
+            if (p != end) FAIL(GCO_ERR_CORRUPT);
+            if (out + litSize > dstCap) FAIL(GCO_ERR_DSTSIZE);
+            memcpy(dstBase + out, lit, litSize); *produced = litSize; return GCO_OK;
+        }
+        if (p >= end) FAIL(GCO_ERR_CORRUPT);
+        modes = *p++;
+        if (modes & 3) FAIL(GCO_ERR_CORRUPT);
+        if (seq_table(&fc->ll, &fc->ll_valid, modes >> 6, &p, end, LL_defaultNorm, 36, 6, 9, 35)) FAIL(GCO_ERR_CORRUPT);
+        if (seq_table(&fc->of, &fc->of_valid, (modes >> 4) & 3, &p, end, OF_defaultNorm, 29, 5, 8, 31)) FAIL(GCO_ERR_CORRUPT);
+        if (seq_table(&fc->ml, &fc->ml_valid, (modes >> 2) & 3, &p, end, ML_defaultNorm, 53, 6, 9, 52)) FAIL(GCO_ERR_CORRUPT);
+        if (bb_init(&b, p, (size_t)(end - p))) FAIL(GCO_ERR_CORRUPT);
+        sLL = (uint32_t)bb_read(&b, fc->ll.al); sOF = (uint32_t)bb_read(&b, fc->of.al); sML = (uint32_t)bb_read(&b, fc->ml.al);
+        if (b.off < 0) FAIL(GCO_ERR_CORRUPT);
+        for (i = 0; i < nbSeq; i++) {
+            uint32_t ofc = fc->of.sym[sOF], mlc = fc->ml.sym[sML], llc = fc->ll.sym[sLL];
+            uint32_t ofv, ml, ll, offset;
+            if (ofc > 31 || mlc > 52 || llc > 35) FAIL(GCO_ERR_CORRUPT);
+            ofv = (1u << ofc) + (uint32_t)bb_read(&b, (int)ofc);
+            ml = ML_base[mlc] + (uint32_t)bb_read(&b, ML_bits[mlc]);
+            ll = LL_base[llc] + (uint32_t)bb_read(&b, LL_bits[llc]);
+            /* repcode rules: zstd_decompress_block.c:1250-1290 */
+            if (ofv > 3) { offset = ofv - 3; fc->rep[2] = fc->rep[1]; fc->rep[1] = fc->rep[0]; fc->rep[0] = offset; }
+            else {
+                uint32_t idx = ofv + (ll == 0 ? 1 : 0);
+                if (idx == 1) offset = fc->rep[0];
+                else {
+                    offset = idx == 4 ? fc->rep[0] - 1 : fc->rep[idx - 1];
+                    if (offset == 0) FAIL(GCO_ERR_CORRUPT);
+                    if (idx != 2) fc->rep[2] = fc->rep[1];
+                    fc->rep[1] = fc->rep[0]; fc->rep[0] = offset;
+                }
+            }
+            if (i + 1 < nbSeq) {
+                sLL = fc->ll.base[sLL] + (uint32_t)bb_read(&b, fc->ll.nb[sLL]);
+                sML = fc->ml.base[sML] + (uint32_t)bb_read(&b, fc->ml.nb[sML]);
+                sOF = fc->of.base[sOF] + (uint32_t)bb_read(&b, fc->of.nb[sOF]);
+            }
+            if (b.off < 0) FAIL(GCO_ERR_CORRUPT);
+            if (litPos + ll > litSize) FAIL(GCO_ERR_CORRUPT);
+            if (out + ll + ml > dstCap) FAIL(GCO_ERR_DSTSIZE);
+            memcpy(dstBase + out, lit + litPos, ll); out += ll; litPos += ll;
+            if (offset > out - windowStart) FAIL(GCO_ERR_CORRUPT);
+            { size_t k; const uint8_t* m = dstBase + out - offset; for (k = 0; k < ml; k++) dstBase[out + k] = m[k]; }
+            out += ml;
+        }
+        if (b.off != 0) FAIL(GCO_ERR_CORRUPT);     /* bitstream must be consumed exactly */
+        if (out + (litSize - litPos) > dstCap) FAIL(GCO_ERR_DSTSIZE);
+        memcpy(dstBase + out, lit + litPos, litSize - litPos); out += litSize - litPos;
+        *produced = out - dstPos;
+        if (*produced > (1 << 17)) FAIL(GCO_ERR_CORRUPT);
+    }
+    return GCO_OK;
+}
+
+/* Decode any number of concatenated zstd / skippable frames.  Returns GCO_OK and *outLen. */
+int gco_zstd_decompress(uint8_t* dst, size_t cap, const uint8_t* src, size_t n, size_t* outLen)
+{
+    size_t ip = 0, op = 0;
+    memset(&g_diag, 0, sizeof(g_diag));
+    while (ip < n) {
+        uint32_t magic; frame_ctx* fc; size_t frameStart = op;
+        int fhd, single, csum, didf, fcsf; uint64_t fcs = 0; int haveFcs = 0; size_t windowSize = 0;
+        g_diag.src_pos = ip; g_diag.dst_pos = op;
+        if (n - ip < 4) FAIL(GCO_ERR_TRUNC);
+        magic = rd32(src + ip);
+        if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {
+            uint32_t sz; if (n - ip < 8) FAIL(GCO_ERR_TRUNC);
+            sz = rd32(src + ip + 4); if (n - ip - 8 < sz) FAIL(GCO_ERR_TRUNC);
+            ip += 8 + (size_t)sz; continue;
+        }
+        if (magic != 0xFD2FB528u) FAIL(GCO_ERR_MAGIC);
+        ip += 4; if (ip >= n) FAIL(GCO_ERR_TRUNC);
+        fhd = src[ip++]; fcsf = fhd >> 6; single = (fhd >> 5) & 1; csum = (fhd >> 2) & 1; didf = fhd & 3;
+        if (fhd & 8) FAIL(GCO_ERR_CORRUPT);
+        if (!single) { int wd; if (ip >= n) FAIL(GCO_ERR_TRUNC); wd = src[ip++];
+            { int wl = 10 + (wd >> 3); uint64_t base = 1ULL << wl; windowSize = (size_t)(base + (base >> 3) * (wd & 7)); } }
+        if (didf) FAIL(GCO_ERR_UNSUP);
+        { int fl = fcsf == 0 ? (single ? 1 : 0) : fcsf == 1 ? 2 : fcsf == 2 ? 4 : 8; int i;
+          if (n - ip < (size_t)fl) FAIL(GCO_ERR_TRUNC);
+          for (i = 0; i < fl; i++) fcs |= (uint64_t)src[ip + i] << (8 * i);
+          if (fl == 2) fcs += 256;
+          haveFcs = fl > 0; ip += fl; }
+        if (single) windowSize = (size_t)fcs;
+        fc = (frame_ctx*)calloc(1, sizeof(*fc));
+        fc->rep[0] = 1; fc->rep[1] = 4; fc->rep[2] = 8;
+        for (;;) {
+            uint32_t bh; int last, type; size_t bsz, prod = 0; int rc;
+            g_diag.src_pos = ip; g_diag.dst_pos = op;
+            if (n - ip < 3) { free(fc); FAIL(GCO_ERR_TRUNC); }
+            bh = src[ip] | (src[ip + 1] << 8) | ((uint32_t)src[ip + 2] << 16); ip += 3;
+            last = bh & 1; type = (bh >> 1) & 3; bsz = bh >> 3;
+            g_diag.blocks++;
+            if (type == 0) { if (n - ip < bsz) { free(fc); FAIL(GCO_ERR_TRUNC); } if (cap - op < bsz) { free(fc); FAIL(GCO_ERR_DSTSIZE); }
+                memcpy(dst + op, src + ip, bsz); ip += bsz; op += bsz; }
+            else if (type == 1) { if (n - ip < 1) { free(fc); FAIL(GCO_ERR_TRUNC); } if (cap - op < bsz) { free(fc); FAIL(GCO_ERR_DSTSIZE); }
+                memset(dst + op, src[ip], bsz); ip += 1; op += bsz; }
+            else if (type == 2) {
+                size_t ws;
+                if (n - ip < bsz) { free(fc); FAIL(GCO_ERR_TRUNC); }
+                if (bsz >= (1 << 17)) { free(fc); FAIL(GCO_ERR_CORRUPT); }
+                ws = (op - frameStart > windowSize) ? op - windowSize : frameStart;
+                rc = decode_block(fc, src + ip, bsz, dst, op, cap, ws, &prod);
+                if (rc) { free(fc); return rc; }
+                ip += bsz; op += prod; }
+            else { free(fc); FAIL(GCO_ERR_CORRUPT); }
+            if (last) break;
+        }
+        free(fc);
+        if (haveFcs && (uint64_t)(op - frameStart) != fcs) FAIL(GCO_ERR_CORRUPT);
+        if (csum) { uint32_t want; if (n - ip < 4) FAIL(GCO_ERR_TRUNC); want = rd32(src + ip); ip += 4;
+            if ((uint32_t)gco_xxh64(dst + frameStart, op - frameStart, 0) != want) FAIL(GCO_ERR_CHECKSUM); }
+        g_diag.frames++;
+    }
+    *outLen = op;
+    return GCO_OK;
+}
+
+const gco_diag_t* gco_last_diag(void) { return &g_diag; }
