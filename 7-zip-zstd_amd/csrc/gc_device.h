@@ -1,0 +1,60 @@
+// gc_device.h -- small device-side helpers (gfx950).  Under tests/emu (HIPEMU) the wave intrinsics are
+// supplied by the SIMT emulator; nothing here selects between GPU back-ends.
+#pragma once
+#include <stdint.h>
+#ifndef HIPEMU
+#include <hip/hip_runtime.h>
+#endif
+
+// Unaligned little-endian loads.  gfx950 global/LDS accesses tolerate any byte alignment (unaligned access
+// mode is on under ROCm), and the compiler turns the memcpy into a single global_load_dwordx2 / dword.
+__device__ __forceinline__ uint64_t gc_ld64(const uint8_t* p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ __forceinline__ uint32_t gc_ld32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+
+// 8 bytes at src[pos..], zero-filled past `limit` (end of the whole input buffer)
+__device__ __forceinline__ uint64_t gc_ld64_guard(const uint8_t* src, uint64_t pos, uint64_t limit)
+{
+    if (pos + 8 <= limit) return gc_ld64(src + pos);
+    uint64_t v = 0;
+    for (int i = 0; i < 8; i++) if (pos + i < limit) v |= (uint64_t)src[pos + i] << (8 * i);
+    return v;
+}
+
+__device__ __forceinline__ uint32_t gc_hibit32(uint32_t v) { return 31u - (uint32_t)__clz((int)v); }   // v != 0
+__device__ __forceinline__ uint32_t gc_ctz64(uint64_t v) { return (uint32_t)__ffsll((long long)v) - 1u; } // v != 0
+
+// value known to be identical in every lane of the wave -> keep it in an SGPR
+__device__ __forceinline__ uint32_t gc_uniform(uint32_t v)
+{
+#ifdef HIPEMU
+    return v;
+#else
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+#endif
+}
+
+__device__ __forceinline__ uint64_t gc_lanemask_lt() { return (1ull << (__lane_id() & 63)) - 1ull; }
+
+// inclusive wave scan (sum) over 64 lanes
+__device__ __forceinline__ uint32_t gc_wave_incl_sum(uint32_t v)
+{
+    uint32_t lane = __lane_id();
+    for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(v, d); if (lane >= (uint32_t)d) v += o; }
+    return v;
+}
+__device__ __forceinline__ uint32_t gc_wave_incl_max(uint32_t v)
+{
+    uint32_t lane = __lane_id();
+    for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(v, d); if (lane >= (uint32_t)d) v = v > o ? v : o; }
+    return v;
+}
+__device__ __forceinline__ uint32_t gc_wave_sum(uint32_t v)
+{
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+__device__ __forceinline__ uint32_t gc_wave_max(uint32_t v)
+{
+    for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(v, d); v = v > o ? v : o; }
+    return v;
+}

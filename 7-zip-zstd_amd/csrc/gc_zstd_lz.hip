@@ -1,0 +1,205 @@
+// gc_zstd_lz.hip -- K1: all-positions-parallel match finder + deterministic greedy/lazy parse.
+//
+// Replaces, for one <=128 KiB zstd block per workgroup, the serial per-position loop of
+// ZSTD_compressBlock_doubleFast_noDict_generic (C/zstd/zstd_double_fast.c:105-323) and the sequence store
+// (ZSTD_storeSeq, zstd_compress_internal.h:776).  The CPU loop visits one position at a time and skips the
+// inside of matches; a CDNA4 workgroup instead evaluates a chunk of LZ_T consecutive positions at once:
+//
+//   P0  every lane loads the 8 bytes at its position and hashes them twice: a 5-byte "short" hash and an
+//       8-byte "long" hash (the reference's two-table idea, zstd_double_fast.c:132-141; the hash functions
+//       themselves are free choices and use 32-bit multiplies, which are full rate on the VALU)
+//   P1  probe both LDS tables (entry = position<<15 | 15-bit tag, so hash collisions are rejected from the
+//       tag alone without touching memory)
+//   P2  insert: ds_max_u32 -> "most recent position wins", identical to sequential insertion order, hence
+//       the result does not depend on wave timing (the encoder is deterministic)
+//   P3  a small generation-stamped table (ds_min_u32 -> first occurrence inside the chunk) supplies the
+//       short-distance candidates that P1 cannot see because the whole chunk was probed before it was inserted
+//   P4  candidates are verified against the immutable input (8-byte words, xor + ctz), capped at GC_MATCH_CAP;
+//       longer matches appear as chains of capped matches with equal offset and are merged in K3
+//   P5  parse: next(t) = t+len if a match is taken at t, else t+1.  Each wave resolves its 64-position
+//       segment for EVERY possible entry lane by pointer doubling through ds_bpermute (6 rounds), one lane
+//       chains the 16 wave exits, then each wave walks its real path with scalar bit tricks.
+//   P6  emit: wave ballots + popcounts place literals and sequences; no atomics, order = position order.
+//
+// LDS: 64 KiB long table + 64 KiB short table + 8 KiB chunk table + 8 KiB parse scratch (1 workgroup / CU).
+#include "gc_common.h"
+#include "gc_device.h"
+
+#define LZ_T        1024u            // threads per workgroup = positions per chunk
+#define LZ_WAVES    (LZ_T / 64u)
+#define LZ_LOG_L    14u              // long-hash table: 2^14 entries
+#define LZ_LOG_S    14u              // short-hash table
+#define LZ_LOG_C    11u              // chunk-local table
+#define LZ_TAG_BITS 15u
+
+__device__ __forceinline__ uint32_t lz_hash_long(uint32_t lo, uint32_t hi)  { return lo * 0x9E3779B1u + hi * 0x85EBCA77u; }
+__device__ __forceinline__ uint32_t lz_hash_short(uint32_t lo, uint32_t hi) { return lo * 0x9E3779B1u + (hi & 0xFFu) * 0xC2B2AE3Du; }
+
+// match length of src[p..] vs src[c..], at most maxLen; loads never pass `limit`
+__device__ __forceinline__ uint32_t lz_match_len(const uint8_t* src, uint64_t base, uint32_t p, uint32_t c,
+                                                 uint32_t maxLen, uint64_t limit)
+{
+    uint32_t len = 0;
+    while (len < maxLen) {
+        uint64_t a = gc_ld64_guard(src, base + p + len, limit);
+        uint64_t b = gc_ld64_guard(src, base + c + len, limit);
+        uint64_t x = a ^ b;
+        if (x) { len += gc_ctz64(x) >> 3; break; }
+        len += 8;
+    }
+    return len < maxLen ? len : maxLen;
+}
+
+// cost-ish score used to compare candidates and for the lazy check: 4 bits per matched byte minus offset bits
+__device__ __forceinline__ int lz_gain(uint32_t len, uint32_t off) { return (int)(len * 4u) - (int)gc_hibit32(off + 1u); }
+
+extern "C" __global__ void __launch_bounds__(LZ_T)
+gc_zstd_lz_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, GcSeqRaw* __restrict__ seqRaw,
+                  uint8_t* __restrict__ lit, GcBlockMeta* __restrict__ meta)
+{
+    __shared__ uint32_t tabL[1u << LZ_LOG_L];
+    __shared__ uint32_t tabS[1u << LZ_LOG_S];
+    __shared__ uint32_t tabC[1u << LZ_LOG_C];
+    __shared__ uint32_t sM[LZ_T];          // per-position match record (offset<<8 | len)
+    __shared__ uint32_t sE[LZ_T];          // per-position exit of its wave segment (chunk-relative)
+    __shared__ uint32_t sEntry[LZ_WAVES];  // real entry lane of each wave (64 = wave not entered)
+    __shared__ uint32_t sCnt[LZ_WAVES];    // per wave: nSeq<<16 | nLit
+    __shared__ uint32_t sCursor;
+
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t b = blockIdx.x;
+    const uint64_t base = (uint64_t)b * GC_ZSTD_BLOCK_MAX;
+    const uint32_t n = (uint32_t)((srcSize - base) < GC_ZSTD_BLOCK_MAX ? (srcSize - base) : GC_ZSTD_BLOCK_MAX);
+    GcSeqRaw* mySeq = seqRaw + (uint64_t)b * GC_MAX_SEQ_PER_BLOCK;
+    uint8_t* myLit = lit + (uint64_t)b * GC_ZSTD_BLOCK_MAX;
+
+    for (uint32_t i = t; i < (1u << LZ_LOG_L); i += LZ_T) tabL[i] = 0;
+    for (uint32_t i = t; i < (1u << LZ_LOG_S); i += LZ_T) tabS[i] = 0;
+    for (uint32_t i = t; i < (1u << LZ_LOG_C); i += LZ_T) tabC[i] = 0xFFFFFFFFu;
+    if (t == 0) sCursor = 0;
+    __syncthreads();
+
+    uint32_t totalSeq = 0, totalLit = 0;   // uniform running totals
+    const uint32_t nChunks = (n + LZ_T - 1) / LZ_T;
+
+    for (uint32_t k = 0; k < nChunks; k++) {
+        const uint32_t cbase = k * LZ_T;
+        const uint32_t p = cbase + t;
+        const bool inBlock = p < n;
+        const bool canHash = p + 8u <= n;          // positions closer than 8 bytes to the block end stay literals
+
+        // ---- P0/P1: load, hash, probe
+        uint32_t lo = 0, hi = 0, hL = 0, hS = 0, eL = 0, eS = 0;
+        if (canHash) {
+            uint64_t v = gc_ld64(src + base + p);
+            lo = (uint32_t)v; hi = (uint32_t)(v >> 32);
+            hL = lz_hash_long(lo, hi); hS = lz_hash_short(lo, hi);
+            eL = tabL[hL >> (32u - LZ_LOG_L)];
+            eS = tabS[hS >> (32u - LZ_LOG_S)];
+        }
+        const uint32_t tagL = (hL >> (32u - LZ_LOG_L - LZ_TAG_BITS)) & ((1u << LZ_TAG_BITS) - 1u);
+        const uint32_t tagS = (hS >> (32u - LZ_LOG_S - LZ_TAG_BITS)) & ((1u << LZ_TAG_BITS) - 1u);
+        const uint32_t gen = (~k) & 0xFFu;
+        const uint32_t tagC = (hS >> 4) & 0x3FFFu;
+        const uint32_t slotC = hS >> (32u - LZ_LOG_C);
+        __syncthreads();
+        // ---- P2: insert (most recent position wins; first-in-chunk wins for the chunk table)
+        if (canHash) {
+            atomicMax(&tabL[hL >> (32u - LZ_LOG_L)], (p << LZ_TAG_BITS) | tagL);
+            atomicMax(&tabS[hS >> (32u - LZ_LOG_S)], (p << LZ_TAG_BITS) | tagS);
+            atomicMin(&tabC[slotC], (gen << 24) | (t << 14) | tagC);
+        }
+        __syncthreads();
+        // ---- P3/P4: near probe + verification
+        uint32_t bestLen = 0, bestOff = 0;
+        if (canHash) {
+            const uint32_t maxLen = (n - p) < GC_MATCH_CAP ? (n - p) : GC_MATCH_CAP;
+            int bestGain = -1000;
+            uint32_t cand[3]; int nc = 0;
+            if (eL != 0 && (eL & ((1u << LZ_TAG_BITS) - 1u)) == tagL) cand[nc++] = eL >> LZ_TAG_BITS;
+            if (eS != 0 && (eS & ((1u << LZ_TAG_BITS) - 1u)) == tagS) { uint32_t c = eS >> LZ_TAG_BITS; if (nc == 0 || cand[0] != c) cand[nc++] = c; }
+            {
+                uint32_t eC = tabC[slotC];
+                if ((eC >> 24) == gen && (eC & 0x3FFFu) == tagC) {
+                    uint32_t tc = (eC >> 14) & 0x3FFu;
+                    if (tc < t) { uint32_t c = cbase + tc; bool dup = false; for (int i = 0; i < nc; i++) dup |= cand[i] == c; if (!dup) cand[nc++] = c; }
+                }
+            }
+            for (int i = 0; i < nc; i++) {
+                uint32_t c = cand[i];
+                uint32_t len = lz_match_len(src, base, p, c, maxLen, srcSize);
+                if (len >= GC_MIN_MATCH) {
+                    int g = lz_gain(len, p - c);
+                    if (g > bestGain) { bestGain = g; bestLen = len; bestOff = p - c; }
+                }
+            }
+        }
+        sM[t] = (bestOff << 8) | bestLen;
+        __syncthreads();
+        // ---- P5a: lazy decision and next pointer
+        bool take = bestLen != 0;
+        if (take && t + 1u < LZ_T) {
+            uint32_t m1 = sM[t + 1u];
+            uint32_t l1 = m1 & 0xFFu;
+            if (l1 > bestLen && lz_gain(l1, m1 >> 8) > lz_gain(bestLen, bestOff) + 4) take = false;
+        }
+        const uint32_t wbase = wave * 64u;
+        uint32_t cur = (take ? lane + bestLen : lane + 1u);      // wave-relative; >= 64 means "left the wave"
+        // ---- P5b: pointer doubling inside the wave: exit reached from every lane
+        for (int r = 0; r < 6; r++) {
+            uint32_t o = __shfl(cur, (int)(cur & 63u));
+            if (cur < 64u) cur = o;
+        }
+        sE[t] = wbase + cur;
+        if (t < LZ_WAVES) sEntry[t] = 64u;
+        __syncthreads();
+        // ---- P5c: chain the wave exits from the carried cursor (one lane)
+        if (t == 0) {
+            uint32_t cursor = sCursor;                            // absolute position in block
+            uint32_t c = cursor > cbase ? cursor - cbase : 0u;    // chunk-relative entry
+            while (c < LZ_T) { sEntry[c >> 6] = c & 63u; c = sE[c]; }
+            sCursor = cbase + c;
+        }
+        __syncthreads();
+        // ---- P5d: walk the real path of this wave
+        const uint32_t entry = gc_uniform(sEntry[wave]);
+        const uint64_t takeMask = __ballot(take);
+        const uint64_t validMask = __ballot(inBlock);
+        uint64_t seqMask = 0, coverMask = 0;
+        if (entry < 64u) {
+            uint32_t pos = entry;
+            while (pos < 64u) {
+                uint64_t rest = takeMask >> pos;
+                if (rest == 0) break;
+                uint32_t s = pos + gc_ctz64(rest);
+                uint32_t L = (uint32_t)__shfl((int)bestLen, (int)s);
+                uint32_t e = s + L;
+                uint64_t hiMask = e >= 64u ? ~0ull : ((1ull << e) - 1ull);
+                seqMask |= 1ull << s;
+                coverMask |= hiMask & ~((1ull << s) - 1ull);
+                pos = e;
+            }
+        }
+        const uint64_t fromEntry = entry < 64u ? ~((1ull << entry) - 1ull) : 0ull;
+        const uint64_t litMask = fromEntry & ~coverMask & validMask;
+        // ---- P6: emit
+        if (lane == 0) sCnt[wave] = ((uint32_t)__popcll(seqMask) << 16) | (uint32_t)__popcll(litMask);
+        __syncthreads();
+        uint32_t seqBefore = 0, litBefore = 0, seqAll = 0, litAll = 0;
+        for (uint32_t w = 0; w < LZ_WAVES; w++) {
+            uint32_t c = sCnt[w];
+            if (w < wave) { seqBefore += c >> 16; litBefore += c & 0xFFFFu; }
+            seqAll += c >> 16; litAll += c & 0xFFFFu;
+        }
+        const uint64_t lt = gc_lanemask_lt();
+        const uint32_t myLitRank = totalLit + litBefore + (uint32_t)__popcll(litMask & lt);
+        if ((seqMask >> lane) & 1ull) {
+            uint32_t idx = totalSeq + seqBefore + (uint32_t)__popcll(seqMask & lt);
+            GcSeqRaw r; r.litRank = myLitRank; r.offml = (bestOff << 8) | bestLen;
+            mySeq[idx] = r;
+        }
+        if ((litMask >> lane) & 1ull) myLit[myLitRank] = src[base + p];
+        totalSeq += seqAll; totalLit += litAll;
+    }
+    if (t == 0) { GcBlockMeta m; m.nSeqRaw = totalSeq; m.nLit = totalLit; meta[b] = m; }
+}

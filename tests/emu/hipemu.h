@@ -1,0 +1,189 @@
+// tests/emu/hipemu.h -- TEST INFRASTRUCTURE ONLY.
+//
+// A tiny SIMT emulator so that the *unmodified* HIP kernel sources under 7-zip-zstd_amd/csrc/ can be
+// executed on the CPU of this GPU-less build container (g++ -x c++ -include hipemu.h kernel.hip).
+// It exists because GPU minutes are scarce and there is no device here: kernels are debugged under
+// emulation first, then the same source is compiled by hipcc for gfx950.  It is NOT a fallback and
+// is never linked into the product libraries (the product fails loudly without a GPU).
+//
+// Model: one OS thread runs one workgroup at a time; every work-item is a fiber (own stack,
+// hand-written x86-64 context switch).  `__syncthreads()` and the wave-collective operations
+// (`__shfl*`, `__ballot`, ...) are rendezvous points that yield to the per-workgroup scheduler.
+// Wave size is 64, as on gfx950.  `__shared__` becomes `static thread_local`, so several workgroups
+// can be emulated concurrently on different OS threads.
+//
+// Limits (by design): wave collectives must be reached by all live lanes of the wave (wave-uniform
+// control flow); data races that the hardware would expose are not detected, because lanes run
+// one after another between rendezvous points.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+#include <algorithm>
+
+#define HIPEMU 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static thread_local
+#define __restrict__ __restrict
+#define __constant__ static const
+
+struct hipemu_dim3 { unsigned x, y, z; };
+struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+
+namespace hipemu {
+struct Fiber;
+struct BlockCtx;
+extern thread_local Fiber* cur;
+extern thread_local BlockCtx* blk;
+struct Fiber {
+    void* sp;                 // saved stack pointer
+    unsigned tid;             // linear thread id in block
+    hipemu_dim3 tidx;
+    int state;                // 0 runnable, 1 wait block barrier, 2 wait wave barrier, 3 done
+    unsigned long wait_gen;   // generation waited for
+    char* stack;
+};
+struct WaveCtx {
+    unsigned long gen;        // wave barrier generation
+    unsigned arrived, live;
+    uint64_t xchg[64];
+    uint64_t pred_mask;
+};
+struct BlockCtx {
+    hipemu_dim3 bidx, bdim, gdim;
+    unsigned nthreads, nwaves;
+    unsigned long gen;        // block barrier generation
+    unsigned arrived, live;
+    Fiber* fibers;
+    WaveCtx* waves;
+};
+void yield_to_scheduler();
+void block_barrier();
+void wave_barrier();
+typedef void (*kernel_thunk_t)(void* args);
+// run `grid` workgroups of `block` threads; thunk is called once per work-item with `args`
+void launch(dim3 grid, dim3 block, kernel_thunk_t thunk, void* args, int os_threads);
+}  // namespace hipemu
+
+#define threadIdx (hipemu::cur->tidx)
+#define blockIdx  (hipemu::blk->bidx)
+#define blockDim  (hipemu::blk->bdim)
+#define gridDim   (hipemu::blk->gdim)
+static const int warpSize = 64;
+
+static inline void __syncthreads() { hipemu::block_barrier(); }
+static inline void __threadfence() {}
+static inline void __threadfence_block() {}
+
+// ---- wave collectives ------------------------------------------------------------------------
+namespace hipemu {
+static inline unsigned lane() { return cur->tid & 63; }
+static inline WaveCtx& wv() { return blk->waves[cur->tid >> 6]; }
+template <typename T> static inline T xchg_read(T v, unsigned src_lane)
+{
+    static_assert(sizeof(T) <= 8, "shuffle payload too large");
+    WaveCtx& w = wv();
+    uint64_t bits = 0; memcpy(&bits, &v, sizeof(T));
+    w.xchg[lane()] = bits;
+    wave_barrier();
+    uint64_t got = w.xchg[src_lane & 63];
+    wave_barrier();
+    T out; memcpy(&out, &got, sizeof(T));
+    return out;
+}
+}  // namespace hipemu
+
+template <typename T> static inline T __shfl(T v, int srcLane, int width = 64)
+{
+    unsigned l = hipemu::lane();
+    unsigned src = (width >= 64) ? ((unsigned)srcLane & 63) : ((l & ~(unsigned)(width - 1)) | ((unsigned)srcLane & (unsigned)(width - 1)));
+    return hipemu::xchg_read(v, src);
+}
+template <typename T> static inline T __shfl_up(T v, unsigned delta, int width = 64)
+{
+    unsigned l = hipemu::lane(); unsigned base = l & ~(unsigned)(width - 1);
+    unsigned src = (l - base >= delta) ? l - delta : l;
+    return hipemu::xchg_read(v, src);
+}
+template <typename T> static inline T __shfl_down(T v, unsigned delta, int width = 64)
+{
+    unsigned l = hipemu::lane(); unsigned base = l & ~(unsigned)(width - 1);
+    unsigned src = (l - base + delta < (unsigned)width) ? l + delta : l;
+    return hipemu::xchg_read(v, src);
+}
+template <typename T> static inline T __shfl_xor(T v, int mask, int width = 64)
+{
+    unsigned l = hipemu::lane();
+    unsigned src = l ^ (unsigned)mask;
+    if ((src & ~(unsigned)(width - 1)) != (l & ~(unsigned)(width - 1))) src = l;
+    return hipemu::xchg_read(v, src);
+}
+static inline unsigned long long __ballot(int pred)
+{
+    hipemu::WaveCtx& w = hipemu::wv();
+    w.xchg[hipemu::lane()] = pred ? 1 : 0;
+    hipemu::wave_barrier();
+    unsigned long long m = 0;
+    unsigned base = (hipemu::cur->tid >> 6) << 6;
+    for (unsigned i = 0; i < 64; i++)
+        if (base + i < hipemu::blk->nthreads && hipemu::blk->fibers[base + i].state != 3 && w.xchg[i]) m |= 1ull << i;
+    hipemu::wave_barrier();
+    return m;
+}
+static inline int __any(int pred) { return __ballot(pred) != 0; }
+static inline int __all(int pred)
+{
+    unsigned long long m = __ballot(pred), live = __ballot(1);
+    return m == live;
+}
+static inline int __popc(unsigned v) { return __builtin_popcount(v); }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __ffs(int v) { return __builtin_ffs(v); }
+static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
+static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
+static inline unsigned __brev(unsigned v)
+{
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1); v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4); v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+    return (v >> 16) | (v << 16);
+}
+static inline unsigned __lane_id() { return hipemu::lane(); }
+
+// ---- atomics (single OS thread per workgroup; cross-workgroup atomics on global memory use GCC builtins)
+template <typename T> static inline T atomicAdd(T* p, T v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+template <typename T> static inline T atomicOr(T* p, T v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+template <typename T> static inline T atomicAnd(T* p, T v) { return __atomic_fetch_and(p, v, __ATOMIC_RELAXED); }
+template <typename T> static inline T atomicExch(T* p, T v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
+template <typename T> static inline T atomicMax(T* p, T v)
+{
+    T old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old < v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
+template <typename T> static inline T atomicMin(T* p, T v)
+{
+    T old = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (old > v && !__atomic_compare_exchange_n(p, &old, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return old;
+}
+template <typename T> static inline T atomicCAS(T* p, T cmp, T v)
+{
+    __atomic_compare_exchange_n(p, &cmp, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
+    return cmp;
+}
+
+template <typename T> static inline T min(T a, T b) { return a < b ? a : b; }
+template <typename T> static inline T max(T a, T b) { return a > b ? a : b; }
+
+// kernel launch helper used by the emulated host shim:  HIPEMU_LAUNCH(kernel, grid, block, args...)
+#define HIPEMU_LAUNCH(kernel, grid, block, ...)                                            \
+    do {                                                                                   \
+        auto hipemu_fn = [&]() { kernel(__VA_ARGS__); };                                   \
+        typedef decltype(hipemu_fn) hipemu_fn_t;                                           \
+        hipemu::launch(grid, block, [](void* a) { (*(hipemu_fn_t*)a)(); }, &hipemu_fn, 0); \
+    } while (0)
