@@ -1,0 +1,119 @@
+"""7-zip-zstd_amd -- host-side Python mirror of the codec interface, over the C ABI (include/gpucodec.h).
+
+The directory name is not an importable identifier; load it with
+
+    import importlib.util, sys
+    spec = importlib.util.spec_from_file_location("sevenzip_zstd_amd", "<repo>/7-zip-zstd_amd/__init__.py")
+    mod = importlib.util.module_from_spec(spec); sys.modules[spec.name] = mod; spec.loader.exec_module(mod)
+
+(`__graft_entry__.load_package()` does exactly that).  The class below mirrors the reference's encoder
+object NCompress::NZSTD::CEncoder (CPP/7zip/Compress/ZstdEncoder.h:35-78): create, set the level
+(SetCoderProperties kLevel, ZstdEncoder.cpp:51-70), Code() bytes -> zstd stream.  Everything runs through
+csrc/libgpucodec.so built by hipcc for gfx950; there is no CPU path and construction raises if the library
+or the GPU is missing.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libgpucodec.so")
+
+GC_OK = 0
+_ERR = {-1: "GC_ERR_NO_DEVICE", -2: "GC_ERR_HIP", -3: "GC_ERR_NOMEM", -4: "GC_ERR_DST_SMALL", -5: "GC_ERR_PARAM"}
+
+EXPORTS = ["gc_device_count", "gc_ctx_create", "gc_ctx_destroy", "gc_last_error_message", "gc_zstd_compress_bound",
+           "gc_zstd_compress_device", "gc_zstd_finish", "gc_zstd_compress_host", "gc_zstd_last_timing", "gc_ctx_stream"]
+
+
+class GpuCodecError(RuntimeError):
+    pass
+
+
+def load_library(path=None):
+    """dlopen libgpucodec.so and declare the prototypes of include/gpucodec.h."""
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise GpuCodecError("HIP extension %s is missing: run __graft_entry__.build()" % path)
+    lib = C.CDLL(path)
+    lib.gc_device_count.restype = C.c_int
+    lib.gc_ctx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    lib.gc_ctx_create.restype = C.c_int
+    lib.gc_ctx_destroy.argtypes = [C.c_void_p]
+    lib.gc_ctx_destroy.restype = None
+    lib.gc_last_error_message.argtypes = [C.c_void_p]
+    lib.gc_last_error_message.restype = C.c_char_p
+    lib.gc_zstd_compress_bound.argtypes = [C.c_size_t]
+    lib.gc_zstd_compress_bound.restype = C.c_size_t
+    lib.gc_zstd_compress_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+    lib.gc_zstd_compress_device.restype = C.c_int
+    lib.gc_zstd_finish.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    lib.gc_zstd_finish.restype = C.c_int
+    lib.gc_zstd_compress_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_size_t)]
+    lib.gc_zstd_compress_host.restype = C.c_int
+    lib.gc_zstd_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    lib.gc_zstd_last_timing.restype = C.c_int
+    lib.gc_ctx_stream.argtypes = [C.c_void_p]
+    lib.gc_ctx_stream.restype = C.c_void_p
+    return lib
+
+
+class ZstdEncoder:
+    """Mirror of NCompress::NZSTD::CEncoder for the compression hot path (one object per GPU)."""
+
+    KERNELS = ("lz", "huf", "seq", "plan", "emit", "total")
+
+    def __init__(self, device=0, level=3, lib_path=None):
+        self._lib = load_library(lib_path)
+        self._ctx = C.c_void_p()
+        rc = self._lib.gc_ctx_create(C.byref(self._ctx), device)
+        if rc != GC_OK:
+            self._ctx = C.c_void_p()
+            raise GpuCodecError("gc_ctx_create(device=%d) failed: %s (no GPU fallback exists)" % (device, _ERR.get(rc, rc)))
+        self.level = level
+
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._lib.gc_ctx_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    __del__ = close
+
+    def _check(self, rc, what):
+        if rc != GC_OK:
+            msg = self._lib.gc_last_error_message(self._ctx)
+            raise GpuCodecError("%s failed: %s (%s)" % (what, _ERR.get(rc, rc), msg.decode() if msg else ""))
+
+    def set_level(self, level):          # SetCoderProperties(kLevel)
+        self.level = int(level)
+
+    def compress_bound(self, n):
+        return self._lib.gc_zstd_compress_bound(n)
+
+    def code(self, data):
+        """bytes-like / numpy uint8 -> compressed bytes (host buffers; includes PCIe copies)."""
+        import numpy as np
+        a = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data, dtype=np.uint8)
+        cap = self.compress_bound(a.size)
+        out = np.empty(cap, dtype=np.uint8)
+        n = C.c_size_t(0)
+        rc = self._lib.gc_zstd_compress_host(self._ctx, a.ctypes.data, a.size, out.ctypes.data, cap, self.level, C.byref(n))
+        self._check(rc, "gc_zstd_compress_host")
+        return out[:n.value]
+
+    def code_device(self, d_src_ptr, n, d_dst_ptr, dst_cap):
+        """Enqueue compression of device memory (raw pointers, e.g. torch.Tensor.data_ptr())."""
+        rc = self._lib.gc_zstd_compress_device(self._ctx, d_src_ptr, n, d_dst_ptr, dst_cap, self.level)
+        self._check(rc, "gc_zstd_compress_device")
+
+    def finish(self):
+        n = C.c_size_t(0)
+        self._check(self._lib.gc_zstd_finish(self._ctx, C.byref(n)), "gc_zstd_finish")
+        return n.value
+
+    def last_timing_ms(self):
+        ms = (C.c_float * 6)()
+        self._check(self._lib.gc_zstd_last_timing(self._ctx, ms), "gc_zstd_last_timing")
+        return dict(zip(self.KERNELS, [float(x) for x in ms]))
+
+    def stream(self):
+        return self._lib.gc_ctx_stream(self._ctx)

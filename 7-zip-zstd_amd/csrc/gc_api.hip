@@ -1,0 +1,206 @@
+// gc_api.hip -- host side of libgpucodec.so: the C ABI declared in include/gpucodec.h.
+//
+// Mirrors what NCompress::NZSTD::CEncoder does around the library (CPP/7zip/Compress/ZstdEncoder.cpp:250-462):
+// own a context, feed bytes, get a zstd stream back.  All work is enqueued on one HIP stream per context:
+//   K1 lz -> (K2 huf || K3 seq, serialised on the same stream for now) -> K4 plan -> K5 emit.
+// No CPU codec path exists here: if no gfx950 device can be opened every call fails with GC_ERR_NO_DEVICE.
+#include "gpucodec.h"
+#include "gc_common.h"
+#ifdef HIPEMU
+#include "hip_runtime_stub.h"
+#else
+#include <hip/hip_runtime.h>
+#define GC_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
+#endif
+#include <stdio.h>
+#include <string.h>
+#include <new>
+
+struct GcFramePlan { uint64_t off; uint32_t size; uint32_t compressed; };
+
+extern "C" __global__ void gc_zstd_lz_kernel(const uint8_t*, uint64_t, GcSeqRaw*, uint8_t*, GcBlockMeta*);
+extern "C" __global__ void gc_zstd_huf_kernel(const uint8_t*, const GcBlockMeta*, uint8_t*, GcSectionInfo*);
+extern "C" __global__ void gc_zstd_seq_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t*, uint32_t*, uint8_t*, uint16_t*,
+                                              uint8_t*, GcSectionInfo*, uint64_t);
+extern "C" __global__ void gc_zstd_plan_kernel(const GcSectionInfo*, uint32_t, uint64_t, uint64_t, GcFramePlan*, uint64_t*);
+extern "C" __global__ void gc_zstd_emit_kernel(const uint8_t*, uint64_t, const uint8_t*, const uint8_t*, const GcSectionInfo*,
+                                               const GcFramePlan*, const uint64_t*, uint8_t*);
+
+struct gc_ctx {
+    int device;
+    hipStream_t stream;
+    hipEvent_t ev[6];
+    char err[256];
+    // workspace, grown on demand
+    uint32_t capBlocks;
+    GcSeqRaw* seqRaw; uint8_t* lit; GcBlockMeta* meta;
+    uint64_t* seqPacked; uint32_t* seqOff; uint8_t* codes; uint16_t* stOut;
+    uint8_t* litSec; uint8_t* seqSec; GcSectionInfo* info; GcFramePlan* plan; uint64_t* result;
+    uint64_t* hostResult;     // pinned
+    // staging for the host-buffer entry point
+    uint8_t* dIn; size_t dInCap; uint8_t* dOut; size_t dOutCap;
+    bool pending; bool timed;
+};
+
+#define HIPCHK(ctx, call)                                                                       \
+    do { hipError_t e_ = (call);                                                                \
+         if (e_ != hipSuccess) { snprintf((ctx)->err, sizeof((ctx)->err), "%s failed: %s", #call, hipGetErrorString(e_)); return GC_ERR_HIP; } } while (0)
+
+extern "C" int gc_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" size_t gc_zstd_compress_bound(size_t n)
+{
+    size_t nb = n ? (n + GC_ZSTD_BLOCK_MAX - 1) / GC_ZSTD_BLOCK_MAX : 1;
+    return n + nb * GC_FRAME_OVERHEAD + 16;
+}
+
+extern "C" int gc_ctx_create(gc_ctx** out, int device)
+{
+    if (!out) return GC_ERR_PARAM;
+    *out = nullptr;
+    int n = gc_device_count();
+    if (n <= 0 || device < 0 || device >= n) return GC_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return GC_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return GC_ERR_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return GC_ERR_NO_DEVICE;     // kernels are built for gfx950 only
+    gc_ctx* c = new (std::nothrow) gc_ctx();
+    if (!c) return GC_ERR_NOMEM;
+    memset(c, 0, sizeof(*c));
+    c->device = device;
+    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return GC_ERR_HIP; }
+    for (int i = 0; i < 6; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return GC_ERR_HIP; }
+    if (hipMalloc((void**)&c->result, 16) != hipSuccess || hipHostMalloc((void**)&c->hostResult, 16) != hipSuccess) { delete c; return GC_ERR_NOMEM; }
+    *out = c;
+    return GC_OK;
+}
+
+static void free_workspace(gc_ctx* c)
+{
+    hipFree(c->seqRaw); hipFree(c->lit); hipFree(c->meta); hipFree(c->seqPacked); hipFree(c->seqOff); hipFree(c->codes);
+    hipFree(c->stOut); hipFree(c->litSec); hipFree(c->seqSec); hipFree(c->info); hipFree(c->plan);
+    c->seqRaw = nullptr; c->lit = nullptr; c->meta = nullptr; c->seqPacked = nullptr; c->seqOff = nullptr; c->codes = nullptr;
+    c->stOut = nullptr; c->litSec = nullptr; c->seqSec = nullptr; c->info = nullptr; c->plan = nullptr; c->capBlocks = 0;
+}
+
+extern "C" void gc_ctx_destroy(gc_ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipStreamSynchronize(c->stream);
+    free_workspace(c);
+    hipFree(c->result); hipHostFree(c->hostResult); hipFree(c->dIn); hipFree(c->dOut);
+    for (int i = 0; i < 6; i++) hipEventDestroy(c->ev[i]);
+    hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" const char* gc_last_error_message(const gc_ctx* c) { return c ? c->err : "no context"; }
+extern "C" void* gc_ctx_stream(gc_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+static int ensure_workspace(gc_ctx* c, uint32_t nBlocks)
+{
+    if (nBlocks <= c->capBlocks) return GC_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    free_workspace(c);
+    const size_t nb = nBlocks, ms = GC_MAX_SEQ_PER_BLOCK;
+    if (hipMalloc((void**)&c->seqRaw, nb * ms * sizeof(GcSeqRaw)) != hipSuccess ||
+        hipMalloc((void**)&c->lit, nb * GC_ZSTD_BLOCK_MAX) != hipSuccess ||
+        hipMalloc((void**)&c->meta, nb * sizeof(GcBlockMeta)) != hipSuccess ||
+        hipMalloc((void**)&c->seqPacked, nb * ms * sizeof(uint64_t)) != hipSuccess ||
+        hipMalloc((void**)&c->seqOff, nb * ms * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void**)&c->codes, nb * ms * 3) != hipSuccess ||
+        hipMalloc((void**)&c->stOut, nb * ms * 3 * sizeof(uint16_t)) != hipSuccess ||
+        hipMalloc((void**)&c->litSec, nb * GC_LITSEC_STRIDE) != hipSuccess ||
+        hipMalloc((void**)&c->seqSec, nb * GC_SEQSEC_STRIDE) != hipSuccess ||
+        hipMalloc((void**)&c->info, nb * sizeof(GcSectionInfo)) != hipSuccess ||
+        hipMalloc((void**)&c->plan, nb * sizeof(GcFramePlan)) != hipSuccess) {
+        free_workspace(c);
+        snprintf(c->err, sizeof(c->err), "workspace allocation for %u blocks failed", nBlocks);
+        return GC_ERR_NOMEM;
+    }
+    c->capBlocks = nBlocks;
+    return GC_OK;
+}
+
+extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, void* d_dst, size_t dstCap, int level)
+{
+    if (!c || (!d_src && n) || !d_dst) return GC_ERR_PARAM;
+    (void)level;
+    HIPCHK(c, hipSetDevice(c->device));
+    c->timed = false;
+    if (n == 0) {
+        // empty input: one frame with FCS=0 and an empty raw last block (ZSTD_compress on 0 bytes does the same)
+        static const uint8_t empty[9] = { 0x28, 0xB5, 0x2F, 0xFD, 0x20, 0x00, 0x01, 0x00, 0x00 };
+        if (dstCap < sizeof(empty)) return GC_ERR_DST_SMALL;
+        HIPCHK(c, hipMemcpyAsync(d_dst, empty, sizeof(empty), hipMemcpyHostToDevice, c->stream));
+        c->hostResult[0] = sizeof(empty); c->hostResult[1] = 0;
+        HIPCHK(c, hipMemcpyAsync(c->result, c->hostResult, 16, hipMemcpyHostToDevice, c->stream));
+        c->pending = true;
+        return GC_OK;
+    }
+    const uint32_t nBlocks = gc_num_blocks(n);
+    int rc = ensure_workspace(c, nBlocks);
+    if (rc != GC_OK) return rc;
+    const uint8_t* src = (const uint8_t*)d_src;
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    GC_LAUNCH(gc_zstd_lz_kernel, nBlocks, 1024, c->stream, src, (uint64_t)n, c->seqRaw, c->lit, c->meta);
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    GC_LAUNCH(gc_zstd_huf_kernel, nBlocks, 256, c->stream, (const uint8_t*)c->lit, (const GcBlockMeta*)c->meta, c->litSec, c->info);
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    GC_LAUNCH(gc_zstd_seq_kernel, nBlocks, 256, c->stream, (const GcSeqRaw*)c->seqRaw, (const GcBlockMeta*)c->meta, c->seqPacked,
+              c->seqOff, c->codes, c->stOut, c->seqSec, c->info, (uint64_t)n);
+    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    GC_LAUNCH(gc_zstd_plan_kernel, 1, 1024, c->stream, (const GcSectionInfo*)c->info, nBlocks, (uint64_t)n, (uint64_t)dstCap, c->plan, c->result);
+    HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+    GC_LAUNCH(gc_zstd_emit_kernel, nBlocks, 256, c->stream, src, (uint64_t)n, (const uint8_t*)c->litSec, (const uint8_t*)c->seqSec,
+              (const GcSectionInfo*)c->info, (const GcFramePlan*)c->plan, (const uint64_t*)c->result, (uint8_t*)d_dst);
+    HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+    HIPCHK(c, hipGetLastError());
+    c->pending = true; c->timed = true;
+    return GC_OK;
+}
+
+extern "C" int gc_zstd_finish(gc_ctx* c, size_t* compressedSize)
+{
+    if (!c || !c->pending) return GC_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(c->hostResult, c->result, 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->pending = false;
+    if (c->hostResult[1]) { snprintf(c->err, sizeof(c->err), "destination too small: need %llu bytes", (unsigned long long)c->hostResult[0]); return GC_ERR_DST_SMALL; }
+    if (compressedSize) *compressedSize = (size_t)c->hostResult[0];
+    return GC_OK;
+}
+
+extern "C" int gc_zstd_last_timing(gc_ctx* c, float ms[6])
+{
+    if (!c || !c->timed || c->pending) return GC_ERR_PARAM;
+    for (int i = 0; i < 5; i++) HIPCHK(c, hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
+    HIPCHK(c, hipEventElapsedTime(&ms[5], c->ev[0], c->ev[5]));
+    return GC_OK;
+}
+
+extern "C" int gc_zstd_compress_host(gc_ctx* c, const void* src, size_t n, void* dst, size_t dstCap, int level, size_t* outSize)
+{
+    if (!c || (!src && n) || !dst) return GC_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t bound = gc_zstd_compress_bound(n);
+    if (n > c->dInCap) { hipFree(c->dIn); c->dIn = nullptr; c->dInCap = 0; if (hipMalloc((void**)&c->dIn, n + 64) != hipSuccess) return GC_ERR_NOMEM; c->dInCap = n; }
+    if (bound > c->dOutCap) { hipFree(c->dOut); c->dOut = nullptr; c->dOutCap = 0; if (hipMalloc((void**)&c->dOut, bound) != hipSuccess) return GC_ERR_NOMEM; c->dOutCap = bound; }
+    if (n) HIPCHK(c, hipMemcpyAsync(c->dIn, src, n, hipMemcpyHostToDevice, c->stream));
+    int rc = gc_zstd_compress_device(c, c->dIn, n, c->dOut, c->dOutCap, level);
+    if (rc != GC_OK) return rc;
+    size_t sz = 0;
+    rc = gc_zstd_finish(c, &sz);
+    if (rc != GC_OK) return rc;
+    if (sz > dstCap) { snprintf(c->err, sizeof(c->err), "destination too small: need %zu bytes", sz); return GC_ERR_DST_SMALL; }
+    HIPCHK(c, hipMemcpy(dst, c->dOut, sz, hipMemcpyDeviceToHost));
+    if (outSize) *outSize = sz;
+    return GC_OK;
+}

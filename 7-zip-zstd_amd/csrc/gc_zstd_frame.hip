@@ -1,0 +1,85 @@
+// gc_zstd_frame.hip -- K4/K5: frame planning and assembly.
+//
+// Every block becomes one single-segment zstd frame (magic, frame header descriptor, frame content size,
+// one block header, payload) -- ZSTD_writeFrameHeader (C/zstd/zstd_compress.c:4695-4745), block header
+// `last | type<<1 | size<<3` (:4655-4658), raw-block fallback when the sections do not beat the input
+// (ZSTD_noCompressBlock, zstd_compress_internal.h:650; decision :3033-3035).  The reference decoder accepts any
+// number of concatenated frames (CPP/7zip/Compress/ZstdDecoder.cpp:145-158), which is what makes the blocks
+// independent units for the GPU and, one level up, for range-splitting across GPUs.
+#include "gc_common.h"
+#include "gc_device.h"
+
+#define FRAME_T 256u
+
+struct GcFramePlan { uint64_t off; uint32_t size; uint32_t compressed; };
+
+__device__ __forceinline__ uint32_t frame_hdr_size(uint32_t blockLen) { return 5u + (blockLen < 256u ? 1u : (blockLen < 65536u + 256u ? 2u : 4u)); }
+
+// K4: one workgroup; exclusive scan of frame sizes
+extern "C" __global__ void __launch_bounds__(1024)
+gc_zstd_plan_kernel(const GcSectionInfo* __restrict__ info, uint32_t nBlocks, uint64_t srcSize, uint64_t dstCap,
+                    GcFramePlan* __restrict__ plan, uint64_t* __restrict__ result /* [0]=total bytes, [1]=error */)
+{
+    __shared__ uint32_t sWave[16];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    uint64_t carry = 0;
+    for (uint32_t tb = 0; tb < nBlocks; tb += 1024u) {
+        const uint32_t b = tb + t;
+        uint32_t size = 0, comp = 0;
+        if (b < nBlocks) {
+            const uint64_t base = (uint64_t)b * GC_ZSTD_BLOCK_MAX;
+            const uint32_t blockLen = (uint32_t)((srcSize - base) < GC_ZSTD_BLOCK_MAX ? (srcSize - base) : GC_ZSTD_BLOCK_MAX);
+            const GcSectionInfo si = info[b];
+            const uint64_t payload = (uint64_t)si.litSecSize + si.seqSecSize;
+            comp = (si.seqSecSize != 0xFFFFFFFFu && payload < blockLen) ? 1u : 0u;
+            size = frame_hdr_size(blockLen) + 3u + (comp ? (uint32_t)payload : blockLen);
+        }
+        uint32_t incl = gc_wave_incl_sum(size);
+        if (lane == 63u) sWave[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+        for (uint32_t w = 0; w < 16u; w++) { uint32_t c = sWave[w]; if (w < wave) before += c; all += c; }
+        __syncthreads();
+        if (b < nBlocks) { GcFramePlan p; p.off = carry + before + incl - size; p.size = size; p.compressed = comp; plan[b] = p; }
+        carry += all;
+    }
+    if (t == 0) { result[0] = carry; result[1] = carry > dstCap ? 1u : 0u; }
+}
+
+// K5: one workgroup per block writes its frame
+extern "C" __global__ void __launch_bounds__(FRAME_T)
+gc_zstd_emit_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const uint8_t* __restrict__ litSec,
+                    const uint8_t* __restrict__ seqSec, const GcSectionInfo* __restrict__ info,
+                    const GcFramePlan* __restrict__ plan, const uint64_t* __restrict__ result, uint8_t* __restrict__ dst)
+{
+    if (result[1]) return;                       // output buffer too small: write nothing
+    const uint32_t t = threadIdx.x, b = blockIdx.x;
+    const uint64_t base = (uint64_t)b * GC_ZSTD_BLOCK_MAX;
+    const uint32_t blockLen = (uint32_t)((srcSize - base) < GC_ZSTD_BLOCK_MAX ? (srcSize - base) : GC_ZSTD_BLOCK_MAX);
+    const GcFramePlan p = plan[b];
+    const GcSectionInfo si = info[b];
+    uint8_t* o = dst + p.off;
+    const uint32_t hs = frame_hdr_size(blockLen);
+    if (t == 0) {
+        o[0] = 0x28; o[1] = 0xB5; o[2] = 0x2F; o[3] = 0xFD;                     // ZSTD_MAGICNUMBER 0xFD2FB528
+        const uint32_t fcsCode = hs == 6u ? 0u : (hs == 7u ? 1u : 2u);
+        o[4] = (uint8_t)((fcsCode << 6) | (1u << 5));                            // single segment, no checksum, no dictID
+        if (hs == 6u) o[5] = (uint8_t)blockLen;
+        else if (hs == 7u) { uint32_t v = blockLen - 256u; o[5] = (uint8_t)v; o[6] = (uint8_t)(v >> 8); }
+        else { o[5] = (uint8_t)blockLen; o[6] = (uint8_t)(blockLen >> 8); o[7] = (uint8_t)(blockLen >> 16); o[8] = (uint8_t)(blockLen >> 24); }
+        const uint32_t bsz = p.compressed ? si.litSecSize + si.seqSecSize : blockLen;
+        const uint32_t bh = 1u | ((p.compressed ? 2u : 0u) << 1) | (bsz << 3);  // last block, type, size
+        o[hs] = (uint8_t)bh; o[hs + 1u] = (uint8_t)(bh >> 8); o[hs + 2u] = (uint8_t)(bh >> 16);
+    }
+    uint8_t* pay = o + hs + 3u;
+    if (p.compressed) {
+        const uint8_t* ls = litSec + (uint64_t)b * GC_LITSEC_STRIDE;
+        const uint8_t* ss = seqSec + (uint64_t)b * GC_SEQSEC_STRIDE;
+        for (uint32_t i = t; i < si.litSecSize; i += FRAME_T) pay[i] = ls[i];
+        pay += si.litSecSize;
+        for (uint32_t i = t; i < si.seqSecSize; i += FRAME_T) pay[i] = ss[i];
+    } else {
+        const uint8_t* s = src + base;
+        for (uint32_t i = t; i < blockLen; i += FRAME_T) pay[i] = s[i];
+    }
+}

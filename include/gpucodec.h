@@ -1,0 +1,68 @@
+/* include/gpucodec.h -- C ABI of the MI355X block-parallel compression engine (libgpucodec.so).
+ *
+ * This is the boundary the reference's codec wrappers bind.  Each entry point names the reference
+ * interface it replaces (paths relative to /root/reference):
+ *
+ *   gc_zstd_compress_host   <->  the ZSTD_compressStream2() loop inside NCompress::NZSTD::CEncoder::Code
+ *                                (CPP/7zip/Compress/ZstdEncoder.cpp:398-461; library entry
+ *                                C/zstd/zstd_compress.c:6447).  Same contract: bytes in, a zstd stream out
+ *                                that ZSTD_decompressStream / NCompress::NZSTD::CDecoder
+ *                                (CPP/7zip/Compress/ZstdDecoder.cpp:66-175) regenerates bit-exactly.
+ *   gc_zstd_compress_device <->  same, for callers that already hold the input in HBM (bench, multi-GPU
+ *                                sharding: one context per GPU, host range-splits the input).
+ *   gc_zstd_compress_bound  <->  ZSTD_compressBound (C/zstd/zstd_compress.c:69).
+ *   gc_ctx_create/destroy   <->  ZSTD_createCCtx / ZSTD_freeCCtx (ZstdEncoder.cpp:262, :44).
+ *
+ * The 7-Zip plugin surface (GetNumberOfMethods, GetMethodProperty, CreateEncoder, CreateDecoder,
+ * CreateObject, GetModuleProp + the ICompressCoder vtable; CPP/7zip/Compress/CodecExports.cpp:153-378)
+ * lives in lib7zgpucodec.so, which is a thin C++ layer over this ABI.
+ *
+ * Plain C types only; no torch / HIP types cross this boundary.  All functions return GC_OK (0) or a
+ * negative GC_ERR_* code; there is NO CPU fallback: without a usable gfx950 device gc_ctx_create fails.
+ */
+#ifndef GPUCODEC_H
+#define GPUCODEC_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GC_OK               0
+#define GC_ERR_NO_DEVICE   -1   /* no HIP device / wrong architecture */
+#define GC_ERR_HIP         -2   /* a HIP runtime call failed; see gc_last_error_message */
+#define GC_ERR_NOMEM       -3
+#define GC_ERR_DST_SMALL   -4   /* dstCapacity < compressed size (cf. ZSTD_error_dstSize_tooSmall) */
+#define GC_ERR_PARAM       -5
+
+typedef struct gc_ctx gc_ctx;
+
+int         gc_device_count(void);
+int         gc_ctx_create(gc_ctx** out, int device);
+void        gc_ctx_destroy(gc_ctx* ctx);
+const char* gc_last_error_message(const gc_ctx* ctx);
+
+/* worst-case compressed size for n input bytes (every block stored raw + frame overhead) */
+size_t      gc_zstd_compress_bound(size_t n);
+
+/* Compress n bytes already resident in device memory into device memory.  Asynchronous on the context's
+ * stream; call gc_zstd_finish to synchronise and fetch the size.  `level` follows the reference's -mx
+ * scale (1..22); levels map onto the GPU parser's effort knobs (currently one configuration). */
+int         gc_zstd_compress_device(gc_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t dstCapacity, int level);
+int         gc_zstd_finish(gc_ctx* ctx, size_t* compressedSize);
+
+/* Host-buffer convenience: H2D copy, compress, D2H copy (what CEncoder::Code needs). */
+int         gc_zstd_compress_host(gc_ctx* ctx, const void* src, size_t n, void* dst, size_t dstCapacity, int level,
+                                  size_t* compressedSize);
+
+/* HIP-event timing of the kernels of the last gc_zstd_compress_device call (after gc_zstd_finish):
+ * ms[0..4] = lz, huf, seq, plan, emit; ms[5] = first launch -> last kernel end. */
+int         gc_zstd_last_timing(gc_ctx* ctx, float ms[6]);
+
+/* raw stream handle (hipStream_t) so callers can order their own work against the context */
+void*       gc_ctx_stream(gc_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

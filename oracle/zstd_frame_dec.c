@@ -30,6 +30,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <stdlib.h>
+#include <stdio.h>
 
 #define GCO_OK            0
 #define GCO_ERR_TRUNC    -1   /* input ends early */
@@ -48,6 +49,7 @@ typedef struct {
 } gco_diag_t;
 
 static gco_diag_t g_diag;
+static int g_trace;   /* GCO_TRACE=1: print every decoded sequence (encoder bring-up aid) */
 #define FAIL(c) do { g_diag.code = (c); g_diag.line = __LINE__; return (c); } while (0)
 
 /* ------------------------------------------------------------------ XXH64 (content checksum) */
@@ -384,6 +386,7 @@ static int decode_block(frame_ctx* fc, const uint8_t* src, size_t n, uint8_t* ds
             ml = ML_base[mlc] + (uint32_t)bb_read(&b, ML_bits[mlc]);
             ll = LL_base[llc] + (uint32_t)bb_read(&b, LL_bits[llc]);
             /* repcode rules: zstd_decompress_block.c:1250-1290 */
+            if (g_trace) fprintf(stderr, "D %zu ofv=%u ml=%u ll=%u\n", i, ofv, ml, ll);
             if (ofv > 3) { offset = ofv - 3; fc->rep[2] = fc->rep[1]; fc->rep[1] = fc->rep[0]; fc->rep[0] = offset; }
             else {
                 uint32_t idx = ofv + (ll == 0 ? 1 : 0);
@@ -422,6 +425,7 @@ int gco_zstd_decompress(uint8_t* dst, size_t cap, const uint8_t* src, size_t n, 
 {
     size_t ip = 0, op = 0;
     memset(&g_diag, 0, sizeof(g_diag));
+    g_trace = getenv("GCO_TRACE") != NULL;
     while (ip < n) {
         uint32_t magic; frame_ctx* fc; size_t frameStart = op;
         int fhd, single, csum, didf, fcsf; uint64_t fcs = 0; int haveFcs = 0; size_t windowSize = 0;

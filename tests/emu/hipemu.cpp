@@ -134,28 +134,13 @@ static void run_block(dim3 grid, dim3 block, unsigned linear_block, kernel_thunk
     blk = nullptr; cur = nullptr;
 }
 
-void launch(dim3 grid, dim3 block, kernel_thunk_t thunk, void* args, int os_threads)
+void launch(dim3 grid, dim3 block, kernel_thunk_t thunk, void* args, int)
 {
+    // `__shared__` variables are plain statics, so workgroups of one process run one after another;
+    // tests that want parallelism split the input across processes (frames are independent).
     unsigned nblocks = grid.x * grid.y * grid.z;
-    if (os_threads <= 0) {
-        const char* e = getenv("HIPEMU_THREADS");
-        os_threads = e ? atoi(e) : (int)std::thread::hardware_concurrency();
-        if (os_threads < 1) os_threads = 1;
-    }
-    if ((unsigned)os_threads > nblocks) os_threads = (int)nblocks;
-    if (os_threads <= 1) {
-        Pool pool;
-        for (unsigned i = 0; i < nblocks; i++) run_block(grid, block, i, thunk, args, pool);
-        return;
-    }
-    std::atomic<unsigned> next(0);
-    std::vector<std::thread> th;
-    for (int k = 0; k < os_threads; k++)
-        th.emplace_back([&]() {
-            Pool pool;
-            for (;;) { unsigned i = next.fetch_add(1); if (i >= nblocks) break; run_block(grid, block, i, thunk, args, pool); }
-        });
-    for (auto& t : th) t.join();
+    static Pool pool;
+    for (unsigned i = 0; i < nblocks; i++) run_block(grid, block, i, thunk, args, pool);
 }
 
 }  // namespace hipemu

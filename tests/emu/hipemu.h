@@ -9,8 +9,8 @@
 // Model: one OS thread runs one workgroup at a time; every work-item is a fiber (own stack,
 // hand-written x86-64 context switch).  `__syncthreads()` and the wave-collective operations
 // (`__shfl*`, `__ballot`, ...) are rendezvous points that yield to the per-workgroup scheduler.
-// Wave size is 64, as on gfx950.  `__shared__` becomes `static thread_local`, so several workgroups
-// can be emulated concurrently on different OS threads.
+// Wave size is 64, as on gfx950.  `__shared__` becomes a plain `static`, so one process emulates one
+// workgroup at a time (tests parallelise across processes).
 //
 // Limits (by design): wave collectives must be reached by all live lanes of the wave (wave-uniform
 // control flow); data races that the hardware would expose are not detected, because lanes run
@@ -27,7 +27,7 @@
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
-#define __shared__ static thread_local
+#define __shared__ static
 #define __restrict__ __restrict
 #define __constant__ static const
 

@@ -1,0 +1,65 @@
+"""CPU bring-up of the real kernel sources under the SIMT emulator (tests/emu): every stream must decode
+bit-exactly under the oracle decoder and the reference decoder.  Sizes are small: the emulator runs one
+workgroup at a time at roughly 1 s per 128 KiB block."""
+import numpy as np
+import pytest
+
+BLK = 128 * 1024
+
+
+def _roundtrip(O, enc, x):
+    c = enc.code(x)
+    y = O.port_zstd_decompress(c, x.size)
+    assert np.array_equal(x, y)
+    if O.ref("zstd") is not None:
+        assert np.array_equal(O.ref_zstd_decompress(c, x.size), x)
+    return c
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 7, 8, 9, 63, 64, 255, 256, 257, 1023, 1024, 1025, 4097])
+def test_tiny_inputs(O, emu_enc, n):
+    _roundtrip(O, emu_enc, O.corpus("text-zipf", n))
+
+
+@pytest.mark.parametrize("kind", ["text-zipf", "lz-7zip", "silesia-like", "web-text"])
+def test_corpora_multi_block(O, emu_enc, kind):
+    x = O.corpus(kind, 2 * BLK + 4321)
+    c = _roundtrip(O, emu_enc, x)
+    if O.ref("zstd") is not None:
+        ref = O.ref_zstd_compress(x, 3, piece=BLK)
+        assert len(c) <= 1.05 * len(ref), (len(c), len(ref))
+
+
+@pytest.mark.parametrize("n", [BLK - 1, BLK, BLK + 1])
+def test_block_boundaries(O, emu_enc, n):
+    _roundtrip(O, emu_enc, O.corpus("text-zipf", n))
+
+
+def test_incompressible_goes_raw(O, emu_enc):
+    x = O.corpus("random", BLK + 777)
+    c = _roundtrip(O, emu_enc, x)
+    assert len(c) <= emu_enc.compress_bound(x.size)
+    assert len(c) >= x.size
+
+
+def test_all_same_and_long_matches(O, emu_enc):
+    _roundtrip(O, emu_enc, O.corpus("zeros", BLK + 100))
+    # long period-7 pattern: matches far longer than 65535 after merging, litLength 0 chains
+    x = np.tile(np.arange(7, dtype=np.uint8), (BLK + 50) // 7 + 1)[:BLK + 50].copy()
+    _roundtrip(O, emu_enc, x)
+    # one literal run longer than 65535 followed by a repeat of it
+    r = O.corpus("random", 70_000)
+    _roundtrip(O, emu_enc, np.concatenate([r, r[:50_000]]))
+
+
+def test_binary_alphabet_over_128_symbols(O, emu_enc):
+    # skewed distribution over all 256 byte values: exercises the FSE-compressed Huffman weight header
+    rng = np.random.default_rng(7)
+    p = 1.0 / np.arange(1, 257) ** 1.2; p /= p.sum()
+    x = rng.choice(256, size=BLK, p=p).astype(np.uint8)
+    _roundtrip(O, emu_enc, x)
+
+
+def test_deterministic(O, emu_enc):
+    x = O.corpus("silesia-like", BLK)
+    assert np.array_equal(emu_enc.code(x), emu_enc.code(x))
