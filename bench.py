@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""bench.py -- compression throughput of the MI355X zstd path on BASELINE.json config 2.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the whole hot path (K1 lz -> K2 huf -> K3 seq -> K4 plan -> K5 emit) over one
+100 000 000-byte buffer per GPU that is already resident in HBM (enwik8 is not available offline; the stand-in
+is the deterministic `text-zipf` corpus, labelled synthetic).  The zstd blocks are 128 KiB independent frames.
+With N>1 every rank compresses its own 100 MB shard (weak scaling, no data-path collective: the host
+range-splits the input and concatenates frames; RCCL is only used for the timing barrier / max-reduction).
+
+One JSON line is printed by rank 0; see DESIGN.md "Measurement" for the definition of every field.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(x, level, budget_s=25.0):
+    """Reference zstd (oracle/_ref/libzstd_ref.so = C/zstd compiled from /root/reference) timed on the host
+    cores of this box, on a bounded sample of the same workload.  Reported, not the optimisation target."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O          # cpu_baseline leg only
+    if O.ref("zstd") is None:
+        return None, None
+    cores = os.cpu_count() or 1
+    sample = x[: min(x.size, 100_000_000)]
+    out = {}
+    ref_size = None
+    for label, workers in (("1 thread (nbWorkers=0)", 0), ("%d threads (ZSTDMT nbWorkers=%d)" % (cores, cores), cores)):
+        best = None
+        t_spent = 0.0
+        for _ in range(3):
+            t0 = time.perf_counter()
+            c = O.ref_zstd_compress(sample, level, workers=workers)
+            dt = time.perf_counter() - t0
+            t_spent += dt
+            best = dt if best is None else min(best, dt)
+            if workers == 0:
+                ref_size = len(c)
+            if t_spent > budget_s / 2:
+                break
+        out[label] = sample.size / best / 1e6
+    mt_label = list(out.keys())[1]
+    res = {"value": round(out[mt_label], 1), "unit": "MB/s", "cores": cores, "kind": "reference",
+           "sample": "ZSTD_compress2 level %d on the first %d bytes of the same buffer, best of <=3 runs; %s; single thread: %.1f MB/s"
+                     % (level, sample.size, mt_label, list(out.values())[0])}
+    return res, ref_size
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--bytes", type=int, default=100_000_000, help="input bytes per GPU (enwik8 size)")
+    ap.add_argument("--corpus", default="text-zipf")
+    ap.add_argument("--level", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import __graft_entry__ as g
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    g.build_hip()
+    pkg = g.load_package()
+    from importlib import util as _u
+    spec = _u.spec_from_file_location("sevenzip_zstd_amd_corpus", os.path.join(ROOT, "7-zip-zstd_amd", "corpus", "__init__.py"))
+    corpus_mod = _u.module_from_spec(spec); spec.loader.exec_module(corpus_mod)
+
+    n = args.bytes
+    x = corpus_mod.corpus(args.corpus, n, seed=20260921 + rank)      # each rank owns a different shard
+    enc = pkg.ZstdEncoder(device=local_rank, level=args.level)
+    dev = torch.device("cuda", local_rank)
+    d_src = torch.from_numpy(x).to(dev)
+    cap = enc.compress_bound(n)
+    d_dst = torch.empty(cap, dtype=torch.uint8, device=dev)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    csize = 0
+    for _ in range(args.warmup):
+        enc.code_device(d_src.data_ptr(), n, d_dst.data_ptr(), cap)
+        csize = enc.finish()
+
+    kern_ms = {k: 0.0 for k in pkg.ZstdEncoder.KERNELS}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        enc.code_device(d_src.data_ptr(), n, d_dst.data_ptr(), cap)
+        csize = enc.finish()
+        t = enc.last_timing_ms()         # hipEvent pairs recorded on the library's own stream around each kernel
+        for k in kern_ms:
+            kern_ms[k] += t[k]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        sz = torch.tensor([csize], dtype=torch.int64, device=dev)
+        dist.all_reduce(sz, op=dist.ReduceOp.SUM)
+        total_csize = int(sz.item())
+    else:
+        total_csize = csize
+    for k in kern_ms:
+        kern_ms[k] /= max(args.steps, 1)
+
+    if rank == 0:
+        total_in = n * world
+        value = total_in * args.steps / elapsed / 1e6
+        ratio = n / csize
+        # dominant kernel = the longest of the five; algorithmic bytes per launch = N_in * (1 + 1/ratio)  
+        dom = max(("lz", "huf", "seq", "plan", "emit"), key=lambda k: kern_ms[k])
+        algo_bytes = n * (1.0 + 1.0 / ratio)
+        achieved = algo_bytes / (kern_ms[dom] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "gc_zstd_%s_kernel" % dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "algorithmic_bytes_per_launch": int(algo_bytes),
+                    "kernel_ms": {k: round(v, 4) for k, v in kern_ms.items()},
+                    "pipeline_read_frac": round(n / (kern_ms["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "pipeline_rw_frac": round(algo_bytes / (kern_ms["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+        cpu, ref_size = (None, None) if args.no_cpu_baseline else cpu_baseline(x, args.level)
+        line = {
+            "metric": "zstd-L3 compression throughput, 128 KiB independent blocks (input MB/s)",
+            "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "zstd level 3, enwik8 stand-in (%s, %d B per GPU), 128 KiB independent blocks" % (args.corpus, n),
+                       "bytes_per_gpu": n, "blocks_per_gpu": (n + 131071) // 131072, "parallelism": "range-shard x%d, no collective" % world},
+            "compressed_bytes": total_csize, "ratio": round(ratio, 4),
+            "ratio_vs_ref": None if (not ref_size or n > 100_000_000) else
+                            {"ours_over_ref_single_stream_L%d" % args.level: round(csize / ref_size, 4), "ref_bytes": ref_size},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    enc.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

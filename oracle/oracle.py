@@ -3,7 +3,7 @@
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module
 (the product path under 7-zip-zstd_amd/ never does).
 
-  port : oracle/libgc_oracle.so        -- this repo's plain-C restatement (zstd_frame_dec.c) + corpus generators
+  port : oracle/libgc_oracle.so        -- this repo's plain-C restatement (zstd_frame_dec.c)
   ref  : oracle/_ref/lib*_ref.so       -- the reference's own C codecs compiled from /root/reference by oracle/Makefile
 """
 import ctypes as C
@@ -47,9 +47,6 @@ def port():
         _port.gco_last_diag.restype = C.POINTER(_Diag)
         _port.gco_xxh64.argtypes = [_VP, _SZ, C.c_uint64]
         _port.gco_xxh64.restype = C.c_uint64
-        for name in ("gc_corpus_text_zipf", "gc_corpus_webtext", "gc_corpus_silesia_like"):
-            getattr(_port, name).argtypes = [_VP, _SZ, C.c_uint64]
-        _port.gc_corpus_lz7zip.argtypes = [_VP, _SZ, C.c_uint, C.c_uint32]
     return _port
 
 
@@ -99,23 +96,14 @@ def _buf(x):
 
 # ----------------------------------------------------------------------------- corpora
 def corpus(kind, n, seed=20260921):
-    out = np.empty(n, dtype=np.uint8)
-    p = port()
-    if kind == "text-zipf":
-        p.gc_corpus_text_zipf(out.ctypes.data, n, seed)
-    elif kind == "web-text":
-        p.gc_corpus_webtext(out.ctypes.data, n, seed)
-    elif kind == "lz-7zip":
-        p.gc_corpus_lz7zip(out.ctypes.data, n, 24, seed & 0xFFFFFFFF if seed != 20260921 else 0)
-    elif kind == "silesia-like":
-        p.gc_corpus_silesia_like(out.ctypes.data, n, seed)
-    elif kind == "random":
-        out[:] = np.random.default_rng(seed).integers(0, 256, n, dtype=np.uint8)
-    elif kind == "zeros":
-        out[:] = 0
-    else:
-        raise ValueError(kind)
-    return out
+    """Synthetic corpora live with the harness (7-zip-zstd_amd/corpus); re-exported here for the tests."""
+    import importlib.util
+    import sys
+    name = "sevenzip_zstd_amd_corpus"
+    if name not in sys.modules:
+        spec = importlib.util.spec_from_file_location(name, os.path.join(os.path.dirname(HERE), "7-zip-zstd_amd", "corpus", "__init__.py"))
+        mod = importlib.util.module_from_spec(spec); sys.modules[name] = mod; spec.loader.exec_module(mod)
+    return sys.modules[name].corpus(kind, n, seed)
 
 
 # ----------------------------------------------------------------------------- zstd
