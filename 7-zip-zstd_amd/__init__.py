@@ -22,7 +22,8 @@ GC_OK = 0
 _ERR = {-1: "GC_ERR_NO_DEVICE", -2: "GC_ERR_HIP", -3: "GC_ERR_NOMEM", -4: "GC_ERR_DST_SMALL", -5: "GC_ERR_PARAM"}
 
 EXPORTS = ["gc_device_count", "gc_ctx_create", "gc_ctx_destroy", "gc_last_error_message", "gc_zstd_compress_bound",
-           "gc_zstd_compress_device", "gc_zstd_finish", "gc_zstd_compress_host", "gc_zstd_last_timing", "gc_ctx_stream"]
+           "gc_zstd_compress_device", "gc_zstd_finish", "gc_zstd_compress_host", "gc_zstd_last_timing", "gc_ctx_stream",
+           "gc_zstd_set_phase_profile", "gc_zstd_phase_profile"]
 
 
 class GpuCodecError(RuntimeError):
@@ -52,6 +53,10 @@ def load_library(path=None):
     lib.gc_zstd_compress_host.restype = C.c_int
     lib.gc_zstd_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.gc_zstd_last_timing.restype = C.c_int
+    lib.gc_zstd_set_phase_profile.argtypes = [C.c_void_p, C.c_int]
+    lib.gc_zstd_set_phase_profile.restype = C.c_int
+    lib.gc_zstd_phase_profile.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    lib.gc_zstd_phase_profile.restype = C.c_int
     lib.gc_ctx_stream.argtypes = [C.c_void_p]
     lib.gc_ctx_stream.restype = C.c_void_p
     return lib
@@ -114,6 +119,18 @@ class ZstdEncoder:
         ms = (C.c_float * 6)()
         self._check(self._lib.gc_zstd_last_timing(self._ctx, ms), "gc_zstd_last_timing")
         return dict(zip(self.KERNELS, [float(x) for x in ms]))
+
+    PHASES = ("lz.probe", "lz.insert", "lz.verify", "lz.double", "lz.chain", "lz.walk", "lz.emit",
+              "seq.merge", "seq.codes", "seq.tables", "seq.chains", "seq.pack")
+
+    def set_phase_profile(self, on=True):
+        self._check(self._lib.gc_zstd_set_phase_profile(self._ctx, 1 if on else 0), "gc_zstd_set_phase_profile")
+
+    def phase_profile(self):
+        """Average shader cycles per block and phase of the last call (thread 0's view, barrier waits included)."""
+        v = (C.c_double * 12)()
+        self._check(self._lib.gc_zstd_phase_profile(self._ctx, v), "gc_zstd_phase_profile")
+        return dict(zip(self.PHASES, [float(x) for x in v]))
 
     def stream(self):
         return self._lib.gc_ctx_stream(self._ctx)

@@ -18,10 +18,10 @@
 
 struct GcFramePlan { uint64_t off; uint32_t size; uint32_t compressed; };
 
-extern "C" __global__ void gc_zstd_lz_kernel(const uint8_t*, uint64_t, GcSeqRaw*, uint8_t*, GcBlockMeta*);
+extern "C" __global__ void gc_zstd_lz_kernel(const uint8_t*, uint64_t, GcSeqRaw*, uint8_t*, GcBlockMeta*, unsigned long long*);
 extern "C" __global__ void gc_zstd_huf_kernel(const uint8_t*, const GcBlockMeta*, uint8_t*, GcSectionInfo*);
 extern "C" __global__ void gc_zstd_seq_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t*, uint32_t*, uint8_t*, uint16_t*,
-                                              uint8_t*, GcSectionInfo*, uint64_t);
+                                              uint8_t*, GcSectionInfo*, uint64_t, unsigned long long*);
 extern "C" __global__ void gc_zstd_plan_kernel(const GcSectionInfo*, uint32_t, uint64_t, uint64_t, GcFramePlan*, uint64_t*);
 extern "C" __global__ void gc_zstd_emit_kernel(const uint8_t*, uint64_t, const uint8_t*, const uint8_t*, const GcSectionInfo*,
                                                const GcFramePlan*, const uint64_t*, uint8_t*);
@@ -40,6 +40,8 @@ struct gc_ctx {
     // staging for the host-buffer entry point
     uint8_t* dIn; size_t dInCap; uint8_t* dOut; size_t dOutCap;
     bool pending; bool timed;
+    unsigned long long* prof;  // device: GC_LZ_PHASES + GC_SEQ_PHASES cycle sums, only when profiling is on
+    bool profOn; uint32_t profBlocks;
 };
 
 #define HIPCHK(ctx, call)                                                                       \
@@ -75,6 +77,7 @@ extern "C" int gc_ctx_create(gc_ctx** out, int device)
     c->device = device;
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return GC_ERR_HIP; }
     for (int i = 0; i < 6; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return GC_ERR_HIP; }
+    if (hipMalloc((void**)&c->prof, (GC_LZ_PHASES + GC_SEQ_PHASES) * sizeof(unsigned long long)) != hipSuccess) { delete c; return GC_ERR_NOMEM; }
     if (hipMalloc((void**)&c->result, 16) != hipSuccess || hipHostMalloc((void**)&c->hostResult, 16) != hipSuccess) { delete c; return GC_ERR_NOMEM; }
     *out = c;
     return GC_OK;
@@ -94,7 +97,7 @@ extern "C" void gc_ctx_destroy(gc_ctx* c)
     hipSetDevice(c->device);
     hipStreamSynchronize(c->stream);
     free_workspace(c);
-    hipFree(c->result); hipHostFree(c->hostResult); hipFree(c->dIn); hipFree(c->dOut);
+    hipFree(c->prof); hipFree(c->result); hipHostFree(c->hostResult); hipFree(c->dIn); hipFree(c->dOut);
     for (int i = 0; i < 6; i++) hipEventDestroy(c->ev[i]);
     hipStreamDestroy(c->stream);
     delete c;
@@ -148,13 +151,14 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
     int rc = ensure_workspace(c, nBlocks);
     if (rc != GC_OK) return rc;
     const uint8_t* src = (const uint8_t*)d_src;
+    if (c->profOn) { HIPCHK(c, hipMemsetAsync(c->prof, 0, (GC_LZ_PHASES + GC_SEQ_PHASES) * sizeof(unsigned long long), c->stream)); c->profBlocks = nBlocks; }
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    GC_LAUNCH(gc_zstd_lz_kernel, nBlocks, 1024, c->stream, src, (uint64_t)n, c->seqRaw, c->lit, c->meta);
+    GC_LAUNCH(gc_zstd_lz_kernel, nBlocks, 1024, c->stream, src, (uint64_t)n, c->seqRaw, c->lit, c->meta, c->profOn ? c->prof : nullptr);
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     GC_LAUNCH(gc_zstd_huf_kernel, nBlocks, 256, c->stream, (const uint8_t*)c->lit, (const GcBlockMeta*)c->meta, c->litSec, c->info);
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     GC_LAUNCH(gc_zstd_seq_kernel, nBlocks, 256, c->stream, (const GcSeqRaw*)c->seqRaw, (const GcBlockMeta*)c->meta, c->seqPacked,
-              c->seqOff, c->codes, c->stOut, c->seqSec, c->info, (uint64_t)n);
+              c->seqOff, c->codes, c->stOut, c->seqSec, c->info, (uint64_t)n, c->profOn ? c->prof + GC_LZ_PHASES : nullptr);
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     GC_LAUNCH(gc_zstd_plan_kernel, 1, 1024, c->stream, (const GcSectionInfo*)c->info, nBlocks, (uint64_t)n, (uint64_t)dstCap, c->plan, c->result);
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
@@ -202,5 +206,17 @@ extern "C" int gc_zstd_compress_host(gc_ctx* c, const void* src, size_t n, void*
     if (sz > dstCap) { snprintf(c->err, sizeof(c->err), "destination too small: need %zu bytes", sz); return GC_ERR_DST_SMALL; }
     HIPCHK(c, hipMemcpy(dst, c->dOut, sz, hipMemcpyDeviceToHost));
     if (outSize) *outSize = sz;
+    return GC_OK;
+}
+
+// Optional in-kernel phase profile (s_memtime deltas of thread 0, averaged over blocks): K1 phases
+// [probe, insert, verify, double, chain, walk, emit] then K3 phases [merge, codes, tables, chains, pack].
+extern "C" int gc_zstd_set_phase_profile(gc_ctx* c, int enable) { if (!c) return GC_ERR_PARAM; c->profOn = enable != 0; return GC_OK; }
+extern "C" int gc_zstd_phase_profile(gc_ctx* c, double cyclesPerBlock[GC_LZ_PHASES + GC_SEQ_PHASES])
+{
+    if (!c || !c->profOn || c->pending || !c->profBlocks) return GC_ERR_PARAM;
+    unsigned long long h[GC_LZ_PHASES + GC_SEQ_PHASES];
+    HIPCHK(c, hipMemcpy(h, c->prof, sizeof(h), hipMemcpyDeviceToHost));
+    for (int i = 0; i < GC_LZ_PHASES + GC_SEQ_PHASES; i++) cyclesPerBlock[i] = (double)h[i] / c->profBlocks;
     return GC_OK;
 }

@@ -33,6 +33,37 @@ __device__ __forceinline__ uint32_t gc_uniform(uint32_t v)
 #endif
 }
 
+// make LDS writes of this wave visible to its other lanes (wave-synchronous code: no workgroup barrier needed)
+__device__ __forceinline__ void gc_wave_sync()
+{
+#ifdef HIPEMU
+    hipemu::wave_barrier();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#endif
+}
+
+// shader cycle counter (s_memtime); only used by the optional phase profile
+__device__ __forceinline__ unsigned long long gc_clock()
+{
+#ifdef HIPEMU
+    return __builtin_ia32_rdtsc();
+#else
+    return (unsigned long long)clock64();
+#endif
+}
+
+// value of `v` in lane `lane`, where `lane` is wave-uniform: a single v_readlane_b32 (no LDS round trip)
+__device__ __forceinline__ uint32_t gc_readlane(uint32_t v, uint32_t lane)
+{
+#ifdef HIPEMU
+    return __shfl(v, (int)lane);
+#else
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)lane));
+#endif
+}
+
 __device__ __forceinline__ uint64_t gc_lanemask_lt() { return (1ull << (__lane_id() & 63)) - 1ull; }
 
 // inclusive wave scan (sum) over 64 lanes

@@ -14,8 +14,9 @@
 //       the result does not depend on wave timing (the encoder is deterministic)
 //   P3  a small generation-stamped table (ds_min_u32 -> first occurrence inside the chunk) supplies the
 //       short-distance candidates that P1 cannot see because the whole chunk was probed before it was inserted
-//   P4  candidates are verified against the immutable input (8-byte words, xor + ctz), capped at GC_MATCH_CAP;
-//       longer matches appear as chains of capped matches with equal offset and are merged in K3
+//   P4  candidates are verified against the immutable input: all candidate windows (16 B each) are requested
+//       together so only one memory latency is exposed; a saturated best candidate is extended 16 B per round
+//       up to GC_MATCH_CAP; longer matches appear as chains of capped matches with equal offset, merged in K3
 //   P5  parse: next(t) = t+len if a match is taken at t, else t+1.  Each wave resolves its 64-position
 //       segment for EVERY possible entry lane by pointer doubling through ds_bpermute (6 rounds), one lane
 //       chains the 16 wave exits, then each wave walks its real path with scalar bit tricks.
@@ -35,19 +36,22 @@
 __device__ __forceinline__ uint32_t lz_hash_long(uint32_t lo, uint32_t hi)  { return lo * 0x9E3779B1u + hi * 0x85EBCA77u; }
 __device__ __forceinline__ uint32_t lz_hash_short(uint32_t lo, uint32_t hi) { return lo * 0x9E3779B1u + (hi & 0xFFu) * 0xC2B2AE3Du; }
 
-// match length of src[p..] vs src[c..], at most maxLen; loads never pass `limit`
-__device__ __forceinline__ uint32_t lz_match_len(const uint8_t* src, uint64_t base, uint32_t p, uint32_t c,
-                                                 uint32_t maxLen, uint64_t limit)
+// 16 bytes at src[pos..] as two little-endian words, zero-filled past `limit`
+struct LzW16 { uint64_t a, b; };
+__device__ __forceinline__ LzW16 lz_ld16(const uint8_t* src, uint64_t pos, uint64_t limit)
 {
-    uint32_t len = 0;
-    while (len < maxLen) {
-        uint64_t a = gc_ld64_guard(src, base + p + len, limit);
-        uint64_t b = gc_ld64_guard(src, base + c + len, limit);
-        uint64_t x = a ^ b;
-        if (x) { len += gc_ctz64(x) >> 3; break; }
-        len += 8;
-    }
-    return len < maxLen ? len : maxLen;
+    LzW16 w;
+    if (pos + 16 <= limit) { __builtin_memcpy(&w, src + pos, 16); }
+    else { w.a = gc_ld64_guard(src, pos, limit); w.b = gc_ld64_guard(src, pos + 8, limit); }
+    return w;
+}
+// common prefix length (0..16) of two 16-byte windows
+__device__ __forceinline__ uint32_t lz_cmp16(LzW16 x, LzW16 y)
+{
+    uint64_t d0 = x.a ^ y.a, d1 = x.b ^ y.b;
+    if (d0) return gc_ctz64(d0) >> 3;
+    if (d1) return 8u + (gc_ctz64(d1) >> 3);
+    return 16u;
 }
 
 // cost-ish score used to compare candidates and for the lazy check: 4 bits per matched byte minus offset bits
@@ -55,7 +59,8 @@ __device__ __forceinline__ int lz_gain(uint32_t len, uint32_t off) { return (int
 
 extern "C" __global__ void __launch_bounds__(LZ_T)
 gc_zstd_lz_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, GcSeqRaw* __restrict__ seqRaw,
-                  uint8_t* __restrict__ lit, GcBlockMeta* __restrict__ meta)
+                  uint8_t* __restrict__ lit, GcBlockMeta* __restrict__ meta,
+                  unsigned long long* __restrict__ prof /* optional: per-phase cycle sums (thread 0 of every block) */)
 {
     __shared__ uint32_t tabL[1u << LZ_LOG_L];
     __shared__ uint32_t tabS[1u << LZ_LOG_S];
@@ -79,8 +84,12 @@ gc_zstd_lz_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, GcSeqRaw* _
     if (t == 0) sCursor = 0;
     __syncthreads();
 
+    unsigned long long pc[GC_LZ_PHASES]; for (int i = 0; i < GC_LZ_PHASES; i++) pc[i] = 0;
+    unsigned long long tprev = prof ? gc_clock() : 0ull;
+#define LZ_PHASE(i) do { if (prof && t == 0) { unsigned long long now_ = gc_clock(); pc[i] += now_ - tprev; tprev = now_; } } while (0)
     uint32_t totalSeq = 0, totalLit = 0;   // uniform running totals
     const uint32_t nChunks = (n + LZ_T - 1) / LZ_T;
+    LzW16 own = lz_ld16(src, base + t, srcSize);        // own 16 bytes, always loaded one chunk ahead
 
     for (uint32_t k = 0; k < nChunks; k++) {
         const uint32_t cbase = k * LZ_T;
@@ -90,9 +99,9 @@ gc_zstd_lz_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, GcSeqRaw* _
 
         // ---- P0/P1: load, hash, probe
         uint32_t lo = 0, hi = 0, hL = 0, hS = 0, eL = 0, eS = 0;
+        const LzW16 me = own;
         if (canHash) {
-            uint64_t v = gc_ld64(src + base + p);
-            lo = (uint32_t)v; hi = (uint32_t)(v >> 32);
+            lo = (uint32_t)me.a; hi = (uint32_t)(me.a >> 32);
             hL = lz_hash_long(lo, hi); hS = lz_hash_short(lo, hi);
             eL = tabL[hL >> (32u - LZ_LOG_L)];
             eS = tabS[hS >> (32u - LZ_LOG_S)];
@@ -103,6 +112,7 @@ gc_zstd_lz_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, GcSeqRaw* _
         const uint32_t tagC = (hS >> 4) & 0x3FFFu;
         const uint32_t slotC = hS >> (32u - LZ_LOG_C);
         __syncthreads();
+        LZ_PHASE(0);    // load + hash + probe
         // ---- P2: insert (most recent position wins; first-in-chunk wins for the chunk table)
         if (canHash) {
             atomicMax(&tabL[hL >> (32u - LZ_LOG_L)], (p << LZ_TAG_BITS) | tagL);
@@ -110,6 +120,7 @@ gc_zstd_lz_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, GcSeqRaw* _
             atomicMin(&tabC[slotC], (gen << 24) | (t << 14) | tagC);
         }
         __syncthreads();
+        LZ_PHASE(1);    // insert
         // ---- P3/P4: near probe + verification
         uint32_t bestLen = 0, bestOff = 0;
         if (canHash) {
@@ -125,17 +136,35 @@ gc_zstd_lz_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, GcSeqRaw* _
                     if (tc < t) { uint32_t c = cbase + tc; bool dup = false; for (int i = 0; i < nc; i++) dup |= cand[i] == c; if (!dup) cand[nc++] = c; }
                 }
             }
-            for (int i = 0; i < nc; i++) {
-                uint32_t c = cand[i];
-                uint32_t len = lz_match_len(src, base, p, c, maxLen, srcSize);
-                if (len >= GC_MIN_MATCH) {
-                    int g = lz_gain(len, p - c);
-                    if (g > bestGain) { bestGain = g; bestLen = len; bestOff = p - c; }
+            // level 1: all candidate windows are requested together (one exposed memory latency), 16 bytes each
+            LzW16 cw[3];
+            for (int i = 0; i < 3; i++) if (i < nc) cw[i] = lz_ld16(src, base + cand[i], srcSize);
+            uint32_t bestC = 0;
+            for (int i = 0; i < 3; i++) {
+                if (i < nc) {
+                    uint32_t len = lz_cmp16(me, cw[i]);
+                    if (len > maxLen) len = maxLen;
+                    if (len >= GC_MIN_MATCH) {
+                        int g = lz_gain(len, p - cand[i]);
+                        if (g > bestGain) { bestGain = g; bestLen = len; bestOff = p - cand[i]; bestC = cand[i]; }
+                    }
                 }
             }
+            // level 2: only a saturated best candidate is extended, 16 bytes per round, up to GC_MATCH_CAP
+            while (bestLen >= 16u && (bestLen & 15u) == 0u && bestLen < maxLen) {
+                LzW16 x = lz_ld16(src, base + p + bestLen, srcSize);
+                LzW16 y = lz_ld16(src, base + bestC + bestLen, srcSize);
+                uint32_t more = lz_cmp16(x, y);
+                bestLen += more;
+                if (bestLen > maxLen) bestLen = maxLen;
+                if (more < 16u) break;
+            }
         }
+        // prefetch the next chunk's own bytes; the latency hides under the parse below
+        own = lz_ld16(src, base + p + LZ_T, srcSize);
         sM[t] = (bestOff << 8) | bestLen;
         __syncthreads();
+        LZ_PHASE(2);    // verify
         // ---- P5a: lazy decision and next pointer
         bool take = bestLen != 0;
         if (take && t + 1u < LZ_T) {
@@ -151,16 +180,30 @@ gc_zstd_lz_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, GcSeqRaw* _
             if (cur < 64u) cur = o;
         }
         sE[t] = wbase + cur;
-        if (t < LZ_WAVES) sEntry[t] = 64u;
         __syncthreads();
-        // ---- P5c: chain the wave exits from the carried cursor (one lane)
-        if (t == 0) {
-            uint32_t cursor = sCursor;                            // absolute position in block
-            uint32_t c = cursor > cbase ? cursor - cbase : 0u;    // chunk-relative entry
-            while (c < LZ_T) { sEntry[c >> 6] = c & 63u; c = sE[c]; }
-            sCursor = cbase + c;
+        LZ_PHASE(3);    // lazy + wave pointer doubling
+        // ---- P5c: chain the wave exits from the carried cursor.  Wave 0 pulls the 16 exit tables into registers
+        //      (lane l holds the exit for entry lane l of every wave) and hops with v_readlane: 16 short steps.
+        if (wave == 0) {
+            uint32_t ex[LZ_WAVES];
+#pragma unroll
+            for (uint32_t w = 0; w < LZ_WAVES; w++) ex[w] = sE[w * 64u + lane];
+            const uint32_t cursor = sCursor;                      // absolute position in block (uniform)
+            uint32_t c = gc_uniform(cursor > cbase ? cursor - cbase : 0u);   // chunk-relative entry
+            uint32_t myEntry = 64u;                               // lane w < 16 keeps wave w's entry
+#pragma unroll
+            for (uint32_t w = 0; w < LZ_WAVES; w++) {
+                if (c < (w + 1u) * 64u) {                         // path enters wave w (c >= w*64 by monotonicity)
+                    const uint32_t e = c - w * 64u;
+                    if (lane == w) myEntry = e;
+                    c = gc_readlane(ex[w], e);
+                }
+            }
+            if (lane < LZ_WAVES) sEntry[lane] = myEntry;
+            if (lane == 0) sCursor = cbase + c;
         }
         __syncthreads();
+        LZ_PHASE(4);    // exit chain
         // ---- P5d: walk the real path of this wave
         const uint32_t entry = gc_uniform(sEntry[wave]);
         const uint64_t takeMask = __ballot(take);
@@ -172,7 +215,7 @@ gc_zstd_lz_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, GcSeqRaw* _
                 uint64_t rest = takeMask >> pos;
                 if (rest == 0) break;
                 uint32_t s = pos + gc_ctz64(rest);
-                uint32_t L = (uint32_t)__shfl((int)bestLen, (int)s);
+                uint32_t L = gc_readlane(bestLen, s);
                 uint32_t e = s + L;
                 uint64_t hiMask = e >= 64u ? ~0ull : ((1ull << e) - 1ull);
                 seqMask |= 1ull << s;
@@ -185,6 +228,7 @@ gc_zstd_lz_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, GcSeqRaw* _
         // ---- P6: emit
         if (lane == 0) sCnt[wave] = ((uint32_t)__popcll(seqMask) << 16) | (uint32_t)__popcll(litMask);
         __syncthreads();
+        LZ_PHASE(5);    // path walk
         uint32_t seqBefore = 0, litBefore = 0, seqAll = 0, litAll = 0;
         for (uint32_t w = 0; w < LZ_WAVES; w++) {
             uint32_t c = sCnt[w];
@@ -200,6 +244,8 @@ gc_zstd_lz_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, GcSeqRaw* _
         }
         if ((litMask >> lane) & 1ull) myLit[myLitRank] = src[base + p];
         totalSeq += seqAll; totalLit += litAll;
+        LZ_PHASE(6);    // emit
     }
+    if (prof && t == 0) for (int i = 0; i < GC_LZ_PHASES; i++) atomicAdd(&prof[i], pc[i]);
     if (t == 0) { GcBlockMeta m; m.nSeqRaw = totalSeq; m.nLit = totalLit; meta[b] = m; }
 }

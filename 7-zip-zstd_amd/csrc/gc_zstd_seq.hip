@@ -29,6 +29,7 @@
 
 #define SEQ_T 256u
 #define SEQ_TILE_WORDS ((SEQ_T * 80u) / 32u + 8u)
+#define SEQ_CHAIN_TILE 1024u   // sequences per state-chain tile
 
 __constant__ uint8_t kLLCode[64] = { 0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,16,17,17,18,18,19,19,20,20,20,20,21,21,21,21,
                                      22,22,22,22,22,22,22,22,23,23,23,23,23,23,23,23,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24 };
@@ -54,6 +55,12 @@ struct SeqTab {              // one FSE table in LDS
     uint16_t cumul[66];
     uint8_t  desc[96];       // table description bytes for the section header
     uint32_t descSize, mode, tableLog, maxSym, finalState;
+    uint32_t tabMaxSym;      // last symbol described by norm[] (predefined: whole default table)
+    // state-chain tile scratch (see "chains" in the kernel)
+    uint8_t  tCode[SEQ_CHAIN_TILE];
+    uint16_t tOut[SEQ_CHAIN_TILE];
+    uint16_t rpos[SEQ_CHAIN_TILE + 2];
+    uint16_t sfin[SEQ_CHAIN_TILE + 2];
 };
 
 // block-wide exclusive sum scan (SEQ_T threads)
@@ -106,7 +113,7 @@ __device__ inline void seq_build_table(SeqTab& T, int which, uint32_t nbSeq)
     T.maxSym = maxSym;
     if (maxCount == nbSeq) {                                   // one code only -> RLE table (1 byte)
         uint32_t sym = maxSym;
-        T.mode = 1; T.tableLog = 0; T.descSize = 1; T.desc[0] = (uint8_t)sym;
+        T.mode = 1; T.tableLog = 0; T.descSize = 1; T.desc[0] = (uint8_t)sym; T.tabMaxSym = sym;
         T.state[0] = 0; T.tt[sym].deltaNbBits = 0; T.tt[sym].deltaFindState = 0;
         return;
     }
@@ -128,11 +135,11 @@ __device__ inline void seq_build_table(SeqTab& T, int which, uint32_t nbSeq)
     uint32_t descBytes = gc_fse_write_ncount(T.desc, T.norm, maxSym, tl);
     costFse += (uint64_t)descBytes * 8u * 256u;
     if (defOk && costDef <= costFse) {
-        T.mode = 0; T.tableLog = defLog; T.descSize = 0;
+        T.mode = 0; T.tableLog = defLog; T.descSize = 0; T.tabMaxSym = defMax;
         for (uint32_t s = 0; s <= defMax; s++) T.norm[s] = defNorm[s];
         gc_fse_build_ctable(T.norm, defMax, defLog, T.state, T.tt, T.spread, T.cumul);
     } else {
-        T.mode = 2; T.tableLog = tl; T.descSize = descBytes;
+        T.mode = 2; T.tableLog = tl; T.descSize = descBytes; T.tabMaxSym = maxSym;
         gc_fse_build_ctable(T.norm, maxSym, tl, T.state, T.tt, T.spread, T.cumul);
     }
 }
@@ -143,7 +150,8 @@ gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __res
                    uint32_t* __restrict__ seqOff,         // scratch: GC_MAX_SEQ_PER_BLOCK per block (real offsets)
                    uint8_t* __restrict__ codes,           // scratch: 3 * GC_MAX_SEQ_PER_BLOCK per block (LL, OF, ML)
                    uint16_t* __restrict__ stOut,          // scratch: 3 * GC_MAX_SEQ_PER_BLOCK per block
-                   uint8_t* __restrict__ seqSec, GcSectionInfo* __restrict__ info, uint64_t srcSize)
+                   uint8_t* __restrict__ seqSec, GcSectionInfo* __restrict__ info, uint64_t srcSize,
+                   unsigned long long* __restrict__ prof /* optional per-phase cycle sums */)
 {
     __shared__ SeqTab sTab[3];
     __shared__ uint32_t sWave[8];
@@ -168,6 +176,8 @@ gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __res
     if (nRaw == 0) { if (t == 0) { out[0] = 0; info[b].seqSecSize = 1; info[b].nSeq = 0; } return; }
 
     for (uint32_t i = t; i < 3u * 64u; i += SEQ_T) sTab[i >> 6].count[i & 63u] = 0;
+    unsigned long long tprev = prof ? gc_clock() : 0ull;
+#define SEQ_PHASE(i) do { if (prof && t == 0) { unsigned long long now_ = gc_clock(); atomicAdd(&prof[i], now_ - tprev); tprev = now_; } } while (0)
 
     // ---- S1: merge chains of capped matches.  Head = first record of a run with equal offset and litLength 0.
     //      P[j] = ll(17) | ml(18)<<17 for merged sequence j, O[j] = its offset
@@ -196,6 +206,7 @@ gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __res
         nSeq += tot;
     }
     __syncthreads();      // P/O written by this workgroup are read back by other lanes below
+    SEQ_PHASE(0);         // merge
 
     // ---- S2: repeat offsets as scans, then codes + histograms
     //      virtual history: index -1 -> offset 1, -2 -> 4 (start state {1,4,8}, zstd_internal.h:65)
@@ -232,38 +243,78 @@ gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __res
         __syncthreads();
     }
 
+    SEQ_PHASE(1);         // repcodes + codes + histograms
     // ---- tables: one lane per table
     if (wave < 3u && lane == 0u) seq_build_table(sTab[wave], (int)wave, nSeq);
     __syncthreads();
+    SEQ_PHASE(2);         // tables
 
-    // ---- chains: wave w walks table w's state backwards (last sequence first)
+    // ---- chains: wave w walks table w's FSE state backwards (last sequence first = processing index u 0).
+    //      The walk is serial through the state, except that a symbol whose normalised count is 1 (or -1) sends
+    //      EVERY state to the same successor (FSE_encodeSymbol: nbBits = tableLog, index = 1 + deltaFindState).
+    //      Such "reset" symbols cut the sequence array into segments whose start state is known up front, so the
+    //      64 lanes of the wave walk 64 segments at once; the bits emitted AT a reset step (low tableLog bits of
+    //      the previous state) are patched in afterwards from the previous segment's final state.
     if (wave < 3u) {
         SeqTab& T = sTab[wave];
         const uint8_t* C = wave == 0u ? cLL : (wave == 1u ? cOF : cML);
         uint16_t* S = wave == 0u ? stLL : (wave == 1u ? stOF : stML);
-        uint32_t state = 0; bool first = true;
-        for (int top = (int)nSeq - 1; top >= 0; top -= 64) {
-            const int j = top - (int)lane;
-            const uint32_t code = j >= 0 ? C[j] : 0u;
-            const GcFseSym sy = T.tt[code];
-            const int cnt = top + 1 < 64 ? top + 1 : 64;
-            uint32_t res = 0;
-#pragma unroll
-            for (int s = 0; s < 64; s++) {
-                if (s < cnt) {
-                    const uint32_t dnb = (uint32_t)__shfl((int)sy.deltaNbBits, s);
-                    const uint32_t dfs = (uint32_t)__shfl((int)sy.deltaFindState, s);
-                    uint32_t nb = 0, val = 0;
-                    if (first) { GcFseSym f; f.deltaNbBits = dnb; f.deltaFindState = (int32_t)dfs; state = gc_fse_init_state(T.state, f); first = false; }
-                    else { nb = (state + dnb) >> 16; val = state & ((1u << nb) - 1u); state = T.state[(state >> nb) + dfs]; }
-                    if ((int)lane == s) res = (nb << 10) | val;
+        if (T.mode == 1u) {                                   // RLE table: no state bits at all
+            for (uint32_t j = lane; j < nSeq; j += 64u) S[j] = 0;
+            if (lane == 0u) T.finalState = 0;
+        } else {
+            const uint32_t L = T.tableLog;
+            int nv = 0;
+            if (lane <= T.tabMaxSym) nv = T.norm[lane];
+            const uint64_t resetMask = __ballot(nv == 1 || nv == -1);
+            uint32_t carry = 0;
+            for (uint32_t tb = 0; tb < nSeq; tb += SEQ_CHAIN_TILE) {
+                const uint32_t tileLen = min(SEQ_CHAIN_TILE, nSeq - tb);
+                // stage codes, list reset points (tile-relative processing index, ascending)
+                uint32_t nR = 0;
+                for (uint32_t k = 0; k < SEQ_CHAIN_TILE; k += 64u) {
+                    const uint32_t u = k + lane;
+                    uint32_t code = 0; bool isR = false;
+                    if (u < tileLen) {
+                        code = C[nSeq - 1u - (tb + u)];
+                        isR = ((resetMask >> code) & 1ull) != 0ull || (tb + u == 0u);
+                    }
+                    T.tCode[u] = (uint8_t)code;
+                    const uint64_t bal = __ballot(isR);
+                    if (isR) T.rpos[nR + (uint32_t)__popcll(bal & gc_lanemask_lt())] = (uint16_t)u;
+                    nR += (uint32_t)__popcll(bal);
                 }
+                gc_wave_sync();
+                // segment i: [start_i, end_i) with start_0 = 0 (continues the carried state), start_i = rpos[i-1]
+                for (uint32_t i = lane; i <= nR; i += 64u) {
+                    const uint32_t start = i ? T.rpos[i - 1u] : 0u;
+                    const uint32_t end = i < nR ? T.rpos[i] : tileLen;
+                    uint32_t state = carry, u = start;
+                    if (i) { state = gc_fse_init_state(T.state, T.tt[T.tCode[start]]); u = start + 1u; }   // reset / first symbol
+                    for (; u < end; u++) {
+                        const GcFseSym sy = T.tt[T.tCode[u]];
+                        const uint32_t nb = (state + sy.deltaNbBits) >> 16;
+                        T.tOut[u] = (uint16_t)((nb << 10) | (state & ((1u << nb) - 1u)));
+                        state = T.state[(state >> nb) + (uint32_t)sy.deltaFindState];
+                    }
+                    T.sfin[i] = (uint16_t)state;
+                }
+                gc_wave_sync();
+                // bits emitted at the reset steps: low L bits of the previous segment's final state
+                for (uint32_t i = 1u + lane; i <= nR; i += 64u) {
+                    const uint32_t idx = T.rpos[i - 1u];
+                    T.tOut[idx] = (tb + idx == 0u) ? (uint16_t)0 : (uint16_t)((L << 10) | (T.sfin[i - 1u] & ((1u << L) - 1u)));
+                }
+                gc_wave_sync();
+                carry = T.sfin[nR];
+                for (uint32_t u = lane; u < tileLen; u += 64u) S[nSeq - 1u - (tb + u)] = T.tOut[u];
+                gc_wave_sync();
             }
-            if (j >= 0) S[j] = (uint16_t)res;
+            if (lane == 0u) T.finalState = carry;
         }
-        if (lane == 0u) T.finalState = state;
     }
     __syncthreads();
+    SEQ_PHASE(3);         // state chains
 
     // ---- section header (zstd_compress.c:2939-2953 nbSeq; modes byte; table descriptions LL, OF, ML)
     uint32_t hdrLen;
@@ -332,5 +383,6 @@ gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __res
         }
         __syncthreads();
     }
+    SEQ_PHASE(4);         // pack
     if (t == 0) { info[b].seqSecSize = overflow ? 0xFFFFFFFFu : hdrLen + outBytes; info[b].nSeq = nSeq; }
 }

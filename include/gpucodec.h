@@ -59,6 +59,12 @@ int         gc_zstd_compress_host(gc_ctx* ctx, const void* src, size_t n, void* 
  * ms[0..4] = lz, huf, seq, plan, emit; ms[5] = first launch -> last kernel end. */
 int         gc_zstd_last_timing(gc_ctx* ctx, float ms[6]);
 
+/* Optional in-kernel phase profile (shader-clock deltas measured by thread 0 of every workgroup, averaged over
+ * blocks): cycles[0..6] = K1 {probe, insert, verify, double, chain, walk, emit}, cycles[7..11] = K3 {merge,
+ * codes, tables, chains, pack}.  Off by default (no cost when off). */
+int         gc_zstd_set_phase_profile(gc_ctx* ctx, int enable);
+int         gc_zstd_phase_profile(gc_ctx* ctx, double cyclesPerBlock[12]);
+
 /* raw stream handle (hipStream_t) so callers can order their own work against the context */
 void*       gc_ctx_stream(gc_ctx* ctx);
 

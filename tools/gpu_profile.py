@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Kernel timings (HIP events) + in-kernel phase profile of the zstd path on one GPU.
+usage: python tools/gpu_profile.py [--bytes N] [--corpus KIND] [--reps R]"""
+import argparse, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import __graft_entry__ as g
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--bytes", type=int, default=100_000_000)
+ap.add_argument("--corpus", default="text-zipf")
+ap.add_argument("--reps", type=int, default=5)
+a = ap.parse_args()
+g.build_hip()
+pkg = g.load_package()
+from importlib import util as _u
+spec = _u.spec_from_file_location("c", os.path.join(ROOT, "7-zip-zstd_amd", "corpus", "__init__.py"))
+cm = _u.module_from_spec(spec); spec.loader.exec_module(cm)
+x = cm.corpus(a.corpus, a.bytes)
+enc = pkg.ZstdEncoder(device=0)
+d_src = torch.from_numpy(x).cuda(); cap = enc.compress_bound(x.size); d_dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+def run():
+    enc.code_device(d_src.data_ptr(), x.size, d_dst.data_ptr(), cap); return enc.finish()
+for _ in range(2): size = run()
+acc = {}
+for _ in range(a.reps):
+    size = run()
+    for k, v in enc.last_timing_ms().items(): acc[k] = acc.get(k, 0) + v / a.reps
+enc.set_phase_profile(True)
+run(); ph = enc.phase_profile(); tp = enc.last_timing_ms()
+enc.set_phase_profile(False)
+print(json.dumps({"corpus": a.corpus, "bytes": a.bytes, "compressed": size, "ratio": round(a.bytes / size, 4),
+                  "GBps_total": round(a.bytes / acc["total"] / 1e6, 2), "kernel_ms": {k: round(v, 4) for k, v in acc.items()},
+                  "kernel_ms_profiled": {k: round(v, 4) for k, v in tp.items()},
+                  "phase_cycles_per_block": {k: round(v) for k, v in ph.items()}}))
