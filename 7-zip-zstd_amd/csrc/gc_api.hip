@@ -2,7 +2,7 @@
 //
 // Mirrors what NCompress::NZSTD::CEncoder does around the library (CPP/7zip/Compress/ZstdEncoder.cpp:250-462):
 // own a context, feed bytes, get a zstd stream back.  All work is enqueued on one HIP stream per context:
-//   K1 lz -> (K2 huf || K3 seq, serialised on the same stream for now) -> K4 plan -> K5 emit.
+//   K1 lz -> (K2 huf || K3 seq on a second stream) -> K4 plan -> K5 emit.
 // No CPU codec path exists here: if no gfx950 device can be opened every call fails with GC_ERR_NO_DEVICE.
 #include "gpucodec.h"
 #include "gc_common.h"
@@ -28,8 +28,9 @@ extern "C" __global__ void gc_zstd_emit_kernel(const uint8_t*, uint64_t, const u
 
 struct gc_ctx {
     int device;
-    hipStream_t stream;
-    hipEvent_t ev[6];
+    hipStream_t stream;       // main stream: K1 -> K2 -> (join) -> K4 -> K5
+    hipStream_t stream2;      // K3 runs here, concurrently with K2 (both only depend on K1)
+    hipEvent_t ev[8];         // 0 lz start, 1 lz end, 2 huf end, 3 seq start, 4 seq end, 5 plan start, 6 plan end, 7 emit end
     char err[256];
     // workspace, grown on demand
     uint32_t capBlocks;
@@ -75,8 +76,8 @@ extern "C" int gc_ctx_create(gc_ctx** out, int device)
     if (!c) return GC_ERR_NOMEM;
     memset(c, 0, sizeof(*c));
     c->device = device;
-    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; return GC_ERR_HIP; }
-    for (int i = 0; i < 6; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return GC_ERR_HIP; }
+    if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess) { delete c; return GC_ERR_HIP; }
+    for (int i = 0; i < 8; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return GC_ERR_HIP; }
     if (hipMalloc((void**)&c->prof, (GC_LZ_PHASES + GC_SEQ_PHASES) * sizeof(unsigned long long)) != hipSuccess) { delete c; return GC_ERR_NOMEM; }
     if (hipMalloc((void**)&c->result, 16) != hipSuccess || hipHostMalloc((void**)&c->hostResult, 16) != hipSuccess) { delete c; return GC_ERR_NOMEM; }
     *out = c;
@@ -98,7 +99,8 @@ extern "C" void gc_ctx_destroy(gc_ctx* c)
     hipStreamSynchronize(c->stream);
     free_workspace(c);
     hipFree(c->prof); hipFree(c->result); hipHostFree(c->hostResult); hipFree(c->dIn); hipFree(c->dOut);
-    for (int i = 0; i < 6; i++) hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 8; i++) hipEventDestroy(c->ev[i]);
+    hipStreamDestroy(c->stream2);
     hipStreamDestroy(c->stream);
     delete c;
 }
@@ -155,16 +157,21 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     GC_LAUNCH(gc_zstd_lz_kernel, nBlocks, 1024, c->stream, src, (uint64_t)n, c->seqRaw, c->lit, c->meta, c->profOn ? c->prof : nullptr);
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    // K2 (literals) and K3 (sequences) are independent consumers of K1: run them on two streams
+    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev[1], 0));
+    HIPCHK(c, hipEventRecord(c->ev[3], c->stream2));
+    GC_LAUNCH(gc_zstd_seq_kernel, nBlocks, 256, c->stream2, (const GcSeqRaw*)c->seqRaw, (const GcBlockMeta*)c->meta, c->seqPacked,
+              c->seqOff, c->codes, c->stOut, c->seqSec, c->info, (uint64_t)n, c->profOn ? c->prof + GC_LZ_PHASES : nullptr);
+    HIPCHK(c, hipEventRecord(c->ev[4], c->stream2));
     GC_LAUNCH(gc_zstd_huf_kernel, nBlocks, 256, c->stream, (const uint8_t*)c->lit, (const GcBlockMeta*)c->meta, c->litSec, c->info);
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-    GC_LAUNCH(gc_zstd_seq_kernel, nBlocks, 256, c->stream, (const GcSeqRaw*)c->seqRaw, (const GcBlockMeta*)c->meta, c->seqPacked,
-              c->seqOff, c->codes, c->stOut, c->seqSec, c->info, (uint64_t)n, c->profOn ? c->prof + GC_LZ_PHASES : nullptr);
-    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev[4], 0));
+    HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     GC_LAUNCH(gc_zstd_plan_kernel, 1, 1024, c->stream, (const GcSectionInfo*)c->info, nBlocks, (uint64_t)n, (uint64_t)dstCap, c->plan, c->result);
-    HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     GC_LAUNCH(gc_zstd_emit_kernel, nBlocks, 256, c->stream, src, (uint64_t)n, (const uint8_t*)c->litSec, (const uint8_t*)c->seqSec,
               (const GcSectionInfo*)c->info, (const GcFramePlan*)c->plan, (const uint64_t*)c->result, (uint8_t*)d_dst);
-    HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
     HIPCHK(c, hipGetLastError());
     c->pending = true; c->timed = true;
     return GC_OK;
@@ -185,8 +192,12 @@ extern "C" int gc_zstd_finish(gc_ctx* c, size_t* compressedSize)
 extern "C" int gc_zstd_last_timing(gc_ctx* c, float ms[6])
 {
     if (!c || !c->timed || c->pending) return GC_ERR_PARAM;
-    for (int i = 0; i < 5; i++) HIPCHK(c, hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));
-    HIPCHK(c, hipEventElapsedTime(&ms[5], c->ev[0], c->ev[5]));
+    HIPCHK(c, hipEventElapsedTime(&ms[0], c->ev[0], c->ev[1]));     // lz
+    HIPCHK(c, hipEventElapsedTime(&ms[1], c->ev[1], c->ev[2]));     // huf (runs concurrently with seq)
+    HIPCHK(c, hipEventElapsedTime(&ms[2], c->ev[3], c->ev[4]));     // seq
+    HIPCHK(c, hipEventElapsedTime(&ms[3], c->ev[5], c->ev[6]));     // plan
+    HIPCHK(c, hipEventElapsedTime(&ms[4], c->ev[6], c->ev[7]));     // emit
+    HIPCHK(c, hipEventElapsedTime(&ms[5], c->ev[0], c->ev[7]));     // first kernel start -> last kernel end
     return GC_OK;
 }
 

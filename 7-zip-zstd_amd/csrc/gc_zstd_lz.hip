@@ -19,7 +19,7 @@
 //       up to GC_MATCH_CAP; longer matches appear as chains of capped matches with equal offset, merged in K3
 //   P5  parse: next(t) = t+len if a match is taken at t, else t+1.  Each wave resolves its 64-position
 //       segment for EVERY possible entry lane by pointer doubling through ds_bpermute (6 rounds), one lane
-//       chains the 16 wave exits, then each wave walks its real path with scalar bit tricks.
+//       chains the 16 wave exits, then each wave marks its real path by binary lifting over the same jump tables.
 //   P6  emit: wave ballots + popcounts place literals and sequences; no atomics, order = position order.
 //
 // LDS: 64 KiB long table + 64 KiB short table + 8 KiB chunk table + 8 KiB parse scratch (1 workgroup / CU).
@@ -36,14 +36,13 @@
 __device__ __forceinline__ uint32_t lz_hash_long(uint32_t lo, uint32_t hi)  { return lo * 0x9E3779B1u + hi * 0x85EBCA77u; }
 __device__ __forceinline__ uint32_t lz_hash_short(uint32_t lo, uint32_t hi) { return lo * 0x9E3779B1u + (hi & 0xFFu) * 0xC2B2AE3Du; }
 
-// 16 bytes at src[pos..] as two little-endian words, zero-filled past `limit`
+// 16 bytes at src[pos..] as two little-endian words.  Callers only load windows that lie inside the input:
+// a position takes part in matching only if GC_MATCH_CAP + 16 bytes are readable behind it (the last ~80 bytes
+// of the whole input are therefore always literals), and every candidate lies before its position.
 struct LzW16 { uint64_t a, b; };
-__device__ __forceinline__ LzW16 lz_ld16(const uint8_t* src, uint64_t pos, uint64_t limit)
+__device__ __forceinline__ LzW16 lz_ld16(const uint8_t* src, uint64_t pos)
 {
-    LzW16 w;
-    if (pos + 16 <= limit) { __builtin_memcpy(&w, src + pos, 16); }
-    else { w.a = gc_ld64_guard(src, pos, limit); w.b = gc_ld64_guard(src, pos + 8, limit); }
-    return w;
+    LzW16 w; __builtin_memcpy(&w, src + pos, 16); return w;
 }
 // common prefix length (0..16) of two 16-byte windows
 __device__ __forceinline__ uint32_t lz_cmp16(LzW16 x, LzW16 y)
@@ -70,6 +69,7 @@ gc_zstd_lz_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, GcSeqRaw* _
     __shared__ uint32_t sEntry[LZ_WAVES];  // real entry lane of each wave (64 = wave not entered)
     __shared__ uint32_t sCnt[LZ_WAVES];    // per wave: nSeq<<16 | nLit
     __shared__ uint32_t sCursor;
+    __shared__ uint8_t  sMark[LZ_T];       // path marks (P5d)
 
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint32_t b = blockIdx.x;
@@ -89,13 +89,15 @@ gc_zstd_lz_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, GcSeqRaw* _
 #define LZ_PHASE(i) do { if (prof && t == 0) { unsigned long long now_ = gc_clock(); pc[i] += now_ - tprev; tprev = now_; } } while (0)
     uint32_t totalSeq = 0, totalLit = 0;   // uniform running totals
     const uint32_t nChunks = (n + LZ_T - 1) / LZ_T;
-    LzW16 own = lz_ld16(src, base + t, srcSize);        // own 16 bytes, always loaded one chunk ahead
+    LzW16 own; own.a = 0; own.b = 0;                    // own 16 bytes, always loaded one chunk ahead
+    if (base + t + GC_MATCH_CAP + 16u <= srcSize) own = lz_ld16(src, base + t);
 
     for (uint32_t k = 0; k < nChunks; k++) {
         const uint32_t cbase = k * LZ_T;
         const uint32_t p = cbase + t;
         const bool inBlock = p < n;
-        const bool canHash = p + 8u <= n;          // positions closer than 8 bytes to the block end stay literals
+        // positions closer than 8 bytes to the block end, or without a readable compare window, stay literals
+        const bool canHash = p + 8u <= n && base + p + GC_MATCH_CAP + 16u <= srcSize;
 
         // ---- P0/P1: load, hash, probe
         uint32_t lo = 0, hi = 0, hL = 0, hS = 0, eL = 0, eS = 0;
@@ -138,7 +140,7 @@ gc_zstd_lz_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, GcSeqRaw* _
             }
             // level 1: all candidate windows are requested together (one exposed memory latency), 16 bytes each
             LzW16 cw[3];
-            for (int i = 0; i < 3; i++) if (i < nc) cw[i] = lz_ld16(src, base + cand[i], srcSize);
+            for (int i = 0; i < 3; i++) if (i < nc) cw[i] = lz_ld16(src, base + cand[i]);
             uint32_t bestC = 0;
             for (int i = 0; i < 3; i++) {
                 if (i < nc) {
@@ -152,8 +154,8 @@ gc_zstd_lz_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, GcSeqRaw* _
             }
             // level 2: only a saturated best candidate is extended, 16 bytes per round, up to GC_MATCH_CAP
             while (bestLen >= 16u && (bestLen & 15u) == 0u && bestLen < maxLen) {
-                LzW16 x = lz_ld16(src, base + p + bestLen, srcSize);
-                LzW16 y = lz_ld16(src, base + bestC + bestLen, srcSize);
+                LzW16 x = lz_ld16(src, base + p + bestLen);
+                LzW16 y = lz_ld16(src, base + bestC + bestLen);
                 uint32_t more = lz_cmp16(x, y);
                 bestLen += more;
                 if (bestLen > maxLen) bestLen = maxLen;
@@ -161,7 +163,7 @@ gc_zstd_lz_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, GcSeqRaw* _
             }
         }
         // prefetch the next chunk's own bytes; the latency hides under the parse below
-        own = lz_ld16(src, base + p + LZ_T, srcSize);
+        if (base + p + LZ_T + GC_MATCH_CAP + 16u <= srcSize) own = lz_ld16(src, base + p + LZ_T);
         sM[t] = (bestOff << 8) | bestLen;
         __syncthreads();
         LZ_PHASE(2);    // verify
@@ -175,10 +177,14 @@ gc_zstd_lz_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, GcSeqRaw* _
         const uint32_t wbase = wave * 64u;
         uint32_t cur = (take ? lane + bestLen : lane + 1u);      // wave-relative; >= 64 means "left the wave"
         // ---- P5b: pointer doubling inside the wave: exit reached from every lane
+        uint32_t jump[6];                                          // jump[r] = position after 2^r hops
+#pragma unroll
         for (int r = 0; r < 6; r++) {
+            jump[r] = cur;
             uint32_t o = __shfl(cur, (int)(cur & 63u));
             if (cur < 64u) cur = o;
         }
+        sMark[t] = 0;
         sE[t] = wbase + cur;
         __syncthreads();
         LZ_PHASE(3);    // lazy + wave pointer doubling
@@ -204,27 +210,18 @@ gc_zstd_lz_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, GcSeqRaw* _
         }
         __syncthreads();
         LZ_PHASE(4);    // exit chain
-        // ---- P5d: walk the real path of this wave
+        // ---- P5d: mark the real path of this wave by binary lifting over the saved jump tables:
+        //      after round r every node within 2^(r+1)-1 hops of the entry lane is marked (LDS byte scatter, wave-local)
         const uint32_t entry = gc_uniform(sEntry[wave]);
-        const uint64_t takeMask = __ballot(take);
-        const uint64_t validMask = __ballot(inBlock);
-        uint64_t seqMask = 0, coverMask = 0;
-        if (entry < 64u) {
-            uint32_t pos = entry;
-            while (pos < 64u) {
-                uint64_t rest = takeMask >> pos;
-                if (rest == 0) break;
-                uint32_t s = pos + gc_ctz64(rest);
-                uint32_t L = gc_readlane(bestLen, s);
-                uint32_t e = s + L;
-                uint64_t hiMask = e >= 64u ? ~0ull : ((1ull << e) - 1ull);
-                seqMask |= 1ull << s;
-                coverMask |= hiMask & ~((1ull << s) - 1ull);
-                pos = e;
-            }
+        bool marked = lane == entry;
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            if (marked && jump[r] < 64u) sMark[wbase + jump[r]] = 1;
+            gc_wave_sync();
+            marked = marked || sMark[t] != 0;
         }
-        const uint64_t fromEntry = entry < 64u ? ~((1ull << entry) - 1ull) : 0ull;
-        const uint64_t litMask = fromEntry & ~coverMask & validMask;
+        const uint64_t seqMask = __ballot(marked && take);          // path nodes that start a match
+        const uint64_t litMask = __ballot(marked && !take && inBlock);   // all other path nodes are literals
         // ---- P6: emit
         if (lane == 0) sCnt[wave] = ((uint32_t)__popcll(seqMask) << 16) | (uint32_t)__popcll(litMask);
         __syncthreads();

@@ -56,7 +56,7 @@ int         gc_zstd_compress_host(gc_ctx* ctx, const void* src, size_t n, void* 
                                   size_t* compressedSize);
 
 /* HIP-event timing of the kernels of the last gc_zstd_compress_device call (after gc_zstd_finish):
- * ms[0..4] = lz, huf, seq, plan, emit; ms[5] = first launch -> last kernel end. */
+ * ms[0..4] = lz, huf, seq, plan, emit (huf and seq overlap on two streams); ms[5] = first kernel start -> last kernel end. */
 int         gc_zstd_last_timing(gc_ctx* ctx, float ms[6]);
 
 /* Optional in-kernel phase profile (shader-clock deltas measured by thread 0 of every workgroup, averaged over
