@@ -1,0 +1,215 @@
+// gc_7z_plugin.cpp -- lib7zgpucodec.so: the 7-Zip codec-plugin surface over libgpucodec's C ABI.
+//
+// What a 7-Zip host (`7z` built with Z7_EXTERNAL_CODECS; CPP/7zip/UI/Common/LoadCodecs.cpp:531-650) does with a module
+// found in its Codecs/ directory, and what therefore has to exist here:
+//   dlsym GetModuleProp        -> kInterfaceType must be 0 (IUnknown without virtual destructor)   CodecExports.cpp:360-378
+//   dlsym GetNumberOfMethods / GetMethodProperty -> id, name, encoder/decoder class ids            CodecExports.cpp:198-265
+//   dlsym CreateEncoder / CreateDecoder / CreateObject -> COM-style coder object                   CodecExports.cpp:127-195
+// The coder object mirrors NCompress::NZSTD::CEncoder (CPP/7zip/Compress/ZstdEncoder.h:35-78): ICompressCoder,
+// ICompressSetCoderMt, ICompressSetCoderProperties, ICompressSetCoderPropertiesOpt, ICompressWriteCoderProperties.
+// Only ENCODERS are provided (the hot path of SURVEY.md section 8); decoding stays with the host's own decoders, which is
+// how 7-Zip resolves a method id that several modules register (decoder lookup by id, CreateCoder.cpp:206-232).
+//
+// No C++ exception crosses the boundary (the reference wraps with COM_TRY, CodecExports.cpp:97-124): nothing below
+// throws; allocations are checked.
+#include "gc_7z_abi.h"
+#include "gpucodec.h"
+#include <new>
+
+#define GC_EXPORT extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+struct MethodInfo { uint64_t id; const char* name; int kind; };
+enum { KIND_ZSTD = 0 };
+// Names and ids as registered by the reference (CPP/7zip/Compress/ZstdRegister.cpp:13-17).
+const MethodInfo kMethods[] = {
+    { 0x4F71101, "ZSTD", KIND_ZSTD },
+};
+const uint32_t kNumMethods = sizeof(kMethods) / sizeof(kMethods[0]);
+
+HRESULT write_all(ISequentialOutStream* out, const void* data, size_t size)     // StreamUtils.cpp:54-100
+{
+    const uint8_t* p = (const uint8_t*)data;
+    while (size) {
+        uint32_t cur = size > 0x80000000u ? 0x80000000u : (uint32_t)size, done = 0;
+        HRESULT r = out->Write(p, cur, &done);
+        p += done; size -= done;
+        if (r != S_OK) return r;
+        if (done == 0) return E_FAIL;
+    }
+    return S_OK;
+}
+
+HRESULT read_full(ISequentialInStream* in, void* data, size_t* size)            // ReadStream, StreamUtils.cpp:20-40
+{
+    uint8_t* p = (uint8_t*)data; size_t want = *size; *size = 0;
+    while (want) {
+        uint32_t cur = want > 0x80000000u ? 0x80000000u : (uint32_t)want, done = 0;
+        HRESULT r = in->Read(p, cur, &done);
+        p += done; want -= done; *size += done;
+        if (r != S_OK) return r;
+        if (done == 0) return S_OK;
+    }
+    return S_OK;
+}
+
+HRESULT hresult_of(int gcErr)
+{
+    switch (gcErr) {
+        case GC_OK: return S_OK;
+        case GC_ERR_NOMEM: return E_OUTOFMEMORY;
+        case GC_ERR_PARAM: return E_INVALIDARG;
+        default: return E_FAIL;           // no device / HIP failure: there is no CPU codec to fall back to
+    }
+}
+
+class CGpuZstdEncoder final : public ICompressCoder, public ICompressSetCoderMt, public ICompressSetCoderProperties,
+                              public ICompressSetCoderPropertiesOpt, public ICompressWriteCoderProperties {
+    ULONG refs_ = 1;
+    gc_ctx* ctx_ = nullptr;
+    uint8_t* inBuf_ = nullptr; uint8_t* outBuf_ = nullptr; size_t inCap_ = 0, outCap_ = 0;
+    int level_ = 3;                                   // ZSTD_CLEVEL_DEFAULT
+    uint8_t props_[5] = { 1, 5, 3, 0, 0 };            // CProps{major, minor, level, reserved[2]}  ZstdEncoder.h:17-32
+    uint64_t expected_ = 0;
+    // input is cut at multiples of the 128 KiB frame grain, so the stream equals a single whole-buffer call
+    static const size_t kChunk = 64u << 20;
+
+public:
+    ~CGpuZstdEncoder() { if (ctx_) gc_ctx_destroy(ctx_); free(inBuf_); free(outBuf_); }
+
+    HRESULT QueryInterface(const GUID& iid, void** out) override
+    {
+        if (!out) return E_INVALIDARG;
+        *out = nullptr;
+        if (iid == IID_IUnknown || iid == IID_ICompressCoder) *out = static_cast<ICompressCoder*>(this);
+        else if (iid == IID_ICompressSetCoderMt) *out = static_cast<ICompressSetCoderMt*>(this);
+        else if (iid == IID_ICompressSetCoderProperties) *out = static_cast<ICompressSetCoderProperties*>(this);
+        else if (iid == IID_ICompressSetCoderPropertiesOpt) *out = static_cast<ICompressSetCoderPropertiesOpt*>(this);
+        else if (iid == IID_ICompressWriteCoderProperties) *out = static_cast<ICompressWriteCoderProperties*>(this);
+        else return E_NOINTERFACE;
+        ++refs_;
+        return S_OK;
+    }
+    ULONG AddRef() override { return ++refs_; }
+    ULONG Release() override { if (--refs_ != 0) return refs_; delete this; return 0; }      // non-atomic like MyCom.h:380-390
+
+    HRESULT SetNumberOfThreads(uint32_t) override { return S_OK; }    // the GPU path has no host worker threads to size
+
+    HRESULT SetCoderProperties(const PROPID* ids, const PROPVARIANT* props, uint32_t n) override
+    {
+        // same clamping as the reference for the properties that have a meaning here (ZstdEncoder.cpp:51-230);
+        // the remaining zstd tuning properties are accepted and ignored, exactly as the reference's default branch does
+        level_ = 3; props_[2] = 3;
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t v = props[i].ulVal;
+            if (ids[i] == NCoderPropID::kLevel) {
+                int lv = (int)v;
+                if (v < 1) lv = 1;
+                if (v > 22) lv = 22;                   // ZSTD_maxCLevel()
+                level_ = lv; props_[2] = (uint8_t)lv;
+            }
+        }
+        return S_OK;
+    }
+    HRESULT SetCoderPropertiesOpt(const PROPID* ids, const PROPVARIANT* props, uint32_t n) override
+    {
+        for (uint32_t i = 0; i < n; i++)
+            if (ids[i] == NCoderPropID::kExpectedDataSize && props[i].vt == VT_UI8 && props[i].uhVal) expected_ = props[i].uhVal;
+        return S_OK;
+    }
+    HRESULT WriteCoderProperties(ISequentialOutStream* out) override { return write_all(out, props_, sizeof(props_)); }
+
+    HRESULT Code(ISequentialInStream* in, ISequentialOutStream* out, const uint64_t*, const uint64_t*, ICompressProgressInfo* progress) override
+    {
+        if (!in || !out) return E_INVALIDARG;
+        if (!ctx_) { int rc = gc_ctx_create(&ctx_, 0); if (rc != GC_OK) { ctx_ = nullptr; return hresult_of(rc); } }
+        size_t chunk = kChunk;
+        if (expected_ && expected_ < chunk) chunk = (size_t)((expected_ + 131071u) & ~(uint64_t)131071u);
+        if (chunk > inCap_) { free(inBuf_); inBuf_ = (uint8_t*)malloc(chunk); inCap_ = inBuf_ ? chunk : 0; if (!inBuf_) return E_OUTOFMEMORY; }
+        const size_t bound = gc_zstd_compress_bound(inCap_);
+        if (bound > outCap_) { free(outBuf_); outBuf_ = (uint8_t*)malloc(bound); outCap_ = outBuf_ ? bound : 0; if (!outBuf_) return E_OUTOFMEMORY; }
+        uint64_t totalIn = 0, totalOut = 0;
+        for (;;) {
+            size_t got = inCap_;
+            HRESULT r = read_full(in, inBuf_, &got);
+            if (r != S_OK) return r;
+            if (got == 0 && totalIn != 0) break;
+            size_t produced = 0;
+            int rc = gc_zstd_compress_host(ctx_, inBuf_, got, outBuf_, outCap_, level_, &produced);
+            if (rc != GC_OK) return hresult_of(rc);
+            r = write_all(out, outBuf_, produced);
+            if (r != S_OK) return r;
+            totalIn += got; totalOut += produced;
+            if (progress) { r = progress->SetRatioInfo(&totalIn, &totalOut); if (r != S_OK) return r; }
+            if (got < inCap_) break;      // short read = end of stream
+        }
+        return S_OK;
+    }
+};
+
+HRESULT create_encoder(uint32_t index, const GUID* iid, void** out)
+{
+    if (!out) return E_INVALIDARG;
+    *out = nullptr;
+    if (index >= kNumMethods) return CLASS_E_CLASSNOTAVAILABLE;
+    if (!iid || !(*iid == IID_ICompressCoder)) return E_NOINTERFACE;     // 1-stream, non-filter codecs only (CodecExports.cpp:127-150)
+    IUnknown* obj = nullptr;
+    switch (kMethods[index].kind) {
+        case KIND_ZSTD: { CGpuZstdEncoder* e = new (std::nothrow) CGpuZstdEncoder(); obj = e ? static_cast<ICompressCoder*>(e) : nullptr; break; }
+    }
+    if (!obj) return E_OUTOFMEMORY;
+    *out = obj;          // pointer to the ICompressCoder sub-object, reference count 1 (RegisterCodec.h:25-26)
+    return S_OK;
+}
+
+}  // namespace
+
+GC_EXPORT HRESULT GetNumberOfMethods(uint32_t* n) { if (!n) return E_INVALIDARG; *n = kNumMethods; return S_OK; }
+
+GC_EXPORT HRESULT GetMethodProperty(uint32_t index, PROPID propID, PROPVARIANT* value)
+{
+    if (!value) return E_INVALIDARG;
+    gc_variant_clear(value);
+    if (index >= kNumMethods) return E_INVALIDARG;
+    const MethodInfo& m = kMethods[index];
+    switch (propID) {
+        case NMethodPropID::kID: value->vt = VT_UI8; value->uhVal = m.id; break;
+        case NMethodPropID::kName: value->bstrVal = gc_bstr_ascii(m.name); if (!value->bstrVal) return E_OUTOFMEMORY; value->vt = VT_BSTR; break;
+        case NMethodPropID::kEncoder: {
+            GUID g = gc_codec_clsid(m.id, true);
+            value->bstrVal = gc_bstr_bytes(&g, sizeof(g)); if (!value->bstrVal) return E_OUTOFMEMORY; value->vt = VT_BSTR; break;
+        }
+        case NMethodPropID::kEncoderIsAssigned: value->vt = VT_BOOL; value->boolVal = -1; break;   // VARIANT_TRUE
+        case NMethodPropID::kDecoderIsAssigned: value->vt = VT_BOOL; value->boolVal = 0; break;
+        case NMethodPropID::kIsFilter: value->vt = VT_BOOL; value->boolVal = 0; break;
+        default: break;      // kDecoder, kPackStreams, ...: left VT_EMPTY
+    }
+    return S_OK;
+}
+
+GC_EXPORT HRESULT CreateEncoder(uint32_t index, const GUID* iid, void** out) { return create_encoder(index, iid, out); }
+
+GC_EXPORT HRESULT CreateDecoder(uint32_t, const GUID*, void** out) { if (out) *out = nullptr; return CLASS_E_CLASSNOTAVAILABLE; }
+
+GC_EXPORT HRESULT CreateObject(const GUID* clsid, const GUID* iid, void** out)
+{
+    if (!out) return E_INVALIDARG;
+    *out = nullptr;
+    if (!clsid) return E_INVALIDARG;
+    for (uint32_t i = 0; i < kNumMethods; i++)
+        if (*clsid == gc_codec_clsid(kMethods[i].id, true)) return create_encoder(i, iid, out);
+    return CLASS_E_CLASSNOTAVAILABLE;
+}
+
+GC_EXPORT HRESULT GetModuleProp(PROPID propID, PROPVARIANT* value)
+{
+    if (!value) return E_INVALIDARG;
+    gc_variant_clear(value);
+    switch (propID) {
+        case NModulePropID::kInterfaceType: value->vt = VT_UI4; value->ulVal = 0; break;            // no virtual destructor in IUnknown
+        case NModulePropID::kVersion: value->vt = VT_UI4; value->ulVal = (26u << 16) + 1u; break;   // host ABI generation (CodecExports.cpp:372)
+        default: break;
+    }
+    return S_OK;
+}

@@ -1,0 +1,65 @@
+"""The 7-Zip plugin surface, driven the way the 7-Zip host drives a codec module (tests/host/plugin_host.cpp).
+CPU: the plugin layer linked against the emulator build of the kernels.  GPU (-m gpu): the product module
+7-zip-zstd_amd/plugin/lib7zgpucodec.so over libgpucodec.so."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "emu", "_build")
+BLK = 128 * 1024
+
+
+def _host(module, *args):
+    return subprocess.run([os.path.join(EMU, "plugin_host"), module] + [str(a) for a in args], capture_output=True, text=True)
+
+
+@pytest.fixture(scope="module")
+def emu_module(emu_lib_path):
+    return os.path.join(EMU, "lib7zgpucodec_emu.so")
+
+
+def test_exports_and_method_listing(emu_module):
+    r = _host(emu_module, "list")
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.strip().splitlines()
+    assert lines[0].split()[1:3] == ["4F71101", "ZSTD"]            # id and name of ZstdRegister.cpp:13-17
+    assert "enc=1 dec=0" in lines[0] and "clsid=23170F69-40C1-2791" in lines[0]
+    import ctypes
+    lib = ctypes.CDLL(emu_module)
+    for sym in ["GetNumberOfMethods", "GetMethodProperty", "CreateEncoder", "CreateDecoder", "CreateObject", "GetModuleProp"]:
+        assert hasattr(lib, sym)
+
+
+@pytest.mark.parametrize("n,how", [(0, "index"), (1, "index"), (2 * BLK + 777, "index"), (BLK, "by-clsid")])
+def test_code_through_com_surface(O, emu_module, emu_enc, tmp_path, n, how):
+    x = O.corpus("text-zipf", n)
+    src, dst, props = tmp_path / "in.bin", tmp_path / "out.zst", tmp_path / "props.bin"
+    x.tofile(src)
+    args = ["encode", "ZSTD", 3, src, dst, props] + (["by-clsid"] if how == "by-clsid" else [])
+    r = _host(emu_module, *args)
+    assert r.returncode == 0, r.stderr + r.stdout
+    c = np.fromfile(dst, dtype=np.uint8)
+    assert np.array_equal(c, emu_enc.code(x))                      # same bytes as the C ABI called directly
+    assert np.array_equal(O.port_zstd_decompress(c, n), x)
+    if O.ref("zstd") is not None:
+        assert np.array_equal(O.ref_zstd_decompress(c, n), x)
+    assert props.read_bytes() == bytes([1, 5, 3, 0, 0])           # CProps of ZstdEncoder.h:17-32; decoder accepts 1/3/5 bytes
+
+
+@pytest.mark.gpu
+def test_product_plugin_on_gpu(O, graft, tmp_path):
+    graft.build_hip()
+    module = graft.build_plugin()
+    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "emu"), "_build/plugin_host"], check=True, capture_output=True)
+    n = 20 * 1024 * 1024 + 4321
+    x = O.corpus("silesia-like", n)
+    src, dst = tmp_path / "in.bin", tmp_path / "out.zst"
+    x.tofile(src)
+    r = _host(module, "encode", "ZSTD", 3, src, dst, "-")
+    assert r.returncode == 0, r.stderr + r.stdout
+    c = np.fromfile(dst, dtype=np.uint8)
+    dec = O.ref_zstd_decompress(c, n) if O.ref("zstd") is not None else O.port_zstd_decompress(c, n)
+    assert np.array_equal(dec, x)
