@@ -23,7 +23,9 @@ _ERR = {-1: "GC_ERR_NO_DEVICE", -2: "GC_ERR_HIP", -3: "GC_ERR_NOMEM", -4: "GC_ER
 
 EXPORTS = ["gc_device_count", "gc_ctx_create", "gc_ctx_destroy", "gc_last_error_message", "gc_zstd_compress_bound",
            "gc_zstd_compress_device", "gc_zstd_finish", "gc_zstd_compress_host", "gc_zstd_last_timing", "gc_ctx_stream",
-           "gc_zstd_set_phase_profile", "gc_zstd_phase_profile"]
+           "gc_zstd_set_phase_profile", "gc_zstd_phase_profile",
+           "gc_flzma2_compress_bound", "gc_flzma2_dict_prop", "gc_flzma2_compress_device", "gc_flzma2_finish", "gc_flzma2_compress_host",
+           "gc_flzma2_last_timing"]
 
 
 class GpuCodecError(RuntimeError):
@@ -57,16 +59,24 @@ def load_library(path=None):
     lib.gc_zstd_set_phase_profile.restype = C.c_int
     lib.gc_zstd_phase_profile.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     lib.gc_zstd_phase_profile.restype = C.c_int
+    lib.gc_flzma2_compress_bound.argtypes = [C.c_size_t]
+    lib.gc_flzma2_compress_bound.restype = C.c_size_t
+    lib.gc_flzma2_dict_prop.argtypes = [C.c_int]
+    lib.gc_flzma2_dict_prop.restype = C.c_ubyte
+    lib.gc_flzma2_compress_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_uint]
+    lib.gc_flzma2_compress_device.restype = C.c_int
+    lib.gc_flzma2_finish.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    lib.gc_flzma2_finish.restype = C.c_int
+    lib.gc_flzma2_compress_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_uint, C.POINTER(C.c_size_t)]
+    lib.gc_flzma2_compress_host.restype = C.c_int
+    lib.gc_flzma2_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    lib.gc_flzma2_last_timing.restype = C.c_int
     lib.gc_ctx_stream.argtypes = [C.c_void_p]
     lib.gc_ctx_stream.restype = C.c_void_p
     return lib
 
 
-class ZstdEncoder:
-    """Mirror of NCompress::NZSTD::CEncoder for the compression hot path (one object per GPU)."""
-
-    KERNELS = ("lz", "huf", "seq", "plan", "emit", "total")
-
+class _EncoderBase:
     def __init__(self, device=0, level=3, lib_path=None):
         self._lib = load_library(lib_path)
         self._ctx = C.c_void_p()
@@ -90,6 +100,55 @@ class ZstdEncoder:
 
     def set_level(self, level):          # SetCoderProperties(kLevel)
         self.level = int(level)
+
+    def stream(self):
+        return self._lib.gc_ctx_stream(self._ctx)
+
+
+class Flzma2Encoder(_EncoderBase):
+    """Mirror of NCompress::NLzma2::CFastEncoder (CPP/7zip/Compress/Lzma2Encoder.h:60-100; Code() at Lzma2Encoder.cpp:260-350):
+    bytes -> LZMA2 chunk stream; `coder_props()` is what WriteCoderProperties emits (1 byte dictionary size, :353-364)."""
+
+    KERNELS = ("lz", "prep", "enc", "plan", "emit", "total")
+    NO_END_MARK = 1
+
+    def __init__(self, device=0, level=5, lib_path=None):
+        super().__init__(device, level, lib_path)
+
+    def compress_bound(self, n):
+        return self._lib.gc_flzma2_compress_bound(n)
+
+    def coder_props(self):
+        return bytes([self._lib.gc_flzma2_dict_prop(self.level)])
+
+    def code(self, data, flags=0):
+        import numpy as np
+        a = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data, dtype=np.uint8)
+        cap = self.compress_bound(a.size)
+        out = np.empty(cap, dtype=np.uint8)
+        n = C.c_size_t(0)
+        rc = self._lib.gc_flzma2_compress_host(self._ctx, a.ctypes.data, a.size, out.ctypes.data, cap, self.level, flags, C.byref(n))
+        self._check(rc, "gc_flzma2_compress_host")
+        return out[:n.value]
+
+    def code_device(self, d_src_ptr, n, d_dst_ptr, dst_cap, flags=0):
+        self._check(self._lib.gc_flzma2_compress_device(self._ctx, d_src_ptr, n, d_dst_ptr, dst_cap, self.level, flags), "gc_flzma2_compress_device")
+
+    def finish(self):
+        n = C.c_size_t(0)
+        self._check(self._lib.gc_flzma2_finish(self._ctx, C.byref(n)), "gc_flzma2_finish")
+        return n.value
+
+    def last_timing_ms(self):
+        ms = (C.c_float * 6)()
+        self._check(self._lib.gc_flzma2_last_timing(self._ctx, ms), "gc_flzma2_last_timing")
+        return dict(zip(self.KERNELS, [float(x) for x in ms]))
+
+
+class ZstdEncoder(_EncoderBase):
+    """Mirror of NCompress::NZSTD::CEncoder for the compression hot path (one object per GPU)."""
+
+    KERNELS = ("lz", "huf", "seq", "plan", "emit", "total")
 
     def compress_bound(self, n):
         return self._lib.gc_zstd_compress_bound(n)
@@ -131,6 +190,3 @@ class ZstdEncoder:
         v = (C.c_double * 12)()
         self._check(self._lib.gc_zstd_phase_profile(self._ctx, v), "gc_zstd_phase_profile")
         return dict(zip(self.PHASES, [float(x) for x in v]))
-
-    def stream(self):
-        return self._lib.gc_ctx_stream(self._ctx)

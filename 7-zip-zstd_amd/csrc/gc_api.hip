@@ -6,6 +6,7 @@
 // No CPU codec path exists here: if no gfx950 device can be opened every call fails with GC_ERR_NO_DEVICE.
 #include "gpucodec.h"
 #include "gc_common.h"
+#include "gc_lzma2.h"
 #ifdef HIPEMU
 #include "hip_runtime_stub.h"
 #else
@@ -26,6 +27,12 @@ extern "C" __global__ void gc_zstd_plan_kernel(const GcSectionInfo*, uint32_t, u
 extern "C" __global__ void gc_zstd_emit_kernel(const uint8_t*, uint64_t, const uint8_t*, const uint8_t*, const GcSectionInfo*,
                                                const GcFramePlan*, const uint64_t*, uint8_t*);
 
+extern "C" __global__ void gc_lzma2_prep_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t*, uint32_t*);
+extern "C" __global__ void gc_lzma2_enc_kernel(const uint8_t*, uint64_t, const uint64_t*, const uint32_t*, uint32_t, uint8_t*, GcLzmaChunkInfo*);
+extern "C" __global__ void gc_lzma2_plan_kernel(const GcLzmaChunkInfo*, uint32_t, uint64_t, uint32_t, GcLzmaPlan*, uint64_t*);
+extern "C" __global__ void gc_lzma2_emit_kernel(const uint8_t*, uint32_t, const uint8_t*, const GcLzmaChunkInfo*, const GcLzmaPlan*, uint32_t,
+                                                uint32_t, const uint64_t*, uint8_t*);
+
 struct gc_ctx {
     int device;
     hipStream_t stream;       // main stream: K1 -> K2 -> (join) -> K4 -> K5
@@ -37,6 +44,8 @@ struct gc_ctx {
     GcSeqRaw* seqRaw; uint8_t* lit; GcBlockMeta* meta;
     uint64_t* seqPacked; uint32_t* seqOff; uint8_t* codes; uint16_t* stOut;
     uint8_t* litSec; uint8_t* seqSec; GcSectionInfo* info; GcFramePlan* plan; uint64_t* result;
+    uint32_t* lzNM; GcLzmaChunkInfo* lzInfo; GcLzmaPlan* lzPlan;       // FLZMA2 path (M aliases seqPacked, chunk staging aliases litSec)
+    int lastCodec;            // 0 zstd, 1 flzma2: which kernels the events of the last call bracket
     uint64_t* hostResult;     // pinned
     // staging for the host-buffer entry point
     uint8_t* dIn; size_t dInCap; uint8_t* dOut; size_t dOutCap;
@@ -88,6 +97,7 @@ static void free_workspace(gc_ctx* c)
 {
     hipFree(c->seqRaw); hipFree(c->lit); hipFree(c->meta); hipFree(c->seqPacked); hipFree(c->seqOff); hipFree(c->codes);
     hipFree(c->stOut); hipFree(c->litSec); hipFree(c->seqSec); hipFree(c->info); hipFree(c->plan);
+    hipFree(c->lzNM); hipFree(c->lzInfo); hipFree(c->lzPlan); c->lzNM = nullptr; c->lzInfo = nullptr; c->lzPlan = nullptr;
     c->seqRaw = nullptr; c->lit = nullptr; c->meta = nullptr; c->seqPacked = nullptr; c->seqOff = nullptr; c->codes = nullptr;
     c->stOut = nullptr; c->litSec = nullptr; c->seqSec = nullptr; c->info = nullptr; c->plan = nullptr; c->capBlocks = 0;
 }
@@ -124,7 +134,10 @@ static int ensure_workspace(gc_ctx* c, uint32_t nBlocks)
         hipMalloc((void**)&c->litSec, nb * GC_LITSEC_STRIDE) != hipSuccess ||
         hipMalloc((void**)&c->seqSec, nb * GC_SEQSEC_STRIDE) != hipSuccess ||
         hipMalloc((void**)&c->info, nb * sizeof(GcSectionInfo)) != hipSuccess ||
-        hipMalloc((void**)&c->plan, nb * sizeof(GcFramePlan)) != hipSuccess) {
+        hipMalloc((void**)&c->plan, nb * sizeof(GcFramePlan)) != hipSuccess ||
+        hipMalloc((void**)&c->lzNM, nb * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void**)&c->lzInfo, nb * (GC_ZSTD_BLOCK_MAX >> GC_LZMA_CHUNK_LOG_MIN) * sizeof(GcLzmaChunkInfo)) != hipSuccess ||
+        hipMalloc((void**)&c->lzPlan, nb * (GC_ZSTD_BLOCK_MAX >> GC_LZMA_CHUNK_LOG_MIN) * sizeof(GcLzmaPlan)) != hipSuccess) {
         free_workspace(c);
         snprintf(c->err, sizeof(c->err), "workspace allocation for %u blocks failed", nBlocks);
         return GC_ERR_NOMEM;
@@ -173,7 +186,7 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
               (const GcSectionInfo*)c->info, (const GcFramePlan*)c->plan, (const uint64_t*)c->result, (uint8_t*)d_dst);
     HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
     HIPCHK(c, hipGetLastError());
-    c->pending = true; c->timed = true;
+    c->pending = true; c->timed = true; c->lastCodec = 0;
     return GC_OK;
 }
 
@@ -191,7 +204,7 @@ extern "C" int gc_zstd_finish(gc_ctx* c, size_t* compressedSize)
 
 extern "C" int gc_zstd_last_timing(gc_ctx* c, float ms[6])
 {
-    if (!c || !c->timed || c->pending) return GC_ERR_PARAM;
+    if (!c || !c->timed || c->pending || c->lastCodec != 0) return GC_ERR_PARAM;
     HIPCHK(c, hipEventElapsedTime(&ms[0], c->ev[0], c->ev[1]));     // lz
     HIPCHK(c, hipEventElapsedTime(&ms[1], c->ev[1], c->ev[2]));     // huf (runs concurrently with seq)
     HIPCHK(c, hipEventElapsedTime(&ms[2], c->ev[3], c->ev[4]));     // seq
@@ -229,5 +242,94 @@ extern "C" int gc_zstd_phase_profile(gc_ctx* c, double cyclesPerBlock[GC_LZ_PHAS
     unsigned long long h[GC_LZ_PHASES + GC_SEQ_PHASES];
     HIPCHK(c, hipMemcpy(h, c->prof, sizeof(h), hipMemcpyDeviceToHost));
     for (int i = 0; i < GC_LZ_PHASES + GC_SEQ_PHASES; i++) cyclesPerBlock[i] = (double)h[i] / c->profBlocks;
+    return GC_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------ FLZMA2 (LZMA2 stream)
+// level -> chunk size: smaller chunks = more independent range coders in flight (faster), more state resets (larger).
+static uint32_t flzma2_chunk_log(int level)
+{
+    if (level <= 2) return 13u;
+    if (level <= 4) return 14u;
+    if (level <= 6) return 15u;
+    return 16u;
+}
+
+extern "C" size_t gc_flzma2_compress_bound(size_t n)
+{
+    const size_t nChunks = (n + (1u << GC_LZMA_CHUNK_LOG_MIN) - 1) >> GC_LZMA_CHUNK_LOG_MIN;
+    return n + nChunks * 6u + 16u;
+}
+
+// dictionary-size property byte of the 7z coder (Lzma2Encoder.cpp:353-364): dict = (2|(p&1)) << (p/2+11).
+// Matches never reach back further than one 128 KiB match-finder block.
+extern "C" unsigned char gc_flzma2_dict_prop(int level) { (void)level; return 10; }
+
+extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n, void* d_dst, size_t dstCap, int level, unsigned flags)
+{
+    if (!c || (!d_src && n) || !d_dst) return GC_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    c->timed = false;
+    if (n == 0) {
+        const size_t sz = (flags & GC_FLZMA2_NO_END_MARK) ? 0 : 1;
+        if (dstCap < sz) return GC_ERR_DST_SMALL;
+        static const uint8_t endMark[1] = { 0x00 };
+        if (sz) HIPCHK(c, hipMemcpyAsync(d_dst, endMark, 1, hipMemcpyHostToDevice, c->stream));
+        c->hostResult[0] = sz; c->hostResult[1] = 0;
+        HIPCHK(c, hipMemcpyAsync(c->result, c->hostResult, 16, hipMemcpyHostToDevice, c->stream));
+        c->pending = true;
+        return GC_OK;
+    }
+    const uint32_t nBlocks = gc_num_blocks(n);
+    int rc = ensure_workspace(c, nBlocks);
+    if (rc != GC_OK) return rc;
+    const uint32_t chunkLog = flzma2_chunk_log(level);
+    const uint32_t nChunks = nBlocks * (GC_ZSTD_BLOCK_MAX >> chunkLog);
+    const uint8_t* src = (const uint8_t*)d_src;
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    GC_LAUNCH(gc_zstd_lz_kernel, nBlocks, 1024, c->stream, src, (uint64_t)n, c->seqRaw, c->lit, c->meta, (unsigned long long*)nullptr);
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    GC_LAUNCH(gc_lzma2_prep_kernel, nBlocks, 256, c->stream, (const GcSeqRaw*)c->seqRaw, (const GcBlockMeta*)c->meta, c->seqPacked, c->lzNM);
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    GC_LAUNCH(gc_lzma2_enc_kernel, nChunks, 64, c->stream, src, (uint64_t)n, (const uint64_t*)c->seqPacked, (const uint32_t*)c->lzNM, chunkLog,
+              c->litSec, c->lzInfo);
+    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    GC_LAUNCH(gc_lzma2_plan_kernel, 1, 1024, c->stream, (const GcLzmaChunkInfo*)c->lzInfo, nChunks, (uint64_t)dstCap, (uint32_t)flags, c->lzPlan, c->result);
+    HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+    GC_LAUNCH(gc_lzma2_emit_kernel, nChunks + 1u, 256, c->stream, src, chunkLog, (const uint8_t*)c->litSec, (const GcLzmaChunkInfo*)c->lzInfo,
+              (const GcLzmaPlan*)c->lzPlan, nChunks, (uint32_t)flags, (const uint64_t*)c->result, (uint8_t*)d_dst);
+    HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+    HIPCHK(c, hipGetLastError());
+    c->pending = true; c->timed = true; c->lastCodec = 1;
+    return GC_OK;
+}
+
+extern "C" int gc_flzma2_finish(gc_ctx* c, size_t* compressedSize) { return gc_zstd_finish(c, compressedSize); }
+
+extern "C" int gc_flzma2_last_timing(gc_ctx* c, float ms[6])
+{
+    if (!c || !c->timed || c->pending || c->lastCodec != 1) return GC_ERR_PARAM;
+    for (int i = 0; i < 5; i++) HIPCHK(c, hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));   // lz, prep, enc, plan, emit
+    HIPCHK(c, hipEventElapsedTime(&ms[5], c->ev[0], c->ev[5]));
+    return GC_OK;
+}
+
+extern "C" int gc_flzma2_compress_host(gc_ctx* c, const void* src, size_t n, void* dst, size_t dstCap, int level, unsigned flags, size_t* outSize)
+{
+    if (!c || (!src && n) || !dst) return GC_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t bound = gc_flzma2_compress_bound(n);
+    if (n > c->dInCap) { hipFree(c->dIn); c->dIn = nullptr; c->dInCap = 0; if (hipMalloc((void**)&c->dIn, n + 64) != hipSuccess) return GC_ERR_NOMEM; c->dInCap = n; }
+    if (bound > c->dOutCap) { hipFree(c->dOut); c->dOut = nullptr; c->dOutCap = 0; if (hipMalloc((void**)&c->dOut, bound) != hipSuccess) return GC_ERR_NOMEM; c->dOutCap = bound; }
+    if (n) HIPCHK(c, hipMemcpyAsync(c->dIn, src, n, hipMemcpyHostToDevice, c->stream));
+    int rc = gc_flzma2_compress_device(c, c->dIn, n, c->dOut, c->dOutCap, level, flags);
+    if (rc != GC_OK) return rc;
+    size_t sz = 0;
+    rc = gc_zstd_finish(c, &sz);
+    if (rc != GC_OK) return rc;
+    if (sz > dstCap) { snprintf(c->err, sizeof(c->err), "destination too small: need %zu bytes", sz); return GC_ERR_DST_SMALL; }
+    if (sz) HIPCHK(c, hipMemcpy(dst, c->dOut, sz, hipMemcpyDeviceToHost));
+    if (outSize) *outSize = sz;
     return GC_OK;
 }

@@ -1,0 +1,70 @@
+// gc_lzma2_frame.hip -- L3/L4 of the FLZMA2 path: LZMA2 chunk headers and stream assembly.
+//
+// Chunk layout (C/fast-lzma2/lzma2_enc.c:94-102,2040-2075; decoder C/Lzma2Dec.c:97-220):
+//   0x00                                   end of stream
+//   0x01 / 0x02, u16be (size-1), bytes     stored chunk (0x01 also resets the dictionary)
+//   0x80 | reset<<5 | (usize-1)>>16, u16be (usize-1), u16be (csize-1), [props]   LZMA chunk; reset 2 = state + props,
+//                                          3 = state + props + dictionary.  Every chunk here resets the state (that is
+//                                          what makes chunks independent work items) and repeats the props byte.
+#include "gc_common.h"
+#include "gc_device.h"
+#include "gc_lzma2.h"
+
+// L3: one workgroup; exclusive scan of chunk sizes.  flags bit0: no end marker (more shards follow)
+extern "C" __global__ void __launch_bounds__(1024)
+gc_lzma2_plan_kernel(const GcLzmaChunkInfo* __restrict__ cinfo, uint32_t nChunks, uint64_t dstCap, uint32_t flags,
+                     GcLzmaPlan* __restrict__ plan, uint64_t* __restrict__ result /* [0]=total bytes, [1]=error */)
+{
+    __shared__ uint32_t sWave[16];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    uint64_t carry = 0;
+    for (uint32_t tb = 0; tb < nChunks; tb += 1024u) {
+        const uint32_t c = tb + t;
+        uint32_t size = 0, kind = 0;
+        if (c < nChunks) {
+            const GcLzmaChunkInfo ci = cinfo[c];
+            if (ci.usize) { kind = ci.csize == 0xFFFFFFFFu ? 2u : 1u; size = kind == 1u ? 6u + ci.csize : 3u + ci.usize; }
+        }
+        uint32_t incl = gc_wave_incl_sum(size);
+        if (lane == 63u) sWave[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+        for (uint32_t w = 0; w < 16u; w++) { uint32_t v = sWave[w]; if (w < wave) before += v; all += v; }
+        __syncthreads();
+        if (c < nChunks) { GcLzmaPlan p; p.off = carry + before + incl - size; p.size = size; p.kind = kind; plan[c] = p; }
+        carry += all;
+    }
+    if (t == 0) {
+        const uint64_t total = carry + ((flags & 1u) ? 0u : 1u);
+        result[0] = total; result[1] = total > dstCap ? 1u : 0u;
+    }
+}
+
+// L4: one workgroup per chunk (+ one extra workgroup for the end marker)
+extern "C" __global__ void __launch_bounds__(256)
+gc_lzma2_emit_kernel(const uint8_t* __restrict__ src, uint32_t chunkLog, const uint8_t* __restrict__ chunkOut,
+                     const GcLzmaChunkInfo* __restrict__ cinfo, const GcLzmaPlan* __restrict__ plan, uint32_t nChunks,
+                     uint32_t flags, const uint64_t* __restrict__ result, uint8_t* __restrict__ dst)
+{
+    if (result[1]) return;
+    const uint32_t t = threadIdx.x, c = blockIdx.x;
+    if (c == nChunks) { if (t == 0 && !(flags & 1u)) dst[result[0] - 1u] = 0x00; return; }
+    const GcLzmaPlan p = plan[c];
+    if (p.kind == 0u) return;
+    const GcLzmaChunkInfo ci = cinfo[c];
+    uint8_t* o = dst + p.off;
+    const uint32_t u1 = ci.usize - 1u;
+    if (p.kind == 1u) {
+        if (t == 0) {
+            const uint32_t c1 = ci.csize - 1u;
+            o[0] = (uint8_t)(0x80u | ((c == 0u ? 3u : 2u) << 5) | (u1 >> 16));
+            o[1] = (uint8_t)(u1 >> 8); o[2] = (uint8_t)u1; o[3] = (uint8_t)(c1 >> 8); o[4] = (uint8_t)c1; o[5] = (uint8_t)GC_LZMA_PROPS;
+        }
+        const uint8_t* s = chunkOut + ((uint64_t)c << chunkLog);
+        for (uint32_t i = t; i < ci.csize; i += 256u) o[6u + i] = s[i];
+    } else {
+        if (t == 0) { o[0] = c == 0u ? 0x01 : 0x02; o[1] = (uint8_t)(u1 >> 8); o[2] = (uint8_t)u1; }
+        const uint8_t* s = src + ((uint64_t)c << chunkLog);
+        for (uint32_t i = t; i < ci.usize; i += 256u) o[3u + i] = s[i];
+    }
+}

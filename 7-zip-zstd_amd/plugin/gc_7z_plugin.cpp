@@ -5,7 +5,8 @@
 //   dlsym GetModuleProp        -> kInterfaceType must be 0 (IUnknown without virtual destructor)   CodecExports.cpp:360-378
 //   dlsym GetNumberOfMethods / GetMethodProperty -> id, name, encoder/decoder class ids            CodecExports.cpp:198-265
 //   dlsym CreateEncoder / CreateDecoder / CreateObject -> COM-style coder object                   CodecExports.cpp:127-195
-// The coder object mirrors NCompress::NZSTD::CEncoder (CPP/7zip/Compress/ZstdEncoder.h:35-78): ICompressCoder,
+// The coder object mirrors NCompress::NZSTD::CEncoder (CPP/7zip/Compress/ZstdEncoder.h:35-78) and
+// NCompress::NLzma2::CFastEncoder (CPP/7zip/Compress/Lzma2Encoder.h:60-100): ICompressCoder,
 // ICompressSetCoderMt, ICompressSetCoderProperties, ICompressSetCoderPropertiesOpt, ICompressWriteCoderProperties.
 // Only ENCODERS are provided (the hot path of SURVEY.md section 8); decoding stays with the host's own decoders, which is
 // how 7-Zip resolves a method id that several modules register (decoder lookup by id, CreateCoder.cpp:206-232).
@@ -21,10 +22,11 @@
 namespace {
 
 struct MethodInfo { uint64_t id; const char* name; int kind; };
-enum { KIND_ZSTD = 0 };
-// Names and ids as registered by the reference (CPP/7zip/Compress/ZstdRegister.cpp:13-17).
+enum { KIND_ZSTD = 0, KIND_FLZMA2 = 1 };
+// Names and ids as registered by the reference (CPP/7zip/Compress/ZstdRegister.cpp:13-17, FastLzma2Register.cpp:13-18).
 const MethodInfo kMethods[] = {
     { 0x4F71101, "ZSTD", KIND_ZSTD },
+    { 0x21, "FLZMA2", KIND_FLZMA2 },
 };
 const uint32_t kNumMethods = sizeof(kMethods) / sizeof(kMethods[0]);
 
@@ -64,19 +66,21 @@ HRESULT hresult_of(int gcErr)
     }
 }
 
-class CGpuZstdEncoder final : public ICompressCoder, public ICompressSetCoderMt, public ICompressSetCoderProperties,
+class CGpuEncoder final : public ICompressCoder, public ICompressSetCoderMt, public ICompressSetCoderProperties,
                               public ICompressSetCoderPropertiesOpt, public ICompressWriteCoderProperties {
     ULONG refs_ = 1;
+    const int kind_;
     gc_ctx* ctx_ = nullptr;
     uint8_t* inBuf_ = nullptr; uint8_t* outBuf_ = nullptr; size_t inCap_ = 0, outCap_ = 0;
-    int level_ = 3;                                   // ZSTD_CLEVEL_DEFAULT
-    uint8_t props_[5] = { 1, 5, 3, 0, 0 };            // CProps{major, minor, level, reserved[2]}  ZstdEncoder.h:17-32
+    int level_;                                       // ZSTD_CLEVEL_DEFAULT 3 / FL2 default 5 (Lzma2Encoder.cpp:178-239 maps -mx to it)
+    uint8_t props_[5] = { 1, 5, 3, 0, 0 };            // ZSTD: CProps{major, minor, level, reserved[2]}  ZstdEncoder.h:17-32
     uint64_t expected_ = 0;
     // input is cut at multiples of the 128 KiB frame grain, so the stream equals a single whole-buffer call
     static const size_t kChunk = 64u << 20;
 
 public:
-    ~CGpuZstdEncoder() { if (ctx_) gc_ctx_destroy(ctx_); free(inBuf_); free(outBuf_); }
+    explicit CGpuEncoder(int kind) : kind_(kind), level_(kind == KIND_ZSTD ? 3 : 5) {}
+    ~CGpuEncoder() { if (ctx_) gc_ctx_destroy(ctx_); free(inBuf_); free(outBuf_); }
 
     HRESULT QueryInterface(const GUID& iid, void** out) override
     {
@@ -100,14 +104,15 @@ public:
     {
         // same clamping as the reference for the properties that have a meaning here (ZstdEncoder.cpp:51-230);
         // the remaining zstd tuning properties are accepted and ignored, exactly as the reference's default branch does
-        level_ = 3; props_[2] = 3;
+        level_ = kind_ == KIND_ZSTD ? 3 : 5; props_[2] = 3;
         for (uint32_t i = 0; i < n; i++) {
             const uint32_t v = props[i].ulVal;
             if (ids[i] == NCoderPropID::kLevel) {
                 int lv = (int)v;
                 if (v < 1) lv = 1;
-                if (v > 22) lv = 22;                   // ZSTD_maxCLevel()
-                level_ = lv; props_[2] = (uint8_t)lv;
+                if (kind_ == KIND_ZSTD) { if (v > 22) lv = 22; props_[2] = (uint8_t)lv; }   // ZSTD_maxCLevel()
+                else if (v > 9) lv = 9;                                                     // FL2_MAX_7Z_CLEVEL
+                level_ = lv;
             }
         }
         return S_OK;
@@ -118,7 +123,11 @@ public:
             if (ids[i] == NCoderPropID::kExpectedDataSize && props[i].vt == VT_UI8 && props[i].uhVal) expected_ = props[i].uhVal;
         return S_OK;
     }
-    HRESULT WriteCoderProperties(ISequentialOutStream* out) override { return write_all(out, props_, sizeof(props_)); }
+    HRESULT WriteCoderProperties(ISequentialOutStream* out) override
+    {
+        if (kind_ == KIND_FLZMA2) { const uint8_t p = gc_flzma2_dict_prop(level_); return write_all(out, &p, 1); }    // Lzma2Encoder.cpp:353-364
+        return write_all(out, props_, sizeof(props_));
+    }
 
     HRESULT Code(ISequentialInStream* in, ISequentialOutStream* out, const uint64_t*, const uint64_t*, ICompressProgressInfo* progress) override
     {
@@ -127,22 +136,31 @@ public:
         size_t chunk = kChunk;
         if (expected_ && expected_ < chunk) chunk = (size_t)((expected_ + 131071u) & ~(uint64_t)131071u);
         if (chunk > inCap_) { free(inBuf_); inBuf_ = (uint8_t*)malloc(chunk); inCap_ = inBuf_ ? chunk : 0; if (!inBuf_) return E_OUTOFMEMORY; }
-        const size_t bound = gc_zstd_compress_bound(inCap_);
+        const size_t bound = kind_ == KIND_ZSTD ? gc_zstd_compress_bound(inCap_) : gc_flzma2_compress_bound(inCap_);
         if (bound > outCap_) { free(outBuf_); outBuf_ = (uint8_t*)malloc(bound); outCap_ = outBuf_ ? bound : 0; if (!outBuf_) return E_OUTOFMEMORY; }
         uint64_t totalIn = 0, totalOut = 0;
         for (;;) {
             size_t got = inCap_;
             HRESULT r = read_full(in, inBuf_, &got);
             if (r != S_OK) return r;
-            if (got == 0 && totalIn != 0) break;
+            if (got == 0 && (totalIn != 0 || kind_ != KIND_ZSTD)) break;
             size_t produced = 0;
-            int rc = gc_zstd_compress_host(ctx_, inBuf_, got, outBuf_, outCap_, level_, &produced);
+            // FLZMA2: every piece is a run of LZMA2 chunks starting with a dictionary reset; the single end marker follows the loop
+            int rc = kind_ == KIND_ZSTD ? gc_zstd_compress_host(ctx_, inBuf_, got, outBuf_, outCap_, level_, &produced)
+                                        : gc_flzma2_compress_host(ctx_, inBuf_, got, outBuf_, outCap_, level_, GC_FLZMA2_NO_END_MARK, &produced);
             if (rc != GC_OK) return hresult_of(rc);
             r = write_all(out, outBuf_, produced);
             if (r != S_OK) return r;
             totalIn += got; totalOut += produced;
             if (progress) { r = progress->SetRatioInfo(&totalIn, &totalOut); if (r != S_OK) return r; }
             if (got < inCap_) break;      // short read = end of stream
+        }
+        if (kind_ == KIND_FLZMA2) {
+            const uint8_t endMark = 0x00;
+            HRESULT r = write_all(out, &endMark, 1);
+            if (r != S_OK) return r;
+            totalOut += 1;
+            if (progress) { r = progress->SetRatioInfo(&totalIn, &totalOut); if (r != S_OK) return r; }
         }
         return S_OK;
     }
@@ -154,10 +172,8 @@ HRESULT create_encoder(uint32_t index, const GUID* iid, void** out)
     *out = nullptr;
     if (index >= kNumMethods) return CLASS_E_CLASSNOTAVAILABLE;
     if (!iid || !(*iid == IID_ICompressCoder)) return E_NOINTERFACE;     // 1-stream, non-filter codecs only (CodecExports.cpp:127-150)
-    IUnknown* obj = nullptr;
-    switch (kMethods[index].kind) {
-        case KIND_ZSTD: { CGpuZstdEncoder* e = new (std::nothrow) CGpuZstdEncoder(); obj = e ? static_cast<ICompressCoder*>(e) : nullptr; break; }
-    }
+    CGpuEncoder* e = new (std::nothrow) CGpuEncoder(kMethods[index].kind);
+    IUnknown* obj = e ? static_cast<ICompressCoder*>(e) : nullptr;
     if (!obj) return E_OUTOFMEMORY;
     *out = obj;          // pointer to the ICompressCoder sub-object, reference count 1 (RegisterCodec.h:25-26)
     return S_OK;

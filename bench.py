@@ -23,6 +23,23 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def cpu_baseline_flzma2(x, level, budget_s=25.0):
+    """Reference Fast-LZMA2 (oracle/_ref/libflzma2_ref.so = C/fast-lzma2 compiled from /root/reference) on the host cores,
+    on a bounded sample (the first 32 MiB: ~10-20 s of CPU work over both legs)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O          # cpu_baseline leg only
+    if O.ref("flzma2") is None:
+        return None, None
+    cores = os.cpu_count() or 1
+    sample = x[: min(x.size, 32 * 1024 * 1024)]
+    t0 = time.perf_counter(); c1, _ = O.ref_fl2_compress(sample, level, threads=1); t1 = time.perf_counter() - t0
+    t0 = time.perf_counter(); cm, _ = O.ref_fl2_compress(sample, level, threads=cores); tm = time.perf_counter() - t0
+    res = {"value": round(sample.size / tm / 1e6, 1), "unit": "MB/s", "cores": cores, "kind": "reference",
+           "sample": "FL2_compressCCtx level %d on the first %d bytes of the same buffer, one run; %d threads; single thread: %.1f MB/s"
+                     % (level, sample.size, cores, sample.size / t1 / 1e6)}
+    return res, (len(c1), sample.size)
+
+
 def cpu_baseline(x, level, budget_s=25.0):
     """Reference zstd (oracle/_ref/libzstd_ref.so = C/zstd compiled from /root/reference) timed on the host
     cores of this box, on a bounded sample of the same workload.  Reported, not the optimisation target."""
@@ -60,9 +77,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--bytes", type=int, default=100_000_000, help="input bytes per GPU (enwik8 size)")
-    ap.add_argument("--corpus", default="text-zipf")
-    ap.add_argument("--level", type=int, default=3)
+    ap.add_argument("--codec", default="zstd", choices=["zstd", "flzma2"])
+    ap.add_argument("--bytes", type=int, default=0, help="input bytes per GPU (default: 100 000 000 = enwik8 size for zstd, 211 900 000 = Silesia for flzma2)")
+    ap.add_argument("--corpus", default="")
+    ap.add_argument("--level", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -88,9 +106,13 @@ def main():
     spec = _u.spec_from_file_location("sevenzip_zstd_amd_corpus", os.path.join(ROOT, "7-zip-zstd_amd", "corpus", "__init__.py"))
     corpus_mod = _u.module_from_spec(spec); spec.loader.exec_module(corpus_mod)
 
+    fl2 = args.codec == "flzma2"
+    args.bytes = args.bytes or (211_900_000 if fl2 else 100_000_000)
+    args.corpus = args.corpus or ("silesia-like" if fl2 else "text-zipf")
+    args.level = args.level or (5 if fl2 else 3)
     n = args.bytes
     x = corpus_mod.corpus(args.corpus, n, seed=20260921 + rank)      # each rank owns a different shard
-    enc = pkg.ZstdEncoder(device=local_rank, level=args.level)
+    enc = (pkg.Flzma2Encoder if fl2 else pkg.ZstdEncoder)(device=local_rank, level=args.level)
     dev = torch.device("cuda", local_rank)
     d_src = torch.from_numpy(x).to(dev)
     cap = enc.compress_bound(n)
@@ -106,7 +128,7 @@ def main():
         enc.code_device(d_src.data_ptr(), n, d_dst.data_ptr(), cap)
         csize = enc.finish()
 
-    kern_ms = {k: 0.0 for k in pkg.ZstdEncoder.KERNELS}
+    kern_ms = {k: 0.0 for k in enc.KERNELS}
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -134,26 +156,36 @@ def main():
         value = total_in * args.steps / elapsed / 1e6
         ratio = n / csize
         # dominant kernel = the longest of the five; algorithmic bytes per launch = N_in * (1 + 1/ratio)  
-        dom = max(("lz", "huf", "seq", "plan", "emit"), key=lambda k: kern_ms[k])
+        dom = max([k for k in enc.KERNELS if k != "total"], key=lambda k: kern_ms[k])
         algo_bytes = n * (1.0 + 1.0 / ratio)
         achieved = algo_bytes / (kern_ms[dom] * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "gc_zstd_%s_kernel" % dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+        kname = "gc_zstd_lz_kernel" if dom == "lz" else ("gc_lzma2_%s_kernel" if fl2 else "gc_zstd_%s_kernel") % dom
+        roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                     "algorithmic_bytes_per_launch": int(algo_bytes),
                     "kernel_ms": {k: round(v, 4) for k, v in kern_ms.items()},
                     "pipeline_read_frac": round(n / (kern_ms["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                     "pipeline_rw_frac": round(algo_bytes / (kern_ms["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
-        cpu, ref_size = (None, None) if args.no_cpu_baseline else cpu_baseline(x, args.level)
+        if fl2:
+            cpu, ref_info = (None, None) if args.no_cpu_baseline else cpu_baseline_flzma2(x, args.level)
+            ref_size = None
+        else:
+            cpu, ref_size = (None, None) if args.no_cpu_baseline else cpu_baseline(x, args.level)
+            ref_info = None
         line = {
-            "metric": "zstd-L3 compression throughput, 128 KiB independent blocks (input MB/s)",
+            "metric": ("flzma2-L%d compression throughput (input MB/s)" % args.level) if fl2 else
+                      "zstd-L3 compression throughput, 128 KiB independent blocks (input MB/s)",
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "zstd level 3, enwik8 stand-in (%s, %d B per GPU), 128 KiB independent blocks" % (args.corpus, n),
+            "config": {"workload": ("Fast-LZMA2 level %d, Silesia stand-in (%s, %d B per GPU), LZMA2 chunks with per-chunk state reset" % (args.level, args.corpus, n)) if fl2 else
+                                   "zstd level 3, enwik8 stand-in (%s, %d B per GPU), 128 KiB independent blocks" % (args.corpus, n),
                        "bytes_per_gpu": n, "blocks_per_gpu": (n + 131071) // 131072, "parallelism": "range-shard x%d, no collective" % world},
             "compressed_bytes": total_csize, "ratio": round(ratio, 4),
-            "ratio_vs_ref": None if (not ref_size or n > 100_000_000) else
-                            {"ours_over_ref_single_stream_L%d" % args.level: round(csize / ref_size, 4), "ref_bytes": ref_size},
+            "ratio_vs_ref": ({"note": "reference size measured on its CPU sample only", "ref_ratio_on_sample": round(ref_info[1] / ref_info[0], 4),
+                              "ours_ratio_whole_input": round(ratio, 4)} if ref_info else None) if fl2 else
+                            (None if (not ref_size or n > 100_000_000) else
+                             {"ours_over_ref_single_stream_L%d" % args.level: round(csize / ref_size, 4), "ref_bytes": ref_size}),
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

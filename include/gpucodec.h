@@ -65,6 +65,24 @@ int         gc_zstd_last_timing(gc_ctx* ctx, float ms[6]);
 int         gc_zstd_set_phase_profile(gc_ctx* ctx, int enable);
 int         gc_zstd_phase_profile(gc_ctx* ctx, double cyclesPerBlock[12]);
 
+/* ---- FLZMA2 (7-Zip method id 0x21): an LZMA2 chunk stream that the stock decoder NCompress::NLzma2::CDecoder
+ * (C/Lzma2Dec.c; registered for FLZMA2 at CPP/7zip/Compress/FastLzma2Register.cpp:15) regenerates bit-exactly.
+ *   gc_flzma2_compress_host   <->  the FL2_compressStream loop of NCompress::NLzma2::CFastEncoder::Code
+ *                                  (CPP/7zip/Compress/Lzma2Encoder.cpp:260-350; library entry C/fast-lzma2/fl2_compress.c:1020)
+ *   gc_flzma2_dict_prop       <->  FL2_getCCtxDictProp: the 1-byte coder property (Lzma2Encoder.cpp:353-364)
+ *   gc_flzma2_compress_bound  <->  FL2_compressBound (fl2_compress.c:612)
+ * flags: GC_FLZMA2_NO_END_MARK omits the terminating 0x00 so that the streams of several range shards can be concatenated
+ * (the last shard writes it); every call starts with a dictionary reset, so shards are independent. */
+#define GC_FLZMA2_NO_END_MARK 1u
+size_t        gc_flzma2_compress_bound(size_t n);
+unsigned char gc_flzma2_dict_prop(int level);
+int           gc_flzma2_compress_device(gc_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t dstCapacity, int level, unsigned flags);
+int           gc_flzma2_finish(gc_ctx* ctx, size_t* compressedSize);
+int           gc_flzma2_compress_host(gc_ctx* ctx, const void* src, size_t n, void* dst, size_t dstCapacity, int level, unsigned flags,
+                                      size_t* compressedSize);
+/* ms[0..4] = lz (match finder), prep, enc (range coder), plan, emit; ms[5] = first kernel start -> last kernel end */
+int           gc_flzma2_last_timing(gc_ctx* ctx, float ms[6]);
+
 /* raw stream handle (hipStream_t) so callers can order their own work against the context */
 void*       gc_ctx_stream(gc_ctx* ctx);
 

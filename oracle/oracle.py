@@ -47,6 +47,8 @@ def port():
         _port.gco_last_diag.restype = C.POINTER(_Diag)
         _port.gco_xxh64.argtypes = [_VP, _SZ, C.c_uint64]
         _port.gco_xxh64.restype = C.c_uint64
+        _port.gco_lzma2_decode.argtypes = [_VP, _SZ, _VP, _SZ, C.c_ubyte]
+        _port.gco_lzma2_decode.restype = _SZ
     return _port
 
 
@@ -167,6 +169,16 @@ def ref_fl2_compress(data, level=5, threads=1):
     if r == _BAD:
         raise RuntimeError("reference FL2 compress failed")
     return out[:r].copy(), prop.value
+
+
+def port_lzma2_decode(comp, cap, prop):
+    """oracle/lzma2_dec.c: the plain-C restatement of the LZMA2 decoder."""
+    a, ap = _buf(comp)
+    out = np.empty(max(cap, 1), dtype=np.uint8)
+    r = port().gco_lzma2_decode(ap, a.size, out.ctypes.data, cap, prop)
+    if r > (1 << 63):
+        raise ValueError("port LZMA2 decoder rejected the stream (check %d)" % ((1 << 64) - 1 - r))
+    return out[:r]
 
 
 def ref_lzma2_decode(comp, cap, prop):

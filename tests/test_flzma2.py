@@ -1,0 +1,165 @@
+"""FLZMA2 path (7-Zip method id 0x21): LZMA2 streams produced by the HIP kernels must regenerate the input bit-exactly under
+the stock LZMA2 decoder (reference C/Lzma2Dec.c via oracle/_ref, and its plain-C restatement oracle/lzma2_dec.c).
+
+CPU tests run the unmodified kernel sources under the SIMT emulator; -m gpu tests run the product library on the MI355X and
+additionally require GPU bytes == emulator bytes (the encoder is deterministic)."""
+import os
+
+import numpy as np
+import pytest
+
+BLK = 128 * 1024
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def emu_fl2(pkg, emu_lib_path):
+    encs = {lv: pkg.Flzma2Encoder(lib_path=emu_lib_path, level=lv) for lv in (1, 5, 9)}
+    yield encs
+    for e in encs.values():
+        e.close()
+
+
+@pytest.fixture(scope="module")
+def gpu_fl2(pkg, graft):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    graft.build_hip()
+    encs = {lv: pkg.Flzma2Encoder(device=0, level=lv) for lv in (1, 5, 9)}
+    yield encs
+    for e in encs.values():
+        e.close()
+
+
+def _roundtrip(O, enc, x):
+    c = enc.code(x)
+    prop = enc.coder_props()[0]
+    assert np.array_equal(O.port_lzma2_decode(c, x.size, prop), x)
+    if O.ref("flzma2") is not None:
+        assert np.array_equal(O.ref_lzma2_decode(c, x.size, prop), x)
+    return c
+
+
+# ---------------------------------------------------------------------------------------------- oracle pinning (CPU)
+@pytest.mark.parametrize("kind", ["text-zipf", "silesia-like", "lz-7zip", "random", "zeros"])
+def test_port_decoder_pinned_on_reference_encoder_output(O, kind):
+    if O.ref("flzma2") is None:
+        pytest.skip("oracle/_ref not built")
+    x = O.corpus(kind, 3 * BLK + 999)
+    for lv in (1, 5, 9):
+        c, prop = O.ref_fl2_compress(x, lv)
+        assert np.array_equal(O.port_lzma2_decode(c, x.size, prop), x)
+        assert np.array_equal(O.ref_lzma2_decode(c, x.size, prop), x)
+
+
+def test_port_decoder_rejects_corruption(O):
+    if O.ref("flzma2") is None:
+        pytest.skip("oracle/_ref not built")
+    x = O.corpus("text-zipf", 50_000)
+    c, prop = O.ref_fl2_compress(x, 5)
+    bad = c.copy(); bad[len(bad) // 2] ^= 0x40
+    try:
+        y = O.port_lzma2_decode(bad, x.size, prop)
+        assert not np.array_equal(y, x)
+    except ValueError:
+        pass
+    with pytest.raises(ValueError):
+        O.port_lzma2_decode(c[:-1], x.size, prop)          # missing end marker
+
+
+# ---------------------------------------------------------------------------------------------- emulator (CPU)
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 7, 64, 255, 1000, 4097, BLK - 1, BLK, BLK + 1])
+def test_emu_edge_sizes(O, emu_fl2, n):
+    _roundtrip(O, emu_fl2[5], O.corpus("text-zipf", n))
+
+
+@pytest.mark.parametrize("kind", ["text-zipf", "lz-7zip", "silesia-like", "web-text", "random", "zeros"])
+def test_emu_corpora_all_levels(O, emu_fl2, kind):
+    x = O.corpus(kind, BLK + 70_000)
+    sizes = [len(_roundtrip(O, emu_fl2[lv], x)) for lv in (1, 5, 9)]
+    if kind == "random":
+        assert sizes[1] <= x.size + 3 * (x.size // 32768 + 2) + 1      # stored chunks: 3-byte headers only
+    if kind in ("text-zipf", "web-text"):
+        assert sizes[2] <= sizes[0]                                    # larger chunks = fewer state resets
+
+
+def test_emu_long_matches_and_patterns(O, emu_fl2):
+    x = np.tile(np.arange(7, dtype=np.uint8), (BLK + 50) // 7 + 1)[:BLK + 50].copy()      # one match >> 273: rep0 continuation pieces
+    _roundtrip(O, emu_fl2[5], x)
+    r = O.corpus("random", 70_000)
+    _roundtrip(O, emu_fl2[5], np.concatenate([r, r[:50_000]]))                            # stored chunks followed by LZMA chunks
+    rng = np.random.default_rng(11)
+    words = [bytes(rng.integers(97, 123, size=int(k)).astype(np.uint8)) for k in rng.integers(5, 12, size=40)]
+    y = np.frombuffer(b" ".join(words[int(i)] for i in rng.integers(0, 40, size=30_000)), dtype=np.uint8)[:2 * BLK].copy()
+    _roundtrip(O, emu_fl2[1], y)                                                         # dense rep0 / rep1 usage
+
+
+def test_emu_ratio_band_vs_reference(O, emu_fl2):
+    """Size against the reference encoder at level 5 (recorded, and bounded so that regressions show)."""
+    if O.ref("flzma2") is None:
+        pytest.skip("oracle/_ref not built")
+    x = O.corpus("text-zipf", 4 * BLK)
+    ours = len(emu_fl2[5].code(x))
+    ref, _ = O.ref_fl2_compress(x, 5)
+    assert ours <= 1.25 * len(ref), (ours, len(ref))
+
+
+def test_emu_shards_concatenate(O, emu_fl2):
+    """Range shards: every shard but the last omits the end marker; the concatenation is one LZMA2 stream."""
+    enc = emu_fl2[5]
+    x = O.corpus("silesia-like", 3 * BLK + 5000)
+    a = enc.code(x[:2 * BLK], flags=enc.NO_END_MARK)
+    b = enc.code(x[2 * BLK:])
+    c = np.concatenate([a, b])
+    assert np.array_equal(O.port_lzma2_decode(c, x.size, enc.coder_props()[0]), x)
+    if O.ref("flzma2") is not None:
+        assert np.array_equal(O.ref_lzma2_decode(c, x.size, enc.coder_props()[0]), x)
+
+
+def test_emu_deterministic(O, emu_fl2):
+    x = O.corpus("silesia-like", BLK)
+    assert np.array_equal(emu_fl2[5].code(x), emu_fl2[5].code(x))
+
+
+# ---------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 64, 255, 4097, BLK - 1, BLK, BLK + 1, 3 * BLK + 17])
+def test_gpu_edge_sizes(O, gpu_fl2, n):
+    _roundtrip(O, gpu_fl2[5], O.corpus("text-zipf", n))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["text-zipf", "lz-7zip", "silesia-like", "web-text", "random", "zeros"])
+def test_gpu_corpora_all_levels(O, gpu_fl2, kind):
+    x = O.corpus(kind, 8 * 1024 * 1024 + 999)
+    for lv in (1, 5, 9):
+        _roundtrip(O, gpu_fl2[lv], x)
+
+
+@pytest.mark.gpu
+def test_gpu_bytes_equal_emulator_bytes(O, gpu_fl2, emu_fl2):
+    for kind in ("text-zipf", "silesia-like"):
+        x = O.corpus(kind, 2 * BLK + 1234)
+        for lv in (1, 5):
+            assert np.array_equal(gpu_fl2[lv].code(x), emu_fl2[lv].code(x)), (kind, lv)
+
+
+@pytest.mark.gpu
+def test_gpu_full_silesia_size_device_api(O, gpu_fl2):
+    """BASELINE config 3 size (silesia-like, 212 MB) through the device-pointer entry, checked by the reference decoder."""
+    import torch
+    n = 211_900_000
+    x = O.corpus("silesia-like", n)
+    enc = gpu_fl2[5]
+    d_src = torch.from_numpy(x).to("cuda:0")
+    cap = enc.compress_bound(n)
+    d_dst = torch.empty(cap, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    enc.code_device(d_src.data_ptr(), n, d_dst.data_ptr(), cap)
+    size = enc.finish()
+    comp = d_dst[:size].cpu().numpy()
+    prop = enc.coder_props()[0]
+    dec = O.ref_lzma2_decode(comp, n, prop) if O.ref("flzma2") is not None else O.port_lzma2_decode(comp, n, prop)
+    assert np.array_equal(dec, x)
+    assert enc.last_timing_ms()["total"] > 0

@@ -27,6 +27,7 @@ def test_exports_and_method_listing(emu_module):
     lines = r.stdout.strip().splitlines()
     assert lines[0].split()[1:3] == ["4F71101", "ZSTD"]            # id and name of ZstdRegister.cpp:13-17
     assert "enc=1 dec=0" in lines[0] and "clsid=23170F69-40C1-2791" in lines[0]
+    assert lines[1].split()[1:3] == ["21", "FLZMA2"]               # FastLzma2Register.cpp:13-18
     import ctypes
     lib = ctypes.CDLL(emu_module)
     for sym in ["GetNumberOfMethods", "GetMethodProperty", "CreateEncoder", "CreateDecoder", "CreateObject", "GetModuleProp"]:
@@ -47,6 +48,38 @@ def test_code_through_com_surface(O, emu_module, emu_enc, tmp_path, n, how):
     if O.ref("zstd") is not None:
         assert np.array_equal(O.ref_zstd_decompress(c, n), x)
     assert props.read_bytes() == bytes([1, 5, 3, 0, 0])           # CProps of ZstdEncoder.h:17-32; decoder accepts 1/3/5 bytes
+
+
+@pytest.mark.parametrize("n", [0, 5, BLK + 4321])
+def test_flzma2_code_through_com_surface(O, emu_module, pkg, emu_lib_path, tmp_path, n):
+    x = O.corpus("silesia-like", n)
+    src, dst, props = tmp_path / "in.bin", tmp_path / "out.lzma2", tmp_path / "props.bin"
+    x.tofile(src)
+    r = _host(emu_module, "encode", "FLZMA2", 5, src, dst, props)
+    assert r.returncode == 0, r.stderr + r.stdout
+    c = np.fromfile(dst, dtype=np.uint8)
+    prop = props.read_bytes()
+    assert len(prop) == 1                                           # 1-byte dictionary-size code, Lzma2Encoder.cpp:353-364
+    assert np.array_equal(O.port_lzma2_decode(c, n, prop[0]), x)
+    if O.ref("flzma2") is not None:
+        assert np.array_equal(O.ref_lzma2_decode(c, n, prop[0]), x)
+
+
+@pytest.mark.gpu
+def test_product_plugin_flzma2_on_gpu(O, graft, tmp_path):
+    graft.build_hip()
+    module = graft.build_plugin()
+    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "emu"), "_build/plugin_host"], check=True, capture_output=True)
+    n = 70 * 1024 * 1024 + 4321                                     # > one 64 MiB Code() piece: two dictionary-reset runs + end marker
+    x = O.corpus("silesia-like", n)
+    src, dst, props = tmp_path / "in.bin", tmp_path / "out.lzma2", tmp_path / "props.bin"
+    x.tofile(src)
+    r = _host(module, "encode", "FLZMA2", 5, src, dst, props)
+    assert r.returncode == 0, r.stderr + r.stdout
+    c = np.fromfile(dst, dtype=np.uint8)
+    prop = props.read_bytes()[0]
+    dec = O.ref_lzma2_decode(c, n, prop) if O.ref("flzma2") is not None else O.port_lzma2_decode(c, n, prop)
+    assert np.array_equal(dec, x)
 
 
 @pytest.mark.gpu

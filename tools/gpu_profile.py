@@ -12,6 +12,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--bytes", type=int, default=100_000_000)
 ap.add_argument("--corpus", default="text-zipf")
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--codec", default="zstd")
+ap.add_argument("--level", type=int, default=0)
 a = ap.parse_args()
 g.build_hip()
 pkg = g.load_package()
@@ -19,7 +21,8 @@ from importlib import util as _u
 spec = _u.spec_from_file_location("c", os.path.join(ROOT, "7-zip-zstd_amd", "corpus", "__init__.py"))
 cm = _u.module_from_spec(spec); spec.loader.exec_module(cm)
 x = cm.corpus(a.corpus, a.bytes)
-enc = pkg.ZstdEncoder(device=0)
+fl2 = a.codec == "flzma2"
+enc = pkg.Flzma2Encoder(device=0, level=a.level or 5) if fl2 else pkg.ZstdEncoder(device=0)
 d_src = torch.from_numpy(x).cuda(); cap = enc.compress_bound(x.size); d_dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
 def run():
     enc.code_device(d_src.data_ptr(), x.size, d_dst.data_ptr(), cap); return enc.finish()
@@ -28,10 +31,13 @@ acc = {}
 for _ in range(a.reps):
     size = run()
     for k, v in enc.last_timing_ms().items(): acc[k] = acc.get(k, 0) + v / a.reps
-enc.set_phase_profile(True)
-run(); ph = enc.phase_profile(); tp = enc.last_timing_ms()
-enc.set_phase_profile(False)
-print(json.dumps({"corpus": a.corpus, "bytes": a.bytes, "compressed": size, "ratio": round(a.bytes / size, 4),
+if fl2:
+    ph, tp = {}, acc
+else:
+    enc.set_phase_profile(True)
+    run(); ph = enc.phase_profile(); tp = enc.last_timing_ms()
+    enc.set_phase_profile(False)
+print(json.dumps({"codec": a.codec, "level": enc.level, "corpus": a.corpus, "bytes": a.bytes, "compressed": size, "ratio": round(a.bytes / size, 4),
                   "GBps_total": round(a.bytes / acc["total"] / 1e6, 2), "kernel_ms": {k: round(v, 4) for k, v in acc.items()},
                   "kernel_ms_profiled": {k: round(v, 4) for k, v in tp.items()},
                   "phase_cycles_per_block": {k: round(v) for k, v in ph.items()}}))
