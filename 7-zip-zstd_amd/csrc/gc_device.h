@@ -89,3 +89,24 @@ __device__ __forceinline__ uint32_t gc_wave_max(uint32_t v)
     for (int d = 32; d >= 1; d >>= 1) { uint32_t o = __shfl_xor(v, d); v = v > o ? v : o; }
     return v;
 }
+
+// Wave "publish / peek": every lane contributes one 32-bit value, afterwards any lane's value can be read with a
+// wave-uniform index.  On gfx950 this is a plain VGPR + v_readlane_b32 (result in an SGPR, so everything computed from it
+// stays on the scalar unit); under the emulator the values are copied out once per publish instead of once per peek.
+#ifdef HIPEMU
+struct GcPub { uint32_t v[64]; };
+__device__ __forceinline__ void gc_publish(GcPub& pub, uint32_t mine)
+{
+    hipemu::WaveCtx& w = hipemu::wv();
+    hipemu::wave_barrier();
+    w.xchg[hipemu::lane()] = mine;
+    hipemu::wave_barrier();
+    for (int i = 0; i < 64; i++) pub.v[i] = (uint32_t)w.xchg[i];
+    hipemu::wave_barrier();          // nobody reuses the exchange slots before every lane has copied them out
+}
+__device__ __forceinline__ uint32_t gc_peek(const GcPub& pub, uint32_t lane) { return pub.v[lane & 63u]; }
+#else
+struct GcPub { uint32_t mine; };
+__device__ __forceinline__ void gc_publish(GcPub& pub, uint32_t mine) { pub.mine = mine; }
+__device__ __forceinline__ uint32_t gc_peek(const GcPub& pub, uint32_t lane) { return gc_readlane(pub.mine, lane); }
+#endif

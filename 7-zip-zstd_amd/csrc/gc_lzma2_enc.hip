@@ -17,13 +17,18 @@
 //                            their start positions (scan), M[j] = pos | len<<17 | off<<34
 //   L2 gc_lzma2_enc_kernel   one WAVE per chunk.  The 64 lanes turn symbols into (probability index, bit) entries in
 //                            parallel -- state machine, repeat-distance history, slot/length trees are all computed
-//                            per symbol from local information (scans), nothing serial; then lane 0 runs the only
-//                            inherently serial part, a ~15-instruction loop per entry: probability read-modify-write in
-//                            LDS + range update + carry/byte output.
+//                            per symbol from local information (scans), nothing serial.  The probability updates of one
+//                            symbol touch distinct entries, so they are applied by all lanes at once (LDS read-modify-write);
+//                            what remains serial is the range recurrence (bound = (range >> 11) * p ...), a wave-uniform
+//                            loop that runs on the scalar unit with the probabilities fetched by v_readlane.
 //   L3/L4 plan + emit        chunk headers and concatenation (gc_lzma2_frame.hip)
 #include "gc_common.h"
 #include "gc_device.h"
 #include "gc_lzma2.h"
+#ifdef HIPEMU
+#include <stdio.h>
+#include <stdlib.h>
+#endif
 
 #define LZP_T 256u
 
@@ -76,13 +81,13 @@ gc_lzma2_prep_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __r
 // ---------------------------------------------------------------------------------------------- L2: chunk encoder
 struct LzRc { uint64_t low; uint32_t range; uint32_t cache; uint32_t cacheSize; uint32_t outPos; uint32_t outCap; uint8_t* out; };
 
-__device__ __forceinline__ void rc_shift_low(LzRc& rc)                    // range_enc.c RC_shiftLow
+__device__ __forceinline__ void rc_shift_low(LzRc& rc, uint32_t lane)     // range_enc.c RC_shiftLow; every field is wave-uniform
 {
     if ((uint32_t)rc.low < 0xFF000000u || (rc.low >> 32) != 0) {
         const uint32_t carry = (uint32_t)(rc.low >> 32);
         uint32_t c = rc.cache;
         do {
-            if (rc.outPos < rc.outCap) rc.out[rc.outPos] = (uint8_t)(c + carry);
+            if (lane == 0u && rc.outPos < rc.outCap) rc.out[rc.outPos] = (uint8_t)(c + carry);
             rc.outPos++;
             c = 0xFFu;
         } while (--rc.cacheSize != 0);
@@ -92,27 +97,48 @@ __device__ __forceinline__ void rc_shift_low(LzRc& rc)                    // ran
     rc.low = (rc.low & 0x00FFFFFFull) << 8;
 }
 
-// the serial part: consume n entries
-__device__ __forceinline__ void rc_run(LzRc& rc, const uint32_t* ent, uint32_t n, uint16_t* P)
+// Consume the entries of ONE group held one per lane (lane k < cnt holds entry k, in coding order).
+//   * probability update: all lanes at once.  `rounds` lane groups of `per` lanes are applied one after the other
+//     (round r = lanes [r*per, (r+1)*per)): inside one symbol all indices are distinct by construction (one node per tree
+//     depth), different symbols may share indices, so symbols are applied in order (LDS operations of a wave are in order);
+//   * range recurrence: a wave-uniform loop -- the probabilities come back through v_readlane into SGPRs and range / low /
+//     cache live in SGPRs, so the only serial work runs on the scalar unit.
+__device__ __forceinline__ void rc_consume(LzRc& rc, uint32_t e, uint32_t cnt, uint32_t per, uint16_t* P, uint32_t lane)
 {
-    for (uint32_t k = 0; k < n; k++) {
-        const uint32_t e = ent[k];
-        if (e & 0x80000000u) {                                             // direct bits, most significant first
-            uint32_t nb = (e >> 26) & 31u; const uint32_t v = e & 0x03FFFFFFu;
+    const bool valid = lane < cnt;
+    const bool isDirect = valid && (e >> 31) != 0u;
+    uint32_t p = 0;
+    for (uint32_t r0 = 0; r0 < cnt; r0 += per) {
+        if (valid && !isDirect && lane >= r0 && lane < r0 + per) {
+            const uint32_t idx = e >> 1;
+            p = P[idx];
+            P[idx] = (uint16_t)((e & 1u) ? p - (p >> 5) : p + ((2048u - p) >> 5));
+        }
+        gc_wave_sync();
+    }
+    const uint64_t bits = __ballot(valid && (e & 1u));
+    const uint64_t dmask = __ballot(isDirect);
+    GcPub pubP, pubE;
+    gc_publish(pubP, p);
+    if (dmask) gc_publish(pubE, e);
+    for (uint32_t k = 0; k < cnt; k++) {
+#ifdef HIPEMU
+        if (lane == 0 && getenv("GC_TRACE_RC")) fprintf(stderr, "E %u %u p=%u\n", (dmask >> k) & 1ull ? 0xFFFFu : 0u, (unsigned)((bits >> k) & 1ull), gc_peek(pubP, k));
+#endif
+        if ((dmask >> k) & 1ull) {                                          // direct bits, most significant first
+            const uint32_t ev = gc_peek(pubE, k);
+            uint32_t nb = (ev >> 26) & 31u; const uint32_t v = ev & 0x03FFFFFFu;
             while (nb) {
                 nb--;
                 rc.range >>= 1;
                 if ((v >> nb) & 1u) rc.low += rc.range;
-                if (rc.range < (1u << 24)) { rc.range <<= 8; rc_shift_low(rc); }
+                if (rc.range < (1u << 24)) { rc.range <<= 8; rc_shift_low(rc, lane); }
             }
         } else {
-            const uint32_t idx = e >> 1;
-            uint32_t p = P[idx];
-            const uint32_t bound = (rc.range >> 11) * p;
-            if (e & 1u) { rc.low += bound; rc.range -= bound; p -= p >> 5; }
-            else { rc.range = bound; p += (2048u - p) >> 5; }
-            P[idx] = (uint16_t)p;
-            if (rc.range < (1u << 24)) { rc.range <<= 8; rc_shift_low(rc); }
+            const uint32_t bound = (rc.range >> 11) * gc_peek(pubP, k);
+            if ((bits >> k) & 1ull) { rc.low += bound; rc.range -= bound; }
+            else rc.range = bound;
+            if (rc.range < (1u << 24)) { rc.range <<= 8; rc_shift_low(rc, lane); }
         }
     }
 }
@@ -214,14 +240,13 @@ __device__ __forceinline__ LzItem lz_item(const uint64_t* M, uint32_t idx, uint3
     return it;
 }
 
-#define LZE_LIT_TILE 64u
 extern "C" __global__ void __launch_bounds__(64)
 gc_lzma2_enc_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const uint64_t* __restrict__ Mall,
                     const uint32_t* __restrict__ nM, uint32_t chunkLog, uint8_t* __restrict__ chunkOut,
                     GcLzmaChunkInfo* __restrict__ cinfo)
 {
     __shared__ uint16_t P[LZP_TOTAL];
-    __shared__ uint32_t sLit[LZE_LIT_TILE * 9u];
+    __shared__ uint32_t sPiece[24]; __shared__ uint32_t sPieceN;
     __shared__ uint32_t sMat[64u * 24u];
     __shared__ uint32_t sMatN[64];
 
@@ -251,6 +276,7 @@ gc_lzma2_enc_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const uin
     // a clipped piece shorter than 2 bytes cannot be a match: it can only be the first or the last item
     if (first < last && lz_item(M, first, cs, ce).len < 2u) first++;
     if (first < last && lz_item(M, last - 1u, cs, ce).len < 2u) last--;
+    first = gc_uniform(first); last = gc_uniform(last);     // keep the walk below on the scalar unit
 
     LzRc rc; rc.low = 0; rc.range = 0xFFFFFFFFu; rc.cache = 0; rc.cacheSize = 1; rc.outPos = 0;
     rc.outCap = (ce - cs);                                 // beyond this the chunk is stored raw anyway
@@ -299,49 +325,63 @@ gc_lzma2_enc_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const uin
         for (uint32_t j = 0; j < steps; j++) {
             const bool isTail = j >= cnt;
             const uint32_t jj = isTail ? 0u : j;
-            const uint32_t ipos = isTail ? ce : __shfl(it.pos, (int)jj);
-            const uint32_t ilen = isTail ? 0u : __shfl(it.len, (int)jj);
-            const uint32_t ioff = isTail ? 0u : __shfl(it.off, (int)jj);
-            const uint32_t iflen = isTail ? 0u : __shfl(firstLen, (int)jj);
-            const uint32_t iexit = isTail ? 0u : __shfl(myExit, (int)jj);
+            const uint32_t ipos = isTail ? ce : gc_readlane(it.pos, jj);
+            const uint32_t ilen = isTail ? 0u : gc_readlane(it.len, jj);
+            const uint32_t ioff = isTail ? 0u : gc_readlane(it.off, jj);
+            const uint32_t iflen = isTail ? 0u : gc_readlane(firstLen, jj);
+            const uint32_t iexit = isTail ? 0u : gc_readlane(myExit, jj);
             const uint32_t sAfterPrev = exitState;
-            // literals [cursor, ipos)
-            for (uint32_t lp = cursor; lp < ipos; lp += LZE_LIT_TILE) {
-                const uint32_t cntL = ipos - lp < LZE_LIT_TILE ? ipos - lp : LZE_LIT_TILE;
-                if (lane < cntL) {
-                    const uint32_t p = lp + lane, i = p - cursor;
+            // literals [cursor, ipos): 7 literals x 9 entries per group, lane = (literal, tree depth), entries in closed form
+            for (uint32_t lp = cursor; lp < ipos; lp += 7u) {
+                const uint32_t cntL = ipos - lp < 7u ? ipos - lp : 7u;
+                const uint32_t li = lane / 9u, d = lane - li * 9u;          // literal in group, entry 0 = isMatch, 1..8 = tree depth
+                uint32_t e = 0;
+                if (li < cntL) {
+                    const uint32_t p = lp + li, i = p - cursor;
                     const uint32_t st = lz_lit_advance(sAfterPrev, i);
-                    const uint32_t prev = (blockBase + p) ? S[(int64_t)p - 1] : 0u;
-                    const uint32_t mb = st >= 7u ? S[(int64_t)p - (int64_t)prevOff] : 0u;
-                    lz_gen_literal(&sLit[lane * 9u], S[p], prev, mb, st, p & 3u);
+                    const uint32_t cur = S[p];
+                    if (d == 0u) e = ENT(LZP_ISMATCH + st * 4u + (p & 3u), 0);
+                    else {
+                        const uint32_t prev = (blockBase + p) ? S[(int64_t)p - 1] : 0u;
+                        const uint32_t pb = LZP_LITERAL + 0x300u * (prev >> (8u - GC_LZMA_LC));
+                        const uint32_t m = (0x100u | cur) >> (9u - d), bit = (cur >> (8u - d)) & 1u;
+                        uint32_t idx = pb + m;
+                        if (st >= 7u) {                                      // matched literal (LzmaDec.c MATCHED_LITER_DEC)
+                            const uint32_t mb = S[(int64_t)p - (int64_t)prevOff];
+                            // still "matching" at depth d iff the d-1 bits above agree; then the node is selected by the match bit too
+                            const bool on = ((cur ^ mb) >> (9u - d)) == 0u;
+                            if (on) idx += 0x100u + (((mb >> (8u - d)) & 1u) << 8);
+                        }
+                        e = ENT(idx, bit);
+                    }
                 }
-                gc_wave_sync();
-                if (lane == 0) rc_run(rc, sLit, cntL * 9u, P);
-                gc_wave_sync();
+                rc_consume(rc, e, cntL * 9u, 9u, P, lane);
             }
             if (isTail) { cursor = ce; break; }
             // the match itself (first piece pre-generated by its lane), then continuation pieces of very long matches
-            if (lane == 0) rc_run(rc, &sMat[jj * 24u], sMatN[jj], P);
+            { const uint32_t ne = gc_uniform(sMatN[jj]); rc_consume(rc, lane < ne ? sMat[jj * 24u + lane] : 0u, ne, 24u, P, lane); }
             if (ilen > iflen) {
                 // state after the first piece (match 7/10, rep 8/11); every further piece is a rep0 coded from a state >= 7
-                uint32_t done = iflen, st = __shfl(stAfterFirst, (int)jj);
+                uint32_t done = iflen, st = gc_readlane(stAfterFirst, jj);
                 while (done < ilen) {
                     uint32_t piece = ilen - done < 273u ? ilen - done : 273u;
                     if (ilen - done - piece == 1u) piece--;
-                    if (lane == 0) { const uint32_t ne = lz_gen_match(sLit, 1u, piece, ioff - 1u, st, (ipos + done) & 3u); rc_run(rc, sLit, ne, P); }
+                    if (lane == 0) sPieceN = lz_gen_match(sPiece, 1u, piece, ioff - 1u, st, (ipos + done) & 3u);
+                    gc_wave_sync();
+                    { const uint32_t ne = gc_uniform(sPieceN); rc_consume(rc, lane < ne ? sPiece[lane] : 0u, ne, 24u, P, lane); }
                     gc_wave_sync();
                     st = 11u; done += piece;
                 }
             }
             cursor = ipos + ilen; exitState = iexit; prevOff = ioff;
         }
-        { const uint32_t r = __shfl(runIncl, 63); if (cnt) carryRun = r; }
+        { const uint32_t r = gc_readlane(runIncl, 63u); if (cnt) carryRun = r; }
         gc_wave_sync();
     }
 
     // flush (RC_flush: 5 x shiftLow) and report
+    for (int i = 0; i < 5; i++) rc_shift_low(rc, lane);
     if (lane == 0) {
-        for (int i = 0; i < 5; i++) rc_shift_low(rc);
         GcLzmaChunkInfo ci; ci.usize = ce - cs; ci.csize = rc.outPos < rc.outCap ? rc.outPos : 0xFFFFFFFFu;   // 0xFFFFFFFF: store raw
         cinfo[chunk] = ci;
     }
