@@ -109,7 +109,7 @@ class Flzma2Encoder(_EncoderBase):
     """Mirror of NCompress::NLzma2::CFastEncoder (CPP/7zip/Compress/Lzma2Encoder.h:60-100; Code() at Lzma2Encoder.cpp:260-350):
     bytes -> LZMA2 chunk stream; `coder_props()` is what WriteCoderProperties emits (1 byte dictionary size, :353-364)."""
 
-    KERNELS = ("lz", "prep", "enc", "plan", "emit", "total")
+    KERNELS = ("lz", "prep", "model", "rc", "plan", "emit", "total")
     NO_END_MARK = 1
 
     def __init__(self, device=0, level=5, lib_path=None):
@@ -140,7 +140,7 @@ class Flzma2Encoder(_EncoderBase):
         return n.value
 
     def last_timing_ms(self):
-        ms = (C.c_float * 6)()
+        ms = (C.c_float * 7)()
         self._check(self._lib.gc_flzma2_last_timing(self._ctx, ms), "gc_flzma2_last_timing")
         return dict(zip(self.KERNELS, [float(x) for x in ms]))
 

@@ -28,7 +28,8 @@ extern "C" __global__ void gc_zstd_emit_kernel(const uint8_t*, uint64_t, const u
                                                const GcFramePlan*, const uint64_t*, uint8_t*);
 
 extern "C" __global__ void gc_lzma2_prep_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t*, uint32_t*);
-extern "C" __global__ void gc_lzma2_enc_kernel(const uint8_t*, uint64_t, const uint64_t*, const uint32_t*, uint32_t, uint8_t*, GcLzmaChunkInfo*);
+extern "C" __global__ void gc_lzma2_model_kernel(const uint8_t*, uint64_t, const uint64_t*, const uint32_t*, uint32_t, uint16_t*, GcLzmaChunkInfo*);
+extern "C" __global__ void gc_lzma2_rc_kernel(const uint16_t*, uint32_t, uint32_t, uint8_t*, GcLzmaChunkInfo*);
 extern "C" __global__ void gc_lzma2_plan_kernel(const GcLzmaChunkInfo*, uint32_t, uint64_t, uint32_t, GcLzmaPlan*, uint64_t*);
 extern "C" __global__ void gc_lzma2_emit_kernel(const uint8_t*, uint32_t, const uint8_t*, const GcLzmaChunkInfo*, const GcLzmaPlan*, uint32_t,
                                                 uint32_t, const uint64_t*, uint8_t*);
@@ -44,7 +45,7 @@ struct gc_ctx {
     GcSeqRaw* seqRaw; uint8_t* lit; GcBlockMeta* meta;
     uint64_t* seqPacked; uint32_t* seqOff; uint8_t* codes; uint16_t* stOut;
     uint8_t* litSec; uint8_t* seqSec; GcSectionInfo* info; GcFramePlan* plan; uint64_t* result;
-    uint32_t* lzNM; GcLzmaChunkInfo* lzInfo; GcLzmaPlan* lzPlan;       // FLZMA2 path (M aliases seqPacked, chunk staging aliases litSec)
+    uint32_t* lzNM; GcLzmaChunkInfo* lzInfo; GcLzmaPlan* lzPlan; uint16_t* lzStream; size_t lzStreamCap;       // FLZMA2 path (M aliases seqPacked, chunk staging aliases litSec)
     int lastCodec;            // 0 zstd, 1 flzma2: which kernels the events of the last call bracket
     uint64_t* hostResult;     // pinned
     // staging for the host-buffer entry point
@@ -97,7 +98,7 @@ static void free_workspace(gc_ctx* c)
 {
     hipFree(c->seqRaw); hipFree(c->lit); hipFree(c->meta); hipFree(c->seqPacked); hipFree(c->seqOff); hipFree(c->codes);
     hipFree(c->stOut); hipFree(c->litSec); hipFree(c->seqSec); hipFree(c->info); hipFree(c->plan);
-    hipFree(c->lzNM); hipFree(c->lzInfo); hipFree(c->lzPlan); c->lzNM = nullptr; c->lzInfo = nullptr; c->lzPlan = nullptr;
+    hipFree(c->lzNM); hipFree(c->lzInfo); hipFree(c->lzPlan); hipFree(c->lzStream); c->lzStream = nullptr; c->lzStreamCap = 0; c->lzNM = nullptr; c->lzInfo = nullptr; c->lzPlan = nullptr;
     c->seqRaw = nullptr; c->lit = nullptr; c->meta = nullptr; c->seqPacked = nullptr; c->seqOff = nullptr; c->codes = nullptr;
     c->stOut = nullptr; c->litSec = nullptr; c->seqSec = nullptr; c->info = nullptr; c->plan = nullptr; c->capBlocks = 0;
 }
@@ -250,9 +251,9 @@ extern "C" int gc_zstd_phase_profile(gc_ctx* c, double cyclesPerBlock[GC_LZ_PHAS
 // level -> chunk size: smaller chunks = more independent range coders in flight (faster), more state resets (larger).
 static uint32_t flzma2_chunk_log(int level)
 {
-    if (level <= 2) return 13u;
-    if (level <= 4) return 14u;
-    if (level <= 6) return 15u;
+    if (level <= 3) return 13u;
+    if (level <= 5) return 14u;
+    if (level <= 7) return 15u;
     return 16u;
 }
 
@@ -287,13 +288,24 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     const uint32_t chunkLog = flzma2_chunk_log(level);
     const uint32_t nChunks = nBlocks * (GC_ZSTD_BLOCK_MAX >> chunkLog);
     const uint8_t* src = (const uint8_t*)d_src;
+    {   // (p, bit) stream between the model kernel and the range coder: 2 bytes per coded bit, <= 9 coded bits per input byte
+        const size_t need = (size_t)nChunks * GC_LZMA_STREAM_WORDS(chunkLog) * sizeof(uint16_t);
+        if (need > c->lzStreamCap) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            hipFree(c->lzStream); c->lzStream = nullptr; c->lzStreamCap = 0;
+            if (hipMalloc((void**)&c->lzStream, need) != hipSuccess) { snprintf(c->err, sizeof(c->err), "stream workspace of %zu bytes failed", need); return GC_ERR_NOMEM; }
+            c->lzStreamCap = need;
+        }
+    }
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     GC_LAUNCH(gc_zstd_lz_kernel, nBlocks, 1024, c->stream, src, (uint64_t)n, c->seqRaw, c->lit, c->meta, (unsigned long long*)nullptr);
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     GC_LAUNCH(gc_lzma2_prep_kernel, nBlocks, 256, c->stream, (const GcSeqRaw*)c->seqRaw, (const GcBlockMeta*)c->meta, c->seqPacked, c->lzNM);
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-    GC_LAUNCH(gc_lzma2_enc_kernel, nChunks, 64, c->stream, src, (uint64_t)n, (const uint64_t*)c->seqPacked, (const uint32_t*)c->lzNM, chunkLog,
-              c->litSec, c->lzInfo);
+    GC_LAUNCH(gc_lzma2_model_kernel, nChunks, 64, c->stream, src, (uint64_t)n, (const uint64_t*)c->seqPacked, (const uint32_t*)c->lzNM, chunkLog,
+              c->lzStream, c->lzInfo);
+    HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+    GC_LAUNCH(gc_lzma2_rc_kernel, (nChunks + 63u) / 64u, 64, c->stream, (const uint16_t*)c->lzStream, chunkLog, nChunks, c->litSec, c->lzInfo);
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     GC_LAUNCH(gc_lzma2_plan_kernel, 1, 1024, c->stream, (const GcLzmaChunkInfo*)c->lzInfo, nChunks, (uint64_t)dstCap, (uint32_t)flags, c->lzPlan, c->result);
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
@@ -307,11 +319,16 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
 
 extern "C" int gc_flzma2_finish(gc_ctx* c, size_t* compressedSize) { return gc_zstd_finish(c, compressedSize); }
 
-extern "C" int gc_flzma2_last_timing(gc_ctx* c, float ms[6])
+extern "C" int gc_flzma2_last_timing(gc_ctx* c, float ms[7])
 {
     if (!c || !c->timed || c->pending || c->lastCodec != 1) return GC_ERR_PARAM;
-    for (int i = 0; i < 5; i++) HIPCHK(c, hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));   // lz, prep, enc, plan, emit
-    HIPCHK(c, hipEventElapsedTime(&ms[5], c->ev[0], c->ev[5]));
+    HIPCHK(c, hipEventElapsedTime(&ms[0], c->ev[0], c->ev[1]));     // lz
+    HIPCHK(c, hipEventElapsedTime(&ms[1], c->ev[1], c->ev[2]));     // prep
+    HIPCHK(c, hipEventElapsedTime(&ms[2], c->ev[2], c->ev[6]));     // model
+    HIPCHK(c, hipEventElapsedTime(&ms[3], c->ev[6], c->ev[3]));     // rc
+    HIPCHK(c, hipEventElapsedTime(&ms[4], c->ev[3], c->ev[4]));     // plan
+    HIPCHK(c, hipEventElapsedTime(&ms[5], c->ev[4], c->ev[5]));     // emit
+    HIPCHK(c, hipEventElapsedTime(&ms[6], c->ev[0], c->ev[5]));     // first kernel start -> last kernel end
     return GC_OK;
 }
 

@@ -20,6 +20,8 @@ __device__ __forceinline__ uint64_t gc_ld64_guard(const uint8_t* src, uint64_t p
     return v;
 }
 
+struct __attribute__((aligned(16))) GcU4 { uint32_t x, y, z, w; };     // one global_load_dwordx4
+
 __device__ __forceinline__ uint32_t gc_hibit32(uint32_t v) { return 31u - (uint32_t)__clz((int)v); }   // v != 0
 __device__ __forceinline__ uint32_t gc_ctz64(uint64_t v) { return (uint32_t)__ffsll((long long)v) - 1u; } // v != 0
 

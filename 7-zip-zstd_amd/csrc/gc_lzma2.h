@@ -30,5 +30,7 @@
 #define LZP_LITERAL    (LZP_ALIGN + 16u)                // 1380: 0x300 << lc
 #define LZP_TOTAL      (LZP_LITERAL + (0x300u << GC_LZMA_LC))
 
-struct GcLzmaChunkInfo { uint32_t usize; uint32_t csize; };   // csize 0xFFFFFFFF: store raw; usize 0: chunk does not exist
+struct GcLzmaChunkInfo { uint32_t usize; uint32_t csize; uint32_t nWords; uint32_t pad; };   // csize 0xFFFFFFFF: store raw; usize 0: chunk does not exist
+// words of (p, bit) stream reserved per chunk: a literal is the densest symbol (9 coded bits per byte); keeps 16-byte alignment
+#define GC_LZMA_STREAM_WORDS(chunkLog) ((9u << (chunkLog)) + 64u)
 struct GcLzmaPlan { uint64_t off; uint32_t size; uint32_t kind; };   // kind 0 absent, 1 LZMA, 2 raw

@@ -15,13 +15,15 @@
 // chunks), exactly the device Fast-LZMA2 itself uses to run slices on several threads (lzma2_enc.h:22, lzma2_enc.c:2040-2075).
 //   L1 gc_lzma2_prep_kernel  one workgroup per 128 KiB match-finder block: K1's capped records -> merged matches with
 //                            their start positions (scan), M[j] = pos | len<<17 | off<<34
-//   L2 gc_lzma2_enc_kernel   one WAVE per chunk.  The 64 lanes turn symbols into (probability index, bit) entries in
+//   L2 gc_lzma2_model_kernel one WAVE per chunk.  The 64 lanes turn symbols into (probability index, bit) entries in
 //                            parallel -- state machine, repeat-distance history, slot/length trees are all computed
 //                            per symbol from local information (scans), nothing serial.  The probability updates of one
-//                            symbol touch distinct entries, so they are applied by all lanes at once (LDS read-modify-write);
-//                            what remains serial is the range recurrence (bound = (range >> 11) * p ...), a wave-uniform
-//                            loop that runs on the scalar unit with the probabilities fetched by v_readlane.
-//   L3/L4 plan + emit        chunk headers and concatenation (gc_lzma2_frame.hip)
+//                            symbol touch distinct entries, so they are applied by all lanes at once (LDS read-modify-write).
+//                            Output: the chunk's stream of (probability, bit) words in HBM -- the adaptive model is now
+//                            fully resolved and no longer needed.
+//   L3 gc_lzma2_rc_kernel    one LANE per chunk: what remains serial is the range recurrence (bound = (range >> 11) * p,
+//                            renormalise, carry), register-only work, so 64 chunks advance per wave instruction.
+//   L4/L5 plan + emit        chunk headers and concatenation (gc_lzma2_frame.hip)
 #include "gc_common.h"
 #include "gc_device.h"
 #include "gc_lzma2.h"
@@ -79,31 +81,19 @@ gc_lzma2_prep_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __r
 }
 
 // ---------------------------------------------------------------------------------------------- L2: chunk encoder
-struct LzRc { uint64_t low; uint32_t range; uint32_t cache; uint32_t cacheSize; uint32_t outPos; uint32_t outCap; uint8_t* out; };
+// (p, bit) stream between L2 and L3: one 16-bit word per coded bit.
+//   adaptive bit : bit11 = bit, bits 0..10 = probability of a 0 BEFORE the update
+//   direct bit   : bit14 set, bit11 = bit   (range halving, no probability)
+#define LZW_BIT    0x0800u
+#define LZW_DIRECT 0x4000u
+struct LzStream { uint16_t* w; uint32_t pos; };                 // pos is wave-uniform
 
-__device__ __forceinline__ void rc_shift_low(LzRc& rc, uint32_t lane)     // range_enc.c RC_shiftLow; every field is wave-uniform
-{
-    if ((uint32_t)rc.low < 0xFF000000u || (rc.low >> 32) != 0) {
-        const uint32_t carry = (uint32_t)(rc.low >> 32);
-        uint32_t c = rc.cache;
-        do {
-            if (lane == 0u && rc.outPos < rc.outCap) rc.out[rc.outPos] = (uint8_t)(c + carry);
-            rc.outPos++;
-            c = 0xFFu;
-        } while (--rc.cacheSize != 0);
-        rc.cache = ((uint32_t)rc.low >> 24) & 0xFFu;
-    }
-    rc.cacheSize++;
-    rc.low = (rc.low & 0x00FFFFFFull) << 8;
-}
-
-// Consume the entries of ONE group held one per lane (lane k < cnt holds entry k, in coding order).
-//   * probability update: all lanes at once.  `rounds` lane groups of `per` lanes are applied one after the other
-//     (round r = lanes [r*per, (r+1)*per)): inside one symbol all indices are distinct by construction (one node per tree
-//     depth), different symbols may share indices, so symbols are applied in order (LDS operations of a wave are in order);
-//   * range recurrence: a wave-uniform loop -- the probabilities come back through v_readlane into SGPRs and range / low /
-//     cache live in SGPRs, so the only serial work runs on the scalar unit.
-__device__ __forceinline__ void rc_consume(LzRc& rc, uint32_t e, uint32_t cnt, uint32_t per, uint16_t* P, uint32_t lane)
+// Apply the entries of ONE group held one per lane (lane k < cnt holds entry k, in coding order) to the probability model
+// and append the resulting words to the chunk's stream.  Probability updates: all lanes at once, in `cnt/per` rounds of
+// `per` lanes (round r = lanes [r*per, (r+1)*per)): inside one symbol all indices are distinct by construction (one node
+// per tree depth); different symbols may share indices, so symbols are applied in order (LDS operations of a wave are in
+// order).  Nothing here is serial in the number of coded bits.
+__device__ __forceinline__ void lz_emit_group(LzStream& st, uint32_t e, uint32_t cnt, uint32_t per, uint16_t* P, uint32_t lane)
 {
     const bool valid = lane < cnt;
     const bool isDirect = valid && (e >> 31) != 0u;
@@ -116,30 +106,18 @@ __device__ __forceinline__ void rc_consume(LzRc& rc, uint32_t e, uint32_t cnt, u
         }
         gc_wave_sync();
     }
-    const uint64_t bits = __ballot(valid && (e & 1u));
     const uint64_t dmask = __ballot(isDirect);
-    GcPub pubP, pubE;
-    gc_publish(pubP, p);
-    if (dmask) gc_publish(pubE, e);
-    for (uint32_t k = 0; k < cnt; k++) {
-#ifdef HIPEMU
-        if (lane == 0 && getenv("GC_TRACE_RC")) fprintf(stderr, "E %u %u p=%u\n", (dmask >> k) & 1ull ? 0xFFFFu : 0u, (unsigned)((bits >> k) & 1ull), gc_peek(pubP, k));
-#endif
-        if ((dmask >> k) & 1ull) {                                          // direct bits, most significant first
-            const uint32_t ev = gc_peek(pubE, k);
-            uint32_t nb = (ev >> 26) & 31u; const uint32_t v = ev & 0x03FFFFFFu;
-            while (nb) {
-                nb--;
-                rc.range >>= 1;
-                if ((v >> nb) & 1u) rc.low += rc.range;
-                if (rc.range < (1u << 24)) { rc.range <<= 8; rc_shift_low(rc, lane); }
-            }
-        } else {
-            const uint32_t bound = (rc.range >> 11) * gc_peek(pubP, k);
-            if ((bits >> k) & 1ull) { rc.low += bound; rc.range -= bound; }
-            else rc.range = bound;
-            if (rc.range < (1u << 24)) { rc.range <<= 8; rc_shift_low(rc, lane); }
-        }
+    if (dmask == 0ull) {                                             // common case: one word per lane, one coalesced store
+        if (valid) st.w[st.pos + lane] = (uint16_t)(p | ((e & 1u) ? LZW_BIT : 0u));
+        st.pos += cnt;
+    } else {                                                         // a far match: its direct-bits entry expands to one word per bit
+        const uint32_t nb = isDirect ? (e >> 26) & 31u : 0u;
+        const uint32_t width = valid ? (isDirect ? nb : 1u) : 0u;
+        const uint32_t incl = gc_wave_incl_sum(width);
+        const uint32_t at = st.pos + incl - width;
+        if (valid && !isDirect) st.w[at] = (uint16_t)(p | ((e & 1u) ? LZW_BIT : 0u));
+        if (isDirect) { const uint32_t v = e & 0x03FFFFFFu; for (uint32_t i = 0; i < nb; i++) st.w[at + i] = (uint16_t)(LZW_DIRECT | (((v >> (nb - 1u - i)) & 1u) ? LZW_BIT : 0u)); }
+        st.pos += gc_readlane(incl, 63u);
     }
 }
 
@@ -241,9 +219,9 @@ __device__ __forceinline__ LzItem lz_item(const uint64_t* M, uint32_t idx, uint3
 }
 
 extern "C" __global__ void __launch_bounds__(64)
-gc_lzma2_enc_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const uint64_t* __restrict__ Mall,
-                    const uint32_t* __restrict__ nM, uint32_t chunkLog, uint8_t* __restrict__ chunkOut,
-                    GcLzmaChunkInfo* __restrict__ cinfo)
+gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const uint64_t* __restrict__ Mall,
+                      const uint32_t* __restrict__ nM, uint32_t chunkLog, uint16_t* __restrict__ stream,
+                      GcLzmaChunkInfo* __restrict__ cinfo)
 {
     __shared__ uint16_t P[LZP_TOTAL];
     __shared__ uint32_t sPiece[24]; __shared__ uint32_t sPieceN;
@@ -257,7 +235,7 @@ gc_lzma2_enc_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const uin
     const uint64_t blockBase = (uint64_t)b * GC_ZSTD_BLOCK_MAX;
     const uint32_t blockLen = (uint32_t)((srcSize - blockBase) < GC_ZSTD_BLOCK_MAX ? (srcSize - blockBase) : GC_ZSTD_BLOCK_MAX);
     const uint32_t cs = cInB * chunkSize;
-    if (cs >= blockLen) { if (lane == 0) { cinfo[chunk].usize = 0; cinfo[chunk].csize = 0; } return; }
+    if (cs >= blockLen) { if (lane == 0) { cinfo[chunk].usize = 0; cinfo[chunk].csize = 0; cinfo[chunk].nWords = 0; } return; }
     const uint32_t ce = cs + chunkSize < blockLen ? cs + chunkSize : blockLen;
     const uint8_t* S = src + blockBase;                   // block-relative addressing; S[-1] exists iff blockBase > 0
     const uint64_t* M = Mall + (uint64_t)b * GC_MAX_SEQ_PER_BLOCK;
@@ -278,9 +256,7 @@ gc_lzma2_enc_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const uin
     if (first < last && lz_item(M, last - 1u, cs, ce).len < 2u) last--;
     first = gc_uniform(first); last = gc_uniform(last);     // keep the walk below on the scalar unit
 
-    LzRc rc; rc.low = 0; rc.range = 0xFFFFFFFFu; rc.cache = 0; rc.cacheSize = 1; rc.outPos = 0;
-    rc.outCap = (ce - cs);                                 // beyond this the chunk is stored raw anyway
-    rc.out = chunkOut + ((uint64_t)chunk << chunkLog);
+    LzStream strm; strm.w = stream + (uint64_t)chunk * GC_LZMA_STREAM_WORDS(chunkLog); strm.pos = 0;
     gc_wave_sync();
 
     uint32_t cursor = cs;             // next position to encode (uniform)
@@ -355,11 +331,11 @@ gc_lzma2_enc_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const uin
                         e = ENT(idx, bit);
                     }
                 }
-                rc_consume(rc, e, cntL * 9u, 9u, P, lane);
+                lz_emit_group(strm, e, cntL * 9u, 9u, P, lane);
             }
             if (isTail) { cursor = ce; break; }
             // the match itself (first piece pre-generated by its lane), then continuation pieces of very long matches
-            { const uint32_t ne = gc_uniform(sMatN[jj]); rc_consume(rc, lane < ne ? sMat[jj * 24u + lane] : 0u, ne, 24u, P, lane); }
+            { const uint32_t ne = gc_uniform(sMatN[jj]); lz_emit_group(strm, lane < ne ? sMat[jj * 24u + lane] : 0u, ne, 24u, P, lane); }
             if (ilen > iflen) {
                 // state after the first piece (match 7/10, rep 8/11); every further piece is a rep0 coded from a state >= 7
                 uint32_t done = iflen, st = gc_readlane(stAfterFirst, jj);
@@ -368,7 +344,7 @@ gc_lzma2_enc_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const uin
                     if (ilen - done - piece == 1u) piece--;
                     if (lane == 0) sPieceN = lz_gen_match(sPiece, 1u, piece, ioff - 1u, st, (ipos + done) & 3u);
                     gc_wave_sync();
-                    { const uint32_t ne = gc_uniform(sPieceN); rc_consume(rc, lane < ne ? sPiece[lane] : 0u, ne, 24u, P, lane); }
+                    { const uint32_t ne = gc_uniform(sPieceN); lz_emit_group(strm, lane < ne ? sPiece[lane] : 0u, ne, 24u, P, lane); }
                     gc_wave_sync();
                     st = 11u; done += piece;
                 }
@@ -379,10 +355,65 @@ gc_lzma2_enc_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const uin
         gc_wave_sync();
     }
 
-    // flush (RC_flush: 5 x shiftLow) and report
-    for (int i = 0; i < 5; i++) rc_shift_low(rc, lane);
-    if (lane == 0) {
-        GcLzmaChunkInfo ci; ci.usize = ce - cs; ci.csize = rc.outPos < rc.outCap ? rc.outPos : 0xFFFFFFFFu;   // 0xFFFFFFFF: store raw
-        cinfo[chunk] = ci;
+    if (lane == 0) { GcLzmaChunkInfo ci; ci.usize = ce - cs; ci.csize = 0; ci.nWords = strm.pos; cinfo[chunk] = ci; }
+}
+
+// ---------------------------------------------------------------------------------------------- L3: range coder
+// One chunk per LANE.  With the probabilities already resolved, what is left of LZMA's serial dependency is the range
+// recurrence itself -- bound = (range >> 11) * p; range = bit ? range - bound : bound; renormalise -- about two dozen
+// register-only instructions per coded bit (C/fast-lzma2/range_enc.h:62-152, RC_shiftLow range_enc.c:123-140), so 64
+// chunks advance per wave instruction and the latency of one chunk's chain is shared 64 ways.
+struct LzRc { uint64_t low; uint32_t range; uint32_t cache; uint32_t cacheSize; uint32_t outPos; uint32_t outCap; uint8_t* out; };
+
+__device__ __forceinline__ void rc_shift_low(LzRc& rc)
+{
+    if ((uint32_t)rc.low < 0xFF000000u || (rc.low >> 32) != 0) {
+        const uint32_t carry = (uint32_t)(rc.low >> 32);
+        uint32_t c = rc.cache;
+        do {
+            if (rc.outPos < rc.outCap) rc.out[rc.outPos] = (uint8_t)(c + carry);
+            rc.outPos++;
+            c = 0xFFu;
+        } while (--rc.cacheSize != 0);
+        rc.cache = ((uint32_t)rc.low >> 24) & 0xFFu;
     }
+    rc.cacheSize++;
+    rc.low = (rc.low & 0x00FFFFFFull) << 8;
+}
+
+__device__ __forceinline__ void rc_word(LzRc& rc, uint32_t w)
+{
+    const bool bit = (w & LZW_BIT) != 0u;
+    if (w & LZW_DIRECT) { rc.range >>= 1; if (bit) rc.low += rc.range; }
+    else {
+        const uint32_t bound = (rc.range >> 11) * (w & 0x7FFu);
+        if (bit) { rc.low += bound; rc.range -= bound; } else rc.range = bound;
+    }
+    if (rc.range < (1u << 24)) { rc.range <<= 8; rc_shift_low(rc); }
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+gc_lzma2_rc_kernel(const uint16_t* __restrict__ stream, uint32_t chunkLog, uint32_t nChunks, uint8_t* __restrict__ chunkOut,
+                   GcLzmaChunkInfo* __restrict__ cinfo)
+{
+    const uint32_t chunk = blockIdx.x * 64u + threadIdx.x;
+    if (chunk >= nChunks) return;
+    const GcLzmaChunkInfo ci = cinfo[chunk];
+    if (ci.usize == 0u) return;
+    const uint16_t* W = stream + (uint64_t)chunk * GC_LZMA_STREAM_WORDS(chunkLog);     // 16-byte aligned
+    LzRc rc; rc.low = 0; rc.range = 0xFFFFFFFFu; rc.cache = 0; rc.cacheSize = 1; rc.outPos = 0;
+    rc.outCap = ci.usize;                                  // a chunk that does not shrink is stored raw anyway
+    rc.out = chunkOut + ((uint64_t)chunk << chunkLog);
+    const uint32_t n = ci.nWords, nVec = n >> 3;
+    const GcU4* V = (const GcU4*)W;
+    GcU4 nxt; nxt.x = nxt.y = nxt.z = nxt.w = 0; if (nVec) nxt = V[0];
+    for (uint32_t i = 0; i < nVec; i++) {                  // 8 words per 16-byte load, next load in flight while these are coded
+        const GcU4 cur = nxt;
+        if (i + 1u < nVec) nxt = V[i + 1u];
+        rc_word(rc, cur.x & 0xFFFFu); rc_word(rc, cur.x >> 16); rc_word(rc, cur.y & 0xFFFFu); rc_word(rc, cur.y >> 16);
+        rc_word(rc, cur.z & 0xFFFFu); rc_word(rc, cur.z >> 16); rc_word(rc, cur.w & 0xFFFFu); rc_word(rc, cur.w >> 16);
+    }
+    for (uint32_t k = nVec << 3; k < n; k++) rc_word(rc, W[k]);
+    for (int i = 0; i < 5; i++) rc_shift_low(rc);          // RC_flush
+    cinfo[chunk].csize = rc.outPos < rc.outCap ? rc.outPos : 0xFFFFFFFFu;      // 0xFFFFFFFF: store raw
 }

@@ -80,8 +80,9 @@ int           gc_flzma2_compress_device(gc_ctx* ctx, const void* d_src, size_t n
 int           gc_flzma2_finish(gc_ctx* ctx, size_t* compressedSize);
 int           gc_flzma2_compress_host(gc_ctx* ctx, const void* src, size_t n, void* dst, size_t dstCapacity, int level, unsigned flags,
                                       size_t* compressedSize);
-/* ms[0..4] = lz (match finder), prep, enc (range coder), plan, emit; ms[5] = first kernel start -> last kernel end */
-int           gc_flzma2_last_timing(gc_ctx* ctx, float ms[6]);
+/* ms[0..5] = lz (match finder), prep, model (symbols -> probabilities), rc (range coder), plan, emit;
+ * ms[6] = first kernel start -> last kernel end */
+int           gc_flzma2_last_timing(gc_ctx* ctx, float ms[7]);
 
 /* raw stream handle (hipStream_t) so callers can order their own work against the context */
 void*       gc_ctx_stream(gc_ctx* ctx);
