@@ -25,7 +25,8 @@ EXPORTS = ["gc_device_count", "gc_ctx_create", "gc_ctx_destroy", "gc_last_error_
            "gc_zstd_compress_device", "gc_zstd_finish", "gc_zstd_compress_host", "gc_zstd_last_timing", "gc_ctx_stream",
            "gc_zstd_set_phase_profile", "gc_zstd_phase_profile",
            "gc_flzma2_compress_bound", "gc_flzma2_dict_prop", "gc_flzma2_compress_device", "gc_flzma2_finish", "gc_flzma2_compress_host",
-           "gc_flzma2_last_timing"]
+           "gc_flzma2_last_timing",
+           "gc_brotli_compress_bound", "gc_brotli_compress_device", "gc_brotli_finish", "gc_brotli_compress_host", "gc_brotli_last_timing"]
 
 
 class GpuCodecError(RuntimeError):
@@ -71,6 +72,16 @@ def load_library(path=None):
     lib.gc_flzma2_compress_host.restype = C.c_int
     lib.gc_flzma2_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.gc_flzma2_last_timing.restype = C.c_int
+    lib.gc_brotli_compress_bound.argtypes = [C.c_size_t]
+    lib.gc_brotli_compress_bound.restype = C.c_size_t
+    lib.gc_brotli_compress_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int]
+    lib.gc_brotli_compress_device.restype = C.c_int
+    lib.gc_brotli_finish.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    lib.gc_brotli_finish.restype = C.c_int
+    lib.gc_brotli_compress_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_size_t)]
+    lib.gc_brotli_compress_host.restype = C.c_int
+    lib.gc_brotli_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    lib.gc_brotli_last_timing.restype = C.c_int
     lib.gc_ctx_stream.argtypes = [C.c_void_p]
     lib.gc_ctx_stream.restype = C.c_void_p
     return lib
@@ -142,6 +153,45 @@ class Flzma2Encoder(_EncoderBase):
     def last_timing_ms(self):
         ms = (C.c_float * 7)()
         self._check(self._lib.gc_flzma2_last_timing(self._ctx, ms), "gc_flzma2_last_timing")
+        return dict(zip(self.KERNELS, [float(x) for x in ms]))
+
+
+class BrotliEncoder(_EncoderBase):
+    """Mirror of NCompress::NBROTLI::CEncoder (CPP/7zip/Compress/BrotliEncoder.h:35-70; Code() at BrotliEncoder.cpp:118-164):
+    bytes -> brotli-mt framed chunks; `coder_props()` is the 3-byte blob {1, 0, level} of BrotliEncoder.h:18-32."""
+
+    KERNELS = ("lz", "block", "plan", "emit", "total")
+
+    def __init__(self, device=0, level=6, lib_path=None):
+        super().__init__(device, level, lib_path)
+
+    def compress_bound(self, n):
+        return self._lib.gc_brotli_compress_bound(n)
+
+    def coder_props(self):
+        return bytes([1, 0, self.level])
+
+    def code(self, data):
+        import numpy as np
+        a = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data, dtype=np.uint8)
+        cap = self.compress_bound(a.size)
+        out = np.empty(cap, dtype=np.uint8)
+        n = C.c_size_t(0)
+        rc = self._lib.gc_brotli_compress_host(self._ctx, a.ctypes.data, a.size, out.ctypes.data, cap, self.level, C.byref(n))
+        self._check(rc, "gc_brotli_compress_host")
+        return out[:n.value]
+
+    def code_device(self, d_src_ptr, n, d_dst_ptr, dst_cap):
+        self._check(self._lib.gc_brotli_compress_device(self._ctx, d_src_ptr, n, d_dst_ptr, dst_cap, self.level), "gc_brotli_compress_device")
+
+    def finish(self):
+        n = C.c_size_t(0)
+        self._check(self._lib.gc_brotli_finish(self._ctx, C.byref(n)), "gc_brotli_finish")
+        return n.value
+
+    def last_timing_ms(self):
+        ms = (C.c_float * 5)()
+        self._check(self._lib.gc_brotli_last_timing(self._ctx, ms), "gc_brotli_last_timing")
         return dict(zip(self.KERNELS, [float(x) for x in ms]))
 
 

@@ -7,6 +7,7 @@
 #include "gpucodec.h"
 #include "gc_common.h"
 #include "gc_lzma2.h"
+#include "gc_brotli.h"
 #ifdef HIPEMU
 #include "hip_runtime_stub.h"
 #else
@@ -34,6 +35,12 @@ extern "C" __global__ void gc_lzma2_plan_kernel(const GcLzmaChunkInfo*, uint32_t
 extern "C" __global__ void gc_lzma2_emit_kernel(const uint8_t*, uint32_t, const uint8_t*, const GcLzmaChunkInfo*, const GcLzmaPlan*, uint32_t,
                                                 uint32_t, const uint64_t*, uint8_t*);
 
+extern "C" __global__ void gc_brotli_block_kernel(const uint8_t*, uint64_t, const GcSeqRaw*, const uint8_t*, const GcBlockMeta*, uint64_t*, uint32_t*,
+                                                  uint32_t, uint32_t*, GcBrotliBlockInfo*);
+extern "C" __global__ void gc_brotli_plan_kernel(const GcBrotliBlockInfo*, uint32_t, uint32_t, uint64_t, GcBrotliPlan*, uint64_t*);
+extern "C" __global__ void gc_brotli_emit_kernel(const uint8_t*, uint64_t, const uint8_t*, const GcBrotliBlockInfo*, const GcBrotliPlan*, uint32_t,
+                                                 uint32_t, const uint64_t*, uint8_t*);
+
 struct gc_ctx {
     int device;
     hipStream_t stream;       // main stream: K1 -> K2 -> (join) -> K4 -> K5
@@ -46,6 +53,7 @@ struct gc_ctx {
     uint64_t* seqPacked; uint32_t* seqOff; uint8_t* codes; uint16_t* stOut;
     uint8_t* litSec; uint8_t* seqSec; GcSectionInfo* info; GcFramePlan* plan; uint64_t* result;
     uint32_t* lzNM; GcLzmaChunkInfo* lzInfo; GcLzmaPlan* lzPlan; uint16_t* lzStream; size_t lzStreamCap;       // FLZMA2 path (M aliases seqPacked, chunk staging aliases litSec)
+    uint8_t* brStage; GcBrotliBlockInfo* brInfo; GcBrotliPlan* brPlan;    // BROTLI path
     int lastCodec;            // 0 zstd, 1 flzma2: which kernels the events of the last call bracket
     uint64_t* hostResult;     // pinned
     // staging for the host-buffer entry point
@@ -98,6 +106,7 @@ static void free_workspace(gc_ctx* c)
 {
     hipFree(c->seqRaw); hipFree(c->lit); hipFree(c->meta); hipFree(c->seqPacked); hipFree(c->seqOff); hipFree(c->codes);
     hipFree(c->stOut); hipFree(c->litSec); hipFree(c->seqSec); hipFree(c->info); hipFree(c->plan);
+    hipFree(c->brStage); hipFree(c->brInfo); hipFree(c->brPlan); c->brStage = nullptr; c->brInfo = nullptr; c->brPlan = nullptr;
     hipFree(c->lzNM); hipFree(c->lzInfo); hipFree(c->lzPlan); hipFree(c->lzStream); c->lzStream = nullptr; c->lzStreamCap = 0; c->lzNM = nullptr; c->lzInfo = nullptr; c->lzPlan = nullptr;
     c->seqRaw = nullptr; c->lit = nullptr; c->meta = nullptr; c->seqPacked = nullptr; c->seqOff = nullptr; c->codes = nullptr;
     c->stOut = nullptr; c->litSec = nullptr; c->seqSec = nullptr; c->info = nullptr; c->plan = nullptr; c->capBlocks = 0;
@@ -136,6 +145,9 @@ static int ensure_workspace(gc_ctx* c, uint32_t nBlocks)
         hipMalloc((void**)&c->seqSec, nb * GC_SEQSEC_STRIDE) != hipSuccess ||
         hipMalloc((void**)&c->info, nb * sizeof(GcSectionInfo)) != hipSuccess ||
         hipMalloc((void**)&c->plan, nb * sizeof(GcFramePlan)) != hipSuccess ||
+        hipMalloc((void**)&c->brStage, nb * GC_BR_STAGE_STRIDE) != hipSuccess ||
+        hipMalloc((void**)&c->brInfo, nb * sizeof(GcBrotliBlockInfo)) != hipSuccess ||
+        hipMalloc((void**)&c->brPlan, nb * sizeof(GcBrotliPlan)) != hipSuccess ||
         hipMalloc((void**)&c->lzNM, nb * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void**)&c->lzInfo, nb * (GC_ZSTD_BLOCK_MAX >> GC_LZMA_CHUNK_LOG_MIN) * sizeof(GcLzmaChunkInfo)) != hipSuccess ||
         hipMalloc((void**)&c->lzPlan, nb * (GC_ZSTD_BLOCK_MAX >> GC_LZMA_CHUNK_LOG_MIN) * sizeof(GcLzmaPlan)) != hipSuccess) {
@@ -341,6 +353,83 @@ extern "C" int gc_flzma2_compress_host(gc_ctx* c, const void* src, size_t n, voi
     if (bound > c->dOutCap) { hipFree(c->dOut); c->dOut = nullptr; c->dOutCap = 0; if (hipMalloc((void**)&c->dOut, bound) != hipSuccess) return GC_ERR_NOMEM; c->dOutCap = bound; }
     if (n) HIPCHK(c, hipMemcpyAsync(c->dIn, src, n, hipMemcpyHostToDevice, c->stream));
     int rc = gc_flzma2_compress_device(c, c->dIn, n, c->dOut, c->dOutCap, level, flags);
+    if (rc != GC_OK) return rc;
+    size_t sz = 0;
+    rc = gc_zstd_finish(c, &sz);
+    if (rc != GC_OK) return rc;
+    if (sz > dstCap) { snprintf(c->err, sizeof(c->err), "destination too small: need %zu bytes", sz); return GC_ERR_DST_SMALL; }
+    if (sz) HIPCHK(c, hipMemcpy(dst, c->dOut, sz, hipMemcpyDeviceToHost));
+    if (outSize) *outSize = sz;
+    return GC_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------ BROTLI (brotli-mt framed)
+// chunk = 1 MiB x level as in brotli-mt (C/zstdmt/brotli-mt_compress.c:115-118), in 128 KiB blocks
+static uint32_t brotli_blocks_per_chunk(int level) { if (level < 1) level = 1; if (level > 11) level = 11; return (uint32_t)level * 8u; }
+
+extern "C" size_t gc_brotli_compress_bound(size_t n)
+{
+    const size_t nb = n ? (n + GC_ZSTD_BLOCK_MAX - 1) / GC_ZSTD_BLOCK_MAX : 1;
+    return n + nb * 8u + (nb / 8u + 1u) * 17u + 32u;
+}
+
+extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n, void* d_dst, size_t dstCap, int level)
+{
+    if (!c || (!d_src && n) || !d_dst) return GC_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    c->timed = false;
+    if (n == 0) {
+        // what brotli-mt writes for an empty input: one frame holding the 1-byte empty brotli stream (WBITS=16, ISLAST, ISLASTEMPTY)
+        static const uint8_t empty[17] = { 0x50, 0x2A, 0x4D, 0x18, 8, 0, 0, 0, 1, 0, 0, 0, 0x42, 0x52, 1, 0, 0x06 };
+        if (dstCap < sizeof(empty)) return GC_ERR_DST_SMALL;
+        HIPCHK(c, hipMemcpyAsync(d_dst, empty, sizeof(empty), hipMemcpyHostToDevice, c->stream));
+        c->hostResult[0] = sizeof(empty); c->hostResult[1] = 0;
+        HIPCHK(c, hipMemcpyAsync(c->result, c->hostResult, 16, hipMemcpyHostToDevice, c->stream));
+        c->pending = true;
+        return GC_OK;
+    }
+    const uint32_t nBlocks = gc_num_blocks(n);
+    int rc = ensure_workspace(c, nBlocks);
+    if (rc != GC_OK) return rc;
+    const uint32_t bpc = brotli_blocks_per_chunk(level);
+    const uint8_t* src = (const uint8_t*)d_src;
+    HIPCHK(c, hipMemsetAsync(c->brStage, 0, (size_t)nBlocks * GC_BR_STAGE_STRIDE, c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    GC_LAUNCH(gc_zstd_lz_kernel, nBlocks, 1024, c->stream, src, (uint64_t)n, c->seqRaw, c->lit, c->meta, (unsigned long long*)nullptr);
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    GC_LAUNCH(gc_brotli_block_kernel, nBlocks, 256, c->stream, src, (uint64_t)n, (const GcSeqRaw*)c->seqRaw, (const uint8_t*)c->lit,
+              (const GcBlockMeta*)c->meta, c->seqPacked, c->seqOff, bpc, (uint32_t*)c->brStage, c->brInfo);
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    GC_LAUNCH(gc_brotli_plan_kernel, 1, 1024, c->stream, (const GcBrotliBlockInfo*)c->brInfo, nBlocks, bpc, (uint64_t)dstCap, c->brPlan, c->result);
+    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    GC_LAUNCH(gc_brotli_emit_kernel, nBlocks, 256, c->stream, src, (uint64_t)n, (const uint8_t*)c->brStage, (const GcBrotliBlockInfo*)c->brInfo,
+              (const GcBrotliPlan*)c->brPlan, nBlocks, bpc, (const uint64_t*)c->result, (uint8_t*)d_dst);
+    HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+    HIPCHK(c, hipGetLastError());
+    c->pending = true; c->timed = true; c->lastCodec = 2;
+    return GC_OK;
+}
+
+extern "C" int gc_brotli_finish(gc_ctx* c, size_t* compressedSize) { return gc_zstd_finish(c, compressedSize); }
+
+extern "C" int gc_brotli_last_timing(gc_ctx* c, float ms[5])
+{
+    if (!c || !c->timed || c->pending || c->lastCodec != 2) return GC_ERR_PARAM;
+    for (int i = 0; i < 4; i++) HIPCHK(c, hipEventElapsedTime(&ms[i], c->ev[i], c->ev[i + 1]));   // lz, block, plan, emit
+    HIPCHK(c, hipEventElapsedTime(&ms[4], c->ev[0], c->ev[4]));
+    return GC_OK;
+}
+
+extern "C" int gc_brotli_compress_host(gc_ctx* c, const void* src, size_t n, void* dst, size_t dstCap, int level, size_t* outSize)
+{
+    if (!c || (!src && n) || !dst) return GC_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t bound = gc_brotli_compress_bound(n);
+    if (n > c->dInCap) { hipFree(c->dIn); c->dIn = nullptr; c->dInCap = 0; if (hipMalloc((void**)&c->dIn, n + 64) != hipSuccess) return GC_ERR_NOMEM; c->dInCap = n; }
+    if (bound > c->dOutCap) { hipFree(c->dOut); c->dOut = nullptr; c->dOutCap = 0; if (hipMalloc((void**)&c->dOut, bound) != hipSuccess) return GC_ERR_NOMEM; c->dOutCap = bound; }
+    if (n) HIPCHK(c, hipMemcpyAsync(c->dIn, src, n, hipMemcpyHostToDevice, c->stream));
+    int rc = gc_brotli_compress_device(c, c->dIn, n, c->dOut, c->dOutCap, level);
     if (rc != GC_OK) return rc;
     size_t sz = 0;
     rc = gc_zstd_finish(c, &sz);

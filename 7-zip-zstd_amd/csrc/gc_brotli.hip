@@ -1,0 +1,541 @@
+// gc_brotli.hip -- BROTLI path (7-Zip method id 0x4F71102): one brotli meta-block per 128 KiB match-finder block.
+//
+// Replaces, behind NCompress::NBROTLI::CEncoder (CPP/7zip/Compress/BrotliEncoder.cpp:118-164) and the brotli-mt chunk
+// framing (C/zstdmt/brotli-mt_compress.c:209-333), the per-chunk BrotliEncoderCompress: command formation
+// (C/brotli/enc/command.h: insert / copy length codes, CombineLengthCodes; enc/prefix.h: distance prefix codes), histogram
+// building + BrotliCreateHuffmanTree / BrotliConvertBitDepthsToSymbols (C/brotli/br_entropy_encode.c:68,474), the prefix
+// code serialisation BuildAndStoreHuffmanTree / BrotliStoreHuffmanTree (C/brotli/br_brotli_bit_stream.c:349,254-330) and
+// the command / literal / distance bit stream of BrotliStoreMetaBlock (br_brotli_bit_stream.c:947).
+//
+// What is format-normative (RFC 7932, re-derived by C/brotli/br_decode.c) and reproduced exactly: the stream header
+// (WBITS), meta-block header (ISLAST, MNIBBLES, MLEN-1, ISUNCOMPRESSED, NBLTYPES*, NPOSTFIX, NDIRECT, context modes,
+// NTREES*), simple and complex prefix code descriptions (code-length code in the fixed storage order with its fixed
+// variable-length code, zero-run symbol 17, "stop when the Kraft sum is full"), canonical code assignment with bits sent
+// least-significant-first (so code words are stored bit-reversed), the 704-cell insert&copy alphabet, distance codes
+// (16 ring-buffer codes + 48 direct codes at NPOSTFIX = NDIRECT = 0) and the order cmd code, insert extra, copy extra,
+// literals, distance code, distance extra.  Free choices made here: one block type per category, one literal / distance
+// tree (no context modelling yet), NPOSTFIX = NDIRECT = 0, ring-buffer code 0 ("same distance as the previous copy") only.
+//
+// Every meta-block is followed by an empty metadata meta-block (6 bits + padding, RFC 7932 section 9.2), which byte-aligns
+// the next one: meta-blocks are therefore independent byte strings that L-emit concatenates, and a 128 KiB block is one
+// workgroup's work item like in the zstd and LZMA2 paths.
+//
+// Parallel structure (256 threads): merge of capped match records (scan), symbol histograms (LDS atomics), three Huffman
+// codes (rank sort in parallel, tree + length limiting in one lane), header (one lane, a few hundred symbols), then the bit
+// stream: per-command bit counts -> workgroup prefix sums -> every command and every literal ORs its bits at its absolute
+// bit offset (global atomic OR into the zeroed staging area); literal runs longer than BR_LONG are handled cooperatively.
+#include "gc_common.h"
+#include "gc_device.h"
+#include "gc_fse.h"
+#include "gc_brotli.h"
+
+#define BR_T 256u
+#define BR_LONG 48u            // literal runs up to this length are walked by the command's own lane
+
+// ---- format tables (RFC 7932 section 5)
+__constant__ uint16_t kInsBase[24] = { 0,1,2,3,4,5,6,8,10,14,18,26,34,50,66,98,130,194,322,578,1090,2114,6210,22594 };
+__constant__ uint8_t  kInsExtra[24] = { 0,0,0,0,0,0,1,1,2,2,3,3,4,4,5,5,6,7,8,9,10,12,14,24 };
+__constant__ uint16_t kCopyBase[24] = { 2,3,4,5,6,7,8,9,10,12,14,18,22,30,38,54,70,102,134,198,326,582,1094,2118 };
+__constant__ uint8_t  kCopyExtra[24] = { 0,0,0,0,0,0,0,0,1,1,2,2,3,3,4,4,5,5,6,7,8,9,10,24 };
+// first symbol of the insert&copy cell for (insert code >> 3, copy code >> 3), explicit distance
+__constant__ uint16_t kCellBase[9] = { 128, 192, 384, 256, 320, 512, 448, 576, 640 };
+
+__device__ __forceinline__ uint32_t br_ins_code(uint32_t v)
+{
+    if (v < 6u) return v;
+    if (v < 130u) { const uint32_t nb = gc_hibit32(v - 2u) - 1u; return (nb << 1) + ((v - 2u) >> nb) + 2u; }
+    if (v < 2114u) return gc_hibit32(v - 66u) + 10u;
+    return v < 6210u ? 21u : (v < 22594u ? 22u : 23u);
+}
+__device__ __forceinline__ uint32_t br_copy_code(uint32_t v)
+{
+    if (v < 10u) return v - 2u;
+    if (v < 134u) { const uint32_t nb = gc_hibit32(v - 6u) - 1u; return (nb << 1) + ((v - 6u) >> nb) + 4u; }
+    if (v < 2118u) return gc_hibit32(v - 70u) + 12u;
+    return 23u;
+}
+__device__ __forceinline__ uint32_t br_rev(uint32_t code, uint32_t nbits) { return __brev(code) >> (32u - nbits); }
+
+// one command: everything needed to count and to write it
+struct BrCmd { uint32_t sym; uint32_t insExtraBits, insExtraVal, copyExtraBits, copyExtraVal; uint32_t dsym, dExtraBits, dExtraVal; bool hasDist; };
+// ll literals then a copy of ml bytes at distance off; ml == 0: trailing insert-only command.  useLast: off equals the
+// previous copy's distance of this meta-block
+__device__ __forceinline__ BrCmd br_command(uint32_t ll, uint32_t ml, uint32_t off, bool useLast)
+{
+    BrCmd c;
+    const uint32_t ic = br_ins_code(ll), cc = ml ? br_copy_code(ml) : 0u;
+    c.insExtraBits = kInsExtra[ic]; c.insExtraVal = ll - kInsBase[ic];
+    c.copyExtraBits = ml ? kCopyExtra[cc] : 0u; c.copyExtraVal = ml ? ml - kCopyBase[cc] : 0u;
+    const uint32_t low = ((ic & 7u) << 3) | (cc & 7u);
+    const bool implicitCell = (useLast || ml == 0u) && ic < 8u && cc < 16u;       // cells 0..127: distance code 0 implied
+    if (implicitCell) { c.sym = low | (cc < 8u ? 0u : 64u); c.hasDist = false; }
+    else { c.sym = kCellBase[(cc >> 3) + 3u * (ic >> 3)] | low; c.hasDist = ml != 0u; }
+    c.dsym = 0; c.dExtraBits = 0; c.dExtraVal = 0;
+    if (c.hasDist && !useLast) {
+        const uint32_t v = off + 3u, n = gc_hibit32(v) - 1u, b = (v >> n) & 1u;
+        c.dsym = 16u + 2u * (n - 1u) + b; c.dExtraBits = n; c.dExtraVal = v - ((2u + b) << n);
+    }
+    return c;
+}
+
+// OR up to 64 bits into the (zero-initialised) global bit buffer at absolute bit offset `pos`
+__device__ __forceinline__ void br_or_bits(uint32_t* buf, uint64_t pos, uint64_t v, uint32_t nbits)
+{
+    if (nbits == 0u) return;
+    const uint64_t word = pos >> 5; const uint32_t sh = (uint32_t)pos & 31u;
+    const uint32_t w0 = (uint32_t)(v << sh);
+    const uint64_t rest = sh ? (v >> (32u - sh)) : (v >> 32);
+    if (w0) atomicOr(&buf[word], w0);
+    if ((uint32_t)rest) atomicOr(&buf[word + 1], (uint32_t)rest);
+    if ((uint32_t)(rest >> 32)) atomicOr(&buf[word + 2], (uint32_t)(rest >> 32));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Length-limited Huffman code for an alphabet of n <= 704 symbols, executed by the whole workgroup.
+// count[] -> depth[] (0 = unused) and bit-reversed canonical codes.  Returns the number of used symbols; with exactly one
+// used symbol its depth is 0 (brotli's NSYM = 1 simple code: the symbol costs no bits).
+struct BrHufScratch { uint16_t sorted[704]; uint32_t w[1408]; uint16_t parent[1408]; uint8_t d[1408]; uint32_t misc[4]; };
+
+__device__ uint32_t br_build_code(const uint32_t* count, uint32_t n, uint32_t maxBits, uint8_t* depth, uint16_t* code, BrHufScratch& S, bool* ok)
+{
+    const uint32_t t = threadIdx.x;
+    if (t == 0) S.misc[0] = 0;
+    __syncthreads();
+    // rank sort of the used symbols by (count, symbol)
+    for (uint32_t s = t; s < n; s += BR_T) {
+        const uint32_t c = count[s];
+        depth[s] = 0; code[s] = 0;
+        if (c) {
+            uint32_t rank = 0;
+            for (uint32_t u = 0; u < n; u++) { const uint32_t cu = count[u]; rank += (cu && (cu < c || (cu == c && u < s))) ? 1u : 0u; }
+            S.sorted[rank] = (uint16_t)s;
+            atomicAdd(&S.misc[0], 1u);
+        }
+    }
+    __syncthreads();
+    const uint32_t nsym = S.misc[0];
+    if (t == 0) {
+        S.misc[1] = 1u;
+        if (nsym >= 2u) {
+            for (uint32_t i = 0; i < nsym; i++) S.w[i] = count[S.sorted[i]];
+            uint32_t li = 0, ii = nsym, ni = nsym;                       // two-queue merge over leaves sorted ascending
+            for (uint32_t k = 0; k + 1u < nsym; k++) {
+                uint32_t a, c;
+                if (li < nsym && (ii >= ni || S.w[li] <= S.w[ii])) a = li++; else a = ii++;
+                if (li < nsym && (ii >= ni || S.w[li] <= S.w[ii])) c = li++; else c = ii++;
+                S.w[ni] = S.w[a] + S.w[c]; S.parent[a] = (uint16_t)ni; S.parent[c] = (uint16_t)ni; ni++;
+            }
+            const uint32_t root = 2u * nsym - 2u;
+            S.d[root] = 0;
+            for (int i = (int)root - 1; i >= 0; i--) { const uint32_t dd = S.d[S.parent[i]] + 1u; S.d[i] = (uint8_t)(dd > 255u ? 255u : dd); }
+            uint32_t maxLen = 0;
+            for (uint32_t i = 0; i < nsym; i++) maxLen = max(maxLen, (uint32_t)S.d[i]);
+            if (maxLen > maxBits) {
+                // clamp, then repay the Kraft debt from the least frequent symbols upward (same scheme as the HUF literals kernel)
+                long long debt = 0;
+                for (uint32_t i = 0; i < nsym; i++) { if (S.d[i] > maxBits) S.d[i] = (uint8_t)maxBits; debt += 1ll << (maxBits - S.d[i]); }
+                debt -= 1ll << maxBits;
+                for (int bl = (int)maxBits - 1; bl >= 1 && debt > 0; bl--) {
+                    const long long r = 1ll << (maxBits - 1 - bl);
+                    for (uint32_t i = 0; i < nsym && debt > 0; i++) if (S.d[i] == bl) { S.d[i] = (uint8_t)(bl + 1); debt -= r; }
+                }
+                for (int i = (int)nsym - 1; i >= 0 && debt < 0; i--) if (S.d[i] == maxBits) { S.d[i] = (uint8_t)(maxBits - 1u); debt += 1; }
+                if (debt != 0) S.misc[1] = 0u;
+            }
+            for (uint32_t i = 0; i < nsym; i++) depth[S.sorted[i]] = S.d[i];
+            // canonical codes: shorter first, ascending symbol inside a length (br_entropy_encode.c:474); stored bit-reversed
+            uint32_t blCount[17], next[17];
+            for (uint32_t l = 0; l <= 16u; l++) blCount[l] = 0;
+            for (uint32_t s = 0; s < n; s++) blCount[depth[s]]++;
+            blCount[0] = 0;
+            { uint32_t c = 0; for (uint32_t l = 1; l <= 16u; l++) { c = (c + blCount[l - 1u]) << 1; next[l] = c; } }
+            for (uint32_t s = 0; s < n; s++) if (depth[s]) code[s] = (uint16_t)br_rev(next[depth[s]]++, depth[s]);
+        }
+    }
+    __syncthreads();
+    if (S.misc[1] == 0u) *ok = false;
+    return nsym;
+}
+
+// ---- serial bit writer into LDS bytes (header only)
+struct BrBW { uint8_t* out; uint64_t acc; uint32_t nbits; uint32_t bytes; };
+__device__ __forceinline__ void bw_put(BrBW& w, uint32_t v, uint32_t nb)
+{
+    w.acc |= (uint64_t)v << w.nbits; w.nbits += nb;
+    while (w.nbits >= 8u) { w.out[w.bytes++] = (uint8_t)w.acc; w.acc >>= 8; w.nbits -= 8u; }
+}
+__device__ __forceinline__ uint32_t bw_bits(const BrBW& w) { return w.bytes * 8u + w.nbits; }
+
+// prefix code description (single lane).  alphaBits = ceil(log2(alphabet size)).  scratch: n + 32 uint16 entries.
+__device__ void br_store_code(BrBW& w, const uint8_t* depth, uint32_t n, uint32_t alphaBits, uint32_t nsym, uint16_t* seq)
+{
+    if (nsym <= 1u) {                                                    // simple code, NSYM = 1 (also for an unused alphabet)
+        uint32_t s = 0; for (uint32_t i = 0; i < n; i++) if (depth[i] || nsym == 0u) { s = i; break; }
+        if (nsym == 1u) { /* depth is 0 for a lone symbol: find it through the caller-provided marker in seq[0] */ s = seq[0]; }
+        bw_put(w, 1u, 2); bw_put(w, 0u, 2); bw_put(w, s, alphaBits);
+        return;
+    }
+    // code-length symbol sequence up to the last used symbol; zero runs as symbol 17 (3..10 zeros, 3 extra bits); two
+    // 17s are never adjacent (a plain 0 separates them), so the decoder's run-compounding rule never applies
+    uint32_t last = 0; for (uint32_t i = 0; i < n; i++) if (depth[i]) last = i;
+    uint32_t m = 0, hist[18]; for (int i = 0; i < 18; i++) hist[i] = 0;
+    for (uint32_t i = 0; i <= last;) {
+        if (depth[i]) { seq[m++] = depth[i]; hist[depth[i]]++; i++; continue; }
+        uint32_t run = 0; while (depth[i + run] == 0) run++;            // stops at `last` at the latest
+        if (run >= 3u) {
+            const uint32_t r = run < 10u ? run : 10u;
+            seq[m++] = (uint16_t)(17u | ((r - 3u) << 8)); hist[17]++; i += r;
+            if (depth[i] == 0) { seq[m++] = 0; hist[0]++; i++; }
+        } else { seq[m++] = 0; hist[0]++; i++; }
+    }
+    // Huffman code over the 18 code-length symbols, depth <= 5 (tiny: selection by repeated minimum)
+    uint8_t cd[18]; uint16_t cc[18]; uint32_t used = 0, only = 0;
+    for (int i = 0; i < 18; i++) { cd[i] = 0; cc[i] = 0; if (hist[i]) { used++; only = (uint32_t)i; } }
+    if (used == 1u) cd[only] = 1;        // lone symbol: any non-zero length in the header; it then costs 0 bits per use
+    else {
+        // package-free construction: build the tree with a 36-node pool
+        uint32_t wgt[36]; int par[36]; bool alive[36]; int nn = 18;
+        for (int i = 0; i < 18; i++) { wgt[i] = hist[i]; par[i] = -1; alive[i] = hist[i] != 0; }
+        for (uint32_t k = 0; k + 1u < used; k++) {
+            int a = -1, b = -1;
+            for (int i = 0; i < nn; i++) if (alive[i]) { if (a < 0 || wgt[i] < wgt[a]) { b = a; a = i; } else if (b < 0 || wgt[i] < wgt[b]) b = i; }
+            wgt[nn] = wgt[a] + wgt[b]; par[nn] = -1; alive[nn] = true; alive[a] = alive[b] = false; par[a] = par[b] = nn; nn++;
+        }
+        uint32_t maxd = 0;
+        for (int i = 0; i < 18; i++) if (hist[i]) { uint32_t d = 0; for (int p = i; par[p] >= 0; p = par[p]) d++; cd[i] = (uint8_t)d; maxd = max(maxd, d); }
+        if (maxd > 5u) {                                                 // rare: flatten to a valid 5-bit-limited code
+            // clamp + Kraft repair on 5 bits, least frequent symbols first
+            int order[18], no = 0;
+            for (int i = 0; i < 18; i++) if (hist[i]) order[no++] = i;
+            for (int i = 1; i < no; i++) { int v = order[i], j = i - 1; while (j >= 0 && hist[order[j]] > hist[v]) { order[j + 1] = order[j]; j--; } order[j + 1] = v; }
+            int debt = 0;
+            for (int i = 0; i < no; i++) { if (cd[order[i]] > 5) cd[order[i]] = 5; debt += 1 << (5 - cd[order[i]]); }
+            debt -= 32;
+            for (int bl = 4; bl >= 1 && debt > 0; bl--) for (int i = 0; i < no && debt > 0; i++) if (cd[order[i]] == bl) { cd[order[i]] = (uint8_t)(bl + 1); debt -= 1 << (4 - bl); }
+            for (int i = no - 1; i >= 0 && debt < 0; i--) if (cd[order[i]] == 5) { cd[order[i]] = 4; debt += 1; }
+        }
+        uint32_t blc[7], nx[7]; for (int l = 0; l < 7; l++) blc[l] = 0;
+        for (int i = 0; i < 18; i++) blc[cd[i]]++;
+        blc[0] = 0;
+        { uint32_t c = 0; for (int l = 1; l <= 6; l++) { c = (c + blc[l - 1]) << 1; nx[l] = c; } }
+        for (int i = 0; i < 18; i++) if (cd[i]) cc[i] = (uint16_t)br_rev(nx[cd[i]]++, cd[i]);
+    }
+    // code-length code lengths in the fixed order, with the fixed variable-length code (RFC 7932 section 3.5)
+    const uint8_t order18[18] = { 1, 2, 3, 4, 0, 5, 17, 6, 16, 7, 8, 9, 10, 11, 12, 13, 14, 15 };
+    const uint8_t vlcBits[6] = { 2, 4, 3, 2, 2, 4 }, vlcVal[6] = { 0, 7, 3, 2, 1, 15 };
+    uint32_t skip = 0, store = 18;
+    if (used > 1u) while (store > 0u && cd[order18[store - 1u]] == 0) store--;
+    if (cd[order18[0]] == 0 && cd[order18[1]] == 0) { skip = 2; if (cd[order18[2]] == 0) skip = 3; }
+    bw_put(w, skip, 2);
+    for (uint32_t i = skip; i < store; i++) { const uint32_t l = cd[order18[i]]; bw_put(w, vlcVal[l], vlcBits[l]); }
+    if (used == 1u) cd[only] = 0;
+    for (uint32_t i = 0; i < m; i++) {
+        const uint32_t sy = seq[i] & 0xFFu;
+        bw_put(w, cc[sy], cd[sy]);
+        if (sy == 17u) bw_put(w, seq[i] >> 8, 3);
+    }
+}
+
+// workgroup exclusive sum of a 64-bit-safe uint32 per thread with running total
+__device__ __forceinline__ uint32_t br_excl_scan(uint32_t v, uint32_t* sWave, uint32_t* total)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t incl = gc_wave_incl_sum(v);
+    if (lane == 63u) sWave[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+    for (uint32_t w = 0; w < BR_T / 64u; w++) { const uint32_t c = sWave[w]; if (w < wave) before += c; all += c; }
+    __syncthreads();
+    *total = all;
+    return before + incl - v;
+}
+
+extern "C" __global__ void __launch_bounds__(BR_T)
+gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const GcSeqRaw* __restrict__ seqRaw,
+                       const uint8_t* __restrict__ lit, const GcBlockMeta* __restrict__ meta,
+                       uint64_t* __restrict__ seqPacked /* scratch: GC_MAX_SEQ_PER_BLOCK per block */,
+                       uint32_t* __restrict__ seqLitStart /* scratch: GC_MAX_SEQ_PER_BLOCK per block */,
+                       uint32_t blocksPerChunk, uint32_t* __restrict__ stage /* zeroed, GC_BR_STAGE_STRIDE bytes per block */,
+                       GcBrotliBlockInfo* __restrict__ info)
+{
+    __shared__ uint32_t hLit[256], hCmd[704], hDist[64];
+    __shared__ uint8_t  dLit[256], dCmd[704], dDist[64];
+    __shared__ uint16_t cLit[256], cCmd[704], cDist[64];
+    __shared__ BrHufScratch S;
+    __shared__ uint16_t sSeq[704 + 32];
+    __shared__ uint8_t  sHdr[1024];
+    __shared__ uint32_t sWave[8];
+    __shared__ uint32_t sMisc[8];
+
+    const uint32_t t = threadIdx.x, b = blockIdx.x;
+    const uint64_t blockBase = (uint64_t)b * GC_ZSTD_BLOCK_MAX;
+    const uint32_t blockLen = (uint32_t)((srcSize - blockBase) < GC_ZSTD_BLOCK_MAX ? (srcSize - blockBase) : GC_ZSTD_BLOCK_MAX);
+    const uint32_t nRaw = meta[b].nSeqRaw, nLit = meta[b].nLit;
+    const GcSeqRaw* R = seqRaw + (uint64_t)b * GC_MAX_SEQ_PER_BLOCK;
+    const uint8_t* L = lit + (uint64_t)b * GC_ZSTD_BLOCK_MAX;
+    uint64_t* P = seqPacked + (uint64_t)b * GC_MAX_SEQ_PER_BLOCK;
+    uint32_t* LS = seqLitStart + (uint64_t)b * GC_MAX_SEQ_PER_BLOCK;
+    uint32_t* out = stage + (uint64_t)b * (GC_BR_STAGE_STRIDE / 4u);
+    const bool firstInChunk = (b % blocksPerChunk) == 0u;
+    const bool lastInChunk = ((b + 1u) % blocksPerChunk) == 0u || blockBase + blockLen >= srcSize;
+
+    for (uint32_t i = t; i < 256u; i += BR_T) hLit[i] = 0;
+    for (uint32_t i = t; i < 704u; i += BR_T) hCmd[i] = 0;
+    for (uint32_t i = t; i < 64u; i += BR_T) hDist[i] = 0;
+    __syncthreads();
+
+    // ---- merge chains of capped records (same offset, no literals in between) into commands: P[j] = ll | ml<<18 | off<<36,
+    //      LS[j] = rank of the command's first literal in the literal stream
+    uint32_t nSeq = 0;
+    for (uint32_t tb = 0; tb < nRaw; tb += BR_T) {
+        const uint32_t i = tb + t;
+        uint32_t head = 0, ll = 0, off = 0, ml = 0, start = 0;
+        if (i < nRaw) {
+            const GcSeqRaw r = R[i];
+            uint32_t prevRank = 0, prevOff = 0;
+            if (i) { const GcSeqRaw q = R[i - 1u]; prevRank = q.litRank; prevOff = q.offml >> 8; }
+            ll = r.litRank - prevRank; off = r.offml >> 8; ml = r.offml & 0xFFu; start = prevRank;
+            head = (i == 0u || ll != 0u || off != prevOff) ? 1u : 0u;
+            if (head) for (uint32_t k = i + 1u; k < nRaw; k++) {
+                const GcSeqRaw c = R[k];
+                if (c.litRank != r.litRank || (c.offml >> 8) != off) break;
+                ml += c.offml & 0xFFu;
+            }
+        }
+        uint32_t tot;
+        const uint32_t j = nSeq + br_excl_scan(head, sWave, &tot);
+        if (head) { P[j] = (uint64_t)ll | ((uint64_t)ml << 18) | ((uint64_t)off << 36); LS[j] = start; }
+        nSeq += tot;
+    }
+    __syncthreads();
+    // trailing literals form an insert-only command
+    const uint32_t litBeforeTail = nRaw ? R[nRaw - 1u].litRank : 0u;
+    const uint32_t tailLen = nLit - litBeforeTail;
+    const uint32_t nCmd = nSeq + (tailLen ? 1u : 0u);
+    if (t == 0 && tailLen) { P[nSeq] = (uint64_t)tailLen; LS[nSeq] = litBeforeTail; }
+    __syncthreads();
+
+    // ---- histograms
+    for (uint32_t i = t * 4u; i < nLit; i += BR_T * 4u) {
+        if (i + 4u <= nLit) {
+            const uint32_t v = *(const uint32_t*)(L + i);
+            atomicAdd(&hLit[v & 0xFFu], 1u); atomicAdd(&hLit[(v >> 8) & 0xFFu], 1u); atomicAdd(&hLit[(v >> 16) & 0xFFu], 1u); atomicAdd(&hLit[v >> 24], 1u);
+        } else for (uint32_t k = i; k < nLit; k++) atomicAdd(&hLit[L[k]], 1u);
+    }
+    for (uint32_t j = t; j < nCmd; j += BR_T) {
+        const uint64_t pk = P[j];
+        const uint32_t ll = (uint32_t)(pk & 0x3FFFFu), ml = (uint32_t)((pk >> 18) & 0x3FFFFu), off = (uint32_t)(pk >> 36);
+        const bool useLast = j > 0u && ml != 0u && (uint32_t)(P[j - 1u] >> 36) == off;
+        const BrCmd c = br_command(ll, ml, off, useLast);
+        atomicAdd(&hCmd[c.sym], 1u);
+        if (c.hasDist) atomicAdd(&hDist[c.dsym], 1u);
+    }
+    __syncthreads();
+
+    // ---- prefix codes
+    bool ok = true;
+    const uint32_t nsLit = br_build_code(hLit, 256u, 15u, dLit, cLit, S, &ok);
+    uint32_t oneLit = 0;  if (nsLit == 1u) { for (uint32_t s = 0; s < 256u; s++) if (hLit[s]) oneLit = s; }
+    const uint32_t nsCmd = br_build_code(hCmd, 704u, 15u, dCmd, cCmd, S, &ok);
+    uint32_t oneCmd = 0;  if (nsCmd == 1u) { for (uint32_t s = 0; s < 704u; s++) if (hCmd[s]) oneCmd = s; }
+    const uint32_t nsDist = br_build_code(hDist, 64u, 15u, dDist, cDist, S, &ok);
+    uint32_t oneDist = 0; if (nsDist == 1u) { for (uint32_t s = 0; s < 64u; s++) if (hDist[s]) oneDist = s; }
+
+    // ---- header: [stream header] meta-block header + the three code descriptions (one lane)
+    if (t == 0) {
+        BrBW w; w.out = sHdr; w.acc = 0; w.nbits = 0; w.bytes = 0;
+        if (firstInChunk) bw_put(w, 0x3u, 4);                              // WBITS = 18: '1' + n = 1 (RFC 7932 section 9.1); window 256 KiB - 16
+        bw_put(w, 0u, 1);                                                  // ISLAST = 0 (the stream is closed by an empty last meta-block)
+        const uint32_t mlen1 = blockLen - 1u;
+        const uint32_t nib = mlen1 < (1u << 16) ? 4u : (mlen1 < (1u << 20) ? 5u : 6u);
+        bw_put(w, nib - 4u, 2); bw_put(w, mlen1, nib * 4u);
+        bw_put(w, 0u, 1);                                                  // ISUNCOMPRESSED = 0
+        sMisc[1] = bw_bits(w);                                             // bits before ISUNCOMPRESSED + 1: reused by the stored fallback
+        bw_put(w, 0u, 1); bw_put(w, 0u, 1); bw_put(w, 0u, 1);              // NBLTYPESL = NBLTYPESI = NBLTYPESD = 1
+        bw_put(w, 0u, 2); bw_put(w, 0u, 4);                                // NPOSTFIX = 0, NDIRECT = 0
+        bw_put(w, 0u, 2);                                                  // context mode of the single literal block type (LSB6; unused with one tree)
+        bw_put(w, 0u, 1); bw_put(w, 0u, 1);                                // NTREESL = 1, NTREESD = 1
+        sSeq[0] = (uint16_t)oneLit;  br_store_code(w, dLit, 256u, 8u, nsLit, sSeq);
+        sSeq[0] = (uint16_t)oneCmd;  br_store_code(w, dCmd, 704u, 10u, nsCmd, sSeq);
+        sSeq[0] = (uint16_t)oneDist; br_store_code(w, dDist, 64u, 6u, nsDist, sSeq);
+        const uint32_t hb = bw_bits(w);
+        if (w.nbits) { w.out[w.bytes++] = (uint8_t)w.acc; }
+        sMisc[0] = hb;
+    }
+    __syncthreads();
+    const uint32_t hdrBits = sMisc[0];
+    for (uint32_t i = t; i < (hdrBits + 31u) / 32u; i += BR_T) {
+        uint32_t v = 0; for (uint32_t k = 0; k < 4u; k++) { const uint32_t bi = i * 4u + k; if (bi * 8u < hdrBits) v |= (uint32_t)sHdr[bi] << (8u * k); }
+        if (v) atomicOr(&out[i], v);
+    }
+
+    // ---- commands: bit counts -> offsets -> bits.  A command's literals are walked by its own lane unless the run is long.
+    uint64_t bitBase = hdrBits;                                            // uniform running bit offset
+    for (uint32_t tb = 0; tb < nCmd; tb += BR_T) {
+        const uint32_t j = tb + t;
+        uint32_t ll = 0, ml = 0, off = 0, ls = 0; bool valid = j < nCmd, useLast = false;
+        BrCmd c; c.sym = 0; c.insExtraBits = c.insExtraVal = c.copyExtraBits = c.copyExtraVal = c.dsym = c.dExtraBits = c.dExtraVal = 0; c.hasDist = false;
+        if (valid) {
+            const uint64_t pk = P[j];
+            ll = (uint32_t)(pk & 0x3FFFFu); ml = (uint32_t)((pk >> 18) & 0x3FFFFu); off = (uint32_t)(pk >> 36); ls = LS[j];
+            useLast = j > 0u && ml != 0u && (uint32_t)(P[j - 1u] >> 36) == off;
+            c = br_command(ll, ml, off, useLast);
+        }
+        const uint32_t headBits = valid ? dCmd[c.sym] + c.insExtraBits + c.copyExtraBits : 0u;
+        const uint32_t tailBits = (valid && c.hasDist) ? dDist[c.dsym] + c.dExtraBits : 0u;
+        uint32_t litBits = 0;
+        const bool isLong = valid && ll > BR_LONG;
+        if (valid && !isLong) for (uint32_t i = 0; i < ll; i++) litBits += dLit[L[ls + i]];
+        // long runs of this tile: summed by the whole workgroup, one after the other
+        for (uint32_t w0 = 0; w0 < BR_T / 64u; w0++) {
+            __syncthreads();
+            if ((t >> 6) == w0) { const uint64_t m = __ballot(isLong); if ((t & 63u) == 0u) { sMisc[2] = (uint32_t)m; sMisc[3] = (uint32_t)(m >> 32); } }
+            __syncthreads();
+            uint64_t mask = (uint64_t)sMisc[2] | ((uint64_t)sMisc[3] << 32);
+            while (mask) {
+                const uint32_t ln = gc_ctz64(mask); mask &= mask - 1ull;
+                const uint32_t jj = tb + w0 * 64u + ln;
+                const uint32_t rl = (uint32_t)(P[jj] & 0x3FFFFu), rs = LS[jj];
+                uint32_t part = 0;
+                for (uint32_t i = t; i < rl; i += BR_T) part += dLit[L[rs + i]];
+                uint32_t tot; br_excl_scan(part, sWave, &tot);
+                if (j == jj) litBits = tot;
+            }
+        }
+        uint32_t tileBits;
+        const uint32_t myBits = headBits + litBits + tailBits;
+        const uint64_t q = bitBase + br_excl_scan(myBits, sWave, &tileBits);
+        if (bitBase + tileBits + 64u >= (uint64_t)blockLen * 8u) { ok = false; break; }   // no gain: stored meta-block; nothing past the raw size is ever written
+        if (valid) {
+            uint64_t hv = cCmd[c.sym]; uint32_t hn = dCmd[c.sym];
+            hv |= (uint64_t)c.insExtraVal << hn; hn += c.insExtraBits;
+            hv |= (uint64_t)c.copyExtraVal << hn; hn += c.copyExtraBits;
+            br_or_bits(out, q, hv, hn);
+            if (!isLong) { uint64_t pos = q + headBits; for (uint32_t i = 0; i < ll; i++) { const uint32_t sy = L[ls + i]; br_or_bits(out, pos, cLit[sy], dLit[sy]); pos += dLit[sy]; } }
+            if (c.hasDist) br_or_bits(out, q + headBits + litBits, (uint64_t)cDist[c.dsym] | ((uint64_t)c.dExtraVal << dDist[c.dsym]), dDist[c.dsym] + c.dExtraBits);
+        }
+        // long runs: cooperative write, 256 literals per step with a running bit offset
+        for (uint32_t w0 = 0; w0 < BR_T / 64u; w0++) {
+            __syncthreads();
+            if ((t >> 6) == w0) { const uint64_t m = __ballot(isLong); if ((t & 63u) == 0u) { sMisc[2] = (uint32_t)m; sMisc[3] = (uint32_t)(m >> 32); } }
+            __syncthreads();
+            uint64_t mask = (uint64_t)sMisc[2] | ((uint64_t)sMisc[3] << 32);
+            while (mask) {
+                const uint32_t ln = gc_ctz64(mask); mask &= mask - 1ull;
+                const uint32_t jj = tb + w0 * 64u + ln;
+                if (j == jj) { sMisc[4] = (uint32_t)(q + headBits); sMisc[5] = (uint32_t)((q + headBits) >> 32); }
+                __syncthreads();
+                uint64_t pos = (uint64_t)sMisc[4] | ((uint64_t)sMisc[5] << 32);
+                const uint32_t rl = (uint32_t)(P[jj] & 0x3FFFFu), rs = LS[jj];
+                for (uint32_t i0 = 0; i0 < rl; i0 += BR_T) {
+                    const uint32_t i = i0 + t;
+                    uint32_t sy = 0, nb = 0;
+                    if (i < rl) { sy = L[rs + i]; nb = dLit[sy]; }
+                    uint32_t tot;
+                    const uint32_t at = br_excl_scan(nb, sWave, &tot);
+                    if (i < rl) br_or_bits(out, pos + at, cLit[sy], nb);
+                    pos += tot;
+                }
+            }
+        }
+        bitBase += tileBits;
+    }
+
+    // ---- close: an empty metadata meta-block byte-aligns the next meta-block; the chunk's last block also appends the
+    //      empty last meta-block (ISLAST = 1, ISLASTEMPTY = 1)
+    if (t == 0) {
+        uint64_t e = bitBase;
+        const uint64_t rawLimit = (uint64_t)blockLen * 8u;
+        const bool stored = !ok || e + 64u >= rawLimit;
+        GcBrotliBlockInfo bi;
+        if (!stored) {
+            br_or_bits(out, e, 0x06u, 6); e += 6u;                         // ISLAST=0, MNIBBLES=11 (metadata), reserved 0, MSKIPBYTES=00
+            e = (e + 7u) & ~7ull;
+            if (lastInChunk) { br_or_bits(out, e, 0x3u, 2); e += 8u; }
+            bi.size = (uint32_t)(e >> 3); bi.stored = 0; bi.hdrBits = 0;
+        } else {
+            // stored meta-block: header up to ISUNCOMPRESSED = 1, padding, raw bytes (emit kernel), then as above
+            bi.stored = 1; bi.hdrBits = sMisc[1];
+            const uint32_t hb = (sMisc[1] + 7u) >> 3;
+            bi.size = hb + blockLen + (lastInChunk ? 1u : 0u);
+        }
+        bi.lastInChunk = lastInChunk ? 1u : 0u;
+        info[b] = bi;
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// plan: one workgroup; exclusive scan of block sizes with a 16-byte brotli-mt frame header in front of every chunk
+// (C/zstdmt/brotli-mt_compress.c:299-321: 0x184D2A50, 8, compressed size, 0x5242, hint = 64 KiB units to allocate)
+extern "C" __global__ void __launch_bounds__(1024)
+gc_brotli_plan_kernel(const GcBrotliBlockInfo* __restrict__ info, uint32_t nBlocks, uint32_t blocksPerChunk, uint64_t dstCap,
+                      GcBrotliPlan* __restrict__ plan, uint64_t* __restrict__ result)
+{
+    __shared__ uint32_t sWave[16];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    uint64_t carry = 0;
+    for (uint32_t tb = 0; tb < nBlocks; tb += 1024u) {
+        const uint32_t b = tb + t;
+        uint32_t size = 0;
+        if (b < nBlocks) size = info[b].size + ((b % blocksPerChunk) == 0u ? 16u : 0u);
+        const uint32_t incl = gc_wave_incl_sum(size);
+        if (lane == 63u) sWave[wave] = incl;
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+        for (uint32_t w = 0; w < 16u; w++) { const uint32_t v = sWave[w]; if (w < wave) before += v; all += v; }
+        __syncthreads();
+        if (b < nBlocks) { GcBrotliPlan p; p.off = carry + before + incl - size; p.chunkSize = 0; p.pad = 0; plan[b] = p; }
+        carry += all;
+    }
+    if (t == 0) { result[0] = carry; result[1] = carry > dstCap ? 1u : 0u; }
+}
+
+// emit: one workgroup per block
+extern "C" __global__ void __launch_bounds__(256)
+gc_brotli_emit_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const uint8_t* __restrict__ stage,
+                      const GcBrotliBlockInfo* __restrict__ info, const GcBrotliPlan* __restrict__ plan, uint32_t nBlocks,
+                      uint32_t blocksPerChunk, const uint64_t* __restrict__ result, uint8_t* __restrict__ dst)
+{
+    if (result[1]) return;
+    const uint32_t t = threadIdx.x, b = blockIdx.x;
+    const uint64_t blockBase = (uint64_t)b * GC_ZSTD_BLOCK_MAX;
+    const uint32_t blockLen = (uint32_t)((srcSize - blockBase) < GC_ZSTD_BLOCK_MAX ? (srcSize - blockBase) : GC_ZSTD_BLOCK_MAX);
+    const GcBrotliBlockInfo bi = info[b];
+    uint8_t* o = dst + plan[b].off;
+    const bool first = (b % blocksPerChunk) == 0u;
+    if (first) {
+        if (t == 0) {
+            // chunk extent: up to the next chunk's first block (or the end of the stream)
+            const uint32_t nb = b + blocksPerChunk < nBlocks ? b + blocksPerChunk : nBlocks;
+            const uint64_t end = nb < nBlocks ? plan[nb].off : result[0];
+            const uint32_t csize = (uint32_t)(end - plan[b].off - 16u);
+            const uint64_t usize = (nb < nBlocks ? (uint64_t)nb * GC_ZSTD_BLOCK_MAX : srcSize) - blockBase;
+            const uint32_t hint = (uint32_t)(usize >> 16) + 1u;
+            const uint32_t h[4] = { 0x184D2A50u, 8u, csize, 0x5242u | (hint << 16) };
+            for (int i = 0; i < 16; i++) o[i] = (uint8_t)(h[i >> 2] >> (8 * (i & 3)));
+        }
+        o += 16;
+    }
+    if (!bi.stored) {
+        const uint8_t* s = stage + (uint64_t)b * GC_BR_STAGE_STRIDE;
+        for (uint32_t i = t; i < bi.size; i += 256u) o[i] = s[i];
+    } else {
+        // stored meta-block: [WBITS] ISLAST=0, MNIBBLES, MLEN-1, ISUNCOMPRESSED=1, zero padding, raw bytes
+        uint32_t hb;
+        {
+            uint64_t acc = 0; uint32_t nb = 0;
+            if (first) { acc |= 0x3ull; nb = 4; }
+            nb += 1;                                                       // ISLAST = 0
+            const uint32_t mlen1 = blockLen - 1u, nib = mlen1 < (1u << 16) ? 4u : (mlen1 < (1u << 20) ? 5u : 6u);
+            acc |= (uint64_t)(nib - 4u) << nb; nb += 2;
+            acc |= (uint64_t)mlen1 << nb; nb += nib * 4u;
+            acc |= 1ull << nb; nb += 1;                                    // ISUNCOMPRESSED
+            hb = (nb + 7u) >> 3;
+            if (t == 0) for (uint32_t i = 0; i < hb; i++) o[i] = (uint8_t)(acc >> (8u * i));
+        }
+        const uint8_t* s = src + blockBase;
+        for (uint32_t i = t; i < blockLen; i += 256u) o[hb + i] = s[i];
+        if (bi.lastInChunk && t == 0) o[hb + blockLen] = 0x03;            // ISLAST = 1, ISLASTEMPTY = 1
+    }
+}

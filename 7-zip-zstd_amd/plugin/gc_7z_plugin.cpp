@@ -22,11 +22,13 @@
 namespace {
 
 struct MethodInfo { uint64_t id; const char* name; int kind; };
-enum { KIND_ZSTD = 0, KIND_FLZMA2 = 1 };
-// Names and ids as registered by the reference (CPP/7zip/Compress/ZstdRegister.cpp:13-17, FastLzma2Register.cpp:13-18).
+enum { KIND_ZSTD = 0, KIND_FLZMA2 = 1, KIND_BROTLI = 2 };
+// Names and ids as registered by the reference (CPP/7zip/Compress/ZstdRegister.cpp:13-17, FastLzma2Register.cpp:13-18,
+// BrotliRegister.cpp:13-17).
 const MethodInfo kMethods[] = {
     { 0x4F71101, "ZSTD", KIND_ZSTD },
     { 0x21, "FLZMA2", KIND_FLZMA2 },
+    { 0x4F71102, "BROTLI", KIND_BROTLI },
 };
 const uint32_t kNumMethods = sizeof(kMethods) / sizeof(kMethods[0]);
 
@@ -76,10 +78,11 @@ class CGpuEncoder final : public ICompressCoder, public ICompressSetCoderMt, pub
     uint8_t props_[5] = { 1, 5, 3, 0, 0 };            // ZSTD: CProps{major, minor, level, reserved[2]}  ZstdEncoder.h:17-32
     uint64_t expected_ = 0;
     // input is cut at multiples of the 128 KiB frame grain, so the stream equals a single whole-buffer call
-    static const size_t kChunk = 64u << 20;
+    static const size_t kChunk = 66u << 20;          // multiple of 128 KiB and of the brotli-mt chunk sizes 1, 2, 3, 6, 11 MiB
 
 public:
-    explicit CGpuEncoder(int kind) : kind_(kind), level_(kind == KIND_ZSTD ? 3 : 5) {}
+    explicit CGpuEncoder(int kind) : kind_(kind), level_(default_level(kind)) {}
+    static int default_level(int kind) { return kind == KIND_ZSTD ? 3 : (kind == KIND_FLZMA2 ? 5 : 3); }   // BrotliEncoder.h: _props._level = 3
     ~CGpuEncoder() { if (ctx_) gc_ctx_destroy(ctx_); free(inBuf_); free(outBuf_); }
 
     HRESULT QueryInterface(const GUID& iid, void** out) override
@@ -104,14 +107,15 @@ public:
     {
         // same clamping as the reference for the properties that have a meaning here (ZstdEncoder.cpp:51-230);
         // the remaining zstd tuning properties are accepted and ignored, exactly as the reference's default branch does
-        level_ = kind_ == KIND_ZSTD ? 3 : 5; props_[2] = 3;
+        level_ = default_level(kind_); props_[2] = 3;
         for (uint32_t i = 0; i < n; i++) {
             const uint32_t v = props[i].ulVal;
             if (ids[i] == NCoderPropID::kLevel) {
                 int lv = (int)v;
                 if (v < 1) lv = 1;
                 if (kind_ == KIND_ZSTD) { if (v > 22) lv = 22; props_[2] = (uint8_t)lv; }   // ZSTD_maxCLevel()
-                else if (v > 9) lv = 9;                                                     // FL2_MAX_7Z_CLEVEL
+                else if (kind_ == KIND_FLZMA2) { if (v > 9) lv = 9; }                        // FL2_MAX_7Z_CLEVEL
+                else { lv = (int)v; if (v > 11) lv = 11; }                                  // BROTLIMT_LEVEL_MIN..MAX = 0..11
                 level_ = lv;
             }
         }
@@ -126,6 +130,7 @@ public:
     HRESULT WriteCoderProperties(ISequentialOutStream* out) override
     {
         if (kind_ == KIND_FLZMA2) { const uint8_t p = gc_flzma2_dict_prop(level_); return write_all(out, &p, 1); }    // Lzma2Encoder.cpp:353-364
+        if (kind_ == KIND_BROTLI) { const uint8_t p[3] = { 1, 0, (uint8_t)level_ }; return write_all(out, p, 3); }    // BrotliEncoder.h:18-32; decoder wants exactly 3
         return write_all(out, props_, sizeof(props_));
     }
 
@@ -136,18 +141,20 @@ public:
         size_t chunk = kChunk;
         if (expected_ && expected_ < chunk) chunk = (size_t)((expected_ + 131071u) & ~(uint64_t)131071u);
         if (chunk > inCap_) { free(inBuf_); inBuf_ = (uint8_t*)malloc(chunk); inCap_ = inBuf_ ? chunk : 0; if (!inBuf_) return E_OUTOFMEMORY; }
-        const size_t bound = kind_ == KIND_ZSTD ? gc_zstd_compress_bound(inCap_) : gc_flzma2_compress_bound(inCap_);
+        const size_t bound = kind_ == KIND_ZSTD ? gc_zstd_compress_bound(inCap_) : (kind_ == KIND_FLZMA2 ? gc_flzma2_compress_bound(inCap_) : gc_brotli_compress_bound(inCap_));
         if (bound > outCap_) { free(outBuf_); outBuf_ = (uint8_t*)malloc(bound); outCap_ = outBuf_ ? bound : 0; if (!outBuf_) return E_OUTOFMEMORY; }
         uint64_t totalIn = 0, totalOut = 0;
         for (;;) {
             size_t got = inCap_;
             HRESULT r = read_full(in, inBuf_, &got);
             if (r != S_OK) return r;
-            if (got == 0 && (totalIn != 0 || kind_ != KIND_ZSTD)) break;
+            if (got == 0 && (totalIn != 0 || kind_ == KIND_FLZMA2)) break;
             size_t produced = 0;
             // FLZMA2: every piece is a run of LZMA2 chunks starting with a dictionary reset; the single end marker follows the loop
+            // BROTLI: every piece is a run of complete brotli-mt frames
             int rc = kind_ == KIND_ZSTD ? gc_zstd_compress_host(ctx_, inBuf_, got, outBuf_, outCap_, level_, &produced)
-                                        : gc_flzma2_compress_host(ctx_, inBuf_, got, outBuf_, outCap_, level_, GC_FLZMA2_NO_END_MARK, &produced);
+                   : kind_ == KIND_FLZMA2 ? gc_flzma2_compress_host(ctx_, inBuf_, got, outBuf_, outCap_, level_, GC_FLZMA2_NO_END_MARK, &produced)
+                                          : gc_brotli_compress_host(ctx_, inBuf_, got, outBuf_, outCap_, level_, &produced);
             if (rc != GC_OK) return hresult_of(rc);
             r = write_all(out, outBuf_, produced);
             if (r != S_OK) return r;

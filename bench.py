@@ -40,6 +40,23 @@ def cpu_baseline_flzma2(x, level, budget_s=25.0):
     return res, (len(c1), sample.size)
 
 
+def cpu_baseline_brotli(x, level, budget_s=25.0):
+    """Reference brotli + brotli-mt framing (oracle/_ref/libbrotli_ref.so) on the host cores, bounded sample (first 64 MiB)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O          # cpu_baseline leg only
+    if O.ref("brotli") is None:
+        return None, None
+    cores = min(os.cpu_count() or 1, 128)          # BROTLIMT_THREAD_MAX
+    sample = x[: min(x.size, 64 * 1024 * 1024)]
+    one = sample[: 8 * 1024 * 1024]
+    t0 = time.perf_counter(); c1 = O.ref_brotlimt_compress(one, level, 1); t1 = time.perf_counter() - t0
+    t0 = time.perf_counter(); cm = O.ref_brotlimt_compress(sample, level, cores); tm = time.perf_counter() - t0
+    res = {"value": round(sample.size / tm / 1e6, 1), "unit": "MB/s", "cores": cores, "kind": "reference",
+           "sample": "BROTLIMT_compressCCtx quality %d on the first %d bytes of the same buffer, one run, %d threads; single thread (8 MiB): %.1f MB/s"
+                     % (level, sample.size, cores, one.size / t1 / 1e6)}
+    return res, (len(cm), sample.size)
+
+
 def cpu_baseline(x, level, budget_s=25.0):
     """Reference zstd (oracle/_ref/libzstd_ref.so = C/zstd compiled from /root/reference) timed on the host
     cores of this box, on a bounded sample of the same workload.  Reported, not the optimisation target."""
@@ -77,7 +94,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--codec", default="zstd", choices=["zstd", "flzma2"])
+    ap.add_argument("--codec", default="zstd", choices=["zstd", "flzma2", "brotli"])
     ap.add_argument("--bytes", type=int, default=0, help="input bytes per GPU (default: 100 000 000 = enwik8 size for zstd, 211 900 000 = Silesia for flzma2)")
     ap.add_argument("--corpus", default="")
     ap.add_argument("--level", type=int, default=0)
@@ -107,12 +124,13 @@ def main():
     corpus_mod = _u.module_from_spec(spec); spec.loader.exec_module(corpus_mod)
 
     fl2 = args.codec == "flzma2"
-    args.bytes = args.bytes or (211_900_000 if fl2 else 100_000_000)
-    args.corpus = args.corpus or ("silesia-like" if fl2 else "text-zipf")
-    args.level = args.level or (5 if fl2 else 3)
+    br = args.codec == "brotli"
+    args.bytes = args.bytes or (211_900_000 if fl2 else (1_000_000_000 if br else 100_000_000))
+    args.corpus = args.corpus or ("silesia-like" if fl2 else ("web-text" if br else "text-zipf"))
+    args.level = args.level or (5 if fl2 else (6 if br else 3))
     n = args.bytes
     x = corpus_mod.corpus(args.corpus, n, seed=20260921 + rank)      # each rank owns a different shard
-    enc = (pkg.Flzma2Encoder if fl2 else pkg.ZstdEncoder)(device=local_rank, level=args.level)
+    enc = (pkg.Flzma2Encoder if fl2 else (pkg.BrotliEncoder if br else pkg.ZstdEncoder))(device=local_rank, level=args.level)
     dev = torch.device("cuda", local_rank)
     d_src = torch.from_numpy(x).to(dev)
     cap = enc.compress_bound(n)
@@ -159,31 +177,36 @@ def main():
         dom = max([k for k in enc.KERNELS if k != "total"], key=lambda k: kern_ms[k])
         algo_bytes = n * (1.0 + 1.0 / ratio)
         achieved = algo_bytes / (kern_ms[dom] * 1e-3) / 1e9
-        kname = "gc_zstd_lz_kernel" if dom == "lz" else ("gc_lzma2_%s_kernel" if fl2 else "gc_zstd_%s_kernel") % dom
+        kname = "gc_zstd_lz_kernel" if dom == "lz" else ("gc_lzma2_%s_kernel" if fl2 else ("gc_brotli_%s_kernel" if br else "gc_zstd_%s_kernel")) % dom
         roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
                     "algorithmic_bytes_per_launch": int(algo_bytes),
                     "kernel_ms": {k: round(v, 4) for k, v in kern_ms.items()},
                     "pipeline_read_frac": round(n / (kern_ms["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                     "pipeline_rw_frac": round(algo_bytes / (kern_ms["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
-        if fl2:
+        if br:
+            cpu, ref_info = (None, None) if args.no_cpu_baseline else cpu_baseline_brotli(x, args.level)
+            ref_size = None
+        elif fl2:
             cpu, ref_info = (None, None) if args.no_cpu_baseline else cpu_baseline_flzma2(x, args.level)
             ref_size = None
         else:
             cpu, ref_size = (None, None) if args.no_cpu_baseline else cpu_baseline(x, args.level)
             ref_info = None
         line = {
-            "metric": ("flzma2-L%d compression throughput (input MB/s)" % args.level) if fl2 else
+            "metric": ("brotli-q%d (brotli-mt framed) compression throughput (input MB/s)" % args.level) if br else
+                      ("flzma2-L%d compression throughput (input MB/s)" % args.level) if fl2 else
                       "zstd-L3 compression throughput, 128 KiB independent blocks (input MB/s)",
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": ("Fast-LZMA2 level %d, Silesia stand-in (%s, %d B per GPU), LZMA2 chunks with per-chunk state reset" % (args.level, args.corpus, n)) if fl2 else
+            "config": {"workload": ("Brotli quality %d, synthetic web-text (%s, %d B per GPU), %d MiB brotli-mt chunks" % (args.level, args.corpus, n, args.level)) if br else
+                                   ("Fast-LZMA2 level %d, Silesia stand-in (%s, %d B per GPU), LZMA2 chunks with per-chunk state reset" % (args.level, args.corpus, n)) if fl2 else
                                    "zstd level 3, enwik8 stand-in (%s, %d B per GPU), 128 KiB independent blocks" % (args.corpus, n),
                        "bytes_per_gpu": n, "blocks_per_gpu": (n + 131071) // 131072, "parallelism": "range-shard x%d, no collective" % world},
             "compressed_bytes": total_csize, "ratio": round(ratio, 4),
             "ratio_vs_ref": ({"note": "reference size measured on its CPU sample only", "ref_ratio_on_sample": round(ref_info[1] / ref_info[0], 4),
-                              "ours_ratio_whole_input": round(ratio, 4)} if ref_info else None) if fl2 else
+                              "ours_ratio_whole_input": round(ratio, 4)} if ref_info else None) if (fl2 or br) else
                             (None if (not ref_size or n > 100_000_000) else
                              {"ours_over_ref_single_stream_L%d" % args.level: round(csize / ref_size, 4), "ref_bytes": ref_size}),
             "roofline": roofline, "cpu_baseline": cpu,

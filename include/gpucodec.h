@@ -84,6 +84,18 @@ int           gc_flzma2_compress_host(gc_ctx* ctx, const void* src, size_t n, vo
  * ms[6] = first kernel start -> last kernel end */
 int           gc_flzma2_last_timing(gc_ctx* ctx, float ms[7]);
 
+/* ---- BROTLI (7-Zip method id 0x4F71102): brotli-mt framed chunks, each a complete brotli stream (RFC 7932), that
+ * NCompress::NBROTLI::CDecoder (CPP/7zip/Compress/BrotliDecoder.cpp:124 -> BROTLIMT_decompressDCtx) regenerates bit-exactly.
+ *   gc_brotli_compress_host   <->  BROTLIMT_compressCCtx as driven by NCompress::NBROTLI::CEncoder::Code
+ *                                  (CPP/7zip/Compress/BrotliEncoder.cpp:118-164; C/zstdmt/brotli-mt_compress.c:209-333)
+ * `level` = the reference's quality scale 0..11; it selects the chunk size (1 MiB x level, as brotli-mt does). */
+size_t        gc_brotli_compress_bound(size_t n);
+int           gc_brotli_compress_device(gc_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t dstCapacity, int level);
+int           gc_brotli_finish(gc_ctx* ctx, size_t* compressedSize);
+int           gc_brotli_compress_host(gc_ctx* ctx, const void* src, size_t n, void* dst, size_t dstCapacity, int level, size_t* compressedSize);
+/* ms[0..3] = lz (match finder), block (histograms, prefix codes, bit stream), plan, emit; ms[4] = first kernel start -> last kernel end */
+int           gc_brotli_last_timing(gc_ctx* ctx, float ms[5]);
+
 /* raw stream handle (hipStream_t) so callers can order their own work against the context */
 void*       gc_ctx_stream(gc_ctx* ctx);
 

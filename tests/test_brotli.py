@@ -1,0 +1,157 @@
+"""BROTLI path (7-Zip method id 0x4F71102): brotli-mt framed streams produced by the HIP kernels must regenerate the input
+bit-exactly under the reference's own decoder (C/brotli + C/zstdmt/brotli-mt_decompress.c compiled into oracle/_ref).
+
+CPU tests run the unmodified kernel sources under the SIMT emulator; -m gpu tests run the product library on the MI355X and
+additionally require GPU bytes == emulator bytes."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+BLK = 128 * 1024
+
+
+def _need_ref(O):
+    if O.ref("brotli") is None:
+        pytest.skip("oracle/_ref/libbrotli_ref.so not built")
+
+
+@pytest.fixture(scope="module")
+def emu_br(pkg, emu_lib_path):
+    encs = {lv: pkg.BrotliEncoder(lib_path=emu_lib_path, level=lv) for lv in (1, 6)}
+    yield encs
+    for e in encs.values():
+        e.close()
+
+
+@pytest.fixture(scope="module")
+def gpu_br(pkg, graft):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    graft.build_hip()
+    encs = {lv: pkg.BrotliEncoder(device=0, level=lv) for lv in (1, 6)}
+    yield encs
+    for e in encs.values():
+        e.close()
+
+
+def _frames(c):
+    """walk the brotli-mt frames: (header fields, brotli payload)"""
+    out, p = [], 0
+    while p < len(c):
+        magic, eight, csize, br, hint = struct.unpack_from("<IIIHH", bytes(c[p:p + 16]))
+        assert magic == 0x184D2A50 and eight == 8 and br == 0x5242          # brotli-mt_compress.c:299-321
+        out.append((csize, hint, c[p + 16:p + 16 + csize]))
+        p += 16 + csize
+    assert p == len(c)
+    return out
+
+
+def _roundtrip(O, enc, x):
+    _need_ref(O)
+    c = enc.code(x)
+    assert np.array_equal(O.ref_brotlimt_decompress(c, x.size), x)
+    # every frame is a complete brotli stream that the plain (non-mt) reference decoder accepts, and the hint covers it
+    pos = 0
+    for csize, hint, payload in _frames(c):
+        part = O.ref_brotli_decompress(payload, hint << 16)
+        assert np.array_equal(part, x[pos:pos + part.size])
+        pos += part.size
+    assert pos == x.size
+    return c
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 7, 64, 255, 1000, 4097, BLK - 1, BLK, BLK + 1])
+def test_emu_edge_sizes(O, emu_br, n):
+    _roundtrip(O, emu_br[6], O.corpus("text-zipf", n))
+
+
+@pytest.mark.parametrize("kind", ["text-zipf", "lz-7zip", "silesia-like", "web-text", "random", "zeros"])
+def test_emu_corpora(O, emu_br, kind):
+    x = O.corpus(kind, BLK + 70_000)
+    c = _roundtrip(O, emu_br[6], x)
+    if kind == "random":
+        assert len(c) <= x.size + 64                    # stored meta-blocks
+    if kind in ("text-zipf", "web-text"):
+        ref = O.ref_brotlimt_compress(x, 6, 1)
+        assert len(c) <= 1.15 * len(ref), (len(c), len(ref))
+
+
+def test_emu_patterns_and_degenerate_alphabets(O, emu_br):
+    enc = emu_br[6]
+    _roundtrip(O, enc, np.tile(np.arange(7, dtype=np.uint8), (BLK + 50) // 7 + 1)[:BLK + 50].copy())
+    r = O.corpus("random", 70_000)
+    _roundtrip(O, enc, np.concatenate([r, r[:50_000]]))
+    rng = np.random.default_rng(7)
+    p = 1.0 / np.arange(1, 257) ** 1.2; p /= p.sum()
+    _roundtrip(O, enc, rng.choice(256, size=BLK, p=p).astype(np.uint8))          # 256-symbol literal code, deep tree
+    _roundtrip(O, enc, np.full(5000, 65, dtype=np.uint8))                          # one literal symbol: NSYM = 1 simple code
+    _roundtrip(O, enc, np.frombuffer(b"ab" * 3000, dtype=np.uint8).copy())         # two literal symbols
+    q = 1.0 / 2.0 ** np.arange(1, 41); q /= q.sum()
+    _roundtrip(O, enc, rng.choice(40, size=60_000, p=q).astype(np.uint8))           # Fibonacci-like counts: 15-bit length limit
+
+
+def test_emu_multi_chunk_framing(O, emu_br):
+    _need_ref(O)
+    x = O.corpus("text-zipf", 9 * BLK + 100)             # level 1: 1 MiB chunks = 8 blocks -> 2 frames
+    c = _roundtrip(O, emu_br[1], x)
+    fr = _frames(c)
+    assert len(fr) == 2 and fr[0][1] == (8 * BLK >> 16) + 1
+
+
+def test_emu_deterministic(O, emu_br):
+    x = O.corpus("silesia-like", BLK)
+    assert np.array_equal(emu_br[6].code(x), emu_br[6].code(x))
+
+
+def test_golden_fixtures_decode_under_reference(O):
+    """the reference's own regression fixtures (tests/regr-arc/test.txt.br, .br-mt.br) pin the decoder side of the oracle"""
+    _need_ref(O)
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    plain = np.fromfile(os.path.join(g, "test.txt.br"), dtype=np.uint8)
+    mt = np.fromfile(os.path.join(g, "test.txt.br-mt.br"), dtype=np.uint8)
+    a = O.ref_brotli_decompress(plain, 1 << 20)
+    b = O.ref_brotlimt_decompress(mt, 1 << 20)
+    assert a.size > 0 and np.array_equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [0, 1, 3, 64, 4097, BLK - 1, BLK, BLK + 1, 3 * BLK + 17])
+def test_gpu_edge_sizes(O, gpu_br, n):
+    _roundtrip(O, gpu_br[6], O.corpus("text-zipf", n))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["text-zipf", "lz-7zip", "silesia-like", "web-text", "random", "zeros"])
+def test_gpu_corpora(O, gpu_br, kind):
+    x = O.corpus(kind, 8 * 1024 * 1024 + 999)
+    for lv in (1, 6):
+        _roundtrip(O, gpu_br[lv], x)
+
+
+@pytest.mark.gpu
+def test_gpu_bytes_equal_emulator_bytes(O, gpu_br, emu_br):
+    for kind in ("text-zipf", "silesia-like"):
+        x = O.corpus(kind, 2 * BLK + 1234)
+        assert np.array_equal(gpu_br[6].code(x), emu_br[6].code(x)), kind
+
+
+@pytest.mark.gpu
+def test_gpu_100mb_web_text_device_api(O, gpu_br):
+    import torch
+    _need_ref(O)
+    n = 100_000_000
+    x = O.corpus("web-text", n)
+    enc = gpu_br[6]
+    d_src = torch.from_numpy(x).to("cuda:0")
+    cap = enc.compress_bound(n)
+    d_dst = torch.empty(cap, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    enc.code_device(d_src.data_ptr(), n, d_dst.data_ptr(), cap)
+    size = enc.finish()
+    comp = d_dst[:size].cpu().numpy()
+    assert np.array_equal(O.ref_brotlimt_decompress(comp, n, threads=8), x)
+    assert enc.last_timing_ms()["total"] > 0

@@ -28,6 +28,7 @@ def test_exports_and_method_listing(emu_module):
     assert lines[0].split()[1:3] == ["4F71101", "ZSTD"]            # id and name of ZstdRegister.cpp:13-17
     assert "enc=1 dec=0" in lines[0] and "clsid=23170F69-40C1-2791" in lines[0]
     assert lines[1].split()[1:3] == ["21", "FLZMA2"]               # FastLzma2Register.cpp:13-18
+    assert lines[2].split()[1:3] == ["4F71102", "BROTLI"]          # BrotliRegister.cpp:13-17
     import ctypes
     lib = ctypes.CDLL(emu_module)
     for sym in ["GetNumberOfMethods", "GetMethodProperty", "CreateEncoder", "CreateDecoder", "CreateObject", "GetModuleProp"]:
@@ -63,6 +64,20 @@ def test_flzma2_code_through_com_surface(O, emu_module, pkg, emu_lib_path, tmp_p
     assert np.array_equal(O.port_lzma2_decode(c, n, prop[0]), x)
     if O.ref("flzma2") is not None:
         assert np.array_equal(O.ref_lzma2_decode(c, n, prop[0]), x)
+
+
+@pytest.mark.parametrize("n", [0, 9, BLK + 4321])
+def test_brotli_code_through_com_surface(O, emu_module, tmp_path, n):
+    if O.ref("brotli") is None:
+        pytest.skip("oracle/_ref not built")
+    x = O.corpus("web-text", n)
+    src, dst, props = tmp_path / "in.bin", tmp_path / "out.br", tmp_path / "props.bin"
+    x.tofile(src)
+    r = _host(emu_module, "encode", "BROTLI", 6, src, dst, props)
+    assert r.returncode == 0, r.stderr + r.stdout
+    c = np.fromfile(dst, dtype=np.uint8)
+    assert props.read_bytes() == bytes([1, 0, 6])                   # BrotliEncoder.h:18-32; BrotliDecoder.cpp:86-96 wants exactly 3
+    assert np.array_equal(O.ref_brotlimt_decompress(c, n), x)
 
 
 @pytest.mark.gpu

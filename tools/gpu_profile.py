@@ -22,7 +22,8 @@ spec = _u.spec_from_file_location("c", os.path.join(ROOT, "7-zip-zstd_amd", "cor
 cm = _u.module_from_spec(spec); spec.loader.exec_module(cm)
 x = cm.corpus(a.corpus, a.bytes)
 fl2 = a.codec == "flzma2"
-enc = pkg.Flzma2Encoder(device=0, level=a.level or 5) if fl2 else pkg.ZstdEncoder(device=0)
+br = a.codec == "brotli"
+enc = pkg.Flzma2Encoder(device=0, level=a.level or 5) if fl2 else (pkg.BrotliEncoder(device=0, level=a.level or 6) if br else pkg.ZstdEncoder(device=0))
 d_src = torch.from_numpy(x).cuda(); cap = enc.compress_bound(x.size); d_dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
 def run():
     enc.code_device(d_src.data_ptr(), x.size, d_dst.data_ptr(), cap); return enc.finish()
@@ -31,7 +32,7 @@ acc = {}
 for _ in range(a.reps):
     size = run()
     for k, v in enc.last_timing_ms().items(): acc[k] = acc.get(k, 0) + v / a.reps
-if fl2:
+if fl2 or br:
     ph, tp = {}, acc
 else:
     enc.set_phase_profile(True)
