@@ -178,8 +178,15 @@ def main():
         algo_bytes = n * (1.0 + 1.0 / ratio)
         achieved = algo_bytes / (kern_ms[dom] * 1e-3) / 1e9
         kname = "gc_zstd_lz_kernel" if dom == "lz" else ("gc_lzma2_%s_kernel" if fl2 else ("gc_brotli_%s_kernel" if br else "gc_zstd_%s_kernel")) % dom
+        traffic = None
+        try:        # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/gpu_pmc.sh), same workload only
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            if pm["_workload_bytes"].get(args.codec) == n and kname in pm.get(args.codec, {}):
+                traffic = pm[args.codec][kname]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(algo_bytes),
                     "kernel_ms": {k: round(v, 4) for k, v in kern_ms.items()},
                     "pipeline_read_frac": round(n / (kern_ms["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
