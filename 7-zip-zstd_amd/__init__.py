@@ -23,7 +23,7 @@ _ERR = {-1: "GC_ERR_NO_DEVICE", -2: "GC_ERR_HIP", -3: "GC_ERR_NOMEM", -4: "GC_ER
 
 EXPORTS = ["gc_device_count", "gc_ctx_create", "gc_ctx_destroy", "gc_last_error_message", "gc_zstd_compress_bound",
            "gc_zstd_compress_device", "gc_zstd_finish", "gc_zstd_compress_host", "gc_zstd_last_timing", "gc_ctx_stream",
-           "gc_zstd_set_phase_profile", "gc_zstd_phase_profile",
+           "gc_zstd_set_phase_profile", "gc_zstd_phase_profile", "gc_mf_last_timing",
            "gc_flzma2_compress_bound", "gc_flzma2_dict_prop", "gc_flzma2_compress_device", "gc_flzma2_finish", "gc_flzma2_compress_host",
            "gc_flzma2_last_timing",
            "gc_brotli_compress_bound", "gc_brotli_compress_device", "gc_brotli_finish", "gc_brotli_compress_host", "gc_brotli_last_timing"]
@@ -56,6 +56,8 @@ def load_library(path=None):
     lib.gc_zstd_compress_host.restype = C.c_int
     lib.gc_zstd_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.gc_zstd_last_timing.restype = C.c_int
+    lib.gc_mf_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    lib.gc_mf_last_timing.restype = C.c_int
     lib.gc_zstd_set_phase_profile.argtypes = [C.c_void_p, C.c_int]
     lib.gc_zstd_set_phase_profile.restype = C.c_int
     lib.gc_zstd_phase_profile.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
@@ -114,6 +116,15 @@ class _EncoderBase:
 
     def stream(self):
         return self._lib.gc_ctx_stream(self._ctx)
+
+    MF_KERNELS = ("mf.count", "mf.scan", "mf.scatter", "mf.link", "mf.parse")
+
+    def mf_timing_ms(self):
+        """Stage durations of the windowed match finder in the last call, or None if the block-local finder ran."""
+        ms = (C.c_float * 5)()
+        if self._lib.gc_mf_last_timing(self._ctx, ms) != GC_OK:
+            return None
+        return dict(zip(self.MF_KERNELS, [float(x) for x in ms]))
 
 
 class Flzma2Encoder(_EncoderBase):

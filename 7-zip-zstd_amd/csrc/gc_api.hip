@@ -8,6 +8,7 @@
 #include "gc_common.h"
 #include "gc_lzma2.h"
 #include "gc_brotli.h"
+#include "gc_mf.h"
 #ifdef HIPEMU
 #include "hip_runtime_stub.h"
 #else
@@ -15,6 +16,7 @@
 #define GC_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
 #endif
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <new>
 
@@ -23,10 +25,21 @@ struct GcFramePlan { uint64_t off; uint32_t size; uint32_t compressed; };
 extern "C" __global__ void gc_zstd_lz_kernel(const uint8_t*, uint64_t, GcSeqRaw*, uint8_t*, GcBlockMeta*, unsigned long long*);
 extern "C" __global__ void gc_zstd_huf_kernel(const uint8_t*, const GcBlockMeta*, uint8_t*, GcSectionInfo*);
 extern "C" __global__ void gc_zstd_seq_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t*, uint32_t*, uint8_t*, uint16_t*,
-                                              uint8_t*, GcSectionInfo*, uint64_t, unsigned long long*);
-extern "C" __global__ void gc_zstd_plan_kernel(const GcSectionInfo*, uint32_t, uint64_t, uint64_t, GcFramePlan*, uint64_t*);
+                                              uint8_t*, GcSectionInfo*, uint64_t, uint32_t, unsigned long long*);
+extern "C" __global__ void gc_zstd_plan_kernel(const GcSectionInfo*, uint32_t, uint64_t, uint64_t, uint32_t, GcFramePlan*, uint64_t*);
 extern "C" __global__ void gc_zstd_emit_kernel(const uint8_t*, uint64_t, const uint8_t*, const uint8_t*, const GcSectionInfo*,
-                                               const GcFramePlan*, const uint64_t*, uint8_t*);
+                                               const GcFramePlan*, const uint64_t*, uint32_t, uint32_t, uint8_t*);
+
+extern "C" __global__ void gc_mf_count_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t*);
+extern "C" __global__ void gc_mf_scan_kernel(uint32_t*, uint32_t*, uint32_t);
+extern "C" __global__ void gc_mf_scatter_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*, uint64_t);
+extern "C" __global__ void gc_mf_link_kernel(const uint32_t*, GcMfEntry*, uint64_t, uint64_t);
+extern "C" __global__ void gc_lzw_parse_kernel(const uint8_t*, uint64_t, uint32_t, const uint32_t*, const uint32_t*, const GcMfEntry*, uint64_t,
+                                               GcSeqRaw*, uint8_t*, GcBlockMeta*, unsigned long long*);
+#ifndef HIPEMU
+extern "C" __global__ void gc_lzw_parse_kernel_occ2(const uint8_t*, uint64_t, uint32_t, const uint32_t*, const uint32_t*, const GcMfEntry*, uint64_t,
+                                                    GcSeqRaw*, uint8_t*, GcBlockMeta*, unsigned long long*);
+#endif
 
 extern "C" __global__ void gc_lzma2_prep_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t*, uint32_t*);
 extern "C" __global__ void gc_lzma2_model_kernel(const uint8_t*, uint64_t, const uint64_t*, const uint32_t*, uint32_t, uint16_t*, GcLzmaChunkInfo*);
@@ -54,6 +67,11 @@ struct gc_ctx {
     uint8_t* litSec; uint8_t* seqSec; GcSectionInfo* info; GcFramePlan* plan; uint64_t* result;
     uint32_t* lzNM; GcLzmaChunkInfo* lzInfo; GcLzmaPlan* lzPlan; uint16_t* lzStream; size_t lzStreamCap;       // FLZMA2 path (M aliases seqPacked, chunk staging aliases litSec)
     uint8_t* brStage; GcBrotliBlockInfo* brInfo; GcBrotliPlan* brPlan;    // BROTLI path
+    // windowed match finder (gc_mf.h): counts/offsets, partition starts, entry lists; grown on demand
+    uint32_t* mfCnt; size_t mfCntCap; uint32_t* mfPartStart; size_t mfPartCap; GcMfEntry* mfEnt; size_t mfEntCap;
+    hipEvent_t evMf[6];       // W1 start, W1 end, W2 end, W3 end, W4 end, W5 end
+    bool mfTimed;
+    bool lzwOcc2;             // W5 build with two workgroups per CU (tuning knob, env GC_LZW_OCC2)
     int lastCodec;            // 0 zstd, 1 flzma2: which kernels the events of the last call bracket
     uint64_t* hostResult;     // pinned
     // staging for the host-buffer entry point
@@ -96,8 +114,10 @@ extern "C" int gc_ctx_create(gc_ctx** out, int device)
     c->device = device;
     if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess) { delete c; return GC_ERR_HIP; }
     for (int i = 0; i < 8; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return GC_ERR_HIP; }
+    for (int i = 0; i < 6; i++) if (hipEventCreate(&c->evMf[i]) != hipSuccess) { delete c; return GC_ERR_HIP; }
     if (hipMalloc((void**)&c->prof, (GC_LZ_PHASES + GC_SEQ_PHASES) * sizeof(unsigned long long)) != hipSuccess) { delete c; return GC_ERR_NOMEM; }
     if (hipMalloc((void**)&c->result, 16) != hipSuccess || hipHostMalloc((void**)&c->hostResult, 16) != hipSuccess) { delete c; return GC_ERR_NOMEM; }
+    { const char* e = getenv("GC_LZW_OCC2"); c->lzwOcc2 = e && e[0] == '1'; }
     *out = c;
     return GC_OK;
 }
@@ -119,7 +139,9 @@ extern "C" void gc_ctx_destroy(gc_ctx* c)
     hipStreamSynchronize(c->stream);
     free_workspace(c);
     hipFree(c->prof); hipFree(c->result); hipHostFree(c->hostResult); hipFree(c->dIn); hipFree(c->dOut);
+    hipFree(c->mfCnt); hipFree(c->mfPartStart); hipFree(c->mfEnt);
     for (int i = 0; i < 8; i++) hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 6; i++) hipEventDestroy(c->evMf[i]);
     hipStreamDestroy(c->stream2);
     hipStreamDestroy(c->stream);
     delete c;
@@ -159,10 +181,74 @@ static int ensure_workspace(gc_ctx* c, uint32_t nBlocks)
     return GC_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ match finder dispatch
+// frameBlocks == 1: K1, the block-local finder (hash tables in LDS, matches stay inside the 128 KiB block).
+// frameBlocks  > 1: W1..W5, the windowed finder (gc_lz_window.hip): matches reach back to the start of the frame.
+// Both leave the same interface behind: seqRaw / lit / meta per block.
+static int launch_finder(gc_ctx* c, const uint8_t* src, size_t n, uint32_t frameBlocks, unsigned long long* prof)
+{
+    const uint32_t nBlocks = gc_num_blocks(n);
+    c->mfTimed = false;
+    if (frameBlocks <= 1u) {
+        GC_LAUNCH(gc_zstd_lz_kernel, nBlocks, 1024, c->stream, src, (uint64_t)n, c->seqRaw, c->lit, c->meta, prof);
+        return GC_OK;
+    }
+    const GcMfGeom g = gc_mf_geom(n, frameBlocks);
+    const size_t needCnt = (size_t)g.nFrames * GC_MF_KINDS * GC_MF_PARTS * g.tilesPerFrame;
+    const size_t needPart = (size_t)g.nFrames * GC_MF_KINDS * (GC_MF_PARTS + 1u);
+    const size_t needEnt = (size_t)GC_MF_KINDS * g.entStride;
+    if (needCnt > c->mfCntCap || needPart > c->mfPartCap || needEnt > c->mfEntCap) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (needCnt > c->mfCntCap) { hipFree(c->mfCnt); c->mfCnt = nullptr; c->mfCntCap = 0;
+            if (hipMalloc((void**)&c->mfCnt, needCnt * sizeof(uint32_t)) != hipSuccess) return GC_ERR_NOMEM; c->mfCntCap = needCnt; }
+        if (needPart > c->mfPartCap) { hipFree(c->mfPartStart); c->mfPartStart = nullptr; c->mfPartCap = 0;
+            if (hipMalloc((void**)&c->mfPartStart, needPart * sizeof(uint32_t)) != hipSuccess) return GC_ERR_NOMEM; c->mfPartCap = needPart; }
+        if (needEnt > c->mfEntCap) { hipFree(c->mfEnt); c->mfEnt = nullptr; c->mfEntCap = 0;
+            if (hipMalloc((void**)&c->mfEnt, needEnt * sizeof(GcMfEntry)) != hipSuccess) {
+                snprintf(c->err, sizeof(c->err), "match-finder workspace of %zu bytes failed", needEnt * sizeof(GcMfEntry)); return GC_ERR_NOMEM; }
+            c->mfEntCap = needEnt; }
+    }
+    const uint32_t nTiles = g.nFrames * g.tilesPerFrame;
+    HIPCHK(c, hipEventRecord(c->evMf[0], c->stream));
+    GC_LAUNCH(gc_mf_count_kernel, (nTiles + 3u) / 4u, 256, c->stream, src, (uint64_t)n, frameBlocks, g.nFrames, c->mfCnt);
+    HIPCHK(c, hipEventRecord(c->evMf[1], c->stream));
+    GC_LAUNCH(gc_mf_scan_kernel, g.nFrames * GC_MF_KINDS, 1024, c->stream, c->mfCnt, c->mfPartStart, g.tilesPerFrame);
+    HIPCHK(c, hipEventRecord(c->evMf[2], c->stream));
+    GC_LAUNCH(gc_mf_scatter_kernel, (nTiles + 3u) / 4u, 256, c->stream, src, (uint64_t)n, frameBlocks, g.nFrames, (const uint32_t*)c->mfCnt,
+              c->mfEnt, g.entStride);
+    HIPCHK(c, hipEventRecord(c->evMf[3], c->stream));
+    GC_LAUNCH(gc_mf_link_kernel, g.nFrames * GC_MF_KINDS * GC_MF_PARTS, 1024, c->stream, (const uint32_t*)c->mfPartStart, c->mfEnt, g.entStride,
+              g.frameBytes);
+    HIPCHK(c, hipEventRecord(c->evMf[4], c->stream));
+#ifndef HIPEMU
+    if (c->lzwOcc2)
+        GC_LAUNCH(gc_lzw_parse_kernel_occ2, nBlocks, 1024, c->stream, src, (uint64_t)n, frameBlocks, (const uint32_t*)c->mfCnt,
+                  (const uint32_t*)c->mfPartStart, (const GcMfEntry*)c->mfEnt, g.entStride, c->seqRaw, c->lit, c->meta, prof);
+    else
+#endif
+    GC_LAUNCH(gc_lzw_parse_kernel, nBlocks, 1024, c->stream, src, (uint64_t)n, frameBlocks, (const uint32_t*)c->mfCnt,
+              (const uint32_t*)c->mfPartStart, (const GcMfEntry*)c->mfEnt, g.entStride, c->seqRaw, c->lit, c->meta, prof);
+    HIPCHK(c, hipEventRecord(c->evMf[5], c->stream));
+    c->mfTimed = true;
+    return GC_OK;
+}
+
+// ms[0..4] = count, scan, scatter, link, parse of the windowed match finder in the last call (after *_finish)
+extern "C" int gc_mf_last_timing(gc_ctx* c, float ms[5])
+{
+    if (!c || !c->timed || c->pending || !c->mfTimed) return GC_ERR_PARAM;
+    for (int i = 0; i < 5; i++) HIPCHK(c, hipEventElapsedTime(&ms[i], c->evMf[i], c->evMf[i + 1]));
+    return GC_OK;
+}
+
+// zstd level -> blocks per frame.  Levels 1-2 (the reference's `fast` strategy, clevels.h:29-30) use the block-local finder and
+// one frame per block; level 3 and up (dfast and stronger, clevels.h:31-47, windowLog >= 21) use the windowed finder with
+// 8 MiB frames.
+static uint32_t zstd_frame_blocks(int level) { return level <= 2 ? 1u : GC_MF_MAX_FRAME_BLOCKS; }
+
 extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, void* d_dst, size_t dstCap, int level)
 {
     if (!c || (!d_src && n) || !d_dst) return GC_ERR_PARAM;
-    (void)level;
     HIPCHK(c, hipSetDevice(c->device));
     c->timed = false;
     if (n == 0) {
@@ -180,23 +266,25 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
     if (rc != GC_OK) return rc;
     const uint8_t* src = (const uint8_t*)d_src;
     if (c->profOn) { HIPCHK(c, hipMemsetAsync(c->prof, 0, (GC_LZ_PHASES + GC_SEQ_PHASES) * sizeof(unsigned long long), c->stream)); c->profBlocks = nBlocks; }
+    const uint32_t frameBlocks = zstd_frame_blocks(level) < nBlocks ? zstd_frame_blocks(level) : nBlocks;   // short input: one frame
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    GC_LAUNCH(gc_zstd_lz_kernel, nBlocks, 1024, c->stream, src, (uint64_t)n, c->seqRaw, c->lit, c->meta, c->profOn ? c->prof : nullptr);
+    rc = launch_finder(c, src, n, frameBlocks, c->profOn ? c->prof : nullptr);
+    if (rc != GC_OK) return rc;
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     // K2 (literals) and K3 (sequences) are independent consumers of K1: run them on two streams
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev[1], 0));
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream2));
     GC_LAUNCH(gc_zstd_seq_kernel, nBlocks, 256, c->stream2, (const GcSeqRaw*)c->seqRaw, (const GcBlockMeta*)c->meta, c->seqPacked,
-              c->seqOff, c->codes, c->stOut, c->seqSec, c->info, (uint64_t)n, c->profOn ? c->prof + GC_LZ_PHASES : nullptr);
+              c->seqOff, c->codes, c->stOut, c->seqSec, c->info, (uint64_t)n, frameBlocks, c->profOn ? c->prof + GC_LZ_PHASES : nullptr);
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream2));
     GC_LAUNCH(gc_zstd_huf_kernel, nBlocks, 256, c->stream, (const uint8_t*)c->lit, (const GcBlockMeta*)c->meta, c->litSec, c->info);
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev[4], 0));
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
-    GC_LAUNCH(gc_zstd_plan_kernel, 1, 1024, c->stream, (const GcSectionInfo*)c->info, nBlocks, (uint64_t)n, (uint64_t)dstCap, c->plan, c->result);
+    GC_LAUNCH(gc_zstd_plan_kernel, 1, 1024, c->stream, (const GcSectionInfo*)c->info, nBlocks, (uint64_t)n, (uint64_t)dstCap, frameBlocks, c->plan, c->result);
     HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     GC_LAUNCH(gc_zstd_emit_kernel, nBlocks, 256, c->stream, src, (uint64_t)n, (const uint8_t*)c->litSec, (const uint8_t*)c->seqSec,
-              (const GcSectionInfo*)c->info, (const GcFramePlan*)c->plan, (const uint64_t*)c->result, (uint8_t*)d_dst);
+              (const GcSectionInfo*)c->info, (const GcFramePlan*)c->plan, (const uint64_t*)c->result, nBlocks, frameBlocks, (uint8_t*)d_dst);
     HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
     HIPCHK(c, hipGetLastError());
     c->pending = true; c->timed = true; c->lastCodec = 0;

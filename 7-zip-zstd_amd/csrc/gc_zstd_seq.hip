@@ -162,6 +162,7 @@ gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __res
                    uint8_t* __restrict__ codes,           // scratch: 3 * GC_MAX_SEQ_PER_BLOCK per block (LL, OF, ML)
                    uint16_t* __restrict__ stOut,          // scratch: 3 * GC_MAX_SEQ_PER_BLOCK per block
                    uint8_t* __restrict__ seqSec, GcSectionInfo* __restrict__ info, uint64_t srcSize,
+                   uint32_t frameBlocks,                  // blocks per zstd frame: repeat offsets carry over inside a frame
                    unsigned long long* __restrict__ prof /* optional per-phase cycle sums */)
 {
     __shared__ SeqTab sTab[3];
@@ -220,12 +221,18 @@ gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __res
     SEQ_PHASE(0);         // merge
 
     // ---- S2: repeat offsets as scans, then codes + histograms
-    //      virtual history: index -1 -> offset 1, -2 -> 4 (start state {1,4,8}, zstd_internal.h:65)
+    //      virtual history: index -1 -> offset 1, -2 -> 4 (start state {1,4,8}, zstd_internal.h:65) in the first block of a
+    //      frame.  In later blocks the decoder arrives with the history the previous block left behind; this block is coded
+    //      without knowing it (blocks stay independent units of work): the virtual history is "unknown" (0, never equal to
+    //      an offset), so no repeat code refers to it.  rep1 = previous offset and rep2 = offset before the current run hold
+    //      for the decoder whatever the unknown part was, because every code emitted below moves exactly those two slots.
+    const bool firstInFrame = (b % frameBlocks) == 0u;
+    const uint32_t virt1 = firstInFrame ? 1u : 0u, virt2 = firstInFrame ? 4u : 0u;
     uint32_t carryRun = 1u;      // (run start index + 2) of the run containing the last sequence of the previous tile
     for (uint32_t tb = 0; tb < nSeq; tb += SEQ_T) {
         const uint32_t j = tb + t;
-        uint32_t off = 0, prevOff = 1u;
-        if (j < nSeq) { off = O[j]; prevOff = j ? O[j - 1u] : 1u; }
+        uint32_t off = 0, prevOff = virt1;
+        if (j < nSeq) { off = O[j]; prevOff = j ? O[j - 1u] : virt1; }
         const uint32_t v = (j < nSeq && off != prevOff) ? j + 2u : 0u;
         uint32_t tot;
         const uint32_t runIncl = max(seq_incl_maxscan(v, sWave, &tot), carryRun);  // run start (+2) of the run containing j
@@ -237,7 +244,7 @@ gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __res
             const uint32_t ll = (uint32_t)(pk & 0x1FFFFu), ml = (uint32_t)((pk >> 17) & 0x3FFFFu);
             const uint32_t rep1 = prevOff;
             const int32_t before = (int32_t)runPrev - 3;             // index whose offset is rep2 (>= -2)
-            const uint32_t rep2 = before >= 0 ? O[before] : (before == -1 ? 1u : 4u);
+            const uint32_t rep2 = before >= 0 ? O[before] : (before == -1 ? virt1 : virt2);
             uint32_t offBase;
             if (ll != 0u) offBase = (off == rep1) ? 1u : ((off == rep2) ? 2u : off + 3u);
             else offBase = (off == rep2) ? 1u : ((rep1 > 1u && off == rep1 - 1u) ? 3u : off + 3u);

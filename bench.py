@@ -3,9 +3,10 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the whole hot path (K1 lz -> K2 huf -> K3 seq -> K4 plan -> K5 emit) over one
+A "step" is one pass of the whole hot path (match finder W1..W5 -> K2 huf || K3 seq -> K4 plan -> K5 emit) over one
 100 000 000-byte buffer per GPU that is already resident in HBM (enwik8 is not available offline; the stand-in
-is the deterministic `text-zipf` corpus, labelled synthetic).  The zstd blocks are 128 KiB independent frames.
+is the deterministic `text-zipf` corpus, labelled synthetic).  At level 3 the 128 KiB zstd blocks are grouped into
+independent 8 MiB frames (windowed match finder); levels 1-2 use one frame per block (block-local finder).
 With N>1 every rank compresses its own 100 MB shard (weak scaling, no data-path collective: the host
 range-splits the input and concatenates frames; RCCL is only used for the timing barrier / max-reduction).
 
@@ -147,6 +148,7 @@ def main():
         csize = enc.finish()
 
     kern_ms = {k: 0.0 for k in enc.KERNELS}
+    mf_ms = {}
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -155,6 +157,10 @@ def main():
         t = enc.last_timing_ms()         # hipEvent pairs recorded on the library's own stream around each kernel
         for k in kern_ms:
             kern_ms[k] += t[k]
+        mf = enc.mf_timing_ms()          # stage durations of the windowed match finder (None: block-local finder ran)
+        if mf:
+            for k, v in mf.items():
+                mf_ms[k] = mf_ms.get(k, 0.0) + v
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -168,16 +174,25 @@ def main():
         total_csize = csize
     for k in kern_ms:
         kern_ms[k] /= max(args.steps, 1)
+    for k in mf_ms:
+        mf_ms[k] /= max(args.steps, 1)
 
     if rank == 0:
         total_in = n * world
         value = total_in * args.steps / elapsed / 1e6
         ratio = n / csize
         # dominant kernel = the longest of the five; algorithmic bytes per launch = N_in * (1 + 1/ratio)  
-        dom = max([k for k in enc.KERNELS if k != "total"], key=lambda k: kern_ms[k])
+        per_kernel = {k: v for k, v in kern_ms.items() if k != "total"}
+        if mf_ms:                        # "lz" is the sum of the five finder kernels: rank them individually
+            per_kernel.pop("lz")
+            per_kernel.update(mf_ms)
+        dom = max(per_kernel, key=lambda k: per_kernel[k])
         algo_bytes = n * (1.0 + 1.0 / ratio)
-        achieved = algo_bytes / (kern_ms[dom] * 1e-3) / 1e9
-        kname = "gc_zstd_lz_kernel" if dom == "lz" else ("gc_lzma2_%s_kernel" if fl2 else ("gc_brotli_%s_kernel" if br else "gc_zstd_%s_kernel")) % dom
+        achieved = algo_bytes / (per_kernel[dom] * 1e-3) / 1e9
+        mf_names = {"mf.count": "gc_mf_count_kernel", "mf.scan": "gc_mf_scan_kernel", "mf.scatter": "gc_mf_scatter_kernel",
+                    "mf.link": "gc_mf_link_kernel", "mf.parse": "gc_lzw_parse_kernel"}
+        kname = mf_names[dom] if dom in mf_names else \
+            "gc_zstd_lz_kernel" if dom == "lz" else ("gc_lzma2_%s_kernel" if fl2 else ("gc_brotli_%s_kernel" if br else "gc_zstd_%s_kernel")) % dom
         traffic = None
         try:        # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/gpu_pmc.sh), same workload only
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
@@ -188,7 +203,7 @@ def main():
         roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "algorithmic_bytes_per_launch": int(algo_bytes),
-                    "kernel_ms": {k: round(v, 4) for k, v in kern_ms.items()},
+                    "kernel_ms": {k: round(v, 4) for k, v in list(kern_ms.items()) + list(mf_ms.items())},
                     "pipeline_read_frac": round(n / (kern_ms["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                     "pipeline_rw_frac": round(algo_bytes / (kern_ms["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
         if br:
@@ -203,13 +218,14 @@ def main():
         line = {
             "metric": ("brotli-q%d (brotli-mt framed) compression throughput (input MB/s)" % args.level) if br else
                       ("flzma2-L%d compression throughput (input MB/s)" % args.level) if fl2 else
-                      "zstd-L3 compression throughput, 128 KiB independent blocks (input MB/s)",
+                      "zstd-L%d compression throughput (input MB/s)" % args.level,
             "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": ("Brotli quality %d, synthetic web-text (%s, %d B per GPU), %d MiB brotli-mt chunks" % (args.level, args.corpus, n, args.level)) if br else
                                    ("Fast-LZMA2 level %d, Silesia stand-in (%s, %d B per GPU), LZMA2 chunks with per-chunk state reset" % (args.level, args.corpus, n)) if fl2 else
-                                   "zstd level 3, enwik8 stand-in (%s, %d B per GPU), 128 KiB independent blocks" % (args.corpus, n),
+                                   "zstd level %d, enwik8 stand-in (%s, %d B per GPU), 128 KiB blocks in %s" % (
+                                       args.level, args.corpus, n, "independent 8 MiB frames (windowed match finder)" if mf_ms else "one frame per block (block-local match finder)"),
                        "bytes_per_gpu": n, "blocks_per_gpu": (n + 131071) // 131072, "parallelism": "range-shard x%d, no collective" % world},
             "compressed_bytes": total_csize, "ratio": round(ratio, 4),
             "ratio_vs_ref": ({"note": "reference size measured on its CPU sample only", "ref_ratio_on_sample": round(ref_info[1] / ref_info[0], 4),

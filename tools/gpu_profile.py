@@ -23,7 +23,7 @@ cm = _u.module_from_spec(spec); spec.loader.exec_module(cm)
 x = cm.corpus(a.corpus, a.bytes)
 fl2 = a.codec == "flzma2"
 br = a.codec == "brotli"
-enc = pkg.Flzma2Encoder(device=0, level=a.level or 5) if fl2 else (pkg.BrotliEncoder(device=0, level=a.level or 6) if br else pkg.ZstdEncoder(device=0))
+enc = pkg.Flzma2Encoder(device=0, level=a.level or 5) if fl2 else (pkg.BrotliEncoder(device=0, level=a.level or 6) if br else pkg.ZstdEncoder(device=0, level=a.level or 3))
 d_src = torch.from_numpy(x).cuda(); cap = enc.compress_bound(x.size); d_dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
 def run():
     enc.code_device(d_src.data_ptr(), x.size, d_dst.data_ptr(), cap); return enc.finish()
@@ -32,6 +32,7 @@ acc = {}
 for _ in range(a.reps):
     size = run()
     for k, v in enc.last_timing_ms().items(): acc[k] = acc.get(k, 0) + v / a.reps
+    for k, v in (enc.mf_timing_ms() or {}).items(): acc[k] = acc.get(k, 0) + v / a.reps
 if fl2 or br:
     ph, tp = {}, acc
 else:
