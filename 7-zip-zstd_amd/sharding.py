@@ -11,6 +11,15 @@ torch.distributed is used for the gather of the compressed byte strings only (gl
 import numpy as np
 
 GRAIN_ZSTD = 128 * 1024
+FRAME_ZSTD = 64 * GRAIN_ZSTD      # level >= 3: 8 MiB frames (windowed match finder, csrc/gc_mf.h GC_MF_MAX_FRAME_BLOCKS)
+
+
+def zstd_grain(level, n, world):
+    """Independence grain of the zstd path: one block at levels 1-2; a whole 8 MiB frame at level >= 3 when every rank gets at
+    least one (a range that starts inside a frame would only cut that frame's window short, the stream stays valid)."""
+    if level >= 3 and n >= world * FRAME_ZSTD:
+        return FRAME_ZSTD
+    return GRAIN_ZSTD
 
 
 def shard_ranges(n, world, grain=GRAIN_ZSTD):

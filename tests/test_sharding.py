@@ -32,7 +32,7 @@ def test_shard_ranges_cover_and_align(graft):
             assert max(units) - min(units) <= 1
 
 
-def _worker(rank, world, port, emu_lib, out_path, n):
+def _worker(rank, world, port, emu_lib, out_path, n, level):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import torch.distributed as dist
     import __graft_entry__ as g
@@ -41,7 +41,7 @@ def _worker(rank, world, port, emu_lib, out_path, n):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     pkg = g.load_package()
     S = _sharding(g)
-    enc = pkg.ZstdEncoder(lib_path=emu_lib)
+    enc = pkg.ZstdEncoder(lib_path=emu_lib, level=level)
     x = O.corpus("text-zipf", n)
     y = S.compress_sharded(enc, x, rank, world, dist)
     if rank == 0:
@@ -51,21 +51,29 @@ def _worker(rank, world, port, emu_lib, out_path, n):
     enc.close()
 
 
-@pytest.mark.parametrize("n", [3 * BLK + 1234, BLK // 2])
-def test_two_rank_gloo_equals_single_rank(graft, O, emu_enc, emu_lib_path, tmp_path, n):
+@pytest.mark.parametrize("n,level", [(3 * BLK + 1234, 1), (3 * BLK + 1234, 3), (BLK // 2, 3)])
+def test_two_rank_gloo_equals_single_rank(graft, pkg, O, emu_lib_path, tmp_path, n, level):
     import torch.multiprocessing as mp
     out = str(tmp_path / "sharded.npy")
     port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, emu_lib_path, out, n), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port, emu_lib_path, out, n, level), nprocs=2, join=True)
+    emu_enc = pkg.ZstdEncoder(lib_path=emu_lib_path, level=level)
     y = np.load(out)
     x = O.corpus("text-zipf", n)
     # the sharded stream is the concatenation of the per-range streams (frames are independent) ...
     S = _sharding(graft)
     parts = [emu_enc.code(x[s:e]) for s, e in S.shard_ranges(n, 2) if e > s]
     assert np.array_equal(y, np.concatenate(parts))
-    # ... and differs from the single-rank stream only in the last ~80 bytes before a range end, which the match finder
-    # leaves as literals because it never reads past the end of the buffer it was given
-    assert abs(int(y.size) - int(emu_enc.code(x).size)) <= 64
+    # ... at levels 1-2 (one frame per block) it differs from the single-rank stream only in the last ~80 bytes before a
+    # range end, which the match finder leaves as literals because it never reads past the end of the buffer it was given;
+    # at level >= 3 every range starts its own frame (its window does not reach into the previous range), which costs ratio
+    # on inputs this small and nothing measurable at 8 MiB frames
+    whole = int(emu_enc.code(x).size)
+    if level <= 2:
+        assert abs(int(y.size) - whole) <= 64
+    else:
+        assert whole <= int(y.size) <= whole * 1.10
     assert np.array_equal(O.port_zstd_decompress(y, n), x)
     if O.ref("zstd") is not None:
         assert np.array_equal(O.ref_zstd_decompress(y, n), x)
+    emu_enc.close()
