@@ -363,9 +363,13 @@ extern "C" size_t gc_flzma2_compress_bound(size_t n)
     return n + nChunks * 6u + 16u;
 }
 
+// level -> blocks per match-finder frame.  Levels 1-2: block-local finder (128 KiB window); level 3 and up: windowed finder,
+// 8 MiB frames = the dictionary size of the reference's level 5 (fl2_compress.c:37-104).
+static uint32_t flzma2_frame_blocks(int level) { return level <= 2 ? 1u : GC_MF_MAX_FRAME_BLOCKS; }
+
 // dictionary-size property byte of the 7z coder (Lzma2Encoder.cpp:353-364): dict = (2|(p&1)) << (p/2+11).
-// Matches never reach back further than one 128 KiB match-finder block.
-extern "C" unsigned char gc_flzma2_dict_prop(int level) { (void)level; return 10; }
+// Matches never reach back further than the start of their frame: 128 KiB (p = 10) or 8 MiB (p = 22).
+extern "C" unsigned char gc_flzma2_dict_prop(int level) { return flzma2_frame_blocks(level) == 1u ? 10 : 22; }
 
 extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n, void* d_dst, size_t dstCap, int level, unsigned flags)
 {
@@ -397,8 +401,10 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
             c->lzStreamCap = need;
         }
     }
+    const uint32_t frameBlocks = flzma2_frame_blocks(level) < nBlocks ? flzma2_frame_blocks(level) : nBlocks;
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    GC_LAUNCH(gc_zstd_lz_kernel, nBlocks, 1024, c->stream, src, (uint64_t)n, c->seqRaw, c->lit, c->meta, (unsigned long long*)nullptr);
+    rc = launch_finder(c, src, n, frameBlocks, nullptr);
+    if (rc != GC_OK) return rc;
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     GC_LAUNCH(gc_lzma2_prep_kernel, nBlocks, 256, c->stream, (const GcSeqRaw*)c->seqRaw, (const GcBlockMeta*)c->meta, c->seqPacked, c->lzNM);
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
@@ -456,6 +462,15 @@ extern "C" int gc_flzma2_compress_host(gc_ctx* c, const void* src, size_t n, voi
 // chunk = 1 MiB x level as in brotli-mt (C/zstdmt/brotli-mt_compress.c:115-118), in 128 KiB blocks
 static uint32_t brotli_blocks_per_chunk(int level) { if (level < 1) level = 1; if (level > 11) level = 11; return (uint32_t)level * 8u; }
 
+// quality -> blocks per match-finder frame.  Qualities 0-2: block-local finder.  Above: the windowed finder over frames that
+// tile the chunk exactly (a copy must not reach into the previous chunk: every chunk is a brotli stream of its own), the whole
+// chunk when it is <= 8 MiB (qualities 3-8), half of it above (72/80/88 blocks -> 36/40/44).
+static uint32_t brotli_frame_blocks(int level, uint32_t bpc)
+{
+    if (level <= 2) return 1u;
+    return bpc <= GC_MF_MAX_FRAME_BLOCKS ? bpc : bpc / 2u;
+}
+
 extern "C" size_t gc_brotli_compress_bound(size_t n)
 {
     const size_t nb = n ? (n + GC_ZSTD_BLOCK_MAX - 1) / GC_ZSTD_BLOCK_MAX : 1;
@@ -483,8 +498,11 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     const uint32_t bpc = brotli_blocks_per_chunk(level);
     const uint8_t* src = (const uint8_t*)d_src;
     HIPCHK(c, hipMemsetAsync(c->brStage, 0, (size_t)nBlocks * GC_BR_STAGE_STRIDE, c->stream));
+    uint32_t frameBlocks = brotli_frame_blocks(level, bpc);
+    if (frameBlocks > nBlocks) frameBlocks = nBlocks;                       // short input: one chunk, one frame
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    GC_LAUNCH(gc_zstd_lz_kernel, nBlocks, 1024, c->stream, src, (uint64_t)n, c->seqRaw, c->lit, c->meta, (unsigned long long*)nullptr);
+    rc = launch_finder(c, src, n, frameBlocks, nullptr);
+    if (rc != GC_OK) return rc;
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     GC_LAUNCH(gc_brotli_block_kernel, nBlocks, 256, c->stream, src, (uint64_t)n, (const GcSeqRaw*)c->seqRaw, (const uint8_t*)c->lit,
               (const GcBlockMeta*)c->meta, c->seqPacked, c->seqOff, bpc, (uint32_t*)c->brStage, c->brInfo);

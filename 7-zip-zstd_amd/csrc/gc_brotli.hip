@@ -344,7 +344,7 @@ gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
     // ---- header: [stream header] meta-block header + the three code descriptions (one lane)
     if (t == 0) {
         BrBW w; w.out = sHdr; w.acc = 0; w.nbits = 0; w.bytes = 0;
-        if (firstInChunk) bw_put(w, 0x3u, 4);                              // WBITS = 18: '1' + n = 1 (RFC 7932 section 9.1); window 256 KiB - 16
+        if (firstInChunk) bw_put(w, GC_BR_WBITS_CODE, 4);                  // WBITS = 24: '1' + n = 7 (RFC 7932 section 9.1); window 16 MiB - 16
         bw_put(w, 0u, 1);                                                  // ISLAST = 0 (the stream is closed by an empty last meta-block)
         const uint32_t mlen1 = blockLen - 1u;
         const uint32_t nib = mlen1 < (1u << 16) ? 4u : (mlen1 < (1u << 20) ? 5u : 6u);
@@ -525,7 +525,7 @@ gc_brotli_emit_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
         uint32_t hb;
         {
             uint64_t acc = 0; uint32_t nb = 0;
-            if (first) { acc |= 0x3ull; nb = 4; }
+            if (first) { acc |= (uint64_t)GC_BR_WBITS_CODE; nb = 4; }
             nb += 1;                                                       // ISLAST = 0
             const uint32_t mlen1 = blockLen - 1u, nib = mlen1 < (1u << 16) ? 4u : (mlen1 < (1u << 20) ? 5u : 6u);
             acc |= (uint64_t)(nib - 4u) << nb; nb += 2;

@@ -26,13 +26,16 @@
 struct MfKeys { bool ok; uint32_t kL, kS; };
 
 // keys of absolute position P, or ok = false when P is not listed:
-//   - fewer than 8 bytes left in the frame, or no full compare window left in the input (such positions never match)
+//   - no full compare window (GC_MATCH_CAP + 16 bytes) left in the FRAME: such positions never match.  The limit is the frame
+//     end, not the input end, so that a frame's bytes do not depend on what follows it (a frame-aligned range shard produces
+//     exactly the frames the whole input would)
 //   - inside a run of one byte value (the 8 bytes at P equal the 8 bytes at P-1): all those positions share one key and would
 //     pile into one partition; W5 gives them the candidate P-1 instead, which is what the table would have returned
 __device__ __forceinline__ MfKeys mf_keys(const uint8_t* src, uint64_t srcSize, uint64_t P, uint64_t frameStart, uint64_t frameEnd)
 {
     MfKeys r; r.ok = false; r.kL = 0; r.kS = 0;
-    if (P + 8u <= frameEnd && P + GC_MATCH_CAP + 16u <= srcSize) {
+    (void)srcSize;
+    if (P + GC_MATCH_CAP + 16u <= frameEnd) {
         const uint64_t x = gc_ld64(src + P);
         bool run = false;
         if (P > frameStart) run = ((x << 8) | (uint64_t)src[P - 1u]) == x;
@@ -225,6 +228,7 @@ lzw_parse_body(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frame
     const uint32_t TPF = frameBlocks * GC_MF_TILES_PER_BLOCK;
     const uint64_t frameBytes = (uint64_t)frameBlocks * GC_ZSTD_BLOCK_MAX;
     const uint64_t frameStart = (uint64_t)frame * frameBytes;
+    const uint64_t frameEnd = (frameStart + frameBytes) < srcSize ? (frameStart + frameBytes) : srcSize;
     const uint64_t base = (uint64_t)b * GC_ZSTD_BLOCK_MAX;
     const uint32_t n = (uint32_t)((srcSize - base) < GC_ZSTD_BLOCK_MAX ? (srcSize - base) : GC_ZSTD_BLOCK_MAX);
     const uint32_t wbase = bif * GC_ZSTD_BLOCK_MAX;            // block start relative to the frame
@@ -272,7 +276,7 @@ lzw_parse_body(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frame
             const uint32_t p = cbase + t;                       // block-relative
             const uint32_t pw = wbase + p;                      // frame-relative
             const bool inBlock = p < n;
-            const bool canMatch = p + 8u <= n && base + p + GC_MATCH_CAP + 16u <= srcSize;
+            const bool canMatch = p + 8u <= n && base + p + GC_MATCH_CAP + 16u <= frameEnd;
             const LzW16 me = own;
             const uint32_t pb = prevByte;
             uint32_t bestLen = 0, bestOff = 0;
