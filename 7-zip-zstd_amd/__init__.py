@@ -117,11 +117,11 @@ class _EncoderBase:
     def stream(self):
         return self._lib.gc_ctx_stream(self._ctx)
 
-    MF_KERNELS = ("mf.count", "mf.scan", "mf.scatter", "mf.link", "mf.parse")
+    MF_KERNELS = ("mf.count", "mf.scan", "mf.scatter", "mf.link", "mf.verify", "mf.parse")
 
     def mf_timing_ms(self):
         """Stage durations of the windowed match finder in the last call, or None if the block-local finder ran."""
-        ms = (C.c_float * 5)()
+        ms = (C.c_float * 6)()
         if self._lib.gc_mf_last_timing(self._ctx, ms) != GC_OK:
             return None
         return dict(zip(self.MF_KERNELS, [float(x) for x in ms]))

@@ -30,16 +30,12 @@ extern "C" __global__ void gc_zstd_plan_kernel(const GcSectionInfo*, uint32_t, u
 extern "C" __global__ void gc_zstd_emit_kernel(const uint8_t*, uint64_t, const uint8_t*, const uint8_t*, const GcSectionInfo*,
                                                const GcFramePlan*, const uint64_t*, uint32_t, uint32_t, uint8_t*);
 
-extern "C" __global__ void gc_mf_count_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t*);
-extern "C" __global__ void gc_mf_scan_kernel(uint32_t*, uint32_t*, uint32_t);
-extern "C" __global__ void gc_mf_scatter_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*, uint64_t);
-extern "C" __global__ void gc_mf_link_kernel(const uint32_t*, GcMfEntry*, uint64_t, uint64_t);
-extern "C" __global__ void gc_lzw_parse_kernel(const uint8_t*, uint64_t, uint32_t, const uint32_t*, const uint32_t*, const GcMfEntry*, uint64_t,
-                                               GcSeqRaw*, uint8_t*, GcBlockMeta*, unsigned long long*);
-#ifndef HIPEMU
-extern "C" __global__ void gc_lzw_parse_kernel_occ2(const uint8_t*, uint64_t, uint32_t, const uint32_t*, const uint32_t*, const GcMfEntry*, uint64_t,
-                                                    GcSeqRaw*, uint8_t*, GcBlockMeta*, unsigned long long*);
-#endif
+extern "C" __global__ void gc_mf_count_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
+extern "C" __global__ void gc_mf_scan_kernel(uint32_t*, uint32_t);
+extern "C" __global__ void gc_mf_scatter_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
+extern "C" __global__ void gc_mf_link_kernel(const uint32_t*, const GcMfEntry*, GcMfEntry*, uint32_t, uint64_t);
+extern "C" __global__ void gc_mf_verify_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
+extern "C" __global__ void gc_mf_parse_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, const uint32_t*, GcSeqRaw*, uint8_t*, GcBlockMeta*);
 
 extern "C" __global__ void gc_lzma2_prep_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t*, uint32_t*);
 extern "C" __global__ void gc_lzma2_model_kernel(const uint8_t*, uint64_t, const uint64_t*, const uint32_t*, uint32_t, uint16_t*, GcLzmaChunkInfo*);
@@ -68,10 +64,9 @@ struct gc_ctx {
     uint32_t* lzNM; GcLzmaChunkInfo* lzInfo; GcLzmaPlan* lzPlan; uint16_t* lzStream; size_t lzStreamCap;       // FLZMA2 path (M aliases seqPacked, chunk staging aliases litSec)
     uint8_t* brStage; GcBrotliBlockInfo* brInfo; GcBrotliPlan* brPlan;    // BROTLI path
     // windowed match finder (gc_mf.h): counts/offsets, partition starts, entry lists; grown on demand
-    uint32_t* mfCnt; size_t mfCntCap; uint32_t* mfPartStart; size_t mfPartCap; GcMfEntry* mfEnt; size_t mfEntCap;
-    hipEvent_t evMf[6];       // W1 start, W1 end, W2 end, W3 end, W4 end, W5 end
+    uint32_t* mfCnt; size_t mfCntCap; GcMfEntry* mfEnt; size_t mfEntCap; GcMfEntry* mfEnt2; size_t mfEnt2Cap; uint32_t* mfRec; size_t mfRecCap;
+    hipEvent_t evMf[7];       // W1 start, W1 end, W2 end, W3 end, W4 end, W5 end, W6 end
     bool mfTimed;
-    bool lzwOcc2;             // W5 build with two workgroups per CU (tuning knob, env GC_LZW_OCC2)
     int lastCodec;            // 0 zstd, 1 flzma2: which kernels the events of the last call bracket
     uint64_t* hostResult;     // pinned
     // staging for the host-buffer entry point
@@ -114,10 +109,9 @@ extern "C" int gc_ctx_create(gc_ctx** out, int device)
     c->device = device;
     if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess) { delete c; return GC_ERR_HIP; }
     for (int i = 0; i < 8; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return GC_ERR_HIP; }
-    for (int i = 0; i < 6; i++) if (hipEventCreate(&c->evMf[i]) != hipSuccess) { delete c; return GC_ERR_HIP; }
+    for (int i = 0; i < 7; i++) if (hipEventCreate(&c->evMf[i]) != hipSuccess) { delete c; return GC_ERR_HIP; }
     if (hipMalloc((void**)&c->prof, (GC_LZ_PHASES + GC_SEQ_PHASES) * sizeof(unsigned long long)) != hipSuccess) { delete c; return GC_ERR_NOMEM; }
     if (hipMalloc((void**)&c->result, 16) != hipSuccess || hipHostMalloc((void**)&c->hostResult, 16) != hipSuccess) { delete c; return GC_ERR_NOMEM; }
-    { const char* e = getenv("GC_LZW_OCC2"); c->lzwOcc2 = e && e[0] == '1'; }
     *out = c;
     return GC_OK;
 }
@@ -139,9 +133,9 @@ extern "C" void gc_ctx_destroy(gc_ctx* c)
     hipStreamSynchronize(c->stream);
     free_workspace(c);
     hipFree(c->prof); hipFree(c->result); hipHostFree(c->hostResult); hipFree(c->dIn); hipFree(c->dOut);
-    hipFree(c->mfCnt); hipFree(c->mfPartStart); hipFree(c->mfEnt);
+    hipFree(c->mfCnt); hipFree(c->mfEnt); hipFree(c->mfEnt2); hipFree(c->mfRec);
     for (int i = 0; i < 8; i++) hipEventDestroy(c->ev[i]);
-    for (int i = 0; i < 6; i++) hipEventDestroy(c->evMf[i]);
+    for (int i = 0; i < 7; i++) hipEventDestroy(c->evMf[i]);
     hipStreamDestroy(c->stream2);
     hipStreamDestroy(c->stream);
     delete c;
@@ -183,8 +177,17 @@ static int ensure_workspace(gc_ctx* c, uint32_t nBlocks)
 
 // ------------------------------------------------------------------------------------------------ match finder dispatch
 // frameBlocks == 1: K1, the block-local finder (hash tables in LDS, matches stay inside the 128 KiB block).
-// frameBlocks  > 1: W1..W5, the windowed finder (gc_lz_window.hip): matches reach back to the start of the frame.
+// frameBlocks  > 1: W1..W6, the windowed finder (gc_lz_window.hip): matches reach back to the start of the frame.
 // Both leave the same interface behind: seqRaw / lit / meta per block.
+static int mf_grow(gc_ctx* c, void** p, size_t* cap, size_t needBytes, const char* what)
+{
+    if (needBytes <= *cap) return GC_OK;
+    hipFree(*p); *p = nullptr; *cap = 0;
+    if (hipMalloc(p, needBytes) != hipSuccess) { snprintf(c->err, sizeof(c->err), "match-finder workspace (%s) of %zu bytes failed", what, needBytes); return GC_ERR_NOMEM; }
+    *cap = needBytes;
+    return GC_OK;
+}
+
 static int launch_finder(gc_ctx* c, const uint8_t* src, size_t n, uint32_t frameBlocks, unsigned long long* prof)
 {
     const uint32_t nBlocks = gc_num_blocks(n);
@@ -194,50 +197,41 @@ static int launch_finder(gc_ctx* c, const uint8_t* src, size_t n, uint32_t frame
         return GC_OK;
     }
     const GcMfGeom g = gc_mf_geom(n, frameBlocks);
-    const size_t needCnt = (size_t)g.nFrames * GC_MF_KINDS * GC_MF_PARTS * g.tilesPerFrame;
-    const size_t needPart = (size_t)g.nFrames * GC_MF_KINDS * (GC_MF_PARTS + 1u);
-    const size_t needEnt = (size_t)GC_MF_KINDS * g.entStride;
-    if (needCnt > c->mfCntCap || needPart > c->mfPartCap || needEnt > c->mfEntCap) {
+    const size_t needCnt = g.cntWords * sizeof(uint32_t), needEnt = (size_t)g.nFrames * g.frameBytes * sizeof(GcMfEntry);
+    const size_t needRec = (size_t)nBlocks * GC_ZSTD_BLOCK_MAX * sizeof(uint32_t);
+    if (needCnt > c->mfCntCap || needEnt > c->mfEntCap || needEnt > c->mfEnt2Cap || needRec > c->mfRecCap) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (needCnt > c->mfCntCap) { hipFree(c->mfCnt); c->mfCnt = nullptr; c->mfCntCap = 0;
-            if (hipMalloc((void**)&c->mfCnt, needCnt * sizeof(uint32_t)) != hipSuccess) return GC_ERR_NOMEM; c->mfCntCap = needCnt; }
-        if (needPart > c->mfPartCap) { hipFree(c->mfPartStart); c->mfPartStart = nullptr; c->mfPartCap = 0;
-            if (hipMalloc((void**)&c->mfPartStart, needPart * sizeof(uint32_t)) != hipSuccess) return GC_ERR_NOMEM; c->mfPartCap = needPart; }
-        if (needEnt > c->mfEntCap) { hipFree(c->mfEnt); c->mfEnt = nullptr; c->mfEntCap = 0;
-            if (hipMalloc((void**)&c->mfEnt, needEnt * sizeof(GcMfEntry)) != hipSuccess) {
-                snprintf(c->err, sizeof(c->err), "match-finder workspace of %zu bytes failed", needEnt * sizeof(GcMfEntry)); return GC_ERR_NOMEM; }
-            c->mfEntCap = needEnt; }
+        int rc;
+        if ((rc = mf_grow(c, (void**)&c->mfCnt, &c->mfCntCap, needCnt, "offsets")) != GC_OK) return rc;
+        if ((rc = mf_grow(c, (void**)&c->mfEnt, &c->mfEntCap, needEnt, "entries")) != GC_OK) return rc;
+        if ((rc = mf_grow(c, (void**)&c->mfEnt2, &c->mfEnt2Cap, needEnt, "linked entries")) != GC_OK) return rc;
+        if ((rc = mf_grow(c, (void**)&c->mfRec, &c->mfRecCap, needRec, "records")) != GC_OK) return rc;
     }
-    const uint32_t nTiles = g.nFrames * g.tilesPerFrame;
+    const uint32_t perT = gc_xcd_per(g.nTiles), perB = gc_xcd_per(nBlocks);
     HIPCHK(c, hipEventRecord(c->evMf[0], c->stream));
-    GC_LAUNCH(gc_mf_count_kernel, (nTiles + 3u) / 4u, 256, c->stream, src, (uint64_t)n, frameBlocks, g.nFrames, c->mfCnt);
+    GC_LAUNCH(gc_mf_count_kernel, perT * GC_XCDS, 256, c->stream, src, (uint64_t)n, frameBlocks, g.nTiles, perT, c->mfCnt);
     HIPCHK(c, hipEventRecord(c->evMf[1], c->stream));
-    GC_LAUNCH(gc_mf_scan_kernel, g.nFrames * GC_MF_KINDS, 1024, c->stream, c->mfCnt, c->mfPartStart, g.tilesPerFrame);
+    GC_LAUNCH(gc_mf_scan_kernel, g.nFrames, 1024, c->stream, c->mfCnt, g.tilesPerFrame);
     HIPCHK(c, hipEventRecord(c->evMf[2], c->stream));
-    GC_LAUNCH(gc_mf_scatter_kernel, (nTiles + 3u) / 4u, 256, c->stream, src, (uint64_t)n, frameBlocks, g.nFrames, (const uint32_t*)c->mfCnt,
-              c->mfEnt, g.entStride);
+    GC_LAUNCH(gc_mf_scatter_kernel, perT * GC_XCDS, 256, c->stream, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)c->mfCnt, c->mfEnt);
     HIPCHK(c, hipEventRecord(c->evMf[3], c->stream));
-    GC_LAUNCH(gc_mf_link_kernel, g.nFrames * GC_MF_KINDS * GC_MF_PARTS, 1024, c->stream, (const uint32_t*)c->mfPartStart, c->mfEnt, g.entStride,
-              g.frameBytes);
+    GC_LAUNCH(gc_mf_link_kernel, g.nFrames * GC_MF_PARTS * GC_MF_LINK_SEGS, 64, c->stream, (const uint32_t*)c->mfCnt, (const GcMfEntry*)c->mfEnt, c->mfEnt2, g.tilesPerFrame, g.frameBytes);
     HIPCHK(c, hipEventRecord(c->evMf[4], c->stream));
-#ifndef HIPEMU
-    if (c->lzwOcc2)
-        GC_LAUNCH(gc_lzw_parse_kernel_occ2, nBlocks, 1024, c->stream, src, (uint64_t)n, frameBlocks, (const uint32_t*)c->mfCnt,
-                  (const uint32_t*)c->mfPartStart, (const GcMfEntry*)c->mfEnt, g.entStride, c->seqRaw, c->lit, c->meta, prof);
-    else
-#endif
-    GC_LAUNCH(gc_lzw_parse_kernel, nBlocks, 1024, c->stream, src, (uint64_t)n, frameBlocks, (const uint32_t*)c->mfCnt,
-              (const uint32_t*)c->mfPartStart, (const GcMfEntry*)c->mfEnt, g.entStride, c->seqRaw, c->lit, c->meta, prof);
+    GC_LAUNCH(gc_mf_verify_kernel, perT * GC_XCDS, GC_MF_VERIFY_T, c->stream, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)c->mfCnt,
+              (const GcMfEntry*)c->mfEnt2, c->mfRec);
     HIPCHK(c, hipEventRecord(c->evMf[5], c->stream));
+    GC_LAUNCH(gc_mf_parse_kernel, perB * GC_XCDS, GC_MF_PARSE_T, c->stream, src, (uint64_t)n, nBlocks, perB, (const uint32_t*)c->mfRec, c->seqRaw, c->lit, c->meta);
+    HIPCHK(c, hipEventRecord(c->evMf[6], c->stream));
+    (void)prof;
     c->mfTimed = true;
     return GC_OK;
 }
 
-// ms[0..4] = count, scan, scatter, link, parse of the windowed match finder in the last call (after *_finish)
-extern "C" int gc_mf_last_timing(gc_ctx* c, float ms[5])
+// ms[0..5] = count, scan, scatter, link, verify, parse of the windowed match finder in the last call (after *_finish)
+extern "C" int gc_mf_last_timing(gc_ctx* c, float ms[6])
 {
     if (!c || !c->timed || c->pending || !c->mfTimed) return GC_ERR_PARAM;
-    for (int i = 0; i < 5; i++) HIPCHK(c, hipEventElapsedTime(&ms[i], c->evMf[i], c->evMf[i + 1]));
+    for (int i = 0; i < 6; i++) HIPCHK(c, hipEventElapsedTime(&ms[i], c->evMf[i], c->evMf[i + 1]));
     return GC_OK;
 }
 

@@ -35,8 +35,31 @@ __device__ __forceinline__ uint32_t gc_uniform(uint32_t v)
 #endif
 }
 
-// make LDS writes of this wave visible to its other lanes (wave-synchronous code: no workgroup barrier needed)
+// make LDS writes of this wave visible to its other lanes (wave-synchronous code: no workgroup barrier needed).
+// The fence is restricted to the LDS address space: a fence over all address spaces makes the wave wait for every global
+// load and store it has in flight (s_waitcnt vmcnt(0)), which serialises software-pipelined loops.  Global memory written by
+// one lane and read by another lane of the same wave needs gc_wave_sync_global().
 __device__ __forceinline__ void gc_wave_sync()
+{
+#ifdef HIPEMU
+    hipemu::wave_barrier();
+#else
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+#endif
+}
+// Marks the end of one step of a wave-synchronous loop whose steps communicate only through LDS operations.  The hardware
+// executes the LDS operations of a wave in program order, so nothing is needed there; the emulator runs its lanes one after
+// another and needs the rendezvous to keep the steps of different lanes from overtaking each other.
+__device__ __forceinline__ void gc_wave_step()
+{
+#ifdef HIPEMU
+    hipemu::wave_barrier();
+#else
+    __builtin_amdgcn_wave_barrier();
+#endif
+}
+__device__ __forceinline__ void gc_wave_sync_global()
 {
 #ifdef HIPEMU
     hipemu::wave_barrier();

@@ -1,6 +1,6 @@
 // gc_lz_parse.h -- the position-parallel verification, parse and emit steps shared by the two match finders:
 //   K1 gc_zstd_lz_kernel   (gc_zstd_lz.hip)   block-local finder, candidates from LDS hash tables
-//   W5 gc_lzw_parse_kernel (gc_lz_window.hip) windowed finder, candidates from the partitioned link pass
+//   (the windowed finder W1..W6, gc_lz_window.hip, shares lz_verify and lz_gain; its parse W6 is hierarchical instead)
 // Both evaluate LZ_T consecutive positions per step; what differs is only where the candidates come from and how
 // far back they may lie.  See gc_zstd_lz.hip for the description of the phases (P4 verify, P5 parse, P6 emit).
 #pragma once

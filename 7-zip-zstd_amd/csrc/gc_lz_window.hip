@@ -1,323 +1,561 @@
-// gc_lz_window.hip -- the windowed match finder W1..W5 (geometry and overview: gc_mf.h).
+// gc_lz_window.hip -- the windowed match finder W1..W6 (geometry, entry formats and overview: gc_mf.h).
 //
 // Serves the higher levels of all three codecs: matches reach back to the start of their frame (<= 8 MiB) instead of the start
 // of their 128 KiB block.  Replaces, per position, the table lookups of ZSTD_compressBlock_doubleFast
 // (C/zstd/zstd_double_fast.c:105-323: long + short table, most recent position wins), and stands in for RMF_buildTable /
 // RMF_getMatch (C/fast-lzma2/radix_engine.h:920, radix_get.h:60) and brotli's H6 FindLongestMatch
-// (C/brotli/enc/hash_longest_match64_inc.h:157-290) as the source of candidates.
+// (C/brotli/enc/hash_longest_match64_inc.h:157-290) as the source of candidates; the parse replaces the greedy / one-step-lazy
+// loops around them (zstd_double_fast.c:169-300, backward_references_inc.h:80-130).
 //
-// Why partition: "most recent earlier position with the same key" is a sequential notion.  Inside one LDS table it can be had
-// deterministically with ds_max (K1); for a multi-MiB window the table does not fit LDS, and a table in HBM would be hammered by
-// random atomics from all CUs (one 128-byte line per 4-byte update).  Splitting the key space 128 ways by the top hash bits
-// turns the problem into 128 independent position-ordered lists per frame and kind, each small enough for one workgroup's LDS
-// table; every byte the passes move through HBM is a coalesced run (>= 512 B on average).
+// Why partition: "most recent earlier position with the same key" is a sequential notion.  For a multi-MiB window the tables
+// do not fit LDS, and tables in HBM would be hammered by random atomics from all CUs (one 128-byte line per 4-byte update).
+// Splitting the key space 256 ways turns the problem into 256 independent position-ordered lists per frame, each served by
+// ONE WAVE with private LDS tables: the wave reproduces sequential insertion (64 entries per step, one returning ds_max per
+// table: the LDS unit itself serialises the lanes that share a slot), so there are no barriers and no cross-wave atomics, and
+// every byte the passes move through HBM is a coalesced run.
 //
-// Determinism: W3's scatter is stable (ranks from ballots, no atomics on addresses), W4 uses order-independent ds_max / ds_min
-// updates between barriers, so the candidate lists -- and with them the compressed bytes -- do not depend on wave timing.
+// Determinism: W3 is a stable counting sort (ranks from ballots), W4 is sequential semantics by construction, W5 and W6 are
+// pure functions of their inputs -- the compressed bytes do not depend on wave timing.
+//
+// HBM traffic per input byte: W1 1 R; W3 1 R + 8 W; W4 8 R + 8 W (two entry arrays); W5 8 R + 4 W (+ candidate windows, mostly L2);
+// W6 8 R (records, twice) + sequences and literals out.
 #include "gc_mf.h"
 #include "gc_lz_parse.h"
 
-#define MF_WG        256u             // W1 / W3: four waves, one tile each
-#define MF_WAVES     (MF_WG / 64u)
-#define LINK_T       1024u            // W4: entries per step
-#define LINK_LOG     14u              // W4: LDS table slots per partition (x 128 partitions = 2^21 slots per frame and kind)
-#define LINK_LOG_C   11u
+#define MF_T         256u             // W1 / W3: threads per tile
+#define MF_WAVES     (MF_T / 64u)
+static_assert(MF_T == GC_MF_PARTS, "W1/W3 use one thread per partition for the histogram rows");
+#define MF_STAGE_PAD 16u              // bytes staged in front of / behind the tile
+#define MF_STAGE_WORDS ((GC_MF_TILE + 2u * MF_STAGE_PAD) / 4u)
 
-struct MfKeys { bool ok; uint32_t kL, kS; };
+__device__ __forceinline__ uint32_t mf_item(uint32_t bid, uint32_t per) { return (bid & (GC_XCDS - 1u)) * per + (bid >> 3); }
 
-// keys of absolute position P, or ok = false when P is not listed:
+struct MfTile {
+    uint32_t frame, tif;              // frame index, tile in frame
+    uint64_t frameStart, frameEnd;    // absolute
+    uint64_t tileStart;               // absolute
+    uint32_t len;                     // positions of the tile that exist (0: the tile lies past the end of the input)
+};
+__device__ __forceinline__ MfTile mf_tile(uint32_t tile, uint32_t frameBlocks, uint64_t srcSize)
+{
+    MfTile T;
+    const uint32_t TPF = frameBlocks * GC_MF_TILES_PER_BLOCK;
+    const uint64_t frameBytes = (uint64_t)frameBlocks * GC_ZSTD_BLOCK_MAX;
+    T.frame = tile / TPF; T.tif = tile % TPF;
+    T.frameStart = (uint64_t)T.frame * frameBytes;
+    T.frameEnd = (T.frameStart + frameBytes) < srcSize ? (T.frameStart + frameBytes) : srcSize;
+    T.tileStart = T.frameStart + (uint64_t)T.tif * GC_MF_TILE;
+    T.len = T.tileStart < T.frameEnd ? (uint32_t)((T.frameEnd - T.tileStart) < GC_MF_TILE ? (T.frameEnd - T.tileStart) : GC_MF_TILE) : 0u;
+    return T;
+}
+
+// Stage input bytes [tileStart - 16, tileStart + GC_MF_TILE + 16) into LDS (zero outside the input) with 16-byte loads.
+// LDS byte i <-> input position tileStart - 16 + i.
+__device__ __forceinline__ void mf_stage(uint32_t* sW, const uint8_t* __restrict__ src, uint64_t srcSize, uint64_t tileStart, uint32_t t, uint32_t nThreads)
+{
+    for (uint32_t c = t; c < MF_STAGE_WORDS / 4u; c += nThreads) {
+        GcU4 v; v.x = v.y = v.z = v.w = 0;
+        if (tileStart + 16ull * c >= MF_STAGE_PAD) {
+            const uint64_t pos = tileStart + 16ull * c - MF_STAGE_PAD;
+            if (pos + 16u <= srcSize) __builtin_memcpy(&v, src + pos, 16);
+            else if (pos < srcSize) { uint8_t tmp[16]; for (uint32_t i = 0; i < 16u; i++) tmp[i] = pos + i < srcSize ? src[pos + i] : (uint8_t)0; __builtin_memcpy(&v, tmp, 16); }
+        }
+        sW[4u * c] = v.x; sW[4u * c + 1u] = v.y; sW[4u * c + 2u] = v.z; sW[4u * c + 3u] = v.w;
+    }
+}
+// bytes i .. i+7 of the staged tile: three aligned LDS words + two funnel shifts (v_alignbit)
+__device__ __forceinline__ uint64_t mf_lds_ld64(const uint32_t* sW, uint32_t i)
+{
+    const uint32_t w = i >> 2, sh = (i & 3u) * 8u;
+    const uint32_t w0 = sW[w], w1 = sW[w + 1u], w2 = sW[w + 2u];
+    const uint32_t lo = (uint32_t)((((uint64_t)w1 << 32) | w0) >> sh);
+    const uint32_t hi = (uint32_t)((((uint64_t)w2 << 32) | w1) >> sh);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint32_t mf_lds_byte(const uint32_t* sW, uint32_t i) { return (sW[i >> 2] >> ((i & 3u) * 8u)) & 0xFFu; }
+
+// Is tile position q listed, and with which keys?  Not listed:
 //   - no full compare window (GC_MATCH_CAP + 16 bytes) left in the FRAME: such positions never match.  The limit is the frame
 //     end, not the input end, so that a frame's bytes do not depend on what follows it (a frame-aligned range shard produces
 //     exactly the frames the whole input would)
 //   - inside a run of one byte value (the 8 bytes at P equal the 8 bytes at P-1): all those positions share one key and would
-//     pile into one partition; W5 gives them the candidate P-1 instead, which is what the table would have returned
-__device__ __forceinline__ MfKeys mf_keys(const uint8_t* src, uint64_t srcSize, uint64_t P, uint64_t frameStart, uint64_t frameEnd)
+//     pile into one list; W5 gives them the candidate P-1 instead, which is what the tables would have returned
+struct MfKeys { bool ok, run; uint32_t part; uint64_t entry; };
+__device__ __forceinline__ MfKeys mf_keys(const uint32_t* sW, uint32_t q, const MfTile& T)
 {
-    MfKeys r; r.ok = false; r.kL = 0; r.kS = 0;
-    (void)srcSize;
-    if (P + GC_MATCH_CAP + 16u <= frameEnd) {
-        const uint64_t x = gc_ld64(src + P);
-        bool run = false;
-        if (P > frameStart) run = ((x << 8) | (uint64_t)src[P - 1u]) == x;
-        if (!run) {
-            const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
-            r.ok = true; r.kL = lz_hash_long(lo, hi); r.kS = lz_hash_short(lo, hi);
-        }
+    MfKeys r; r.ok = false; r.run = false; r.part = 0; r.entry = 0;
+    const uint64_t P = T.tileStart + q;
+    const uint64_t x = mf_lds_ld64(sW, q + MF_STAGE_PAD);
+    if (P > T.frameStart) r.run = ((x << 8) | (uint64_t)mf_lds_byte(sW, q + MF_STAGE_PAD - 1u)) == x;
+    if (q < T.len && P + GC_MATCH_CAP + 16u <= T.frameEnd && !r.run) {
+        const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+        const uint32_t hL = lz_hash_long(lo, hi), hS = lz_hash_short(lo, hi);
+        r.ok = true;
+        r.part = hS >> (32u - GC_MF_PART_LOG);
+        r.entry = (uint64_t)(uint32_t)(P - T.frameStart)
+                | ((uint64_t)(hL >> (32u - GC_MF_KL_BITS)) << GC_MF_POS_BITS)
+                | ((uint64_t)((hS >> (32u - GC_MF_PART_LOG - GC_MF_KS_BITS)) & ((1u << GC_MF_KS_BITS) - 1u)) << (GC_MF_POS_BITS + GC_MF_KL_BITS));
     }
     return r;
 }
 
 // ------------------------------------------------------------------------------------------------ W1 count
-extern "C" __global__ void __launch_bounds__(MF_WG)
-gc_mf_count_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nFrames, uint32_t* __restrict__ cnt)
+extern "C" __global__ void __launch_bounds__(MF_T)
+gc_mf_count_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per, uint32_t* __restrict__ cnt)
 {
-    __shared__ uint32_t sHist[MF_WAVES][GC_MF_KINDS][GC_MF_PARTS];
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    __shared__ uint32_t sW[MF_STAGE_WORDS];
+    __shared__ uint32_t sHist[GC_MF_PARTS];
+    const uint32_t t = threadIdx.x;
+    const uint32_t tile = mf_item(blockIdx.x, per);
+    if (tile >= nTiles) return;
+    const MfTile T = mf_tile(tile, frameBlocks, srcSize);
     const uint32_t TPF = frameBlocks * GC_MF_TILES_PER_BLOCK;
-    const uint32_t tile = blockIdx.x * MF_WAVES + wave;
-    if (tile >= nFrames * TPF) return;
-    const uint32_t frame = tile / TPF, tif = tile % TPF;
-    const uint64_t frameBytes = (uint64_t)frameBlocks * GC_ZSTD_BLOCK_MAX;
-    const uint64_t frameStart = (uint64_t)frame * frameBytes;
-    const uint64_t frameEnd = (frameStart + frameBytes) < srcSize ? (frameStart + frameBytes) : srcSize;
-    const uint64_t tileStart = frameStart + (uint64_t)tif * GC_MF_TILE;
-    for (uint32_t i = lane; i < GC_MF_KINDS * GC_MF_PARTS; i += 64u) sHist[wave][i >> GC_MF_PART_LOG][i & (GC_MF_PARTS - 1u)] = 0;
-    gc_wave_sync();
-    if (tileStart < frameEnd) {
-        const uint32_t len = (uint32_t)((frameEnd - tileStart) < GC_MF_TILE ? (frameEnd - tileStart) : GC_MF_TILE);
-        for (uint32_t r = 0; r < len; r += 64u) {
-            const MfKeys k = mf_keys(src, srcSize, tileStart + r + lane, frameStart, frameEnd);
-            if (k.ok) {
-                atomicAdd(&sHist[wave][0][k.kL >> (32u - GC_MF_PART_LOG)], 1u);
-                atomicAdd(&sHist[wave][1][k.kS >> (32u - GC_MF_PART_LOG)], 1u);
-            }
-        }
+    sHist[t] = 0;
+    if (T.len) mf_stage(sW, src, srcSize, T.tileStart, t, MF_T);
+    __syncthreads();
+    for (uint32_t q = t; q < T.len; q += MF_T) {
+        const MfKeys k = mf_keys(sW, q, T);
+        if (k.ok) atomicAdd(&sHist[k.part], 1u);
     }
-    gc_wave_sync();
-    for (uint32_t i = lane; i < GC_MF_KINDS * GC_MF_PARTS; i += 64u) {
-        const uint32_t k = i >> GC_MF_PART_LOG, g = i & (GC_MF_PARTS - 1u);
-        cnt[(((uint64_t)frame * GC_MF_KINDS + k) * GC_MF_PARTS + g) * TPF + tif] = sHist[wave][k][g];
-    }
+    __syncthreads();
+    cnt[((uint64_t)T.frame * (TPF + 1u) + T.tif) * GC_MF_PARTS + t] = sHist[t];
 }
 
 // ------------------------------------------------------------------------------------------------ W2 scan
-// one workgroup per (frame, kind): counts -> exclusive offsets in (partition, tile) order, in place
+// One workgroup per frame: counts[tile][partition] -> exclusive offsets in (partition, tile) order, in place; row
+// `tilesPerFrame` receives the partition ends.  Thread (q, g) walks quarter q of the tiles for partition g (row reads are
+// coalesced over g).
 extern "C" __global__ void __launch_bounds__(1024)
-gc_mf_scan_kernel(uint32_t* __restrict__ cnt, uint32_t* __restrict__ partStart, uint32_t tilesPerFrame)
+gc_mf_scan_kernel(uint32_t* __restrict__ cnt, uint32_t tilesPerFrame)
 {
-    __shared__ uint32_t sWave[16];
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6, fk = blockIdx.x;
-    uint32_t* A = cnt + (uint64_t)fk * GC_MF_PARTS * tilesPerFrame;
-    const uint32_t C = (GC_MF_PARTS * tilesPerFrame) / 1024u;      // elements per thread (tilesPerFrame is a multiple of 16)
+    __shared__ uint32_t sPart[4][GC_MF_PARTS];
+    __shared__ uint32_t sStart[GC_MF_PARTS];
+    __shared__ uint32_t sWave[4];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6, q = t >> GC_MF_PART_LOG, g = t & (GC_MF_PARTS - 1u);
+    uint32_t* A = cnt + (uint64_t)blockIdx.x * (tilesPerFrame + 1u) * GC_MF_PARTS;
+    const uint32_t R = tilesPerFrame / 4u;                        // tilesPerFrame is a multiple of 16
     uint32_t sum = 0;
-    for (uint32_t i = 0; i < C; i++) sum += A[t * C + i];
-    const uint32_t incl = gc_wave_incl_sum(sum);
-    if (lane == 63u) sWave[wave] = incl;
+    for (uint32_t r = q * R; r < (q + 1u) * R; r++) sum += A[(uint64_t)r * GC_MF_PARTS + g];
+    sPart[q][g] = sum;
     __syncthreads();
-    uint32_t before = 0;
-    for (uint32_t w = 0; w < 16u; w++) if (w < wave) before += sWave[w];
-    const uint32_t excl = before + incl - sum;
-    uint32_t run = excl;
-    for (uint32_t i = 0; i < C; i++) { const uint32_t v = A[t * C + i]; A[t * C + i] = run; run += v; }
-    // partition g starts at element g * tilesPerFrame = first element of thread 8g
-    if ((t & 7u) == 0u) partStart[fk * (GC_MF_PARTS + 1u) + (t >> 3)] = excl;
-    if (t == 1023u) partStart[fk * (GC_MF_PARTS + 1u) + GC_MF_PARTS] = excl + sum;
+    uint32_t tot = 0, incl = 0;
+    if (t < GC_MF_PARTS) {
+        tot = sPart[0][t] + sPart[1][t] + sPart[2][t] + sPart[3][t];
+        incl = gc_wave_incl_sum(tot);
+        if (lane == 63u) sWave[wave] = incl;
+    }
+    __syncthreads();
+    if (t < GC_MF_PARTS) {
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < 4u; w++) if (w < wave) before += sWave[w];
+        sStart[t] = before + incl - tot;
+    }
+    __syncthreads();
+    uint32_t run = sStart[g];
+    for (uint32_t qq = 0; qq < 4u; qq++) if (qq < q) run += sPart[qq][g];
+    for (uint32_t r = q * R; r < (q + 1u) * R; r++) {
+        const uint64_t i = (uint64_t)r * GC_MF_PARTS + g;
+        const uint32_t v = A[i]; A[i] = run; run += v;
+    }
+    if (q == 3u) A[(uint64_t)tilesPerFrame * GC_MF_PARTS + g] = run;     // end of partition g
 }
 
 // ------------------------------------------------------------------------------------------------ W3 scatter
-extern "C" __global__ void __launch_bounds__(MF_WG)
-gc_mf_scatter_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nFrames,
-                     const uint32_t* __restrict__ offs, GcMfEntry* __restrict__ ent, uint64_t entStride)
+// Stable counting sort of one tile by partition, staged through LDS as a permutation (16-bit tile positions), so that every
+// partition's run leaves the CU as one contiguous, coalesced store stream.  Wave w owns quarter w of the tile; ranks inside a
+// 64-position round come from ballots (position order = lane order), so the order inside a partition is position order.
+extern "C" __global__ void __launch_bounds__(MF_T)
+gc_mf_scatter_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
+                     const uint32_t* __restrict__ offs, GcMfEntry* __restrict__ ent)
 {
-    __shared__ uint32_t sRun[MF_WAVES][GC_MF_KINDS][GC_MF_PARTS];
+    __shared__ uint32_t sW[MF_STAGE_WORDS];
+    __shared__ uint32_t sRun[MF_WAVES][GC_MF_PARTS];              // pass A: counts; pass B: next free slot of (wave, partition)
+    __shared__ uint32_t sLocal[GC_MF_PARTS], sGlob[GC_MF_PARTS];
+    __shared__ uint32_t sWaveTot[MF_WAVES];
+    __shared__ uint16_t sPerm[GC_MF_TILE];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t tile = mf_item(blockIdx.x, per);
+    if (tile >= nTiles) return;
+    const MfTile T = mf_tile(tile, frameBlocks, srcSize);
+    if (T.len == 0u) return;
     const uint32_t TPF = frameBlocks * GC_MF_TILES_PER_BLOCK;
-    const uint32_t tile = blockIdx.x * MF_WAVES + wave;
-    if (tile >= nFrames * TPF) return;
-    const uint32_t frame = tile / TPF, tif = tile % TPF;
-    const uint64_t frameBytes = (uint64_t)frameBlocks * GC_ZSTD_BLOCK_MAX;
-    const uint64_t frameStart = (uint64_t)frame * frameBytes;
-    const uint64_t frameEnd = (frameStart + frameBytes) < srcSize ? (frameStart + frameBytes) : srcSize;
-    const uint64_t tileStart = frameStart + (uint64_t)tif * GC_MF_TILE;
-    if (tileStart >= frameEnd) return;
-    for (uint32_t i = lane; i < GC_MF_KINDS * GC_MF_PARTS; i += 64u) {
-        const uint32_t k = i >> GC_MF_PART_LOG, g = i & (GC_MF_PARTS - 1u);
-        sRun[wave][k][g] = offs[(((uint64_t)frame * GC_MF_KINDS + k) * GC_MF_PARTS + g) * TPF + tif];
+    for (uint32_t w = 0; w < MF_WAVES; w++) sRun[w][t] = 0;
+    mf_stage(sW, src, srcSize, T.tileStart, t, MF_T);
+    __syncthreads();
+    const uint32_t qBase = wave * (GC_MF_TILE / MF_WAVES);
+    // pass A: per-wave histograms
+    for (uint32_t r = 0; r < GC_MF_TILE / MF_T; r++) {
+        const MfKeys k = mf_keys(sW, qBase + r * 64u + lane, T);
+        if (k.ok) atomicAdd(&sRun[wave][k.part], 1u);
     }
-    gc_wave_sync();
-    const uint32_t len = (uint32_t)((frameEnd - tileStart) < GC_MF_TILE ? (frameEnd - tileStart) : GC_MF_TILE);
+    __syncthreads();
+    // offsets: thread t = partition t
+    uint32_t c[MF_WAVES], tot = 0;
+    for (uint32_t w = 0; w < MF_WAVES; w++) { c[w] = sRun[w][t]; tot += c[w]; }
+    const uint32_t incl = gc_wave_incl_sum(tot);
+    if (lane == 63u) sWaveTot[wave] = incl;
+    __syncthreads();
+    {
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < MF_WAVES; w++) if (w < wave) before += sWaveTot[w];
+        uint32_t ls = before + incl - tot;
+        sLocal[t] = ls;
+        for (uint32_t w = 0; w < MF_WAVES; w++) { sRun[w][t] = ls; ls += c[w]; }
+        sGlob[t] = offs[((uint64_t)T.frame * (TPF + 1u) + T.tif) * GC_MF_PARTS + t];
+    }
+    __syncthreads();
+    const uint32_t nEnt = sWaveTot[0] + sWaveTot[1] + sWaveTot[2] + sWaveTot[3];
+    // pass B: stable ranks -> permutation
     const uint64_t lt = gc_lanemask_lt();
-    for (uint32_t r = 0; r < len; r += 64u) {
-        const uint64_t P = tileStart + r + lane;
-        const MfKeys k = mf_keys(src, srcSize, P, frameStart, frameEnd);
-#pragma unroll
-        for (uint32_t kind = 0; kind < GC_MF_KINDS; kind++) {
-            const uint32_t key = kind ? k.kS : k.kL;
-            const uint32_t g = key >> (32u - GC_MF_PART_LOG);
-            // lanes of this round with the same partition (position order = lane order): stable rank without atomics
-            uint64_t peers = __ballot(k.ok);
+    for (uint32_t r = 0; r < GC_MF_TILE / MF_T; r++) {
+        const uint32_t q = qBase + r * 64u + lane;
+        const MfKeys k = mf_keys(sW, q, T);
+        uint64_t peers = __ballot(k.ok);
+        if (peers != 0ull) {                                      // uniform
 #pragma unroll
             for (uint32_t b = 0; b < GC_MF_PART_LOG; b++) {
-                const bool bit = ((g >> b) & 1u) != 0u;
+                const bool bit = ((k.part >> b) & 1u) != 0u;
                 const uint64_t bal = __ballot(k.ok && bit);
                 peers &= bit ? bal : ~bal;
             }
             const uint32_t rank = (uint32_t)__popcll(peers & lt);
-            const uint32_t base = k.ok ? sRun[wave][kind][g] : 0u;
-            gc_wave_sync();
-            if (k.ok && rank == 0u) sRun[wave][kind][g] = base + (uint32_t)__popcll(peers);
+            const uint32_t base = k.ok ? sRun[wave][k.part] : 0u;
             gc_wave_sync();
             if (k.ok) {
-                GcMfEntry e; e.pos = (uint32_t)(P - frameStart); e.key = key;
-                ent[(uint64_t)kind * entStride + frameStart + base + rank] = e;
+                if (rank == 0u) sRun[wave][k.part] = base + (uint32_t)__popcll(peers);
+                sPerm[base + rank] = (uint16_t)q;
             }
+            gc_wave_sync();
         }
+    }
+    __syncthreads();
+    // output: slot j of the sorted tile -> its partition's run in HBM
+    GcMfEntry* E = ent + (uint64_t)T.frame * ((uint64_t)frameBlocks * GC_ZSTD_BLOCK_MAX);
+    for (uint32_t j = t; j < nEnt; j += MF_T) {
+        const MfKeys k = mf_keys(sW, sPerm[j], T);
+        E[sGlob[k.part] + (j - sLocal[k.part])] = k.entry;
     }
 }
 
 // ------------------------------------------------------------------------------------------------ W4 link
-// One workgroup per (frame, kind, partition) streams the partition's position-ordered list in steps of LINK_T entries:
-//   probe   tab[slot] = most recent entry of all EARLIER steps with this slot (entry = (pos+1)<<8 | tag8)
-//   insert  ds_max -> most recent position wins, as sequential insertion would leave it
-//   in-step tabC (generation-stamped ds_min) = first entry of THIS step with exactly this key; it is nearer than anything in
-//           tab, so it is preferred.  (First, not nearest: a free choice, every candidate is verified against the input in W5.)
-// The entry's key is then replaced by candidate position + 1 (0 = none).
-extern "C" __global__ void __launch_bounds__(LINK_T)
-gc_mf_link_kernel(const uint32_t* __restrict__ partStart, GcMfEntry* __restrict__ ent, uint64_t entStride, uint64_t frameBytes)
+// One wave per (frame, partition, segment).  Per step of 64 list entries, for each of the two keys, ONE returning ds_max:
+// the table entry is (position + 1) << 8 | tag and positions grow along the list, so the maximum is the most recent insertion;
+// the LDS unit serialises the lanes that hit the same slot, and the value returned to a lane is the slot's content when its
+// turn came -- the state left by all earlier steps and by the lower lanes of this step, i.e. what a table updated entry by
+// entry would hold when the entry arrives.  (Should a lane ever be served before a lower one, it would see a position that is
+// not earlier than its own; such a result is discarded, so every candidate handed on is a genuine earlier position.)
+// A candidate is accepted only if its 8-bit tag agrees.
+//
+// Lists longer than LINK_SEG entries (hot keys: one 5-gram can own 2 % of a text, and every 8-byte key that starts with it
+// shares its partition) are cut into segments linked by different waves, so the longest list does not become the tail of the
+// launch.  A later segment first replays the LINK_WARM entries in front of it, insert only: a slot of a 2^12-entry table is
+// overwritten after ~4 Ki insertions on average, so the tables are then what the single walk would have left, up to slots not
+// touched for 16 Ki insertions (e^-4 of them), whose stale candidates are simply not offered.  Output goes to a second entry
+// array because the replay reads what the previous segment's wave is working on.
+#define LINK_DEPTH 8u                 // steps per register set
+#define LINK_SEG   49152u             // entries per segment (1.5 x the mean list length of a full 8 MiB frame)
+#define LINK_WARM  16384u             // entries replayed in front of a segment
+#define LINK_SEGS  GC_MF_LINK_SEGS                 // segments per list; the last one takes whatever is left
+
+// what the table held when the entry arrived -> candidate position + 1, or 0
+__device__ __forceinline__ uint32_t mf_link_pick(uint32_t seen, uint32_t mine)
 {
-    __shared__ uint32_t tab[1u << LINK_LOG];
-    __shared__ uint32_t tabC[1u << LINK_LOG_C];
-    __shared__ uint32_t sPos[2][LINK_T];
-    const uint32_t t = threadIdx.x;
-    const uint32_t fk = blockIdx.x >> GC_MF_PART_LOG, g = blockIdx.x & (GC_MF_PARTS - 1u);
-    const uint32_t frame = fk >> 1, kind = fk & 1u;
-    const uint32_t start = partStart[fk * (GC_MF_PARTS + 1u) + g], end = partStart[fk * (GC_MF_PARTS + 1u) + g + 1u];
-    GcMfEntry* E = ent + (uint64_t)kind * entStride + (uint64_t)frame * frameBytes;
-    for (uint32_t i = t; i < (1u << LINK_LOG); i += LINK_T) tab[i] = 0;
-    for (uint32_t i = t; i < (1u << LINK_LOG_C); i += LINK_T) tabC[i] = 0xFFFFFFFFu;
-    __syncthreads();
-    const uint32_t nSteps = (end - start + LINK_T - 1u) / LINK_T;
-    GcMfEntry nxt; nxt.pos = 0; nxt.key = 0;
-    if (start + t < end) nxt = E[start + t];
-    for (uint32_t k = 0; k < nSteps; k++) {
-        const uint32_t i = start + k * LINK_T + t;
-        const bool valid = i < end;
-        const GcMfEntry cur = nxt;
-        if (i + LINK_T < end) nxt = E[i + LINK_T];               // next step's entry: its latency hides under this step
-        if (k != 0u && (k & 0xFFu) == 0u) {                      // generation stamps wrap every 256 steps
-            __syncthreads();
-            for (uint32_t j = t; j < (1u << LINK_LOG_C); j += LINK_T) tabC[j] = 0xFFFFFFFFu;
-        }
-        const uint32_t slot = (cur.key >> 11) & ((1u << LINK_LOG) - 1u), tag = (cur.key >> 3) & 0xFFu;
-        const uint32_t slotC = (cur.key >> 14) & ((1u << LINK_LOG_C) - 1u), tagC = cur.key & 0x3FFFu;
-        const uint32_t gen = (~k) & 0xFFu;
-        const uint32_t old = valid ? tab[slot] : 0u;
-        sPos[k & 1u][t] = cur.pos;
-        __syncthreads();
-        if (valid) {
-            atomicMax(&tab[slot], ((cur.pos + 1u) << 8) | tag);
-            atomicMin(&tabC[slotC], (gen << 24) | (t << 14) | tagC);
-        }
-        __syncthreads();
-        if (valid) {
-            uint32_t cand = 0;
-            const uint32_t eC = tabC[slotC], tc = (eC >> 14) & 0x3FFu;
-            if ((eC >> 24) == gen && (eC & 0x3FFFu) == tagC && tc < t) cand = sPos[k & 1u][tc] + 1u;
-            else if (old != 0u && (old & 0xFFu) == tag) cand = old >> 8;
-            E[i].key = cand;
-        }
+    return (seen != 0u && seen < mine && ((seen ^ mine) & 0xFFu) == 0u) ? (seen >> 8) : 0u;
+}
+
+__device__ __forceinline__ void mf_link_load(uint64_t q[LINK_DEPTH], const GcMfEntry* __restrict__ E, uint32_t s0, uint32_t end, uint32_t lane)
+{
+#pragma unroll
+    for (uint32_t d = 0; d < LINK_DEPTH; d++) {                   // unconditional (index clamped): the loads stay countable, so the
+        const uint32_t i = s0 + d * 64u + lane;                   // waits in the caller are for exactly the set that is needed
+        q[d] = E[i < end ? i : end - 1u];
     }
 }
 
-// ------------------------------------------------------------------------------------------------ W5 parse
-// One workgroup per block.  Per 8 KiB tile: every wave copies 16 of the tile's 256 (kind, partition) runs into LDS in position
-// order (sCand[kind][position in tile] = candidate + 1), then eight steps of LZ_T positions go through verify / parse / emit.
-__device__ __forceinline__ void
-lzw_parse_body(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, const uint32_t* __restrict__ offs,
-               const uint32_t* __restrict__ partStart, const GcMfEntry* __restrict__ ent, uint64_t entStride,
-               GcSeqRaw* __restrict__ seqRaw, uint8_t* __restrict__ lit, GcBlockMeta* __restrict__ meta,
-               unsigned long long* __restrict__ prof)
+// LINK_DEPTH steps.  All their table operations are issued back to back (the LDS unit executes the operations of a wave in
+// order, so the tables see the steps in order) and their results are collected afterwards: one LDS latency per call instead of
+// two per step.
+__device__ __forceinline__ void mf_link_steps(const uint64_t q[LINK_DEPTH], uint32_t* tabL, uint32_t* tabS, GcMfEntry* __restrict__ EO, uint32_t s0,
+                                              uint32_t end, uint32_t lane)
 {
-    __shared__ uint32_t sCand[GC_MF_KINDS][GC_MF_TILE];
-    __shared__ uint32_t sRunOff[GC_MF_KINDS * GC_MF_PARTS], sRunCnt[GC_MF_KINDS * GC_MF_PARTS];
-    __shared__ LzParseLds S;
+    if (s0 >= end) return;                                        // uniform
+    uint32_t pos[LINK_DEPTH], mL[LINK_DEPTH], mS[LINK_DEPTH], rL[LINK_DEPTH], rS[LINK_DEPTH];
+#pragma unroll
+    for (uint32_t d = 0; d < LINK_DEPTH; d++) {
+        const uint32_t i = s0 + d * 64u + lane;
+        const uint64_t e = q[d];
+        pos[d] = (uint32_t)e & ((1u << GC_MF_POS_BITS) - 1u);
+        const uint32_t kL = (uint32_t)(e >> GC_MF_POS_BITS) & ((1u << GC_MF_KL_BITS) - 1u);
+        const uint32_t kS = (uint32_t)(e >> (GC_MF_POS_BITS + GC_MF_KL_BITS)) & ((1u << GC_MF_KS_BITS) - 1u);
+        mL[d] = ((pos[d] + 1u) << 8) | (kL & 0xFFu); mS[d] = ((pos[d] + 1u) << 8) | (kS & 0xFFu);
+        rL[d] = 0; rS[d] = 0;
+        if (i < end) { rL[d] = atomicMax(&tabL[kL >> 8], mL[d]); rS[d] = atomicMax(&tabS[kS >> 8], mS[d]); }
+        gc_wave_step();
+    }
+#pragma unroll
+    for (uint32_t d = 0; d < LINK_DEPTH; d++) {
+        const uint32_t i = s0 + d * 64u + lane;
+        const uint32_t cL = mf_link_pick(rL[d], mL[d]), cS = mf_link_pick(rS[d], mS[d]);
+        if (i < end) EO[i] = (uint64_t)(pos[d] & (GC_MF_TILE - 1u)) | ((uint64_t)cL << GC_MF_TILE_LOG) | ((uint64_t)cS << (GC_MF_TILE_LOG + 24u));
+    }
+}
 
+extern "C" __global__ void __launch_bounds__(64)
+gc_mf_link_kernel(const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, GcMfEntry* __restrict__ entOut, uint32_t tilesPerFrame,
+                  uint64_t frameBytes)
+{
+    __shared__ uint32_t tabL[1u << GC_MF_LSLOT_LOG];
+    __shared__ uint32_t tabS[1u << GC_MF_SSLOT_LOG];
+    const uint32_t lane = threadIdx.x;
+    // segment-major: the first gridDim / LINK_SEGS workgroups are the segment-0 waves (the only live ones for most lists), so
+    // the live waves are dealt evenly to the XCDs (workgroup i runs on XCD i % 8)
+    const uint32_t nLists = gridDim.x / LINK_SEGS;
+    const uint32_t seg = blockIdx.x / nLists, fg = blockIdx.x % nLists;
+    const uint32_t frame = fg >> GC_MF_PART_LOG, g = fg & (GC_MF_PARTS - 1u);
+    const uint32_t* row = offs + (uint64_t)frame * (tilesPerFrame + 1u) * GC_MF_PARTS;
+    const uint32_t listStart = row[g], listEnd = row[(uint64_t)tilesPerFrame * GC_MF_PARTS + g];
+    const uint32_t start = listStart + seg * LINK_SEG;
+    if (start >= listEnd) return;
+    const uint32_t end = (seg + 1u < LINK_SEGS && start + LINK_SEG < listEnd) ? start + LINK_SEG : listEnd;
+    const GcMfEntry* E = ent + (uint64_t)frame * frameBytes;
+    GcMfEntry* EO = entOut + (uint64_t)frame * frameBytes;
+    for (uint32_t i = lane; i < (1u << GC_MF_LSLOT_LOG); i += 64u) tabL[i] = 0;
+    for (uint32_t i = lane; i < (1u << GC_MF_SSLOT_LOG); i += 64u) tabS[i] = 0;
+    gc_wave_sync();
+    if (seg != 0u) {                                              // warm the tables: insert only (ds_max keeps the most recent)
+        for (uint32_t i = start - LINK_WARM + lane; i < start; i += 64u) {
+            const uint64_t e = E[i];
+            const uint32_t pos = (uint32_t)e & ((1u << GC_MF_POS_BITS) - 1u);
+            const uint32_t kL = (uint32_t)(e >> GC_MF_POS_BITS) & ((1u << GC_MF_KL_BITS) - 1u);
+            const uint32_t kS = (uint32_t)(e >> (GC_MF_POS_BITS + GC_MF_KL_BITS)) & ((1u << GC_MF_KS_BITS) - 1u);
+            atomicMax(&tabL[kL >> 8], ((pos + 1u) << 8) | (kL & 0xFFu));
+            atomicMax(&tabS[kS >> 8], ((pos + 1u) << 8) | (kS & 0xFFu));
+        }
+        gc_wave_sync();
+    }
+    // Two register sets of LINK_DEPTH steps each: while one set is linked, the loads of the other are in flight.  (The set is
+    // requested right after the previous one has been consumed, so every wait in the loop body is for loads that are one whole
+    // set old.)
+    uint64_t qa[LINK_DEPTH], qb[LINK_DEPTH];
+    mf_link_load(qa, E, start, end, lane);
+    for (uint32_t s0 = start; s0 < end; s0 += 2u * 64u * LINK_DEPTH) {
+        mf_link_load(qb, E, s0 + 64u * LINK_DEPTH, end, lane);
+        mf_link_steps(qa, tabL, tabS, EO, s0, end, lane);
+        mf_link_load(qa, E, s0 + 2u * 64u * LINK_DEPTH, end, lane);
+        mf_link_steps(qb, tabL, tabS, EO, s0 + 64u * LINK_DEPTH, end, lane);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ W5 verify
+// One workgroup per tile; every thread is independent.  Listed positions are taken in list order (the tile's 256 runs viewed as
+// one flat array; the run of a flat index is found by bisection over the run starts in LDS), unlisted ones in position order.
+#define MFV_T GC_MF_VERIFY_T
+
+__device__ __forceinline__ LzW16 mf_lds_ld16(const uint32_t* sW, uint32_t i)
+{
+    LzW16 w; w.a = mf_lds_ld64(sW, i); w.b = mf_lds_ld64(sW, i + 8u); return w;
+}
+
+extern "C" __global__ void __launch_bounds__(MFV_T)
+gc_mf_verify_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
+                    const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, uint32_t* __restrict__ rec)
+{
+    __shared__ uint32_t sW[MF_STAGE_WORDS];
+    __shared__ uint32_t sStart[GC_MF_PARTS], sLocal[GC_MF_PARTS + 1u];
+    __shared__ uint32_t sWaveTot[GC_MF_PARTS / 64u];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const uint32_t b = blockIdx.x;
-    const uint32_t frame = b / frameBlocks, bif = b % frameBlocks;
+    const uint32_t tile = mf_item(blockIdx.x, per);
+    if (tile >= nTiles) return;
+    const MfTile T = mf_tile(tile, frameBlocks, srcSize);
+    if (T.len == 0u) return;
     const uint32_t TPF = frameBlocks * GC_MF_TILES_PER_BLOCK;
-    const uint64_t frameBytes = (uint64_t)frameBlocks * GC_ZSTD_BLOCK_MAX;
-    const uint64_t frameStart = (uint64_t)frame * frameBytes;
-    const uint64_t frameEnd = (frameStart + frameBytes) < srcSize ? (frameStart + frameBytes) : srcSize;
+    uint32_t c = 0, incl = 0;
+    if (t < GC_MF_PARTS) {
+        const uint32_t* row = offs + ((uint64_t)T.frame * (TPF + 1u) + T.tif) * GC_MF_PARTS;
+        const uint32_t o = row[t];
+        c = row[GC_MF_PARTS + t] - o;
+        sStart[t] = o;
+        incl = gc_wave_incl_sum(c);
+        if (lane == 63u) sWaveTot[wave] = incl;
+    }
+    mf_stage(sW, src, srcSize, T.tileStart, t, MFV_T);
+    __syncthreads();
+    if (t < GC_MF_PARTS) {
+        uint32_t before = 0;
+        for (uint32_t w = 0; w < GC_MF_PARTS / 64u; w++) if (w < wave) before += sWaveTot[w];
+        sLocal[t] = before + incl - c;
+        if (t == GC_MF_PARTS - 1u) sLocal[GC_MF_PARTS] = before + incl;
+    }
+    __syncthreads();
+    const uint32_t nEnt = sLocal[GC_MF_PARTS];
+    const uint8_t* wsrc = src + T.frameStart;
+    const GcMfEntry* E = ent + (uint64_t)T.frame * ((uint64_t)frameBlocks * GC_ZSTD_BLOCK_MAX);
+    const uint64_t blockBase = T.tileStart & ~(uint64_t)(GC_ZSTD_BLOCK_MAX - 1u);     // a tile never straddles blocks
+    const uint32_t nBlk = (uint32_t)((srcSize - blockBase) < GC_ZSTD_BLOCK_MAX ? (srcSize - blockBase) : GC_ZSTD_BLOCK_MAX);
+    const uint32_t pTile = (uint32_t)(T.tileStart - blockBase);
+    const uint32_t wTile = (uint32_t)(T.tileStart - T.frameStart);
+    uint32_t* R = rec + T.tileStart;
+    // listed positions
+    for (uint32_t j = t; j < nEnt; j += MFV_T) {
+        uint32_t lo = 0, hi = GC_MF_PARTS;                        // largest g with sLocal[g] <= j
+        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (sLocal[mid] <= j) lo = mid; else hi = mid; }
+        const uint64_t e = E[sStart[lo] + (j - sLocal[lo])];
+        const uint32_t q = (uint32_t)e & (GC_MF_TILE - 1u);
+        const uint32_t cL = (uint32_t)(e >> GC_MF_TILE_LOG) & 0xFFFFFFu, cS = (uint32_t)(e >> (GC_MF_TILE_LOG + 24u)) & 0xFFFFFFu;
+        const uint32_t p = pTile + q;                             // block-relative
+        uint32_t bestLen = 0, bestOff = 0;
+        if (p + 8u <= nBlk && (cL | cS) != 0u) {
+            const uint32_t maxLen = (nBlk - p) < GC_MATCH_CAP ? (nBlk - p) : GC_MATCH_CAP;
+            uint32_t cand[3]; int nc = 0;
+            if (cL != 0u) cand[nc++] = cL - 1u;
+            if (cS != 0u && cS != cL) cand[nc++] = cS - 1u;
+            lz_verify(wsrc, wTile + q, mf_lds_ld16(sW, q + MF_STAGE_PAD), cand, nc, maxLen, bestLen, bestOff);
+        }
+        R[q] = (bestOff << 8) | bestLen;
+    }
+    // unlisted positions: byte runs match at distance 1, the tail of the frame does not match at all
+    for (uint32_t q = t; q < T.len; q += MFV_T) {
+        const MfKeys k = mf_keys(sW, q, T);
+        if (k.ok) continue;
+        const uint32_t p = pTile + q;
+        uint32_t bestLen = 0, bestOff = 0;
+        if (k.run && p + 8u <= nBlk && T.tileStart + q + GC_MATCH_CAP + 16u <= T.frameEnd) {
+            const uint32_t maxLen = (nBlk - p) < GC_MATCH_CAP ? (nBlk - p) : GC_MATCH_CAP;
+            uint32_t cand[3]; cand[0] = wTile + q - 1u;
+            lz_verify(wsrc, wTile + q, mf_lds_ld16(sW, q + MF_STAGE_PAD), cand, 1, maxLen, bestLen, bestOff);
+        }
+        R[q] = (bestOff << 8) | bestLen;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ W6 parse
+// Greedy parse with one-step lazy evaluation: next(p) = p + len if the match at p is taken, else p + 1; the block's sequences
+// are the matches on the path from position 0.  The path is found without walking the block serially:
+//   phase 1  every 64-position segment computes, for ALL 64 possible entry lanes, where the path leaves it (pointer doubling
+//            through ds_bpermute, 6 rounds; a capped match leaves its segment by at most 64, so the exit is a lane of the next
+//            segment); a wave composes the exit maps of the 32 segments of a group (2048 positions) into one group map
+//   phase 2  one wave chains the 64 group maps from position 0 (v_readlane hops) -> real entry lane of every group
+//   phase 3  every group is walked from its real entry, segment by segment (scalar hops), the path becomes two lane masks per
+//            segment (match starts, literals); group totals -> prefix sums -> every sequence and literal knows its slot
+#define PZ_T       GC_MF_PARSE_T
+#define PZ_WAVES   (PZ_T / 64u)
+#define PZ_GSEGS   32u                                           // segments per group
+#define PZ_GROUPS  (GC_ZSTD_BLOCK_MAX / 64u / PZ_GSEGS)          // 64 groups per full block
+
+struct PzSeg { uint32_t r0; bool take; uint32_t nxt; };
+// record, lazy decision and next pointer of position p = seg * 64 + lane (R = records of the block, n = block length)
+__device__ __forceinline__ PzSeg pz_seg(const uint32_t* __restrict__ R, uint32_t p, uint32_t n, uint32_t lane)
+{
+    PzSeg s;
+    s.r0 = p < n ? R[p] : 0u;
+    const uint32_t r1 = p + 1u < n ? R[p + 1u] : 0u;
+    const uint32_t len = s.r0 & 0xFFu, l1 = r1 & 0xFFu;
+    s.take = len != 0u;
+    if (s.take && l1 > len && lz_gain(l1, r1 >> 8) > lz_gain(len, s.r0 >> 8) + 4) s.take = false;
+    s.nxt = s.take ? lane + len : lane + 1u;                      // >= 64: leaves the segment
+    return s;
+}
+// exit of the segment for every entry lane: position after following nxt until it is >= 64
+__device__ __forceinline__ uint32_t pz_exit(uint32_t nxt)
+{
+    uint32_t cur = nxt;
+#pragma unroll
+    for (int r = 0; r < 6; r++) { const uint32_t o = __shfl(cur, (int)(cur & 63u)); if (cur < 64u) cur = o; }
+    return cur;                                                   // 64 .. 127
+}
+
+extern "C" __global__ void __launch_bounds__(PZ_T)
+gc_mf_parse_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, const uint32_t* __restrict__ rec,
+                   GcSeqRaw* __restrict__ seqRaw, uint8_t* __restrict__ lit, GcBlockMeta* __restrict__ meta)
+{
+    __shared__ uint8_t  sGExit[PZ_GROUPS][64];
+    __shared__ uint32_t sEntry[PZ_GROUPS];
+    __shared__ uint32_t sGSeq[PZ_GROUPS], sGLit[PZ_GROUPS];      // phase 3a: counts; then exclusive prefix
+    __shared__ uint64_t sMaskSeq[GC_ZSTD_BLOCK_MAX / 64u], sMaskLit[GC_ZSTD_BLOCK_MAX / 64u];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t b = mf_item(blockIdx.x, per);
+    if (b >= nBlocks) return;
     const uint64_t base = (uint64_t)b * GC_ZSTD_BLOCK_MAX;
     const uint32_t n = (uint32_t)((srcSize - base) < GC_ZSTD_BLOCK_MAX ? (srcSize - base) : GC_ZSTD_BLOCK_MAX);
-    const uint32_t wbase = bif * GC_ZSTD_BLOCK_MAX;            // block start relative to the frame
-    const uint8_t* wsrc = src + frameStart;
+    const uint32_t nSeg = (n + 63u) >> 6, nGroups = (nSeg + PZ_GSEGS - 1u) / PZ_GSEGS;
+    const uint32_t* R = rec + base;
     GcSeqRaw* mySeq = seqRaw + (uint64_t)b * GC_MAX_SEQ_PER_BLOCK;
     uint8_t* myLit = lit + (uint64_t)b * GC_ZSTD_BLOCK_MAX;
-    const GcMfEntry* E0 = ent + frameStart;
-    const GcMfEntry* E1 = E0 + entStride;
+    const uint8_t* bsrc = src + base;
 
-    if (t == 0) S.sCursor = 0;
-    LzProf P; P.on = prof != nullptr; for (int i = 0; i < GC_LZ_PHASES; i++) P.pc[i] = 0;
-    P.tprev = P.on ? gc_clock() : 0ull;
-    uint32_t totalSeq = 0, totalLit = 0;
-    LzW16 own; own.a = 0; own.b = 0;
-    uint32_t prevByte = 0x100u;                                  // byte before the own position; 0x100 = none (frame start)
-    if (base + t + GC_MATCH_CAP + 16u <= srcSize) own = lz_ld16(src, base + t);
-    if (base + t > frameStart) prevByte = src[base + t - 1u];
-
-    const uint32_t nTiles = (n + GC_MF_TILE - 1u) >> GC_MF_TILE_LOG;
-    for (uint32_t ti = 0; ti < nTiles; ti++) {
-        const uint32_t tif = bif * GC_MF_TILES_PER_BLOCK + ti;
-        __syncthreads();                                         // the previous tile's steps are done with sCand
-        for (uint32_t i = t; i < GC_MF_KINDS * GC_MF_TILE; i += LZ_T) sCand[i >> GC_MF_TILE_LOG][i & (GC_MF_TILE - 1u)] = 0;
-        if (t < GC_MF_KINDS * GC_MF_PARTS) {
-            const uint32_t k = t >> GC_MF_PART_LOG, g = t & (GC_MF_PARTS - 1u);
-            const uint64_t row = (((uint64_t)frame * GC_MF_KINDS + k) * GC_MF_PARTS + g) * TPF;
-            const uint32_t o = offs[row + tif];
-            const uint32_t nx = (tif + 1u < TPF) ? offs[row + tif + 1u] : partStart[(frame * GC_MF_KINDS + k) * (GC_MF_PARTS + 1u) + g + 1u];
-            sRunOff[t] = o; sRunCnt[t] = nx - o;
+    // ---- phase 1: group exit maps
+    for (uint32_t g = wave; g < nGroups; g += PZ_WAVES) {
+        uint32_t comp = lane;                                     // where the path that enters the group at lane `lane` stands
+        const uint32_t sEnd = (g + 1u) * PZ_GSEGS < nSeg ? (g + 1u) * PZ_GSEGS : nSeg;
+        for (uint32_t seg = g * PZ_GSEGS; seg < sEnd; seg++) {
+            const PzSeg s = pz_seg(R, seg * 64u + lane, n, lane);
+            const uint32_t ex = pz_exit(s.nxt) - 64u;
+            comp = __shfl(ex, (int)comp);
         }
-        __syncthreads();
-        for (uint32_t r = wave; r < GC_MF_KINDS * GC_MF_PARTS; r += LZ_WAVES) {
-            const GcMfEntry* E = (r >> GC_MF_PART_LOG) ? E1 : E0;
-            const uint32_t o = sRunOff[r], c = sRunCnt[r];
-            for (uint32_t i = lane; i < c; i += 64u) {
-                const GcMfEntry e = E[o + i];
-                sCand[r >> GC_MF_PART_LOG][e.pos & (GC_MF_TILE - 1u)] = e.key;
-            }
+        sGExit[g][lane] = (uint8_t)comp;
+    }
+    __syncthreads();
+    // ---- phase 2: chain the groups from position 0
+    if (wave == 0) {
+        uint32_t x4[PZ_GROUPS / 4u];                              // lane e: exits of entry lane e, four groups per register
+#pragma unroll
+        for (uint32_t k = 0; k < PZ_GROUPS / 4u; k++) {
+            uint32_t v = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < 4u; i++) if (4u * k + i < nGroups) v |= (uint32_t)sGExit[4u * k + i][lane] << (8u * i);
+            x4[k] = v;
         }
-        __syncthreads();
-        LZ_PHASE(P, 0);    // gather
-        const uint32_t tileLen = (n - ti * GC_MF_TILE) < GC_MF_TILE ? (n - ti * GC_MF_TILE) : GC_MF_TILE;
-        for (uint32_t s = 0; s * LZ_T < tileLen; s++) {
-            const uint32_t cbase = ti * GC_MF_TILE + s * LZ_T;
-            const uint32_t p = cbase + t;                       // block-relative
-            const uint32_t pw = wbase + p;                      // frame-relative
-            const bool inBlock = p < n;
-            const bool canMatch = p + 8u <= n && base + p + GC_MATCH_CAP + 16u <= frameEnd;
-            const LzW16 me = own;
-            const uint32_t pb = prevByte;
-            uint32_t bestLen = 0, bestOff = 0;
-            if (canMatch) {
-                const uint32_t maxLen = (n - p) < GC_MATCH_CAP ? (n - p) : GC_MATCH_CAP;
-                uint32_t cand[3]; int nc = 0;
-                const uint32_t cL = sCand[0][s * LZ_T + t], cS = sCand[1][s * LZ_T + t];
-                if (cL != 0u) cand[nc++] = cL - 1u;
-                if (cS != 0u && cS != cL) cand[nc++] = cS - 1u;
-                if (nc == 0 && pb == (uint32_t)(me.a & 0xFFu)) cand[nc++] = pw - 1u;     // inside a byte run (not listed, see mf_keys)
-                lz_verify(wsrc, pw, me, cand, nc, maxLen, bestLen, bestOff);
+        uint32_t c = 0, mine = 0;
+#pragma unroll
+        for (uint32_t g = 0; g < PZ_GROUPS; g++) {
+            if (lane == g) mine = c;
+            c = (gc_readlane(x4[g >> 2], c) >> (8u * (g & 3u))) & 0xFFu;
+        }
+        sEntry[lane] = mine;
+    }
+    __syncthreads();
+    // ---- phase 3a: walk every group from its real entry: path masks + counts
+    for (uint32_t g = wave; g < nGroups; g += PZ_WAVES) {
+        uint32_t e = gc_uniform(sEntry[g]);
+        uint32_t nS = 0, nL = 0;
+        const uint32_t sEnd = (g + 1u) * PZ_GSEGS < nSeg ? (g + 1u) * PZ_GSEGS : nSeg;
+        for (uint32_t seg = g * PZ_GSEGS; seg < sEnd; seg++) {
+            const uint32_t p = seg * 64u + lane;
+            const PzSeg s = pz_seg(R, p, n, lane);
+            uint64_t path = 0;
+            uint32_t c = e;
+            while (c < 64u) { path |= 1ull << c; c = gc_readlane(s.nxt, c); }
+            e = c - 64u;
+            const uint64_t takeMask = __ballot(s.take), inMask = __ballot(p < n);
+            const uint64_t mS = path & takeMask, mL = path & ~takeMask & inMask;
+            if (lane == 0) { sMaskSeq[seg] = mS; sMaskLit[seg] = mL; }
+            nS += (uint32_t)__popcll(mS); nL += (uint32_t)__popcll(mL);
+        }
+        if (lane == 0) { sGSeq[g] = nS; sGLit[g] = nL; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const uint32_t cs = lane < nGroups ? sGSeq[lane] : 0u, cl = lane < nGroups ? sGLit[lane] : 0u;
+        const uint32_t is = gc_wave_incl_sum(cs), il = gc_wave_incl_sum(cl);
+        sGSeq[lane] = is - cs; sGLit[lane] = il - cl;
+        if (lane == 63u) { GcBlockMeta m; m.nSeqRaw = is; m.nLit = il; meta[b] = m; }
+    }
+    __syncthreads();
+    // ---- phase 3b: emit
+    const uint64_t lt = gc_lanemask_lt();
+    for (uint32_t g = wave; g < nGroups; g += PZ_WAVES) {
+        uint32_t seqRun = sGSeq[g], litRun = sGLit[g];
+        const uint32_t sEnd = (g + 1u) * PZ_GSEGS < nSeg ? (g + 1u) * PZ_GSEGS : nSeg;
+        for (uint32_t seg = g * PZ_GSEGS; seg < sEnd; seg++) {
+            const uint64_t mS = sMaskSeq[seg], mL = sMaskLit[seg];
+            const uint32_t p = seg * 64u + lane;
+            const uint32_t myLitRank = litRun + (uint32_t)__popcll(mL & lt);
+            if ((mS >> lane) & 1ull) {
+                GcSeqRaw r; r.litRank = myLitRank; r.offml = R[p];
+                mySeq[seqRun + (uint32_t)__popcll(mS & lt)] = r;
             }
-            if (base + p + LZ_T + GC_MATCH_CAP + 16u <= srcSize) own = lz_ld16(src, base + p + LZ_T);
-            if (base + p + LZ_T < srcSize) prevByte = src[base + p + LZ_T - 1u];
-            S.sM[t] = (bestOff << 8) | bestLen;
-            __syncthreads();
-            LZ_PHASE(P, 2);    // verify
-            lz_parse_emit(S, P, cbase, inBlock, bestLen, bestOff, src + base, mySeq, myLit, totalSeq, totalLit);
+            if ((mL >> lane) & 1ull) myLit[myLitRank] = bsrc[p];
+            seqRun += (uint32_t)__popcll(mS); litRun += (uint32_t)__popcll(mL);
         }
     }
-    if (prof && t == 0) for (int i = 0; i < GC_LZ_PHASES; i++) atomicAdd(&prof[i], P.pc[i]);
-    if (t == 0) { GcBlockMeta m; m.nSeqRaw = totalSeq; m.nLit = totalLit; meta[b] = m; }
 }
-
-// Two builds of the same body: 77 KiB of LDS allow two workgroups per CU, which needs <= 64 VGPRs (a few spills); the host
-// picks by block count (few blocks: one workgroup per CU at full register budget is enough to cover the chip).
-extern "C" __global__ void __launch_bounds__(LZ_T)
-gc_lzw_parse_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, const uint32_t* __restrict__ offs,
-                    const uint32_t* __restrict__ partStart, const GcMfEntry* __restrict__ ent, uint64_t entStride,
-                    GcSeqRaw* __restrict__ seqRaw, uint8_t* __restrict__ lit, GcBlockMeta* __restrict__ meta,
-                    unsigned long long* __restrict__ prof)
-{
-    lzw_parse_body(src, srcSize, frameBlocks, offs, partStart, ent, entStride, seqRaw, lit, meta, prof);
-}
-#ifndef HIPEMU
-extern "C" __global__ void __launch_bounds__(LZ_T, 8)
-gc_lzw_parse_kernel_occ2(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, const uint32_t* __restrict__ offs,
-                         const uint32_t* __restrict__ partStart, const GcMfEntry* __restrict__ ent, uint64_t entStride,
-                         GcSeqRaw* __restrict__ seqRaw, uint8_t* __restrict__ lit, GcBlockMeta* __restrict__ meta,
-                         unsigned long long* __restrict__ prof)
-{
-    lzw_parse_body(src, srcSize, frameBlocks, offs, partStart, ent, entStride, seqRaw, lit, meta, prof);
-}
-#endif

@@ -1,20 +1,25 @@
 // gc_mf.h -- geometry of the windowed match finder (gc_lz_window.hip), shared by host and device.
 //
 // Unit of independence = FRAME = F consecutive 128 KiB blocks (F <= 64, i.e. <= 8 MiB).  Matches reach back to the start of
-// their frame.  For every position of a frame and for two key kinds (long = 8-byte hash, short = 5-byte hash) the finder
-// delivers "the most recent earlier position of the frame with the same key" -- what a hash table of unbounded size that is
-// updated position by position would return, the idea behind ZSTD_compressBlock_doubleFast's two tables
+// their frame.  For every position of a frame the finder delivers two candidates: the most recent earlier position of the frame
+// whose 8 bytes hash to the same "long" key and the most recent one whose 5 bytes hash to the same "short" key -- what two hash
+// tables updated position by position would return, the idea behind ZSTD_compressBlock_doubleFast's two tables
 // (C/zstd/zstd_double_fast.c:105-323), Fast-LZMA2's per-dictionary-block match table (C/fast-lzma2/radix_engine.h:920-981)
-// and brotli's H6 buckets (C/brotli/enc/hash_longest_match64_inc.h:157-290).  A table of that size cannot live in LDS and a
-// table in HBM would be hit by random atomics, so the key space is partitioned instead (an MSD radix step):
+// and brotli's H6 buckets (C/brotli/enc/hash_longest_match64_inc.h:157-290).  Tables of that size cannot live in LDS and a
+// table in HBM would be hit by random atomics, so the key space is partitioned instead (an MSD radix step on the top bits of
+// the SHORT hash: equal 8 bytes imply equal 5 bytes, so both keys of a position live in the same partition):
 //
-//   W1 count    wave per 8 KiB tile: histogram of the tile's keys over 128 partitions (top hash bits)
-//   W2 scan     per frame and kind: exclusive offsets in (partition, tile) order
-//   W3 scatter  wave per tile: stable scatter of (position, key) entries -> every partition is a position-ordered list
-//   W4 link     workgroup per (frame, kind, partition): streams its list through an LDS table (most recent wins) and replaces
-//               every key by the previous position with that key
-//   W5 parse    workgroup per block: gathers the candidates of a tile back into position order (LDS), verifies them against
-//               the input, parses and emits literals + sequences (same steps as K1)
+//   W1 count    workgroup per 8 KiB tile: histogram of the tile's positions over 256 partitions
+//   W2 scan     workgroup per frame: exclusive offsets in (partition, tile) order
+//   W3 scatter  workgroup per tile: stable counting sort of the tile in LDS, then one coalesced run per partition of 8-byte
+//               entries {position, long key, short key}
+//   W4 link     ONE WAVE per (frame, partition, list segment): streams its position-ordered list through two private LDS
+//               tables, 64 entries per step, one returning ds_max per table and step = the semantics of sequential insertion
+//               (most recent wins); no barriers.  Rewrites every entry as {position in tile, long candidate, short candidate}
+//   W5 verify   workgroup per tile, fully parallel: compares both candidates with the input, writes one match record
+//               (offset << 8 | length, length <= GC_MATCH_CAP) per position
+//   W6 parse    workgroup per block: greedy/lazy parse of the records by hierarchical composition of per-segment exit maps
+//               (64 positions -> 2048 positions -> block), then literals + sequences are placed by ballots and prefix sums
 #pragma once
 #include <stdint.h>
 #include "gc_common.h"
@@ -22,21 +27,33 @@
 #define GC_MF_TILE_LOG    13u
 #define GC_MF_TILE        (1u << GC_MF_TILE_LOG)          // positions per tile
 #define GC_MF_TILES_PER_BLOCK (GC_ZSTD_BLOCK_MAX >> GC_MF_TILE_LOG)
-#define GC_MF_PART_LOG    7u
+#define GC_MF_PART_LOG    8u
 #define GC_MF_PARTS       (1u << GC_MF_PART_LOG)
-#define GC_MF_KINDS       2u                              // 0 = long key, 1 = short key
-#define GC_MF_MAX_FRAME_BLOCKS 64u                        // 8 MiB: frame-relative positions + 1 fit 24 bits
+#define GC_MF_MAX_FRAME_BLOCKS 64u                        // 8 MiB: frame-relative positions fit 23 bits
 
-// one list entry: W3 writes {frame-relative position, 32-bit key}; W4 replaces `key` by (candidate position + 1), 0 = none
-struct GcMfEntry { uint32_t pos; uint32_t key; };
+// W3 -> W4 entry (64 bit):  pos[0..22] | long key[23..42] (12-bit slot, 8-bit tag) | short key[43..61] (11-bit slot, 8-bit tag)
+// W4 -> W5 entry (64 bit):  position in tile[0..12] | (long candidate + 1)[13..36] | (short candidate + 1)[37..60]   (0 = none;
+//                           candidates are frame-relative)
+typedef uint64_t GcMfEntry;
+#define GC_MF_POS_BITS    23u
+#define GC_MF_KL_BITS     20u
+#define GC_MF_KS_BITS     19u
+#define GC_MF_LSLOT_LOG   12u                             // W4 long table: 2^12 slots per partition (2^20 per frame)
+#define GC_MF_SSLOT_LOG   11u                             // W4 short table: 2^11 slots per partition (2^19 per frame)
 
+#define GC_MF_PARSE_T     1024u                           // W6: threads per block
+#define GC_MF_VERIFY_T    1024u                           // W5: threads per tile
+#define GC_MF_LINK_SEGS   8u                              // W4: waves per (frame, partition): long lists are linked in segments
+
+// W5 -> W6: one 32-bit match record per input position, (offset << 8) | length; 0 = no match
 struct GcMfGeom {
     uint32_t frameBlocks;     // F
     uint32_t nBlocks;
     uint32_t nFrames;
     uint32_t tilesPerFrame;   // F * 16
-    uint64_t frameBytes;      // F * 128 KiB
-    uint64_t entStride;       // entries per kind = nFrames * frameBytes
+    uint32_t nTiles;          // nFrames * tilesPerFrame (tiles past the end of the input are empty)
+    uint64_t frameBytes;      // F * 128 KiB = entries per frame
+    uint64_t cntWords;        // nFrames * (tilesPerFrame + 1) * GC_MF_PARTS
 };
 
 static inline GcMfGeom gc_mf_geom(uint64_t n, uint32_t frameBlocks)
@@ -46,9 +63,17 @@ static inline GcMfGeom gc_mf_geom(uint64_t n, uint32_t frameBlocks)
     g.nBlocks = gc_num_blocks(n);
     g.nFrames = (g.nBlocks + frameBlocks - 1u) / frameBlocks;
     g.tilesPerFrame = frameBlocks * GC_MF_TILES_PER_BLOCK;
+    g.nTiles = g.nFrames * g.tilesPerFrame;
     g.frameBytes = (uint64_t)frameBlocks * GC_ZSTD_BLOCK_MAX;
-    g.entStride = (uint64_t)g.nFrames * g.frameBytes;
+    g.cntWords = (uint64_t)g.nFrames * (g.tilesPerFrame + 1u) * GC_MF_PARTS;
     return g;
 }
-// cnt / offsets: [frame][kind][partition][tile]   (uint32, tilesPerFrame fastest)
-// partStart:     [frame][kind][GC_MF_PARTS + 1]
+// cnt / offsets: [frame][tile 0..tilesPerFrame][partition]  (uint32, partition fastest).  After W2, row `tile` holds the
+// frame-relative entry index where the tile's run of each partition starts; the extra row `tilesPerFrame` holds the partition
+// ends, so run (tile, g) = [row[tile][g], row[tile + 1][g]) for every tile.
+// entries: [frame][frameBytes]
+
+// Workgroup index -> work item such that each of the 8 XCDs (workgroups are dealt round-robin to XCDs) owns one contiguous
+// range of items: neighbouring tiles / blocks then share an L2.  The grid is 8 * per workgroups, per = ceil(n / 8).
+#define GC_XCDS 8u
+static inline uint32_t gc_xcd_per(uint32_t n) { return (n + GC_XCDS - 1u) / GC_XCDS; }

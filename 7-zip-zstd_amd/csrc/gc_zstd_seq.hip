@@ -12,9 +12,9 @@
 //              third history slot never matters and the whole assignment is order-independent
 //   P  codes   LL/ML/OF code + extra bits, three LDS histograms
 //   S  tables  one wave per table: mode (predefined / RLE / FSE), normalisation, NCount header, CTable
-//   S  chains  one wave per table walks its FSE state backwards over all sequences.  This is the only
-//              inherently serial part of zstd's entropy stage (one dependent LDS lookup per sequence); the three
-//              chains run concurrently and many workgroups share a CU, so the latency is hidden across blocks
+//   S  chains  one wave per table walks its FSE state backwards over all sequences: 64 segments at once, each lane finding
+//              its start state by running a few symbols ahead of its segment (FSE states forget their origin), checked and
+//              repaired against the predecessor's final state, so the result is exactly the serial walk
 //   P  pack    per-sequence bit counts -> block prefix sums -> fields OR-ed into an LDS tile -> bytes stream out
 //
 // Bit order is normative (zstd_compress_sequences.c:311-376): last sequence first; per sequence OF-state,
@@ -30,7 +30,8 @@
 #define SEQ_T 256u
 #define SEQ_TILE_WORDS ((SEQ_T * 80u) / 32u + 8u)
 #define SEQ_CHAIN_TILE 4096u   // sequences per state-chain tile
-#define SEQ_CHAIN_SEGS 1022u   // at most this many reset points are used per tile (further ones are walked through)
+#define SEQ_CHAIN_SEG  64u     // sequences per lane and tile
+#define SEQ_WARM_SEGS  4u      // a lane looks this many segments back for a point where all state walks meet
 
 __constant__ uint8_t kLLCode[64] = { 0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,16,17,17,18,18,19,19,20,20,20,20,21,21,21,21,
                                      22,22,22,22,22,22,22,22,23,23,23,23,23,23,23,23,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24 };
@@ -60,8 +61,7 @@ struct SeqTab {              // one FSE table in LDS
     // state-chain tile scratch (see "chains" in the kernel)
     uint8_t  tCode[SEQ_CHAIN_TILE];
     uint16_t tOut[SEQ_CHAIN_TILE];
-    uint16_t rpos[SEQ_CHAIN_SEGS + 2];
-    uint16_t sfin[SEQ_CHAIN_SEGS + 2];
+    uint64_t meet[SEQ_CHAIN_TILE / 64u];
 };
 
 // block-wide exclusive sum scan (SEQ_T threads)
@@ -125,8 +125,10 @@ __device__ inline void seq_build_table(SeqTab& T, int which, uint32_t nbSeq)
     if (tl < 5u) tl = 5u;
     if (tl > maxLog) tl = maxLog;
     gc_fse_normalize(T.count, maxSym, nbSeq, tl, T.norm);
-    // Rare symbols are demoted to a single cell: a count-1 symbol resets the FSE state chain (see "chains"), which is
-    // what lets the walk run segment-parallel.  Cost: < 0.1 bit per sequence on the corpora measured.
+    // Rare symbols are demoted to a single cell: whatever the state, a count-1 symbol sends it to the same successor, and these
+    // are the only points where two walks that started from different states are guaranteed to meet (an FSE step is a monotone
+    // map of the state, so walks otherwise keep their distance) -- they are what lets the state chain below be walked in
+    // parallel segments.  Cost: < 0.1 bit per sequence on the corpora measured.
     {
         uint32_t freed = 0, big = 0; int bigv = 0;
         for (uint32_t s = 0; s <= maxSym; s++) {
@@ -267,12 +269,14 @@ gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __res
     __syncthreads();
     SEQ_PHASE(2);         // tables
 
-    // ---- chains: wave w walks table w's FSE state backwards (last sequence first = processing index u 0).
-    //      The walk is serial through the state, except that a symbol whose normalised count is 1 (or -1) sends
-    //      EVERY state to the same successor (FSE_encodeSymbol: nbBits = tableLog, index = 1 + deltaFindState).
-    //      Such "reset" symbols cut the sequence array into segments whose start state is known up front, so the
-    //      64 lanes of the wave walk 64 segments at once; the bits emitted AT a reset step (low tableLog bits of
-    //      the previous state) are patched in afterwards from the previous segment's final state.
+    // ---- chains: wave w walks table w's FSE state backwards (last sequence first = processing index v 0).
+    //      The walk is serial through the state, but walks that started from different states meet at the next symbol whose
+    //      normalised count is 1 (every state has the same successor there; the table builder above makes sure such symbols
+    //      exist).  So the 64 lanes of the wave walk 64 consecutive segments of 64 sequences at once: a lane first runs
+    //      ahead of its segment from the nearest such meeting point before it (no output), then its own segment.  Afterwards every
+    //      segment's start state is compared with its predecessor's final state; a segment that started wrong is walked again
+    //      from the right state, only until it rejoins the states already stored, and this repeats until nothing changes
+    //      (each round settles at least one more segment, so the result is exactly the serial walk).
     if (wave < 3u) {
         SeqTab& T = sTab[wave];
         const uint8_t* C = wave == 0u ? cLL : (wave == 1u ? cOF : cML);
@@ -284,55 +288,76 @@ gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __res
             const uint32_t L = T.tableLog;
             int nv = 0;
             if (lane <= T.tabMaxSym) nv = T.norm[lane];
-            const uint64_t resetMask = __ballot(nv == 1 || nv == -1);
-            uint32_t carry = 0;
+            const uint64_t resetMask = __ballot(nv == 1 || nv == -1);    // symbols that send every state to the same successor
+            uint32_t carry = 0;                               // state after the last sequence of the previous tile
             for (uint32_t tb = 0; tb < nSeq; tb += SEQ_CHAIN_TILE) {
                 const uint32_t tileLen = min(SEQ_CHAIN_TILE, nSeq - tb);
-                // stage codes, list reset points (tile-relative processing index, ascending)
-                uint32_t nR = 0;
-                for (uint32_t k = 0; k < SEQ_CHAIN_TILE; k += 64u) {
+                // stage the codes; per 64 sequences one mask of the positions that hold a count-1 symbol ("meeting points")
+                for (uint32_t k = 0; k < tileLen; k += 64u) {
                     const uint32_t u = k + lane;
                     uint32_t code = 0; bool isR = false;
-                    if (u < tileLen) {
-                        code = C[nSeq - 1u - (tb + u)];
-                        isR = ((resetMask >> code) & 1ull) != 0ull || (tb + u == 0u);
-                    }
-                    T.tCode[u] = (uint8_t)code;
+                    if (u < tileLen) { code = C[nSeq - 1u - (tb + u)]; isR = ((resetMask >> code) & 1ull) != 0ull; T.tCode[u] = (uint8_t)code; }
                     const uint64_t bal = __ballot(isR);
-                    const uint32_t slot = nR + (uint32_t)__popcll(bal & gc_lanemask_lt());
-                    if (isR && slot < SEQ_CHAIN_SEGS) T.rpos[slot] = (uint16_t)u;
-                    nR = min(nR + (uint32_t)__popcll(bal), SEQ_CHAIN_SEGS);
+                    if (lane == 0u) T.meet[k >> 6] = bal;
                 }
                 gc_wave_sync();
-#ifdef HIPEMU
-                if (getenv("GC_TRACE_CHAIN") && lane == 0) fprintf(stderr, "chain table=%u tile=%u len=%u nR=%u L=%u mode=%u\n", wave, tb, tileLen, nR, L, T.mode);
-#endif
-                // segment i: [start_i, end_i) with start_0 = 0 (continues the carried state), start_i = rpos[i-1]
-                for (uint32_t i = lane; i <= nR; i += 64u) {
-                    const uint32_t start = i ? T.rpos[i - 1u] : 0u;
-                    const uint32_t end = i < nR ? T.rpos[i] : tileLen;
-                    uint32_t state = carry, u = start;
-                    if (i) { state = gc_fse_init_state(T.state, T.tt[T.tCode[start]]); u = start + 1u; }   // reset / first symbol
-                    if (u < end) {
-                        GcFseSym sy = T.tt[T.tCode[u]];
-                        for (; u < end; u++) {
-                            const GcFseSym nxt = T.tt[T.tCode[u + 1u < end ? u + 1u : u]];    // independent of the state: overlaps its lookup
-                            const uint32_t nb = (state + sy.deltaNbBits) >> 16;
-                            T.tOut[u] = (uint16_t)((nb << 10) | (state & ((1u << nb) - 1u)));
-                            state = T.state[(state >> nb) + (uint32_t)sy.deltaFindState];
-                            sy = nxt;
+                const uint32_t nSegs = (tileLen + SEQ_CHAIN_SEG - 1u) / SEQ_CHAIN_SEG;      // <= 64: lane i walks segment i
+                const uint32_t u0 = lane * SEQ_CHAIN_SEG, u1 = min(u0 + SEQ_CHAIN_SEG, tileLen);
+                uint32_t first = u0;                          // first index of the segment that emits bits
+                uint32_t st0 = carry;
+                if (lane < nSegs) {
+                    if (tb + u0 == 0u) { st0 = gc_fse_init_state(T.state, T.tt[T.tCode[0]]); T.tOut[0] = 0; first = 1u; }   // FSE_initCState2: no bits
+                    else if (lane != 0u) {
+                        // run ahead from the nearest meeting point in the SEQ_WARM_SEGS segments before this one (from there the
+                        // state is exact whatever it was before); if there is none, from SEQ_WARM_SEGS segments back (a guess)
+                        uint32_t w = lane > SEQ_WARM_SEGS ? (lane - SEQ_WARM_SEGS) * SEQ_CHAIN_SEG : 0u;
+                        for (uint32_t c = lane; c-- > 0u && c + SEQ_WARM_SEGS >= lane; ) {
+                            const uint64_t m = T.meet[c];
+                            if (m) { w = c * 64u + 63u - (uint32_t)__clzll((long long)m); break; }
+                        }
+                        if (tb + w == 0u) { st0 = gc_fse_init_state(T.state, T.tt[T.tCode[0]]); w = 1u; }                   // exact, not a guess
+                        else st0 = 1u << L;
+                        for (; w < u0; w++) {
+                            const GcFseSym sy = T.tt[T.tCode[w]];
+                            const uint32_t nb = (st0 + sy.deltaNbBits) >> 16;
+                            st0 = T.state[(st0 >> nb) + (uint32_t)sy.deltaFindState];
                         }
                     }
-                    T.sfin[i] = (uint16_t)state;
                 }
-                gc_wave_sync();
-                // bits emitted at the reset steps: low L bits of the previous segment's final state
-                for (uint32_t i = 1u + lane; i <= nR; i += 64u) {
-                    const uint32_t idx = T.rpos[i - 1u];
-                    T.tOut[idx] = (tb + idx == 0u) ? (uint16_t)0 : (uint16_t)((L << 10) | (T.sfin[i - 1u] & ((1u << L) - 1u)));
+                // tOut[u] = nbBits << 10 | state BEFORE symbol u (10 bits): the bits to emit are its low nbBits, and a repair walk
+                // can tell when it has rejoined the trajectory already stored (same state at the same u: the rest is unchanged)
+                uint32_t fin = st0;
+                bool redo = lane < nSegs;
+                bool firstPass = true;
+#ifdef HIPEMU
+                uint32_t dbgRounds = 0, dbgRedo = 0;
+#endif
+                for (;;) {
+                    if (redo) {
+                        uint32_t state = st0, u = first;
+                        for (; u < u1; u++) {
+                            if (!firstPass && (T.tOut[u] & 0x3FFu) == (state & 0x3FFu)) break;
+                            const GcFseSym sy = T.tt[T.tCode[u]];
+                            const uint32_t nb = (state + sy.deltaNbBits) >> 16;
+                            T.tOut[u] = (uint16_t)((nb << 10) | (state & 0x3FFu));
+                            state = T.state[(state >> nb) + (uint32_t)sy.deltaFindState];
+                        }
+                        if (u == u1) fin = state;                 // walked to the end: the final state may have changed
+                    }
+                    firstPass = false;
+                    const uint32_t prevFin = __shfl_up(fin, 1);
+                    redo = lane != 0u && lane < nSegs && prevFin != st0;
+                    if (redo) st0 = prevFin;
+#ifdef HIPEMU
+                    dbgRounds++; dbgRedo += (uint32_t)__popcll(__ballot(redo));
+#endif
+                    if (!__any(redo)) break;
                 }
+#ifdef HIPEMU
+                if (getenv("GC_TRACE_CHAIN") && lane == 0) fprintf(stderr, "chain table=%u tile=%u len=%u L=%u rounds=%u redone=%u\n", wave, tb, tileLen, L, dbgRounds, dbgRedo);
+#endif
+                carry = __shfl(fin, (int)(nSegs - 1u));
                 gc_wave_sync();
-                carry = T.sfin[nR];
                 for (uint32_t u = lane; u < tileLen; u += 64u) S[nSeq - 1u - (tb + u)] = T.tOut[u];
                 gc_wave_sync();
             }
@@ -373,9 +398,9 @@ gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __res
             const uint32_t llc = cLL[j], mlc = cML[j], ofc = cOF[j];
             if (u != 0u) {
                 uint32_t so_ = stOF[j], sm = stML[j], sl = stLL[j];
-                a |= (uint64_t)(so_ & 0x3FFu) << na; na += so_ >> 10;
-                a |= (uint64_t)(sm & 0x3FFu) << na; na += sm >> 10;
-                a |= (uint64_t)(sl & 0x3FFu) << na; na += sl >> 10;
+                a |= (uint64_t)(so_ & ((1u << (so_ >> 10)) - 1u)) << na; na += so_ >> 10;     // low nbBits of the state (stored whole)
+                a |= (uint64_t)(sm & ((1u << (sm >> 10)) - 1u)) << na; na += sm >> 10;
+                a |= (uint64_t)(sl & ((1u << (sl >> 10)) - 1u)) << na; na += sl >> 10;
             }
             { uint32_t nb = kLLBits[llc]; a |= (uint64_t)(ll & ((1u << nb) - 1u)) << na; na += nb; }
             { uint32_t nb = kMLBits[mlc]; c |= (uint64_t)(mlBase & ((1u << nb) - 1u)); nc += nb; }

@@ -3,7 +3,7 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the whole hot path (match finder W1..W5 -> K2 huf || K3 seq -> K4 plan -> K5 emit) over one
+A "step" is one pass of the whole hot path (match finder W1..W6 -> K2 huf || K3 seq -> K4 plan -> K5 emit) over one
 100 000 000-byte buffer per GPU that is already resident in HBM (enwik8 is not available offline; the stand-in
 is the deterministic `text-zipf` corpus, labelled synthetic).  At level 3 the 128 KiB zstd blocks are grouped into
 independent 8 MiB frames (windowed match finder); levels 1-2 use one frame per block (block-local finder).
@@ -190,7 +190,7 @@ def main():
         algo_bytes = n * (1.0 + 1.0 / ratio)
         achieved = algo_bytes / (per_kernel[dom] * 1e-3) / 1e9
         mf_names = {"mf.count": "gc_mf_count_kernel", "mf.scan": "gc_mf_scan_kernel", "mf.scatter": "gc_mf_scatter_kernel",
-                    "mf.link": "gc_mf_link_kernel", "mf.parse": "gc_lzw_parse_kernel"}
+                    "mf.link": "gc_mf_link_kernel", "mf.verify": "gc_mf_verify_kernel", "mf.parse": "gc_mf_parse_kernel"}
         kname = mf_names[dom] if dom in mf_names else \
             "gc_zstd_lz_kernel" if dom == "lz" else ("gc_lzma2_%s_kernel" if fl2 else ("gc_brotli_%s_kernel" if br else "gc_zstd_%s_kernel")) % dom
         traffic = None

@@ -59,9 +59,9 @@ int         gc_zstd_compress_host(gc_ctx* ctx, const void* src, size_t n, void* 
  * ms[0..4] = lz, huf, seq, plan, emit (huf and seq overlap on two streams); ms[5] = first kernel start -> last kernel end. */
 int         gc_zstd_last_timing(gc_ctx* ctx, float ms[6]);
 
-/* Levels >= 3 run the windowed match finder (five kernels: count, scan, scatter, link, parse); ms[0..4] = their HIP-event
- * durations in the last call (any codec).  GC_ERR_PARAM if the last call used the block-local finder. */
-int         gc_mf_last_timing(gc_ctx* ctx, float ms[5]);
+/* Levels >= 3 run the windowed match finder (six kernels: count, scan, scatter, link, verify, parse); ms[0..5] = their
+ * HIP-event durations in the last call (any codec).  GC_ERR_PARAM if the last call used the block-local finder. */
+int         gc_mf_last_timing(gc_ctx* ctx, float ms[6]);
 
 /* Optional in-kernel phase profile (shader-clock deltas measured by thread 0 of every workgroup, averaged over
  * blocks): cycles[0..6] = K1 {probe, insert, verify, double, chain, walk, emit}, cycles[7..11] = K3 {merge,

@@ -62,7 +62,9 @@ void block_barrier()
 {
     BlockCtx* b = blk;
     unsigned long g = b->gen;
-    if (++b->arrived == b->live) { b->arrived = 0; b->gen++; return; }
+    // the last arrival releases the others but yields too, so that everybody resumes in thread order (lane 0 first), the
+    // order in which the hardware serves the lanes of one LDS instruction
+    if (++b->arrived == b->live) { b->arrived = 0; b->gen++; yield_to_scheduler(); return; }
     cur->state = 1; cur->wait_gen = g;
     yield_to_scheduler();
 }
@@ -71,7 +73,7 @@ void wave_barrier()
 {
     WaveCtx& w = wv();
     unsigned long g = w.gen;
-    if (++w.arrived == w.live) { w.arrived = 0; w.gen++; return; }
+    if (++w.arrived == w.live) { w.arrived = 0; w.gen++; yield_to_scheduler(); return; }
     cur->state = 2; cur->wait_gen = g;
     yield_to_scheduler();
 }

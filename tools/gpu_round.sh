@@ -9,7 +9,7 @@ elif [ "$2" != "skip-tests" ]; then
   timeout 1500 python -m pytest tests -m gpu -x -q > $OUT/pytest.log 2>&1; echo "pytest exit $?" >> $OUT/pytest.log; tail -15 $OUT/pytest.log
 fi
 timeout 300 python tools/gpu_profile.py > $OUT/phase.json 2> $OUT/phase.err; cat $OUT/phase.json
-GC_LZW_OCC2=1 timeout 300 python tools/gpu_profile.py > $OUT/phase_occ2.json 2>> $OUT/phase.err; cat $OUT/phase_occ2.json
+
 timeout 300 python tools/gpu_profile.py --level 1 > $OUT/phase_l1.json 2>> $OUT/phase.err; cat $OUT/phase_l1.json
 for c in silesia-like lz-7zip; do timeout 300 python tools/gpu_profile.py --corpus $c >> $OUT/phase_other.json 2>> $OUT/phase.err; done; cat $OUT/phase_other.json
 timeout 600 python bench.py > $OUT/bench.json 2> $OUT/bench.err; cat $OUT/bench.json; tail -3 $OUT/bench.err
