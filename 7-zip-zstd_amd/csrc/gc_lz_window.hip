@@ -49,11 +49,11 @@ __device__ __forceinline__ MfTile mf_tile(uint32_t tile, uint32_t frameBlocks, u
     return T;
 }
 
-// Stage input bytes [tileStart - 16, tileStart + GC_MF_TILE + 16) into LDS (zero outside the input) with 16-byte loads.
+// Stage input bytes [tileStart - 16, tileStart - 16 + 4 * nWords) into LDS (zero outside the input) with 16-byte loads.
 // LDS byte i <-> input position tileStart - 16 + i.
-__device__ __forceinline__ void mf_stage(uint32_t* sW, const uint8_t* __restrict__ src, uint64_t srcSize, uint64_t tileStart, uint32_t t, uint32_t nThreads)
+__device__ __forceinline__ void mf_stage(uint32_t* sW, uint32_t nWords, const uint8_t* __restrict__ src, uint64_t srcSize, uint64_t tileStart, uint32_t t, uint32_t nThreads)
 {
-    for (uint32_t c = t; c < MF_STAGE_WORDS / 4u; c += nThreads) {
+    for (uint32_t c = t; c < nWords / 4u; c += nThreads) {
         GcU4 v; v.x = v.y = v.z = v.w = 0;
         if (tileStart + 16ull * c >= MF_STAGE_PAD) {
             const uint64_t pos = tileStart + 16ull * c - MF_STAGE_PAD;
@@ -111,7 +111,7 @@ gc_mf_count_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t f
     const MfTile T = mf_tile(tile, frameBlocks, srcSize);
     const uint32_t TPF = frameBlocks * GC_MF_TILES_PER_BLOCK;
     sHist[t] = 0;
-    if (T.len) mf_stage(sW, src, srcSize, T.tileStart, t, MF_T);
+    if (T.len) mf_stage(sW, MF_STAGE_WORDS, src, srcSize, T.tileStart, t, MF_T);
     __syncthreads();
     for (uint32_t q = t; q < T.len; q += MF_T) {
         const MfKeys k = mf_keys(sW, q, T);
@@ -180,7 +180,7 @@ gc_mf_scatter_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t
     if (T.len == 0u) return;
     const uint32_t TPF = frameBlocks * GC_MF_TILES_PER_BLOCK;
     for (uint32_t w = 0; w < MF_WAVES; w++) sRun[w][t] = 0;
-    mf_stage(sW, src, srcSize, T.tileStart, t, MF_T);
+    mf_stage(sW, MF_STAGE_WORDS, src, srcSize, T.tileStart, t, MF_T);
     __syncthreads();
     const uint32_t qBase = wave * (GC_MF_TILE / MF_WAVES);
     // pass A: per-wave histograms
@@ -349,18 +349,35 @@ gc_mf_link_kernel(const uint32_t* __restrict__ offs, const GcMfEntry* __restrict
 // ------------------------------------------------------------------------------------------------ W5 verify
 // One workgroup per tile; every thread is independent.  Listed positions are taken in list order (the tile's 256 runs viewed as
 // one flat array; the run of a flat index is found by bisection over the run starts in LDS), unlisted ones in position order.
+// What the kernel costs is the number of random 16-byte reads (each one is a separate L1 access and L2 request), so:
+//   - the position's own bytes come from the staged tile in LDS, never from memory
+//   - the short candidate is only read when the long one is missing or did not verify (a verified long candidate has >= 8
+//     equal bytes; a different short candidate is a more recent position that matches 5..7 bytes, which loses)
+//   - the records are collected in LDS and leave as full lines (stores are written through the L2 at the granularity of the
+//     request: 4-byte stores in list order would reach HBM as 94 M partial-line writes)
 #define MFV_T GC_MF_VERIFY_T
+#define MFV_B 4u                      // listed positions per thread and round
+#define MFV_PAD_AFTER (GC_MATCH_CAP + 32u)                        // staged bytes behind the tile: own side of every compare
+#define MFV_STAGE_WORDS ((MF_STAGE_PAD + GC_MF_TILE + MFV_PAD_AFTER) / 4u)
 
 __device__ __forceinline__ LzW16 mf_lds_ld16(const uint32_t* sW, uint32_t i)
 {
     LzW16 w; w.a = mf_lds_ld64(sW, i); w.b = mf_lds_ld64(sW, i + 8u); return w;
+}
+// first 16 bytes of candidate c (frame-relative position + 1) against the own window; 0 if shorter than GC_MIN_MATCH
+__device__ __forceinline__ uint32_t mfv_len16(const LzW16& me, const LzW16& cw, uint32_t maxLen)
+{
+    uint32_t len = lz_cmp16(me, cw);
+    if (len > maxLen) len = maxLen;
+    return len >= GC_MIN_MATCH ? len : 0u;
 }
 
 extern "C" __global__ void __launch_bounds__(MFV_T)
 gc_mf_verify_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
                     const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, uint32_t* __restrict__ rec)
 {
-    __shared__ uint32_t sW[MF_STAGE_WORDS];
+    __shared__ uint32_t sW[MFV_STAGE_WORDS];
+    __shared__ uint32_t sRec[GC_MF_TILE];
     __shared__ uint32_t sStart[GC_MF_PARTS], sLocal[GC_MF_PARTS + 1u];
     __shared__ uint32_t sWaveTot[GC_MF_PARTS / 64u];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
@@ -378,7 +395,7 @@ gc_mf_verify_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t 
         incl = gc_wave_incl_sum(c);
         if (lane == 63u) sWaveTot[wave] = incl;
     }
-    mf_stage(sW, src, srcSize, T.tileStart, t, MFV_T);
+    mf_stage(sW, MFV_STAGE_WORDS, src, srcSize, T.tileStart, t, MFV_T);
     __syncthreads();
     if (t < GC_MF_PARTS) {
         uint32_t before = 0;
@@ -394,38 +411,81 @@ gc_mf_verify_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t 
     const uint32_t nBlk = (uint32_t)((srcSize - blockBase) < GC_ZSTD_BLOCK_MAX ? (srcSize - blockBase) : GC_ZSTD_BLOCK_MAX);
     const uint32_t pTile = (uint32_t)(T.tileStart - blockBase);
     const uint32_t wTile = (uint32_t)(T.tileStart - T.frameStart);
-    uint32_t* R = rec + T.tileStart;
-    // listed positions
-    for (uint32_t j = t; j < nEnt; j += MFV_T) {
-        uint32_t lo = 0, hi = GC_MF_PARTS;                        // largest g with sLocal[g] <= j
-        while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if (sLocal[mid] <= j) lo = mid; else hi = mid; }
-        const uint64_t e = E[sStart[lo] + (j - sLocal[lo])];
-        const uint32_t q = (uint32_t)e & (GC_MF_TILE - 1u);
-        const uint32_t cL = (uint32_t)(e >> GC_MF_TILE_LOG) & 0xFFFFFFu, cS = (uint32_t)(e >> (GC_MF_TILE_LOG + 24u)) & 0xFFFFFFu;
-        const uint32_t p = pTile + q;                             // block-relative
-        uint32_t bestLen = 0, bestOff = 0;
-        if (p + 8u <= nBlk && (cL | cS) != 0u) {
-            const uint32_t maxLen = (nBlk - p) < GC_MATCH_CAP ? (nBlk - p) : GC_MATCH_CAP;
-            uint32_t cand[3]; int nc = 0;
-            if (cL != 0u) cand[nc++] = cL - 1u;
-            if (cS != 0u && cS != cL) cand[nc++] = cS - 1u;
-            lz_verify(wsrc, wTile + q, mf_lds_ld16(sW, q + MF_STAGE_PAD), cand, nc, maxLen, bestLen, bestOff);
+    // listed positions, MFV_B per thread and round, stage by stage over small arrays so that the entry loads, then the long
+    // candidates, then the short candidates that are still needed are in flight together
+    for (uint32_t j0 = t; j0 < nEnt; j0 += MFV_T * MFV_B) {
+        uint64_t e[MFV_B];
+#pragma unroll
+        for (uint32_t k = 0; k < MFV_B; k++) {
+            const uint32_t j = j0 + k * MFV_T;
+            const uint32_t jj = j < nEnt ? j : nEnt - 1u;
+            uint32_t lo = 0;                                      // largest g with sLocal[g] <= jj (branch-free bisection)
+#pragma unroll
+            for (uint32_t step = GC_MF_PARTS / 2u; step != 0u; step >>= 1) if (sLocal[lo + step] <= jj) lo += step;
+            e[k] = E[sStart[lo] + (jj - sLocal[lo])];
         }
-        R[q] = (bestOff << 8) | bestLen;
+        uint32_t q[MFV_B], cS[MFV_B], maxLen[MFV_B], bestLen[MFV_B], bestC[MFV_B];
+        LzW16 cw[MFV_B];
+#pragma unroll
+        for (uint32_t k = 0; k < MFV_B; k++) {                    // long candidates
+            q[k] = (uint32_t)e[k] & (GC_MF_TILE - 1u);
+            const uint32_t cL = (uint32_t)(e[k] >> GC_MF_TILE_LOG) & 0xFFFFFFu;
+            cS[k] = (uint32_t)(e[k] >> (GC_MF_TILE_LOG + 24u)) & 0xFFFFFFu;
+            const uint32_t p = pTile + q[k];                      // block-relative
+            const bool can = j0 + k * MFV_T < nEnt && p + 8u <= nBlk;
+            maxLen[k] = can ? ((nBlk - p) < GC_MATCH_CAP ? (nBlk - p) : GC_MATCH_CAP) : 0u;
+            if (cS[k] == cL) cS[k] = 0;
+            bestC[k] = (can && cL) ? cL : 0u;
+            if (bestC[k]) cw[k] = lz_ld16(wsrc, bestC[k] - 1u);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < MFV_B; k++) {
+            bestLen[k] = bestC[k] ? mfv_len16(mf_lds_ld16(sW, q[k] + MF_STAGE_PAD), cw[k], maxLen[k]) : 0u;
+            if (bestLen[k] >= 8u || maxLen[k] == 0u) cS[k] = 0;  // verified long candidate: the short one is not needed
+            if (cS[k]) cw[k] = lz_ld16(wsrc, cS[k] - 1u);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < MFV_B; k++) {
+            const uint32_t pw = wTile + q[k];
+            if (cS[k]) {
+                const uint32_t len = mfv_len16(mf_lds_ld16(sW, q[k] + MF_STAGE_PAD), cw[k], maxLen[k]);
+                if (len && (bestLen[k] == 0u || lz_gain(len, pw - (cS[k] - 1u)) > lz_gain(bestLen[k], pw - (bestC[k] - 1u)))) { bestLen[k] = len; bestC[k] = cS[k]; }
+            }
+            uint32_t len = bestLen[k];
+            while (len >= 16u && (len & 15u) == 0u && len < maxLen[k]) {      // saturated: extend 16 bytes per round (own side from LDS)
+                const uint32_t more = lz_cmp16(mf_lds_ld16(sW, q[k] + MF_STAGE_PAD + len), lz_ld16(wsrc, (uint64_t)(bestC[k] - 1u) + len));
+                len += more;
+                if (len > maxLen[k]) len = maxLen[k];
+                if (more < 16u) break;
+            }
+            if (j0 + k * MFV_T < nEnt) sRec[q[k]] = len ? (((pw - (bestC[k] - 1u)) << 8) | len) : 0u;
+        }
     }
     // unlisted positions: byte runs match at distance 1, the tail of the frame does not match at all
     for (uint32_t q = t; q < T.len; q += MFV_T) {
-        const MfKeys k = mf_keys(sW, q, T);
-        if (k.ok) continue;
+        const uint64_t x = mf_lds_ld64(sW, q + MF_STAGE_PAD);
+        const bool run = T.tileStart + q > T.frameStart && ((x << 8) | (uint64_t)mf_lds_byte(sW, q + MF_STAGE_PAD - 1u)) == x;
+        const bool windowed = T.tileStart + q + GC_MATCH_CAP + 16u <= T.frameEnd;
+        if (windowed && !run) continue;                           // listed
         const uint32_t p = pTile + q;
-        uint32_t bestLen = 0, bestOff = 0;
-        if (k.run && p + 8u <= nBlk && T.tileStart + q + GC_MATCH_CAP + 16u <= T.frameEnd) {
+        uint32_t len = 0;
+        if (run && windowed && p + 8u <= nBlk) {                  // both sides of the compare lie in the staged tile
             const uint32_t maxLen = (nBlk - p) < GC_MATCH_CAP ? (nBlk - p) : GC_MATCH_CAP;
-            uint32_t cand[3]; cand[0] = wTile + q - 1u;
-            lz_verify(wsrc, wTile + q, mf_lds_ld16(sW, q + MF_STAGE_PAD), cand, 1, maxLen, bestLen, bestOff);
+            while (len < maxLen) {
+                const uint32_t more = lz_cmp16(mf_lds_ld16(sW, q + MF_STAGE_PAD + len), mf_lds_ld16(sW, q + MF_STAGE_PAD - 1u + len));
+                len += more;
+                if (more < 16u) break;
+            }
+            if (len > maxLen) len = maxLen;
+            if (len < GC_MIN_MATCH) len = 0;
         }
-        R[q] = (bestOff << 8) | bestLen;
+        sRec[q] = len ? ((1u << 8) | len) : 0u;
     }
+    __syncthreads();
+    // records out: 16 bytes per lane, full lines
+    GcU4* R4 = (GcU4*)(rec + T.tileStart);
+    const GcU4* S4 = (const GcU4*)sRec;
+    for (uint32_t i = t; i < (T.len + 3u) / 4u; i += MFV_T) R4[i] = S4[i];
 }
 
 // ------------------------------------------------------------------------------------------------ W6 parse

@@ -42,7 +42,7 @@ typedef uint64_t GcMfEntry;
 #define GC_MF_SSLOT_LOG   11u                             // W4 short table: 2^11 slots per partition (2^19 per frame)
 
 #define GC_MF_PARSE_T     1024u                           // W6: threads per block
-#define GC_MF_VERIFY_T    1024u                           // W5: threads per tile
+#define GC_MF_VERIFY_T    512u                            // W5: threads per tile
 #define GC_MF_LINK_SEGS   8u                              // W4: waves per (frame, partition): long lists are linked in segments
 
 // W5 -> W6: one 32-bit match record per input position, (offset << 8) | length; 0 = no match

@@ -292,11 +292,14 @@ gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __res
             uint32_t carry = 0;                               // state after the last sequence of the previous tile
             for (uint32_t tb = 0; tb < nSeq; tb += SEQ_CHAIN_TILE) {
                 const uint32_t tileLen = min(SEQ_CHAIN_TILE, nSeq - tb);
-                // stage the codes; per 64 sequences one mask of the positions that hold a count-1 symbol ("meeting points")
+                // stage the codes (independent loads, eight in flight per lane), then per 64 sequences one mask of the positions
+                // that hold a count-1 symbol ("meeting points")
+#pragma unroll 8
+                for (uint32_t u = lane; u < tileLen; u += 64u) T.tCode[u] = C[nSeq - 1u - (tb + u)];
+                gc_wave_sync();
                 for (uint32_t k = 0; k < tileLen; k += 64u) {
                     const uint32_t u = k + lane;
-                    uint32_t code = 0; bool isR = false;
-                    if (u < tileLen) { code = C[nSeq - 1u - (tb + u)]; isR = ((resetMask >> code) & 1ull) != 0ull; T.tCode[u] = (uint8_t)code; }
+                    const bool isR = u < tileLen && ((resetMask >> T.tCode[u]) & 1ull) != 0ull;
                     const uint64_t bal = __ballot(isR);
                     if (lane == 0u) T.meet[k >> 6] = bal;
                 }
