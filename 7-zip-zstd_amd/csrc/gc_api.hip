@@ -37,10 +37,10 @@ extern "C" __global__ void gc_mf_link_kernel(const uint32_t*, const GcMfEntry*, 
 extern "C" __global__ void gc_mf_verify_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
 extern "C" __global__ void gc_mf_parse_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, const uint32_t*, GcSeqRaw*, uint8_t*, GcBlockMeta*);
 
-extern "C" __global__ void gc_lzma2_prep_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t*, uint32_t*);
+extern "C" __global__ void gc_lzma2_prep_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t, uint64_t*, uint32_t*);
 extern "C" __global__ void gc_lzma2_model_kernel(const uint8_t*, uint64_t, const uint64_t*, const uint32_t*, uint32_t, uint16_t*, GcLzmaChunkInfo*);
 extern "C" __global__ void gc_lzma2_rc_kernel(const uint16_t*, uint32_t, uint32_t, uint8_t*, GcLzmaChunkInfo*);
-extern "C" __global__ void gc_lzma2_plan_kernel(const GcLzmaChunkInfo*, uint32_t, uint64_t, uint32_t, GcLzmaPlan*, uint64_t*);
+extern "C" __global__ void gc_lzma2_plan_kernel(const GcLzmaChunkInfo*, uint32_t, uint32_t, uint64_t, uint32_t, GcLzmaPlan*, uint64_t*);
 extern "C" __global__ void gc_lzma2_emit_kernel(const uint8_t*, uint32_t, const uint8_t*, const GcLzmaChunkInfo*, const GcLzmaPlan*, uint32_t,
                                                 uint32_t, const uint64_t*, uint8_t*);
 
@@ -61,7 +61,8 @@ struct gc_ctx {
     GcSeqRaw* seqRaw; uint8_t* lit; GcBlockMeta* meta;
     uint64_t* seqPacked; uint32_t* seqOff; uint8_t* codes; uint16_t* stOut;
     uint8_t* litSec; uint8_t* seqSec; GcSectionInfo* info; GcFramePlan* plan; uint64_t* result;
-    uint32_t* lzNM; GcLzmaChunkInfo* lzInfo; GcLzmaPlan* lzPlan; uint16_t* lzStream; size_t lzStreamCap;       // FLZMA2 path (M aliases seqPacked, chunk staging aliases litSec)
+    uint32_t* lzNM; GcLzmaChunkInfo* lzInfo; GcLzmaPlan* lzPlan; uint16_t* lzStream; size_t lzStreamCap;       // FLZMA2 path
+    uint64_t* lzM; size_t lzMCap; uint8_t* lzRcOut; size_t lzRcOutCap;     // item lists, range-coder staging (allocated on the first FLZMA2 call)
     uint8_t* brStage; GcBrotliBlockInfo* brInfo; GcBrotliPlan* brPlan;    // BROTLI path
     // windowed match finder (gc_mf.h): counts/offsets, partition starts, entry lists; grown on demand
     uint32_t* mfCnt; size_t mfCntCap; GcMfEntry* mfEnt; size_t mfEntCap; GcMfEntry* mfEnt2; size_t mfEnt2Cap; uint32_t* mfRec; size_t mfRecCap;
@@ -122,6 +123,7 @@ static void free_workspace(gc_ctx* c)
     hipFree(c->stOut); hipFree(c->litSec); hipFree(c->seqSec); hipFree(c->info); hipFree(c->plan);
     hipFree(c->brStage); hipFree(c->brInfo); hipFree(c->brPlan); c->brStage = nullptr; c->brInfo = nullptr; c->brPlan = nullptr;
     hipFree(c->lzNM); hipFree(c->lzInfo); hipFree(c->lzPlan); hipFree(c->lzStream); c->lzStream = nullptr; c->lzStreamCap = 0; c->lzNM = nullptr; c->lzInfo = nullptr; c->lzPlan = nullptr;
+    hipFree(c->lzM); c->lzM = nullptr; c->lzMCap = 0; hipFree(c->lzRcOut); c->lzRcOut = nullptr; c->lzRcOutCap = 0;
     c->seqRaw = nullptr; c->lit = nullptr; c->meta = nullptr; c->seqPacked = nullptr; c->seqOff = nullptr; c->codes = nullptr;
     c->stOut = nullptr; c->litSec = nullptr; c->seqSec = nullptr; c->info = nullptr; c->plan = nullptr; c->capBlocks = 0;
 }
@@ -165,8 +167,8 @@ static int ensure_workspace(gc_ctx* c, uint32_t nBlocks)
         hipMalloc((void**)&c->brInfo, nb * sizeof(GcBrotliBlockInfo)) != hipSuccess ||
         hipMalloc((void**)&c->brPlan, nb * sizeof(GcBrotliPlan)) != hipSuccess ||
         hipMalloc((void**)&c->lzNM, nb * sizeof(uint32_t)) != hipSuccess ||
-        hipMalloc((void**)&c->lzInfo, nb * (GC_ZSTD_BLOCK_MAX >> GC_LZMA_CHUNK_LOG_MIN) * sizeof(GcLzmaChunkInfo)) != hipSuccess ||
-        hipMalloc((void**)&c->lzPlan, nb * (GC_ZSTD_BLOCK_MAX >> GC_LZMA_CHUNK_LOG_MIN) * sizeof(GcLzmaPlan)) != hipSuccess) {
+        hipMalloc((void**)&c->lzInfo, nb * GC_LZMA_RC_PER_BLOCK * sizeof(GcLzmaChunkInfo)) != hipSuccess ||
+        hipMalloc((void**)&c->lzPlan, nb * GC_LZMA_RC_PER_BLOCK * sizeof(GcLzmaPlan)) != hipSuccess) {
         free_workspace(c);
         snprintf(c->err, sizeof(c->err), "workspace allocation for %u blocks failed", nBlocks);
         return GC_ERR_NOMEM;
@@ -342,18 +344,18 @@ extern "C" int gc_zstd_phase_profile(gc_ctx* c, double cyclesPerBlock[GC_LZ_PHAS
 
 
 // ------------------------------------------------------------------------------------------------ FLZMA2 (LZMA2 stream)
-// level -> chunk size: smaller chunks = more independent range coders in flight (faster), more state resets (larger).
-static uint32_t flzma2_chunk_log(int level)
+// level -> model segment size (gc_lzma2.h): smaller segments = more model waves in flight (faster), more state resets (larger).
+static uint32_t flzma2_seg_log(int level)
 {
-    if (level <= 3) return 13u;
-    if (level <= 5) return 14u;
-    if (level <= 7) return 15u;
-    return 16u;
+    if (level <= 3) return 14u;
+    if (level <= 5) return 15u;
+    if (level <= 7) return 16u;
+    return 17u;
 }
 
 extern "C" size_t gc_flzma2_compress_bound(size_t n)
 {
-    const size_t nChunks = (n + (1u << GC_LZMA_CHUNK_LOG_MIN) - 1) >> GC_LZMA_CHUNK_LOG_MIN;
+    const size_t nChunks = (n + GC_LZMA_RC_SIZE - 1) >> GC_LZMA_RC_LOG;
     return n + nChunks * 6u + 16u;
 }
 
@@ -383,16 +385,18 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     const uint32_t nBlocks = gc_num_blocks(n);
     int rc = ensure_workspace(c, nBlocks);
     if (rc != GC_OK) return rc;
-    const uint32_t chunkLog = flzma2_chunk_log(level);
-    const uint32_t nChunks = nBlocks * (GC_ZSTD_BLOCK_MAX >> chunkLog);
+    const uint32_t segLog = flzma2_seg_log(level);
+    const uint32_t nSegs = nBlocks * (GC_ZSTD_BLOCK_MAX >> segLog), nRc = nBlocks * GC_LZMA_RC_PER_BLOCK;
     const uint8_t* src = (const uint8_t*)d_src;
-    {   // (p, bit) stream between the model kernel and the range coder: 2 bytes per coded bit, <= 9 coded bits per input byte
-        const size_t need = (size_t)nChunks * GC_LZMA_STREAM_WORDS(chunkLog) * sizeof(uint16_t);
-        if (need > c->lzStreamCap) {
+    {   // (p, bit) stream between the model kernel and the range coder: 2 bytes per coded bit, <= 9 coded bits per input byte;
+        // item lists; range-coder staging
+        const size_t needStream = (size_t)nSegs * GC_LZMA_STREAM_WORDS(segLog) * sizeof(uint16_t);
+        const size_t needM = (size_t)nBlocks * GC_LZMA_MAX_ITEMS * sizeof(uint64_t), needRc = (size_t)nRc * GC_LZMA_RC_STRIDE;
+        if (needStream > c->lzStreamCap || needM > c->lzMCap || needRc > c->lzRcOutCap) {
             HIPCHK(c, hipStreamSynchronize(c->stream));
-            hipFree(c->lzStream); c->lzStream = nullptr; c->lzStreamCap = 0;
-            if (hipMalloc((void**)&c->lzStream, need) != hipSuccess) { snprintf(c->err, sizeof(c->err), "stream workspace of %zu bytes failed", need); return GC_ERR_NOMEM; }
-            c->lzStreamCap = need;
+            if ((rc = mf_grow(c, (void**)&c->lzStream, &c->lzStreamCap, needStream, "LZMA stream")) != GC_OK) return rc;
+            if ((rc = mf_grow(c, (void**)&c->lzM, &c->lzMCap, needM, "LZMA items")) != GC_OK) return rc;
+            if ((rc = mf_grow(c, (void**)&c->lzRcOut, &c->lzRcOutCap, needRc, "range-coder staging")) != GC_OK) return rc;
         }
     }
     const uint32_t frameBlocks = flzma2_frame_blocks(level) < nBlocks ? flzma2_frame_blocks(level) : nBlocks;
@@ -400,17 +404,17 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     rc = launch_finder(c, src, n, frameBlocks, nullptr);
     if (rc != GC_OK) return rc;
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    GC_LAUNCH(gc_lzma2_prep_kernel, nBlocks, 256, c->stream, (const GcSeqRaw*)c->seqRaw, (const GcBlockMeta*)c->meta, c->seqPacked, c->lzNM);
+    GC_LAUNCH(gc_lzma2_prep_kernel, nBlocks, 256, c->stream, (const GcSeqRaw*)c->seqRaw, (const GcBlockMeta*)c->meta, (uint64_t)n, c->lzM, c->lzNM);
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-    GC_LAUNCH(gc_lzma2_model_kernel, nChunks, 64, c->stream, src, (uint64_t)n, (const uint64_t*)c->seqPacked, (const uint32_t*)c->lzNM, chunkLog,
+    GC_LAUNCH(gc_lzma2_model_kernel, nSegs, 64, c->stream, src, (uint64_t)n, (const uint64_t*)c->lzM, (const uint32_t*)c->lzNM, segLog,
               c->lzStream, c->lzInfo);
     HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
-    GC_LAUNCH(gc_lzma2_rc_kernel, (nChunks + 63u) / 64u, 64, c->stream, (const uint16_t*)c->lzStream, chunkLog, nChunks, c->litSec, c->lzInfo);
+    GC_LAUNCH(gc_lzma2_rc_kernel, (nRc + 63u) / 64u, 64, c->stream, (const uint16_t*)c->lzStream, segLog, nRc, c->lzRcOut, c->lzInfo);
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-    GC_LAUNCH(gc_lzma2_plan_kernel, 1, 1024, c->stream, (const GcLzmaChunkInfo*)c->lzInfo, nChunks, (uint64_t)dstCap, (uint32_t)flags, c->lzPlan, c->result);
+    GC_LAUNCH(gc_lzma2_plan_kernel, 1, 1024, c->stream, (const GcLzmaChunkInfo*)c->lzInfo, nRc, segLog, (uint64_t)dstCap, (uint32_t)flags, c->lzPlan, c->result);
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
-    GC_LAUNCH(gc_lzma2_emit_kernel, nChunks + 1u, 256, c->stream, src, chunkLog, (const uint8_t*)c->litSec, (const GcLzmaChunkInfo*)c->lzInfo,
-              (const GcLzmaPlan*)c->lzPlan, nChunks, (uint32_t)flags, (const uint64_t*)c->result, (uint8_t*)d_dst);
+    GC_LAUNCH(gc_lzma2_emit_kernel, nRc + 1u, 256, c->stream, src, segLog, (const uint8_t*)c->lzRcOut, (const GcLzmaChunkInfo*)c->lzInfo,
+              (const GcLzmaPlan*)c->lzPlan, nRc, (uint32_t)flags, (const uint64_t*)c->result, (uint8_t*)d_dst);
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     HIPCHK(c, hipGetLastError());
     c->pending = true; c->timed = true; c->lastCodec = 1;

@@ -6,8 +6,6 @@
 #define GC_LZMA_LP 0u
 #define GC_LZMA_PB 2u
 #define GC_LZMA_PROPS ((GC_LZMA_PB * 5u + GC_LZMA_LP) * 9u + GC_LZMA_LC)     // 0x5D
-#define GC_LZMA_CHUNK_LOG_MAX 16u           // LZMA2: packed chunk <= 64 KiB; raw chunk <= 64 KiB (Lzma2Dec.c:97)
-#define GC_LZMA_CHUNK_LOG_MIN 12u
 
 // probability model layout (indices into one uint16 array per chunk; the layout is private to the encoder)
 #define LZP_ISMATCH    0u                   // [12 states][4 posStates]
@@ -30,7 +28,32 @@
 #define LZP_LITERAL    (LZP_ALIGN + 16u)                // 1380: 0x300 << lc
 #define LZP_TOTAL      (LZP_LITERAL + (0x300u << GC_LZMA_LC))
 
-struct GcLzmaChunkInfo { uint32_t usize; uint32_t csize; uint32_t nWords; uint32_t pad; };   // csize 0xFFFFFFFF: store raw; usize 0: chunk does not exist
-// words of (p, bit) stream reserved per chunk: a literal is the densest symbol (9 coded bits per byte); keeps 16-byte alignment
-#define GC_LZMA_STREAM_WORDS(chunkLog) ((9u << (chunkLog)) + 64u)
+// Units of the FLZMA2 path (all sizes are powers of two and nest: rc chunk <= model segment <= 128 KiB match-finder block):
+//   model segment  2^segLog bytes (level dependent, 16..128 KiB): the adaptive model runs through it sequentially and is
+//                  reset at its start (LZMA2 control 0xC0 / 0xE0) -- the unit of parallelism of the model kernel (one wave)
+//   rc chunk       4 KiB: one LZMA2 chunk.  The LZMA2 format restarts the range coder at every chunk anyway (and only the
+//                  range coder: control 0x80 keeps probabilities, state and repeat distances), so the chunks of a segment can
+//                  be range-coded independently once the model has resolved their probabilities -- the unit of parallelism of
+//                  the range-coder kernel (one lane)
+#define GC_LZMA_RC_LOG      12u
+#define GC_LZMA_RC_SIZE     (1u << GC_LZMA_RC_LOG)
+#define GC_LZMA_RC_PER_BLOCK (GC_ZSTD_BLOCK_MAX >> GC_LZMA_RC_LOG)
+#define GC_LZMA_RC_STRIDE   (GC_LZMA_RC_SIZE + 1024u)     // bytes of range-coder output reserved per rc chunk (LZMA expands < 2 %)
+#define GC_LZMA_SEG_LOG_MIN 14u
+#define GC_LZMA_SEG_LOG_MAX 17u
+
+// L1 -> L2: the block's symbols as a position-ordered item list, M[j] = pos | len << 18 | off << 34 (pos block-relative, 0..131072).
+//   len >= 2  match piece: never crosses a 4 KiB boundary, never longer than 273 (the longest LZMA match)
+//   len == 0  cut: no match, only closes the literal run in front of it (off repeats the previous match's distance so that the
+//             repeat-distance scans can ignore it)
+// Every item is preceded by at most GC_LZMA_LIT_CUT literals, and every 4 KiB boundary (and the block end) is the end of an
+// item, so the events of an rc chunk are a contiguous range of its segment's event stream.
+#define GC_LZMA_LIT_CUT     16u
+#define GC_LZMA_MAX_ITEMS   (GC_ZSTD_BLOCK_MAX / 5u + GC_ZSTD_BLOCK_MAX / GC_LZMA_LIT_CUT + 2u * GC_LZMA_RC_PER_BLOCK + 64u)
+
+// per rc chunk: usize 0 = the chunk does not exist; words [wordStart, wordEnd) of its segment's (p, bit) stream;
+// csize = range-coder bytes, 0xFFFFFFFF = did not fit the staging area (the segment is stored)
+struct GcLzmaChunkInfo { uint32_t usize; uint32_t csize; uint32_t wordStart; uint32_t wordEnd; };
+// words of (p, bit) stream reserved per segment: a literal is the densest symbol (9 coded bits per byte); keeps 16-byte alignment
+#define GC_LZMA_STREAM_WORDS(segLog) ((9u << (segLog)) + 64u)
 struct GcLzmaPlan { uint64_t off; uint32_t size; uint32_t kind; };   // kind 0 absent, 1 LZMA, 2 raw

@@ -1,4 +1,4 @@
-// gc_lzma2_enc.hip -- FLZMA2 path: LZMA2 chunk encoder for the matches found by K1 (gc_zstd_lz.hip).
+// gc_lzma2_enc.hip -- FLZMA2 path: LZMA2 encoder for the matches found by the match finders (gc_zstd_lz.hip, gc_lz_window.hip).
 //
 // Replaces, for the 7-Zip method id 0x21 ("FLZMA2", CPP/7zip/Compress/FastLzma2Register.cpp:13-18), the slice encoder of
 // Fast-LZMA2: LZMA2_encode (C/fast-lzma2/lzma2_enc.c:1937-2099), LZMA_encodeChunkFast (:579), the length / distance /
@@ -10,19 +10,21 @@
 // 32-bit range coder with carry propagation, and the LZMA2 chunk header.  The parse, the chunk size and where the coder
 // state is reset are free choices.
 //
-// GPU structure.  Adaptive range coding is serial per coder state, so the unit of parallelism is the LZMA2 chunk: every
-// chunk resets the coder state (control 0xC0/0xE0; the dictionary is NOT reset, so matches still reach back across
-// chunks), exactly the device Fast-LZMA2 itself uses to run slices on several threads (lzma2_enc.h:22, lzma2_enc.c:2040-2075).
-//   L1 gc_lzma2_prep_kernel  one workgroup per 128 KiB match-finder block: K1's capped records -> merged matches with
-//                            their start positions (scan), M[j] = pos | len<<17 | off<<34
-//   L2 gc_lzma2_model_kernel one WAVE per chunk.  The 64 lanes turn symbols into (probability index, bit) entries in
-//                            parallel -- state machine, repeat-distance history, slot/length trees are all computed
-//                            per symbol from local information (scans), nothing serial.  The probability updates of one
-//                            symbol touch distinct entries, so they are applied by all lanes at once (LDS read-modify-write).
-//                            Output: the chunk's stream of (probability, bit) words in HBM -- the adaptive model is now
-//                            fully resolved and no longer needed.
-//   L3 gc_lzma2_rc_kernel    one LANE per chunk: what remains serial is the range recurrence (bound = (range >> 11) * p,
-//                            renormalise, carry), register-only work, so 64 chunks advance per wave instruction.
+// GPU structure (units: gc_lzma2.h).  What is serial in LZMA is (a) the adaptive probabilities, per probability, and (b) the
+// range recurrence, per range-coder run.  The LZMA2 container restarts (b) at every chunk and lets the encoder choose where
+// (a) restarts, the device Fast-LZMA2 itself uses to run slices on several threads (lzma2_enc.h:22, lzma2_enc.c:2040-2075):
+//   L1 gc_lzma2_prep_kernel  one workgroup per 128 KiB block: the finder's capped records -> position-ordered item list
+//                            (matches cut at 4 KiB boundaries and at length 273, literal runs cut every 16 bytes)
+//   L2 gc_lzma2_model_kernel one WAVE per model segment.  Per 64 items the lanes derive everything that is local -- coder
+//                            state (12-state machine), repeat distances (scans), length / slot / tree nodes, literal nodes
+//                            incl. matched literals -- and write the coded bits as events (probability index, bit) into an
+//                            LDS buffer in coding order.  The events are then applied 64 at a time: a returning ds_add on a
+//                            ticket byte per probability gives every lane its rank among the lower lanes that touch the same
+//                            probability (the LDS unit serves them in lane order), and the ranks are played in rounds, so each
+//                            event sees exactly the probability sequential coding would see.  Output: one 16-bit word per
+//                            coded bit (probability before the update + the bit) in HBM.
+//   L3 gc_lzma2_rc_kernel    one LANE per 4 KiB rc chunk: bound = (range >> 11) * p, renormalise, carry -- register-only
+//                            work; output bytes are collected eight at a time
 //   L4/L5 plan + emit        chunk headers and concatenation (gc_lzma2_frame.hip)
 #include "gc_common.h"
 #include "gc_device.h"
@@ -34,18 +36,68 @@
 
 #define LZP_T 256u
 
-// ---------------------------------------------------------------------------------------------- L1: merge + positions
+// ---------------------------------------------------------------------------------------------- L1: item list
+__device__ __forceinline__ uint32_t lzp_excl_scan(uint32_t v, uint32_t* sWave, uint32_t* total)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t incl = gc_wave_incl_sum(v);
+    if (lane == 63u) sWave[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+    for (uint32_t w = 0; w < LZP_T / 64u; w++) { const uint32_t c = sWave[w]; if (w < wave) before += c; all += c; }
+    __syncthreads();
+    *total = all;
+    return before + incl - v;
+}
+// a match [pos, pos + ml) as it is coded: a piece of one byte at either end (left over by a 4 KiB boundary) is given up
+__device__ __forceinline__ void lzp_trim(uint32_t pos, uint32_t ml, uint32_t& mStart, uint32_t& mEnd)
+{
+    mStart = pos; mEnd = pos + ml;
+    if (ml == 0u) return;
+    const uint32_t b1 = (mStart | (GC_LZMA_RC_SIZE - 1u)) + 1u;            // first boundary behind the start
+    if (b1 - mStart == 1u && mEnd > b1) mStart += 1u;
+    const uint32_t b2 = (mEnd - 1u) & ~(GC_LZMA_RC_SIZE - 1u);             // last boundary in front of the end
+    if (mEnd - b2 == 1u && mStart < b2) mEnd -= 1u;
+}
+// items of one head: cuts of the literal run [a, mStart) then the pieces of the match [mStart, mEnd); out == nullptr: count only
+__device__ __forceinline__ uint32_t lzp_items(uint32_t a, uint32_t mStart, uint32_t mEnd, uint32_t off, uint32_t prevOff, bool isTail, uint64_t* out)
+{
+    uint32_t n = 0;
+    if (a < mStart) {
+        for (uint32_t m = (a / GC_LZMA_LIT_CUT + 1u) * GC_LZMA_LIT_CUT; m < mStart; m += GC_LZMA_LIT_CUT) { if (out) out[n] = (uint64_t)m | ((uint64_t)prevOff << 34); n++; }
+        if (isTail || (mStart & (GC_LZMA_RC_SIZE - 1u)) == 0u) { if (out) out[n] = (uint64_t)mStart | ((uint64_t)prevOff << 34); n++; }
+    }
+    uint32_t s = mStart;
+    while (s < mEnd) {
+        uint32_t e = (s | (GC_LZMA_RC_SIZE - 1u)) + 1u; if (e > mEnd) e = mEnd;       // piece inside one rc chunk
+        uint32_t rem = e - s;
+        while (rem) {
+            uint32_t take = rem < 273u ? rem : 273u;
+            if (rem - take == 1u) take--;
+            if (out) out[n] = (uint64_t)s | ((uint64_t)take << 18) | ((uint64_t)off << 34);
+            n++; s += take; rem -= take;
+        }
+    }
+    return n;
+}
+
 extern "C" __global__ void __launch_bounds__(LZP_T)
-gc_lzma2_prep_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __restrict__ meta,
-                     uint64_t* __restrict__ M /* GC_MAX_SEQ_PER_BLOCK per block */, uint32_t* __restrict__ nM)
+gc_lzma2_prep_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __restrict__ meta, uint64_t srcSize,
+                     uint64_t* __restrict__ M /* GC_LZMA_MAX_ITEMS per block */, uint32_t* __restrict__ nM)
 {
     __shared__ uint32_t sWave[LZP_T / 64u];
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6, b = blockIdx.x;
+    const uint32_t t = threadIdx.x, b = blockIdx.x;
     const uint32_t nRaw = meta[b].nSeqRaw;
+    const uint64_t blockBase = (uint64_t)b * GC_ZSTD_BLOCK_MAX;
+    const uint32_t blockLen = (uint32_t)((srcSize - blockBase) < GC_ZSTD_BLOCK_MAX ? (srcSize - blockBase) : GC_ZSTD_BLOCK_MAX);
     const GcSeqRaw* R = seqRaw + (uint64_t)b * GC_MAX_SEQ_PER_BLOCK;
-    uint64_t* out = M + (uint64_t)b * GC_MAX_SEQ_PER_BLOCK;
+    uint64_t* out = M + (uint64_t)b * GC_LZMA_MAX_ITEMS;
     uint32_t nOut = 0, lenBefore = 0;        // uniform running totals
-    for (uint32_t tb = 0; tb < nRaw; tb += LZP_T) {
+#ifdef HIPEMU
+    if (getenv("GC_TRACE_LZ") && t == 0) fprintf(stderr, "prep start block %u nRaw %u len %u\n", b, nRaw, blockLen);
+#endif
+    // one virtual record behind the last one stands for the block end (closes the trailing literal run)
+    for (uint32_t tb = 0; tb <= nRaw; tb += LZP_T) {
         const uint32_t i = tb + t;
         uint32_t head = 0, off = 0, ml = 0, myLen = 0, rank = 0;
         if (i < nRaw) {
@@ -59,69 +111,55 @@ gc_lzma2_prep_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __r
                 if (c.litRank != rank || (c.offml >> 8) != off) break;
                 ml += c.offml & 0xFFu;
             }
-        }
-        // two block-wide exclusive scans: heads (output slot) and record lengths (start position = litRank + lens before)
-        uint32_t inclH = gc_wave_incl_sum(head), inclL = gc_wave_incl_sum(myLen);
-        if (lane == 63u) sWave[wave] = (inclH << 20) | inclL;             // <= 256 heads, <= 256*64 length per tile
-        __syncthreads();
-        uint32_t hBefore = 0, lBefore = 0, hAll = 0, lAll = 0;
-        for (uint32_t w = 0; w < LZP_T / 64u; w++) {
-            const uint32_t c = sWave[w];
-            if (w < wave) { hBefore += c >> 20; lBefore += c & 0xFFFFFu; }
-            hAll += c >> 20; lAll += c & 0xFFFFFu;
-        }
-        __syncthreads();
+        } else if (i == nRaw) head = 1u;
+        // start position of a record = literals before it + lengths of all records before it
+        uint32_t lTot;
+        const uint32_t lBefore = lzp_excl_scan(myLen, sWave, &lTot);
+        uint32_t pos = rank + lenBefore + lBefore;
+        if (i == nRaw) pos = blockLen;
+        // the previous head (walk back over the continuation records): where its coded match ends, and its distance
+        uint32_t a = 0, prevOff = 1u, cnt = 0, mStart = 0, mEnd = 0;
         if (head) {
-            const uint32_t pos = rank + lenBefore + lBefore + inclL - myLen;
-            out[nOut + hBefore + inclH - 1u] = (uint64_t)pos | ((uint64_t)ml << 17) | ((uint64_t)off << 34);
+            if (i) {
+                uint32_t j = i - 1u, plen = 0;
+                const GcSeqRaw last = R[j];
+                plen = last.offml & 0xFFu;
+                while (j > 0u) { const GcSeqRaw q = R[j - 1u]; if (q.litRank != last.litRank || (q.offml >> 8) != (last.offml >> 8)) break; plen += q.offml & 0xFFu; j--; }
+                const uint32_t pEnd = last.litRank + lenBefore + lBefore;     // literals in front of it + all record lengths up to it
+                uint32_t ps, pe; lzp_trim(pEnd - plen, plen, ps, pe);
+                a = pe; prevOff = last.offml >> 8;
+            }
+            lzp_trim(pos, ml, mStart, mEnd);
+            cnt = lzp_items(a, mStart, mEnd, off, prevOff, i == nRaw, nullptr);
         }
-        nOut += hAll; lenBefore += lAll;
+#ifdef HIPEMU
+        if (getenv("GC_TRACE_LZ") && head && cnt > 2000) fprintf(stderr, "  head i=%u pos=%u ml=%u a=%u mS=%u mE=%u cnt=%u\n", i, pos, ml, a, mStart, mEnd, cnt);
+#endif
+        uint32_t cTot;
+        const uint32_t at = nOut + lzp_excl_scan(cnt, sWave, &cTot);
+        if (head && at + cnt <= GC_LZMA_MAX_ITEMS) lzp_items(a, mStart, mEnd, off, prevOff, i == nRaw, out + at);
+        nOut += cTot; lenBefore += lTot;
     }
-    if (t == 0) nM[b] = nOut;
+#ifdef HIPEMU
+    if (getenv("GC_TRACE_LZ") && t == 0) fprintf(stderr, "prep block %u nRaw %u items %u\n", b, nRaw, nOut);
+#endif
+    if (t == 0) nM[b] = nOut <= GC_LZMA_MAX_ITEMS ? nOut : 0xFFFFFFFFu;
 }
 
-// ---------------------------------------------------------------------------------------------- L2: chunk encoder
+// ---------------------------------------------------------------------------------------------- L2: model
 // (p, bit) stream between L2 and L3: one 16-bit word per coded bit.
 //   adaptive bit : bit11 = bit, bits 0..10 = probability of a 0 BEFORE the update
 //   direct bit   : bit14 set, bit11 = bit   (range halving, no probability)
 #define LZW_BIT    0x0800u
 #define LZW_DIRECT 0x4000u
-struct LzStream { uint16_t* w; uint32_t pos; };                 // pos is wave-uniform
+// event in LDS: adaptive bit = index << 1 | bit (index < 2^13), direct bit = 0x8000 | bit
+#define LZE_DIRECT 0x8000u
+#define LZ2_EVCAP  4096u              // events buffered per round
+#define LZ2_EVMAX  (9u * GC_LZMA_LIT_CUT + 48u)                   // most events of one item
 
-// Apply the entries of ONE group held one per lane (lane k < cnt holds entry k, in coding order) to the probability model
-// and append the resulting words to the chunk's stream.  Probability updates: all lanes at once, in `cnt/per` rounds of
-// `per` lanes (round r = lanes [r*per, (r+1)*per)): inside one symbol all indices are distinct by construction (one node
-// per tree depth); different symbols may share indices, so symbols are applied in order (LDS operations of a wave are in
-// order).  Nothing here is serial in the number of coded bits.
-__device__ __forceinline__ void lz_emit_group(LzStream& st, uint32_t e, uint32_t cnt, uint32_t per, uint16_t* P, uint32_t lane)
-{
-    const bool valid = lane < cnt;
-    const bool isDirect = valid && (e >> 31) != 0u;
-    uint32_t p = 0;
-    for (uint32_t r0 = 0; r0 < cnt; r0 += per) {
-        if (valid && !isDirect && lane >= r0 && lane < r0 + per) {
-            const uint32_t idx = e >> 1;
-            p = P[idx];
-            P[idx] = (uint16_t)((e & 1u) ? p - (p >> 5) : p + ((2048u - p) >> 5));
-        }
-        gc_wave_sync();
-    }
-    const uint64_t dmask = __ballot(isDirect);
-    if (dmask == 0ull) {                                             // common case: one word per lane, one coalesced store
-        if (valid) st.w[st.pos + lane] = (uint16_t)(p | ((e & 1u) ? LZW_BIT : 0u));
-        st.pos += cnt;
-    } else {                                                         // a far match: its direct-bits entry expands to one word per bit
-        const uint32_t nb = isDirect ? (e >> 26) & 31u : 0u;
-        const uint32_t width = valid ? (isDirect ? nb : 1u) : 0u;
-        const uint32_t incl = gc_wave_incl_sum(width);
-        const uint32_t at = st.pos + incl - width;
-        if (valid && !isDirect) st.w[at] = (uint16_t)(p | ((e & 1u) ? LZW_BIT : 0u));
-        if (isDirect) { const uint32_t v = e & 0x03FFFFFFu; for (uint32_t i = 0; i < nb; i++) st.w[at + i] = (uint16_t)(LZW_DIRECT | (((v >> (nb - 1u - i)) & 1u) ? LZW_BIT : 0u)); }
-        st.pos += gc_readlane(incl, 63u);
-    }
-}
-
-#define ENT(idx, bit) ((((uint32_t)(idx)) << 1) | ((uint32_t)(bit) & 1u))
+struct LzEv { uint16_t* p; uint32_t n; bool store; };
+__device__ __forceinline__ void ev_put(LzEv& o, uint32_t idx, uint32_t bit) { if (o.store) o.p[o.n] = (uint16_t)((idx << 1) | (bit & 1u)); o.n++; }
+__device__ __forceinline__ void ev_direct(LzEv& o, uint32_t bit) { if (o.store) o.p[o.n] = (uint16_t)(LZE_DIRECT | (bit & 1u)); o.n++; }
 
 // state after `k` literals starting from state s (LzmaDec.c: state < 4 -> 0, < 10 -> s-3, else s-6)
 __device__ __forceinline__ uint32_t lz_lit_advance(uint32_t s, uint32_t k)
@@ -130,75 +168,72 @@ __device__ __forceinline__ uint32_t lz_lit_advance(uint32_t s, uint32_t k)
     return k >= 3u ? 0u : s;
 }
 
-// length coder entries (len >= 2).  base = LZP_LEN or LZP_REPLEN
-__device__ __forceinline__ uint32_t lz_gen_len(uint32_t* e, uint32_t base, uint32_t len, uint32_t posState)
+// length coder (len >= 2).  base = LZP_LEN or LZP_REPLEN
+__device__ __forceinline__ void lz_gen_len(LzEv& o, uint32_t base, uint32_t len, uint32_t posState)
 {
-    uint32_t n = 0, v = len - 2u;
+    uint32_t v = len - 2u;
     if (v < 8u) {
-        e[n++] = ENT(base + LZL_CHOICE, 0);
+        ev_put(o, base + LZL_CHOICE, 0);
         const uint32_t tb = base + LZL_LOW + posState * 8u; uint32_t m = 1;
-        for (int i = 2; i >= 0; i--) { const uint32_t bit = (v >> i) & 1u; e[n++] = ENT(tb + m, bit); m = (m << 1) | bit; }
+        for (int i = 2; i >= 0; i--) { const uint32_t bit = (v >> i) & 1u; ev_put(o, tb + m, bit); m = (m << 1) | bit; }
     } else if (v < 16u) {
-        e[n++] = ENT(base + LZL_CHOICE, 1); e[n++] = ENT(base + LZL_CHOICE2, 0);
+        ev_put(o, base + LZL_CHOICE, 1); ev_put(o, base + LZL_CHOICE2, 0);
         v -= 8u;
         const uint32_t tb = base + LZL_MID + posState * 8u; uint32_t m = 1;
-        for (int i = 2; i >= 0; i--) { const uint32_t bit = (v >> i) & 1u; e[n++] = ENT(tb + m, bit); m = (m << 1) | bit; }
+        for (int i = 2; i >= 0; i--) { const uint32_t bit = (v >> i) & 1u; ev_put(o, tb + m, bit); m = (m << 1) | bit; }
     } else {
-        e[n++] = ENT(base + LZL_CHOICE, 1); e[n++] = ENT(base + LZL_CHOICE2, 1);
+        ev_put(o, base + LZL_CHOICE, 1); ev_put(o, base + LZL_CHOICE2, 1);
         v -= 16u;
         const uint32_t tb = base + LZL_HIGH; uint32_t m = 1;
-        for (int i = 7; i >= 0; i--) { const uint32_t bit = (v >> i) & 1u; e[n++] = ENT(tb + m, bit); m = (m << 1) | bit; }
+        for (int i = 7; i >= 0; i--) { const uint32_t bit = (v >> i) & 1u; ev_put(o, tb + m, bit); m = (m << 1) | bit; }
     }
-    return n;
 }
 
-// one match-type symbol.  kind: 0 normal match, 1 rep0 (long), 2 rep1.  dist = distance-1.  Returns entry count (<= 24).
-__device__ __forceinline__ uint32_t lz_gen_match(uint32_t* e, uint32_t kind, uint32_t len, uint32_t dist, uint32_t state, uint32_t posState)
+// one match-type symbol.  kind: 0 normal match, 1 rep0 (long), 2 rep1.  dist = distance-1.  At most 48 events.
+__device__ __forceinline__ void lz_gen_match(LzEv& o, uint32_t kind, uint32_t len, uint32_t dist, uint32_t state, uint32_t posState)
 {
-    uint32_t n = 0;
-    e[n++] = ENT(LZP_ISMATCH + state * 4u + posState, 1);
+    ev_put(o, LZP_ISMATCH + state * 4u + posState, 1);
     if (kind == 0u) {
-        e[n++] = ENT(LZP_ISREP + state, 0);
-        n += lz_gen_len(e + n, LZP_LEN, len, posState);
+        ev_put(o, LZP_ISREP + state, 0);
+        lz_gen_len(o, LZP_LEN, len, posState);
         const uint32_t lenState = len - 2u < 3u ? len - 2u : 3u;
         uint32_t slot;
         if (dist < 4u) slot = dist;
         else { const uint32_t hb = gc_hibit32(dist); slot = 2u * hb + ((dist >> (hb - 1u)) & 1u); }
         { const uint32_t tb = LZP_POSSLOT + lenState * 64u; uint32_t m = 1;
-          for (int i = 5; i >= 0; i--) { const uint32_t bit = (slot >> i) & 1u; e[n++] = ENT(tb + m, bit); m = (m << 1) | bit; } }
+          for (int i = 5; i >= 0; i--) { const uint32_t bit = (slot >> i) & 1u; ev_put(o, tb + m, bit); m = (m << 1) | bit; } }
         if (slot >= 4u) {
             const uint32_t footer = (slot >> 1) - 1u, base = (2u | (slot & 1u)) << footer, red = dist - base;
             if (slot < 14u) {
                 const uint32_t tb = LZP_SPECPOS + (slot - 4u) * 32u; uint32_t m = 1;
-                for (uint32_t i = 0; i < footer; i++) { const uint32_t bit = (red >> i) & 1u; e[n++] = ENT(tb + m, bit); m = (m << 1) | bit; }
+                for (uint32_t i = 0; i < footer; i++) { const uint32_t bit = (red >> i) & 1u; ev_put(o, tb + m, bit); m = (m << 1) | bit; }
             } else {
-                e[n++] = 0x80000000u | ((footer - 4u) << 26) | (red >> 4);
+                for (uint32_t i = footer - 4u; i-- > 0u; ) ev_direct(o, (red >> (4u + i)) & 1u);          // high bits first
                 uint32_t m = 1;
-                for (uint32_t i = 0; i < 4u; i++) { const uint32_t bit = (red >> i) & 1u; e[n++] = ENT(LZP_ALIGN + m, bit); m = (m << 1) | bit; }
+                for (uint32_t i = 0; i < 4u; i++) { const uint32_t bit = (red >> i) & 1u; ev_put(o, LZP_ALIGN + m, bit); m = (m << 1) | bit; }
             }
         }
     } else {
-        e[n++] = ENT(LZP_ISREP + state, 1);
-        if (kind == 1u) { e[n++] = ENT(LZP_ISREPG0 + state, 0); e[n++] = ENT(LZP_ISREP0LONG + state * 4u + posState, 1); }
-        else { e[n++] = ENT(LZP_ISREPG0 + state, 1); e[n++] = ENT(LZP_ISREPG1 + state, 0); }
-        n += lz_gen_len(e + n, LZP_REPLEN, len, posState);
+        ev_put(o, LZP_ISREP + state, 1);
+        if (kind == 1u) { ev_put(o, LZP_ISREPG0 + state, 0); ev_put(o, LZP_ISREP0LONG + state * 4u + posState, 1); }
+        else { ev_put(o, LZP_ISREPG0 + state, 1); ev_put(o, LZP_ISREPG1 + state, 0); }
+        lz_gen_len(o, LZP_REPLEN, len, posState);
     }
-    return n;
 }
 
 // one literal: isMatch=0 + 8 tree bits (plain, or "matched" after a match: LzmaDec.c MATCHED_LITER_DEC)
-__device__ __forceinline__ void lz_gen_literal(uint32_t* e, uint32_t cur, uint32_t prev, uint32_t matchByte, uint32_t state, uint32_t posState)
+__device__ __forceinline__ void lz_gen_literal(LzEv& o, uint32_t cur, uint32_t prev, uint32_t matchByte, uint32_t state, uint32_t posState)
 {
-    e[0] = ENT(LZP_ISMATCH + state * 4u + posState, 0);
+    ev_put(o, LZP_ISMATCH + state * 4u + posState, 0);
     const uint32_t pb = LZP_LITERAL + 0x300u * (prev >> (8u - GC_LZMA_LC));
     if (state < 7u) {
         uint32_t m = 1;
-        for (int i = 7; i >= 0; i--) { const uint32_t bit = (cur >> i) & 1u; e[8 - i] = ENT(pb + m, bit); m = (m << 1) | bit; }
+        for (int i = 7; i >= 0; i--) { const uint32_t bit = (cur >> i) & 1u; ev_put(o, pb + m, bit); m = (m << 1) | bit; }
     } else {
         uint32_t offs = 0x100u, sym = cur | 0x100u, mb = matchByte;
         for (int i = 0; i < 8; i++) {
             mb <<= 1;
-            e[1 + i] = ENT(pb + offs + (mb & offs) + (sym >> 8), (sym >> 7) & 1u);
+            ev_put(o, pb + offs + (mb & offs) + (sym >> 8), (sym >> 7) & 1u);
             sym <<= 1;
             offs &= ~(mb ^ sym);
         }
@@ -206,214 +241,375 @@ __device__ __forceinline__ void lz_gen_literal(uint32_t* e, uint32_t cur, uint32
 }
 
 struct LzItem { uint32_t pos, len, off; };
-// item k of the chunk = M[first + k] clipped to [cs, ce)
-__device__ __forceinline__ LzItem lz_item(const uint64_t* M, uint32_t idx, uint32_t cs, uint32_t ce)
+__device__ __forceinline__ LzItem lz_item(const uint64_t* M, uint32_t idx)
 {
     const uint64_t m = M[idx];
-    uint32_t pos = (uint32_t)(m & 0x1FFFFu), len = (uint32_t)((m >> 17) & 0x1FFFFu), off = (uint32_t)(m >> 34);
-    uint32_t end = pos + len;
-    if (pos < cs) pos = cs;
-    if (end > ce) end = ce;
-    LzItem it; it.pos = pos; it.len = end - pos; it.off = off;
+    LzItem it; it.pos = (uint32_t)(m & 0x3FFFFu); it.len = (uint32_t)((m >> 18) & 0xFFFFu); it.off = (uint32_t)(m >> 34);
     return it;
+}
+// events of one item: its literals [lp, pos) then its match.  st0 = coder state at the first literal, rep0 = current repeat
+// distance (matched literal), S = block base (S[-1] exists iff blockBase > 0).  The literal bytes (<= GC_LZMA_LIT_CUT of them,
+// plus the byte in front) are fetched with three 8-byte loads up front instead of one dependent byte load per literal.
+__device__ __forceinline__ void lz_gen_item(LzEv& o, const uint8_t* S, uint64_t blockBase, uint64_t srcSize, uint32_t lp, const LzItem& it, uint32_t st0,
+                                            uint32_t rep0, uint32_t kind)
+{
+    uint32_t st = st0;
+    const uint32_t ll = it.pos - lp;
+    if (ll) {
+        const uint64_t absLp = blockBase + lp;
+        uint64_t x0 = 0, x1 = 0, x2 = 0;                            // bytes absLp - 1 .. absLp + 22
+        const bool fast = absLp >= 1u && absLp + 23u <= srcSize;
+        if (fast) { x0 = gc_ld64(S + lp - 1); x1 = gc_ld64(S + lp + 7); x2 = gc_ld64(S + lp + 15); }
+        const uint32_t mb0 = st >= 7u ? S[(int64_t)lp - (int64_t)rep0] : 0u;      // only a literal right behind a match is "matched"
+        uint32_t prev = fast ? (uint32_t)(x0 & 0xFFu) : (absLp ? S[(int64_t)lp - 1] : 0u);
+        for (uint32_t i = 0; i < ll; i++) {
+            uint32_t cur;
+            if (fast) { const uint32_t j = i + 1u; const uint64_t x = j < 8u ? x0 : (j < 16u ? x1 : x2); cur = (uint32_t)(x >> ((j & 7u) * 8u)) & 0xFFu; }
+            else cur = S[lp + i];
+            lz_gen_literal(o, cur, prev, i == 0u ? mb0 : 0u, st, (lp + i) & 3u);
+            st = st < 4u ? 0u : (st < 10u ? st - 3u : st - 6u);
+            prev = cur;
+        }
+    }
+    if (it.len) lz_gen_match(o, kind, it.len, it.off - 1u, st, it.pos & 3u);
 }
 
 extern "C" __global__ void __launch_bounds__(64)
 gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const uint64_t* __restrict__ Mall,
-                      const uint32_t* __restrict__ nM, uint32_t chunkLog, uint16_t* __restrict__ stream,
+                      const uint32_t* __restrict__ nM, uint32_t segLog, uint16_t* __restrict__ stream,
                       GcLzmaChunkInfo* __restrict__ cinfo)
 {
     __shared__ uint16_t P[LZP_TOTAL];
-    __shared__ uint32_t sPiece[24]; __shared__ uint32_t sPieceN;
-    __shared__ uint32_t sMat[64u * 24u];
-    __shared__ uint32_t sMatN[64];
+    __shared__ uint32_t sTick[(LZP_TOTAL + 3u) / 4u];             // one ticket byte per probability
+    __shared__ uint16_t sEv[LZ2_EVCAP];
+    __shared__ uint32_t sWordEnd[GC_LZMA_RC_PER_BLOCK];
 
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t chunk = blockIdx.x;
-    const uint32_t chunkSize = 1u << chunkLog, perBlock = GC_ZSTD_BLOCK_MAX >> chunkLog;
-    const uint32_t b = chunk / perBlock, cInB = chunk % perBlock;
+    const uint32_t seg = blockIdx.x;
+    const uint32_t segSize = 1u << segLog, perBlock = GC_ZSTD_BLOCK_MAX >> segLog, rcPerSeg = segSize >> GC_LZMA_RC_LOG;
+    const uint32_t b = seg / perBlock, sInB = seg % perBlock;
     const uint64_t blockBase = (uint64_t)b * GC_ZSTD_BLOCK_MAX;
     const uint32_t blockLen = (uint32_t)((srcSize - blockBase) < GC_ZSTD_BLOCK_MAX ? (srcSize - blockBase) : GC_ZSTD_BLOCK_MAX);
-    const uint32_t cs = cInB * chunkSize;
-    if (cs >= blockLen) { if (lane == 0) { cinfo[chunk].usize = 0; cinfo[chunk].csize = 0; cinfo[chunk].nWords = 0; } return; }
-    const uint32_t ce = cs + chunkSize < blockLen ? cs + chunkSize : blockLen;
+    const uint32_t ss = sInB << segLog;
+    GcLzmaChunkInfo* CI = cinfo + (uint64_t)b * GC_LZMA_RC_PER_BLOCK + (ss >> GC_LZMA_RC_LOG);
+    const uint32_t nItems = nM[b];
+    if (ss >= blockLen || nItems == 0xFFFFFFFFu) {
+        // no such segment -- or the item list overflowed (cannot happen for lists built by L1; kept as a guard): store it
+        for (uint32_t c = lane; c < rcPerSeg; c += 64u) {
+            const uint32_t cs = ss + (c << GC_LZMA_RC_LOG);
+            GcLzmaChunkInfo ci; ci.usize = cs < blockLen ? ((blockLen - cs) < GC_LZMA_RC_SIZE ? (blockLen - cs) : GC_LZMA_RC_SIZE) : 0u;
+            ci.csize = 0xFFFFFFFFu; ci.wordStart = 0; ci.wordEnd = 0; CI[c] = ci;
+        }
+        return;
+    }
+    const uint32_t se = ss + segSize < blockLen ? ss + segSize : blockLen;
     const uint8_t* S = src + blockBase;                   // block-relative addressing; S[-1] exists iff blockBase > 0
-    const uint64_t* M = Mall + (uint64_t)b * GC_MAX_SEQ_PER_BLOCK;
-    const uint32_t n = nM[b];
+    const uint64_t* M = Mall + (uint64_t)b * GC_LZMA_MAX_ITEMS;
 
     for (uint32_t i = lane; i < LZP_TOTAL; i += 64u) P[i] = 1024u;
+    for (uint32_t i = lane; i < (LZP_TOTAL + 3u) / 4u; i += 64u) sTick[i] = 0;
+    if (lane < GC_LZMA_RC_PER_BLOCK) sWordEnd[lane] = 0;
 
-    // items of this chunk: [first, last) in M (sorted by position), clipped to the chunk
+    // items of this segment = items that END in (ss, se]  (a cut at position ss closes the previous segment)
     uint32_t first, last;
-    { uint32_t lo = 0, hi = n;                            // first item that ends after cs
-      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; const uint64_t m = M[mid]; if ((uint32_t)(m & 0x1FFFFu) + (uint32_t)((m >> 17) & 0x1FFFFu) > cs) hi = mid; else lo = mid + 1u; }
-      first = lo;
-      lo = first; hi = n;                                 // first item that starts at or after ce
-      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)(M[mid] & 0x1FFFFu) >= ce) hi = mid; else lo = mid + 1u; }
+    { uint32_t lo = 0, hi = nItems;
+      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; const LzItem x = lz_item(M, mid); if (x.pos + x.len > ss) hi = mid; else lo = mid + 1u; }
+      first = lo; hi = nItems;
+      while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; const LzItem x = lz_item(M, mid); if (x.pos + x.len > se) hi = mid; else lo = mid + 1u; }
       last = lo; }
-    // a clipped piece shorter than 2 bytes cannot be a match: it can only be the first or the last item
-    if (first < last && lz_item(M, first, cs, ce).len < 2u) first++;
-    if (first < last && lz_item(M, last - 1u, cs, ce).len < 2u) last--;
-    first = gc_uniform(first); last = gc_uniform(last);     // keep the walk below on the scalar unit
-
-    LzStream strm; strm.w = stream + (uint64_t)chunk * GC_LZMA_STREAM_WORDS(chunkLog); strm.pos = 0;
+    first = gc_uniform(first); last = gc_uniform(last);
+    uint16_t* W = stream + (uint64_t)seg * GC_LZMA_STREAM_WORDS(segLog);
     gc_wave_sync();
 
-    uint32_t cursor = cs;             // next position to encode (uniform)
-    uint32_t exitState = 0;           // coder state after the previous item (uniform); 0 at chunk start
-    uint32_t prevOff = 1u;            // distance of the previous item (rep0), 1 after a state reset
-    uint32_t carryRun = 0;            // (index + 1 - first) of the start of the run of equal offsets containing the previous item; 0 = virtual
+    // carried across tiles of 64 items (all wave-uniform)
+    uint32_t cursor = ss;             // end of the previous item
+    uint32_t cOff = 1u;               // effective distance of the previous item (1 until the segment's first match)
+    uint32_t cRun = 0;                // (k + 1) of the start of the run of equal distances containing the previous item; 0 = virtual
+    uint32_t cMatch = 0;              // (k + 1) of the last match item; 0 = none yet
+    uint32_t cExit = 0;               // coder state after the last match item (0: state at segment start)
+    uint32_t cLits = 0;               // literals coded since the last match item (in cut items)
+    uint32_t wpos = 0;                // words written so far
 
-    for (uint32_t base = first; base <= last; base += 64u) {
-        const uint32_t cnt = last - base < 64u ? last - base : 64u;        // may be 0 on the final pass (tail literals only)
-        // ---- per-item parallel part
-        LzItem it; it.pos = ce; it.len = 0; it.off = 0;
-        if (lane < cnt) it = lz_item(M, base + lane, cs, ce);
-        // end of the previous item (cursor for lane 0)
+    for (uint32_t base = first; base < last; base += 64u) {
+        const uint32_t cnt = last - base < 64u ? last - base : 64u;
+#ifdef HIPEMU
+        if (getenv("GC_TRACE_LZ") && lane == 0) fprintf(stderr, "seg %u items [%u,%u) tile base %u cnt %u wpos %u\n", seg, first, last, base, cnt, wpos);
+#endif
+        const uint32_t k = base - first + lane;                              // segment-relative item index
+        LzItem it; it.pos = se; it.len = 0; it.off = 0;
+        if (lane < cnt) it = lz_item(M, base + lane);
+        const bool isM = lane < cnt && it.len != 0u;
         uint32_t prevEnd = __shfl_up(it.pos + it.len, 1); if (lane == 0) prevEnd = cursor;
-        uint32_t pOff = __shfl_up(it.off, 1); if (lane == 0) pOff = prevOff;
-        const uint32_t ll = it.pos - prevEnd;
+        const uint32_t ll = lane < cnt ? it.pos - prevEnd : 0u;
+        // last match item at or before / before this one
+        uint32_t mIncl = gc_wave_incl_max(isM ? k + 1u : 0u); if (mIncl < cMatch) mIncl = cMatch;
+        uint32_t mPrev = __shfl_up(mIncl, 1); if (lane == 0) mPrev = cMatch;
+        // effective distance: a cut repeats the distance of the last match; before the segment's first match it is 1
+        const bool mPrevInTile = mPrev != 0u && mPrev - 1u >= base - first;
+        const uint32_t offAtMPrev = __shfl(it.off, (int)(mPrevInTile ? mPrev - 1u - (base - first) : 0u));
+        const uint32_t offE = isM ? it.off : (mPrev ? (mPrevInTile ? offAtMPrev : cOff) : 1u);
+        uint32_t pOff = __shfl_up(offE, 1); if (lane == 0) pOff = cOff;
         // repeat-distance history as scans: rep0 = previous distance, rep1 = distance before the current run of equal ones
-        const uint32_t k = base - first + lane;                             // chunk-relative item index
-        const uint32_t v = (lane < cnt && it.off != pOff) ? k + 1u : 0u;
-        uint32_t runIncl = gc_wave_incl_max(v); if (runIncl < carryRun) runIncl = carryRun;   // run start (+1) of the run containing item k
-        uint32_t runPrev = __shfl_up(runIncl, 1); if (lane == 0) runPrev = carryRun;          // ... containing item k-1
+        const uint32_t v = (lane < cnt && offE != pOff) ? k + 1u : 0u;
+        uint32_t runIncl = gc_wave_incl_max(v); if (runIncl < cRun) runIncl = cRun;
+        uint32_t runPrev = __shfl_up(runIncl, 1); if (lane == 0) runPrev = cRun;
         uint32_t rep1 = 1u;
-        if (lane < cnt && runPrev >= 2u) rep1 = (uint32_t)(M[first + runPrev - 2u] >> 34);
-        uint32_t kind = 0;
-        if (lane < cnt) kind = it.off == pOff ? 1u : (it.off == rep1 ? 2u : 0u);
-        // coder state: the state after an item depends only on its kind and on whether a literal preceded it
-        const bool split = it.len > 273u;
-        const bool litBefore = ll > 0u || (k == 0u && cursor == cs && base == first);
-        const uint32_t stAfterFirst = kind == 0u ? (litBefore ? 7u : 10u) : (litBefore ? 8u : 11u);
-        const uint32_t myExit = split ? 11u : stAfterFirst;                  // a split match ends with a rep0 continuation piece
-        uint32_t sPrev = __shfl_up(myExit, 1); if (lane == 0) sPrev = exitState;
-        const uint32_t sBefore = lz_lit_advance(sPrev, ll);
-        uint32_t firstLen = it.len;
-        if (split) { firstLen = 273u; if ((it.len - 273u) % 273u == 1u) firstLen = 272u; }
-        uint32_t nEnt = 0;
-        if (lane < cnt) nEnt = lz_gen_match(&sMat[lane * 24u], kind, firstLen, it.off - 1u, sBefore, it.pos & 3u);
-        sMatN[lane] = nEnt;
-        gc_wave_sync();
-
-        // ---- serial walk over the items of this batch (uniform loop), literal runs produced 64 at a time
-        const uint32_t steps = cnt + ((base + cnt >= last) ? 1u : 0u);      // the final pass also flushes the tail literals
-        for (uint32_t j = 0; j < steps; j++) {
-            const bool isTail = j >= cnt;
-            const uint32_t jj = isTail ? 0u : j;
-            const uint32_t ipos = isTail ? ce : gc_readlane(it.pos, jj);
-            const uint32_t ilen = isTail ? 0u : gc_readlane(it.len, jj);
-            const uint32_t ioff = isTail ? 0u : gc_readlane(it.off, jj);
-            const uint32_t iflen = isTail ? 0u : gc_readlane(firstLen, jj);
-            const uint32_t iexit = isTail ? 0u : gc_readlane(myExit, jj);
-            const uint32_t sAfterPrev = exitState;
-            // literals [cursor, ipos): 7 literals x 9 entries per group, lane = (literal, tree depth), entries in closed form
-            for (uint32_t lp = cursor; lp < ipos; lp += 7u) {
-                const uint32_t cntL = ipos - lp < 7u ? ipos - lp : 7u;
-                const uint32_t li = lane / 9u, d = lane - li * 9u;          // literal in group, entry 0 = isMatch, 1..8 = tree depth
-                uint32_t e = 0;
-                if (li < cntL) {
-                    const uint32_t p = lp + li, i = p - cursor;
-                    const uint32_t st = lz_lit_advance(sAfterPrev, i);
-                    const uint32_t cur = S[p];
-                    if (d == 0u) e = ENT(LZP_ISMATCH + st * 4u + (p & 3u), 0);
-                    else {
-                        const uint32_t prev = (blockBase + p) ? S[(int64_t)p - 1] : 0u;
-                        const uint32_t pb = LZP_LITERAL + 0x300u * (prev >> (8u - GC_LZMA_LC));
-                        const uint32_t m = (0x100u | cur) >> (9u - d), bit = (cur >> (8u - d)) & 1u;
-                        uint32_t idx = pb + m;
-                        if (st >= 7u) {                                      // matched literal (LzmaDec.c MATCHED_LITER_DEC)
-                            const uint32_t mb = S[(int64_t)p - (int64_t)prevOff];
-                            // still "matching" at depth d iff the d-1 bits above agree; then the node is selected by the match bit too
-                            const bool on = ((cur ^ mb) >> (9u - d)) == 0u;
-                            if (on) idx += 0x100u + (((mb >> (8u - d)) & 1u) << 8);
-                        }
-                        e = ENT(idx, bit);
-                    }
-                }
-                lz_emit_group(strm, e, cntL * 9u, 9u, P, lane);
+        if (isM && runPrev >= 2u) {                                          // item in front of the run that contains item k-1
+            const uint32_t j = runPrev - 2u;                                 // segment-relative; its effective distance:
+            const LzItem x = lz_item(M, first + j);
+            if (x.len) rep1 = x.off;
+            else {                                                           // a cut: distance of the last match before it, if any
+                uint32_t jj = j; rep1 = 1u;
+                while (jj > 0u) { const LzItem y = lz_item(M, first + jj - 1u); if (y.len) { rep1 = y.off; break; } jj--; }
             }
-            if (isTail) { cursor = ce; break; }
-            // the match itself (first piece pre-generated by its lane), then continuation pieces of very long matches
-            { const uint32_t ne = gc_uniform(sMatN[jj]); lz_emit_group(strm, lane < ne ? sMat[jj * 24u + lane] : 0u, ne, 24u, P, lane); }
-            if (ilen > iflen) {
-                // state after the first piece (match 7/10, rep 8/11); every further piece is a rep0 coded from a state >= 7
-                uint32_t done = iflen, st = gc_readlane(stAfterFirst, jj);
-                while (done < ilen) {
-                    uint32_t piece = ilen - done < 273u ? ilen - done : 273u;
-                    if (ilen - done - piece == 1u) piece--;
-                    if (lane == 0) sPieceN = lz_gen_match(sPiece, 1u, piece, ioff - 1u, st, (ipos + done) & 3u);
-                    gc_wave_sync();
-                    { const uint32_t ne = gc_uniform(sPieceN); lz_emit_group(strm, lane < ne ? sPiece[lane] : 0u, ne, 24u, P, lane); }
-                    gc_wave_sync();
-                    st = 11u; done += piece;
-                }
-            }
-            cursor = ipos + ilen; exitState = iexit; prevOff = ioff;
         }
-        { const uint32_t r = gc_readlane(runIncl, 63u); if (cnt) carryRun = r; }
+        uint32_t kind = 0;
+        if (isM) kind = it.off == pOff ? 1u : (it.off == rep1 ? 2u : 0u);
+        // coder state: literals of cut items since the last match, state after that match
+        const uint32_t cl = (lane < cnt && !isM) ? ll : 0u;
+        const uint32_t aIncl = gc_wave_incl_sum(cl), aExcl = aIncl - cl;
+        const bool mInTile = mPrevInTile;
+        const uint32_t mLane = mInTile ? mPrev - 1u - (base - first) : 0u;
+        const uint32_t aAtM = __shfl(aExcl, (int)mLane);
+        const uint32_t L = mInTile ? aExcl - aAtM : cLits + aExcl;           // literals between the last match and this item
+        const bool litBefore = (L + ll) != 0u || mPrev == 0u;                // <=> coder state before the match is a literal state
+        const uint32_t stAfter = kind == 0u ? (litBefore ? 7u : 10u) : (litBefore ? 8u : 11u);
+        const uint32_t exAtM = __shfl(stAfter, (int)mLane);
+        const uint32_t exM = mInTile ? exAtM : cExit;                        // state after the last match before this item
+        const uint32_t st0 = lz_lit_advance(exM, L);                         // state at this item's first literal
+        // event counts -> offsets
+        uint32_t nEv = 0;
+        if (lane < cnt) {                                                    // 9 per literal + the match's own count (state-independent)
+            LzEv o; o.p = nullptr; o.n = 9u * ll; o.store = false;
+            if (it.len) lz_gen_match(o, kind, it.len, it.off - 1u, 0u, 0u);
+            nEv = o.n;
+        }
+        const uint32_t evIncl = gc_wave_incl_sum(nEv);
+        // rc chunk ends: the item that ends on a 4 KiB boundary (or at the segment end) closes its chunk
+        if (lane < cnt) {
+            const uint32_t end = it.pos + it.len;
+            if ((end & (GC_LZMA_RC_SIZE - 1u)) == 0u || end == se) sWordEnd[(end - 1u - ss) >> GC_LZMA_RC_LOG] = wpos + evIncl;
+        }
+        // ---- rounds: as many items as fit the event buffer, generated by their lanes, applied 64 events at a time
+        uint32_t done = 0;                                                   // items of this tile already coded
+        uint32_t evDone = 0;                                                 // their events
+        while (done < cnt) {
+#ifdef HIPEMU
+            if (getenv("GC_TRACE_LZ") && lane >= done && lane < cnt && nEv > LZ2_EVMAX) { fprintf(stderr, "  BAD item k=%u pos=%u len=%u off=%u prevEnd=%u ll=%u nEv=%u\n", base + lane, it.pos, it.len, it.off, prevEnd, ll, nEv); abort(); }
+#endif
+            const uint64_t fit = __ballot(lane >= done && lane < cnt && evIncl - evDone <= LZ2_EVCAP);
+            const uint32_t upto = done + (uint32_t)__popcll(fit);            // items [done, upto) fit (prefix property of evIncl)
+            const uint32_t evEnd = gc_readlane(evIncl, upto - 1u);
+#ifdef HIPEMU
+            if (getenv("GC_TRACE_LZ") && lane == 0) fprintf(stderr, "  round done %u upto %u evDone %u evEnd %u\n", done, upto, evDone, evEnd);
+#endif
+            if (lane >= done && lane < upto) {
+                LzEv o; o.p = sEv + (evIncl - nEv - evDone); o.n = 0; o.store = true;
+                lz_gen_item(o, S, blockBase, srcSize, prevEnd, it, st0, pOff, kind);
+            }
+            gc_wave_sync();
+            const uint32_t total = evEnd - evDone;
+            for (uint32_t e0 = 0; e0 < total; e0 += 64u) {
+                const bool valid = e0 + lane < total;
+                const uint32_t ev = valid ? sEv[e0 + lane] : 0u;
+                const bool adaptive = valid && (ev & LZE_DIRECT) == 0u;
+                const uint32_t idx = (ev >> 1) & 0x1FFFu, bit = ev & 1u;
+                const uint32_t sh = (idx & 3u) * 8u;
+                uint32_t rank = 0;
+                if (adaptive) rank = (atomicAdd(&sTick[idx >> 2], 1u << sh) >> sh) & 0xFFu;   // lower lanes with the same probability
+                uint32_t p = 0;
+                for (uint32_t r = 0; __any(adaptive && rank >= r); r++) {
+                    if (adaptive && rank == r) {
+                        p = P[idx];
+                        P[idx] = (uint16_t)(bit ? p - (p >> 5) : p + ((2048u - p) >> 5));
+                    }
+                    gc_wave_sync();
+                }
+                if (adaptive && rank == 0u) sTick[idx >> 2] = 0;             // (lanes that share the word all write 0)
+                if (valid) W[wpos + e0 + lane] = (uint16_t)(adaptive ? (p | (bit ? LZW_BIT : 0u)) : (LZW_DIRECT | (bit ? LZW_BIT : 0u)));
+                gc_wave_sync();
+            }
+            wpos += total; evDone = evEnd; done = upto;
+        }
+        // ---- carries
+        const uint32_t lastLane = cnt - 1u;
+        cursor = gc_readlane(it.pos + it.len, lastLane);
+        cOff = gc_readlane(offE, lastLane);
+        cRun = gc_readlane(runIncl, lastLane);
+        const uint32_t mLast = gc_readlane(mIncl, lastLane);
+        if (mLast != 0u && mLast - 1u >= base - first) {                     // the tile contains a match: restart the literal count
+            const uint32_t ml_ = mLast - 1u - (base - first);
+            cExit = gc_readlane(stAfter, ml_);
+            cLits = gc_readlane(aIncl, lastLane) - gc_readlane(aIncl, ml_);
+        } else cLits += gc_readlane(aIncl, lastLane);
+        cMatch = mLast;
         gc_wave_sync();
     }
-
-    if (lane == 0) { GcLzmaChunkInfo ci; ci.usize = ce - cs; ci.csize = 0; ci.nWords = strm.pos; cinfo[chunk] = ci; }
+    gc_wave_sync();
+    for (uint32_t c = lane; c < rcPerSeg; c += 64u) {
+        const uint32_t cs = ss + (c << GC_LZMA_RC_LOG);
+        GcLzmaChunkInfo ci; ci.usize = cs < se ? ((se - cs) < GC_LZMA_RC_SIZE ? (se - cs) : GC_LZMA_RC_SIZE) : 0u;
+        ci.csize = 0; ci.wordStart = c ? sWordEnd[c - 1u] : 0u; ci.wordEnd = sWordEnd[c]; CI[c] = ci;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- L3: range coder
-// One chunk per LANE.  With the probabilities already resolved, what is left of LZMA's serial dependency is the range
-// recurrence itself -- bound = (range >> 11) * p; range = bit ? range - bound : bound; renormalise -- about two dozen
-// register-only instructions per coded bit (C/fast-lzma2/range_enc.h:62-152, RC_shiftLow range_enc.c:123-140), so 64
-// chunks advance per wave instruction and the latency of one chunk's chain is shared 64 ways.
-struct LzRc { uint64_t low; uint32_t range; uint32_t cache; uint32_t cacheSize; uint32_t outPos; uint32_t outCap; uint8_t* out; };
+// One rc chunk per LANE.  With the probabilities already resolved, what is left of LZMA's serial dependency is the range
+// recurrence itself -- bound = (range >> 11) * p; range = bit ? range - bound : bound; renormalise -- register-only work
+// (C/fast-lzma2/range_enc.h:62-152, RC_shiftLow range_enc.c:123-140).  All chunks of an input are coded at the same time, so
+// the kernel takes as long as ONE chunk's chain of ~4.5 coded bits per byte: what matters is the number of dependent cycles per
+// coded bit.  The step is therefore written without branches: every state update is a select, the output byte (if any) is
+// OR-ed into a 16-byte register window at a computed position, and only once per eight coded bits the wave looks whether a
+// lane has a complete group of eight bytes to put away, or has hit the one rare case that needs a loop (a carry rippling
+// through pending 0xFF bytes).
+struct LzRc {
+    uint32_t low, carry;              // low 32 bits of `low` + its 33rd bit
+    uint32_t range, cache, pend;      // pend = cacheSize - 1: 0xFF bytes waiting behind `cache` for a possible carry
+    uint32_t outPos;                  // bytes produced so far
+    uint32_t putQ, flushedQ;          // groups of eight bytes handed to the LDS ring / written to memory
+    uint64_t w0, w1;                  // bytes [8 * putQ, outPos): at most 15
+    uint64_t* out; uint64_t* ring;
+    bool act;                         // false while the lane only runs along (its state is thrown away): no memory side effects
+};
+#define RC_RING 8u                    // groups per lane in the LDS ring
 
-__device__ __forceinline__ void rc_shift_low(LzRc& rc)
+__device__ __forceinline__ void rc_append(LzRc& rc, uint32_t v, bool on)          // byte v at position outPos, if `on`
 {
-    if ((uint32_t)rc.low < 0xFF000000u || (rc.low >> 32) != 0) {
-        const uint32_t carry = (uint32_t)(rc.low >> 32);
-        uint32_t c = rc.cache;
-        do {
-            if (rc.outPos < rc.outCap) rc.out[rc.outPos] = (uint8_t)(c + carry);
-            rc.outPos++;
-            c = 0xFFu;
-        } while (--rc.cacheSize != 0);
-        rc.cache = ((uint32_t)rc.low >> 24) & 0xFFu;
-    }
-    rc.cacheSize++;
-    rc.low = (rc.low & 0x00FFFFFFull) << 8;
+    const uint32_t pos = rc.outPos - 8u * rc.putQ;                 // 0 .. 15
+    const uint64_t x = on ? (uint64_t)(v & 0xFFu) << ((pos & 7u) * 8u) : 0ull;
+    rc.w0 |= pos < 8u ? x : 0ull;
+    rc.w1 |= pos < 8u ? 0ull : x;
+    rc.outPos += on ? 1u : 0u;
 }
-
+// groups [flushedQ, putQ) of this lane: ring -> memory
+__device__ __forceinline__ void rc_flush(LzRc& rc)
+{
+    if (rc.act) for (uint32_t q = rc.flushedQ; q < rc.putQ; q++) if (q < GC_LZMA_RC_STRIDE / 8u) rc.out[q] = rc.ring[(q % RC_RING) * 64u];
+    rc.flushedQ = rc.putQ;
+}
+// hand a complete group of eight bytes (if there is one) to the ring; call with every lane of the wave
+__device__ __forceinline__ void rc_put_away(LzRc& rc)
+{
+    const bool full = rc.outPos - 8u * rc.putQ >= 8u;
+    if (__any(full && rc.putQ - rc.flushedQ >= RC_RING)) rc_flush(rc);             // a ring is full: everybody writes
+    if (full) { if (rc.act) rc.ring[(rc.putQ % RC_RING) * 64u] = rc.w0; rc.w0 = rc.w1; rc.w1 = 0; rc.putQ++; }
+}
+// one coded bit, branch-free except for the wave-level look at the rare case
 __device__ __forceinline__ void rc_word(LzRc& rc, uint32_t w)
 {
-    const bool bit = (w & LZW_BIT) != 0u;
-    if (w & LZW_DIRECT) { rc.range >>= 1; if (bit) rc.low += rc.range; }
-    else {
-        const uint32_t bound = (rc.range >> 11) * (w & 0x7FFu);
-        if (bit) { rc.low += bound; rc.range -= bound; } else rc.range = bound;
+    const bool bit = (w & LZW_BIT) != 0u, direct = (w & LZW_DIRECT) != 0u;
+    const uint32_t bound = direct ? rc.range >> 1 : (rc.range >> 11) * (w & 0x7FFu);
+    const uint32_t add = bit ? bound : 0u;
+    const uint32_t sum = rc.low + add;
+    const uint32_t carry = rc.carry | (sum < add ? 1u : 0u);
+    const uint32_t range = (bit && !direct) ? rc.range - bound : bound;
+    const bool need = range < (1u << 24);                          // RC_shiftLow; one step always suffices (p >= 31)
+    const bool emit = need && (sum < 0xFF000000u || carry != 0u);
+    // emit: the delayed byte `cache` (+ carry), then the pending 0xFF bytes (+ carry: they turn into 0x00), then the top byte
+    // of low becomes the delayed byte.  !emit && need: the top byte is 0xFF and no carry is known yet -> one more pending byte
+    uint32_t extra = emit ? rc.pend : 0u;                          // almost always 0
+    rc_append(rc, rc.cache + carry, emit);
+    if (__any(extra != 0u)) {                                      // rare: a lane has pending bytes to emit
+        while (__any(extra != 0u)) { rc_put_away(rc); rc_append(rc, 0xFFu + carry, extra != 0u); extra -= extra ? 1u : 0u; }
     }
-    if (rc.range < (1u << 24)) { rc.range <<= 8; rc_shift_low(rc); }
+    rc.cache = emit ? sum >> 24 : rc.cache;
+    rc.pend = need ? (emit ? 0u : rc.pend + 1u) : rc.pend;
+    rc.low = need ? sum << 8 : sum;
+    rc.carry = need ? 0u : carry;
+    rc.range = need ? range << 8 : range;
 }
 
 extern "C" __global__ void __launch_bounds__(64)
-gc_lzma2_rc_kernel(const uint16_t* __restrict__ stream, uint32_t chunkLog, uint32_t nChunks, uint8_t* __restrict__ chunkOut,
+gc_lzma2_rc_kernel(const uint16_t* __restrict__ stream, uint32_t segLog, uint32_t nRc, uint8_t* __restrict__ rcOut,
                    GcLzmaChunkInfo* __restrict__ cinfo)
 {
-    const uint32_t chunk = blockIdx.x * 64u + threadIdx.x;
-    if (chunk >= nChunks) return;
-    const GcLzmaChunkInfo ci = cinfo[chunk];
-    if (ci.usize == 0u) return;
-    const uint16_t* W = stream + (uint64_t)chunk * GC_LZMA_STREAM_WORDS(chunkLog);     // 16-byte aligned
-    LzRc rc; rc.low = 0; rc.range = 0xFFFFFFFFu; rc.cache = 0; rc.cacheSize = 1; rc.outPos = 0;
-    rc.outCap = ci.usize;                                  // a chunk that does not shrink is stored raw anyway
-    rc.out = chunkOut + ((uint64_t)chunk << chunkLog);
-    const uint32_t n = ci.nWords, nVec = n >> 3;
-    const GcU4* V = (const GcU4*)W;
-    GcU4 nxt; nxt.x = nxt.y = nxt.z = nxt.w = 0; if (nVec) nxt = V[0];
-    for (uint32_t i = 0; i < nVec; i++) {                  // 8 words per 16-byte load, next load in flight while these are coded
-        const GcU4 cur = nxt;
-        if (i + 1u < nVec) nxt = V[i + 1u];
-        rc_word(rc, cur.x & 0xFFFFu); rc_word(rc, cur.x >> 16); rc_word(rc, cur.y & 0xFFFFu); rc_word(rc, cur.y >> 16);
-        rc_word(rc, cur.z & 0xFFFFu); rc_word(rc, cur.z >> 16); rc_word(rc, cur.w & 0xFFFFu); rc_word(rc, cur.w >> 16);
+    __shared__ uint64_t sRing[RC_RING * 64u];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t c = blockIdx.x * 64u + lane;
+    GcLzmaChunkInfo ci; ci.usize = 0; ci.csize = 0; ci.wordStart = 0; ci.wordEnd = 0;
+    if (c < nRc) ci = cinfo[c];
+    const bool live = ci.usize != 0u && ci.csize != 0xFFFFFFFFu;           // idle lanes run along without words
+    const uint32_t seg = c >> (segLog - GC_LZMA_RC_LOG);
+    const uint16_t* W = stream + (uint64_t)(live ? seg : 0u) * GC_LZMA_STREAM_WORDS(segLog);
+    LzRc rc; rc.low = 0; rc.carry = 0; rc.range = 0xFFFFFFFFu; rc.cache = 0; rc.pend = 0; rc.outPos = 0; rc.putQ = 0; rc.flushedQ = 0; rc.w0 = 0; rc.w1 = 0; rc.act = live;
+    rc.out = (uint64_t*)(rcOut + (uint64_t)(live ? c : 0u) * GC_LZMA_RC_STRIDE);
+    rc.ring = sRing + lane;
+    // words up to the next 16-byte boundary of the stream one by one (every lane of the wave takes part in each step, lanes
+    // without a word just do not advance), then eight at a time from one 16-byte load, then the rest one by one
+    uint32_t k = live ? ci.wordStart : 0u;
+    const uint32_t end = live ? ci.wordEnd : 0u;
+    while (__any(k < end && (k & 7u) != 0u)) {
+        const bool on = k < end && (k & 7u) != 0u;
+        const LzRc save = rc;
+        rc.act = on;
+        rc_word(rc, on ? W[k] : 0u);
+        if (!on) rc = save;
+        k += on ? 1u : 0u;
+        rc.act = live;
+        rc_put_away(rc);
     }
-    for (uint32_t k = nVec << 3; k < n; k++) rc_word(rc, W[k]);
-    for (int i = 0; i < 5; i++) rc_shift_low(rc);          // RC_flush
-    cinfo[chunk].csize = rc.outPos < rc.outCap ? rc.outPos : 0xFFFFFFFFu;      // 0xFFFFFFFF: store raw
+    const uint32_t nVec = k + 8u <= end ? (end - k) >> 3 : 0u;
+    const GcU4* V = (const GcU4*)(W + k);
+    GcU4 nxt; nxt.x = nxt.y = nxt.z = nxt.w = 0;
+    if (nVec) nxt = V[0];
+    for (uint32_t i = 0; __any(i < nVec); i++) {
+        if (__all(i < nVec)) {                              // every lane has a whole vector: nothing to mask
+            const GcU4 cur = nxt;
+            if (i + 1u < nVec) nxt = V[i + 1u];             // next load in flight while these are coded
+            rc_word(rc, cur.x & 0xFFFFu); rc_word(rc, cur.x >> 16); rc_word(rc, cur.y & 0xFFFFu); rc_word(rc, cur.y >> 16);
+            rc_word(rc, cur.z & 0xFFFFu); rc_word(rc, cur.z >> 16); rc_word(rc, cur.w & 0xFFFFu); rc_word(rc, cur.w >> 16);
+        } else {                                            // some lanes have run out of vectors: they run along
+            const bool on = i < nVec;
+            const GcU4 cur = nxt;
+            if (i + 1u < nVec) nxt = V[i + 1u];
+            const LzRc save = rc;
+            rc.act = on;
+            rc_word(rc, cur.x & 0xFFFFu); rc_word(rc, cur.x >> 16); rc_word(rc, cur.y & 0xFFFFu); rc_word(rc, cur.y >> 16);
+            rc_word(rc, cur.z & 0xFFFFu); rc_word(rc, cur.z >> 16); rc_word(rc, cur.w & 0xFFFFu); rc_word(rc, cur.w >> 16);
+            if (!on) rc = save;
+            rc.act = live;
+        }
+        rc_put_away(rc);
+    }
+    k += nVec << 3;
+    while (__any(k < end)) {
+        const bool on = k < end;
+        const LzRc save = rc;
+        rc.act = on;
+        rc_word(rc, on ? W[k] : 0u);
+        if (!on) rc = save;
+        k += on ? 1u : 0u;
+        rc.act = live;
+        rc_put_away(rc);
+    }
+    rc.act = live;
+    if (live) {
+        for (int i = 0; i < 5; i++) {                                       // RC_flush: five shift steps
+            const uint32_t carry = rc.carry;
+            const bool emit = rc.low < 0xFF000000u || carry != 0u;
+            if (emit) {
+                uint8_t tmp = (uint8_t)(rc.cache + carry);
+                // (plain per-lane code: the tail is not performance relevant)
+                { const uint32_t pos = rc.outPos - 8u * rc.putQ; if (pos < 8u) rc.w0 |= (uint64_t)tmp << (pos * 8u); else rc.w1 |= (uint64_t)tmp << ((pos - 8u) * 8u); rc.outPos++; }
+                for (uint32_t e = rc.pend; e != 0u; e--) {
+                    if (rc.outPos - 8u * rc.putQ >= 8u) { if (rc.putQ - rc.flushedQ >= RC_RING) rc_flush(rc); rc.ring[(rc.putQ % RC_RING) * 64u] = rc.w0; rc.w0 = rc.w1; rc.w1 = 0; rc.putQ++; }
+                    const uint32_t pos = rc.outPos - 8u * rc.putQ; const uint64_t x = (uint64_t)((0xFFu + carry) & 0xFFu);
+                    if (pos < 8u) rc.w0 |= x << (pos * 8u); else rc.w1 |= x << ((pos - 8u) * 8u);
+                    rc.outPos++;
+                }
+                rc.cache = rc.low >> 24; rc.pend = 0;
+            } else rc.pend++;
+            rc.low <<= 8; rc.carry = 0;
+            if (rc.outPos - 8u * rc.putQ >= 8u) { if (rc.putQ - rc.flushedQ >= RC_RING) rc_flush(rc); rc.ring[(rc.putQ % RC_RING) * 64u] = rc.w0; rc.w0 = rc.w1; rc.w1 = 0; rc.putQ++; }
+        }
+    }
+    rc_flush(rc);
+    if (live) {
+        const uint32_t n = rc.outPos;
+        if (n <= GC_LZMA_RC_STRIDE) {
+            uint8_t* o = (uint8_t*)rc.out;
+            for (uint32_t i = 8u * rc.putQ; i < n; i++) { const uint32_t pos = i - 8u * rc.putQ; o[i] = (uint8_t)((pos < 8u ? rc.w0 >> (pos * 8u) : rc.w1 >> ((pos - 8u) * 8u)) & 0xFFu); }
+            cinfo[c].csize = n;
+        } else cinfo[c].csize = 0xFFFFFFFFu;                 // did not fit the staging area: the segment is stored
+    }
 }

@@ -1,29 +1,51 @@
-// gc_lzma2_frame.hip -- L3/L4 of the FLZMA2 path: LZMA2 chunk headers and stream assembly.
+// gc_lzma2_frame.hip -- L4/L5 of the FLZMA2 path: LZMA2 chunk headers and stream assembly.
 //
 // Chunk layout (C/fast-lzma2/lzma2_enc.c:94-102,2040-2075; decoder C/Lzma2Dec.c:97-220):
 //   0x00                                   end of stream
 //   0x01 / 0x02, u16be (size-1), bytes     stored chunk (0x01 also resets the dictionary)
-//   0x80 | reset<<5 | (usize-1)>>16, u16be (usize-1), u16be (csize-1), [props]   LZMA chunk; reset 2 = state + props,
-//                                          3 = state + props + dictionary.  Every chunk here resets the state (that is
-//                                          what makes chunks independent work items) and repeats the props byte.
+//   0x80 | reset<<5 | (usize-1)>>16, u16be (usize-1), u16be (csize-1), [props]   LZMA chunk; reset 0 = nothing (the chunk
+//                                          continues the model of the previous one, only the range coder restarts), 2 = state +
+//                                          props, 3 = state + props + dictionary.
+// Every 4 KiB rc chunk becomes one LZMA2 chunk.  The first chunk of a model segment resets the coder state (0xC0; 0xE0 for the
+// first chunk of the stream) and carries the props byte, the others continue (0x80).  A segment whose LZMA chunks would not be
+// smaller than the data is stored whole (one stored chunk per rc chunk); the segment behind it starts with a state reset like
+// every segment, which is also what the decoder demands after a dictionary-resetting stored chunk.
 #include "gc_common.h"
 #include "gc_device.h"
 #include "gc_lzma2.h"
 
-// L3: one workgroup; exclusive scan of chunk sizes.  flags bit0: no end marker (more shards follow)
+// bytes of the chunks of the segment that contains rc chunk c, as LZMA chunks; 0xFFFFFFFF if one of them overflowed its staging
+__device__ __forceinline__ bool lzma2_seg_is_lzma(const GcLzmaChunkInfo* __restrict__ cinfo, uint32_t c, uint32_t rcPerSeg)
+{
+    const uint32_t s0 = c & ~(rcPerSeg - 1u);
+    uint32_t lz = 0, raw = 0;
+    for (uint32_t k = 0; k < rcPerSeg; k++) {
+        const GcLzmaChunkInfo ci = cinfo[s0 + k];
+        if (ci.usize == 0u) continue;
+        if (ci.csize == 0xFFFFFFFFu || ci.csize == 0u) return false;
+        lz += (k == 0u ? 6u : 5u) + ci.csize; raw += 3u + ci.usize;
+    }
+    return lz < raw;
+}
+
+// L4: one workgroup; exclusive scan of chunk sizes.  flags bit0: no end marker (more shards follow)
 extern "C" __global__ void __launch_bounds__(1024)
-gc_lzma2_plan_kernel(const GcLzmaChunkInfo* __restrict__ cinfo, uint32_t nChunks, uint64_t dstCap, uint32_t flags,
+gc_lzma2_plan_kernel(const GcLzmaChunkInfo* __restrict__ cinfo, uint32_t nRc, uint32_t segLog, uint64_t dstCap, uint32_t flags,
                      GcLzmaPlan* __restrict__ plan, uint64_t* __restrict__ result /* [0]=total bytes, [1]=error */)
 {
     __shared__ uint32_t sWave[16];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t rcPerSeg = 1u << (segLog - GC_LZMA_RC_LOG);
     uint64_t carry = 0;
-    for (uint32_t tb = 0; tb < nChunks; tb += 1024u) {
+    for (uint32_t tb = 0; tb < nRc; tb += 1024u) {
         const uint32_t c = tb + t;
         uint32_t size = 0, kind = 0;
-        if (c < nChunks) {
+        if (c < nRc) {
             const GcLzmaChunkInfo ci = cinfo[c];
-            if (ci.usize) { kind = ci.csize == 0xFFFFFFFFu ? 2u : 1u; size = kind == 1u ? 6u + ci.csize : 3u + ci.usize; }
+            if (ci.usize) {
+                kind = lzma2_seg_is_lzma(cinfo, c, rcPerSeg) ? 1u : 2u;
+                size = kind == 1u ? ((c & (rcPerSeg - 1u)) == 0u ? 6u : 5u) + ci.csize : 3u + ci.usize;
+            }
         }
         uint32_t incl = gc_wave_incl_sum(size);
         if (lane == 63u) sWave[wave] = incl;
@@ -31,7 +53,7 @@ gc_lzma2_plan_kernel(const GcLzmaChunkInfo* __restrict__ cinfo, uint32_t nChunks
         uint32_t before = 0, all = 0;
         for (uint32_t w = 0; w < 16u; w++) { uint32_t v = sWave[w]; if (w < wave) before += v; all += v; }
         __syncthreads();
-        if (c < nChunks) { GcLzmaPlan p; p.off = carry + before + incl - size; p.size = size; p.kind = kind; plan[c] = p; }
+        if (c < nRc) { GcLzmaPlan p; p.off = carry + before + incl - size; p.size = size; p.kind = kind; plan[c] = p; }
         carry += all;
     }
     if (t == 0) {
@@ -40,31 +62,35 @@ gc_lzma2_plan_kernel(const GcLzmaChunkInfo* __restrict__ cinfo, uint32_t nChunks
     }
 }
 
-// L4: one workgroup per chunk (+ one extra workgroup for the end marker)
+// L5: one workgroup per rc chunk (+ one extra workgroup for the end marker)
 extern "C" __global__ void __launch_bounds__(256)
-gc_lzma2_emit_kernel(const uint8_t* __restrict__ src, uint32_t chunkLog, const uint8_t* __restrict__ chunkOut,
-                     const GcLzmaChunkInfo* __restrict__ cinfo, const GcLzmaPlan* __restrict__ plan, uint32_t nChunks,
+gc_lzma2_emit_kernel(const uint8_t* __restrict__ src, uint32_t segLog, const uint8_t* __restrict__ rcOut,
+                     const GcLzmaChunkInfo* __restrict__ cinfo, const GcLzmaPlan* __restrict__ plan, uint32_t nRc,
                      uint32_t flags, const uint64_t* __restrict__ result, uint8_t* __restrict__ dst)
 {
     if (result[1]) return;
     const uint32_t t = threadIdx.x, c = blockIdx.x;
-    if (c == nChunks) { if (t == 0 && !(flags & 1u)) dst[result[0] - 1u] = 0x00; return; }
+    if (c == nRc) { if (t == 0 && !(flags & 1u)) dst[result[0] - 1u] = 0x00; return; }
     const GcLzmaPlan p = plan[c];
     if (p.kind == 0u) return;
     const GcLzmaChunkInfo ci = cinfo[c];
     uint8_t* o = dst + p.off;
     const uint32_t u1 = ci.usize - 1u;
+    const uint32_t rcPerSeg = 1u << (segLog - GC_LZMA_RC_LOG);
     if (p.kind == 1u) {
+        const bool segFirst = (c & (rcPerSeg - 1u)) == 0u;
+        const uint32_t hdr = segFirst ? 6u : 5u;
         if (t == 0) {
             const uint32_t c1 = ci.csize - 1u;
-            o[0] = (uint8_t)(0x80u | ((c == 0u ? 3u : 2u) << 5) | (u1 >> 16));
-            o[1] = (uint8_t)(u1 >> 8); o[2] = (uint8_t)u1; o[3] = (uint8_t)(c1 >> 8); o[4] = (uint8_t)c1; o[5] = (uint8_t)GC_LZMA_PROPS;
+            o[0] = (uint8_t)(0x80u | ((segFirst ? (c == 0u ? 3u : 2u) : 0u) << 5) | (u1 >> 16));
+            o[1] = (uint8_t)(u1 >> 8); o[2] = (uint8_t)u1; o[3] = (uint8_t)(c1 >> 8); o[4] = (uint8_t)c1;
+            if (segFirst) o[5] = (uint8_t)GC_LZMA_PROPS;
         }
-        const uint8_t* s = chunkOut + ((uint64_t)c << chunkLog);
-        for (uint32_t i = t; i < ci.csize; i += 256u) o[6u + i] = s[i];
+        const uint8_t* s = rcOut + (uint64_t)c * GC_LZMA_RC_STRIDE;
+        for (uint32_t i = t; i < ci.csize; i += 256u) o[hdr + i] = s[i];
     } else {
         if (t == 0) { o[0] = c == 0u ? 0x01 : 0x02; o[1] = (uint8_t)(u1 >> 8); o[2] = (uint8_t)u1; }
-        const uint8_t* s = src + ((uint64_t)c << chunkLog);
+        const uint8_t* s = src + ((uint64_t)c << GC_LZMA_RC_LOG);
         for (uint32_t i = t; i < ci.usize; i += 256u) o[3u + i] = s[i];
     }
 }
