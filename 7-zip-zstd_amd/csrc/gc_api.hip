@@ -22,6 +22,11 @@
 
 struct GcFramePlan { uint64_t off; uint32_t size; uint32_t compressed; };
 
+// FLZMA2 can process its input in up to GC_MAX_PARTS frame-aligned parts whose stages (match finder, model, range coder) run on
+// different HIP streams, stage k of part p overlapping stage k-1 of part p+1.  Off by default: see gc_flzma2_compress_device.
+#define GC_MAX_PARTS   8u
+#define GC_PART_EVENTS 8u    // 0 finder start, 1 finder end (= prep start), 2 prep end, 3 model start, 4 model end, 5 rc start, 6 rc end
+
 extern "C" __global__ void gc_zstd_lz_kernel(const uint8_t*, uint64_t, GcSeqRaw*, uint8_t*, GcBlockMeta*, unsigned long long*);
 extern "C" __global__ void gc_zstd_huf_kernel(const uint8_t*, const GcBlockMeta*, uint8_t*, GcSectionInfo*);
 extern "C" __global__ void gc_zstd_seq_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t*, uint32_t*, uint8_t*, uint16_t*,
@@ -38,7 +43,7 @@ extern "C" __global__ void gc_mf_verify_kernel(const uint8_t*, uint64_t, uint32_
 extern "C" __global__ void gc_mf_parse_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, const uint32_t*, GcSeqRaw*, uint8_t*, GcBlockMeta*);
 
 extern "C" __global__ void gc_lzma2_prep_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t, uint64_t*, uint32_t*);
-extern "C" __global__ void gc_lzma2_model_kernel(const uint8_t*, uint64_t, const uint64_t*, const uint32_t*, uint32_t, uint16_t*, GcLzmaChunkInfo*);
+extern "C" __global__ void gc_lzma2_model_kernel(const uint8_t*, uint64_t, const uint64_t*, const uint32_t*, uint32_t, uint32_t, uint16_t*, GcLzmaChunkInfo*);
 extern "C" __global__ void gc_lzma2_rc_kernel(const uint16_t*, uint32_t, uint32_t, uint8_t*, GcLzmaChunkInfo*);
 extern "C" __global__ void gc_lzma2_plan_kernel(const GcLzmaChunkInfo*, uint32_t, uint32_t, uint64_t, uint32_t, GcLzmaPlan*, uint64_t*);
 extern "C" __global__ void gc_lzma2_emit_kernel(const uint8_t*, uint32_t, const uint8_t*, const GcLzmaChunkInfo*, const GcLzmaPlan*, uint32_t,
@@ -53,7 +58,12 @@ extern "C" __global__ void gc_brotli_emit_kernel(const uint8_t*, uint64_t, const
 struct gc_ctx {
     int device;
     hipStream_t stream;       // main stream: K1 -> K2 -> (join) -> K4 -> K5
-    hipStream_t stream2;      // K3 runs here, concurrently with K2 (both only depend on K1)
+    hipStream_t stream2;      // K3 runs here, concurrently with K2 (both only depend on K1); FLZMA2: model stage
+    hipStream_t stream3;      // FLZMA2: range-coder stage
+    hipEvent_t evPart[GC_MAX_PARTS][GC_PART_EVENTS];   // per input part: stage boundaries (see gc_flzma2_compress_device)
+    uint32_t nParts;
+    uint32_t dbgFrameBlocks, dbgPartFrames;   // test hooks (env GC_FRAME_BLOCKS / GC_PART_FRAMES): small frames / parts so that
+                                              // the multi-frame and multi-part paths can be exercised on small inputs
     hipEvent_t ev[8];         // 0 lz start, 1 lz end, 2 huf end, 3 seq start, 4 seq end, 5 plan start, 6 plan end, 7 emit end
     char err[256];
     // workspace, grown on demand
@@ -66,8 +76,8 @@ struct gc_ctx {
     uint8_t* brStage; GcBrotliBlockInfo* brInfo; GcBrotliPlan* brPlan;    // BROTLI path
     // windowed match finder (gc_mf.h): counts/offsets, partition starts, entry lists; grown on demand
     uint32_t* mfCnt; size_t mfCntCap; GcMfEntry* mfEnt; size_t mfEntCap; GcMfEntry* mfEnt2; size_t mfEnt2Cap; uint32_t* mfRec; size_t mfRecCap;
-    hipEvent_t evMf[7];       // W1 start, W1 end, W2 end, W3 end, W4 end, W5 end, W6 end
-    bool mfTimed;
+    hipEvent_t evMf[GC_MAX_PARTS][7];       // per part: W1 start, W1 end, W2 end, W3 end, W4 end, W5 end, W6 end
+    bool mfTimed; uint32_t mfParts;
     int lastCodec;            // 0 zstd, 1 flzma2: which kernels the events of the last call bracket
     uint64_t* hostResult;     // pinned
     // staging for the host-buffer entry point
@@ -108,11 +118,16 @@ extern "C" int gc_ctx_create(gc_ctx** out, int device)
     if (!c) return GC_ERR_NOMEM;
     memset(c, 0, sizeof(*c));
     c->device = device;
-    if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess) { delete c; return GC_ERR_HIP; }
+    if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess || hipStreamCreate(&c->stream3) != hipSuccess) { delete c; return GC_ERR_HIP; }
     for (int i = 0; i < 8; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return GC_ERR_HIP; }
-    for (int i = 0; i < 7; i++) if (hipEventCreate(&c->evMf[i]) != hipSuccess) { delete c; return GC_ERR_HIP; }
+    for (uint32_t p = 0; p < GC_MAX_PARTS; p++) {
+        for (int i = 0; i < 7; i++) if (hipEventCreate(&c->evMf[p][i]) != hipSuccess) { delete c; return GC_ERR_HIP; }
+        for (uint32_t i = 0; i < GC_PART_EVENTS; i++) if (hipEventCreate(&c->evPart[p][i]) != hipSuccess) { delete c; return GC_ERR_HIP; }
+    }
     if (hipMalloc((void**)&c->prof, (GC_LZ_PHASES + GC_SEQ_PHASES) * sizeof(unsigned long long)) != hipSuccess) { delete c; return GC_ERR_NOMEM; }
     if (hipMalloc((void**)&c->result, 16) != hipSuccess || hipHostMalloc((void**)&c->hostResult, 16) != hipSuccess) { delete c; return GC_ERR_NOMEM; }
+    { const char* e = getenv("GC_FRAME_BLOCKS"); c->dbgFrameBlocks = e ? (uint32_t)atoi(e) : 0u; }
+    { const char* e = getenv("GC_PART_FRAMES"); c->dbgPartFrames = e ? (uint32_t)atoi(e) : 0u; }
     *out = c;
     return GC_OK;
 }
@@ -137,7 +152,11 @@ extern "C" void gc_ctx_destroy(gc_ctx* c)
     hipFree(c->prof); hipFree(c->result); hipHostFree(c->hostResult); hipFree(c->dIn); hipFree(c->dOut);
     hipFree(c->mfCnt); hipFree(c->mfEnt); hipFree(c->mfEnt2); hipFree(c->mfRec);
     for (int i = 0; i < 8; i++) hipEventDestroy(c->ev[i]);
-    for (int i = 0; i < 7; i++) hipEventDestroy(c->evMf[i]);
+    for (uint32_t p = 0; p < GC_MAX_PARTS; p++) {
+        for (int i = 0; i < 7; i++) hipEventDestroy(c->evMf[p][i]);
+        for (uint32_t i = 0; i < GC_PART_EVENTS; i++) hipEventDestroy(c->evPart[p][i]);
+    }
+    hipStreamDestroy(c->stream3);
     hipStreamDestroy(c->stream2);
     hipStreamDestroy(c->stream);
     delete c;
@@ -190,17 +209,13 @@ static int mf_grow(gc_ctx* c, void** p, size_t* cap, size_t needBytes, const cha
     return GC_OK;
 }
 
-static int launch_finder(gc_ctx* c, const uint8_t* src, size_t n, uint32_t frameBlocks, unsigned long long* prof)
+// workspace of the windowed finder for n input bytes
+static int ensure_finder_workspace(gc_ctx* c, size_t n, uint32_t frameBlocks)
 {
-    const uint32_t nBlocks = gc_num_blocks(n);
-    c->mfTimed = false;
-    if (frameBlocks <= 1u) {
-        GC_LAUNCH(gc_zstd_lz_kernel, nBlocks, 1024, c->stream, src, (uint64_t)n, c->seqRaw, c->lit, c->meta, prof);
-        return GC_OK;
-    }
+    if (frameBlocks <= 1u) return GC_OK;
     const GcMfGeom g = gc_mf_geom(n, frameBlocks);
     const size_t needCnt = g.cntWords * sizeof(uint32_t), needEnt = (size_t)g.nFrames * g.frameBytes * sizeof(GcMfEntry);
-    const size_t needRec = (size_t)nBlocks * GC_ZSTD_BLOCK_MAX * sizeof(uint32_t);
+    const size_t needRec = (size_t)g.nBlocks * GC_ZSTD_BLOCK_MAX * sizeof(uint32_t);
     if (needCnt > c->mfCntCap || needEnt > c->mfEntCap || needEnt > c->mfEnt2Cap || needRec > c->mfRecCap) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         int rc;
@@ -209,31 +224,67 @@ static int launch_finder(gc_ctx* c, const uint8_t* src, size_t n, uint32_t frame
         if ((rc = mf_grow(c, (void**)&c->mfEnt2, &c->mfEnt2Cap, needEnt, "linked entries")) != GC_OK) return rc;
         if ((rc = mf_grow(c, (void**)&c->mfRec, &c->mfRecCap, needRec, "records")) != GC_OK) return rc;
     }
-    const uint32_t perT = gc_xcd_per(g.nTiles), perB = gc_xcd_per(nBlocks);
-    HIPCHK(c, hipEventRecord(c->evMf[0], c->stream));
-    GC_LAUNCH(gc_mf_count_kernel, perT * GC_XCDS, 256, c->stream, src, (uint64_t)n, frameBlocks, g.nTiles, perT, c->mfCnt);
-    HIPCHK(c, hipEventRecord(c->evMf[1], c->stream));
-    GC_LAUNCH(gc_mf_scan_kernel, g.nFrames, 1024, c->stream, c->mfCnt, g.tilesPerFrame);
-    HIPCHK(c, hipEventRecord(c->evMf[2], c->stream));
-    GC_LAUNCH(gc_mf_scatter_kernel, perT * GC_XCDS, 256, c->stream, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)c->mfCnt, c->mfEnt);
-    HIPCHK(c, hipEventRecord(c->evMf[3], c->stream));
-    GC_LAUNCH(gc_mf_link_kernel, g.nFrames * GC_MF_PARTS * GC_MF_LINK_SEGS, 64, c->stream, (const uint32_t*)c->mfCnt, (const GcMfEntry*)c->mfEnt, c->mfEnt2, g.tilesPerFrame, g.frameBytes);
-    HIPCHK(c, hipEventRecord(c->evMf[4], c->stream));
-    GC_LAUNCH(gc_mf_verify_kernel, perT * GC_XCDS, GC_MF_VERIFY_T, c->stream, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)c->mfCnt,
-              (const GcMfEntry*)c->mfEnt2, c->mfRec);
-    HIPCHK(c, hipEventRecord(c->evMf[5], c->stream));
-    GC_LAUNCH(gc_mf_parse_kernel, perB * GC_XCDS, GC_MF_PARSE_T, c->stream, src, (uint64_t)n, nBlocks, perB, (const uint32_t*)c->mfRec, c->seqRaw, c->lit, c->meta);
-    HIPCHK(c, hipEventRecord(c->evMf[6], c->stream));
-    (void)prof;
-    c->mfTimed = true;
     return GC_OK;
 }
 
-// ms[0..5] = count, scan, scatter, link, verify, parse of the windowed match finder in the last call (after *_finish)
+// Match finder for one part of the input: `src` / `n` are the part, blk0 its first block (a multiple of frameBlocks: parts are
+// whole frames, so everything inside is relative to the part and only the workspace pointers are offset).
+static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const uint8_t* src, size_t n, uint32_t frameBlocks, uint32_t blk0, unsigned long long* prof)
+{
+    const uint32_t nBlocks = gc_num_blocks(n);
+    GcSeqRaw* seqRaw = c->seqRaw + (size_t)blk0 * GC_MAX_SEQ_PER_BLOCK;
+    uint8_t* lit = c->lit + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
+    GcBlockMeta* meta = c->meta + blk0;
+    if (frameBlocks <= 1u) {
+        GC_LAUNCH(gc_zstd_lz_kernel, nBlocks, 1024, st, src, (uint64_t)n, seqRaw, lit, meta, prof);
+        return GC_OK;
+    }
+    const GcMfGeom g = gc_mf_geom(n, frameBlocks);
+    const uint32_t frame0 = blk0 / frameBlocks;
+    uint32_t* cnt = c->mfCnt + (size_t)frame0 * (g.tilesPerFrame + 1u) * GC_MF_PARTS;
+    GcMfEntry* ent = c->mfEnt + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
+    GcMfEntry* ent2 = c->mfEnt2 + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
+    uint32_t* rec = c->mfRec + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
+    const uint32_t perT = gc_xcd_per(g.nTiles), perB = gc_xcd_per(nBlocks);
+    hipEvent_t* ev = c->evMf[part];
+    HIPCHK(c, hipEventRecord(ev[0], st));
+    GC_LAUNCH(gc_mf_count_kernel, perT * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, cnt);
+    HIPCHK(c, hipEventRecord(ev[1], st));
+    GC_LAUNCH(gc_mf_scan_kernel, g.nFrames, 1024, st, cnt, g.tilesPerFrame);
+    HIPCHK(c, hipEventRecord(ev[2], st));
+    GC_LAUNCH(gc_mf_scatter_kernel, perT * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt, ent);
+    HIPCHK(c, hipEventRecord(ev[3], st));
+    GC_LAUNCH(gc_mf_link_kernel, g.nFrames * GC_MF_PARTS * GC_MF_LINK_SEGS, 64, st, (const uint32_t*)cnt, (const GcMfEntry*)ent, ent2, g.tilesPerFrame, g.frameBytes);
+    HIPCHK(c, hipEventRecord(ev[4], st));
+    GC_LAUNCH(gc_mf_verify_kernel, perT * GC_XCDS, GC_MF_VERIFY_T, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt,
+              (const GcMfEntry*)ent2, rec);
+    HIPCHK(c, hipEventRecord(ev[5], st));
+    GC_LAUNCH(gc_mf_parse_kernel, perB * GC_XCDS, GC_MF_PARSE_T, st, src, (uint64_t)n, nBlocks, perB, (const uint32_t*)rec, seqRaw, lit, meta);
+    HIPCHK(c, hipEventRecord(ev[6], st));
+    (void)prof;
+    return GC_OK;
+}
+
+// whole input as one part on the main stream
+static int launch_finder(gc_ctx* c, const uint8_t* src, size_t n, uint32_t frameBlocks, unsigned long long* prof)
+{
+    c->mfTimed = false;
+    int rc = ensure_finder_workspace(c, n, frameBlocks);
+    if (rc != GC_OK) return rc;
+    rc = launch_finder_part(c, c->stream, 0, src, n, frameBlocks, 0, prof);
+    if (rc != GC_OK) return rc;
+    c->mfTimed = frameBlocks > 1u; c->mfParts = 1;
+    return GC_OK;
+}
+
+// ms[0..5] = count, scan, scatter, link, verify, parse of the windowed match finder in the last call (after *_finish), summed
+// over the parts of the input
 extern "C" int gc_mf_last_timing(gc_ctx* c, float ms[6])
 {
     if (!c || !c->timed || c->pending || !c->mfTimed) return GC_ERR_PARAM;
-    for (int i = 0; i < 6; i++) HIPCHK(c, hipEventElapsedTime(&ms[i], c->evMf[i], c->evMf[i + 1]));
+    for (int i = 0; i < 6; i++) ms[i] = 0.f;
+    for (uint32_t p = 0; p < c->mfParts; p++)
+        for (int i = 0; i < 6; i++) { float t = 0.f; HIPCHK(c, hipEventElapsedTime(&t, c->evMf[p][i], c->evMf[p][i + 1])); ms[i] += t; }
     return GC_OK;
 }
 
@@ -399,17 +450,56 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
             if ((rc = mf_grow(c, (void**)&c->lzRcOut, &c->lzRcOutCap, needRc, "range-coder staging")) != GC_OK) return rc;
         }
     }
-    const uint32_t frameBlocks = flzma2_frame_blocks(level) < nBlocks ? flzma2_frame_blocks(level) : nBlocks;
-    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    rc = launch_finder(c, src, n, frameBlocks, nullptr);
+    uint32_t frameBlocks = flzma2_frame_blocks(level);
+    if (frameBlocks > 1u && c->dbgFrameBlocks) frameBlocks = c->dbgFrameBlocks;
+    if (frameBlocks > nBlocks) frameBlocks = nBlocks;
+    rc = ensure_finder_workspace(c, n, frameBlocks);
     if (rc != GC_OK) return rc;
-    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    GC_LAUNCH(gc_lzma2_prep_kernel, nBlocks, 256, c->stream, (const GcSeqRaw*)c->seqRaw, (const GcBlockMeta*)c->meta, (uint64_t)n, c->lzM, c->lzNM);
-    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
-    GC_LAUNCH(gc_lzma2_model_kernel, nSegs, 64, c->stream, src, (uint64_t)n, (const uint64_t*)c->lzM, (const uint32_t*)c->lzNM, segLog,
-              c->lzStream, c->lzInfo);
-    HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
-    GC_LAUNCH(gc_lzma2_rc_kernel, (nRc + 63u) / 64u, 64, c->stream, (const uint16_t*)c->lzStream, segLog, nRc, c->lzRcOut, c->lzInfo);
+    // parts: ONE by default.  Overlapping the stages of several parts was measured and lost (212 MB: 33.9 ms with 4 parts against
+    // 24.3 ms with one, profiles/r01_run8_flzma2_kernel_stats.md): model and range coder are chains whose duration is set by the
+    // length of one segment / chunk, not by how many there are, so every part pays the full chain again, and the model kernel's
+    // LDS footprint keeps the finder of the next part waiting.  GC_PART_FRAMES (test hook) still selects parts of that many frames.
+    const uint32_t nFrames = (nBlocks + frameBlocks - 1u) / frameBlocks;
+    uint32_t nParts = c->dbgPartFrames ? nFrames / c->dbgPartFrames : 1u; if (nParts < 1u) nParts = 1u; if (nParts > GC_MAX_PARTS) nParts = GC_MAX_PARTS;
+    if (frameBlocks <= 1u) nParts = 1u;
+    c->mfTimed = false; c->nParts = nParts;
+    const uint32_t segPerBlock = GC_ZSTD_BLOCK_MAX >> segLog;
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    uint32_t f0 = 0;
+    for (uint32_t p = 0; p < nParts; p++) {
+        const uint32_t f1 = (uint32_t)(((uint64_t)nFrames * (p + 1u)) / nParts);
+        const uint32_t blk0 = f0 * frameBlocks, blk1 = f1 * frameBlocks < nBlocks ? f1 * frameBlocks : nBlocks;
+        const uint64_t off = (uint64_t)blk0 * GC_ZSTD_BLOCK_MAX;
+        const size_t pn = (size_t)(((uint64_t)blk1 * GC_ZSTD_BLOCK_MAX < n ? (uint64_t)blk1 * GC_ZSTD_BLOCK_MAX : (uint64_t)n) - off);
+        const uint32_t pBlocks = blk1 - blk0, pSegs = pBlocks * segPerBlock, pRc = pBlocks * GC_LZMA_RC_PER_BLOCK;
+        hipEvent_t* ev = c->evPart[p];
+        // stage 1 (main stream): match finder + item lists
+        HIPCHK(c, hipEventRecord(ev[0], c->stream));
+        rc = launch_finder_part(c, c->stream, p, src + off, pn, frameBlocks, blk0, nullptr);
+        if (rc != GC_OK) return rc;
+        HIPCHK(c, hipEventRecord(ev[1], c->stream));
+        GC_LAUNCH(gc_lzma2_prep_kernel, pBlocks, 256, c->stream, (const GcSeqRaw*)(c->seqRaw + (size_t)blk0 * GC_MAX_SEQ_PER_BLOCK),
+                  (const GcBlockMeta*)(c->meta + blk0), (uint64_t)pn, c->lzM + (size_t)blk0 * GC_LZMA_MAX_ITEMS, c->lzNM + blk0);
+        HIPCHK(c, hipEventRecord(ev[2], c->stream));
+        // stage 2 (stream2): model
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, ev[2], 0));
+        HIPCHK(c, hipEventRecord(ev[3], c->stream2));
+        GC_LAUNCH(gc_lzma2_model_kernel, pSegs, 64, c->stream2, src + off, (uint64_t)pn, (const uint64_t*)(c->lzM + (size_t)blk0 * GC_LZMA_MAX_ITEMS),
+                  (const uint32_t*)(c->lzNM + blk0), segLog, (uint32_t)(off != 0u ? 1u : 0u),
+                  c->lzStream + (size_t)blk0 * segPerBlock * GC_LZMA_STREAM_WORDS(segLog), c->lzInfo + (size_t)blk0 * GC_LZMA_RC_PER_BLOCK);
+        HIPCHK(c, hipEventRecord(ev[4], c->stream2));
+        // stage 3 (stream3): range coder
+        HIPCHK(c, hipStreamWaitEvent(c->stream3, ev[4], 0));
+        HIPCHK(c, hipEventRecord(ev[5], c->stream3));
+        GC_LAUNCH(gc_lzma2_rc_kernel, (pRc + 63u) / 64u, 64, c->stream3, (const uint16_t*)(c->lzStream + (size_t)blk0 * segPerBlock * GC_LZMA_STREAM_WORDS(segLog)),
+                  segLog, pRc, c->lzRcOut + (size_t)blk0 * GC_LZMA_RC_PER_BLOCK * GC_LZMA_RC_STRIDE, c->lzInfo + (size_t)blk0 * GC_LZMA_RC_PER_BLOCK);
+        HIPCHK(c, hipEventRecord(ev[6], c->stream3));
+        f0 = f1;
+    }
+    c->mfTimed = frameBlocks > 1u; c->mfParts = nParts;
+    (void)nSegs;
+    // all parts coded -> headers and assembly on the main stream
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->evPart[nParts - 1u][6], 0));
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     GC_LAUNCH(gc_lzma2_plan_kernel, 1, 1024, c->stream, (const GcLzmaChunkInfo*)c->lzInfo, nRc, segLog, (uint64_t)dstCap, (uint32_t)flags, c->lzPlan, c->result);
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
@@ -423,13 +513,16 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
 
 extern "C" int gc_flzma2_finish(gc_ctx* c, size_t* compressedSize) { return gc_zstd_finish(c, compressedSize); }
 
+// Stage times are summed over the parts of the input; stages of different parts overlap (three streams), so their sum exceeds
+// ms[6], the time from the first kernel's start to the last kernel's end.
 extern "C" int gc_flzma2_last_timing(gc_ctx* c, float ms[7])
 {
     if (!c || !c->timed || c->pending || c->lastCodec != 1) return GC_ERR_PARAM;
-    HIPCHK(c, hipEventElapsedTime(&ms[0], c->ev[0], c->ev[1]));     // lz
-    HIPCHK(c, hipEventElapsedTime(&ms[1], c->ev[1], c->ev[2]));     // prep
-    HIPCHK(c, hipEventElapsedTime(&ms[2], c->ev[2], c->ev[6]));     // model
-    HIPCHK(c, hipEventElapsedTime(&ms[3], c->ev[6], c->ev[3]));     // rc
+    for (int i = 0; i < 4; i++) ms[i] = 0.f;
+    for (uint32_t p = 0; p < c->nParts; p++) {
+        static const int a[4] = { 0, 1, 3, 5 }, b[4] = { 1, 2, 4, 6 };      // lz, prep, model, rc
+        for (int i = 0; i < 4; i++) { float t = 0.f; HIPCHK(c, hipEventElapsedTime(&t, c->evPart[p][a[i]], c->evPart[p][b[i]])); ms[i] += t; }
+    }
     HIPCHK(c, hipEventElapsedTime(&ms[4], c->ev[3], c->ev[4]));     // plan
     HIPCHK(c, hipEventElapsedTime(&ms[5], c->ev[4], c->ev[5]));     // emit
     HIPCHK(c, hipEventElapsedTime(&ms[6], c->ev[0], c->ev[5]));     // first kernel start -> last kernel end

@@ -307,10 +307,12 @@ gc_mf_link_kernel(const uint32_t* __restrict__ offs, const GcMfEntry* __restrict
     __shared__ uint32_t tabL[1u << GC_MF_LSLOT_LOG];
     __shared__ uint32_t tabS[1u << GC_MF_SSLOT_LOG];
     const uint32_t lane = threadIdx.x;
-    // segment-major: the first gridDim / LINK_SEGS workgroups are the segment-0 waves (the only live ones for most lists), so
-    // the live waves are dealt evenly to the XCDs (workgroup i runs on XCD i % 8)
+    // segment-major, so that the live waves are dealt evenly to the XCDs (workgroup i runs on XCD i % 8), and HIGHEST segment
+    // first: most workgroups of the leading groups find no such segment and retire at once; the ones that do exist belong to
+    // the long lists and are the longest pieces of work (LINK_SEG + LINK_WARM entries), so they start first instead of forming
+    // the tail of the launch
     const uint32_t nLists = gridDim.x / LINK_SEGS;
-    const uint32_t seg = blockIdx.x / nLists, fg = blockIdx.x % nLists;
+    const uint32_t seg = LINK_SEGS - 1u - blockIdx.x / nLists, fg = blockIdx.x % nLists;
     const uint32_t frame = fg >> GC_MF_PART_LOG, g = fg & (GC_MF_PARTS - 1u);
     const uint32_t* row = offs + (uint64_t)frame * (tilesPerFrame + 1u) * GC_MF_PARTS;
     const uint32_t listStart = row[g], listEnd = row[(uint64_t)tilesPerFrame * GC_MF_PARTS + g];

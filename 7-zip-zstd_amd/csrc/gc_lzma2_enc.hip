@@ -250,18 +250,18 @@ __device__ __forceinline__ LzItem lz_item(const uint64_t* M, uint32_t idx)
 // events of one item: its literals [lp, pos) then its match.  st0 = coder state at the first literal, rep0 = current repeat
 // distance (matched literal), S = block base (S[-1] exists iff blockBase > 0).  The literal bytes (<= GC_LZMA_LIT_CUT of them,
 // plus the byte in front) are fetched with three 8-byte loads up front instead of one dependent byte load per literal.
-__device__ __forceinline__ void lz_gen_item(LzEv& o, const uint8_t* S, uint64_t blockBase, uint64_t srcSize, uint32_t lp, const LzItem& it, uint32_t st0,
-                                            uint32_t rep0, uint32_t kind)
+__device__ __forceinline__ void lz_gen_item(LzEv& o, const uint8_t* S, uint64_t blockBase, uint64_t srcSize, uint32_t hasPrev, uint32_t lp, const LzItem& it,
+                                            uint32_t st0, uint32_t rep0, uint32_t kind)
 {
     uint32_t st = st0;
     const uint32_t ll = it.pos - lp;
     if (ll) {
         const uint64_t absLp = blockBase + lp;
         uint64_t x0 = 0, x1 = 0, x2 = 0;                            // bytes absLp - 1 .. absLp + 22
-        const bool fast = absLp >= 1u && absLp + 23u <= srcSize;
+        const bool fast = absLp + hasPrev >= 1u && absLp + 23u <= srcSize;           // hasPrev: the buffer is a later part of a stream
         if (fast) { x0 = gc_ld64(S + lp - 1); x1 = gc_ld64(S + lp + 7); x2 = gc_ld64(S + lp + 15); }
         const uint32_t mb0 = st >= 7u ? S[(int64_t)lp - (int64_t)rep0] : 0u;      // only a literal right behind a match is "matched"
-        uint32_t prev = fast ? (uint32_t)(x0 & 0xFFu) : (absLp ? S[(int64_t)lp - 1] : 0u);
+        uint32_t prev = fast ? (uint32_t)(x0 & 0xFFu) : (absLp + hasPrev ? S[(int64_t)lp - 1] : 0u);
         for (uint32_t i = 0; i < ll; i++) {
             uint32_t cur;
             if (fast) { const uint32_t j = i + 1u; const uint64_t x = j < 8u ? x0 : (j < 16u ? x1 : x2); cur = (uint32_t)(x >> ((j & 7u) * 8u)) & 0xFFu; }
@@ -276,8 +276,8 @@ __device__ __forceinline__ void lz_gen_item(LzEv& o, const uint8_t* S, uint64_t 
 
 extern "C" __global__ void __launch_bounds__(64)
 gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const uint64_t* __restrict__ Mall,
-                      const uint32_t* __restrict__ nM, uint32_t segLog, uint16_t* __restrict__ stream,
-                      GcLzmaChunkInfo* __restrict__ cinfo)
+                      const uint32_t* __restrict__ nM, uint32_t segLog, uint32_t hasPrev /* the byte in front of src exists (src is a later part of a stream) */,
+                      uint16_t* __restrict__ stream, GcLzmaChunkInfo* __restrict__ cinfo)
 {
     __shared__ uint16_t P[LZP_TOTAL];
     __shared__ uint32_t sTick[(LZP_TOTAL + 3u) / 4u];             // one ticket byte per probability
@@ -405,7 +405,7 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
 #endif
             if (lane >= done && lane < upto) {
                 LzEv o; o.p = sEv + (evIncl - nEv - evDone); o.n = 0; o.store = true;
-                lz_gen_item(o, S, blockBase, srcSize, prevEnd, it, st0, pOff, kind);
+                lz_gen_item(o, S, blockBase, srcSize, hasPrev, prevEnd, it, st0, pOff, kind);
             }
             gc_wave_sync();
             const uint32_t total = evEnd - evDone;
@@ -459,19 +459,17 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
 // (C/fast-lzma2/range_enc.h:62-152, RC_shiftLow range_enc.c:123-140).  All chunks of an input are coded at the same time, so
 // the kernel takes as long as ONE chunk's chain of ~4.5 coded bits per byte: what matters is the number of dependent cycles per
 // coded bit.  The step is therefore written without branches: every state update is a select, the output byte (if any) is
-// OR-ed into a 16-byte register window at a computed position, and only once per eight coded bits the wave looks whether a
-// lane has a complete group of eight bytes to put away, or has hit the one rare case that needs a loop (a carry rippling
-// through pending 0xFF bytes).
+// OR-ed into a 16-byte register window at a computed position, and only once per eight coded bits a lane with a complete
+// group of eight bytes stores it; the one rare case that needs a loop is a carry rippling through pending 0xFF bytes.
 struct LzRc {
     uint32_t low, carry;              // low 32 bits of `low` + its 33rd bit
     uint32_t range, cache, pend;      // pend = cacheSize - 1: 0xFF bytes waiting behind `cache` for a possible carry
     uint32_t outPos;                  // bytes produced so far
-    uint32_t putQ, flushedQ;          // groups of eight bytes handed to the LDS ring / written to memory
+    uint32_t putQ;                    // groups of eight bytes written to memory
     uint64_t w0, w1;                  // bytes [8 * putQ, outPos): at most 15
-    uint64_t* out; uint64_t* ring;
+    uint64_t* out;
     bool act;                         // false while the lane only runs along (its state is thrown away): no memory side effects
 };
-#define RC_RING 8u                    // groups per lane in the LDS ring
 
 __device__ __forceinline__ void rc_append(LzRc& rc, uint32_t v, bool on)          // byte v at position outPos, if `on`
 {
@@ -481,18 +479,13 @@ __device__ __forceinline__ void rc_append(LzRc& rc, uint32_t v, bool on)        
     rc.w1 |= pos < 8u ? 0ull : x;
     rc.outPos += on ? 1u : 0u;
 }
-// groups [flushedQ, putQ) of this lane: ring -> memory
-__device__ __forceinline__ void rc_flush(LzRc& rc)
-{
-    if (rc.act) for (uint32_t q = rc.flushedQ; q < rc.putQ; q++) if (q < GC_LZMA_RC_STRIDE / 8u) rc.out[q] = rc.ring[(q % RC_RING) * 64u];
-    rc.flushedQ = rc.putQ;
-}
-// hand a complete group of eight bytes (if there is one) to the ring; call with every lane of the wave
+// write a complete group of eight bytes (if there is one)
 __device__ __forceinline__ void rc_put_away(LzRc& rc)
 {
-    const bool full = rc.outPos - 8u * rc.putQ >= 8u;
-    if (__any(full && rc.putQ - rc.flushedQ >= RC_RING)) rc_flush(rc);             // a ring is full: everybody writes
-    if (full) { if (rc.act) rc.ring[(rc.putQ % RC_RING) * 64u] = rc.w0; rc.w0 = rc.w1; rc.w1 = 0; rc.putQ++; }
+    if (rc.outPos - 8u * rc.putQ >= 8u) {
+        if (rc.act && rc.putQ < GC_LZMA_RC_STRIDE / 8u) rc.out[rc.putQ] = rc.w0;
+        rc.w0 = rc.w1; rc.w1 = 0; rc.putQ++;
+    }
 }
 // one coded bit, branch-free except for the wave-level look at the rare case
 __device__ __forceinline__ void rc_word(LzRc& rc, uint32_t w)
@@ -523,7 +516,6 @@ extern "C" __global__ void __launch_bounds__(64)
 gc_lzma2_rc_kernel(const uint16_t* __restrict__ stream, uint32_t segLog, uint32_t nRc, uint8_t* __restrict__ rcOut,
                    GcLzmaChunkInfo* __restrict__ cinfo)
 {
-    __shared__ uint64_t sRing[RC_RING * 64u];
     const uint32_t lane = threadIdx.x;
     const uint32_t c = blockIdx.x * 64u + lane;
     GcLzmaChunkInfo ci; ci.usize = 0; ci.csize = 0; ci.wordStart = 0; ci.wordEnd = 0;
@@ -531,9 +523,8 @@ gc_lzma2_rc_kernel(const uint16_t* __restrict__ stream, uint32_t segLog, uint32_
     const bool live = ci.usize != 0u && ci.csize != 0xFFFFFFFFu;           // idle lanes run along without words
     const uint32_t seg = c >> (segLog - GC_LZMA_RC_LOG);
     const uint16_t* W = stream + (uint64_t)(live ? seg : 0u) * GC_LZMA_STREAM_WORDS(segLog);
-    LzRc rc; rc.low = 0; rc.carry = 0; rc.range = 0xFFFFFFFFu; rc.cache = 0; rc.pend = 0; rc.outPos = 0; rc.putQ = 0; rc.flushedQ = 0; rc.w0 = 0; rc.w1 = 0; rc.act = live;
+    LzRc rc; rc.low = 0; rc.carry = 0; rc.range = 0xFFFFFFFFu; rc.cache = 0; rc.pend = 0; rc.outPos = 0; rc.putQ = 0; rc.w0 = 0; rc.w1 = 0; rc.act = live;
     rc.out = (uint64_t*)(rcOut + (uint64_t)(live ? c : 0u) * GC_LZMA_RC_STRIDE);
-    rc.ring = sRing + lane;
     // words up to the next 16-byte boundary of the stream one by one (every lane of the wave takes part in each step, lanes
     // without a word just do not advance), then eight at a time from one 16-byte load, then the rest one by one
     uint32_t k = live ? ci.wordStart : 0u;
@@ -592,7 +583,7 @@ gc_lzma2_rc_kernel(const uint16_t* __restrict__ stream, uint32_t segLog, uint32_
                 // (plain per-lane code: the tail is not performance relevant)
                 { const uint32_t pos = rc.outPos - 8u * rc.putQ; if (pos < 8u) rc.w0 |= (uint64_t)tmp << (pos * 8u); else rc.w1 |= (uint64_t)tmp << ((pos - 8u) * 8u); rc.outPos++; }
                 for (uint32_t e = rc.pend; e != 0u; e--) {
-                    if (rc.outPos - 8u * rc.putQ >= 8u) { if (rc.putQ - rc.flushedQ >= RC_RING) rc_flush(rc); rc.ring[(rc.putQ % RC_RING) * 64u] = rc.w0; rc.w0 = rc.w1; rc.w1 = 0; rc.putQ++; }
+                    rc_put_away(rc);
                     const uint32_t pos = rc.outPos - 8u * rc.putQ; const uint64_t x = (uint64_t)((0xFFu + carry) & 0xFFu);
                     if (pos < 8u) rc.w0 |= x << (pos * 8u); else rc.w1 |= x << ((pos - 8u) * 8u);
                     rc.outPos++;
@@ -600,10 +591,9 @@ gc_lzma2_rc_kernel(const uint16_t* __restrict__ stream, uint32_t segLog, uint32_
                 rc.cache = rc.low >> 24; rc.pend = 0;
             } else rc.pend++;
             rc.low <<= 8; rc.carry = 0;
-            if (rc.outPos - 8u * rc.putQ >= 8u) { if (rc.putQ - rc.flushedQ >= RC_RING) rc_flush(rc); rc.ring[(rc.putQ % RC_RING) * 64u] = rc.w0; rc.w0 = rc.w1; rc.w1 = 0; rc.putQ++; }
+            rc_put_away(rc);
         }
     }
-    rc_flush(rc);
     if (live) {
         const uint32_t n = rc.outPos;
         if (n <= GC_LZMA_RC_STRIDE) {

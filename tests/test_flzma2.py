@@ -95,6 +95,20 @@ def test_emu_long_matches_and_patterns(O, emu_fl2):
     _roundtrip(O, emu_fl2[1], y)                                                         # dense rep0 / rep1 usage
 
 
+def test_emu_many_frames_and_parts(O, pkg, emu_lib_path, monkeypatch):
+    """The multi-frame and multi-part paths on a small input: test hooks shrink the match-finder frame to 2 blocks and make every
+    frame its own part (stages of different parts run on different streams; a later part's first literal has the last byte of
+    the previous part as its context).  Parts must not change the stream: same bytes as the single-part run."""
+    x = O.corpus("silesia-like", 5 * 2 * BLK + 4321)
+    monkeypatch.setenv("GC_FRAME_BLOCKS", "2")
+    one = pkg.Flzma2Encoder(lib_path=emu_lib_path, level=5)
+    c1 = _roundtrip(O, one, x); one.close()
+    monkeypatch.setenv("GC_PART_FRAMES", "1")
+    many = pkg.Flzma2Encoder(lib_path=emu_lib_path, level=5)
+    c2 = _roundtrip(O, many, x); many.close()
+    assert np.array_equal(c1, c2)
+
+
 def test_emu_ratio_band_vs_reference(O, emu_fl2):
     """Size against the reference encoder at level 5 (recorded, and bounded so that regressions show)."""
     if O.ref("flzma2") is None:
