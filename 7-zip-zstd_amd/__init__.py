@@ -241,13 +241,14 @@ class ZstdEncoder(_EncoderBase):
         return dict(zip(self.KERNELS, [float(x) for x in ms]))
 
     PHASES = ("lz.probe", "lz.insert", "lz.verify", "lz.double", "lz.chain", "lz.walk", "lz.emit",
-              "seq.merge", "seq.codes", "seq.tables", "seq.chains", "seq.pack")
+              "seq.merge", "seq.codes", "seq.tables", "seq.chains", "seq.pack",
+              "seq.chains.stage", "seq.chains.warm", "seq.chains.walk", "seq.chains.out")
 
     def set_phase_profile(self, on=True):
         self._check(self._lib.gc_zstd_set_phase_profile(self._ctx, 1 if on else 0), "gc_zstd_set_phase_profile")
 
     def phase_profile(self):
         """Average shader cycles per block and phase of the last call (thread 0's view, barrier waits included)."""
-        v = (C.c_double * 12)()
+        v = (C.c_double * 16)()
         self._check(self._lib.gc_zstd_phase_profile(self._ctx, v), "gc_zstd_phase_profile")
         return dict(zip(self.PHASES, [float(x) for x in v]))

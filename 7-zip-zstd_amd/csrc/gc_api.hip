@@ -321,7 +321,7 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
     // K2 (literals) and K3 (sequences) are independent consumers of K1: run them on two streams
     HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev[1], 0));
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream2));
-    GC_LAUNCH(gc_zstd_seq_kernel, nBlocks, 256, c->stream2, (const GcSeqRaw*)c->seqRaw, (const GcBlockMeta*)c->meta, c->seqPacked,
+    GC_LAUNCH(gc_zstd_seq_kernel, nBlocks, GC_SEQ_T, c->stream2, (const GcSeqRaw*)c->seqRaw, (const GcBlockMeta*)c->meta, c->seqPacked,
               c->seqOff, c->codes, c->stOut, c->seqSec, c->info, (uint64_t)n, frameBlocks, c->profOn ? c->prof + GC_LZ_PHASES : nullptr);
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream2));
     GC_LAUNCH(gc_zstd_huf_kernel, nBlocks, 256, c->stream, (const uint8_t*)c->lit, (const GcBlockMeta*)c->meta, c->litSec, c->info);

@@ -47,7 +47,8 @@ struct GcSectionInfo {
 // worst-case frame: 4 magic + 1 FHD + 4 FCS + 3 block header + payload
 #define GC_FRAME_OVERHEAD 12u
 
+#define GC_SEQ_T      512u  // K3: threads per block
 #define GC_LZ_PHASES  7   // K1 phase profile slots: probe, insert, verify, double, chain, walk, emit
-#define GC_SEQ_PHASES 5   // K3 phase profile slots: merge, codes, tables, chains, pack
+#define GC_SEQ_PHASES 9   // K3 phase profile slots: merge, codes, tables, chains, pack + chain sub-phases: stage, warm-up, walk, copy-out
 
 static inline uint32_t gc_num_blocks(uint64_t n) { return (uint32_t)((n + GC_ZSTD_BLOCK_MAX - 1) / GC_ZSTD_BLOCK_MAX); }

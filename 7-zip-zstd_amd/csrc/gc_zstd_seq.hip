@@ -27,7 +27,7 @@
 #include <stdlib.h>
 #endif
 
-#define SEQ_T 256u
+#define SEQ_T GC_SEQ_T
 #define SEQ_TILE_WORDS ((SEQ_T * 80u) / 32u + 8u)
 #define SEQ_CHAIN_TILE 4096u   // sequences per state-chain tile
 #define SEQ_CHAIN_SEG  64u     // sequences per lane and tile
@@ -168,7 +168,7 @@ gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __res
                    unsigned long long* __restrict__ prof /* optional per-phase cycle sums */)
 {
     __shared__ SeqTab sTab[3];
-    __shared__ uint32_t sWave[8];
+    __shared__ uint32_t sWave[SEQ_T / 64u];
     __shared__ uint32_t sRun[SEQ_T];
     __shared__ uint32_t sTile[SEQ_TILE_WORDS];
 
@@ -192,6 +192,8 @@ gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __res
     for (uint32_t i = t; i < 3u * 64u; i += SEQ_T) sTab[i >> 6].count[i & 63u] = 0;
     unsigned long long tprev = prof ? gc_clock() : 0ull;
 #define SEQ_PHASE(i) do { if (prof && t == 0) { unsigned long long now_ = gc_clock(); atomicAdd(&prof[i], now_ - tprev); tprev = now_; } } while (0)
+    unsigned long long tsub = 0;
+#define SEQ_SUB(i) do { if (prof && t == 0) { unsigned long long now_ = gc_clock(); if (tsub) atomicAdd(&prof[i], now_ - tsub); tsub = now_; } } while (0)
 
     // ---- S1: merge chains of capped matches.  Head = first record of a run with equal offset and litLength 0.
     //      P[j] = ll(17) | ml(18)<<17 for merged sequence j, O[j] = its offset
@@ -292,11 +294,13 @@ gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __res
             uint32_t carry = 0;                               // state after the last sequence of the previous tile
             for (uint32_t tb = 0; tb < nSeq; tb += SEQ_CHAIN_TILE) {
                 const uint32_t tileLen = min(SEQ_CHAIN_TILE, nSeq - tb);
+                if (prof && t == 0) tsub = gc_clock();
                 // stage the codes (independent loads, eight in flight per lane), then per 64 sequences one mask of the positions
                 // that hold a count-1 symbol ("meeting points")
 #pragma unroll 8
                 for (uint32_t u = lane; u < tileLen; u += 64u) T.tCode[u] = C[nSeq - 1u - (tb + u)];
                 gc_wave_sync();
+                SEQ_SUB(5);
                 for (uint32_t k = 0; k < tileLen; k += 64u) {
                     const uint32_t u = k + lane;
                     const bool isR = u < tileLen && ((resetMask >> T.tCode[u]) & 1ull) != 0ull;
@@ -320,13 +324,18 @@ gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __res
                         }
                         if (tb + w == 0u) { st0 = gc_fse_init_state(T.state, T.tt[T.tCode[0]]); w = 1u; }                   // exact, not a guess
                         else st0 = 1u << L;
-                        for (; w < u0; w++) {
-                            const GcFseSym sy = T.tt[T.tCode[w]];
-                            const uint32_t nb = (st0 + sy.deltaNbBits) >> 16;
-                            st0 = T.state[(st0 >> nb) + (uint32_t)sy.deltaFindState];
+                        if (w < u0) {                              // the symbol's table entry does not depend on the state: fetched one
+                            GcFseSym sy = T.tt[T.tCode[w]];          // step ahead, so a step costs one dependent LDS read, not three
+                            for (; w < u0; w++) {
+                                const GcFseSym nx = T.tt[T.tCode[w + 1u < u0 ? w + 1u : w]];
+                                const uint32_t nb = (st0 + sy.deltaNbBits) >> 16;
+                                st0 = T.state[(st0 >> nb) + (uint32_t)sy.deltaFindState];
+                                sy = nx;
+                            }
                         }
                     }
                 }
+                SEQ_SUB(6);
                 // tOut[u] = nbBits << 10 | state BEFORE symbol u (10 bits): the bits to emit are its low nbBits, and a repair walk
                 // can tell when it has rejoined the trajectory already stored (same state at the same u: the rest is unchanged)
                 uint32_t fin = st0;
@@ -338,12 +347,14 @@ gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __res
                 for (;;) {
                     if (redo) {
                         uint32_t state = st0, u = first;
+                        GcFseSym sy = T.tt[T.tCode[u < u1 ? u : u1 - 1u]];
                         for (; u < u1; u++) {
                             if (!firstPass && (T.tOut[u] & 0x3FFu) == (state & 0x3FFu)) break;
-                            const GcFseSym sy = T.tt[T.tCode[u]];
+                            const GcFseSym nx = T.tt[T.tCode[u + 1u < u1 ? u + 1u : u]];
                             const uint32_t nb = (state + sy.deltaNbBits) >> 16;
                             T.tOut[u] = (uint16_t)((nb << 10) | (state & 0x3FFu));
                             state = T.state[(state >> nb) + (uint32_t)sy.deltaFindState];
+                            sy = nx;
                         }
                         if (u == u1) fin = state;                 // walked to the end: the final state may have changed
                     }
@@ -361,8 +372,10 @@ gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __res
 #endif
                 carry = __shfl(fin, (int)(nSegs - 1u));
                 gc_wave_sync();
+                SEQ_SUB(7);
                 for (uint32_t u = lane; u < tileLen; u += 64u) S[nSeq - 1u - (tb + u)] = T.tOut[u];
                 gc_wave_sync();
+                SEQ_SUB(8);
             }
             if (lane == 0u) T.finalState = carry;
         }

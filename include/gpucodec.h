@@ -65,9 +65,9 @@ int         gc_mf_last_timing(gc_ctx* ctx, float ms[6]);
 
 /* Optional in-kernel phase profile (shader-clock deltas measured by thread 0 of every workgroup, averaged over
  * blocks): cycles[0..6] = K1 {probe, insert, verify, double, chain, walk, emit}, cycles[7..11] = K3 {merge,
- * codes, tables, chains, pack}.  Off by default (no cost when off). */
+ * codes, tables, chains, pack}, cycles[12..15] = parts of K3's chains phase {stage, warm-up, walk, copy-out}.  Off by default (no cost when off). */
 int         gc_zstd_set_phase_profile(gc_ctx* ctx, int enable);
-int         gc_zstd_phase_profile(gc_ctx* ctx, double cyclesPerBlock[12]);
+int         gc_zstd_phase_profile(gc_ctx* ctx, double cyclesPerBlock[16]);
 
 /* ---- FLZMA2 (7-Zip method id 0x21): an LZMA2 chunk stream that the stock decoder NCompress::NLzma2::CDecoder
  * (C/Lzma2Dec.c; registered for FLZMA2 at CPP/7zip/Compress/FastLzma2Register.cpp:15) regenerates bit-exactly.
