@@ -40,7 +40,7 @@ extern "C" __global__ void gc_mf_scan_kernel(uint32_t*, uint32_t);
 extern "C" __global__ void gc_mf_scatter_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
 extern "C" __global__ void gc_mf_link_kernel(const uint32_t*, const GcMfEntry*, GcMfEntry*, uint32_t, uint64_t);
 extern "C" __global__ void gc_mf_verify_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
-extern "C" __global__ void gc_mf_parse_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, const uint32_t*, GcSeqRaw*, uint8_t*, GcBlockMeta*);
+extern "C" __global__ void gc_mf_parse_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcSeqRaw*, uint8_t*, GcBlockMeta*);
 
 extern "C" __global__ void gc_lzma2_prep_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t, uint64_t*, uint32_t*);
 extern "C" __global__ void gc_lzma2_model_kernel(const uint8_t*, uint64_t, const uint64_t*, const uint32_t*, uint32_t, uint32_t, uint16_t*, GcLzmaChunkInfo*);
@@ -62,6 +62,7 @@ struct gc_ctx {
     hipStream_t stream3;      // FLZMA2: range-coder stage
     hipEvent_t evPart[GC_MAX_PARTS][GC_PART_EVENTS];   // per input part: stage boundaries (see gc_flzma2_compress_device)
     uint32_t nParts;
+    uint32_t lazyDepth;       // W6: 1 = one-step lazy, 2 = lazy2 (set per call from codec + level)
     uint32_t dbgFrameBlocks, dbgPartFrames;   // test hooks (env GC_FRAME_BLOCKS / GC_PART_FRAMES): small frames / parts so that
                                               // the multi-frame and multi-part paths can be exercised on small inputs
     hipEvent_t ev[8];         // 0 lz start, 1 lz end, 2 huf end, 3 seq start, 4 seq end, 5 plan start, 6 plan end, 7 emit end
@@ -259,7 +260,7 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
     GC_LAUNCH(gc_mf_verify_kernel, perT * GC_XCDS, GC_MF_VERIFY_T, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt,
               (const GcMfEntry*)ent2, rec);
     HIPCHK(c, hipEventRecord(ev[5], st));
-    GC_LAUNCH(gc_mf_parse_kernel, perB * GC_XCDS, GC_MF_PARSE_T, st, src, (uint64_t)n, nBlocks, perB, (const uint32_t*)rec, seqRaw, lit, meta);
+    GC_LAUNCH(gc_mf_parse_kernel, perB * GC_XCDS, GC_MF_PARSE_T, st, src, (uint64_t)n, nBlocks, perB, c->lazyDepth, (const uint32_t*)rec, seqRaw, lit, meta);
     HIPCHK(c, hipEventRecord(ev[6], st));
     (void)prof;
     return GC_OK;
@@ -314,6 +315,7 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
     const uint8_t* src = (const uint8_t*)d_src;
     if (c->profOn) { HIPCHK(c, hipMemsetAsync(c->prof, 0, (GC_LZ_PHASES + GC_SEQ_PHASES) * sizeof(unsigned long long), c->stream)); c->profBlocks = nBlocks; }
     const uint32_t frameBlocks = zstd_frame_blocks(level) < nBlocks ? zstd_frame_blocks(level) : nBlocks;   // short input: one frame
+    c->lazyDepth = level >= 6 ? 2u : 1u;          // the reference's lazy2 begins at level 8 of its table; deeper look-ahead from 6 here
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     rc = launch_finder(c, src, n, frameBlocks, c->profOn ? c->prof : nullptr);
     if (rc != GC_OK) return rc;
@@ -451,6 +453,7 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
         }
     }
     uint32_t frameBlocks = flzma2_frame_blocks(level);
+    c->lazyDepth = level >= 5 ? 2u : 1u;
     if (frameBlocks > 1u && c->dbgFrameBlocks) frameBlocks = c->dbgFrameBlocks;
     if (frameBlocks > nBlocks) frameBlocks = nBlocks;
     rc = ensure_finder_workspace(c, n, frameBlocks);
@@ -590,6 +593,7 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     const uint8_t* src = (const uint8_t*)d_src;
     HIPCHK(c, hipMemsetAsync(c->brStage, 0, (size_t)nBlocks * GC_BR_STAGE_STRIDE, c->stream));
     uint32_t frameBlocks = brotli_frame_blocks(level, bpc);
+    c->lazyDepth = level >= 7 ? 2u : 1u;
     if (frameBlocks > nBlocks) frameBlocks = nBlocks;                       // short input: one chunk, one frame
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     rc = launch_finder(c, src, n, frameBlocks, nullptr);

@@ -505,15 +505,24 @@ gc_mf_verify_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t 
 #define PZ_GROUPS  (GC_ZSTD_BLOCK_MAX / 64u / PZ_GSEGS)          // 64 groups per full block
 
 struct PzSeg { uint32_t r0; bool take; uint32_t nxt; };
-// record, lazy decision and next pointer of position p = seg * 64 + lane (R = records of the block, n = block length)
-__device__ __forceinline__ PzSeg pz_seg(const uint32_t* __restrict__ R, uint32_t p, uint32_t n, uint32_t lane)
+// record, lazy decision and next pointer of position p = seg * 64 + lane (R = records of the block, n = block length).
+// lazy: 1 = give the match at p up if the one at p + 1 is clearly better (ZSTD_compressBlock_lazy, zstd_lazy.c:1516; brotli's
+// one-step lazy matching, backward_references_inc.h:80-130); 2 = also look at p + 2 (lazy2).  The decision only looks ahead,
+// never at decisions made for other positions, so it stays a pure function of the records.
+__device__ __forceinline__ PzSeg pz_seg(const uint32_t* __restrict__ R, uint32_t p, uint32_t n, uint32_t lane, uint32_t lazy)
 {
     PzSeg s;
     s.r0 = p < n ? R[p] : 0u;
     const uint32_t r1 = p + 1u < n ? R[p + 1u] : 0u;
     const uint32_t len = s.r0 & 0xFFu, l1 = r1 & 0xFFu;
     s.take = len != 0u;
-    if (s.take && l1 > len && lz_gain(l1, r1 >> 8) > lz_gain(len, s.r0 >> 8) + 4) s.take = false;
+    const int g0 = lz_gain(len, s.r0 >> 8);
+    if (s.take && l1 > len && lz_gain(l1, r1 >> 8) > g0 + 4) s.take = false;
+    if (lazy >= 2u) {
+        const uint32_t r2 = p + 2u < n ? R[p + 2u] : 0u;
+        const uint32_t l2 = r2 & 0xFFu;
+        if (s.take && l2 > len + 1u && lz_gain(l2, r2 >> 8) > g0 + 8) s.take = false;
+    }
     s.nxt = s.take ? lane + len : lane + 1u;                      // >= 64: leaves the segment
     return s;
 }
@@ -527,7 +536,7 @@ __device__ __forceinline__ uint32_t pz_exit(uint32_t nxt)
 }
 
 extern "C" __global__ void __launch_bounds__(PZ_T)
-gc_mf_parse_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, const uint32_t* __restrict__ rec,
+gc_mf_parse_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t lazy, const uint32_t* __restrict__ rec,
                    GcSeqRaw* __restrict__ seqRaw, uint8_t* __restrict__ lit, GcBlockMeta* __restrict__ meta)
 {
     __shared__ uint8_t  sGExit[PZ_GROUPS][64];
@@ -550,7 +559,7 @@ gc_mf_parse_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t n
         uint32_t comp = lane;                                     // where the path that enters the group at lane `lane` stands
         const uint32_t sEnd = (g + 1u) * PZ_GSEGS < nSeg ? (g + 1u) * PZ_GSEGS : nSeg;
         for (uint32_t seg = g * PZ_GSEGS; seg < sEnd; seg++) {
-            const PzSeg s = pz_seg(R, seg * 64u + lane, n, lane);
+            const PzSeg s = pz_seg(R, seg * 64u + lane, n, lane, lazy);
             const uint32_t ex = pz_exit(s.nxt) - 64u;
             comp = __shfl(ex, (int)comp);
         }
@@ -583,7 +592,7 @@ gc_mf_parse_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t n
         const uint32_t sEnd = (g + 1u) * PZ_GSEGS < nSeg ? (g + 1u) * PZ_GSEGS : nSeg;
         for (uint32_t seg = g * PZ_GSEGS; seg < sEnd; seg++) {
             const uint32_t p = seg * 64u + lane;
-            const PzSeg s = pz_seg(R, p, n, lane);
+            const PzSeg s = pz_seg(R, p, n, lane, lazy);
             uint64_t path = 0;
             uint32_t c = e;
             while (c < 64u) { path |= 1ull << c; c = gc_readlane(s.nxt, c); }
