@@ -40,6 +40,7 @@ extern "C" __global__ void gc_mf_scan_kernel(uint32_t*, uint32_t);
 extern "C" __global__ void gc_mf_scatter_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
 extern "C" __global__ void gc_mf_link_kernel(const uint32_t*, const GcMfEntry*, GcMfEntry*, uint32_t, uint64_t);
 extern "C" __global__ void gc_mf_verify_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
+extern "C" __global__ void gc_mf_deepen_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, uint32_t*);
 extern "C" __global__ void gc_mf_parse_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcSeqRaw*, uint8_t*, GcBlockMeta*);
 
 extern "C" __global__ void gc_lzma2_prep_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t, uint64_t*, uint32_t*);
@@ -63,6 +64,7 @@ struct gc_ctx {
     hipEvent_t evPart[GC_MAX_PARTS][GC_PART_EVENTS];   // per input part: stage boundaries (see gc_flzma2_compress_device)
     uint32_t nParts;
     uint32_t lazyDepth;       // W6: 1 = one-step lazy, 2 = lazy2 (set per call from codec + level)
+    uint32_t searchDepth;     // W5b: match links followed per position (0 = W5's two candidates only)
     uint32_t dbgFrameBlocks, dbgPartFrames;   // test hooks (env GC_FRAME_BLOCKS / GC_PART_FRAMES): small frames / parts so that
                                               // the multi-frame and multi-part paths can be exercised on small inputs
     hipEvent_t ev[8];         // 0 lz start, 1 lz end, 2 huf end, 3 seq start, 4 seq end, 5 plan start, 6 plan end, 7 emit end
@@ -76,7 +78,7 @@ struct gc_ctx {
     uint64_t* lzM; size_t lzMCap; uint8_t* lzRcOut; size_t lzRcOutCap;     // item lists, range-coder staging (allocated on the first FLZMA2 call)
     uint8_t* brStage; GcBrotliBlockInfo* brInfo; GcBrotliPlan* brPlan;    // BROTLI path
     // windowed match finder (gc_mf.h): counts/offsets, partition starts, entry lists; grown on demand
-    uint32_t* mfCnt; size_t mfCntCap; GcMfEntry* mfEnt; size_t mfEntCap; GcMfEntry* mfEnt2; size_t mfEnt2Cap; uint32_t* mfRec; size_t mfRecCap;
+    uint32_t* mfCnt; size_t mfCntCap; GcMfEntry* mfEnt; size_t mfEntCap; GcMfEntry* mfEnt2; size_t mfEnt2Cap; uint32_t* mfRec; size_t mfRecCap; uint32_t* mfRec2; size_t mfRec2Cap;
     hipEvent_t evMf[GC_MAX_PARTS][7];       // per part: W1 start, W1 end, W2 end, W3 end, W4 end, W5 end, W6 end
     bool mfTimed; uint32_t mfParts;
     int lastCodec;            // 0 zstd, 1 flzma2: which kernels the events of the last call bracket
@@ -151,7 +153,7 @@ extern "C" void gc_ctx_destroy(gc_ctx* c)
     hipStreamSynchronize(c->stream);
     free_workspace(c);
     hipFree(c->prof); hipFree(c->result); hipHostFree(c->hostResult); hipFree(c->dIn); hipFree(c->dOut);
-    hipFree(c->mfCnt); hipFree(c->mfEnt); hipFree(c->mfEnt2); hipFree(c->mfRec);
+    hipFree(c->mfCnt); hipFree(c->mfEnt); hipFree(c->mfEnt2); hipFree(c->mfRec); hipFree(c->mfRec2);
     for (int i = 0; i < 8; i++) hipEventDestroy(c->ev[i]);
     for (uint32_t p = 0; p < GC_MAX_PARTS; p++) {
         for (int i = 0; i < 7; i++) hipEventDestroy(c->evMf[p][i]);
@@ -217,13 +219,14 @@ static int ensure_finder_workspace(gc_ctx* c, size_t n, uint32_t frameBlocks)
     const GcMfGeom g = gc_mf_geom(n, frameBlocks);
     const size_t needCnt = g.cntWords * sizeof(uint32_t), needEnt = (size_t)g.nFrames * g.frameBytes * sizeof(GcMfEntry);
     const size_t needRec = (size_t)g.nBlocks * GC_ZSTD_BLOCK_MAX * sizeof(uint32_t);
-    if (needCnt > c->mfCntCap || needEnt > c->mfEntCap || needEnt > c->mfEnt2Cap || needRec > c->mfRecCap) {
+    if (needCnt > c->mfCntCap || needEnt > c->mfEntCap || needEnt > c->mfEnt2Cap || needRec > c->mfRecCap || (c->searchDepth && needRec > c->mfRec2Cap)) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         int rc;
         if ((rc = mf_grow(c, (void**)&c->mfCnt, &c->mfCntCap, needCnt, "offsets")) != GC_OK) return rc;
         if ((rc = mf_grow(c, (void**)&c->mfEnt, &c->mfEntCap, needEnt, "entries")) != GC_OK) return rc;
         if ((rc = mf_grow(c, (void**)&c->mfEnt2, &c->mfEnt2Cap, needEnt, "linked entries")) != GC_OK) return rc;
         if ((rc = mf_grow(c, (void**)&c->mfRec, &c->mfRecCap, needRec, "records")) != GC_OK) return rc;
+        if (c->searchDepth && (rc = mf_grow(c, (void**)&c->mfRec2, &c->mfRec2Cap, needRec, "deepened records")) != GC_OK) return rc;
     }
     return GC_OK;
 }
@@ -259,6 +262,11 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
     HIPCHK(c, hipEventRecord(ev[4], st));
     GC_LAUNCH(gc_mf_verify_kernel, perT * GC_XCDS, GC_MF_VERIFY_T, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt,
               (const GcMfEntry*)ent2, rec);
+    if (c->searchDepth) {                                       // W5b: follow match links (timed with W5)
+        uint32_t* rec2 = c->mfRec2 + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
+        GC_LAUNCH(gc_mf_deepen_kernel, perT * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, c->searchDepth, (const uint32_t*)rec, rec2);
+        rec = rec2;
+    }
     HIPCHK(c, hipEventRecord(ev[5], st));
     GC_LAUNCH(gc_mf_parse_kernel, perB * GC_XCDS, GC_MF_PARSE_T, st, src, (uint64_t)n, nBlocks, perB, c->lazyDepth, (const uint32_t*)rec, seqRaw, lit, meta);
     HIPCHK(c, hipEventRecord(ev[6], st));
@@ -293,6 +301,8 @@ extern "C" int gc_mf_last_timing(gc_ctx* c, float ms[6])
 // one frame per block; level 3 and up (dfast and stronger, clevels.h:31-47, windowLog >= 21) use the windowed finder with
 // 8 MiB frames.
 static uint32_t zstd_frame_blocks(int level) { return level <= 2 ? 1u : GC_MF_MAX_FRAME_BLOCKS; }
+// zstd level -> match links followed per position (the reference's searchLog grows the same way: clevels.h:25-47)
+static uint32_t zstd_search_depth(int level) { return level < 6 ? 0u : (level < 10 ? 2u : (level < 16 ? 4u : 8u)); }
 
 extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, void* d_dst, size_t dstCap, int level)
 {
@@ -316,6 +326,7 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
     if (c->profOn) { HIPCHK(c, hipMemsetAsync(c->prof, 0, (GC_LZ_PHASES + GC_SEQ_PHASES) * sizeof(unsigned long long), c->stream)); c->profBlocks = nBlocks; }
     const uint32_t frameBlocks = zstd_frame_blocks(level) < nBlocks ? zstd_frame_blocks(level) : nBlocks;   // short input: one frame
     c->lazyDepth = level >= 6 ? 2u : 1u;          // the reference's lazy2 begins at level 8 of its table; deeper look-ahead from 6 here
+    c->searchDepth = zstd_search_depth(level);
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     rc = launch_finder(c, src, n, frameBlocks, c->profOn ? c->prof : nullptr);
     if (rc != GC_OK) return rc;
@@ -454,6 +465,7 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     }
     uint32_t frameBlocks = flzma2_frame_blocks(level);
     c->lazyDepth = level >= 5 ? 2u : 1u;
+    c->searchDepth = level >= 5 ? (level >= 8 ? 8u : 4u) : 0u;
     if (frameBlocks > 1u && c->dbgFrameBlocks) frameBlocks = c->dbgFrameBlocks;
     if (frameBlocks > nBlocks) frameBlocks = nBlocks;
     rc = ensure_finder_workspace(c, n, frameBlocks);
@@ -594,6 +606,7 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     HIPCHK(c, hipMemsetAsync(c->brStage, 0, (size_t)nBlocks * GC_BR_STAGE_STRIDE, c->stream));
     uint32_t frameBlocks = brotli_frame_blocks(level, bpc);
     c->lazyDepth = level >= 7 ? 2u : 1u;
+    c->searchDepth = level >= 7 ? (level >= 10 ? 8u : 4u) : 0u;
     if (frameBlocks > nBlocks) frameBlocks = nBlocks;                       // short input: one chunk, one frame
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     rc = launch_finder(c, src, n, frameBlocks, nullptr);

@@ -490,6 +490,55 @@ gc_mf_verify_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t 
     for (uint32_t i = t; i < (T.len + 3u) / 4u; i += MFV_T) R4[i] = S4[i];
 }
 
+// ------------------------------------------------------------------------------------------------ W5b deepen
+// Higher levels search deeper, as the reference does with hash chains / binary trees of growing search depth
+// (ZSTD_HcFindBestMatch zstd_lazy.c:667, searchLog in clevels.h; RMF depth in fl2_compress.c:37-104).  Here the chain is implicit:
+// W5 left at every position p the offset of its best match, i.e. a link to an earlier position c with the same context; c's own
+// record links to a still earlier occurrence, and so on.  One thread per position follows `depth` such links and keeps the
+// candidate with the best gain.  Reads the records of W5, writes a second record array (other threads still follow the old links).
+#define MFD_T 256u
+extern "C" __global__ void __launch_bounds__(MFD_T)
+gc_mf_deepen_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per, uint32_t depth,
+                    const uint32_t* __restrict__ recIn, uint32_t* __restrict__ recOut)
+{
+    const uint32_t t = threadIdx.x;
+    const uint32_t tile = mf_item(blockIdx.x, per);
+    if (tile >= nTiles) return;
+    const MfTile T = mf_tile(tile, frameBlocks, srcSize);
+    if (T.len == 0u) return;
+    const uint8_t* wsrc = src + T.frameStart;
+    const uint32_t* RI = recIn + T.frameStart;                     // frame-relative indexing, like the candidates
+    const uint64_t blockBase = T.tileStart & ~(uint64_t)(GC_ZSTD_BLOCK_MAX - 1u);
+    const uint32_t nBlk = (uint32_t)((srcSize - blockBase) < GC_ZSTD_BLOCK_MAX ? (srcSize - blockBase) : GC_ZSTD_BLOCK_MAX);
+    const uint32_t pTile = (uint32_t)(T.tileStart - blockBase), wTile = (uint32_t)(T.tileStart - T.frameStart);
+    for (uint32_t q = t; q < T.len; q += MFD_T) {
+        const uint32_t pw = wTile + q, p = pTile + q;
+        const uint32_t r = RI[pw];
+        uint32_t bestLen = r & 0xFFu, bestOff = r >> 8;
+        if (bestLen != 0u && T.tileStart + q + GC_MATCH_CAP + 16u <= T.frameEnd) {
+            const uint32_t maxLen = (nBlk - p) < GC_MATCH_CAP ? (nBlk - p) : GC_MATCH_CAP;
+            const LzW16 me = lz_ld16(wsrc, pw);
+            int bestGain = lz_gain(bestLen, bestOff);
+            uint32_t c = pw - bestOff;
+            for (uint32_t d = 0; d < depth; d++) {
+                const uint32_t rc = RI[c];
+                if ((rc & 0xFFu) == 0u) break;
+                const uint32_t c2 = c - (rc >> 8);
+                uint32_t len = lz_cmp16(me, lz_ld16(wsrc, c2));
+                while (len >= 16u && (len & 15u) == 0u && len < maxLen) {
+                    const uint32_t more = lz_cmp16(lz_ld16(wsrc, (uint64_t)pw + len), lz_ld16(wsrc, (uint64_t)c2 + len));
+                    len += more;
+                    if (more < 16u) break;
+                }
+                if (len > maxLen) len = maxLen;
+                if (len >= GC_MIN_MATCH) { const int g = lz_gain(len, pw - c2); if (g > bestGain) { bestGain = g; bestLen = len; bestOff = pw - c2; } }
+                c = c2;
+            }
+        }
+        recOut[T.tileStart + q] = (bestOff << 8) | bestLen;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ W6 parse
 // Greedy parse with one-step lazy evaluation: next(p) = p + len if the match at p is taken, else p + 1; the block's sequences
 // are the matches on the path from position 0.  The path is found without walking the block serially:

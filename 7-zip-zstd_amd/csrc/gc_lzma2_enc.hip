@@ -154,7 +154,7 @@ gc_lzma2_prep_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __r
 #define LZW_DIRECT 0x4000u
 // event in LDS: adaptive bit = index << 1 | bit (index < 2^13), direct bit = 0x8000 | bit
 #define LZE_DIRECT 0x8000u
-#define LZ2_EVCAP  4096u              // events buffered per round
+#define LZ2_EVCAP  2048u              // events buffered per round (26.8 KiB of LDS per wave: six waves per CU)
 #define LZ2_EVMAX  (9u * GC_LZMA_LIT_CUT + 48u)                   // most events of one item
 
 struct LzEv { uint16_t* p; uint32_t n; bool store; };
