@@ -41,7 +41,9 @@ extern "C" __global__ void gc_mf_scatter_kernel(const uint8_t*, uint64_t, uint32
 extern "C" __global__ void gc_mf_link_kernel(const uint32_t*, const GcMfEntry*, GcMfEntry*, uint32_t, uint64_t);
 extern "C" __global__ void gc_mf_verify_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
 extern "C" __global__ void gc_mf_deepen_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, uint32_t*);
-extern "C" __global__ void gc_mf_parse_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcSeqRaw*, uint8_t*, GcBlockMeta*);
+extern "C" __global__ void gc_mf_parse_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcSeqRaw*, uint8_t*, GcBlockMeta*, uint16_t*, uint32_t);
+extern "C" __global__ void gc_mf_short_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint16_t*);
+extern "C" __global__ void gc_mf_dp_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*);
 
 extern "C" __global__ void gc_lzma2_prep_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t, uint64_t*, uint32_t*);
 extern "C" __global__ void gc_lzma2_model_kernel(const uint8_t*, uint64_t, const uint64_t*, const uint32_t*, uint32_t, uint32_t, uint16_t*, GcLzmaChunkInfo*);
@@ -65,6 +67,8 @@ struct gc_ctx {
     uint32_t nParts;
     uint32_t lazyDepth;       // W6: 1 = one-step lazy, 2 = lazy2 (set per call from codec + level)
     uint32_t searchDepth;     // W5b: match links followed per position (0 = W5's two candidates only)
+    uint32_t priceParse;      // W5s + W7: price-based parse on top of the greedy one (gc_lz_price.hip)
+    uint32_t priceMinLen, priceLitCtx;        // its shortest match and literal context bits (LZMA: 2, 7; zstd: 3, 0)
     uint32_t dbgFrameBlocks, dbgPartFrames;   // test hooks (env GC_FRAME_BLOCKS / GC_PART_FRAMES): small frames / parts so that
                                               // the multi-frame and multi-part paths can be exercised on small inputs
     hipEvent_t ev[8];         // 0 lz start, 1 lz end, 2 huf end, 3 seq start, 4 seq end, 5 plan start, 6 plan end, 7 emit end
@@ -79,6 +83,7 @@ struct gc_ctx {
     uint8_t* brStage; GcBrotliBlockInfo* brInfo; GcBrotliPlan* brPlan;    // BROTLI path
     // windowed match finder (gc_mf.h): counts/offsets, partition starts, entry lists; grown on demand
     uint32_t* mfCnt; size_t mfCntCap; GcMfEntry* mfEnt; size_t mfEntCap; GcMfEntry* mfEnt2; size_t mfEnt2Cap; uint32_t* mfRec; size_t mfRecCap; uint32_t* mfRec2; size_t mfRec2Cap;
+    uint16_t* mfRec3; size_t mfRec3Cap; uint32_t* mfDp; size_t mfDpCap; uint16_t* mfPrice; size_t mfPriceCap;      // W5s records, W7 records, price tables
     hipEvent_t evMf[GC_MAX_PARTS][7];       // per part: W1 start, W1 end, W2 end, W3 end, W4 end, W5 end, W6 end
     bool mfTimed; uint32_t mfParts;
     int lastCodec;            // 0 zstd, 1 flzma2: which kernels the events of the last call bracket
@@ -153,7 +158,7 @@ extern "C" void gc_ctx_destroy(gc_ctx* c)
     hipStreamSynchronize(c->stream);
     free_workspace(c);
     hipFree(c->prof); hipFree(c->result); hipHostFree(c->hostResult); hipFree(c->dIn); hipFree(c->dOut);
-    hipFree(c->mfCnt); hipFree(c->mfEnt); hipFree(c->mfEnt2); hipFree(c->mfRec); hipFree(c->mfRec2);
+    hipFree(c->mfCnt); hipFree(c->mfEnt); hipFree(c->mfEnt2); hipFree(c->mfRec); hipFree(c->mfRec2); hipFree(c->mfRec3); hipFree(c->mfDp); hipFree(c->mfPrice);
     for (int i = 0; i < 8; i++) hipEventDestroy(c->ev[i]);
     for (uint32_t p = 0; p < GC_MAX_PARTS; p++) {
         for (int i = 0; i < 7; i++) hipEventDestroy(c->evMf[p][i]);
@@ -219,7 +224,9 @@ static int ensure_finder_workspace(gc_ctx* c, size_t n, uint32_t frameBlocks)
     const GcMfGeom g = gc_mf_geom(n, frameBlocks);
     const size_t needCnt = g.cntWords * sizeof(uint32_t), needEnt = (size_t)g.nFrames * g.frameBytes * sizeof(GcMfEntry);
     const size_t needRec = (size_t)g.nBlocks * GC_ZSTD_BLOCK_MAX * sizeof(uint32_t);
-    if (needCnt > c->mfCntCap || needEnt > c->mfEntCap || needEnt > c->mfEnt2Cap || needRec > c->mfRecCap || (c->searchDepth && needRec > c->mfRec2Cap)) {
+    const size_t needPrice = (size_t)g.nBlocks * GC_PRICE_WORDS * sizeof(uint16_t);
+    if (needCnt > c->mfCntCap || needEnt > c->mfEntCap || needEnt > c->mfEnt2Cap || needRec > c->mfRecCap || (c->searchDepth && needRec > c->mfRec2Cap) ||
+        (c->priceParse && (needRec / 2u > c->mfRec3Cap || needRec > c->mfDpCap || needPrice > c->mfPriceCap))) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         int rc;
         if ((rc = mf_grow(c, (void**)&c->mfCnt, &c->mfCntCap, needCnt, "offsets")) != GC_OK) return rc;
@@ -227,6 +234,11 @@ static int ensure_finder_workspace(gc_ctx* c, size_t n, uint32_t frameBlocks)
         if ((rc = mf_grow(c, (void**)&c->mfEnt2, &c->mfEnt2Cap, needEnt, "linked entries")) != GC_OK) return rc;
         if ((rc = mf_grow(c, (void**)&c->mfRec, &c->mfRecCap, needRec, "records")) != GC_OK) return rc;
         if (c->searchDepth && (rc = mf_grow(c, (void**)&c->mfRec2, &c->mfRec2Cap, needRec, "deepened records")) != GC_OK) return rc;
+        if (c->priceParse) {
+            if ((rc = mf_grow(c, (void**)&c->mfRec3, &c->mfRec3Cap, needRec / 2u, "short candidates")) != GC_OK) return rc;
+            if ((rc = mf_grow(c, (void**)&c->mfDp, &c->mfDpCap, needRec, "price-parse records")) != GC_OK) return rc;
+            if ((rc = mf_grow(c, (void**)&c->mfPrice, &c->mfPriceCap, needPrice, "price tables")) != GC_OK) return rc;
+        }
     }
     return GC_OK;
 }
@@ -268,7 +280,20 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
         rec = rec2;
     }
     HIPCHK(c, hipEventRecord(ev[5], st));
-    GC_LAUNCH(gc_mf_parse_kernel, perB * GC_XCDS, GC_MF_PARSE_T, st, src, (uint64_t)n, nBlocks, perB, c->lazyDepth, (const uint32_t*)rec, seqRaw, lit, meta);
+    if (c->priceParse) {
+        // greedy parse first (its symbol statistics become the block's price table), then the price-based parse W7 over the same
+        // candidates + the short ones of W5s, written as records that W6 follows as they are (lazy 0)
+        uint16_t* price = c->mfPrice + (size_t)blk0 * GC_PRICE_WORDS;
+        uint16_t* rec3 = c->mfRec3 + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
+        uint32_t* dp = c->mfDp + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
+        GC_LAUNCH(gc_mf_parse_kernel, perB * GC_XCDS, GC_MF_PARSE_T, st, src, (uint64_t)n, nBlocks, perB, c->lazyDepth, (const uint32_t*)rec, seqRaw, lit, meta, price, c->priceLitCtx);
+        const uint32_t nChunkWg = (uint32_t)(((n + 2047u) / 2048u + 3u) / 4u), perC = gc_xcd_per(nChunkWg);
+        GC_LAUNCH(gc_mf_short_kernel, perC * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, (uint32_t)((n + 2047u) / 2048u), perC, rec3);
+        const uint32_t nDpWg = nBlocks * 8u, perD = gc_xcd_per(nDpWg);
+        GC_LAUNCH(gc_mf_dp_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, c->priceMinLen, c->priceLitCtx, (const uint32_t*)rec, (const uint16_t*)rec3, (const uint16_t*)price, dp);
+        GC_LAUNCH(gc_mf_parse_kernel, perB * GC_XCDS, GC_MF_PARSE_T, st, src, (uint64_t)n, nBlocks, perB, 0u, (const uint32_t*)dp, seqRaw, lit, meta, (uint16_t*)nullptr, 0u);
+    } else
+        GC_LAUNCH(gc_mf_parse_kernel, perB * GC_XCDS, GC_MF_PARSE_T, st, src, (uint64_t)n, nBlocks, perB, c->lazyDepth, (const uint32_t*)rec, seqRaw, lit, meta, (uint16_t*)nullptr, 0u);
     HIPCHK(c, hipEventRecord(ev[6], st));
     (void)prof;
     return GC_OK;
@@ -327,6 +352,7 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
     const uint32_t frameBlocks = zstd_frame_blocks(level) < nBlocks ? zstd_frame_blocks(level) : nBlocks;   // short input: one frame
     c->lazyDepth = level >= 6 ? 2u : 1u;          // the reference's lazy2 begins at level 8 of its table; deeper look-ahead from 6 here
     c->searchDepth = zstd_search_depth(level);
+    c->priceParse = 0;
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     rc = launch_finder(c, src, n, frameBlocks, c->profOn ? c->prof : nullptr);
     if (rc != GC_OK) return rc;
@@ -411,6 +437,7 @@ extern "C" int gc_zstd_phase_profile(gc_ctx* c, double cyclesPerBlock[GC_LZ_PHAS
 // level -> model segment size (gc_lzma2.h): smaller segments = more model waves in flight (faster), more state resets (larger).
 static uint32_t flzma2_seg_log(int level)
 {
+    { const char* e = getenv("GC_SEG_LOG"); if (e) { const uint32_t v = (uint32_t)atoi(e); if (v >= GC_LZMA_SEG_LOG_MIN && v <= GC_LZMA_SEG_LOG_MAX) return v; } }   // test hook
     if (level <= 3) return 14u;
     if (level <= 5) return 15u;
     if (level <= 7) return 16u;
@@ -466,6 +493,9 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     uint32_t frameBlocks = flzma2_frame_blocks(level);
     c->lazyDepth = level >= 5 ? 2u : 1u;
     c->searchDepth = level >= 5 ? (level >= 8 ? 8u : 4u) : 0u;
+    c->priceMinLen = 2u; c->priceLitCtx = 7u;
+    c->priceParse = level >= 5 ? 1u : 0u;         // the reference's FL2_opt / FL2_ultra strategies start at level 5 (fl2_compress.c:37-104)
+    { const char* e = getenv("GC_PRICE_PARSE"); if (e) c->priceParse = (uint32_t)atoi(e); }    // test hook: 0 = greedy parse only
     if (frameBlocks > 1u && c->dbgFrameBlocks) frameBlocks = c->dbgFrameBlocks;
     if (frameBlocks > nBlocks) frameBlocks = nBlocks;
     rc = ensure_finder_workspace(c, n, frameBlocks);
@@ -607,6 +637,7 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     uint32_t frameBlocks = brotli_frame_blocks(level, bpc);
     c->lazyDepth = level >= 7 ? 2u : 1u;
     c->searchDepth = level >= 7 ? (level >= 10 ? 8u : 4u) : 0u;
+    c->priceParse = 0;
     if (frameBlocks > nBlocks) frameBlocks = nBlocks;                       // short input: one chunk, one frame
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     rc = launch_finder(c, src, n, frameBlocks, nullptr);

@@ -25,6 +25,14 @@ struct __attribute__((aligned(16))) GcU4 { uint32_t x, y, z, w; };     // one gl
 __device__ __forceinline__ uint32_t gc_hibit32(uint32_t v) { return 31u - (uint32_t)__clz((int)v); }   // v != 0
 __device__ __forceinline__ uint32_t gc_ctz64(uint64_t v) { return (uint32_t)__ffsll((long long)v) - 1u; } // v != 0
 
+// LZMA distance slot of dist = distance - 1 (C/LzmaEnc.c GetPosSlot): 2 * floor(log2 dist) + next bit
+__device__ __forceinline__ uint32_t gc_dist_slot(uint32_t dist)
+{
+    if (dist < 4u) return dist;
+    const uint32_t hb = 31u - (uint32_t)__clz((int)dist);
+    return 2u * hb + ((dist >> (hb - 1u)) & 1u);
+}
+
 // value known to be identical in every lane of the wave -> keep it in an SGPR
 __device__ __forceinline__ uint32_t gc_uniform(uint32_t v)
 {
@@ -86,6 +94,29 @@ __device__ __forceinline__ uint32_t gc_readlane(uint32_t v, uint32_t lane)
     return __shfl(v, (int)lane);
 #else
     return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)__builtin_amdgcn_readfirstlane((int)lane));
+#endif
+}
+
+// Wave-wide shift by one lane towards lane 0: lane t receives the value of lane t + 1, lane 63 receives `fill`.
+// One DPP move (wave_shl:1, a GFX9 control) -- no LDS crossbar, no index registers.
+__device__ __forceinline__ uint32_t gc_wave_shl1(uint32_t v, uint32_t fill)
+{
+#ifdef HIPEMU
+    const uint32_t o = __shfl_down(v, 1);
+    return (__lane_id() & 63u) == 63u ? fill : o;
+#else
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+#endif
+}
+// write the wave-uniform value `s` into lane `lane` (wave-uniform) of `v`: one v_writelane_b32
+__device__ __forceinline__ uint32_t gc_writelane(uint32_t v, uint32_t s, uint32_t lane)
+{
+#ifdef HIPEMU
+    return (__lane_id() & 63u) == (lane & 63u) ? s : v;
+#else
+    // (this compiler has no writelane builtin; the lane select travels in M0 because a VOP3 instruction reads one SGPR only)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane((int)s)), "s"(__builtin_amdgcn_readfirstlane((int)lane)) : "m0");
+    return v;
 #endif
 }
 

@@ -1,0 +1,269 @@
+// gc_lz_price.hip -- price-based ("optimal") parse on top of the windowed match finder: W5s short candidates + W7 shortest path.
+//
+// Replaces the optimal parsers of the reference for the levels that use them: LZMA_optimalParse / LZMA_encodeOptimumSequence of
+// Fast-LZMA2 (C/fast-lzma2/lzma2_enc.c:949, :1443; level 5 and up are FL2_opt / FL2_ultra, fl2_compress.c:37-104) and, with
+// other price tables, ZSTD_compressBlock_opt_generic (C/zstd/zstd_opt.c:1077).  What those do: a forward dynamic programme
+// over positions -- the cheapest way to reach every position, where a step is a literal or any prefix (length >= 2) of a match
+// candidate, priced with the entropy coder's current statistics -- in buffers of 2-4 K positions, strictly serial.
+//
+// Here (measured first on the CPU with tools/lzma_parse_lab.c: what each simplification costs in compressed size):
+//   - prices are STATIC per 128 KiB block: W6 parses the block greedily first and turns the symbol statistics of that parse
+//     into price tables (literal given the top bits of the previous byte, piece length, distance slot, literal/match flag);
+//     costs 0.1-0.8 % against prices taken from the adapting model, and makes every edge weight a pure function of the
+//     position -- no coder state, no repeat-distance history travels along the path
+//   - the unit is a WINDOW of 4 KiB (= one LZMA2 chunk / range-coder run, which no match crosses anyway): 32 independent
+//     shortest-path problems per block, one WAVE each
+//   - candidates per position: the finder's best match (any prefix of its <= 64 bytes) and a SHORT candidate (most recent
+//     position within ~2-4 KiB with the same 3 bytes, lengths 2..17: W5s) -- what the reference gets from its 2-byte radix heads;
+//     worth 1.4-3.7 % on binary data, nothing on text
+//   - a match that fills the 64-byte cap is taken whole (the reference's fast-length rule) and the piece behind it with the
+//     same distance is priced as its continuation
+//
+// W7 on the hardware: the open nodes of the programme are the next 64 positions -- ONE VGPR: while node i is expanded, lane t
+// holds node i + t.  Lane t owns the edge of length t + 1 (so its length price is a loop invariant) and relaxes it into its own
+// register after a one-lane DPP shift: no LDS, no atomics; per position a handful of VALU operations (a wave64 operation
+// occupies its SIMD for four cycles: what the kernel costs is the number of vector instructions per node), the rest is scalar.
+// A node is cost << 8 | kind << 6 | (length - 1), so the minimum carries its back pointer.  Back pointers of a window live in
+// 4 KiB of LDS.
+#include "gc_mf.h"
+#include "gc_lz_parse.h"
+
+__device__ __forceinline__ uint32_t ps_item(uint32_t bid, uint32_t per) { return (bid & (GC_XCDS - 1u)) * per + (bid >> 3); }
+
+// ------------------------------------------------------------------------------------------------ W5s short candidates
+// One wave per 2 KiB chunk, private table of 2^11 slots in LDS; the 2 KiB in front of the chunk (same frame) are inserted first.
+// Per step 64 positions and one returning ds_max: the LDS unit serves the lanes in lane order, so a lane gets the most recent
+// earlier position with its hash (same mechanism as W4).  Output: uint16 per position, (distance - 1) << 4 | (length - 2),
+// GC_SHORT_NONE = no candidate.  Positions whose 17 bytes do not lie inside their block have none (keeps frames independent of
+// what follows them).
+#define SH_T        256u
+#define SH_WAVES    (SH_T / 64u)
+#define SH_CHUNK    2048u
+#define SH_SLOT_LOG 11u
+#define SH_MAXLEN   17u
+#define SH_STAGE_WORDS ((2u * SH_CHUNK + 32u) / 4u)
+
+__device__ __forceinline__ uint32_t sh_lds_ld32(const uint32_t* sW, uint32_t i)     // bytes i .. i+3 of the staged window
+{
+    const uint32_t w = i >> 2, sh = (i & 3u) * 8u;
+    return (uint32_t)((((uint64_t)sW[w + 1u] << 32) | sW[w]) >> sh);
+}
+
+extern "C" __global__ void __launch_bounds__(SH_T)
+gc_mf_short_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nChunks, uint32_t per, uint16_t* __restrict__ rec3)
+{
+    __shared__ uint32_t sTab[SH_WAVES][1u << SH_SLOT_LOG];
+    __shared__ uint32_t sW[SH_WAVES][SH_STAGE_WORDS];
+    const uint32_t lane = threadIdx.x & 63u, wave = gc_uniform(threadIdx.x >> 6);    // (uniform: everything derived from it stays scalar)
+    const uint32_t chunk = ps_item(blockIdx.x, per) * SH_WAVES + wave;
+    if (chunk >= nChunks) return;                                 // no workgroup barrier below: waves are independent
+    const uint64_t cs = (uint64_t)chunk * SH_CHUNK;
+    const uint64_t frameBytes = (uint64_t)frameBlocks * GC_ZSTD_BLOCK_MAX;
+    const uint64_t frameStart = cs / frameBytes * frameBytes;
+    const uint32_t warm = cs > frameStart ? SH_CHUNK : 0u;
+    const uint64_t ws = cs - warm;                                // window start (absolute)
+    const uint64_t blockEnd = ((cs / GC_ZSTD_BLOCK_MAX + 1u) * GC_ZSTD_BLOCK_MAX) < srcSize ? (cs / GC_ZSTD_BLOCK_MAX + 1u) * GC_ZSTD_BLOCK_MAX : srcSize;
+    uint32_t* tab = sTab[wave];
+    uint32_t* W = sW[wave];
+    for (uint32_t i = lane; i < (1u << SH_SLOT_LOG); i += 64u) tab[i] = 0;
+    for (uint32_t c = lane; c < SH_STAGE_WORDS / 4u; c += 64u) {  // 16 bytes per lane; zero past the end of the input
+        GcU4 v; v.x = v.y = v.z = v.w = 0;
+        const uint64_t pos = ws + 16ull * c;
+        if (pos + 16u <= srcSize) __builtin_memcpy(&v, src + pos, 16);
+        else if (pos < srcSize) { uint8_t tmp[16]; for (uint32_t k = 0; k < 16u; k++) tmp[k] = pos + k < srcSize ? src[pos + k] : (uint8_t)0; __builtin_memcpy(&v, tmp, 16); }
+        W[4u * c] = v.x; W[4u * c + 1u] = v.y; W[4u * c + 2u] = v.z; W[4u * c + 3u] = v.w;
+    }
+    gc_wave_sync();
+    const uint32_t nPos = warm + SH_CHUNK;
+    for (uint32_t q0 = 0; q0 < nPos; q0 += 64u) {
+        const uint32_t q = q0 + lane;                             // window-relative
+        const uint64_t P = ws + q;
+        const bool listed = P + SH_MAXLEN <= blockEnd;
+        const uint32_t x = sh_lds_ld32(W, q) & 0xFFFFFFu;
+        const uint32_t h = x * 0x9E3779B1u;
+        const uint32_t mine = ((q + 1u) << 8) | ((h >> 13) & 0xFFu);
+        uint32_t seen = 0;
+        if (listed) seen = atomicMax(&tab[h >> (32u - SH_SLOT_LOG)], mine);
+        gc_wave_step();
+        if (q0 < warm) continue;                                  // uniform: the warm-up only inserts
+        uint32_t out = GC_SHORT_NONE;
+        if (listed && seen != 0u && seen < mine && ((seen ^ mine) & 0xFFu) == 0u) {
+            const uint32_t c = (seen >> 8) - 1u;                  // candidate, window-relative, c < q
+            uint32_t len = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 20u; k += 4u) {
+                if (len == k) { const uint32_t d = sh_lds_ld32(W, q + k) ^ sh_lds_ld32(W, c + k); len += d ? (uint32_t)(__ffs((int)d) - 1) >> 3 : 4u; }
+            }
+            if (len > SH_MAXLEN) len = SH_MAXLEN;
+            if (len >= 2u && q - c <= 4095u) out = ((q - c - 1u) << 4) | (len - 2u);
+        }
+        if (P < srcSize) rec3[P] = (uint16_t)out;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ W7 shortest path
+#define DP_T       256u
+#define DP_WAVES   (DP_T / 64u)
+#define DP_WIN_LOG 12u
+#define DP_WIN     (1u << DP_WIN_LOG)
+#define DP_WINS_PER_BLOCK (GC_ZSTD_BLOCK_MAX >> DP_WIN_LOG)
+#define DP_ROWS    (DP_WIN / 64u + 1u)
+#define DP_INF     0xFFFFFFFFu
+#define DP_CONT_PRICE 4u               // continuation of a capped match: a quarter of a bit
+#define DP_MAX_MATCHES (DP_WIN / GC_MIN_MATCH)                    // matches per window that the sequence arrays are sure to hold
+
+// node word: cost << 8 | kind << 6 | (length - 1);  kind 0 literal (length 1), 1 finder candidate, 2 short candidate.
+// The low byte is the back pointer; a price in word units is price << 8.
+#define DP_KIND1   (1u << 6)
+#define DP_KIND2   (2u << 6)
+
+extern "C" __global__ void __launch_bounds__(DP_T)
+gc_mf_dp_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t minLen /* 2 LZMA, 3 zstd */,
+                uint32_t litCtxMask /* bits of (previous byte >> 5) that select the literal price row: 7 LZMA (lc = 3), 0 zstd */,
+                const uint32_t* __restrict__ rec, const uint16_t* __restrict__ rec3, const uint16_t* __restrict__ priceTab, uint32_t* __restrict__ recOut)
+{
+    __shared__ uint16_t sPrice[GC_PRICE_WORDS];
+    __shared__ uint8_t sRow[DP_WAVES][DP_ROWS][64];               // back pointers by end node, later edges by start node
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = gc_uniform(t >> 6);        // (uniform: the node index i must live in an SGPR)
+    // a workgroup = DP_WAVES consecutive windows of one block
+    const uint32_t item = ps_item(blockIdx.x, per);
+    const uint32_t b = item / (DP_WINS_PER_BLOCK / DP_WAVES);
+    if (b >= nBlocks) return;
+    const uint32_t win = (item % (DP_WINS_PER_BLOCK / DP_WAVES)) * DP_WAVES + wave;
+    { const GcU4* T4 = (const GcU4*)(priceTab + (uint64_t)b * GC_PRICE_WORDS); GcU4* S4 = (GcU4*)sPrice;
+      for (uint32_t i = t; i < GC_PRICE_WORDS / 8u; i += DP_T) S4[i] = T4[i]; }
+    __syncthreads();
+    const uint64_t base = (uint64_t)b * GC_ZSTD_BLOCK_MAX;
+    const uint32_t blockLen = (uint32_t)((srcSize - base) < GC_ZSTD_BLOCK_MAX ? (srcSize - base) : GC_ZSTD_BLOCK_MAX);
+    const uint32_t w0 = win << DP_WIN_LOG;
+    if (w0 >= blockLen) return;
+    const uint32_t n = (blockLen - w0) < DP_WIN ? (blockLen - w0) : DP_WIN;          // nodes 0 .. n
+    const uint32_t* R = rec + base + w0;
+    const uint16_t* R3 = rec3 + base + w0;
+    const uint8_t* S = src + base + w0;
+    uint8_t (*row)[64] = sRow[wave];
+    const uint32_t flagLit = sPrice[GC_PRICE_FLAGS], flagMat = sPrice[GC_PRICE_FLAGS + 1u];
+
+    // Lane t holds node i + t while node i is expanded (lane 0 = node i, final), and owns the edge of length t + 1: its length
+    // price is a loop invariant.  After the expansion the register is shifted by one lane (DPP), node i + 64 enters at lane 63.
+    // What the loop costs is its instruction count -- a wave issues at most one instruction per four cycles, vector or scalar --
+    // so everything that depends on the position only is prepared 64 positions at a time (lane = position) as ready-made word
+    // addends, and a step is: read node i, two scalar adds, shift, two vector adds, two compares + selects, two minima.
+    const uint32_t X1 = ((uint32_t)sPrice[GC_PRICE_LEN + lane + 1u] << 8) | DP_KIND1 | lane;     // length price + back pointer of this lane's edge
+    const uint32_t X2 = (X1 & ~0xC0u) | DP_KIND2;
+    const uint32_t capAdd = ((uint32_t)sPrice[GC_PRICE_LEN + GC_MATCH_CAP] << 8) | DP_KIND1 | (GC_MATCH_CAP - 1u);
+    uint32_t ring = lane == 0u ? 0u : DP_INF;                     // node 0: cost 0
+    uint32_t cc = 0;                                              // back pointers of the current group's nodes (lane = node mod 64)
+    uint32_t curG = 0xFFFFFFFFu;
+    bool contNext = false; uint32_t contOff = 0;                  // the node being expanded is the end of a capped match with this distance
+    GcPub pL, pA, pL3, pA3, pC, pD;       // per position of the group: candidate lengths, word addends (distance price), literal addend, distance
+    // raw inputs of the NEXT group, requested one group (64 nodes) ahead of their use
+    uint32_t nR = 0, nR3 = GC_SHORT_NONE, nByte = 0, nPrev = 0;
+    if (lane < n) { nR = R[lane]; nR3 = R3[lane]; nByte = S[lane]; nPrev = (base + w0 + lane) ? (uint32_t)S[(int64_t)lane - 1] : 0u; }
+    uint32_t i = 0;
+    while (i < n) {
+        const uint32_t g = i >> 6, k = i & 63u;
+        if (g != curG) {                                          // uniform: new group of 64 positions
+            if (curG != 0xFFFFFFFFu) row[curG][lane] = (uint8_t)cc;
+            cc = 0; curG = g;
+            const uint32_t p = (g << 6) + lane;                   // window-relative
+            uint32_t L = 0, A = 0, L3 = 0, A3 = 0, C = 0, D = 0;
+            if (p < n) {
+                const uint32_t r = nR, r3 = nR3;
+                uint32_t l = r & 0xFFu, off = r >> 8;
+                if (l > n - p) l = n - p;
+                if (l >= minLen) { const uint32_t sl = gc_dist_slot(off - 1u); L = l; A = (flagMat + sPrice[GC_PRICE_SLOT + sl] + (sl >= 4u ? 16u * ((sl >> 1) - 1u) : 0u)) << 8; D = off; }
+                if (r3 != GC_SHORT_NONE) {
+                    uint32_t l3 = (r3 & 15u) + 2u; const uint32_t off3 = (r3 >> 4) + 1u;
+                    if (l3 > n - p) l3 = n - p;
+                    if (l3 >= minLen && !(l >= l3 && off <= off3)) { const uint32_t sl = gc_dist_slot(off3 - 1u); L3 = l3; A3 = (flagMat + sPrice[GC_PRICE_SLOT + sl] + (sl >= 4u ? 16u * ((sl >> 1) - 1u) : 0u)) << 8; }
+                }
+                C = (flagLit + sPrice[GC_PRICE_LIT + (((nPrev >> 5) & litCtxMask) << 8) + nByte]) << 8;
+            }
+            gc_publish(pL, L); gc_publish(pA, A); gc_publish(pL3, L3); gc_publish(pA3, A3); gc_publish(pC, C); gc_publish(pD, D);
+            const uint32_t pn = p + 64u;
+            if (pn < n) { nR = R[pn]; nR3 = R3[pn]; nByte = S[pn]; nPrev = S[pn - 1u]; }
+        }
+        const uint32_t w = gc_readlane(ring, 0u);                 // node i: final
+        cc = gc_writelane(cc, w, k);                              // (its low byte is the back pointer)
+        const uint32_t costw = w & ~0xFFu;                        // cost in word units
+        const uint32_t L = gc_peek(pL, k);
+        if (contNext || L == GC_MATCH_CAP) {                      // uniform, rare: end and / or start of a capped match
+            const bool cont = contNext && L != 0u && gc_peek(pD, k) == contOff;
+            contNext = false;
+            if (L == GC_MATCH_CAP) {                              // take the capped match whole (L is clipped to the window)
+                const uint32_t c = costw + (cont ? (DP_CONT_PRICE << 8) | DP_KIND1 | (GC_MATCH_CAP - 1u) : gc_peek(pA, k) + capAdd);
+                ring = lane == 0u ? c : DP_INF;                   // node i + 64 is the only open node
+                contNext = true; contOff = gc_peek(pD, k);
+                i += GC_MATCH_CAP;
+                continue;
+            }
+            if (cont) {                                           // the piece behind a capped match: same price for every length
+                ring = gc_wave_shl1(ring, DP_INF);
+                uint32_t cand = lane < L ? costw + ((DP_CONT_PRICE << 8) | DP_KIND1 | lane) : DP_INF;
+                cand = gc_writelane(cand, costw + gc_peek(pC, k), 0u);
+                if (minLen > 2u) cand = gc_writelane(cand, DP_INF, 1u);
+                ring = cand < ring ? cand : ring;
+                i++;
+                continue;
+            }
+        }
+        ring = gc_wave_shl1(ring, DP_INF);                        // lane t: node i + 1 + t, the end of this lane's edge
+        const uint32_t w1 = X1 + (costw + gc_peek(pA, k));
+        uint32_t cand = lane < L ? w1 : DP_INF;
+        const uint32_t L3 = gc_peek(pL3, k);
+        if (L3 != 0u) {                                           // uniform
+            const uint32_t w2 = X2 + (costw + gc_peek(pA3, k));
+            cand = (lane < L3 && w2 < cand) ? w2 : cand;
+        }
+        cand = gc_writelane(cand, costw + gc_peek(pC, k), 0u);    // lane 0: the literal (kind 0, length 1)
+        if (minLen > 2u) cand = gc_writelane(cand, DP_INF, 1u);   // zstd: no matches of two bytes
+        ring = cand < ring ? cand : ring;
+        i++;
+    }
+    // node n (i == n; a forced jump never passes n): lane 0
+    {
+        const uint32_t g = n >> 6, k = n & 63u;
+        if (g != curG) { if (curG != 0xFFFFFFFFu) row[curG][lane] = (uint8_t)cc; cc = 0; curG = g; }
+        cc = gc_writelane(cc, gc_readlane(ring, 0u), k);
+        row[curG][lane] = (uint8_t)cc;
+    }
+    gc_wave_sync();
+    // ---- walk back from node n; the rows are rewritten in place: lane of the START position of every match on the path <- its byte
+    uint32_t nMatch = 0;
+    {
+        uint32_t j = n, q = n >> 6;
+        uint32_t cg = row[q][lane], fg = 0;
+        while (j > 0u) {
+            const uint32_t c = gc_readlane(cg, j & 63u);
+            const uint32_t s = j - ((c & 63u) + 1u), qs = s >> 6;
+            if (qs != q) { row[q][lane] = (uint8_t)fg; gc_wave_sync(); q = qs; cg = row[q][lane]; fg = 0; }
+            if ((c >> 6) != 0u) { nMatch++; fg = gc_writelane(fg, c, s & 63u); }
+            j = s;
+        }
+        row[q][lane] = (uint8_t)fg;
+        gc_wave_sync();
+    }
+    // ---- the window's parse as records: a match where the path takes one, 0 (literal) elsewhere
+    //      The sequence arrays behind W6 hold GC_MAX_SEQ_PER_BLOCK = 128 KiB / 5 entries per block.  A path of many 2-4 byte
+    //      matches could exceed that, so a window whose path has more than its share (DP_MAX_MATCHES = 4096 / 5) falls back to the
+    //      finder's own records, clipped to the window: followed from the window start they are matches of >= GC_MIN_MATCH bytes
+    //      (but the last one), i.e. within the share.
+    const bool fallback = nMatch > DP_MAX_MATCHES;                // uniform
+    uint32_t* RO = recOut + base + w0;
+    for (uint32_t q = 0; (q << 6) < n; q++) {
+        const uint32_t p = (q << 6) + lane;
+        if (p >= n) break;
+        const uint32_t c = row[q][lane];
+        uint32_t out = 0;
+        if (fallback) {
+            const uint32_t r = R[p];
+            uint32_t L = r & 0xFFu; if (L > n - p) L = n - p;
+            out = L >= minLen ? ((r & ~0xFFu) | L) : 0u;
+        } else if (c != 0u) {
+            const uint32_t off = (c >> 6) == 1u ? R[p] >> 8 : ((uint32_t)R3[p] >> 4) + 1u;
+            out = (off << 8) | ((c & 63u) + 1u);
+        }
+        RO[p] = out;
+    }
+}

@@ -555,7 +555,7 @@ gc_mf_deepen_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t 
 
 struct PzSeg { uint32_t r0; bool take; uint32_t nxt; };
 // record, lazy decision and next pointer of position p = seg * 64 + lane (R = records of the block, n = block length).
-// lazy: 1 = give the match at p up if the one at p + 1 is clearly better (ZSTD_compressBlock_lazy, zstd_lazy.c:1516; brotli's
+// lazy: 0 = follow the records as they are (they already are a parse: W7 wrote them); 1 = give the match at p up if the one at p + 1 is clearly better (ZSTD_compressBlock_lazy, zstd_lazy.c:1516; brotli's
 // one-step lazy matching, backward_references_inc.h:80-130); 2 = also look at p + 2 (lazy2).  The decision only looks ahead,
 // never at decisions made for other positions, so it stays a pure function of the records.
 __device__ __forceinline__ PzSeg pz_seg(const uint32_t* __restrict__ R, uint32_t p, uint32_t n, uint32_t lane, uint32_t lazy)
@@ -566,7 +566,7 @@ __device__ __forceinline__ PzSeg pz_seg(const uint32_t* __restrict__ R, uint32_t
     const uint32_t len = s.r0 & 0xFFu, l1 = r1 & 0xFFu;
     s.take = len != 0u;
     const int g0 = lz_gain(len, s.r0 >> 8);
-    if (s.take && l1 > len && lz_gain(l1, r1 >> 8) > g0 + 4) s.take = false;
+    if (lazy >= 1u && s.take && l1 > len && lz_gain(l1, r1 >> 8) > g0 + 4) s.take = false;
     if (lazy >= 2u) {
         const uint32_t r2 = p + 2u < n ? R[p + 2u] : 0u;
         const uint32_t l2 = r2 & 0xFFu;
@@ -584,10 +584,30 @@ __device__ __forceinline__ uint32_t pz_exit(uint32_t nxt)
     return cur;                                                   // 64 .. 127
 }
 
+// price = 16 * log2(den / num), clamped to [1, GC_PRICE_MAX]: integer arithmetic only, so that the emulator build and the GPU
+// produce the same tables (and with them the same parse, byte for byte)
+__device__ __forceinline__ uint32_t pz_log2_q8(uint32_t x)       // 256 * log2(x), x >= 1; error < 0.01 bit
+{
+    const uint32_t e = gc_hibit32(x);
+    const uint32_t f = ((x << (31u - e)) >> 15) & 0xFFFFu;         // mantissa - 1 in Q16
+    const uint32_t t = (f * (65536u - f)) >> 16;
+    const uint32_t frac = f + ((t * 22713u) >> 16);                // log2(1 + f) ~ f + 0.3466 f (1 - f)
+    return (e << 8) + (frac >> 8);
+}
+__device__ __forceinline__ uint32_t pz_price(uint32_t num, uint32_t den)
+{
+    const uint32_t a = pz_log2_q8(den), b = pz_log2_q8(num);
+    uint32_t pr = a > b ? (a - b + 8u) >> 4 : 0u;
+    if (pr < 1u) pr = 1u;
+    return pr > GC_PRICE_MAX ? GC_PRICE_MAX : pr;
+}
+
 extern "C" __global__ void __launch_bounds__(PZ_T)
 gc_mf_parse_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t lazy, const uint32_t* __restrict__ rec,
-                   GcSeqRaw* __restrict__ seqRaw, uint8_t* __restrict__ lit, GcBlockMeta* __restrict__ meta)
+                   GcSeqRaw* __restrict__ seqRaw, uint8_t* __restrict__ lit, GcBlockMeta* __restrict__ meta, uint16_t* __restrict__ priceTab,
+                   uint32_t litCtxMask /* price statistics: bits of (previous byte >> 5) that select the literal row */)
 {
+    __shared__ uint32_t sStat[GC_PRICE_WORDS];                    // symbol statistics of this parse (only when priceTab != nullptr)
     __shared__ uint8_t  sGExit[PZ_GROUPS][64];
     __shared__ uint32_t sEntry[PZ_GROUPS];
     __shared__ uint32_t sGSeq[PZ_GROUPS], sGLit[PZ_GROUPS];      // phase 3a: counts; then exclusive prefix
@@ -603,6 +623,8 @@ gc_mf_parse_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t n
     uint8_t* myLit = lit + (uint64_t)b * GC_ZSTD_BLOCK_MAX;
     const uint8_t* bsrc = src + base;
 
+    const bool stats = priceTab != nullptr;
+    if (stats) for (uint32_t i = t; i < GC_PRICE_WORDS; i += PZ_T) sStat[i] = 0;
     // ---- phase 1: group exit maps
     for (uint32_t g = wave; g < nGroups; g += PZ_WAVES) {
         uint32_t comp = lane;                                     // where the path that enters the group at lane `lane` stands
@@ -673,9 +695,41 @@ gc_mf_parse_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t n
             if ((mS >> lane) & 1ull) {
                 GcSeqRaw r; r.litRank = myLitRank; r.offml = R[p];
                 mySeq[seqRun + (uint32_t)__popcll(mS & lt)] = r;
+                if (stats) { atomicAdd(&sStat[GC_PRICE_LEN + (r.offml & 0xFFu)], 1u); atomicAdd(&sStat[GC_PRICE_SLOT + gc_dist_slot((r.offml >> 8) - 1u)], 1u); }
             }
-            if ((mL >> lane) & 1ull) myLit[myLitRank] = bsrc[p];
+            if ((mL >> lane) & 1ull) {
+                const uint32_t byte = bsrc[p];
+                myLit[myLitRank] = (uint8_t)byte;
+                if (stats) atomicAdd(&sStat[GC_PRICE_LIT + ((((base + p) ? (uint32_t)bsrc[(int64_t)p - 1] >> 5 : 0u) & litCtxMask) << 8) + byte], 1u);
+            }
             seqRun += (uint32_t)__popcll(mS); litRun += (uint32_t)__popcll(mL);
         }
+    }
+    if (!stats) return;
+    // ---- statistics -> static prices of this block for the price-based parse W7 (units of 1/16 bit):
+    //      literal given the top 3 bits of the byte in front of it, piece length, distance slot, literal / match flag
+    __shared__ uint32_t sSum[12];
+    __syncthreads();
+    if (wave < 10u) {                                             // row sums: 8 literal contexts, lengths, slots
+        uint32_t a = 0;
+        if (wave < 8u) for (uint32_t i = lane; i < 256u; i += 64u) a += sStat[GC_PRICE_LIT + wave * 256u + i];
+        else if (wave == 8u) for (uint32_t i = lane; i < GC_PRICE_NLEN; i += 64u) a += sStat[GC_PRICE_LEN + i];
+        else a = sStat[GC_PRICE_SLOT + lane];
+        a = gc_wave_sum(a);
+        if (lane == 0) sSum[wave] = a;
+    }
+    __syncthreads();
+    uint32_t nLit = 0; for (uint32_t c = 0; c < 8u; c++) nLit += sSum[c];
+    const uint32_t nMat = sSum[8];
+    uint16_t* T = priceTab + (uint64_t)b * GC_PRICE_WORDS;
+    for (uint32_t i = t; i < GC_PRICE_WORDS; i += PZ_T) {
+        uint32_t pr;
+        if (i < GC_PRICE_LEN) pr = pz_price(10u * sStat[i] + 3u, 10u * sSum[i >> 8] + 768u);
+        else if (i < GC_PRICE_SLOT) pr = pz_price(2u * sStat[i] + 1u, 2u * nMat + 63u);
+        else if (i < GC_PRICE_FLAGS) pr = pz_price(2u * sStat[i] + 1u, 2u * nMat + 44u);
+        else if (i == GC_PRICE_FLAGS) pr = pz_price(nLit + 1u, nLit + nMat + 2u);          // "this symbol is a literal"
+        else if (i == GC_PRICE_FLAGS + 1u) pr = pz_price(nMat + 1u, nLit + nMat + 2u);     // "this symbol is a match"
+        else pr = 0;
+        T[i] = (uint16_t)pr;
     }
 }

@@ -73,6 +73,17 @@ static inline GcMfGeom gc_mf_geom(uint64_t n, uint32_t frameBlocks)
 // ends, so run (tile, g) = [row[tile][g], row[tile + 1][g]) for every tile.
 // entries: [frame][frameBytes]
 
+// Static prices of one block for the price-based parse W7 (gc_lz_price.hip), written by W6 from the statistics of its own
+// (greedy) parse of the block; uint16, units of 1/16 bit.  The same index space is used for the counts inside W6.
+#define GC_PRICE_LIT    0u                 // [8 contexts = top 3 bits of the previous byte][256]
+#define GC_PRICE_LEN    2048u              // [piece length 0..64] (0, 1 unused)
+#define GC_PRICE_NLEN   80u
+#define GC_PRICE_SLOT   (GC_PRICE_LEN + GC_PRICE_NLEN)            // [LZMA distance slot 0..63] (without the footer bits)
+#define GC_PRICE_FLAGS  (GC_PRICE_SLOT + 64u)                     // literal flag, match flag
+#define GC_PRICE_WORDS  (GC_PRICE_FLAGS + 8u)                     // 2200: a multiple of 8 (16-byte rows)
+#define GC_PRICE_MAX    240u               // 15 bits: literal + flag of 4096 positions stay below 2^21 units (the cost field of a W7 node)
+#define GC_SHORT_NONE   0xFFFFu            // W5s -> W7: uint16 per position, (distance - 1) << 4 | (length - 2), or none
+
 // Workgroup index -> work item such that each of the 8 XCDs (workgroups are dealt round-robin to XCDs) owns one contiguous
 // range of items: neighbouring tiles / blocks then share an L2.  The grid is 8 * per workgroups, per = ceil(n / 8).
 #define GC_XCDS 8u

@@ -32,9 +32,11 @@ static float g_cost[2048 + 1];          /* -log2(p/2048) */
 typedef struct { uint16_t p[NPROB]; } Model;
 static void model_reset(Model* m) { for (int i = 0; i < NPROB; i++) m->p[i] = 1024; }
 typedef struct { Model* m; int update; double bits; } Enc;
+int g_counting = 0; static u32 cnt0[NPROB], cnt1[NPROB];
 static inline void ebit(Enc* e, u32 idx, u32 bit)
 {
     u32 p = e->m->p[idx];
+    if (g_counting) { if (bit) cnt1[idx]++; else cnt0[idx]++; }
     e->bits += bit ? g_cost[2048 - p] : g_cost[p];
     if (e->update) e->m->p[idx] = (uint16_t)(bit ? p - (p >> 5) : p + ((2048 - p) >> 5));
 }
@@ -177,6 +179,7 @@ static void parse_greedy(int lazy)
 static double price_syms(int segLog, int rcLog, double* hdrBytes)
 {
     static Model m; Enc e; e.m = &m; e.update = 1; e.bits = 0;
+    { u32 j = 0; for (u32 i = 0; i < nSyms; i++) { if (j && syms[j - 1].pos + syms[j - 1].len == syms[i].pos && syms[j - 1].off == syms[i].off) syms[j - 1].len += syms[i].len; else syms[j++] = syms[i]; } nSyms = j; }   /* L1 merges adjacent pieces of one match */
     St s; u32 p = 0, k = 0; u32 segSize = 1u << segLog;
     u32 nRep = 0, nMatch = 0, nLit = 0, nShort = 0;
     for (u32 ss = 0; ss < N; ss += segSize) {
@@ -302,6 +305,162 @@ static void parse_optimal(int segLog, int use3, int allLens)
     free(nd);
 }
 
+
+/* ---------------------------------------------------------------- the GPU-feasible DP ("W7") restated on the CPU
+ * Differences from parse_optimal that the GPU design needs:
+ *   - static prices: one probability set per 128 KiB block, counted from the symbols of a first greedy parse of that block
+ *   - independent windows of 4 KiB (= rc chunks; matches never cross them): coder state and repeat distances unknown at the start
+ *   - repeat distances are only recognised by equality with the candidate's distance (no path-dependent memory compares), plus
+ *     the precomputed continuation behind every record: match(d, L) + literal + rep0(d, c)
+ *   - no short rep; matched literals priced exactly or as plain literals (flag) */
+typedef struct { int staticPrices, win, repCompare, composite, shortRep, litPlain, use3, maxLenCap, repDetect, d3max, simpleState; } DpCfg;
+static Model g_blockModel; static u32 g_blockModelFor = 0xFFFFFFFFu;
+typedef struct { Model* m; } CountSink;
+static void count_block(u32 b0, u32 b1)          /* events of the greedy symbols inside [b0, b1) -> static probabilities */
+{
+    memset(cnt0, 0, sizeof cnt0); memset(cnt1, 0, sizeof cnt1);
+    /* run the symbol list with a model that records counts: emulate by encoding with update into a scratch model while counting */
+    static Model scratch; model_reset(&scratch);
+    Enc e; e.m = &scratch; e.update = 0; e.bits = 0;
+    /* we need the event indices: re-implement via a hook -- simplest: temporarily use probabilities as event recorders */
+    /* (hook: p[idx] is left at 1024; counts are collected in ebit_count below) */
+    g_counting = 1;
+    St s; s.st = 0; s.rep[0] = s.rep[1] = s.rep[2] = s.rep[3] = 1;
+    u32 k = 0; while (k < nSyms && syms[k].pos + syms[k].len <= b0) k++;
+    u32 p = b0;
+    while (p < b1) {
+        if (k < nSyms && syms[k].pos <= p) {
+            u32 sp = syms[k].pos, len = syms[k].len, off = syms[k].off;
+            if (sp < p) { len -= p - sp; }
+            if (len > b1 - p) len = b1 - p;
+            k++;
+            while (len >= 2) { u32 take = len < 273 ? len : 273; if (len - take == 1) take--; u32 kind = 1; for (u32 r = 0; r < 4; r++) if (s.rep[r] == off) { kind = 3 + r; break; }
+                e_symbol(&e, &s, p, kind, take, off); p += take; len -= take; }
+            if (len == 1) { e_symbol(&e, &s, p, 0, 0, 0); p++; }
+        } else { e_symbol(&e, &s, p, 0, 0, 0); p++; }
+    }
+    g_counting = 0;
+    for (int i = 0; i < NPROB; i++) { u32 a = cnt0[i], b = cnt1[i]; u32 pr = (a + b) ? (u32)(2048.0 * (a + 0.4) / (a + b + 0.8)) : 1024; if (pr < 31) pr = 31; if (pr > 2017) pr = 2017; g_blockModel.p[i] = (uint16_t)pr; }
+}
+typedef struct { float cost; u32 prev; u32 len; u32 off; u32 len2; u8 kind; St s; } Node2;   /* kind 9 = composite: match(off,len) lit rep0(len2) */
+static void dp_relax(Node2* nd, u32 to, float c, u32 from, u8 kind, u32 len, u32 off, u32 len2, const St* t)
+{ if (c < nd[to].cost) { nd[to].cost = c; nd[to].prev = from; nd[to].kind = kind; nd[to].len = len; nd[to].off = off; nd[to].len2 = len2; nd[to].s = *t; } }
+static void parse_dp_gpu(DpCfg cfg, int greedyLazy)
+{
+    static Model madapt;
+    parse_greedy(greedyLazy);
+    Sym* g = malloc(sizeof(Sym) * (nSyms + 1)); u32 ng = nSyms; memcpy(g, syms, sizeof(Sym) * nSyms);
+    Sym* out = malloc(sizeof(Sym) * (N / 2 + 16)); u32 nOut = 0;
+    Node2* nd = malloc(sizeof(Node2) * (cfg.win + 2));
+    Enc pe; pe.update = 0;
+    for (u32 b0 = 0; b0 < N; b0 += (128u << 10)) {
+        u32 b1 = b0 + (128u << 10) < N ? b0 + (128u << 10) : N;
+        memcpy(syms, g, sizeof(Sym) * ng); nSyms = ng;
+        if (cfg.staticPrices) { count_block(b0, b1); pe.m = &g_blockModel; } else { model_reset(&madapt); pe.m = &madapt; }
+        for (u32 w0 = b0; w0 < b1; w0 += cfg.win) {
+            u32 w1 = w0 + cfg.win < b1 ? w0 + cfg.win : b1, n = w1 - w0;
+            for (u32 i = 0; i <= n; i++) nd[i].cost = 1e30f;
+            nd[0].cost = 0; nd[0].s.st = 0; nd[0].s.rep[0] = nd[0].s.rep[1] = nd[0].s.rep[2] = nd[0].s.rep[3] = 0;   /* 0 = unknown */
+            for (u32 i = 0; i < n; i++) {
+                u32 p = w0 + i; St s = nd[i].s; u32 fs = p / FRAME * FRAME; float c0 = nd[i].cost;
+                if (cfg.simpleState) s.st = s.st >= 7 ? 7 : 0;
+                St sl = s; if (!sl.rep[0]) sl.rep[0] = 1;
+                { pe.bits = 0; St t = sl; if (cfg.litPlain && t.st >= 7) { u32 keep = t.st; t.st = 0; e_symbol(&pe, &t, p, 0, 0, 0); t.st = st_lit(keep); pe.bits += 0; } else e_symbol(&pe, &t, p, 0, 0, 0);
+                  t.rep[0] = s.rep[0]; dp_relax(nd, i + 1, c0 + (float)pe.bits, i, 0, 0, 0, 0, &t); }
+                u32 maxl = n - i; if (maxl > 273) maxl = 273;
+                if (cfg.shortRep && s.rep[0] && p >= fs + s.rep[0] && S[p] == S[p - s.rep[0]]) { pe.bits = 0; St t = s; e_symbol(&pe, &t, p, 2, 1, 0); dp_relax(nd, i + 1, c0 + (float)pe.bits, i, 2, 1, 0, 0, &t); }
+                if (maxl < 2) continue;
+                if (cfg.repCompare) for (u32 r = 0; r < 4; r++) { u32 d = s.rep[r]; if (!d || p < fs + d) continue; u32 l = mlen(p, p - d, maxl); if (l < 2) continue;
+                    for (u32 x = 2; x <= l; x++) { pe.bits = 0; St t = s; e_symbol(&pe, &t, p, 3 + r, x, d); dp_relax(nd, i + x, c0 + (float)pe.bits, i, 3 + r, x, d, 0, &t); } }
+                for (int w = 0; w < 2; w++) {
+                    u32 d = w ? rec3Off[p] : recOff[p], l = w ? rec3Len[p] : recLen[p];
+                    if (w && !cfg.use3) break; if (!l) continue;
+                    u32 cap = cfg.maxLenCap ? (u32)cfg.maxLenCap : 273;
+                    l = full_len(p, d, l, maxl < cap ? maxl : cap); if (l < 2) continue;
+                    u32 kind = 1; for (u32 r = 0; r < (u32)cfg.repDetect; r++) if (s.rep[r] == d) { kind = 3 + r; break; }
+                    if (w && cfg.d3max && d > (u32)cfg.d3max) continue;
+                    St tl; float cl = 0;
+                    for (u32 x = 2; x <= l; x++) { pe.bits = 0; St t = s; for (int q = 0; q < 4; q++) if (!t.rep[q]) t.rep[q] = 0xFFFFFFFFu; e_symbol(&pe, &t, p, kind, x, d); for (int q = 0; q < 4; q++) if (t.rep[q] == 0xFFFFFFFFu) t.rep[q] = 0;
+                        dp_relax(nd, i + x, c0 + (float)pe.bits, i, kind, x, d, 0, &t); if (x == l) { tl = t; cl = c0 + (float)pe.bits; } }
+                    if (cfg.composite && !w && i + l + 3 <= n && l < 273) {   /* match + literal + rep0 */
+                        u32 q = p + l; u32 c = mlen(q + 1, q + 1 - d, (n - i - l - 1) < 273 ? (n - i - l - 1) : 273);
+                        if (c >= 2) { pe.bits = 0; St t = tl; e_symbol(&pe, &t, q, 0, 0, 0); float c1 = cl + (float)pe.bits;
+                            for (u32 x = 2; x <= c; x++) { pe.bits = 0; St t2 = t; e_symbol(&pe, &t2, q + 1, 3, x, d); dp_relax(nd, i + l + 1 + x, c1 + (float)pe.bits, i, 9, l, d, x, &t2); } }
+                    }
+                }
+            }
+            static u32 stack[8192]; u32 sp = 0; for (u32 i = n; i != 0; i = nd[i].prev) stack[sp++] = i;
+            u32 at = 0;
+            while (sp) { u32 i = stack[--sp]; u32 p = w0 + at;
+                if (nd[i].kind == 9) { out[nOut].pos = p; out[nOut].len = nd[i].len; out[nOut].off = nd[i].off; nOut++; out[nOut].pos = p + nd[i].len + 1; out[nOut].len = nd[i].len2; out[nOut].off = nd[i].off; nOut++; }
+                else if (nd[i].kind == 1 || nd[i].kind >= 3) { out[nOut].pos = p; out[nOut].len = nd[i].len; out[nOut].off = nd[i].off; nOut++; }
+                at = i; }
+        }
+    }
+    memcpy(syms, out, sizeof(Sym) * nOut); nSyms = nOut; free(out); free(g); free(nd);
+}
+
+
+/* ---------------------------------------------------------------- W7 as it would run on the GPU: entropy-style static prices
+ * from simple per-block statistics (no LZMA event counting), no state, candidates main (2..L<=64) and short. */
+static void parse_dp_simple(int litFromAll, int d3max, int win, int lsClasses)
+{
+    parse_greedy(2);
+    Sym* g = malloc(sizeof(Sym) * (nSyms + 1)); u32 ng = nSyms; memcpy(g, syms, sizeof(Sym) * nSyms);
+    Sym* out = malloc(sizeof(Sym) * (N / 2 + 16)); u32 nOut = 0;
+    float* cost = malloc(4 * (win + 2)); u32* bk = malloc(4 * (win + 2)); u8* bkind = malloc(win + 2);
+    static float litP[8][256], lenP[66], slotP[4][64];
+    u32 k = 0;
+    for (u32 b0 = 0; b0 < N; b0 += (128u << 10)) {
+        u32 b1 = b0 + (128u << 10) < N ? b0 + (128u << 10) : N;
+        /* statistics of the block */
+        static u32 lc[8][256], ls[8], lenH[66], slotH[4][64], slotN[4]; u32 nLit = 0, nMat = 0;
+        memset(lc, 0, sizeof lc); memset(ls, 0, sizeof ls); memset(lenH, 0, sizeof lenH); memset(slotH, 0, sizeof slotH); memset(slotN, 0, sizeof slotN);
+        u32 p = b0; u32 kk = k;
+        while (p < b1) {
+            if (kk < ng && g[kk].pos <= p) { u32 sp = g[kk].pos, len = g[kk].len, off = g[kk].off; if (sp < p) len -= p - sp; if (len > b1 - p) len = b1 - p; kk++;
+                u32 q = p; p += len;
+                while (len >= 2) { u32 t = len < 64 ? len : 64; if (len - t == 1) t--; lenH[t]++; nMat++; u32 dd = off - 1, slot; if (dd < 4) slot = dd; else { u32 hb = hibit(dd); slot = 2 * hb + ((dd >> (hb - 1)) & 1); }
+                    u32 c = lsClasses == 1 ? 0 : (t - 2 < 3 ? t - 2 : 3); slotH[c][slot]++; slotN[c]++; len -= t; }
+                if (litFromAll) for (; q < p; q++) { u32 ctx = q ? S[q - 1] >> 5 : 0; lc[ctx][S[q]]++; ls[ctx]++; }
+            } else { u32 ctx = p ? S[p - 1] >> 5 : 0; lc[ctx][S[p]]++; ls[ctx]++; nLit++; p++; }
+        }
+        while (k < ng && g[k].pos + g[k].len <= b1) k++;
+        for (int c = 0; c < 8; c++) for (int b = 0; b < 256; b++) litP[c][b] = (float)-log2((lc[c][b] + 0.3) / (ls[c] + 0.3 * 256));
+        float fl = (float)-log2((nLit + 1.0) / (nLit + nMat + 2.0)), fm = (float)-log2((nMat + 1.0) / (nLit + nMat + 2.0));
+        for (int l = 2; l <= 65; l++) lenP[l] = (float)-log2((lenH[l < 64 ? l : 64] + 0.5) / (nMat + 0.5 * 63));
+        for (int c = 0; c < 4; c++) for (int sl = 0; sl < 64; sl++) slotP[c][sl] = (float)-log2((slotH[c][sl] + 0.5) / (slotN[c] + 0.5 * 44));
+        for (u32 w0 = b0; w0 < b1; w0 += win) {
+            u32 w1 = w0 + win < b1 ? w0 + win : b1, n = w1 - w0;
+            for (u32 i = 0; i <= n; i++) cost[i] = 1e30f; cost[0] = 0;
+            u32 skipTo = 0, contAt = 0xFFFFFFFFu, contOff = 0;
+            for (u32 i = 0; i < n; i++) {
+                u32 pp = w0 + i; float c0 = cost[i];
+                if (i < skipTo) continue;
+                if (getenv("LAB_NICE") && recLen[pp] == 64 && n - i >= 64) { u32 d = recOff[pp]; u32 M = full_len(pp, d, 64, (n - i) < 273 ? (n - i) : 273); if (atoi(getenv("LAB_NICE")) >= 2) M = 64;
+                    if (atoi(getenv("LAB_NICE")) == 3) { float c = c0 + ((contAt == i && contOff == d) ? 0.25f : fm + lenP[64] + slotP[3][(d - 1) < 4 ? (d - 1) : 2 * hibit(d - 1) + (((d - 1) >> (hibit(d - 1) - 1)) & 1)] + ((d - 1) >= 4 ? (float)(hibit(d - 1) - 1) : 0));
+                        if (c < cost[i + M]) { cost[i + M] = c; bk[i + M] = M; bkind[i + M] = 1; } skipTo = i + M; contAt = i + M; contOff = d; continue; }
+                    u32 dd = d - 1, slot; if (dd < 4) slot = dd; else { u32 hb = hibit(dd); slot = 2 * hb + ((dd >> (hb - 1)) & 1); }
+                    float c = c0 + fm + lenP[64] + slotP[3][slot] + (slot >= 4 ? (float)((slot >> 1) - 1) : 0);
+                    if (c < cost[i + M]) { cost[i + M] = c; bk[i + M] = M; bkind[i + M] = 1; } skipTo = i + M; continue; }
+                { float c = c0 + fl + litP[pp ? S[pp - 1] >> 5 : 0][S[pp]]; if (c < cost[i + 1]) { cost[i + 1] = c; bk[i + 1] = 1; bkind[i + 1] = 0; } }
+                for (int w = 0; w < 2; w++) {
+                    u32 d = w ? rec3Off[pp] : recOff[pp], l = w ? rec3Len[pp] : recLen[pp];
+                    if (!l || (w && d3max && d > (u32)d3max)) continue;
+                    if (l > n - i) l = n - i; if (l > 64) l = 64;
+                    u32 dd = d - 1, slot; if (dd < 4) slot = dd; else { u32 hb = hibit(dd); slot = 2 * hb + ((dd >> (hb - 1)) & 1); }
+                    float foot = slot >= 4 ? (float)((slot >> 1) - 1) : 0;
+                    for (u32 x = 2; x <= l; x++) { u32 c4 = lsClasses == 1 ? 0 : (x - 2 < 3 ? x - 2 : 3); float c = c0 + fm + lenP[x] + slotP[c4][slot] + foot; if (!w && contAt == i && contOff == d) c = c0 + 0.25f; if (c < cost[i + x]) { cost[i + x] = c; bk[i + x] = x; bkind[i + x] = 1 + w; } }
+                }
+            }
+            static u32 stack[8192]; u32 sp = 0; for (u32 i = n; i != 0; i -= bk[i]) stack[sp++] = i;
+            u32 at = 0;
+            while (sp) { u32 i = stack[--sp]; u32 pp = w0 + at; if (bkind[i]) { out[nOut].pos = pp; out[nOut].len = bk[i]; out[nOut].off = bkind[i] == 1 ? recOff[pp] : rec3Off[pp]; nOut++; } at = i; }
+        }
+    }
+    memcpy(syms, out, sizeof(Sym) * nOut); nSyms = nOut; free(out); free(g); free(cost); free(bk); free(bkind);
+}
+
 int main(int argc, char** argv)
 {
     for (int i = 1; i <= 2048; i++) g_cost[i] = (float)(-log2((double)i / 2048.0)); g_cost[0] = 20;
@@ -313,6 +472,15 @@ int main(int argc, char** argv)
     double h;
     finder(depth, 5, 1);
     if (getenv("LAB_HC")) finder_hc(atoi(getenv("LAB_HC")));
+    if (getenv("LAB_DP")) {
+        parse_greedy(2); double a0 = price_syms(segLog, 12, &h); printf("greedy-lazy2 seg %d: %.0f\n", segLog, a0);
+        int v[11] = {1, 4096, 0, 1, 0, 0, 0, 0, 4, 0, 0}; const char* e = getenv("LAB_DP"); sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", v, v+1, v+2, v+3, v+4, v+5, v+6, v+7, v+8, v+9, v+10);
+        DpCfg c = { v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10] };
+        parse_dp_gpu(c, 2); double a = price_syms(segLog, 12, &h); printf("dp [%s] seg %d: %.0f  (%.4f of greedy)\n", e, segLog, a, a / a0); return 0; }
+    if (getenv("LAB_SIMPLE")) {
+        parse_greedy(2); double a0 = price_syms(segLog, 12, &h); printf("greedy-lazy2 seg %d: %.0f\n", segLog, a0);
+        int v[4] = {0, 4096, 4096, 4}; const char* e = getenv("LAB_SIMPLE"); sscanf(e, "%d,%d,%d,%d", v, v+1, v+2, v+3);
+        parse_dp_simple(v[0], v[1], v[2], v[3]); double a = price_syms(segLog, 12, &h); printf("simple [%s] seg %d: %.0f  (%.4f of greedy)\n", e, segLog, a, a / a0); return 0; }
     if (getenv("LAB_QUICK")) { parse_greedy(2); double a = price_syms(segLog, 12, &h); printf("greedy-lazy2 seg %d: %.0f (+hdr %.0f)\n", segLog, a, h);
         parse_optimal(segLog, 1, 1); parse_optimal(23, 1, 1); return 0; }
     parse_greedy(2); double a = price_syms(segLog, 12, &h); printf("greedy-lazy2 seg %d: %.0f (+hdr %.0f)\n", segLog, a, h);
