@@ -40,13 +40,17 @@ extern "C" __global__ void gc_mf_scan_kernel(uint32_t*, uint32_t);
 extern "C" __global__ void gc_mf_scatter_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
 extern "C" __global__ void gc_mf_link_kernel(const uint32_t*, const GcMfEntry*, GcMfEntry*, uint32_t, uint64_t);
 extern "C" __global__ void gc_mf_verify_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
+extern "C" __global__ void gc_mf_count_far_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
+extern "C" __global__ void gc_mf_scatter_far_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
+extern "C" __global__ void gc_mf_verify_far_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
 extern "C" __global__ void gc_mf_deepen_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, uint32_t*);
 extern "C" __global__ void gc_mf_parse_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcSeqRaw*, uint8_t*, GcBlockMeta*, uint16_t*, uint32_t);
 extern "C" __global__ void gc_mf_short_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint16_t*);
-extern "C" __global__ void gc_mf_dp_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*);
+extern "C" __global__ void gc_mf_dp2_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
+extern "C" __global__ void gc_mf_dp3_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
 
 extern "C" __global__ void gc_lzma2_prep_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t, uint64_t*, uint32_t*);
-extern "C" __global__ void gc_lzma2_model_kernel(const uint8_t*, uint64_t, const uint64_t*, const uint32_t*, uint32_t, uint32_t, uint16_t*, GcLzmaChunkInfo*);
+extern "C" __global__ void gc_lzma2_model_kernel(const uint8_t*, uint64_t, const uint64_t*, const uint32_t*, uint32_t, uint32_t, uint16_t*, GcLzmaChunkInfo*, const uint32_t*);
 extern "C" __global__ void gc_lzma2_rc_kernel(const uint16_t*, uint32_t, uint32_t, uint8_t*, GcLzmaChunkInfo*);
 extern "C" __global__ void gc_lzma2_plan_kernel(const GcLzmaChunkInfo*, uint32_t, uint32_t, uint64_t, uint32_t, GcLzmaPlan*, uint64_t*);
 extern "C" __global__ void gc_lzma2_emit_kernel(const uint8_t*, uint32_t, const uint8_t*, const GcLzmaChunkInfo*, const GcLzmaPlan*, uint32_t,
@@ -67,6 +71,7 @@ struct gc_ctx {
     uint32_t nParts;
     uint32_t lazyDepth;       // W6: 1 = one-step lazy, 2 = lazy2 (set per call from codec + level)
     uint32_t searchDepth;     // W5b: match links followed per position (0 = W5's two candidates only)
+    uint32_t farPass;         // second finder pass with 16- / 12-byte keys (longer matches), merged into the records by gain
     uint32_t priceParse;      // W5s + W7: price-based parse on top of the greedy one (gc_lz_price.hip)
     uint32_t priceMinLen, priceLitCtx;        // its shortest match and literal context bits (LZMA: 2, 7; zstd: 3, 0)
     uint32_t dbgFrameBlocks, dbgPartFrames;   // test hooks (env GC_FRAME_BLOCKS / GC_PART_FRAMES): small frames / parts so that
@@ -83,8 +88,9 @@ struct gc_ctx {
     uint8_t* brStage; GcBrotliBlockInfo* brInfo; GcBrotliPlan* brPlan;    // BROTLI path
     // windowed match finder (gc_mf.h): counts/offsets, partition starts, entry lists; grown on demand
     uint32_t* mfCnt; size_t mfCntCap; GcMfEntry* mfEnt; size_t mfEntCap; GcMfEntry* mfEnt2; size_t mfEnt2Cap; uint32_t* mfRec; size_t mfRecCap; uint32_t* mfRec2; size_t mfRec2Cap;
-    uint16_t* mfRec3; size_t mfRec3Cap; uint32_t* mfDp; size_t mfDpCap; uint16_t* mfPrice; size_t mfPriceCap;      // W5s records, W7 records, price tables
-    hipEvent_t evMf[GC_MAX_PARTS][7];       // per part: W1 start, W1 end, W2 end, W3 end, W4 end, W5 end, W6 end
+    uint16_t* mfRec3; size_t mfRec3Cap; uint32_t* mfDp; size_t mfDpCap; uint16_t* mfPrice; size_t mfPriceCap; uint32_t* mfWinCost; size_t mfWinCostCap;      // W5s records, W7 records, price tables
+    hipEvent_t evMf[GC_MAX_PARTS][10];      // per part: W1 start, W1 end, W2 end, W3 end, W4 end, W5 end, W6 end; price-based parse: greedy W6 end, W5s end, W7 end
+    bool mfPriced;                          // the last call ran the price-based parse (events 7..9 are valid)
     bool mfTimed; uint32_t mfParts;
     int lastCodec;            // 0 zstd, 1 flzma2: which kernels the events of the last call bracket
     uint64_t* hostResult;     // pinned
@@ -129,7 +135,7 @@ extern "C" int gc_ctx_create(gc_ctx** out, int device)
     if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess || hipStreamCreate(&c->stream3) != hipSuccess) { delete c; return GC_ERR_HIP; }
     for (int i = 0; i < 8; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return GC_ERR_HIP; }
     for (uint32_t p = 0; p < GC_MAX_PARTS; p++) {
-        for (int i = 0; i < 7; i++) if (hipEventCreate(&c->evMf[p][i]) != hipSuccess) { delete c; return GC_ERR_HIP; }
+        for (int i = 0; i < 10; i++) if (hipEventCreate(&c->evMf[p][i]) != hipSuccess) { delete c; return GC_ERR_HIP; }
         for (uint32_t i = 0; i < GC_PART_EVENTS; i++) if (hipEventCreate(&c->evPart[p][i]) != hipSuccess) { delete c; return GC_ERR_HIP; }
     }
     if (hipMalloc((void**)&c->prof, (GC_LZ_PHASES + GC_SEQ_PHASES) * sizeof(unsigned long long)) != hipSuccess) { delete c; return GC_ERR_NOMEM; }
@@ -158,10 +164,10 @@ extern "C" void gc_ctx_destroy(gc_ctx* c)
     hipStreamSynchronize(c->stream);
     free_workspace(c);
     hipFree(c->prof); hipFree(c->result); hipHostFree(c->hostResult); hipFree(c->dIn); hipFree(c->dOut);
-    hipFree(c->mfCnt); hipFree(c->mfEnt); hipFree(c->mfEnt2); hipFree(c->mfRec); hipFree(c->mfRec2); hipFree(c->mfRec3); hipFree(c->mfDp); hipFree(c->mfPrice);
+    hipFree(c->mfCnt); hipFree(c->mfEnt); hipFree(c->mfEnt2); hipFree(c->mfRec); hipFree(c->mfRec2); hipFree(c->mfRec3); hipFree(c->mfDp); hipFree(c->mfPrice); hipFree(c->mfWinCost);
     for (int i = 0; i < 8; i++) hipEventDestroy(c->ev[i]);
     for (uint32_t p = 0; p < GC_MAX_PARTS; p++) {
-        for (int i = 0; i < 7; i++) hipEventDestroy(c->evMf[p][i]);
+        for (int i = 0; i < 10; i++) hipEventDestroy(c->evMf[p][i]);
         for (uint32_t i = 0; i < GC_PART_EVENTS; i++) hipEventDestroy(c->evPart[p][i]);
     }
     hipStreamDestroy(c->stream3);
@@ -226,7 +232,7 @@ static int ensure_finder_workspace(gc_ctx* c, size_t n, uint32_t frameBlocks)
     const size_t needRec = (size_t)g.nBlocks * GC_ZSTD_BLOCK_MAX * sizeof(uint32_t);
     const size_t needPrice = (size_t)g.nBlocks * GC_PRICE_WORDS * sizeof(uint16_t);
     if (needCnt > c->mfCntCap || needEnt > c->mfEntCap || needEnt > c->mfEnt2Cap || needRec > c->mfRecCap || (c->searchDepth && needRec > c->mfRec2Cap) ||
-        (c->priceParse && (needRec / 2u > c->mfRec3Cap || needRec > c->mfDpCap || needPrice > c->mfPriceCap))) {
+        (c->priceParse && (needRec / 2u > c->mfRec3Cap || needRec > c->mfDpCap || needPrice > c->mfPriceCap || (size_t)g.nBlocks * 128u > c->mfWinCostCap))) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         int rc;
         if ((rc = mf_grow(c, (void**)&c->mfCnt, &c->mfCntCap, needCnt, "offsets")) != GC_OK) return rc;
@@ -238,6 +244,7 @@ static int ensure_finder_workspace(gc_ctx* c, size_t n, uint32_t frameBlocks)
             if ((rc = mf_grow(c, (void**)&c->mfRec3, &c->mfRec3Cap, needRec / 2u, "short candidates")) != GC_OK) return rc;
             if ((rc = mf_grow(c, (void**)&c->mfDp, &c->mfDpCap, needRec, "price-parse records")) != GC_OK) return rc;
             if ((rc = mf_grow(c, (void**)&c->mfPrice, &c->mfPriceCap, needPrice, "price tables")) != GC_OK) return rc;
+            if ((rc = mf_grow(c, (void**)&c->mfWinCost, &c->mfWinCostCap, (size_t)g.nBlocks * 128u, "window costs")) != GC_OK) return rc;
         }
     }
     return GC_OK;
@@ -274,6 +281,14 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
     HIPCHK(c, hipEventRecord(ev[4], st));
     GC_LAUNCH(gc_mf_verify_kernel, perT * GC_XCDS, GC_MF_VERIFY_T, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt,
               (const GcMfEntry*)ent2, rec);
+    if (c->farPass) {                                           // second pass with 16- / 12-byte keys, merged into rec (timed with W5)
+        GC_LAUNCH(gc_mf_count_far_kernel, perT * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, cnt);
+        GC_LAUNCH(gc_mf_scan_kernel, g.nFrames, 1024, st, cnt, g.tilesPerFrame);
+        GC_LAUNCH(gc_mf_scatter_far_kernel, perT * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt, ent);
+        GC_LAUNCH(gc_mf_link_kernel, g.nFrames * GC_MF_PARTS * GC_MF_LINK_SEGS, 64, st, (const uint32_t*)cnt, (const GcMfEntry*)ent, ent2, g.tilesPerFrame, g.frameBytes);
+        GC_LAUNCH(gc_mf_verify_far_kernel, perT * GC_XCDS, GC_MF_VERIFY_T, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt,
+                  (const GcMfEntry*)ent2, rec);
+    }
     if (c->searchDepth) {                                       // W5b: follow match links (timed with W5)
         uint32_t* rec2 = c->mfRec2 + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
         GC_LAUNCH(gc_mf_deepen_kernel, perT * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, c->searchDepth, (const uint32_t*)rec, rec2);
@@ -286,11 +301,16 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
         uint16_t* price = c->mfPrice + (size_t)blk0 * GC_PRICE_WORDS;
         uint16_t* rec3 = c->mfRec3 + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
         uint32_t* dp = c->mfDp + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
+        uint32_t* wc = c->mfWinCost + (size_t)blk0 * 32u;
         GC_LAUNCH(gc_mf_parse_kernel, perB * GC_XCDS, GC_MF_PARSE_T, st, src, (uint64_t)n, nBlocks, perB, c->lazyDepth, (const uint32_t*)rec, seqRaw, lit, meta, price, c->priceLitCtx);
+        HIPCHK(c, hipEventRecord(ev[7], st));
         const uint32_t nChunkWg = (uint32_t)(((n + 2047u) / 2048u + 3u) / 4u), perC = gc_xcd_per(nChunkWg);
         GC_LAUNCH(gc_mf_short_kernel, perC * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, (uint32_t)((n + 2047u) / 2048u), perC, rec3);
+        HIPCHK(c, hipEventRecord(ev[8], st));
         const uint32_t nDpWg = nBlocks * 8u, perD = gc_xcd_per(nDpWg);
-        GC_LAUNCH(gc_mf_dp_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, c->priceMinLen, c->priceLitCtx, (const uint32_t*)rec, (const uint16_t*)rec3, (const uint16_t*)price, dp);
+        if (c->priceMinLen <= 2u) GC_LAUNCH(gc_mf_dp2_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, c->priceLitCtx, (const uint32_t*)rec, (const uint16_t*)rec3, (const uint16_t*)price, dp, wc);
+        else GC_LAUNCH(gc_mf_dp3_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, c->priceLitCtx, (const uint32_t*)rec, (const uint16_t*)rec3, (const uint16_t*)price, dp, wc);
+        HIPCHK(c, hipEventRecord(ev[9], st));
         GC_LAUNCH(gc_mf_parse_kernel, perB * GC_XCDS, GC_MF_PARSE_T, st, src, (uint64_t)n, nBlocks, perB, 0u, (const uint32_t*)dp, seqRaw, lit, meta, (uint16_t*)nullptr, 0u);
     } else
         GC_LAUNCH(gc_mf_parse_kernel, perB * GC_XCDS, GC_MF_PARSE_T, st, src, (uint64_t)n, nBlocks, perB, c->lazyDepth, (const uint32_t*)rec, seqRaw, lit, meta, (uint16_t*)nullptr, 0u);
@@ -307,7 +327,7 @@ static int launch_finder(gc_ctx* c, const uint8_t* src, size_t n, uint32_t frame
     if (rc != GC_OK) return rc;
     rc = launch_finder_part(c, c->stream, 0, src, n, frameBlocks, 0, prof);
     if (rc != GC_OK) return rc;
-    c->mfTimed = frameBlocks > 1u; c->mfParts = 1;
+    c->mfTimed = frameBlocks > 1u; c->mfParts = 1; c->mfPriced = c->mfTimed && c->priceParse != 0u;
     return GC_OK;
 }
 
@@ -319,6 +339,18 @@ extern "C" int gc_mf_last_timing(gc_ctx* c, float ms[6])
     for (int i = 0; i < 6; i++) ms[i] = 0.f;
     for (uint32_t p = 0; p < c->mfParts; p++)
         for (int i = 0; i < 6; i++) { float t = 0.f; HIPCHK(c, hipEventElapsedTime(&t, c->evMf[p][i], c->evMf[p][i + 1])); ms[i] += t; }
+    return GC_OK;
+}
+
+// ms[0..3] = greedy parse (W6 + statistics), short candidates (W5s), shortest path (W7), second W6 pass that follows W7's records:
+// the parts of gc_mf_last_timing's "parse" entry when the last call ran the price-based parse (GC_ERR_PARAM otherwise)
+extern "C" int gc_mf_price_timing(gc_ctx* c, float ms[4])
+{
+    if (!c || !c->timed || c->pending || !c->mfTimed || !c->mfPriced) return GC_ERR_PARAM;
+    static const int a[4] = { 5, 7, 8, 9 }, b[4] = { 7, 8, 9, 6 };
+    for (int i = 0; i < 4; i++) ms[i] = 0.f;
+    for (uint32_t p = 0; p < c->mfParts; p++)
+        for (int i = 0; i < 4; i++) { float t = 0.f; HIPCHK(c, hipEventElapsedTime(&t, c->evMf[p][a[i]], c->evMf[p][b[i]])); ms[i] += t; }
     return GC_OK;
 }
 
@@ -349,10 +381,16 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
     if (rc != GC_OK) return rc;
     const uint8_t* src = (const uint8_t*)d_src;
     if (c->profOn) { HIPCHK(c, hipMemsetAsync(c->prof, 0, (GC_LZ_PHASES + GC_SEQ_PHASES) * sizeof(unsigned long long), c->stream)); c->profBlocks = nBlocks; }
-    const uint32_t frameBlocks = zstd_frame_blocks(level) < nBlocks ? zstd_frame_blocks(level) : nBlocks;   // short input: one frame
+    uint32_t frameBlocks = zstd_frame_blocks(level);
+    if (frameBlocks > 1u && c->dbgFrameBlocks) frameBlocks = c->dbgFrameBlocks;                              // test hook: small frames
+    if (frameBlocks > nBlocks) frameBlocks = nBlocks;                                                       // short input: one frame
     c->lazyDepth = level >= 6 ? 2u : 1u;          // the reference's lazy2 begins at level 8 of its table; deeper look-ahead from 6 here
     c->searchDepth = zstd_search_depth(level);
-    c->priceParse = 0;
+    c->farPass = level >= 16 ? 1u : 0u;           // with the price-based parse (btopt and up)
+    { const char* e = getenv("GC_FAR_PASS"); if (e) c->farPass = (uint32_t)atoi(e); }          // test hook
+    c->priceMinLen = 3u; c->priceLitCtx = 0u;     // zstd: matches of >= 3 bytes, literals without context (one Huffman table per block)
+    c->priceParse = level >= 16 ? 1u : 0u;        // the reference's btopt / btultra strategies start at level 16 (clevels.h:44-47)
+    { const char* e = getenv("GC_PRICE_PARSE"); if (e) c->priceParse = (uint32_t)atoi(e); }    // test hook
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     rc = launch_finder(c, src, n, frameBlocks, c->profOn ? c->prof : nullptr);
     if (rc != GC_OK) return rc;
@@ -493,6 +531,9 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     uint32_t frameBlocks = flzma2_frame_blocks(level);
     c->lazyDepth = level >= 5 ? 2u : 1u;
     c->searchDepth = level >= 5 ? (level >= 8 ? 8u : 4u) : 0u;
+    c->farPass = level >= 5 ? 1u : 0u;            // the reference's match table resolves to depth 42 at level 5 (fl2_compress.c:37-104)
+    { const char* e = getenv("GC_FAR_PASS"); if (e) c->farPass = (uint32_t)atoi(e); }          // test hook
+    { const char* e = getenv("GC_SEARCH_DEPTH"); if (e) c->searchDepth = (uint32_t)atoi(e); }  // test hook
     c->priceMinLen = 2u; c->priceLitCtx = 7u;
     c->priceParse = level >= 5 ? 1u : 0u;         // the reference's FL2_opt / FL2_ultra strategies start at level 5 (fl2_compress.c:37-104)
     { const char* e = getenv("GC_PRICE_PARSE"); if (e) c->priceParse = (uint32_t)atoi(e); }    // test hook: 0 = greedy parse only
@@ -531,7 +572,8 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
         HIPCHK(c, hipEventRecord(ev[3], c->stream2));
         GC_LAUNCH(gc_lzma2_model_kernel, pSegs, 64, c->stream2, src + off, (uint64_t)pn, (const uint64_t*)(c->lzM + (size_t)blk0 * GC_LZMA_MAX_ITEMS),
                   (const uint32_t*)(c->lzNM + blk0), segLog, (uint32_t)(off != 0u ? 1u : 0u),
-                  c->lzStream + (size_t)blk0 * segPerBlock * GC_LZMA_STREAM_WORDS(segLog), c->lzInfo + (size_t)blk0 * GC_LZMA_RC_PER_BLOCK);
+                  c->lzStream + (size_t)blk0 * segPerBlock * GC_LZMA_STREAM_WORDS(segLog), c->lzInfo + (size_t)blk0 * GC_LZMA_RC_PER_BLOCK,
+                  (const uint32_t*)((c->priceParse && frameBlocks > 1u) ? c->mfWinCost + (size_t)blk0 * 32u : nullptr));
         HIPCHK(c, hipEventRecord(ev[4], c->stream2));
         // stage 3 (stream3): range coder
         HIPCHK(c, hipStreamWaitEvent(c->stream3, ev[4], 0));
@@ -541,7 +583,7 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
         HIPCHK(c, hipEventRecord(ev[6], c->stream3));
         f0 = f1;
     }
-    c->mfTimed = frameBlocks > 1u; c->mfParts = nParts;
+    c->mfTimed = frameBlocks > 1u; c->mfParts = nParts; c->mfPriced = c->mfTimed && c->priceParse != 0u;
     (void)nSegs;
     // all parts coded -> headers and assembly on the main stream
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->evPart[nParts - 1u][6], 0));
@@ -637,7 +679,12 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     uint32_t frameBlocks = brotli_frame_blocks(level, bpc);
     c->lazyDepth = level >= 7 ? 2u : 1u;
     c->searchDepth = level >= 7 ? (level >= 10 ? 8u : 4u) : 0u;
-    c->priceParse = 0;
+    c->farPass = level >= 7 ? 1u : 0u;
+    { const char* e = getenv("GC_FAR_PASS"); if (e) c->farPass = (uint32_t)atoi(e); }          // test hook
+    c->priceMinLen = 3u; c->priceLitCtx = 0u;     // copies of >= 3 bytes (a 2-byte copy at a fresh distance never pays in brotli), one literal code per meta-block
+    c->priceParse = level >= 6 ? 1u : 0u;         // the reference parses greedily up to quality 9; the price-based parse here pays for the
+                                                  // context modelling and block splitting its entropy stage has and B1 has not
+    { const char* e = getenv("GC_PRICE_PARSE"); if (e) c->priceParse = (uint32_t)atoi(e); }    // test hook
     if (frameBlocks > nBlocks) frameBlocks = nBlocks;                       // short input: one chunk, one frame
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     rc = launch_finder(c, src, n, frameBlocks, nullptr);

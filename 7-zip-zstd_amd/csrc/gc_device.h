@@ -120,6 +120,17 @@ __device__ __forceinline__ uint32_t gc_writelane(uint32_t v, uint32_t s, uint32_
 #endif
 }
 
+// same with a compile-time lane (inline constant: no M0 traffic)
+template <int LANE> __device__ __forceinline__ uint32_t gc_writelane_c(uint32_t v, uint32_t s)
+{
+#ifdef HIPEMU
+    return (__lane_id() & 63u) == (uint32_t)LANE ? s : v;
+#else
+    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(v) : "s"(__builtin_amdgcn_readfirstlane((int)s)), "n"(LANE));
+    return v;
+#endif
+}
+
 __device__ __forceinline__ uint64_t gc_lanemask_lt() { return (1ull << (__lane_id() & 63)) - 1ull; }
 
 // inclusive wave scan (sum) over 64 lanes

@@ -117,10 +117,11 @@ gc_mf_short_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t f
 #define DP_KIND1   (1u << 6)
 #define DP_KIND2   (2u << 6)
 
-extern "C" __global__ void __launch_bounds__(DP_T)
-gc_mf_dp_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t minLen /* 2 LZMA, 3 zstd */,
+template <uint32_t minLen /* shortest match: 2 LZMA, 3 zstd */>
+__device__ __forceinline__ void dp_window(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per,
                 uint32_t litCtxMask /* bits of (previous byte >> 5) that select the literal price row: 7 LZMA (lc = 3), 0 zstd */,
-                const uint32_t* __restrict__ rec, const uint16_t* __restrict__ rec3, const uint16_t* __restrict__ priceTab, uint32_t* __restrict__ recOut)
+                const uint32_t* __restrict__ rec, const uint16_t* __restrict__ rec3, const uint16_t* __restrict__ priceTab, uint32_t* __restrict__ recOut,
+                uint32_t* __restrict__ winCost /* per window: cost of the cheapest path in 1/16 bit (an estimate of its coded size), or nullptr */)
 {
     __shared__ uint16_t sPrice[GC_PRICE_WORDS];
     __shared__ uint8_t sRow[DP_WAVES][DP_ROWS][64];               // back pointers by end node, later edges by start node
@@ -155,7 +156,7 @@ gc_mf_dp_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlo
     uint32_t ring = lane == 0u ? 0u : DP_INF;                     // node 0: cost 0
     uint32_t cc = 0;                                              // back pointers of the current group's nodes (lane = node mod 64)
     uint32_t curG = 0xFFFFFFFFu;
-    bool contNext = false; uint32_t contOff = 0;                  // the node being expanded is the end of a capped match with this distance
+    uint32_t contBit = 0, contOff = 0;                            // contBit = 64: the node being expanded is the end of a capped match with this distance
     GcPub pL, pA, pL3, pA3, pC, pD;       // per position of the group: candidate lengths, word addends (distance price), literal addend, distance
     // raw inputs of the NEXT group, requested one group (64 nodes) ahead of their use
     uint32_t nR = 0, nR3 = GC_SHORT_NONE, nByte = 0, nPrev = 0;
@@ -188,21 +189,21 @@ gc_mf_dp_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlo
         cc = gc_writelane(cc, w, k);                              // (its low byte is the back pointer)
         const uint32_t costw = w & ~0xFFu;                        // cost in word units
         const uint32_t L = gc_peek(pL, k);
-        if (contNext || L == GC_MATCH_CAP) {                      // uniform, rare: end and / or start of a capped match
-            const bool cont = contNext && L != 0u && gc_peek(pD, k) == contOff;
-            contNext = false;
+        if ((L | contBit) >= GC_MATCH_CAP) {                      // uniform, rare: end and / or start of a capped match
+            const bool cont = contBit != 0u && L != 0u && gc_peek(pD, k) == contOff;
+            contBit = 0;
             if (L == GC_MATCH_CAP) {                              // take the capped match whole (L is clipped to the window)
                 const uint32_t c = costw + (cont ? (DP_CONT_PRICE << 8) | DP_KIND1 | (GC_MATCH_CAP - 1u) : gc_peek(pA, k) + capAdd);
                 ring = lane == 0u ? c : DP_INF;                   // node i + 64 is the only open node
-                contNext = true; contOff = gc_peek(pD, k);
+                contBit = GC_MATCH_CAP; contOff = gc_peek(pD, k);
                 i += GC_MATCH_CAP;
                 continue;
             }
             if (cont) {                                           // the piece behind a capped match: same price for every length
                 ring = gc_wave_shl1(ring, DP_INF);
                 uint32_t cand = lane < L ? costw + ((DP_CONT_PRICE << 8) | DP_KIND1 | lane) : DP_INF;
-                cand = gc_writelane(cand, costw + gc_peek(pC, k), 0u);
-                if (minLen > 2u) cand = gc_writelane(cand, DP_INF, 1u);
+                cand = gc_writelane_c<0>(cand, costw + gc_peek(pC, k));
+                if (minLen > 2u) cand = gc_writelane_c<1>(cand, DP_INF);
                 ring = cand < ring ? cand : ring;
                 i++;
                 continue;
@@ -216,8 +217,8 @@ gc_mf_dp_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlo
             const uint32_t w2 = X2 + (costw + gc_peek(pA3, k));
             cand = (lane < L3 && w2 < cand) ? w2 : cand;
         }
-        cand = gc_writelane(cand, costw + gc_peek(pC, k), 0u);    // lane 0: the literal (kind 0, length 1)
-        if (minLen > 2u) cand = gc_writelane(cand, DP_INF, 1u);   // zstd: no matches of two bytes
+        cand = gc_writelane_c<0>(cand, costw + gc_peek(pC, k));   // lane 0: the literal (kind 0, length 1)
+        if (minLen > 2u) cand = gc_writelane_c<1>(cand, DP_INF);  // zstd: no matches of two bytes
         ring = cand < ring ? cand : ring;
         i++;
     }
@@ -225,8 +226,10 @@ gc_mf_dp_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlo
     {
         const uint32_t g = n >> 6, k = n & 63u;
         if (g != curG) { if (curG != 0xFFFFFFFFu) row[curG][lane] = (uint8_t)cc; cc = 0; curG = g; }
-        cc = gc_writelane(cc, gc_readlane(ring, 0u), k);
+        const uint32_t wn = gc_readlane(ring, 0u);
+        cc = gc_writelane(cc, wn, k);
         row[curG][lane] = (uint8_t)cc;
+        if (winCost != nullptr && lane == 0u) winCost[(uint64_t)b * DP_WINS_PER_BLOCK + win] = wn >> 8;
     }
     gc_wave_sync();
     // ---- walk back from node n; the rows are rewritten in place: lane of the START position of every match on the path <- its byte
@@ -266,4 +269,20 @@ gc_mf_dp_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlo
         }
         RO[p] = out;
     }
+}
+
+// one kernel per shortest match length (the shared arrays of dp_window are per instantiation: two in one kernel would double its LDS)
+extern "C" __global__ void __launch_bounds__(DP_T)
+gc_mf_dp2_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t litCtxMask,
+                 const uint32_t* __restrict__ rec, const uint16_t* __restrict__ rec3, const uint16_t* __restrict__ priceTab, uint32_t* __restrict__ recOut,
+                 uint32_t* __restrict__ winCost)
+{
+    dp_window<2u>(src, srcSize, nBlocks, per, litCtxMask, rec, rec3, priceTab, recOut, winCost);
+}
+extern "C" __global__ void __launch_bounds__(DP_T)
+gc_mf_dp3_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t litCtxMask,
+                 const uint32_t* __restrict__ rec, const uint16_t* __restrict__ rec3, const uint16_t* __restrict__ priceTab, uint32_t* __restrict__ recOut,
+                 uint32_t* __restrict__ winCost)
+{
+    dp_window<3u>(src, srcSize, nBlocks, per, litCtxMask, rec, rec3, priceTab, recOut, winCost);
 }

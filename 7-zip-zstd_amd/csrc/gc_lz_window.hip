@@ -80,7 +80,13 @@ __device__ __forceinline__ uint32_t mf_lds_byte(const uint32_t* sW, uint32_t i) 
 //     exactly the frames the whole input would)
 //   - inside a run of one byte value (the 8 bytes at P equal the 8 bytes at P-1): all those positions share one key and would
 //     pile into one list; W5 gives them the candidate P-1 instead, which is what the tables would have returned
+// FAR = the second pass of the finder at higher levels: the same machinery with keys of 16 ("long") and 12 ("short") bytes.
+// The most recent position with the same 16 bytes is usually a LONGER match than the most recent one with the same 8 bytes; it
+// is what brings the candidates close to the longest match the reference's exhaustive structures return (RMF_buildTable
+// radix_engine.h:920: depth 42 at level 5; ZSTD_insertBtAndGetAllMatches zstd_opt.c:590).  Equal 16 bytes imply equal 12 bytes,
+// so both keys of a position again live in one partition.
 struct MfKeys { bool ok, run; uint32_t part; uint64_t entry; };
+template <bool FAR>
 __device__ __forceinline__ MfKeys mf_keys(const uint32_t* sW, uint32_t q, const MfTile& T)
 {
     MfKeys r; r.ok = false; r.run = false; r.part = 0; r.entry = 0;
@@ -89,7 +95,15 @@ __device__ __forceinline__ MfKeys mf_keys(const uint32_t* sW, uint32_t q, const 
     if (P > T.frameStart) r.run = ((x << 8) | (uint64_t)mf_lds_byte(sW, q + MF_STAGE_PAD - 1u)) == x;
     if (q < T.len && P + GC_MATCH_CAP + 16u <= T.frameEnd && !r.run) {
         const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
-        const uint32_t hL = lz_hash_long(lo, hi), hS = lz_hash_short(lo, hi);
+        uint32_t hL = lz_hash_long(lo, hi), hS = lz_hash_short(lo, hi);
+        if (FAR) {
+            const uint64_t y = mf_lds_ld64(sW, q + MF_STAGE_PAD + 8u);
+            const uint32_t lo1 = (uint32_t)y, hi1 = (uint32_t)(y >> 32);
+            hS = hL + lo1 * 0xC2B2AE3Du;                          // bytes 0..11
+            hS ^= hS >> 15; hS *= 0x2C1B3C6Du;
+            hL = hS + hi1 * 0x27D4EB2Fu;                          // bytes 0..15
+            hL ^= hL >> 13; hL *= 0x165667B1u;
+        }
         r.ok = true;
         r.part = hS >> (32u - GC_MF_PART_LOG);
         r.entry = (uint64_t)(uint32_t)(P - T.frameStart)
@@ -100,8 +114,8 @@ __device__ __forceinline__ MfKeys mf_keys(const uint32_t* sW, uint32_t q, const 
 }
 
 // ------------------------------------------------------------------------------------------------ W1 count
-extern "C" __global__ void __launch_bounds__(MF_T)
-gc_mf_count_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per, uint32_t* __restrict__ cnt)
+template <bool FAR>
+__device__ __forceinline__ void mf_count_body(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per, uint32_t* __restrict__ cnt)
 {
     __shared__ uint32_t sW[MF_STAGE_WORDS];
     __shared__ uint32_t sHist[GC_MF_PARTS];
@@ -114,11 +128,21 @@ gc_mf_count_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t f
     if (T.len) mf_stage(sW, MF_STAGE_WORDS, src, srcSize, T.tileStart, t, MF_T);
     __syncthreads();
     for (uint32_t q = t; q < T.len; q += MF_T) {
-        const MfKeys k = mf_keys(sW, q, T);
+        const MfKeys k = mf_keys<FAR>(sW, q, T);
         if (k.ok) atomicAdd(&sHist[k.part], 1u);
     }
     __syncthreads();
     cnt[((uint64_t)T.frame * (TPF + 1u) + T.tif) * GC_MF_PARTS + t] = sHist[t];
+}
+extern "C" __global__ void __launch_bounds__(MF_T)
+gc_mf_count_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per, uint32_t* __restrict__ cnt)
+{
+    mf_count_body<false>(src, srcSize, frameBlocks, nTiles, per, cnt);
+}
+extern "C" __global__ void __launch_bounds__(MF_T)
+gc_mf_count_far_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per, uint32_t* __restrict__ cnt)
+{
+    mf_count_body<true>(src, srcSize, frameBlocks, nTiles, per, cnt);
 }
 
 // ------------------------------------------------------------------------------------------------ W2 scan
@@ -164,8 +188,8 @@ gc_mf_scan_kernel(uint32_t* __restrict__ cnt, uint32_t tilesPerFrame)
 // Stable counting sort of one tile by partition, staged through LDS as a permutation (16-bit tile positions), so that every
 // partition's run leaves the CU as one contiguous, coalesced store stream.  Wave w owns quarter w of the tile; ranks inside a
 // 64-position round come from ballots (position order = lane order), so the order inside a partition is position order.
-extern "C" __global__ void __launch_bounds__(MF_T)
-gc_mf_scatter_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
+template <bool FAR>
+__device__ __forceinline__ void mf_scatter_body(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
                      const uint32_t* __restrict__ offs, GcMfEntry* __restrict__ ent)
 {
     __shared__ uint32_t sW[MF_STAGE_WORDS];
@@ -185,7 +209,7 @@ gc_mf_scatter_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t
     const uint32_t qBase = wave * (GC_MF_TILE / MF_WAVES);
     // pass A: per-wave histograms
     for (uint32_t r = 0; r < GC_MF_TILE / MF_T; r++) {
-        const MfKeys k = mf_keys(sW, qBase + r * 64u + lane, T);
+        const MfKeys k = mf_keys<FAR>(sW, qBase + r * 64u + lane, T);
         if (k.ok) atomicAdd(&sRun[wave][k.part], 1u);
     }
     __syncthreads();
@@ -209,7 +233,7 @@ gc_mf_scatter_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t
     const uint64_t lt = gc_lanemask_lt();
     for (uint32_t r = 0; r < GC_MF_TILE / MF_T; r++) {
         const uint32_t q = qBase + r * 64u + lane;
-        const MfKeys k = mf_keys(sW, q, T);
+        const MfKeys k = mf_keys<FAR>(sW, q, T);
         uint64_t peers = __ballot(k.ok);
         if (peers != 0ull) {                                      // uniform
 #pragma unroll
@@ -232,9 +256,21 @@ gc_mf_scatter_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t
     // output: slot j of the sorted tile -> its partition's run in HBM
     GcMfEntry* E = ent + (uint64_t)T.frame * ((uint64_t)frameBlocks * GC_ZSTD_BLOCK_MAX);
     for (uint32_t j = t; j < nEnt; j += MF_T) {
-        const MfKeys k = mf_keys(sW, sPerm[j], T);
+        const MfKeys k = mf_keys<FAR>(sW, sPerm[j], T);
         E[sGlob[k.part] + (j - sLocal[k.part])] = k.entry;
     }
+}
+extern "C" __global__ void __launch_bounds__(MF_T)
+gc_mf_scatter_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
+                     const uint32_t* __restrict__ offs, GcMfEntry* __restrict__ ent)
+{
+    mf_scatter_body<false>(src, srcSize, frameBlocks, nTiles, per, offs, ent);
+}
+extern "C" __global__ void __launch_bounds__(MF_T)
+gc_mf_scatter_far_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
+                         const uint32_t* __restrict__ offs, GcMfEntry* __restrict__ ent)
+{
+    mf_scatter_body<true>(src, srcSize, frameBlocks, nTiles, per, offs, ent);
 }
 
 // ------------------------------------------------------------------------------------------------ W4 link
@@ -374,8 +410,10 @@ __device__ __forceinline__ uint32_t mfv_len16(const LzW16& me, const LzW16& cw, 
     return len >= GC_MIN_MATCH ? len : 0u;
 }
 
-extern "C" __global__ void __launch_bounds__(MFV_T)
-gc_mf_verify_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
+// FAR: the candidates come from the second pass (16- and 12-byte keys); rec already holds the records of the first pass and a
+// position's record is replaced only by a candidate of better gain.
+template <bool FAR>
+__device__ __forceinline__ void mf_verify_body(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
                     const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, uint32_t* __restrict__ rec)
 {
     __shared__ uint32_t sW[MFV_STAGE_WORDS];
@@ -398,6 +436,11 @@ gc_mf_verify_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t 
         if (lane == 63u) sWaveTot[wave] = incl;
     }
     mf_stage(sW, MFV_STAGE_WORDS, src, srcSize, T.tileStart, t, MFV_T);
+    if (FAR) {                                                    // records of the first pass
+        const GcU4* R4 = (const GcU4*)(rec + T.tileStart);
+        GcU4* S4 = (GcU4*)sRec;
+        for (uint32_t i = t; i < (T.len + 3u) / 4u; i += MFV_T) S4[i] = R4[i];
+    }
     __syncthreads();
     if (t < GC_MF_PARTS) {
         uint32_t before = 0;
@@ -443,7 +486,7 @@ gc_mf_verify_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t 
 #pragma unroll
         for (uint32_t k = 0; k < MFV_B; k++) {
             bestLen[k] = bestC[k] ? mfv_len16(mf_lds_ld16(sW, q[k] + MF_STAGE_PAD), cw[k], maxLen[k]) : 0u;
-            if (bestLen[k] >= 8u || maxLen[k] == 0u) cS[k] = 0;  // verified long candidate: the short one is not needed
+            if (bestLen[k] >= (FAR ? 16u : 8u) || maxLen[k] == 0u) cS[k] = 0;  // verified long candidate: the short one is not needed
             if (cS[k]) cw[k] = lz_ld16(wsrc, cS[k] - 1u);
         }
 #pragma unroll
@@ -460,11 +503,15 @@ gc_mf_verify_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t 
                 if (len > maxLen[k]) len = maxLen[k];
                 if (more < 16u) break;
             }
-            if (j0 + k * MFV_T < nEnt) sRec[q[k]] = len ? (((pw - (bestC[k] - 1u)) << 8) | len) : 0u;
+            if (j0 + k * MFV_T < nEnt) {
+                const uint32_t nr = len ? (((pw - (bestC[k] - 1u)) << 8) | len) : 0u;
+                if (!FAR) sRec[q[k]] = nr;
+                else if (nr) { const uint32_t old = sRec[q[k]]; if (old == 0u || lz_gain(len, nr >> 8) > lz_gain(old & 0xFFu, old >> 8)) sRec[q[k]] = nr; }
+            }
         }
     }
     // unlisted positions: byte runs match at distance 1, the tail of the frame does not match at all
-    for (uint32_t q = t; q < T.len; q += MFV_T) {
+    if (!FAR) for (uint32_t q = t; q < T.len; q += MFV_T) {
         const uint64_t x = mf_lds_ld64(sW, q + MF_STAGE_PAD);
         const bool run = T.tileStart + q > T.frameStart && ((x << 8) | (uint64_t)mf_lds_byte(sW, q + MF_STAGE_PAD - 1u)) == x;
         const bool windowed = T.tileStart + q + GC_MATCH_CAP + 16u <= T.frameEnd;
@@ -488,6 +535,18 @@ gc_mf_verify_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t 
     GcU4* R4 = (GcU4*)(rec + T.tileStart);
     const GcU4* S4 = (const GcU4*)sRec;
     for (uint32_t i = t; i < (T.len + 3u) / 4u; i += MFV_T) R4[i] = S4[i];
+}
+extern "C" __global__ void __launch_bounds__(MFV_T)
+gc_mf_verify_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
+                    const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, uint32_t* __restrict__ rec)
+{
+    mf_verify_body<false>(src, srcSize, frameBlocks, nTiles, per, offs, ent, rec);
+}
+extern "C" __global__ void __launch_bounds__(MFV_T)
+gc_mf_verify_far_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
+                        const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, uint32_t* __restrict__ rec)
+{
+    mf_verify_body<true>(src, srcSize, frameBlocks, nTiles, per, offs, ent, rec);
 }
 
 // ------------------------------------------------------------------------------------------------ W5b deepen

@@ -154,7 +154,10 @@ gc_lzma2_prep_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __r
 #define LZW_DIRECT 0x4000u
 // event in LDS: adaptive bit = index << 1 | bit (index < 2^13), direct bit = 0x8000 | bit
 #define LZE_DIRECT 0x8000u
-#define LZ2_EVCAP  2048u              // events buffered per round (26.8 KiB of LDS per wave: six waves per CU)
+#define LZ2_EVCAP  1792u              // events buffered per round
+#define LZ2_TICKS  1024u              // ticket bytes: a probability's ticket is the byte (index mod LZ2_TICKS).  Probabilities that share a
+                                      // byte are merely ranked together (an extra round now and then); the point is LDS: 19.8 KiB per wave
+                                      // = eight waves per CU instead of five, and the kernel's throughput is waves in flight
 #define LZ2_EVMAX  (9u * GC_LZMA_LIT_CUT + 48u)                   // most events of one item
 
 struct LzEv { uint16_t* p; uint32_t n; bool store; };
@@ -277,10 +280,11 @@ __device__ __forceinline__ void lz_gen_item(LzEv& o, const uint8_t* S, uint64_t 
 extern "C" __global__ void __launch_bounds__(64)
 gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const uint64_t* __restrict__ Mall,
                       const uint32_t* __restrict__ nM, uint32_t segLog, uint32_t hasPrev /* the byte in front of src exists (src is a later part of a stream) */,
-                      uint16_t* __restrict__ stream, GcLzmaChunkInfo* __restrict__ cinfo)
+                      uint16_t* __restrict__ stream, GcLzmaChunkInfo* __restrict__ cinfo,
+                      const uint32_t* __restrict__ winCost /* W7's estimate per 4 KiB window of each block (1/16 bit), or nullptr */)
 {
     __shared__ uint16_t P[LZP_TOTAL];
-    __shared__ uint32_t sTick[(LZP_TOTAL + 3u) / 4u];             // one ticket byte per probability
+    __shared__ uint32_t sTick[LZ2_TICKS / 4u];                    // ticket bytes (see LZ2_TICKS)
     __shared__ uint16_t sEv[LZ2_EVCAP];
     __shared__ uint32_t sWordEnd[GC_LZMA_RC_PER_BLOCK];
 
@@ -293,7 +297,18 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
     const uint32_t ss = sInB << segLog;
     GcLzmaChunkInfo* CI = cinfo + (uint64_t)b * GC_LZMA_RC_PER_BLOCK + (ss >> GC_LZMA_RC_LOG);
     const uint32_t nItems = nM[b];
-    if (ss >= blockLen || nItems == 0xFFFFFFFFu) {
+    // A segment that the price-based parse already prices at or above its raw size (random or encrypted data) is stored without
+    // being modelled: nothing is lost -- it would be stored after coding anyway -- and such segments are the longest chains of
+    // this kernel and of the range coder (9 coded bits per byte), i.e. the tail of both launches.
+    bool hopeless = false;
+    if (winCost != nullptr && ss < blockLen) {
+        uint32_t est = 0;
+        for (uint32_t w = lane; w < rcPerSeg; w += 64u) { const uint32_t cs = ss + (w << GC_LZMA_RC_LOG); if (cs < blockLen) est += winCost[(uint64_t)b * GC_LZMA_RC_PER_BLOCK + (cs >> GC_LZMA_RC_LOG)]; }
+        est = gc_wave_sum(est);
+        const uint32_t segLen = (ss + segSize < blockLen ? ss + segSize : blockLen) - ss;
+        hopeless = est >= segLen * 128u;                          // 8 bits per byte in 1/16 bit units
+    }
+    if (ss >= blockLen || nItems == 0xFFFFFFFFu || hopeless) {
         // no such segment -- or the item list overflowed (cannot happen for lists built by L1; kept as a guard): store it
         for (uint32_t c = lane; c < rcPerSeg; c += 64u) {
             const uint32_t cs = ss + (c << GC_LZMA_RC_LOG);
@@ -307,7 +322,7 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
     const uint64_t* M = Mall + (uint64_t)b * GC_LZMA_MAX_ITEMS;
 
     for (uint32_t i = lane; i < LZP_TOTAL; i += 64u) P[i] = 1024u;
-    for (uint32_t i = lane; i < (LZP_TOTAL + 3u) / 4u; i += 64u) sTick[i] = 0;
+    for (uint32_t i = lane; i < LZ2_TICKS / 4u; i += 64u) sTick[i] = 0;
     if (lane < GC_LZMA_RC_PER_BLOCK) sWordEnd[lane] = 0;
 
     // items of this segment = items that END in (ss, se]  (a cut at position ss closes the previous segment)
@@ -414,9 +429,9 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
                 const uint32_t ev = valid ? sEv[e0 + lane] : 0u;
                 const bool adaptive = valid && (ev & LZE_DIRECT) == 0u;
                 const uint32_t idx = (ev >> 1) & 0x1FFFu, bit = ev & 1u;
-                const uint32_t sh = (idx & 3u) * 8u;
+                const uint32_t tk = idx & (LZ2_TICKS - 1u), sh = (tk & 3u) * 8u;
                 uint32_t rank = 0;
-                if (adaptive) rank = (atomicAdd(&sTick[idx >> 2], 1u << sh) >> sh) & 0xFFu;   // lower lanes with the same probability
+                if (adaptive) rank = (atomicAdd(&sTick[tk >> 2], 1u << sh) >> sh) & 0xFFu;   // lower lanes with the same ticket byte
                 uint32_t p = 0;
                 for (uint32_t r = 0; __any(adaptive && rank >= r); r++) {
                     if (adaptive && rank == r) {
@@ -425,7 +440,7 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
                     }
                     gc_wave_sync();
                 }
-                if (adaptive && rank == 0u) sTick[idx >> 2] = 0;             // (lanes that share the word all write 0)
+                if (adaptive && rank == 0u) sTick[tk >> 2] = 0;              // (lanes that share the word all write 0)
                 if (valid) W[wpos + e0 + lane] = (uint16_t)(adaptive ? (p | (bit ? LZW_BIT : 0u)) : (LZW_DIRECT | (bit ? LZW_BIT : 0u)));
                 gc_wave_sync();
             }

@@ -190,7 +190,8 @@ def main():
         algo_bytes = n * (1.0 + 1.0 / ratio)
         achieved = algo_bytes / (per_kernel[dom] * 1e-3) / 1e9
         mf_names = {"mf.count": "gc_mf_count_kernel", "mf.scan": "gc_mf_scan_kernel", "mf.scatter": "gc_mf_scatter_kernel",
-                    "mf.link": "gc_mf_link_kernel", "mf.verify": "gc_mf_verify_kernel", "mf.parse": "gc_mf_parse_kernel"}
+                    "mf.link": "gc_mf_link_kernel", "mf.verify": "gc_mf_verify_kernel", "mf.parse": "gc_mf_parse_kernel",
+                    "mf.short": "gc_mf_short_kernel", "mf.dp": "gc_mf_dp2_kernel" if fl2 else "gc_mf_dp3_kernel"}
         kname = mf_names[dom] if dom in mf_names else \
             "gc_zstd_lz_kernel" if dom == "lz" else ("gc_lzma2_%s_kernel" if fl2 else ("gc_brotli_%s_kernel" if br else "gc_zstd_%s_kernel")) % dom
         traffic = None

@@ -55,17 +55,25 @@ static void rc_norm(Rc* rc)
         rc->range <<= 8; rc->code = (rc->code << 8) | rc->in[rc->inPos++];
     }
 }
+/* optional observation hooks (tools/lzma2_stats.c defines them before including this file; the checker builds without) */
+#ifndef GCO_ON_BIT
+#define GCO_ON_BIT(p, bit)
+#define GCO_ON_DIRECT(n)
+#define GCO_ON_SYM(kind, len, dist)
+#endif
 static unsigned rc_bit(Rc* rc, uint16_t* prob)
 {
     uint32_t bound;
     rc_norm(rc);
     bound = (rc->range >> 11) * *prob;
+    GCO_ON_BIT(*prob, rc->code >= bound);
     if (rc->code < bound) { rc->range = bound; *prob = (uint16_t)(*prob + ((2048 - *prob) >> 5)); return 0; }
     rc->range -= bound; rc->code -= bound; *prob = (uint16_t)(*prob - (*prob >> 5)); return 1;
 }
 static unsigned rc_direct(Rc* rc, unsigned n)
 {
     unsigned v = 0;
+    GCO_ON_DIRECT(n);
     while (n--) { rc_norm(rc); rc->range >>= 1; if (rc->code >= rc->range) { rc->code -= rc->range; v = (v << 1) | 1; } else v <<= 1; }
     return v;
 }
@@ -119,9 +127,10 @@ static int lzma_chunk(Lz* z, Probs* P, const uint8_t* in, size_t inPos, size_t c
                 } while (sym < 0x100);
             }
             dst[pos++] = (uint8_t)sym;
+            GCO_ON_SYM(0, 1, 0);
             z->state = z->state < 4 ? 0 : (z->state < 10 ? z->state - 3 : z->state - 6);
         } else {
-            unsigned len; uint32_t dist;
+            unsigned len; uint32_t dist; int kind = 1;
             if (!rc_bit(&rc, &P->isRep[z->state])) {
                 unsigned slot, lenState;
                 len = len_decode(&rc, P->lenC, posState);
@@ -142,15 +151,17 @@ static int lzma_chunk(Lz* z, Probs* P, const uint8_t* in, size_t inPos, size_t c
                     if (!rc_bit(&rc, &P->isRep0Long[z->state][posState])) {
                         if (pos - dicStart <= z->reps[0]) return 21;
                         dst[pos] = dst[pos - z->reps[0] - 1]; pos++;
+                        GCO_ON_SYM(2, 1, z->reps[0]);
                         z->state = z->state < kNumLitStates ? 9 : 11;
                         continue;
                     }
+                    kind = 3;
                 } else {
                     uint32_t d;
-                    if (!rc_bit(&rc, &P->isRepG1[z->state])) d = z->reps[1];
+                    if (!rc_bit(&rc, &P->isRepG1[z->state])) { d = z->reps[1]; kind = 4; }
                     else {
-                        if (!rc_bit(&rc, &P->isRepG2[z->state])) d = z->reps[2];
-                        else { d = z->reps[3]; z->reps[3] = z->reps[2]; }
+                        if (!rc_bit(&rc, &P->isRepG2[z->state])) { d = z->reps[2]; kind = 5; }
+                        else { d = z->reps[3]; z->reps[3] = z->reps[2]; kind = 6; }
                         z->reps[2] = z->reps[1];
                     }
                     z->reps[1] = z->reps[0]; z->reps[0] = d;
@@ -159,6 +170,7 @@ static int lzma_chunk(Lz* z, Probs* P, const uint8_t* in, size_t inPos, size_t c
                 z->state = z->state < kNumLitStates ? 8 : 11;
             }
             len += 2; dist = z->reps[0];
+            GCO_ON_SYM(kind, len, dist);
             if (pos - dicStart <= dist || dist >= dictSize) return 22;
             if (pos + len > end) return 23;                /* a match may not cross the chunk end (LzmaDec.c remainLen handling is for streaming) */
             while (len--) { dst[pos] = dst[pos - dist - 1]; pos++; }

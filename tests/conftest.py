@@ -12,6 +12,40 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _no_gpu_here():
+    try:
+        import torch
+        return not torch.cuda.is_available()
+    except Exception:
+        return True
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_cmdline_main(config):
+    """CPU runs (no GPU in the machine) spread the test FILES over a few worker processes (pytest-xdist, if installed): the SIMT
+    emulator is slow and single-threaded.  GPU runs stay in one process (one device, and the driver records which libraries that
+    process loads).  GC_TEST_WORKERS overrides (0 = off)."""
+    want = os.environ.get("GC_TEST_WORKERS")
+    n = int(want) if want is not None else (4 if _no_gpu_here() else 0)
+    if os.environ.get("PYTEST_XDIST_WORKER") or hasattr(config, "workerinput"):
+        return                                     # inside a worker: never nest
+    if n > 0 and getattr(config.option, "numprocesses", None) is None and config.pluginmanager.hasplugin("xdist"):
+        config.option.numprocesses = n
+        config.option.dist = "loadfile"
+        config.option.tx = ["popen"] * n          # (what -n would have filled in)
+
+
+class _BuildLock:
+    """Serialises on-demand builds of the checkers between xdist workers."""
+    def __enter__(self):
+        import fcntl
+        self.f = open(os.path.join(ROOT, "tests", ".build.lock"), "w")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+    def __exit__(self, *a):
+        import fcntl
+        fcntl.flock(self.f, fcntl.LOCK_UN); self.f.close()
+
+
 @pytest.fixture(scope="session")
 def graft():
     import __graft_entry__ as g
@@ -26,7 +60,8 @@ def pkg(graft):
 @pytest.fixture(scope="session")
 def O():
     import oracle
-    oracle.port()        # builds libgc_oracle.so on demand
+    with _BuildLock():
+        oracle.port()        # builds libgc_oracle.so on demand
     return oracle
 
 
@@ -34,7 +69,8 @@ def O():
 def emu_lib_path(graft):
     """The product's HIP sources compiled against the SIMT emulator (tests/emu) -- CPU bring-up only."""
     import subprocess
-    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "emu"), "-j8"], check=True, capture_output=True)
+    with _BuildLock():
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "emu"), "-j8"], check=True, capture_output=True)
     return os.path.join(ROOT, "tests", "emu", "_build", "libgpucodec_emu.so")
 
 

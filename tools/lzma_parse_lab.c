@@ -105,9 +105,12 @@ static void finder(int depth, int minMatch, int use3)
 {
     recOff = calloc(N, 4); recLen = calloc(N, 1); rec3Off = calloc(N, 4); rec3Len = calloc(N, 1);
     u32* tL = malloc(4u << 20), *tS = malloc(4u << 19), *t3 = malloc(4u << 16);
+    int nx = 0, xk[8]; u32* tX[8];              /* LAB_MULTI=12,16,24: extra "most recent wins" tables keyed on longer prefixes */
+    if (getenv("LAB_MULTI")) { const char* e = getenv("LAB_MULTI"); while (*e && nx < 8) { xk[nx] = atoi(e); tX[nx] = malloc(4u << 20); nx++; while (*e && *e != ',') e++; if (*e) e++; } }
     for (u32 f = 0; f < N; f += FRAME) {
         u32 fe = f + FRAME < N ? f + FRAME : N;
         memset(tL, 0xFF, 4u << 20); memset(tS, 0xFF, 4u << 19); memset(t3, 0xFF, 4u << 16);
+        for (int j = 0; j < nx; j++) memset(tX[j], 0xFF, 4u << 20);
         for (u32 p = f; p + CAP + 16 <= fe; p++) {
             u64 x; memcpy(&x, S + p, 8);
             u32 lo = (u32)x, hi = (u32)(x >> 32);
@@ -120,6 +123,11 @@ static void finder(int depth, int minMatch, int use3)
             u32 bl = 0, bo = 0;
             if (cL != 0xFFFFFFFFu) { u32 l = mlen(p, cL, CAP); if (l >= (u32)minMatch) { bl = l; bo = p - cL; } }
             if (bl < 8 && cS != 0xFFFFFFFFu && cS != cL) { u32 l = mlen(p, cS, CAP); if (l >= (u32)minMatch && (bl == 0 || gain(l, p - cS) > gain(bl, bo))) { bl = l; bo = p - cS; } }
+            for (int j = 0; j < nx; j++) {
+                u64 h = 0xcbf29ce484222325ull; for (int q = 0; q < xk[j]; q++) h = (h ^ S[p + q]) * 0x100000001b3ull;
+                u32 hx = (u32)(h >> 44), c = tX[j][hx]; tX[j][hx] = p;
+                if (c != 0xFFFFFFFFu) { u32 l = mlen(p, c, CAP); if (l >= (u32)minMatch && (bl == 0 || gain(l, p - c) > gain(bl, bo))) { bl = l; bo = p - c; } }
+            }
             recOff[p] = bo; recLen[p] = bl;
         }
     }
@@ -134,6 +142,13 @@ static void finder(int depth, int minMatch, int use3)
         free(recOff); free(recLen); recOff = o2; recLen = l2;
     }
     free(tL); free(tS); free(t3);
+    if (getenv("LAB_INHERIT")) {                   /* left-neighbour inheritance: the match that covers p-1 also covers p */
+        u32 cnt = 0;
+        for (u32 p = 1; p < N; p++) { u32 l = recLen[p - 1], d = recOff[p - 1]; if (l < 3 || (p % FRAME) == 0) continue; u32 l1 = l - 1;
+            if (l == CAP) l1 = mlen(p, p - d, CAP);   /* capped: the real remainder */
+            if (l1 >= 2 && (recLen[p] == 0 || gain(l1, d) > gain(recLen[p], recOff[p]))) { recLen[p] = l1; recOff[p] = d; cnt++; } }
+        fprintf(stderr, "   inherited %u records\n", cnt);
+    }
 }
 
 /* reference-like candidates: longest match (nearest among equals) by a deep hash-chain search on 3 bytes; replaces rec[] */
