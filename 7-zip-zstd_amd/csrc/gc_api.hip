@@ -40,6 +40,9 @@ extern "C" __global__ void gc_mf_scan_kernel(uint32_t*, uint32_t);
 extern "C" __global__ void gc_mf_scatter_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
 extern "C" __global__ void gc_mf_link_kernel(const uint32_t*, const GcMfEntry*, GcMfEntry*, uint32_t, uint64_t);
 extern "C" __global__ void gc_mf_verify_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
+extern "C" __global__ void gc_mf_count_short_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
+extern "C" __global__ void gc_mf_scatter_short_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
+extern "C" __global__ void gc_mf_verify_short_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, const uint32_t*, uint32_t*);
 extern "C" __global__ void gc_mf_count_far_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
 extern "C" __global__ void gc_mf_scatter_far_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
 extern "C" __global__ void gc_mf_verify_far_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
@@ -71,6 +74,7 @@ struct gc_ctx {
     uint32_t nParts;
     uint32_t lazyDepth;       // W6: 1 = one-step lazy, 2 = lazy2 (set per call from codec + level)
     uint32_t searchDepth;     // W5b: match links followed per position (0 = W5's two candidates only)
+    uint32_t shortPass;       // third finder pass with 4- / 3-byte keys; its merged records feed the price-based parse only
     uint32_t farPass;         // second finder pass with 16- / 12-byte keys (longer matches), merged into the records by gain
     uint32_t priceParse;      // W5s + W7: price-based parse on top of the greedy one (gc_lz_price.hip)
     uint32_t priceMinLen, priceLitCtx;        // its shortest match and literal context bits (LZMA: 2, 7; zstd: 3, 0)
@@ -231,7 +235,7 @@ static int ensure_finder_workspace(gc_ctx* c, size_t n, uint32_t frameBlocks)
     const size_t needCnt = g.cntWords * sizeof(uint32_t), needEnt = (size_t)g.nFrames * g.frameBytes * sizeof(GcMfEntry);
     const size_t needRec = (size_t)g.nBlocks * GC_ZSTD_BLOCK_MAX * sizeof(uint32_t);
     const size_t needPrice = (size_t)g.nBlocks * GC_PRICE_WORDS * sizeof(uint16_t);
-    if (needCnt > c->mfCntCap || needEnt > c->mfEntCap || needEnt > c->mfEnt2Cap || needRec > c->mfRecCap || (c->searchDepth && needRec > c->mfRec2Cap) ||
+    if (needCnt > c->mfCntCap || needEnt > c->mfEntCap || needEnt > c->mfEnt2Cap || needRec > c->mfRecCap || ((c->searchDepth || c->shortPass) && needRec > c->mfRec2Cap) ||
         (c->priceParse && (needRec / 2u > c->mfRec3Cap || needRec > c->mfDpCap || needPrice > c->mfPriceCap || (size_t)g.nBlocks * 128u > c->mfWinCostCap))) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         int rc;
@@ -239,7 +243,7 @@ static int ensure_finder_workspace(gc_ctx* c, size_t n, uint32_t frameBlocks)
         if ((rc = mf_grow(c, (void**)&c->mfEnt, &c->mfEntCap, needEnt, "entries")) != GC_OK) return rc;
         if ((rc = mf_grow(c, (void**)&c->mfEnt2, &c->mfEnt2Cap, needEnt, "linked entries")) != GC_OK) return rc;
         if ((rc = mf_grow(c, (void**)&c->mfRec, &c->mfRecCap, needRec, "records")) != GC_OK) return rc;
-        if (c->searchDepth && (rc = mf_grow(c, (void**)&c->mfRec2, &c->mfRec2Cap, needRec, "deepened records")) != GC_OK) return rc;
+        if ((c->searchDepth || c->shortPass) && (rc = mf_grow(c, (void**)&c->mfRec2, &c->mfRec2Cap, needRec, "deepened records")) != GC_OK) return rc;
         if (c->priceParse) {
             if ((rc = mf_grow(c, (void**)&c->mfRec3, &c->mfRec3Cap, needRec / 2u, "short candidates")) != GC_OK) return rc;
             if ((rc = mf_grow(c, (void**)&c->mfDp, &c->mfDpCap, needRec, "price-parse records")) != GC_OK) return rc;
@@ -294,6 +298,17 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
         GC_LAUNCH(gc_mf_deepen_kernel, perT * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, c->searchDepth, (const uint32_t*)rec, rec2);
         rec = rec2;
     }
+    const uint32_t* recDp = rec;                                // what W7 reads: the records, or the records + short candidates
+    if (c->priceParse && c->shortPass) {                        // third pass with 4- / 3-byte keys (timed with W5)
+        uint32_t* recN = rec == c->mfRec + (size_t)blk0 * GC_ZSTD_BLOCK_MAX ? c->mfRec2 + (size_t)blk0 * GC_ZSTD_BLOCK_MAX : c->mfRec + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
+        GC_LAUNCH(gc_mf_count_short_kernel, perT * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, cnt);
+        GC_LAUNCH(gc_mf_scan_kernel, g.nFrames, 1024, st, cnt, g.tilesPerFrame);
+        GC_LAUNCH(gc_mf_scatter_short_kernel, perT * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt, ent);
+        GC_LAUNCH(gc_mf_link_kernel, g.nFrames * GC_MF_PARTS * GC_MF_LINK_SEGS, 64, st, (const uint32_t*)cnt, (const GcMfEntry*)ent, ent2, g.tilesPerFrame, g.frameBytes);
+        GC_LAUNCH(gc_mf_verify_short_kernel, perT * GC_XCDS, GC_MF_VERIFY_T, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt,
+                  (const GcMfEntry*)ent2, (const uint32_t*)rec, recN);
+        recDp = recN;
+    }
     HIPCHK(c, hipEventRecord(ev[5], st));
     if (c->priceParse) {
         // greedy parse first (its symbol statistics become the block's price table), then the price-based parse W7 over the same
@@ -308,8 +323,8 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
         GC_LAUNCH(gc_mf_short_kernel, perC * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, (uint32_t)((n + 2047u) / 2048u), perC, rec3);
         HIPCHK(c, hipEventRecord(ev[8], st));
         const uint32_t nDpWg = nBlocks * 8u, perD = gc_xcd_per(nDpWg);
-        if (c->priceMinLen <= 2u) GC_LAUNCH(gc_mf_dp2_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, c->priceLitCtx, (const uint32_t*)rec, (const uint16_t*)rec3, (const uint16_t*)price, dp, wc);
-        else GC_LAUNCH(gc_mf_dp3_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, c->priceLitCtx, (const uint32_t*)rec, (const uint16_t*)rec3, (const uint16_t*)price, dp, wc);
+        if (c->priceMinLen <= 2u) GC_LAUNCH(gc_mf_dp2_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, c->priceLitCtx, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wc);
+        else GC_LAUNCH(gc_mf_dp3_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, c->priceLitCtx, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wc);
         HIPCHK(c, hipEventRecord(ev[9], st));
         GC_LAUNCH(gc_mf_parse_kernel, perB * GC_XCDS, GC_MF_PARSE_T, st, src, (uint64_t)n, nBlocks, perB, 0u, (const uint32_t*)dp, seqRaw, lit, meta, (uint16_t*)nullptr, 0u);
     } else
@@ -387,7 +402,9 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
     c->lazyDepth = level >= 6 ? 2u : 1u;          // the reference's lazy2 begins at level 8 of its table; deeper look-ahead from 6 here
     c->searchDepth = zstd_search_depth(level);
     c->farPass = level >= 16 ? 1u : 0u;           // with the price-based parse (btopt and up)
+    c->shortPass = level >= 16 ? 1u : 0u;         // the reference's btopt strategies search 3-byte matches (minMatch 3, clevels.h:44-47)
     { const char* e = getenv("GC_FAR_PASS"); if (e) c->farPass = (uint32_t)atoi(e); }          // test hook
+    { const char* e = getenv("GC_SHORT_PASS"); if (e) c->shortPass = (uint32_t)atoi(e); }      // test hook
     c->priceMinLen = 3u; c->priceLitCtx = 0u;     // zstd: matches of >= 3 bytes, literals without context (one Huffman table per block)
     c->priceParse = level >= 16 ? 1u : 0u;        // the reference's btopt / btultra strategies start at level 16 (clevels.h:44-47)
     { const char* e = getenv("GC_PRICE_PARSE"); if (e) c->priceParse = (uint32_t)atoi(e); }    // test hook
@@ -530,9 +547,11 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     }
     uint32_t frameBlocks = flzma2_frame_blocks(level);
     c->lazyDepth = level >= 5 ? 2u : 1u;
-    c->searchDepth = level >= 5 ? (level >= 8 ? 8u : 4u) : 0u;
+    c->searchDepth = level >= 5 ? (level >= 8 ? 8u : 2u) : 0u;      // (with the far pass in, links beyond the second add < 0.1 %)
     c->farPass = level >= 5 ? 1u : 0u;            // the reference's match table resolves to depth 42 at level 5 (fl2_compress.c:37-104)
+    c->shortPass = level >= 5 ? 1u : 0u;          // ... and holds the nearest match of >= 2 bytes for every position
     { const char* e = getenv("GC_FAR_PASS"); if (e) c->farPass = (uint32_t)atoi(e); }          // test hook
+    { const char* e = getenv("GC_SHORT_PASS"); if (e) c->shortPass = (uint32_t)atoi(e); }      // test hook
     { const char* e = getenv("GC_SEARCH_DEPTH"); if (e) c->searchDepth = (uint32_t)atoi(e); }  // test hook
     c->priceMinLen = 2u; c->priceLitCtx = 7u;
     c->priceParse = level >= 5 ? 1u : 0u;         // the reference's FL2_opt / FL2_ultra strategies start at level 5 (fl2_compress.c:37-104)
@@ -679,7 +698,7 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     uint32_t frameBlocks = brotli_frame_blocks(level, bpc);
     c->lazyDepth = level >= 7 ? 2u : 1u;
     c->searchDepth = level >= 7 ? (level >= 10 ? 8u : 4u) : 0u;
-    c->farPass = level >= 7 ? 1u : 0u;
+    c->farPass = level >= 7 ? 1u : 0u; c->shortPass = 0;
     { const char* e = getenv("GC_FAR_PASS"); if (e) c->farPass = (uint32_t)atoi(e); }          // test hook
     c->priceMinLen = 3u; c->priceLitCtx = 0u;     // copies of >= 3 bytes (a 2-byte copy at a fresh distance never pays in brotli), one literal code per meta-block
     c->priceParse = level >= 6 ? 1u : 0u;         // the reference parses greedily up to quality 9; the price-based parse here pays for the

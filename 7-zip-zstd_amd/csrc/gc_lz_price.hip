@@ -262,7 +262,7 @@ __device__ __forceinline__ void dp_window(const uint8_t* __restrict__ src, uint6
         if (fallback) {
             const uint32_t r = R[p];
             uint32_t L = r & 0xFFu; if (L > n - p) L = n - p;
-            out = L >= minLen ? ((r & ~0xFFu) | L) : 0u;
+            out = (L >= minLen && (r & 0xFFu) >= GC_MIN_MATCH) ? ((r & ~0xFFu) | L) : 0u;       // (records of the short pass are left out)
         } else if (c != 0u) {
             const uint32_t off = (c >> 6) == 1u ? R[p] >> 8 : ((uint32_t)R3[p] >> 4) + 1u;
             out = (off << 8) | ((c & 63u) + 1u);

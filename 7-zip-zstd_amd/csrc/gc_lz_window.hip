@@ -85,8 +85,15 @@ __device__ __forceinline__ uint32_t mf_lds_byte(const uint32_t* sW, uint32_t i) 
 // is what brings the candidates close to the longest match the reference's exhaustive structures return (RMF_buildTable
 // radix_engine.h:920: depth 42 at level 5; ZSTD_insertBtAndGetAllMatches zstd_opt.c:590).  Equal 16 bytes imply equal 12 bytes,
 // so both keys of a position again live in one partition.
+// MODE 2 = the third pass at the levels that parse by price: keys of 4 ("long") and 3 ("short") bytes, i.e. the nearest
+// occurrence of a position's first 4 / 3 bytes anywhere in the frame -- the short matches that the reference's structures
+// deliver at every position (2-byte radix heads radix_engine.h:106-171; ZSTD's hash3 table zstd_opt.c:408) and that pay where
+// literals are expensive.  Its records (lengths from 3) only feed the price-based parse W7.
+#define MF_BASE  0
+#define MF_FAR   1
+#define MF_SHORT 2
 struct MfKeys { bool ok, run; uint32_t part; uint64_t entry; };
-template <bool FAR>
+template <int MODE>
 __device__ __forceinline__ MfKeys mf_keys(const uint32_t* sW, uint32_t q, const MfTile& T)
 {
     MfKeys r; r.ok = false; r.run = false; r.part = 0; r.entry = 0;
@@ -96,7 +103,11 @@ __device__ __forceinline__ MfKeys mf_keys(const uint32_t* sW, uint32_t q, const 
     if (q < T.len && P + GC_MATCH_CAP + 16u <= T.frameEnd && !r.run) {
         const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
         uint32_t hL = lz_hash_long(lo, hi), hS = lz_hash_short(lo, hi);
-        if (FAR) {
+        if (MODE == MF_SHORT) {
+            hS = (lo & 0xFFFFFFu) * 0x9E3779B1u; hS ^= hS >> 15; hS *= 0x2C1B3C6Du;     // bytes 0..2
+            hL = lo * 0x9E3779B1u; hL ^= hL >> 15; hL *= 0x85EBCA77u;                   // bytes 0..3
+        }
+        if (MODE == MF_FAR) {
             const uint64_t y = mf_lds_ld64(sW, q + MF_STAGE_PAD + 8u);
             const uint32_t lo1 = (uint32_t)y, hi1 = (uint32_t)(y >> 32);
             hS = hL + lo1 * 0xC2B2AE3Du;                          // bytes 0..11
@@ -114,7 +125,7 @@ __device__ __forceinline__ MfKeys mf_keys(const uint32_t* sW, uint32_t q, const 
 }
 
 // ------------------------------------------------------------------------------------------------ W1 count
-template <bool FAR>
+template <int MODE>
 __device__ __forceinline__ void mf_count_body(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per, uint32_t* __restrict__ cnt)
 {
     __shared__ uint32_t sW[MF_STAGE_WORDS];
@@ -128,7 +139,7 @@ __device__ __forceinline__ void mf_count_body(const uint8_t* __restrict__ src, u
     if (T.len) mf_stage(sW, MF_STAGE_WORDS, src, srcSize, T.tileStart, t, MF_T);
     __syncthreads();
     for (uint32_t q = t; q < T.len; q += MF_T) {
-        const MfKeys k = mf_keys<FAR>(sW, q, T);
+        const MfKeys k = mf_keys<MODE>(sW, q, T);
         if (k.ok) atomicAdd(&sHist[k.part], 1u);
     }
     __syncthreads();
@@ -137,12 +148,17 @@ __device__ __forceinline__ void mf_count_body(const uint8_t* __restrict__ src, u
 extern "C" __global__ void __launch_bounds__(MF_T)
 gc_mf_count_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per, uint32_t* __restrict__ cnt)
 {
-    mf_count_body<false>(src, srcSize, frameBlocks, nTiles, per, cnt);
+    mf_count_body<MF_BASE>(src, srcSize, frameBlocks, nTiles, per, cnt);
+}
+extern "C" __global__ void __launch_bounds__(MF_T)
+gc_mf_count_short_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per, uint32_t* __restrict__ cnt)
+{
+    mf_count_body<MF_SHORT>(src, srcSize, frameBlocks, nTiles, per, cnt);
 }
 extern "C" __global__ void __launch_bounds__(MF_T)
 gc_mf_count_far_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per, uint32_t* __restrict__ cnt)
 {
-    mf_count_body<true>(src, srcSize, frameBlocks, nTiles, per, cnt);
+    mf_count_body<MF_FAR>(src, srcSize, frameBlocks, nTiles, per, cnt);
 }
 
 // ------------------------------------------------------------------------------------------------ W2 scan
@@ -188,7 +204,7 @@ gc_mf_scan_kernel(uint32_t* __restrict__ cnt, uint32_t tilesPerFrame)
 // Stable counting sort of one tile by partition, staged through LDS as a permutation (16-bit tile positions), so that every
 // partition's run leaves the CU as one contiguous, coalesced store stream.  Wave w owns quarter w of the tile; ranks inside a
 // 64-position round come from ballots (position order = lane order), so the order inside a partition is position order.
-template <bool FAR>
+template <int MODE>
 __device__ __forceinline__ void mf_scatter_body(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
                      const uint32_t* __restrict__ offs, GcMfEntry* __restrict__ ent)
 {
@@ -209,7 +225,7 @@ __device__ __forceinline__ void mf_scatter_body(const uint8_t* __restrict__ src,
     const uint32_t qBase = wave * (GC_MF_TILE / MF_WAVES);
     // pass A: per-wave histograms
     for (uint32_t r = 0; r < GC_MF_TILE / MF_T; r++) {
-        const MfKeys k = mf_keys<FAR>(sW, qBase + r * 64u + lane, T);
+        const MfKeys k = mf_keys<MODE>(sW, qBase + r * 64u + lane, T);
         if (k.ok) atomicAdd(&sRun[wave][k.part], 1u);
     }
     __syncthreads();
@@ -233,7 +249,7 @@ __device__ __forceinline__ void mf_scatter_body(const uint8_t* __restrict__ src,
     const uint64_t lt = gc_lanemask_lt();
     for (uint32_t r = 0; r < GC_MF_TILE / MF_T; r++) {
         const uint32_t q = qBase + r * 64u + lane;
-        const MfKeys k = mf_keys<FAR>(sW, q, T);
+        const MfKeys k = mf_keys<MODE>(sW, q, T);
         uint64_t peers = __ballot(k.ok);
         if (peers != 0ull) {                                      // uniform
 #pragma unroll
@@ -256,7 +272,7 @@ __device__ __forceinline__ void mf_scatter_body(const uint8_t* __restrict__ src,
     // output: slot j of the sorted tile -> its partition's run in HBM
     GcMfEntry* E = ent + (uint64_t)T.frame * ((uint64_t)frameBlocks * GC_ZSTD_BLOCK_MAX);
     for (uint32_t j = t; j < nEnt; j += MF_T) {
-        const MfKeys k = mf_keys<FAR>(sW, sPerm[j], T);
+        const MfKeys k = mf_keys<MODE>(sW, sPerm[j], T);
         E[sGlob[k.part] + (j - sLocal[k.part])] = k.entry;
     }
 }
@@ -264,13 +280,19 @@ extern "C" __global__ void __launch_bounds__(MF_T)
 gc_mf_scatter_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
                      const uint32_t* __restrict__ offs, GcMfEntry* __restrict__ ent)
 {
-    mf_scatter_body<false>(src, srcSize, frameBlocks, nTiles, per, offs, ent);
+    mf_scatter_body<MF_BASE>(src, srcSize, frameBlocks, nTiles, per, offs, ent);
+}
+extern "C" __global__ void __launch_bounds__(MF_T)
+gc_mf_scatter_short_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
+                           const uint32_t* __restrict__ offs, GcMfEntry* __restrict__ ent)
+{
+    mf_scatter_body<MF_SHORT>(src, srcSize, frameBlocks, nTiles, per, offs, ent);
 }
 extern "C" __global__ void __launch_bounds__(MF_T)
 gc_mf_scatter_far_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
                          const uint32_t* __restrict__ offs, GcMfEntry* __restrict__ ent)
 {
-    mf_scatter_body<true>(src, srcSize, frameBlocks, nTiles, per, offs, ent);
+    mf_scatter_body<MF_FAR>(src, srcSize, frameBlocks, nTiles, per, offs, ent);
 }
 
 // ------------------------------------------------------------------------------------------------ W4 link
@@ -403,19 +425,22 @@ __device__ __forceinline__ LzW16 mf_lds_ld16(const uint32_t* sW, uint32_t i)
     LzW16 w; w.a = mf_lds_ld64(sW, i); w.b = mf_lds_ld64(sW, i + 8u); return w;
 }
 // first 16 bytes of candidate c (frame-relative position + 1) against the own window; 0 if shorter than GC_MIN_MATCH
-__device__ __forceinline__ uint32_t mfv_len16(const LzW16& me, const LzW16& cw, uint32_t maxLen)
+__device__ __forceinline__ uint32_t mfv_len16(const LzW16& me, const LzW16& cw, uint32_t maxLen, uint32_t minLen = GC_MIN_MATCH)
 {
     uint32_t len = lz_cmp16(me, cw);
     if (len > maxLen) len = maxLen;
-    return len >= GC_MIN_MATCH ? len : 0u;
+    return len >= minLen ? len : 0u;
 }
 
-// FAR: the candidates come from the second pass (16- and 12-byte keys); rec already holds the records of the first pass and a
-// position's record is replaced only by a candidate of better gain.
-template <bool FAR>
+// MF_FAR / MF_SHORT: the candidates come from a later pass; recIn holds the records so far and a position's record is replaced
+// only by a candidate of better gain (recIn == rec: in place; a workgroup reads and writes its own tile only).
+template <int MODE>
 __device__ __forceinline__ void mf_verify_body(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
-                    const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, uint32_t* __restrict__ rec)
+                    const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, const uint32_t* recIn, uint32_t* rec)
 {
+    constexpr bool FAR = MODE != MF_BASE;                         // a merging pass
+    constexpr uint32_t MINLEN = MODE == MF_SHORT ? 3u : GC_MIN_MATCH;
+    constexpr uint32_t LONGLEN = MODE == MF_SHORT ? 4u : (MODE == MF_FAR ? 16u : 8u);   // a verified long candidate has this many bytes
     __shared__ uint32_t sW[MFV_STAGE_WORDS];
     __shared__ uint32_t sRec[GC_MF_TILE];
     __shared__ uint32_t sStart[GC_MF_PARTS], sLocal[GC_MF_PARTS + 1u];
@@ -437,7 +462,7 @@ __device__ __forceinline__ void mf_verify_body(const uint8_t* __restrict__ src, 
     }
     mf_stage(sW, MFV_STAGE_WORDS, src, srcSize, T.tileStart, t, MFV_T);
     if (FAR) {                                                    // records of the first pass
-        const GcU4* R4 = (const GcU4*)(rec + T.tileStart);
+        const GcU4* R4 = (const GcU4*)(recIn + T.tileStart);
         GcU4* S4 = (GcU4*)sRec;
         for (uint32_t i = t; i < (T.len + 3u) / 4u; i += MFV_T) S4[i] = R4[i];
     }
@@ -485,15 +510,15 @@ __device__ __forceinline__ void mf_verify_body(const uint8_t* __restrict__ src, 
         }
 #pragma unroll
         for (uint32_t k = 0; k < MFV_B; k++) {
-            bestLen[k] = bestC[k] ? mfv_len16(mf_lds_ld16(sW, q[k] + MF_STAGE_PAD), cw[k], maxLen[k]) : 0u;
-            if (bestLen[k] >= (FAR ? 16u : 8u) || maxLen[k] == 0u) cS[k] = 0;  // verified long candidate: the short one is not needed
+            bestLen[k] = bestC[k] ? mfv_len16(mf_lds_ld16(sW, q[k] + MF_STAGE_PAD), cw[k], maxLen[k], MINLEN) : 0u;
+            if (bestLen[k] >= LONGLEN || maxLen[k] == 0u) cS[k] = 0;  // verified long candidate: the short one is not needed
             if (cS[k]) cw[k] = lz_ld16(wsrc, cS[k] - 1u);
         }
 #pragma unroll
         for (uint32_t k = 0; k < MFV_B; k++) {
             const uint32_t pw = wTile + q[k];
             if (cS[k]) {
-                const uint32_t len = mfv_len16(mf_lds_ld16(sW, q[k] + MF_STAGE_PAD), cw[k], maxLen[k]);
+                const uint32_t len = mfv_len16(mf_lds_ld16(sW, q[k] + MF_STAGE_PAD), cw[k], maxLen[k], MINLEN);
                 if (len && (bestLen[k] == 0u || lz_gain(len, pw - (cS[k] - 1u)) > lz_gain(bestLen[k], pw - (bestC[k] - 1u)))) { bestLen[k] = len; bestC[k] = cS[k]; }
             }
             uint32_t len = bestLen[k];
@@ -540,13 +565,19 @@ extern "C" __global__ void __launch_bounds__(MFV_T)
 gc_mf_verify_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
                     const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, uint32_t* __restrict__ rec)
 {
-    mf_verify_body<false>(src, srcSize, frameBlocks, nTiles, per, offs, ent, rec);
+    mf_verify_body<MF_BASE>(src, srcSize, frameBlocks, nTiles, per, offs, ent, rec, rec);
 }
 extern "C" __global__ void __launch_bounds__(MFV_T)
 gc_mf_verify_far_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
                         const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, uint32_t* __restrict__ rec)
 {
-    mf_verify_body<true>(src, srcSize, frameBlocks, nTiles, per, offs, ent, rec);
+    mf_verify_body<MF_FAR>(src, srcSize, frameBlocks, nTiles, per, offs, ent, rec, rec);
+}
+extern "C" __global__ void __launch_bounds__(MFV_T)
+gc_mf_verify_short_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
+                          const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, const uint32_t* __restrict__ recIn, uint32_t* __restrict__ recOut)
+{
+    mf_verify_body<MF_SHORT>(src, srcSize, frameBlocks, nTiles, per, offs, ent, recIn, recOut);
 }
 
 // ------------------------------------------------------------------------------------------------ W5b deepen
@@ -784,6 +815,12 @@ gc_mf_parse_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t n
     for (uint32_t i = t; i < GC_PRICE_WORDS; i += PZ_T) {
         uint32_t pr;
         if (i < GC_PRICE_LEN) pr = pz_price(10u * sStat[i] + 3u, 10u * sSum[i >> 8] + 768u);
+        else if (i < GC_PRICE_LEN + GC_MIN_MATCH) {
+            // lengths below the finder's own minimum never occur in the greedy parse; W7 is offered them (W5s, short pass).  Priced as
+            // if each were as frequent as the average of the five lengths above them: what they cost once the coder has adapted
+            const uint32_t avg = (sStat[GC_PRICE_LEN + 5u] + sStat[GC_PRICE_LEN + 6u] + sStat[GC_PRICE_LEN + 7u] + sStat[GC_PRICE_LEN + 8u] + sStat[GC_PRICE_LEN + 9u]) / 5u;
+            pr = pz_price(2u * avg + 1u, 2u * (nMat + 3u * avg) + 63u);
+        }
         else if (i < GC_PRICE_SLOT) pr = pz_price(2u * sStat[i] + 1u, 2u * nMat + 63u);
         else if (i < GC_PRICE_FLAGS) pr = pz_price(2u * sStat[i] + 1u, 2u * nMat + 44u);
         else if (i == GC_PRICE_FLAGS) pr = pz_price(nLit + 1u, nLit + nMat + 2u);          // "this symbol is a literal"
