@@ -23,7 +23,7 @@ _ERR = {-1: "GC_ERR_NO_DEVICE", -2: "GC_ERR_HIP", -3: "GC_ERR_NOMEM", -4: "GC_ER
 
 EXPORTS = ["gc_device_count", "gc_ctx_create", "gc_ctx_destroy", "gc_last_error_message", "gc_zstd_compress_bound",
            "gc_zstd_compress_device", "gc_zstd_finish", "gc_zstd_compress_host", "gc_zstd_last_timing", "gc_ctx_stream",
-           "gc_zstd_set_phase_profile", "gc_zstd_phase_profile", "gc_mf_last_timing", "gc_mf_price_timing",
+           "gc_zstd_set_phase_profile", "gc_zstd_phase_profile", "gc_mf_last_timing", "gc_mf_price_timing", "gc_mf_pass_timing",
            "gc_flzma2_compress_bound", "gc_flzma2_dict_prop", "gc_flzma2_compress_device", "gc_flzma2_finish", "gc_flzma2_compress_host",
            "gc_flzma2_last_timing",
            "gc_brotli_compress_bound", "gc_brotli_compress_device", "gc_brotli_finish", "gc_brotli_compress_host", "gc_brotli_last_timing"]
@@ -60,6 +60,8 @@ def load_library(path=None):
     lib.gc_mf_last_timing.restype = C.c_int
     lib.gc_mf_price_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.gc_mf_price_timing.restype = C.c_int
+    lib.gc_mf_pass_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    lib.gc_mf_pass_timing.restype = C.c_int
     lib.gc_zstd_set_phase_profile.argtypes = [C.c_void_p, C.c_int]
     lib.gc_zstd_set_phase_profile.restype = C.c_int
     lib.gc_zstd_phase_profile.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
@@ -132,6 +134,12 @@ class _EncoderBase:
             d["mf.parse"] = float(pm[0]) + float(pm[3])               # W6 twice (greedy + statistics, then following W7's records)
             d["mf.short"] = float(pm[1])
             d["mf.dp"] = float(pm[2])
+        ps = (C.c_float * 4)()
+        if self._lib.gc_mf_pass_timing(self._ctx, ps) == GC_OK and (ps[1] or ps[2] or ps[3]):   # extra passes ran: split "verify"
+            d["mf.verify"] = float(ps[0])
+            d["mf.far"] = float(ps[1])
+            d["mf.deepen"] = float(ps[2])
+            d["mf.shortpass"] = float(ps[3])
         return d
 
 

@@ -93,7 +93,8 @@ struct gc_ctx {
     // windowed match finder (gc_mf.h): counts/offsets, partition starts, entry lists; grown on demand
     uint32_t* mfCnt; size_t mfCntCap; GcMfEntry* mfEnt; size_t mfEntCap; GcMfEntry* mfEnt2; size_t mfEnt2Cap; uint32_t* mfRec; size_t mfRecCap; uint32_t* mfRec2; size_t mfRec2Cap;
     uint16_t* mfRec3; size_t mfRec3Cap; uint32_t* mfDp; size_t mfDpCap; uint16_t* mfPrice; size_t mfPriceCap; uint32_t* mfWinCost; size_t mfWinCostCap;      // W5s records, W7 records, price tables
-    hipEvent_t evMf[GC_MAX_PARTS][10];      // per part: W1 start, W1 end, W2 end, W3 end, W4 end, W5 end, W6 end; price-based parse: greedy W6 end, W5s end, W7 end
+    hipEvent_t evMf[GC_MAX_PARTS][13];      // per part: W1 start, W1 end, W2 end, W3 end, W4 end, W5 end, W6 end; price-based parse: greedy W6 end, W5s end, W7 end;
+                                            // inside W5: first verify end, far pass end, deepen end
     bool mfPriced;                          // the last call ran the price-based parse (events 7..9 are valid)
     bool mfTimed; uint32_t mfParts;
     int lastCodec;            // 0 zstd, 1 flzma2: which kernels the events of the last call bracket
@@ -139,7 +140,7 @@ extern "C" int gc_ctx_create(gc_ctx** out, int device)
     if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess || hipStreamCreate(&c->stream3) != hipSuccess) { delete c; return GC_ERR_HIP; }
     for (int i = 0; i < 8; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return GC_ERR_HIP; }
     for (uint32_t p = 0; p < GC_MAX_PARTS; p++) {
-        for (int i = 0; i < 10; i++) if (hipEventCreate(&c->evMf[p][i]) != hipSuccess) { delete c; return GC_ERR_HIP; }
+        for (int i = 0; i < 13; i++) if (hipEventCreate(&c->evMf[p][i]) != hipSuccess) { delete c; return GC_ERR_HIP; }
         for (uint32_t i = 0; i < GC_PART_EVENTS; i++) if (hipEventCreate(&c->evPart[p][i]) != hipSuccess) { delete c; return GC_ERR_HIP; }
     }
     if (hipMalloc((void**)&c->prof, (GC_LZ_PHASES + GC_SEQ_PHASES) * sizeof(unsigned long long)) != hipSuccess) { delete c; return GC_ERR_NOMEM; }
@@ -171,7 +172,7 @@ extern "C" void gc_ctx_destroy(gc_ctx* c)
     hipFree(c->mfCnt); hipFree(c->mfEnt); hipFree(c->mfEnt2); hipFree(c->mfRec); hipFree(c->mfRec2); hipFree(c->mfRec3); hipFree(c->mfDp); hipFree(c->mfPrice); hipFree(c->mfWinCost);
     for (int i = 0; i < 8; i++) hipEventDestroy(c->ev[i]);
     for (uint32_t p = 0; p < GC_MAX_PARTS; p++) {
-        for (int i = 0; i < 10; i++) hipEventDestroy(c->evMf[p][i]);
+        for (int i = 0; i < 13; i++) hipEventDestroy(c->evMf[p][i]);
         for (uint32_t i = 0; i < GC_PART_EVENTS; i++) hipEventDestroy(c->evPart[p][i]);
     }
     hipStreamDestroy(c->stream3);
@@ -285,6 +286,7 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
     HIPCHK(c, hipEventRecord(ev[4], st));
     GC_LAUNCH(gc_mf_verify_kernel, perT * GC_XCDS, GC_MF_VERIFY_T, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt,
               (const GcMfEntry*)ent2, rec);
+    HIPCHK(c, hipEventRecord(ev[10], st));
     if (c->farPass) {                                           // second pass with 16- / 12-byte keys, merged into rec (timed with W5)
         GC_LAUNCH(gc_mf_count_far_kernel, perT * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, cnt);
         GC_LAUNCH(gc_mf_scan_kernel, g.nFrames, 1024, st, cnt, g.tilesPerFrame);
@@ -293,11 +295,13 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
         GC_LAUNCH(gc_mf_verify_far_kernel, perT * GC_XCDS, GC_MF_VERIFY_T, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt,
                   (const GcMfEntry*)ent2, rec);
     }
+    HIPCHK(c, hipEventRecord(ev[11], st));
     if (c->searchDepth) {                                       // W5b: follow match links (timed with W5)
         uint32_t* rec2 = c->mfRec2 + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
         GC_LAUNCH(gc_mf_deepen_kernel, perT * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, c->searchDepth, (const uint32_t*)rec, rec2);
         rec = rec2;
     }
+    HIPCHK(c, hipEventRecord(ev[12], st));
     const uint32_t* recDp = rec;                                // what W7 reads: the records, or the records + short candidates
     if (c->priceParse && c->shortPass) {                        // third pass with 4- / 3-byte keys (timed with W5)
         uint32_t* recN = rec == c->mfRec + (size_t)blk0 * GC_ZSTD_BLOCK_MAX ? c->mfRec2 + (size_t)blk0 * GC_ZSTD_BLOCK_MAX : c->mfRec + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
@@ -363,6 +367,18 @@ extern "C" int gc_mf_price_timing(gc_ctx* c, float ms[4])
 {
     if (!c || !c->timed || c->pending || !c->mfTimed || !c->mfPriced) return GC_ERR_PARAM;
     static const int a[4] = { 5, 7, 8, 9 }, b[4] = { 7, 8, 9, 6 };
+    for (int i = 0; i < 4; i++) ms[i] = 0.f;
+    for (uint32_t p = 0; p < c->mfParts; p++)
+        for (int i = 0; i < 4; i++) { float t = 0.f; HIPCHK(c, hipEventElapsedTime(&t, c->evMf[p][a[i]], c->evMf[p][b[i]])); ms[i] += t; }
+    return GC_OK;
+}
+
+// ms[0..3] = the parts of gc_mf_last_timing's "verify" entry: W5 itself, the far pass (W1'..W5' with 16- / 12-byte keys), W5b link
+// following, the short pass (W1"..W5" with 4- / 3-byte keys); a part that did not run reads 0
+extern "C" int gc_mf_pass_timing(gc_ctx* c, float ms[4])
+{
+    if (!c || !c->timed || c->pending || !c->mfTimed) return GC_ERR_PARAM;
+    static const int a[4] = { 4, 10, 11, 12 }, b[4] = { 10, 11, 12, 5 };
     for (int i = 0; i < 4; i++) ms[i] = 0.f;
     for (uint32_t p = 0; p < c->mfParts; p++)
         for (int i = 0; i < 4; i++) { float t = 0.f; HIPCHK(c, hipEventElapsedTime(&t, c->evMf[p][a[i]], c->evMf[p][b[i]])); ms[i] += t; }

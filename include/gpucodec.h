@@ -69,6 +69,12 @@ int         gc_mf_last_timing(gc_ctx* ctx, float ms[6]);
  * last call did not run it. */
 int         gc_mf_price_timing(gc_ctx* ctx, float ms[4]);
 
+/* The "verify" entry of gc_mf_last_timing covers up to four groups of kernels: ms[0..3] = W5 verify, the far pass (a second
+ * W1..W5 with 16- / 12-byte keys: the longer matches that RMF_buildTable radix_engine.h:920 / ZSTD_insertBtAndGetAllMatches
+ * zstd_opt.c:590 return), W5b link following, the short pass (a third W1..W5 with 4- / 3-byte keys feeding the price-based
+ * parse).  Parts that did not run read 0. */
+int         gc_mf_pass_timing(gc_ctx* ctx, float ms[4]);
+
 /* Optional in-kernel phase profile (shader-clock deltas measured by thread 0 of every workgroup, averaged over
  * blocks): cycles[0..6] = K1 {probe, insert, verify, double, chain, walk, emit}, cycles[7..11] = K3 {merge,
  * codes, tables, chains, pack}, cycles[12..15] = parts of K3's chains phase {stage, warm-up, walk, copy-out}.  Off by default (no cost when off). */
