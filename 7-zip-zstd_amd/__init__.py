@@ -135,11 +135,11 @@ class _EncoderBase:
             d["mf.short"] = float(pm[1])
             d["mf.dp"] = float(pm[2])
         ps = (C.c_float * 4)()
-        if self._lib.gc_mf_pass_timing(self._ctx, ps) == GC_OK and (ps[1] or ps[2] or ps[3]):   # extra passes ran: split "verify"
-            d["mf.verify"] = float(ps[0])
-            d["mf.far"] = float(ps[1])
-            d["mf.deepen"] = float(ps[2])
-            d["mf.shortpass"] = float(ps[3])
+        if self._lib.gc_mf_pass_timing(self._ctx, ps) == GC_OK and max(ps[1], ps[2], ps[3]) > 0.02:   # extra passes ran: split "verify"
+            d["mf.verify"] = float(ps[0])           # (a part that did not run reads the few microseconds between two event records)
+            for k, v in (("mf.far", ps[1]), ("mf.deepen", ps[2]), ("mf.shortpass", ps[3])):
+                if v > 0.02:
+                    d[k] = float(v)
         return d
 
 
