@@ -118,7 +118,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    g.build_hip()
+    if rank == 0:
+        g.build_hip()                    # (a no-op when the in-tree library is up to date; never two ranks at once)
+    if dist is not None:
+        dist.barrier()
     pkg = g.load_package()
     from importlib import util as _u
     spec = _u.spec_from_file_location("sevenzip_zstd_amd_corpus", os.path.join(ROOT, "7-zip-zstd_amd", "corpus", "__init__.py"))

@@ -99,7 +99,7 @@ def test_emu_many_frames_and_parts(O, pkg, emu_lib_path, monkeypatch):
     """The multi-frame and multi-part paths on a small input: test hooks shrink the match-finder frame to 2 blocks and make every
     frame its own part (stages of different parts run on different streams; a later part's first literal has the last byte of
     the previous part as its context).  Parts must not change the stream: same bytes as the single-part run."""
-    x = O.corpus("silesia-like", 5 * 2 * BLK + 4321)
+    x = O.corpus("silesia-like", 3 * 2 * BLK + 4321)
     monkeypatch.setenv("GC_FRAME_BLOCKS", "2")
     one = pkg.Flzma2Encoder(lib_path=emu_lib_path, level=5)
     c1 = _roundtrip(O, one, x); one.close()
@@ -116,7 +116,7 @@ def test_emu_ratio_band_vs_reference(O, emu_fl2):
     x = O.corpus("text-zipf", 4 * BLK)
     ours = len(emu_fl2[5].code(x))
     ref, _ = O.ref_fl2_compress(x, 5)
-    assert ours <= 1.25 * len(ref), (ours, len(ref))
+    assert ours <= 1.06 * len(ref), (ours, len(ref))      # 1.033 with the far + short pass and the price-based parse
 
 
 def test_emu_shards_concatenate(O, emu_fl2):
