@@ -144,6 +144,17 @@ class _EncoderBase:
 
 
 class Flzma2Encoder(_EncoderBase):
+    L2_PHASES = ("l2.header_cycles", "l2.generate_cycles", "l2.apply_cycles", "l2.apply_steps", "l2.rounds", "l2.segments")
+
+    def set_phase_profile(self, on=True):
+        self._check(self._lib.gc_zstd_set_phase_profile(self._ctx, 1 if on else 0), "gc_zstd_set_phase_profile")
+
+    def phase_profile(self):
+        """Sums over all model segments of the last call: shader cycles per L2 phase, 64-event application steps, rounds played."""
+        v = (C.c_double * 16)()
+        self._check(self._lib.gc_zstd_phase_profile(self._ctx, v), "gc_zstd_phase_profile")
+        return dict(zip(self.L2_PHASES, [float(x) for x in v[:6]]))
+
     """Mirror of NCompress::NLzma2::CFastEncoder (CPP/7zip/Compress/Lzma2Encoder.h:60-100; Code() at Lzma2Encoder.cpp:260-350):
     bytes -> LZMA2 chunk stream; `coder_props()` is what WriteCoderProperties emits (1 byte dictionary size, :353-364)."""
 

@@ -154,8 +154,8 @@ gc_lzma2_prep_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __r
 #define LZW_DIRECT 0x4000u
 // event in LDS: adaptive bit = index << 1 | bit (index < 2^13), direct bit = 0x8000 | bit
 #define LZE_DIRECT 0x8000u
-#define LZ2_EVCAP  1792u              // events buffered per round
-#define LZ2_TICKS  1024u              // ticket bytes: a probability's ticket is the byte (index mod LZ2_TICKS).  Probabilities that share a
+#define LZ2_EVCAP  1600u              // events buffered per round
+#define LZ2_TICKS  2048u              // ticket bytes: a probability's ticket is the byte (index mod LZ2_TICKS).  Probabilities that share a
                                       // byte are merely ranked together (an extra round now and then); the point is LDS: 19.8 KiB per wave
                                       // = eight waves per CU instead of five, and the kernel's throughput is waves in flight
 #define LZ2_EVMAX  (9u * GC_LZMA_LIT_CUT + 48u)                   // most events of one item
@@ -281,7 +281,10 @@ extern "C" __global__ void __launch_bounds__(64)
 gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const uint64_t* __restrict__ Mall,
                       const uint32_t* __restrict__ nM, uint32_t segLog, uint32_t hasPrev /* the byte in front of src exists (src is a later part of a stream) */,
                       uint16_t* __restrict__ stream, GcLzmaChunkInfo* __restrict__ cinfo,
-                      const uint32_t* __restrict__ winCost /* W7's estimate per 4 KiB window of each block (1/16 bit), or nullptr */)
+                      const uint32_t* __restrict__ winCost /* W7's estimate per 4 KiB window of each block (1/16 bit), or nullptr */,
+                      unsigned long long* __restrict__ prof /* optional phase profile (shader-clock sums over all segments): [0] tile header
+                         (item loads + scans), [1] event generation, [2] event application, [3] application steps (64 events each),
+                         [4] rounds played, [5] segments; nullptr = off */)
 {
     __shared__ uint16_t P[LZP_TOTAL];
     __shared__ uint32_t sTick[LZ2_TICKS / 4u];                    // ticket bytes (see LZ2_TICKS)
@@ -345,6 +348,8 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
     uint32_t cLits = 0;               // literals coded since the last match item (in cut items)
     uint32_t wpos = 0;                // words written so far
 
+    unsigned long long tprev = prof ? gc_clock() : 0ull, pc0 = 0, pc1 = 0, pc2 = 0; uint32_t pSteps = 0, pRounds = 0;
+#define L2_PHASE(acc) do { if (prof) { const unsigned long long now_ = gc_clock(); acc += now_ - tprev; tprev = now_; } } while (0)
     for (uint32_t base = first; base < last; base += 64u) {
         const uint32_t cnt = last - base < 64u ? last - base : 64u;
 #ifdef HIPEMU
@@ -408,6 +413,7 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
         // ---- rounds: as many items as fit the event buffer, generated by their lanes, applied 64 events at a time
         uint32_t done = 0;                                                   // items of this tile already coded
         uint32_t evDone = 0;                                                 // their events
+        L2_PHASE(pc0);
         while (done < cnt) {
 #ifdef HIPEMU
             if (getenv("GC_TRACE_LZ") && lane >= done && lane < cnt && nEv > LZ2_EVMAX) { fprintf(stderr, "  BAD item k=%u pos=%u len=%u off=%u prevEnd=%u ll=%u nEv=%u\n", base + lane, it.pos, it.len, it.off, prevEnd, ll, nEv); abort(); }
@@ -423,28 +429,40 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
                 lz_gen_item(o, S, blockBase, srcSize, hasPrev, prevEnd, it, st0, pOff, kind);
             }
             gc_wave_sync();
+            L2_PHASE(pc1);
             const uint32_t total = evEnd - evDone;
             for (uint32_t e0 = 0; e0 < total; e0 += 64u) {
                 const bool valid = e0 + lane < total;
-                const uint32_t ev = valid ? sEv[e0 + lane] : 0u;
-                const bool adaptive = valid && (ev & LZE_DIRECT) == 0u;
+                const uint32_t ev = valid ? sEv[e0 + lane] : LZE_DIRECT;
+                const bool adaptive = (ev & LZE_DIRECT) == 0u;
                 const uint32_t idx = (ev >> 1) & 0x1FFFu, bit = ev & 1u;
                 const uint32_t tk = idx & (LZ2_TICKS - 1u), sh = (tk & 3u) * 8u;
                 uint32_t rank = 0;
                 if (adaptive) rank = (atomicAdd(&sTick[tk >> 2], 1u << sh) >> sh) & 0xFFu;   // lower lanes with the same ticket byte
-                uint32_t p = 0;
-                for (uint32_t r = 0; __any(adaptive && rank >= r); r++) {
-                    if (adaptive && rank == r) {
+                // The rounds communicate through LDS only, and the LDS unit executes the operations of one wave in program order: the
+                // read of round r + 1 is queued behind the write of round r (no fence).  Measured (run 22-25, phase profile): a step
+                // costs ~1400 cycles at ~3 rounds -- instruction issue as much as LDS latency -- so the loop is kept short (the
+                // update is a select).  (Issuing the next step's ticket atomics and event loads ahead
+                // of the rounds was tried and gained nothing.)
+                const uint32_t my = adaptive ? rank : 0xFFFFFFFFu;
+                const uint32_t left = adaptive ? rank + 1u : 0u;             // rounds this lane still needs
+                uint32_t p = 0, nRounds = 0;
+                for (uint32_t r = 0; __any(left > r); r++) {
+                    if (my == r) {
                         p = P[idx];
-                        P[idx] = (uint16_t)(bit ? p - (p >> 5) : p + ((2048u - p) >> 5));
+                        const uint32_t up = p + ((2048u - p) >> 5), dn = p - (p >> 5);
+                        P[idx] = (uint16_t)(bit ? dn : up);
                     }
-                    gc_wave_sync();
+                    gc_wave_step();
+                    nRounds++;
                 }
-                if (adaptive && rank == 0u) sTick[tk >> 2] = 0;              // (lanes that share the word all write 0)
+                if (prof) { pRounds += nRounds; pSteps++; }
+                if (my == 0u) sTick[tk >> 2] = 0;                            // (lanes that share the word all write 0)
                 if (valid) W[wpos + e0 + lane] = (uint16_t)(adaptive ? (p | (bit ? LZW_BIT : 0u)) : (LZW_DIRECT | (bit ? LZW_BIT : 0u)));
-                gc_wave_sync();
+                gc_wave_step();
             }
             wpos += total; evDone = evEnd; done = upto;
+            L2_PHASE(pc2);
         }
         // ---- carries
         const uint32_t lastLane = cnt - 1u;
@@ -461,6 +479,10 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
         gc_wave_sync();
     }
     gc_wave_sync();
+    if (prof && lane == 0u) {
+        atomicAdd(&prof[0], pc0); atomicAdd(&prof[1], pc1); atomicAdd(&prof[2], pc2);
+        atomicAdd(&prof[3], (unsigned long long)pSteps); atomicAdd(&prof[4], (unsigned long long)pRounds); atomicAdd(&prof[5], 1ull);
+    }
     for (uint32_t c = lane; c < rcPerSeg; c += 64u) {
         const uint32_t cs = ss + (c << GC_LZMA_RC_LOG);
         GcLzmaChunkInfo ci; ci.usize = cs < se ? ((se - cs) < GC_LZMA_RC_SIZE ? (se - cs) : GC_LZMA_RC_SIZE) : 0u;

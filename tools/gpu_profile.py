@@ -33,7 +33,10 @@ for _ in range(a.reps):
     size = run()
     for k, v in enc.last_timing_ms().items(): acc[k] = acc.get(k, 0) + v / a.reps
     for k, v in (enc.mf_timing_ms() or {}).items(): acc[k] = acc.get(k, 0) + v / a.reps
-if fl2 or br:
+if fl2:
+    enc.set_phase_profile(True)
+    run(); ph = enc.phase_profile(); tp = acc
+elif br:
     ph, tp = {}, acc
 else:
     enc.set_phase_profile(True)
