@@ -119,10 +119,12 @@ gc_mf_short_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t f
 
 template <uint32_t minLen /* shortest match: 2 LZMA, 3 zstd */>
 __device__ __forceinline__ void dp_window(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per,
-                uint32_t litCtxMask /* bits of (previous byte >> 5) that select the literal price row: 7 LZMA (lc = 3), 0 zstd */,
+                uint32_t litCtxArg /* bits of (previous byte >> 5) that select the literal price row: 7 LZMA (lc = 3), 0 zstd; bit 31: the
+                                      byte in front of src exists (src is a later part of one buffer) */,
                 const uint32_t* __restrict__ rec, const uint16_t* __restrict__ rec3, const uint16_t* __restrict__ priceTab, uint32_t* __restrict__ recOut,
                 uint32_t* __restrict__ winCost /* per window: cost of the cheapest path in 1/16 bit (an estimate of its coded size), or nullptr */)
 {
+    const uint32_t litCtxMask = litCtxArg & 0xFFu, hasPrev = litCtxArg >> 31;
     __shared__ uint16_t sPrice[GC_PRICE_WORDS];
     __shared__ uint8_t sRow[DP_WAVES][DP_ROWS][64];               // back pointers by end node, later edges by start node
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = gc_uniform(t >> 6);        // (uniform: the node index i must live in an SGPR)
@@ -160,7 +162,7 @@ __device__ __forceinline__ void dp_window(const uint8_t* __restrict__ src, uint6
     GcPub pL, pA, pL3, pA3, pC, pD;       // per position of the group: candidate lengths, word addends (distance price), literal addend, distance
     // raw inputs of the NEXT group, requested one group (64 nodes) ahead of their use
     uint32_t nR = 0, nR3 = GC_SHORT_NONE, nByte = 0, nPrev = 0;
-    if (lane < n) { nR = R[lane]; nR3 = R3[lane]; nByte = S[lane]; nPrev = (base + w0 + lane) ? (uint32_t)S[(int64_t)lane - 1] : 0u; }
+    if (lane < n) { nR = R[lane]; nR3 = R3[lane]; nByte = S[lane]; nPrev = (base + w0 + lane + hasPrev) ? (uint32_t)S[(int64_t)lane - 1] : 0u; }
     uint32_t i = 0;
     while (i < n) {
         const uint32_t g = i >> 6, k = i & 63u;

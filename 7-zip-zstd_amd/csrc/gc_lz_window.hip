@@ -695,8 +695,10 @@ __device__ __forceinline__ uint32_t pz_price(uint32_t num, uint32_t den)
 extern "C" __global__ void __launch_bounds__(PZ_T)
 gc_mf_parse_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t lazy, const uint32_t* __restrict__ rec,
                    GcSeqRaw* __restrict__ seqRaw, uint8_t* __restrict__ lit, GcBlockMeta* __restrict__ meta, uint16_t* __restrict__ priceTab,
-                   uint32_t litCtxMask /* price statistics: bits of (previous byte >> 5) that select the literal row */)
+                   uint32_t litCtxArg /* price statistics: bits of (previous byte >> 5) that select the literal row; bit 31: the byte in
+                                         front of src exists (src is a later part of one buffer), so position 0 has a real context */)
 {
+    const uint32_t litCtxMask = litCtxArg & 0xFFu, hasPrev = litCtxArg >> 31;
     __shared__ uint32_t sStat[GC_PRICE_WORDS];                    // symbol statistics of this parse (only when priceTab != nullptr)
     __shared__ uint8_t  sGExit[PZ_GROUPS][64];
     __shared__ uint32_t sEntry[PZ_GROUPS];
@@ -790,7 +792,7 @@ gc_mf_parse_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t n
             if ((mL >> lane) & 1ull) {
                 const uint32_t byte = bsrc[p];
                 myLit[myLitRank] = (uint8_t)byte;
-                if (stats) atomicAdd(&sStat[GC_PRICE_LIT + ((((base + p) ? (uint32_t)bsrc[(int64_t)p - 1] >> 5 : 0u) & litCtxMask) << 8) + byte], 1u);
+                if (stats) atomicAdd(&sStat[GC_PRICE_LIT + ((((base + p + hasPrev) ? (uint32_t)bsrc[(int64_t)p - 1] >> 5 : 0u) & litCtxMask) << 8) + byte], 1u);
             }
             seqRun += (uint32_t)__popcll(mS); litRun += (uint32_t)__popcll(mL);
         }
