@@ -30,6 +30,7 @@
 #include "gc_brotli.h"
 
 #define BR_T 256u
+#define BR_WIN_WORDS 2048u     // 8 KiB: the bits of one tile of 256 commands are assembled in LDS and leave as full words
 #define BR_LONG 48u            // literal runs up to this length are walked by the command's own lane
 
 // ---- format tables (RFC 7932 section 5)
@@ -88,6 +89,17 @@ __device__ __forceinline__ void br_or_bits(uint32_t* buf, uint64_t pos, uint64_t
     if (w0) atomicOr(&buf[word], w0);
     if ((uint32_t)rest) atomicOr(&buf[word + 1], (uint32_t)rest);
     if ((uint32_t)(rest >> 32)) atomicOr(&buf[word + 2], (uint32_t)(rest >> 32));
+}
+// the same into an LDS window (bit offset relative to the window's first word)
+__device__ __forceinline__ void br_or_bits_lds(uint32_t* win, uint32_t pos, uint64_t v, uint32_t nbits)
+{
+    if (nbits == 0u) return;
+    const uint32_t word = pos >> 5, sh = pos & 31u;
+    const uint32_t w0 = (uint32_t)(v << sh);
+    const uint64_t rest = sh ? (v >> (32u - sh)) : (v >> 32);
+    if (w0) atomicOr(&win[word], w0);
+    if ((uint32_t)rest) atomicOr(&win[word + 1u], (uint32_t)rest);
+    if ((uint32_t)(rest >> 32)) atomicOr(&win[word + 2u], (uint32_t)(rest >> 32));
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -266,6 +278,7 @@ gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
     __shared__ uint8_t  sHdr[1024];
     __shared__ uint32_t sWave[8];
     __shared__ uint32_t sMisc[8];
+    __shared__ uint32_t sBits[BR_WIN_WORDS];                               // bit window of one tile of commands (see below)
 
     const uint32_t t = threadIdx.x, b = blockIdx.x;
     const uint64_t blockBase = (uint64_t)b * GC_ZSTD_BLOCK_MAX;
@@ -406,13 +419,36 @@ gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
         const uint32_t myBits = headBits + litBits + tailBits;
         const uint64_t q = bitBase + br_excl_scan(myBits, sWave, &tileBits);
         if (bitBase + tileBits + 64u >= (uint64_t)blockLen * 8u) { ok = false; break; }   // no gain: stored meta-block; nothing past the raw size is ever written
+        // The tile's bits form one contiguous range of the stream.  Without long literal runs (those are written cooperatively
+        // below) and if the range fits the window, it is assembled in LDS and leaves as whole words: plain stores for the words
+        // that lie entirely inside the range, an atomic OR only for its first and last word (shared with the neighbouring tiles /
+        // the header).  Bit by bit into HBM, every output word took ~5 global atomics (PMC: 6 x the algorithmic bytes).
+        uint32_t nLongTile; br_excl_scan(isLong ? 1u : 0u, sWave, &nLongTile);
+        const uint64_t word0 = bitBase >> 5;
+        const uint32_t nWinWords = (uint32_t)(((bitBase + tileBits + 31u) >> 5) - word0);
+        const bool useWin = nLongTile == 0u && tileBits != 0u && nWinWords + 2u <= BR_WIN_WORDS;      // uniform
+        if (useWin) { for (uint32_t i = t; i < nWinWords + 2u; i += BR_T) sBits[i] = 0; __syncthreads(); }
         if (valid) {
             uint64_t hv = cCmd[c.sym]; uint32_t hn = dCmd[c.sym];
             hv |= (uint64_t)c.insExtraVal << hn; hn += c.insExtraBits;
             hv |= (uint64_t)c.copyExtraVal << hn; hn += c.copyExtraBits;
-            br_or_bits(out, q, hv, hn);
-            if (!isLong) { uint64_t pos = q + headBits; for (uint32_t i = 0; i < ll; i++) { const uint32_t sy = L[ls + i]; br_or_bits(out, pos, cLit[sy], dLit[sy]); pos += dLit[sy]; } }
-            if (c.hasDist) br_or_bits(out, q + headBits + litBits, (uint64_t)cDist[c.dsym] | ((uint64_t)c.dExtraVal << dDist[c.dsym]), dDist[c.dsym] + c.dExtraBits);
+            if (useWin) {
+                const uint32_t rq = (uint32_t)(q - (word0 << 5));
+                br_or_bits_lds(sBits, rq, hv, hn);
+                { uint32_t pos = rq + headBits; for (uint32_t i = 0; i < ll; i++) { const uint32_t sy = L[ls + i]; br_or_bits_lds(sBits, pos, cLit[sy], dLit[sy]); pos += dLit[sy]; } }
+                if (c.hasDist) br_or_bits_lds(sBits, rq + headBits + litBits, (uint64_t)cDist[c.dsym] | ((uint64_t)c.dExtraVal << dDist[c.dsym]), dDist[c.dsym] + c.dExtraBits);
+            } else {
+                br_or_bits(out, q, hv, hn);
+                if (!isLong) { uint64_t pos = q + headBits; for (uint32_t i = 0; i < ll; i++) { const uint32_t sy = L[ls + i]; br_or_bits(out, pos, cLit[sy], dLit[sy]); pos += dLit[sy]; } }
+                if (c.hasDist) br_or_bits(out, q + headBits + litBits, (uint64_t)cDist[c.dsym] | ((uint64_t)c.dExtraVal << dDist[c.dsym]), dDist[c.dsym] + c.dExtraBits);
+            }
+        }
+        if (useWin) {
+            __syncthreads();
+            for (uint32_t i = t; i < nWinWords; i += BR_T) {
+                const uint32_t v = sBits[i];
+                if (v) { if (i == 0u || i + 1u == nWinWords) atomicOr(&out[word0 + i], v); else out[word0 + i] = v; }
+            }
         }
         // long runs: cooperative write, 256 literals per step with a running bit offset
         for (uint32_t w0 = 0; w0 < BR_T / 64u; w0++) {
