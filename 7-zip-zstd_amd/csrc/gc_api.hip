@@ -53,7 +53,7 @@ extern "C" __global__ void gc_mf_dp2_kernel(const uint8_t*, uint64_t, uint32_t, 
 extern "C" __global__ void gc_mf_dp3_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
 
 extern "C" __global__ void gc_lzma2_prep_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t, uint64_t*, uint32_t*);
-extern "C" __global__ void gc_lzma2_model_kernel(const uint8_t*, uint64_t, const uint64_t*, const uint32_t*, uint32_t, uint32_t, uint16_t*, GcLzmaChunkInfo*, const uint32_t*, unsigned long long*);
+extern "C" __global__ void gc_lzma2_model_kernel(const uint8_t*, uint64_t, const uint64_t*, const uint32_t*, uint32_t, uint32_t, uint16_t*, GcLzmaChunkInfo*, const uint32_t*, unsigned long long*, uint32_t);
 extern "C" __global__ void gc_lzma2_rc_kernel(const uint16_t*, uint32_t, uint32_t, uint8_t*, GcLzmaChunkInfo*);
 extern "C" __global__ void gc_lzma2_plan_kernel(const GcLzmaChunkInfo*, uint32_t, uint32_t, uint64_t, uint32_t, GcLzmaPlan*, uint64_t*);
 extern "C" __global__ void gc_lzma2_emit_kernel(const uint8_t*, uint32_t, const uint8_t*, const GcLzmaChunkInfo*, const GcLzmaPlan*, uint32_t,
@@ -588,6 +588,8 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     if (frameBlocks <= 1u) nParts = 1u;
     c->mfTimed = false; c->nParts = nParts;
     const uint32_t segPerBlock = GC_ZSTD_BLOCK_MAX >> segLog;
+    uint32_t mergeWords = GC_LZMA_RC_MERGE_WORDS;
+    { const char* e = getenv("GC_RC_MERGE_WORDS"); if (e) mergeWords = (uint32_t)atoi(e); }    // test hook: 0 = one LZMA2 chunk per rc chunk
     if (c->profOn) { HIPCHK(c, hipMemsetAsync(c->prof, 0, (GC_LZ_PHASES + GC_SEQ_PHASES) * sizeof(unsigned long long), c->stream)); c->profBlocks = 1u; }   // L2 phase sums (raw)
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     uint32_t f0 = 0;
@@ -613,7 +615,7 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
                   (const uint32_t*)(c->lzNM + blk0), segLog, (uint32_t)(off != 0u ? 1u : 0u),
                   c->lzStream + (size_t)blk0 * segPerBlock * GC_LZMA_STREAM_WORDS(segLog), c->lzInfo + (size_t)blk0 * GC_LZMA_RC_PER_BLOCK,
                   (const uint32_t*)((c->priceParse && frameBlocks > 1u) ? c->mfWinCost + (size_t)blk0 * 32u : nullptr),
-                  c->profOn ? c->prof : nullptr);
+                  c->profOn ? c->prof : nullptr, mergeWords);
         HIPCHK(c, hipEventRecord(ev[4], c->stream2));
         // stage 3 (stream3): range coder
         HIPCHK(c, hipStreamWaitEvent(c->stream3, ev[4], 0));

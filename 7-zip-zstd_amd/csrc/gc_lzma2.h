@@ -31,7 +31,8 @@
 // Units of the FLZMA2 path (all sizes are powers of two and nest: rc chunk <= model segment <= 128 KiB match-finder block):
 //   model segment  2^segLog bytes (level dependent, 16..128 KiB): the adaptive model runs through it sequentially and is
 //                  reset at its start (LZMA2 control 0xC0 / 0xE0) -- the unit of parallelism of the model kernel (one wave)
-//   rc chunk       4 KiB: one LZMA2 chunk.  The LZMA2 format restarts the range coder at every chunk anyway (and only the
+//   rc chunk       4 KiB: one LZMA2 chunk (or, where the data compresses well, a group of up to 8 neighbours of one segment
+//                  coded as one: GC_LZMA_RC_MERGE_WORDS).  The LZMA2 format restarts the range coder at every chunk anyway (and only the
 //                  range coder: control 0x80 keeps probabilities, state and repeat distances), so the chunks of a segment can
 //                  be range-coded independently once the model has resolved their probabilities -- the unit of parallelism of
 //                  the range-coder kernel (one lane)
@@ -39,6 +40,8 @@
 #define GC_LZMA_RC_SIZE     (1u << GC_LZMA_RC_LOG)
 #define GC_LZMA_RC_PER_BLOCK (GC_ZSTD_BLOCK_MAX >> GC_LZMA_RC_LOG)
 #define GC_LZMA_RC_STRIDE   (GC_LZMA_RC_SIZE + 1024u)     // bytes of range-coder output reserved per rc chunk (LZMA expands < 2 %)
+#define GC_LZMA_RC_GROUP_MAX 8u                           // rc chunks that may be coded as one LZMA2 chunk (32 KiB: below the 64 KiB of a stored chunk)
+#define GC_LZMA_RC_MERGE_WORDS 36864u                     // ... while their coded bits stay within this many words: what 4 KiB of literals cost (9 per byte)
 #define GC_LZMA_SEG_LOG_MIN 14u
 #define GC_LZMA_SEG_LOG_MAX 17u
 

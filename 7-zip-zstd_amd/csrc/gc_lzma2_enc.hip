@@ -284,7 +284,11 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
                       const uint32_t* __restrict__ winCost /* W7's estimate per 4 KiB window of each block (1/16 bit), or nullptr */,
                       unsigned long long* __restrict__ prof /* optional phase profile (shader-clock sums over all segments): [0] tile header
                          (item loads + scans), [1] event generation, [2] event application, [3] application steps (64 events each),
-                         [4] rounds played, [5] segments; nullptr = off */)
+                         [4] rounds played, [5] segments; nullptr = off */,
+                      uint32_t mergeWords /* neighbouring rc chunks of a segment are coded as ONE LZMA2 chunk while their coded bits stay
+                         within this many words (0 = never): a chunk costs 10 bytes (5 of header, 5 of range-coder start / flush), which
+                         is 1 % of a well-compressed 4 KiB; the bound keeps the longest range-coder chain what it is for 4 KiB of
+                         incompressible data */)
 {
     __shared__ uint16_t P[LZP_TOTAL];
     __shared__ uint32_t sTick[LZ2_TICKS / 4u];                    // ticket bytes (see LZ2_TICKS)
@@ -483,10 +487,30 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
         atomicAdd(&prof[0], pc0); atomicAdd(&prof[1], pc1); atomicAdd(&prof[2], pc2);
         atomicAdd(&prof[3], (unsigned long long)pSteps); atomicAdd(&prof[4], (unsigned long long)pRounds); atomicAdd(&prof[5], 1ull);
     }
-    for (uint32_t c = lane; c < rcPerSeg; c += 64u) {
-        const uint32_t cs = ss + (c << GC_LZMA_RC_LOG);
-        GcLzmaChunkInfo ci; ci.usize = cs < se ? ((se - cs) < GC_LZMA_RC_SIZE ? (se - cs) : GC_LZMA_RC_SIZE) : 0u;
-        ci.csize = 0; ci.wordStart = c ? sWordEnd[c - 1u] : 0u; ci.wordEnd = sWordEnd[c]; CI[c] = ci;
+    // rc chunks -> LZMA2 chunks: greedy groups of neighbours (one lane; at most 32 chunks).  The leader carries the group (its
+    // uncompressed size, the word range of all members), the other members are marked absent (usize 0), which is what every
+    // later stage already skips; the group's range-coder output lies in the members' staging areas, which are contiguous.
+    if (lane == 0u) {
+        uint32_t c = 0;
+        while (c < rcPerSeg) {
+            const uint32_t cs = ss + (c << GC_LZMA_RC_LOG);
+            GcLzmaChunkInfo ci; ci.csize = 0; ci.usize = 0; ci.wordStart = 0; ci.wordEnd = 0;
+            if (cs >= se) { CI[c] = ci; c++; continue; }
+            ci.usize = (se - cs) < GC_LZMA_RC_SIZE ? (se - cs) : GC_LZMA_RC_SIZE;
+            ci.wordStart = c ? sWordEnd[c - 1u] : 0u; ci.wordEnd = sWordEnd[c];
+            uint32_t k = 1;
+            while (c + k < rcPerSeg && k < GC_LZMA_RC_GROUP_MAX) {
+                const uint32_t cs2 = ss + ((c + k) << GC_LZMA_RC_LOG);
+                if (cs2 >= se || sWordEnd[c + k] - ci.wordStart > mergeWords) break;
+                ci.usize += (se - cs2) < GC_LZMA_RC_SIZE ? (se - cs2) : GC_LZMA_RC_SIZE;
+                ci.wordEnd = sWordEnd[c + k];
+                k++;
+            }
+            CI[c] = ci;
+            GcLzmaChunkInfo none; none.usize = 0; none.csize = 0; none.wordStart = 0; none.wordEnd = 0;
+            for (uint32_t j = 1; j < k; j++) CI[c + j] = none;
+            c += k;
+        }
     }
 }
 
@@ -505,6 +529,7 @@ struct LzRc {
     uint32_t putQ;                    // groups of eight bytes written to memory
     uint64_t w0, w1;                  // bytes [8 * putQ, outPos): at most 15
     uint64_t* out;
+    uint32_t capQ;                    // groups of eight bytes the staging area of this chunk (group of chunks) holds
     bool act;                         // false while the lane only runs along (its state is thrown away): no memory side effects
 };
 
@@ -520,7 +545,7 @@ __device__ __forceinline__ void rc_append(LzRc& rc, uint32_t v, bool on)        
 __device__ __forceinline__ void rc_put_away(LzRc& rc)
 {
     if (rc.outPos - 8u * rc.putQ >= 8u) {
-        if (rc.act && rc.putQ < GC_LZMA_RC_STRIDE / 8u) rc.out[rc.putQ] = rc.w0;
+        if (rc.act && rc.putQ < rc.capQ) rc.out[rc.putQ] = rc.w0;
         rc.w0 = rc.w1; rc.w1 = 0; rc.putQ++;
     }
 }
@@ -562,6 +587,8 @@ gc_lzma2_rc_kernel(const uint16_t* __restrict__ stream, uint32_t segLog, uint32_
     const uint16_t* W = stream + (uint64_t)(live ? seg : 0u) * GC_LZMA_STREAM_WORDS(segLog);
     LzRc rc; rc.low = 0; rc.carry = 0; rc.range = 0xFFFFFFFFu; rc.cache = 0; rc.pend = 0; rc.outPos = 0; rc.putQ = 0; rc.w0 = 0; rc.w1 = 0; rc.act = live;
     rc.out = (uint64_t*)(rcOut + (uint64_t)(live ? c : 0u) * GC_LZMA_RC_STRIDE);
+    const uint32_t members = (ci.usize + GC_LZMA_RC_SIZE - 1u) >> GC_LZMA_RC_LOG;       // rc chunks coded as this one LZMA2 chunk
+    rc.capQ = members * (GC_LZMA_RC_STRIDE / 8u);
     // words up to the next 16-byte boundary of the stream one by one (every lane of the wave takes part in each step, lanes
     // without a word just do not advance), then eight at a time from one 16-byte load, then the rest one by one
     uint32_t k = live ? ci.wordStart : 0u;
@@ -633,7 +660,7 @@ gc_lzma2_rc_kernel(const uint16_t* __restrict__ stream, uint32_t segLog, uint32_
     }
     if (live) {
         const uint32_t n = rc.outPos;
-        if (n <= GC_LZMA_RC_STRIDE) {
+        if (n <= rc.capQ * 8u && n <= 65536u) {                // (an LZMA2 chunk holds at most 64 KiB of coded bytes)
             uint8_t* o = (uint8_t*)rc.out;
             for (uint32_t i = 8u * rc.putQ; i < n; i++) { const uint32_t pos = i - 8u * rc.putQ; o[i] = (uint8_t)((pos < 8u ? rc.w0 >> (pos * 8u) : rc.w1 >> ((pos - 8u) * 8u)) & 0xFFu); }
             cinfo[c].csize = n;
