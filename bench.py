@@ -237,7 +237,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": ("Brotli quality %d, synthetic web-text (%s, %d B per GPU), %d MiB brotli-mt chunks" % (args.level, args.corpus, n, args.level)) if br else
-                                   ("Fast-LZMA2 level %d, Silesia stand-in (%s, %d B per GPU), 8 MiB match-finder frames, 4 KiB LZMA2 chunks, model reset every %d KiB" % (args.level, args.corpus, n, {1: 16, 2: 16, 3: 16, 4: 32, 5: 32, 6: 64, 7: 64}.get(args.level, 128))) if fl2 else
+                                   ("Fast-LZMA2 level %d, Silesia stand-in (%s, %d B per GPU), 8 MiB match-finder frames, 4 KiB range-coder chunks grouped into LZMA2 chunks of <= 32 KiB, model reset every %d KiB" % (args.level, args.corpus, n, {1: 16, 2: 16, 3: 16, 4: 32, 5: 32, 6: 64, 7: 64}.get(args.level, 128))) if fl2 else
                                    "zstd level %d, enwik8 stand-in (%s, %d B per GPU), 128 KiB blocks in %s" % (
                                        args.level, args.corpus, n, "independent 8 MiB frames (windowed match finder)" if mf_ms else "one frame per block (block-local match finder)"),
                        "bytes_per_gpu": n, "blocks_per_gpu": (n + 131071) // 131072, "parallelism": "range-shard x%d, no collective" % world},
