@@ -26,7 +26,13 @@ EXPORTS = ["gc_device_count", "gc_ctx_create", "gc_ctx_destroy", "gc_last_error_
            "gc_zstd_set_phase_profile", "gc_zstd_phase_profile", "gc_mf_last_timing", "gc_mf_price_timing", "gc_mf_pass_timing",
            "gc_flzma2_compress_bound", "gc_flzma2_dict_prop", "gc_flzma2_compress_device", "gc_flzma2_finish", "gc_flzma2_compress_host",
            "gc_flzma2_last_timing",
-           "gc_brotli_compress_bound", "gc_brotli_compress_device", "gc_brotli_finish", "gc_brotli_compress_host", "gc_brotli_last_timing"]
+           "gc_brotli_compress_bound", "gc_brotli_compress_device", "gc_brotli_finish", "gc_brotli_compress_host", "gc_brotli_last_timing",
+           "gc_codec_grain", "gc_codec_compress_bound", "gc_host_begin", "gc_host_size", "gc_host_fetch", "gc_codec_compress_host",
+           "gc_host_alloc", "gc_host_free", "gc_multi_create", "gc_multi_destroy", "gc_multi_workers", "gc_multi_last_error",
+           "gc_multi_piece_bytes", "gc_multi_compress_host"]
+
+CODEC_ZSTD, CODEC_FLZMA2, CODEC_BROTLI = 0, 1, 2
+CODEC_IDS = {"zstd": CODEC_ZSTD, "flzma2": CODEC_FLZMA2, "brotli": CODEC_BROTLI}
 
 
 class GpuCodecError(RuntimeError):
@@ -90,7 +96,79 @@ def load_library(path=None):
     lib.gc_brotli_last_timing.restype = C.c_int
     lib.gc_ctx_stream.argtypes = [C.c_void_p]
     lib.gc_ctx_stream.restype = C.c_void_p
+    lib.gc_codec_grain.argtypes = [C.c_int, C.c_int]
+    lib.gc_codec_grain.restype = C.c_size_t
+    lib.gc_codec_compress_bound.argtypes = [C.c_int, C.c_size_t]
+    lib.gc_codec_compress_bound.restype = C.c_size_t
+    lib.gc_host_begin.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_uint]
+    lib.gc_host_begin.restype = C.c_int
+    lib.gc_host_size.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+    lib.gc_host_size.restype = C.c_int
+    lib.gc_host_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    lib.gc_host_fetch.restype = C.c_int
+    lib.gc_codec_compress_host.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_uint, C.POINTER(C.c_size_t)]
+    lib.gc_codec_compress_host.restype = C.c_int
+    lib.gc_host_alloc.argtypes = [C.c_size_t]
+    lib.gc_host_alloc.restype = C.c_void_p
+    lib.gc_host_free.argtypes = [C.c_void_p]
+    lib.gc_host_free.restype = None
+    lib.gc_multi_create.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int]
+    lib.gc_multi_create.restype = C.c_int
+    lib.gc_multi_destroy.argtypes = [C.c_void_p]
+    lib.gc_multi_destroy.restype = None
+    lib.gc_multi_workers.argtypes = [C.c_void_p]
+    lib.gc_multi_workers.restype = C.c_int
+    lib.gc_multi_last_error.argtypes = [C.c_void_p]
+    lib.gc_multi_last_error.restype = C.c_char_p
+    lib.gc_multi_piece_bytes.argtypes = [C.c_int, C.c_int]
+    lib.gc_multi_piece_bytes.restype = C.c_size_t
+    lib.gc_multi_compress_host.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_uint, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.gc_multi_compress_host.restype = C.c_int
     return lib
+
+
+def codec_grain(codec, level, lib_path=None):
+    """Independence grain in bytes of a codec ("zstd" / "flzma2" / "brotli") at a level (gc_codec_grain)."""
+    return load_library(lib_path).gc_codec_grain(CODEC_IDS[codec], int(level))
+
+
+class MultiEncoder:
+    """The host scheduler gc_multi (csrc/gc_multi.hip): one host buffer range-split over the contexts of the node's GPUs,
+    compressed pieces concatenated in order -- the job front end of ZSTDMT / brotli-mt (C/zstd/zstdmt_compress.c:1184-1247,
+    C/zstdmt/brotli-mt_compress.c:209-333) with GPU contexts in place of worker threads."""
+
+    def __init__(self, codec="zstd", level=None, devices=None, ctx_per_device=2, lib_path=None):
+        self._lib = load_library(lib_path)
+        self.codec = CODEC_IDS[codec]
+        self.level = {"zstd": 3, "flzma2": 5, "brotli": 6}[codec] if level is None else int(level)
+        self._m = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices) if devices else None
+        rc = self._lib.gc_multi_create(C.byref(self._m), arr, len(devices) if devices else 0, ctx_per_device)
+        if rc != GC_OK:
+            self._m = C.c_void_p()
+            raise GpuCodecError("gc_multi_create failed: %s (no GPU fallback exists)" % _ERR.get(rc, rc))
+
+    def close(self):
+        if getattr(self, "_m", None) and self._m.value:
+            self._lib.gc_multi_destroy(self._m)
+            self._m = C.c_void_p()
+
+    __del__ = close
+
+    def workers(self):
+        return self._lib.gc_multi_workers(self._m)
+
+    def code(self, data, flags=0, piece_bytes=0):
+        import numpy as np
+        a = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data, dtype=np.uint8)
+        cap = self._lib.gc_codec_compress_bound(self.codec, a.size) + 1
+        out = np.empty(cap, dtype=np.uint8)
+        n = C.c_size_t(0)
+        rc = self._lib.gc_multi_compress_host(self._m, self.codec, a.ctypes.data, a.size, out.ctypes.data, cap, self.level, flags, piece_bytes, C.byref(n))
+        if rc != GC_OK:
+            msg = self._lib.gc_multi_last_error(self._m)
+            raise GpuCodecError("gc_multi_compress_host failed: %s (%s)" % (_ERR.get(rc, rc), msg.decode() if msg else ""))
+        return out[:n.value]
 
 
 class _EncoderBase:
@@ -196,7 +274,7 @@ class Flzma2Encoder(_EncoderBase):
 
 class BrotliEncoder(_EncoderBase):
     """Mirror of NCompress::NBROTLI::CEncoder (CPP/7zip/Compress/BrotliEncoder.h:35-70; Code() at BrotliEncoder.cpp:118-164):
-    bytes -> brotli-mt framed chunks; `coder_props()` is the 3-byte blob {1, 0, level} of BrotliEncoder.h:18-32."""
+    bytes -> brotli-mt framed chunks; `coder_props()` is the 3-byte blob {BROTLI_VERSION_MAJOR 1, BROTLI_VERSION_MINOR 2, level} of BrotliEncoder.h:18-32."""
 
     KERNELS = ("lz", "block", "plan", "emit", "total")
 
@@ -207,7 +285,7 @@ class BrotliEncoder(_EncoderBase):
         return self._lib.gc_brotli_compress_bound(n)
 
     def coder_props(self):
-        return bytes([1, 0, self.level])
+        return bytes([1, 2, self.level])
 
     def code(self, data):
         import numpy as np

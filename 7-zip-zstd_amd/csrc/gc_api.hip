@@ -97,7 +97,7 @@ struct gc_ctx {
                                             // inside W5: first verify end, far pass end, deepen end
     bool mfPriced;                          // the last call ran the price-based parse (events 7..9 are valid)
     bool mfTimed; uint32_t mfParts;
-    int lastCodec;            // 0 zstd, 1 flzma2: which kernels the events of the last call bracket
+    int lastCodec;            // 0 zstd, 1 flzma2, 2 brotli: which kernels the events of the last call bracket
     uint64_t* hostResult;     // pinned
     // staging for the host-buffer entry point
     uint8_t* dIn; size_t dInCap; uint8_t* dOut; size_t dOutCap;
@@ -105,6 +105,19 @@ struct gc_ctx {
     unsigned long long* prof;  // device: GC_LZ_PHASES + GC_SEQ_PHASES cycle sums, only when profiling is on
     bool profOn; uint32_t profBlocks;
 };
+
+// Test hooks (environment variables) are validated: a value outside [lo, hi] is ignored, so that no setting can push the kernels
+// outside the geometry their entry formats were sized for (23-bit frame-relative positions, 8 MiB dictionary property, ...).
+static bool gc_env_u32(const char* name, uint32_t lo, uint32_t hi, uint32_t* out)
+{
+    const char* e = getenv(name);
+    if (!e || !*e) return false;
+    char* end = nullptr;
+    const long v = strtol(e, &end, 10);
+    if (end == e || v < (long)lo || v > (long)hi) return false;
+    *out = (uint32_t)v;
+    return true;
+}
 
 #define HIPCHK(ctx, call)                                                                       \
     do { hipError_t e_ = (call);                                                                \
@@ -123,6 +136,9 @@ extern "C" size_t gc_zstd_compress_bound(size_t n)
     return n + nb * GC_FRAME_OVERHEAD + 16;
 }
 
+static void free_workspace(gc_ctx* c);
+static void ctx_release(gc_ctx* c);
+
 extern "C" int gc_ctx_create(gc_ctx** out, int device)
 {
     if (!out) return GC_ERR_PARAM;
@@ -137,16 +153,20 @@ extern "C" int gc_ctx_create(gc_ctx** out, int device)
     if (!c) return GC_ERR_NOMEM;
     memset(c, 0, sizeof(*c));
     c->device = device;
-    if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess || hipStreamCreate(&c->stream3) != hipSuccess) { delete c; return GC_ERR_HIP; }
-    for (int i = 0; i < 8; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) { delete c; return GC_ERR_HIP; }
-    for (uint32_t p = 0; p < GC_MAX_PARTS; p++) {
-        for (int i = 0; i < 13; i++) if (hipEventCreate(&c->evMf[p][i]) != hipSuccess) { delete c; return GC_ERR_HIP; }
-        for (uint32_t i = 0; i < GC_PART_EVENTS; i++) if (hipEventCreate(&c->evPart[p][i]) != hipSuccess) { delete c; return GC_ERR_HIP; }
+    // every failure below releases what has been created so far (ctx_release skips what is still null)
+    int rc = GC_OK;
+    if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess || hipStreamCreate(&c->stream3) != hipSuccess) rc = GC_ERR_HIP;
+    for (int i = 0; rc == GC_OK && i < 8; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) rc = GC_ERR_HIP;
+    for (uint32_t p = 0; rc == GC_OK && p < GC_MAX_PARTS; p++) {
+        for (int i = 0; rc == GC_OK && i < 13; i++) if (hipEventCreate(&c->evMf[p][i]) != hipSuccess) rc = GC_ERR_HIP;
+        for (uint32_t i = 0; rc == GC_OK && i < GC_PART_EVENTS; i++) if (hipEventCreate(&c->evPart[p][i]) != hipSuccess) rc = GC_ERR_HIP;
     }
-    if (hipMalloc((void**)&c->prof, (GC_LZ_PHASES + GC_SEQ_PHASES) * sizeof(unsigned long long)) != hipSuccess) { delete c; return GC_ERR_NOMEM; }
-    if (hipMalloc((void**)&c->result, 16) != hipSuccess || hipHostMalloc((void**)&c->hostResult, 16) != hipSuccess) { delete c; return GC_ERR_NOMEM; }
-    { const char* e = getenv("GC_FRAME_BLOCKS"); c->dbgFrameBlocks = e ? (uint32_t)atoi(e) : 0u; }
-    { const char* e = getenv("GC_PART_FRAMES"); c->dbgPartFrames = e ? (uint32_t)atoi(e) : 0u; }
+    if (rc == GC_OK && hipMalloc((void**)&c->prof, (GC_LZ_PHASES + GC_SEQ_PHASES) * sizeof(unsigned long long)) != hipSuccess) rc = GC_ERR_NOMEM;
+    if (rc == GC_OK && (hipMalloc((void**)&c->result, 16) != hipSuccess || hipHostMalloc((void**)&c->hostResult, 16) != hipSuccess)) rc = GC_ERR_NOMEM;
+    if (rc != GC_OK) { ctx_release(c); return rc; }
+    c->dbgFrameBlocks = 0; c->dbgPartFrames = 0;
+    gc_env_u32("GC_FRAME_BLOCKS", 1u, GC_MF_MAX_FRAME_BLOCKS, &c->dbgFrameBlocks);      // test hooks: small frames / parts
+    gc_env_u32("GC_PART_FRAMES", 1u, 1u << 20, &c->dbgPartFrames);
     *out = c;
     return GC_OK;
 }
@@ -162,23 +182,28 @@ static void free_workspace(gc_ctx* c)
     c->stOut = nullptr; c->litSec = nullptr; c->seqSec = nullptr; c->info = nullptr; c->plan = nullptr; c->capBlocks = 0;
 }
 
+static void ctx_release(gc_ctx* c)
+{
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    free_workspace(c);
+    hipFree(c->prof); hipFree(c->result); if (c->hostResult) hipHostFree(c->hostResult); hipFree(c->dIn); hipFree(c->dOut);
+    hipFree(c->mfCnt); hipFree(c->mfEnt); hipFree(c->mfEnt2); hipFree(c->mfRec); hipFree(c->mfRec2); hipFree(c->mfRec3); hipFree(c->mfDp); hipFree(c->mfPrice); hipFree(c->mfWinCost);
+    for (int i = 0; i < 8; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
+    for (uint32_t p = 0; p < GC_MAX_PARTS; p++) {
+        for (int i = 0; i < 13; i++) if (c->evMf[p][i]) hipEventDestroy(c->evMf[p][i]);
+        for (uint32_t i = 0; i < GC_PART_EVENTS; i++) if (c->evPart[p][i]) hipEventDestroy(c->evPart[p][i]);
+    }
+    if (c->stream3) hipStreamDestroy(c->stream3);
+    if (c->stream2) hipStreamDestroy(c->stream2);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
 extern "C" void gc_ctx_destroy(gc_ctx* c)
 {
     if (!c) return;
-    hipSetDevice(c->device);
-    hipStreamSynchronize(c->stream);
-    free_workspace(c);
-    hipFree(c->prof); hipFree(c->result); hipHostFree(c->hostResult); hipFree(c->dIn); hipFree(c->dOut);
-    hipFree(c->mfCnt); hipFree(c->mfEnt); hipFree(c->mfEnt2); hipFree(c->mfRec); hipFree(c->mfRec2); hipFree(c->mfRec3); hipFree(c->mfDp); hipFree(c->mfPrice); hipFree(c->mfWinCost);
-    for (int i = 0; i < 8; i++) hipEventDestroy(c->ev[i]);
-    for (uint32_t p = 0; p < GC_MAX_PARTS; p++) {
-        for (int i = 0; i < 13; i++) hipEventDestroy(c->evMf[p][i]);
-        for (uint32_t i = 0; i < GC_PART_EVENTS; i++) hipEventDestroy(c->evPart[p][i]);
-    }
-    hipStreamDestroy(c->stream3);
-    hipStreamDestroy(c->stream2);
-    hipStreamDestroy(c->stream);
-    delete c;
+    ctx_release(c);
 }
 
 extern "C" const char* gc_last_error_message(const gc_ctx* c) { return c ? c->err : "no context"; }
@@ -222,9 +247,12 @@ static int ensure_workspace(gc_ctx* c, uint32_t nBlocks)
 static int mf_grow(gc_ctx* c, void** p, size_t* cap, size_t needBytes, const char* what)
 {
     if (needBytes <= *cap) return GC_OK;
-    hipFree(*p); *p = nullptr; *cap = 0;
-    if (hipMalloc(p, needBytes) != hipSuccess) { snprintf(c->err, sizeof(c->err), "match-finder workspace (%s) of %zu bytes failed", what, needBytes); return GC_ERR_NOMEM; }
-    *cap = needBytes;
+    void* np = nullptr;                                            // the old buffer stays valid if the growth fails
+    if (hipMalloc(&np, needBytes) != hipSuccess) {
+        hipFree(*p); *p = nullptr; *cap = 0;                       // second try with the old one released first
+        if (hipMalloc(&np, needBytes) != hipSuccess) { snprintf(c->err, sizeof(c->err), "workspace (%s) of %zu bytes failed", what, needBytes); return GC_ERR_NOMEM; }
+    }
+    hipFree(*p); *p = np; *cap = needBytes;
     return GC_OK;
 }
 
@@ -421,11 +449,10 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
     c->farPass = level >= 7 ? 1u : 0u;            // where the reference searches chains / trees (lazy2 and up).  Measured (run 29, 32 MiB): level 9
                                                   // 1.027 -> 0.984 x the reference on text, level 12 1.040 -> 1.001 x
     c->shortPass = level >= 16 ? 1u : 0u;         // the reference's btopt strategies search 3-byte matches (minMatch 3, clevels.h:44-47)
-    { const char* e = getenv("GC_FAR_PASS"); if (e) c->farPass = (uint32_t)atoi(e); }          // test hook
-    { const char* e = getenv("GC_SHORT_PASS"); if (e) c->shortPass = (uint32_t)atoi(e); }      // test hook
+    gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass); gc_env_u32("GC_SHORT_PASS", 0u, 1u, &c->shortPass);   // test hooks
     c->priceMinLen = 3u; c->priceLitCtx = 0u;     // zstd: matches of >= 3 bytes, literals without context (one Huffman table per block)
     c->priceParse = level >= 16 ? 1u : 0u;        // the reference's btopt / btultra strategies start at level 16 (clevels.h:44-47)
-    { const char* e = getenv("GC_PRICE_PARSE"); if (e) c->priceParse = (uint32_t)atoi(e); }    // test hook
+    gc_env_u32("GC_PRICE_PARSE", 0u, 1u, &c->priceParse);                                      // test hook
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     rc = launch_finder(c, src, n, frameBlocks, c->profOn ? c->prof : nullptr);
     if (rc != GC_OK) return rc;
@@ -476,21 +503,7 @@ extern "C" int gc_zstd_last_timing(gc_ctx* c, float ms[6])
 
 extern "C" int gc_zstd_compress_host(gc_ctx* c, const void* src, size_t n, void* dst, size_t dstCap, int level, size_t* outSize)
 {
-    if (!c || (!src && n) || !dst) return GC_ERR_PARAM;
-    HIPCHK(c, hipSetDevice(c->device));
-    const size_t bound = gc_zstd_compress_bound(n);
-    if (n > c->dInCap) { hipFree(c->dIn); c->dIn = nullptr; c->dInCap = 0; if (hipMalloc((void**)&c->dIn, n + 64) != hipSuccess) return GC_ERR_NOMEM; c->dInCap = n; }
-    if (bound > c->dOutCap) { hipFree(c->dOut); c->dOut = nullptr; c->dOutCap = 0; if (hipMalloc((void**)&c->dOut, bound) != hipSuccess) return GC_ERR_NOMEM; c->dOutCap = bound; }
-    if (n) HIPCHK(c, hipMemcpyAsync(c->dIn, src, n, hipMemcpyHostToDevice, c->stream));
-    int rc = gc_zstd_compress_device(c, c->dIn, n, c->dOut, c->dOutCap, level);
-    if (rc != GC_OK) return rc;
-    size_t sz = 0;
-    rc = gc_zstd_finish(c, &sz);
-    if (rc != GC_OK) return rc;
-    if (sz > dstCap) { snprintf(c->err, sizeof(c->err), "destination too small: need %zu bytes", sz); return GC_ERR_DST_SMALL; }
-    HIPCHK(c, hipMemcpy(dst, c->dOut, sz, hipMemcpyDeviceToHost));
-    if (outSize) *outSize = sz;
-    return GC_OK;
+    return gc_codec_compress_host(c, GC_CODEC_ZSTD, src, n, dst, dstCap, level, 0u, outSize);
 }
 
 // Optional in-kernel phase profile (s_memtime deltas of thread 0, averaged over blocks): K1 phases
@@ -510,7 +523,7 @@ extern "C" int gc_zstd_phase_profile(gc_ctx* c, double cyclesPerBlock[GC_LZ_PHAS
 // level -> model segment size (gc_lzma2.h): smaller segments = more model waves in flight (faster), more state resets (larger).
 static uint32_t flzma2_seg_log(int level)
 {
-    { const char* e = getenv("GC_SEG_LOG"); if (e) { const uint32_t v = (uint32_t)atoi(e); if (v >= GC_LZMA_SEG_LOG_MIN && v <= GC_LZMA_SEG_LOG_MAX) return v; } }   // test hook
+    { uint32_t v = 0; if (gc_env_u32("GC_SEG_LOG", GC_LZMA_SEG_LOG_MIN, GC_LZMA_SEG_LOG_MAX, &v)) return v; }   // test hook
     if (level <= 3) return 14u;
     if (level <= 5) return 15u;
     if (level <= 7) return 16u;
@@ -569,12 +582,11 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     c->farPass = level >= 3 ? 1u : 0u;            // the reference's match table resolves to depth 42 at level 5 (fl2_compress.c:37-104);
                                                   // level 3 (run 30x, 32 MiB): 1.071 -> 1.026 x the reference on text
     c->shortPass = level >= 5 ? 1u : 0u;          // ... and holds the nearest match of >= 2 bytes for every position
-    { const char* e = getenv("GC_FAR_PASS"); if (e) c->farPass = (uint32_t)atoi(e); }          // test hook
-    { const char* e = getenv("GC_SHORT_PASS"); if (e) c->shortPass = (uint32_t)atoi(e); }      // test hook
-    { const char* e = getenv("GC_SEARCH_DEPTH"); if (e) c->searchDepth = (uint32_t)atoi(e); }  // test hook
+    gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass); gc_env_u32("GC_SHORT_PASS", 0u, 1u, &c->shortPass);   // test hooks
+    gc_env_u32("GC_SEARCH_DEPTH", 0u, 8u, &c->searchDepth);
     c->priceMinLen = 2u; c->priceLitCtx = 7u;
     c->priceParse = level >= 5 ? 1u : 0u;         // the reference's FL2_opt / FL2_ultra strategies start at level 5 (fl2_compress.c:37-104)
-    { const char* e = getenv("GC_PRICE_PARSE"); if (e) c->priceParse = (uint32_t)atoi(e); }    // test hook: 0 = greedy parse only
+    gc_env_u32("GC_PRICE_PARSE", 0u, 1u, &c->priceParse);                                      // test hook: 0 = greedy parse only
     if (frameBlocks > 1u && c->dbgFrameBlocks) frameBlocks = c->dbgFrameBlocks;
     if (frameBlocks > nBlocks) frameBlocks = nBlocks;
     rc = ensure_finder_workspace(c, n, frameBlocks);
@@ -589,7 +601,7 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     c->mfTimed = false; c->nParts = nParts;
     const uint32_t segPerBlock = GC_ZSTD_BLOCK_MAX >> segLog;
     uint32_t mergeWords = GC_LZMA_RC_MERGE_WORDS;
-    { const char* e = getenv("GC_RC_MERGE_WORDS"); if (e) mergeWords = (uint32_t)atoi(e); }    // test hook: 0 = one LZMA2 chunk per rc chunk
+    gc_env_u32("GC_RC_MERGE_WORDS", 0u, GC_LZMA_RC_MERGE_WORDS, &mergeWords);                  // test hook: 0 = one LZMA2 chunk per rc chunk
     if (c->profOn) { HIPCHK(c, hipMemsetAsync(c->prof, 0, (GC_LZ_PHASES + GC_SEQ_PHASES) * sizeof(unsigned long long), c->stream)); c->profBlocks = 1u; }   // L2 phase sums (raw)
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     uint32_t f0 = 0;
@@ -660,21 +672,7 @@ extern "C" int gc_flzma2_last_timing(gc_ctx* c, float ms[7])
 
 extern "C" int gc_flzma2_compress_host(gc_ctx* c, const void* src, size_t n, void* dst, size_t dstCap, int level, unsigned flags, size_t* outSize)
 {
-    if (!c || (!src && n) || !dst) return GC_ERR_PARAM;
-    HIPCHK(c, hipSetDevice(c->device));
-    const size_t bound = gc_flzma2_compress_bound(n);
-    if (n > c->dInCap) { hipFree(c->dIn); c->dIn = nullptr; c->dInCap = 0; if (hipMalloc((void**)&c->dIn, n + 64) != hipSuccess) return GC_ERR_NOMEM; c->dInCap = n; }
-    if (bound > c->dOutCap) { hipFree(c->dOut); c->dOut = nullptr; c->dOutCap = 0; if (hipMalloc((void**)&c->dOut, bound) != hipSuccess) return GC_ERR_NOMEM; c->dOutCap = bound; }
-    if (n) HIPCHK(c, hipMemcpyAsync(c->dIn, src, n, hipMemcpyHostToDevice, c->stream));
-    int rc = gc_flzma2_compress_device(c, c->dIn, n, c->dOut, c->dOutCap, level, flags);
-    if (rc != GC_OK) return rc;
-    size_t sz = 0;
-    rc = gc_zstd_finish(c, &sz);
-    if (rc != GC_OK) return rc;
-    if (sz > dstCap) { snprintf(c->err, sizeof(c->err), "destination too small: need %zu bytes", sz); return GC_ERR_DST_SMALL; }
-    if (sz) HIPCHK(c, hipMemcpy(dst, c->dOut, sz, hipMemcpyDeviceToHost));
-    if (outSize) *outSize = sz;
-    return GC_OK;
+    return gc_codec_compress_host(c, GC_CODEC_FLZMA2, src, n, dst, dstCap, level, flags, outSize);
 }
 
 
@@ -722,12 +720,12 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     c->lazyDepth = level >= 7 ? 2u : 1u;
     c->searchDepth = level >= 7 ? (level >= 10 ? 8u : 4u) : 0u;
     c->farPass = level >= 5 ? 1u : 0u; c->shortPass = 0;      // longer matches stand in for the context modelling / block splitting B1 lacks
-    { const char* e = getenv("GC_FAR_PASS"); if (e) c->farPass = (uint32_t)atoi(e); }          // test hook
+    gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass);                                            // test hook
     c->priceMinLen = 3u; c->priceLitCtx = 0u;     // copies of >= 3 bytes (a 2-byte copy at a fresh distance never pays in brotli), one literal code per meta-block
     c->priceParse = level >= 8 ? 1u : 0u;         // the reference parses greedily up to quality 9 (zopfli from 10).  Measured at quality 6
                                                   // (run 28, 64 MiB per corpus): greedy + far pass 0.979-1.002 x the reference at 16.6 GB/s,
                                                   // price-based parse without far pass 0.983-1.012 x at 11.1 GB/s, both 0.93-0.98 x at 9.4 GB/s
-    { const char* e = getenv("GC_PRICE_PARSE"); if (e) c->priceParse = (uint32_t)atoi(e); }    // test hook
+    gc_env_u32("GC_PRICE_PARSE", 0u, 1u, &c->priceParse);                                      // test hook
     if (frameBlocks > nBlocks) frameBlocks = nBlocks;                       // short input: one chunk, one frame
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     rc = launch_finder(c, src, n, frameBlocks, nullptr);
@@ -758,19 +756,68 @@ extern "C" int gc_brotli_last_timing(gc_ctx* c, float ms[5])
 
 extern "C" int gc_brotli_compress_host(gc_ctx* c, const void* src, size_t n, void* dst, size_t dstCap, int level, size_t* outSize)
 {
-    if (!c || (!src && n) || !dst) return GC_ERR_PARAM;
+    return gc_codec_compress_host(c, GC_CODEC_BROTLI, src, n, dst, dstCap, level, 0u, outSize);
+}
+
+// ------------------------------------------------------------------------------------------------ host-buffer building blocks
+// What the three CEncoder::Code loops need (ZstdEncoder.cpp:398-461, Lzma2Encoder.cpp:260-350, BrotliEncoder.cpp:118-164), split so
+// that a host scheduler (gc_multi.hip) can keep the H2D copy of one piece, the kernels of another and the D2H copy of a third in
+// flight: begin = stage the bytes into the context's device buffer + enqueue the codec (asynchronous for pinned `src`),
+// size = wait for the compressed size, fetch = copy the compressed bytes to their final place.
+extern "C" size_t gc_codec_compress_bound(int codec, size_t n)
+{
+    return codec == GC_CODEC_ZSTD ? gc_zstd_compress_bound(n) : (codec == GC_CODEC_FLZMA2 ? gc_flzma2_compress_bound(n) : gc_brotli_compress_bound(n));
+}
+
+extern "C" int gc_host_begin(gc_ctx* c, int codec, const void* src, size_t n, int level, unsigned flags)
+{
+    if (!c || (!src && n) || codec < GC_CODEC_ZSTD || codec > GC_CODEC_BROTLI) return GC_ERR_PARAM;
     HIPCHK(c, hipSetDevice(c->device));
-    const size_t bound = gc_brotli_compress_bound(n);
+    const size_t bound = gc_codec_compress_bound(codec, n);
     if (n > c->dInCap) { hipFree(c->dIn); c->dIn = nullptr; c->dInCap = 0; if (hipMalloc((void**)&c->dIn, n + 64) != hipSuccess) return GC_ERR_NOMEM; c->dInCap = n; }
     if (bound > c->dOutCap) { hipFree(c->dOut); c->dOut = nullptr; c->dOutCap = 0; if (hipMalloc((void**)&c->dOut, bound) != hipSuccess) return GC_ERR_NOMEM; c->dOutCap = bound; }
     if (n) HIPCHK(c, hipMemcpyAsync(c->dIn, src, n, hipMemcpyHostToDevice, c->stream));
-    int rc = gc_brotli_compress_device(c, c->dIn, n, c->dOut, c->dOutCap, level);
+    return codec == GC_CODEC_ZSTD ? gc_zstd_compress_device(c, c->dIn, n, c->dOut, c->dOutCap, level)
+         : codec == GC_CODEC_FLZMA2 ? gc_flzma2_compress_device(c, c->dIn, n, c->dOut, c->dOutCap, level, flags)
+                                    : gc_brotli_compress_device(c, c->dIn, n, c->dOut, c->dOutCap, level);
+}
+
+extern "C" int gc_host_size(gc_ctx* c, size_t* compressedSize) { return gc_zstd_finish(c, compressedSize); }
+
+extern "C" int gc_host_fetch(gc_ctx* c, void* dst, size_t size)
+{
+    if (!c || (!dst && size) || size > c->dOutCap) return GC_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (size) { HIPCHK(c, hipMemcpyAsync(dst, c->dOut, size, hipMemcpyDeviceToHost, c->stream)); HIPCHK(c, hipStreamSynchronize(c->stream)); }
+    return GC_OK;
+}
+
+extern "C" int gc_codec_compress_host(gc_ctx* c, int codec, const void* src, size_t n, void* dst, size_t dstCap, int level, unsigned flags, size_t* outSize)
+{
+    if (!c || (!src && n) || !dst) return GC_ERR_PARAM;
+    int rc = gc_host_begin(c, codec, src, n, level, flags);
     if (rc != GC_OK) return rc;
     size_t sz = 0;
-    rc = gc_zstd_finish(c, &sz);
+    rc = gc_host_size(c, &sz);
     if (rc != GC_OK) return rc;
     if (sz > dstCap) { snprintf(c->err, sizeof(c->err), "destination too small: need %zu bytes", sz); return GC_ERR_DST_SMALL; }
-    if (sz) HIPCHK(c, hipMemcpy(dst, c->dOut, sz, hipMemcpyDeviceToHost));
+    rc = gc_host_fetch(c, dst, sz);
+    if (rc != GC_OK) return rc;
     if (outSize) *outSize = sz;
     return GC_OK;
+}
+
+// pinned host memory for callers that want the copies of gc_host_begin / gc_host_fetch to run at link speed and asynchronously
+extern "C" void* gc_host_alloc(size_t n) { void* p = nullptr; return hipHostMalloc(&p, n ? n : 1) == hipSuccess ? p : nullptr; }
+extern "C" void gc_host_free(void* p) { if (p) hipHostFree(p); }
+
+// Independence grain of a codec at a level: a range of the input that starts at a multiple of it is compressed to exactly the
+// bytes it has inside a whole-buffer call (zstd: frames; brotli: brotli-mt chunks) or to a run of LZMA2 chunks that starts with a
+// dictionary reset (FLZMA2: match-finder frames).  Host schedulers split the input at multiples of it.
+extern "C" size_t gc_codec_grain(int codec, int level)
+{
+    uint32_t fb = codec == GC_CODEC_ZSTD ? zstd_frame_blocks(level) : flzma2_frame_blocks(level);
+    if (codec != GC_CODEC_BROTLI && fb > 1u) gc_env_u32("GC_FRAME_BLOCKS", 1u, GC_MF_MAX_FRAME_BLOCKS, &fb);     // test hook: small frames (as in gc_ctx_create)
+    if (codec != GC_CODEC_BROTLI) return (size_t)fb * GC_ZSTD_BLOCK_MAX;
+    return (size_t)brotli_blocks_per_chunk(level) * GC_ZSTD_BLOCK_MAX;
 }

@@ -24,11 +24,17 @@ namespace {
 struct MethodInfo { uint64_t id; const char* name; int kind; };
 enum { KIND_ZSTD = 0, KIND_FLZMA2 = 1, KIND_BROTLI = 2 };
 // Names and ids as registered by the reference (CPP/7zip/Compress/ZstdRegister.cpp:13-17, FastLzma2Register.cpp:13-18,
-// BrotliRegister.cpp:13-17).
+// BrotliRegister.cpp:13-17).  A host that has these codecs built in (the reference's own 7z.so) resolves a method NAME to its
+// built-in encoder first (FindMethod_Index, CPP/7zip/Common/CreateCoder.cpp:160-204), so every method is registered a second
+// time under an alias with the SAME id -- the way FastLzma2Register.cpp:13-18 registers FLZMA2 beside LZMA2 under id 0x21:
+// `7z a -m0=ZSTDGPU` then runs this module's encoder, the archive records only the id, and any 7-Zip-zstd decodes it.
 const MethodInfo kMethods[] = {
     { 0x4F71101, "ZSTD", KIND_ZSTD },
     { 0x21, "FLZMA2", KIND_FLZMA2 },
     { 0x4F71102, "BROTLI", KIND_BROTLI },
+    { 0x4F71101, "ZSTDGPU", KIND_ZSTD },
+    { 0x21, "FLZMA2GPU", KIND_FLZMA2 },
+    { 0x4F71102, "BROTLIGPU", KIND_BROTLI },
 };
 const uint32_t kNumMethods = sizeof(kMethods) / sizeof(kMethods[0]);
 
@@ -72,18 +78,17 @@ class CGpuEncoder final : public ICompressCoder, public ICompressSetCoderMt, pub
                               public ICompressSetCoderPropertiesOpt, public ICompressWriteCoderProperties {
     ULONG refs_ = 1;
     const int kind_;
-    gc_ctx* ctx_ = nullptr;
-    uint8_t* inBuf_ = nullptr; uint8_t* outBuf_ = nullptr; size_t inCap_ = 0, outCap_ = 0;
+    gc_multi* multi_ = nullptr;                       // host scheduler over every visible GPU, two contexts each (csrc/gc_multi.hip)
+    uint8_t* inBuf_ = nullptr; uint8_t* outBuf_ = nullptr; size_t inCap_ = 0, outCap_ = 0;     // pinned (gc_host_alloc)
     int level_;                                       // ZSTD_CLEVEL_DEFAULT 3 / FL2 default 5 (Lzma2Encoder.cpp:178-239 maps -mx to it)
     uint8_t props_[5] = { 1, 5, 3, 0, 0 };            // ZSTD: CProps{major, minor, level, reserved[2]}  ZstdEncoder.h:17-32
     uint64_t expected_ = 0;
-    // input is cut at multiples of the 128 KiB frame grain, so the stream equals a single whole-buffer call
-    static const size_t kChunk = 66u << 20;          // multiple of 128 KiB and of the brotli-mt chunk sizes 1, 2, 3, 6, 11 MiB
+    int codec() const { return kind_ == KIND_ZSTD ? GC_CODEC_ZSTD : (kind_ == KIND_FLZMA2 ? GC_CODEC_FLZMA2 : GC_CODEC_BROTLI); }
 
 public:
     explicit CGpuEncoder(int kind) : kind_(kind), level_(default_level(kind)) {}
     static int default_level(int kind) { return kind == KIND_ZSTD ? 3 : (kind == KIND_FLZMA2 ? 5 : 3); }   // BrotliEncoder.h: _props._level = 3
-    ~CGpuEncoder() { if (ctx_) gc_ctx_destroy(ctx_); free(inBuf_); free(outBuf_); }
+    ~CGpuEncoder() { if (multi_) gc_multi_destroy(multi_); gc_host_free(inBuf_); gc_host_free(outBuf_); }
 
     HRESULT QueryInterface(const GUID& iid, void** out) override
     {
@@ -101,23 +106,24 @@ public:
     ULONG AddRef() override { return ++refs_; }
     ULONG Release() override { if (--refs_ != 0) return refs_; delete this; return 0; }      // non-atomic like MyCom.h:380-390
 
-    HRESULT SetNumberOfThreads(uint32_t) override { return S_OK; }    // the GPU path has no host worker threads to size
+    HRESULT SetNumberOfThreads(uint32_t) override { return S_OK; }    // the workers are GPU contexts; their number follows the devices
 
     HRESULT SetCoderProperties(const PROPID* ids, const PROPVARIANT* props, uint32_t n) override
     {
-        // same clamping as the reference for the properties that have a meaning here (ZstdEncoder.cpp:51-230);
-        // the remaining zstd tuning properties are accepted and ignored, exactly as the reference's default branch does
+        // same clamping as the reference for the properties that have a meaning here (ZstdEncoder.cpp:51-230, Lzma2Encoder.cpp:178-239,
+        // BrotliEncoder.cpp:30-80); the remaining tuning properties (dictionary, strategy, fast bytes, ...) are accepted and ignored,
+        // as the reference's default branches do: the GPU path has one configuration per level
         level_ = default_level(kind_); props_[2] = 3;
         for (uint32_t i = 0; i < n; i++) {
+            if (ids[i] != NCoderPropID::kLevel) continue;
+            if (kind_ == KIND_FLZMA2 && props[i].vt != VT_UI4) return E_INVALIDARG;           // Lzma2Encoder.cpp SetLzma2Prop: level must be VT_UI4
             const uint32_t v = props[i].ulVal;
-            if (ids[i] == NCoderPropID::kLevel) {
-                int lv = (int)v;
-                if (v < 1) lv = 1;
-                if (kind_ == KIND_ZSTD) { if (v > 22) lv = 22; props_[2] = (uint8_t)lv; }   // ZSTD_maxCLevel()
-                else if (kind_ == KIND_FLZMA2) { if (v > 9) lv = 9; }                        // FL2_MAX_7Z_CLEVEL
-                else { lv = (int)v; if (v > 11) lv = 11; }                                  // BROTLIMT_LEVEL_MIN..MAX = 0..11
-                level_ = lv;
-            }
+            int lv = (int)v;
+            if (v < 1) lv = 1;
+            if (kind_ == KIND_ZSTD) { if (v > 22) lv = 22; props_[2] = (uint8_t)lv; }   // ZSTD_maxCLevel()
+            else if (kind_ == KIND_FLZMA2) { if (v > 9) lv = 9; }                        // FL2_MAX_7Z_CLEVEL
+            else { lv = (int)v; if (v > 11) lv = 11; }                                  // BROTLIMT_LEVEL_MIN..MAX = 0..11
+            level_ = lv;
         }
         return S_OK;
     }
@@ -130,19 +136,24 @@ public:
     HRESULT WriteCoderProperties(ISequentialOutStream* out) override
     {
         if (kind_ == KIND_FLZMA2) { const uint8_t p = gc_flzma2_dict_prop(level_); return write_all(out, &p, 1); }    // Lzma2Encoder.cpp:353-364
-        if (kind_ == KIND_BROTLI) { const uint8_t p[3] = { 1, 0, (uint8_t)level_ }; return write_all(out, p, 3); }    // BrotliEncoder.h:18-32; decoder wants exactly 3
+        if (kind_ == KIND_BROTLI) { const uint8_t p[3] = { 1, 2, (uint8_t)level_ }; return write_all(out, p, 3); }    // {BROTLI_VERSION_MAJOR, _MINOR, level}: BrotliEncoder.h:18-32, C/brotli/common/version.h:20-21
         return write_all(out, props_, sizeof(props_));
     }
 
+    // The input is taken in batches of whole pieces (gc_multi_piece_bytes: a multiple of the codec's independence grain -- 8 MiB
+    // frames, or the brotli-mt chunk of `level` MiB), one piece per GPU context.  zstd and brotli: the stream equals what one
+    // whole-buffer call would produce; FLZMA2: every piece starts with a dictionary reset (as every dictionary block of the
+    // reference does after its overlap, fl2_compress.c:1020) and the single end marker follows the last one.
     HRESULT Code(ISequentialInStream* in, ISequentialOutStream* out, const uint64_t*, const uint64_t*, ICompressProgressInfo* progress) override
     {
         if (!in || !out) return E_INVALIDARG;
-        if (!ctx_) { int rc = gc_ctx_create(&ctx_, 0); if (rc != GC_OK) { ctx_ = nullptr; return hresult_of(rc); } }
-        size_t chunk = kChunk;
-        if (expected_ && expected_ < chunk) chunk = (size_t)((expected_ + 131071u) & ~(uint64_t)131071u);
-        if (chunk > inCap_) { free(inBuf_); inBuf_ = (uint8_t*)malloc(chunk); inCap_ = inBuf_ ? chunk : 0; if (!inBuf_) return E_OUTOFMEMORY; }
-        const size_t bound = kind_ == KIND_ZSTD ? gc_zstd_compress_bound(inCap_) : (kind_ == KIND_FLZMA2 ? gc_flzma2_compress_bound(inCap_) : gc_brotli_compress_bound(inCap_));
-        if (bound > outCap_) { free(outBuf_); outBuf_ = (uint8_t*)malloc(bound); outCap_ = outBuf_ ? bound : 0; if (!outBuf_) return E_OUTOFMEMORY; }
+        if (!multi_) { int rc = gc_multi_create(&multi_, nullptr, 0, 2); if (rc != GC_OK) { multi_ = nullptr; return hresult_of(rc); } }
+        const size_t piece = gc_multi_piece_bytes(codec(), level_);
+        size_t batch = piece * (size_t)gc_multi_workers(multi_);
+        if (expected_ && expected_ < batch) batch = (size_t)((expected_ + 131071u) & ~(uint64_t)131071u);
+        if (batch > inCap_) { gc_host_free(inBuf_); inBuf_ = (uint8_t*)gc_host_alloc(batch); inCap_ = inBuf_ ? batch : 0; if (!inBuf_) return E_OUTOFMEMORY; }
+        const size_t bound = gc_codec_compress_bound(codec(), inCap_) + 1u;
+        if (bound > outCap_) { gc_host_free(outBuf_); outBuf_ = (uint8_t*)gc_host_alloc(bound); outCap_ = outBuf_ ? bound : 0; if (!outBuf_) return E_OUTOFMEMORY; }
         uint64_t totalIn = 0, totalOut = 0;
         for (;;) {
             size_t got = inCap_;
@@ -150,11 +161,7 @@ public:
             if (r != S_OK) return r;
             if (got == 0 && (totalIn != 0 || kind_ == KIND_FLZMA2)) break;
             size_t produced = 0;
-            // FLZMA2: every piece is a run of LZMA2 chunks starting with a dictionary reset; the single end marker follows the loop
-            // BROTLI: every piece is a run of complete brotli-mt frames
-            int rc = kind_ == KIND_ZSTD ? gc_zstd_compress_host(ctx_, inBuf_, got, outBuf_, outCap_, level_, &produced)
-                   : kind_ == KIND_FLZMA2 ? gc_flzma2_compress_host(ctx_, inBuf_, got, outBuf_, outCap_, level_, GC_FLZMA2_NO_END_MARK, &produced)
-                                          : gc_brotli_compress_host(ctx_, inBuf_, got, outBuf_, outCap_, level_, &produced);
+            const int rc = gc_multi_compress_host(multi_, codec(), inBuf_, got, outBuf_, outCap_, level_, kind_ == KIND_FLZMA2 ? GC_FLZMA2_NO_END_MARK : 0u, 0, &produced);
             if (rc != GC_OK) return hresult_of(rc);
             r = write_all(out, outBuf_, produced);
             if (r != S_OK) return r;

@@ -47,7 +47,9 @@ size_t      gc_zstd_compress_bound(size_t n);
 
 /* Compress n bytes already resident in device memory into device memory.  Asynchronous on the context's
  * stream; call gc_zstd_finish to synchronise and fetch the size.  `level` follows the reference's -mx
- * scale (1..22); levels map onto the GPU parser's effort knobs (currently one configuration). */
+ * scale (1..22) and selects the configuration of the GPU path: levels 1-2 the block-local finder (one frame per 128 KiB
+ * block), 3-5 the windowed finder over 8 MiB frames with a one-step lazy parse, 6+ lazy2 and link following, 7+ the far pass
+ * (16- / 12-byte keys), 16+ the short pass and the price-based parse. */
 int         gc_zstd_compress_device(gc_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t dstCapacity, int level);
 int         gc_zstd_finish(gc_ctx* ctx, size_t* compressedSize);
 
@@ -111,6 +113,42 @@ int           gc_brotli_finish(gc_ctx* ctx, size_t* compressedSize);
 int           gc_brotli_compress_host(gc_ctx* ctx, const void* src, size_t n, void* dst, size_t dstCapacity, int level, size_t* compressedSize);
 /* ms[0..3] = lz (match finder), block (histograms, prefix codes, bit stream), plan, emit; ms[4] = first kernel start -> last kernel end */
 int           gc_brotli_last_timing(gc_ctx* ctx, float ms[5]);
+
+/* ---- host-side building blocks shared by the three codecs, and the multi-GPU host scheduler
+ * The reference's front ends split the input into independent jobs and run them on worker threads: ZSTDMT jobs
+ * (C/zstd/zstdmt_compress.c:1184-1247), brotli-mt chunks (C/zstdmt/brotli-mt_compress.c:209-333), FL2 dictionary blocks
+ * (C/fast-lzma2/fl2_compress.c:1020).  Here the workers are GPU contexts.
+ *   gc_codec_grain          independence grain in bytes: ranges that start at a multiple of it compress independently
+ *   gc_host_begin/size/fetch  one gc_*_compress_host call split into its three phases (H2D + enqueue, wait for the size, D2H)
+ *   gc_host_alloc/free      pinned host memory (copies from / to it run at link speed and asynchronously)
+ *   gc_multi_*              range-split of one host buffer over the contexts of one or more GPUs, two contexts per GPU by default
+ *                           so that the PCIe copies of one piece overlap the kernels of another; compressed pieces are
+ *                           concatenated in order.  FLZMA2: every piece is coded with GC_FLZMA2_NO_END_MARK and a single end
+ *                           marker follows the last one (unless `flags` carries GC_FLZMA2_NO_END_MARK itself). */
+#define GC_CODEC_ZSTD   0
+#define GC_CODEC_FLZMA2 1
+#define GC_CODEC_BROTLI 2
+size_t      gc_codec_grain(int codec, int level);
+size_t      gc_codec_compress_bound(int codec, size_t n);
+int         gc_host_begin(gc_ctx* ctx, int codec, const void* src, size_t n, int level, unsigned flags);
+int         gc_host_size(gc_ctx* ctx, size_t* compressedSize);
+int         gc_host_fetch(gc_ctx* ctx, void* dst, size_t size);
+int         gc_codec_compress_host(gc_ctx* ctx, int codec, const void* src, size_t n, void* dst, size_t dstCapacity, int level, unsigned flags,
+                                   size_t* compressedSize);
+void*       gc_host_alloc(size_t n);
+void        gc_host_free(void* p);
+
+typedef struct gc_multi gc_multi;
+/* devices == NULL or nDevices <= 0: every visible device.  ctxPerDevice <= 0: 2. */
+int         gc_multi_create(gc_multi** out, const int* devices, int nDevices, int ctxPerDevice);
+void        gc_multi_destroy(gc_multi* m);
+int         gc_multi_workers(const gc_multi* m);
+const char* gc_multi_last_error(const gc_multi* m);
+/* default piece size for a codec and level: the multiple of the grain closest to 64 MiB from below (at least one grain) */
+size_t      gc_multi_piece_bytes(int codec, int level);
+/* pieceBytes == 0: gc_multi_piece_bytes(); otherwise rounded up to a multiple of the grain */
+int         gc_multi_compress_host(gc_multi* m, int codec, const void* src, size_t n, void* dst, size_t dstCapacity, int level, unsigned flags,
+                                   size_t pieceBytes, size_t* compressedSize);
 
 /* raw stream handle (hipStream_t) so callers can order their own work against the context */
 void*       gc_ctx_stream(gc_ctx* ctx);

@@ -15,7 +15,8 @@ typedef hipemu_event* hipEvent_t;
 #define hipMemcpyDeviceToHost 2
 #define hipMemcpyDeviceToDevice 3
 struct hipDeviceProp_t { char gcnArchName[64]; int multiProcessorCount; };
-static inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
+// HIPEMU_DEVICES=N makes the emulated machine report N devices (they share the one CPU): the multi-device host scheduler can then be exercised
+static inline hipError_t hipGetDeviceCount(int* n) { const char* e = getenv("HIPEMU_DEVICES"); const int v = e ? atoi(e) : 1; *n = v >= 1 && v <= 64 ? v : 1; return 0; }
 static inline hipError_t hipSetDevice(int) { return 0; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { strcpy(p->gcnArchName, "gfx950:emu"); p->multiProcessorCount = 256; return 0; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }

@@ -6,6 +6,7 @@
 #include <thread>
 #include <vector>
 #include <atomic>
+#include <mutex>
 
 namespace hipemu {
 
@@ -140,6 +141,9 @@ void launch(dim3 grid, dim3 block, kernel_thunk_t thunk, void* args, int)
 {
     // `__shared__` variables are plain statics, so workgroups of one process run one after another;
     // tests that want parallelism split the input across processes (frames are independent).
+    // One launch at a time per process for the same reason: host threads that own different contexts (gc_multi.hip) take turns.
+    static std::mutex launchMutex;
+    std::lock_guard<std::mutex> guard(launchMutex);
     unsigned nblocks = grid.x * grid.y * grid.z;
     static Pool pool;
     for (unsigned i = 0; i < nblocks; i++) run_block(grid, block, i, thunk, args, pool);

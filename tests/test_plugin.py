@@ -76,7 +76,7 @@ def test_brotli_code_through_com_surface(O, emu_module, tmp_path, n):
     r = _host(emu_module, "encode", "BROTLI", 6, src, dst, props)
     assert r.returncode == 0, r.stderr + r.stdout
     c = np.fromfile(dst, dtype=np.uint8)
-    assert props.read_bytes() == bytes([1, 0, 6])                   # BrotliEncoder.h:18-32; BrotliDecoder.cpp:86-96 wants exactly 3
+    assert props.read_bytes() == bytes([1, 2, 6])                   # BrotliEncoder.h:18-32; BrotliDecoder.cpp:86-96 wants exactly 3
     assert np.array_equal(O.ref_brotlimt_decompress(c, n), x)
 
 

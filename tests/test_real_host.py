@@ -1,0 +1,119 @@
+"""Config C1 under the REAL host: the reference's own `7z` console program (built by oracle/build_ref_7z.sh from
+/root/reference into oracle/_ref/host7z/, test infrastructure) loads the plugin from its Codecs/ directory the way the product
+does (CPP/7zip/UI/Common/LoadCodecs.cpp:531-650), lists its methods (`7z i`), and runs `7z a -m0=<method> -mx<level>` through
+the plugin's ICompressCoder::Code / SetCoderProperties / WriteCoderProperties (CPP/7zip/Archive/7z/7zEncode.cpp:160-304);
+`7z t` / `7z x` then decode the archive with the host's own built-in decoders (decoder lookup is by method id,
+CPP/7zip/Common/CreateCoder.cpp:206-232).
+
+The host has ZSTD / FLZMA2 / BROTLI built in and resolves a method NAME to its built-in encoder first, so the plugin is driven
+through its alias names ZSTDGPU / FLZMA2GPU / BROTLIGPU (same method ids).
+
+CPU: the plugin layer over the emulator build of the kernels.  GPU (-m gpu): the product module lib7zgpucodec.so."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "emu", "_build")
+HOST = os.path.join(ROOT, "oracle", "_ref", "host7z")
+
+
+def _have_host():
+    return os.path.exists(os.path.join(HOST, "7z")) and os.path.exists(os.path.join(HOST, "7z.so"))
+
+
+@pytest.fixture(scope="module")
+def host_dir(tmp_path_factory):
+    """A private install directory: 7z + 7z.so + Codecs/ (the host looks for Codecs/ next to its own binary)."""
+    if not _have_host():
+        if os.path.isdir("/root/reference/CPP"):
+            subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "_ref/host7z/7z"], check=True, capture_output=True)
+        if not _have_host():
+            pytest.skip("reference host not built (oracle/_ref/host7z)")
+    d = tmp_path_factory.mktemp("host7z")
+    for f in ("7z", "7z.so"):
+        shutil.copy2(os.path.join(HOST, f), d / f)
+    (d / "Codecs").mkdir()
+    return d
+
+
+def _install(host_dir, module, libdir):
+    for f in os.listdir(host_dir / "Codecs"):
+        os.remove(host_dir / "Codecs" / f)
+    shutil.copy2(module, host_dir / "Codecs" / os.path.basename(module))
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = libdir + os.pathsep + env.get("LD_LIBRARY_PATH", "")     # libgpucodec*.so stays outside Codecs/ (the host would try to load it as a codec module)
+    return env
+
+
+def _run(host_dir, env, *args):
+    return subprocess.run([str(host_dir / "7z")] + [str(a) for a in args], capture_output=True, text=True, env=env, cwd=host_dir)
+
+
+def _check_listing(out, module_name):
+    assert module_name in out, out
+    lines = [l.split() for l in out.splitlines()]
+    ours = [l for l in lines if len(l) == 4 and l[0] == "1" and l[1] == "E"]        # "<lib index> E <id> <name>": encoder only, from library 1
+    got = {(l[2], l[3]) for l in ours}
+    for want in [("4F71101", "ZSTD"), ("21", "FLZMA2"), ("4F71102", "BROTLI"), ("4F71101", "ZSTDGPU"), ("21", "FLZMA2GPU"), ("4F71102", "BROTLIGPU")]:
+        assert want in got, (want, out)
+
+
+def _roundtrip(host_dir, env, O, method, level, expect_method, n, kind="text-zipf"):
+    x = O.corpus(kind, n)
+    src = host_dir / ("f_%s_%d.bin" % (method, n))
+    x.tofile(src)
+    arc = host_dir / ("a_%s_%d.7z" % (method, n))
+    if arc.exists():
+        arc.unlink()
+    r = _run(host_dir, env, "a", "-m0=%s" % method, "-mx%d" % level, arc.name, src.name)
+    assert r.returncode == 0 and "Everything is Ok" in r.stdout, r.stdout + r.stderr
+    r = _run(host_dir, env, "t", arc.name)
+    assert r.returncode == 0 and "Everything is Ok" in r.stdout, r.stdout + r.stderr
+    r = _run(host_dir, env, "l", "-slt", arc.name)
+    assert ("Method = " + expect_method) in r.stdout, r.stdout                        # the archive records the method id (0x21 is listed as LZMA2)
+    out = host_dir / "x"
+    if out.exists():
+        shutil.rmtree(out)
+    r = _run(host_dir, env, "x", "-o" + str(out), arc.name)
+    assert r.returncode == 0, r.stdout + r.stderr
+    y = np.fromfile(out / src.name, dtype=np.uint8)
+    assert np.array_equal(x, y)
+    return os.path.getsize(arc)
+
+
+def test_real_host_lists_the_emulator_module(host_dir, emu_lib_path):
+    env = _install(host_dir, os.path.join(EMU, "lib7zgpucodec_emu.so"), EMU)
+    r = _run(host_dir, env, "i")
+    assert r.returncode == 0, r.stderr
+    _check_listing(r.stdout, "lib7zgpucodec_emu.so")
+
+
+@pytest.mark.parametrize("method,level,expect,n", [("ZSTDGPU", 1, "ZSTD", 1048576),        # BASELINE config C1: zstd level 1 on a 1 MiB buffer
+                                                   ("ZSTDGPU", 3, "ZSTD", 300000),
+                                                   ("FLZMA2GPU", 1, "LZMA2", 200000),
+                                                   ("BROTLIGPU", 1, "BROTLI", 200000)])
+def test_real_host_archives_through_the_emulator_module(host_dir, emu_lib_path, O, method, level, expect, n):
+    env = _install(host_dir, os.path.join(EMU, "lib7zgpucodec_emu.so"), EMU)
+    size = _roundtrip(host_dir, env, O, method, level, expect, n)
+    assert size < n
+
+
+@pytest.mark.gpu
+def test_gpu_real_host_archives_through_the_product_module(host_dir, graft, O):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    graft.build_hip()
+    module = graft.build_plugin()
+    env = _install(host_dir, module, os.path.join(ROOT, "7-zip-zstd_amd", "csrc"))
+    r = _run(host_dir, env, "i")
+    assert r.returncode == 0, r.stderr
+    _check_listing(r.stdout, "lib7zgpucodec.so")
+    _roundtrip(host_dir, env, O, "ZSTDGPU", 1, "ZSTD", 1048576)                       # config C1
+    _roundtrip(host_dir, env, O, "ZSTDGPU", 3, "ZSTD", 150_000_000)                   # three pieces of 64 MiB over the host scheduler
+    _roundtrip(host_dir, env, O, "FLZMA2GPU", 5, "LZMA2", 80_000_000, "silesia-like")
+    _roundtrip(host_dir, env, O, "BROTLIGPU", 6, "BROTLI", 80_000_000, "web-text")

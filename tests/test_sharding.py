@@ -32,6 +32,64 @@ def test_shard_ranges_cover_and_align(graft):
             assert max(units) - min(units) <= 1
 
 
+def _worker_codec(rank, world, port, emu_lib, out_path, n, codec, level):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import torch.distributed as dist
+    import __graft_entry__ as g
+    import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg = g.load_package()
+    S = _sharding(g)
+    enc = (pkg.Flzma2Encoder if codec == "flzma2" else pkg.BrotliEncoder)(lib_path=emu_lib, level=level)
+    x = O.corpus("silesia-like", n)
+    y = S.compress_sharded(enc, x, rank, world, dist)
+    if rank == 0:
+        np.save(out_path, y)
+    dist.barrier()
+    dist.destroy_process_group()
+    enc.close()
+
+
+@pytest.mark.parametrize("codec,level,n", [("flzma2", 1, 3 * BLK + 1234), ("flzma2", 3, 2 * BLK + 77), ("brotli", 1, 8 * BLK + 4321)])
+def test_two_rank_gloo_flzma2_and_brotli(graft, pkg, O, emu_lib_path, tmp_path, codec, level, n):
+    """FLZMA2: every rank codes with NO_END_MARK, one end marker closes the concatenation (the reference decoder must regenerate
+    ALL of the input, not only the first shard); brotli: ranges are whole brotli-mt chunks."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "sharded.npy")
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_worker_codec, args=(2, port, emu_lib_path, out, n, codec, level), nprocs=2, join=True)
+    y = np.load(out)
+    x = O.corpus("silesia-like", n)
+    S = _sharding(graft)
+    if codec == "flzma2":
+        enc = pkg.Flzma2Encoder(lib_path=emu_lib_path, level=level)
+        prop = enc.coder_props()[0]
+        ranges = [(s, e) for s, e in S.shard_ranges(n, 2, S.GRAIN_ZSTD) if e > s]
+        assert len(ranges) == 2
+        parts = [enc.code(x[s:e], flags=enc.NO_END_MARK) for s, e in ranges]
+        assert np.array_equal(y, np.concatenate(parts + [np.zeros(1, dtype=np.uint8)]))
+        assert int((y == 0).sum()) >= 1 and y[-1] == 0
+        assert np.array_equal(O.port_lzma2_decode(y, n, prop), x)
+        if O.ref("flzma2") is not None:
+            assert np.array_equal(O.ref_lzma2_decode(y, n, prop), x)
+        enc.close()
+    else:
+        enc = pkg.BrotliEncoder(lib_path=emu_lib_path, level=level)
+        whole = enc.code(x)                                  # ranges = whole chunks; quality <= 2 uses the block-local finder, which leaves
+        assert abs(int(y.size) - int(whole.size)) <= 64      # the last ~80 bytes in front of the end of the buffer it was given as literals
+        if O.ref("brotli") is not None:
+            assert np.array_equal(O.ref_brotlimt_decompress(y, n, 2), x)
+        enc.close()
+
+
+def test_codec_grain_matches_the_library(graft, pkg, emu_lib_path):
+    S = _sharding(graft)
+    for codec in ("zstd", "flzma2", "brotli"):
+        for level in range(1, 12 if codec == "brotli" else 10):
+            assert S.codec_grain(codec, level) == pkg.codec_grain(codec, level, emu_lib_path), (codec, level)
+
+
 def _worker(rank, world, port, emu_lib, out_path, n, level):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import torch.distributed as dist
