@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py -- compression throughput of the MI355X zstd path on BASELINE.json config 2.
+"""bench.py -- BASELINE.json's metric on MI355X: compression MB/s + size against the reference for
+    (a) zstd level 3 on the enwik9 stand-in (1 000 000 000 B of `text-zipf`)            -> the top-level fields of the JSON line
+    (b) Fast-LZMA2 level 5 on the Silesia stand-in (211 900 000 B of `silesia-like`)    -> the object "flzma2_l5_silesia"
+at 1 / 2 / 4 / 8 GPUs.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-A "step" is one pass of the whole hot path (match finder W1..W6 -> K2 huf || K3 seq -> K4 plan -> K5 emit) over one
-100 000 000-byte buffer per GPU that is already resident in HBM (enwik8 is not available offline; the stand-in
-is the deterministic `text-zipf` corpus, labelled synthetic).  At level 3 the 128 KiB zstd blocks are grouped into
-independent 8 MiB frames (windowed match finder); levels 1-2 use one frame per block (block-local finder).
-With N>1 every rank compresses its own 100 MB shard (weak scaling, no data-path collective: the host
-range-splits the input and concatenates frames; RCCL is only used for the timing barrier / max-reduction).
+STRONG scaling: the corpus is fixed; the host range-splits it at the codec's independence grain (8 MiB match-finder frames;
+`sharding.shard_ranges`), rank r compresses range r on GPU r, and the compressed ranges concatenated in rank order are ONE valid
+stream (zstd frames / LZMA2 chunk runs with a single end marker).  There is no data-path collective: RCCL carries the timing
+barrier + max-reduction inside the timed region, and -- outside it -- the gather of the compressed bytes to rank 0, where the
+concatenation is decoded by the reference's own decoder (oracle/_ref, test infrastructure) and compared with the corpus.
 
-One JSON line is printed by rank 0; see DESIGN.md "Measurement" for the definition of every field.
+A "step" is one pass of the whole hot path (match finder -> entropy stage -> framing) over the rank's range, input resident in
+HBM before the timed region starts, output left in HBM.  K steps are timed per codec between barrier + synchronize pairs; the
+maximum over ranks counts.  `value` = corpus bytes * K / that time.  One JSON line is printed by rank 0 (DESIGN.md section 6
+defines every field).  `--codec brotli|zstd|flzma2` with `--bytes/--level/--corpus` runs ONE codec on a chosen workload
+(configs C4 / C5 and experiments); the default run is the metric.
 """
 import argparse
 import json
@@ -23,86 +29,201 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
+ENWIK9_BYTES = 1_000_000_000
+SILESIA_BYTES = 211_900_000
+DEFAULTS = {"zstd": (3, "text-zipf", ENWIK9_BYTES), "flzma2": (5, "silesia-like", SILESIA_BYTES), "brotli": (6, "web-text", ENWIK9_BYTES)}
 
-def cpu_baseline_flzma2(x, level, budget_s=25.0):
-    """Reference Fast-LZMA2 (oracle/_ref/libflzma2_ref.so = C/fast-lzma2 compiled from /root/reference) on the host cores,
-    on a bounded sample (the first 32 MiB: ~10-20 s of CPU work over both legs)."""
+
+def _oracle():
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle as O          # cpu_baseline leg only
-    if O.ref("flzma2") is None:
+    import oracle as O          # cpu_baseline + decode-check legs only
+    return O
+
+
+def cpu_baseline(codec, x, level):
+    """The reference codec (oracle/_ref = C/zstd, C/fast-lzma2, C/brotli compiled from /root/reference) on this box's host cores.
+    Returns (cpu_baseline object, reference size of the WHOLE corpus or None).  Bounded: about 10-20 s of CPU work per codec."""
+    O = _oracle()
+    if O.ref(codec) is None:
         return None, None
     cores = os.cpu_count() or 1
-    sample = x[: min(x.size, 32 * 1024 * 1024)]
-    t0 = time.perf_counter(); c1, _ = O.ref_fl2_compress(sample, level, threads=1); t1 = time.perf_counter() - t0
-    t0 = time.perf_counter(); cm, _ = O.ref_fl2_compress(sample, level, threads=cores); tm = time.perf_counter() - t0
-    res = {"value": round(sample.size / tm / 1e6, 1), "unit": "MB/s", "cores": cores, "kind": "reference",
-           "sample": "FL2_compressCCtx level %d on the first %d bytes of the same buffer, one run; %d threads; single thread: %.1f MB/s"
-                     % (level, sample.size, cores, sample.size / t1 / 1e6)}
-    return res, (len(c1), sample.size)
-
-
-def cpu_baseline_brotli(x, level, budget_s=25.0):
-    """Reference brotli + brotli-mt framing (oracle/_ref/libbrotli_ref.so) on the host cores, bounded sample (first 64 MiB)."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle as O          # cpu_baseline leg only
-    if O.ref("brotli") is None:
-        return None, None
-    cores = min(os.cpu_count() or 1, 128)          # BROTLIMT_THREAD_MAX
-    sample = x[: min(x.size, 64 * 1024 * 1024)]
+    if codec == "zstd":
+        # all threads on the whole corpus (ZSTDMT), one thread on the whole corpus (nbWorkers=0: the stricter size reference, SURVEY.md 8d)
+        t0 = time.perf_counter(); cm = O.ref_zstd_compress(x, level, workers=cores); tm = time.perf_counter() - t0
+        one = x if x.size <= 1_000_000_000 else x[:1_000_000_000]
+        t0 = time.perf_counter(); c1 = O.ref_zstd_compress(one, level, workers=0); t1 = time.perf_counter() - t0
+        return ({"value": round(x.size / tm / 1e6, 1), "unit": "MB/s", "cores": cores, "kind": "reference",
+                 "sample": "ZSTD_compress2 level %d on the whole %d-byte corpus, one run, %d threads (ZSTDMT nbWorkers=%d: %d B); single thread "
+                           "(nbWorkers=0, %d bytes): %.1f MB/s" % (level, x.size, cores, cores, len(cm), one.size, one.size / t1 / 1e6)},
+                len(c1) if one.size == x.size else None)
+    if codec == "flzma2":
+        thr = min(cores, 64)
+        t0 = time.perf_counter(); cm, _ = O.ref_fl2_compress(x, level, threads=thr); tm = time.perf_counter() - t0
+        one = x[: min(x.size, 16 * 1024 * 1024)]
+        t0 = time.perf_counter(); O.ref_fl2_compress(one, level, threads=1); t1 = time.perf_counter() - t0
+        return ({"value": round(x.size / tm / 1e6, 1), "unit": "MB/s", "cores": thr, "kind": "reference",
+                 "sample": "FL2_compressCCtx level %d on the whole %d-byte corpus, one run, %d threads; single thread (first %d bytes): %.1f MB/s"
+                           % (level, x.size, thr, one.size, one.size / t1 / 1e6)}, len(cm))
+    thr = min(cores, 128)           # BROTLIMT_THREAD_MAX
+    sample = x[: min(x.size, 256 * 1024 * 1024)]
     one = sample[: 8 * 1024 * 1024]
-    t0 = time.perf_counter(); c1 = O.ref_brotlimt_compress(one, level, 1); t1 = time.perf_counter() - t0
-    t0 = time.perf_counter(); cm = O.ref_brotlimt_compress(sample, level, cores); tm = time.perf_counter() - t0
-    res = {"value": round(sample.size / tm / 1e6, 1), "unit": "MB/s", "cores": cores, "kind": "reference",
-           "sample": "BROTLIMT_compressCCtx quality %d on the first %d bytes of the same buffer, one run, %d threads; single thread (8 MiB): %.1f MB/s"
-                     % (level, sample.size, cores, one.size / t1 / 1e6)}
-    return res, (len(cm), sample.size)
+    t0 = time.perf_counter(); O.ref_brotlimt_compress(one, level, 1); t1 = time.perf_counter() - t0
+    t0 = time.perf_counter(); cm = O.ref_brotlimt_compress(sample, level, thr); tm = time.perf_counter() - t0
+    return ({"value": round(sample.size / tm / 1e6, 1), "unit": "MB/s", "cores": thr, "kind": "reference",
+             "sample": "BROTLIMT_compressCCtx quality %d on the first %d bytes of the corpus, one run, %d threads; single thread (8 MiB): %.1f MB/s"
+                       % (level, sample.size, thr, one.size / t1 / 1e6)}, (len(cm), sample.size))
 
 
-def cpu_baseline(x, level, budget_s=25.0):
-    """Reference zstd (oracle/_ref/libzstd_ref.so = C/zstd compiled from /root/reference) timed on the host
-    cores of this box, on a bounded sample of the same workload.  Reported, not the optimisation target."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import oracle as O          # cpu_baseline leg only
-    if O.ref("zstd") is None:
-        return None, None
-    cores = os.cpu_count() or 1
-    sample = x[: min(x.size, 100_000_000)]
-    out = {}
-    ref_size = None
-    for label, workers in (("1 thread (nbWorkers=0)", 0), ("%d threads (ZSTDMT nbWorkers=%d)" % (cores, cores), cores)):
-        best = None
-        t_spent = 0.0
-        for _ in range(3):
-            t0 = time.perf_counter()
-            c = O.ref_zstd_compress(sample, level, workers=workers)
-            dt = time.perf_counter() - t0
-            t_spent += dt
-            best = dt if best is None else min(best, dt)
-            if workers == 0:
-                ref_size = len(c)
-            if t_spent > budget_s / 2:
-                break
-        out[label] = sample.size / best / 1e6
-    mt_label = list(out.keys())[1]
-    res = {"value": round(out[mt_label], 1), "unit": "MB/s", "cores": cores, "kind": "reference",
-           "sample": "ZSTD_compress2 level %d on the first %d bytes of the same buffer, best of <=3 runs; %s; single thread: %.1f MB/s"
-                     % (level, sample.size, mt_label, list(out.values())[0])}
-    return res, ref_size
+def run_codec(codec, level, corpus_name, total, args, env):
+    """K timed steps of one codec over this rank's range of the corpus; rank 0 returns the result object."""
+    import numpy as np
+    import torch
+    rank, world, dist, dev, pkg, corpus_mod, S = env["rank"], env["world"], env["dist"], env["dev"], env["pkg"], env["corpus"], env["sharding"]
+    fl2, br = codec == "flzma2", codec == "brotli"
+    x_all = corpus_mod.corpus(corpus_name, total, seed=20260921)              # the same corpus on every rank
+    grain = S.codec_grain(codec, level)
+    if not br and total < world * grain:
+        grain = S.GRAIN_ZSTD
+    s, e = S.shard_ranges(total, world, grain)[rank]
+    n = e - s
+    enc = (pkg.Flzma2Encoder if fl2 else (pkg.BrotliEncoder if br else pkg.ZstdEncoder))(device=env["local_rank"], level=level)
+    d_src = torch.from_numpy(x_all[s:e]).to(dev) if n else torch.empty(1, dtype=torch.uint8, device=dev)
+    cap = enc.compress_bound(n) + 16
+    d_dst = torch.empty(cap, dtype=torch.uint8, device=dev)
+    code = (lambda: enc.code_device(d_src.data_ptr(), n, d_dst.data_ptr(), cap, enc.NO_END_MARK)) if fl2 else \
+           (lambda: enc.code_device(d_src.data_ptr(), n, d_dst.data_ptr(), cap))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    csize = 0
+    for _ in range(args.warmup if n else 0):
+        code(); csize = enc.finish()
+    kern_ms = {k: 0.0 for k in enc.KERNELS}
+    mf_ms = {}
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps if n else 0):
+        code(); csize = enc.finish()
+        t = enc.last_timing_ms()         # hipEvent pairs recorded on the library's own streams around each kernel
+        for k in kern_ms:
+            kern_ms[k] += t[k]
+        mf = enc.mf_timing_ms()          # stage durations of the windowed match finder (None: block-local finder ran)
+        if mf:
+            for k, v in mf.items():
+                mf_ms[k] = mf_ms.get(k, 0.0) + v
+    barrier()
+    elapsed = time.perf_counter() - t0
+    # ---- outside the timed region: max over ranks, gather of the compressed ranges, decode of the concatenation
+    sizes = [csize]
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        sz = torch.tensor([csize], dtype=torch.int64, device=dev)
+        all_sz = [torch.zeros_like(sz) for _ in range(world)]
+        dist.all_gather(all_sz, sz)
+        sizes = [int(v.item()) for v in all_sz]
+        pad = max(sizes) + 1
+        mine = torch.zeros(pad, dtype=torch.uint8, device=dev); mine[:csize] = d_dst[:csize]
+        parts = [torch.empty(pad, dtype=torch.uint8, device=dev) for _ in range(world)]
+        dist.all_gather(parts, mine)
+        stream = np.concatenate([p[:z].cpu().numpy() for p, z in zip(parts, sizes)]) if rank == 0 else None
+    else:
+        stream = d_dst[:csize].cpu().numpy()
+    if rank != 0:
+        enc.close()
+        return None
+    if fl2:
+        stream = np.concatenate([stream, np.zeros(1, dtype=np.uint8)])         # the single LZMA2 end marker
+    total_csize = int(stream.size)
+    for k in kern_ms:
+        kern_ms[k] /= max(args.steps, 1)
+    for k in mf_ms:
+        mf_ms[k] /= max(args.steps, 1)
+    decodes = None
+    if not args.no_decode_check:
+        O = _oracle()
+        if O.ref(codec) is not None:
+            thr = min(os.cpu_count() or 1, 64)
+            y = O.ref_zstd_decompress(stream, total) if codec == "zstd" else \
+                O.ref_lzma2_decode(stream, total, enc.coder_props()[0]) if fl2 else O.ref_brotlimt_decompress(stream, total, thr)
+            decodes = bool(np.array_equal(y, x_all))
+            del y
+    value = total * args.steps / elapsed / 1e6
+    ratio = total / total_csize
+    # dominant kernel of rank 0 = the longest single kernel by live HIP-event timing; algorithmic bytes per launch =
+    # (1 + 1/ratio) bytes per input byte (SURVEY.md 8d) x the bytes one launch of it processes (this rank's range)
+    per_kernel = {k: v for k, v in kern_ms.items() if k != "total"}
+    if mf_ms:                            # "lz" is the sum of the finder kernels: rank them individually
+        per_kernel.pop("lz")
+        per_kernel.update(mf_ms)
+    for grp in ("mf.far", "mf.shortpass"):       # groups of five kernels each (a second / third W1..W5 pass), not single kernels
+        per_kernel.pop(grp, None)
+    if "mf.dp" in per_kernel and "mf.parse" in per_kernel:
+        per_kernel["mf.parse"] = per_kernel["mf.parse"] / 2.0                  # two launches of gc_mf_parse_kernel
+    dom = max(per_kernel, key=lambda k: per_kernel[k])
+    algo_bytes = n * (1.0 + 1.0 / ratio)
+    achieved = algo_bytes / (per_kernel[dom] * 1e-3) / 1e9
+    mf_names = {"mf.count": "gc_mf_count_kernel", "mf.scan": "gc_mf_scan_kernel", "mf.scatter": "gc_mf_scatter_kernel",
+                "mf.link": "gc_mf_link_kernel", "mf.verify": "gc_mf_verify_kernel", "mf.parse": "gc_mf_parse_kernel",
+                "mf.short": "gc_mf_short_kernel", "mf.deepen": "gc_mf_deepen_kernel", "mf.dp": "gc_mf_dp2_kernel" if fl2 else "gc_mf_dp3_kernel"}
+    kname = mf_names[dom] if dom in mf_names else \
+        "gc_zstd_lz_kernel" if dom == "lz" else ("gc_lzma2_%s_kernel" if fl2 else ("gc_brotli_%s_kernel" if br else "gc_zstd_%s_kernel")) % dom
+    traffic = None
+    try:        # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/gpu_pmc.sh), same per-launch workload only
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        if pm["_workload_bytes"].get(codec) == n and kname in pm.get(codec, {}):
+            traffic = pm[codec][kname]["hbm_bytes_per_launch"]
+    except Exception:
+        traffic = None
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "algorithmic_bytes_per_launch": int(algo_bytes),
+                "kernel_ms": {k: round(v, 4) for k, v in list(kern_ms.items()) + list(mf_ms.items())},
+                "pipeline_read_frac": round(n / (kern_ms["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "pipeline_rw_frac": round(algo_bytes / (kern_ms["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+    cpu, ref = (None, None) if args.no_cpu_baseline else cpu_baseline(codec, x_all, level)
+    ratio_vs_ref = None
+    if ref is not None and not isinstance(ref, tuple):
+        ratio_vs_ref = {"note": "whole corpus: our %d-rank stream against the reference's %s at the same level" % (world, "single stream (nbWorkers=0)" if codec == "zstd" else "stream"),
+                        "ref_bytes": ref, "ours_bytes": total_csize, "ours_over_ref": round(total_csize / ref, 4), "pass_le_1.02": bool(total_csize <= 1.02 * ref)}
+    elif isinstance(ref, tuple) and world == 1:      # reference ran on a prefix: the GPU path once more on exactly that prefix (outside the timed region)
+        enc.code_device(d_src.data_ptr(), ref[1], d_dst.data_ptr(), cap)
+        ours = enc.finish()
+        ratio_vs_ref = {"note": "both encoders on the first sample_bytes of the corpus", "sample_bytes": ref[1], "ref_bytes": ref[0], "ours_bytes": ours,
+                        "ours_over_ref": round(ours / ref[0], 4), "pass_le_1.02": bool(ours <= 1.02 * ref[0])}
+    frames = "8 MiB match-finder frames" if mf_ms else "block-local match finder"
+    res = {
+        "metric": ("brotli-q%d (brotli-mt framed)" % level if br else "flzma2-L%d" % level if fl2 else "zstd-L%d" % level) + " compression throughput (input MB/s)",
+        "value": round(value, 1), "unit": "MB/s", "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+        "workload": ("Brotli quality %d, synthetic web-text (%s, %d B), %d MiB brotli-mt chunks" % (level, corpus_name, total, max(level, 1))) if br else
+                    ("Fast-LZMA2 level %d, Silesia stand-in (%s, %d B), %s, 4 KiB range-coder chunks grouped into LZMA2 chunks, "
+                     "model segments per gc_api.hip flzma2_seg_log" % (level, corpus_name, total, frames)) if fl2 else
+                    ("zstd level %d, %s stand-in (%s, %d B), 128 KiB blocks in independent %s" % (level, "enwik9" if total == ENWIK9_BYTES else "enwik", corpus_name, total, frames)),
+        "bytes_total": total, "bytes_per_gpu": [b - a for a, b in S.shard_ranges(total, world, grain)], "shard_grain": grain,
+        "compressed_bytes": total_csize, "compressed_bytes_per_gpu": sizes, "ratio": round(ratio, 4),
+        "decodes_under_reference": decodes, "ratio_vs_ref": ratio_vs_ref, "roofline": roofline, "cpu_baseline": cpu,
+    }
+    enc.close()
+    return res
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--codec", default="zstd", choices=["zstd", "flzma2", "brotli"])
-    ap.add_argument("--bytes", type=int, default=0, help="input bytes per GPU (default: 100 000 000 = enwik8 size for zstd, 211 900 000 = Silesia for flzma2)")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--codec", default="", choices=["", "zstd", "flzma2", "brotli"], help="run ONE codec (default: the metric = zstd-L3 enwik9 + flzma2-L5 Silesia)")
+    ap.add_argument("--bytes", type=int, default=0, help="corpus bytes (whole job; default: the codec's BASELINE workload)")
     ap.add_argument("--corpus", default="")
     ap.add_argument("--level", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-decode-check", action="store_true")
     args = ap.parse_args()
 
-    import numpy as np
     import torch
     import __graft_entry__ as g
 
@@ -117,7 +238,6 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-
     if rank == 0:
         g.build_hip()                    # (a no-op when the in-tree library is up to date; never two ranks at once)
     if dist is not None:
@@ -126,132 +246,37 @@ def main():
     from importlib import util as _u
     spec = _u.spec_from_file_location("sevenzip_zstd_amd_corpus", os.path.join(ROOT, "7-zip-zstd_amd", "corpus", "__init__.py"))
     corpus_mod = _u.module_from_spec(spec); spec.loader.exec_module(corpus_mod)
+    spec = _u.spec_from_file_location("sevenzip_zstd_amd.sharding", os.path.join(ROOT, "7-zip-zstd_amd", "sharding.py"))
+    sharding = _u.module_from_spec(spec); spec.loader.exec_module(sharding)
+    env = {"rank": rank, "local_rank": local_rank, "world": world, "dist": dist, "dev": torch.device("cuda", local_rank), "pkg": pkg,
+           "corpus": corpus_mod, "sharding": sharding}
 
-    fl2 = args.codec == "flzma2"
-    br = args.codec == "brotli"
-    args.bytes = args.bytes or (211_900_000 if fl2 else (1_000_000_000 if br else 100_000_000))
-    args.corpus = args.corpus or ("silesia-like" if fl2 else ("web-text" if br else "text-zipf"))
-    args.level = args.level or (5 if fl2 else (6 if br else 3))
-    n = args.bytes
-    x = corpus_mod.corpus(args.corpus, n, seed=20260921 + rank)      # each rank owns a different shard
-    enc = (pkg.Flzma2Encoder if fl2 else (pkg.BrotliEncoder if br else pkg.ZstdEncoder))(device=local_rank, level=args.level)
-    dev = torch.device("cuda", local_rank)
-    d_src = torch.from_numpy(x).to(dev)
-    cap = enc.compress_bound(n)
-    d_dst = torch.empty(cap, dtype=torch.uint8, device=dev)
+    def one(codec):
+        lv, cn, nb = DEFAULTS[codec]
+        return run_codec(codec, args.level or lv, args.corpus or cn, args.bytes or nb, args, env)
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    csize = 0
-    for _ in range(args.warmup):
-        enc.code_device(d_src.data_ptr(), n, d_dst.data_ptr(), cap)
-        csize = enc.finish()
-
-    kern_ms = {k: 0.0 for k in enc.KERNELS}
-    mf_ms = {}
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        enc.code_device(d_src.data_ptr(), n, d_dst.data_ptr(), cap)
-        csize = enc.finish()
-        t = enc.last_timing_ms()         # hipEvent pairs recorded on the library's own stream around each kernel
-        for k in kern_ms:
-            kern_ms[k] += t[k]
-        mf = enc.mf_timing_ms()          # stage durations of the windowed match finder (None: block-local finder ran)
-        if mf:
-            for k, v in mf.items():
-                mf_ms[k] = mf_ms.get(k, 0.0) + v
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        sz = torch.tensor([csize], dtype=torch.int64, device=dev)
-        dist.all_reduce(sz, op=dist.ReduceOp.SUM)
-        total_csize = int(sz.item())
+    if args.codec:
+        main_res, extra = one(args.codec), None
     else:
-        total_csize = csize
-    for k in kern_ms:
-        kern_ms[k] /= max(args.steps, 1)
-    for k in mf_ms:
-        mf_ms[k] /= max(args.steps, 1)
-
+        main_res = one("zstd")
+        extra = one("flzma2")
     if rank == 0:
-        total_in = n * world
-        value = total_in * args.steps / elapsed / 1e6
-        ratio = n / csize
-        # dominant kernel = the longest of the five; algorithmic bytes per launch = N_in * (1 + 1/ratio)  
-        per_kernel = {k: v for k, v in kern_ms.items() if k != "total"}
-        if mf_ms:                        # "lz" is the sum of the five finder kernels: rank them individually
-            per_kernel.pop("lz")
-            per_kernel.update(mf_ms)
-        # single-kernel entries only: "mf.far" / "mf.shortpass" are groups of five kernels each (a second / third W1..W5 pass),
-        # and with the price-based parse "mf.parse" is two launches of gc_mf_parse_kernel (rank it by its per-launch average)
-        for grp in ("mf.far", "mf.shortpass"):
-            per_kernel.pop(grp, None)
-        if "mf.dp" in per_kernel and "mf.parse" in per_kernel:
-            per_kernel["mf.parse"] = per_kernel["mf.parse"] / 2.0
-        dom = max(per_kernel, key=lambda k: per_kernel[k])
-        algo_bytes = n * (1.0 + 1.0 / ratio)
-        achieved = algo_bytes / (per_kernel[dom] * 1e-3) / 1e9
-        mf_names = {"mf.count": "gc_mf_count_kernel", "mf.scan": "gc_mf_scan_kernel", "mf.scatter": "gc_mf_scatter_kernel",
-                    "mf.link": "gc_mf_link_kernel", "mf.verify": "gc_mf_verify_kernel", "mf.parse": "gc_mf_parse_kernel",
-                    "mf.short": "gc_mf_short_kernel", "mf.deepen": "gc_mf_deepen_kernel", "mf.dp": "gc_mf_dp2_kernel" if fl2 else "gc_mf_dp3_kernel"}
-        kname = mf_names[dom] if dom in mf_names else \
-            "gc_zstd_lz_kernel" if dom == "lz" else ("gc_lzma2_%s_kernel" if fl2 else ("gc_brotli_%s_kernel" if br else "gc_zstd_%s_kernel")) % dom
-        traffic = None
-        try:        # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/gpu_pmc.sh), same workload only
-            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            if pm["_workload_bytes"].get(args.codec) == n and kname in pm.get(args.codec, {}):
-                traffic = pm[args.codec][kname]["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
-        roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": int(algo_bytes),
-                    "kernel_ms": {k: round(v, 4) for k, v in list(kern_ms.items()) + list(mf_ms.items())},
-                    "pipeline_read_frac": round(n / (kern_ms["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                    "pipeline_rw_frac": round(algo_bytes / (kern_ms["total"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
-        if br:
-            cpu, ref_info = (None, None) if args.no_cpu_baseline else cpu_baseline_brotli(x, args.level)
-            ref_size = None
-        elif fl2:
-            cpu, ref_info = (None, None) if args.no_cpu_baseline else cpu_baseline_flzma2(x, args.level)
-            ref_size = None
-        else:
-            cpu, ref_size = (None, None) if args.no_cpu_baseline else cpu_baseline(x, args.level)
-            ref_info = None
-        ours_on_sample = None
-        if ref_info:                     # same bytes through the GPU path (outside the timed region): size against the reference's, like for like
-            enc.code_device(d_src.data_ptr(), ref_info[1], d_dst.data_ptr(), cap)
-            ours_on_sample = enc.finish()
         line = {
-            "metric": ("brotli-q%d (brotli-mt framed) compression throughput (input MB/s)" % args.level) if br else
-                      ("flzma2-L%d compression throughput (input MB/s)" % args.level) if fl2 else
-                      "zstd-L%d compression throughput (input MB/s)" % args.level,
-            "value": round(value, 1), "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "metric": main_res["metric"] if args.codec else "compress MB/s + ratio-vs-ref, enwik9 zstd-L3 & Silesia flzma2-L5 (value = the zstd-L3 enwik9 leg; flzma2_l5_silesia = the other leg)",
+            "value": main_res["value"], "unit": "MB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": ("Brotli quality %d, synthetic web-text (%s, %d B per GPU), %d MiB brotli-mt chunks" % (args.level, args.corpus, n, args.level)) if br else
-                                   ("Fast-LZMA2 level %d, Silesia stand-in (%s, %d B per GPU), 8 MiB match-finder frames, 4 KiB range-coder chunks grouped into LZMA2 chunks of <= 32 KiB, model reset every %d KiB" % (args.level, args.corpus, n, {1: 16, 2: 16, 3: 16, 4: 32, 5: 32, 6: 64, 7: 64}.get(args.level, 128))) if fl2 else
-                                   "zstd level %d, enwik8 stand-in (%s, %d B per GPU), 128 KiB blocks in %s" % (
-                                       args.level, args.corpus, n, "independent 8 MiB frames (windowed match finder)" if mf_ms else "one frame per block (block-local match finder)"),
-                       "bytes_per_gpu": n, "blocks_per_gpu": (n + 131071) // 131072, "parallelism": "range-shard x%d, no collective" % world},
-            "compressed_bytes": total_csize, "ratio": round(ratio, 4),
-            "ratio_vs_ref": ({"note": "both encoders on the reference's CPU sample (the first sample_bytes of the buffer)", "sample_bytes": ref_info[1],
-                              "ref_bytes": ref_info[0], "ours_bytes": ours_on_sample, "ours_over_ref": round(ours_on_sample / ref_info[0], 4),
-                              "ours_ratio_whole_input": round(ratio, 4)} if ref_info else None) if (fl2 or br) else
-                            (None if (not ref_size or n > 100_000_000) else
-                             {"ours_over_ref_single_stream_L%d" % args.level: round(csize / ref_size, 4), "ref_bytes": ref_size}),
-            "roofline": roofline, "cpu_baseline": cpu,
+            "config": {"workload": main_res["workload"], "bytes_total": main_res["bytes_total"], "bytes_per_gpu": main_res["bytes_per_gpu"],
+                       "shard_grain": main_res["shard_grain"], "parallelism": "range-shard x%d at the codec grain, rank-ordered concatenation, no data-path collective" % world},
+            "compressed_bytes": main_res["compressed_bytes"], "compressed_bytes_per_gpu": main_res["compressed_bytes_per_gpu"], "ratio": main_res["ratio"],
+            "decodes_under_reference": main_res["decodes_under_reference"], "ratio_vs_ref": main_res["ratio_vs_ref"],
+            "roofline": main_res["roofline"], "cpu_baseline": main_res["cpu_baseline"],
         }
+        if extra is not None:
+            line["flzma2_l5_silesia"] = extra
         print(json.dumps(line), flush=True)
-    enc.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -1,0 +1,86 @@
+"""GPU ratio bars (-m gpu): compressed size of the HIP path against the reference ENCODER (oracle/_ref, the reference's own C
+sources compiled here) at the same level on the same bytes, with the north-star band of 2 %, plus decode under the reference
+decoder -- for the levels and configs that round 1 only measured in profiles/: zstd 5 / 7 / 9 / 12 (the lazy range),
+zstd 19 (btultra2, config C4), FLZMA2 level 5 on the Silesia stand-in and three more corpora (config C3), brotli quality 6 on
+binary-like corpora, and the per-GPU shares of configs C4 (125 MB at level 19) and C5 (1.25 GB of web-text at quality 6)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+MiB = 1024 * 1024
+THR = min(os.cpu_count() or 1, 64)
+
+
+@pytest.fixture(scope="module")
+def gpu(pkg, graft):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    graft.build_hip()
+    return pkg
+
+
+def _need(O, name):
+    if O.ref(name) is None:
+        pytest.skip("oracle/_ref did not travel")
+
+
+@pytest.mark.parametrize("level", [5, 7, 9, 12])
+@pytest.mark.parametrize("kind", ["text-zipf", "lz-7zip"])
+def test_zstd_lazy_levels_within_2_percent(O, gpu, level, kind):
+    _need(O, "zstd")
+    x = O.corpus(kind, 32 * MiB)
+    e = gpu.ZstdEncoder(level=level); c = e.code(x); e.close()
+    assert np.array_equal(O.ref_zstd_decompress(c, x.size), x)
+    ref = O.ref_zstd_compress(x, level)
+    assert len(c) <= 1.02 * len(ref), (level, kind, len(c), len(ref), round(len(c) / len(ref), 4))
+
+
+@pytest.mark.parametrize("kind", ["text-zipf", "lz-7zip"])
+def test_zstd_level19_within_2_percent(O, gpu, kind):
+    """config C4's codec: btultra2 (clevels.h:47)"""
+    _need(O, "zstd")
+    x = O.corpus(kind, 32 * MiB)
+    e = gpu.ZstdEncoder(level=19); c = e.code(x); e.close()
+    assert np.array_equal(O.ref_zstd_decompress(c, x.size), x)
+    ref = O.ref_zstd_compress(x, 19, workers=THR)
+    assert len(c) <= 1.02 * len(ref), (kind, len(c), len(ref), round(len(c) / len(ref), 4))
+
+
+@pytest.mark.parametrize("kind,n", [("silesia-like", 211_900_000), ("text-zipf", 64 * MiB), ("lz-7zip", 64 * MiB), ("web-text", 64 * MiB)])
+def test_flzma2_level5_within_2_percent(O, gpu, kind, n):
+    """config C3 and the second half of the headline metric: level 5 against FL2_compressMt on the same bytes"""
+    _need(O, "flzma2")
+    x = O.corpus(kind, n)
+    e = gpu.Flzma2Encoder(level=5); c = e.code(x); prop = e.coder_props()[0]; e.close()
+    assert np.array_equal(O.ref_lzma2_decode(c, x.size, prop), x)
+    ref, _ = O.ref_fl2_compress(x, 5, threads=THR)
+    assert len(c) <= 1.02 * len(ref), (kind, len(c), len(ref), round(len(c) / len(ref), 4))
+
+
+@pytest.mark.parametrize("kind", ["silesia-like", "lz-7zip", "web-text"])
+def test_brotli_q6_within_2_percent(O, gpu, kind):
+    _need(O, "brotli")
+    x = O.corpus(kind, 48 * MiB)
+    e = gpu.BrotliEncoder(level=6); c = e.code(x); e.close()
+    assert np.array_equal(O.ref_brotlimt_decompress(c, x.size, THR), x)
+    ref = O.ref_brotlimt_compress(x, 6, THR)
+    assert len(c) <= 1.02 * len(ref), (kind, len(c), len(ref), round(len(c) / len(ref), 4))
+
+
+def test_config_c4_share_round_trip(O, gpu):
+    """zstd level 19 on one GPU's share of enwik9 over 8 GPUs (125 MB)"""
+    _need(O, "zstd")
+    x = O.corpus("text-zipf", 125_000_000)
+    e = gpu.ZstdEncoder(level=19); c = e.code(x); e.close()
+    assert np.array_equal(O.ref_zstd_decompress(c, x.size), x)
+
+
+def test_config_c5_share_round_trip(O, gpu):
+    """brotli quality 6 on one GPU's share of 10 GB of web-text over 8 GPUs (1.25 GB), through the host scheduler"""
+    _need(O, "brotli")
+    x = O.corpus("web-text", 1_250_000_000)
+    m = gpu.MultiEncoder("brotli", 6); c = m.code(x); m.close()
+    assert np.array_equal(O.ref_brotlimt_decompress(c, x.size, THR), x)
