@@ -49,8 +49,8 @@ extern "C" __global__ void gc_mf_verify_far_kernel(const uint8_t*, uint64_t, uin
 extern "C" __global__ void gc_mf_deepen_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, uint32_t*);
 extern "C" __global__ void gc_mf_parse_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcSeqRaw*, uint8_t*, GcBlockMeta*, uint16_t*, uint32_t);
 extern "C" __global__ void gc_mf_short_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint16_t*);
-extern "C" __global__ void gc_mf_dp2_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
-extern "C" __global__ void gc_mf_dp3_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
+extern "C" __global__ void gc_mf_dp2_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
+extern "C" __global__ void gc_mf_dp3_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
 
 extern "C" __global__ void gc_lzma2_prep_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t, uint64_t*, uint32_t*);
 extern "C" __global__ void gc_lzma2_model_kernel(const uint8_t*, uint64_t, const uint64_t*, const uint32_t*, uint32_t, uint32_t, uint16_t*, GcLzmaChunkInfo*, const uint32_t*, unsigned long long*, uint32_t);
@@ -92,7 +92,7 @@ struct gc_ctx {
     uint8_t* brStage; GcBrotliBlockInfo* brInfo; GcBrotliPlan* brPlan;    // BROTLI path
     // windowed match finder (gc_mf.h): counts/offsets, partition starts, entry lists; grown on demand
     uint32_t* mfCnt; size_t mfCntCap; GcMfEntry* mfEnt; size_t mfEntCap; GcMfEntry* mfEnt2; size_t mfEnt2Cap; uint32_t* mfRec; size_t mfRecCap; uint32_t* mfRec2; size_t mfRec2Cap;
-    uint16_t* mfRec3; size_t mfRec3Cap; uint32_t* mfDp; size_t mfDpCap; uint16_t* mfPrice; size_t mfPriceCap; uint32_t* mfWinCost; size_t mfWinCostCap;      // W5s records, W7 records, price tables
+    uint16_t* mfRec3; size_t mfRec3Cap; uint32_t* mfDp; size_t mfDpCap; uint16_t* mfPrice; size_t mfPriceCap; uint32_t* mfWinCost; size_t mfWinCostCap; uint32_t* mfDpStat; size_t mfDpStatCap;      // W5s records, W7 records, price tables, W7 phase-A symbol counts
     hipEvent_t evMf[GC_MAX_PARTS][13];      // per part: W1 start, W1 end, W2 end, W3 end, W4 end, W5 end, W6 end; price-based parse: greedy W6 end, W5s end, W7 end;
                                             // inside W5: first verify end, far pass end, deepen end
     bool mfPriced;                          // the last call ran the price-based parse (events 7..9 are valid)
@@ -188,7 +188,7 @@ static void ctx_release(gc_ctx* c)
     if (c->stream) hipStreamSynchronize(c->stream);
     free_workspace(c);
     hipFree(c->prof); hipFree(c->result); if (c->hostResult) hipHostFree(c->hostResult); hipFree(c->dIn); hipFree(c->dOut);
-    hipFree(c->mfCnt); hipFree(c->mfEnt); hipFree(c->mfEnt2); hipFree(c->mfRec); hipFree(c->mfRec2); hipFree(c->mfRec3); hipFree(c->mfDp); hipFree(c->mfPrice); hipFree(c->mfWinCost);
+    hipFree(c->mfCnt); hipFree(c->mfEnt); hipFree(c->mfEnt2); hipFree(c->mfRec); hipFree(c->mfRec2); hipFree(c->mfRec3); hipFree(c->mfDp); hipFree(c->mfPrice); hipFree(c->mfWinCost); hipFree(c->mfDpStat);
     for (int i = 0; i < 8; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
     for (uint32_t p = 0; p < GC_MAX_PARTS; p++) {
         for (int i = 0; i < 13; i++) if (c->evMf[p][i]) hipEventDestroy(c->evMf[p][i]);
@@ -265,7 +265,7 @@ static int ensure_finder_workspace(gc_ctx* c, size_t n, uint32_t frameBlocks)
     const size_t needRec = (size_t)g.nBlocks * GC_ZSTD_BLOCK_MAX * sizeof(uint32_t);
     const size_t needPrice = (size_t)g.nBlocks * GC_PRICE_WORDS * sizeof(uint16_t);
     if (needCnt > c->mfCntCap || needEnt > c->mfEntCap || needEnt > c->mfEnt2Cap || needRec > c->mfRecCap || ((c->searchDepth || c->shortPass) && needRec > c->mfRec2Cap) ||
-        (c->priceParse && (needRec / 2u > c->mfRec3Cap || needRec > c->mfDpCap || needPrice > c->mfPriceCap || (size_t)g.nBlocks * 128u > c->mfWinCostCap))) {
+        (c->priceParse && (needRec / 2u > c->mfRec3Cap || needRec > c->mfDpCap || needPrice > c->mfPriceCap || (size_t)g.nBlocks * 128u > c->mfWinCostCap || (size_t)g.nBlocks * GC_DPS_WORDS * 4u > c->mfDpStatCap))) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         int rc;
         if ((rc = mf_grow(c, (void**)&c->mfCnt, &c->mfCntCap, needCnt, "offsets")) != GC_OK) return rc;
@@ -278,6 +278,7 @@ static int ensure_finder_workspace(gc_ctx* c, size_t n, uint32_t frameBlocks)
             if ((rc = mf_grow(c, (void**)&c->mfDp, &c->mfDpCap, needRec, "price-parse records")) != GC_OK) return rc;
             if ((rc = mf_grow(c, (void**)&c->mfPrice, &c->mfPriceCap, needPrice, "price tables")) != GC_OK) return rc;
             if ((rc = mf_grow(c, (void**)&c->mfWinCost, &c->mfWinCostCap, (size_t)g.nBlocks * 128u, "window costs")) != GC_OK) return rc;
+            if ((rc = mf_grow(c, (void**)&c->mfDpStat, &c->mfDpStatCap, (size_t)g.nBlocks * GC_DPS_WORDS * 4u, "path symbol counts")) != GC_OK) return rc;
         }
     }
     return GC_OK;
@@ -304,11 +305,11 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
     const uint32_t perT = gc_xcd_per(g.nTiles), perB = gc_xcd_per(nBlocks);
     hipEvent_t* ev = c->evMf[part];
     HIPCHK(c, hipEventRecord(ev[0], st));
-    GC_LAUNCH(gc_mf_count_kernel, perT * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, cnt);
+    GC_LAUNCH(gc_mf_count_kernel, perT * GC_XCDS, GC_MF_PARTS, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, cnt);
     HIPCHK(c, hipEventRecord(ev[1], st));
     GC_LAUNCH(gc_mf_scan_kernel, g.nFrames, 1024, st, cnt, g.tilesPerFrame);
     HIPCHK(c, hipEventRecord(ev[2], st));
-    GC_LAUNCH(gc_mf_scatter_kernel, perT * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt, ent);
+    GC_LAUNCH(gc_mf_scatter_kernel, perT * GC_XCDS, GC_MF_PARTS, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt, ent);
     HIPCHK(c, hipEventRecord(ev[3], st));
     GC_LAUNCH(gc_mf_link_kernel, g.nFrames * GC_MF_PARTS * GC_MF_LINK_SEGS, 64, st, (const uint32_t*)cnt, (const GcMfEntry*)ent, ent2, g.tilesPerFrame, g.frameBytes);
     HIPCHK(c, hipEventRecord(ev[4], st));
@@ -316,9 +317,9 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
               (const GcMfEntry*)ent2, rec);
     HIPCHK(c, hipEventRecord(ev[10], st));
     if (c->farPass) {                                           // second pass with 16- / 12-byte keys, merged into rec (timed with W5)
-        GC_LAUNCH(gc_mf_count_far_kernel, perT * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, cnt);
+        GC_LAUNCH(gc_mf_count_far_kernel, perT * GC_XCDS, GC_MF_PARTS, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, cnt);
         GC_LAUNCH(gc_mf_scan_kernel, g.nFrames, 1024, st, cnt, g.tilesPerFrame);
-        GC_LAUNCH(gc_mf_scatter_far_kernel, perT * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt, ent);
+        GC_LAUNCH(gc_mf_scatter_far_kernel, perT * GC_XCDS, GC_MF_PARTS, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt, ent);
         GC_LAUNCH(gc_mf_link_kernel, g.nFrames * GC_MF_PARTS * GC_MF_LINK_SEGS, 64, st, (const uint32_t*)cnt, (const GcMfEntry*)ent, ent2, g.tilesPerFrame, g.frameBytes);
         GC_LAUNCH(gc_mf_verify_far_kernel, perT * GC_XCDS, GC_MF_VERIFY_T, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt,
                   (const GcMfEntry*)ent2, rec);
@@ -334,9 +335,9 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
     const uint32_t* recDp = rec;                                // what W7 reads: the records, or the records + short candidates
     if (c->priceParse && c->shortPass) {                        // third pass with 4- / 3-byte keys (timed with W5)
         uint32_t* recN = rec == c->mfRec + (size_t)blk0 * GC_ZSTD_BLOCK_MAX ? c->mfRec2 + (size_t)blk0 * GC_ZSTD_BLOCK_MAX : c->mfRec + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
-        GC_LAUNCH(gc_mf_count_short_kernel, perT * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, cnt);
+        GC_LAUNCH(gc_mf_count_short_kernel, perT * GC_XCDS, GC_MF_PARTS, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, cnt);
         GC_LAUNCH(gc_mf_scan_kernel, g.nFrames, 1024, st, cnt, g.tilesPerFrame);
-        GC_LAUNCH(gc_mf_scatter_short_kernel, perT * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt, ent);
+        GC_LAUNCH(gc_mf_scatter_short_kernel, perT * GC_XCDS, GC_MF_PARTS, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt, ent);
         GC_LAUNCH(gc_mf_link_kernel, g.nFrames * GC_MF_PARTS * GC_MF_LINK_SEGS, 64, st, (const uint32_t*)cnt, (const GcMfEntry*)ent, ent2, g.tilesPerFrame, g.frameBytes);
         GC_LAUNCH(gc_mf_verify_short_kernel, perT * GC_XCDS, GC_MF_VERIFY_T, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt,
                   (const GcMfEntry*)ent2, (const uint32_t*)rec, recN);
@@ -355,9 +356,17 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
         const uint32_t nChunkWg = (uint32_t)(((n + 2047u) / 2048u + 3u) / 4u), perC = gc_xcd_per(nChunkWg);
         GC_LAUNCH(gc_mf_short_kernel, perC * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, (uint32_t)((n + 2047u) / 2048u), perC, rec3);
         HIPCHK(c, hipEventRecord(ev[8], st));
-        const uint32_t nDpWg = nBlocks * 8u, perD = gc_xcd_per(nDpWg);
-        if (c->priceMinLen <= 2u) GC_LAUNCH(gc_mf_dp2_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wc);
-        else GC_LAUNCH(gc_mf_dp3_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wc);
+        // W7 in two phases: A = a sample of the windows (2 workgroups of 4 windows per block) under optimistic prices, counting the symbols of its
+        // paths; B = every window under prices made from those counts (gc_lz_price.hip)
+        uint32_t* dps = c->mfDpStat + (size_t)blk0 * GC_DPS_WORDS;
+        HIPCHK(c, hipMemsetAsync(dps, 0, (size_t)nBlocks * GC_DPS_WORDS * sizeof(uint32_t), st));
+        uint32_t phase0 = 0; { uint32_t one = 0; if (gc_env_u32("GC_DP_PHASES", 1u, 2u, &one) && one == 1u) phase0 = 2u; }    // test hook: 1 = W6's prices only
+        for (uint32_t phase = phase0; phase != 3u; phase = phase == 0u ? 1u : 3u) {
+            const uint32_t nDpWg = nBlocks * (phase == 0u ? 2u : 8u), perD = gc_xcd_per(nDpWg);
+            uint32_t* wcp = phase == 0u ? (uint32_t*)nullptr : wc;
+            if (c->priceMinLen <= 2u) GC_LAUNCH(gc_mf_dp2_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
+            else GC_LAUNCH(gc_mf_dp3_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
+        }
         HIPCHK(c, hipEventRecord(ev[9], st));
         GC_LAUNCH(gc_mf_parse_kernel, perB * GC_XCDS, GC_MF_PARSE_T, st, src, (uint64_t)n, nBlocks, perB, 0u, (const uint32_t*)dp, seqRaw, lit, meta, (uint16_t*)nullptr, 0u);
     } else
@@ -524,10 +533,10 @@ extern "C" int gc_zstd_phase_profile(gc_ctx* c, double cyclesPerBlock[GC_LZ_PHAS
 static uint32_t flzma2_seg_log(int level)
 {
     { uint32_t v = 0; if (gc_env_u32("GC_SEG_LOG", GC_LZMA_SEG_LOG_MIN, GC_LZMA_SEG_LOG_MAX, &v)) return v; }   // test hook
-    if (level <= 3) return 14u;
-    if (level <= 5) return 15u;
-    if (level <= 7) return 16u;
-    return 17u;
+    if (level <= 2) return 14u;
+    if (level <= 4) return 15u;
+    return 17u;                 // 128 KiB: what the reference's slices are (>= 112 KiB, lzma2_enc.h:22).  Measured (run r2_c, 64 MiB per corpus):
+                                // 32 KiB -> 128 KiB segments is worth 0.9-1.5 % of the level-5 size
 }
 
 extern "C" size_t gc_flzma2_compress_bound(size_t n)

@@ -33,6 +33,25 @@ __device__ __forceinline__ uint32_t lz_cmp16(LzW16 x, LzW16 y)
 // cost-ish score used to compare candidates and for the lazy check: 4 bits per matched byte minus offset bits
 __device__ __forceinline__ int lz_gain(uint32_t len, uint32_t off) { return (int)(len * 4u) - (int)gc_hibit32(off + 1u); }
 
+#include "gc_mf.h"
+// price = 16 * log2(den / num), clamped to [1, GC_PRICE_MAX]: integer arithmetic only, so that the emulator build and the GPU
+// produce the same tables (and with them the same parse, byte for byte)
+__device__ __forceinline__ uint32_t pz_log2_q8(uint32_t x)       // 256 * log2(x), x >= 1; error < 0.01 bit
+{
+    const uint32_t e = gc_hibit32(x);
+    const uint32_t f = ((x << (31u - e)) >> 15) & 0xFFFFu;         // mantissa - 1 in Q16
+    const uint32_t t = (f * (65536u - f)) >> 16;
+    const uint32_t frac = f + ((t * 22713u) >> 16);                // log2(1 + f) ~ f + 0.3466 f (1 - f)
+    return (e << 8) + (frac >> 8);
+}
+__device__ __forceinline__ uint32_t pz_price(uint32_t num, uint32_t den)
+{
+    const uint32_t a = pz_log2_q8(den), b = pz_log2_q8(num);
+    uint32_t pr = a > b ? (a - b + 8u) >> 4 : 0u;
+    if (pr < 1u) pr = 1u;
+    return pr > GC_PRICE_MAX ? GC_PRICE_MAX : pr;
+}
+
 // optional in-kernel phase profile (thread 0's shader-clock deltas)
 struct LzProf {
     unsigned long long pc[GC_LZ_PHASES];

@@ -31,7 +31,8 @@
 __device__ __forceinline__ uint32_t ps_item(uint32_t bid, uint32_t per) { return (bid & (GC_XCDS - 1u)) * per + (bid >> 3); }
 
 // ------------------------------------------------------------------------------------------------ W5s short candidates
-// One wave per 2 KiB chunk, private table of 2^11 slots in LDS; the 2 KiB in front of the chunk (same frame) are inserted first.
+// One wave per 2 KiB chunk, private tables in LDS (2^11 slots on a 3-byte hash, 2^10 slots on a 2-byte hash); the 2 KiB in front of
+// the chunk (same frame) are inserted first.
 // Per step 64 positions and one returning ds_max: the LDS unit serves the lanes in lane order, so a lane gets the most recent
 // earlier position with its hash (same mechanism as W4).  Output: uint16 per position, (distance - 1) << 4 | (length - 2),
 // GC_SHORT_NONE = no candidate.  Positions whose 17 bytes do not lie inside their block have none (keeps frames independent of
@@ -40,6 +41,10 @@ __device__ __forceinline__ uint32_t ps_item(uint32_t bid, uint32_t per) { return
 #define SH_WAVES    (SH_T / 64u)
 #define SH_CHUNK    2048u
 #define SH_SLOT_LOG 11u
+#define SH_SLOT2_LOG 10u              // second table, keyed by TWO bytes: the nearest earlier occurrence of a byte pair.  LZMA codes a 2-byte
+#define SH_DIST2_MAX 127u             // match at a distance below 128 in ~13 bits (LZMA_optimalParse keeps them only there, lzma2_enc.c:1005-1010:
+                                      // "len == 2 && dist >= 0x80" is dropped); where a literal costs 8-9 bits (binary data) that pays:
+                                      // the reference's stream of lz-7zip holds 3.8 % of its symbols as such matches
 #define SH_MAXLEN   17u
 #define SH_STAGE_WORDS ((2u * SH_CHUNK + 32u) / 4u)
 
@@ -53,6 +58,7 @@ extern "C" __global__ void __launch_bounds__(SH_T)
 gc_mf_short_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nChunks, uint32_t per, uint16_t* __restrict__ rec3)
 {
     __shared__ uint32_t sTab[SH_WAVES][1u << SH_SLOT_LOG];
+    __shared__ uint32_t sTab2[SH_WAVES][1u << SH_SLOT2_LOG];
     __shared__ uint32_t sW[SH_WAVES][SH_STAGE_WORDS];
     const uint32_t lane = threadIdx.x & 63u, wave = gc_uniform(threadIdx.x >> 6);    // (uniform: everything derived from it stays scalar)
     const uint32_t chunk = ps_item(blockIdx.x, per) * SH_WAVES + wave;
@@ -64,8 +70,10 @@ gc_mf_short_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t f
     const uint64_t ws = cs - warm;                                // window start (absolute)
     const uint64_t blockEnd = ((cs / GC_ZSTD_BLOCK_MAX + 1u) * GC_ZSTD_BLOCK_MAX) < srcSize ? (cs / GC_ZSTD_BLOCK_MAX + 1u) * GC_ZSTD_BLOCK_MAX : srcSize;
     uint32_t* tab = sTab[wave];
+    uint32_t* tab2 = sTab2[wave];
     uint32_t* W = sW[wave];
     for (uint32_t i = lane; i < (1u << SH_SLOT_LOG); i += 64u) tab[i] = 0;
+    for (uint32_t i = lane; i < (1u << SH_SLOT2_LOG); i += 64u) tab2[i] = 0;
     for (uint32_t c = lane; c < SH_STAGE_WORDS / 4u; c += 64u) {  // 16 bytes per lane; zero past the end of the input
         GcU4 v; v.x = v.y = v.z = v.w = 0;
         const uint64_t pos = ws + 16ull * c;
@@ -82,11 +90,13 @@ gc_mf_short_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t f
         const uint32_t x = sh_lds_ld32(W, q) & 0xFFFFFFu;
         const uint32_t h = x * 0x9E3779B1u;
         const uint32_t mine = ((q + 1u) << 8) | ((h >> 13) & 0xFFu);
-        uint32_t seen = 0;
-        if (listed) seen = atomicMax(&tab[h >> (32u - SH_SLOT_LOG)], mine);
+        const uint32_t h2 = (x & 0xFFFFu) * 0x9E3779B1u;
+        const uint32_t mine2 = ((q + 1u) << 8) | ((h2 >> 14) & 0xFFu);
+        uint32_t seen = 0, seen2 = 0;
+        if (listed) { seen = atomicMax(&tab[h >> (32u - SH_SLOT_LOG)], mine); seen2 = atomicMax(&tab2[h2 >> (32u - SH_SLOT2_LOG)], mine2); }
         gc_wave_step();
         if (q0 < warm) continue;                                  // uniform: the warm-up only inserts
-        uint32_t out = GC_SHORT_NONE;
+        uint32_t out = GC_SHORT_NONE, bestLen = 0;
         if (listed && seen != 0u && seen < mine && ((seen ^ mine) & 0xFFu) == 0u) {
             const uint32_t c = (seen >> 8) - 1u;                  // candidate, window-relative, c < q
             uint32_t len = 0;
@@ -95,7 +105,15 @@ gc_mf_short_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t f
                 if (len == k) { const uint32_t d = sh_lds_ld32(W, q + k) ^ sh_lds_ld32(W, c + k); len += d ? (uint32_t)(__ffs((int)d) - 1) >> 3 : 4u; }
             }
             if (len > SH_MAXLEN) len = SH_MAXLEN;
-            if (len >= 2u && q - c <= 4095u) out = ((q - c - 1u) << 4) | (len - 2u);
+            if (len >= 2u && q - c <= 4095u) { out = ((q - c - 1u) << 4) | (len - 2u); bestLen = len; }
+        }
+        if (listed && bestLen < 3u && seen2 != 0u && seen2 < mine2 && ((seen2 ^ mine2) & 0xFFu) == 0u) {
+            // the byte pair's nearest earlier occurrence: only wanted where the 3-byte table has nothing of >= 3 bytes (a position
+            // that shares three bytes shares two: if the pair's nearest occurrence were >= 3 long it would be the one found above)
+            const uint32_t c = (seen2 >> 8) - 1u;
+            const uint32_t d = sh_lds_ld32(W, q) ^ sh_lds_ld32(W, c);
+            const uint32_t len = d ? (uint32_t)(__ffs((int)d) - 1) >> 3 : 4u;
+            if (len >= 2u && q - c <= SH_DIST2_MAX && (bestLen < 2u || q - c - 1u < (out >> 4))) out = ((q - c - 1u) << 4) | ((len > 3u ? 3u : len) - 2u);
         }
         if (P < srcSize) rec3[P] = (uint16_t)out;
     }
@@ -117,8 +135,19 @@ gc_mf_short_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t f
 #define DP_KIND1   (1u << 6)
 #define DP_KIND2   (2u << 6)
 
+// Two phases (one launch each).  The price tables W6 leaves behind are those of a GREEDY parse whose matches have >= 5 bytes: it says
+// nothing about the 2-4 byte matches, and where it finds no matches at all (16-bit samples, tables of small records) it makes every
+// match look expensive, so a shortest path under those prices never tries what the reference codes such data with (its adaptive
+// model prices a symbol by how often the parse itself has used it: the reference's stream of the PCM-like part of the Silesia
+// stand-in is 19 % 3-byte matches, the greedy-priced path found 0.1 %).  So:
+//   phase A  the shortest path of a SAMPLE of windows (8 of the 32 windows of a block), under W6's prices capped at optimistic
+//            ceilings for the match side, and the symbol counts of those paths (lengths, distance slots, literals / matches)
+//   phase B  every window, lengths / slots / flags priced from phase A's counts (literals keep W6's prices: which byte values
+//            occur does not depend on the parse)
+// i.e. one round of the iteration "parse -> statistics -> prices -> parse" (tools/lzma_parse_lab.c LAB_ITER: -0.6 % on text).
 template <uint32_t minLen /* shortest match: 2 LZMA, 3 zstd */>
-__device__ __forceinline__ void dp_window(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per,
+__device__ __forceinline__ void dp_window(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t phaseArg /* 0: phase A; 1: phase B; 2: one
+                phase only (W6's prices as they are, every window, no counting) */, uint32_t* __restrict__ dpStat,
                 uint32_t litCtxArg /* bits of (previous byte >> 5) that select the literal price row: 7 LZMA (lc = 3), 0 zstd; bit 31: the
                                       byte in front of src exists (src is a later part of one buffer) */,
                 const uint32_t* __restrict__ rec, const uint16_t* __restrict__ rec3, const uint16_t* __restrict__ priceTab, uint32_t* __restrict__ recOut,
@@ -127,19 +156,50 @@ __device__ __forceinline__ void dp_window(const uint8_t* __restrict__ src, uint6
     const uint32_t litCtxMask = litCtxArg & 0xFFu, hasPrev = litCtxArg >> 31;
     __shared__ uint16_t sPrice[GC_PRICE_WORDS];
     __shared__ uint8_t sRow[DP_WAVES][DP_ROWS][64];               // back pointers by end node, later edges by start node
+    __shared__ uint32_t sCnt[GC_DPS_WORDS];                       // phase A: symbol counts of this workgroup's paths
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = gc_uniform(t >> 6);        // (uniform: the node index i must live in an SGPR)
-    // a workgroup = DP_WAVES consecutive windows of one block
+    const bool phaseA = phaseArg == 0u, phaseB = phaseArg == 1u;
+    // a workgroup = DP_WAVES windows of one block: consecutive ones, or in phase A every fourth one (windows 1, 5, 9, ... 29)
     const uint32_t item = ps_item(blockIdx.x, per);
-    const uint32_t b = item / (DP_WINS_PER_BLOCK / DP_WAVES);
+    const uint32_t wgPerBlock = phaseA ? DP_WINS_PER_BLOCK / DP_WAVES / 4u : DP_WINS_PER_BLOCK / DP_WAVES;
+    const uint32_t b = item / wgPerBlock;
     if (b >= nBlocks) return;
-    const uint32_t win = (item % (DP_WINS_PER_BLOCK / DP_WAVES)) * DP_WAVES + wave;
+    const uint32_t win = phaseA ? ((item % wgPerBlock) * DP_WAVES + wave) * 4u + 1u : (item % wgPerBlock) * DP_WAVES + wave;
     { const GcU4* T4 = (const GcU4*)(priceTab + (uint64_t)b * GC_PRICE_WORDS); GcU4* S4 = (GcU4*)sPrice;
       for (uint32_t i = t; i < GC_PRICE_WORDS / 8u; i += DP_T) S4[i] = T4[i]; }
+    if (phaseA) for (uint32_t i = t; i < GC_DPS_WORDS; i += DP_T) sCnt[i] = 0;
     __syncthreads();
+    if (phaseA && sPrice[GC_PRICE_FLAGS + 1u] >= 64u) {
+        // A block whose greedy parse is (almost) all literals -- fewer than one symbol in 16 is a match -- says nothing about what matches would
+        // cost if they were used: price the match side at optimistic ceilings (1/16 bit: flag 1, length <= 9: 0.5, slot 3 bits: what they cost once a third of the symbols are such matches), so that the
+        // sampled paths take the short matches that exist, and let phase B price them by how often they were taken.  (Blocks with matches keep
+        // W6's prices in phase A: ceilings there made text 0.3 % larger.)
+        __syncthreads();
+        for (uint32_t i = t; i < GC_PRICE_NLEN + 64u + 1u; i += DP_T) {
+            const uint32_t idx = i < GC_PRICE_NLEN ? GC_PRICE_LEN + i : (i < GC_PRICE_NLEN + 64u ? GC_PRICE_SLOT + (i - GC_PRICE_NLEN) : GC_PRICE_FLAGS + 1u);
+            const uint32_t cap = i < 10u ? 8u : (i < GC_PRICE_NLEN ? 0xFFFFu : (i < GC_PRICE_NLEN + 64u ? 48u : 16u));
+            if (sPrice[idx] > cap) sPrice[idx] = (uint16_t)cap;
+        }
+        __syncthreads();
+    }
+    if (phaseB) {                                                 // lengths, slots and flags from the counts of phase A's paths
+        const uint32_t* C = dpStat + (uint64_t)b * GC_DPS_WORDS;
+        const uint32_t nLit = C[GC_DPS_NLIT], nMat = C[GC_DPS_NMAT];
+        if (nLit + nMat != 0u) {                                  // (uniform; a block whose sampled windows do not exist keeps W6's prices)
+            for (uint32_t i = t; i < GC_PRICE_NLEN + 64u + 2u; i += DP_T) {
+                if (i < GC_PRICE_NLEN) sPrice[GC_PRICE_LEN + i] = (uint16_t)pz_price(4u * C[GC_DPS_LEN + i] + 1u, 4u * nMat + 63u);
+                else if (i < GC_PRICE_NLEN + 64u) sPrice[GC_PRICE_SLOT + (i - GC_PRICE_NLEN)] = (uint16_t)pz_price(4u * C[GC_DPS_SLOT + (i - GC_PRICE_NLEN)] + 1u, 4u * nMat + 44u);
+                else if (i == GC_PRICE_NLEN + 64u) sPrice[GC_PRICE_FLAGS] = (uint16_t)pz_price(nLit + 1u, nLit + nMat + 2u);
+                else sPrice[GC_PRICE_FLAGS + 1u] = (uint16_t)pz_price(nMat + 1u, nLit + nMat + 2u);
+            }
+        }
+        __syncthreads();
+    }
     const uint64_t base = (uint64_t)b * GC_ZSTD_BLOCK_MAX;
     const uint32_t blockLen = (uint32_t)((srcSize - base) < GC_ZSTD_BLOCK_MAX ? (srcSize - base) : GC_ZSTD_BLOCK_MAX);
     const uint32_t w0 = win << DP_WIN_LOG;
-    if (w0 >= blockLen) return;
+    const bool live = w0 < blockLen;                              // (a wave without a window still meets the others at the barrier below)
+    if (live) {
     const uint32_t n = (blockLen - w0) < DP_WIN ? (blockLen - w0) : DP_WIN;          // nodes 0 .. n
     const uint32_t* R = rec + base + w0;
     const uint16_t* R3 = rec3 + base + w0;
@@ -256,6 +316,7 @@ __device__ __forceinline__ void dp_window(const uint8_t* __restrict__ src, uint6
     //      (but the last one), i.e. within the share.
     const bool fallback = nMatch > DP_MAX_MATCHES;                // uniform
     uint32_t* RO = recOut + base + w0;
+    uint32_t lenSum = 0;
     for (uint32_t q = 0; (q << 6) < n; q++) {
         const uint32_t p = (q << 6) + lane;
         if (p >= n) break;
@@ -269,22 +330,37 @@ __device__ __forceinline__ void dp_window(const uint8_t* __restrict__ src, uint6
             const uint32_t off = (c >> 6) == 1u ? R[p] >> 8 : ((uint32_t)R3[p] >> 4) + 1u;
             out = (off << 8) | ((c & 63u) + 1u);
         }
-        RO[p] = out;
+        if (!phaseA) RO[p] = out;
+        else if (out != 0u && !fallback) {                        // phase A: count the path's symbols instead (nothing is written)
+            atomicAdd(&sCnt[GC_DPS_LEN + (out & 0xFFu)], 1u);
+            atomicAdd(&sCnt[GC_DPS_SLOT + gc_dist_slot((out >> 8) - 1u)], 1u);
+            lenSum += out & 0xFFu;
+        }
+    }
+    if (phaseA && !fallback) {
+        lenSum = gc_wave_sum(lenSum);
+        if (lane == 0u) { atomicAdd(&sCnt[GC_DPS_NMAT], nMatch); atomicAdd(&sCnt[GC_DPS_NLIT], n - lenSum); }
+    }
+    }   // live
+    if (phaseA) {
+        __syncthreads();
+        uint32_t* C = dpStat + (uint64_t)b * GC_DPS_WORDS;
+        for (uint32_t i = t; i < GC_DPS_WORDS; i += DP_T) { const uint32_t v = sCnt[i]; if (v) atomicAdd(&C[i], v); }
     }
 }
 
 // one kernel per shortest match length (the shared arrays of dp_window are per instantiation: two in one kernel would double its LDS)
 extern "C" __global__ void __launch_bounds__(DP_T)
-gc_mf_dp2_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t litCtxMask,
+gc_mf_dp2_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t phase, uint32_t* __restrict__ dpStat, uint32_t litCtxMask,
                  const uint32_t* __restrict__ rec, const uint16_t* __restrict__ rec3, const uint16_t* __restrict__ priceTab, uint32_t* __restrict__ recOut,
                  uint32_t* __restrict__ winCost)
 {
-    dp_window<2u>(src, srcSize, nBlocks, per, litCtxMask, rec, rec3, priceTab, recOut, winCost);
+    dp_window<2u>(src, srcSize, nBlocks, per, phase, dpStat, litCtxMask, rec, rec3, priceTab, recOut, winCost);
 }
 extern "C" __global__ void __launch_bounds__(DP_T)
-gc_mf_dp3_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t litCtxMask,
+gc_mf_dp3_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t phase, uint32_t* __restrict__ dpStat, uint32_t litCtxMask,
                  const uint32_t* __restrict__ rec, const uint16_t* __restrict__ rec3, const uint16_t* __restrict__ priceTab, uint32_t* __restrict__ recOut,
                  uint32_t* __restrict__ winCost)
 {
-    dp_window<3u>(src, srcSize, nBlocks, per, litCtxMask, rec, rec3, priceTab, recOut, winCost);
+    dp_window<3u>(src, srcSize, nBlocks, per, phase, dpStat, litCtxMask, rec, rec3, priceTab, recOut, winCost);
 }

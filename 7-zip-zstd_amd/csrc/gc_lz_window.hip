@@ -22,7 +22,7 @@
 #include "gc_mf.h"
 #include "gc_lz_parse.h"
 
-#define MF_T         256u             // W1 / W3: threads per tile
+#define MF_T         GC_MF_PARTS      // W1 / W3: threads per tile (one per partition)
 #define MF_WAVES     (MF_T / 64u)
 static_assert(MF_T == GC_MF_PARTS, "W1/W3 use one thread per partition for the histogram rows");
 #define MF_STAGE_PAD 16u              // bytes staged in front of / behind the tile
@@ -168,36 +168,39 @@ gc_mf_count_far_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32
 extern "C" __global__ void __launch_bounds__(1024)
 gc_mf_scan_kernel(uint32_t* __restrict__ cnt, uint32_t tilesPerFrame)
 {
-    __shared__ uint32_t sPart[4][GC_MF_PARTS];
+    constexpr uint32_t Q = 1024u / GC_MF_PARTS;                   // groups of tile rows walked side by side (1 with 1024 partitions)
+    constexpr uint32_t NW = GC_MF_PARTS / 64u;                    // waves that hold one partition per lane
+    __shared__ uint32_t sPart[Q][GC_MF_PARTS];
     __shared__ uint32_t sStart[GC_MF_PARTS];
-    __shared__ uint32_t sWave[4];
+    __shared__ uint32_t sWave[NW];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6, q = t >> GC_MF_PART_LOG, g = t & (GC_MF_PARTS - 1u);
     uint32_t* A = cnt + (uint64_t)blockIdx.x * (tilesPerFrame + 1u) * GC_MF_PARTS;
-    const uint32_t R = tilesPerFrame / 4u;                        // tilesPerFrame is a multiple of 16
+    const uint32_t R = (tilesPerFrame + Q - 1u) / Q;
+    const uint32_t r0 = q * R < tilesPerFrame ? q * R : tilesPerFrame, r1 = (q + 1u) * R < tilesPerFrame ? (q + 1u) * R : tilesPerFrame;
     uint32_t sum = 0;
-    for (uint32_t r = q * R; r < (q + 1u) * R; r++) sum += A[(uint64_t)r * GC_MF_PARTS + g];
+    for (uint32_t r = r0; r < r1; r++) sum += A[(uint64_t)r * GC_MF_PARTS + g];
     sPart[q][g] = sum;
     __syncthreads();
     uint32_t tot = 0, incl = 0;
     if (t < GC_MF_PARTS) {
-        tot = sPart[0][t] + sPart[1][t] + sPart[2][t] + sPart[3][t];
+        for (uint32_t qq = 0; qq < Q; qq++) tot += sPart[qq][t];
         incl = gc_wave_incl_sum(tot);
         if (lane == 63u) sWave[wave] = incl;
     }
     __syncthreads();
     if (t < GC_MF_PARTS) {
         uint32_t before = 0;
-        for (uint32_t w = 0; w < 4u; w++) if (w < wave) before += sWave[w];
+        for (uint32_t w = 0; w < NW; w++) if (w < wave) before += sWave[w];
         sStart[t] = before + incl - tot;
     }
     __syncthreads();
     uint32_t run = sStart[g];
-    for (uint32_t qq = 0; qq < 4u; qq++) if (qq < q) run += sPart[qq][g];
-    for (uint32_t r = q * R; r < (q + 1u) * R; r++) {
+    for (uint32_t qq = 0; qq < Q; qq++) if (qq < q) run += sPart[qq][g];
+    for (uint32_t r = r0; r < r1; r++) {
         const uint64_t i = (uint64_t)r * GC_MF_PARTS + g;
         const uint32_t v = A[i]; A[i] = run; run += v;
     }
-    if (q == 3u) A[(uint64_t)tilesPerFrame * GC_MF_PARTS + g] = run;     // end of partition g
+    if (q == Q - 1u) A[(uint64_t)tilesPerFrame * GC_MF_PARTS + g] = run;     // end of partition g
 }
 
 // ------------------------------------------------------------------------------------------------ W3 scatter
@@ -224,7 +227,7 @@ __device__ __forceinline__ void mf_scatter_body(const uint8_t* __restrict__ src,
     __syncthreads();
     const uint32_t qBase = wave * (GC_MF_TILE / MF_WAVES);
     // pass A: per-wave histograms
-    for (uint32_t r = 0; r < GC_MF_TILE / MF_T; r++) {
+    for (uint32_t r = 0; r < GC_MF_TILE / MF_T; r++) {                // (a wave owns GC_MF_TILE / MF_WAVES positions = GC_MF_TILE / MF_T rounds of 64)
         const MfKeys k = mf_keys<MODE>(sW, qBase + r * 64u + lane, T);
         if (k.ok) atomicAdd(&sRun[wave][k.part], 1u);
     }
@@ -244,7 +247,8 @@ __device__ __forceinline__ void mf_scatter_body(const uint8_t* __restrict__ src,
         sGlob[t] = offs[((uint64_t)T.frame * (TPF + 1u) + T.tif) * GC_MF_PARTS + t];
     }
     __syncthreads();
-    const uint32_t nEnt = sWaveTot[0] + sWaveTot[1] + sWaveTot[2] + sWaveTot[3];
+    uint32_t nEnt = 0;
+    for (uint32_t w = 0; w < MF_WAVES; w++) nEnt += sWaveTot[w];
     // pass B: stable ranks -> permutation
     const uint64_t lt = gc_lanemask_lt();
     for (uint32_t r = 0; r < GC_MF_TILE / MF_T; r++) {
@@ -311,7 +315,7 @@ gc_mf_scatter_far_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint
 // touched for 16 Ki insertions (e^-4 of them), whose stale candidates are simply not offered.  Output goes to a second entry
 // array because the replay reads what the previous segment's wave is working on.
 #define LINK_DEPTH 8u                 // steps per register set
-#define LINK_SEG   49152u             // entries per segment (1.5 x the mean list length of a full 8 MiB frame)
+#define LINK_SEG   16384u             // entries per segment (2 x the mean list length of a full 8 MiB frame)
 #define LINK_WARM  16384u             // entries replayed in front of a segment
 #define LINK_SEGS  GC_MF_LINK_SEGS                 // segments per list; the last one takes whatever is left
 
@@ -674,24 +678,6 @@ __device__ __forceinline__ uint32_t pz_exit(uint32_t nxt)
     return cur;                                                   // 64 .. 127
 }
 
-// price = 16 * log2(den / num), clamped to [1, GC_PRICE_MAX]: integer arithmetic only, so that the emulator build and the GPU
-// produce the same tables (and with them the same parse, byte for byte)
-__device__ __forceinline__ uint32_t pz_log2_q8(uint32_t x)       // 256 * log2(x), x >= 1; error < 0.01 bit
-{
-    const uint32_t e = gc_hibit32(x);
-    const uint32_t f = ((x << (31u - e)) >> 15) & 0xFFFFu;         // mantissa - 1 in Q16
-    const uint32_t t = (f * (65536u - f)) >> 16;
-    const uint32_t frac = f + ((t * 22713u) >> 16);                // log2(1 + f) ~ f + 0.3466 f (1 - f)
-    return (e << 8) + (frac >> 8);
-}
-__device__ __forceinline__ uint32_t pz_price(uint32_t num, uint32_t den)
-{
-    const uint32_t a = pz_log2_q8(den), b = pz_log2_q8(num);
-    uint32_t pr = a > b ? (a - b + 8u) >> 4 : 0u;
-    if (pr < 1u) pr = 1u;
-    return pr > GC_PRICE_MAX ? GC_PRICE_MAX : pr;
-}
-
 extern "C" __global__ void __launch_bounds__(PZ_T)
 gc_mf_parse_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t lazy, const uint32_t* __restrict__ rec,
                    GcSeqRaw* __restrict__ seqRaw, uint8_t* __restrict__ lit, GcBlockMeta* __restrict__ meta, uint16_t* __restrict__ priceTab,
@@ -826,7 +812,10 @@ gc_mf_parse_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t n
         else if (i < GC_PRICE_SLOT) pr = pz_price(2u * sStat[i] + 1u, 2u * nMat + 63u);
         else if (i < GC_PRICE_FLAGS) pr = pz_price(2u * sStat[i] + 1u, 2u * nMat + 44u);
         else if (i == GC_PRICE_FLAGS) pr = pz_price(nLit + 1u, nLit + nMat + 2u);          // "this symbol is a literal"
-        else if (i == GC_PRICE_FLAGS + 1u) pr = pz_price(nMat + 1u, nLit + nMat + 2u);     // "this symbol is a match"
+        else if (i == GC_PRICE_FLAGS + 1u) { pr = pz_price(nMat + 1u, nLit + nMat + 2u); if (pr > 64u) pr = 64u; }   // "this symbol is a match": at most 4 bits.
+                                                                  // The greedy parse only knows matches of >= 5 bytes; where it finds none (16-bit samples,
+                                                                  // tables of small records) the flag would be priced at 15 bits and the shortest path would never
+                                                                  // try the 2-4 byte matches the reference codes such data with (its adaptive flag settles near 1 bit)
         else pr = 0;
         T[i] = (uint16_t)pr;
     }

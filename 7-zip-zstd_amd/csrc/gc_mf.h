@@ -7,9 +7,14 @@
 // (C/zstd/zstd_double_fast.c:105-323), Fast-LZMA2's per-dictionary-block match table (C/fast-lzma2/radix_engine.h:920-981)
 // and brotli's H6 buckets (C/brotli/enc/hash_longest_match64_inc.h:157-290).  Tables of that size cannot live in LDS and a
 // table in HBM would be hit by random atomics, so the key space is partitioned instead (an MSD radix step on the top bits of
-// the SHORT hash: equal 8 bytes imply equal 5 bytes, so both keys of a position live in the same partition):
+// the SHORT hash: equal 8 bytes imply equal 5 bytes, so both keys of a position live in the same partition).
+// 1024 partitions: a frame's list of a partition holds 8 Ki entries on average, so the private tables of W4 (2^12 + 2^11 slots
+// per partition = 2^22 + 2^21 per frame for 2^23 positions) keep a candidate that lies MiBs back: a slot is overwritten after
+// ~4 Ki insertions of its partition, i.e. ~4 MiB of input.  (Round 1 had 256 partitions = 2^20 + 2^19 slots per frame, and lost
+// most candidates beyond ~1 MiB; measured with tools/lzma_parse_lab.c, LAB_TBITS: 2^20 -> 2^22 slots per key is worth 1.4-1.6 %
+// of the FLZMA2 level-5 size, exact tables another 0.8 %.)
 //
-//   W1 count    workgroup per 8 KiB tile: histogram of the tile's positions over 256 partitions
+//   W1 count    workgroup per 16 KiB tile: histogram of the tile's positions over 1024 partitions
 //   W2 scan     workgroup per frame: exclusive offsets in (partition, tile) order
 //   W3 scatter  workgroup per tile: stable counting sort of the tile in LDS, then one coalesced run per partition of 8-byte
 //               entries {position, long key, short key}
@@ -24,15 +29,15 @@
 #include <stdint.h>
 #include "gc_common.h"
 
-#define GC_MF_TILE_LOG    13u
+#define GC_MF_TILE_LOG    14u
 #define GC_MF_TILE        (1u << GC_MF_TILE_LOG)          // positions per tile
 #define GC_MF_TILES_PER_BLOCK (GC_ZSTD_BLOCK_MAX >> GC_MF_TILE_LOG)
-#define GC_MF_PART_LOG    8u
+#define GC_MF_PART_LOG    10u
 #define GC_MF_PARTS       (1u << GC_MF_PART_LOG)
 #define GC_MF_MAX_FRAME_BLOCKS 64u                        // 8 MiB: frame-relative positions fit 23 bits
 
 // W3 -> W4 entry (64 bit):  pos[0..22] | long key[23..42] (12-bit slot, 8-bit tag) | short key[43..61] (11-bit slot, 8-bit tag)
-// W4 -> W5 entry (64 bit):  position in tile[0..12] | (long candidate + 1)[13..36] | (short candidate + 1)[37..60]   (0 = none;
+// W4 -> W5 entry (64 bit):  position in tile[0..13] | (long candidate + 1)[14..37] | (short candidate + 1)[38..61]   (0 = none;
 //                           candidates are frame-relative)
 typedef uint64_t GcMfEntry;
 #define GC_MF_POS_BITS    23u
@@ -42,7 +47,7 @@ typedef uint64_t GcMfEntry;
 #define GC_MF_SSLOT_LOG   11u                             // W4 short table: 2^11 slots per partition (2^19 per frame)
 
 #define GC_MF_PARSE_T     1024u                           // W6: threads per block
-#define GC_MF_VERIFY_T    512u                            // W5: threads per tile
+#define GC_MF_VERIFY_T    1024u                           // W5: threads per tile (>= GC_MF_PARTS: one thread per run start)
 #define GC_MF_LINK_SEGS   8u                              // W4: waves per (frame, partition): long lists are linked in segments
 
 // W5 -> W6: one 32-bit match record per input position, (offset << 8) | length; 0 = no match
@@ -82,6 +87,13 @@ static inline GcMfGeom gc_mf_geom(uint64_t n, uint32_t frameBlocks)
 #define GC_PRICE_FLAGS  (GC_PRICE_SLOT + 64u)                     // literal flag, match flag
 #define GC_PRICE_WORDS  (GC_PRICE_FLAGS + 8u)                     // 2200: a multiple of 8 (16-byte rows)
 #define GC_PRICE_MAX    240u               // 15 bits: literal + flag of 4096 positions stay below 2^21 units (the cost field of a W7 node)
+// Symbol counts of the price-based parse's own path (W7 phase A, a sample of the windows of every block): what phase B prices
+// lengths, distance slots and the literal / match flag with.  uint32 per block.
+#define GC_DPS_LEN      0u                 // [piece length 0..79]
+#define GC_DPS_SLOT     GC_PRICE_NLEN      // [distance slot 0..63]
+#define GC_DPS_NLIT     (GC_DPS_SLOT + 64u)
+#define GC_DPS_NMAT     (GC_DPS_NLIT + 1u)
+#define GC_DPS_WORDS    160u
 #define GC_SHORT_NONE   0xFFFFu            // W5s -> W7: uint16 per position, (distance - 1) << 4 | (length - 2), or none
 
 // Workgroup index -> work item such that each of the 8 XCDs (workgroups are dealt round-robin to XCDs) owns one contiguous

@@ -99,18 +99,20 @@ static void e_symbol(Enc* e, St* s, u32 pos, u32 kind, u32 len, u32 off)
 #define FRAME (8u << 20)
 static u32 *recOff; static u8 *recLen;            /* best candidate per position (len <= CAP) */
 static u32 *rec3Off; static u8 *rec3Len;          /* optional short candidate (hash of 3 bytes, nearest) */
+static u32 *rec2Off; static u8 *rec2Len;          /* LAB_TWO=1: second-best main candidate (by gain, other distance) */
 static inline u32 mlen(u32 a, u32 b, u32 max) { u32 l = 0; while (l < max && S[a + l] == S[b + l]) l++; return l; }
 static inline int gain(u32 len, u32 off) { return (int)(len * 4) - (int)hibit(off + 1); }
 static void finder(int depth, int minMatch, int use3)
 {
-    recOff = calloc(N, 4); recLen = calloc(N, 1); rec3Off = calloc(N, 4); rec3Len = calloc(N, 1);
+    recOff = calloc(N, 4); recLen = calloc(N, 1); rec3Off = calloc(N, 4); rec3Len = calloc(N, 1); rec2Off = calloc(N, 4); rec2Len = calloc(N, 1);
+    int two = getenv("LAB_TWO") ? atoi(getenv("LAB_TWO")) : 0;   /* 1: second by gain; 2: the LONGEST other candidate */
     u32* tL = malloc(4u << 20), *tS = malloc(4u << 19), *t3 = malloc(4u << 16);
-    int nx = 0, xk[8]; u32* tX[8];              /* LAB_MULTI=12,16,24: extra "most recent wins" tables keyed on longer prefixes */
-    if (getenv("LAB_MULTI")) { const char* e = getenv("LAB_MULTI"); while (*e && nx < 8) { xk[nx] = atoi(e); tX[nx] = malloc(4u << 20); nx++; while (*e && *e != ',') e++; if (*e) e++; } }
+    int nx = 0, xk[16]; u32* tX[16]; int tbits = getenv("LAB_TBITS") ? atoi(getenv("LAB_TBITS")) : 20;              /* LAB_MULTI=12,16,24: extra "most recent wins" tables keyed on longer prefixes */
+    if (getenv("LAB_MULTI")) { const char* e = getenv("LAB_MULTI"); while (*e && nx < 16) { xk[nx] = atoi(e); tX[nx] = malloc((size_t)4u << tbits); nx++; while (*e && *e != ',') e++; if (*e) e++; } }
     for (u32 f = 0; f < N; f += FRAME) {
         u32 fe = f + FRAME < N ? f + FRAME : N;
         memset(tL, 0xFF, 4u << 20); memset(tS, 0xFF, 4u << 19); memset(t3, 0xFF, 4u << 16);
-        for (int j = 0; j < nx; j++) memset(tX[j], 0xFF, 4u << 20);
+        for (int j = 0; j < nx; j++) memset(tX[j], 0xFF, (size_t)4u << tbits);
         for (u32 p = f; p + CAP + 16 <= fe; p++) {
             u64 x; memcpy(&x, S + p, 8);
             u32 lo = (u32)x, hi = (u32)(x >> 32);
@@ -121,12 +123,16 @@ static void finder(int depth, int minMatch, int use3)
             u32 hL = (lo * 0x9E3779B1u + hi * 0x85EBCA77u) >> 12, hS = (lo * 0x9E3779B1u + (hi & 0xFF) * 0xC2B2AE3Du) >> 13;
             u32 cL = tL[hL], cS = tS[hS]; tL[hL] = p; tS[hS] = p;
             u32 bl = 0, bo = 0;
+            if (getenv("LAB_NOBASE")) cL = cS = 0xFFFFFFFFu;
             if (cL != 0xFFFFFFFFu) { u32 l = mlen(p, cL, CAP); if (l >= (u32)minMatch) { bl = l; bo = p - cL; } }
             if (bl < 8 && cS != 0xFFFFFFFFu && cS != cL) { u32 l = mlen(p, cS, CAP); if (l >= (u32)minMatch && (bl == 0 || gain(l, p - cS) > gain(bl, bo))) { bl = l; bo = p - cS; } }
             for (int j = 0; j < nx; j++) {
                 u64 h = 0xcbf29ce484222325ull; for (int q = 0; q < xk[j]; q++) h = (h ^ S[p + q]) * 0x100000001b3ull;
-                u32 hx = (u32)(h >> 44), c = tX[j][hx]; tX[j][hx] = p;
-                if (c != 0xFFFFFFFFu) { u32 l = mlen(p, c, CAP); if (l >= (u32)minMatch && (bl == 0 || gain(l, p - c) > gain(bl, bo))) { bl = l; bo = p - c; } }
+                u32 hx = (u32)(h >> (64 - tbits)), c = tX[j][hx]; tX[j][hx] = p;
+                if (c != 0xFFFFFFFFu) { u32 l = mlen(p, c, CAP); if (l >= (u32)minMatch) {
+                    u32 o = p - c;
+                    if (bl == 0 || gain(l, o) > gain(bl, bo)) { if (two && bl && bo != o && (two == 1 || bl > rec2Len[p])) { rec2Len[p] = bl; rec2Off[p] = bo; } bl = l; bo = o; }
+                    else if (two && o != bo && (rec2Len[p] == 0 || (two == 1 ? gain(l, o) > gain(rec2Len[p], rec2Off[p]) : l > rec2Len[p]))) { rec2Len[p] = l; rec2Off[p] = o; } } }
             }
             recOff[p] = bo; recLen[p] = bl;
         }
@@ -167,6 +173,54 @@ static void finder_hc(int depth)
         }
     }
     free(head); free(chain);
+}
+
+
+/* exact candidates: for every position the LONGEST earlier match inside its frame (compare cap CAP), the nearest one among equally
+ * long ones -- what RMF_buildTable resolves to (radix_engine.h:920: depth 42 at level 5, then extended) -- from a suffix sort of
+ * the frame by the first CAP bytes (ties by position) and nearest-smaller-position scans in rank order.  LAB_LPM=1 */
+static const u8* g_sortBase; static u32 g_sortEnd;
+static int lpm_cmp(const void* a, const void* b)
+{
+    u32 x = *(const u32*)a, y = *(const u32*)b;
+    u32 mx = g_sortEnd - x < CAP ? g_sortEnd - x : CAP, my = g_sortEnd - y < CAP ? g_sortEnd - y : CAP, m = mx < my ? mx : my;
+    int c = memcmp(g_sortBase + x, g_sortBase + y, m);
+    if (c) return c;
+    if (mx != my) return mx < my ? -1 : 1;
+    return x < y ? -1 : 1;
+}
+static void finder_lpm(int minMatch)
+{
+    for (u32 f = 0; f < N; f += FRAME) {
+        u32 fe = f + FRAME < N ? f + FRAME : N, n = fe - f;
+        u32* sa = malloc(4u * n); u8* lcp = malloc(n);            /* lcp[r] = common prefix of sa[r-1], sa[r], capped */
+        for (u32 i = 0; i < n; i++) sa[i] = f + i;
+        g_sortBase = S; g_sortEnd = fe;
+        qsort(sa, n, 4, lpm_cmp);
+        lcp[0] = 0;
+        for (u32 r = 1; r < n; r++) { u32 a = sa[r - 1], b = sa[r], m = fe - (a > b ? a : b); if (m > CAP) m = CAP; lcp[r] = (u8)mlen(a, b, m); }
+        /* previous smaller position in rank order, with the minimum lcp on the way: stack scan; then the same from the other side */
+        u32* bestPos = malloc(4u * n); u8* bestLen = calloc(n, 1);
+        u32* stR = malloc(4u * n); u8* stL = malloc(n); u32 sp;
+        for (int dir = 0; dir < 2; dir++) {
+            sp = 0;
+            for (u32 k = 0; k < n; k++) {
+                u32 r = dir ? n - 1 - k : k;
+                /* lcp between rank r and the previous visited rank */
+                u32 l = k == 0 ? 0 : (dir ? lcp[r + 1] : lcp[r]);
+                /* stack holds ranks with increasing positions...: pop entries whose position is larger than ours, carrying the min lcp */
+                u32 cur = l;
+                while (sp && sa[stR[sp - 1]] > sa[r]) { if (stL[sp - 1] < cur) cur = stL[sp - 1]; sp--; }
+                if (sp) { u32 q = sa[stR[sp - 1]]; u32 p = sa[r]; u32 i = p - f;
+                    if (cur > bestLen[i] || (cur == bestLen[i] && cur && q > bestPos[i])) { bestLen[i] = (u8)cur; bestPos[i] = q; } }
+                /* push: the lcp stored with an entry is the min lcp between it and the entry below it */
+                stR[sp] = r; stL[sp] = (u8)cur; sp++;
+            }
+        }
+        for (u32 i = 0; i < n; i++) { u32 p = f + i; if (p + CAP + 16 > fe) { recOff[p] = 0; recLen[p] = 0; continue; }
+            if (bestLen[i] >= (u32)minMatch) { recOff[p] = p - bestPos[i]; recLen[p] = bestLen[i]; } else { recOff[p] = 0; recLen[p] = 0; } }
+        free(sa); free(lcp); free(bestPos); free(bestLen); free(stR); free(stL);
+    }
 }
 
 /* ---------------------------------------------------------------- parses: produce symbol list */
@@ -292,9 +346,9 @@ static void parse_optimal(int segLog, int use3, int allLens)
                         if (c < nd[i + x].cost) { nd[i + x].cost = c; nd[i + x].prev = i; nd[i + x].kind = 3 + r; nd[i + x].len = x; nd[i + x].off = d; nd[i + x].s = t; } }
                 }
                 /* main candidates */
-                for (int w = 0; w < 2; w++) {
-                    u32 d = w ? rec3Off[p] : recOff[p], l = w ? rec3Len[p] : recLen[p];
-                    if (w && !use3) break; if (!l) continue;
+                for (int w = 0; w < 3; w++) {
+                    u32 d = w == 2 ? rec2Off[p] : w ? rec3Off[p] : recOff[p], l = w == 2 ? rec2Len[p] : w ? rec3Len[p] : recLen[p];
+                    if (w == 1 && !use3) continue; if (!l) continue;
                     l = full_len(p, d, l, maxl); if (l > maxl) l = maxl; if (l < 2) continue;
                     for (u32 x = allLens ? 2 : l; x <= l; x++) { pe.bits = 0; St t = s; e_symbol(&pe, &t, p, 1, x, d); float c = nd[i].cost + (float)pe.bits;
                         if (c < nd[i + x].cost) { nd[i + x].cost = c; nd[i + x].prev = i; nd[i + x].kind = 1; nd[i + x].len = x; nd[i + x].off = d; nd[i + x].s = t; } }
@@ -360,10 +414,11 @@ static void count_block(u32 b0, u32 b1)          /* events of the greedy symbols
 typedef struct { float cost; u32 prev; u32 len; u32 off; u32 len2; u8 kind; St s; } Node2;   /* kind 9 = composite: match(off,len) lit rep0(len2) */
 static void dp_relax(Node2* nd, u32 to, float c, u32 from, u8 kind, u32 len, u32 off, u32 len2, const St* t)
 { if (c < nd[to].cost) { nd[to].cost = c; nd[to].prev = from; nd[to].kind = kind; nd[to].len = len; nd[to].off = off; nd[to].len2 = len2; nd[to].s = *t; } }
+static int g_dpIter = 0;     /* > 0: the symbol list already in syms[] (a previous DP's parse) supplies the statistics instead of the greedy parse */
 static void parse_dp_gpu(DpCfg cfg, int greedyLazy)
 {
     static Model madapt;
-    parse_greedy(greedyLazy);
+    if (!g_dpIter) parse_greedy(greedyLazy);
     Sym* g = malloc(sizeof(Sym) * (nSyms + 1)); u32 ng = nSyms; memcpy(g, syms, sizeof(Sym) * nSyms);
     Sym* out = malloc(sizeof(Sym) * (N / 2 + 16)); u32 nOut = 0;
     Node2* nd = malloc(sizeof(Node2) * (cfg.win + 2));
@@ -485,13 +540,17 @@ int main(int argc, char** argv)
     int depth = argc > 3 ? atoi(argv[3]) : 2;
     syms = malloc(sizeof(Sym) * (N / 2 + 16));
     double h;
-    finder(depth, 5, 1);
+    finder(depth, getenv("LAB_MINMATCH") ? atoi(getenv("LAB_MINMATCH")) : 5, 1);
     if (getenv("LAB_HC")) finder_hc(atoi(getenv("LAB_HC")));
+    if (getenv("LAB_LPM")) finder_lpm(atoi(getenv("LAB_LPM")));
+    if (getenv("LAB_OPT")) { parse_optimal(atoi(getenv("LAB_OPT")), 1, 1); return 0; }
     if (getenv("LAB_DP")) {
         parse_greedy(2); double a0 = price_syms(segLog, 12, &h); printf("greedy-lazy2 seg %d: %.0f\n", segLog, a0);
         int v[11] = {1, 4096, 0, 1, 0, 0, 0, 0, 4, 0, 0}; const char* e = getenv("LAB_DP"); sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", v, v+1, v+2, v+3, v+4, v+5, v+6, v+7, v+8, v+9, v+10);
         DpCfg c = { v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10] };
-        parse_dp_gpu(c, 2); double a = price_syms(segLog, 12, &h); printf("dp [%s] seg %d: %.0f  (%.4f of greedy)\n", e, segLog, a, a / a0); return 0; }
+        parse_dp_gpu(c, 2); double a = price_syms(segLog, 12, &h); printf("dp [%s] seg %d: %.0f  (%.4f of greedy)\n", e, segLog, a, a / a0);
+        for (int it = 0; it < (getenv("LAB_ITER") ? atoi(getenv("LAB_ITER")) : 0); it++) { g_dpIter = 1; parse_dp_gpu(c, 2); a = price_syms(segLog, 12, &h); printf("  iteration %d: %.0f\n", it + 2, a); }
+        return 0; }
     if (getenv("LAB_SIMPLE")) {
         parse_greedy(2); double a0 = price_syms(segLog, 12, &h); printf("greedy-lazy2 seg %d: %.0f\n", segLog, a0);
         int v[4] = {0, 4096, 4096, 4}; const char* e = getenv("LAB_SIMPLE"); sscanf(e, "%d,%d,%d,%d", v, v+1, v+2, v+3);
