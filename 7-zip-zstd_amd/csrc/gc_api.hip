@@ -49,8 +49,8 @@ extern "C" __global__ void gc_mf_verify_far_kernel(const uint8_t*, uint64_t, uin
 extern "C" __global__ void gc_mf_deepen_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, uint32_t*);
 extern "C" __global__ void gc_mf_parse_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcSeqRaw*, uint8_t*, GcBlockMeta*, uint16_t*, uint32_t);
 extern "C" __global__ void gc_mf_short_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint16_t*);
-extern "C" __global__ void gc_mf_dp2_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
-extern "C" __global__ void gc_mf_dp3_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
+extern "C" __global__ void gc_mf_dp2_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
+extern "C" __global__ void gc_mf_dp3_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
 
 extern "C" __global__ void gc_lzma2_prep_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t, uint64_t*, uint32_t*);
 extern "C" __global__ void gc_lzma2_model_kernel(const uint8_t*, uint64_t, const uint64_t*, const uint32_t*, uint32_t, uint32_t, uint16_t*, GcLzmaChunkInfo*, const uint32_t*, unsigned long long*, uint32_t);
@@ -356,16 +356,16 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
         const uint32_t nChunkWg = (uint32_t)(((n + 2047u) / 2048u + 3u) / 4u), perC = gc_xcd_per(nChunkWg);
         GC_LAUNCH(gc_mf_short_kernel, perC * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, (uint32_t)((n + 2047u) / 2048u), perC, rec3);
         HIPCHK(c, hipEventRecord(ev[8], st));
-        // W7 in two phases: A = a sample of the windows (2 workgroups of 4 windows per block) under optimistic prices, counting the symbols of its
+        // W7 in two phases: A = a sample of the windows (one workgroup of 4 windows per block) under optimistic prices, counting the symbols of its
         // paths; B = every window under prices made from those counts (gc_lz_price.hip)
         uint32_t* dps = c->mfDpStat + (size_t)blk0 * GC_DPS_WORDS;
         HIPCHK(c, hipMemsetAsync(dps, 0, (size_t)nBlocks * GC_DPS_WORDS * sizeof(uint32_t), st));
         uint32_t phase0 = 0; { uint32_t one = 0; if (gc_env_u32("GC_DP_PHASES", 1u, 2u, &one) && one == 1u) phase0 = 2u; }    // test hook: 1 = W6's prices only
         for (uint32_t phase = phase0; phase != 3u; phase = phase == 0u ? 1u : 3u) {
-            const uint32_t nDpWg = nBlocks * (phase == 0u ? 2u : 8u), perD = gc_xcd_per(nDpWg);
+            const uint32_t nDpWg = nBlocks * (phase == 0u ? 1u : 8u), perD = gc_xcd_per(nDpWg);
             uint32_t* wcp = phase == 0u ? (uint32_t*)nullptr : wc;
-            if (c->priceMinLen <= 2u) GC_LAUNCH(gc_mf_dp2_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
-            else GC_LAUNCH(gc_mf_dp3_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
+            if (c->priceMinLen <= 2u) GC_LAUNCH(gc_mf_dp2_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
+            else GC_LAUNCH(gc_mf_dp3_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
         }
         HIPCHK(c, hipEventRecord(ev[9], st));
         GC_LAUNCH(gc_mf_parse_kernel, perB * GC_XCDS, GC_MF_PARSE_T, st, src, (uint64_t)n, nBlocks, perB, 0u, (const uint32_t*)dp, seqRaw, lit, meta, (uint16_t*)nullptr, 0u);

@@ -120,6 +120,31 @@ gc_mf_short_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t f
 }
 
 // ------------------------------------------------------------------------------------------------ W7 shortest path
+// Repeat hints of the positions p = p0 + lane of one group of 64 (LZMA): the distances of the finder records that end one to four bytes in
+// front of p -- "match, a few literals (or short repeats), the same distance again" is how a copy with changed bytes looks, and where the path
+// took that match its distance is the node's repeat distance.  Two distinct distances are kept, the nearest record end first.
+// recHere = records of p0 + lane, recPrev = records of p0 - 64 + lane.  Only records of 2..8 bytes are looked at: the tail of a longer
+// match is recorded at its later positions with the same distance.
+__device__ __forceinline__ void dp_rep_hints(uint32_t recHere, uint32_t recPrev, uint32_t lane, uint32_t& d1, uint32_t& d2)
+{
+    uint32_t e1 = 0, e2 = 0, e3 = 0, e4 = 0;                      // e<k>: distance of the longest such record that ends at p - k
+#pragma unroll
+    for (uint32_t j = 3u; j <= 12u; j++) {                        // the record j positions in front of p
+        const uint32_t a = __shfl(recHere, (int)((lane - j) & 63u)), b = __shfl(recPrev, (int)((lane - j) & 63u));
+        const uint32_t r = lane >= j ? a : b;
+        const uint32_t len = r & 0xFFu, dist = r >> 8;            // (longer records are visited later and win)
+        if (j <= 9u && len == j - 1u) e1 = dist;
+        if (j >= 4u && j <= 10u && len == j - 2u) e2 = dist;
+        if (j >= 5u && j <= 11u && len == j - 3u) e3 = dist;
+        if (j >= 6u && len == j - 4u) e4 = dist;
+    }
+    d1 = e1 ? e1 : (e2 ? e2 : (e3 ? e3 : e4));
+    d2 = (e4 != 0u && e4 != d1) ? e4 : 0u;                        // nearest record end with another distance
+    d2 = (e3 != 0u && e3 != d1) ? e3 : d2;
+    d2 = (e2 != 0u && e2 != d1) ? e2 : d2;
+    d2 = (e1 != 0u && e1 != d1) ? e1 : d2;
+}
+
 #define DP_T       256u
 #define DP_WAVES   (DP_T / 64u)
 #define DP_WIN_LOG 12u
@@ -130,23 +155,24 @@ gc_mf_short_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t f
 #define DP_CONT_PRICE 4u               // continuation of a capped match: a quarter of a bit
 #define DP_MAX_MATCHES (DP_WIN / GC_MIN_MATCH)                    // matches per window that the sequence arrays are sure to hold
 
-// node word: cost << 8 | kind << 6 | (length - 1);  kind 0 literal (length 1), 1 finder candidate, 2 short candidate.
+// node word: cost << 8 | kind << 6 | (length - 1);  kind 0 literal (length 1), 1 finder candidate, 2 short candidate, 3 repeat.
 // The low byte is the back pointer; a price in word units is price << 8.
 #define DP_KIND1   (1u << 6)
 #define DP_KIND2   (2u << 6)
+#define DP_KIND3   (3u << 6)           // LZMA only: a repeat of the path's current distance (length 1 = LZMA's "short rep")
 
 // Two phases (one launch each).  The price tables W6 leaves behind are those of a GREEDY parse whose matches have >= 5 bytes: it says
 // nothing about the 2-4 byte matches, and where it finds no matches at all (16-bit samples, tables of small records) it makes every
 // match look expensive, so a shortest path under those prices never tries what the reference codes such data with (its adaptive
 // model prices a symbol by how often the parse itself has used it: the reference's stream of the PCM-like part of the Silesia
 // stand-in is 19 % 3-byte matches, the greedy-priced path found 0.1 %).  So:
-//   phase A  the shortest path of a SAMPLE of windows (8 of the 32 windows of a block), under W6's prices capped at optimistic
+//   phase A  the shortest path of a SAMPLE of windows (4 of the 32 windows of a block), under W6's prices capped at optimistic
 //            ceilings for the match side, and the symbol counts of those paths (lengths, distance slots, literals / matches)
 //   phase B  every window, lengths / slots / flags priced from phase A's counts (literals keep W6's prices: which byte values
 //            occur does not depend on the parse)
 // i.e. one round of the iteration "parse -> statistics -> prices -> parse" (tools/lzma_parse_lab.c LAB_ITER: -0.6 % on text).
 template <uint32_t minLen /* shortest match: 2 LZMA, 3 zstd */>
-__device__ __forceinline__ void dp_window(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t phaseArg /* 0: phase A; 1: phase B; 2: one
+__device__ __forceinline__ void dp_window(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t frameBlocks, uint32_t phaseArg /* 0: phase A; 1: phase B; 2: one
                 phase only (W6's prices as they are, every window, no counting) */, uint32_t* __restrict__ dpStat,
                 uint32_t litCtxArg /* bits of (previous byte >> 5) that select the literal price row: 7 LZMA (lc = 3), 0 zstd; bit 31: the
                                       byte in front of src exists (src is a later part of one buffer) */,
@@ -157,17 +183,21 @@ __device__ __forceinline__ void dp_window(const uint8_t* __restrict__ src, uint6
     __shared__ uint16_t sPrice[GC_PRICE_WORDS];
     __shared__ uint8_t sRow[DP_WAVES][DP_ROWS][64];               // back pointers by end node, later edges by start node
     __shared__ uint32_t sCnt[GC_DPS_WORDS];                       // phase A: symbol counts of this workgroup's paths
+    constexpr bool REPS = minLen == 2u;                           // LZMA: the path carries its last match distance (rep0) and may repeat it
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = gc_uniform(t >> 6);        // (uniform: the node index i must live in an SGPR)
     const bool phaseA = phaseArg == 0u, phaseB = phaseArg == 1u;
-    // a workgroup = DP_WAVES windows of one block: consecutive ones, or in phase A every fourth one (windows 1, 5, 9, ... 29)
+    bool useReps = REPS;                                          // (uniform per workgroup = per block)
+    // a workgroup = DP_WAVES windows of one block: consecutive ones, or in phase A every eighth one (windows 3, 11, 19, 27)
     const uint32_t item = ps_item(blockIdx.x, per);
-    const uint32_t wgPerBlock = phaseA ? DP_WINS_PER_BLOCK / DP_WAVES / 4u : DP_WINS_PER_BLOCK / DP_WAVES;
+    const uint32_t wgPerBlock = phaseA ? DP_WINS_PER_BLOCK / DP_WAVES / 8u : DP_WINS_PER_BLOCK / DP_WAVES;
     const uint32_t b = item / wgPerBlock;
     if (b >= nBlocks) return;
-    const uint32_t win = phaseA ? ((item % wgPerBlock) * DP_WAVES + wave) * 4u + 1u : (item % wgPerBlock) * DP_WAVES + wave;
+    const uint32_t win = phaseA ? ((item % wgPerBlock) * DP_WAVES + wave) * 8u + 3u : (item % wgPerBlock) * DP_WAVES + wave;
     { const GcU4* T4 = (const GcU4*)(priceTab + (uint64_t)b * GC_PRICE_WORDS); GcU4* S4 = (GcU4*)sPrice;
       for (uint32_t i = t; i < GC_PRICE_WORDS / 8u; i += DP_T) S4[i] = T4[i]; }
     if (phaseA) for (uint32_t i = t; i < GC_DPS_WORDS; i += DP_T) sCnt[i] = 0;
+    __syncthreads();
+    if (REPS && t == 0u) { sPrice[GC_PRICE_FLAGS + 2u] = 48u; sPrice[GC_PRICE_FLAGS + 3u] = 56u; }     // repeats before anything is known: 3 / 3.5 bits on top of the match flag
     __syncthreads();
     if (phaseA && sPrice[GC_PRICE_FLAGS + 1u] >= 64u) {
         // A block whose greedy parse is (almost) all literals -- fewer than one symbol in 16 is a match -- says nothing about what matches would
@@ -185,12 +215,18 @@ __device__ __forceinline__ void dp_window(const uint8_t* __restrict__ src, uint6
     if (phaseB) {                                                 // lengths, slots and flags from the counts of phase A's paths
         const uint32_t* C = dpStat + (uint64_t)b * GC_DPS_WORDS;
         const uint32_t nLit = C[GC_DPS_NLIT], nMat = C[GC_DPS_NMAT];
+        if (REPS && nLit + nMat != 0u) useReps = (C[GC_DPS_NREP] + C[GC_DPS_NSREP]) * 64u >= nMat;     // fewer than 1.6 % repeats among the matches: not worth the longer loop
         if (nLit + nMat != 0u) {                                  // (uniform; a block whose sampled windows do not exist keeps W6's prices)
             for (uint32_t i = t; i < GC_PRICE_NLEN + 64u + 2u; i += DP_T) {
-                if (i < GC_PRICE_NLEN) sPrice[GC_PRICE_LEN + i] = (uint16_t)pz_price(4u * C[GC_DPS_LEN + i] + 1u, 4u * nMat + 63u);
-                else if (i < GC_PRICE_NLEN + 64u) sPrice[GC_PRICE_SLOT + (i - GC_PRICE_NLEN)] = (uint16_t)pz_price(4u * C[GC_DPS_SLOT + (i - GC_PRICE_NLEN)] + 1u, 4u * nMat + 44u);
+                if (i < GC_PRICE_NLEN) sPrice[GC_PRICE_LEN + i] = (uint16_t)pz_price(8u * C[GC_DPS_LEN + i] + 1u, 8u * nMat + 63u);
+                else if (i < GC_PRICE_NLEN + 64u) sPrice[GC_PRICE_SLOT + (i - GC_PRICE_NLEN)] = (uint16_t)pz_price(8u * C[GC_DPS_SLOT + (i - GC_PRICE_NLEN)] + 1u, 8u * nMat + 44u);
                 else if (i == GC_PRICE_NLEN + 64u) sPrice[GC_PRICE_FLAGS] = (uint16_t)pz_price(nLit + 1u, nLit + nMat + 2u);
                 else sPrice[GC_PRICE_FLAGS + 1u] = (uint16_t)pz_price(nMat + 1u, nLit + nMat + 2u);
+            }
+            if (REPS && t == 0u) {                                // "is a repeat" + "repeat 0" + long / short, from how often phase A's paths repeated
+                const uint32_t nRep = C[GC_DPS_NREP], nSrep = C[GC_DPS_NSREP], isRep = pz_price(nRep + nSrep + 1u, nMat + 2u);
+                sPrice[GC_PRICE_FLAGS + 2u] = (uint16_t)(isRep + 4u + pz_price(nRep + 1u, nRep + nSrep + 2u));
+                sPrice[GC_PRICE_FLAGS + 3u] = (uint16_t)(isRep + 4u + pz_price(nSrep + 1u, nRep + nSrep + 2u));
             }
         }
         __syncthreads();
@@ -214,23 +250,48 @@ __device__ __forceinline__ void dp_window(const uint8_t* __restrict__ src, uint6
     // addends, and a step is: read node i, two scalar adds, shift, two vector adds, two compares + selects, two minima.
     const uint32_t X1 = ((uint32_t)sPrice[GC_PRICE_LEN + lane + 1u] << 8) | DP_KIND1 | lane;     // length price + back pointer of this lane's edge
     const uint32_t X2 = (X1 & ~0xC0u) | DP_KIND2;
+    const uint32_t X3 = X1 | DP_KIND3;
     const uint32_t capAdd = ((uint32_t)sPrice[GC_PRICE_LEN + GC_MATCH_CAP] << 8) | DP_KIND1 | (GC_MATCH_CAP - 1u);
+    // LZMA: a repeat of the path's last match distance costs the match flag + a few bits instead of slot + footer.  Every node carries
+    // that distance (ringR, shifted and selected along with ring); a candidate whose distance equals it is priced as a repeat, and where
+    // a hint (dp_rep_hints: the distance of a record that ends just in front of the node) names it, the bytes that repeat at the node
+    // are edges of their own (kind 3): lengths 2.., and length 1 = LZMA's short repeat -- what the reference codes copies with changed
+    // bytes, 16-bit samples and small records with (LZMA_optimalParse, lzma2_enc.c:949-1440: rep0 / shortrep edges at every position).
+    // (Looking at EVERY node for repeats at near distances, from the window's bytes, was tried as well: +0.05 % for a third more time.)
+    // Blocks whose sampled paths (phase A) hardly ever repeated run phase B without any of this (useReps).
+    const uint32_t repAdd = ((uint32_t)flagMat + sPrice[GC_PRICE_FLAGS + 2u]) << 8, srepAdd = (((uint32_t)flagMat + sPrice[GC_PRICE_FLAGS + 3u]) << 8) | DP_KIND3;
     uint32_t ring = lane == 0u ? 0u : DP_INF;                     // node 0: cost 0
+    uint32_t ringR = 0;                                           // node 0: no distance known
     uint32_t cc = 0;                                              // back pointers of the current group's nodes (lane = node mod 64)
     uint32_t curG = 0xFFFFFFFFu;
     uint32_t contBit = 0, contOff = 0;                            // contBit = 64: the node being expanded is the end of a capped match with this distance
-    GcPub pL, pA, pL3, pA3, pC, pD;       // per position of the group: candidate lengths, word addends (distance price), literal addend, distance
+    GcPub pL, pA, pL3, pA3, pC, pD, pD3;  // per position of the group: candidate lengths, word addends (distance price), literal addend, distances
     // raw inputs of the NEXT group, requested one group (64 nodes) ahead of their use
-    uint32_t nR = 0, nR3 = GC_SHORT_NONE, nByte = 0, nPrev = 0;
-    if (lane < n) { nR = R[lane]; nR3 = R3[lane]; nByte = S[lane]; nPrev = (base + w0 + lane + hasPrev) ? (uint32_t)S[(int64_t)lane - 1] : 0u; }
+    uint32_t nR = 0, nR3 = GC_SHORT_NONE, nPB = 0;                // nPB: the position's byte << 8 | the byte in front of it -- ONE load, taken apart when it is used
+    if (lane < n) { nR = R[lane]; nR3 = R3[lane]; nPB = ((uint32_t)S[lane] << 8) | ((base + w0 + lane + hasPrev) ? (uint32_t)S[(int64_t)lane - 1] : 0u); }
+    // LZMA: the records are requested TWO groups ahead (nR = next group, nR2 = the one behind it), because the repeat hints of a group need its
+    // records one group early: their distances tell which 16 bytes to fetch for the comparison (hB1 / hB2, one group ahead of their use)
+    GcPub pH1, pH2;                                               // per position: hint distance << 5 | bytes that repeat there (1..16), 0 = none
+    uint32_t nR2 = 0, hD1 = 0, hD2 = 0; LzW16 hB0, hB1, hB2; hB0.a = hB0.b = hB1.a = hB1.b = hB2.a = hB2.b = 0;     // hB0: the position's own 16 bytes
+    if (useReps) {
+        if (64u + lane < n) nR2 = R[64u + lane];
+        dp_rep_hints(nR, 0u, lane, hD1, hD2);                     // group 0: nothing in front of the window
+        const uint64_t absP = base + w0 + lane;
+        if (lane >= n || absP + 16u > srcSize) { hD1 = 0; hD2 = 0; }
+        if (hD1 | hD2) hB0 = lz_ld16(S, (uint64_t)lane);
+        if (hD1) hB1 = lz_ld16(S + (int64_t)lane - (int64_t)hD1, 0);
+        if (hD2) hB2 = lz_ld16(S + (int64_t)lane - (int64_t)hD2, 0);
+    }
     uint32_t i = 0;
+    // outer loop: one round per group of 64 positions (its inputs were requested a group earlier and are consumed before the new requests go out:
+    // the loads have a whole group of nodes to arrive); inner loop: the nodes of the group.  (A forced jump of 64 lands in the next group.)
     while (i < n) {
-        const uint32_t g = i >> 6, k = i & 63u;
-        if (g != curG) {                                          // uniform: new group of 64 positions
+        const uint32_t g = i >> 6;
+        {                                                         // new group of 64 positions
             if (curG != 0xFFFFFFFFu) row[curG][lane] = (uint8_t)cc;
             cc = 0; curG = g;
             const uint32_t p = (g << 6) + lane;                   // window-relative
-            uint32_t L = 0, A = 0, L3 = 0, A3 = 0, C = 0, D = 0;
+            uint32_t L = 0, A = 0, L3 = 0, A3 = 0, C = 0, D = 0, D3 = 0;
             if (p < n) {
                 const uint32_t r = nR, r3 = nR3;
                 uint32_t l = r & 0xFFu, off = r >> 8;
@@ -239,15 +300,35 @@ __device__ __forceinline__ void dp_window(const uint8_t* __restrict__ src, uint6
                 if (r3 != GC_SHORT_NONE) {
                     uint32_t l3 = (r3 & 15u) + 2u; const uint32_t off3 = (r3 >> 4) + 1u;
                     if (l3 > n - p) l3 = n - p;
-                    if (l3 >= minLen && !(l >= l3 && off <= off3)) { const uint32_t sl = gc_dist_slot(off3 - 1u); L3 = l3; A3 = (flagMat + sPrice[GC_PRICE_SLOT + sl] + (sl >= 4u ? 16u * ((sl >> 1) - 1u) : 0u)) << 8; }
+                    if (l3 >= minLen && !(l >= l3 && off <= off3)) { const uint32_t sl = gc_dist_slot(off3 - 1u); L3 = l3; A3 = (flagMat + sPrice[GC_PRICE_SLOT + sl] + (sl >= 4u ? 16u * ((sl >> 1) - 1u) : 0u)) << 8; D3 = off3; }
                 }
-                C = (flagLit + sPrice[GC_PRICE_LIT + (((nPrev >> 5) & litCtxMask) << 8) + nByte]) << 8;
+                C = (flagLit + sPrice[GC_PRICE_LIT + ((((nPB & 0xFFu) >> 5) & litCtxMask) << 8) + (nPB >> 8)]) << 8;
             }
             gc_publish(pL, L); gc_publish(pA, A); gc_publish(pL3, L3); gc_publish(pA3, A3); gc_publish(pC, C); gc_publish(pD, D);
             const uint32_t pn = p + 64u;
-            if (pn < n) { nR = R[pn]; nR3 = R3[pn]; nByte = S[pn]; nPrev = S[pn - 1u]; }
+            if (useReps) {
+                gc_publish(pD3, D3);
+                uint32_t H1 = 0, H2 = 0;                          // hints of this group: the fetched bytes against the window's own (LDS)
+                if (hD1 | hD2) {
+                    const LzW16 me = hB0;
+                    if (hD1) { uint32_t l = lz_cmp16(me, hB1); if (l > n - p) l = n - p; if (l) H1 = (hD1 << 5) | l; }
+                    if (hD2) { uint32_t l = lz_cmp16(me, hB2); if (l > n - p) l = n - p; if (l) H2 = (hD2 << 5) | l; }
+                }
+                gc_publish(pH1, H1); gc_publish(pH2, H2);
+                const uint32_t recThis = nR;                      // (nR still holds this group's records here)
+                dp_rep_hints(nR2, recThis, lane, hD1, hD2);       // next group's hints: distances now, bytes in flight until its turn
+                if (pn >= n || base + w0 + pn + 16u > srcSize) { hD1 = 0; hD2 = 0; }
+                if (hD1 | hD2) hB0 = lz_ld16(S, (uint64_t)pn);
+                if (hD1) hB1 = lz_ld16(S + (int64_t)pn - (int64_t)hD1, 0);
+                if (hD2) hB2 = lz_ld16(S + (int64_t)pn - (int64_t)hD2, 0);
+                nR = nR2; nR2 = pn + 64u < n ? R[pn + 64u] : 0u;
+                if (pn < n) { nR3 = R3[pn]; uint16_t two; __builtin_memcpy(&two, S + pn - 1u, 2); nPB = two; }
+            } else if (pn < n) { nR = R[pn]; nR3 = R3[pn]; uint16_t two; __builtin_memcpy(&two, S + pn - 1u, 2); nPB = two; }
         }
+        while (i < n && (i >> 6) == g) {
+        const uint32_t k = i & 63u;
         const uint32_t w = gc_readlane(ring, 0u);                 // node i: final
+        const uint32_t Rn = useReps ? gc_readlane(ringR, 0u) : 0u;   // ... and the distance of the last match on the way to it (0: none yet)
         cc = gc_writelane(cc, w, k);                              // (its low byte is the back pointer)
         const uint32_t costw = w & ~0xFFu;                        // cost in word units
         const uint32_t L = gc_peek(pL, k);
@@ -258,6 +339,7 @@ __device__ __forceinline__ void dp_window(const uint8_t* __restrict__ src, uint6
                 const uint32_t c = costw + (cont ? (DP_CONT_PRICE << 8) | DP_KIND1 | (GC_MATCH_CAP - 1u) : gc_peek(pA, k) + capAdd);
                 ring = lane == 0u ? c : DP_INF;                   // node i + 64 is the only open node
                 contBit = GC_MATCH_CAP; contOff = gc_peek(pD, k);
+                if (useReps) ringR = contOff;
                 i += GC_MATCH_CAP;
                 continue;
             }
@@ -266,23 +348,57 @@ __device__ __forceinline__ void dp_window(const uint8_t* __restrict__ src, uint6
                 uint32_t cand = lane < L ? costw + ((DP_CONT_PRICE << 8) | DP_KIND1 | lane) : DP_INF;
                 cand = gc_writelane_c<0>(cand, costw + gc_peek(pC, k));
                 if (minLen > 2u) cand = gc_writelane_c<1>(cand, DP_INF);
+                if (useReps) { ringR = gc_wave_shl1(ringR, 0u); const uint32_t candR = gc_writelane_c<0>(contOff, Rn); ringR = cand < ring ? candR : ringR; }
                 ring = cand < ring ? cand : ring;
                 i++;
                 continue;
             }
         }
         ring = gc_wave_shl1(ring, DP_INF);                        // lane t: node i + 1 + t, the end of this lane's edge
-        const uint32_t w1 = X1 + (costw + gc_peek(pA, k));
-        uint32_t cand = lane < L ? w1 : DP_INF;
-        const uint32_t L3 = gc_peek(pL3, k);
-        if (L3 != 0u) {                                           // uniform
-            const uint32_t w2 = X2 + (costw + gc_peek(pA3, k));
-            cand = (lane < L3 && w2 < cand) ? w2 : cand;
+        if (!useReps) {
+            const uint32_t w1 = X1 + (costw + gc_peek(pA, k));
+            uint32_t cand = lane < L ? w1 : DP_INF;
+            const uint32_t L3 = gc_peek(pL3, k);
+            if (L3 != 0u) {                                       // uniform
+                const uint32_t w2 = X2 + (costw + gc_peek(pA3, k));
+                cand = (lane < L3 && w2 < cand) ? w2 : cand;
+            }
+            cand = gc_writelane_c<0>(cand, costw + gc_peek(pC, k));   // lane 0: the literal (kind 0, length 1)
+            if (minLen > 2u) cand = gc_writelane_c<1>(cand, DP_INF);  // zstd: no matches of two bytes
+            ring = cand < ring ? cand : ring;
+        } else {
+            ringR = gc_wave_shl1(ringR, 0u);
+            const uint32_t D = gc_peek(pD, k);
+            const uint32_t w1 = X1 + (costw + ((L != 0u && D == Rn) ? repAdd : gc_peek(pA, k)));      // the candidate repeats the path's distance: repeat price
+            uint32_t cand = lane < L ? w1 : DP_INF;
+            uint32_t candR = D;
+            const uint32_t L3 = gc_peek(pL3, k);
+            if (L3 != 0u) {                                       // uniform
+                const uint32_t D3 = gc_peek(pD3, k);
+                const uint32_t w2 = X2 + (costw + (D3 == Rn ? repAdd : gc_peek(pA3, k)));
+                const bool t2 = lane < L3 && w2 < cand;
+                cand = t2 ? w2 : cand; candR = t2 ? D3 : candR;
+            }
+            uint32_t lane0 = costw + gc_peek(pC, k);              // the literal (kind 0, length 1)
+            uint32_t Lr = 0;                                      // bytes from node i on that repeat at the path's distance: where a hint names this very distance
+            if (Rn != 0u) {
+                const uint32_t h1 = gc_peek(pH1, k), h2 = gc_peek(pH2, k);
+                Lr = (h1 >> 5) == Rn ? (h1 & 31u) : ((h2 >> 5) == Rn ? (h2 & 31u) : 0u);
+            }
+            if (Lr != 0u) {                                       // uniform
+                const uint32_t w3 = X3 + (costw + repAdd);
+                const bool t3 = lane < Lr && lane != 0u && w3 < cand;
+                cand = t3 ? w3 : cand; candR = t3 ? Rn : candR;
+                const uint32_t sr = costw + srepAdd;              // short repeat: one byte, kind 3, length 1
+                lane0 = sr < lane0 ? sr : lane0;
+            }
+            cand = gc_writelane_c<0>(cand, lane0);
+            candR = gc_writelane_c<0>(candR, Rn);                 // a literal or a short repeat keeps the distance
+            const bool better = cand < ring;
+            ring = better ? cand : ring; ringR = better ? candR : ringR;
         }
-        cand = gc_writelane_c<0>(cand, costw + gc_peek(pC, k));   // lane 0: the literal (kind 0, length 1)
-        if (minLen > 2u) cand = gc_writelane_c<1>(cand, DP_INF);  // zstd: no matches of two bytes
-        ring = cand < ring ? cand : ring;
         i++;
+        }   // nodes of the group
     }
     // node n (i == n; a forced jump never passes n): lane 0
     {
@@ -316,30 +432,40 @@ __device__ __forceinline__ void dp_window(const uint8_t* __restrict__ src, uint6
     //      (but the last one), i.e. within the share.
     const bool fallback = nMatch > DP_MAX_MATCHES;                // uniform
     uint32_t* RO = recOut + base + w0;
-    uint32_t lenSum = 0;
+    uint32_t lenSum = 0, nRepC = 0, nSrepC = 0;
+    uint32_t lastD = 0;                                           // distance of the last kind 1 / 2 match of the path so far (uniform)
     for (uint32_t q = 0; (q << 6) < n; q++) {
         const uint32_t p = (q << 6) + lane;
-        if (p >= n) break;
-        const uint32_t c = row[q][lane];
+        const uint32_t c = p < n ? row[q][lane] : 0u;
         uint32_t out = 0;
         if (fallback) {
-            const uint32_t r = R[p];
-            uint32_t L = r & 0xFFu; if (L > n - p) L = n - p;
+            const uint32_t r = p < n ? R[p] : 0u;
+            uint32_t L = r & 0xFFu; if (p < n && L > n - p) L = n - p;
             out = (L >= minLen && (r & 0xFFu) >= GC_MIN_MATCH) ? ((r & ~0xFFu) | L) : 0u;       // (records of the short pass are left out)
-        } else if (c != 0u) {
-            const uint32_t off = (c >> 6) == 1u ? R[p] >> 8 : ((uint32_t)R3[p] >> 4) + 1u;
-            out = (off << 8) | ((c & 63u) + 1u);
+        } else {
+            const uint32_t kind = c >> 6;
+            uint32_t off = kind == 1u ? R[p] >> 8 : (kind == 2u ? ((uint32_t)R3[p] >> 4) + 1u : 0u);
+            if (REPS) {                                           // a repeat takes the distance of the nearest path match in front of it that has one
+                const uint32_t from = gc_wave_incl_max(off != 0u ? lane + 1u : 0u);
+                const uint32_t offPrev = __shfl(off, (int)(from ? from - 1u : 0u));
+                const uint32_t dHere = from ? offPrev : lastD;
+                if (kind == 3u) { off = dHere; nRepC += (c & 63u) != 0u ? 1u : 0u; nSrepC += (c & 63u) == 0u ? 1u : 0u; }
+                lastD = gc_readlane(dHere, 63u);
+            }
+            if (c != 0u && off != 0u) out = (off << 8) | ((c & 63u) + 1u);
         }
+        if (p >= n) continue;
         if (!phaseA) RO[p] = out;
         else if (out != 0u && !fallback) {                        // phase A: count the path's symbols instead (nothing is written)
             atomicAdd(&sCnt[GC_DPS_LEN + (out & 0xFFu)], 1u);
-            atomicAdd(&sCnt[GC_DPS_SLOT + gc_dist_slot((out >> 8) - 1u)], 1u);
+            if ((c >> 6) != 3u) atomicAdd(&sCnt[GC_DPS_SLOT + gc_dist_slot((out >> 8) - 1u)], 1u);
             lenSum += out & 0xFFu;
         }
     }
     if (phaseA && !fallback) {
         lenSum = gc_wave_sum(lenSum);
-        if (lane == 0u) { atomicAdd(&sCnt[GC_DPS_NMAT], nMatch); atomicAdd(&sCnt[GC_DPS_NLIT], n - lenSum); }
+        if (REPS) { nRepC = gc_wave_sum(nRepC); nSrepC = gc_wave_sum(nSrepC); }
+        if (lane == 0u) { atomicAdd(&sCnt[GC_DPS_NMAT], nMatch); atomicAdd(&sCnt[GC_DPS_NLIT], n - lenSum); atomicAdd(&sCnt[GC_DPS_NREP], nRepC); atomicAdd(&sCnt[GC_DPS_NSREP], nSrepC); }
     }
     }   // live
     if (phaseA) {
@@ -351,16 +477,16 @@ __device__ __forceinline__ void dp_window(const uint8_t* __restrict__ src, uint6
 
 // one kernel per shortest match length (the shared arrays of dp_window are per instantiation: two in one kernel would double its LDS)
 extern "C" __global__ void __launch_bounds__(DP_T)
-gc_mf_dp2_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t phase, uint32_t* __restrict__ dpStat, uint32_t litCtxMask,
+gc_mf_dp2_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t frameBlocks, uint32_t phase, uint32_t* __restrict__ dpStat, uint32_t litCtxMask,
                  const uint32_t* __restrict__ rec, const uint16_t* __restrict__ rec3, const uint16_t* __restrict__ priceTab, uint32_t* __restrict__ recOut,
                  uint32_t* __restrict__ winCost)
 {
-    dp_window<2u>(src, srcSize, nBlocks, per, phase, dpStat, litCtxMask, rec, rec3, priceTab, recOut, winCost);
+    dp_window<2u>(src, srcSize, nBlocks, per, frameBlocks, phase, dpStat, litCtxMask, rec, rec3, priceTab, recOut, winCost);
 }
 extern "C" __global__ void __launch_bounds__(DP_T)
-gc_mf_dp3_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t phase, uint32_t* __restrict__ dpStat, uint32_t litCtxMask,
+gc_mf_dp3_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t frameBlocks, uint32_t phase, uint32_t* __restrict__ dpStat, uint32_t litCtxMask,
                  const uint32_t* __restrict__ rec, const uint16_t* __restrict__ rec3, const uint16_t* __restrict__ priceTab, uint32_t* __restrict__ recOut,
                  uint32_t* __restrict__ winCost)
 {
-    dp_window<3u>(src, srcSize, nBlocks, per, phase, dpStat, litCtxMask, rec, rec3, priceTab, recOut, winCost);
+    dp_window<3u>(src, srcSize, nBlocks, per, frameBlocks, phase, dpStat, litCtxMask, rec, rec3, priceTab, recOut, winCost);
 }

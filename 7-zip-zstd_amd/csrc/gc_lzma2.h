@@ -41,7 +41,7 @@
 #define GC_LZMA_RC_PER_BLOCK (GC_ZSTD_BLOCK_MAX >> GC_LZMA_RC_LOG)
 #define GC_LZMA_RC_STRIDE   (GC_LZMA_RC_SIZE + 1024u)     // bytes of range-coder output reserved per rc chunk (LZMA expands < 2 %)
 #define GC_LZMA_RC_GROUP_MAX 8u                           // rc chunks that may be coded as one LZMA2 chunk (32 KiB: below the 64 KiB of a stored chunk)
-#define GC_LZMA_RC_MERGE_WORDS 36864u                     // ... while their coded bits stay within this many words: what 4 KiB of literals cost (9 per byte)
+#define GC_LZMA_RC_MERGE_WORDS 49152u                     // ... while their coded bits stay within this many words (4 KiB of literals cost 36864: 9 per byte)
 #define GC_LZMA_SEG_LOG_MIN 14u
 #define GC_LZMA_SEG_LOG_MAX 17u
 

@@ -192,10 +192,12 @@ __device__ __forceinline__ void lz_gen_len(LzEv& o, uint32_t base, uint32_t len,
     }
 }
 
-// one match-type symbol.  kind: 0 normal match, 1 rep0 (long), 2 rep1.  dist = distance-1.  At most 48 events.
+// one match-type symbol.  kind: 0 normal match, 1 rep0 (long), 2 rep1, 3 short rep (one byte at rep0: LzmaDec.c "IsRep0Long = 0").
+// dist = distance-1.  At most 48 events.
 __device__ __forceinline__ void lz_gen_match(LzEv& o, uint32_t kind, uint32_t len, uint32_t dist, uint32_t state, uint32_t posState)
 {
     ev_put(o, LZP_ISMATCH + state * 4u + posState, 1);
+    if (kind == 3u) { ev_put(o, LZP_ISREP + state, 1); ev_put(o, LZP_ISREPG0 + state, 0); ev_put(o, LZP_ISREP0LONG + state * 4u + posState, 0); return; }
     if (kind == 0u) {
         ev_put(o, LZP_ISREP + state, 0);
         lz_gen_len(o, LZP_LEN, len, posState);
@@ -388,7 +390,10 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
             }
         }
         uint32_t kind = 0;
-        if (isM) kind = it.off == pOff ? 1u : (it.off == rep1 ? 2u : 0u);
+        if (isM) kind = it.off == pOff ? (it.len == 1u ? 3u : 1u) : (it.off == rep1 ? 2u : 0u);
+#ifdef HIPEMU
+        if (isM && it.len == 1u && kind != 3u) { fprintf(stderr, "L2: one-byte item at %u is not a repeat of the previous distance (%u vs %u)\n", it.pos, it.off, pOff); abort(); }
+#endif
         // coder state: literals of cut items since the last match, state after that match
         const uint32_t cl = (lane < cnt && !isM) ? ll : 0u;
         const uint32_t aIncl = gc_wave_incl_sum(cl), aExcl = aIncl - cl;
@@ -397,7 +402,7 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
         const uint32_t aAtM = __shfl(aExcl, (int)mLane);
         const uint32_t L = mInTile ? aExcl - aAtM : cLits + aExcl;           // literals between the last match and this item
         const bool litBefore = (L + ll) != 0u || mPrev == 0u;                // <=> coder state before the match is a literal state
-        const uint32_t stAfter = kind == 0u ? (litBefore ? 7u : 10u) : (litBefore ? 8u : 11u);
+        const uint32_t stAfter = kind == 0u ? (litBefore ? 7u : 10u) : (kind == 3u ? (litBefore ? 9u : 11u) : (litBefore ? 8u : 11u));   // LzmaDec.c state updates
         const uint32_t exAtM = __shfl(stAfter, (int)mLane);
         const uint32_t exM = mInTile ? exAtM : cExit;                        // state after the last match before this item
         const uint32_t st0 = lz_lit_advance(exM, L);                         // state at this item's first literal

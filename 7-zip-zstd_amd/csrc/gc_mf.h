@@ -93,6 +93,8 @@ static inline GcMfGeom gc_mf_geom(uint64_t n, uint32_t frameBlocks)
 #define GC_DPS_SLOT     GC_PRICE_NLEN      // [distance slot 0..63]
 #define GC_DPS_NLIT     (GC_DPS_SLOT + 64u)
 #define GC_DPS_NMAT     (GC_DPS_NLIT + 1u)
+#define GC_DPS_NREP      (GC_DPS_NLIT + 2u)     // repeats of >= 2 bytes found through the path's own distance
+#define GC_DPS_NSREP     (GC_DPS_NLIT + 3u)     // short repeats (one byte)
 #define GC_DPS_WORDS    160u
 #define GC_SHORT_NONE   0xFFFFu            // W5s -> W7: uint16 per position, (distance - 1) << 4 | (length - 2), or none
 
