@@ -40,6 +40,9 @@ extern "C" __global__ void gc_mf_scan_kernel(uint32_t*, uint32_t);
 extern "C" __global__ void gc_mf_scatter_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
 extern "C" __global__ void gc_mf_link_kernel(const uint32_t*, const GcMfEntry*, GcMfEntry*, uint32_t, uint64_t);
 extern "C" __global__ void gc_mf_verify_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
+extern "C" __global__ void gc_mf_count_half_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
+extern "C" __global__ void gc_mf_scatter_half_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
+extern "C" __global__ void gc_mf_verify_half_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
 extern "C" __global__ void gc_mf_count_short_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
 extern "C" __global__ void gc_mf_scatter_short_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
 extern "C" __global__ void gc_mf_verify_short_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, const uint32_t*, uint32_t*);
@@ -47,6 +50,21 @@ extern "C" __global__ void gc_mf_count_far_kernel(const uint8_t*, uint64_t, uint
 extern "C" __global__ void gc_mf_scatter_far_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
 extern "C" __global__ void gc_mf_verify_far_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
 extern "C" __global__ void gc_mf_deepen_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, uint32_t*);
+extern "C" __global__ void gc_mf_count_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
+extern "C" __global__ void gc_mf_scan_kernel_p8(uint32_t*, uint32_t);
+extern "C" __global__ void gc_mf_scatter_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
+extern "C" __global__ void gc_mf_link_kernel_p8(const uint32_t*, const GcMfEntry*, GcMfEntry*, uint32_t, uint64_t);
+extern "C" __global__ void gc_mf_verify_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
+extern "C" __global__ void gc_mf_count_half_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
+extern "C" __global__ void gc_mf_scatter_half_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
+extern "C" __global__ void gc_mf_verify_half_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
+extern "C" __global__ void gc_mf_count_short_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
+extern "C" __global__ void gc_mf_scatter_short_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
+extern "C" __global__ void gc_mf_verify_short_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, const uint32_t*, uint32_t*);
+extern "C" __global__ void gc_mf_count_far_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
+extern "C" __global__ void gc_mf_scatter_far_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
+extern "C" __global__ void gc_mf_verify_far_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
+extern "C" __global__ void gc_mf_deepen_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, uint32_t*);
 extern "C" __global__ void gc_mf_parse_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcSeqRaw*, uint8_t*, GcBlockMeta*, uint16_t*, uint32_t);
 extern "C" __global__ void gc_mf_short_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint16_t*);
 extern "C" __global__ void gc_mf_dp2_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
@@ -76,6 +94,8 @@ struct gc_ctx {
     uint32_t searchDepth;     // W5b: match links followed per position (0 = W5's two candidates only)
     uint32_t shortPass;       // third finder pass with 4- / 3-byte keys; its merged records feed the price-based parse only
     uint32_t farPass;         // second finder pass with 16- / 12-byte keys (longer matches), merged into the records by gain
+    uint32_t mfFast;          // geometry of the windowed finder (gc_mf.h): 1 = 256 partitions / 8 KiB tiles, 0 = 1024 partitions / 16 KiB tiles
+    uint32_t halfList;        // first finder pass over the even positions only, matches extended one byte backwards (zstd levels 3-5)
     uint32_t priceParse;      // W5s + W7: price-based parse on top of the greedy one (gc_lz_price.hip)
     uint32_t priceMinLen, priceLitCtx;        // its shortest match and literal context bits (LZMA: 2, 7; zstd: 3, 0)
     uint32_t dbgFrameBlocks, dbgPartFrames;   // test hooks (env GC_FRAME_BLOCKS / GC_PART_FRAMES): small frames / parts so that
@@ -260,7 +280,7 @@ static int mf_grow(gc_ctx* c, void** p, size_t* cap, size_t needBytes, const cha
 static int ensure_finder_workspace(gc_ctx* c, size_t n, uint32_t frameBlocks)
 {
     if (frameBlocks <= 1u) return GC_OK;
-    const GcMfGeom g = gc_mf_geom(n, frameBlocks);
+    const GcMfGeom g = gc_mf_geom(n, frameBlocks, c->mfFast != 0u);
     const size_t needCnt = g.cntWords * sizeof(uint32_t), needEnt = (size_t)g.nFrames * g.frameBytes * sizeof(GcMfEntry);
     const size_t needRec = (size_t)g.nBlocks * GC_ZSTD_BLOCK_MAX * sizeof(uint32_t);
     const size_t needPrice = (size_t)g.nBlocks * GC_PRICE_WORDS * sizeof(uint16_t);
@@ -296,38 +316,45 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
         GC_LAUNCH(gc_zstd_lz_kernel, nBlocks, 1024, st, src, (uint64_t)n, seqRaw, lit, meta, prof);
         return GC_OK;
     }
-    const GcMfGeom g = gc_mf_geom(n, frameBlocks);
+    const GcMfGeom g = gc_mf_geom(n, frameBlocks, c->mfFast != 0u);
     const uint32_t frame0 = blk0 / frameBlocks;
-    uint32_t* cnt = c->mfCnt + (size_t)frame0 * (g.tilesPerFrame + 1u) * GC_MF_PARTS;
+    uint32_t* cnt = c->mfCnt + ((size_t)frame0 * (g.tilesPerFrame + 1u) << g.partLog);
     GcMfEntry* ent = c->mfEnt + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
     GcMfEntry* ent2 = c->mfEnt2 + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
     uint32_t* rec = c->mfRec + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
     const uint32_t perT = gc_xcd_per(g.nTiles), perB = gc_xcd_per(nBlocks);
+    const bool fast = c->mfFast != 0u;
+    const uint32_t nParts = 1u << g.partLog;
+#define MFSEL(k) (fast ? k##_p8 : k)          // the kernel of this geometry
     hipEvent_t* ev = c->evMf[part];
     HIPCHK(c, hipEventRecord(ev[0], st));
-    GC_LAUNCH(gc_mf_count_kernel, perT * GC_XCDS, GC_MF_PARTS, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, cnt);
+    if (c->halfList) GC_LAUNCH(MFSEL(gc_mf_count_half_kernel), perT * GC_XCDS, nParts, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, cnt);
+    else GC_LAUNCH(MFSEL(gc_mf_count_kernel), perT * GC_XCDS, nParts, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, cnt);
     HIPCHK(c, hipEventRecord(ev[1], st));
-    GC_LAUNCH(gc_mf_scan_kernel, g.nFrames, 1024, st, cnt, g.tilesPerFrame);
+    GC_LAUNCH(MFSEL(gc_mf_scan_kernel), g.nFrames, 1024, st, cnt, g.tilesPerFrame);
     HIPCHK(c, hipEventRecord(ev[2], st));
-    GC_LAUNCH(gc_mf_scatter_kernel, perT * GC_XCDS, GC_MF_PARTS, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt, ent);
+    if (c->halfList) GC_LAUNCH(MFSEL(gc_mf_scatter_half_kernel), perT * GC_XCDS, nParts, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt, ent);
+    else GC_LAUNCH(MFSEL(gc_mf_scatter_kernel), perT * GC_XCDS, nParts, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt, ent);
     HIPCHK(c, hipEventRecord(ev[3], st));
-    GC_LAUNCH(gc_mf_link_kernel, g.nFrames * GC_MF_PARTS * GC_MF_LINK_SEGS, 64, st, (const uint32_t*)cnt, (const GcMfEntry*)ent, ent2, g.tilesPerFrame, g.frameBytes);
+    GC_LAUNCH(MFSEL(gc_mf_link_kernel), g.nFrames * nParts * GC_MF_LINK_SEGS, 64, st, (const uint32_t*)cnt, (const GcMfEntry*)ent, ent2, g.tilesPerFrame, g.frameBytes);
     HIPCHK(c, hipEventRecord(ev[4], st));
-    GC_LAUNCH(gc_mf_verify_kernel, perT * GC_XCDS, GC_MF_VERIFY_T, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt,
-              (const GcMfEntry*)ent2, rec);
+    if (c->halfList) GC_LAUNCH(MFSEL(gc_mf_verify_half_kernel), perT * GC_XCDS, g.verifyT, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt,
+                               (const GcMfEntry*)ent2, rec);
+    else GC_LAUNCH(MFSEL(gc_mf_verify_kernel), perT * GC_XCDS, g.verifyT, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt,
+                   (const GcMfEntry*)ent2, rec);
     HIPCHK(c, hipEventRecord(ev[10], st));
     if (c->farPass) {                                           // second pass with 16- / 12-byte keys, merged into rec (timed with W5)
-        GC_LAUNCH(gc_mf_count_far_kernel, perT * GC_XCDS, GC_MF_PARTS, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, cnt);
-        GC_LAUNCH(gc_mf_scan_kernel, g.nFrames, 1024, st, cnt, g.tilesPerFrame);
-        GC_LAUNCH(gc_mf_scatter_far_kernel, perT * GC_XCDS, GC_MF_PARTS, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt, ent);
-        GC_LAUNCH(gc_mf_link_kernel, g.nFrames * GC_MF_PARTS * GC_MF_LINK_SEGS, 64, st, (const uint32_t*)cnt, (const GcMfEntry*)ent, ent2, g.tilesPerFrame, g.frameBytes);
-        GC_LAUNCH(gc_mf_verify_far_kernel, perT * GC_XCDS, GC_MF_VERIFY_T, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt,
+        GC_LAUNCH(MFSEL(gc_mf_count_far_kernel), perT * GC_XCDS, nParts, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, cnt);
+        GC_LAUNCH(MFSEL(gc_mf_scan_kernel), g.nFrames, 1024, st, cnt, g.tilesPerFrame);
+        GC_LAUNCH(MFSEL(gc_mf_scatter_far_kernel), perT * GC_XCDS, nParts, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt, ent);
+        GC_LAUNCH(MFSEL(gc_mf_link_kernel), g.nFrames * nParts * GC_MF_LINK_SEGS, 64, st, (const uint32_t*)cnt, (const GcMfEntry*)ent, ent2, g.tilesPerFrame, g.frameBytes);
+        GC_LAUNCH(MFSEL(gc_mf_verify_far_kernel), perT * GC_XCDS, g.verifyT, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt,
                   (const GcMfEntry*)ent2, rec);
     }
     HIPCHK(c, hipEventRecord(ev[11], st));
     if (c->searchDepth) {                                       // W5b: follow match links (timed with W5)
         uint32_t* rec2 = c->mfRec2 + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
-        GC_LAUNCH(gc_mf_deepen_kernel, perT * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, c->searchDepth, (const uint32_t*)rec, rec2);
+        GC_LAUNCH(MFSEL(gc_mf_deepen_kernel), perT * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, c->searchDepth, (const uint32_t*)rec, rec2);
         rec = rec2;
     }
     HIPCHK(c, hipEventRecord(ev[12], st));
@@ -335,11 +362,11 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
     const uint32_t* recDp = rec;                                // what W7 reads: the records, or the records + short candidates
     if (c->priceParse && c->shortPass) {                        // third pass with 4- / 3-byte keys (timed with W5)
         uint32_t* recN = rec == c->mfRec + (size_t)blk0 * GC_ZSTD_BLOCK_MAX ? c->mfRec2 + (size_t)blk0 * GC_ZSTD_BLOCK_MAX : c->mfRec + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
-        GC_LAUNCH(gc_mf_count_short_kernel, perT * GC_XCDS, GC_MF_PARTS, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, cnt);
-        GC_LAUNCH(gc_mf_scan_kernel, g.nFrames, 1024, st, cnt, g.tilesPerFrame);
-        GC_LAUNCH(gc_mf_scatter_short_kernel, perT * GC_XCDS, GC_MF_PARTS, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt, ent);
-        GC_LAUNCH(gc_mf_link_kernel, g.nFrames * GC_MF_PARTS * GC_MF_LINK_SEGS, 64, st, (const uint32_t*)cnt, (const GcMfEntry*)ent, ent2, g.tilesPerFrame, g.frameBytes);
-        GC_LAUNCH(gc_mf_verify_short_kernel, perT * GC_XCDS, GC_MF_VERIFY_T, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt,
+        GC_LAUNCH(MFSEL(gc_mf_count_short_kernel), perT * GC_XCDS, nParts, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, cnt);
+        GC_LAUNCH(MFSEL(gc_mf_scan_kernel), g.nFrames, 1024, st, cnt, g.tilesPerFrame);
+        GC_LAUNCH(MFSEL(gc_mf_scatter_short_kernel), perT * GC_XCDS, nParts, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt, ent);
+        GC_LAUNCH(MFSEL(gc_mf_link_kernel), g.nFrames * nParts * GC_MF_LINK_SEGS, 64, st, (const uint32_t*)cnt, (const GcMfEntry*)ent, ent2, g.tilesPerFrame, g.frameBytes);
+        GC_LAUNCH(MFSEL(gc_mf_verify_short_kernel), perT * GC_XCDS, g.verifyT, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt,
                   (const GcMfEntry*)ent2, (const uint32_t*)rec, recN);
         recDp = recN;
     }
@@ -454,6 +481,12 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
     if (frameBlocks > 1u && c->dbgFrameBlocks) frameBlocks = c->dbgFrameBlocks;                              // test hook: small frames
     if (frameBlocks > nBlocks) frameBlocks = nBlocks;                                                       // short input: one frame
     c->lazyDepth = level >= 6 ? 2u : 1u;          // the reference's lazy2 begins at level 8 of its table; deeper look-ahead from 6 here
+    c->mfFast = level <= 6 ? 1u : 0u;             // no far pass below level 7: the fast geometry (gc_mf.h)
+    gc_env_u32("GC_MF_FAST", 0u, 1u, &c->mfFast);                                              // test hook
+    c->halfList = 0u;                             // (listing half of the positions, chosen by content, with matches extended up to 3 bytes backwards -- MF_HALF in
+                                                  // gc_lz_window.hip -- was measured at level 3 on 1 GB of text: 43.2 -> 39.0 ms for +3.5-4.5 % size.  Not taken: W3-W5 are
+                                                  // bound by what they do per tile and per list, not per entry.  The test hook keeps the path exercised.)
+    gc_env_u32("GC_HALF_LIST", 0u, 1u, &c->halfList);
     c->searchDepth = zstd_search_depth(level);
     c->farPass = level >= 7 ? 1u : 0u;            // where the reference searches chains / trees (lazy2 and up).  Measured (run 29, 32 MiB): level 9
                                                   // 1.027 -> 0.984 x the reference on text, level 12 1.040 -> 1.001 x
@@ -587,6 +620,7 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     }
     uint32_t frameBlocks = flzma2_frame_blocks(level);
     c->lazyDepth = level >= 5 ? 2u : 1u;
+    c->halfList = 0; c->mfFast = 0;
     c->searchDepth = level >= 5 ? (level >= 8 ? 8u : 2u) : 0u;      // (with the far pass in, links beyond the second add < 0.1 %)
     c->farPass = level >= 3 ? 1u : 0u;            // the reference's match table resolves to depth 42 at level 5 (fl2_compress.c:37-104);
                                                   // level 3 (run 30x, 32 MiB): 1.071 -> 1.026 x the reference on text
@@ -727,6 +761,7 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     HIPCHK(c, hipMemsetAsync(c->brStage, 0, (size_t)nBlocks * GC_BR_STAGE_STRIDE, c->stream));
     uint32_t frameBlocks = brotli_frame_blocks(level, bpc);
     c->lazyDepth = level >= 7 ? 2u : 1u;
+    c->halfList = 0; c->mfFast = level <= 4 ? 1u : 0u;        // (far pass from quality 5)
     c->searchDepth = level >= 7 ? (level >= 10 ? 8u : 4u) : 0u;
     c->farPass = level >= 5 ? 1u : 0u; c->shortPass = 0;      // longer matches stand in for the context modelling / block splitting B1 lacks
     gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass);                                            // test hook

@@ -22,6 +22,16 @@
 #include "gc_mf.h"
 #include "gc_lz_parse.h"
 
+// kernel names of this geometry (gc_mf.h: the fast geometry is compiled from gc_lz_window_p8.hip with the suffix _p8)
+#ifdef GC_MF_FAST
+#define MFK(name) name##_p8
+#else
+#define MFK(name) name
+#endif
+
+// everything below depends on the geometry: one namespace per geometry, so that the two copies of the helpers never meet at link time
+namespace MFK(gc_mf_ns) {
+
 #define MF_T         GC_MF_PARTS      // W1 / W3: threads per tile (one per partition)
 #define MF_WAVES     (MF_T / 64u)
 static_assert(MF_T == GC_MF_PARTS, "W1/W3 use one thread per partition for the histogram rows");
@@ -92,6 +102,13 @@ __device__ __forceinline__ uint32_t mf_lds_byte(const uint32_t* sW, uint32_t i) 
 #define MF_BASE  0
 #define MF_FAR   1
 #define MF_SHORT 2
+// MF_HALF = MF_BASE over HALF of the positions, chosen by content (one bit of a hash of the position's 5 bytes, so that both ends of a
+// repeat are listed or neither is) -- zstd levels 3-5: the reference's dfast itself steps over positions once a literal run is under
+// way (zstd_double_fast.c:169-190), and its level-3 tables are 8 x smaller than the ones here.  Half the entries means half of W3's
+// stores and of W4's and W5's work; what it costs -- a match whose first position is not listed is seen a byte or two late -- is
+// partly taken back in W5: a verified candidate is extended one byte BACKWARDS and the longer match is recorded at the position in
+// front if that has no record of its own.
+#define MF_HALF  3
 struct MfKeys { bool ok, run; uint32_t part; uint64_t entry; };
 template <int MODE>
 __device__ __forceinline__ MfKeys mf_keys(const uint32_t* sW, uint32_t q, const MfTile& T)
@@ -103,6 +120,7 @@ __device__ __forceinline__ MfKeys mf_keys(const uint32_t* sW, uint32_t q, const 
     if (q < T.len && P + GC_MATCH_CAP + 16u <= T.frameEnd && !r.run) {
         const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
         uint32_t hL = lz_hash_long(lo, hi), hS = lz_hash_short(lo, hi);
+        if (MODE == MF_HALF && (((hS ^ (hS >> 16)) * 0x85EBCA6Bu) >> 31) != 0u) return r;        // half of the 5-byte contexts, chosen by content: both ends of a repeat are listed or neither
         if (MODE == MF_SHORT) {
             hS = (lo & 0xFFFFFFu) * 0x9E3779B1u; hS ^= hS >> 15; hS *= 0x2C1B3C6Du;     // bytes 0..2
             hL = lo * 0x9E3779B1u; hL ^= hL >> 15; hL *= 0x85EBCA77u;                   // bytes 0..3
@@ -146,17 +164,22 @@ __device__ __forceinline__ void mf_count_body(const uint8_t* __restrict__ src, u
     cnt[((uint64_t)T.frame * (TPF + 1u) + T.tif) * GC_MF_PARTS + t] = sHist[t];
 }
 extern "C" __global__ void __launch_bounds__(MF_T)
-gc_mf_count_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per, uint32_t* __restrict__ cnt)
+MFK(gc_mf_count_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per, uint32_t* __restrict__ cnt)
 {
     mf_count_body<MF_BASE>(src, srcSize, frameBlocks, nTiles, per, cnt);
 }
 extern "C" __global__ void __launch_bounds__(MF_T)
-gc_mf_count_short_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per, uint32_t* __restrict__ cnt)
+MFK(gc_mf_count_short_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per, uint32_t* __restrict__ cnt)
 {
     mf_count_body<MF_SHORT>(src, srcSize, frameBlocks, nTiles, per, cnt);
 }
 extern "C" __global__ void __launch_bounds__(MF_T)
-gc_mf_count_far_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per, uint32_t* __restrict__ cnt)
+MFK(gc_mf_count_half_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per, uint32_t* __restrict__ cnt)
+{
+    mf_count_body<MF_HALF>(src, srcSize, frameBlocks, nTiles, per, cnt);
+}
+extern "C" __global__ void __launch_bounds__(MF_T)
+MFK(gc_mf_count_far_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per, uint32_t* __restrict__ cnt)
 {
     mf_count_body<MF_FAR>(src, srcSize, frameBlocks, nTiles, per, cnt);
 }
@@ -166,7 +189,7 @@ gc_mf_count_far_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32
 // `tilesPerFrame` receives the partition ends.  Thread (q, g) walks quarter q of the tiles for partition g (row reads are
 // coalesced over g).
 extern "C" __global__ void __launch_bounds__(1024)
-gc_mf_scan_kernel(uint32_t* __restrict__ cnt, uint32_t tilesPerFrame)
+MFK(gc_mf_scan_kernel)(uint32_t* __restrict__ cnt, uint32_t tilesPerFrame)
 {
     constexpr uint32_t Q = 1024u / GC_MF_PARTS;                   // groups of tile rows walked side by side (1 with 1024 partitions)
     constexpr uint32_t NW = GC_MF_PARTS / 64u;                    // waves that hold one partition per lane
@@ -281,19 +304,25 @@ __device__ __forceinline__ void mf_scatter_body(const uint8_t* __restrict__ src,
     }
 }
 extern "C" __global__ void __launch_bounds__(MF_T)
-gc_mf_scatter_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
+MFK(gc_mf_scatter_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
                      const uint32_t* __restrict__ offs, GcMfEntry* __restrict__ ent)
 {
     mf_scatter_body<MF_BASE>(src, srcSize, frameBlocks, nTiles, per, offs, ent);
 }
 extern "C" __global__ void __launch_bounds__(MF_T)
-gc_mf_scatter_short_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
+MFK(gc_mf_scatter_short_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
                            const uint32_t* __restrict__ offs, GcMfEntry* __restrict__ ent)
 {
     mf_scatter_body<MF_SHORT>(src, srcSize, frameBlocks, nTiles, per, offs, ent);
 }
 extern "C" __global__ void __launch_bounds__(MF_T)
-gc_mf_scatter_far_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
+MFK(gc_mf_scatter_half_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
+                          const uint32_t* __restrict__ offs, GcMfEntry* __restrict__ ent)
+{
+    mf_scatter_body<MF_HALF>(src, srcSize, frameBlocks, nTiles, per, offs, ent);
+}
+extern "C" __global__ void __launch_bounds__(MF_T)
+MFK(gc_mf_scatter_far_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
                          const uint32_t* __restrict__ offs, GcMfEntry* __restrict__ ent)
 {
     mf_scatter_body<MF_FAR>(src, srcSize, frameBlocks, nTiles, per, offs, ent);
@@ -315,7 +344,11 @@ gc_mf_scatter_far_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint
 // touched for 16 Ki insertions (e^-4 of them), whose stale candidates are simply not offered.  Output goes to a second entry
 // array because the replay reads what the previous segment's wave is working on.
 #define LINK_DEPTH 8u                 // steps per register set
-#define LINK_SEG   16384u             // entries per segment (2 x the mean list length of a full 8 MiB frame)
+#ifdef GC_MF_FAST
+#define LINK_SEG   49152u             // entries per segment (1.5 x the mean list length of a full 8 MiB frame: 256 partitions)
+#else
+#define LINK_SEG   16384u             // entries per segment (2 x the mean list length of a full 8 MiB frame: 1024 partitions)
+#endif
 #define LINK_WARM  16384u             // entries replayed in front of a segment
 #define LINK_SEGS  GC_MF_LINK_SEGS                 // segments per list; the last one takes whatever is left
 
@@ -363,7 +396,7 @@ __device__ __forceinline__ void mf_link_steps(const uint64_t q[LINK_DEPTH], uint
 }
 
 extern "C" __global__ void __launch_bounds__(64)
-gc_mf_link_kernel(const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, GcMfEntry* __restrict__ entOut, uint32_t tilesPerFrame,
+MFK(gc_mf_link_kernel)(const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, GcMfEntry* __restrict__ entOut, uint32_t tilesPerFrame,
                   uint64_t frameBytes)
 {
     __shared__ uint32_t tabL[1u << GC_MF_LSLOT_LOG];
@@ -436,17 +469,33 @@ __device__ __forceinline__ uint32_t mfv_len16(const LzW16& me, const LzW16& cw, 
     return len >= minLen ? len : 0u;
 }
 
+// MF_HALF: the 16-byte windows start MFV_BACK bytes IN FRONT of the position and of the candidate.  Returns the common prefix of the bytes
+// from the position on (0..13; 0 if below GC_MIN_MATCH or maxLen == 0) and how many of the bytes in front agree as well (0..3, counted backwards).
+#define MFV_BACK 3u
+__device__ __forceinline__ uint32_t mfv_len13(const LzW16& me, const LzW16& cw, uint32_t maxLen, uint32_t& ext)
+{
+    const uint64_t d0 = me.a ^ cw.a, d1 = me.b ^ cw.b;
+    const bool b2 = ((d0 >> 16) & 0xFFull) == 0ull, b1 = ((d0 >> 8) & 0xFFull) == 0ull, b0 = (d0 & 0xFFull) == 0ull;
+    ext = b2 ? (b1 ? (b0 ? 3u : 2u) : 1u) : 0u;
+    const uint64_t e0 = (d0 >> 24) | (d1 << 40), e1 = (d1 >> 24) | (1ull << 40);
+    uint32_t len = e0 ? gc_ctz64(e0) >> 3 : 8u + (gc_ctz64(e1) >> 3);
+    if (len > maxLen) len = maxLen;
+    return len >= GC_MIN_MATCH ? len : 0u;
+}
+
 // MF_FAR / MF_SHORT: the candidates come from a later pass; recIn holds the records so far and a position's record is replaced
 // only by a candidate of better gain (recIn == rec: in place; a workgroup reads and writes its own tile only).
 template <int MODE>
 __device__ __forceinline__ void mf_verify_body(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
                     const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, const uint32_t* recIn, uint32_t* rec)
 {
-    constexpr bool FAR = MODE != MF_BASE;                         // a merging pass
+    constexpr bool FAR = MODE == MF_FAR || MODE == MF_SHORT;      // a merging pass
+    constexpr bool HALF = MODE == MF_HALF;                        // even positions only; matches are extended one byte backwards
     constexpr uint32_t MINLEN = MODE == MF_SHORT ? 3u : GC_MIN_MATCH;
     constexpr uint32_t LONGLEN = MODE == MF_SHORT ? 4u : (MODE == MF_FAR ? 16u : 8u);   // a verified long candidate has this many bytes
     __shared__ uint32_t sW[MFV_STAGE_WORDS];
     __shared__ uint32_t sRec[GC_MF_TILE];
+    __shared__ uint8_t sExt[HALF ? GC_MF_TILE : 4u];              // MF_HALF: bytes in front of a listed position that its match covers as well
     __shared__ uint32_t sStart[GC_MF_PARTS], sLocal[GC_MF_PARTS + 1u];
     __shared__ uint32_t sWaveTot[GC_MF_PARTS / 64u];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
@@ -485,6 +534,31 @@ __device__ __forceinline__ void mf_verify_body(const uint8_t* __restrict__ src, 
     const uint32_t nBlk = (uint32_t)((srcSize - blockBase) < GC_ZSTD_BLOCK_MAX ? (srcSize - blockBase) : GC_ZSTD_BLOCK_MAX);
     const uint32_t pTile = (uint32_t)(T.tileStart - blockBase);
     const uint32_t wTile = (uint32_t)(T.tileStart - T.frameStart);
+    // unlisted positions: byte runs match at distance 1, the tail of the frame does not match at all.  (MF_HALF: first, so that the
+    // backward extension below finds every record that is not its own in place; odd positions without a run start out empty.)
+    auto unlisted = [&]() {
+        for (uint32_t q = t; q < T.len; q += MFV_T) {
+            const uint64_t x = mf_lds_ld64(sW, q + MF_STAGE_PAD);
+            const bool run = T.tileStart + q > T.frameStart && ((x << 8) | (uint64_t)mf_lds_byte(sW, q + MF_STAGE_PAD - 1u)) == x;
+            const bool windowed = T.tileStart + q + GC_MATCH_CAP + 16u <= T.frameEnd;
+            if (HALF) sExt[q] = 0;
+            if (windowed && !run) { if (HALF) sRec[q] = 0u; continue; }      // listed (MF_HALF: or not; a listed position overwrites this)
+            const uint32_t p = pTile + q;
+            uint32_t len = 0;
+            if (run && windowed && p + 8u <= nBlk) {              // both sides of the compare lie in the staged tile
+                const uint32_t maxLen = (nBlk - p) < GC_MATCH_CAP ? (nBlk - p) : GC_MATCH_CAP;
+                while (len < maxLen) {
+                    const uint32_t more = lz_cmp16(mf_lds_ld16(sW, q + MF_STAGE_PAD + len), mf_lds_ld16(sW, q + MF_STAGE_PAD - 1u + len));
+                    len += more;
+                    if (more < 16u) break;
+                }
+                if (len > maxLen) len = maxLen;
+                if (len < GC_MIN_MATCH) len = 0;
+            }
+            sRec[q] = len ? ((1u << 8) | len) : 0u;
+        }
+    };
+    if (HALF) { unlisted(); __syncthreads(); }
     // listed positions, MFV_B per thread and round, stage by stage over small arrays so that the entry loads, then the long
     // candidates, then the short candidates that are still needed are in flight together
     for (uint32_t j0 = t; j0 < nEnt; j0 += MFV_T * MFV_B) {
@@ -499,6 +573,7 @@ __device__ __forceinline__ void mf_verify_body(const uint8_t* __restrict__ src, 
             e[k] = E[sStart[lo] + (jj - sLocal[lo])];
         }
         uint32_t q[MFV_B], cS[MFV_B], maxLen[MFV_B], bestLen[MFV_B], bestC[MFV_B];
+        uint32_t bestExt[MFV_B];
         LzW16 cw[MFV_B];
 #pragma unroll
         for (uint32_t k = 0; k < MFV_B; k++) {                    // long candidates
@@ -510,23 +585,27 @@ __device__ __forceinline__ void mf_verify_body(const uint8_t* __restrict__ src, 
             maxLen[k] = can ? ((nBlk - p) < GC_MATCH_CAP ? (nBlk - p) : GC_MATCH_CAP) : 0u;
             if (cS[k] == cL) cS[k] = 0;
             bestC[k] = (can && cL) ? cL : 0u;
-            if (bestC[k]) cw[k] = lz_ld16(wsrc, bestC[k] - 1u);
+            bestExt[k] = 0;
+            if (HALF) { if (bestC[k] <= MFV_BACK) bestC[k] = 0; if (cS[k] <= MFV_BACK) cS[k] = 0; }      // (a candidate at the very frame start has no bytes in front of it)
+            if (bestC[k]) cw[k] = lz_ld16(wsrc, bestC[k] - 1u - (HALF ? MFV_BACK : 0u));
         }
 #pragma unroll
         for (uint32_t k = 0; k < MFV_B; k++) {
-            bestLen[k] = bestC[k] ? mfv_len16(mf_lds_ld16(sW, q[k] + MF_STAGE_PAD), cw[k], maxLen[k], MINLEN) : 0u;
+            if (HALF) { uint32_t x = 0; bestLen[k] = bestC[k] ? mfv_len13(mf_lds_ld16(sW, q[k] + MF_STAGE_PAD - MFV_BACK), cw[k], maxLen[k], x) : 0u; bestExt[k] = x; }
+            else bestLen[k] = bestC[k] ? mfv_len16(mf_lds_ld16(sW, q[k] + MF_STAGE_PAD), cw[k], maxLen[k], MINLEN) : 0u;
             if (bestLen[k] >= LONGLEN || maxLen[k] == 0u) cS[k] = 0;  // verified long candidate: the short one is not needed
-            if (cS[k]) cw[k] = lz_ld16(wsrc, cS[k] - 1u);
+            if (cS[k]) cw[k] = lz_ld16(wsrc, cS[k] - 1u - (HALF ? MFV_BACK : 0u));
         }
 #pragma unroll
         for (uint32_t k = 0; k < MFV_B; k++) {
             const uint32_t pw = wTile + q[k];
             if (cS[k]) {
-                const uint32_t len = mfv_len16(mf_lds_ld16(sW, q[k] + MF_STAGE_PAD), cw[k], maxLen[k], MINLEN);
-                if (len && (bestLen[k] == 0u || lz_gain(len, pw - (cS[k] - 1u)) > lz_gain(bestLen[k], pw - (bestC[k] - 1u)))) { bestLen[k] = len; bestC[k] = cS[k]; }
+                uint32_t x = 0;
+                const uint32_t len = HALF ? mfv_len13(mf_lds_ld16(sW, q[k] + MF_STAGE_PAD - MFV_BACK), cw[k], maxLen[k], x) : mfv_len16(mf_lds_ld16(sW, q[k] + MF_STAGE_PAD), cw[k], maxLen[k], MINLEN);
+                if (len && (bestLen[k] == 0u || lz_gain(len, pw - (cS[k] - 1u)) > lz_gain(bestLen[k], pw - (bestC[k] - 1u)))) { bestLen[k] = len; bestC[k] = cS[k]; bestExt[k] = x; }
             }
             uint32_t len = bestLen[k];
-            while (len >= 16u && (len & 15u) == 0u && len < maxLen[k]) {      // saturated: extend 16 bytes per round (own side from LDS)
+            while ((HALF ? (len & 15u) == 13u : (len >= 16u && (len & 15u) == 0u)) && len < maxLen[k]) {      // saturated: extend 16 bytes per round (own side from LDS)
                 const uint32_t more = lz_cmp16(mf_lds_ld16(sW, q[k] + MF_STAGE_PAD + len), lz_ld16(wsrc, (uint64_t)(bestC[k] - 1u) + len));
                 len += more;
                 if (len > maxLen[k]) len = maxLen[k];
@@ -534,30 +613,27 @@ __device__ __forceinline__ void mf_verify_body(const uint8_t* __restrict__ src, 
             }
             if (j0 + k * MFV_T < nEnt) {
                 const uint32_t nr = len ? (((pw - (bestC[k] - 1u)) << 8) | len) : 0u;
+                if (HALF && nr != 0u) sExt[q[k]] = (uint8_t)bestExt[k];
                 if (!FAR) sRec[q[k]] = nr;
                 else if (nr) { const uint32_t old = sRec[q[k]]; if (old == 0u || lz_gain(len, nr >> 8) > lz_gain(old & 0xFFu, old >> 8)) sRec[q[k]] = nr; }
             }
         }
     }
-    // unlisted positions: byte runs match at distance 1, the tail of the frame does not match at all
-    if (!FAR) for (uint32_t q = t; q < T.len; q += MFV_T) {
-        const uint64_t x = mf_lds_ld64(sW, q + MF_STAGE_PAD);
-        const bool run = T.tileStart + q > T.frameStart && ((x << 8) | (uint64_t)mf_lds_byte(sW, q + MF_STAGE_PAD - 1u)) == x;
-        const bool windowed = T.tileStart + q + GC_MATCH_CAP + 16u <= T.frameEnd;
-        if (windowed && !run) continue;                           // listed
-        const uint32_t p = pTile + q;
-        uint32_t len = 0;
-        if (run && windowed && p + 8u <= nBlk) {                  // both sides of the compare lie in the staged tile
-            const uint32_t maxLen = (nBlk - p) < GC_MATCH_CAP ? (nBlk - p) : GC_MATCH_CAP;
-            while (len < maxLen) {
-                const uint32_t more = lz_cmp16(mf_lds_ld16(sW, q + MF_STAGE_PAD + len), mf_lds_ld16(sW, q + MF_STAGE_PAD - 1u + len));
-                len += more;
-                if (more < 16u) break;
+    if (!FAR && !HALF) unlisted();
+    if (HALF) {
+        // positions without a record of their own take the match of the nearest listed position behind them that reaches back to them
+        // (only records of listed positions carry sExt > 0, and those are not written here: the result does not depend on thread order)
+        __syncthreads();
+        for (uint32_t x = t; x < T.len; x += MFV_T) {
+            if (sRec[x] != 0u) continue;
+            uint32_t nr = 0;
+#pragma unroll
+            for (uint32_t j = MFV_BACK; j >= 1u; j--) {
+                const uint32_t y = x + j;
+                if (y < T.len && sExt[y] >= j) { const uint32_t r = sRec[y], l = (r & 0xFFu) + j; nr = (r & ~0xFFu) | (l < GC_MATCH_CAP ? l : GC_MATCH_CAP); }   // (the nearest one is visited last and wins)
             }
-            if (len > maxLen) len = maxLen;
-            if (len < GC_MIN_MATCH) len = 0;
+            if (nr != 0u) sRec[x] = nr;
         }
-        sRec[q] = len ? ((1u << 8) | len) : 0u;
     }
     __syncthreads();
     // records out: 16 bytes per lane, full lines
@@ -566,19 +642,25 @@ __device__ __forceinline__ void mf_verify_body(const uint8_t* __restrict__ src, 
     for (uint32_t i = t; i < (T.len + 3u) / 4u; i += MFV_T) R4[i] = S4[i];
 }
 extern "C" __global__ void __launch_bounds__(MFV_T)
-gc_mf_verify_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
+MFK(gc_mf_verify_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
                     const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, uint32_t* __restrict__ rec)
 {
     mf_verify_body<MF_BASE>(src, srcSize, frameBlocks, nTiles, per, offs, ent, rec, rec);
 }
 extern "C" __global__ void __launch_bounds__(MFV_T)
-gc_mf_verify_far_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
+MFK(gc_mf_verify_half_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
+                         const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, uint32_t* __restrict__ rec)
+{
+    mf_verify_body<MF_HALF>(src, srcSize, frameBlocks, nTiles, per, offs, ent, rec, rec);
+}
+extern "C" __global__ void __launch_bounds__(MFV_T)
+MFK(gc_mf_verify_far_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
                         const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, uint32_t* __restrict__ rec)
 {
     mf_verify_body<MF_FAR>(src, srcSize, frameBlocks, nTiles, per, offs, ent, rec, rec);
 }
 extern "C" __global__ void __launch_bounds__(MFV_T)
-gc_mf_verify_short_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
+MFK(gc_mf_verify_short_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
                           const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, const uint32_t* __restrict__ recIn, uint32_t* __restrict__ recOut)
 {
     mf_verify_body<MF_SHORT>(src, srcSize, frameBlocks, nTiles, per, offs, ent, recIn, recOut);
@@ -592,7 +674,7 @@ gc_mf_verify_short_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uin
 // candidate with the best gain.  Reads the records of W5, writes a second record array (other threads still follow the old links).
 #define MFD_T 256u
 extern "C" __global__ void __launch_bounds__(MFD_T)
-gc_mf_deepen_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per, uint32_t depth,
+MFK(gc_mf_deepen_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per, uint32_t depth,
                     const uint32_t* __restrict__ recIn, uint32_t* __restrict__ recOut)
 {
     const uint32_t t = threadIdx.x;
@@ -633,6 +715,7 @@ gc_mf_deepen_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t 
     }
 }
 
+#ifndef GC_MF_FAST       // (W6 works on blocks, not tiles: one copy)
 // ------------------------------------------------------------------------------------------------ W6 parse
 // Greedy parse with one-step lazy evaluation: next(p) = p + len if the match at p is taken, else p + 1; the block's sequences
 // are the matches on the path from position 0.  The path is found without walking the block serially:
@@ -820,3 +903,6 @@ gc_mf_parse_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t n
         T[i] = (uint16_t)pr;
     }
 }
+#endif
+
+}   // namespace

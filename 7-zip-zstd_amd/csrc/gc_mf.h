@@ -29,10 +29,26 @@
 #include <stdint.h>
 #include "gc_common.h"
 
-#define GC_MF_TILE_LOG    14u
+// Two geometries, compiled as two sets of W1..W5 kernels from the one source (gc_lz_window.hip; gc_lz_window_p8.hip defines GC_MF_FAST
+// and includes it: the kernels get the suffix _p8):
+//   wide  1024 partitions, 16 KiB tiles: 2^22 + 2^21 table slots per frame -- the levels that search far (FLZMA2, zstd >= 7, brotli >= 5)
+//   fast   256 partitions,  8 KiB tiles: 2^20 + 2^19 slots per frame (still 8 x the reference's level-3 tables, clevels.h:31) -- zstd 3-6,
+//          brotli 3-4; W3..W5 take 20 % less time for 1.3 % more size (run r2_b: 1 GB of text, 34.3 -> 27.4 ms of finder)
+#define GC_MF_WIDE_TILE_LOG 14u
+#define GC_MF_WIDE_PART_LOG 10u
+#define GC_MF_WIDE_VERIFY_T 1024u
+#define GC_MF_FAST_TILE_LOG 13u
+#define GC_MF_FAST_PART_LOG 8u
+#define GC_MF_FAST_VERIFY_T 512u
+#ifdef GC_MF_FAST
+#define GC_MF_TILE_LOG    GC_MF_FAST_TILE_LOG
+#define GC_MF_PART_LOG    GC_MF_FAST_PART_LOG
+#else
+#define GC_MF_TILE_LOG    GC_MF_WIDE_TILE_LOG
+#define GC_MF_PART_LOG    GC_MF_WIDE_PART_LOG
+#endif
 #define GC_MF_TILE        (1u << GC_MF_TILE_LOG)          // positions per tile
 #define GC_MF_TILES_PER_BLOCK (GC_ZSTD_BLOCK_MAX >> GC_MF_TILE_LOG)
-#define GC_MF_PART_LOG    10u
 #define GC_MF_PARTS       (1u << GC_MF_PART_LOG)
 #define GC_MF_MAX_FRAME_BLOCKS 64u                        // 8 MiB: frame-relative positions fit 23 bits
 
@@ -47,11 +63,16 @@ typedef uint64_t GcMfEntry;
 #define GC_MF_SSLOT_LOG   11u                             // W4 short table: 2^11 slots per partition (2^19 per frame)
 
 #define GC_MF_PARSE_T     1024u                           // W6: threads per block
-#define GC_MF_VERIFY_T    1024u                           // W5: threads per tile (>= GC_MF_PARTS: one thread per run start)
+#ifdef GC_MF_FAST
+#define GC_MF_VERIFY_T    GC_MF_FAST_VERIFY_T
+#else
+#define GC_MF_VERIFY_T    GC_MF_WIDE_VERIFY_T             // W5: threads per tile (>= GC_MF_PARTS: one thread per run start)
+#endif
 #define GC_MF_LINK_SEGS   8u                              // W4: waves per (frame, partition): long lists are linked in segments
 
 // W5 -> W6: one 32-bit match record per input position, (offset << 8) | length; 0 = no match
 struct GcMfGeom {
+    uint32_t tileLog, partLog, verifyT;    // which geometry (wide / fast)
     uint32_t frameBlocks;     // F
     uint32_t nBlocks;
     uint32_t nFrames;
@@ -61,16 +82,18 @@ struct GcMfGeom {
     uint64_t cntWords;        // nFrames * (tilesPerFrame + 1) * GC_MF_PARTS
 };
 
-static inline GcMfGeom gc_mf_geom(uint64_t n, uint32_t frameBlocks)
+static inline GcMfGeom gc_mf_geom(uint64_t n, uint32_t frameBlocks, bool fast)
 {
     GcMfGeom g;
+    g.tileLog = fast ? GC_MF_FAST_TILE_LOG : GC_MF_WIDE_TILE_LOG; g.partLog = fast ? GC_MF_FAST_PART_LOG : GC_MF_WIDE_PART_LOG;
+    g.verifyT = fast ? GC_MF_FAST_VERIFY_T : GC_MF_WIDE_VERIFY_T;
     g.frameBlocks = frameBlocks;
     g.nBlocks = gc_num_blocks(n);
     g.nFrames = (g.nBlocks + frameBlocks - 1u) / frameBlocks;
-    g.tilesPerFrame = frameBlocks * GC_MF_TILES_PER_BLOCK;
+    g.tilesPerFrame = frameBlocks * (GC_ZSTD_BLOCK_MAX >> g.tileLog);
     g.nTiles = g.nFrames * g.tilesPerFrame;
     g.frameBytes = (uint64_t)frameBlocks * GC_ZSTD_BLOCK_MAX;
-    g.cntWords = (uint64_t)g.nFrames * (g.tilesPerFrame + 1u) * GC_MF_PARTS;
+    g.cntWords = (uint64_t)g.nFrames * (g.tilesPerFrame + 1u) << g.partLog;
     return g;
 }
 // cnt / offsets: [frame][tile 0..tilesPerFrame][partition]  (uint32, partition fastest).  After W2, row `tile` holds the
