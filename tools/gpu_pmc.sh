@@ -8,7 +8,7 @@ IFS=';' read -ra GROUPS_ARR <<< "${PMC_GROUPS:-$GROUPS_DEFAULT}"
 rm -f $OUT/pmc.md
 for ctr in "${GROUPS_ARR[@]}"; do
   name=$(echo $ctr | tr ' ' '_' | cut -c1-40)
-  timeout 600 rocprofv3 --pmc $ctr --kernel-trace -d $OUT/$name -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/$name.json 2> $OUT/$name.err
+  timeout 600 rocprofv3 --pmc $ctr --kernel-trace -d $OUT/$name -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-decode-check "$@" > $OUT/$name.json 2> $OUT/$name.err
   DB=$(find $OUT/$name -name '*.db' | head -1)
   if [ -n "$DB" ]; then echo "## $ctr" >> $OUT/pmc.md; python tools/rocpd_pmc.py $DB >> $OUT/pmc.md; echo >> $OUT/pmc.md; else echo "## $ctr: no result" >> $OUT/pmc.md; tail -3 $OUT/$name.err >> $OUT/pmc.md; fi
   rm -rf $OUT/$name
