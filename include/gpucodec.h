@@ -144,7 +144,7 @@ int         gc_multi_create(gc_multi** out, const int* devices, int nDevices, in
 void        gc_multi_destroy(gc_multi* m);
 int         gc_multi_workers(const gc_multi* m);
 const char* gc_multi_last_error(const gc_multi* m);
-/* default piece size for a codec and level: the multiple of the grain closest to 64 MiB from below (at least one grain) */
+/* default piece size for a codec and level: the multiple of the grain closest to 64 MiB (FLZMA2: 256 MiB) from below, at least one grain */
 size_t      gc_multi_piece_bytes(int codec, int level);
 /* pieceBytes == 0: gc_multi_piece_bytes(); otherwise rounded up to a multiple of the grain */
 int         gc_multi_compress_host(gc_multi* m, int codec, const void* src, size_t n, void* dst, size_t dstCapacity, int level, unsigned flags,

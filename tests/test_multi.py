@@ -32,7 +32,7 @@ def test_grain_and_piece_sizes(pkg, emu_lib_path):
         assert g == max(q, 1) * 8 * BLK                      # the brotli-mt chunk (C/zstdmt/brotli-mt_compress.c:115-118)
         p = lib.gc_multi_piece_bytes(pkg.CODEC_BROTLI, q)
         assert p % g == 0 and 0 < p <= 64 << 20
-    assert lib.gc_multi_piece_bytes(pkg.CODEC_ZSTD, 3) == 64 << 20
+    assert lib.gc_multi_piece_bytes(pkg.CODEC_ZSTD, 3) == 64 << 20 and lib.gc_multi_piece_bytes(pkg.CODEC_FLZMA2, 5) == 256 << 20
 
 
 @pytest.mark.parametrize("codec,level,piece,n", [("zstd", 1, BLK, 5 * BLK + 777), ("zstd", 3, 2 * BLK, 5 * BLK + 5),
@@ -82,7 +82,7 @@ def test_destination_too_small_is_reported(pkg, O, emu_lib_path, two_devices):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("codec,level,kind,n", [("zstd", 3, "text-zipf", 200_000_000), ("flzma2", 5, "silesia-like", 150_000_000),
+@pytest.mark.parametrize("codec,level,kind,n", [("zstd", 3, "text-zipf", 200_000_000), ("flzma2", 5, "silesia-like", 300_000_000),
                                                 ("brotli", 6, "web-text", 150_000_000)])
 def test_gpu_multi_pieces(pkg, O, graft, codec, level, kind, n):
     import torch

@@ -115,5 +115,5 @@ def test_gpu_real_host_archives_through_the_product_module(host_dir, graft, O):
     _check_listing(r.stdout, "lib7zgpucodec.so")
     _roundtrip(host_dir, env, O, "ZSTDGPU", 1, "ZSTD", 1048576)                       # config C1
     _roundtrip(host_dir, env, O, "ZSTDGPU", 3, "ZSTD", 150_000_000)                   # three pieces of 64 MiB over the host scheduler
-    _roundtrip(host_dir, env, O, "FLZMA2GPU", 5, "LZMA2", 80_000_000, "silesia-like")
+    _roundtrip(host_dir, env, O, "FLZMA2GPU", 5, "LZMA2", 80_000_000, "silesia-like")        # (one piece: FLZMA2 pieces are 256 MiB)
     _roundtrip(host_dir, env, O, "BROTLIGPU", 6, "BROTLI", 80_000_000, "web-text")
