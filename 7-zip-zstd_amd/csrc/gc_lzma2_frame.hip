@@ -6,9 +6,10 @@
 //   0x80 | reset<<5 | (usize-1)>>16, u16be (usize-1), u16be (csize-1), [props]   LZMA chunk; reset 0 = nothing (the chunk
 //                                          continues the model of the previous one, only the range coder restarts), 2 = state +
 //                                          props, 3 = state + props + dictionary.
-// Every 4 KiB rc chunk becomes one LZMA2 chunk.  The first chunk of a model segment resets the coder state (0xC0; 0xE0 for the
-// first chunk of the stream) and carries the props byte, the others continue (0x80).  A segment whose LZMA chunks would not be
-// smaller than the data is stored whole (one stored chunk per rc chunk); the segment behind it starts with a state reset like
+// A 4 KiB rc chunk -- or a group of neighbouring rc chunks of one model segment that L2 merged (GC_LZMA_RC_MERGE_WORDS: the leader
+// carries the group, the other members are marked absent) -- becomes one LZMA2 chunk.  The first chunk of a model segment resets the
+// coder state (0xC0; 0xE0 for the first chunk of the stream) and carries the props byte, the others continue (0x80).  A segment whose
+// LZMA chunks would not be smaller than the data is stored whole (one stored chunk per rc chunk); the segment behind it starts with a state reset like
 // every segment, which is also what the decoder demands after a dictionary-resetting stored chunk.
 #include "gc_common.h"
 #include "gc_device.h"
