@@ -761,7 +761,7 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     HIPCHK(c, hipMemsetAsync(c->brStage, 0, (size_t)nBlocks * GC_BR_STAGE_STRIDE, c->stream));
     uint32_t frameBlocks = brotli_frame_blocks(level, bpc);
     c->lazyDepth = level >= 7 ? 2u : 1u;
-    c->halfList = 0; c->mfFast = level <= 4 ? 1u : 0u;        // (far pass from quality 5)
+    c->halfList = 0; c->mfFast = level <= 6 ? 1u : 0u;        // (qualities 5-6 run the far pass on the fast geometry: 0.97-0.99 x the reference at 15 % less time than on the wide one)
     c->searchDepth = level >= 7 ? (level >= 10 ? 8u : 4u) : 0u;
     c->farPass = level >= 5 ? 1u : 0u; c->shortPass = 0;      // longer matches stand in for the context modelling / block splitting B1 lacks
     gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass);                                            // test hook
