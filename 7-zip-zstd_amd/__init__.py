@@ -27,7 +27,7 @@ EXPORTS = ["gc_device_count", "gc_ctx_create", "gc_ctx_destroy", "gc_last_error_
            "gc_flzma2_compress_bound", "gc_flzma2_dict_prop", "gc_flzma2_compress_device", "gc_flzma2_finish", "gc_flzma2_compress_host",
            "gc_flzma2_last_timing",
            "gc_brotli_compress_bound", "gc_brotli_compress_device", "gc_brotli_finish", "gc_brotli_compress_host", "gc_brotli_last_timing",
-           "gc_codec_grain", "gc_codec_compress_bound", "gc_host_begin", "gc_host_size", "gc_host_fetch", "gc_codec_compress_host",
+           "gc_ctx_set_option", "gc_codec_grain", "gc_codec_compress_bound", "gc_host_begin", "gc_host_size", "gc_host_fetch", "gc_codec_compress_host",
            "gc_host_alloc", "gc_host_free", "gc_multi_create", "gc_multi_destroy", "gc_multi_workers", "gc_multi_last_error",
            "gc_multi_piece_bytes", "gc_multi_compress_host"]
 
@@ -96,6 +96,8 @@ def load_library(path=None):
     lib.gc_brotli_last_timing.restype = C.c_int
     lib.gc_ctx_stream.argtypes = [C.c_void_p]
     lib.gc_ctx_stream.restype = C.c_void_p
+    lib.gc_ctx_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.gc_ctx_set_option.restype = C.c_int
     lib.gc_codec_grain.argtypes = [C.c_int, C.c_int]
     lib.gc_codec_grain.restype = C.c_size_t
     lib.gc_codec_compress_bound.argtypes = [C.c_int, C.c_size_t]
@@ -195,6 +197,11 @@ class _EncoderBase:
 
     def set_level(self, level):          # SetCoderProperties(kLevel)
         self.level = int(level)
+
+    OPT_ZSTD_SEEK_TABLE, OPT_BROTLI_PLAIN = 1, 2
+
+    def set_option(self, option, value=1):
+        self._check(self._lib.gc_ctx_set_option(self._ctx, int(option), int(value)), "gc_ctx_set_option")
 
     def stream(self):
         return self._lib.gc_ctx_stream(self._ctx)

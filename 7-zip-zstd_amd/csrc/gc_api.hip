@@ -31,7 +31,7 @@ extern "C" __global__ void gc_zstd_lz_kernel(const uint8_t*, uint64_t, GcSeqRaw*
 extern "C" __global__ void gc_zstd_huf_kernel(const uint8_t*, const GcBlockMeta*, uint8_t*, GcSectionInfo*);
 extern "C" __global__ void gc_zstd_seq_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t*, uint32_t*, uint8_t*, uint16_t*,
                                               uint8_t*, GcSectionInfo*, uint64_t, uint32_t, unsigned long long*);
-extern "C" __global__ void gc_zstd_plan_kernel(const GcSectionInfo*, uint32_t, uint64_t, uint64_t, uint32_t, GcFramePlan*, uint64_t*);
+extern "C" __global__ void gc_zstd_plan_kernel(const GcSectionInfo*, uint32_t, uint64_t, uint64_t, uint32_t, GcFramePlan*, uint64_t*, uint32_t);
 extern "C" __global__ void gc_zstd_emit_kernel(const uint8_t*, uint64_t, const uint8_t*, const uint8_t*, const GcSectionInfo*,
                                                const GcFramePlan*, const uint64_t*, uint32_t, uint32_t, uint8_t*);
 
@@ -78,10 +78,10 @@ extern "C" __global__ void gc_lzma2_emit_kernel(const uint8_t*, uint32_t, const 
                                                 uint32_t, const uint64_t*, uint8_t*);
 
 extern "C" __global__ void gc_brotli_block_kernel(const uint8_t*, uint64_t, const GcSeqRaw*, const uint8_t*, const GcBlockMeta*, uint64_t*, uint32_t*,
-                                                  uint32_t, uint32_t*, GcBrotliBlockInfo*);
+                                                  uint32_t, uint32_t, uint32_t*, GcBrotliBlockInfo*);
 extern "C" __global__ void gc_brotli_plan_kernel(const GcBrotliBlockInfo*, uint32_t, uint32_t, uint64_t, GcBrotliPlan*, uint64_t*);
 extern "C" __global__ void gc_brotli_emit_kernel(const uint8_t*, uint64_t, const uint8_t*, const GcBrotliBlockInfo*, const GcBrotliPlan*, uint32_t,
-                                                 uint32_t, const uint64_t*, uint8_t*);
+                                                 uint32_t, uint32_t, const uint64_t*, uint8_t*);
 
 struct gc_ctx {
     int device;
@@ -94,6 +94,7 @@ struct gc_ctx {
     uint32_t searchDepth;     // W5b: match links followed per position (0 = W5's two candidates only)
     uint32_t shortPass;       // third finder pass with 4- / 3-byte keys; its merged records feed the price-based parse only
     uint32_t farPass;         // second finder pass with 16- / 12-byte keys (longer matches), merged into the records by gain
+    uint32_t optSeekTable, optBrotliPlain;   // gc_ctx_set_option
     uint32_t mfFast;          // geometry of the windowed finder (gc_mf.h): 1 = 256 partitions / 8 KiB tiles, 0 = 1024 partitions / 16 KiB tiles
     uint32_t halfList;        // first finder pass over the even positions only, matches extended one byte backwards (zstd levels 3-5)
     uint32_t priceParse;      // W5s + W7: price-based parse on top of the greedy one (gc_lz_price.hip)
@@ -153,7 +154,7 @@ extern "C" int gc_device_count(void)
 extern "C" size_t gc_zstd_compress_bound(size_t n)
 {
     size_t nb = n ? (n + GC_ZSTD_BLOCK_MAX - 1) / GC_ZSTD_BLOCK_MAX : 1;
-    return n + nb * GC_FRAME_OVERHEAD + 16;
+    return n + nb * GC_FRAME_OVERHEAD + 16 + nb * 8 + 17;       // (+ the optional seek table: 8 bytes per frame, 17 of header and footer)
 }
 
 static void free_workspace(gc_ctx* c);
@@ -224,6 +225,15 @@ extern "C" void gc_ctx_destroy(gc_ctx* c)
 {
     if (!c) return;
     ctx_release(c);
+}
+
+extern "C" int gc_ctx_set_option(gc_ctx* c, int option, int value)
+{
+    if (!c) return GC_ERR_PARAM;
+    if (option == GC_OPT_ZSTD_SEEK_TABLE) c->optSeekTable = value != 0;
+    else if (option == GC_OPT_BROTLI_PLAIN) c->optBrotliPlain = value ? ((uint32_t)value & 7u) | 1u : 0u;     // bit 0 plain, bits 1 / 2: GC_BROTLI_NOT_FIRST / GC_BROTLI_NOT_LAST
+    else return GC_ERR_PARAM;
+    return GC_OK;
 }
 
 extern "C" const char* gc_last_error_message(const gc_ctx* c) { return c ? c->err : "no context"; }
@@ -509,9 +519,9 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev[4], 0));
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
-    GC_LAUNCH(gc_zstd_plan_kernel, 1, 1024, c->stream, (const GcSectionInfo*)c->info, nBlocks, (uint64_t)n, (uint64_t)dstCap, frameBlocks, c->plan, c->result);
+    GC_LAUNCH(gc_zstd_plan_kernel, 1, 1024, c->stream, (const GcSectionInfo*)c->info, nBlocks, (uint64_t)n, (uint64_t)dstCap, frameBlocks, c->plan, c->result, c->optSeekTable);
     HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
-    GC_LAUNCH(gc_zstd_emit_kernel, nBlocks, 256, c->stream, src, (uint64_t)n, (const uint8_t*)c->litSec, (const uint8_t*)c->seqSec,
+    GC_LAUNCH(gc_zstd_emit_kernel, nBlocks + (c->optSeekTable ? 1u : 0u), 256, c->stream, src, (uint64_t)n, (const uint8_t*)c->litSec, (const uint8_t*)c->seqSec,
               (const GcSectionInfo*)c->info, (const GcFramePlan*)c->plan, (const uint64_t*)c->result, nBlocks, frameBlocks, (uint8_t*)d_dst);
     HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
     HIPCHK(c, hipGetLastError());
@@ -746,9 +756,10 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     if (n == 0) {
         // what brotli-mt writes for an empty input: one frame holding the 1-byte empty brotli stream (WBITS=16, ISLAST, ISLASTEMPTY)
         static const uint8_t empty[17] = { 0x50, 0x2A, 0x4D, 0x18, 8, 0, 0, 0, 1, 0, 0, 0, 0x42, 0x52, 1, 0, 0x06 };
-        if (dstCap < sizeof(empty)) return GC_ERR_DST_SMALL;
-        HIPCHK(c, hipMemcpyAsync(d_dst, empty, sizeof(empty), hipMemcpyHostToDevice, c->stream));
-        c->hostResult[0] = sizeof(empty); c->hostResult[1] = 0;
+        const size_t skip = c->optBrotliPlain ? 16u : 0u, sz = (c->optBrotliPlain & 6u) ? 0u : sizeof(empty) - skip;       // plain stream: just the empty brotli stream (nothing for an inner piece)
+        if (dstCap < sz) return GC_ERR_DST_SMALL;
+        HIPCHK(c, hipMemcpyAsync(d_dst, empty + skip, sz, hipMemcpyHostToDevice, c->stream));
+        c->hostResult[0] = sz; c->hostResult[1] = 0;
         HIPCHK(c, hipMemcpyAsync(c->result, c->hostResult, 16, hipMemcpyHostToDevice, c->stream));
         c->pending = true;
         return GC_OK;
@@ -756,10 +767,11 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     const uint32_t nBlocks = gc_num_blocks(n);
     int rc = ensure_workspace(c, nBlocks);
     if (rc != GC_OK) return rc;
-    const uint32_t bpc = brotli_blocks_per_chunk(level);
+    const uint32_t bpcFinder = brotli_blocks_per_chunk(level);
+    const uint32_t bpc = c->optBrotliPlain ? 0xFFFFFFFFu : bpcFinder;        // plain: one stream (B1 writes the stream header once, B2 / B3 no frame headers)
     const uint8_t* src = (const uint8_t*)d_src;
     HIPCHK(c, hipMemsetAsync(c->brStage, 0, (size_t)nBlocks * GC_BR_STAGE_STRIDE, c->stream));
-    uint32_t frameBlocks = brotli_frame_blocks(level, bpc);
+    uint32_t frameBlocks = brotli_frame_blocks(level, bpcFinder);
     c->lazyDepth = level >= 7 ? 2u : 1u;
     c->halfList = 0; c->mfFast = level <= 6 ? 1u : 0u;        // (qualities 5-6 run the far pass on the fast geometry: 0.97-0.99 x the reference at 15 % less time than on the wide one)
     c->searchDepth = level >= 7 ? (level >= 10 ? 8u : 4u) : 0u;
@@ -776,12 +788,12 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     if (rc != GC_OK) return rc;
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
     GC_LAUNCH(gc_brotli_block_kernel, nBlocks, 256, c->stream, src, (uint64_t)n, (const GcSeqRaw*)c->seqRaw, (const uint8_t*)c->lit,
-              (const GcBlockMeta*)c->meta, c->seqPacked, c->seqOff, bpc, (uint32_t*)c->brStage, c->brInfo);
+              (const GcBlockMeta*)c->meta, c->seqPacked, c->seqOff, bpc, c->optBrotliPlain, (uint32_t*)c->brStage, c->brInfo);
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     GC_LAUNCH(gc_brotli_plan_kernel, 1, 1024, c->stream, (const GcBrotliBlockInfo*)c->brInfo, nBlocks, bpc, (uint64_t)dstCap, c->brPlan, c->result);
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     GC_LAUNCH(gc_brotli_emit_kernel, nBlocks, 256, c->stream, src, (uint64_t)n, (const uint8_t*)c->brStage, (const GcBrotliBlockInfo*)c->brInfo,
-              (const GcBrotliPlan*)c->brPlan, nBlocks, bpc, (const uint64_t*)c->result, (uint8_t*)d_dst);
+              (const GcBrotliPlan*)c->brPlan, nBlocks, bpc, c->optBrotliPlain, (const uint64_t*)c->result, (uint8_t*)d_dst);
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
     HIPCHK(c, hipGetLastError());
     c->pending = true; c->timed = true; c->lastCodec = 2;
@@ -821,6 +833,13 @@ extern "C" int gc_host_begin(gc_ctx* c, int codec, const void* src, size_t n, in
     if (n > c->dInCap) { hipFree(c->dIn); c->dIn = nullptr; c->dInCap = 0; if (hipMalloc((void**)&c->dIn, n + 64) != hipSuccess) return GC_ERR_NOMEM; c->dInCap = n; }
     if (bound > c->dOutCap) { hipFree(c->dOut); c->dOut = nullptr; c->dOutCap = 0; if (hipMalloc((void**)&c->dOut, bound) != hipSuccess) return GC_ERR_NOMEM; c->dOutCap = bound; }
     if (n) HIPCHK(c, hipMemcpyAsync(c->dIn, src, n, hipMemcpyHostToDevice, c->stream));
+    if (codec == GC_CODEC_BROTLI && (flags & GC_BROTLI_PLAIN)) {      // per-call form of GC_OPT_BROTLI_PLAIN (pieces of one stream); the context's own option comes back afterwards
+        const uint32_t keep = c->optBrotliPlain;
+        c->optBrotliPlain = (flags & 7u) | 1u;
+        const int rc = gc_brotli_compress_device(c, c->dIn, n, c->dOut, c->dOutCap, level);
+        c->optBrotliPlain = keep;
+        return rc;
+    }
     return codec == GC_CODEC_ZSTD ? gc_zstd_compress_device(c, c->dIn, n, c->dOut, c->dOutCap, level)
          : codec == GC_CODEC_FLZMA2 ? gc_flzma2_compress_device(c, c->dIn, n, c->dOut, c->dOutCap, level, flags)
                                     : gc_brotli_compress_device(c, c->dIn, n, c->dOut, c->dOutCap, level);

@@ -267,8 +267,9 @@ gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
                        const uint8_t* __restrict__ lit, const GcBlockMeta* __restrict__ meta,
                        uint64_t* __restrict__ seqPacked /* scratch: GC_MAX_SEQ_PER_BLOCK per block */,
                        uint32_t* __restrict__ seqLitStart /* scratch: GC_MAX_SEQ_PER_BLOCK per block */,
-                       uint32_t blocksPerChunk, uint32_t* __restrict__ stage /* zeroed, GC_BR_STAGE_STRIDE bytes per block */,
-                       GcBrotliBlockInfo* __restrict__ info)
+                       uint32_t blocksPerChunk /* 0xFFFFFFFF: ONE plain stream (no brotli-mt chunks) */, uint32_t plainFlags /* plain stream: bit 1 = this call is
+                       not its first piece (no stream header), bit 2 = not its last (no closing meta-block) */,
+                       uint32_t* __restrict__ stage /* zeroed, GC_BR_STAGE_STRIDE bytes per block */, GcBrotliBlockInfo* __restrict__ info)
 {
     __shared__ uint32_t hLit[256], hCmd[704], hDist[64];
     __shared__ uint8_t  dLit[256], dCmd[704], dDist[64];
@@ -289,8 +290,9 @@ gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
     uint64_t* P = seqPacked + (uint64_t)b * GC_MAX_SEQ_PER_BLOCK;
     uint32_t* LS = seqLitStart + (uint64_t)b * GC_MAX_SEQ_PER_BLOCK;
     uint32_t* out = stage + (uint64_t)b * (GC_BR_STAGE_STRIDE / 4u);
-    const bool firstInChunk = (b % blocksPerChunk) == 0u;
-    const bool lastInChunk = ((b + 1u) % blocksPerChunk) == 0u || blockBase + blockLen >= srcSize;
+    const bool plain = blocksPerChunk == 0xFFFFFFFFu;
+    const bool firstInChunk = plain ? (b == 0u && !(plainFlags & 2u)) : (b % blocksPerChunk) == 0u;
+    const bool lastInChunk = plain ? (blockBase + blockLen >= srcSize && !(plainFlags & 4u)) : (((b + 1u) % blocksPerChunk) == 0u || blockBase + blockLen >= srcSize);
 
     for (uint32_t i = t; i < 256u; i += BR_T) hLit[i] = 0;
     for (uint32_t i = t; i < 704u; i += BR_T) hCmd[i] = 0;
@@ -505,16 +507,17 @@ gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
 // plan: one workgroup; exclusive scan of block sizes with a 16-byte brotli-mt frame header in front of every chunk
 // (C/zstdmt/brotli-mt_compress.c:299-321: 0x184D2A50, 8, compressed size, 0x5242, hint = 64 KiB units to allocate)
 extern "C" __global__ void __launch_bounds__(1024)
-gc_brotli_plan_kernel(const GcBrotliBlockInfo* __restrict__ info, uint32_t nBlocks, uint32_t blocksPerChunk, uint64_t dstCap,
-                      GcBrotliPlan* __restrict__ plan, uint64_t* __restrict__ result)
+gc_brotli_plan_kernel(const GcBrotliBlockInfo* __restrict__ info, uint32_t nBlocks, uint32_t blocksPerChunk /* 0xFFFFFFFF: plain stream, no brotli-mt frame headers */,
+                      uint64_t dstCap, GcBrotliPlan* __restrict__ plan, uint64_t* __restrict__ result)
 {
+    const bool framed = blocksPerChunk != 0xFFFFFFFFu;
     __shared__ uint32_t sWave[16];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     uint64_t carry = 0;
     for (uint32_t tb = 0; tb < nBlocks; tb += 1024u) {
         const uint32_t b = tb + t;
         uint32_t size = 0;
-        if (b < nBlocks) size = info[b].size + ((b % blocksPerChunk) == 0u ? 16u : 0u);
+        if (b < nBlocks) size = info[b].size + ((framed && (b % blocksPerChunk) == 0u) ? 16u : 0u);
         const uint32_t incl = gc_wave_incl_sum(size);
         if (lane == 63u) sWave[wave] = incl;
         __syncthreads();
@@ -531,7 +534,7 @@ gc_brotli_plan_kernel(const GcBrotliBlockInfo* __restrict__ info, uint32_t nBloc
 extern "C" __global__ void __launch_bounds__(256)
 gc_brotli_emit_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const uint8_t* __restrict__ stage,
                       const GcBrotliBlockInfo* __restrict__ info, const GcBrotliPlan* __restrict__ plan, uint32_t nBlocks,
-                      uint32_t blocksPerChunk, const uint64_t* __restrict__ result, uint8_t* __restrict__ dst)
+                      uint32_t blocksPerChunk, uint32_t plainFlags, const uint64_t* __restrict__ result, uint8_t* __restrict__ dst)
 {
     if (result[1]) return;
     const uint32_t t = threadIdx.x, b = blockIdx.x;
@@ -539,8 +542,8 @@ gc_brotli_emit_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
     const uint32_t blockLen = (uint32_t)((srcSize - blockBase) < GC_ZSTD_BLOCK_MAX ? (srcSize - blockBase) : GC_ZSTD_BLOCK_MAX);
     const GcBrotliBlockInfo bi = info[b];
     uint8_t* o = dst + plan[b].off;
-    const bool first = (b % blocksPerChunk) == 0u;
-    if (first) {
+    const bool first = blocksPerChunk == 0xFFFFFFFFu ? (b == 0u && !(plainFlags & 2u)) : (b % blocksPerChunk) == 0u;    // first block of a stream: its stored form carries the stream header
+    if (first && blocksPerChunk != 0xFFFFFFFFu) {                // ... and, in brotli-mt framing, the chunk's frame header goes in front
         if (t == 0) {
             // chunk extent: up to the next chunk's first block (or the end of the stream)
             const uint32_t nb = b + blocksPerChunk < nBlocks ? b + blocksPerChunk : nBlocks;

@@ -108,7 +108,9 @@ void worker(Job& j, size_t w)
         if (!m->ctx[w]) { const int rc = gc_ctx_create(&m->ctx[w], m->workerDevice[w]); if (rc != GC_OK) { m->ctx[w] = nullptr; job_fail(j, k, rc, "gc_ctx_create", nullptr); continue; } }
         gc_ctx* c = m->ctx[w];
         const size_t off = k * j.piece, len = (j.n - off) < j.piece ? (j.n - off) : j.piece;
-        const unsigned flags = j.codec == GC_CODEC_FLZMA2 ? (j.flags | GC_FLZMA2_NO_END_MARK) : j.flags;    // one end marker for the whole stream, written by the caller below
+        unsigned flags = j.codec == GC_CODEC_FLZMA2 ? (j.flags | GC_FLZMA2_NO_END_MARK) : j.flags;    // one end marker for the whole stream, written by the caller below
+        if (j.codec == GC_CODEC_BROTLI && (j.flags & GC_BROTLI_PLAIN))                                  // pieces of ONE brotli stream: header in the first, closing meta-block in the last
+            flags |= (k > 0 ? GC_BROTLI_NOT_FIRST : 0u) | (k + 1 < j.nPieces ? GC_BROTLI_NOT_LAST : 0u);
         int rc = gc_host_begin(c, j.codec, j.src + off, len, j.level, flags);
         if (rc != GC_OK) { job_fail(j, k, rc, "gc_host_begin", c); continue; }
         size_t sz = 0;

@@ -26,7 +26,8 @@ __device__ __forceinline__ uint32_t frame_len_of(uint32_t b, uint32_t frameBlock
 // K4: one workgroup; exclusive scan of frame sizes
 extern "C" __global__ void __launch_bounds__(1024)
 gc_zstd_plan_kernel(const GcSectionInfo* __restrict__ info, uint32_t nBlocks, uint64_t srcSize, uint64_t dstCap, uint32_t frameBlocks,
-                    GcFramePlan* __restrict__ plan, uint64_t* __restrict__ result /* [0]=total bytes, [1]=error */)
+                    GcFramePlan* __restrict__ plan, uint64_t* __restrict__ result /* [0]=total bytes, [1]=error */,
+                    uint32_t seekTable /* 1: a seek table (skippable frame) follows the last frame */)
 {
     __shared__ uint32_t sWave[16];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
@@ -52,10 +53,16 @@ gc_zstd_plan_kernel(const GcSectionInfo* __restrict__ info, uint32_t nBlocks, ui
         if (b < nBlocks) { GcFramePlan p; p.off = carry + before + incl - size; p.size = size; p.compressed = comp; plan[b] = p; }
         carry += all;
     }
-    if (t == 0) { result[0] = carry; result[1] = carry > dstCap ? 1u : 0u; }
+    if (t == 0) {
+        const uint32_t nFrames = (nBlocks + frameBlocks - 1u) / frameBlocks;
+        const uint64_t total = carry + (seekTable ? 8ull + 8ull * nFrames + 9ull : 0ull);
+        result[0] = total; result[1] = total > dstCap ? 1u : 0u;
+    }
 }
 
-// K5: one workgroup per block writes its frame
+// K5: one workgroup per block writes its frame; with a seek table one more workgroup (blockIdx == nBlocks) writes it:
+//   0x184D2A5E | size of the rest | per frame { compressed size, decompressed size } | number of frames | descriptor 0 | 0x8F92EAB1
+// (zstd seekable format, contrib/seekable_format/zstd_seekable_compression_format.md; little endian, no per-frame checksums)
 extern "C" __global__ void __launch_bounds__(FRAME_T)
 gc_zstd_emit_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const uint8_t* __restrict__ litSec,
                     const uint8_t* __restrict__ seqSec, const GcSectionInfo* __restrict__ info,
@@ -64,6 +71,21 @@ gc_zstd_emit_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const uin
 {
     if (result[1]) return;                       // output buffer too small: write nothing
     const uint32_t t = threadIdx.x, b = blockIdx.x;
+    if (b == nBlocks) {                          // the seek table (only launched when one is wanted)
+        const uint32_t nFrames = (nBlocks + frameBlocks - 1u) / frameBlocks;
+        const uint64_t tableBytes = 8ull + 8ull * nFrames + 9ull, framesEnd = result[0] - tableBytes;
+        uint8_t* o = dst + framesEnd;
+        auto put32 = [](uint8_t* q, uint32_t v) { q[0] = (uint8_t)v; q[1] = (uint8_t)(v >> 8); q[2] = (uint8_t)(v >> 16); q[3] = (uint8_t)(v >> 24); };
+        if (t == 0) { put32(o, 0x184D2A5Eu); put32(o + 4, (uint32_t)(tableBytes - 8ull)); }
+        for (uint32_t f = t; f < nFrames; f += FRAME_T) {
+            const uint32_t b0 = f * frameBlocks, b1 = b0 + frameBlocks;
+            const uint64_t end = b1 < nBlocks ? plan[b1].off : framesEnd;
+            put32(o + 8u + 8ull * f, (uint32_t)(end - plan[b0].off));
+            put32(o + 12u + 8ull * f, frame_len_of(b0, frameBlocks, srcSize));
+        }
+        if (t == 0) { uint8_t* ft = o + 8u + 8ull * nFrames; put32(ft, nFrames); ft[4] = 0; put32(ft + 5, 0x8F92EAB1u); }
+        return;
+    }
     const uint64_t base = (uint64_t)b * GC_ZSTD_BLOCK_MAX;
     const uint32_t blockLen = (uint32_t)((srcSize - base) < GC_ZSTD_BLOCK_MAX ? (srcSize - base) : GC_ZSTD_BLOCK_MAX);
     const GcFramePlan p = plan[b];

@@ -83,6 +83,7 @@ class CGpuEncoder final : public ICompressCoder, public ICompressSetCoderMt, pub
     int level_;                                       // ZSTD_CLEVEL_DEFAULT 3 / FL2 default 5 (Lzma2Encoder.cpp:178-239 maps -mx to it)
     uint8_t props_[5] = { 1, 5, 3, 0, 0 };            // ZSTD: CProps{major, minor, level, reserved[2]}  ZstdEncoder.h:17-32
     uint64_t expected_ = 0;
+    bool plainBrotli_ = false;
     int codec() const { return kind_ == KIND_ZSTD ? GC_CODEC_ZSTD : (kind_ == KIND_FLZMA2 ? GC_CODEC_FLZMA2 : GC_CODEC_BROTLI); }
 
 public:
@@ -106,7 +107,9 @@ public:
     ULONG AddRef() override { return ++refs_; }
     ULONG Release() override { if (--refs_ != 0) return refs_; delete this; return 0; }      // non-atomic like MyCom.h:380-390
 
-    HRESULT SetNumberOfThreads(uint32_t) override { return S_OK; }    // the workers are GPU contexts; their number follows the devices
+    // the workers are GPU contexts, their number follows the devices; BROTLI with "0 threads" = a plain .br stream without brotli-mt
+    // framing, which is how the reference's bare-file handler asks for it (BrotliHandler.cpp:286-291, BrotliEncoder.cpp:166-177)
+    HRESULT SetNumberOfThreads(uint32_t n) override { plainBrotli_ = kind_ == KIND_BROTLI && (int)n < 1; return S_OK; }
 
     HRESULT SetCoderProperties(const PROPID* ids, const PROPVARIANT* props, uint32_t n) override
     {
@@ -161,13 +164,24 @@ public:
             if (r != S_OK) return r;
             if (got == 0 && (totalIn != 0 || kind_ == KIND_FLZMA2)) break;
             size_t produced = 0;
-            const int rc = gc_multi_compress_host(multi_, codec(), inBuf_, got, outBuf_, outCap_, level_, kind_ == KIND_FLZMA2 ? GC_FLZMA2_NO_END_MARK : 0u, 0, &produced);
+            // FLZMA2: one end marker behind the last batch; plain brotli: stream header in the first batch, the closing meta-block behind the last
+            const unsigned fl = kind_ == KIND_FLZMA2 ? GC_FLZMA2_NO_END_MARK
+                              : plainBrotli_ ? (GC_BROTLI_PLAIN | GC_BROTLI_NOT_LAST | (totalIn != 0 ? GC_BROTLI_NOT_FIRST : 0u)) : 0u;
+            if (plainBrotli_ && got == 0) break;
+            const int rc = gc_multi_compress_host(multi_, codec(), inBuf_, got, outBuf_, outCap_, level_, fl, 0, &produced);
             if (rc != GC_OK) return hresult_of(rc);
             r = write_all(out, outBuf_, produced);
             if (r != S_OK) return r;
             totalIn += got; totalOut += produced;
             if (progress) { r = progress->SetRatioInfo(&totalIn, &totalOut); if (r != S_OK) return r; }
             if (got < inCap_) break;      // short read = end of stream
+        }
+        if (plainBrotli_) {
+            const uint8_t closeStream = totalIn != 0 ? 0x03 : 0x06;      // ISLAST + ISLASTEMPTY (an empty input: WBITS 16 + the same)
+            HRESULT r = write_all(out, &closeStream, 1);
+            if (r != S_OK) return r;
+            totalOut += 1;
+            if (progress) { r = progress->SetRatioInfo(&totalIn, &totalOut); if (r != S_OK) return r; }
         }
         if (kind_ == KIND_FLZMA2) {
             const uint8_t endMark = 0x00;

@@ -150,6 +150,22 @@ size_t      gc_multi_piece_bytes(int codec, int level);
 int         gc_multi_compress_host(gc_multi* m, int codec, const void* src, size_t n, void* dst, size_t dstCapacity, int level, unsigned flags,
                                    size_t pieceBytes, size_t* compressedSize);
 
+/* ---- options for the bare-file handlers (CPP/7zip/Archive/ZstdHandler.cpp:273-280, BrotliHandler.cpp:286-291)
+ *   GC_OPT_ZSTD_SEEK_TABLE  append a seek table -- a skippable frame (magic 0x184D2A5E) listing the compressed and decompressed size of every
+ *                           zstd frame, footer magic 0x8F92EAB1: the "zstd seekable format" of zstd's contrib/seekable_format, which the
+ *                           reference tree does not vendor -- so that a decoder can go frame-parallel without walking the stream.  Every zstd
+ *                           decoder skips it (ZstdDecoder.cpp:145-158 accepts skippable frames).
+ *   GC_OPT_BROTLI_PLAIN     ONE brotli stream without the brotli-mt frame headers: what BROTLIMT_compressCCtx writes for threads == 0
+ *                           (C/zstdmt/brotli-mt_compress.c:462-466) and what a bare .br file is.  Copies still stay inside their chunk.
+ * Options hold for the following calls of the context (0 = off, the default). */
+#define GC_OPT_ZSTD_SEEK_TABLE 1
+#define GC_OPT_BROTLI_PLAIN    2
+/* flags of gc_host_begin / gc_codec_compress_host / gc_multi_compress_host for BROTLI: the call is one piece of ONE plain stream */
+#define GC_BROTLI_PLAIN     1u
+#define GC_BROTLI_NOT_FIRST 2u      /* ... and not its first piece: no stream header */
+#define GC_BROTLI_NOT_LAST  4u      /* ... and not its last piece: no closing (ISLAST) meta-block */
+int         gc_ctx_set_option(gc_ctx* ctx, int option, int value);
+
 /* raw stream handle (hipStream_t) so callers can order their own work against the context */
 void*       gc_ctx_stream(gc_ctx* ctx);
 

@@ -109,10 +109,12 @@ int main(int argc, char** argv)
     if (coder->QueryInterface(IID_ICompressSetCoderPropertiesOpt, (void**)&opt) != S_OK) return 11;
     if (coder->QueryInterface(IID_IUnknown, (void**)&unk) != S_OK) return 11;
     if (coder->QueryInterface(IID_ISequentialOutStream, &none) != E_NOINTERFACE) return 11;
-    mt->SetNumberOfThreads(8);
+    // "threads0" as the last argument: what the reference's bare .br handler does with its encoder (BrotliHandler.cpp:286-291) -- a plain stream
+    const bool threads0 = std::string(argv[argc - 1]) == "threads0";
+    mt->SetNumberOfThreads(threads0 ? 0 : 8);
     PROPID ids[2] = { NCoderPropID::kLevel, NCoderPropID::kNumThreads }; PROPVARIANT pv[2]; memset(pv, 0, sizeof(pv));
     pv[0].vt = VT_UI4; pv[0].ulVal = (uint32_t)atoi(argv[4]); pv[1].vt = VT_UI4; pv[1].ulVal = 8;
-    if (setProps->SetCoderProperties(ids, pv, 2) != S_OK) return 12;
+    if (setProps->SetCoderProperties(ids, pv, threads0 ? 1 : 2) != S_OK) return 12;
     FileIn in; in.f = fopen(argv[5], "rb"); FileOut out; out.f = fopen(argv[6], "wb");
     if (!in.f || !out.f) { fprintf(stderr, "file open\n"); return 13; }
     { fseek(in.f, 0, SEEK_END); uint64_t sz = (uint64_t)ftell(in.f); fseek(in.f, 0, SEEK_SET);

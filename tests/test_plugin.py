@@ -111,3 +111,17 @@ def test_product_plugin_on_gpu(O, graft, tmp_path):
     c = np.fromfile(dst, dtype=np.uint8)
     dec = O.ref_zstd_decompress(c, n) if O.ref("zstd") is not None else O.port_zstd_decompress(c, n)
     assert np.array_equal(dec, x)
+
+
+@pytest.mark.parametrize("n", [0, 7, 3 * BLK + 99])
+def test_brotli_plain_stream_through_com_surface(O, emu_module, tmp_path, n):
+    """SetNumberOfThreads(0) on the BROTLI coder = a bare .br stream (no brotli-mt frames), as the reference's BrotliHandler asks of its encoder."""
+    if O.ref("brotli") is None:
+        pytest.skip("oracle/_ref not built")
+    x = O.corpus("text-zipf", n)
+    src, dst = tmp_path / "in.bin", tmp_path / "out.br"
+    x.tofile(src)
+    r = _host(emu_module, "encode", "BROTLI", 1, src, dst, "-", "threads0")
+    assert r.returncode == 0, r.stderr + r.stdout
+    c = np.fromfile(dst, dtype=np.uint8)
+    assert np.array_equal(O.ref_brotli_decompress(c, n), x)
