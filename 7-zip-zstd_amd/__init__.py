@@ -27,7 +27,7 @@ EXPORTS = ["gc_device_count", "gc_ctx_create", "gc_ctx_destroy", "gc_last_error_
            "gc_flzma2_compress_bound", "gc_flzma2_dict_prop", "gc_flzma2_compress_device", "gc_flzma2_finish", "gc_flzma2_compress_host",
            "gc_flzma2_last_timing",
            "gc_brotli_compress_bound", "gc_brotli_compress_device", "gc_brotli_finish", "gc_brotli_compress_host", "gc_brotli_last_timing",
-           "gc_ctx_set_option", "gc_codec_grain", "gc_codec_compress_bound", "gc_host_begin", "gc_host_size", "gc_host_fetch", "gc_codec_compress_host",
+           "gc_ctx_set_option", "gc_crc32_device", "gc_codec_grain", "gc_codec_compress_bound", "gc_host_begin", "gc_host_size", "gc_host_fetch", "gc_codec_compress_host",
            "gc_host_alloc", "gc_host_free", "gc_multi_create", "gc_multi_destroy", "gc_multi_workers", "gc_multi_last_error",
            "gc_multi_piece_bytes", "gc_multi_compress_host"]
 
@@ -96,6 +96,8 @@ def load_library(path=None):
     lib.gc_brotli_last_timing.restype = C.c_int
     lib.gc_ctx_stream.argtypes = [C.c_void_p]
     lib.gc_ctx_stream.restype = C.c_void_p
+    lib.gc_crc32_device.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]
+    lib.gc_crc32_device.restype = C.c_int
     lib.gc_ctx_set_option.argtypes = [C.c_void_p, C.c_int, C.c_int]
     lib.gc_ctx_set_option.restype = C.c_int
     lib.gc_codec_grain.argtypes = [C.c_int, C.c_int]
@@ -127,6 +129,15 @@ def load_library(path=None):
     lib.gc_multi_compress_host.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_uint, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.gc_multi_compress_host.restype = C.c_int
     return lib
+
+
+def crc32_device(ptr, n, lib_path=None):
+    """CRC-32 (as C/7zCrc.c) of n bytes at a device pointer (under the emulator: any host pointer)."""
+    v = C.c_uint32(0)
+    rc = load_library(lib_path).gc_crc32_device(ptr, n, C.byref(v))
+    if rc != GC_OK:
+        raise GpuCodecError("gc_crc32_device failed: %s" % _ERR.get(rc, rc))
+    return v.value
 
 
 def codec_grain(codec, level, lib_path=None):

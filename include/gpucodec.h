@@ -166,6 +166,10 @@ int         gc_multi_compress_host(gc_multi* m, int codec, const void* src, size
 #define GC_BROTLI_NOT_LAST  4u      /* ... and not its last piece: no closing (ISLAST) meta-block */
 int         gc_ctx_set_option(gc_ctx* ctx, int option, int value);
 
+/* ---- CRC-32 of data that lies in device memory (C/7zCrc.c CrcCalc: polynomial 0xEDB88320, init and final XOR 0xFFFFFFFF).
+ * Synchronous, on the current device's default stream. */
+int         gc_crc32_device(const void* d_src, size_t n, uint32_t* crc);
+
 /* raw stream handle (hipStream_t) so callers can order their own work against the context */
 void*       gc_ctx_stream(gc_ctx* ctx);
 
