@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Round-trip fuzz of the three codecs on the GPU (or, with --lib, the emulator build): inputs stitched from random, text, runs, PCM-like and
+repeated segments of ragged lengths, random levels, sizes from a few bytes to tens of MiB; every stream must decode under the reference
+decoder.  Failing inputs are saved under gpurun_out/fuzz/.   usage: python tools/gpu_fuzz.py --seconds 60 [--max-mib 24] [--lib path]"""
+import argparse, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import numpy as np
+import __graft_entry__ as g
+import oracle as O
+ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=60); ap.add_argument("--max-mib", type=float, default=24); ap.add_argument("--lib", default=""); ap.add_argument("--seed", type=int, default=7)
+a = ap.parse_args()
+pkg = g.load_package(); kw = {"lib_path": a.lib} if a.lib else {"device": 0}
+rng = np.random.default_rng(a.seed)
+text = O.corpus("text-zipf", 4 << 20); lz = O.corpus("lz-7zip", 4 << 20); sil = O.corpus("silesia-like", 211_900_000)[31_785_000:31_785_000 + (4 << 20)]   # PCM-like part
+os.makedirs(os.path.join(ROOT, "gpurun_out", "fuzz"), exist_ok=True)
+t0 = time.time(); it = bad = 0; encs = {}; total = 0
+while time.time() - t0 < a.seconds:
+    target = int(min(a.max_mib * (1 << 20), 2 ** rng.uniform(3, 25)))
+    parts, n = [], 0
+    while n < target:
+        L = int(min(target - n, rng.choice([1, 7, 1000, 4095, 4096, 4097, 16385, 65536, 131071, 131072, 131073, 1 << 20, 3 << 20])))
+        k = int(rng.integers(0, 7))
+        if k == 0: p = rng.integers(0, 256, L, dtype=np.uint8)
+        elif k == 1: o = int(rng.integers(0, text.size - L)); p = text[o:o + L]
+        elif k == 2: p = np.full(L, int(rng.integers(0, 256)), dtype=np.uint8)
+        elif k == 3 and parts: q = parts[int(rng.integers(0, len(parts)))]; p = np.resize(q, L)
+        elif k == 4: o = int(rng.integers(0, lz.size - L)); p = lz[o:o + L]
+        elif k == 5: o = int(rng.integers(0, sil.size - L)); p = sil[o:o + L]
+        else: p = np.tile(rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8), L // 1 + 1)[:L]
+        parts.append(np.ascontiguousarray(p)); n += L
+    x = np.ascontiguousarray(np.concatenate(parts)) if parts else np.empty(0, dtype=np.uint8); n = x.size
+    codec = ["zstd", "flzma2", "brotli"][it % 3]
+    level = int(rng.choice({"zstd": [1, 3, 5, 7, 9, 12, 16, 19], "flzma2": [1, 3, 5, 7, 9], "brotli": [1, 3, 4, 5, 6, 8, 10]}[codec]))
+    key = (codec, level)
+    if key not in encs:
+        encs[key] = {"zstd": pkg.ZstdEncoder, "flzma2": pkg.Flzma2Encoder, "brotli": pkg.BrotliEncoder}[codec](level=level, **kw)
+    e = encs[key]
+    try:
+        y = e.code(x)
+        z = O.ref_zstd_decompress(y, n) if codec == "zstd" else O.ref_lzma2_decode(y, n, e.coder_props()[0]) if codec == "flzma2" else O.ref_brotlimt_decompress(y, n, 8)
+        ok = np.array_equal(np.asarray(z), x)
+    except Exception as ex:
+        ok = False; print("EXC", codec, level, n, repr(ex)[:200], flush=True)
+    if not ok:
+        bad += 1; print("FAIL", codec, level, n, flush=True); np.save(os.path.join(ROOT, "gpurun_out", "fuzz", "fail_%s_%d_%d.npy" % (codec, level, n)), x)
+    it += 1; total += n
+print("iterations", it, "bytes", total, "failures", bad)
