@@ -19,7 +19,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libgpucodec.so")
 
 GC_OK = 0
-_ERR = {-1: "GC_ERR_NO_DEVICE", -2: "GC_ERR_HIP", -3: "GC_ERR_NOMEM", -4: "GC_ERR_DST_SMALL", -5: "GC_ERR_PARAM"}
+_ERR = {-1: "GC_ERR_NO_DEVICE", -2: "GC_ERR_HIP", -3: "GC_ERR_NOMEM", -4: "GC_ERR_DST_SMALL", -5: "GC_ERR_PARAM", -6: "GC_ERR_CORRUPT"}
 
 EXPORTS = ["gc_device_count", "gc_ctx_create", "gc_ctx_destroy", "gc_last_error_message", "gc_zstd_compress_bound",
            "gc_zstd_compress_device", "gc_zstd_finish", "gc_zstd_compress_host", "gc_zstd_last_timing", "gc_ctx_stream",
@@ -29,7 +29,8 @@ EXPORTS = ["gc_device_count", "gc_ctx_create", "gc_ctx_destroy", "gc_last_error_
            "gc_brotli_compress_bound", "gc_brotli_compress_device", "gc_brotli_finish", "gc_brotli_compress_host", "gc_brotli_last_timing",
            "gc_ctx_set_option", "gc_crc32_device", "gc_codec_grain", "gc_codec_compress_bound", "gc_host_begin", "gc_host_size", "gc_host_fetch", "gc_codec_compress_host",
            "gc_host_alloc", "gc_host_free", "gc_multi_create", "gc_multi_destroy", "gc_multi_workers", "gc_multi_last_error",
-           "gc_multi_piece_bytes", "gc_multi_compress_host"]
+           "gc_multi_piece_bytes", "gc_multi_compress_host",
+           "gc_zstd_scan_frames", "gc_zstd_decompress_device", "gc_zstd_decompress_host", "gc_zstd_decompress_timing"]
 
 CODEC_ZSTD, CODEC_FLZMA2, CODEC_BROTLI = 0, 1, 2
 CODEC_IDS = {"zstd": CODEC_ZSTD, "flzma2": CODEC_FLZMA2, "brotli": CODEC_BROTLI}
@@ -128,7 +129,21 @@ def load_library(path=None):
     lib.gc_multi_piece_bytes.restype = C.c_size_t
     lib.gc_multi_compress_host.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_uint, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.gc_multi_compress_host.restype = C.c_int
+    lib.gc_zstd_scan_frames.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64)]
+    lib.gc_zstd_scan_frames.restype = C.c_int
+    lib.gc_zstd_decompress_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.gc_zstd_decompress_device.restype = C.c_int
+    lib.gc_zstd_decompress_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.gc_zstd_decompress_host.restype = C.c_int
+    lib.gc_zstd_decompress_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    lib.gc_zstd_decompress_timing.restype = C.c_int
     return lib
+
+
+class ZstdFrame(C.Structure):
+    """gc_zstd_frame of include/gpucodec.h"""
+    _fields_ = [("src_off", C.c_uint64), ("src_size", C.c_uint64), ("dst_off", C.c_uint64), ("content_size", C.c_uint64),
+                ("flags", C.c_uint32), ("header_size", C.c_uint32)]
 
 
 def crc32_device(ptr, n, lib_path=None):
@@ -327,6 +342,48 @@ class BrotliEncoder(_EncoderBase):
         ms = (C.c_float * 5)()
         self._check(self._lib.gc_brotli_last_timing(self._ctx, ms), "gc_brotli_last_timing")
         return dict(zip(self.KERNELS, [float(x) for x in ms]))
+
+
+class ZstdDecoder(_EncoderBase):
+    """Mirror of NCompress::NZSTD::CDecoder (CPP/7zip/Compress/ZstdDecoder.cpp) for whole streams: frames decode concurrently on the GPU."""
+    UNKNOWN = (1 << 64) - 1
+
+    def scan(self, data):
+        """-> (array of ZstdFrame, total content size or None if a frame does not state its size)"""
+        import numpy as np
+        a = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data, dtype=np.uint8)
+        n = C.c_size_t(0)
+        rc = self._lib.gc_zstd_scan_frames(a.ctypes.data, a.size, None, 0, C.byref(n), None)
+        if rc != GC_OK:
+            raise GpuCodecError("gc_zstd_scan_frames failed: %s" % _ERR.get(rc, rc))
+        frames = (ZstdFrame * max(1, n.value))()
+        total = C.c_uint64(0)
+        rc = self._lib.gc_zstd_scan_frames(a.ctypes.data, a.size, frames, n.value, C.byref(n), C.byref(total))
+        if rc != GC_OK:
+            raise GpuCodecError("gc_zstd_scan_frames failed: %s" % _ERR.get(rc, rc))
+        return frames, n.value, (None if total.value == self.UNKNOWN else total.value)
+
+    def code(self, data, capacity=None):
+        """compressed bytes-like -> numpy uint8 content (host buffers; includes PCIe copies).  capacity is only needed for
+        frames that do not state their content size."""
+        import numpy as np
+        a = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data, dtype=np.uint8)
+        _, _, total = self.scan(a)
+        cap = total if total is not None else (capacity if capacity is not None else max(1 << 20, 64 * a.size))
+        out = np.empty(max(1, cap), dtype=np.uint8)
+        n = C.c_size_t(0)
+        self._check(self._lib.gc_zstd_decompress_host(self._ctx, a.ctypes.data, a.size, out.ctypes.data, cap, C.byref(n)), "gc_zstd_decompress_host")
+        return out[:n.value]
+
+    def code_device(self, d_src_ptr, n, d_dst_ptr, dst_cap, frames, n_frames):
+        size = C.c_size_t(0)
+        self._check(self._lib.gc_zstd_decompress_device(self._ctx, d_src_ptr, n, d_dst_ptr, dst_cap, frames, n_frames, C.byref(size)), "gc_zstd_decompress_device")
+        return size.value
+
+    def last_timing_ms(self):
+        ms = C.c_float(0)
+        self._check(self._lib.gc_zstd_decompress_timing(self._ctx, C.byref(ms)), "gc_zstd_decompress_timing")
+        return float(ms.value)
 
 
 class ZstdEncoder(_EncoderBase):

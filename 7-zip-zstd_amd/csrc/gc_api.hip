@@ -9,6 +9,7 @@
 #include "gc_lzma2.h"
 #include "gc_brotli.h"
 #include "gc_mf.h"
+#include "gc_zstd_dec.h"
 #ifdef HIPEMU
 #include "hip_runtime_stub.h"
 #else
@@ -123,6 +124,9 @@ struct gc_ctx {
     // staging for the host-buffer entry point
     uint8_t* dIn; size_t dInCap; uint8_t* dOut; size_t dOutCap;
     bool pending; bool timed;
+    // zstd decoder (gc_zstd_dec.hip): per-workgroup literal / sequence workspace, frame table, per-frame results, ticket counter
+    uint8_t* zdLit; void* zdSeq; uint32_t* zdLpos; uint32_t zdWg; GcZdFrame* zdFrames; size_t zdFramesCap; uint64_t* zdResult; size_t zdResultCap;
+    uint32_t* zdTicket; hipEvent_t zdEv[2]; float zdMs;
     unsigned long long* prof;  // device: GC_LZ_PHASES + GC_SEQ_PHASES cycle sums, only when profiling is on
     bool profOn; uint32_t profBlocks;
 };
@@ -209,6 +213,8 @@ static void ctx_release(gc_ctx* c)
     if (c->stream) hipStreamSynchronize(c->stream);
     free_workspace(c);
     hipFree(c->prof); hipFree(c->result); if (c->hostResult) hipHostFree(c->hostResult); hipFree(c->dIn); hipFree(c->dOut);
+    hipFree(c->zdLit); hipFree(c->zdSeq); hipFree(c->zdLpos); hipFree(c->zdFrames); hipFree(c->zdResult); hipFree(c->zdTicket);
+    for (int i = 0; i < 2; i++) if (c->zdEv[i]) hipEventDestroy(c->zdEv[i]);
     hipFree(c->mfCnt); hipFree(c->mfEnt); hipFree(c->mfEnt2); hipFree(c->mfRec); hipFree(c->mfRec2); hipFree(c->mfRec3); hipFree(c->mfDp); hipFree(c->mfPrice); hipFree(c->mfWinCost); hipFree(c->mfDpStat);
     for (int i = 0; i < 8; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
     for (uint32_t p = 0; p < GC_MAX_PARTS; p++) {
@@ -883,4 +889,109 @@ extern "C" size_t gc_codec_grain(int codec, int level)
     if (codec != GC_CODEC_BROTLI && fb > 1u) gc_env_u32("GC_FRAME_BLOCKS", 1u, GC_MF_MAX_FRAME_BLOCKS, &fb);     // test hook: small frames (as in gc_ctx_create)
     if (codec != GC_CODEC_BROTLI) return (size_t)fb * GC_ZSTD_BLOCK_MAX;
     return (size_t)brotli_blocks_per_chunk(level) * GC_ZSTD_BLOCK_MAX;
+}
+
+// ---------------------------------------------------------------- ZSTD decoding ----------------------------------------------------------------
+extern "C" void gc_zstd_dec_launch(hipStream_t st, uint32_t grid, const uint8_t* src, uint8_t* dst, uint64_t dstCap, const GcZdFrame* frames, uint32_t nFrames,
+                                   uint32_t* ticket, uint8_t* litWork, void* seqWork, uint32_t* lposWork, uint64_t* result);
+static_assert(sizeof(GcZdFrame) == sizeof(gc_zstd_frame), "frame record layout");
+
+static int zd_ensure(gc_ctx* c, uint32_t wg, size_t nFrames)
+{
+    if (wg > c->zdWg) {
+        hipFree(c->zdLit); hipFree(c->zdSeq); hipFree(c->zdLpos); c->zdLit = nullptr; c->zdSeq = nullptr; c->zdLpos = nullptr; c->zdWg = 0;
+        if (hipMalloc((void**)&c->zdLit, (size_t)wg * GC_ZD_LIT_STRIDE) != hipSuccess || hipMalloc(&c->zdSeq, (size_t)wg * GC_ZD_MAX_SEQ * 16u) != hipSuccess ||
+            hipMalloc((void**)&c->zdLpos, (size_t)wg * GC_ZD_MAX_SEQ * 4u) != hipSuccess) { snprintf(c->err, sizeof(c->err), "decoder workspace: out of device memory"); return GC_ERR_NOMEM; }
+        c->zdWg = wg;
+    }
+    if (nFrames > c->zdFramesCap) {
+        hipFree(c->zdFrames); hipFree(c->zdResult); c->zdFrames = nullptr; c->zdResult = nullptr; c->zdFramesCap = 0;
+        const size_t cap = nFrames + nFrames / 2u + 64u;
+        if (hipMalloc((void**)&c->zdFrames, cap * sizeof(GcZdFrame)) != hipSuccess || hipMalloc((void**)&c->zdResult, cap * 8u) != hipSuccess) return GC_ERR_NOMEM;
+        c->zdFramesCap = cap;
+    }
+    if (!c->zdTicket && hipMalloc((void**)&c->zdTicket, 4) != hipSuccess) return GC_ERR_NOMEM;
+    for (int i = 0; i < 2; i++) if (!c->zdEv[i] && hipEventCreate(&c->zdEv[i]) != hipSuccess) return GC_ERR_HIP;
+    return GC_OK;
+}
+
+extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n, void* d_dst, size_t dstCap, const gc_zstd_frame* frames, size_t nFrames, size_t* outSize)
+{
+    if (!c || (!d_src && n) || (!d_dst && dstCap) || (!frames && nFrames)) return GC_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    c->zdMs = 0.f;
+    if (outSize) *outSize = 0;
+    if (!nFrames) return GC_OK;
+    GcZdFrame* h = (GcZdFrame*)malloc(nFrames * sizeof(GcZdFrame));
+    uint64_t* res = (uint64_t*)malloc(nFrames * 8u);
+    if (!h || !res) { free(h); free(res); return GC_ERR_NOMEM; }
+    memcpy(h, frames, nFrames * sizeof(GcZdFrame));
+    int rc = GC_OK;
+    uint64_t dstOff = 0;
+    size_t i = 0;
+    while (i < nFrames && rc == GC_OK) {
+        // a batch: frames that state their content size, closed by at most one that does not
+        size_t j = i; uint64_t off = dstOff;
+        for (; j < nFrames; j++) {
+            if (h[j].srcOff > n || h[j].srcSize > n - h[j].srcOff || h[j].hdrSize > h[j].srcSize) { rc = GC_ERR_PARAM; break; }
+            h[j].dstOff = off;
+            if (!(h[j].flags & GC_ZD_F_SIZE_KNOWN)) { j++; break; }
+            if (h[j].contentSize > dstCap - off) { snprintf(c->err, sizeof(c->err), "destination too small"); rc = GC_ERR_DST_SMALL; break; }
+            off += h[j].contentSize;
+        }
+        if (rc != GC_OK) break;
+        const size_t cnt = j - i;
+        const uint32_t wg = (uint32_t)(cnt < GC_ZD_MAX_WG ? cnt : GC_ZD_MAX_WG);
+        if ((rc = zd_ensure(c, wg, cnt)) != GC_OK) break;
+        if (hipMemcpyAsync(c->zdFrames, h + i, cnt * sizeof(GcZdFrame), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
+            hipMemsetAsync(c->zdTicket, 0, 4, c->stream) != hipSuccess) { rc = GC_ERR_HIP; break; }
+        hipEventRecord(c->zdEv[0], c->stream);
+        gc_zstd_dec_launch(c->stream, wg, (const uint8_t*)d_src, (uint8_t*)d_dst, dstCap, c->zdFrames, (uint32_t)cnt, c->zdTicket, c->zdLit, c->zdSeq, c->zdLpos, c->zdResult);
+        hipEventRecord(c->zdEv[1], c->stream);
+        if (hipMemcpyAsync(res + i, c->zdResult, cnt * 8u, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+            snprintf(c->err, sizeof(c->err), "decode kernel failed: %s", hipGetErrorString(hipGetLastError())); rc = GC_ERR_HIP; break;
+        }
+        float ms = 0.f; if (hipEventElapsedTime(&ms, c->zdEv[0], c->zdEv[1]) == hipSuccess) c->zdMs += ms;
+        for (size_t k = i; k < j; k++) {
+            const uint32_t st = (uint32_t)(res[k] >> 56);
+            const uint64_t produced = res[k] & 0x00FFFFFFFFFFFFFFull;
+            if (st == GC_ZD_OK) { dstOff = h[k].dstOff + produced; continue; }
+            snprintf(c->err, sizeof(c->err), "frame %zu: %s", k, st == GC_ZD_DST_SMALL ? "destination too small" : st == GC_ZD_CHECKSUM ? "content checksum mismatch" :
+                     st == GC_ZD_SIZE ? "content size field does not match" : st == GC_ZD_UNSUPPORTED ? "unsupported frame" : "corrupted data");
+            rc = st == GC_ZD_DST_SMALL ? GC_ERR_DST_SMALL : (st == GC_ZD_UNSUPPORTED ? GC_ERR_PARAM : GC_ERR_CORRUPT);
+            break;
+        }
+        i = j;
+    }
+    free(h); free(res);
+    if (rc == GC_OK && outSize) *outSize = (size_t)dstOff;
+    return rc;
+}
+
+extern "C" int gc_zstd_decompress_timing(gc_ctx* c, float* ms) { if (!c || !ms) return GC_ERR_PARAM; *ms = c->zdMs; return GC_OK; }
+
+extern "C" int gc_zstd_decompress_host(gc_ctx* c, const void* src, size_t n, void* dst, size_t dstCap, size_t* outSize)
+{
+    if (!c || (!src && n) || (!dst && dstCap)) return GC_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (outSize) *outSize = 0;
+    size_t nFrames = 0;
+    int rc = gc_zstd_scan_frames(src, n, nullptr, 0, &nFrames, nullptr);
+    if (rc != GC_OK) { snprintf(c->err, sizeof(c->err), "not a zstd stream this decoder handles (frame scan failed)"); return rc; }
+    if (!nFrames) return GC_OK;
+    gc_zstd_frame* fr = (gc_zstd_frame*)malloc(nFrames * sizeof(gc_zstd_frame));
+    if (!fr) return GC_ERR_NOMEM;
+    uint64_t total = 0;
+    rc = gc_zstd_scan_frames(src, n, fr, nFrames, &nFrames, &total);
+    if (rc == GC_OK && total != ~0ull && total > dstCap) { snprintf(c->err, sizeof(c->err), "destination too small: need %llu bytes", (unsigned long long)total); rc = GC_ERR_DST_SMALL; }
+    if (rc == GC_OK && n > c->dInCap) { hipFree(c->dIn); c->dIn = nullptr; c->dInCap = 0; if (hipMalloc((void**)&c->dIn, n + 64) != hipSuccess) rc = GC_ERR_NOMEM; else c->dInCap = n; }
+    const size_t need = total != ~0ull ? (size_t)total : dstCap;
+    if (rc == GC_OK && need > c->dOutCap) { hipFree(c->dOut); c->dOut = nullptr; c->dOutCap = 0; if (hipMalloc((void**)&c->dOut, need + 64) != hipSuccess) rc = GC_ERR_NOMEM; else c->dOutCap = need; }
+    size_t produced = 0;
+    if (rc == GC_OK && hipMemcpyAsync(c->dIn, src, n, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = GC_ERR_HIP;
+    if (rc == GC_OK) rc = gc_zstd_decompress_device(c, c->dIn, n, c->dOut, need, fr, nFrames, &produced);
+    if (rc == GC_OK && produced && (hipMemcpyAsync(dst, c->dOut, produced, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)) rc = GC_ERR_HIP;
+    free(fr);
+    if (rc == GC_OK && outSize) *outSize = produced;
+    return rc;
 }

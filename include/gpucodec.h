@@ -34,6 +34,7 @@ extern "C" {
 #define GC_ERR_NOMEM       -3
 #define GC_ERR_DST_SMALL   -4   /* dstCapacity < compressed size (cf. ZSTD_error_dstSize_tooSmall) */
 #define GC_ERR_PARAM       -5
+#define GC_ERR_CORRUPT     -6   /* decoder: the compressed data is damaged (cf. ZSTD_error_corruption_detected, checksum_wrong) */
 
 typedef struct gc_ctx gc_ctx;
 
@@ -169,6 +170,31 @@ int         gc_ctx_set_option(gc_ctx* ctx, int option, int value);
 /* ---- CRC-32 of data that lies in device memory (C/7zCrc.c CrcCalc: polynomial 0xEDB88320, init and final XOR 0xFFFFFFFF).
  * Synchronous, on the current device's default stream. */
 int         gc_crc32_device(const void* d_src, size_t n, uint32_t* crc);
+
+/* ---- ZSTD decoding on the device.  Replaces the ZSTD_decompressStream loop of NCompress::NZSTD::CDecoder::CodeSpec
+ * (CPP/7zip/Compress/ZstdDecoder.cpp:66-240; C/zstd/zstd_decompress.c:2086) for callers that hold a whole compressed stream.  The frame is
+ * the unit of parallelism (one workgroup each): streams of this engine's encoder carry one frame per 8 MiB, a stream of the reference's
+ * encoder is one frame.  Frames with a dictionary id are refused (GC_ERR_PARAM); a damaged stream, a wrong content checksum (XXH64, checked
+ * on the device) or a content size field that does not match give GC_ERR_CORRUPT.
+ *   gc_zstd_scan_frames       host: walks frame and block headers (ZSTD_findFrameCompressedSize zstd_decompress.c:809, ZSTD_getFrameContentSize
+ *                             :569), skips skippable frames.  frames may be NULL to count.  *contentTotal = sum of the content sizes, or
+ *                             UINT64_MAX if a frame does not state its size (then the caller has to guess dstCapacity).
+ *   gc_zstd_decompress_device frames as the scan returned them (host memory); d_src / d_dst device memory.  Frames that state their size are
+ *                             decoded concurrently; a frame that does not ends a batch (its size is read back before the next batch starts).
+ *   gc_zstd_decompress_host   scan + H2D + decode + D2H. */
+typedef struct gc_zstd_frame {
+    uint64_t src_off, src_size;      /* the frame inside the compressed stream */
+    uint64_t dst_off;                /* where its content starts in the output; UINT64_MAX if unknown before decoding */
+    uint64_t content_size;           /* valid if flags & 2 */
+    uint32_t flags;                  /* 1: content checksum present, 2: content size known */
+    uint32_t header_size;
+} gc_zstd_frame;
+int         gc_zstd_scan_frames(const void* src, size_t n, gc_zstd_frame* frames, size_t maxFrames, size_t* nFrames, uint64_t* contentTotal);
+int         gc_zstd_decompress_device(gc_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t dstCapacity,
+                                      const gc_zstd_frame* frames, size_t nFrames, size_t* decompressedSize);
+int         gc_zstd_decompress_host(gc_ctx* ctx, const void* src, size_t n, void* dst, size_t dstCapacity, size_t* decompressedSize);
+/* HIP-event duration of the decode kernels of the last gc_zstd_decompress_* call */
+int         gc_zstd_decompress_timing(gc_ctx* ctx, float* ms);
 
 /* raw stream handle (hipStream_t) so callers can order their own work against the context */
 void*       gc_ctx_stream(gc_ctx* ctx);

@@ -145,6 +145,20 @@ def ref_zstd_compress(data, level=3, workers=0, piece=0):
     return out[:r].copy()
 
 
+def ref_zstd_compress_opts(data, level=3, checksum=False, streamed=False, ldm=False):
+    """One frame from the reference encoder with a content checksum / without a content size field / with long-distance matching."""
+    a, ap = _buf(data)
+    lib = ref("zstd")
+    cap = lib.ref_zstd_compress_bound(a.size) + 1024
+    out = np.empty(cap, dtype=np.uint8)
+    lib.ref_zstd_compress_opts.restype = C.c_size_t
+    lib.ref_zstd_compress_opts.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_uint]
+    r = lib.ref_zstd_compress_opts(out.ctypes.data, cap, ap, a.size, level, (1 if checksum else 0) | (2 if streamed else 0) | (4 if ldm else 0))
+    if r == _BAD:
+        raise RuntimeError("reference zstd compress failed")
+    return out[:r].copy()
+
+
 def ref_zstd_compress_sequences(data, offs, lls, mls, level=3):
     a, ap = _buf(data)
     lib = ref("zstd")

@@ -45,6 +45,41 @@ size_t ref_zstd_compress_pieces(void* dst, size_t cap, const void* src, size_t n
     return out;
 }
 
+/* one frame with the options the decoder tests need: flags bit0 = content checksum, bit1 = streamed in 100 000-byte writes without a pledged
+ * size (what CEncoder::Code does when the size is not known: no Frame_Content_Size field, window descriptor instead), bit2 = long-distance
+ * matching on with windowLog 27 (large offsets) */
+size_t ref_zstd_compress_opts(void* dst, size_t cap, const void* src, size_t n, int level, unsigned flags)
+{
+    ZSTD_CCtx* c = ZSTD_createCCtx();
+    size_t r = 0;
+    if (!c) return (size_t)-1;
+    ZSTD_CCtx_setParameter(c, ZSTD_c_compressionLevel, level);
+    ZSTD_CCtx_setParameter(c, ZSTD_c_checksumFlag, (flags & 1u) ? 1 : 0);
+    if (flags & 4u) { ZSTD_CCtx_setParameter(c, ZSTD_c_enableLongDistanceMatching, 1); ZSTD_CCtx_setParameter(c, ZSTD_c_windowLog, 27); }
+    if (flags & 2u) {
+        ZSTD_inBuffer in; ZSTD_outBuffer out;
+        size_t off = 0;
+        out.dst = dst; out.size = cap; out.pos = 0;
+        for (;;) {
+            size_t take = n - off < 100000u ? n - off : 100000u;
+            int last = off + take == n;
+            in.src = (const char*)src + off; in.size = take; in.pos = 0;
+            do {
+                r = ZSTD_compressStream2(c, &out, &in, last ? ZSTD_e_end : ZSTD_e_continue);
+                if (ZSTD_isError(r) || (out.pos == out.size && (r || in.pos < in.size))) { ZSTD_freeCCtx(c); return (size_t)-1; }
+            } while (last ? r != 0 : in.pos < in.size);
+            off += take;
+            if (last) break;
+        }
+        r = out.pos;
+    } else {
+        ZSTD_CCtx_setParameter(c, ZSTD_c_contentSizeFlag, 1);
+        r = ZSTD_compress2(c, dst, cap, src, n);
+    }
+    ZSTD_freeCCtx(c);
+    return ZSTD_isError(r) ? (size_t)-1 : r;
+}
+
 /* multi-frame decode exactly as the 7-Zip decoder loop does (ZstdDecoder.cpp:145-158):
  * ZSTD_decompress() itself walks concatenated + skippable frames. */
 size_t ref_zstd_decompress(void* dst, size_t cap, const void* src, size_t n)

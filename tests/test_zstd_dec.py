@@ -1,0 +1,176 @@
+"""ZSTD decoding on the device: the content must be bit-exact for streams of the REFERENCE's encoder (every level family,
+content checksum, streamed frames without a content size, long offsets, concatenated and skippable frames) and of this engine's encoder,
+and damaged streams must be refused, never crash.  CPU: the kernel under the SIMT emulator; GPU: the product library, larger inputs."""
+import struct
+
+import numpy as np
+import pytest
+
+MiB = 1 << 20
+KINDS = ["silesia-like", "text-zipf", "lz-7zip", "random", "zeros", "runs"]
+
+
+def _corpus(O, kind, n):
+    if n == 0:
+        return np.empty(0, dtype=np.uint8)
+    if kind == "zeros":
+        return np.zeros(n, dtype=np.uint8)
+    if kind == "runs":                       # RLE blocks, RLE literals, long matches with tiny offsets
+        rng = np.random.default_rng(7)
+        out = np.repeat(rng.integers(0, 256, size=n // 700 + 2, dtype=np.uint8), rng.integers(1, 1400, size=n // 700 + 2))
+        return np.ascontiguousarray(np.resize(out, n))
+    return O.corpus(kind, n)
+
+
+def _check(dec, comp, want, capacity=None):
+    out = dec.code(comp, capacity=capacity if capacity is not None else len(want) + 64)
+    assert out.size == len(want)
+    assert out.tobytes() == bytes(want)
+
+
+@pytest.fixture(scope="module")
+def emu_dec(pkg, emu_lib_path):
+    d = pkg.ZstdDecoder(lib_path=emu_lib_path)
+    yield d
+    d.close()
+
+
+@pytest.fixture(scope="module")
+def gpu_dec(pkg, graft):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    graft.build_hip()
+    d = pkg.ZstdDecoder(device=0)
+    yield d
+    d.close()
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_emu_reference_streams(O, emu_dec, kind):
+    for n, level in ((0, 3), (1, 3), (5000, 1), (131072, 3), (131073, 6), (400_000, 19), (300_000, 22)):
+        x = _corpus(O, kind, n)
+        _check(emu_dec, O.ref_zstd_compress(x.tobytes(), level), x.tobytes())
+
+
+def test_emu_reference_frame_options(O, emu_dec):
+    x = _corpus(O, "silesia-like", 700_000)
+    for kw in (dict(checksum=True), dict(streamed=True), dict(checksum=True, streamed=True), dict(ldm=True, checksum=True)):
+        for level in (1, 5, 17):
+            _check(emu_dec, O.ref_zstd_compress_opts(x.tobytes(), level, **kw), x.tobytes())
+    # empty and tiny frames with checksum / without size
+    for n in (0, 1, 31, 32, 33, 63):
+        y = x[:n].tobytes()
+        _check(emu_dec, O.ref_zstd_compress_opts(y, 3, checksum=True, streamed=True), y)
+
+
+def test_emu_concatenated_and_skippable_frames(O, emu_dec):
+    x = _corpus(O, "text-zipf", 600_000).tobytes()
+    comp = O.ref_zstd_compress(x, 3, piece=100_000).tobytes()                 # 6 frames that state their sizes
+    frames, n, total = emu_dec.scan(comp)
+    assert n == 6 and total == len(x)
+    assert [frames[i].dst_off for i in range(n)] == [100_000 * i for i in range(6)]
+    _check(emu_dec, comp, x)
+    skip = struct.pack("<II", 0x184D2A53, 11) + b"hello world"
+    a, b = O.ref_zstd_compress_opts(x[:250_000], 3, streamed=True).tobytes(), O.ref_zstd_compress_opts(x[250_000:], 6, checksum=True).tobytes()
+    mixed = skip + a + skip + b + skip                                         # a frame of unknown size closes a batch
+    frames, n, total = emu_dec.scan(mixed)
+    assert n == 2 and total is None
+    _check(emu_dec, mixed, x, capacity=len(x))
+    with pytest.raises(Exception):
+        emu_dec.code(mixed, capacity=len(x) - 1)                               # destination too small
+
+
+@pytest.mark.parametrize("level", [1, 3, 12, 19])
+def test_emu_own_encoder_roundtrip(pkg, O, emu_lib_path, emu_dec, level, monkeypatch):
+    monkeypatch.setenv("GC_FRAME_BLOCKS", "2")                                 # frames of 256 KiB so that a small input carries several
+    x = _corpus(O, "silesia-like", 900_000)
+    enc = pkg.ZstdEncoder(lib_path=emu_lib_path, level=level)
+    try:
+        comp = enc.code(x)
+        enc.set_option(enc.OPT_ZSTD_SEEK_TABLE, 1)
+        comp2 = enc.code(x)
+    finally:
+        enc.close()
+    frames, n, total = emu_dec.scan(comp)
+    assert total == x.size and n >= (1 if level <= 2 else 3)
+    _check(emu_dec, comp, x.tobytes())
+    _check(emu_dec, comp2, x.tobytes())                                        # the seek table is a skippable frame
+
+
+def test_emu_damaged_streams_are_refused(pkg, O, emu_dec):
+    x = _corpus(O, "silesia-like", 200_000).tobytes()
+    comp = bytearray(O.ref_zstd_compress_opts(x, 3, checksum=True).tobytes())
+    rng = np.random.default_rng(3)
+    refused = 0
+    for _ in range(40):
+        bad = bytearray(comp)
+        pos = int(rng.integers(0, len(bad)))
+        bad[pos] ^= 1 << int(rng.integers(0, 8))
+        try:
+            out = emu_dec.code(bytes(bad), capacity=len(x) + 64)
+            assert out.tobytes() == x           # a flip the format does not notice must not change the content (checksum present)
+        except pkg.GpuCodecError:
+            refused += 1
+    assert refused >= 36
+    for cut in (0, 3, 4, 9, len(comp) // 2, len(comp) - 1):                    # truncated
+        if cut == 0:
+            continue
+        with pytest.raises(pkg.GpuCodecError):
+            emu_dec.code(bytes(comp[:cut]), capacity=len(x) + 64)
+    with pytest.raises(pkg.GpuCodecError):
+        emu_dec.code(b"\x00" * 16)                                             # not a zstd stream
+
+
+# ------------------------------------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", KINDS)
+def test_gpu_reference_streams(O, gpu_dec, kind):
+    for n, level in ((0, 3), (1, 1), (131072, 3), (3 * MiB + 17, 1), (8 * MiB, 3), (5 * MiB, 19)):
+        x = _corpus(O, kind, n)
+        _check(gpu_dec, O.ref_zstd_compress(x.tobytes(), level), x.tobytes())
+
+
+@pytest.mark.gpu
+def test_gpu_reference_frame_options(O, gpu_dec):
+    x = _corpus(O, "silesia-like", 20 * MiB + 12345).tobytes()
+    for kw in (dict(checksum=True), dict(streamed=True), dict(checksum=True, streamed=True), dict(ldm=True, checksum=True)):
+        _check(gpu_dec, O.ref_zstd_compress_opts(x, 3, **kw), x)
+    comp = O.ref_zstd_compress(x, 3, piece=MiB).tobytes()                      # 21 frames
+    frames, n, total = gpu_dec.scan(comp)
+    assert n == 21 and total == len(x)
+    _check(gpu_dec, comp, x)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [1, 3, 12, 19])
+def test_gpu_own_encoder_roundtrip(pkg, O, gpu_dec, level):
+    x = _corpus(O, "silesia-like", 100 * MiB + 4321)
+    enc = pkg.ZstdEncoder(device=0, level=level)
+    try:
+        comp = enc.code(x)
+    finally:
+        enc.close()
+    assert O.ref_zstd_decompress(comp, x.size).tobytes() == x.tobytes()        # the reference decoder agrees on the stream first
+    frames, n, total = gpu_dec.scan(comp)
+    assert total == x.size
+    _check(gpu_dec, comp, x.tobytes())
+
+
+@pytest.mark.gpu
+def test_gpu_damaged_streams_are_refused(pkg, O, gpu_dec):
+    x = _corpus(O, "text-zipf", 3 * MiB).tobytes()
+    comp = bytearray(O.ref_zstd_compress_opts(x, 3, checksum=True).tobytes())
+    rng = np.random.default_rng(5)
+    refused = 0
+    for _ in range(200):
+        bad = bytearray(comp)
+        pos = int(rng.integers(0, len(bad)))
+        bad[pos] ^= 1 << int(rng.integers(0, 8))
+        try:
+            out = gpu_dec.code(bytes(bad), capacity=len(x) + 64)
+            assert out.tobytes() == x
+        except pkg.GpuCodecError:
+            refused += 1
+    assert refused >= 190
+    _check(gpu_dec, bytes(comp), x)                                            # the context still works afterwards
