@@ -143,7 +143,7 @@ def load_library(path=None):
 class ZstdFrame(C.Structure):
     """gc_zstd_frame of include/gpucodec.h"""
     _fields_ = [("src_off", C.c_uint64), ("src_size", C.c_uint64), ("dst_off", C.c_uint64), ("content_size", C.c_uint64),
-                ("flags", C.c_uint32), ("header_size", C.c_uint32)]
+                ("flags", C.c_uint32), ("header_size", C.c_uint32), ("n_blocks", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 def crc32_device(ptr, n, lib_path=None):

@@ -125,8 +125,8 @@ struct gc_ctx {
     uint8_t* dIn; size_t dInCap; uint8_t* dOut; size_t dOutCap;
     bool pending; bool timed;
     // zstd decoder (gc_zstd_dec.hip): per-workgroup literal / sequence workspace, frame table, per-frame results, ticket counter
-    uint8_t* zdLit; void* zdSeq; uint32_t* zdLpos; uint32_t zdWg; GcZdFrame* zdFrames; size_t zdFramesCap; uint64_t* zdResult; size_t zdResultCap;
-    uint32_t* zdTicket; hipEvent_t zdEv[2]; float zdMs;
+    uint8_t* zdLit; size_t zdLitCap; void* zdSeq; size_t zdSeqCap; GcZdFrame* zdFrames; size_t zdFramesCap; uint64_t* zdResult; uint64_t* zdTot;
+    GcZdBlock* zdBlocks; size_t zdBlocksCap; uint32_t* zdTicket; hipEvent_t zdEv[2]; float zdMs;
     unsigned long long* prof;  // device: GC_LZ_PHASES + GC_SEQ_PHASES cycle sums, only when profiling is on
     bool profOn; uint32_t profBlocks;
 };
@@ -213,7 +213,7 @@ static void ctx_release(gc_ctx* c)
     if (c->stream) hipStreamSynchronize(c->stream);
     free_workspace(c);
     hipFree(c->prof); hipFree(c->result); if (c->hostResult) hipHostFree(c->hostResult); hipFree(c->dIn); hipFree(c->dOut);
-    hipFree(c->zdLit); hipFree(c->zdSeq); hipFree(c->zdLpos); hipFree(c->zdFrames); hipFree(c->zdResult); hipFree(c->zdTicket);
+    hipFree(c->zdLit); hipFree(c->zdSeq); hipFree(c->zdFrames); hipFree(c->zdResult); hipFree(c->zdTot); hipFree(c->zdBlocks); hipFree(c->zdTicket);
     for (int i = 0; i < 2; i++) if (c->zdEv[i]) hipEventDestroy(c->zdEv[i]);
     hipFree(c->mfCnt); hipFree(c->mfEnt); hipFree(c->mfEnt2); hipFree(c->mfRec); hipFree(c->mfRec2); hipFree(c->mfRec3); hipFree(c->mfDp); hipFree(c->mfPrice); hipFree(c->mfWinCost); hipFree(c->mfDpStat);
     for (int i = 0; i < 8; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
@@ -892,26 +892,17 @@ extern "C" size_t gc_codec_grain(int codec, int level)
 }
 
 // ---------------------------------------------------------------- ZSTD decoding ----------------------------------------------------------------
-extern "C" void gc_zstd_dec_launch(hipStream_t st, uint32_t grid, const uint8_t* src, uint8_t* dst, uint64_t dstCap, const GcZdFrame* frames, uint32_t nFrames,
-                                   uint32_t* ticket, uint8_t* litWork, void* seqWork, uint32_t* lposWork, uint64_t* result);
-static_assert(sizeof(GcZdFrame) == sizeof(gc_zstd_frame), "frame record layout");
+extern "C" void gc_zstd_dec_launch_index(hipStream_t st, const uint8_t* src, const GcZdFrame* frames, uint32_t nFrames, GcZdBlock* blocks, uint64_t* frameTot);
+extern "C" void gc_zstd_dec_launch_decode(hipStream_t st, const uint8_t* src, uint64_t srcSize, uint8_t* dst, uint64_t dstCap, const GcZdFrame* frames, uint32_t nFrames,
+                                          GcZdBlock* blocks, uint32_t nBlocks, uint32_t* ticket, uint8_t* litWork, uint64_t litWorkSize, void* seqWork, uint64_t* result);
 
-static int zd_ensure(gc_ctx* c, uint32_t wg, size_t nFrames)
+static int zd_grow(gc_ctx* c, void** p, size_t* cap, size_t need)
 {
-    if (wg > c->zdWg) {
-        hipFree(c->zdLit); hipFree(c->zdSeq); hipFree(c->zdLpos); c->zdLit = nullptr; c->zdSeq = nullptr; c->zdLpos = nullptr; c->zdWg = 0;
-        if (hipMalloc((void**)&c->zdLit, (size_t)wg * GC_ZD_LIT_STRIDE) != hipSuccess || hipMalloc(&c->zdSeq, (size_t)wg * GC_ZD_MAX_SEQ * 16u) != hipSuccess ||
-            hipMalloc((void**)&c->zdLpos, (size_t)wg * GC_ZD_MAX_SEQ * 4u) != hipSuccess) { snprintf(c->err, sizeof(c->err), "decoder workspace: out of device memory"); return GC_ERR_NOMEM; }
-        c->zdWg = wg;
-    }
-    if (nFrames > c->zdFramesCap) {
-        hipFree(c->zdFrames); hipFree(c->zdResult); c->zdFrames = nullptr; c->zdResult = nullptr; c->zdFramesCap = 0;
-        const size_t cap = nFrames + nFrames / 2u + 64u;
-        if (hipMalloc((void**)&c->zdFrames, cap * sizeof(GcZdFrame)) != hipSuccess || hipMalloc((void**)&c->zdResult, cap * 8u) != hipSuccess) return GC_ERR_NOMEM;
-        c->zdFramesCap = cap;
-    }
-    if (!c->zdTicket && hipMalloc((void**)&c->zdTicket, 4) != hipSuccess) return GC_ERR_NOMEM;
-    for (int i = 0; i < 2; i++) if (!c->zdEv[i] && hipEventCreate(&c->zdEv[i]) != hipSuccess) return GC_ERR_HIP;
+    if (need <= *cap) return GC_OK;
+    hipFree(*p); *p = nullptr; *cap = 0;
+    const size_t want = need + need / 8u + 4096u;
+    if (hipMalloc(p, want) != hipSuccess) { *p = nullptr; snprintf(c->err, sizeof(c->err), "decoder workspace: out of device memory (%zu bytes)", want); return GC_ERR_NOMEM; }
+    *cap = want;
     return GC_OK;
 }
 
@@ -922,41 +913,63 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
     c->zdMs = 0.f;
     if (outSize) *outSize = 0;
     if (!nFrames) return GC_OK;
-    GcZdFrame* h = (GcZdFrame*)malloc(nFrames * sizeof(GcZdFrame));
-    uint64_t* res = (uint64_t*)malloc(nFrames * 8u);
+    GcZdFrame* h = (GcZdFrame*)calloc(nFrames, sizeof(GcZdFrame));
+    uint64_t* res = (uint64_t*)malloc(nFrames * 16u);           // per frame results; also the (literal bytes, sequence records) totals of the index pass
     if (!h || !res) { free(h); free(res); return GC_ERR_NOMEM; }
-    memcpy(h, frames, nFrames * sizeof(GcZdFrame));
     int rc = GC_OK;
+    if (!c->zdTicket && hipMalloc((void**)&c->zdTicket, 4) != hipSuccess) rc = GC_ERR_NOMEM;
+    for (int i = 0; i < 2 && rc == GC_OK; i++) if (!c->zdEv[i] && hipEventCreate(&c->zdEv[i]) != hipSuccess) rc = GC_ERR_HIP;
     uint64_t dstOff = 0;
     size_t i = 0;
     while (i < nFrames && rc == GC_OK) {
         // a batch: frames that state their content size, closed by at most one that does not
-        size_t j = i; uint64_t off = dstOff;
+        size_t j = i; uint64_t off = dstOff, nBlocks = 0;
         for (; j < nFrames; j++) {
-            if (h[j].srcOff > n || h[j].srcSize > n - h[j].srcOff || h[j].hdrSize > h[j].srcSize) { rc = GC_ERR_PARAM; break; }
-            h[j].dstOff = off;
-            if (!(h[j].flags & GC_ZD_F_SIZE_KNOWN)) { j++; break; }
-            if (h[j].contentSize > dstCap - off) { snprintf(c->err, sizeof(c->err), "destination too small"); rc = GC_ERR_DST_SMALL; break; }
-            off += h[j].contentSize;
+            const gc_zstd_frame& f = frames[j];
+            if (f.src_off > n || f.src_size > n - f.src_off || f.header_size + 3ull > f.src_size || !f.n_blocks || (uint64_t)f.n_blocks * 3u > f.src_size || nBlocks + f.n_blocks > 0x7FFFFFFFull) { rc = GC_ERR_PARAM; break; }
+            GcZdFrame& g = h[j];
+            g.srcOff = f.src_off; g.srcSize = f.src_size; g.dstOff = off; g.contentSize = f.content_size; g.flags = f.flags; g.hdrSize = f.header_size;
+            g.nBlocks = f.n_blocks; g.blockBase = (uint32_t)nBlocks; g.litBase = 0; g.seqBase = 0;
+            nBlocks += f.n_blocks;
+            if (!(f.flags & GC_ZD_F_SIZE_KNOWN)) { j++; break; }
+            if (f.content_size > dstCap - off) { snprintf(c->err, sizeof(c->err), "destination too small"); rc = GC_ERR_DST_SMALL; break; }
+            off += f.content_size;
         }
         if (rc != GC_OK) break;
         const size_t cnt = j - i;
-        const uint32_t wg = (uint32_t)(cnt < GC_ZD_MAX_WG ? cnt : GC_ZD_MAX_WG);
-        if ((rc = zd_ensure(c, wg, cnt)) != GC_OK) break;
+        if (cnt > c->zdFramesCap) {
+            hipFree(c->zdFrames); hipFree(c->zdResult); hipFree(c->zdTot); c->zdFrames = nullptr; c->zdResult = nullptr; c->zdTot = nullptr; c->zdFramesCap = 0;
+            const size_t cap = cnt + cnt / 2u + 64u;
+            if (hipMalloc((void**)&c->zdFrames, cap * sizeof(GcZdFrame)) != hipSuccess || hipMalloc((void**)&c->zdResult, cap * 8u) != hipSuccess ||
+                hipMalloc((void**)&c->zdTot, cap * 16u) != hipSuccess) { rc = GC_ERR_NOMEM; break; }
+            c->zdFramesCap = cap;
+        }
+        if ((rc = zd_grow(c, (void**)&c->zdBlocks, &c->zdBlocksCap, (size_t)nBlocks * sizeof(GcZdBlock))) != GC_OK) break;      // capacity in bytes
+        // index pass: block table, per-frame workspace needs
+        if (hipMemcpyAsync(c->zdFrames, h + i, cnt * sizeof(GcZdFrame), hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = GC_ERR_HIP; break; }
+        hipEventRecord(c->zdEv[0], c->stream);
+        gc_zstd_dec_launch_index(c->stream, (const uint8_t*)d_src, c->zdFrames, (uint32_t)cnt, c->zdBlocks, c->zdTot);
+        if (hipMemcpyAsync(res, c->zdTot, cnt * 16u, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+            snprintf(c->err, sizeof(c->err), "index kernel failed: %s", hipGetErrorString(hipGetLastError())); rc = GC_ERR_HIP; break;
+        }
+        uint64_t litTot = 0, seqTot = 0;
+        for (size_t k = 0; k < cnt; k++) { h[i + k].litBase = litTot; h[i + k].seqBase = seqTot; litTot += res[2u * k]; seqTot += res[2u * k + 1u]; }
+        if ((rc = zd_grow(c, (void**)&c->zdLit, &c->zdLitCap, (size_t)litTot + 64u)) != GC_OK) break;
+        if ((rc = zd_grow(c, &c->zdSeq, &c->zdSeqCap, (size_t)seqTot * 16u + 64u)) != GC_OK) break;
         if (hipMemcpyAsync(c->zdFrames, h + i, cnt * sizeof(GcZdFrame), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
             hipMemsetAsync(c->zdTicket, 0, 4, c->stream) != hipSuccess) { rc = GC_ERR_HIP; break; }
-        hipEventRecord(c->zdEv[0], c->stream);
-        gc_zstd_dec_launch(c->stream, wg, (const uint8_t*)d_src, (uint8_t*)d_dst, dstCap, c->zdFrames, (uint32_t)cnt, c->zdTicket, c->zdLit, c->zdSeq, c->zdLpos, c->zdResult);
+        gc_zstd_dec_launch_decode(c->stream, (const uint8_t*)d_src, n, (uint8_t*)d_dst, dstCap, c->zdFrames, (uint32_t)cnt, c->zdBlocks, (uint32_t)nBlocks, c->zdTicket,
+                                  c->zdLit, litTot + 64u, c->zdSeq, c->zdResult);
         hipEventRecord(c->zdEv[1], c->stream);
-        if (hipMemcpyAsync(res + i, c->zdResult, cnt * 8u, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
-            snprintf(c->err, sizeof(c->err), "decode kernel failed: %s", hipGetErrorString(hipGetLastError())); rc = GC_ERR_HIP; break;
+        if (hipMemcpyAsync(res, c->zdResult, cnt * 8u, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+            snprintf(c->err, sizeof(c->err), "decode kernels failed: %s", hipGetErrorString(hipGetLastError())); rc = GC_ERR_HIP; break;
         }
         float ms = 0.f; if (hipEventElapsedTime(&ms, c->zdEv[0], c->zdEv[1]) == hipSuccess) c->zdMs += ms;
-        for (size_t k = i; k < j; k++) {
+        for (size_t k = 0; k < cnt; k++) {
             const uint32_t st = (uint32_t)(res[k] >> 56);
             const uint64_t produced = res[k] & 0x00FFFFFFFFFFFFFFull;
-            if (st == GC_ZD_OK) { dstOff = h[k].dstOff + produced; continue; }
-            snprintf(c->err, sizeof(c->err), "frame %zu: %s", k, st == GC_ZD_DST_SMALL ? "destination too small" : st == GC_ZD_CHECKSUM ? "content checksum mismatch" :
+            if (st == GC_ZD_OK) { dstOff = h[i + k].dstOff + produced; continue; }
+            snprintf(c->err, sizeof(c->err), "frame %zu: %s", i + k, st == GC_ZD_DST_SMALL ? "destination too small" : st == GC_ZD_CHECKSUM ? "content checksum mismatch" :
                      st == GC_ZD_SIZE ? "content size field does not match" : st == GC_ZD_UNSUPPORTED ? "unsupported frame" : "corrupted data");
             rc = st == GC_ZD_DST_SMALL ? GC_ERR_DST_SMALL : (st == GC_ZD_UNSUPPORTED ? GC_ERR_PARAM : GC_ERR_CORRUPT);
             break;

@@ -1,23 +1,27 @@
 // gc_zstd_dec.hip -- zstd frame decoder on the device (the decoding half of the ZSTD method, what
 // NCompress::NZSTD::CDecoder::CodeSpec does with ZSTD_decompressStream, CPP/7zip/Compress/ZstdDecoder.cpp:66-240).
 //
-// Unit of parallelism: the frame.  Frames are independent by format (own window, own repeat offsets), and this engine's encoder
-// writes one frame per 8 MiB of input (one per 128 KiB at levels 1-2), so a stream of N MiB carries N/8 frames; a stream from the
-// reference's single-threaded encoder is one frame and decodes on one workgroup.  One workgroup (256 threads) takes one frame at a
-// time from a ticket counter and walks its blocks in order:
+// Three kernels per batch of frames:
 //
-//   stage     the compressed block (<= 128 KiB) goes into LDS -- every bit of it is read through LDS from here on
-//   tables    thread 0: literals header, Huffman weights (direct or FSE-coded) -> 2^11-entry decoding table in LDS;
-//             sequences header, the three FSE decoding tables (predefined / RLE / described / repeated) in LDS
-//   entropy   threads 64..67 decode the 1 or 4 Huffman streams into the workgroup's literal buffer in HBM while thread 0 decodes the
-//             sequence bitstream (the three interleaved FSE states are one serial chain by format), resolves the repeat offsets and
-//             writes (litLength, matchLength, offset, output position) records
-//   pass 1    all threads, one sequence each: literals -> the block image in LDS (which replaces the staged input), and every match
-//             whose source lies in front of the block (copied from the frame's output in HBM)
-//   pass 2    wave 0, sequence by sequence in order, 64 bytes per step: the matches that read the block itself
-//             (offset < 64: dst[k] = src[k mod offset], so overlapping copies are parallel as well)
-//   flush     the block image -> HBM, fence, next block
-//   checksum  XXH64 of the content (4 lanes = the 4 accumulators) when the frame carries one
+//   index     one thread per frame walks its block headers and, for compressed blocks, the literals header and the sequence count:
+//             the block table (GcZdBlock) with each block's place in the literal / sequence workspaces
+//   entropy   one workgroup (2 waves) per BLOCK -- blocks are entropy-coded independently of what they decode to, so a stream of
+//             one frame spreads over the chip just like a stream of a thousand:
+//               wave 1  Huffman tree (direct or FSE-coded weights) -> 2^11-entry table in LDS; the 1 or 4 streams are decoded
+//                       by 64 lanes at once: every lane starts at a guessed bit position inside its stream, Huffman codes
+//                       re-synchronise after a few symbols, each lane then restarts where its predecessor really ended until
+//                       nothing moves any more (usually one round), a prefix sum of the symbol counts places the output
+//               wave 0  the three FSE tables (predefined / RLE / described / repeated from an earlier block: found by walking the
+//                       block table backwards), then lane 0 decodes the sequence bitstream -- three interleaved FSE states, one
+//                       serial chain by format -- from 4 KiB pieces the whole wave stages in LDS, and writes one 16-byte record
+//                       per sequence.  Repeat offsets that reach into the history in front of the block stay symbolic
+//                       (GC_ZD_SYM: "incoming offset k minus delta").
+//   execute   one workgroup per FRAME, blocks in order, the block image in LDS:
+//               pass 1  all threads, one sequence each: symbolic offsets get their values, literals -> image, and every match whose
+//                       source lies in front of the block (copied from the frame's output in HBM)
+//               pass 2  wave 0, sequence by sequence, 64 bytes per step: the matches that read the block itself
+//                       (offset < 64: dst[k] = src[k mod offset], so overlapping copies are parallel as well)
+//               flush   image -> HBM; XXH64 of the content (4 lanes = the 4 accumulators) when the frame carries a checksum
 //
 // Restated from the reference decoder (the format is normative, every rule has to match):
 //   frame header, block headers        ZSTD_getFrameHeader_advanced zstd_decompress.c:447, ZSTD_decompressFrame :953, ZSTD_findFrameSizeInfo :734
@@ -26,7 +30,7 @@
 //   NCount, FSE decoding tables        FSE_readNCount_body entropy_common.c:42, ZSTD_buildFSETable_body zstd_decompress_block.c:485
 //   sequences header / decode / exec   ZSTD_decodeSeqHeaders :695, ZSTD_decodeSequence :1229, ZSTD_execSequence :1001
 //   content checksum                   XXH64 (xxhash.h), zstd_decompress.c:1034-1056
-// Not supported: dictionaries (a frame with a dictionary id is refused), legacy (v0.x) frames.
+// Not supported: dictionaries (a frame with a dictionary id is refused), legacy (v0.x) frames, offsets of 2 GiB and more.
 #include "gpucodec.h"
 #include "gc_zstd_dec.h"
 #include "gc_device.h"
@@ -49,14 +53,18 @@ __constant__ int16_t  kZdMLNorm[53] = { 1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,
 __constant__ int16_t  kZdOFNorm[29] = { 1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1 };
 
 #define ZD_HUF_LOG_MAX 11u
-#define ZD_PAD 32u
+#define ZD_WIN_L 256u             // bytes staged from the start of a block: literals header, tree description (<= 5 + 129)
+#define ZD_WIN_S 512u             // bytes staged from the symbol-modes byte on: modes + three NCount headers (well below 200)
 
-// shared scalars of the workgroup
-enum { ZV_ERR = 0, ZV_FRAME, ZV_BTYPE, ZV_BSIZE, ZV_LAST, ZV_LITKIND, ZV_LITREGEN, ZV_LITOFF, ZV_NSTREAMS, ZV_HUFLOG, ZV_HUFOK,
-       ZV_SEQPOS, ZV_NSEQ, ZV_LLLOG, ZV_OFLOG, ZV_MLLOG, ZV_FSEOK, ZV_OUTSIZE, ZV_LITEND, ZV_DPOSEND, ZV_STR0, ZV_STR1 = ZV_STR0 + 2, ZV_STR2 = ZV_STR0 + 4,
-       ZV_STR3 = ZV_STR0 + 6, ZV_RLEBYTE = ZV_STR0 + 8, ZV_REP0, ZV_REP1, ZV_REP2, ZV_COUNT };
-// literal kinds of a block
-enum { ZL_RAW = 0, ZL_RLE = 1, ZL_HUF = 2 };
+struct __attribute__((aligned(8))) GcU2 { uint32_t x, y; };
+
+// which of the three sequence symbol tables
+enum { ZT_LL = 0, ZT_OF = 1, ZT_ML = 2 };
+struct ZdConst {                  // the tables above, staged in LDS (a lane that walks them one entry at a time should not wait on HBM)
+    uint32_t llBase[36], mlBase[53];
+    uint8_t llBits[36], mlBits[53];
+    int16_t llNorm[36], mlNorm[53], ofNorm[29];
+};
 
 // ---- backward bit reader over a stream in LDS (bits are consumed from the end; the highest set bit of the last byte is the end mark) ----
 struct ZdBR { const uint8_t* p; int32_t off; };         // off = bits left below the read position; negative after an over-read
@@ -79,7 +87,7 @@ __device__ __forceinline__ uint32_t zd_br_peek(const ZdBR& r, uint32_t nb)
 }
 __device__ __forceinline__ uint32_t zd_br_read(ZdBR& r, uint32_t nb) { const uint32_t v = zd_br_peek(r, nb); r.off -= (int32_t)nb; return v; }
 
-// ---- NCount (forward, LSB first).  Returns the bytes used, 0 on error. ----
+// ---- NCount (forward, LSB first) from LDS.  Returns the bytes used, 0 on error. ----
 __device__ uint32_t zd_read_ncount(const uint8_t* p, uint32_t n, int16_t* norm, uint32_t maxSymAllowed, uint32_t maxLog, uint32_t* maxSymOut, uint32_t* logOut)
 {
     if (n < 1u) return 0;
@@ -128,35 +136,42 @@ __device__ uint32_t zd_read_ncount(const uint8_t* p, uint32_t n, int16_t* norm, 
     return bytes;
 }
 
-// ---- FSE decoding table: tab[state] = newStateBase | nbBits << 16 | symbol << 24 ----
-__device__ bool zd_fse_build(uint32_t* tab, const int16_t* norm, uint32_t maxSym, uint32_t log, uint16_t* symNext)
+// ---- FSE decoding table.  First the symbol of every cell (tab[cell].x), then
+//      tab[state] = { newStateBase | nbBits << 16 | extraBits << 24, baseline }  (for the Huffman weights: extraBits = 0, baseline = symbol) ----
+__device__ bool zd_fse_build(GcU2* tab, const int16_t* norm, uint32_t maxSym, uint32_t log, uint16_t* symNext, const ZdConst* k, int which)
 {
     const uint32_t size = 1u << log, mask = size - 1u, step = (size >> 1) + (size >> 3) + 3u;
     uint32_t high = size - 1u;
     for (uint32_t s = 0; s <= maxSym; s++) {
-        if (norm[s] == -1) { tab[high--] = s; symNext[s] = 1; }
+        if (norm[s] == -1) { tab[high--].x = s; symNext[s] = 1; }
         else symNext[s] = (uint16_t)norm[s];
     }
     uint32_t pos = 0;
     for (uint32_t s = 0; s <= maxSym; s++) {
         const int cnt = norm[s];
         for (int i = 0; i < cnt; i++) {
-            tab[pos] = s;
+            tab[pos].x = s;
             do pos = (pos + step) & mask; while (pos > high);
         }
     }
     if (pos != 0) return false;
     for (uint32_t u = 0; u < size; u++) {
-        const uint32_t s = tab[u];
+        const uint32_t s = tab[u].x;
         const uint32_t next = symNext[s]++;
         const uint32_t nb = log - gc_hibit32(next);
-        tab[u] = (((next << nb) - size) & 0xFFFFu) | (nb << 16) | (s << 24);
+        uint32_t base, extra;
+        if (which == ZT_LL) { base = k->llBase[s]; extra = k->llBits[s]; }
+        else if (which == ZT_ML) { base = k->mlBase[s]; extra = k->mlBits[s]; }
+        else if (which == ZT_OF) { base = 1u << s; extra = s; }
+        else { base = s; extra = 0; }
+        GcU2 e; e.x = (((next << nb) - size) & 0xFFFFu) | (nb << 16) | (extra << 24); e.y = base;
+        tab[u] = e;
     }
     return true;
 }
 
-// ---- Huffman tree description -> sHuf[2^log] = symbol | nbBits << 8.  Returns the bytes used, 0 on error. ----
-__device__ uint32_t zd_huf_read(const uint8_t* p, uint32_t n, uint16_t* sHuf, uint8_t* sW, int16_t* sNorm, uint16_t* sNext, uint32_t* sFseW, uint32_t* logOut)
+// ---- Huffman tree description (in LDS) -> sHuf[2^log] = symbol | nbBits << 8.  Returns the bytes used, 0 on error. ----
+__device__ uint32_t zd_huf_read(const uint8_t* p, uint32_t n, uint16_t* sHuf, uint8_t* sW, int16_t* sNorm, uint16_t* sNext, GcU2* sFseW, uint32_t* logOut)
 {
     if (n < 1u) return 0;
     const uint32_t hb = p[0];
@@ -171,7 +186,7 @@ __device__ uint32_t zd_huf_read(const uint8_t* p, uint32_t n, uint16_t* sHuf, ui
         uint32_t maxSym = 0, log = 0;
         const uint32_t h = zd_read_ncount(p + 1u, hb, sNorm, 255u, 6u, &maxSym, &log);
         if (!h || h >= hb) return 0;
-        if (!zd_fse_build(sFseW, sNorm, maxSym, log, sNext)) return 0;
+        if (!zd_fse_build(sFseW, sNorm, maxSym, log, sNext, nullptr, -1)) return 0;
         ZdBR r;
         if (!zd_br_init(r, p + 1u + h, hb - h)) return 0;
         uint32_t s1 = zd_br_read(r, log), s2 = zd_br_read(r, log);
@@ -179,15 +194,15 @@ __device__ uint32_t zd_huf_read(const uint8_t* p, uint32_t n, uint16_t* sHuf, ui
         nw = 0;
         for (;;) {
             if (nw > 253u) return 0;
-            uint32_t e = sFseW[s1];
-            sW[nw++] = (uint8_t)(e >> 24);
-            s1 = (e & 0xFFFFu) + zd_br_read(r, (e >> 16) & 0xFFu);
-            if (r.off < 0) { sW[nw++] = (uint8_t)(sFseW[s2] >> 24); break; }
+            GcU2 e = sFseW[s1];
+            sW[nw++] = (uint8_t)e.y;
+            s1 = (e.x & 0xFFFFu) + zd_br_read(r, (e.x >> 16) & 0xFFu);
+            if (r.off < 0) { sW[nw++] = (uint8_t)sFseW[s2].y; break; }
             if (nw > 253u) return 0;
             e = sFseW[s2];
-            sW[nw++] = (uint8_t)(e >> 24);
-            s2 = (e & 0xFFFFu) + zd_br_read(r, (e >> 16) & 0xFFu);
-            if (r.off < 0) { sW[nw++] = (uint8_t)(sFseW[s1] >> 24); break; }
+            sW[nw++] = (uint8_t)e.y;
+            s2 = (e.x & 0xFFFFu) + zd_br_read(r, (e.x >> 16) & 0xFFu);
+            if (r.off < 0) { sW[nw++] = (uint8_t)sFseW[s1].y; break; }
         }
     }
     uint32_t total = 0, rank1 = 0;
@@ -220,42 +235,433 @@ __device__ uint32_t zd_huf_read(const uint8_t* p, uint32_t n, uint16_t* sHuf, ui
     return used;
 }
 
-// one Huffman stream -> count bytes.  false = the stream does not end exactly where the symbols do
-__device__ bool zd_huf_stream(const uint8_t* p, uint32_t n, const uint16_t* sHuf, uint32_t log, uint8_t* out, uint32_t count)
+// ---- backward bit reader over a stream in HBM with a 64-bit register window ----
+struct ZdGW { const uint8_t* p; uint64_t w; int32_t wb; };          // w = stream bits [wb, wb + 64)
+__device__ __forceinline__ void zd_gw_fill(ZdGW& g, int32_t off)      // afterwards wb + 56 < off <= wb + 64 (for off > 0)
 {
-    ZdBR r;
-    if (!zd_br_init(r, p, n)) return false;
-    for (uint32_t i = 0; i < count; i++) {
-        const uint32_t e = sHuf[zd_br_peek(r, log)];
-        out[i] = (uint8_t)e;
-        r.off -= (int32_t)(e >> 8);
+    const int32_t b = ((off + 7) >> 3) - 8;
+    g.wb = b * 8;
+    if (b >= 0) g.w = gc_ld64(g.p + b);
+    else {
+        uint64_t v = 0;
+        for (int32_t i = 0; i < b + 8; i++) v |= (uint64_t)g.p[i] << (8 * i);
+        g.w = b <= -8 ? 0ull : v << (uint32_t)(-b * 8);
     }
-    return r.off == 0;
+}
+__device__ __forceinline__ uint32_t zd_gw_peek(ZdGW& g, int32_t off, uint32_t nb)       // nb <= 11
+{
+    if (off - (int32_t)nb < g.wb || off > g.wb + 64) zd_gw_fill(g, off);
+    const int32_t sh = off - (int32_t)nb - g.wb;
+    const uint64_t v = sh >= 0 ? g.w >> (uint32_t)sh : g.w << (uint32_t)(-sh);
+    return (uint32_t)v & ((1u << nb) - 1u);
 }
 
-// ---- one of the three symbol tables of the sequences section.  Returns the bytes used (0 is valid for predefined / repeat), -1 on error ----
-__device__ int zd_seq_table(uint32_t mode, const uint8_t* p, uint32_t n, uint32_t* tab, uint32_t* logVar, uint32_t maxSym, uint32_t maxLog,
-                            const int16_t* defNorm, uint32_t defMaxSym, uint32_t defLog, bool haveOld, int16_t* sNorm, uint16_t* sNext)
+// Source of a repeated table: the nearest earlier block of the frame (compressed, with sequences) whose mode for this table is not
+// "repeat".  Returns the block index or 0xFFFFFFFF.
+__device__ uint32_t zd_find_table_source(const GcZdBlock* blocks, uint32_t first, uint32_t b, int which)
 {
+    const uint32_t sh = which == ZT_LL ? 6u : (which == ZT_OF ? 4u : 2u);
+    for (uint32_t k = b; k > first; ) {
+        k--;
+        const uint32_t ty = blocks[k].type;
+        if ((ty & 3u) != 2u || (ty & GC_ZD_B_BAD) || !blocks[k].nSeq) continue;
+        if (((blocks[k].modes >> sh) & 3u) != 3u) return k;
+    }
+    return 0xFFFFFFFFu;
+}
+
+// One symbol table of the sequences section from the window `win` (modes byte at win[0]), p = read position inside the window.
+// Returns the new read position, 0 on error.  mode 3 is resolved by the caller.
+__device__ uint32_t zd_seq_table(uint32_t mode, const uint8_t* win, uint32_t winLen, uint32_t p, GcU2* tab, uint32_t* logOut, int which,
+                                 const ZdConst* k, int16_t* sNorm, uint16_t* sNext)
+{
+    const uint32_t maxSym = which == ZT_LL ? 35u : (which == ZT_OF ? 30u : 52u), maxLog = which == ZT_OF ? 8u : 9u;
     if (mode == 0u) {
-        for (uint32_t s = 0; s <= defMaxSym; s++) sNorm[s] = defNorm[s];
-        if (!zd_fse_build(tab, sNorm, defMaxSym, defLog, sNext)) return -1;
-        *logVar = defLog; return 0;
+        const int16_t* dn = which == ZT_LL ? k->llNorm : (which == ZT_OF ? k->ofNorm : k->mlNorm);
+        const uint32_t dm = which == ZT_LL ? 35u : (which == ZT_OF ? 28u : 52u), dl = which == ZT_OF ? 5u : 6u;
+        for (uint32_t s = 0; s <= dm; s++) sNorm[s] = dn[s];
+        if (!zd_fse_build(tab, sNorm, dm, dl, sNext, k, which)) return 0;
+        *logOut = dl; return p;
     }
     if (mode == 1u) {
-        if (n < 1u || p[0] > maxSym) return -1;
-        tab[0] = (uint32_t)p[0] << 24; *logVar = 0; return 1;
+        if (p >= winLen) return 0;
+        const uint32_t s = win[p];
+        if (s > maxSym) return 0;
+        GcU2 e;
+        if (which == ZT_LL) { e.y = k->llBase[s]; e.x = (uint32_t)k->llBits[s] << 24; }
+        else if (which == ZT_ML) { e.y = k->mlBase[s]; e.x = (uint32_t)k->mlBits[s] << 24; }
+        else { e.y = 1u << s; e.x = s << 24; }
+        tab[0] = e; *logOut = 0; return p + 1u;
     }
-    if (mode == 2u) {
-        uint32_t ms = 0, log = 0;
-        const uint32_t h = zd_read_ncount(p, n, sNorm, maxSym, maxLog, &ms, &log);
-        if (!h) return -1;
-        if (!zd_fse_build(tab, sNorm, ms, log, sNext)) return -1;
-        *logVar = log; return (int)h;
-    }
-    return haveOld ? 0 : -1;
+    uint32_t ms = 0, log = 0;
+    if (p >= winLen) return 0;
+    const uint32_t h = zd_read_ncount(win + p, winLen - p, sNorm, maxSym, maxLog, &ms, &log);
+    if (!h) return 0;
+    if (!zd_fse_build(tab, sNorm, ms, log, sNext, k, which)) return 0;
+    *logOut = log; return p + h;
 }
 
+// bytes of table `which` in a window (to skip it): 0 on error for mode 2
+__device__ int zd_seq_table_skip(uint32_t mode, const uint8_t* win, uint32_t winLen, uint32_t p, int which, int16_t* sNorm)
+{
+    if (mode == 0u || mode == 3u) return 0;
+    if (mode == 1u) return 1;
+    const uint32_t maxSym = which == ZT_LL ? 35u : (which == ZT_OF ? 30u : 52u), maxLog = which == ZT_OF ? 8u : 9u;
+    uint32_t ms = 0, log = 0;
+    if (p >= winLen) return -1;
+    const uint32_t h = zd_read_ncount(win + p, winLen - p, sNorm, maxSym, maxLog, &ms, &log);
+    return h ? (int)h : -1;
+}
+
+// lane 0 only: n bytes from HBM (8 at a time, bounded by the end of the compressed stream) into LDS
+__device__ void zd_load_window(uint8_t* win, const uint8_t* src, uint64_t srcSize, uint64_t from, uint32_t n)
+{
+    for (uint32_t i = 0; i < n; i += 8u) {
+        uint64_t v = 0;
+        if (from + i + 8u <= srcSize) v = gc_ld64(src + from + i);
+        else for (uint32_t k = 0; k < 8u && from + i + k < srcSize; k++) v |= (uint64_t)src[from + i + k] << (8u * k);
+        __builtin_memcpy(win + i, &v, 8);
+    }
+}
+
+// =============================================================== index kernel ===============================================================
+extern "C" __global__ void __launch_bounds__(64)
+gc_zstd_dec_index_kernel(const uint8_t* __restrict__ src, const GcZdFrame* __restrict__ frames, uint32_t nFrames, GcZdBlock* blocks, uint64_t* frameTot)
+{
+    const uint32_t f = blockIdx.x * 64u + threadIdx.x;
+    if (f >= nFrames) return;
+    const GcZdFrame fr = frames[f];
+    const uint8_t* const fsrc = src + fr.srcOff;
+    const uint64_t srcEnd = fr.srcSize - ((fr.flags & GC_ZD_F_CHECKSUM) ? 4u : 0u);
+    uint64_t ip = fr.hdrSize, lit = 0, seq = 0;
+    bool broken = false;
+    for (uint32_t k = 0; k < fr.nBlocks; k++) {
+        GcZdBlock e;
+        e.srcOff = 0; e.litOff = lit; e.seqOff = seq; e.size = 0; e.type = GC_ZD_B_BAD | GC_ZD_B_LAST; e.regen = 0; e.litInfo = 0; e.comp = 0; e.nSeq = 0; e.seqPos = 0; e.modes = 0;
+        e.frame = f; e.status = GC_ZD_CORRUPT; e.outSize = 0; e.lposEnd = 0; e.dposEnd = 0; e.rep[0] = e.rep[1] = e.rep[2] = 0; e.pad = 0;
+        if (!broken && ip + 3u <= srcEnd) {
+            const uint32_t h = (uint32_t)fsrc[ip] | ((uint32_t)fsrc[ip + 1] << 8) | ((uint32_t)fsrc[ip + 2] << 16);
+            const uint32_t bt = (h >> 1) & 3u, bs = h >> 3, last = h & 1u;
+            const uint64_t payload = bt == 1u ? 1u : bs;
+            if (bt == 3u || bs > GC_ZSTD_BLOCK_MAX || ip + 3u + payload > srcEnd || (last != 0u) != (k + 1u == fr.nBlocks)) broken = true;
+            else {
+                e.srcOff = fr.srcOff + ip + 3u; e.size = (uint32_t)payload; e.type = bt | (last ? GC_ZD_B_LAST : 0u); e.status = GC_ZD_OK;
+                if (bt < 2u) e.regen = bs;
+                else {
+                    const uint8_t* const b = fsrc + ip + 3u;
+                    bool bad = bs < 2u;
+                    uint32_t hdr = 0, regen = 0, comp = 0, nStreams = 1, lt = 0;
+                    if (!bad) {
+                        const uint32_t b0 = b[0], sf = (b0 >> 2) & 3u;
+                        lt = b0 & 3u;
+                        if (lt < 2u) {
+                            if (!(sf & 1u)) { hdr = 1; regen = b0 >> 3; }
+                            else if (sf == 1u) { hdr = 2; regen = (b0 | ((uint32_t)b[1] << 8)) >> 4; }
+                            else { hdr = 3; if (bs < 3u) bad = true; else regen = (b0 | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16)) >> 4; }
+                            comp = lt == 0u ? regen : 1u;
+                        } else {
+                            hdr = sf < 2u ? 3u : (sf == 2u ? 4u : 5u);
+                            if (bs < hdr) bad = true;
+                            else {
+                                uint64_t v = 0;
+                                for (uint32_t i = 0; i < hdr; i++) v |= (uint64_t)b[i] << (8u * i);
+                                if (sf < 2u) { regen = (uint32_t)(v >> 4) & 0x3FFu; comp = (uint32_t)(v >> 14) & 0x3FFu; nStreams = sf == 0u ? 1u : 4u; }
+                                else if (sf == 2u) { regen = (uint32_t)(v >> 4) & 0x3FFFu; comp = (uint32_t)(v >> 18) & 0x3FFFu; nStreams = 4; }
+                                else { regen = (uint32_t)(v >> 4) & 0x3FFFFu; comp = (uint32_t)(v >> 22) & 0x3FFFFu; nStreams = 4; }
+                                if (regen == 0u) bad = true;
+                            }
+                        }
+                        if (regen > GC_ZSTD_BLOCK_MAX || (uint64_t)hdr + comp >= bs) bad = true;       // at least the sequence count follows
+                    }
+                    uint32_t nSeq = 0, p = hdr + comp;
+                    if (!bad) {
+                        const uint32_t b0 = b[p++];
+                        if (b0 < 128u) nSeq = b0;
+                        else if (b0 < 255u) { if (p >= bs) bad = true; else nSeq = ((b0 - 128u) << 8) + b[p++]; }
+                        else { if (p + 2u > bs) bad = true; else { nSeq = (uint32_t)b[p] + ((uint32_t)b[p + 1] << 8) + 0x7F00u; p += 2u; } }
+                    }
+                    if (!bad) {
+                        if (nSeq == 0u) { if (p != bs) bad = true; }
+                        else if (p >= bs) bad = true;
+                        else { e.modes = b[p]; if (e.modes & 3u) bad = true; }
+                    }
+                    if (bad) { e.type |= GC_ZD_B_BAD; e.status = GC_ZD_CORRUPT; }
+                    else {
+                        e.regen = regen; e.litInfo = lt | (nStreams << 2) | (hdr << 8); e.comp = comp; e.nSeq = nSeq; e.seqPos = p;
+                        if (lt >= 2u) lit += (regen + 15u) & ~15ull;
+                        seq += nSeq;
+                    }
+                }
+                ip += 3u + payload;
+            }
+        } else broken = true;
+        blocks[fr.blockBase + k] = e;
+    }
+    frameTot[2u * f] = lit + 64u; frameTot[2u * f + 1u] = seq + 1u;
+}
+
+// =============================================================== entropy kernel ===============================================================
+// literal streams, wave 1.  G lanes per stream; every lane owns a slice of its stream's bit range.
+__device__ bool zd_huf_parallel(const uint8_t* sp, uint32_t n, uint32_t count, uint8_t* out, const uint16_t* sHuf, uint32_t log, uint32_t G, uint32_t li, bool valid)
+{
+    // (all 64 lanes of the wave call this together; lanes of a stream that failed to open keep valid = false and only take part in the shuffles)
+    ZdGW g; g.p = sp; g.w = 0; g.wb = 0x40000000;
+    int32_t B = 0;
+    if (valid) {
+        const uint32_t last = n ? sp[n - 1u] : 0u;
+        if (!last) valid = false; else B = (int32_t)((n - 1u) * 8u + gc_hibit32(last));
+    }
+    const int32_t S = valid ? ((B + (int32_t)G - 1) / (int32_t)G < 64 ? 64 : (B + (int32_t)G - 1) / (int32_t)G) : 64;
+    int32_t lo = B - (int32_t)(li + 1u) * S; if (lo < 0 || li + 1u == G) lo = 0;
+    int32_t start = B - (int32_t)li * S;                 // first guess; exact for lane 0
+    int32_t e = start; uint32_t c = 0;
+    int32_t chkOff = -1; uint32_t chkIdx = 0;            // a position the previous pass went through, and how many symbols it had decoded by then
+    bool first = true;
+    for (;;) {
+        int32_t prevE = __shfl_up(e, 1u, (int)G);
+        if (li == 0u) prevE = B;
+        const bool changed = valid && (first || prevE != start);
+        if (changed) {
+            start = first ? start : prevE;
+            int32_t off = start; uint32_t k = 0;
+            const int32_t oldChk = chkOff; const uint32_t oldIdx = chkIdx, oldC = c; const int32_t oldE = e;
+            chkOff = -1; chkIdx = 0;
+            bool joined = false;
+            while (off > lo) {
+                const uint32_t en = sHuf[zd_gw_peek(g, off, log)];
+                off -= (int32_t)(en >> 8); k++;
+                if (k == 24u) { chkOff = off; chkIdx = k; }
+                if (off == oldChk && off > lo) {         // from here on the previous pass saw the same bits
+                    if (chkOff < 0) { chkOff = off; chkIdx = k; }
+                    c = k + (oldC - oldIdx); e = oldE; joined = true; break;
+                }
+            }
+            if (!joined) { c = k; e = off; }
+        }
+        first = false;
+        if (!__any(changed)) break;
+    }
+    // placement: exclusive prefix of the symbol counts inside the group
+    uint32_t incl = c;
+    for (uint32_t d = 1; d < G; d <<= 1) { const uint32_t v = __shfl_up(incl, d, (int)G); if (li >= d) incl += v; }
+    const uint32_t total = __shfl(incl, (int)(G - 1u), (int)G);
+    const int32_t lastE = __shfl(e, (int)(G - 1u), (int)G);
+    const bool ok = valid && total == count && lastE == 0;
+    if (ok) {
+        uint8_t* o = out + (incl - c);
+        int32_t off = start;
+        for (uint32_t k = 0; k < c; k++) {
+            const uint32_t en = sHuf[zd_gw_peek(g, off, log)];
+            o[k] = (uint8_t)en;
+            off -= (int32_t)(en >> 8);
+        }
+    }
+    return ok;
+}
+
+extern "C" __global__ void __launch_bounds__(GC_ZD_ENT_T)
+gc_zstd_dec_entropy_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const GcZdFrame* __restrict__ frames, GcZdBlock* blocks, uint8_t* litWork, GcU4* seqWork)
+{
+    __shared__ uint16_t sHuf[1u << ZD_HUF_LOG_MAX];
+    __shared__ GcU2 sLL[512], sML[512], sOF[256], sFseW[64];
+    __shared__ __attribute__((aligned(16))) uint8_t sBuf[GC_ZD_CHUNK + 32u];
+    __shared__ __attribute__((aligned(16))) uint8_t sWinL[ZD_WIN_L + 8u], sWinS[ZD_WIN_S + 8u], sWinR[ZD_WIN_S + 8u];
+    __shared__ int16_t sNormA[64], sNormB[256];
+    __shared__ uint16_t sNextA[64], sNextB[256];
+    __shared__ uint8_t sW[256];
+    __shared__ ZdConst sK;
+    __shared__ uint32_t sV[16];       // 0 err wave 0, 1 err wave 1, 2 huf log, 3 tree bytes, 4 seq stream start, 5..7 table logs
+
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6, b = blockIdx.x;
+    const uint32_t ty = blocks[b].type;
+    if ((ty & 3u) != 2u || (ty & GC_ZD_B_BAD)) return;
+    const GcZdBlock e = blocks[b];
+    const GcZdFrame fr = frames[e.frame];
+    const uint8_t* const bsrc = src + e.srcOff;
+    const uint32_t bs = e.size;
+
+    for (uint32_t i = t; i < 36u; i += GC_ZD_ENT_T) { sK.llBase[i] = kZdLLBase[i]; sK.llBits[i] = kZdLLBits[i]; sK.llNorm[i] = kZdLLNorm[i]; }
+    for (uint32_t i = t; i < 53u; i += GC_ZD_ENT_T) { sK.mlBase[i] = kZdMLBase[i]; sK.mlBits[i] = kZdMLBits[i]; sK.mlNorm[i] = kZdMLNorm[i]; }
+    for (uint32_t i = t; i < 29u; i += GC_ZD_ENT_T) sK.ofNorm[i] = kZdOFNorm[i];
+    for (uint32_t i = t; i < ZD_WIN_L + 8u; i += GC_ZD_ENT_T) sWinL[i] = i < bs ? bsrc[i] : (uint8_t)0;
+    for (uint32_t i = t; i < ZD_WIN_S + 8u; i += GC_ZD_ENT_T) sWinS[i] = e.seqPos + i < bs ? bsrc[e.seqPos + i] : (uint8_t)0;
+    if (t < 16u) sV[t] = 0;
+    __syncthreads();
+
+    if (wave == 1u) {
+        // ------------------------------------------------ literals ------------------------------------------------
+        const uint32_t lt = e.litInfo & 3u, nStreams = (e.litInfo >> 2) & 7u, hdr = e.litInfo >> 8;
+        if (lt >= 2u) {
+            if (lane == 0u) {
+                uint32_t log = 0, tree = 0, err = 0;
+                if (lt == 2u) {
+                    const uint32_t avail = e.comp < ZD_WIN_L - hdr ? e.comp : ZD_WIN_L - hdr;
+                    tree = zd_huf_read(sWinL + hdr, avail, sHuf, sW, sNormB, sNextB, sFseW, &log);
+                    if (!tree) err = 1;
+                } else {                                   // treeless: the tree of the nearest earlier block that carries one
+                    uint32_t k = b; bool found = false;
+                    while (k > fr.blockBase) {
+                        k--;
+                        if ((blocks[k].type & 3u) == 2u && !(blocks[k].type & GC_ZD_B_BAD) && (blocks[k].litInfo & 3u) == 2u) { found = true; break; }
+                    }
+                    if (!found) err = 1;
+                    else {
+                        const uint32_t h2 = blocks[k].litInfo >> 8, c2 = blocks[k].comp;
+                        zd_load_window(sWinL, src, srcSize, blocks[k].srcOff + h2, ZD_WIN_L);
+                        const uint32_t used = zd_huf_read(sWinL, c2 < ZD_WIN_L ? c2 : ZD_WIN_L, sHuf, sW, sNormB, sNextB, sFseW, &log);
+                        if (!used) err = 1;
+                    }
+                }
+                sV[2] = log; sV[3] = tree; if (err) sV[1] = 1;
+            }
+            gc_wave_sync();
+            const uint32_t log = sV[2], tree = sV[3];
+            bool ok = sV[1] == 0u;
+            const uint32_t base = hdr + tree, avail = ok && e.comp >= tree ? e.comp - tree : 0u;
+            const uint32_t G = nStreams == 4u ? 16u : 64u, q = nStreams == 4u ? lane >> 4 : 0u, li = lane & (G - 1u);
+            uint32_t sOff = base, sLen = avail, cnt = e.regen, oOff = 0;
+            if (nStreams == 4u) {
+                if (avail < 10u || e.regen < 4u) ok = false;
+                else {
+                    const uint32_t s1 = (uint32_t)bsrc[base] | ((uint32_t)bsrc[base + 1] << 8), s2 = (uint32_t)bsrc[base + 2] | ((uint32_t)bsrc[base + 3] << 8),
+                                   s3 = (uint32_t)bsrc[base + 4] | ((uint32_t)bsrc[base + 5] << 8);
+                    const uint32_t seg = (e.regen + 3u) >> 2;
+                    if ((uint64_t)6u + s1 + s2 + s3 >= avail || 3u * seg > e.regen) ok = false;
+                    else {
+                        sOff = base + 6u + (q > 0u ? s1 : 0u) + (q > 1u ? s2 : 0u) + (q > 2u ? s3 : 0u);
+                        sLen = q == 0u ? s1 : (q == 1u ? s2 : (q == 2u ? s3 : avail - 6u - s1 - s2 - s3));
+                        oOff = q * seg; cnt = q == 3u ? e.regen - 3u * seg : seg;
+                    }
+                }
+            } else if (!avail) ok = false;
+            uint8_t* const out = litWork + fr.litBase + e.litOff + oOff;
+            const bool good = zd_huf_parallel(bsrc + sOff, sLen, cnt, out, sHuf, log, G, li, ok);
+            if (!good) sV[1] = 1;
+        }
+    } else {
+        // ------------------------------------------------ sequences ------------------------------------------------
+        const uint32_t nSeq = e.nSeq;
+        uint32_t err = 0, dpos = 0, lpos = 0;
+        uint32_t rep0 = GC_ZD_SYM | 0u, rep1 = GC_ZD_SYM | 1u, rep2 = GC_ZD_SYM | 2u;
+        if (nSeq) {
+            if (lane == 0u) {
+                uint32_t p = 1;                                // behind the modes byte
+                const int order[3] = { ZT_LL, ZT_OF, ZT_ML };
+                for (int i = 0; i < 3 && !err; i++) {
+                    const int which = order[i];
+                    GcU2* const tab = which == ZT_LL ? sLL : (which == ZT_OF ? sOF : sML);
+                    const uint32_t mode = (e.modes >> (which == ZT_LL ? 6u : (which == ZT_OF ? 4u : 2u))) & 3u;
+                    if (mode != 3u) { p = zd_seq_table(mode, sWinS, ZD_WIN_S, p, tab, &sV[5 + which], which, &sK, sNormA, sNextA); if (!p) err = 1; }
+                    else {
+                        const uint32_t k = zd_find_table_source(blocks, fr.blockBase, b, which);
+                        if (k == 0xFFFFFFFFu) { err = 1; break; }
+                        const uint32_t m2 = blocks[k].modes;
+                        const uint32_t mk = (m2 >> (which == ZT_LL ? 6u : (which == ZT_OF ? 4u : 2u))) & 3u;
+                        uint32_t q = 1;
+                        if (mk != 0u) {
+                            zd_load_window(sWinR, src, srcSize, blocks[k].srcOff + blocks[k].seqPos, ZD_WIN_S);
+                            for (int y = 0; y < 3 && order[y] != which; y++) {
+                                const int w2 = order[y];
+                                const int sk = zd_seq_table_skip((m2 >> (w2 == ZT_LL ? 6u : (w2 == ZT_OF ? 4u : 2u))) & 3u, sWinR, ZD_WIN_S, q, w2, sNormA);
+                                if (sk < 0) { err = 1; break; }
+                                q += (uint32_t)sk;
+                            }
+                        }
+                        if (!err && !zd_seq_table(mk, sWinR, ZD_WIN_S, q, tab, &sV[5 + which], which, &sK, sNormA, sNextA)) err = 1;
+                    }
+                }
+                if (!err && (p > ZD_WIN_S || e.seqPos + p >= bs)) err = 1;
+                sV[4] = e.seqPos + p; if (err) sV[0] = 1;
+            }
+            gc_wave_sync();
+            err = sV[0];
+            const uint32_t seqStart = sV[4];
+            const uint8_t* const sp = bsrc + seqStart;
+            const uint32_t n = err ? 1u : bs - seqStart;
+            int32_t off = 0;
+            if (!err) {
+                const uint32_t last = sp[n - 1u];
+                if (!last) err = 1; else off = (int32_t)((n - 1u) * 8u + gc_hibit32(last));
+            }
+            const uint32_t llLog = sV[5 + ZT_LL], ofLog = sV[5 + ZT_OF], mlLog = sV[5 + ZT_ML];
+            uint32_t stLL = 0, stOF = 0, stML = 0, j = 0;
+            GcU4* const seq = seqWork + fr.seqBase + e.seqOff;
+            bool first = true;
+            while (!err) {
+                // stage the piece of the bitstream the next sequences read: bytes [cLo, hi + 8)
+                const uint32_t hi = (uint32_t)(off + 7) >> 3;
+                const uint32_t cLo = hi > GC_ZD_CHUNK ? (hi - GC_ZD_CHUNK) & ~7u : 0u;
+                for (uint32_t i = lane * 8u; i < hi + 8u - cLo; i += 512u) {
+                    uint64_t v = 0;
+                    if (cLo + i + 8u <= n) v = gc_ld64(sp + cLo + i);
+                    else for (uint32_t k = 0; k < 8u && cLo + i + k < n; k++) v |= (uint64_t)sp[cLo + i + k] << (8u * k);
+                    __builtin_memcpy(sBuf + i, &v, 8);
+                }
+                gc_wave_sync();
+                if (lane == 0u) {
+#define ZD_PK(nbits, at) ({ const int32_t pos_ = (at) - (int32_t)(nbits); const uint64_t v_ = pos_ >= 0 ? gc_ld64(sBuf + (((uint32_t)pos_ >> 3) - cLo)) >> ((uint32_t)pos_ & 7u) \
+                                                          : (pos_ <= -64 ? 0ull : gc_ld64(sBuf) << (uint32_t)(-pos_)); (uint32_t)(v_ & ((1ull << (nbits)) - 1ull)); })
+                    if (first) {
+                        stLL = ZD_PK(llLog, off); off -= (int32_t)llLog;
+                        stOF = ZD_PK(ofLog, off); off -= (int32_t)ofLog;
+                        stML = ZD_PK(mlLog, off); off -= (int32_t)mlLog;
+                        if (off < 0) err = 1;
+                    }
+                    while (!err && j < nSeq && (cLo == 0u || ((uint32_t)off >> 3) >= cLo + 16u)) {
+                        const GcU2 eLL = sLL[stLL], eOF = sOF[stOF], eML = sML[stML];
+                        const uint32_t ofb = eOF.x >> 24, mlb = eML.x >> 24, llb = eLL.x >> 24;
+                        if (ofb > 30u) { err = GC_ZD_UNSUPPORTED; break; }
+                        const uint32_t ofv = eOF.y + ZD_PK(ofb, off); off -= (int32_t)ofb;
+                        const uint32_t ml = eML.y + ZD_PK(mlb, off); off -= (int32_t)mlb;
+                        const uint32_t ll = eLL.y + ZD_PK(llb, off); off -= (int32_t)llb;
+                        uint32_t o;
+                        if (ofv > 3u) { o = ofv - 3u; rep2 = rep1; rep1 = rep0; rep0 = o; }
+                        else {
+                            const uint32_t idx = ofv - 1u + (ll == 0u ? 1u : 0u);
+                            if (idx == 0u) o = rep0;
+                            else {
+                                if (idx == 3u) {
+                                    if (rep0 & GC_ZD_SYM) o = rep0 + 4u;          // delta + 1
+                                    else { o = rep0 - 1u; if (!o) { err = 1; break; } }
+                                } else o = idx == 1u ? rep1 : rep2;
+                                if (idx != 1u) rep2 = rep1;
+                                rep1 = rep0; rep0 = o;
+                            }
+                        }
+                        if (j + 1u < nSeq) {
+                            const uint32_t nl = (eLL.x >> 16) & 0xFFu, nm = (eML.x >> 16) & 0xFFu, no = (eOF.x >> 16) & 0xFFu;
+                            stLL = (eLL.x & 0xFFFFu) + ZD_PK(nl, off); off -= (int32_t)nl;
+                            stML = (eML.x & 0xFFFFu) + ZD_PK(nm, off); off -= (int32_t)nm;
+                            stOF = (eOF.x & 0xFFFFu) + ZD_PK(no, off); off -= (int32_t)no;
+                        }
+                        if (off < 0 || (uint64_t)lpos + ll > e.regen || (uint64_t)dpos + ll + ml > GC_ZSTD_BLOCK_MAX) { err = 1; break; }
+                        GcU4 rec; rec.x = ll | (ml << 18); rec.y = (ml >> 14) | (lpos << 4); rec.z = o; rec.w = dpos;
+                        seq[j] = rec;
+                        dpos += ll + ml; lpos += ll; j++;
+                    }
+#undef ZD_PK
+                }
+                first = false;
+                j = __shfl(j, 0); off = __shfl(off, 0); err = __shfl(err, 0);
+                if (j >= nSeq) break;
+            }
+            if (!err && off != 0) err = 1;
+            if (err && lane == 0u) sV[0] = err;
+        }
+        if (lane == 0u) { sV[8] = dpos; sV[9] = lpos; sV[10] = rep0; sV[11] = rep1; sV[12] = rep2; }
+    }
+    __syncthreads();
+    if (t == 0) {
+        const uint32_t dpos = sV[8], lpos = sV[9];
+        uint32_t status = sV[0] ? (sV[0] == GC_ZD_UNSUPPORTED ? GC_ZD_UNSUPPORTED : GC_ZD_CORRUPT) : (sV[1] ? GC_ZD_CORRUPT : GC_ZD_OK);
+        const uint32_t outSize = dpos + (e.regen - lpos);
+        if (!status && outSize > GC_ZSTD_BLOCK_MAX) status = GC_ZD_CORRUPT;
+        blocks[b].status = status; blocks[b].outSize = outSize; blocks[b].lposEnd = lpos; blocks[b].dposEnd = dpos;
+        blocks[b].rep[0] = sV[10]; blocks[b].rep[1] = sV[11]; blocks[b].rep[2] = sV[12];
+    }
+}
+
+// =============================================================== execution kernel ===============================================================
 __device__ __forceinline__ uint64_t zd_rotl(uint64_t v, uint32_t r) { return (v << r) | (v >> (64u - r)); }
 #define XP1 0x9E3779B185EBCA87ull
 #define XP2 0xC2B2AE3D27D4EB4Full
@@ -264,239 +670,93 @@ __device__ __forceinline__ uint64_t zd_rotl(uint64_t v, uint32_t r) { return (v 
 #define XP5 0x27D4EB2F165667C5ull
 __device__ __forceinline__ uint64_t zd_xround(uint64_t acc, uint64_t in) { return zd_rotl(acc + in * XP2, 31) * XP1; }
 
-extern "C" __global__ void __launch_bounds__(GC_ZD_T)
-gc_zstd_dec_kernel(const uint8_t* __restrict__ src, uint8_t* dst, uint64_t dstCap, const GcZdFrame* __restrict__ frames, uint32_t nFrames,
-                   uint32_t* ticket, uint8_t* litWork, GcU4* seqWork, uint32_t* lposWork, uint64_t* result)
+// n bytes from HBM to LDS; src may be read up to 7 bytes past src + n when that stays below srcLimit
+__device__ __forceinline__ void zd_copy_in(uint8_t* d, const uint8_t* s, uint32_t n, const uint8_t* srcLimit)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t sOut[GC_ZSTD_BLOCK_MAX + ZD_PAD];
-    __shared__ uint16_t sHuf[1u << ZD_HUF_LOG_MAX];
-    __shared__ uint32_t sLL[512], sOF[256], sML[512], sFseW[64];
-    __shared__ int16_t sNorm[256];
-    __shared__ uint16_t sNext[256];
-    __shared__ uint8_t sW[256];
-    __shared__ uint32_t sV[ZV_COUNT];
-    __shared__ uint64_t sAcc[4];
+    uint32_t k = 0;
+    for (; k + 8u <= n; k += 8u) { const uint64_t v = gc_ld64(s + k); __builtin_memcpy(d + k, &v, 8); }
+    if (k < n) {
+        if (s + k + 8u <= srcLimit) { uint64_t v = gc_ld64(s + k); for (; k < n; k++) { d[k] = (uint8_t)v; v >>= 8; } }
+        else for (; k < n; k++) d[k] = s[k];
+    }
+}
 
+enum { XV_ERR = 0, XV_FRAME, XV_REP0, XV_REP1, XV_REP2, XV_COUNT };
+
+extern "C" __global__ void __launch_bounds__(GC_ZD_T)
+gc_zstd_dec_exec_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint8_t* dst, uint64_t dstCap, const GcZdFrame* __restrict__ frames, uint32_t nFrames,
+                        const GcZdBlock* __restrict__ blocks, uint32_t* ticket, const uint8_t* litWork, uint64_t litWorkSize, GcU4* seqWork, uint64_t* result)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t sOut[GC_ZSTD_BLOCK_MAX + 32u];
+    __shared__ uint32_t sV[XV_COUNT];
+    __shared__ uint64_t sAcc[4];
     const uint32_t t = threadIdx.x, lane = t & 63u;
-    uint8_t* const lit = litWork + (size_t)blockIdx.x * GC_ZD_LIT_STRIDE;
-    GcU4* const seq = seqWork + (size_t)blockIdx.x * GC_ZD_MAX_SEQ;
-    uint32_t* const lposA = lposWork + (size_t)blockIdx.x * GC_ZD_MAX_SEQ;
 
     for (;;) {
-        if (t == 0) sV[ZV_FRAME] = atomicAdd(ticket, 1u);
+        if (t == 0) sV[XV_FRAME] = atomicAdd(ticket, 1u);
         __syncthreads();
-        const uint32_t f = sV[ZV_FRAME];
+        const uint32_t f = sV[XV_FRAME];
         __syncthreads();
         if (f >= nFrames) return;
         const GcZdFrame fr = frames[f];
         const uint8_t* const fsrc = src + fr.srcOff;
         uint8_t* const fdst = dst + fr.dstOff;
         const uint64_t cap = (fr.flags & GC_ZD_F_SIZE_KNOWN) ? fr.contentSize : (dstCap - fr.dstOff);
-        const uint64_t srcEnd = fr.srcSize - ((fr.flags & GC_ZD_F_CHECKSUM) ? 4u : 0u);      // end of the blocks
-        uint64_t ip = fr.hdrSize;          // frame-relative read position (uniform)
+        const uint64_t srcEnd = fr.srcSize - ((fr.flags & GC_ZD_F_CHECKSUM) ? 4u : 0u);
         uint64_t produced = 0;
-        if (t == 0) { sV[ZV_ERR] = GC_ZD_OK; sV[ZV_HUFOK] = 0; sV[ZV_FSEOK] = 0; sV[ZV_REP0] = 1; sV[ZV_REP1] = 4; sV[ZV_REP2] = 8; }
+        if (t == 0) { sV[XV_ERR] = GC_ZD_OK; sV[XV_REP0] = 1; sV[XV_REP1] = 4; sV[XV_REP2] = 8; }
         __syncthreads();
 
-        for (;;) {      // blocks
-            if (t == 0) {
-                if (ip + 3u > srcEnd) sV[ZV_ERR] = GC_ZD_CORRUPT;
-                else {
-                    const uint32_t h = (uint32_t)fsrc[ip] | ((uint32_t)fsrc[ip + 1] << 8) | ((uint32_t)fsrc[ip + 2] << 16);
-                    const uint32_t bt = (h >> 1) & 3u, bs = h >> 3;
-                    sV[ZV_LAST] = h & 1u; sV[ZV_BTYPE] = bt; sV[ZV_BSIZE] = bs;
-                    const uint64_t payload = bt == 1u ? 1u : bs;
-                    if (bt == 3u || bs > GC_ZSTD_BLOCK_MAX || ip + 3u + payload > srcEnd) sV[ZV_ERR] = GC_ZD_CORRUPT;
-                    else if (bt != 2u && produced + bs > cap) sV[ZV_ERR] = GC_ZD_DST_SMALL;
-                }
-            }
-            __syncthreads();
-            if (sV[ZV_ERR]) break;
-            const uint32_t bt = sV[ZV_BTYPE], bs = sV[ZV_BSIZE], lastBlock = sV[ZV_LAST];
-            const uint8_t* const bsrc = fsrc + ip + 3u;
+        for (uint32_t bi = 0; bi < fr.nBlocks; bi++) {
+            const GcZdBlock e = blocks[fr.blockBase + bi];
+            const uint32_t bt = e.type & 3u;
+            uint32_t fail = 0;
+            if (e.type & GC_ZD_B_BAD) fail = GC_ZD_CORRUPT;
+            else if (bt == 2u && e.status) fail = e.status;
+            else if (produced + (bt == 2u ? e.outSize : e.regen) > cap) fail = GC_ZD_DST_SMALL;
+            if (fail) { if (t == 0) sV[XV_ERR] = fail; break; }
+            const uint8_t* const bsrc = src + e.srcOff;
             uint8_t* const bdst = fdst + produced;
-            if (bt == 0u) {                                       // raw
-                for (uint32_t i = t; i < bs; i += GC_ZD_T) bdst[i] = bsrc[i];
-                ip += 3u + bs; produced += bs;
-            } else if (bt == 1u) {                                // RLE
-                const uint8_t b = bsrc[0];
-                for (uint32_t i = t; i < bs; i += GC_ZD_T) bdst[i] = b;
-                ip += 4u; produced += bs;
+            if (bt == 0u) {
+                for (uint32_t i = t; i < e.regen; i += GC_ZD_T) bdst[i] = bsrc[i];
+                produced += e.regen;
+            } else if (bt == 1u) {
+                const uint8_t v = bsrc[0];
+                for (uint32_t i = t; i < e.regen; i += GC_ZD_T) bdst[i] = v;
+                produced += e.regen;
             } else {
-                // ---- stage the compressed block ----
-                for (uint32_t i = t * 8u; i < bs; i += GC_ZD_T * 8u) {
-                    if (i + 8u <= bs) { const uint64_t v = gc_ld64(bsrc + i); __builtin_memcpy(sOut + i, &v, 8); }
-                    else for (uint32_t k = i; k < bs; k++) sOut[k] = bsrc[k];
-                }
-                for (uint32_t i = t; i < ZD_PAD; i += GC_ZD_T) if (bs + i < GC_ZSTD_BLOCK_MAX + ZD_PAD) sOut[bs + i] = 0;
-                __syncthreads();
-                // ---- literals header + Huffman table ----
-                if (t == 0) {
-                    uint32_t err = 0;
-                    if (bs < 1u) err = 1;       // a compressed block holds at least the two section headers (2 bytes); checked as we go
-                    uint32_t hdr = 0, regen = 0, comp = 0, nStreams = 1, kind = ZL_RAW;
-                    if (!err) {
-                        const uint32_t b0 = sOut[0], lt = b0 & 3u, sf = (b0 >> 2) & 3u;
-                        if (lt < 2u) {
-                            if (!(sf & 1u)) { hdr = 1; regen = b0 >> 3; }
-                            else if (sf == 1u) { hdr = 2; regen = ((uint32_t)sOut[0] | ((uint32_t)sOut[1] << 8)) >> 4; }
-                            else { hdr = 3; regen = ((uint32_t)sOut[0] | ((uint32_t)sOut[1] << 8) | ((uint32_t)sOut[2] << 16)) >> 4; }
-                            kind = lt == 0u ? ZL_RAW : ZL_RLE;
-                            comp = lt == 0u ? regen : 1u;
-                        } else {
-                            const uint64_t v = gc_ld64(sOut);
-                            if (sf < 2u) { hdr = 3; regen = (uint32_t)(v >> 4) & 0x3FFu; comp = (uint32_t)(v >> 14) & 0x3FFu; nStreams = sf == 0u ? 1u : 4u; }
-                            else if (sf == 2u) { hdr = 4; regen = (uint32_t)(v >> 4) & 0x3FFFu; comp = (uint32_t)(v >> 18) & 0x3FFFu; nStreams = 4; }
-                            else { hdr = 5; regen = (uint32_t)(v >> 4) & 0x3FFFFu; comp = (uint32_t)(v >> 22) & 0x3FFFFu; nStreams = 4; }
-                            kind = ZL_HUF;
-                            if (lt == 3u && !sV[ZV_HUFOK]) err = 1;          // treeless block without a table from an earlier block
-                            if (regen == 0u) err = 1;
-                        }
-                        if (hdr > bs || regen > GC_ZSTD_BLOCK_MAX || (uint64_t)hdr + comp > bs) err = 1;
-                        if (!err && kind == ZL_HUF) {
-                            uint32_t treeBytes = 0;
-                            if (lt == 2u) {
-                                uint32_t log = 0;
-                                treeBytes = zd_huf_read(sOut + hdr, comp, sHuf, sW, sNorm, sNext, sFseW, &log);
-                                if (!treeBytes) err = 1; else { sV[ZV_HUFLOG] = log; sV[ZV_HUFOK] = 1; }
-                            }
-                            if (!err) {
-                                const uint32_t base = hdr + treeBytes, avail = comp - treeBytes;
-                                if (nStreams == 1u) { sV[ZV_STR0] = base; sV[ZV_STR0 + 1] = avail; if (!avail) err = 1; }
-                                else {
-                                    if (avail < 10u) err = 1;
-                                    else {
-                                        const uint32_t s1 = (uint32_t)sOut[base] | ((uint32_t)sOut[base + 1] << 8), s2 = (uint32_t)sOut[base + 2] | ((uint32_t)sOut[base + 3] << 8),
-                                                       s3 = (uint32_t)sOut[base + 4] | ((uint32_t)sOut[base + 5] << 8);
-                                        if ((uint64_t)6u + s1 + s2 + s3 >= avail) err = 1;
-                                        else {
-                                            sV[ZV_STR0] = base + 6u; sV[ZV_STR0 + 1] = s1;
-                                            sV[ZV_STR1] = base + 6u + s1; sV[ZV_STR1 + 1] = s2;
-                                            sV[ZV_STR2] = base + 6u + s1 + s2; sV[ZV_STR2 + 1] = s3;
-                                            sV[ZV_STR3] = base + 6u + s1 + s2 + s3; sV[ZV_STR3 + 1] = avail - 6u - s1 - s2 - s3;
-                                        }
-                                    }
-                                }
-                            }
-                        }
-                        if (kind == ZL_RLE) sV[ZV_RLEBYTE] = sOut[hdr];
-                    }
-                    sV[ZV_LITKIND] = kind; sV[ZV_LITREGEN] = regen; sV[ZV_LITOFF] = hdr; sV[ZV_NSTREAMS] = nStreams;
-                    sV[ZV_SEQPOS] = hdr + comp;
-                    if (err) sV[ZV_ERR] = GC_ZD_CORRUPT;
-                }
-                __syncthreads();
-                if (sV[ZV_ERR]) break;
-                // ---- entropy stage: Huffman streams (threads 64..67) beside the sequences (thread 0) ----
-                if (t >= 64u && t < 64u + sV[ZV_NSTREAMS] && sV[ZV_LITKIND] == ZL_HUF) {
-                    const uint32_t q = t - 64u, regen = sV[ZV_LITREGEN], ns = sV[ZV_NSTREAMS];
-                    const uint32_t seg = ns == 1u ? regen : (regen + 3u) >> 2;
-                    const uint32_t o = q * seg;
-                    bool ok = true;
-                    uint32_t cnt = 0;
-                    if (ns == 1u) cnt = regen;
-                    else if (o > regen) ok = false;
-                    else cnt = q == 3u ? regen - o : (seg <= regen - o ? seg : 0xFFFFFFFFu);
-                    if (cnt == 0xFFFFFFFFu) ok = false;
-                    if (ok) ok = zd_huf_stream(sOut + sV[ZV_STR0 + 2u * q], sV[ZV_STR0 + 2u * q + 1u], sHuf, sV[ZV_HUFLOG], lit + o, cnt);
-                    if (!ok) sV[ZV_ERR] = GC_ZD_CORRUPT;
-                }
-                if (t == 0) {
-                    uint32_t err = 0;
-                    const uint32_t sp = sV[ZV_SEQPOS], regen = sV[ZV_LITREGEN];
-                    uint32_t p = sp, nSeq = 0;
-                    if (p >= bs) err = 1;
-                    else {
-                        const uint32_t b0 = sOut[p++];
-                        if (b0 < 128u) nSeq = b0;
-                        else if (b0 < 255u) { if (p >= bs) err = 1; else nSeq = ((b0 - 128u) << 8) + sOut[p++]; }
-                        else { if (p + 2u > bs) err = 1; else { nSeq = (uint32_t)sOut[p] + ((uint32_t)sOut[p + 1] << 8) + 0x7F00u; p += 2u; } }
-                    }
-                    uint32_t dpos = 0, lpos = 0;
-                    if (!err && nSeq == 0u) { if (p != bs) err = 1; }
-                    else if (!err) {
-                        if (p >= bs) err = 1;
-                        else {
-                            const uint32_t modes = sOut[p++];
-                            if (modes & 3u) err = 1;
-                            const bool old = sV[ZV_FSEOK] != 0u;
-                            int h;
-                            if (!err) { h = zd_seq_table(modes >> 6, sOut + p, bs - p, sLL, &sV[ZV_LLLOG], 35u, 9u, kZdLLNorm, 35u, 6u, old, sNorm, sNext); if (h < 0) err = 1; else p += (uint32_t)h; }
-                            if (!err) { h = zd_seq_table((modes >> 4) & 3u, sOut + p, bs - p, sOF, &sV[ZV_OFLOG], 31u, 8u, kZdOFNorm, 28u, 5u, old, sNorm, sNext); if (h < 0) err = 1; else p += (uint32_t)h; }
-                            if (!err) { h = zd_seq_table((modes >> 2) & 3u, sOut + p, bs - p, sML, &sV[ZV_MLLOG], 52u, 9u, kZdMLNorm, 52u, 6u, old, sNorm, sNext); if (h < 0) err = 1; else p += (uint32_t)h; }
-                            if (!err) sV[ZV_FSEOK] = 1;
-                        }
-                        ZdBR r;
-                        if (!err && (p >= bs || !zd_br_init(r, sOut + p, bs - p))) err = 1;
-                        if (!err) {
-                            const uint32_t llLog = sV[ZV_LLLOG], ofLog = sV[ZV_OFLOG], mlLog = sV[ZV_MLLOG];
-                            uint32_t stLL = zd_br_read(r, llLog), stOF = zd_br_read(r, ofLog), stML = zd_br_read(r, mlLog);
-                            uint32_t rep0 = sV[ZV_REP0], rep1 = sV[ZV_REP1], rep2 = sV[ZV_REP2];
-                            const uint64_t frameBase = produced;              // bytes of the frame in front of this block
-                            for (uint32_t j = 0; j < nSeq; j++) {
-                                const uint32_t eLL = sLL[stLL], eOF = sOF[stOF], eML = sML[stML];
-                                const uint32_t llc = eLL >> 24, ofc = eOF >> 24, mlc = eML >> 24;
-                                if (ofc > 31u) { err = 1; break; }
-                                const uint32_t ofv = (1u << ofc) + zd_br_read(r, ofc);
-                                const uint32_t ml = kZdMLBase[mlc] + zd_br_read(r, kZdMLBits[mlc]);
-                                const uint32_t ll = kZdLLBase[llc] + zd_br_read(r, kZdLLBits[llc]);
-                                uint32_t off;
-                                if (ofv > 3u) { off = ofv - 3u; rep2 = rep1; rep1 = rep0; rep0 = off; }
-                                else {
-                                    const uint32_t idx = ofv - 1u + (ll == 0u ? 1u : 0u);
-                                    if (idx == 0u) off = rep0;
-                                    else {
-                                        off = idx == 1u ? rep1 : (idx == 2u ? rep2 : rep0 - 1u);
-                                        if (idx != 1u) rep2 = rep1;
-                                        rep1 = rep0; rep0 = off;
-                                    }
-                                }
-                                if (j + 1u < nSeq) {
-                                    stLL = (eLL & 0xFFFFu) + zd_br_read(r, (eLL >> 16) & 0xFFu);
-                                    stML = (eML & 0xFFFFu) + zd_br_read(r, (eML >> 16) & 0xFFu);
-                                    stOF = (eOF & 0xFFFFu) + zd_br_read(r, (eOF >> 16) & 0xFFu);
-                                }
-                                if (r.off < 0) { err = 1; break; }
-                                if ((uint64_t)lpos + ll > regen || (uint64_t)dpos + ll + ml > GC_ZSTD_BLOCK_MAX) { err = 1; break; }
-                                if (off == 0u || (uint64_t)off > frameBase + dpos + ll) { err = 1; break; }
-                                GcU4 rec; rec.x = ll; rec.y = ml; rec.z = off; rec.w = dpos;
-                                seq[j] = rec; lposA[j] = lpos;
-                                dpos += ll + ml; lpos += ll;
-                            }
-                            if (!err && r.off != 0) err = 1;
-                            sV[ZV_REP0] = rep0; sV[ZV_REP1] = rep1; sV[ZV_REP2] = rep2;
-                        }
-                    }
-                    const uint32_t outSize = dpos + (regen - lpos);
-                    if (!err && outSize > GC_ZSTD_BLOCK_MAX) err = 1;
-                    sV[ZV_NSEQ] = nSeq; sV[ZV_LITEND] = lpos; sV[ZV_DPOSEND] = dpos; sV[ZV_OUTSIZE] = outSize;
-                    if (err) sV[ZV_ERR] = GC_ZD_CORRUPT;
-                    else if (produced + outSize > cap) sV[ZV_ERR] = GC_ZD_DST_SMALL;
-                }
-                __threadfence();
-                __syncthreads();
-                if (sV[ZV_ERR]) break;
-                // ---- pass 1: literals and the matches that lie in front of the block ----
-                const uint32_t nSeq = sV[ZV_NSEQ], kind = sV[ZV_LITKIND], outSize = sV[ZV_OUTSIZE];
-                const uint8_t* const litSrc = kind == ZL_HUF ? lit : bsrc + sV[ZV_LITOFF];
-                const uint8_t rleByte = (uint8_t)sV[ZV_RLEBYTE];
+                const uint32_t nSeq = e.nSeq, lt = e.litInfo & 3u, outSize = e.outSize;
+                const uint8_t* const litSrc = lt >= 2u ? litWork + fr.litBase + e.litOff : bsrc + (e.litInfo >> 8);
+                const uint8_t* const litLimit = lt >= 2u ? litWork + litWorkSize : src + srcSize;
+                const uint8_t rleByte = lt == 1u ? bsrc[e.litInfo >> 8] : (uint8_t)0;
+                GcU4* const seq = seqWork + fr.seqBase + e.seqOff;
+                const uint32_t in0 = sV[XV_REP0], in1 = sV[XV_REP1], in2 = sV[XV_REP2];
+                // ---- pass 1: offsets get their values; literals; matches that lie in front of the block ----
+                uint32_t bad = 0;
                 for (uint32_t j = t; j < nSeq; j += GC_ZD_T) {
-                    const GcU4 rec = seq[j];
-                    const uint32_t lp = lposA[j];
-                    if (kind == ZL_RLE) for (uint32_t k = 0; k < rec.x; k++) sOut[rec.w + k] = rleByte;
-                    else for (uint32_t k = 0; k < rec.x; k++) sOut[rec.w + k] = litSrc[lp + k];
-                    const uint32_t d = rec.w + rec.x;
-                    if (rec.z >= d + rec.y) {                      // the whole source lies in front of the block
-                        const uint8_t* const ms = bdst + d - rec.z;
-                        for (uint32_t k = 0; k < rec.y; k++) sOut[d + k] = ms[k];
+                    GcU4 rec = seq[j];
+                    const uint32_t ll = rec.x & 0x3FFFFu, ml = (rec.x >> 18) | ((rec.y & 15u) << 14), lp = rec.y >> 4, dp = rec.w;
+                    uint32_t off = rec.z;
+                    if (off & GC_ZD_SYM) {
+                        const uint32_t k = off & 3u, delta = (off & 0x7FFFFFFFu) >> 2, in = k == 0u ? in0 : (k == 1u ? in1 : in2);
+                        if (in <= delta) { bad = 1; continue; }
+                        off = in - delta; rec.z = off; seq[j] = rec;
                     }
+                    const uint32_t d = dp + ll;
+                    if ((uint64_t)off > produced + d) { bad = 1; continue; }
+                    if (lt == 1u) for (uint32_t k = 0; k < ll; k++) sOut[dp + k] = rleByte;
+                    else zd_copy_in(sOut + dp, litSrc + lp, ll, litLimit);
+                    if (off >= d + ml) zd_copy_in(sOut + d, bdst + d - off, ml, bdst);      // the whole source lies in front of the block
                 }
                 {
-                    const uint32_t lp = sV[ZV_LITEND], dp = sV[ZV_DPOSEND], rest = sV[ZV_LITREGEN] - lp;
-                    if (kind == ZL_RLE) for (uint32_t k = t; k < rest; k += GC_ZD_T) sOut[dp + k] = rleByte;
+                    const uint32_t lp = e.lposEnd, dp = e.dposEnd, rest = e.regen - lp;
+                    if (lt == 1u) for (uint32_t k = t; k < rest; k += GC_ZD_T) sOut[dp + k] = rleByte;
                     else for (uint32_t k = t; k < rest; k += GC_ZD_T) sOut[dp + k] = litSrc[lp + k];
                 }
+                if (bad) sV[XV_ERR] = GC_ZD_CORRUPT;
+                __threadfence();
                 __syncthreads();
+                if (sV[XV_ERR]) break;
                 // ---- pass 2: matches that read the block itself, in order ----
                 if (t < 64u) {
                     for (uint32_t j0 = 0; j0 < nSeq; j0 += 64u) {
@@ -504,7 +764,8 @@ gc_zstd_dec_kernel(const uint8_t* __restrict__ src, uint8_t* dst, uint64_t dstCa
                         if (j0 + lane < nSeq) mine = seq[j0 + lane];
                         const uint32_t cnt = nSeq - j0 < 64u ? nSeq - j0 : 64u;
                         for (uint32_t i = 0; i < cnt; i++) {
-                            const uint32_t ll = __shfl(mine.x, (int)i), ml = __shfl(mine.y, (int)i), off = __shfl(mine.z, (int)i), dp = __shfl(mine.w, (int)i);
+                            const uint32_t x = __shfl(mine.x, (int)i), y = __shfl(mine.y, (int)i), off = __shfl(mine.z, (int)i), dp = __shfl(mine.w, (int)i);
+                            const uint32_t ll = x & 0x3FFFFu, ml = (x >> 18) | ((y & 15u) << 14);
                             const uint32_t d = dp + ll;
                             if (off >= d + ml) continue;             // done in pass 1
                             const int32_t s0 = (int32_t)d - (int32_t)off;
@@ -524,21 +785,29 @@ gc_zstd_dec_kernel(const uint8_t* __restrict__ src, uint8_t* dst, uint64_t dstCa
                         }
                     }
                 }
+                if (t == 64u) {                                    // repeat offsets behind the block
+                    uint32_t out[3];
+                    for (int i = 0; i < 3; i++) {
+                        uint32_t v = e.rep[i];
+                        if (v & GC_ZD_SYM) { const uint32_t k = v & 3u, delta = (v & 0x7FFFFFFFu) >> 2, in = k == 0u ? in0 : (k == 1u ? in1 : in2); v = in > delta ? in - delta : 1u; }
+                        out[i] = v;
+                    }
+                    sV[XV_REP0] = out[0]; sV[XV_REP1] = out[1]; sV[XV_REP2] = out[2];
+                }
                 __syncthreads();
                 // ---- flush ----
                 for (uint32_t i = t * 16u; i < outSize; i += GC_ZD_T * 16u) {
                     if (i + 16u <= outSize) { GcU4 v; __builtin_memcpy(&v, sOut + i, 16); __builtin_memcpy(bdst + i, &v, 16); }
                     else for (uint32_t k = i; k < outSize; k++) bdst[k] = sOut[k];
                 }
-                ip += 3u + bs; produced += outSize;
+                produced += outSize;
             }
             __threadfence();
             __syncthreads();
-            if (lastBlock) break;
         }
         __syncthreads();
-        uint32_t status = sV[ZV_ERR];
-        if (!status && ip != srcEnd) status = GC_ZD_CORRUPT;
+        uint32_t status = sV[XV_ERR];
+        if (!status && fr.nBlocks == 0u) status = GC_ZD_CORRUPT;
         if (!status && (fr.flags & GC_ZD_F_SIZE_KNOWN) && produced != fr.contentSize) status = GC_ZD_SIZE;
         if (!status && (fr.flags & GC_ZD_F_CHECKSUM)) {
             // XXH64, seed 0: lanes 0..3 of wave 0 are the four accumulators
@@ -563,10 +832,10 @@ gc_zstd_dec_kernel(const uint8_t* __restrict__ src, uint8_t* dst, uint64_t dstCa
                 while (pos < produced) { h ^= (uint64_t)fdst[pos] * XP5; h = zd_rotl(h, 11) * XP1; pos++; }
                 h ^= h >> 33; h *= XP2; h ^= h >> 29; h *= XP3; h ^= h >> 32;
                 const uint32_t want = (uint32_t)fsrc[srcEnd] | ((uint32_t)fsrc[srcEnd + 1] << 8) | ((uint32_t)fsrc[srcEnd + 2] << 16) | ((uint32_t)fsrc[srcEnd + 3] << 24);
-                sV[ZV_ERR] = (uint32_t)h == want ? GC_ZD_OK : GC_ZD_CHECKSUM;
+                sV[XV_ERR] = (uint32_t)h == want ? GC_ZD_OK : GC_ZD_CHECKSUM;
             }
             __syncthreads();
-            status = sV[ZV_ERR];
+            status = sV[XV_ERR];
         }
         if (t == 0) result[f] = produced | ((uint64_t)status << 56);
         __syncthreads();
@@ -609,6 +878,7 @@ extern "C" int gc_zstd_scan_frames(const void* srcv, size_t n, gc_zstd_frame* ou
         for (uint32_t i = 0; i < fcsSize; i++) fcs |= (uint64_t)src[p + i] << (8u * i);
         if (fcsSize == 2u) fcs += 256u;
         p += fcsSize;
+        uint64_t nb = 0;
         for (;;) {                                                     // blocks
             if (n - p < 3u) return GC_ERR_CORRUPT;
             const uint32_t h = (uint32_t)src[p] | ((uint32_t)src[p + 1] << 8) | ((uint32_t)src[p + 2] << 16);
@@ -616,15 +886,17 @@ extern "C" int gc_zstd_scan_frames(const void* srcv, size_t n, gc_zstd_frame* ou
             if (bt == 3u) return GC_ERR_CORRUPT;
             const size_t payload = bt == 1u ? 1u : bs;
             if (n - p - 3u < payload) return GC_ERR_CORRUPT;
-            p += 3u + payload;
+            p += 3u + payload; nb++;
             if (h & 1u) break;
         }
         if (checksum) { if (n - p < 4u) return GC_ERR_CORRUPT; p += 4u; }
+        if (nb > 0xFFFFFFFFull) return GC_ERR_PARAM;
         if (out) {
             if (cnt >= maxFrames) return GC_ERR_DST_SMALL;
             gc_zstd_frame& f = out[cnt];
             f.src_off = start; f.src_size = p - start; f.dst_off = known ? total : ~0ull; f.content_size = fcs;
             f.flags = (checksum ? GC_ZD_F_CHECKSUM : 0u) | (fcsSize ? GC_ZD_F_SIZE_KNOWN : 0u); f.header_size = (uint32_t)hdr;
+            f.n_blocks = (uint32_t)nb; f.reserved = 0;
         }
         if (fcsSize) total += fcs; else known = false;
         cnt++; pos = p;
@@ -635,8 +907,14 @@ extern "C" int gc_zstd_scan_frames(const void* srcv, size_t n, gc_zstd_frame* ou
 }
 
 // called by gc_api.hip
-extern "C" void gc_zstd_dec_launch(hipStream_t st, uint32_t grid, const uint8_t* src, uint8_t* dst, uint64_t dstCap, const GcZdFrame* frames, uint32_t nFrames,
-                                   uint32_t* ticket, uint8_t* litWork, void* seqWork, uint32_t* lposWork, uint64_t* result)
+extern "C" void gc_zstd_dec_launch_index(hipStream_t st, const uint8_t* src, const GcZdFrame* frames, uint32_t nFrames, GcZdBlock* blocks, uint64_t* frameTot)
 {
-    GC_LAUNCH(gc_zstd_dec_kernel, grid, GC_ZD_T, st, src, dst, dstCap, frames, nFrames, ticket, litWork, (GcU4*)seqWork, lposWork, result);
+    GC_LAUNCH(gc_zstd_dec_index_kernel, (nFrames + 63u) / 64u, 64, st, src, frames, nFrames, blocks, frameTot);
+}
+extern "C" void gc_zstd_dec_launch_decode(hipStream_t st, const uint8_t* src, uint64_t srcSize, uint8_t* dst, uint64_t dstCap, const GcZdFrame* frames, uint32_t nFrames,
+                                          GcZdBlock* blocks, uint32_t nBlocks, uint32_t* ticket, uint8_t* litWork, uint64_t litWorkSize, void* seqWork, uint64_t* result)
+{
+    if (nBlocks) GC_LAUNCH(gc_zstd_dec_entropy_kernel, nBlocks, GC_ZD_ENT_T, st, src, srcSize, frames, blocks, litWork, (GcU4*)seqWork);
+    const uint32_t wg = nFrames < GC_ZD_MAX_WG ? nFrames : GC_ZD_MAX_WG;
+    GC_LAUNCH(gc_zstd_dec_exec_kernel, wg, GC_ZD_T, st, src, srcSize, dst, dstCap, frames, nFrames, (const GcZdBlock*)blocks, ticket, (const uint8_t*)litWork, litWorkSize, (GcU4*)seqWork, result);
 }

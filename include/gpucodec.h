@@ -173,8 +173,9 @@ int         gc_crc32_device(const void* d_src, size_t n, uint32_t* crc);
 
 /* ---- ZSTD decoding on the device.  Replaces the ZSTD_decompressStream loop of NCompress::NZSTD::CDecoder::CodeSpec
  * (CPP/7zip/Compress/ZstdDecoder.cpp:66-240; C/zstd/zstd_decompress.c:2086) for callers that hold a whole compressed stream.  The frame is
- * the unit of parallelism (one workgroup each): streams of this engine's encoder carry one frame per 8 MiB, a stream of the reference's
- * encoder is one frame.  Frames with a dictionary id are refused (GC_ERR_PARAM); a damaged stream, a wrong content checksum (XXH64, checked
+ * Entropy decoding (Huffman literals, FSE sequences) runs per BLOCK (<= 128 KiB, one workgroup each, whatever the frame structure);
+ * the match copies run per FRAME (one workgroup each, blocks in order): streams of this engine's encoder carry one frame per 8 MiB, a
+ * stream of the reference's encoder is one frame.  Frames with a dictionary id are refused (GC_ERR_PARAM); a damaged stream, a wrong content checksum (XXH64, checked
  * on the device) or a content size field that does not match give GC_ERR_CORRUPT.
  *   gc_zstd_scan_frames       host: walks frame and block headers (ZSTD_findFrameCompressedSize zstd_decompress.c:809, ZSTD_getFrameContentSize
  *                             :569), skips skippable frames.  frames may be NULL to count.  *contentTotal = sum of the content sizes, or
@@ -188,6 +189,8 @@ typedef struct gc_zstd_frame {
     uint64_t content_size;           /* valid if flags & 2 */
     uint32_t flags;                  /* 1: content checksum present, 2: content size known */
     uint32_t header_size;
+    uint32_t n_blocks;               /* blocks of the frame (the unit of parallelism of the entropy stage) */
+    uint32_t reserved;
 } gc_zstd_frame;
 int         gc_zstd_scan_frames(const void* src, size_t n, gc_zstd_frame* frames, size_t maxFrames, size_t* nFrames, uint64_t* contentTotal);
 int         gc_zstd_decompress_device(gc_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t dstCapacity,
