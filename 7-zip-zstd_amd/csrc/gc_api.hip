@@ -894,7 +894,8 @@ extern "C" size_t gc_codec_grain(int codec, int level)
 // ---------------------------------------------------------------- ZSTD decoding ----------------------------------------------------------------
 extern "C" void gc_zstd_dec_launch_index(hipStream_t st, const uint8_t* src, const GcZdFrame* frames, uint32_t nFrames, GcZdBlock* blocks, uint64_t* frameTot);
 extern "C" void gc_zstd_dec_launch_decode(hipStream_t st, const uint8_t* src, uint64_t srcSize, uint8_t* dst, uint64_t dstCap, const GcZdFrame* frames, uint32_t nFrames,
-                                          GcZdBlock* blocks, uint32_t nBlocks, uint32_t* ticket, uint8_t* litWork, uint64_t litWorkSize, void* seqWork, uint64_t* result);
+                                          GcZdBlock* blocks, uint32_t nBlocks, uint32_t* ticket, uint8_t* litWork, uint64_t litWorkSize, void* seqWork, uint64_t* result,
+                                          unsigned long long* prof);
 
 static int zd_grow(gc_ctx* c, void** p, size_t* cap, size_t need)
 {
@@ -919,6 +920,9 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
     int rc = GC_OK;
     if (!c->zdTicket && hipMalloc((void**)&c->zdTicket, 4) != hipSuccess) rc = GC_ERR_NOMEM;
     for (int i = 0; i < 2 && rc == GC_OK; i++) if (!c->zdEv[i] && hipEventCreate(&c->zdEv[i]) != hipSuccess) rc = GC_ERR_HIP;
+    // test hook GC_ZD_PROF=1: shader cycles of the execution kernel's phases (thread 0's view, summed over blocks) on stderr
+    unsigned long long* zdProf = nullptr;
+    { uint32_t v = 0; if (gc_env_u32("GC_ZD_PROF", 1, 1, &v) && hipMalloc((void**)&zdProf, 32) == hipSuccess) hipMemsetAsync(zdProf, 0, 32, c->stream); }
     uint64_t dstOff = 0;
     size_t i = 0;
     while (i < nFrames && rc == GC_OK) {
@@ -959,7 +963,7 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
         if (hipMemcpyAsync(c->zdFrames, h + i, cnt * sizeof(GcZdFrame), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
             hipMemsetAsync(c->zdTicket, 0, 4, c->stream) != hipSuccess) { rc = GC_ERR_HIP; break; }
         gc_zstd_dec_launch_decode(c->stream, (const uint8_t*)d_src, n, (uint8_t*)d_dst, dstCap, c->zdFrames, (uint32_t)cnt, c->zdBlocks, (uint32_t)nBlocks, c->zdTicket,
-                                  c->zdLit, litTot + 64u, c->zdSeq, c->zdResult);
+                                  c->zdLit, litTot + 64u, c->zdSeq, c->zdResult, zdProf);
         hipEventRecord(c->zdEv[1], c->stream);
         if (hipMemcpyAsync(res, c->zdResult, cnt * 8u, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
             snprintf(c->err, sizeof(c->err), "decode kernels failed: %s", hipGetErrorString(hipGetLastError())); rc = GC_ERR_HIP; break;
@@ -977,6 +981,12 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
         i = j;
     }
     free(h); free(res);
+    if (zdProf) {
+        unsigned long long pv[4] = { 0, 0, 0, 0 };
+        if (hipMemcpy(pv, zdProf, 32, hipMemcpyDeviceToHost) == hipSuccess && pv[3])
+            fprintf(stderr, "[GC_ZD_PROF] compressed blocks %llu: cycles per block pass1 %.0f pass2 %.0f flush %.0f\n", pv[3], (double)pv[0] / pv[3], (double)pv[1] / pv[3], (double)pv[2] / pv[3]);
+        hipFree(zdProf);
+    }
     if (rc == GC_OK && outSize) *outSize = (size_t)dstOff;
     return rc;
 }

@@ -662,6 +662,15 @@ gc_zstd_dec_entropy_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, co
 }
 
 // =============================================================== execution kernel ===============================================================
+// byte `si` of the block image, or of the frame's output in front of the block when si < 0.  (The LDS read is unconditional and the HBM read sits in
+// its own branch: a select between an LDS and a global pointer makes this compiler emit an illegal compare against src_shared_base.)
+__device__ __forceinline__ uint8_t zd_image_byte(const uint8_t* sOut, const uint8_t* bdst, int32_t si)
+{
+    uint8_t b = sOut[si < 0 ? 0 : si];
+    if (si < 0) b = bdst[si];
+    return b;
+}
+
 __device__ __forceinline__ uint64_t zd_rotl(uint64_t v, uint32_t r) { return (v << r) | (v >> (64u - r)); }
 #define XP1 0x9E3779B185EBCA87ull
 #define XP2 0xC2B2AE3D27D4EB4Full
@@ -685,7 +694,8 @@ enum { XV_ERR = 0, XV_FRAME, XV_REP0, XV_REP1, XV_REP2, XV_COUNT };
 
 extern "C" __global__ void __launch_bounds__(GC_ZD_T)
 gc_zstd_dec_exec_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint8_t* dst, uint64_t dstCap, const GcZdFrame* __restrict__ frames, uint32_t nFrames,
-                        const GcZdBlock* __restrict__ blocks, uint32_t* ticket, const uint8_t* litWork, uint64_t litWorkSize, GcU4* seqWork, uint64_t* result)
+                        const GcZdBlock* __restrict__ blocks, uint32_t* ticket, const uint8_t* litWork, uint64_t litWorkSize, GcU4* seqWork, uint64_t* result,
+                        unsigned long long* prof)
 {
     __shared__ __attribute__((aligned(16))) uint8_t sOut[GC_ZSTD_BLOCK_MAX + 32u];
     __shared__ uint32_t sV[XV_COUNT];
@@ -732,6 +742,7 @@ gc_zstd_dec_exec_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint8
                 GcU4* const seq = seqWork + fr.seqBase + e.seqOff;
                 const uint32_t in0 = sV[XV_REP0], in1 = sV[XV_REP1], in2 = sV[XV_REP2];
                 // ---- pass 1: offsets get their values; literals; matches that lie in front of the block ----
+                const unsigned long long c0 = prof ? gc_clock() : 0ull;
                 uint32_t bad = 0;
                 for (uint32_t j = t; j < nSeq; j += GC_ZD_T) {
                     GcU4 rec = seq[j];
@@ -757,31 +768,62 @@ gc_zstd_dec_exec_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint8
                 __threadfence();
                 __syncthreads();
                 if (sV[XV_ERR]) break;
-                // ---- pass 2: matches that read the block itself, in order ----
+                const unsigned long long c1 = prof ? gc_clock() : 0ull;
+                // ---- pass 2: matches that read the block itself.  One lane per sequence, 64 sequences at a time; everything below the output
+                //      position W of the first unfinished match of the group is final, so every match whose source ends at or below W can be
+                //      copied now, all of them at once (their outputs are disjoint); the first one itself always can.  A few rounds per group
+                //      instead of 64 dependent steps.  Long matches are copied by the whole wave, 64 bytes per step. ----
                 if (t < 64u) {
                     for (uint32_t j0 = 0; j0 < nSeq; j0 += 64u) {
                         GcU4 mine; mine.x = mine.y = mine.z = mine.w = 0;
-                        if (j0 + lane < nSeq) mine = seq[j0 + lane];
-                        const uint32_t cnt = nSeq - j0 < 64u ? nSeq - j0 : 64u;
-                        for (uint32_t i = 0; i < cnt; i++) {
-                            const uint32_t x = __shfl(mine.x, (int)i), y = __shfl(mine.y, (int)i), off = __shfl(mine.z, (int)i), dp = __shfl(mine.w, (int)i);
-                            const uint32_t ll = x & 0x3FFFFu, ml = (x >> 18) | ((y & 15u) << 14);
-                            const uint32_t d = dp + ll;
-                            if (off >= d + ml) continue;             // done in pass 1
-                            const int32_t s0 = (int32_t)d - (int32_t)off;
-                            if (off < 64u) {
-                                for (uint32_t k = lane; k < ml; k += 64u) {
-                                    const int32_t si = s0 + (int32_t)(k % off);
-                                    sOut[d + k] = si < 0 ? bdst[si] : sOut[si];
-                                }
-                                gc_wave_step();
-                            } else {
-                                for (uint32_t c = 0; c < ml; c += 64u) {
-                                    const uint32_t k = c + lane;
-                                    if (k < ml) { const int32_t si = s0 + (int32_t)k; sOut[d + k] = si < 0 ? bdst[si] : sOut[si]; }
+                        const bool have = j0 + lane < nSeq;
+                        if (have) mine = seq[j0 + lane];
+                        const uint32_t ll = mine.x & 0x3FFFFu, ml = (mine.x >> 18) | ((mine.y & 15u) << 14), off = mine.z, d = mine.w + ll;
+                        bool pending = have && off < d + ml;
+                        const int32_t s0 = (int32_t)d - (int32_t)off;
+                        const uint32_t srcEnd = off >= ml ? (uint32_t)(s0 + (int32_t)ml) : d;      // end of the part of the source that is not its own output
+                        const uint32_t isLong = ml > 48u ? 1u : 0u;
+                        for (;;) {
+                            const uint64_t pm = __ballot(pending);
+                            if (!pm) break;
+                            const uint32_t fl = gc_ctz64(pm);
+                            const uint32_t W = gc_readlane(d, fl);
+                            if (gc_readlane(isLong, fl)) {
+                                const uint32_t fml = gc_readlane(ml, fl), foff = gc_readlane(off, fl);
+                                const int32_t fs0 = (int32_t)W - (int32_t)foff;
+                                if (foff < 64u) {
+                                    for (uint32_t k = lane; k < fml; k += 64u) {
+                                        const int32_t si = fs0 + (int32_t)(k % foff);
+                                        sOut[W + k] = zd_image_byte(sOut, bdst, si);
+                                    }
                                     gc_wave_step();
+                                } else {
+                                    for (uint32_t c = 0; c < fml; c += 64u) {
+                                        const uint32_t k = c + lane;
+                                        if (k < fml) { const int32_t si = fs0 + (int32_t)k; sOut[W + k] = zd_image_byte(sOut, bdst, si); }
+                                        gc_wave_step();
+                                    }
+                                }
+                                if (lane == fl) pending = false;
+                                continue;
+                            }
+                            if (pending && !isLong && (lane == fl || srcEnd <= W)) {
+                                pending = false;
+                                if (s0 >= 0 && off >= 8u) {
+                                    uint32_t k = 0;
+                                    for (; k + 8u <= ml; k += 8u) { const uint64_t v = gc_ld64(sOut + s0 + k); __builtin_memcpy(sOut + d + k, &v, 8); }
+                                    if (k < ml) { uint64_t v = gc_ld64(sOut + s0 + k); for (; k < ml; k++) { sOut[d + k] = (uint8_t)v; v >>= 8; } }
+                                } else if (s0 >= 0) {                      // period below 8: the pattern lives in a register
+                                    const uint64_t pat = gc_ld64(sOut + s0);
+                                    uint32_t ph = 0;
+                                    for (uint32_t k = 0; k < ml; k++) { sOut[d + k] = (uint8_t)(pat >> (8u * ph)); ph = ph + 1u == off ? 0u : ph + 1u; }
+                                } else {
+                                    const uint32_t nFront = (uint32_t)(-s0) < ml ? (uint32_t)(-s0) : ml;      // the source starts in front of the block
+                                    for (uint32_t k = 0; k < nFront; k++) sOut[d + k] = bdst[s0 + (int32_t)k];
+                                    for (uint32_t k = nFront; k < ml; k++) sOut[d + k] = sOut[k - nFront];
                                 }
                             }
+                            gc_wave_step();
                         }
                     }
                 }
@@ -795,12 +837,17 @@ gc_zstd_dec_exec_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint8
                     sV[XV_REP0] = out[0]; sV[XV_REP1] = out[1]; sV[XV_REP2] = out[2];
                 }
                 __syncthreads();
+                const unsigned long long c2 = prof ? gc_clock() : 0ull;
                 // ---- flush ----
                 for (uint32_t i = t * 16u; i < outSize; i += GC_ZD_T * 16u) {
                     if (i + 16u <= outSize) { GcU4 v; __builtin_memcpy(&v, sOut + i, 16); __builtin_memcpy(bdst + i, &v, 16); }
                     else for (uint32_t k = i; k < outSize; k++) bdst[k] = sOut[k];
                 }
                 produced += outSize;
+                if (prof && t == 0) {
+                    const unsigned long long c3 = gc_clock();
+                    atomicAdd(&prof[0], c1 - c0); atomicAdd(&prof[1], c2 - c1); atomicAdd(&prof[2], c3 - c2); atomicAdd(&prof[3], 1ull);
+                }
             }
             __threadfence();
             __syncthreads();
@@ -912,9 +959,10 @@ extern "C" void gc_zstd_dec_launch_index(hipStream_t st, const uint8_t* src, con
     GC_LAUNCH(gc_zstd_dec_index_kernel, (nFrames + 63u) / 64u, 64, st, src, frames, nFrames, blocks, frameTot);
 }
 extern "C" void gc_zstd_dec_launch_decode(hipStream_t st, const uint8_t* src, uint64_t srcSize, uint8_t* dst, uint64_t dstCap, const GcZdFrame* frames, uint32_t nFrames,
-                                          GcZdBlock* blocks, uint32_t nBlocks, uint32_t* ticket, uint8_t* litWork, uint64_t litWorkSize, void* seqWork, uint64_t* result)
+                                          GcZdBlock* blocks, uint32_t nBlocks, uint32_t* ticket, uint8_t* litWork, uint64_t litWorkSize, void* seqWork, uint64_t* result,
+                                          unsigned long long* prof)
 {
     if (nBlocks) GC_LAUNCH(gc_zstd_dec_entropy_kernel, nBlocks, GC_ZD_ENT_T, st, src, srcSize, frames, blocks, litWork, (GcU4*)seqWork);
     const uint32_t wg = nFrames < GC_ZD_MAX_WG ? nFrames : GC_ZD_MAX_WG;
-    GC_LAUNCH(gc_zstd_dec_exec_kernel, wg, GC_ZD_T, st, src, srcSize, dst, dstCap, frames, nFrames, (const GcZdBlock*)blocks, ticket, (const uint8_t*)litWork, litWorkSize, (GcU4*)seqWork, result);
+    GC_LAUNCH(gc_zstd_dec_exec_kernel, wg, GC_ZD_T, st, src, srcSize, dst, dstCap, frames, nFrames, (const GcZdBlock*)blocks, ticket, (const uint8_t*)litWork, litWorkSize, (GcU4*)seqWork, result, prof);
 }
