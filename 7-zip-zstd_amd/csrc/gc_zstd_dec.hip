@@ -783,9 +783,11 @@ gc_zstd_dec_exec_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint8
                         const int32_t s0 = (int32_t)d - (int32_t)off;
                         const uint32_t srcEnd = off >= ml ? (uint32_t)(s0 + (int32_t)ml) : d;      // end of the part of the source that is not its own output
                         const uint32_t isLong = ml > 48u ? 1u : 0u;
+                        if (prof && lane == 0u) atomicAdd(&prof[5], 1ull);
                         for (;;) {
                             const uint64_t pm = __ballot(pending);
                             if (!pm) break;
+                            if (prof && lane == 0u) atomicAdd(&prof[4], 1ull);
                             const uint32_t fl = gc_ctz64(pm);
                             const uint32_t W = gc_readlane(d, fl);
                             if (gc_readlane(isLong, fl)) {
@@ -892,29 +894,33 @@ gc_zstd_dec_exec_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint8
 // ---- host: frame scan (headers only) ----
 static uint32_t zd_le32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 
-// ZSTD_findFrameSizeInfo (zstd_decompress.c:734) + ZSTD_getFrameHeader_advanced (:447) for every frame of the input
-extern "C" int gc_zstd_scan_frames(const void* srcv, size_t n, gc_zstd_frame* out, size_t maxFrames, size_t* nFrames, uint64_t* contentTotal)
+// ZSTD_findFrameSizeInfo (zstd_decompress.c:734) + ZSTD_getFrameHeader_advanced (:447) for every frame of the input.
+// partial: an input that ends inside a frame is not an error; *consumed = end of the last whole frame (or skippable frame).
+static int zd_scan(const uint8_t* src, size_t n, gc_zstd_frame* out, size_t maxFrames, size_t* nFrames, uint64_t* contentTotal, bool partial, size_t* consumed)
 {
-    if ((!srcv && n) || !nFrames) return GC_ERR_PARAM;
-    const uint8_t* src = (const uint8_t*)srcv;
     size_t pos = 0, cnt = 0;
     uint64_t total = 0; bool known = true;
+    const int truncated = partial ? GC_OK : GC_ERR_CORRUPT;
+#define ZD_NEED(cond) if (!(cond)) { rc = truncated; break; }
+    int rc = GC_OK;
     while (pos < n) {
-        if (n - pos < 8u) return GC_ERR_CORRUPT;
+        ZD_NEED(n - pos >= 4u)
         const uint32_t magic = zd_le32(src + pos);
         if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {                   // skippable frame
+            ZD_NEED(n - pos >= 8u)
             const uint64_t sz = zd_le32(src + pos + 4);
-            if (sz > n - pos - 8u) return GC_ERR_CORRUPT;
+            ZD_NEED(sz <= n - pos - 8u)
             pos += 8u + (size_t)sz; continue;
         }
         if (magic != 0xFD2FB528u) return GC_ERR_CORRUPT;
+        ZD_NEED(n - pos >= 6u)
         const size_t start = pos;
         const uint32_t fhd = src[pos + 4];
         const uint32_t fcsFlag = fhd >> 6, single = (fhd >> 5) & 1u, checksum = (fhd >> 2) & 1u, didFlag = fhd & 3u;
         if (fhd & 8u) return GC_ERR_CORRUPT;                           // reserved bit
         const uint32_t didSize = didFlag == 3u ? 4u : didFlag, fcsSize = fcsFlag == 0u ? single : (fcsFlag == 1u ? 2u : (fcsFlag == 2u ? 4u : 8u));
         const size_t hdr = 5u + (single ? 0u : 1u) + didSize + fcsSize;
-        if (n - pos < hdr) return GC_ERR_CORRUPT;
+        ZD_NEED(n - pos >= hdr)
         size_t p = pos + 5u;
         if (!single) { if ((src[p] >> 3) + 10u > 31u) return GC_ERR_PARAM; p++; }   // ZSTD_WINDOWLOG_MAX
         uint32_t did = 0;
@@ -926,17 +932,19 @@ extern "C" int gc_zstd_scan_frames(const void* srcv, size_t n, gc_zstd_frame* ou
         if (fcsSize == 2u) fcs += 256u;
         p += fcsSize;
         uint64_t nb = 0;
+        bool whole = false;
         for (;;) {                                                     // blocks
-            if (n - p < 3u) return GC_ERR_CORRUPT;
+            if (n - p < 3u) break;
             const uint32_t h = (uint32_t)src[p] | ((uint32_t)src[p + 1] << 8) | ((uint32_t)src[p + 2] << 16);
             const uint32_t bt = (h >> 1) & 3u, bs = h >> 3;
             if (bt == 3u) return GC_ERR_CORRUPT;
             const size_t payload = bt == 1u ? 1u : bs;
-            if (n - p - 3u < payload) return GC_ERR_CORRUPT;
+            if (n - p - 3u < payload) break;
             p += 3u + payload; nb++;
-            if (h & 1u) break;
+            if (h & 1u) { whole = true; break; }
         }
-        if (checksum) { if (n - p < 4u) return GC_ERR_CORRUPT; p += 4u; }
+        if (whole && checksum) { if (n - p < 4u) whole = false; else p += 4u; }
+        ZD_NEED(whole)
         if (nb > 0xFFFFFFFFull) return GC_ERR_PARAM;
         if (out) {
             if (cnt >= maxFrames) return GC_ERR_DST_SMALL;
@@ -948,9 +956,24 @@ extern "C" int gc_zstd_scan_frames(const void* srcv, size_t n, gc_zstd_frame* ou
         if (fcsSize) total += fcs; else known = false;
         cnt++; pos = p;
     }
+#undef ZD_NEED
+    if (rc != GC_OK) return rc;
     *nFrames = cnt;
     if (contentTotal) *contentTotal = known ? total : ~0ull;
+    if (consumed) *consumed = pos;
     return GC_OK;
+}
+
+extern "C" int gc_zstd_scan_frames(const void* src, size_t n, gc_zstd_frame* out, size_t maxFrames, size_t* nFrames, uint64_t* contentTotal)
+{
+    if ((!src && n) || !nFrames) return GC_ERR_PARAM;
+    return zd_scan((const uint8_t*)src, n, out, maxFrames, nFrames, contentTotal, false, nullptr);
+}
+
+extern "C" int gc_zstd_scan_prefix(const void* src, size_t n, gc_zstd_frame* out, size_t maxFrames, size_t* nFrames, uint64_t* contentTotal, size_t* consumed)
+{
+    if ((!src && n) || !nFrames || !consumed) return GC_ERR_PARAM;
+    return zd_scan((const uint8_t*)src, n, out, maxFrames, nFrames, contentTotal, true, consumed);
 }
 
 // called by gc_api.hip

@@ -78,6 +78,7 @@ static const GUID IID_ICompressProgressInfo          = GC_7Z_IID(4, 0x04);
 static const GUID IID_ICompressCoder                 = GC_7Z_IID(4, 0x05);
 static const GUID IID_ICompressSetCoderPropertiesOpt = GC_7Z_IID(4, 0x1F);
 static const GUID IID_ICompressSetCoderProperties    = GC_7Z_IID(4, 0x20);
+static const GUID IID_ICompressSetDecoderProperties2 = GC_7Z_IID(4, 0x22);
 static const GUID IID_ICompressWriteCoderProperties  = GC_7Z_IID(4, 0x23);
 static const GUID IID_ICompressSetCoderMt            = GC_7Z_IID(4, 0x25);
 
@@ -105,6 +106,7 @@ struct ICompressSetCoderPropertiesOpt : IUnknown { virtual HRESULT SetCoderPrope
 struct ICompressSetCoderProperties : IUnknown { virtual HRESULT SetCoderProperties(const PROPID* ids, const PROPVARIANT* props, uint32_t n) = 0; };
 struct ICompressWriteCoderProperties : IUnknown { virtual HRESULT WriteCoderProperties(ISequentialOutStream* out) = 0; };
 struct ICompressSetCoderMt : IUnknown { virtual HRESULT SetNumberOfThreads(uint32_t n) = 0; };
+struct ICompressSetDecoderProperties2 : IUnknown { virtual HRESULT SetDecoderProperties2(const uint8_t* data, uint32_t size) = 0; };   // ICoder.h:187-189
 
 namespace NCoderPropID { enum { kDefaultProp = 0, kDictionarySize = 1, kNumThreads = 13, kLevel = 15, kReduceSize = 16, kExpectedDataSize = 17 }; }
 namespace NMethodPropID { enum { kID = 0, kName, kDecoder, kEncoder, kPackStreams, kUnpackStreams, kDescription, kDecoderIsAssigned, kEncoderIsAssigned, kDigestSize, kIsFilter }; }

@@ -8,14 +8,17 @@
 // The coder object mirrors NCompress::NZSTD::CEncoder (CPP/7zip/Compress/ZstdEncoder.h:35-78) and
 // NCompress::NLzma2::CFastEncoder (CPP/7zip/Compress/Lzma2Encoder.h:60-100): ICompressCoder,
 // ICompressSetCoderMt, ICompressSetCoderProperties, ICompressSetCoderPropertiesOpt, ICompressWriteCoderProperties.
-// Only ENCODERS are provided (the hot path of SURVEY.md section 8); decoding stays with the host's own decoders, which is
-// how 7-Zip resolves a method id that several modules register (decoder lookup by id, CreateCoder.cpp:206-232).
+// ENCODERS for the three methods (the hot path of SURVEY.md section 8) and a DECODER for ZSTD (section 8f1; mirrors
+// NCompress::NZSTD::CDecoder, CPP/7zip/Compress/ZstdDecoder.h:43-100).  Decoders are looked up by method id, built-in codecs first
+// (CreateCoder.cpp:206-232): a host that has a ZSTD decoder of its own keeps using it, a host without one (mainline 7-Zip) gets this one.
 //
 // No C++ exception crosses the boundary (the reference wraps with COM_TRY, CodecExports.cpp:97-124): nothing below
 // throws; allocations are checked.
 #include "gc_7z_abi.h"
 #include "gpucodec.h"
 #include <new>
+#include <stdlib.h>
+#include <string.h>
 
 #define GC_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -194,6 +197,123 @@ public:
     }
 };
 
+// ZSTD decoder: the input stream is read in large pieces; every piece is cut at the end of its last whole frame (gc_zstd_scan_prefix), those
+// frames are decoded on the GPU (entropy stage per block, match copies per frame), the content is written out, the cut-off tail moves to the
+// front of the buffer.  A frame larger than the buffer grows the buffer.  Errors follow ZstdDecoder.cpp:113-131: damaged data E_FAIL,
+// unsupported frames (dictionary) E_NOTIMPL.
+class CGpuZstdDecoder final : public ICompressCoder, public ICompressSetDecoderProperties2, public ICompressSetCoderMt {
+    ULONG refs_ = 1;
+    gc_ctx* ctx_ = nullptr;
+    uint8_t* inBuf_ = nullptr; uint8_t* outBuf_ = nullptr; size_t inCap_ = 0, outCap_ = 0;     // pinned (gc_host_alloc)
+    gc_zstd_frame* frames_ = nullptr; size_t framesCap_ = 0;
+
+    bool grow(uint8_t** buf, size_t* cap, size_t need, size_t keep)
+    {
+        if (need <= *cap) return true;
+        uint8_t* nb = (uint8_t*)gc_host_alloc(need);
+        if (!nb) return false;
+        if (keep) memcpy(nb, *buf, keep);
+        gc_host_free(*buf); *buf = nb; *cap = need;
+        return true;
+    }
+
+public:
+    ~CGpuZstdDecoder() { if (ctx_) gc_ctx_destroy(ctx_); gc_host_free(inBuf_); gc_host_free(outBuf_); free(frames_); }
+
+    HRESULT QueryInterface(const GUID& iid, void** out) override
+    {
+        if (!out) return E_INVALIDARG;
+        *out = nullptr;
+        if (iid == IID_IUnknown || iid == IID_ICompressCoder) *out = static_cast<ICompressCoder*>(this);
+        else if (iid == IID_ICompressSetDecoderProperties2) *out = static_cast<ICompressSetDecoderProperties2*>(this);
+        else if (iid == IID_ICompressSetCoderMt) *out = static_cast<ICompressSetCoderMt*>(this);
+        else return E_NOINTERFACE;
+        ++refs_;
+        return S_OK;
+    }
+    ULONG AddRef() override { return ++refs_; }
+    ULONG Release() override { if (--refs_ != 0) return refs_; delete this; return 0; }
+
+    HRESULT SetNumberOfThreads(uint32_t) override { return S_OK; }
+    // 1 byte of flags; 3 or 5 bytes from older encoders (and from this module's encoder) are accepted as well -- ZstdDecoder.cpp:32-49
+    HRESULT SetDecoderProperties2(const uint8_t*, uint32_t size) override { return (size == 1 || size == 3 || size == 5) ? S_OK : E_NOTIMPL; }
+
+    HRESULT Code(ISequentialInStream* in, ISequentialOutStream* out, const uint64_t*, const uint64_t* outSize, ICompressProgressInfo* progress) override
+    {
+        if (!in || !out) return E_INVALIDARG;
+        if (!ctx_ && gc_ctx_create(&ctx_, 0) != GC_OK) { ctx_ = nullptr; return E_FAIL; }       // no gfx950 device: there is no CPU decoder behind this object
+        const size_t kPiece = (size_t)64 << 20;
+        if (!grow(&inBuf_, &inCap_, kPiece, 0)) return E_OUTOFMEMORY;
+        uint64_t totalIn = 0, totalOut = 0;
+        size_t have = 0;
+        bool eof = false;
+        for (;;) {
+            while (!eof && have < inCap_) {
+                const size_t want = inCap_ - have;
+                size_t got = want;
+                HRESULT r = read_full(in, inBuf_ + have, &got);
+                if (r != S_OK) return r;
+                have += got; totalIn += got;
+                if (got < want) eof = true;
+            }
+            if (have == 0) break;
+            size_t nFrames = 0, consumed = 0; uint64_t content = 0;
+            int rc = gc_zstd_scan_prefix(inBuf_, have, nullptr, 0, &nFrames, nullptr, &consumed);
+            if (rc != GC_OK) return rc == GC_ERR_PARAM ? E_NOTIMPL : E_FAIL;
+            if (consumed == 0) {                                   // not even one whole frame in the buffer
+                if (eof) return E_FAIL;                            // the stream ends inside a frame
+                if (!grow(&inBuf_, &inCap_, inCap_ * 2u, have)) return E_OUTOFMEMORY;
+                continue;
+            }
+            if (nFrames > framesCap_) {
+                free(frames_); framesCap_ = 0;
+                frames_ = (gc_zstd_frame*)malloc((nFrames + 64u) * sizeof(gc_zstd_frame));
+                if (!frames_) return E_OUTOFMEMORY;
+                framesCap_ = nFrames + 64u;
+            }
+            if (nFrames) {
+                rc = gc_zstd_scan_prefix(inBuf_, have, frames_, framesCap_, &nFrames, &content, &consumed);
+                if (rc != GC_OK) return E_FAIL;
+                // capacity: the content sizes the frames state; else what the host expects (outSize); else a guess that doubles until it fits
+                size_t cap = content != ~0ull ? (size_t)content : (outSize && *outSize > totalOut ? (size_t)(*outSize - totalOut) : consumed * 8u + ((size_t)1 << 20));
+                size_t produced = 0;
+                for (;;) {
+                    if (!grow(&outBuf_, &outCap_, cap ? cap : 1u, 0)) return E_OUTOFMEMORY;
+                    rc = gc_zstd_decompress_host(ctx_, inBuf_, consumed, outBuf_, cap, &produced);
+                    if (rc == GC_ERR_DST_SMALL && content == ~0ull && cap < ((size_t)1 << 40)) { cap *= 2u; continue; }
+                    break;
+                }
+                if (rc != GC_OK) return rc == GC_ERR_PARAM ? E_NOTIMPL : hresult_of(rc);
+                HRESULT r = write_all(out, outBuf_, produced);
+                if (r != S_OK) return r;
+                totalOut += produced;
+            }
+            have -= consumed;
+            if (have) memmove(inBuf_, inBuf_ + consumed, have);
+            if (progress) {
+                const uint64_t pin = totalIn - have;
+                HRESULT r = progress->SetRatioInfo(&pin, &totalOut);
+                if (r != S_OK) return r;
+            }
+            if (eof && have == 0) break;
+        }
+        return S_OK;
+    }
+};
+
+HRESULT create_decoder(uint32_t index, const GUID* iid, void** out)
+{
+    if (!out) return E_INVALIDARG;
+    *out = nullptr;
+    if (index >= kNumMethods || kMethods[index].kind != KIND_ZSTD) return CLASS_E_CLASSNOTAVAILABLE;
+    if (!iid || !(*iid == IID_ICompressCoder)) return E_NOINTERFACE;
+    CGpuZstdDecoder* d = new (std::nothrow) CGpuZstdDecoder();
+    IUnknown* obj = d ? static_cast<ICompressCoder*>(d) : nullptr;
+    if (!obj) return E_OUTOFMEMORY;
+    *out = obj;
+    return S_OK;
+}
+
 HRESULT create_encoder(uint32_t index, const GUID* iid, void** out)
 {
     if (!out) return E_INVALIDARG;
@@ -225,16 +345,22 @@ GC_EXPORT HRESULT GetMethodProperty(uint32_t index, PROPID propID, PROPVARIANT* 
             value->bstrVal = gc_bstr_bytes(&g, sizeof(g)); if (!value->bstrVal) return E_OUTOFMEMORY; value->vt = VT_BSTR; break;
         }
         case NMethodPropID::kEncoderIsAssigned: value->vt = VT_BOOL; value->boolVal = -1; break;   // VARIANT_TRUE
-        case NMethodPropID::kDecoderIsAssigned: value->vt = VT_BOOL; value->boolVal = 0; break;
+        case NMethodPropID::kDecoder:
+            if (m.kind == KIND_ZSTD) {
+                GUID g = gc_codec_clsid(m.id, false);
+                value->bstrVal = gc_bstr_bytes(&g, sizeof(g)); if (!value->bstrVal) return E_OUTOFMEMORY; value->vt = VT_BSTR;
+            }
+            break;
+        case NMethodPropID::kDecoderIsAssigned: value->vt = VT_BOOL; value->boolVal = m.kind == KIND_ZSTD ? -1 : 0; break;
         case NMethodPropID::kIsFilter: value->vt = VT_BOOL; value->boolVal = 0; break;
-        default: break;      // kDecoder, kPackStreams, ...: left VT_EMPTY
+        default: break;      // kPackStreams, ...: left VT_EMPTY
     }
     return S_OK;
 }
 
 GC_EXPORT HRESULT CreateEncoder(uint32_t index, const GUID* iid, void** out) { return create_encoder(index, iid, out); }
 
-GC_EXPORT HRESULT CreateDecoder(uint32_t, const GUID*, void** out) { if (out) *out = nullptr; return CLASS_E_CLASSNOTAVAILABLE; }
+GC_EXPORT HRESULT CreateDecoder(uint32_t index, const GUID* iid, void** out) { return create_decoder(index, iid, out); }
 
 GC_EXPORT HRESULT CreateObject(const GUID* clsid, const GUID* iid, void** out)
 {
@@ -243,6 +369,8 @@ GC_EXPORT HRESULT CreateObject(const GUID* clsid, const GUID* iid, void** out)
     if (!clsid) return E_INVALIDARG;
     for (uint32_t i = 0; i < kNumMethods; i++)
         if (*clsid == gc_codec_clsid(kMethods[i].id, true)) return create_encoder(i, iid, out);
+    for (uint32_t i = 0; i < kNumMethods; i++)
+        if (kMethods[i].kind == KIND_ZSTD && *clsid == gc_codec_clsid(kMethods[i].id, false)) return create_decoder(i, iid, out);
     return CLASS_E_CLASSNOTAVAILABLE;
 }
 

@@ -193,6 +193,10 @@ typedef struct gc_zstd_frame {
     uint32_t reserved;
 } gc_zstd_frame;
 int         gc_zstd_scan_frames(const void* src, size_t n, gc_zstd_frame* frames, size_t maxFrames, size_t* nFrames, uint64_t* contentTotal);
+/* the same for a stream that is still being read: an input that ends inside a frame is not an error, *consumed = the bytes the whole
+ * frames (and skippable frames) in front of it take -- what a streaming caller (the plugin's ICompressCoder::Code) can decode now */
+int         gc_zstd_scan_prefix(const void* src, size_t n, gc_zstd_frame* frames, size_t maxFrames, size_t* nFrames, uint64_t* contentTotal,
+                                size_t* consumed);
 int         gc_zstd_decompress_device(gc_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t dstCapacity,
                                       const gc_zstd_frame* frames, size_t nFrames, size_t* decompressedSize);
 int         gc_zstd_decompress_host(gc_ctx* ctx, const void* src, size_t n, void* dst, size_t dstCapacity, size_t* decompressedSize);

@@ -6,6 +6,7 @@
 //
 //   plugin_host <module.so> list
 //   plugin_host <module.so> encode <method-name> <level> <in-file> <out-file> [props-out-file] [by-clsid]
+//   plugin_host <module.so> decode <method-name> <props-file|-> <in-file> <out-file> [by-clsid]     (what 7zDecode.cpp:260-420 does with a decoder)
 #include "../../7-zip-zstd_amd/plugin/gc_7z_abi.h"
 #include <dlfcn.h>
 #include <stdio.h>
@@ -87,9 +88,38 @@ int main(int argc, char** argv)
             memcpy(&encId, v.bstrVal, 16); gc_variant_clear(&v);
         }
         if (mode == "list") printf("%u %llX %s enc=%d dec=%d clsid=%08X-%04X-%04X\n", i, (unsigned long long)id, name.c_str(), enc, dec, encId.Data1, encId.Data2, encId.Data3);
-        if (argc > 3 && name == argv[3] && enc) { found = (int)i; foundId = id; }
+        if (argc > 3 && name == argv[3] && (mode == "decode" ? dec : enc)) { found = (int)i; foundId = id; }
     }
     if (mode == "list") return 0;
+    if (mode == "decode") {
+        if (argc < 7 || found < 0) { fprintf(stderr, "method not found\n"); return 8; }
+        const bool byClsidD = argc > 7 && std::string(argv[7]) == "by-clsid";
+        void* rawD = nullptr; HRESULT rd;
+        if (byClsidD) { GUID c = gc_codec_clsid(foundId, false); rd = createObj(&c, &IID_ICompressCoder, &rawD); }
+        else rd = createDec((uint32_t)found, &IID_ICompressCoder, &rawD);
+        if (rd != S_OK || !rawD) { fprintf(stderr, "CreateDecoder failed: %08X\n", (unsigned)rd); return 9; }
+        ICompressCoder* dec = (ICompressCoder*)rawD;
+        ICompressSetDecoderProperties2* sp = nullptr;
+        if (dec->QueryInterface(IID_ICompressSetDecoderProperties2, (void**)&sp) != S_OK) return 11;
+        if (std::string(argv[4]) != "-") {
+            FILE* pf = fopen(argv[4], "rb"); if (!pf) return 13;
+            uint8_t pb[16]; size_t pn = fread(pb, 1, sizeof(pb), pf); fclose(pf);
+            if (sp->SetDecoderProperties2(pb, (uint32_t)pn) != S_OK) { fprintf(stderr, "SetDecoderProperties2 refused %zu bytes\n", pn); return 12; }
+        }
+        if (sp->SetDecoderProperties2(nullptr, 7) != E_NOTIMPL) { fprintf(stderr, "property size check\n"); return 12; }
+        FileIn in; in.f = fopen(argv[5], "rb"); FileOut out; out.f = fopen(argv[6], "wb");
+        if (!in.f || !out.f) { fprintf(stderr, "file open\n"); return 13; }
+        Progress prog;
+        HRESULT r2 = dec->Code(&in, &out, nullptr, nullptr, &prog);
+        fclose(in.f); fclose(out.f);
+        if (r2 != S_OK) { fprintf(stderr, "Code failed: %08X\n", (unsigned)r2); return 15; }
+        if (prog.out != out.total) { fprintf(stderr, "progress accounting\n"); return 16; }
+        if (in.refs != 1 || out.refs != 1 || prog.refs != 1) { fprintf(stderr, "coder kept a stream reference\n"); return 17; }
+        sp->Release();
+        if (dec->Release() != 0) { fprintf(stderr, "refcount leak\n"); return 18; }
+        printf("ok in=%llu out=%llu\n", (unsigned long long)prog.in, (unsigned long long)prog.out);
+        return 0;
+    }
     if (mode != "encode" || argc < 7 || found < 0) { fprintf(stderr, "method not found\n"); return 8; }
     const bool byClsid = argc > 8 && std::string(argv[8]) == "by-clsid";
     void* raw = nullptr;
@@ -99,7 +129,7 @@ int main(int argc, char** argv)
     if (r != S_OK || !raw) { fprintf(stderr, "CreateEncoder failed: %08X\n", (unsigned)r); return 9; }
     // wrong interface id must be refused, decoders are not provided
     { void* bad = nullptr; if (createEnc((uint32_t)found, &IID_ISequentialInStream, &bad) != E_NOINTERFACE || bad) { fprintf(stderr, "iid check\n"); return 10; }
-      if (createDec((uint32_t)found, &IID_ICompressCoder, &bad) != CLASS_E_CLASSNOTAVAILABLE || bad) { fprintf(stderr, "decoder check\n"); return 10; } }
+      if (foundId != 0x4F71101 && (createDec((uint32_t)found, &IID_ICompressCoder, &bad) != CLASS_E_CLASSNOTAVAILABLE || bad)) { fprintf(stderr, "decoder check\n"); return 10; } }
     ICompressCoder* coder = (ICompressCoder*)raw;
     ICompressSetCoderProperties* setProps = nullptr; ICompressWriteCoderProperties* writeProps = nullptr;
     ICompressSetCoderMt* mt = nullptr; ICompressSetCoderPropertiesOpt* opt = nullptr; IUnknown* unk = nullptr; void* none = nullptr;

@@ -26,7 +26,8 @@ def test_exports_and_method_listing(emu_module):
     assert r.returncode == 0, r.stderr
     lines = r.stdout.strip().splitlines()
     assert lines[0].split()[1:3] == ["4F71101", "ZSTD"]            # id and name of ZstdRegister.cpp:13-17
-    assert "enc=1 dec=0" in lines[0] and "clsid=23170F69-40C1-2791" in lines[0]
+    assert "enc=1 dec=1" in lines[0] and "clsid=23170F69-40C1-2791" in lines[0]      # ZSTD: encoder and decoder
+    assert "enc=1 dec=0" in lines[1] and "enc=1 dec=0" in lines[2]
     assert lines[1].split()[1:3] == ["21", "FLZMA2"]               # FastLzma2Register.cpp:13-18
     assert lines[2].split()[1:3] == ["4F71102", "BROTLI"]          # BrotliRegister.cpp:13-17
     import ctypes
@@ -125,3 +126,72 @@ def test_brotli_plain_stream_through_com_surface(O, emu_module, tmp_path, n):
     assert r.returncode == 0, r.stderr + r.stdout
     c = np.fromfile(dst, dtype=np.uint8)
     assert np.array_equal(O.ref_brotli_decompress(c, n), x)
+
+
+def _zstd_streams(O, x):
+    """(name, compressed bytes) the decoder object has to handle: one frame, six frames + a skippable one, a frame without a content size"""
+    import struct
+    b = x.tobytes()
+    skip = struct.pack("<II", 0x184D2A50, 5) + b"12345"
+    yield "one-frame", O.ref_zstd_compress(b, 3).tobytes()
+    yield "frames+skippable", skip + O.ref_zstd_compress(b, 5, piece=max(1, len(b) // 6)).tobytes() + skip
+    yield "streamed+checksum", O.ref_zstd_compress_opts(b, 1, checksum=True, streamed=True).tobytes()
+
+
+@pytest.mark.parametrize("n", [0, 1, 5 * BLK + 333])
+def test_zstd_decode_through_com_surface(O, emu_module, tmp_path, n):
+    """CreateDecoder / CreateObject(decoder class id) -> SetDecoderProperties2 -> Code(): the content of reference-encoder streams."""
+    if O.ref("zstd") is None:
+        pytest.skip("oracle/_ref not built")
+    x = O.corpus("silesia-like", n)
+    props = tmp_path / "props.bin"
+    props.write_bytes(bytes([1, 5, 3, 0, 0]))
+    for i, (name, comp) in enumerate(_zstd_streams(O, x)):
+        src, dst = tmp_path / ("c%d.zst" % i), tmp_path / ("d%d.bin" % i)
+        src.write_bytes(comp)
+        r = _host(emu_module, "decode", "ZSTD", props if i != 1 else "-", src, dst, *(["by-clsid"] if i == 2 else []))
+        assert r.returncode == 0, name + ": " + r.stderr + r.stdout
+        assert dst.read_bytes() == x.tobytes(), name
+    bad = tmp_path / "bad.zst"
+    comp = bytearray(O.ref_zstd_compress_opts(x.tobytes(), 3, checksum=True).tobytes())
+    comp[len(comp) // 2] ^= 0x10
+    bad.write_bytes(bytes(comp))
+    r = _host(emu_module, "decode", "ZSTD", "-", bad, tmp_path / "bad.out")
+    assert r.returncode == 15 and "80004005" in r.stderr                    # E_FAIL, like ZstdDecoder.cpp:113-131
+    trunc = tmp_path / "trunc.zst"
+    trunc.write_bytes(bytes(comp[: len(comp) - 3]))
+    r = _host(emu_module, "decode", "ZSTD", "-", trunc, tmp_path / "trunc.out")
+    assert r.returncode == 15
+
+
+def test_zstd_encode_then_decode_through_com_surface(O, emu_module, tmp_path):
+    x = O.corpus("text-zipf", 3 * BLK + 17)
+    src, mid, props, dst = tmp_path / "in.bin", tmp_path / "mid.zst", tmp_path / "props.bin", tmp_path / "out.bin"
+    x.tofile(src)
+    r = _host(emu_module, "encode", "ZSTD", 3, src, mid, props)
+    assert r.returncode == 0, r.stderr + r.stdout
+    r = _host(emu_module, "decode", "ZSTDGPU", props, mid, dst)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert dst.read_bytes() == x.tobytes()
+
+
+@pytest.mark.gpu
+def test_product_plugin_zstd_decoder_on_gpu(O, graft, tmp_path):
+    graft.build_hip()
+    module = graft.build_plugin()
+    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "emu"), "_build/plugin_host"], check=True, capture_output=True)
+    n = 150 * 1024 * 1024 + 4321                                   # the compressed stream exceeds one 64 MiB read piece of the decoder
+    x = O.corpus("silesia-like", n)
+    src, mid, props, dst = tmp_path / "in.bin", tmp_path / "mid.zst", tmp_path / "props.bin", tmp_path / "out.bin"
+    x.tofile(src)
+    r = _host(module, "encode", "ZSTD", 3, src, mid, props)
+    assert r.returncode == 0, r.stderr + r.stdout
+    r = _host(module, "decode", "ZSTD", props, mid, dst)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert np.array_equal(np.fromfile(dst, dtype=np.uint8), x)
+    for i, (name, comp) in enumerate(_zstd_streams(O, x[: 40 * 1024 * 1024])):
+        s2, d2 = tmp_path / ("c%d.zst" % i), tmp_path / ("d%d.bin" % i)
+        s2.write_bytes(comp)
+        r = _host(module, "decode", "ZSTD", "-", s2, d2)
+        assert r.returncode == 0, name + ": " + r.stderr + r.stdout
+        assert d2.read_bytes() == x[: 40 * 1024 * 1024].tobytes(), name

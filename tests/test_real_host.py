@@ -56,8 +56,9 @@ def _run(host_dir, env, *args):
 def _check_listing(out, module_name):
     assert module_name in out, out
     lines = [l.split() for l in out.splitlines()]
-    ours = [l for l in lines if len(l) == 4 and l[0] == "1" and l[1] == "E"]        # "<lib index> E <id> <name>": encoder only, from library 1
+    ours = [l for l in lines if len(l) == 4 and l[0] == "1" and l[1] in ("E", "ED")]   # "<lib index> E|ED <id> <name>" from library 1
     got = {(l[2], l[3]) for l in ours}
+    assert {l[3] for l in ours if l[1] == "ED"} == {"ZSTD", "ZSTDGPU"}               # encoder + decoder: ZSTD only
     for want in [("4F71101", "ZSTD"), ("21", "FLZMA2"), ("4F71102", "BROTLI"), ("4F71101", "ZSTDGPU"), ("21", "FLZMA2GPU"), ("4F71102", "BROTLIGPU")]:
         assert want in got, (want, out)
 
