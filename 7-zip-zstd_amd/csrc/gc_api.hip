@@ -922,7 +922,7 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
     for (int i = 0; i < 2 && rc == GC_OK; i++) if (!c->zdEv[i] && hipEventCreate(&c->zdEv[i]) != hipSuccess) rc = GC_ERR_HIP;
     // test hook GC_ZD_PROF=1: shader cycles of the execution kernel's phases (thread 0's view, summed over blocks) on stderr
     unsigned long long* zdProf = nullptr;
-    { uint32_t v = 0; if (gc_env_u32("GC_ZD_PROF", 1, 1, &v) && hipMalloc((void**)&zdProf, 64) == hipSuccess) hipMemsetAsync(zdProf, 0, 64, c->stream); }
+    { uint32_t v = 0; if (gc_env_u32("GC_ZD_PROF", 1, 1, &v) && hipMalloc((void**)&zdProf, 128) == hipSuccess) hipMemsetAsync(zdProf, 0, 128, c->stream); }
     uint64_t dstOff = 0;
     size_t i = 0;
     while (i < nFrames && rc == GC_OK) {
@@ -982,10 +982,12 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
     }
     free(h); free(res);
     if (zdProf) {
-        unsigned long long pv[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-        if (hipMemcpy(pv, zdProf, 64, hipMemcpyDeviceToHost) == hipSuccess && pv[3])
-            fprintf(stderr, "[GC_ZD_PROF] compressed blocks %llu: cycles per block pass1 %.0f pass2 %.0f flush %.0f; pass 2: %.1f groups of 64 sequences per block, %.2f rounds per group\n", pv[3],
-                    (double)pv[0] / pv[3], (double)pv[1] / pv[3], (double)pv[2] / pv[3], (double)pv[5] / pv[3], pv[5] ? (double)pv[4] / pv[5] : 0.0);
+        unsigned long long pv[16] = { 0 };
+        if (hipMemcpy(pv, zdProf, 128, hipMemcpyDeviceToHost) == hipSuccess && pv[3])
+            fprintf(stderr, "[GC_ZD_PROF] compressed blocks %llu: cycles per block pass1 %.0f pass2 %.0f flush %.0f; pass 2: %.1f groups of 64 sequences per block, %.2f rounds per group of which %.2f for one special match\n", pv[3],
+                    (double)pv[0] / pv[3], (double)pv[1] / pv[3], (double)pv[2] / pv[3], (double)pv[5] / pv[3], pv[5] ? (double)pv[4] / pv[5] : 0.0, pv[5] ? (double)pv[6] / pv[5] : 0.0);
+        if (pv[12]) fprintf(stderr, "[GC_ZD_PROF] entropy kernel, cycles per block: sequences wave tables %.0f decode %.0f; literals wave tree %.0f streams %.0f\n",
+                            (double)pv[8] / pv[12], (double)pv[9] / pv[12], (double)pv[10] / pv[12], (double)pv[11] / pv[12]);
         hipFree(zdProf);
     }
     if (rc == GC_OK && outSize) *outSize = (size_t)dstOff;

@@ -460,11 +460,12 @@ __device__ bool zd_huf_parallel(const uint8_t* sp, uint32_t n, uint32_t count, u
 }
 
 extern "C" __global__ void __launch_bounds__(GC_ZD_ENT_T)
-gc_zstd_dec_entropy_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const GcZdFrame* __restrict__ frames, GcZdBlock* blocks, uint8_t* litWork, GcU4* seqWork)
+gc_zstd_dec_entropy_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const GcZdFrame* __restrict__ frames, GcZdBlock* blocks, uint8_t* litWork, GcU4* seqWork,
+                           unsigned long long* prof)
 {
     __shared__ uint16_t sHuf[1u << ZD_HUF_LOG_MAX];
     __shared__ GcU2 sLL[512], sML[512], sOF[256], sFseW[64];
-    __shared__ __attribute__((aligned(16))) uint8_t sBuf[GC_ZD_CHUNK + 32u];
+    __shared__ __attribute__((aligned(16))) uint8_t sBuf[GC_ZD_CHUNK + 64u];
     __shared__ __attribute__((aligned(16))) uint8_t sWinL[ZD_WIN_L + 8u], sWinS[ZD_WIN_S + 8u], sWinR[ZD_WIN_S + 8u];
     __shared__ int16_t sNormA[64], sNormB[256];
     __shared__ uint16_t sNextA[64], sNextB[256];
@@ -487,6 +488,8 @@ gc_zstd_dec_entropy_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, co
     for (uint32_t i = t; i < ZD_WIN_S + 8u; i += GC_ZD_ENT_T) sWinS[i] = e.seqPos + i < bs ? bsrc[e.seqPos + i] : (uint8_t)0;
     if (t < 16u) sV[t] = 0;
     __syncthreads();
+    const unsigned long long pc0 = prof ? gc_clock() : 0ull;
+    unsigned long long pc1 = 0;
 
     if (wave == 1u) {
         // ------------------------------------------------ literals ------------------------------------------------
@@ -515,6 +518,7 @@ gc_zstd_dec_entropy_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, co
                 sV[2] = log; sV[3] = tree; if (err) sV[1] = 1;
             }
             gc_wave_sync();
+            pc1 = prof ? gc_clock() : 0ull;
             const uint32_t log = sV[2], tree = sV[3];
             bool ok = sV[1] == 0u;
             const uint32_t base = hdr + tree, avail = ok && e.comp >= tree ? e.comp - tree : 0u;
@@ -574,6 +578,7 @@ gc_zstd_dec_entropy_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, co
                 sV[4] = e.seqPos + p; if (err) sV[0] = 1;
             }
             gc_wave_sync();
+            pc1 = prof ? gc_clock() : 0ull;
             err = sV[0];
             const uint32_t seqStart = sV[4];
             const uint8_t* const sp = bsrc + seqStart;
@@ -588,58 +593,66 @@ gc_zstd_dec_entropy_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, co
             GcU4* const seq = seqWork + fr.seqBase + e.seqOff;
             bool first = true;
             while (!err) {
-                // stage the piece of the bitstream the next sequences read: bytes [cLo, hi + 8)
+                // stage the piece of the bitstream the next sequences read: bytes [cLo, hi + 8) of the stream at sBuf + 16.  With 16 zero bytes in
+                // front of byte 0 a read that reaches below the start of the stream (legal at the very end: the bits there read as zeros; an
+                // over-read otherwise, caught right after) needs no special case: bit p lies in byte ((p + 128) >> 3) - cLo of sBuf.
                 const uint32_t hi = (uint32_t)(off + 7) >> 3;
                 const uint32_t cLo = hi > GC_ZD_CHUNK ? (hi - GC_ZD_CHUNK) & ~7u : 0u;
+                if (lane < 2u) { const uint64_t z = 0; __builtin_memcpy(sBuf + 8u * lane, &z, 8); }
                 for (uint32_t i = lane * 8u; i < hi + 8u - cLo; i += 512u) {
                     uint64_t v = 0;
                     if (cLo + i + 8u <= n) v = gc_ld64(sp + cLo + i);
                     else for (uint32_t k = 0; k < 8u && cLo + i + k < n; k++) v |= (uint64_t)sp[cLo + i + k] << (8u * k);
-                    __builtin_memcpy(sBuf + i, &v, 8);
+                    __builtin_memcpy(sBuf + 16u + i, &v, 8);
                 }
                 gc_wave_sync();
                 if (lane == 0u) {
-#define ZD_PK(nbits, at) ({ const int32_t pos_ = (at) - (int32_t)(nbits); const uint64_t v_ = pos_ >= 0 ? gc_ld64(sBuf + (((uint32_t)pos_ >> 3) - cLo)) >> ((uint32_t)pos_ & 7u) \
-                                                          : (pos_ <= -64 ? 0ull : gc_ld64(sBuf) << (uint32_t)(-pos_)); (uint32_t)(v_ & ((1ull << (nbits)) - 1ull)); })
+#define ZD_RD64(p) (gc_ld64(sBuf + (((uint32_t)((p) + 128) >> 3) - cLo)) >> ((uint32_t)(p) & 7u))
+#define ZD_RD32(p) (gc_ld32(sBuf + (((uint32_t)((p) + 128) >> 3) - cLo)) >> ((uint32_t)(p) & 7u))
                     if (first) {
-                        stLL = ZD_PK(llLog, off); off -= (int32_t)llLog;
-                        stOF = ZD_PK(ofLog, off); off -= (int32_t)ofLog;
-                        stML = ZD_PK(mlLog, off); off -= (int32_t)mlLog;
-                        if (off < 0) err = 1;
+                        const int32_t p1 = off - (int32_t)llLog, p2 = p1 - (int32_t)ofLog, p3 = p2 - (int32_t)mlLog;
+                        if (p3 < 0) err = 1;
+                        else {
+                            stLL = ZD_RD32(p1) & ((1u << llLog) - 1u); stOF = ZD_RD32(p2) & ((1u << ofLog) - 1u); stML = ZD_RD32(p3) & ((1u << mlLog) - 1u);
+                            off = p3;
+                        }
                     }
+                    // One step per sequence.  Every bit position of the step follows from the three table entries, so the six reads go out
+                    // together; the repeat-offset rules are selects, the checks one flag.
                     while (!err && j < nSeq && (cLo == 0u || ((uint32_t)off >> 3) >= cLo + 16u)) {
                         const GcU2 eLL = sLL[stLL], eOF = sOF[stOF], eML = sML[stML];
+                        const uint32_t more = j + 1u < nSeq ? 0xFFu : 0u;            // the last sequence does not move the states on
                         const uint32_t ofb = eOF.x >> 24, mlb = eML.x >> 24, llb = eLL.x >> 24;
+                        const uint32_t nl = (eLL.x >> 16) & more, nm = (eML.x >> 16) & more, no = (eOF.x >> 16) & more;
+                        const int32_t p1 = off - (int32_t)ofb, p2 = p1 - (int32_t)mlb, p3 = p2 - (int32_t)llb;
+                        const int32_t p4 = p3 - (int32_t)nl, p5 = p4 - (int32_t)nm, p6 = p5 - (int32_t)no;
+                        const uint64_t w1 = ZD_RD64(p1);
+                        const uint32_t w2 = ZD_RD32(p2), w3 = ZD_RD32(p3), w4 = ZD_RD32(p4), w5 = ZD_RD32(p5), w6 = ZD_RD32(p6);
+                        const uint32_t ofv = eOF.y + ((uint32_t)w1 & ((1u << (ofb & 31u)) - 1u));
+                        const uint32_t ml = eML.y + (w2 & ((1u << mlb) - 1u));
+                        const uint32_t ll = eLL.y + (w3 & ((1u << llb) - 1u));
+                        stLL = (eLL.x & 0xFFFFu) + (w4 & ((1u << nl) - 1u));
+                        stML = (eML.x & 0xFFFFu) + (w5 & ((1u << nm) - 1u));
+                        stOF = (eOF.x & 0xFFFFu) + (w6 & ((1u << no) - 1u));
+                        off = p6;
+                        // offset value 1..3 = one of the three last offsets (shifted by one when the sequence has no literals; "4" = the first minus 1)
+                        const bool isRep = ofv <= 3u;
+                        const uint32_t idx = ofv - 1u + (ll == 0u ? 1u : 0u);
+                        const uint32_t r0m1 = (rep0 & GC_ZD_SYM) ? rep0 + 4u : rep0 - 1u;
+                        const uint32_t o = !isRep ? ofv - 3u : (idx == 0u ? rep0 : (idx == 1u ? rep1 : (idx == 2u ? rep2 : r0m1)));
+                        const bool shift3 = !isRep || idx >= 2u, shift2 = isRep && idx == 1u;
+                        rep2 = shift3 ? rep1 : rep2;
+                        rep1 = (shift3 || shift2) ? rep0 : rep1;
+                        rep0 = o;
+                        const bool bad = off < 0 || o == 0u || lpos + ll > e.regen || dpos + ll + ml > GC_ZSTD_BLOCK_MAX;
                         if (ofb > 30u) { err = GC_ZD_UNSUPPORTED; break; }
-                        const uint32_t ofv = eOF.y + ZD_PK(ofb, off); off -= (int32_t)ofb;
-                        const uint32_t ml = eML.y + ZD_PK(mlb, off); off -= (int32_t)mlb;
-                        const uint32_t ll = eLL.y + ZD_PK(llb, off); off -= (int32_t)llb;
-                        uint32_t o;
-                        if (ofv > 3u) { o = ofv - 3u; rep2 = rep1; rep1 = rep0; rep0 = o; }
-                        else {
-                            const uint32_t idx = ofv - 1u + (ll == 0u ? 1u : 0u);
-                            if (idx == 0u) o = rep0;
-                            else {
-                                if (idx == 3u) {
-                                    if (rep0 & GC_ZD_SYM) o = rep0 + 4u;          // delta + 1
-                                    else { o = rep0 - 1u; if (!o) { err = 1; break; } }
-                                } else o = idx == 1u ? rep1 : rep2;
-                                if (idx != 1u) rep2 = rep1;
-                                rep1 = rep0; rep0 = o;
-                            }
-                        }
-                        if (j + 1u < nSeq) {
-                            const uint32_t nl = (eLL.x >> 16) & 0xFFu, nm = (eML.x >> 16) & 0xFFu, no = (eOF.x >> 16) & 0xFFu;
-                            stLL = (eLL.x & 0xFFFFu) + ZD_PK(nl, off); off -= (int32_t)nl;
-                            stML = (eML.x & 0xFFFFu) + ZD_PK(nm, off); off -= (int32_t)nm;
-                            stOF = (eOF.x & 0xFFFFu) + ZD_PK(no, off); off -= (int32_t)no;
-                        }
-                        if (off < 0 || (uint64_t)lpos + ll > e.regen || (uint64_t)dpos + ll + ml > GC_ZSTD_BLOCK_MAX) { err = 1; break; }
+                        if (bad) { err = 1; break; }
                         GcU4 rec; rec.x = ll | (ml << 18); rec.y = (ml >> 14) | (lpos << 4); rec.z = o; rec.w = dpos;
                         seq[j] = rec;
                         dpos += ll + ml; lpos += ll; j++;
                     }
-#undef ZD_PK
+#undef ZD_RD64
+#undef ZD_RD32
                 }
                 first = false;
                 j = __shfl(j, 0); off = __shfl(off, 0); err = __shfl(err, 0);
@@ -649,6 +662,11 @@ gc_zstd_dec_entropy_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, co
             if (err && lane == 0u) sV[0] = err;
         }
         if (lane == 0u) { sV[8] = dpos; sV[9] = lpos; sV[10] = rep0; sV[11] = rep1; sV[12] = rep2; }
+    }
+    if (prof && lane == 0u) {          // per wave: tables, streams
+        const unsigned long long pc2 = gc_clock();
+        atomicAdd(&prof[8u + 2u * wave], (pc1 ? pc1 : pc2) - pc0); atomicAdd(&prof[9u + 2u * wave], pc1 ? pc2 - pc1 : 0ull);
+        if (wave == 0u) atomicAdd(&prof[12], 1ull);
     }
     __syncthreads();
     if (t == 0) {
@@ -744,8 +762,11 @@ gc_zstd_dec_exec_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint8
                 // ---- pass 1: offsets get their values; literals; matches that lie in front of the block ----
                 const unsigned long long c0 = prof ? gc_clock() : 0ull;
                 uint32_t bad = 0;
+                GcU4 nextRec; nextRec.x = nextRec.y = nextRec.z = nextRec.w = 0;
+                if (t < nSeq) nextRec = seq[t];
                 for (uint32_t j = t; j < nSeq; j += GC_ZD_T) {
-                    GcU4 rec = seq[j];
+                    GcU4 rec = nextRec;
+                    if (j + GC_ZD_T < nSeq) nextRec = seq[j + GC_ZD_T];
                     const uint32_t ll = rec.x & 0x3FFFFu, ml = (rec.x >> 18) | ((rec.y & 15u) << 14), lp = rec.y >> 4, dp = rec.w;
                     uint32_t off = rec.z;
                     if (off & GC_ZD_SYM) {
@@ -774,26 +795,42 @@ gc_zstd_dec_exec_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint8
                 //      copied now, all of them at once (their outputs are disjoint); the first one itself always can.  A few rounds per group
                 //      instead of 64 dependent steps.  Long matches are copied by the whole wave, 64 bytes per step. ----
                 if (t < 64u) {
+                    uint32_t nGroups = 0, nRounds = 0, nSpecial = 0;
+                    GcU4 ahead; ahead.x = ahead.y = ahead.z = ahead.w = 0;             // the records of the next group are fetched while this one is worked on
+                    if (lane < nSeq) ahead = seq[lane];
                     for (uint32_t j0 = 0; j0 < nSeq; j0 += 64u) {
-                        GcU4 mine; mine.x = mine.y = mine.z = mine.w = 0;
+                        const GcU4 mine = ahead;
                         const bool have = j0 + lane < nSeq;
-                        if (have) mine = seq[j0 + lane];
-                        const uint32_t ll = mine.x & 0x3FFFFu, ml = (mine.x >> 18) | ((mine.y & 15u) << 14), off = mine.z, d = mine.w + ll;
+                        if (j0 + 64u + lane < nSeq) ahead = seq[j0 + 64u + lane];
+                        const uint32_t ll = mine.x & 0x3FFFFu, ml0 = (mine.x >> 18) | ((mine.y & 15u) << 14), off0 = mine.z;
+                        // what is left of my match: output position, length, distance.  A lane copies at most 16 bytes per round (so that one
+                        // long match does not hold up the round); what remains is the same kind of match further on.
+                        uint32_t d = mine.w + ll, ml = ml0, off = off0;
                         bool pending = have && off < d + ml;
-                        const int32_t s0 = (int32_t)d - (int32_t)off;
-                        const uint32_t srcEnd = off >= ml ? (uint32_t)(s0 + (int32_t)ml) : d;      // end of the part of the source that is not its own output
-                        const uint32_t isLong = ml > 48u ? 1u : 0u;
-                        if (prof && lane == 0u) atomicAdd(&prof[5], 1ull);
+                        // matches the lane-parallel path does not take: long ones, periods below 8 bytes, sources that start in front of the block.
+                        // They wait until they are first, then the whole wave copies them (64 bytes per step).
+                        const bool special = ml > 64u || off < 8u || off > d;
+                        nGroups++;
                         for (;;) {
                             const uint64_t pm = __ballot(pending);
                             if (!pm) break;
-                            if (prof && lane == 0u) atomicAdd(&prof[4], 1ull);
+                            nRounds++;
                             const uint32_t fl = gc_ctz64(pm);
                             const uint32_t W = gc_readlane(d, fl);
-                            if (gc_readlane(isLong, fl)) {
+                            if (gc_readlane(special ? 1u : 0u, fl)) {
                                 const uint32_t fml = gc_readlane(ml, fl), foff = gc_readlane(off, fl);
                                 const int32_t fs0 = (int32_t)W - (int32_t)foff;
-                                if (foff < 64u) {
+                                nSpecial++;
+                                if (fs0 >= 0 && foff < 64u) {          // (the common cases stay inside LDS)
+                                    for (uint32_t k = lane; k < fml; k += 64u) sOut[W + k] = sOut[(uint32_t)fs0 + k % foff];
+                                    gc_wave_step();
+                                } else if (fs0 >= 0) {
+                                    for (uint32_t c = 0; c < fml; c += 64u) {
+                                        const uint32_t k = c + lane;
+                                        if (k < fml) sOut[W + k] = sOut[(uint32_t)fs0 + k];
+                                        gc_wave_step();
+                                    }
+                                } else if (foff < 64u) {
                                     for (uint32_t k = lane; k < fml; k += 64u) {
                                         const int32_t si = fs0 + (int32_t)(k % foff);
                                         sOut[W + k] = zd_image_byte(sOut, bdst, si);
@@ -809,25 +846,29 @@ gc_zstd_dec_exec_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint8
                                 if (lane == fl) pending = false;
                                 continue;
                             }
-                            if (pending && !isLong && (lane == fl || srcEnd <= W)) {
-                                pending = false;
-                                if (s0 >= 0 && off >= 8u) {
-                                    uint32_t k = 0;
-                                    for (; k + 8u <= ml; k += 8u) { const uint64_t v = gc_ld64(sOut + s0 + k); __builtin_memcpy(sOut + d + k, &v, 8); }
-                                    if (k < ml) { uint64_t v = gc_ld64(sOut + s0 + k); for (; k < ml; k++) { sOut[d + k] = (uint8_t)v; v >>= 8; } }
-                                } else if (s0 >= 0) {                      // period below 8: the pattern lives in a register
-                                    const uint64_t pat = gc_ld64(sOut + s0);
-                                    uint32_t ph = 0;
-                                    for (uint32_t k = 0; k < ml; k++) { sOut[d + k] = (uint8_t)(pat >> (8u * ph)); ph = ph + 1u == off ? 0u : ph + 1u; }
-                                } else {
-                                    const uint32_t nFront = (uint32_t)(-s0) < ml ? (uint32_t)(-s0) : ml;      // the source starts in front of the block
-                                    for (uint32_t k = 0; k < nFront; k++) sOut[d + k] = bdst[s0 + (int32_t)k];
-                                    for (uint32_t k = nFront; k < ml; k++) sOut[d + k] = sOut[k - nFront];
+                            const uint32_t s0 = d - off;
+                            const uint32_t srcEnd = off >= ml ? s0 + ml : d;      // end of the part of the source that is not my own output
+                            if (pending && !special && (lane == fl || srcEnd <= W)) {
+#pragma unroll
+                                for (int step = 0; step < 2; step++) {
+                                    if (ml) {
+                                        const uint64_t v = gc_ld64(sOut + (d - off));
+                                        if (ml >= 8u) { __builtin_memcpy(sOut + d, &v, 8); d += 8u; ml -= 8u; }
+                                        else {
+                                            uint32_t lo = (uint32_t)v, k = d;
+                                            if (ml & 4u) { __builtin_memcpy(sOut + k, &lo, 4); k += 4u; lo = (uint32_t)(v >> 32); }
+                                            if (ml & 2u) { const uint16_t h = (uint16_t)lo; __builtin_memcpy(sOut + k, &h, 2); k += 2u; lo >>= 16; }
+                                            if (ml & 1u) sOut[k] = (uint8_t)lo;
+                                            d += ml; ml = 0;
+                                        }
+                                    }
                                 }
+                                pending = ml != 0u;
                             }
                             gc_wave_step();
                         }
                     }
+                    if (prof && lane == 0u) { atomicAdd(&prof[4], (unsigned long long)nRounds); atomicAdd(&prof[5], (unsigned long long)nGroups); atomicAdd(&prof[6], (unsigned long long)nSpecial); }
                 }
                 if (t == 64u) {                                    // repeat offsets behind the block
                     uint32_t out[3];
@@ -985,7 +1026,7 @@ extern "C" void gc_zstd_dec_launch_decode(hipStream_t st, const uint8_t* src, ui
                                           GcZdBlock* blocks, uint32_t nBlocks, uint32_t* ticket, uint8_t* litWork, uint64_t litWorkSize, void* seqWork, uint64_t* result,
                                           unsigned long long* prof)
 {
-    if (nBlocks) GC_LAUNCH(gc_zstd_dec_entropy_kernel, nBlocks, GC_ZD_ENT_T, st, src, srcSize, frames, blocks, litWork, (GcU4*)seqWork);
+    if (nBlocks) GC_LAUNCH(gc_zstd_dec_entropy_kernel, nBlocks, GC_ZD_ENT_T, st, src, srcSize, frames, blocks, litWork, (GcU4*)seqWork, prof);
     const uint32_t wg = nFrames < GC_ZD_MAX_WG ? nFrames : GC_ZD_MAX_WG;
     GC_LAUNCH(gc_zstd_dec_exec_kernel, wg, GC_ZD_T, st, src, srcSize, dst, dstCap, frames, nFrames, (const GcZdBlock*)blocks, ticket, (const uint8_t*)litWork, litWorkSize, (GcU4*)seqWork, result, prof);
 }

@@ -40,6 +40,22 @@ def host_dir(tmp_path_factory):
     return d
 
 
+@pytest.fixture(scope="module")
+def host_dir_nozstd(tmp_path_factory, host_dir):
+    """The same host with a format/codec bundle that has no ZSTD codec of its own (oracle/build_ref_7z.sh links it without ZstdRegister.o),
+    like mainline 7-Zip: method id 4F71101 then resolves to the plugin for encoding AND decoding."""
+    if not os.path.exists(os.path.join(HOST, "7z_nozstd.so")):
+        if os.path.isdir("/root/reference/CPP"):
+            subprocess.run(["bash", os.path.join(ROOT, "oracle", "build_ref_7z.sh"), HOST], check=True, capture_output=True, env=dict(os.environ, REF_ROOT="/root/reference"))
+        if not os.path.exists(os.path.join(HOST, "7z_nozstd.so")):
+            pytest.skip("reference host without zstd not built (oracle/_ref/host7z/7z_nozstd.so)")
+    d = tmp_path_factory.mktemp("host7z_nozstd")
+    shutil.copy2(os.path.join(HOST, "7z"), d / "7z")
+    shutil.copy2(os.path.join(HOST, "7z_nozstd.so"), d / "7z.so")
+    (d / "Codecs").mkdir()
+    return d
+
+
 def _install(host_dir, module, libdir):
     for f in os.listdir(host_dir / "Codecs"):
         os.remove(host_dir / "Codecs" / f)
@@ -101,6 +117,47 @@ def test_real_host_archives_through_the_emulator_module(host_dir, emu_lib_path, 
     env = _install(host_dir, os.path.join(EMU, "lib7zgpucodec_emu.so"), EMU)
     size = _roundtrip(host_dir, env, O, method, level, expect, n)
     assert size < n
+
+
+def _decoder_under_real_host(host_dir, host_dir_nozstd, env_full, env_nozstd, O, n, level):
+    """(1) the host without its own ZSTD codec archives with -m0=ZSTD (the plugin's encoder) and tests / extracts with the plugin's DECODER;
+    (2) an archive written by the reference's own CPU encoder is extracted by the plugin's decoder; (3) and the other way round."""
+    r = _run(host_dir_nozstd, env_nozstd, "i")
+    assert r.returncode == 0 and " ED " in r.stdout and "4F71101 ZSTD" in r.stdout, r.stdout
+    _roundtrip(host_dir_nozstd, env_nozstd, O, "ZSTD", level, "ZSTD", n)
+    x = O.corpus("silesia-like", n)
+    src = host_dir / "cpu_src.bin"
+    x.tofile(src)
+    arc = host_dir / "cpu.7z"
+    if arc.exists():
+        arc.unlink()
+    r = _run(host_dir, env_full, "a", "-m0=zstd", "-mx%d" % level, arc.name, src.name)                 # the reference's built-in encoder
+    assert r.returncode == 0 and "Everything is Ok" in r.stdout, r.stdout + r.stderr
+    shutil.copy2(arc, host_dir_nozstd / "cpu.7z")
+    out = host_dir_nozstd / "x_cpu"
+    if out.exists():
+        shutil.rmtree(out)
+    r = _run(host_dir_nozstd, env_nozstd, "x", "-o" + str(out), "cpu.7z")                                 # ... decoded by the plugin
+    assert r.returncode == 0 and "Everything is Ok" in r.stdout, r.stdout + r.stderr
+    assert np.array_equal(np.fromfile(out / src.name, dtype=np.uint8), x)
+    r = _run(host_dir, env_full, "t", str(host_dir_nozstd / ("a_ZSTD_%d.7z" % n)))                        # the plugin's archive under the reference's decoder
+    assert r.returncode == 0 and "Everything is Ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_real_host_decodes_through_the_emulator_module(host_dir, host_dir_nozstd, emu_lib_path, O):
+    module = os.path.join(EMU, "lib7zgpucodec_emu.so")
+    _decoder_under_real_host(host_dir, host_dir_nozstd, _install(host_dir, module, EMU), _install(host_dir_nozstd, module, EMU), O, 400_000, 3)
+
+
+@pytest.mark.gpu
+def test_gpu_real_host_decodes_through_the_product_module(host_dir, host_dir_nozstd, graft, O):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    graft.build_hip()
+    module = graft.build_plugin()
+    libdir = os.path.join(ROOT, "7-zip-zstd_amd", "csrc")
+    _decoder_under_real_host(host_dir, host_dir_nozstd, _install(host_dir, module, libdir), _install(host_dir_nozstd, module, libdir), O, 150_000_000, 3)
 
 
 @pytest.mark.gpu
