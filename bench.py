@@ -144,14 +144,33 @@ def run_codec(codec, level, corpus_name, total, args, env):
     for k in mf_ms:
         mf_ms[k] /= max(args.steps, 1)
     decodes = None
+    gpu_decode = None
     if not args.no_decode_check:
         O = _oracle()
         if O.ref(codec) is not None:
             thr = min(os.cpu_count() or 1, 64)
+            td = time.perf_counter()
             y = O.ref_zstd_decompress(stream, total) if codec == "zstd" else \
                 O.ref_lzma2_decode(stream, total, enc.coder_props()[0]) if fl2 else O.ref_brotlimt_decompress(stream, total, thr)
+            td = time.perf_counter() - td
             decodes = bool(np.array_equal(y, x_all))
             del y
+            if codec == "zstd" and world == 1:
+                # SURVEY.md 8f1, outside the timed region: the same stream through the GPU decoder (compressed bytes and content in HBM), content
+                # compared on the device; beside it the reference's decoder on one host core (its 7-Zip decoder is single-threaded per stream)
+                dec = pkg.ZstdDecoder(device=env["local_rank"])
+                frames, nf, content = dec.scan(stream)
+                d_c = torch.from_numpy(np.ascontiguousarray(stream)).to(dev)
+                d_y = torch.empty(total + 64, dtype=torch.uint8, device=dev)
+                best = None
+                for _ in range(3):
+                    got = dec.code_device(d_c.data_ptr(), int(stream.size), d_y.data_ptr(), total, frames, nf)
+                    ms = dec.last_timing_ms()
+                    best = ms if best is None else min(best, ms)
+                same = bool(got == total and torch.equal(d_y[:total], d_src[:total]))
+                gpu_decode = {"frames": nf, "content_bytes": total, "kernel_ms": round(best, 3), "value": round(total / best / 1e3, 1), "unit": "MB/s of content",
+                              "bit_exact": same, "reference_decoder_1_core_MBps": round(total / td / 1e6, 1)}
+                dec.close(); del d_c, d_y
     value = total * args.steps / elapsed / 1e6
     ratio = total / total_csize
     # dominant kernel of rank 0 = the longest single kernel by live HIP-event timing; algorithmic bytes per launch =
@@ -205,7 +224,7 @@ def run_codec(codec, level, corpus_name, total, args, env):
                     ("zstd level %d, %s stand-in (%s, %d B), 128 KiB blocks in independent %s" % (level, "enwik9" if total == ENWIK9_BYTES else "enwik", corpus_name, total, frames)),
         "bytes_total": total, "bytes_per_gpu": [b - a for a, b in S.shard_ranges(total, world, grain)], "shard_grain": grain,
         "compressed_bytes": total_csize, "compressed_bytes_per_gpu": sizes, "ratio": round(ratio, 4),
-        "decodes_under_reference": decodes, "ratio_vs_ref": ratio_vs_ref, "roofline": roofline, "cpu_baseline": cpu,
+        "decodes_under_reference": decodes, "gpu_decode": gpu_decode, "ratio_vs_ref": ratio_vs_ref, "roofline": roofline, "cpu_baseline": cpu,
     }
     enc.close()
     return res
@@ -269,7 +288,7 @@ def main():
             "config": {"workload": main_res["workload"], "bytes_total": main_res["bytes_total"], "bytes_per_gpu": main_res["bytes_per_gpu"],
                        "shard_grain": main_res["shard_grain"], "parallelism": "range-shard x%d at the codec grain, rank-ordered concatenation, no data-path collective" % world},
             "compressed_bytes": main_res["compressed_bytes"], "compressed_bytes_per_gpu": main_res["compressed_bytes_per_gpu"], "ratio": main_res["ratio"],
-            "decodes_under_reference": main_res["decodes_under_reference"], "ratio_vs_ref": main_res["ratio_vs_ref"],
+            "decodes_under_reference": main_res["decodes_under_reference"], "gpu_decode": main_res.get("gpu_decode"), "ratio_vs_ref": main_res["ratio_vs_ref"],
             "roofline": main_res["roofline"], "cpu_baseline": main_res["cpu_baseline"],
         }
         if extra is not None:
