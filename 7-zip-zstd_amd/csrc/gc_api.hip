@@ -893,9 +893,12 @@ extern "C" size_t gc_codec_grain(int codec, int level)
 
 // ---------------------------------------------------------------- ZSTD decoding ----------------------------------------------------------------
 extern "C" void gc_zstd_dec_launch_index(hipStream_t st, const uint8_t* src, const GcZdFrame* frames, uint32_t nFrames, GcZdBlock* blocks, uint64_t* frameTot);
-extern "C" void gc_zstd_dec_launch_decode(hipStream_t st, const uint8_t* src, uint64_t srcSize, uint8_t* dst, uint64_t dstCap, const GcZdFrame* frames, uint32_t nFrames,
-                                          GcZdBlock* blocks, uint32_t nBlocks, uint32_t* ticket, uint8_t* litWork, uint64_t litWorkSize, void* seqWork, uint64_t* result,
-                                          unsigned long long* prof);
+extern "C" void gc_zstd_dec_launch_literals(hipStream_t st, const uint8_t* src, uint64_t srcSize, const GcZdFrame* frames, GcZdBlock* blocks, uint32_t nBlocks, uint8_t* litWork,
+                                            unsigned long long* prof);
+extern "C" void gc_zstd_dec_launch_sequences(hipStream_t st, const uint8_t* src, uint64_t srcSize, const GcZdFrame* frames, GcZdBlock* blocks, uint32_t nBlocks, void* seqWork,
+                                             unsigned long long* prof);
+extern "C" void gc_zstd_dec_launch_exec(hipStream_t st, const uint8_t* src, uint64_t srcSize, uint8_t* dst, uint64_t dstCap, const GcZdFrame* frames, uint32_t nFrames,
+                                        GcZdBlock* blocks, uint32_t* ticket, uint8_t* litWork, uint64_t litWorkSize, void* seqWork, uint64_t* result, unsigned long long* prof);
 
 static int zd_grow(gc_ctx* c, void** p, size_t* cap, size_t need)
 {
@@ -962,8 +965,15 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
         if ((rc = zd_grow(c, &c->zdSeq, &c->zdSeqCap, (size_t)seqTot * 16u + 64u)) != GC_OK) break;
         if (hipMemcpyAsync(c->zdFrames, h + i, cnt * sizeof(GcZdFrame), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
             hipMemsetAsync(c->zdTicket, 0, 4, c->stream) != hipSuccess) { rc = GC_ERR_HIP; break; }
-        gc_zstd_dec_launch_decode(c->stream, (const uint8_t*)d_src, n, (uint8_t*)d_dst, dstCap, c->zdFrames, (uint32_t)cnt, c->zdBlocks, (uint32_t)nBlocks, c->zdTicket,
-                                  c->zdLit, litTot + 64u, c->zdSeq, c->zdResult, zdProf);
+        // literals on stream2, sequences on the main stream (both only need the block table), then the execution kernel
+        hipEventRecord(c->evPart[0][0], c->stream);
+        hipStreamWaitEvent(c->stream2, c->evPart[0][0], 0);
+        gc_zstd_dec_launch_literals(c->stream2, (const uint8_t*)d_src, n, c->zdFrames, c->zdBlocks, (uint32_t)nBlocks, c->zdLit, zdProf);
+        hipEventRecord(c->evPart[0][1], c->stream2);
+        gc_zstd_dec_launch_sequences(c->stream, (const uint8_t*)d_src, n, c->zdFrames, c->zdBlocks, (uint32_t)nBlocks, c->zdSeq, zdProf);
+        hipStreamWaitEvent(c->stream, c->evPart[0][1], 0);
+        gc_zstd_dec_launch_exec(c->stream, (const uint8_t*)d_src, n, (uint8_t*)d_dst, dstCap, c->zdFrames, (uint32_t)cnt, c->zdBlocks, c->zdTicket,
+                                c->zdLit, litTot + 64u, c->zdSeq, c->zdResult, zdProf);
         hipEventRecord(c->zdEv[1], c->stream);
         if (hipMemcpyAsync(res, c->zdResult, cnt * 8u, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
             snprintf(c->err, sizeof(c->err), "decode kernels failed: %s", hipGetErrorString(hipGetLastError())); rc = GC_ERR_HIP; break;

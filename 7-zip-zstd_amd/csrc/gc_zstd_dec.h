@@ -20,7 +20,7 @@ struct GcZdFrame {
 #define GC_ZD_F_CHECKSUM   1u
 #define GC_ZD_F_SIZE_KNOWN 2u
 
-// One entry per block, written by the index kernel, completed by the entropy kernel.
+// One entry per block, written by the index kernel, completed by the two entropy kernels (literals, sequences).
 struct GcZdBlock {
     uint64_t srcOff;        // payload (behind the 3-byte block header), absolute in the compressed stream
     uint64_t litOff;        // frame-relative offsets into the literal (bytes) and sequence (records) workspaces
@@ -40,7 +40,7 @@ struct GcZdBlock {
     uint32_t lposEnd;       // literals consumed by the sequences (the rest goes behind the last match)
     uint32_t dposEnd;       // content bytes covered by the sequences
     uint32_t rep[3];        // repeat offsets behind the block, possibly symbolic (GC_ZD_SYM)
-    uint32_t pad;
+    uint32_t litStatus;     // GC_ZD_* of the literals kernel (blocks with Huffman-coded literals)
 };
 #define GC_ZD_B_LAST 4u
 #define GC_ZD_B_BAD  8u
@@ -49,10 +49,9 @@ struct GcZdBlock {
 // and puts the real values in.
 #define GC_ZD_SYM 0x80000000u
 
-#define GC_ZD_ENT_T     128u                          // entropy kernel: wave 0 sequences, wave 1 literals
 #define GC_ZD_T         256u                          // execution kernel
 #define GC_ZD_MAX_WG    256u                          // frames in execution at a time (129 KB of LDS: one workgroup per CU)
-#define GC_ZD_CHUNK     4096u                         // bytes of the sequence bitstream staged in LDS at a time
+#define GC_ZD_CHUNK     2048u                         // bytes of the sequence bitstream staged in LDS at a time
 
 // per frame result word: produced bytes | status << 56
 #define GC_ZD_OK          0u

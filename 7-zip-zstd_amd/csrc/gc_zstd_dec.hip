@@ -1,17 +1,17 @@
 // gc_zstd_dec.hip -- zstd frame decoder on the device (the decoding half of the ZSTD method, what
 // NCompress::NZSTD::CDecoder::CodeSpec does with ZSTD_decompressStream, CPP/7zip/Compress/ZstdDecoder.cpp:66-240).
 //
-// Three kernels per batch of frames:
+// Four kernels per batch of frames:
 //
 //   index     one thread per frame walks its block headers and, for compressed blocks, the literals header and the sequence count:
 //             the block table (GcZdBlock) with each block's place in the literal / sequence workspaces
-//   entropy   one workgroup (2 waves) per BLOCK -- blocks are entropy-coded independently of what they decode to, so a stream of
-//             one frame spreads over the chip just like a stream of a thousand:
-//               wave 1  Huffman tree (direct or FSE-coded weights) -> 2^11-entry table in LDS; the 1 or 4 streams are decoded
+//   literals  \  one wave per BLOCK each, two kernels on two streams -- blocks are entropy-coded independently of what they decode to,
+//   sequences /  so a stream of one frame spreads over the chip just like a stream of a thousand:
+//             literals  Huffman tree (direct or FSE-coded weights) -> 2^11-entry table in LDS; the 1 or 4 streams are decoded
 //                       by 64 lanes at once: every lane starts at a guessed bit position inside its stream, Huffman codes
 //                       re-synchronise after a few symbols, each lane then restarts where its predecessor really ended until
 //                       nothing moves any more (usually one round), a prefix sum of the symbol counts places the output
-//               wave 0  the three FSE tables (predefined / RLE / described / repeated from an earlier block: found by walking the
+//             sequences the three FSE tables (predefined / RLE / described / repeated from an earlier block: found by walking the
 //                       block table backwards), then lane 0 decodes the sequence bitstream -- three interleaved FSE states, one
 //                       serial chain by format -- from 4 KiB pieces the whole wave stages in LDS, and writes one 16-byte record
 //                       per sequence.  Repeat offsets that reach into the history in front of the block stay symbolic
@@ -136,9 +136,8 @@ __device__ uint32_t zd_read_ncount(const uint8_t* p, uint32_t n, int16_t* norm, 
     return bytes;
 }
 
-// ---- FSE decoding table.  First the symbol of every cell (tab[cell].x), then
-//      tab[state] = { newStateBase | nbBits << 16 | extraBits << 24, baseline }  (for the Huffman weights: extraBits = 0, baseline = symbol) ----
-__device__ bool zd_fse_build(GcU2* tab, const int16_t* norm, uint32_t maxSym, uint32_t log, uint16_t* symNext, const ZdConst* k, int which)
+// ---- FSE decoding table of the Huffman weights.  First the symbol of every cell (tab[cell].x), then tab[state] = { newStateBase | nbBits << 16, symbol } ----
+__device__ bool zd_fse_build(GcU2* tab, const int16_t* norm, uint32_t maxSym, uint32_t log, uint16_t* symNext)
 {
     const uint32_t size = 1u << log, mask = size - 1u, step = (size >> 1) + (size >> 3) + 3u;
     uint32_t high = size - 1u;
@@ -159,13 +158,39 @@ __device__ bool zd_fse_build(GcU2* tab, const int16_t* norm, uint32_t maxSym, ui
         const uint32_t s = tab[u].x;
         const uint32_t next = symNext[s]++;
         const uint32_t nb = log - gc_hibit32(next);
-        uint32_t base, extra;
-        if (which == ZT_LL) { base = k->llBase[s]; extra = k->llBits[s]; }
-        else if (which == ZT_ML) { base = k->mlBase[s]; extra = k->mlBits[s]; }
-        else if (which == ZT_OF) { base = 1u << s; extra = s; }
-        else { base = s; extra = 0; }
-        GcU2 e; e.x = (((next << nb) - size) & 0xFFFFu) | (nb << 16) | (extra << 24); e.y = base;
+        GcU2 e; e.x = (((next << nb) - size) & 0xFFFFu) | (nb << 16); e.y = s;
         tab[u] = e;
+    }
+    return true;
+}
+
+// The same for the three symbol tables of the sequences section, 4 bytes per cell:
+//   next-state base (10 bits) | state bits << 10 (4) | extra bits of the symbol << 14 (5) | symbol << 19 (6)
+// (the baseline of a literal-length / match-length symbol comes from a 36- / 53-entry table, the offset's is 1 << symbol)
+#define ZD_SEQ_ENTRY(base, nb, extra, sym) ((base) | ((nb) << 10) | ((extra) << 14) | ((sym) << 19))
+__device__ bool zd_seq_fse_build(uint32_t* tab, const int16_t* norm, uint32_t maxSym, uint32_t log, uint16_t* symNext, const ZdConst* k, int which)
+{
+    const uint32_t size = 1u << log, mask = size - 1u, step = (size >> 1) + (size >> 3) + 3u;
+    uint32_t high = size - 1u;
+    for (uint32_t s = 0; s <= maxSym; s++) {
+        if (norm[s] == -1) { tab[high--] = s; symNext[s] = 1; }
+        else symNext[s] = (uint16_t)norm[s];
+    }
+    uint32_t pos = 0;
+    for (uint32_t s = 0; s <= maxSym; s++) {
+        const int cnt = norm[s];
+        for (int i = 0; i < cnt; i++) {
+            tab[pos] = s;
+            do pos = (pos + step) & mask; while (pos > high);
+        }
+    }
+    if (pos != 0) return false;
+    for (uint32_t u = 0; u < size; u++) {
+        const uint32_t s = tab[u];
+        const uint32_t next = symNext[s]++;
+        const uint32_t nb = log - gc_hibit32(next);
+        const uint32_t extra = which == ZT_LL ? k->llBits[s] : (which == ZT_ML ? k->mlBits[s] : s);
+        tab[u] = ZD_SEQ_ENTRY(((next << nb) - size) & 0x3FFu, nb, extra, s);
     }
     return true;
 }
@@ -186,7 +211,7 @@ __device__ uint32_t zd_huf_read(const uint8_t* p, uint32_t n, uint16_t* sHuf, ui
         uint32_t maxSym = 0, log = 0;
         const uint32_t h = zd_read_ncount(p + 1u, hb, sNorm, 255u, 6u, &maxSym, &log);
         if (!h || h >= hb) return 0;
-        if (!zd_fse_build(sFseW, sNorm, maxSym, log, sNext, nullptr, -1)) return 0;
+        if (!zd_fse_build(sFseW, sNorm, maxSym, log, sNext)) return 0;
         ZdBR r;
         if (!zd_br_init(r, p + 1u + h, hb - h)) return 0;
         uint32_t s1 = zd_br_read(r, log), s2 = zd_br_read(r, log);
@@ -272,7 +297,7 @@ __device__ uint32_t zd_find_table_source(const GcZdBlock* blocks, uint32_t first
 
 // One symbol table of the sequences section from the window `win` (modes byte at win[0]), p = read position inside the window.
 // Returns the new read position, 0 on error.  mode 3 is resolved by the caller.
-__device__ uint32_t zd_seq_table(uint32_t mode, const uint8_t* win, uint32_t winLen, uint32_t p, GcU2* tab, uint32_t* logOut, int which,
+__device__ uint32_t zd_seq_table(uint32_t mode, const uint8_t* win, uint32_t winLen, uint32_t p, uint32_t* tab, uint32_t* logOut, int which,
                                  const ZdConst* k, int16_t* sNorm, uint16_t* sNext)
 {
     const uint32_t maxSym = which == ZT_LL ? 35u : (which == ZT_OF ? 30u : 52u), maxLog = which == ZT_OF ? 8u : 9u;
@@ -280,24 +305,21 @@ __device__ uint32_t zd_seq_table(uint32_t mode, const uint8_t* win, uint32_t win
         const int16_t* dn = which == ZT_LL ? k->llNorm : (which == ZT_OF ? k->ofNorm : k->mlNorm);
         const uint32_t dm = which == ZT_LL ? 35u : (which == ZT_OF ? 28u : 52u), dl = which == ZT_OF ? 5u : 6u;
         for (uint32_t s = 0; s <= dm; s++) sNorm[s] = dn[s];
-        if (!zd_fse_build(tab, sNorm, dm, dl, sNext, k, which)) return 0;
+        if (!zd_seq_fse_build(tab, sNorm, dm, dl, sNext, k, which)) return 0;
         *logOut = dl; return p;
     }
     if (mode == 1u) {
         if (p >= winLen) return 0;
         const uint32_t s = win[p];
         if (s > maxSym) return 0;
-        GcU2 e;
-        if (which == ZT_LL) { e.y = k->llBase[s]; e.x = (uint32_t)k->llBits[s] << 24; }
-        else if (which == ZT_ML) { e.y = k->mlBase[s]; e.x = (uint32_t)k->mlBits[s] << 24; }
-        else { e.y = 1u << s; e.x = s << 24; }
-        tab[0] = e; *logOut = 0; return p + 1u;
+        const uint32_t extra = which == ZT_LL ? k->llBits[s] : (which == ZT_ML ? k->mlBits[s] : s);
+        tab[0] = ZD_SEQ_ENTRY(0u, 0u, extra, s); *logOut = 0; return p + 1u;
     }
     uint32_t ms = 0, log = 0;
     if (p >= winLen) return 0;
     const uint32_t h = zd_read_ncount(win + p, winLen - p, sNorm, maxSym, maxLog, &ms, &log);
     if (!h) return 0;
-    if (!zd_fse_build(tab, sNorm, ms, log, sNext, k, which)) return 0;
+    if (!zd_seq_fse_build(tab, sNorm, ms, log, sNext, k, which)) return 0;
     *logOut = log; return p + h;
 }
 
@@ -338,7 +360,7 @@ gc_zstd_dec_index_kernel(const uint8_t* __restrict__ src, const GcZdFrame* __res
     for (uint32_t k = 0; k < fr.nBlocks; k++) {
         GcZdBlock e;
         e.srcOff = 0; e.litOff = lit; e.seqOff = seq; e.size = 0; e.type = GC_ZD_B_BAD | GC_ZD_B_LAST; e.regen = 0; e.litInfo = 0; e.comp = 0; e.nSeq = 0; e.seqPos = 0; e.modes = 0;
-        e.frame = f; e.status = GC_ZD_CORRUPT; e.outSize = 0; e.lposEnd = 0; e.dposEnd = 0; e.rep[0] = e.rep[1] = e.rep[2] = 0; e.pad = 0;
+        e.frame = f; e.status = GC_ZD_CORRUPT; e.outSize = 0; e.lposEnd = 0; e.dposEnd = 0; e.rep[0] = e.rep[1] = e.rep[2] = 0; e.litStatus = GC_ZD_OK;
         if (!broken && ip + 3u <= srcEnd) {
             const uint32_t h = (uint32_t)fsrc[ip] | ((uint32_t)fsrc[ip + 1] << 8) | ((uint32_t)fsrc[ip + 2] << 16);
             const uint32_t bt = (h >> 1) & 3u, bs = h >> 3, last = h & 1u;
@@ -459,219 +481,247 @@ __device__ bool zd_huf_parallel(const uint8_t* sp, uint32_t n, uint32_t count, u
     return ok;
 }
 
-extern "C" __global__ void __launch_bounds__(GC_ZD_ENT_T)
-gc_zstd_dec_entropy_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const GcZdFrame* __restrict__ frames, GcZdBlock* blocks, uint8_t* litWork, GcU4* seqWork,
-                           unsigned long long* prof)
+// ---- literals: one wave per block ----
+extern "C" __global__ void __launch_bounds__(64)
+gc_zstd_dec_lit_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const GcZdFrame* __restrict__ frames, GcZdBlock* blocks, uint8_t* litWork, unsigned long long* prof)
 {
     __shared__ uint16_t sHuf[1u << ZD_HUF_LOG_MAX];
-    __shared__ GcU2 sLL[512], sML[512], sOF[256], sFseW[64];
-    __shared__ __attribute__((aligned(16))) uint8_t sBuf[GC_ZD_CHUNK + 64u];
-    __shared__ __attribute__((aligned(16))) uint8_t sWinL[ZD_WIN_L + 8u], sWinS[ZD_WIN_S + 8u], sWinR[ZD_WIN_S + 8u];
-    __shared__ int16_t sNormA[64], sNormB[256];
-    __shared__ uint16_t sNextA[64], sNextB[256];
+    __shared__ GcU2 sFseW[64];
+    __shared__ __attribute__((aligned(16))) uint8_t sWinL[ZD_WIN_L + 8u];
+    __shared__ int16_t sNormB[256];
+    __shared__ uint16_t sNextB[256];
     __shared__ uint8_t sW[256];
-    __shared__ ZdConst sK;
-    __shared__ uint32_t sV[16];       // 0 err wave 0, 1 err wave 1, 2 huf log, 3 tree bytes, 4 seq stream start, 5..7 table logs
+    __shared__ uint32_t sV[4];        // 1 error, 2 huf log, 3 tree bytes
 
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6, b = blockIdx.x;
+    const uint32_t lane = threadIdx.x, b = blockIdx.x;
+    const uint32_t ty = blocks[b].type;
+    if ((ty & 3u) != 2u || (ty & GC_ZD_B_BAD) || (blocks[b].litInfo & 3u) < 2u) return;
+    const GcZdBlock e = blocks[b];
+    const GcZdFrame fr = frames[e.frame];
+    const uint8_t* const bsrc = src + e.srcOff;
+    const uint32_t bs = e.size;
+    for (uint32_t i = lane; i < ZD_WIN_L + 8u; i += 64u) sWinL[i] = i < bs ? bsrc[i] : (uint8_t)0;
+    if (lane < 4u) sV[lane] = 0;
+    gc_wave_sync();
+    const unsigned long long pc0 = prof ? gc_clock() : 0ull;
+    unsigned long long pc1 = 0;
+    {
+    // ------------------------------------------------ literals ------------------------------------------------
+    const uint32_t lt = e.litInfo & 3u, nStreams = (e.litInfo >> 2) & 7u, hdr = e.litInfo >> 8;
+    if (lt >= 2u) {
+        if (lane == 0u) {
+            uint32_t log = 0, tree = 0, err = 0;
+            if (lt == 2u) {
+                const uint32_t avail = e.comp < ZD_WIN_L - hdr ? e.comp : ZD_WIN_L - hdr;
+                tree = zd_huf_read(sWinL + hdr, avail, sHuf, sW, sNormB, sNextB, sFseW, &log);
+                if (!tree) err = 1;
+            } else {                                   // treeless: the tree of the nearest earlier block that carries one
+                uint32_t k = b; bool found = false;
+                while (k > fr.blockBase) {
+                    k--;
+                    if ((blocks[k].type & 3u) == 2u && !(blocks[k].type & GC_ZD_B_BAD) && (blocks[k].litInfo & 3u) == 2u) { found = true; break; }
+                }
+                if (!found) err = 1;
+                else {
+                    const uint32_t h2 = blocks[k].litInfo >> 8, c2 = blocks[k].comp;
+                    zd_load_window(sWinL, src, srcSize, blocks[k].srcOff + h2, ZD_WIN_L);
+                    const uint32_t used = zd_huf_read(sWinL, c2 < ZD_WIN_L ? c2 : ZD_WIN_L, sHuf, sW, sNormB, sNextB, sFseW, &log);
+                    if (!used) err = 1;
+                }
+            }
+            sV[2] = log; sV[3] = tree; if (err) sV[1] = 1;
+        }
+        gc_wave_sync();
+        pc1 = prof ? gc_clock() : 0ull;
+        const uint32_t log = sV[2], tree = sV[3];
+        bool ok = sV[1] == 0u;
+        const uint32_t base = hdr + tree, avail = ok && e.comp >= tree ? e.comp - tree : 0u;
+        const uint32_t G = nStreams == 4u ? 16u : 64u, q = nStreams == 4u ? lane >> 4 : 0u, li = lane & (G - 1u);
+        uint32_t sOff = base, sLen = avail, cnt = e.regen, oOff = 0;
+        if (nStreams == 4u) {
+            if (avail < 10u || e.regen < 4u) ok = false;
+            else {
+                const uint32_t s1 = (uint32_t)bsrc[base] | ((uint32_t)bsrc[base + 1] << 8), s2 = (uint32_t)bsrc[base + 2] | ((uint32_t)bsrc[base + 3] << 8),
+                               s3 = (uint32_t)bsrc[base + 4] | ((uint32_t)bsrc[base + 5] << 8);
+                const uint32_t seg = (e.regen + 3u) >> 2;
+                if ((uint64_t)6u + s1 + s2 + s3 >= avail || 3u * seg > e.regen) ok = false;
+                else {
+                    sOff = base + 6u + (q > 0u ? s1 : 0u) + (q > 1u ? s2 : 0u) + (q > 2u ? s3 : 0u);
+                    sLen = q == 0u ? s1 : (q == 1u ? s2 : (q == 2u ? s3 : avail - 6u - s1 - s2 - s3));
+                    oOff = q * seg; cnt = q == 3u ? e.regen - 3u * seg : seg;
+                }
+            }
+        } else if (!avail) ok = false;
+        uint8_t* const out = litWork + fr.litBase + e.litOff + oOff;
+        const bool good = zd_huf_parallel(bsrc + sOff, sLen, cnt, out, sHuf, log, G, li, ok);
+        if (!good) sV[1] = 1;
+    }
+    }
+    if (prof && lane == 0u) {
+        const unsigned long long pc2 = gc_clock();
+        atomicAdd(&prof[10], (pc1 ? pc1 : pc2) - pc0); atomicAdd(&prof[11], pc1 ? pc2 - pc1 : 0ull);
+    }
+    gc_wave_sync();
+    if (lane == 0u) blocks[b].litStatus = sV[1] ? GC_ZD_CORRUPT : GC_ZD_OK;
+}
+
+// ---- sequences: one wave per block (lane 0 decodes; 10 KB of LDS, so that many blocks are in flight per CU) ----
+extern "C" __global__ void __launch_bounds__(64)
+gc_zstd_dec_seq_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const GcZdFrame* __restrict__ frames, GcZdBlock* blocks, GcU4* seqWork, unsigned long long* prof)
+{
+    __shared__ uint32_t sLL[512], sML[512], sOF[256];
+    __shared__ __attribute__((aligned(16))) uint8_t sBuf[GC_ZD_CHUNK + 64u];
+    __shared__ __attribute__((aligned(16))) uint8_t sWinS[ZD_WIN_S + 8u], sWinR[ZD_WIN_S + 8u];
+    __shared__ int16_t sNormA[64];
+    __shared__ uint16_t sNextA[64];
+    __shared__ ZdConst sK;
+    __shared__ uint32_t sV[16];       // 0 error, 4 seq stream start, 5..7 table logs, 8.. results
+
+    const uint32_t lane = threadIdx.x, t = lane, b = blockIdx.x;
     const uint32_t ty = blocks[b].type;
     if ((ty & 3u) != 2u || (ty & GC_ZD_B_BAD)) return;
     const GcZdBlock e = blocks[b];
     const GcZdFrame fr = frames[e.frame];
     const uint8_t* const bsrc = src + e.srcOff;
     const uint32_t bs = e.size;
-
-    for (uint32_t i = t; i < 36u; i += GC_ZD_ENT_T) { sK.llBase[i] = kZdLLBase[i]; sK.llBits[i] = kZdLLBits[i]; sK.llNorm[i] = kZdLLNorm[i]; }
-    for (uint32_t i = t; i < 53u; i += GC_ZD_ENT_T) { sK.mlBase[i] = kZdMLBase[i]; sK.mlBits[i] = kZdMLBits[i]; sK.mlNorm[i] = kZdMLNorm[i]; }
-    for (uint32_t i = t; i < 29u; i += GC_ZD_ENT_T) sK.ofNorm[i] = kZdOFNorm[i];
-    for (uint32_t i = t; i < ZD_WIN_L + 8u; i += GC_ZD_ENT_T) sWinL[i] = i < bs ? bsrc[i] : (uint8_t)0;
-    for (uint32_t i = t; i < ZD_WIN_S + 8u; i += GC_ZD_ENT_T) sWinS[i] = e.seqPos + i < bs ? bsrc[e.seqPos + i] : (uint8_t)0;
+    for (uint32_t i = t; i < 36u; i += 64u) { sK.llBase[i] = kZdLLBase[i]; sK.llBits[i] = kZdLLBits[i]; sK.llNorm[i] = kZdLLNorm[i]; }
+    for (uint32_t i = t; i < 53u; i += 64u) { sK.mlBase[i] = kZdMLBase[i]; sK.mlBits[i] = kZdMLBits[i]; sK.mlNorm[i] = kZdMLNorm[i]; }
+    for (uint32_t i = t; i < 29u; i += 64u) sK.ofNorm[i] = kZdOFNorm[i];
+    for (uint32_t i = t; i < ZD_WIN_S + 8u; i += 64u) sWinS[i] = e.seqPos + i < bs ? bsrc[e.seqPos + i] : (uint8_t)0;
     if (t < 16u) sV[t] = 0;
-    __syncthreads();
+    gc_wave_sync();
     const unsigned long long pc0 = prof ? gc_clock() : 0ull;
     unsigned long long pc1 = 0;
-
-    if (wave == 1u) {
-        // ------------------------------------------------ literals ------------------------------------------------
-        const uint32_t lt = e.litInfo & 3u, nStreams = (e.litInfo >> 2) & 7u, hdr = e.litInfo >> 8;
-        if (lt >= 2u) {
-            if (lane == 0u) {
-                uint32_t log = 0, tree = 0, err = 0;
-                if (lt == 2u) {
-                    const uint32_t avail = e.comp < ZD_WIN_L - hdr ? e.comp : ZD_WIN_L - hdr;
-                    tree = zd_huf_read(sWinL + hdr, avail, sHuf, sW, sNormB, sNextB, sFseW, &log);
-                    if (!tree) err = 1;
-                } else {                                   // treeless: the tree of the nearest earlier block that carries one
-                    uint32_t k = b; bool found = false;
-                    while (k > fr.blockBase) {
-                        k--;
-                        if ((blocks[k].type & 3u) == 2u && !(blocks[k].type & GC_ZD_B_BAD) && (blocks[k].litInfo & 3u) == 2u) { found = true; break; }
-                    }
-                    if (!found) err = 1;
-                    else {
-                        const uint32_t h2 = blocks[k].litInfo >> 8, c2 = blocks[k].comp;
-                        zd_load_window(sWinL, src, srcSize, blocks[k].srcOff + h2, ZD_WIN_L);
-                        const uint32_t used = zd_huf_read(sWinL, c2 < ZD_WIN_L ? c2 : ZD_WIN_L, sHuf, sW, sNormB, sNextB, sFseW, &log);
-                        if (!used) err = 1;
-                    }
-                }
-                sV[2] = log; sV[3] = tree; if (err) sV[1] = 1;
-            }
-            gc_wave_sync();
-            pc1 = prof ? gc_clock() : 0ull;
-            const uint32_t log = sV[2], tree = sV[3];
-            bool ok = sV[1] == 0u;
-            const uint32_t base = hdr + tree, avail = ok && e.comp >= tree ? e.comp - tree : 0u;
-            const uint32_t G = nStreams == 4u ? 16u : 64u, q = nStreams == 4u ? lane >> 4 : 0u, li = lane & (G - 1u);
-            uint32_t sOff = base, sLen = avail, cnt = e.regen, oOff = 0;
-            if (nStreams == 4u) {
-                if (avail < 10u || e.regen < 4u) ok = false;
+    {
+    // ------------------------------------------------ sequences ------------------------------------------------
+    const uint32_t nSeq = e.nSeq;
+    uint32_t err = 0, dpos = 0, lpos = 0;
+    uint32_t rep0 = GC_ZD_SYM | 0u, rep1 = GC_ZD_SYM | 1u, rep2 = GC_ZD_SYM | 2u;
+    if (nSeq) {
+        if (lane == 0u) {
+            uint32_t p = 1;                                // behind the modes byte
+            const int order[3] = { ZT_LL, ZT_OF, ZT_ML };
+            for (int i = 0; i < 3 && !err; i++) {
+                const int which = order[i];
+                uint32_t* const tab = which == ZT_LL ? sLL : (which == ZT_OF ? sOF : sML);
+                const uint32_t mode = (e.modes >> (which == ZT_LL ? 6u : (which == ZT_OF ? 4u : 2u))) & 3u;
+                if (mode != 3u) { p = zd_seq_table(mode, sWinS, ZD_WIN_S, p, tab, &sV[5 + which], which, &sK, sNormA, sNextA); if (!p) err = 1; }
                 else {
-                    const uint32_t s1 = (uint32_t)bsrc[base] | ((uint32_t)bsrc[base + 1] << 8), s2 = (uint32_t)bsrc[base + 2] | ((uint32_t)bsrc[base + 3] << 8),
-                                   s3 = (uint32_t)bsrc[base + 4] | ((uint32_t)bsrc[base + 5] << 8);
-                    const uint32_t seg = (e.regen + 3u) >> 2;
-                    if ((uint64_t)6u + s1 + s2 + s3 >= avail || 3u * seg > e.regen) ok = false;
-                    else {
-                        sOff = base + 6u + (q > 0u ? s1 : 0u) + (q > 1u ? s2 : 0u) + (q > 2u ? s3 : 0u);
-                        sLen = q == 0u ? s1 : (q == 1u ? s2 : (q == 2u ? s3 : avail - 6u - s1 - s2 - s3));
-                        oOff = q * seg; cnt = q == 3u ? e.regen - 3u * seg : seg;
-                    }
-                }
-            } else if (!avail) ok = false;
-            uint8_t* const out = litWork + fr.litBase + e.litOff + oOff;
-            const bool good = zd_huf_parallel(bsrc + sOff, sLen, cnt, out, sHuf, log, G, li, ok);
-            if (!good) sV[1] = 1;
-        }
-    } else {
-        // ------------------------------------------------ sequences ------------------------------------------------
-        const uint32_t nSeq = e.nSeq;
-        uint32_t err = 0, dpos = 0, lpos = 0;
-        uint32_t rep0 = GC_ZD_SYM | 0u, rep1 = GC_ZD_SYM | 1u, rep2 = GC_ZD_SYM | 2u;
-        if (nSeq) {
-            if (lane == 0u) {
-                uint32_t p = 1;                                // behind the modes byte
-                const int order[3] = { ZT_LL, ZT_OF, ZT_ML };
-                for (int i = 0; i < 3 && !err; i++) {
-                    const int which = order[i];
-                    GcU2* const tab = which == ZT_LL ? sLL : (which == ZT_OF ? sOF : sML);
-                    const uint32_t mode = (e.modes >> (which == ZT_LL ? 6u : (which == ZT_OF ? 4u : 2u))) & 3u;
-                    if (mode != 3u) { p = zd_seq_table(mode, sWinS, ZD_WIN_S, p, tab, &sV[5 + which], which, &sK, sNormA, sNextA); if (!p) err = 1; }
-                    else {
-                        const uint32_t k = zd_find_table_source(blocks, fr.blockBase, b, which);
-                        if (k == 0xFFFFFFFFu) { err = 1; break; }
-                        const uint32_t m2 = blocks[k].modes;
-                        const uint32_t mk = (m2 >> (which == ZT_LL ? 6u : (which == ZT_OF ? 4u : 2u))) & 3u;
-                        uint32_t q = 1;
-                        if (mk != 0u) {
-                            zd_load_window(sWinR, src, srcSize, blocks[k].srcOff + blocks[k].seqPos, ZD_WIN_S);
-                            for (int y = 0; y < 3 && order[y] != which; y++) {
-                                const int w2 = order[y];
-                                const int sk = zd_seq_table_skip((m2 >> (w2 == ZT_LL ? 6u : (w2 == ZT_OF ? 4u : 2u))) & 3u, sWinR, ZD_WIN_S, q, w2, sNormA);
-                                if (sk < 0) { err = 1; break; }
-                                q += (uint32_t)sk;
-                            }
+                    const uint32_t k = zd_find_table_source(blocks, fr.blockBase, b, which);
+                    if (k == 0xFFFFFFFFu) { err = 1; break; }
+                    const uint32_t m2 = blocks[k].modes;
+                    const uint32_t mk = (m2 >> (which == ZT_LL ? 6u : (which == ZT_OF ? 4u : 2u))) & 3u;
+                    uint32_t q = 1;
+                    if (mk != 0u) {
+                        zd_load_window(sWinR, src, srcSize, blocks[k].srcOff + blocks[k].seqPos, ZD_WIN_S);
+                        for (int y = 0; y < 3 && order[y] != which; y++) {
+                            const int w2 = order[y];
+                            const int sk = zd_seq_table_skip((m2 >> (w2 == ZT_LL ? 6u : (w2 == ZT_OF ? 4u : 2u))) & 3u, sWinR, ZD_WIN_S, q, w2, sNormA);
+                            if (sk < 0) { err = 1; break; }
+                            q += (uint32_t)sk;
                         }
-                        if (!err && !zd_seq_table(mk, sWinR, ZD_WIN_S, q, tab, &sV[5 + which], which, &sK, sNormA, sNextA)) err = 1;
                     }
+                    if (!err && !zd_seq_table(mk, sWinR, ZD_WIN_S, q, tab, &sV[5 + which], which, &sK, sNormA, sNextA)) err = 1;
                 }
-                if (!err && (p > ZD_WIN_S || e.seqPos + p >= bs)) err = 1;
-                sV[4] = e.seqPos + p; if (err) sV[0] = 1;
+            }
+            if (!err && (p > ZD_WIN_S || e.seqPos + p >= bs)) err = 1;
+            sV[4] = e.seqPos + p; if (err) sV[0] = 1;
+        }
+        gc_wave_sync();
+        pc1 = prof ? gc_clock() : 0ull;
+        err = sV[0];
+        const uint32_t seqStart = sV[4];
+        const uint8_t* const sp = bsrc + seqStart;
+        const uint32_t n = err ? 1u : bs - seqStart;
+        int32_t off = 0;
+        if (!err) {
+            const uint32_t last = sp[n - 1u];
+            if (!last) err = 1; else off = (int32_t)((n - 1u) * 8u + gc_hibit32(last));
+        }
+        const uint32_t llLog = sV[5 + ZT_LL], ofLog = sV[5 + ZT_OF], mlLog = sV[5 + ZT_ML];
+        uint32_t stLL = 0, stOF = 0, stML = 0, j = 0;
+        GcU4* const seq = seqWork + fr.seqBase + e.seqOff;
+        bool first = true;
+        while (!err) {
+            // stage the piece of the bitstream the next sequences read: bytes [cLo, hi + 8) of the stream at sBuf + 16.  With 16 zero bytes in
+            // front of byte 0 a read that reaches below the start of the stream (legal at the very end: the bits there read as zeros; an
+            // over-read otherwise, caught right after) needs no special case: bit p lies in byte ((p + 128) >> 3) - cLo of sBuf.
+            const uint32_t hi = (uint32_t)(off + 7) >> 3;
+            const uint32_t cLo = hi > GC_ZD_CHUNK ? (hi - GC_ZD_CHUNK) & ~7u : 0u;
+            if (lane < 2u) { const uint64_t z = 0; __builtin_memcpy(sBuf + 8u * lane, &z, 8); }
+            for (uint32_t i = lane * 8u; i < hi + 8u - cLo; i += 512u) {
+                uint64_t v = 0;
+                if (cLo + i + 8u <= n) v = gc_ld64(sp + cLo + i);
+                else for (uint32_t k = 0; k < 8u && cLo + i + k < n; k++) v |= (uint64_t)sp[cLo + i + k] << (8u * k);
+                __builtin_memcpy(sBuf + 16u + i, &v, 8);
             }
             gc_wave_sync();
-            pc1 = prof ? gc_clock() : 0ull;
-            err = sV[0];
-            const uint32_t seqStart = sV[4];
-            const uint8_t* const sp = bsrc + seqStart;
-            const uint32_t n = err ? 1u : bs - seqStart;
-            int32_t off = 0;
-            if (!err) {
-                const uint32_t last = sp[n - 1u];
-                if (!last) err = 1; else off = (int32_t)((n - 1u) * 8u + gc_hibit32(last));
-            }
-            const uint32_t llLog = sV[5 + ZT_LL], ofLog = sV[5 + ZT_OF], mlLog = sV[5 + ZT_ML];
-            uint32_t stLL = 0, stOF = 0, stML = 0, j = 0;
-            GcU4* const seq = seqWork + fr.seqBase + e.seqOff;
-            bool first = true;
-            while (!err) {
-                // stage the piece of the bitstream the next sequences read: bytes [cLo, hi + 8) of the stream at sBuf + 16.  With 16 zero bytes in
-                // front of byte 0 a read that reaches below the start of the stream (legal at the very end: the bits there read as zeros; an
-                // over-read otherwise, caught right after) needs no special case: bit p lies in byte ((p + 128) >> 3) - cLo of sBuf.
-                const uint32_t hi = (uint32_t)(off + 7) >> 3;
-                const uint32_t cLo = hi > GC_ZD_CHUNK ? (hi - GC_ZD_CHUNK) & ~7u : 0u;
-                if (lane < 2u) { const uint64_t z = 0; __builtin_memcpy(sBuf + 8u * lane, &z, 8); }
-                for (uint32_t i = lane * 8u; i < hi + 8u - cLo; i += 512u) {
-                    uint64_t v = 0;
-                    if (cLo + i + 8u <= n) v = gc_ld64(sp + cLo + i);
-                    else for (uint32_t k = 0; k < 8u && cLo + i + k < n; k++) v |= (uint64_t)sp[cLo + i + k] << (8u * k);
-                    __builtin_memcpy(sBuf + 16u + i, &v, 8);
-                }
-                gc_wave_sync();
-                if (lane == 0u) {
+            if (lane == 0u) {
 #define ZD_RD64(p) (gc_ld64(sBuf + (((uint32_t)((p) + 128) >> 3) - cLo)) >> ((uint32_t)(p) & 7u))
 #define ZD_RD32(p) (gc_ld32(sBuf + (((uint32_t)((p) + 128) >> 3) - cLo)) >> ((uint32_t)(p) & 7u))
-                    if (first) {
-                        const int32_t p1 = off - (int32_t)llLog, p2 = p1 - (int32_t)ofLog, p3 = p2 - (int32_t)mlLog;
-                        if (p3 < 0) err = 1;
-                        else {
-                            stLL = ZD_RD32(p1) & ((1u << llLog) - 1u); stOF = ZD_RD32(p2) & ((1u << ofLog) - 1u); stML = ZD_RD32(p3) & ((1u << mlLog) - 1u);
-                            off = p3;
-                        }
+                if (first) {
+                    const int32_t p1 = off - (int32_t)llLog, p2 = p1 - (int32_t)ofLog, p3 = p2 - (int32_t)mlLog;
+                    if (p3 < 0) err = 1;
+                    else {
+                        stLL = ZD_RD32(p1) & ((1u << llLog) - 1u); stOF = ZD_RD32(p2) & ((1u << ofLog) - 1u); stML = ZD_RD32(p3) & ((1u << mlLog) - 1u);
+                        off = p3;
                     }
-                    // One step per sequence.  Every bit position of the step follows from the three table entries, so the six reads go out
-                    // together; the repeat-offset rules are selects, the checks one flag.
-                    while (!err && j < nSeq && (cLo == 0u || ((uint32_t)off >> 3) >= cLo + 16u)) {
-                        const GcU2 eLL = sLL[stLL], eOF = sOF[stOF], eML = sML[stML];
-                        const uint32_t more = j + 1u < nSeq ? 0xFFu : 0u;            // the last sequence does not move the states on
-                        const uint32_t ofb = eOF.x >> 24, mlb = eML.x >> 24, llb = eLL.x >> 24;
-                        const uint32_t nl = (eLL.x >> 16) & more, nm = (eML.x >> 16) & more, no = (eOF.x >> 16) & more;
-                        const int32_t p1 = off - (int32_t)ofb, p2 = p1 - (int32_t)mlb, p3 = p2 - (int32_t)llb;
-                        const int32_t p4 = p3 - (int32_t)nl, p5 = p4 - (int32_t)nm, p6 = p5 - (int32_t)no;
-                        const uint64_t w1 = ZD_RD64(p1);
-                        const uint32_t w2 = ZD_RD32(p2), w3 = ZD_RD32(p3), w4 = ZD_RD32(p4), w5 = ZD_RD32(p5), w6 = ZD_RD32(p6);
-                        const uint32_t ofv = eOF.y + ((uint32_t)w1 & ((1u << (ofb & 31u)) - 1u));
-                        const uint32_t ml = eML.y + (w2 & ((1u << mlb) - 1u));
-                        const uint32_t ll = eLL.y + (w3 & ((1u << llb) - 1u));
-                        stLL = (eLL.x & 0xFFFFu) + (w4 & ((1u << nl) - 1u));
-                        stML = (eML.x & 0xFFFFu) + (w5 & ((1u << nm) - 1u));
-                        stOF = (eOF.x & 0xFFFFu) + (w6 & ((1u << no) - 1u));
-                        off = p6;
-                        // offset value 1..3 = one of the three last offsets (shifted by one when the sequence has no literals; "4" = the first minus 1)
-                        const bool isRep = ofv <= 3u;
-                        const uint32_t idx = ofv - 1u + (ll == 0u ? 1u : 0u);
-                        const uint32_t r0m1 = (rep0 & GC_ZD_SYM) ? rep0 + 4u : rep0 - 1u;
-                        const uint32_t o = !isRep ? ofv - 3u : (idx == 0u ? rep0 : (idx == 1u ? rep1 : (idx == 2u ? rep2 : r0m1)));
-                        const bool shift3 = !isRep || idx >= 2u, shift2 = isRep && idx == 1u;
-                        rep2 = shift3 ? rep1 : rep2;
-                        rep1 = (shift3 || shift2) ? rep0 : rep1;
-                        rep0 = o;
-                        const bool bad = off < 0 || o == 0u || lpos + ll > e.regen || dpos + ll + ml > GC_ZSTD_BLOCK_MAX;
-                        if (ofb > 30u) { err = GC_ZD_UNSUPPORTED; break; }
-                        if (bad) { err = 1; break; }
-                        GcU4 rec; rec.x = ll | (ml << 18); rec.y = (ml >> 14) | (lpos << 4); rec.z = o; rec.w = dpos;
-                        seq[j] = rec;
-                        dpos += ll + ml; lpos += ll; j++;
-                    }
+                }
+                // One step per sequence.  Every bit position of the step follows from the three table entries, so the six reads go out
+                // together; the repeat-offset rules are selects, the checks one flag.
+                while (!err && j < nSeq && (cLo == 0u || ((uint32_t)off >> 3) >= cLo + 16u)) {
+                    const uint32_t eLL = sLL[stLL], eOF = sOF[stOF], eML = sML[stML];
+                    const uint32_t more = j + 1u < nSeq ? 15u : 0u;              // the last sequence does not move the states on
+                    const uint32_t ofb = (eOF >> 14) & 31u, mlb = (eML >> 14) & 31u, llb = (eLL >> 14) & 31u;
+                    const uint32_t nl = (eLL >> 10) & more, nm = (eML >> 10) & more, no = (eOF >> 10) & more;
+                    const int32_t p1 = off - (int32_t)ofb, p2 = p1 - (int32_t)mlb, p3 = p2 - (int32_t)llb;
+                    const int32_t p4 = p3 - (int32_t)nl, p5 = p4 - (int32_t)nm, p6 = p5 - (int32_t)no;
+                    const uint64_t w1 = ZD_RD64(p1);
+                    const uint32_t w2 = ZD_RD32(p2), w3 = ZD_RD32(p3), w4 = ZD_RD32(p4), w5 = ZD_RD32(p5), w6 = ZD_RD32(p6);
+                    const uint32_t mlBase = sK.mlBase[eML >> 19], llBase = sK.llBase[eLL >> 19];
+                    const uint32_t ofv = (1u << ofb) + ((uint32_t)w1 & ((1u << ofb) - 1u));
+                    const uint32_t ml = mlBase + (w2 & ((1u << mlb) - 1u));
+                    const uint32_t ll = llBase + (w3 & ((1u << llb) - 1u));
+                    stLL = (eLL & 0x3FFu) + (w4 & ((1u << nl) - 1u));
+                    stML = (eML & 0x3FFu) + (w5 & ((1u << nm) - 1u));
+                    stOF = (eOF & 0x3FFu) + (w6 & ((1u << no) - 1u));
+                    off = p6;
+                    // offset value 1..3 = one of the three last offsets (shifted by one when the sequence has no literals; "4" = the first minus 1)
+                    const bool isRep = ofv <= 3u;
+                    const uint32_t idx = ofv - 1u + (ll == 0u ? 1u : 0u);
+                    const uint32_t r0m1 = (rep0 & GC_ZD_SYM) ? rep0 + 4u : rep0 - 1u;
+                    const uint32_t o = !isRep ? ofv - 3u : (idx == 0u ? rep0 : (idx == 1u ? rep1 : (idx == 2u ? rep2 : r0m1)));
+                    const bool shift3 = !isRep || idx >= 2u, shift2 = isRep && idx == 1u;
+                    rep2 = shift3 ? rep1 : rep2;
+                    rep1 = (shift3 || shift2) ? rep0 : rep1;
+                    rep0 = o;
+                    const bool bad = off < 0 || o == 0u || lpos + ll > e.regen || dpos + ll + ml > GC_ZSTD_BLOCK_MAX;
+                    if (ofb > 30u) { err = GC_ZD_UNSUPPORTED; break; }
+                    if (bad) { err = 1; break; }
+                    GcU4 rec; rec.x = ll | (ml << 18); rec.y = (ml >> 14) | (lpos << 4); rec.z = o; rec.w = dpos;
+                    seq[j] = rec;
+                    dpos += ll + ml; lpos += ll; j++;
+                }
 #undef ZD_RD64
 #undef ZD_RD32
-                }
-                first = false;
-                j = __shfl(j, 0); off = __shfl(off, 0); err = __shfl(err, 0);
-                if (j >= nSeq) break;
             }
-            if (!err && off != 0) err = 1;
-            if (err && lane == 0u) sV[0] = err;
+            first = false;
+            j = __shfl(j, 0); off = __shfl(off, 0); err = __shfl(err, 0);
+            if (j >= nSeq) break;
         }
-        if (lane == 0u) { sV[8] = dpos; sV[9] = lpos; sV[10] = rep0; sV[11] = rep1; sV[12] = rep2; }
+        if (!err && off != 0) err = 1;
+        if (err && lane == 0u) sV[0] = err;
     }
-    if (prof && lane == 0u) {          // per wave: tables, streams
+    if (lane == 0u) { sV[8] = dpos; sV[9] = lpos; sV[10] = rep0; sV[11] = rep1; sV[12] = rep2; }
+    }
+    if (prof && lane == 0u) {
         const unsigned long long pc2 = gc_clock();
-        atomicAdd(&prof[8u + 2u * wave], (pc1 ? pc1 : pc2) - pc0); atomicAdd(&prof[9u + 2u * wave], pc1 ? pc2 - pc1 : 0ull);
-        if (wave == 0u) atomicAdd(&prof[12], 1ull);
+        atomicAdd(&prof[8], (pc1 ? pc1 : pc2) - pc0); atomicAdd(&prof[9], pc1 ? pc2 - pc1 : 0ull); atomicAdd(&prof[12], 1ull);
     }
-    __syncthreads();
+    gc_wave_sync();
     if (t == 0) {
         const uint32_t dpos = sV[8], lpos = sV[9];
-        uint32_t status = sV[0] ? (sV[0] == GC_ZD_UNSUPPORTED ? GC_ZD_UNSUPPORTED : GC_ZD_CORRUPT) : (sV[1] ? GC_ZD_CORRUPT : GC_ZD_OK);
+        uint32_t status = sV[0] ? (sV[0] == GC_ZD_UNSUPPORTED ? GC_ZD_UNSUPPORTED : GC_ZD_CORRUPT) : GC_ZD_OK;
         const uint32_t outSize = dpos + (e.regen - lpos);
         if (!status && outSize > GC_ZSTD_BLOCK_MAX) status = GC_ZD_CORRUPT;
         blocks[b].status = status; blocks[b].outSize = outSize; blocks[b].lposEnd = lpos; blocks[b].dposEnd = dpos;
@@ -740,7 +790,7 @@ gc_zstd_dec_exec_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint8
             const uint32_t bt = e.type & 3u;
             uint32_t fail = 0;
             if (e.type & GC_ZD_B_BAD) fail = GC_ZD_CORRUPT;
-            else if (bt == 2u && e.status) fail = e.status;
+            else if (bt == 2u && (e.status || e.litStatus)) fail = e.status ? e.status : e.litStatus;
             else if (produced + (bt == 2u ? e.outSize : e.regen) > cap) fail = GC_ZD_DST_SMALL;
             if (fail) { if (t == 0) sV[XV_ERR] = fail; break; }
             const uint8_t* const bsrc = src + e.srcOff;
@@ -1022,11 +1072,20 @@ extern "C" void gc_zstd_dec_launch_index(hipStream_t st, const uint8_t* src, con
 {
     GC_LAUNCH(gc_zstd_dec_index_kernel, (nFrames + 63u) / 64u, 64, st, src, frames, nFrames, blocks, frameTot);
 }
-extern "C" void gc_zstd_dec_launch_decode(hipStream_t st, const uint8_t* src, uint64_t srcSize, uint8_t* dst, uint64_t dstCap, const GcZdFrame* frames, uint32_t nFrames,
-                                          GcZdBlock* blocks, uint32_t nBlocks, uint32_t* ticket, uint8_t* litWork, uint64_t litWorkSize, void* seqWork, uint64_t* result,
-                                          unsigned long long* prof)
+// literals and sequences of all blocks: independent of each other (two streams), both in front of the execution kernel
+extern "C" void gc_zstd_dec_launch_literals(hipStream_t st, const uint8_t* src, uint64_t srcSize, const GcZdFrame* frames, GcZdBlock* blocks, uint32_t nBlocks, uint8_t* litWork,
+                                            unsigned long long* prof)
 {
-    if (nBlocks) GC_LAUNCH(gc_zstd_dec_entropy_kernel, nBlocks, GC_ZD_ENT_T, st, src, srcSize, frames, blocks, litWork, (GcU4*)seqWork, prof);
+    if (nBlocks) GC_LAUNCH(gc_zstd_dec_lit_kernel, nBlocks, 64, st, src, srcSize, frames, blocks, litWork, prof);
+}
+extern "C" void gc_zstd_dec_launch_sequences(hipStream_t st, const uint8_t* src, uint64_t srcSize, const GcZdFrame* frames, GcZdBlock* blocks, uint32_t nBlocks, void* seqWork,
+                                             unsigned long long* prof)
+{
+    if (nBlocks) GC_LAUNCH(gc_zstd_dec_seq_kernel, nBlocks, 64, st, src, srcSize, frames, blocks, (GcU4*)seqWork, prof);
+}
+extern "C" void gc_zstd_dec_launch_exec(hipStream_t st, const uint8_t* src, uint64_t srcSize, uint8_t* dst, uint64_t dstCap, const GcZdFrame* frames, uint32_t nFrames,
+                                        GcZdBlock* blocks, uint32_t* ticket, uint8_t* litWork, uint64_t litWorkSize, void* seqWork, uint64_t* result, unsigned long long* prof)
+{
     const uint32_t wg = nFrames < GC_ZD_MAX_WG ? nFrames : GC_ZD_MAX_WG;
     GC_LAUNCH(gc_zstd_dec_exec_kernel, wg, GC_ZD_T, st, src, srcSize, dst, dstCap, frames, nFrames, (const GcZdBlock*)blocks, ticket, (const uint8_t*)litWork, litWorkSize, (GcU4*)seqWork, result, prof);
 }
