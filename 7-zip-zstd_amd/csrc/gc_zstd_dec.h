@@ -49,7 +49,7 @@ struct GcZdBlock {
 // and puts the real values in.
 #define GC_ZD_SYM 0x80000000u
 
-#define GC_ZD_T         256u                          // execution kernel
+#define GC_ZD_T         1024u                         // execution kernel
 #define GC_ZD_MAX_WG    256u                          // frames in execution at a time (129 KB of LDS: one workgroup per CU)
 #define GC_ZD_CHUNK     2048u                         // bytes of the sequence bitstream staged in LDS at a time
 
