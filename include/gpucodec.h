@@ -171,6 +171,18 @@ int         gc_ctx_set_option(gc_ctx* ctx, int option, int value);
  * Synchronous, on the current device's default stream. */
 int         gc_crc32_device(const void* d_src, size_t n, uint32_t* crc);
 
+/* ---- Branch converters on data in device memory (the filters 7-Zip puts in front of a compressor for executables:
+ * z7_BranchConv_ARM64_Enc / _Dec ... of C/Bra.c:75-340, called from NCompress::NBranch::CCoder::Filter, CPP/7zip/Compress/BranchMisc.cpp:21-26).
+ * pc = virtual address of byte 0 (the filters' kBranchOffset property); encoding != 0 converts relative -> absolute.  d_dst may equal d_src
+ * except for GC_BRA_ARMT.  *processed = the byte count the reference's converter reports for one call on the whole buffer (bytes behind it are
+ * copied unchanged).  X86, IA64 and RISCV are not provided.  Synchronous on the default stream. */
+#define GC_BRA_ARM64 0
+#define GC_BRA_ARM   1
+#define GC_BRA_ARMT  2
+#define GC_BRA_PPC   3
+#define GC_BRA_SPARC 4
+int         gc_bra_convert_device(int kind, const void* d_src, void* d_dst, size_t n, uint32_t pc, int encoding, size_t* processed);
+
 /* ---- ZSTD decoding on the device.  Replaces the ZSTD_decompressStream loop of NCompress::NZSTD::CDecoder::CodeSpec
  * (CPP/7zip/Compress/ZstdDecoder.cpp:66-240; C/zstd/zstd_decompress.c:2086) for callers that hold a whole compressed stream.  The frame is
  * Entropy decoding (Huffman literals, FSE sequences) runs per BLOCK (<= 128 KiB, one workgroup each, whatever the frame structure);

@@ -58,7 +58,7 @@ class _Diag(C.Structure):
 
 
 def ref(name):
-    """name in {'zstd','flzma2','brotli'}; returns CDLL or None when the prebuilt .so is absent."""
+    """name in {'zstd','flzma2','brotli','bra'}; returns CDLL or None when the prebuilt .so is absent."""
     if name not in _ref:
         lib = _load(os.path.join(HERE, "_ref", "lib%s_ref.so" % name))
         if lib is not None:
@@ -76,6 +76,9 @@ def ref(name):
                 lib.ref_fl2_compress.restype = _SZ
                 lib.ref_lzma2_decode.argtypes = [_VP, _SZ, _VP, _SZ, C.c_ubyte]
                 lib.ref_lzma2_decode.restype = _SZ
+            elif name == "bra":
+                lib.ref_bra_convert.argtypes = [C.c_int, _VP, _SZ, C.c_uint, C.c_int]
+                lib.ref_bra_convert.restype = _SZ
             elif name == "brotli":
                 lib.ref_brotli_compress.argtypes = [_VP, _SZ, _VP, _SZ, C.c_int, C.c_int]
                 lib.ref_brotli_decompress.argtypes = [_VP, _SZ, _VP, _SZ]
@@ -143,6 +146,16 @@ def ref_zstd_compress(data, level=3, workers=0, piece=0):
     if r == _BAD:
         raise RuntimeError("reference zstd compress failed")
     return out[:r].copy()
+
+
+def ref_bra_convert(kind, data, pc=0, encoding=True):
+    """The reference's branch converter (C/Bra.c) on a copy of data, one call: (converted array, processed bytes).  kind 0 ARM64 1 ARM 2 ARMT 3 PPC 4 SPARC"""
+    a = np.array(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data, dtype=np.uint8, copy=True)
+    buf = np.zeros(a.size + 64, dtype=np.uint8)          # 16-byte aligned start, room behind the end
+    off = (-buf.ctypes.data) % 16
+    view = buf[off:off + a.size]; view[:] = a
+    done = ref("bra").ref_bra_convert(kind, view.ctypes.data, a.size, pc & 0xFFFFFFFF, 1 if encoding else 0)
+    return view.copy(), int(done)
 
 
 def ref_zstd_compress_opts(data, level=3, checksum=False, streamed=False, ldm=False):

@@ -1,0 +1,20 @@
+/* oracle/ref_shim_bra.c -- TEST INFRASTRUCTURE ONLY.
+ * The REFERENCE's branch converters (compiled from /root/reference/C/Bra.c by oracle/Makefile into oracle/_ref/libbra_ref.so), one entry point
+ * that converts a buffer in place with one call, the way NCompress::NBranch::CCoder::Filter does (CPP/7zip/Compress/BranchMisc.cpp:21-26). */
+#include <stddef.h>
+#include "Bra.h"
+
+/* kind: 0 ARM64, 1 ARM, 2 ARMT, 3 PPC, 4 SPARC; returns the processed byte count */
+size_t ref_bra_convert(int kind, unsigned char* data, size_t n, unsigned pc, int encoding)
+{
+    z7_Func_BranchConv f = 0;
+    switch (kind) {
+        case 0: f = encoding ? z7_BranchConv_ARM64_Enc : z7_BranchConv_ARM64_Dec; break;
+        case 1: f = encoding ? z7_BranchConv_ARM_Enc : z7_BranchConv_ARM_Dec; break;
+        case 2: f = encoding ? z7_BranchConv_ARMT_Enc : z7_BranchConv_ARMT_Dec; break;
+        case 3: f = encoding ? z7_BranchConv_PPC_Enc : z7_BranchConv_PPC_Dec; break;
+        case 4: f = encoding ? z7_BranchConv_SPARC_Enc : z7_BranchConv_SPARC_Dec; break;
+        default: return (size_t)-1;
+    }
+    return (size_t)(f(data, n, pc) - data);
+}

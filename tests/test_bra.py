@@ -1,0 +1,101 @@
+"""Branch converters on the device against the reference's own C/Bra.c (oracle/_ref/libbra_ref.so): bit-exact encode and decode
+on instruction-like data for ARM64 / ARM / ARMT / PPC / SPARC, ragged sizes, unaligned-looking program counters, and encode -> decode = identity."""
+import numpy as np
+import pytest
+
+KINDS = ["ARM64", "ARM", "ARMT", "PPC", "SPARC"]
+KID = {"ARM64": 0, "ARM": 1, "ARMT": 2, "PPC": 3, "SPARC": 4}
+
+
+def _code_like(kind, n, seed):
+    """random bytes with many instructions of the kind the converter looks for (and near misses of them)"""
+    rng = np.random.default_rng(seed)
+    x = rng.integers(0, 256, size=n + 8, dtype=np.uint8)
+    w = x[: (n // 4) * 4].view("<u4")
+    m = rng.random(w.size)
+    if kind == "ARM64":
+        w[m < 0.25] = (w[m < 0.25] & 0x03FFFFFF) | 0x94000000                                  # BL
+        sel = (m >= 0.25) & (m < 0.5)
+        w[sel] = (w[sel] & 0x6000001F) | 0x90000000 | ((rng.integers(0, 1 << 19, size=int(sel.sum()), dtype=np.uint32) - (1 << 18)).astype(np.uint32) & 0x7FFFF) << 5   # ADRP, small and large offsets
+        sel = (m >= 0.5) & (m < 0.6)
+        w[sel] = (w[sel] & 0x7FFFFFFF) | 0x90000000
+    elif kind == "ARM":
+        w[m < 0.4] = (w[m < 0.4] & 0x00FFFFFF) | 0xEB000000
+    elif kind == "PPC":
+        b = w.byteswap()
+        b[m < 0.4] = (b[m < 0.4] & 0x03FFFFFC) | 0x48000001
+        w[:] = b.byteswap()
+    elif kind == "SPARC":
+        b = w.byteswap()
+        sel = m < 0.3
+        b[sel] = 0x40000000 | (b[sel] & 0x003FFFFF)
+        sel = (m >= 0.3) & (m < 0.6)
+        b[sel] = 0x7FC00000 | (b[sel] & 0x003FFFFF)
+        w[:] = b.byteswap()
+    else:                                                                                      # Thumb: F000..F7FF followed by F800..FFFF, and lone halves
+        h = x[: (n // 2) * 2].view("<u2")
+        m2 = rng.random(h.size)
+        first = np.nonzero(m2 < 0.3)[0]
+        h[first] = (h[first] & 0x07FF) | 0xF000
+        nxt = first[first + 1 < h.size] + 1
+        keep = rng.random(nxt.size) < 0.8
+        h[nxt[keep]] = (h[nxt[keep]] & 0x07FF) | 0xF800
+        lone = np.nonzero((m2 >= 0.3) & (m2 < 0.4))[0]
+        h[lone] = (h[lone] & 0x07FF) | 0xF800
+    return np.ascontiguousarray(x[:n])
+
+
+def _gpu_like(pkg, lib_path, kind, x, pc, enc, to_dev=None):
+    out = np.empty_like(x) if x.size else np.empty(1, dtype=np.uint8)
+    if to_dev is None:
+        done = pkg.bra_convert_device(kind, x.ctypes.data if x.size else 0, out.ctypes.data if x.size else 0, x.size, pc, enc, lib_path)
+        return out[: x.size], done
+    import torch
+    d_in = torch.from_numpy(x).cuda() if x.size else torch.empty(1, dtype=torch.uint8, device="cuda")
+    d_out = torch.empty(max(1, x.size), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    done = pkg.bra_convert_device(kind, d_in.data_ptr(), d_out.data_ptr(), x.size, pc, enc)
+    return d_out[: x.size].cpu().numpy(), done
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_emu_branch_converters_match_the_reference(pkg, O, emu_lib_path, kind):
+    if O.ref("bra") is None:
+        pytest.skip("oracle/_ref not built")
+    for n, pc in ((0, 0), (1, 0), (3, 4), (4, 0), (5, 0), (15, 0x1000), (16, 0), (17, 0), (4099, 0x7FFFF000), (70_001, 0x12345678 & ~3), (262_144, 0xFFFFF000)):
+        x = _code_like(kind, n, 100 + n)
+        for enc in (True, False):
+            want, wdone = O.ref_bra_convert(KID[kind], x, pc, enc)
+            got, gdone = _gpu_like(pkg, emu_lib_path, kind, x, pc, enc)
+            assert np.array_equal(got, want), (kind, n, pc, enc, np.nonzero(got != want)[0][:8])
+            assert gdone == wdone, (kind, n, enc, gdone, wdone)
+        y, _ = _gpu_like(pkg, emu_lib_path, kind, x, pc, True)
+        z, _ = _gpu_like(pkg, emu_lib_path, kind, y, pc, False)
+        assert np.array_equal(z, x)                                            # encode -> decode is the identity
+    assert sum(int((_gpu_like(pkg, emu_lib_path, kind, _code_like(kind, 4096, 1), 0x4000, True)[0] != _code_like(kind, 4096, 1)).sum()) for _ in range(1)) > 100   # the corpus really exercises it
+
+
+def test_emu_in_place_and_parameter_checks(pkg, O, emu_lib_path):
+    x = _code_like("ARM64", 10_000, 5)
+    y = x.copy()
+    pkg.bra_convert_device("ARM64", y.ctypes.data, y.ctypes.data, y.size, 0x8000, True, emu_lib_path)       # in place is allowed for the word converters
+    if O.ref("bra") is not None:
+        assert np.array_equal(y, O.ref_bra_convert(0, x, 0x8000, True)[0])
+    with pytest.raises(pkg.GpuCodecError):
+        pkg.bra_convert_device("ARMT", y.ctypes.data, y.ctypes.data, y.size, 0, True, emu_lib_path)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", KINDS)
+def test_gpu_branch_converters_match_the_reference(pkg, O, graft, kind):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    graft.build_hip()
+    for n, pc in ((0, 0), (7, 0), (100_000_003, 0x00400000), (16 << 20, 0xFFFF0000)):
+        x = _code_like(kind, n, 7 + (n & 0xFFFF))
+        for enc in (True, False):
+            want, wdone = O.ref_bra_convert(KID[kind], x, pc, enc)
+            got, gdone = _gpu_like(pkg, None, kind, x, pc, enc, to_dev=True)
+            assert np.array_equal(got, want), (kind, n, enc)
+            assert gdone == wdone
