@@ -30,7 +30,7 @@ EXPORTS = ["gc_device_count", "gc_ctx_create", "gc_ctx_destroy", "gc_last_error_
            "gc_ctx_set_option", "gc_crc32_device", "gc_codec_grain", "gc_codec_compress_bound", "gc_host_begin", "gc_host_size", "gc_host_fetch", "gc_codec_compress_host",
            "gc_host_alloc", "gc_host_free", "gc_multi_create", "gc_multi_destroy", "gc_multi_workers", "gc_multi_last_error",
            "gc_multi_piece_bytes", "gc_multi_compress_host",
-           "gc_bra_convert_device", "gc_zstd_scan_frames", "gc_zstd_scan_prefix", "gc_zstd_decompress_device", "gc_zstd_decompress_host", "gc_zstd_decompress_timing"]
+           "gc_bra_convert_device", "gc_bra_x86_convert_device", "gc_zstd_scan_frames", "gc_zstd_scan_prefix", "gc_zstd_decompress_device", "gc_zstd_decompress_host", "gc_zstd_decompress_timing"]
 
 CODEC_ZSTD, CODEC_FLZMA2, CODEC_BROTLI = 0, 1, 2
 CODEC_IDS = {"zstd": CODEC_ZSTD, "flzma2": CODEC_FLZMA2, "brotli": CODEC_BROTLI}
@@ -152,6 +152,17 @@ def bra_convert_device(kind, src_ptr, dst_ptr, n, pc=0, encoding=True, lib_path=
     if rc != GC_OK:
         raise GpuCodecError("gc_bra_convert_device failed: %s" % _ERR.get(rc, rc))
     return done.value
+
+
+def bra_x86_convert_device(src_ptr, dst_ptr, n, pc=0, encoding=True, state=0, lib_path=None):
+    """X86 branch converter (C/Bra86.c) over n bytes at device pointers, out of place; returns (processed bytes, state out)."""
+    lib = load_library(lib_path)
+    lib.gc_bra_x86_convert_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_int, C.POINTER(C.c_uint32), C.POINTER(C.c_size_t)]
+    done = C.c_size_t(0); st = C.c_uint32(state)
+    rc = lib.gc_bra_x86_convert_device(src_ptr, dst_ptr, n, pc & 0xFFFFFFFF, 1 if encoding else 0, C.byref(st), C.byref(done))
+    if rc != GC_OK:
+        raise GpuCodecError("gc_bra_x86_convert_device failed: %s" % _ERR.get(rc, rc))
+    return done.value, st.value
 
 
 class ZstdFrame(C.Structure):

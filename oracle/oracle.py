@@ -79,6 +79,8 @@ def ref(name):
             elif name == "bra":
                 lib.ref_bra_convert.argtypes = [C.c_int, _VP, _SZ, C.c_uint, C.c_int]
                 lib.ref_bra_convert.restype = _SZ
+                lib.ref_bra_x86_convert.argtypes = [_VP, _SZ, C.c_uint, C.c_int, C.POINTER(C.c_uint)]
+                lib.ref_bra_x86_convert.restype = _SZ
             elif name == "brotli":
                 lib.ref_brotli_compress.argtypes = [_VP, _SZ, _VP, _SZ, C.c_int, C.c_int]
                 lib.ref_brotli_decompress.argtypes = [_VP, _SZ, _VP, _SZ]
@@ -156,6 +158,14 @@ def ref_bra_convert(kind, data, pc=0, encoding=True):
     view = buf[off:off + a.size]; view[:] = a
     done = ref("bra").ref_bra_convert(kind, view.ctypes.data, a.size, pc & 0xFFFFFFFF, 1 if encoding else 0)
     return view.copy(), int(done)
+
+
+def ref_bra_x86_convert(data, pc=0, encoding=True, state=0):
+    """The reference's X86 converter (C/Bra86.c), one call on a copy: (converted array, processed bytes, state out)"""
+    a = np.array(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data, dtype=np.uint8, copy=True)
+    st = C.c_uint(state)
+    done = ref("bra").ref_bra_x86_convert(a.ctypes.data if a.size else None, a.size, pc & 0xFFFFFFFF, 1 if encoding else 0, C.byref(st))
+    return a, int(done), int(st.value)
 
 
 def ref_zstd_compress_opts(data, level=3, checksum=False, streamed=False, ldm=False):

@@ -18,3 +18,12 @@ size_t ref_bra_convert(int kind, unsigned char* data, size_t n, unsigned pc, int
     }
     return (size_t)(f(data, n, pc) - data);
 }
+
+/* X86 with its state (C/Bra86.c): returns the processed byte count, *state in/out */
+size_t ref_bra_x86_convert(unsigned char* data, size_t n, unsigned pc, int encoding, unsigned* state)
+{
+    UInt32 st = *state;
+    Byte* e = encoding ? z7_BranchConvSt_X86_Enc(data, n, pc, &st) : z7_BranchConvSt_X86_Dec(data, n, pc, &st);
+    *state = st;
+    return (size_t)(e - data);
+}

@@ -99,3 +99,69 @@ def test_gpu_branch_converters_match_the_reference(pkg, O, graft, kind):
             got, gdone = _gpu_like(pkg, None, kind, x, pc, enc, to_dev=True)
             assert np.array_equal(got, want), (kind, n, enc)
             assert gdone == wdone
+
+
+# ------------------------------------------------------------------------------------------------------------------------------- X86
+def _x86_like(n, seed, dense=False):
+    """random bytes with CALL / JMP opcodes whose operands look like near offsets (top byte 00 / FF), clusters of E8 bytes, operands that contain E8"""
+    rng = np.random.default_rng(seed)
+    x = rng.integers(0, 256, size=n + 16, dtype=np.uint8)
+    k = max(1, n // (6 if dense else 40))
+    pos = rng.integers(0, max(1, n - 5), size=k)
+    x[pos] = np.where(rng.random(k) < 0.8, 0xE8, 0xE9).astype(np.uint8)
+    top = rng.random(k)
+    x[np.minimum(pos + 4, n + 8)] = np.where(top < 0.45, 0x00, np.where(top < 0.9, 0xFF, x[np.minimum(pos + 4, n + 8)])).astype(np.uint8)
+    inner = pos[rng.random(k) < 0.2]
+    x[np.minimum(inner + rng.integers(1, 4, size=inner.size), n + 8)] = 0xE8                  # an E8 inside an operand / right behind an opcode
+    if dense and n > 3000:
+        x[1000:2600] = 0xE8                                                                   # no restart point for 1.6 KB: one lane has to run through
+        x[2600:2700] = 0x00
+    return np.ascontiguousarray(x[:n])
+
+
+def _x86_gpu(pkg, lib_path, x, pc, enc, state, dev=False):
+    if not dev:
+        out = np.empty(max(1, x.size), dtype=np.uint8)
+        done, st = pkg.bra_x86_convert_device(x.ctypes.data if x.size else 0, out.ctypes.data if x.size else 0, x.size, pc, enc, state, lib_path)
+        return out[: x.size], done, st
+    import torch
+    d_in = torch.from_numpy(x).cuda() if x.size else torch.empty(1, dtype=torch.uint8, device="cuda")
+    d_out = torch.empty(max(1, x.size), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    done, st = pkg.bra_x86_convert_device(d_in.data_ptr(), d_out.data_ptr(), x.size, pc, enc, state)
+    return d_out[: x.size].cpu().numpy(), done, st
+
+
+def test_emu_x86_converter_matches_the_reference(pkg, O, emu_lib_path):
+    if O.ref("bra") is None:
+        pytest.skip("oracle/_ref not built")
+    cases = [(0, 0, 0), (4, 0, 0), (5, 0, 0), (6, 3, 1), (9, 0, 5), (511, 0, 0), (512, 0, 7), (513, 0x1000, 0), (517, 0, 2), (4096, 0xFFFFF000, 0), (70_003, 0x00401000, 4), (300_001, 0, 0)]
+    for dense in (False, True):
+        for n, pc, st in cases:
+            x = _x86_like(n, 50 + n, dense)
+            for enc in (True, False):
+                want, wdone, wst = O.ref_bra_x86_convert(x, pc, enc, st)
+                got, gdone, gst = _x86_gpu(pkg, emu_lib_path, x, pc, enc, st)
+                assert np.array_equal(got, want), (dense, n, pc, enc, st, np.nonzero(got != want)[0][:8])
+                assert (gdone, gst) == (wdone, wst), (dense, n, enc, st, gdone, wdone, gst, wst)
+            y, d1, s1 = _x86_gpu(pkg, emu_lib_path, x, pc, True, 0)
+            z, d2, s2 = _x86_gpu(pkg, emu_lib_path, y, pc, False, 0)
+            assert np.array_equal(z, x) and d1 == d2                               # encode -> decode is the identity
+    x = _x86_like(100_000, 9)
+    assert int((_x86_gpu(pkg, emu_lib_path, x, 0x400000, True, 0)[0] != x).sum()) > 1000
+
+
+@pytest.mark.gpu
+def test_gpu_x86_converter_matches_the_reference(pkg, O, graft):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    graft.build_hip()
+    for dense in (False, True):
+        for n, pc, st in ((0, 0, 0), (7, 0, 0), (100_000_003, 0x00400000, 0), (16 << 20, 0xFFFF0000, 5)):
+            x = _x86_like(n, 11 + (n & 0xFFFF), dense)
+            for enc in (True, False):
+                want, wdone, wst = O.ref_bra_x86_convert(x, pc, enc, st)
+                got, gdone, gst = _x86_gpu(pkg, None, x, pc, enc, st, dev=True)
+                assert np.array_equal(got, want), (dense, n, enc)
+                assert (gdone, gst) == (wdone, wst)

@@ -22,3 +22,16 @@ for kind in ("ARM64", "ARM", "ARMT", "PPC", "SPARC"):
     ok = bool(np.array_equal(d_out.cpu().numpy(), want))
     print("%-6s %d B: call %.3f ms = %.0f GB/s of input (%.0f GB/s read+write = %.1f %% of 8 TB/s); reference on one core %.2f GB/s; bit-exact %s"
           % (kind, n, best, n / best / 1e6, 2 * n / best / 1e6, 2 * n / best / 1e6 / 80.0, n / cpu / 1e9, ok), flush=True)
+from test_bra import _x86_like
+x = _x86_like(n, 3)
+d_in = torch.from_numpy(x).cuda(); d_out = torch.empty_like(d_in)
+torch.cuda.synchronize()
+best = 1e9
+for _ in range(5):
+    t0 = time.perf_counter()
+    done, st = pkg.bra_x86_convert_device(d_in.data_ptr(), d_out.data_ptr(), n, 0x400000, True, 0)
+    best = min(best, (time.perf_counter() - t0) * 1e3)
+t0 = time.perf_counter(); want, wdone, wst = O.ref_bra_x86_convert(x, 0x400000, True, 0); cpu = time.perf_counter() - t0
+ok = bool(np.array_equal(d_out.cpu().numpy(), want)) and (done, st) == (wdone, wst)
+print("X86    %d B: call %.3f ms = %.0f GB/s of input (copy + scan: 3 B of traffic per byte = %.1f %% of 8 TB/s); reference on one core %.2f GB/s; bit-exact %s"
+      % (n, best, n / best / 1e6, 3 * n / best / 1e6 / 80.0, n / cpu / 1e9, ok), flush=True)
