@@ -17,6 +17,7 @@
 #include "gc_7z_abi.h"
 #include "gpucodec.h"
 #include <new>
+#include <thread>
 #include <stdlib.h>
 #include <string.h>
 
@@ -82,7 +83,7 @@ class CGpuEncoder final : public ICompressCoder, public ICompressSetCoderMt, pub
     ULONG refs_ = 1;
     const int kind_;
     gc_multi* multi_ = nullptr;                       // host scheduler over every visible GPU, two contexts each (csrc/gc_multi.hip)
-    uint8_t* inBuf_ = nullptr; uint8_t* outBuf_ = nullptr; size_t inCap_ = 0, outCap_ = 0;     // pinned (gc_host_alloc)
+    uint8_t* inBuf_ = nullptr; uint8_t* inBuf2_ = nullptr; uint8_t* outBuf_ = nullptr; size_t inCap_ = 0, outCap_ = 0;     // pinned (gc_host_alloc)
     int level_;                                       // ZSTD_CLEVEL_DEFAULT 3 / FL2 default 5 (Lzma2Encoder.cpp:178-239 maps -mx to it)
     uint8_t props_[5] = { 1, 5, 3, 0, 0 };            // ZSTD: CProps{major, minor, level, reserved[2]}  ZstdEncoder.h:17-32
     uint64_t expected_ = 0;
@@ -92,7 +93,7 @@ class CGpuEncoder final : public ICompressCoder, public ICompressSetCoderMt, pub
 public:
     explicit CGpuEncoder(int kind) : kind_(kind), level_(default_level(kind)) {}
     static int default_level(int kind) { return kind == KIND_ZSTD ? 3 : (kind == KIND_FLZMA2 ? 5 : 3); }   // BrotliEncoder.h: _props._level = 3
-    ~CGpuEncoder() { if (multi_) gc_multi_destroy(multi_); gc_host_free(inBuf_); gc_host_free(outBuf_); }
+    ~CGpuEncoder() { if (multi_) gc_multi_destroy(multi_); gc_host_free(inBuf_); gc_host_free(inBuf2_); gc_host_free(outBuf_); }
 
     HRESULT QueryInterface(const GUID& iid, void** out) override
     {
@@ -157,28 +158,47 @@ public:
         const size_t piece = gc_multi_piece_bytes(codec(), level_);
         size_t batch = piece * (size_t)gc_multi_workers(multi_);
         if (expected_ && expected_ < batch) batch = (size_t)((expected_ + 131071u) & ~(uint64_t)131071u);
-        if (batch > inCap_) { gc_host_free(inBuf_); inBuf_ = (uint8_t*)gc_host_alloc(batch); inCap_ = inBuf_ ? batch : 0; if (!inBuf_) return E_OUTOFMEMORY; }
+        // two input buffers: while a helper thread compresses batch k on the GPUs and writes it out, this thread reads batch k + 1 (the host's
+        // reader also computes its CRC there), so that the slower of the two sides sets the pace, not their sum
+        if (batch > inCap_) {
+            gc_host_free(inBuf_); gc_host_free(inBuf2_);
+            inBuf_ = (uint8_t*)gc_host_alloc(batch); inBuf2_ = (uint8_t*)gc_host_alloc(batch);
+            inCap_ = inBuf_ && inBuf2_ ? batch : 0;
+            if (!inCap_) { gc_host_free(inBuf_); gc_host_free(inBuf2_); inBuf_ = inBuf2_ = nullptr; return E_OUTOFMEMORY; }
+        }
         const size_t bound = gc_codec_compress_bound(codec(), inCap_) + 1u;
         if (bound > outCap_) { gc_host_free(outBuf_); outBuf_ = (uint8_t*)gc_host_alloc(bound); outCap_ = outBuf_ ? bound : 0; if (!outBuf_) return E_OUTOFMEMORY; }
         uint64_t totalIn = 0, totalOut = 0;
-        for (;;) {
+        struct Job { std::thread th; HRESULT hr = S_OK; size_t got = 0, produced = 0; bool active = false; } job;
+        auto finish = [&]() -> HRESULT {                      // wait for the batch in flight, account for it
+            if (!job.active) return S_OK;
+            job.th.join(); job.active = false;
+            if (job.hr != S_OK) return job.hr;
+            totalIn += job.got; totalOut += job.produced;
+            return progress ? progress->SetRatioInfo(&totalIn, &totalOut) : S_OK;
+        };
+        HRESULT res = S_OK;
+        for (unsigned batchIdx = 0;; batchIdx++) {
+            uint8_t* const buf = (batchIdx & 1u) ? inBuf2_ : inBuf_;
             size_t got = inCap_;
-            HRESULT r = read_full(in, inBuf_, &got);
-            if (r != S_OK) return r;
-            if (got == 0 && (totalIn != 0 || kind_ == KIND_FLZMA2)) break;
-            size_t produced = 0;
+            HRESULT r = read_full(in, buf, &got);
+            HRESULT f = finish();
+            if (r != S_OK) { res = r; break; }
+            if (f != S_OK) { res = f; break; }
+            if (got == 0 && (batchIdx != 0 || kind_ == KIND_FLZMA2)) break;
             // FLZMA2: one end marker behind the last batch; plain brotli: stream header in the first batch, the closing meta-block behind the last
             const unsigned fl = kind_ == KIND_FLZMA2 ? GC_FLZMA2_NO_END_MARK
-                              : plainBrotli_ ? (GC_BROTLI_PLAIN | GC_BROTLI_NOT_LAST | (totalIn != 0 ? GC_BROTLI_NOT_FIRST : 0u)) : 0u;
+                              : plainBrotli_ ? (GC_BROTLI_PLAIN | GC_BROTLI_NOT_LAST | (batchIdx != 0 ? GC_BROTLI_NOT_FIRST : 0u)) : 0u;
             if (plainBrotli_ && got == 0) break;
-            const int rc = gc_multi_compress_host(multi_, codec(), inBuf_, got, outBuf_, outCap_, level_, fl, 0, &produced);
-            if (rc != GC_OK) return hresult_of(rc);
-            r = write_all(out, outBuf_, produced);
-            if (r != S_OK) return r;
-            totalIn += got; totalOut += produced;
-            if (progress) { r = progress->SetRatioInfo(&totalIn, &totalOut); if (r != S_OK) return r; }
+            job.got = got; job.produced = 0; job.hr = S_OK; job.active = true;
+            job.th = std::thread([this, buf, got, fl, out, &job]() {
+                const int rc = gc_multi_compress_host(multi_, codec(), buf, got, outBuf_, outCap_, level_, fl, 0, &job.produced);
+                job.hr = rc != GC_OK ? hresult_of(rc) : write_all(out, outBuf_, job.produced);
+            });
             if (got < inCap_) break;      // short read = end of stream
         }
+        { const HRESULT f = finish(); if (res == S_OK) res = f; }
+        if (res != S_OK) return res;
         if (plainBrotli_) {
             const uint8_t closeStream = totalIn != 0 ? 0x03 : 0x06;      // ISLAST + ISLASTEMPTY (an empty input: WBITS 16 + the same)
             HRESULT r = write_all(out, &closeStream, 1);
