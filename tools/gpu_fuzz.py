@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Round-trip fuzz of the three codecs on the GPU (or, with --lib, the emulator build): inputs stitched from random, text, runs, PCM-like and
 repeated segments of ragged lengths, random levels, sizes from a few bytes to tens of MiB; every stream must decode under the reference
-decoder.  Failing inputs are saved under gpurun_out/fuzz/.   usage: python tools/gpu_fuzz.py --seconds 60 [--max-mib 24] [--lib path]"""
+decoder.  ZSTD streams additionally go through the GPU decoder (this engine's stream and a reference-encoder stream of a random level, which must
+both give the input back), and a damaged copy of the stream must be refused or decode to the same content -- never hang or crash.  Failing inputs are saved under gpurun_out/fuzz/.   usage: python tools/gpu_fuzz.py --seconds 60 [--max-mib 24] [--lib path]"""
 import argparse, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -14,7 +15,7 @@ pkg = g.load_package(); kw = {"lib_path": a.lib} if a.lib else {"device": 0}
 rng = np.random.default_rng(a.seed)
 text = O.corpus("text-zipf", 4 << 20); lz = O.corpus("lz-7zip", 4 << 20); sil = O.corpus("silesia-like", 211_900_000)[31_785_000:31_785_000 + (4 << 20)]   # PCM-like part
 os.makedirs(os.path.join(ROOT, "gpurun_out", "fuzz"), exist_ok=True)
-t0 = time.time(); it = bad = 0; encs = {}; total = 0
+t0 = time.time(); it = bad = 0; encs = {}; total = 0; dec = pkg.ZstdDecoder(**kw); ndec = nrefused = 0
 while time.time() - t0 < a.seconds:
     target = int(min(a.max_mib * (1 << 20), 2 ** rng.uniform(3, 25)))
     parts, n = [], 0
@@ -40,9 +41,23 @@ while time.time() - t0 < a.seconds:
         y = e.code(x)
         z = O.ref_zstd_decompress(y, n) if codec == "zstd" else O.ref_lzma2_decode(y, n, e.coder_props()[0]) if codec == "flzma2" else O.ref_brotlimt_decompress(y, n, 8)
         ok = np.array_equal(np.asarray(z), x)
+        if ok and codec == "zstd":
+            ok = np.array_equal(dec.code(y, capacity=n + 64), x)
+            if ok and n <= (8 << 20):
+                opts = dict(checksum=bool(rng.integers(0, 2)), streamed=bool(rng.integers(0, 2)), ldm=bool(rng.integers(0, 4) == 0))
+                r = O.ref_zstd_compress_opts(x.tobytes(), int(rng.choice([1, 2, 3, 5, 8, 13, 17, 19, 22])) if n <= (1 << 20) else int(rng.choice([1, 3, 5])), **opts)
+                ok = np.array_equal(dec.code(r, capacity=n + 64), x)
+                ndec += 1
+                if ok and r.size > 12:
+                    badr = r.copy(); badr[int(rng.integers(4, r.size))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+                    try:
+                        w = dec.code(badr, capacity=n + 64)
+                        ok = (not opts["checksum"]) or np.array_equal(w, x)     # without a checksum a flip may go unnoticed by the format
+                    except pkg.GpuCodecError:
+                        nrefused += 1
     except Exception as ex:
         ok = False; print("EXC", codec, level, n, repr(ex)[:200], flush=True)
     if not ok:
         bad += 1; print("FAIL", codec, level, n, flush=True); np.save(os.path.join(ROOT, "gpurun_out", "fuzz", "fail_%s_%d_%d.npy" % (codec, level, n)), x)
     it += 1; total += n
-print("iterations", it, "bytes", total, "failures", bad)
+print("iterations", it, "bytes", total, "failures", bad, "| reference streams through the GPU decoder", ndec, "damaged copies refused", nrefused)
