@@ -639,7 +639,7 @@ gc_zstd_dec_seq_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
             if (!last) err = 1; else off = (int32_t)((n - 1u) * 8u + gc_hibit32(last));
         }
         const uint32_t llLog = sV[5 + ZT_LL], ofLog = sV[5 + ZT_OF], mlLog = sV[5 + ZT_ML];
-        uint32_t stLL = 0, stOF = 0, stML = 0, j = 0;
+        uint32_t st = 0, j = 0;                               // st: the FSE state of my table (lanes 0..2)
         GcU4* const seq = seqWork + fr.seqBase + e.seqOff;
         bool first = true;
         while (!err) {
@@ -656,35 +656,40 @@ gc_zstd_dec_seq_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
                 __builtin_memcpy(sBuf + 16u + i, &v, 8);
             }
             gc_wave_sync();
-            if (lane == 0u) {
+            {
 #define ZD_RD64(p) (gc_ld64(sBuf + (((uint32_t)((p) + 128) >> 3) - cLo)) >> ((uint32_t)(p) & 7u))
 #define ZD_RD32(p) (gc_ld32(sBuf + (((uint32_t)((p) + 128) >> 3) - cLo)) >> ((uint32_t)(p) & 7u))
+                // Three lanes decode: lane 0 owns the literal-length state, lane 1 the match-length state, lane 2 the offset state (the other
+                // lanes run along idle).  One table read, one read of the symbol's extra bits and one of the state bits serve all three; what
+                // the three have to know of each other -- the bit counts, then the three values -- travels through v_readlane into scalar
+                // registers, where the bit positions, the repeat-offset rules and the checks are computed once per wave.
+                const uint32_t* const myTab = lane == 1u ? sML : (lane == 2u ? sOF : sLL);
+                const uint32_t* const myBase = lane == 1u ? sK.mlBase : sK.llBase;
                 if (first) {
                     const int32_t p1 = off - (int32_t)llLog, p2 = p1 - (int32_t)ofLog, p3 = p2 - (int32_t)mlLog;
                     if (p3 < 0) err = 1;
                     else {
-                        stLL = ZD_RD32(p1) & ((1u << llLog) - 1u); stOF = ZD_RD32(p2) & ((1u << ofLog) - 1u); stML = ZD_RD32(p3) & ((1u << mlLog) - 1u);
+                        const int32_t pm = lane == 0u ? p1 : (lane == 2u ? p2 : p3);
+                        const uint32_t lg = lane == 0u ? llLog : (lane == 2u ? ofLog : mlLog);
+                        st = lane < 3u ? ZD_RD32(pm) & ((1u << lg) - 1u) : 0u;
                         off = p3;
                     }
                 }
-                // One step per sequence.  Every bit position of the step follows from the three table entries, so the six reads go out
-                // together; the repeat-offset rules are selects, the checks one flag.
                 while (!err && j < nSeq && (cLo == 0u || ((uint32_t)off >> 3) >= cLo + 16u)) {
-                    const uint32_t eLL = sLL[stLL], eOF = sOF[stOF], eML = sML[stML];
+                    const uint32_t en = myTab[st];
                     const uint32_t more = j + 1u < nSeq ? 15u : 0u;              // the last sequence does not move the states on
-                    const uint32_t ofb = (eOF >> 14) & 31u, mlb = (eML >> 14) & 31u, llb = (eLL >> 14) & 31u;
-                    const uint32_t nl = (eLL >> 10) & more, nm = (eML >> 10) & more, no = (eOF >> 10) & more;
-                    const int32_t p1 = off - (int32_t)ofb, p2 = p1 - (int32_t)mlb, p3 = p2 - (int32_t)llb;
-                    const int32_t p4 = p3 - (int32_t)nl, p5 = p4 - (int32_t)nm, p6 = p5 - (int32_t)no;
-                    const uint64_t w1 = ZD_RD64(p1);
-                    const uint32_t w2 = ZD_RD32(p2), w3 = ZD_RD32(p3), w4 = ZD_RD32(p4), w5 = ZD_RD32(p5), w6 = ZD_RD32(p6);
-                    const uint32_t mlBase = sK.mlBase[eML >> 19], llBase = sK.llBase[eLL >> 19];
-                    const uint32_t ofv = (1u << ofb) + ((uint32_t)w1 & ((1u << ofb) - 1u));
-                    const uint32_t ml = mlBase + (w2 & ((1u << mlb) - 1u));
-                    const uint32_t ll = llBase + (w3 & ((1u << llb) - 1u));
-                    stLL = (eLL & 0x3FFu) + (w4 & ((1u << nl) - 1u));
-                    stML = (eML & 0x3FFu) + (w5 & ((1u << nm) - 1u));
-                    stOF = (eOF & 0x3FFu) + (w6 & ((1u << no) - 1u));
+                    const uint32_t eb = (en >> 14) & 31u, nb = (en >> 10) & more;
+                    const uint32_t llb = gc_readlane(eb, 0), mlb = gc_readlane(eb, 1), ofb = gc_readlane(eb, 2);
+                    const uint32_t nl = gc_readlane(nb, 0), nm = gc_readlane(nb, 1), no = gc_readlane(nb, 2);
+                    const int32_t p1 = off - (int32_t)ofb, p2 = p1 - (int32_t)mlb, p3 = p2 - (int32_t)llb;      // extra bits: offset, match length, literal length
+                    const int32_t p4 = p3 - (int32_t)nl, p5 = p4 - (int32_t)nm, p6 = p5 - (int32_t)no;          // state bits: literal length, match length, offset
+                    const int32_t pe = lane == 0u ? p3 : (lane == 1u ? p2 : p1), ps = lane == 0u ? p4 : (lane == 1u ? p5 : p6);
+                    const uint64_t we = ZD_RD64(pe);
+                    const uint32_t ws = ZD_RD32(ps);
+                    const uint32_t base = lane == 2u ? 1u << eb : myBase[lane < 2u ? en >> 19 : 0u];
+                    const uint32_t val = base + ((uint32_t)we & ((1u << eb) - 1u));
+                    st = lane < 3u ? (en & 0x3FFu) + (ws & ((1u << nb) - 1u)) : 0u;
+                    const uint32_t ll = gc_readlane(val, 0), ml = gc_readlane(val, 1), ofv = gc_readlane(val, 2);
                     off = p6;
                     // offset value 1..3 = one of the three last offsets (shifted by one when the sequence has no literals; "4" = the first minus 1)
                     const bool isRep = ofv <= 3u;
@@ -698,15 +703,13 @@ gc_zstd_dec_seq_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
                     const bool bad = off < 0 || o == 0u || lpos + ll > e.regen || dpos + ll + ml > GC_ZSTD_BLOCK_MAX;
                     if (ofb > 30u) { err = GC_ZD_UNSUPPORTED; break; }
                     if (bad) { err = 1; break; }
-                    GcU4 rec; rec.x = ll | (ml << 18); rec.y = (ml >> 14) | (lpos << 4); rec.z = o; rec.w = dpos;
-                    seq[j] = rec;
+                    if (lane == 0u) { GcU4 rec; rec.x = ll | (ml << 18); rec.y = (ml >> 14) | (lpos << 4); rec.z = o; rec.w = dpos; seq[j] = rec; }
                     dpos += ll + ml; lpos += ll; j++;
                 }
 #undef ZD_RD64
 #undef ZD_RD32
             }
             first = false;
-            j = __shfl(j, 0); off = __shfl(off, 0); err = __shfl(err, 0);
             if (j >= nSeq) break;
         }
         if (!err && off != 0) err = 1;

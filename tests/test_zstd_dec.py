@@ -48,13 +48,13 @@ def gpu_dec(pkg, graft):
 
 @pytest.mark.parametrize("kind", KINDS)
 def test_emu_reference_streams(O, emu_dec, kind):
-    for n, level in ((0, 3), (1, 3), (5000, 1), (131072, 3), (131073, 6), (400_000, 19), (300_000, 22)):
+    for n, level in ((0, 3), (1, 3), (5000, 1), (131072, 3), (131073, 6), (300_000, 19), (200_000, 22)):
         x = _corpus(O, kind, n)
         _check(emu_dec, O.ref_zstd_compress(x.tobytes(), level), x.tobytes())
 
 
 def test_emu_reference_frame_options(O, emu_dec):
-    x = _corpus(O, "silesia-like", 700_000)
+    x = _corpus(O, "silesia-like", 400_000)
     for kw in (dict(checksum=True), dict(streamed=True), dict(checksum=True, streamed=True), dict(ldm=True, checksum=True)):
         for level in (1, 5, 17):
             _check(emu_dec, O.ref_zstd_compress_opts(x.tobytes(), level, **kw), x.tobytes())
@@ -81,10 +81,10 @@ def test_emu_concatenated_and_skippable_frames(O, emu_dec):
         emu_dec.code(mixed, capacity=len(x) - 1)                               # destination too small
 
 
-@pytest.mark.parametrize("level", [1, 3, 12, 19])
+@pytest.mark.parametrize("level", [1, 3, 19])
 def test_emu_own_encoder_roundtrip(pkg, O, emu_lib_path, emu_dec, level, monkeypatch):
     monkeypatch.setenv("GC_FRAME_BLOCKS", "2")                                 # frames of 256 KiB so that a small input carries several
-    x = _corpus(O, "silesia-like", 900_000)
+    x = _corpus(O, "silesia-like", 600_000)
     enc = pkg.ZstdEncoder(lib_path=emu_lib_path, level=level)
     try:
         comp = enc.code(x)
@@ -93,7 +93,7 @@ def test_emu_own_encoder_roundtrip(pkg, O, emu_lib_path, emu_dec, level, monkeyp
     finally:
         enc.close()
     frames, n, total = emu_dec.scan(comp)
-    assert total == x.size and n >= (1 if level <= 2 else 3)
+    assert total == x.size and n >= (1 if level <= 2 else 2)
     _check(emu_dec, comp, x.tobytes())
     _check(emu_dec, comp2, x.tobytes())                                        # the seek table is a skippable frame
 
