@@ -140,7 +140,7 @@ def load_library(path=None):
     return lib
 
 
-BRA_KINDS = {"ARM64": 0, "ARM": 1, "ARMT": 2, "PPC": 3, "SPARC": 4}
+BRA_KINDS = {"ARM64": 0, "ARM": 1, "ARMT": 2, "PPC": 3, "SPARC": 4, "IA64": 5, "RISCV": 6}
 
 
 def bra_convert_device(kind, src_ptr, dst_ptr, n, pc=0, encoding=True, lib_path=None):

@@ -5,7 +5,7 @@
 // The five converters built here are the ones whose decision is local: ARM64 (BL and ADRP), ARM (BL), PPC (bl), SPARC (call) look at one
 // aligned 4-byte word (C/Bra.c:75-257); ARMT (Thumb BL) looks at a pair of 16-bit units, and since the second unit of a pair (top bits 11111) can
 // never be the first unit of one (11110), pairs never overlap and every pair is decided on its own as well (C/Bra.c:260-340).  One thread per
-// 16 bytes, one 16-byte load and one 16-byte store: 2 bytes of HBM traffic per byte, which is the algorithmic minimum.  IA64 and RISCV are not built.
+// 16 bytes, one 16-byte load and one 16-byte store: 2 bytes of HBM traffic per byte, which is the algorithmic minimum.  IA64 decides per 16-byte bundle (one thread each).
 //
 // X86 (C/Bra86.c, "BCJ") is a state machine: whether an E8 / E9 byte is taken as CALL / JMP depends on the E8 / E9 bytes among the three bytes in
 // front of it (the mask) and on whether it lies inside the operand of a converted instruction (those four bytes are skipped).  It is made parallel
@@ -25,6 +25,8 @@
 #include <hip/hip_runtime.h>
 #define GC_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
 #endif
+
+#define BRA86_CHUNK 512u           // bytes per lane of the two converters that run a state machine (X86, RISCV)
 
 __device__ __forceinline__ uint32_t bra_bswap(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xFF00u) | ((v << 8) & 0xFF0000u) | (v << 24); }
 
@@ -81,6 +83,36 @@ gc_bra_kernel(const uint8_t* __restrict__ src, uint8_t* dst, uint64_t n, uint32_
     const uint64_t o = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * 16u;
     if (o >= n) return;
     const bool enc = encoding != 0u;
+    if (kind == GC_BRA_IA64) {
+        // one 16-byte bundle: the template (low 5 bits) says which of the three 41-bit slots hold branch instructions (C/Bra.c:343-420)
+        if (o + 16u > (n & ~15ull)) { for (uint64_t b = o; b < n && b < o + 16u; b++) dst[b] = src[b]; return; }
+        uint8_t q[20];
+        { GcU4 v; __builtin_memcpy(&v, src + o, 16); __builtin_memcpy(q, &v, 16); q[16] = q[17] = q[18] = q[19] = 0; }
+        uint32_t m = (0x334b0000u >> (q[0] & 0x1eu)) & 3u;
+        if (m) {
+            const uint32_t pcv = ((pc - 16u) >> 3) + 2u * (uint32_t)(o >> 4) + 2u;
+            uint32_t at = 5u * m - 4u;                               // byte offset of the slot's first byte inside the bundle
+            do {
+                const uint32_t t = (uint32_t)q[at] | ((uint32_t)q[at + 1u] << 8);
+                uint32_t z = ((uint32_t)q[at + 1u] | ((uint32_t)q[at + 2u] << 8) | ((uint32_t)q[at + 3u] << 16) | ((uint32_t)q[at + 4u] << 24)) >> m;
+                if (((t >> m) & (0x70u << 1)) == 0u && ((z - (0x5000000u << 1)) & (0xf000000u << 1)) == 0u) {
+                    uint32_t v = ((0x8fffffu << 1) | 1u) & z;
+                    z ^= v;
+                    const uint32_t low = (0x1fffffu << 1) | 1u;
+                    v = enc ? v + (pcv & low) : v - (pcv | ~low);
+                    v &= ~(0x600000u << 1);
+                    v += 0x700000u << 1;
+                    v &= (0x8fffffu << 1) | 1u;
+                    z |= v;
+                    z <<= m;
+                    q[at + 1u] = (uint8_t)z; q[at + 2u] = (uint8_t)(z >> 8); q[at + 3u] = (uint8_t)(z >> 16); q[at + 4u] = (uint8_t)(z >> 24);
+                }
+                at += 5u; m++;
+            } while (m &= 3u);
+        }
+        { GcU4 v; __builtin_memcpy(&v, q, 16); __builtin_memcpy(dst + o, &v, 16); }
+        return;
+    }
     if (kind != GC_BRA_ARMT) {
         const uint64_t lim = n & ~3ull;
         if (o + 16u <= lim) {
@@ -144,10 +176,157 @@ gc_bra_kernel(const uint8_t* __restrict__ src, uint8_t* dst, uint64_t n, uint32_
     }
 }
 
+
+// ---------------------------------------------------------------- RISCV ----------------------------------------------------------------
+// C/Bra.c:428-709.  JAL and AUIPC(+ the instruction behind it) at 2-byte granularity; after a candidate the scan goes on 2, 4, 6 or 8 bytes
+// further, so whether a 16-bit unit is looked at depends on what came before -- the same situation as X86, solved the same way: a candidate
+// unit with no candidate among the three units in front of it is reached by every history (restart point); lanes of 512 bytes start at
+// their first restart point and run the reference's loop, restated, to the next lane's; decisions read the source, conversions go to a copy.
+__device__ __forceinline__ bool rv_is(uint32_t hw) { return ((((hw) ^ 0x10u) + 1u) & 0x77u) == 0u; }
+__device__ __forceinline__ uint32_t rv_ld16(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+__device__ __forceinline__ void rv_st32(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+#define RV_REG_VAL (2u << 7)
+#define RV_CMD_VAL 3u
+#define RV_CHECK_1(v, b) (((((b) - RV_CMD_VAL) ^ ((v) << 8)) & (0xf8000u + RV_CMD_VAL)) == 0u)
+#define RV_CHECK_2(v, r) ((((v) - ((RV_CMD_VAL << 12) | RV_REG_VAL | 8u)) << 18) < ((r) & 0x1du))
+
+// from position p (a candidate unit when atCand) to the end or to the first restart candidate >= stopFrom; true = reached the end, *outP = the reference's return value
+__device__ bool rv_run(const uint8_t* __restrict__ src, uint8_t* dst, uint64_t n, uint32_t pc, bool enc, uint64_t p, bool atCand, uint64_t stopFrom, uint64_t* outP)
+{
+    const uint64_t lim = (n & ~1ull) - 6u;
+    for (;;) {
+        uint32_t a = 0;
+        if (atCand) { a = (rv_ld16(src + p) ^ 0x10u) + 1u; atCand = false; }
+        else {
+            bool found = false;
+            for (;;) {
+                if (p >= lim) { *outP = p; return true; }
+                a = (rv_ld16(src + p) ^ 0x10u) + 1u;
+                if ((a & 0x77u) == 0u) { found = true; break; }
+                a = (rv_ld16(src + p + 2u) ^ 0x10u) + 1u;
+                p += 4u;
+                if ((a & 0x77u) == 0u) { p -= 2u; if (p >= lim) { *outP = p; return true; } found = true; break; }
+            }
+            (void)found;
+            if (p >= stopFrom && p >= 6u && !rv_is(rv_ld16(src + p - 2u)) && !rv_is(rv_ld16(src + p - 4u)) && !rv_is(rv_ld16(src + p - 6u))) return false;   // the next lane's start
+        }
+        const uint32_t pcAt = pc + (uint32_t)p;
+        uint32_t v = a;
+        a = gc_ld32(src + p);
+        if (enc) {
+            if ((v & 8u) == 0u) {                                   // JAL
+                if ((v - 0x100u) & 0xd80u) { p += 2u; continue; }
+                v = ((a & (1u << 31)) >> 11) | ((a & (0x3ffu << 21)) >> 20) | ((a & (1u << 20)) >> 9) | (a & (0xffu << 12));
+                v += pcAt;
+                dst[p + 1u] = (uint8_t)(((v >> 13) & 0xf0u) | ((a >> 8) & 0xfu));
+                dst[p + 2u] = (uint8_t)(v >> 9);
+                dst[p + 3u] = (uint8_t)(v >> 1);
+                p += 4u; continue;
+            }
+            if (v & 0xe80u) {                                       // AUIPC, rd neither x0 nor x2
+                const uint32_t b = gc_ld32(src + p + 4u);
+                if (RV_CHECK_1(v, b)) {
+                    rv_st32(dst + p, (b << 12) | (0x17u + RV_REG_VAL));
+                    a &= 0xfffff000u;
+                    a += (uint32_t)((int32_t)b >> 20);
+                    a += pcAt;
+                    rv_st32(dst + p + 4u, bra_bswap(a));
+                    p += 8u;
+                } else p += 6u;
+            } else {
+                uint32_t r = a >> 27;
+                if (RV_CHECK_2(v, r)) {
+                    v = gc_ld32(src + p + 4u);
+                    r = (r << 7) + 0x17u + (v & 0xfffff000u);
+                    a = (a >> 12) | (v << 20);
+                    rv_st32(dst + p, r); rv_st32(dst + p + 4u, a);
+                    p += 8u;
+                } else p += 4u;
+            }
+        } else {
+            if ((v & 8u) == 0u) {                                   // JAL (v holds the transformed low 16 bits)
+                uint32_t t = v - 0x100u + 0x7fu;
+                if (t & 0xd80u) { p += 2u; continue; }
+                const uint32_t a_old = (t + (0xefu - 0x7fu)) & 0xfffu;
+                uint32_t x = ((uint32_t)src[p + 3u] << 1) | ((uint32_t)src[p + 2u] << 9) | ((t & 0xf000u) << 5);
+                x -= pcAt;
+                const uint32_t w = a_old | ((x << 11) & (1u << 31)) | ((x << 20) & (0x3ffu << 21)) | ((x << 9) & (1u << 20)) | (x & (0xffu << 12));
+                rv_st32(dst + p, w);
+                p += 4u; continue;
+            }
+            if ((v & 0xe80u) == 0u) {                               // x0 / x2
+                const uint32_t r = a >> 27;
+                if (RV_CHECK_2(v, r)) {
+                    uint32_t b = bra_bswap(gc_ld32(src + p + 4u));
+                    uint32_t x = a >> 12;
+                    b -= pcAt;
+                    uint32_t w = (r << 7) + 0x17u;
+                    w += (b + 0x800u) & 0xfffff000u;
+                    x |= b << 20;
+                    rv_st32(dst + p, w); rv_st32(dst + p + 4u, x);
+                    p += 8u;
+                } else p += 4u;
+            } else {
+                const uint32_t b = gc_ld32(src + p + 4u);
+                if (!RV_CHECK_1(v, b)) p += 6u;
+                else {
+                    const uint32_t x = (a & 0xfffff000u) | (b >> 20);
+                    const uint32_t w = (b << 12) | (0x17u + RV_REG_VAL);
+                    rv_st32(dst + p, w); rv_st32(dst + p + 4u, x);
+                    p += 8u;
+                }
+            }
+        }
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+gc_bra_riscv_kernel(const uint8_t* __restrict__ src, uint8_t* dst, uint64_t n, uint32_t pc, uint32_t encoding, uint64_t* result)
+{
+    const uint64_t lane = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    const uint64_t lim = (n & ~1ull) - 6u, c0 = lane * BRA86_CHUNK, c1 = c0 + BRA86_CHUNK;
+    if (c0 >= lim) return;
+    uint64_t p = 0; bool atCand = false;
+    if (lane) {
+        const uint64_t hi = c1 < lim ? c1 : lim;
+        uint64_t c = c0 < 6u ? 6u : c0;
+        uint32_t quiet = 0;                                  // non-candidate units in a row in front of c
+        for (uint64_t k = c - 6u; k < c; k += 2u) quiet = rv_is(rv_ld16(src + k)) ? 0u : quiet + 1u;
+        bool found = false;
+        for (; c < hi; c += 2u) {
+            const bool is = rv_is(rv_ld16(src + c));
+            if (is && quiet >= 3u) { found = true; break; }
+            quiet = is ? 0u : quiet + 1u;
+        }
+        if (!found) return;
+        p = c; atCand = true;
+    }
+    uint64_t outP = 0;
+    if (rv_run(src, dst, n, pc, encoding != 0u, p, atCand, c1, &outP)) result[0] = outP;
+}
+
+static int bra_riscv(const void* d_src, void* d_dst, size_t n, uint32_t pc, int encoding, size_t* processed)
+{
+    if (processed) *processed = 0;
+    if (!n) return GC_OK;
+    if (hipMemcpy(d_dst, d_src, n, hipMemcpyDeviceToDevice) != hipSuccess) return GC_ERR_HIP;
+    if ((n & ~(size_t)1) <= 6u) return GC_OK;
+    uint64_t* dRes = nullptr; uint64_t res = 0;
+    if (hipMalloc((void**)&dRes, 8) != hipSuccess) return GC_ERR_NOMEM;
+    const uint64_t lanes = (((uint64_t)n & ~1ull) - 6u + BRA86_CHUNK - 1u) / BRA86_CHUNK;
+    GC_LAUNCH(gc_bra_riscv_kernel, (uint32_t)((lanes + 255u) / 256u), 256, (hipStream_t)0, (const uint8_t*)d_src, (uint8_t*)d_dst, (uint64_t)n, pc, (uint32_t)(encoding != 0), dRes);
+    const bool ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(&res, dRes, 8, hipMemcpyDeviceToHost) == hipSuccess;
+    hipFree(dRes);
+    if (!ok) return GC_ERR_HIP;
+    if (processed) *processed = (size_t)res;
+    return GC_OK;
+}
+
 extern "C" int gc_bra_convert_device(int kind, const void* d_src, void* d_dst, size_t n, uint32_t pc, int encoding, size_t* processed)
 {
-    if (kind < GC_BRA_ARM64 || kind > GC_BRA_SPARC || (!d_src && n) || (!d_dst && n)) return GC_ERR_PARAM;
-    if (kind == GC_BRA_ARMT && d_src == d_dst && n) return GC_ERR_PARAM;          // a Thumb pair can straddle two threads' chunks: out of place only
+    if (kind < GC_BRA_ARM64 || kind > GC_BRA_RISCV || (!d_src && n) || (!d_dst && n)) return GC_ERR_PARAM;
+    if ((kind == GC_BRA_ARMT || kind == GC_BRA_RISCV) && d_src == d_dst && n) return GC_ERR_PARAM;          // a Thumb pair can straddle two threads' chunks: out of place only
+    if (kind == GC_BRA_RISCV) return bra_riscv(d_src, d_dst, n, pc, encoding, processed);
     if (processed) *processed = 0;
     if (!n) return GC_OK;
     uint32_t* dFlag = nullptr;
@@ -165,13 +344,12 @@ extern "C" int gc_bra_convert_device(int kind, const void* d_src, void* d_dst, s
     if (processed) {
         // what the reference's converter returns for one call on the whole buffer (the tail it leaves to the next call)
         if (kind == GC_BRA_ARMT) { const size_t sz = n & ~(size_t)1; *processed = sz <= 2u ? 0u : (flag ? sz : sz - 2u); }
-        else *processed = n & ~(size_t)3;
+        else *processed = kind == GC_BRA_IA64 ? n & ~(size_t)15 : n & ~(size_t)3;
     }
     return GC_OK;
 }
 
 // ---------------------------------------------------------------- X86 ----------------------------------------------------------------
-#define BRA86_CHUNK 512u
 __device__ __forceinline__ bool bra86_is(uint32_t b) { return (b & 0xFEu) == 0xE8u; }
 __device__ __forceinline__ bool bra86_ms(uint32_t b) { return (((b) + 1u) & 0xFEu) == 0u; }        // 0x00 or 0xFF (BR86_NEED_CONV_FOR_MS_BYTE)
 // no E8 / E9 among the 7 bytes in front of position c (c >= 7)

@@ -175,12 +175,14 @@ int         gc_crc32_device(const void* d_src, size_t n, uint32_t* crc);
  * z7_BranchConv_ARM64_Enc / _Dec ... of C/Bra.c:75-340, called from NCompress::NBranch::CCoder::Filter, CPP/7zip/Compress/BranchMisc.cpp:21-26).
  * pc = virtual address of byte 0 (the filters' kBranchOffset property); encoding != 0 converts relative -> absolute.  d_dst may equal d_src
  * except for GC_BRA_ARMT.  *processed = the byte count the reference's converter reports for one call on the whole buffer (bytes behind it are
- * copied unchanged).  IA64 and RISCV are not provided.  Synchronous on the default stream. */
+ * copied unchanged).  Synchronous on the default stream. */
 #define GC_BRA_ARM64 0
 #define GC_BRA_ARM   1
 #define GC_BRA_ARMT  2
 #define GC_BRA_PPC   3
 #define GC_BRA_SPARC 4
+#define GC_BRA_IA64  5
+#define GC_BRA_RISCV 6      /* out of place only, like GC_BRA_ARMT */
 int         gc_bra_convert_device(int kind, const void* d_src, void* d_dst, size_t n, uint32_t pc, int encoding, size_t* processed);
 /* The X86 converter ("BCJ": z7_BranchConvSt_X86_Enc / _Dec, C/Bra86.c:49-186): *state goes in and out as with the reference (0 at the start of a
  * stream, Z7_BRANCH_CONV_ST_X86_STATE_INIT_VAL); out of place only.  Converted bytes, *processed and *state equal the reference's for one call. */

@@ -4,7 +4,7 @@
 #include <stddef.h>
 #include "Bra.h"
 
-/* kind: 0 ARM64, 1 ARM, 2 ARMT, 3 PPC, 4 SPARC; returns the processed byte count */
+/* kind: 0 ARM64, 1 ARM, 2 ARMT, 3 PPC, 4 SPARC, 5 IA64, 6 RISCV; returns the processed byte count */
 size_t ref_bra_convert(int kind, unsigned char* data, size_t n, unsigned pc, int encoding)
 {
     z7_Func_BranchConv f = 0;
@@ -14,6 +14,8 @@ size_t ref_bra_convert(int kind, unsigned char* data, size_t n, unsigned pc, int
         case 2: f = encoding ? z7_BranchConv_ARMT_Enc : z7_BranchConv_ARMT_Dec; break;
         case 3: f = encoding ? z7_BranchConv_PPC_Enc : z7_BranchConv_PPC_Dec; break;
         case 4: f = encoding ? z7_BranchConv_SPARC_Enc : z7_BranchConv_SPARC_Dec; break;
+        case 5: f = encoding ? z7_BranchConv_IA64_Enc : z7_BranchConv_IA64_Dec; break;
+        case 6: f = encoding ? z7_BranchConv_RISCV_Enc : z7_BranchConv_RISCV_Dec; break;
         default: return (size_t)-1;
     }
     return (size_t)(f(data, n, pc) - data);

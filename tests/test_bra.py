@@ -3,8 +3,8 @@ on instruction-like data for ARM64 / ARM / ARMT / PPC / SPARC, ragged sizes, una
 import numpy as np
 import pytest
 
-KINDS = ["ARM64", "ARM", "ARMT", "PPC", "SPARC"]
-KID = {"ARM64": 0, "ARM": 1, "ARMT": 2, "PPC": 3, "SPARC": 4}
+KINDS = ["ARM64", "ARM", "ARMT", "PPC", "SPARC", "IA64", "RISCV"]
+KID = {"ARM64": 0, "ARM": 1, "ARMT": 2, "PPC": 3, "SPARC": 4, "IA64": 5, "RISCV": 6}
 
 
 def _code_like(kind, n, seed):
@@ -32,6 +32,30 @@ def _code_like(kind, n, seed):
         sel = (m >= 0.3) & (m < 0.6)
         b[sel] = 0x7FC00000 | (b[sel] & 0x003FFFFF)
         w[:] = b.byteswap()
+    elif kind == "IA64":
+        b = x[: (n // 16) * 16].reshape(-1, 16)
+        sel = rng.random(b.shape[0]) < 0.7
+        b[sel, 0] = (b[sel, 0] & 0xE0) | rng.choice([0x10, 0x11, 0x12, 0x13, 0x16, 0x17, 0x18, 0x19, 0x1C, 0x1D], size=int(sel.sum())).astype(np.uint8)   # templates with branch slots
+        for at in (1, 6, 11):                                                                  # opcode 4 / 5 in many slots, the tested bits cleared
+            s2 = rng.random(b.shape[0]) < 0.5
+            b[s2, at + 4] = (b[s2, at + 4] & 0x01) | rng.choice([0x28, 0x2A, 0x50, 0x54, 0xA0, 0xA8], size=int(s2.sum())).astype(np.uint8)
+            b[s2, at] &= 0x07; b[s2, at + 1] &= 0xF8
+    elif kind == "RISCV":
+        h = x[: (n // 2) * 2].view("<u2")
+        m2 = rng.random(h.size)
+        j = np.nonzero(m2 < 0.10)[0]
+        h[j] = (h[j] & 0xF000) | rng.choice([0x0EF, 0x06F, 0x2EF, 0x0EF], size=j.size).astype(np.uint16)          # JAL ra / x0 / x5
+        a_ = np.nonzero((m2 >= 0.10) & (m2 < 0.25))[0]
+        a_ = a_[a_ + 3 < h.size]
+        rd = rng.integers(0, 32, size=a_.size).astype(np.uint32)
+        rd[rng.random(a_.size) < 0.3] = 2                                                      # AUIPC x2: the converter's escape form
+        h[a_] = ((h[a_].astype(np.uint32) & 0xF000) | (rd << 7) | 0x17).astype(np.uint16)
+        same = rng.random(a_.size) < 0.7                                                       # the instruction behind it uses the same register
+        lo = ((rng.integers(0, 2, size=a_.size).astype(np.uint32) << 15) | (rng.integers(0, 8, size=a_.size).astype(np.uint32) << 12) | (rng.integers(0, 32, size=a_.size).astype(np.uint32) << 7) | rng.choice([0x67, 0x03, 0x13, 0x23], size=a_.size).astype(np.uint32))
+        hi = h[a_ + 3].astype(np.uint32)
+        hi = np.where(same, (hi & 0xFFF0) | (rd >> 1), hi)
+        lo = np.where(same, (lo & 0x7FFF) | ((rd & 1) << 15), lo)
+        h[a_ + 2] = lo.astype(np.uint16); h[a_ + 3] = hi.astype(np.uint16)
     else:                                                                                      # Thumb: F000..F7FF followed by F800..FFFF, and lone halves
         h = x[: (n // 2) * 2].view("<u2")
         m2 = rng.random(h.size)
@@ -81,8 +105,9 @@ def test_emu_in_place_and_parameter_checks(pkg, O, emu_lib_path):
     pkg.bra_convert_device("ARM64", y.ctypes.data, y.ctypes.data, y.size, 0x8000, True, emu_lib_path)       # in place is allowed for the word converters
     if O.ref("bra") is not None:
         assert np.array_equal(y, O.ref_bra_convert(0, x, 0x8000, True)[0])
-    with pytest.raises(pkg.GpuCodecError):
-        pkg.bra_convert_device("ARMT", y.ctypes.data, y.ctypes.data, y.size, 0, True, emu_lib_path)
+    for k in ("ARMT", "RISCV"):
+        with pytest.raises(pkg.GpuCodecError):
+            pkg.bra_convert_device(k, y.ctypes.data, y.ctypes.data, y.size, 0, True, emu_lib_path)
 
 
 @pytest.mark.gpu

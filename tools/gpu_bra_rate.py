@@ -8,7 +8,7 @@ pkg = g.load_package()
 import oracle as O
 from test_bra import _code_like, KID
 n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1 << 30
-for kind in ("ARM64", "ARM", "ARMT", "PPC", "SPARC"):
+for kind in ("ARM64", "ARM", "ARMT", "PPC", "SPARC", "IA64", "RISCV"):
     x = _code_like(kind, n, 3)
     d_in = torch.from_numpy(x).cuda(); d_out = torch.empty_like(d_in)
     torch.cuda.synchronize()
