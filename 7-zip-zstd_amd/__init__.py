@@ -30,7 +30,7 @@ EXPORTS = ["gc_device_count", "gc_ctx_create", "gc_ctx_destroy", "gc_last_error_
            "gc_ctx_set_option", "gc_crc32_device", "gc_codec_grain", "gc_codec_compress_bound", "gc_host_begin", "gc_host_size", "gc_host_fetch", "gc_codec_compress_host",
            "gc_host_alloc", "gc_host_free", "gc_multi_create", "gc_multi_destroy", "gc_multi_workers", "gc_multi_last_error",
            "gc_multi_piece_bytes", "gc_multi_compress_host",
-           "gc_bra_convert_device", "gc_bra_x86_convert_device", "gc_zstd_scan_frames", "gc_zstd_scan_prefix", "gc_zstd_decompress_device", "gc_zstd_decompress_host", "gc_zstd_decompress_timing"]
+           "gc_bra_convert_device", "gc_bra_x86_convert_device", "gc_delta_convert_device", "gc_zstd_scan_frames", "gc_zstd_scan_prefix", "gc_zstd_decompress_device", "gc_zstd_decompress_host", "gc_zstd_decompress_timing"]
 
 CODEC_ZSTD, CODEC_FLZMA2, CODEC_BROTLI = 0, 1, 2
 CODEC_IDS = {"zstd": CODEC_ZSTD, "flzma2": CODEC_FLZMA2, "brotli": CODEC_BROTLI}
@@ -163,6 +163,17 @@ def bra_x86_convert_device(src_ptr, dst_ptr, n, pc=0, encoding=True, state=0, li
     if rc != GC_OK:
         raise GpuCodecError("gc_bra_x86_convert_device failed: %s" % _ERR.get(rc, rc))
     return done.value, st.value
+
+
+def delta_convert_device(src_ptr, dst_ptr, n, delta, encoding=True, state=None, lib_path=None):
+    """Delta filter (C/Delta.c) over n bytes at device pointers; state = bytes-like of 256 (None: zeros); returns the state behind the buffer."""
+    lib = load_library(lib_path)
+    lib.gc_delta_convert_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint, C.c_int, C.POINTER(C.c_ubyte)]
+    st = (C.c_ubyte * 256)(*(bytes(state) if state is not None else bytes(256)))
+    rc = lib.gc_delta_convert_device(src_ptr, dst_ptr, n, int(delta), 1 if encoding else 0, st)
+    if rc != GC_OK:
+        raise GpuCodecError("gc_delta_convert_device failed: %s" % _ERR.get(rc, rc))
+    return bytes(st)
 
 
 class ZstdFrame(C.Structure):

@@ -188,6 +188,10 @@ int         gc_bra_convert_device(int kind, const void* d_src, void* d_dst, size
  * stream, Z7_BRANCH_CONV_ST_X86_STATE_INIT_VAL); out of place only.  Converted bytes, *processed and *state equal the reference's for one call. */
 int         gc_bra_x86_convert_device(const void* d_src, void* d_dst, size_t n, uint32_t pc, int encoding, uint32_t* state, size_t* processed);
 
+/* The Delta filter (Delta_Encode / Delta_Decode, C/Delta.c:16-169; method 3 of the 7z pipeline) on data in device memory: delta 1..256;
+ * state[256] in/out as the reference keeps it (zeros at the start of a stream: Delta_Init); encoding is out of place only. */
+int         gc_delta_convert_device(const void* d_src, void* d_dst, size_t n, unsigned delta, int encoding, unsigned char state[256]);
+
 /* ---- ZSTD decoding on the device.  Replaces the ZSTD_decompressStream loop of NCompress::NZSTD::CDecoder::CodeSpec
  * (CPP/7zip/Compress/ZstdDecoder.cpp:66-240; C/zstd/zstd_decompress.c:2086) for callers that hold a whole compressed stream.  The frame is
  * Entropy decoding (Huffman literals, FSE sequences) runs per BLOCK (<= 128 KiB, one workgroup each, whatever the frame structure);

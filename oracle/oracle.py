@@ -81,6 +81,8 @@ def ref(name):
                 lib.ref_bra_convert.restype = _SZ
                 lib.ref_bra_x86_convert.argtypes = [_VP, _SZ, C.c_uint, C.c_int, C.POINTER(C.c_uint)]
                 lib.ref_bra_x86_convert.restype = _SZ
+                lib.ref_delta_convert.argtypes = [_VP, _SZ, C.c_uint, C.c_int, _VP]
+                lib.ref_delta_convert.restype = None
             elif name == "brotli":
                 lib.ref_brotli_compress.argtypes = [_VP, _SZ, _VP, _SZ, C.c_int, C.c_int]
                 lib.ref_brotli_decompress.argtypes = [_VP, _SZ, _VP, _SZ]
@@ -158,6 +160,14 @@ def ref_bra_convert(kind, data, pc=0, encoding=True):
     view = buf[off:off + a.size]; view[:] = a
     done = ref("bra").ref_bra_convert(kind, view.ctypes.data, a.size, pc & 0xFFFFFFFF, 1 if encoding else 0)
     return view.copy(), int(done)
+
+
+def ref_delta_convert(data, delta, encoding=True, state=None):
+    """The reference's Delta filter (C/Delta.c) on a copy: (converted array, state out as bytes)"""
+    a = np.array(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data, dtype=np.uint8, copy=True)
+    st = np.frombuffer(bytes(state) if state is not None else bytes(256), dtype=np.uint8).copy()
+    ref("bra").ref_delta_convert(a.ctypes.data if a.size else None, a.size, int(delta), 1 if encoding else 0, st.ctypes.data)
+    return a, st.tobytes()
 
 
 def ref_bra_x86_convert(data, pc=0, encoding=True, state=0):

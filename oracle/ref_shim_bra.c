@@ -3,6 +3,7 @@
  * that converts a buffer in place with one call, the way NCompress::NBranch::CCoder::Filter does (CPP/7zip/Compress/BranchMisc.cpp:21-26). */
 #include <stddef.h>
 #include "Bra.h"
+#include "Delta.h"
 
 /* kind: 0 ARM64, 1 ARM, 2 ARMT, 3 PPC, 4 SPARC, 5 IA64, 6 RISCV; returns the processed byte count */
 size_t ref_bra_convert(int kind, unsigned char* data, size_t n, unsigned pc, int encoding)
@@ -28,4 +29,10 @@ size_t ref_bra_x86_convert(unsigned char* data, size_t n, unsigned pc, int encod
     Byte* e = encoding ? z7_BranchConvSt_X86_Enc(data, n, pc, &st) : z7_BranchConvSt_X86_Dec(data, n, pc, &st);
     *state = st;
     return (size_t)(e - data);
+}
+
+/* Delta filter (C/Delta.c) in place; state[256] in/out */
+void ref_delta_convert(unsigned char* data, size_t n, unsigned delta, int encoding, unsigned char* state)
+{
+    if (encoding) Delta_Encode(state, delta, data, n); else Delta_Decode(state, delta, data, n);
 }

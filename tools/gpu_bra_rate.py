@@ -35,3 +35,13 @@ t0 = time.perf_counter(); want, wdone, wst = O.ref_bra_x86_convert(x, 0x400000, 
 ok = bool(np.array_equal(d_out.cpu().numpy(), want)) and (done, st) == (wdone, wst)
 print("X86    %d B: call %.3f ms = %.0f GB/s of input (copy + scan: 3 B of traffic per byte = %.1f %% of 8 TB/s); reference on one core %.2f GB/s; bit-exact %s"
       % (n, best, n / best / 1e6, 3 * n / best / 1e6 / 80.0, n / cpu / 1e9, ok), flush=True)
+rng = np.random.default_rng(2); x = rng.integers(0, 256, size=n, dtype=np.uint8)
+d_in = torch.from_numpy(x).cuda(); d_out = torch.empty_like(d_in); torch.cuda.synchronize()
+for delta in (1, 4, 100):
+    for enc in (True, False):
+        best = 1e9
+        for _ in range(4):
+            t0 = time.perf_counter(); pkg.delta_convert_device(d_in.data_ptr(), d_out.data_ptr(), n, delta, enc); best = min(best, (time.perf_counter() - t0) * 1e3)
+        t0 = time.perf_counter(); want, _ = O.ref_delta_convert(x, delta, enc); cpu = time.perf_counter() - t0
+        print("DELTA %3d %s %d B: call %.3f ms = %.0f GB/s of input; reference on one core %.2f GB/s; bit-exact %s"
+              % (delta, "enc" if enc else "dec", n, best, n / best / 1e6, n / cpu / 1e9, bool(np.array_equal(d_out.cpu().numpy(), want))), flush=True)
