@@ -96,11 +96,11 @@ def test_emu_long_matches_and_patterns(O, emu_fl2):
 
 
 def test_emu_many_frames_and_parts(O, pkg, emu_lib_path, monkeypatch):
-    """The multi-frame and multi-part paths on a small input: test hooks shrink the match-finder frame to 2 blocks and make every
+    """The multi-frame and multi-part paths on a small input: test hooks shrink the match-finder frame to one block and make every
     frame its own part (stages of different parts run on different streams; a later part's first literal has the last byte of
     the previous part as its context).  Parts must not change the stream: same bytes as the single-part run."""
-    x = O.corpus("silesia-like", 3 * 2 * BLK + 4321)
-    monkeypatch.setenv("GC_FRAME_BLOCKS", "2")
+    x = O.corpus("silesia-like", 3 * BLK + 4321)                       # four frames of one block each (the last one short)
+    monkeypatch.setenv("GC_FRAME_BLOCKS", "1")
     one = pkg.Flzma2Encoder(lib_path=emu_lib_path, level=5)
     c1 = _roundtrip(O, one, x); one.close()
     monkeypatch.setenv("GC_PART_FRAMES", "1")

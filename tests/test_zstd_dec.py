@@ -84,7 +84,7 @@ def test_emu_concatenated_and_skippable_frames(O, emu_dec):
 @pytest.mark.parametrize("level", [1, 3, 19])
 def test_emu_own_encoder_roundtrip(pkg, O, emu_lib_path, emu_dec, level, monkeypatch):
     monkeypatch.setenv("GC_FRAME_BLOCKS", "2")                                 # frames of 256 KiB so that a small input carries several
-    x = _corpus(O, "silesia-like", 600_000)
+    x = _corpus(O, "silesia-like", 600_000 if level < 16 else 300_000)      # (the price-based parse is slow under the emulator)
     enc = pkg.ZstdEncoder(lib_path=emu_lib_path, level=level)
     try:
         comp = enc.code(x)
@@ -103,7 +103,7 @@ def test_emu_damaged_streams_are_refused(pkg, O, emu_dec):
     comp = bytearray(O.ref_zstd_compress_opts(x, 3, checksum=True).tobytes())
     rng = np.random.default_rng(3)
     refused = 0
-    for _ in range(40):
+    for _ in range(24):
         bad = bytearray(comp)
         pos = int(rng.integers(0, len(bad)))
         bad[pos] ^= 1 << int(rng.integers(0, 8))
@@ -112,7 +112,7 @@ def test_emu_damaged_streams_are_refused(pkg, O, emu_dec):
             assert out.tobytes() == x           # a flip the format does not notice must not change the content (checksum present)
         except pkg.GpuCodecError:
             refused += 1
-    assert refused >= 36
+    assert refused >= 21
     for cut in (0, 3, 4, 9, len(comp) // 2, len(comp) - 1):                    # truncated
         if cut == 0:
             continue
