@@ -126,7 +126,7 @@ struct gc_ctx {
     bool pending; bool timed;
     // zstd decoder (gc_zstd_dec.hip): per-workgroup literal / sequence workspace, frame table, per-frame results, ticket counter
     uint8_t* zdLit; size_t zdLitCap; void* zdSeq; size_t zdSeqCap; GcZdFrame* zdFrames; size_t zdFramesCap; uint64_t* zdResult; uint64_t* zdTot;
-    GcZdBlock* zdBlocks; size_t zdBlocksCap; uint32_t* zdTicket; hipEvent_t zdEv[2]; float zdMs;
+    GcZdBlock* zdBlocks; size_t zdBlocksCap; uint32_t* zdTicket; hipEvent_t zdEv[2]; float zdMs; float zdKms[4];   // last call: whole, and index / literals / sequences / execution kernels
     unsigned long long* prof;  // device: GC_LZ_PHASES + GC_SEQ_PHASES cycle sums, only when profiling is on
     bool profOn; uint32_t profBlocks;
 };
@@ -914,7 +914,7 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
 {
     if (!c || (!d_src && n) || (!d_dst && dstCap) || (!frames && nFrames)) return GC_ERR_PARAM;
     HIPCHK(c, hipSetDevice(c->device));
-    c->zdMs = 0.f;
+    c->zdMs = 0.f; c->zdKms[0] = c->zdKms[1] = c->zdKms[2] = c->zdKms[3] = 0.f;
     if (outSize) *outSize = 0;
     if (!nFrames) return GC_OK;
     GcZdFrame* h = (GcZdFrame*)calloc(nFrames, sizeof(GcZdFrame));
@@ -956,6 +956,7 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
         if (hipMemcpyAsync(c->zdFrames, h + i, cnt * sizeof(GcZdFrame), hipMemcpyHostToDevice, c->stream) != hipSuccess) { rc = GC_ERR_HIP; break; }
         hipEventRecord(c->zdEv[0], c->stream);
         gc_zstd_dec_launch_index(c->stream, (const uint8_t*)d_src, c->zdFrames, (uint32_t)cnt, c->zdBlocks, c->zdTot);
+        hipEventRecord(c->evPart[1][0], c->stream);
         if (hipMemcpyAsync(res, c->zdTot, cnt * 16u, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
             snprintf(c->err, sizeof(c->err), "index kernel failed: %s", hipGetErrorString(hipGetLastError())); rc = GC_ERR_HIP; break;
         }
@@ -968,10 +969,13 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
         // literals on stream2, sequences on the main stream (both only need the block table), then the execution kernel
         hipEventRecord(c->evPart[0][0], c->stream);
         hipStreamWaitEvent(c->stream2, c->evPart[0][0], 0);
+        hipEventRecord(c->evPart[1][2], c->stream2);
         gc_zstd_dec_launch_literals(c->stream2, (const uint8_t*)d_src, n, c->zdFrames, c->zdBlocks, (uint32_t)nBlocks, c->zdLit, zdProf);
         hipEventRecord(c->evPart[0][1], c->stream2);
         gc_zstd_dec_launch_sequences(c->stream, (const uint8_t*)d_src, n, c->zdFrames, c->zdBlocks, (uint32_t)nBlocks, c->zdSeq, zdProf);
+        hipEventRecord(c->evPart[1][1], c->stream);
         hipStreamWaitEvent(c->stream, c->evPart[0][1], 0);
+        hipEventRecord(c->evPart[1][3], c->stream);
         gc_zstd_dec_launch_exec(c->stream, (const uint8_t*)d_src, n, (uint8_t*)d_dst, dstCap, c->zdFrames, (uint32_t)cnt, c->zdBlocks, c->zdTicket,
                                 c->zdLit, litTot + 64u, c->zdSeq, c->zdResult, zdProf);
         hipEventRecord(c->zdEv[1], c->stream);
@@ -979,6 +983,10 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
             snprintf(c->err, sizeof(c->err), "decode kernels failed: %s", hipGetErrorString(hipGetLastError())); rc = GC_ERR_HIP; break;
         }
         float ms = 0.f; if (hipEventElapsedTime(&ms, c->zdEv[0], c->zdEv[1]) == hipSuccess) c->zdMs += ms;
+        if (hipEventElapsedTime(&ms, c->zdEv[0], c->evPart[1][0]) == hipSuccess) c->zdKms[0] += ms;
+        if (hipEventElapsedTime(&ms, c->evPart[1][2], c->evPart[0][1]) == hipSuccess) c->zdKms[1] += ms;
+        if (hipEventElapsedTime(&ms, c->evPart[0][0], c->evPart[1][1]) == hipSuccess) c->zdKms[2] += ms;
+        if (hipEventElapsedTime(&ms, c->evPart[1][3], c->zdEv[1]) == hipSuccess) c->zdKms[3] += ms;
         for (size_t k = 0; k < cnt; k++) {
             const uint32_t st = (uint32_t)(res[k] >> 56);
             const uint64_t produced = res[k] & 0x00FFFFFFFFFFFFFFull;
@@ -1005,6 +1013,7 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
 }
 
 extern "C" int gc_zstd_decompress_timing(gc_ctx* c, float* ms) { if (!c || !ms) return GC_ERR_PARAM; *ms = c->zdMs; return GC_OK; }
+extern "C" int gc_zstd_decompress_kernel_timing(gc_ctx* c, float ms[4]) { if (!c || !ms) return GC_ERR_PARAM; for (int i = 0; i < 4; i++) ms[i] = c->zdKms[i]; return GC_OK; }
 
 extern "C" int gc_zstd_decompress_host(gc_ctx* c, const void* src, size_t n, void* dst, size_t dstCap, size_t* outSize)
 {

@@ -166,10 +166,24 @@ def run_codec(codec, level, corpus_name, total, args, env):
                 for _ in range(3):
                     got = dec.code_device(d_c.data_ptr(), int(stream.size), d_y.data_ptr(), total, frames, nf)
                     ms = dec.last_timing_ms()
-                    best = ms if best is None else min(best, ms)
+                    if best is None or ms < best:
+                        best, kms = ms, dec.kernel_timing_ms()
                 same = bool(got == total and torch.equal(d_y[:total], d_src[:total]))
+                dom = max(kms, key=lambda k: kms[k])
+                algo = total + int(stream.size)                      # compressed stream read once + content written once
+                dtraffic = None
+                try:
+                    pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+                    if pm.get("_workload_bytes", {}).get("zstd_dec") == total:
+                        dtraffic = pm["zstd_dec"]["gc_zstd_dec_%s_kernel" % {"execution": "exec", "sequences": "seq", "literals": "lit", "index": "index"}[dom]]["hbm_bytes_per_launch"]
+                except Exception:
+                    dtraffic = None
                 gpu_decode = {"frames": nf, "content_bytes": total, "kernel_ms": round(best, 3), "value": round(total / best / 1e3, 1), "unit": "MB/s of content",
-                              "bit_exact": same, "reference_decoder_1_core_MBps": round(total / td / 1e6, 1)}
+                              "bit_exact": same, "reference_decoder_1_core_MBps": round(total / td / 1e6, 1),
+                              "kernels_ms": {k: round(v, 3) for k, v in kms.items()},
+                              "roofline": {"bound": "hbm", "kernel": "gc_zstd_dec_%s_kernel" % {"execution": "exec", "sequences": "seq", "literals": "lit", "index": "index"}[dom],
+                                           "achieved": round(algo / (kms[dom] * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": round(algo / (kms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": dtraffic, "algorithmic_bytes_per_launch": algo}}
                 dec.close(); del d_c, d_y
     value = total * args.steps / elapsed / 1e6
     ratio = total / total_csize

@@ -223,6 +223,8 @@ int         gc_zstd_decompress_device(gc_ctx* ctx, const void* d_src, size_t n, 
 int         gc_zstd_decompress_host(gc_ctx* ctx, const void* src, size_t n, void* dst, size_t dstCapacity, size_t* decompressedSize);
 /* HIP-event duration of the decode kernels of the last gc_zstd_decompress_* call */
 int         gc_zstd_decompress_timing(gc_ctx* ctx, float* ms);
+/* ... and of its kernels: ms[0] index, ms[1] literals (second stream, beside the sequences), ms[2] sequences, ms[3] execution */
+int         gc_zstd_decompress_kernel_timing(gc_ctx* ctx, float ms[4]);
 
 /* raw stream handle (hipStream_t) so callers can order their own work against the context */
 void*       gc_ctx_stream(gc_ctx* ctx);
