@@ -51,7 +51,7 @@ struct GcZdBlock {
 
 #define GC_ZD_T         1024u                         // execution kernel
 #define GC_ZD_MAX_WG    256u                          // frames in execution at a time (129 KB of LDS: one workgroup per CU)
-#define GC_ZD_CHUNK     2048u                         // bytes of the sequence bitstream staged in LDS at a time
+#define GC_ZD_CHUNK     1024u                         // bytes of the sequence bitstream staged in LDS at a time
 
 // per frame result word: produced bytes | status << 56
 #define GC_ZD_OK          0u

@@ -570,8 +570,9 @@ extern "C" __global__ void __launch_bounds__(64)
 gc_zstd_dec_seq_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const GcZdFrame* __restrict__ frames, GcZdBlock* blocks, GcU4* seqWork, unsigned long long* prof)
 {
     __shared__ uint32_t sLL[512], sML[512], sOF[256];
-    __shared__ __attribute__((aligned(16))) uint8_t sBuf[GC_ZD_CHUNK + 64u];
-    __shared__ __attribute__((aligned(16))) uint8_t sWinS[ZD_WIN_S + 8u], sWinR[ZD_WIN_S + 8u];
+    __shared__ __attribute__((aligned(16))) uint8_t sBuf[(GC_ZD_CHUNK + 64u) > 2u * (ZD_WIN_S + 16u) ? (GC_ZD_CHUNK + 64u) : 2u * (ZD_WIN_S + 16u)];
+    uint8_t* const sWinS = sBuf;                               // the two header windows are only needed while the tables are built:
+    uint8_t* const sWinR = sBuf + ZD_WIN_S + 16u;              // they share their LDS with the bitstream pieces staged afterwards
     __shared__ int16_t sNormA[64];
     __shared__ uint16_t sNextA[64];
     __shared__ ZdConst sK;
