@@ -172,9 +172,9 @@ int         gc_ctx_set_option(gc_ctx* ctx, int option, int value);
 int         gc_crc32_device(const void* d_src, size_t n, uint32_t* crc);
 
 /* ---- Branch converters on data in device memory (the filters 7-Zip puts in front of a compressor for executables:
- * z7_BranchConv_ARM64_Enc / _Dec ... of C/Bra.c:75-340, called from NCompress::NBranch::CCoder::Filter, CPP/7zip/Compress/BranchMisc.cpp:21-26).
+ * z7_BranchConv_ARM64_Enc / _Dec ... of C/Bra.c:75-709, called from NCompress::NBranch::CCoder::Filter, CPP/7zip/Compress/BranchMisc.cpp:21-26).
  * pc = virtual address of byte 0 (the filters' kBranchOffset property); encoding != 0 converts relative -> absolute.  d_dst may equal d_src
- * except for GC_BRA_ARMT.  *processed = the byte count the reference's converter reports for one call on the whole buffer (bytes behind it are
+ * except for GC_BRA_ARMT and GC_BRA_RISCV.  *processed = the byte count the reference's converter reports for one call on the whole buffer (bytes behind it are
  * copied unchanged).  Synchronous on the default stream. */
 #define GC_BRA_ARM64 0
 #define GC_BRA_ARM   1
@@ -193,11 +193,11 @@ int         gc_bra_x86_convert_device(const void* d_src, void* d_dst, size_t n, 
 int         gc_delta_convert_device(const void* d_src, void* d_dst, size_t n, unsigned delta, int encoding, unsigned char state[256]);
 
 /* ---- ZSTD decoding on the device.  Replaces the ZSTD_decompressStream loop of NCompress::NZSTD::CDecoder::CodeSpec
- * (CPP/7zip/Compress/ZstdDecoder.cpp:66-240; C/zstd/zstd_decompress.c:2086) for callers that hold a whole compressed stream.  The frame is
+ * (CPP/7zip/Compress/ZstdDecoder.cpp:66-240; C/zstd/zstd_decompress.c:2086) for callers that hold a whole compressed stream.
  * Entropy decoding (Huffman literals, FSE sequences) runs per BLOCK (<= 128 KiB, one workgroup each, whatever the frame structure);
  * the match copies run per FRAME (one workgroup each, blocks in order): streams of this engine's encoder carry one frame per 8 MiB, a
- * stream of the reference's encoder is one frame.  Frames with a dictionary id are refused (GC_ERR_PARAM); a damaged stream, a wrong content checksum (XXH64, checked
- * on the device) or a content size field that does not match give GC_ERR_CORRUPT.
+ * stream of the reference's encoder is one frame.  Frames with a dictionary id are refused (GC_ERR_PARAM); a damaged stream, a wrong content
+ * checksum (XXH64, checked on the device) or a content size field that does not match give GC_ERR_CORRUPT.
  *   gc_zstd_scan_frames       host: walks frame and block headers (ZSTD_findFrameCompressedSize zstd_decompress.c:809, ZSTD_getFrameContentSize
  *                             :569), skips skippable frames.  frames may be NULL to count.  *contentTotal = sum of the content sizes, or
  *                             UINT64_MAX if a frame does not state its size (then the caller has to guess dstCapacity).
