@@ -1,12 +1,17 @@
 """ZSTD decoding on the device: the content must be bit-exact for streams of the REFERENCE's encoder (every level family,
 content checksum, streamed frames without a content size, long offsets, concatenated and skippable frames) and of this engine's encoder,
 and damaged streams must be refused, never crash.  CPU: the kernel under the SIMT emulator; GPU: the product library, larger inputs."""
+import hashlib
+import os
 import struct
 
 import numpy as np
 import pytest
 
 MiB = 1 << 20
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+# the reference's own golden vector (tests/regression.test:31-89): test.txt.zstd decodes to 1 000 000 bytes with this SHA-256
+TEST_TXT_SHA256 = "aeda0f81c8376d1678af53927a08cf641cafab8b68aef509c881eb0be0bc3c97"
 KINDS = ["silesia-like", "text-zipf", "lz-7zip", "random", "zeros", "runs"]
 
 
@@ -44,6 +49,22 @@ def gpu_dec(pkg, graft):
     d = pkg.ZstdDecoder(device=0)
     yield d
     d.close()
+
+
+def _golden(dec):
+    comp = open(os.path.join(GOLD, "test.txt.zstd"), "rb").read()
+    out = dec.code(comp, capacity=2_000_000)
+    assert out.size == 1_000_000 and hashlib.sha256(out.tobytes()).hexdigest() == TEST_TXT_SHA256
+    assert out[:5].tobytes() == b"TEST\n" and out[-5:].tobytes() == b"\nEND."
+
+
+def test_emu_golden_fixture_of_the_reference(emu_dec):
+    _golden(emu_dec)
+
+
+@pytest.mark.gpu
+def test_gpu_golden_fixture_of_the_reference(gpu_dec):
+    _golden(gpu_dec)
 
 
 @pytest.mark.parametrize("kind", KINDS)
