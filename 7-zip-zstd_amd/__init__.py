@@ -248,7 +248,7 @@ class _EncoderBase:
     def close(self):
         if getattr(self, "_ctx", None) and self._ctx.value:
             self._lib.gc_ctx_destroy(self._ctx)
-            self._ctx = C.c_void_p()
+            self._ctx = C.c_void_p() if C is not None else None      # (C is gone when this runs at interpreter shutdown)
 
     __del__ = close
 

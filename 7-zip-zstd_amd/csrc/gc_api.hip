@@ -126,7 +126,7 @@ struct gc_ctx {
     bool pending; bool timed;
     // zstd decoder (gc_zstd_dec.hip): per-workgroup literal / sequence workspace, frame table, per-frame results, ticket counter
     uint8_t* zdLit; size_t zdLitCap; void* zdSeq; size_t zdSeqCap; GcZdFrame* zdFrames; size_t zdFramesCap; uint64_t* zdResult; uint64_t* zdTot;
-    GcZdBlock* zdBlocks; size_t zdBlocksCap; uint32_t* zdTicket; hipEvent_t zdEv[2]; float zdMs; float zdKms[4];   // last call: whole, and index / literals / sequences / execution kernels
+    GcZdBlock* zdBlocks; size_t zdBlocksCap; uint32_t* zdOrder; size_t zdOrderCap; uint32_t* zdReady; size_t zdReadyCap; uint32_t* zdTicket; hipEvent_t zdEv[2]; float zdMs; float zdKms[4];   // last call: whole, and index / literals / sequences / execution kernels
     unsigned long long* prof;  // device: GC_LZ_PHASES + GC_SEQ_PHASES cycle sums, only when profiling is on
     bool profOn; uint32_t profBlocks;
 };
@@ -213,7 +213,7 @@ static void ctx_release(gc_ctx* c)
     if (c->stream) hipStreamSynchronize(c->stream);
     free_workspace(c);
     hipFree(c->prof); hipFree(c->result); if (c->hostResult) hipHostFree(c->hostResult); hipFree(c->dIn); hipFree(c->dOut);
-    hipFree(c->zdLit); hipFree(c->zdSeq); hipFree(c->zdFrames); hipFree(c->zdResult); hipFree(c->zdTot); hipFree(c->zdBlocks); hipFree(c->zdTicket);
+    hipFree(c->zdLit); hipFree(c->zdSeq); hipFree(c->zdFrames); hipFree(c->zdResult); hipFree(c->zdTot); hipFree(c->zdBlocks); hipFree(c->zdOrder); hipFree(c->zdReady); hipFree(c->zdTicket);
     for (int i = 0; i < 2; i++) if (c->zdEv[i]) hipEventDestroy(c->zdEv[i]);
     hipFree(c->mfCnt); hipFree(c->mfEnt); hipFree(c->mfEnt2); hipFree(c->mfRec); hipFree(c->mfRec2); hipFree(c->mfRec3); hipFree(c->mfDp); hipFree(c->mfPrice); hipFree(c->mfWinCost); hipFree(c->mfDpStat);
     for (int i = 0; i < 8; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
@@ -894,11 +894,12 @@ extern "C" size_t gc_codec_grain(int codec, int level)
 // ---------------------------------------------------------------- ZSTD decoding ----------------------------------------------------------------
 extern "C" void gc_zstd_dec_launch_index(hipStream_t st, const uint8_t* src, const GcZdFrame* frames, uint32_t nFrames, GcZdBlock* blocks, uint64_t* frameTot);
 extern "C" void gc_zstd_dec_launch_literals(hipStream_t st, const uint8_t* src, uint64_t srcSize, const GcZdFrame* frames, GcZdBlock* blocks, uint32_t nBlocks, uint8_t* litWork,
-                                            unsigned long long* prof);
+                                            unsigned long long* prof, const uint32_t* order, uint32_t* ready);
 extern "C" void gc_zstd_dec_launch_sequences(hipStream_t st, const uint8_t* src, uint64_t srcSize, const GcZdFrame* frames, GcZdBlock* blocks, uint32_t nBlocks, void* seqWork,
-                                             unsigned long long* prof);
+                                             unsigned long long* prof, const uint32_t* order, uint32_t* ready);
 extern "C" void gc_zstd_dec_launch_exec(hipStream_t st, const uint8_t* src, uint64_t srcSize, uint8_t* dst, uint64_t dstCap, const GcZdFrame* frames, uint32_t nFrames,
-                                        GcZdBlock* blocks, uint32_t* ticket, uint8_t* litWork, uint64_t litWorkSize, void* seqWork, uint64_t* result, unsigned long long* prof);
+                                        GcZdBlock* blocks, uint32_t* ticket, uint8_t* litWork, uint64_t litWorkSize, void* seqWork, uint64_t* result, unsigned long long* prof,
+                                        const uint32_t* ready);
 
 static int zd_grow(gc_ctx* c, void** p, size_t* cap, size_t need)
 {
@@ -966,18 +967,53 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
         if ((rc = zd_grow(c, &c->zdSeq, &c->zdSeqCap, (size_t)seqTot * 16u + 64u)) != GC_OK) break;
         if (hipMemcpyAsync(c->zdFrames, h + i, cnt * sizeof(GcZdFrame), hipMemcpyHostToDevice, c->stream) != hipSuccess ||
             hipMemsetAsync(c->zdTicket, 0, 4, c->stream) != hipSuccess) { rc = GC_ERR_HIP; break; }
-        // literals on stream2, sequences on the main stream (both only need the block table), then the execution kernel
+        // literals on stream2, sequences on the main stream (both only need the block table), the execution kernel on stream3.  With few frames
+        // (fewer than 5/8 of the CUs would host an execution workgroup) the execution kernel starts FIRST and follows the entropy kernels block by
+        // block (a counter per block says when its one or two entropy workgroups are through), so that the two stages overlap; the entropy
+        // kernels then take the blocks round by round over the frames (block 0 of every frame, block 1, ...), so that every frame's first blocks
+        // come first.  With many frames the execution kernel would crowd the entropy kernels out: it runs behind them, blocks in plain order.
+        // (The emulator runs one launch after the other: there the entropy kernels always come first.)
+        bool overlap = cnt <= 160u;
+#ifdef HIPEMU
+        overlap = false;
+#endif
+        { uint32_t v = 0; if (gc_env_u32("GC_ZD_OVERLAP", 0, 1, &v)) overlap = overlap && v != 0u; }
+        if ((rc = zd_grow(c, (void**)&c->zdOrder, &c->zdOrderCap, (size_t)nBlocks * 4u)) != GC_OK) break;
+        if ((rc = zd_grow(c, (void**)&c->zdReady, &c->zdReadyCap, (size_t)nBlocks * 4u)) != GC_OK) break;
+        {
+            uint32_t* ord = (uint32_t*)malloc((size_t)nBlocks * 4u);
+            if (!ord) { rc = GC_ERR_NOMEM; break; }
+            uint32_t maxB = 0; size_t w = 0;
+            for (size_t k = 0; k < cnt; k++) if (h[i + k].nBlocks > maxB) maxB = h[i + k].nBlocks;
+            if (overlap && (uint64_t)maxB * cnt <= 4u * nBlocks + 1024u) {
+                for (uint32_t r = 0; r < maxB; r++) for (size_t k = 0; k < cnt; k++) if (r < h[i + k].nBlocks) ord[w++] = h[i + k].blockBase + r;
+            } else for (w = 0; w < nBlocks; w++) ord[w] = (uint32_t)w;          // (also for very uneven frames, where the loop above would be quadratic)
+            const bool okc = hipMemcpyAsync(c->zdOrder, ord, (size_t)nBlocks * 4u, hipMemcpyHostToDevice, c->stream) == hipSuccess &&
+                             hipMemsetAsync(c->zdReady, 0, (size_t)nBlocks * 4u, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
+            free(ord);
+            if (!okc) { rc = GC_ERR_HIP; break; }
+        }
         hipEventRecord(c->evPart[0][0], c->stream);
         hipStreamWaitEvent(c->stream2, c->evPart[0][0], 0);
+        hipStreamWaitEvent(c->stream3, c->evPart[0][0], 0);
+        hipEventRecord(c->evPart[1][3], c->stream3);
+        if (overlap) gc_zstd_dec_launch_exec(c->stream3, (const uint8_t*)d_src, n, (uint8_t*)d_dst, dstCap, c->zdFrames, (uint32_t)cnt, c->zdBlocks, c->zdTicket,
+                                             c->zdLit, litTot + 64u, c->zdSeq, c->zdResult, zdProf, c->zdReady);
         hipEventRecord(c->evPart[1][2], c->stream2);
-        gc_zstd_dec_launch_literals(c->stream2, (const uint8_t*)d_src, n, c->zdFrames, c->zdBlocks, (uint32_t)nBlocks, c->zdLit, zdProf);
+        gc_zstd_dec_launch_literals(c->stream2, (const uint8_t*)d_src, n, c->zdFrames, c->zdBlocks, (uint32_t)nBlocks, c->zdLit, zdProf, c->zdOrder, c->zdReady);
         hipEventRecord(c->evPart[0][1], c->stream2);
-        gc_zstd_dec_launch_sequences(c->stream, (const uint8_t*)d_src, n, c->zdFrames, c->zdBlocks, (uint32_t)nBlocks, c->zdSeq, zdProf);
+        gc_zstd_dec_launch_sequences(c->stream, (const uint8_t*)d_src, n, c->zdFrames, c->zdBlocks, (uint32_t)nBlocks, c->zdSeq, zdProf, c->zdOrder, c->zdReady);
         hipEventRecord(c->evPart[1][1], c->stream);
         hipStreamWaitEvent(c->stream, c->evPart[0][1], 0);
-        hipEventRecord(c->evPart[1][3], c->stream);
-        gc_zstd_dec_launch_exec(c->stream, (const uint8_t*)d_src, n, (uint8_t*)d_dst, dstCap, c->zdFrames, (uint32_t)cnt, c->zdBlocks, c->zdTicket,
-                                c->zdLit, litTot + 64u, c->zdSeq, c->zdResult, zdProf);
+        if (!overlap) {
+            hipEventRecord(c->evPart[1][3], c->stream);
+            gc_zstd_dec_launch_exec(c->stream, (const uint8_t*)d_src, n, (uint8_t*)d_dst, dstCap, c->zdFrames, (uint32_t)cnt, c->zdBlocks, c->zdTicket,
+                                    c->zdLit, litTot + 64u, c->zdSeq, c->zdResult, zdProf, c->zdReady);
+            hipEventRecord(c->evPart[1][4], c->stream);
+        } else {
+            hipEventRecord(c->evPart[1][4], c->stream3);
+            hipStreamWaitEvent(c->stream, c->evPart[1][4], 0);
+        }
         hipEventRecord(c->zdEv[1], c->stream);
         if (hipMemcpyAsync(res, c->zdResult, cnt * 8u, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
             snprintf(c->err, sizeof(c->err), "decode kernels failed: %s", hipGetErrorString(hipGetLastError())); rc = GC_ERR_HIP; break;
@@ -986,7 +1022,7 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
         if (hipEventElapsedTime(&ms, c->zdEv[0], c->evPart[1][0]) == hipSuccess) c->zdKms[0] += ms;
         if (hipEventElapsedTime(&ms, c->evPart[1][2], c->evPart[0][1]) == hipSuccess) c->zdKms[1] += ms;
         if (hipEventElapsedTime(&ms, c->evPart[0][0], c->evPart[1][1]) == hipSuccess) c->zdKms[2] += ms;
-        if (hipEventElapsedTime(&ms, c->evPart[1][3], c->zdEv[1]) == hipSuccess) c->zdKms[3] += ms;
+        if (hipEventElapsedTime(&ms, c->evPart[1][3], c->evPart[1][4]) == hipSuccess) c->zdKms[3] += ms;
         for (size_t k = 0; k < cnt; k++) {
             const uint32_t st = (uint32_t)(res[k] >> 56);
             const uint64_t produced = res[k] & 0x00FFFFFFFFFFFFFFull;

@@ -77,6 +77,39 @@ __device__ __forceinline__ void gc_wave_sync_global()
 #endif
 }
 
+// Kernels that run beside each other: the producer makes what it wrote visible to the whole device and counts itself in; the consumer polls the
+// counter and, once it has seen the value it waits for, drops what its caches may hold of the producer's lines (agent scope: across the XCDs' L2s).
+__device__ __forceinline__ void gc_signal_device(uint32_t* counter)         // called by every lane of the wave; one lane counts
+{
+#ifdef HIPEMU
+    hipemu::wave_barrier();
+    if ((__lane_id() & 63u) == 0u) __atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE);
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if ((threadIdx.x & 63u) == 0u) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ uint32_t gc_poll_device(const uint32_t* counter)
+{
+#ifdef HIPEMU
+    return __atomic_load_n(counter, __ATOMIC_ACQUIRE);
+#else
+    return __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+__device__ __forceinline__ void gc_acquire_device()
+{
+#ifndef HIPEMU
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#endif
+}
+__device__ __forceinline__ void gc_nap()
+{
+#ifndef HIPEMU
+    __builtin_amdgcn_s_sleep(32);
+#endif
+}
+
 // shader cycle counter (s_memtime); only used by the optional phase profile
 __device__ __forceinline__ unsigned long long gc_clock()
 {

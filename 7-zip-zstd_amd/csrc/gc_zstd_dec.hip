@@ -483,7 +483,8 @@ __device__ bool zd_huf_parallel(const uint8_t* sp, uint32_t n, uint32_t count, u
 
 // ---- literals: one wave per block ----
 extern "C" __global__ void __launch_bounds__(64)
-gc_zstd_dec_lit_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const GcZdFrame* __restrict__ frames, GcZdBlock* blocks, uint8_t* litWork, unsigned long long* prof)
+gc_zstd_dec_lit_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const GcZdFrame* __restrict__ frames, GcZdBlock* blocks, uint8_t* litWork, unsigned long long* prof,
+                       const uint32_t* __restrict__ order, uint32_t* ready)
 {
     __shared__ uint16_t sHuf[1u << ZD_HUF_LOG_MAX];
     __shared__ GcU2 sFseW[64];
@@ -493,7 +494,7 @@ gc_zstd_dec_lit_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
     __shared__ uint8_t sW[256];
     __shared__ uint32_t sV[4];        // 1 error, 2 huf log, 3 tree bytes
 
-    const uint32_t lane = threadIdx.x, b = blockIdx.x;
+    const uint32_t lane = threadIdx.x, b = order[blockIdx.x];            // blocks are taken round by round over the frames (block 0 of every frame first)
     const uint32_t ty = blocks[b].type;
     if ((ty & 3u) != 2u || (ty & GC_ZD_B_BAD) || (blocks[b].litInfo & 3u) < 2u) return;
     const GcZdBlock e = blocks[b];
@@ -563,11 +564,13 @@ gc_zstd_dec_lit_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
     }
     gc_wave_sync();
     if (lane == 0u) blocks[b].litStatus = sV[1] ? GC_ZD_CORRUPT : GC_ZD_OK;
+    gc_signal_device(&ready[b]);                                           // the execution kernel may be waiting for this block
 }
 
 // ---- sequences: one wave per block (lane 0 decodes; 10 KB of LDS, so that many blocks are in flight per CU) ----
 extern "C" __global__ void __launch_bounds__(64)
-gc_zstd_dec_seq_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const GcZdFrame* __restrict__ frames, GcZdBlock* blocks, GcU4* seqWork, unsigned long long* prof)
+gc_zstd_dec_seq_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const GcZdFrame* __restrict__ frames, GcZdBlock* blocks, GcU4* seqWork, unsigned long long* prof,
+                       const uint32_t* __restrict__ order, uint32_t* ready)
 {
     __shared__ uint32_t sLL[512], sML[512], sOF[256];
     __shared__ __attribute__((aligned(16))) uint8_t sBuf[(GC_ZD_CHUNK + 64u) > 2u * (ZD_WIN_S + 16u) ? (GC_ZD_CHUNK + 64u) : 2u * (ZD_WIN_S + 16u)];
@@ -578,7 +581,7 @@ gc_zstd_dec_seq_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
     __shared__ ZdConst sK;
     __shared__ uint32_t sV[16];       // 0 error, 4 seq stream start, 5..7 table logs, 8.. results
 
-    const uint32_t lane = threadIdx.x, t = lane, b = blockIdx.x;
+    const uint32_t lane = threadIdx.x, t = lane, b = order[blockIdx.x];
     const uint32_t ty = blocks[b].type;
     if ((ty & 3u) != 2u || (ty & GC_ZD_B_BAD)) return;
     const GcZdBlock e = blocks[b];
@@ -731,6 +734,7 @@ gc_zstd_dec_seq_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
         blocks[b].status = status; blocks[b].outSize = outSize; blocks[b].lposEnd = lpos; blocks[b].dposEnd = dpos;
         blocks[b].rep[0] = sV[10]; blocks[b].rep[1] = sV[11]; blocks[b].rep[2] = sV[12];
     }
+    gc_signal_device(&ready[b]);
 }
 
 // =============================================================== execution kernel ===============================================================
@@ -766,8 +770,8 @@ enum { XV_ERR = 0, XV_FRAME, XV_REP0, XV_REP1, XV_REP2, XV_COUNT };
 
 extern "C" __global__ void __launch_bounds__(GC_ZD_T)
 gc_zstd_dec_exec_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint8_t* dst, uint64_t dstCap, const GcZdFrame* __restrict__ frames, uint32_t nFrames,
-                        const GcZdBlock* __restrict__ blocks, uint32_t* ticket, const uint8_t* litWork, uint64_t litWorkSize, GcU4* seqWork, uint64_t* result,
-                        unsigned long long* prof)
+                        const GcZdBlock* blocks, uint32_t* ticket, const uint8_t* litWork, uint64_t litWorkSize, GcU4* seqWork, uint64_t* result,
+                        unsigned long long* prof, const uint32_t* ready)
 {
     __shared__ __attribute__((aligned(16))) uint8_t sOut[GC_ZSTD_BLOCK_MAX + 32u];
     __shared__ uint32_t sV[XV_COUNT];
@@ -790,6 +794,19 @@ gc_zstd_dec_exec_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint8
         __syncthreads();
 
         for (uint32_t bi = 0; bi < fr.nBlocks; bi++) {
+            {   // the entropy kernels may still be at work on this block (they run beside this kernel): wait for its one or two workgroups
+                const uint32_t ty = blocks[fr.blockBase + bi].type, li = blocks[fr.blockBase + bi].litInfo;       // (written by the index kernel: final)
+                if ((ty & 3u) == 2u && !(ty & GC_ZD_B_BAD)) {
+                    const uint32_t need = 1u + ((li & 3u) >= 2u ? 1u : 0u);
+                    if (t == 0) {
+                        uint32_t spins = 0;
+                        while (gc_poll_device(&ready[fr.blockBase + bi]) < need) { gc_nap(); if (++spins > (1u << 24)) { sV[XV_ERR] = GC_ZD_CORRUPT; break; } }
+                    }
+                    __syncthreads();
+                    gc_acquire_device();
+                    if (sV[XV_ERR]) break;
+                }
+            }
             const GcZdBlock e = blocks[fr.blockBase + bi];
             const uint32_t bt = e.type & 3u;
             uint32_t fail = 0;
@@ -1078,18 +1095,19 @@ extern "C" void gc_zstd_dec_launch_index(hipStream_t st, const uint8_t* src, con
 }
 // literals and sequences of all blocks: independent of each other (two streams), both in front of the execution kernel
 extern "C" void gc_zstd_dec_launch_literals(hipStream_t st, const uint8_t* src, uint64_t srcSize, const GcZdFrame* frames, GcZdBlock* blocks, uint32_t nBlocks, uint8_t* litWork,
-                                            unsigned long long* prof)
+                                            unsigned long long* prof, const uint32_t* order, uint32_t* ready)
 {
-    if (nBlocks) GC_LAUNCH(gc_zstd_dec_lit_kernel, nBlocks, 64, st, src, srcSize, frames, blocks, litWork, prof);
+    if (nBlocks) GC_LAUNCH(gc_zstd_dec_lit_kernel, nBlocks, 64, st, src, srcSize, frames, blocks, litWork, prof, order, ready);
 }
 extern "C" void gc_zstd_dec_launch_sequences(hipStream_t st, const uint8_t* src, uint64_t srcSize, const GcZdFrame* frames, GcZdBlock* blocks, uint32_t nBlocks, void* seqWork,
-                                             unsigned long long* prof)
+                                             unsigned long long* prof, const uint32_t* order, uint32_t* ready)
 {
-    if (nBlocks) GC_LAUNCH(gc_zstd_dec_seq_kernel, nBlocks, 64, st, src, srcSize, frames, blocks, (GcU4*)seqWork, prof);
+    if (nBlocks) GC_LAUNCH(gc_zstd_dec_seq_kernel, nBlocks, 64, st, src, srcSize, frames, blocks, (GcU4*)seqWork, prof, order, ready);
 }
 extern "C" void gc_zstd_dec_launch_exec(hipStream_t st, const uint8_t* src, uint64_t srcSize, uint8_t* dst, uint64_t dstCap, const GcZdFrame* frames, uint32_t nFrames,
-                                        GcZdBlock* blocks, uint32_t* ticket, uint8_t* litWork, uint64_t litWorkSize, void* seqWork, uint64_t* result, unsigned long long* prof)
+                                        GcZdBlock* blocks, uint32_t* ticket, uint8_t* litWork, uint64_t litWorkSize, void* seqWork, uint64_t* result, unsigned long long* prof,
+                                        const uint32_t* ready)
 {
     const uint32_t wg = nFrames < GC_ZD_MAX_WG ? nFrames : GC_ZD_MAX_WG;
-    GC_LAUNCH(gc_zstd_dec_exec_kernel, wg, GC_ZD_T, st, src, srcSize, dst, dstCap, frames, nFrames, (const GcZdBlock*)blocks, ticket, (const uint8_t*)litWork, litWorkSize, (GcU4*)seqWork, result, prof);
+    GC_LAUNCH(gc_zstd_dec_exec_kernel, wg, GC_ZD_T, st, src, srcSize, dst, dstCap, frames, nFrames, (const GcZdBlock*)blocks, ticket, (const uint8_t*)litWork, litWorkSize, (GcU4*)seqWork, result, prof, ready);
 }
