@@ -290,7 +290,8 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
                       uint32_t mergeWords /* neighbouring rc chunks of a segment are coded as ONE LZMA2 chunk while their coded bits stay
                          within this many words (0 = never): a chunk costs 10 bytes (5 of header, 5 of range-coder start / flush), which
                          is 1 % of a well-compressed 4 KiB; the bound keeps the longest range-coder chain what it is for 4 KiB of
-                         incompressible data */)
+                         incompressible data */,
+                      uint32_t wordCap /* words the segment may produce (its reserved place, GC_LZMA_STREAM_WORDS); beyond that it is stored */)
 {
     __shared__ uint16_t P[LZP_TOTAL];
     __shared__ uint32_t sTick[LZ2_TICKS / 4u];                    // ticket bytes (see LZ2_TICKS)
@@ -353,6 +354,7 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
     uint32_t cExit = 0;               // coder state after the last match item (0: state at segment start)
     uint32_t cLits = 0;               // literals coded since the last match item (in cut items)
     uint32_t wpos = 0;                // words written so far
+    bool overflow = false;            // the words of the segment outgrew their reserved place: the segment is stored
 
     unsigned long long tprev = prof ? gc_clock() : 0ull, pc0 = 0, pc1 = 0, pc2 = 0; uint32_t pSteps = 0, pRounds = 0;
 #define L2_PHASE(acc) do { if (prof) { const unsigned long long now_ = gc_clock(); acc += now_ - tprev; tprev = now_; } } while (0)
@@ -440,6 +442,15 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
             gc_wave_sync();
             L2_PHASE(pc1);
             const uint32_t total = evEnd - evDone;
+            // The segment's words have a reserved place (9 per byte: a literal is 9 coded bits).  A match can take more words per byte than that
+            // (a far 3- or 4-byte match: ~40), so a segment of almost only literals plus a few such matches can outgrow it: then it is not coded
+            // at all but stored (found by the randomized round trips: the words ran into the next segment's place and its last chunk was garbage).
+            if (wpos + total > wordCap) {
+#ifdef HIPEMU
+                if (getenv("GC_TRACE_OVF") && lane == 0) fprintf(stderr, "L2 overflow: seg %u (block %u) words %u + %u > %u, items [%u,%u) tile base %u, segment bytes %u\n", seg, b, wpos, total, wordCap, first, last, base, se - ss);
+#endif
+                overflow = true; break;
+            }
             for (uint32_t e0 = 0; e0 < total; e0 += 64u) {
                 const bool valid = e0 + lane < total;
                 const uint32_t ev = valid ? sEv[e0 + lane] : LZE_DIRECT;
@@ -473,6 +484,7 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
             wpos += total; evDone = evEnd; done = upto;
             L2_PHASE(pc2);
         }
+        if (overflow) break;
         // ---- carries
         const uint32_t lastLane = cnt - 1u;
         cursor = gc_readlane(it.pos + it.len, lastLane);
@@ -491,6 +503,14 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
     if (prof && lane == 0u) {
         atomicAdd(&prof[0], pc0); atomicAdd(&prof[1], pc1); atomicAdd(&prof[2], pc2);
         atomicAdd(&prof[3], (unsigned long long)pSteps); atomicAdd(&prof[4], (unsigned long long)pRounds); atomicAdd(&prof[5], 1ull);
+    }
+    if (overflow) {                                                          // (wave-uniform) same marking as for a segment that is not modelled at all
+        for (uint32_t c = lane; c < rcPerSeg; c += 64u) {
+            const uint32_t cs = ss + (c << GC_LZMA_RC_LOG);
+            GcLzmaChunkInfo ci; ci.usize = cs < blockLen ? ((blockLen - cs) < GC_LZMA_RC_SIZE ? (blockLen - cs) : GC_LZMA_RC_SIZE) : 0u;
+            ci.csize = 0xFFFFFFFFu; ci.wordStart = 0; ci.wordEnd = 0; CI[c] = ci;
+        }
+        return;
     }
     // rc chunks -> LZMA2 chunks: greedy groups of neighbours (one lane; at most 32 chunks).  The leader carries the group (its
     // uncompressed size, the word range of all members), the other members are marked absent (usize 0), which is what every

@@ -109,6 +109,19 @@ def test_emu_many_frames_and_parts(O, pkg, emu_lib_path, monkeypatch):
     assert np.array_equal(c1, c2)
 
 
+def test_emu_segment_whose_words_outgrow_their_place_is_stored(O, pkg, emu_lib_path, monkeypatch):
+    """A model segment may produce more coded bits than the 9 per byte its stream has room for (almost only literals plus matches that take many
+    bits each: found by the randomized round trips on PCM-like data, where the overrun clobbered the next segment's words).  Such a segment is
+    stored.  The test hook lowers the cap so that ordinary text takes that path: segments above the cap are stored, the others stay LZMA, and the
+    stream decodes."""
+    x = O.corpus("text-zipf", 3 * BLK + 777)
+    plain = pkg.Flzma2Encoder(lib_path=emu_lib_path, level=5); c0 = _roundtrip(O, plain, x); plain.close()
+    monkeypatch.setenv("GC_SEG_WORD_CAP", "300000")                # a 128 KiB segment of this text needs ~350 000 words, the short last one far fewer
+    capped = pkg.Flzma2Encoder(lib_path=emu_lib_path, level=5); c1 = _roundtrip(O, capped, x); capped.close()
+    assert len(c1) > len(c0) + 2 * BLK // 2                         # whole segments went out stored ...
+    assert len(c1) < x.size + 64                                   # ... but not everything (the short last segment is still LZMA)
+
+
 def test_emu_ratio_band_vs_reference(O, emu_fl2):
     """Size against the reference encoder at level 5 (recorded, and bounded so that regressions show)."""
     if O.ref("flzma2") is None:
