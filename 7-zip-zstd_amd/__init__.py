@@ -30,7 +30,7 @@ EXPORTS = ["gc_device_count", "gc_ctx_create", "gc_ctx_destroy", "gc_last_error_
            "gc_ctx_set_option", "gc_crc32_device", "gc_codec_grain", "gc_codec_compress_bound", "gc_host_begin", "gc_host_size", "gc_host_fetch", "gc_codec_compress_host",
            "gc_host_alloc", "gc_host_free", "gc_multi_create", "gc_multi_destroy", "gc_multi_workers", "gc_multi_last_error",
            "gc_multi_piece_bytes", "gc_multi_compress_host",
-           "gc_bra_convert_device", "gc_bra_x86_convert_device", "gc_delta_convert_device", "gc_zstd_scan_frames", "gc_zstd_scan_prefix", "gc_zstd_decompress_device", "gc_zstd_decompress_host", "gc_zstd_decompress_timing", "gc_zstd_decompress_kernel_timing"]
+           "gc_bra_convert_device", "gc_bra_x86_convert_device", "gc_delta_convert_device", "gc_zstd_scan_frames", "gc_zstd_scan_prefix", "gc_zstd_decompress_device", "gc_zstd_decompress_host", "gc_zstd_decompress_timing", "gc_zstd_decompress_kernel_timing", "gc_zstd_decompress_wide_rounds"]
 
 CODEC_ZSTD, CODEC_FLZMA2, CODEC_BROTLI = 0, 1, 2
 CODEC_IDS = {"zstd": CODEC_ZSTD, "flzma2": CODEC_FLZMA2, "brotli": CODEC_BROTLI}
@@ -428,6 +428,13 @@ class ZstdDecoder(_EncoderBase):
         self._lib.gc_zstd_decompress_kernel_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
         self._check(self._lib.gc_zstd_decompress_kernel_timing(self._ctx, ms), "gc_zstd_decompress_kernel_timing")
         return dict(zip(self.KERNELS, [float(v) for v in ms]))
+
+    def wide_rounds(self):
+        """Pointer-jumping rounds of the last call if it took the wide execution path (0: the frame-per-workgroup kernel ran)."""
+        r = C.c_uint(0)
+        self._lib.gc_zstd_decompress_wide_rounds.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
+        self._check(self._lib.gc_zstd_decompress_wide_rounds(self._ctx, C.byref(r)), "gc_zstd_decompress_wide_rounds")
+        return int(r.value)
 
 
 class ZstdEncoder(_EncoderBase):

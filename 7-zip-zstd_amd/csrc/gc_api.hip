@@ -126,7 +126,7 @@ struct gc_ctx {
     bool pending; bool timed;
     // zstd decoder (gc_zstd_dec.hip): per-workgroup literal / sequence workspace, frame table, per-frame results, ticket counter
     uint8_t* zdLit; size_t zdLitCap; void* zdSeq; size_t zdSeqCap; GcZdFrame* zdFrames; size_t zdFramesCap; uint64_t* zdResult; uint64_t* zdTot;
-    GcZdBlock* zdBlocks; size_t zdBlocksCap; uint32_t* zdOrder; size_t zdOrderCap; uint32_t* zdReady; size_t zdReadyCap; uint32_t* zdTicket; hipEvent_t zdEv[2]; float zdMs; float zdKms[4];   // last call: whole, and index / literals / sequences / execution kernels
+    GcZdBlock* zdBlocks; size_t zdBlocksCap; uint32_t* zdOrder; size_t zdOrderCap; uint32_t* zdReady; size_t zdReadyCap; uint32_t* zdTicket; GcZdPlace* zdPlace; size_t zdPlaceCap; uint32_t* zdPtr; size_t zdPtrCap; uint8_t* zdDone; size_t zdDoneCap; uint32_t* zdFerr; size_t zdFerrCap; uint32_t zdRounds; hipEvent_t zdEv[2]; float zdMs; float zdKms[4];   // last call: whole, and index / literals / sequences / execution kernels
     unsigned long long* prof;  // device: GC_LZ_PHASES + GC_SEQ_PHASES cycle sums, only when profiling is on
     bool profOn; uint32_t profBlocks;
 };
@@ -213,7 +213,7 @@ static void ctx_release(gc_ctx* c)
     if (c->stream) hipStreamSynchronize(c->stream);
     free_workspace(c);
     hipFree(c->prof); hipFree(c->result); if (c->hostResult) hipHostFree(c->hostResult); hipFree(c->dIn); hipFree(c->dOut);
-    hipFree(c->zdLit); hipFree(c->zdSeq); hipFree(c->zdFrames); hipFree(c->zdResult); hipFree(c->zdTot); hipFree(c->zdBlocks); hipFree(c->zdOrder); hipFree(c->zdReady); hipFree(c->zdTicket);
+    hipFree(c->zdLit); hipFree(c->zdSeq); hipFree(c->zdFrames); hipFree(c->zdResult); hipFree(c->zdTot); hipFree(c->zdBlocks); hipFree(c->zdOrder); hipFree(c->zdReady); hipFree(c->zdTicket); hipFree(c->zdPlace); hipFree(c->zdPtr); hipFree(c->zdDone); hipFree(c->zdFerr);
     for (int i = 0; i < 2; i++) if (c->zdEv[i]) hipEventDestroy(c->zdEv[i]);
     hipFree(c->mfCnt); hipFree(c->mfEnt); hipFree(c->mfEnt2); hipFree(c->mfRec); hipFree(c->mfRec2); hipFree(c->mfRec3); hipFree(c->mfDp); hipFree(c->mfPrice); hipFree(c->mfWinCost); hipFree(c->mfDpStat);
     for (int i = 0; i < 8; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
@@ -903,6 +903,12 @@ extern "C" void gc_zstd_dec_launch_exec(hipStream_t st, const uint8_t* src, uint
                                         GcZdBlock* blocks, uint32_t* ticket, uint8_t* litWork, uint64_t litWorkSize, void* seqWork, uint64_t* result, unsigned long long* prof,
                                         const uint32_t* ready);
 
+extern "C" void gc_zstd_dec_launch_place(hipStream_t st, const GcZdFrame* frames, uint32_t nFrames, const GcZdBlock* blocks, uint64_t dstCap, GcZdPlace* place, uint64_t* result, uint32_t* ferr);
+extern "C" void gc_zstd_dec_launch_spread(hipStream_t st, const uint8_t* src, uint64_t srcSize, uint8_t* dst, const GcZdFrame* frames, const GcZdBlock* blocks, uint32_t nBlocks,
+                                          const GcZdPlace* place, const uint8_t* litWork, uint64_t litWorkSize, const void* seqWork, uint32_t* ptr, uint64_t batchBase, uint32_t* ferr);
+extern "C" void gc_zstd_dec_launch_chase(hipStream_t st, uint8_t* dstBatch, uint32_t* ptr, uint32_t n, uint32_t hops, uint8_t* pieceDone, uint32_t* counter);
+extern "C" void gc_zstd_dec_launch_finish(hipStream_t st, const uint8_t* src, const uint8_t* dst, const GcZdFrame* frames, uint32_t nFrames, uint64_t* result, const uint32_t* ferr);
+
 static int zd_grow(gc_ctx* c, void** p, size_t* cap, size_t need)
 {
     if (need <= *cap) return GC_OK;
@@ -917,14 +923,14 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
 {
     if (!c || (!d_src && n) || (!d_dst && dstCap) || (!frames && nFrames)) return GC_ERR_PARAM;
     HIPCHK(c, hipSetDevice(c->device));
-    c->zdMs = 0.f; c->zdKms[0] = c->zdKms[1] = c->zdKms[2] = c->zdKms[3] = 0.f;
+    c->zdMs = 0.f; c->zdKms[0] = c->zdKms[1] = c->zdKms[2] = c->zdKms[3] = 0.f; c->zdRounds = 0;
     if (outSize) *outSize = 0;
     if (!nFrames) return GC_OK;
     GcZdFrame* h = (GcZdFrame*)calloc(nFrames, sizeof(GcZdFrame));
     uint64_t* res = (uint64_t*)malloc(nFrames * 16u);           // per frame results; also the (literal bytes, sequence records) totals of the index pass
     if (!h || !res) { free(h); free(res); return GC_ERR_NOMEM; }
     int rc = GC_OK;
-    if (!c->zdTicket && hipMalloc((void**)&c->zdTicket, 4) != hipSuccess) rc = GC_ERR_NOMEM;
+    if (!c->zdTicket && hipMalloc((void**)&c->zdTicket, 8) != hipSuccess) rc = GC_ERR_NOMEM;      // [0] the execution kernel's frame ticket, [1] the chase kernel's count
     for (int i = 0; i < 2 && rc == GC_OK; i++) if (!c->zdEv[i] && hipEventCreate(&c->zdEv[i]) != hipSuccess) rc = GC_ERR_HIP;
     // test hook GC_ZD_PROF=1: shader cycles of the execution kernel's phases (thread 0's view, summed over blocks) on stderr
     unsigned long long* zdProf = nullptr;
@@ -980,6 +986,18 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
         overlap = false;
 #endif
         { uint32_t v = 0; if (gc_env_u32("GC_ZD_OVERLAP", 0, 1, &v)) overlap = overlap && v != 0u; }
+        // The wide execution (all blocks of all frames at once through byte pointers and pointer jumping, see gc_zstd_dec.hip) instead of one workgroup
+        // per frame that copies its blocks in order (~0.27 GB/s per frame): 1 GB in 120 frames 13.7 ms against 49 ms, and it does not care how few
+        // the frames are (one frame of 128 MiB: 4.7 against 460 ms).  It needs 4 bytes of workspace per content byte; frames of one block each stay
+        // with the frame kernel (nothing to gain there).  Hook GC_ZD_WIDE = 0 / 1 forces the choice.
+        bool wide = nBlocks >= 2u * cnt;
+        { uint32_t v = 0; if (gc_env_u32("GC_ZD_WIDE", 0, 1, &v)) wide = v != 0u; }
+        {   // the 32-bit positions of the wide path must cover the batch (a frame of unknown size may grow up to the end of the destination)
+            const GcZdFrame& lastF = h[j - 1];
+            const uint64_t extentMax = (lastF.flags & GC_ZD_F_SIZE_KNOWN) ? off - h[i].dstOff : dstCap - h[i].dstOff;
+            if (extentMax > GC_ZD_WIDE_MAX) wide = false;
+        }
+        if (wide) overlap = false;
         if ((rc = zd_grow(c, (void**)&c->zdOrder, &c->zdOrderCap, (size_t)nBlocks * 4u)) != GC_OK) break;
         if ((rc = zd_grow(c, (void**)&c->zdReady, &c->zdReadyCap, (size_t)nBlocks * 4u)) != GC_OK) break;
         {
@@ -1007,7 +1025,46 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
         gc_zstd_dec_launch_sequences(c->stream, (const uint8_t*)d_src, n, c->zdFrames, c->zdBlocks, (uint32_t)nBlocks, c->zdSeq, zdProf, c->zdOrder, c->zdReady);
         hipEventRecord(c->evPart[1][1], c->stream);
         hipStreamWaitEvent(c->stream, c->evPart[0][1], 0);
-        if (!overlap) {
+        if (wide) {
+            hipEventRecord(c->evPart[1][3], c->stream);
+            if ((rc = zd_grow(c, (void**)&c->zdPlace, &c->zdPlaceCap, (size_t)nBlocks * sizeof(GcZdPlace))) != GC_OK) break;
+            if ((rc = zd_grow(c, (void**)&c->zdFerr, &c->zdFerrCap, cnt * 4u)) != GC_OK) break;
+            gc_zstd_dec_launch_place(c->stream, c->zdFrames, (uint32_t)cnt, c->zdBlocks, dstCap, c->zdPlace, c->zdResult, c->zdFerr);
+            if (hipMemcpyAsync(res, c->zdResult, cnt * 8u, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+                snprintf(c->err, sizeof(c->err), "decode kernels failed: %s", hipGetErrorString(hipGetLastError())); rc = GC_ERR_HIP; break;
+            }
+            uint64_t extent = 0;                                   // content bytes of the batch, from its first byte
+            for (size_t k = 0; k < cnt; k++) { const uint64_t e = h[i + k].dstOff - h[i].dstOff + (res[k] & 0x00FFFFFFFFFFFFFFull); if (e > extent) extent = e; }
+            const uint64_t padded = (extent + 4095u) & ~4095ull;
+            uint32_t noRoom = 0; gc_env_u32("GC_ZD_WIDE_NOMEM", 1u, 1u, &noRoom);               // test hook: as if the workspace could not be had
+            if (noRoom || zd_grow(c, (void**)&c->zdPtr, &c->zdPtrCap, (size_t)padded * 4u + 16u) != GC_OK || zd_grow(c, (void**)&c->zdDone, &c->zdDoneCap, (size_t)(padded / 1024u) + 16u) != GC_OK) {
+                wide = false; c->err[0] = 0;                       // no room for the pointers: the frame kernel does it
+            }
+        }
+        if (wide) {
+            uint64_t extent = 0;
+            for (size_t k = 0; k < cnt; k++) { const uint64_t e = h[i + k].dstOff - h[i].dstOff + (res[k] & 0x00FFFFFFFFFFFFFFull); if (e > extent) extent = e; }
+            const uint64_t padded = (extent + 4095u) & ~4095ull;
+            if (hipMemsetAsync(c->zdPtr, 0xFF, (size_t)padded * 4u, c->stream) != hipSuccess || hipMemsetAsync(c->zdDone, 0, (size_t)(padded / 1024u) + 16u, c->stream) != hipSuccess) { rc = GC_ERR_HIP; break; }
+            gc_zstd_dec_launch_spread(c->stream, (const uint8_t*)d_src, n, (uint8_t*)d_dst, c->zdFrames, c->zdBlocks, (uint32_t)nBlocks, c->zdPlace, c->zdLit, litTot + 64u, c->zdSeq,
+                                      c->zdPtr, h[i].dstOff, c->zdFerr);
+            uint32_t round = 0, hops = 0;                          // (0: the kernel's own number of links per round; test hook GC_ZD_HOPS)
+            gc_env_u32("GC_ZD_HOPS", 1u, 64u, &hops);
+            for (; extent && round < 64u; round++) {
+                uint32_t left = 0;
+                hipMemsetAsync(c->zdTicket + 1, 0, 4, c->stream);
+                gc_zstd_dec_launch_chase(c->stream, (uint8_t*)d_dst + h[i].dstOff, c->zdPtr, (uint32_t)extent, hops, c->zdDone, c->zdTicket + 1);
+                if (hipMemcpyAsync(&left, c->zdTicket + 1, 4, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) {
+                    snprintf(c->err, sizeof(c->err), "decode kernels failed: %s", hipGetErrorString(hipGetLastError())); rc = GC_ERR_HIP; break;
+                }
+                if (!left) break;
+            }
+            if (rc != GC_OK) break;
+            if (round >= 64u) { snprintf(c->err, sizeof(c->err), "wide execution did not settle"); rc = GC_ERR_HIP; break; }      // (a chain of 2^32 bytes takes 33 rounds)
+            c->zdRounds += round + 1u;
+            gc_zstd_dec_launch_finish(c->stream, (const uint8_t*)d_src, (const uint8_t*)d_dst, c->zdFrames, (uint32_t)cnt, c->zdResult, c->zdFerr);
+            hipEventRecord(c->evPart[1][4], c->stream);
+        } else if (!overlap) {
             hipEventRecord(c->evPart[1][3], c->stream);
             gc_zstd_dec_launch_exec(c->stream, (const uint8_t*)d_src, n, (uint8_t*)d_dst, dstCap, c->zdFrames, (uint32_t)cnt, c->zdBlocks, c->zdTicket,
                                     c->zdLit, litTot + 64u, c->zdSeq, c->zdResult, zdProf, c->zdReady);
@@ -1052,6 +1109,8 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
 
 extern "C" int gc_zstd_decompress_timing(gc_ctx* c, float* ms) { if (!c || !ms) return GC_ERR_PARAM; *ms = c->zdMs; return GC_OK; }
 extern "C" int gc_zstd_decompress_kernel_timing(gc_ctx* c, float ms[4]) { if (!c || !ms) return GC_ERR_PARAM; for (int i = 0; i < 4; i++) ms[i] = c->zdKms[i]; return GC_OK; }
+
+extern "C" int gc_zstd_decompress_wide_rounds(gc_ctx* c, unsigned* rounds) { if (!c || !rounds) return GC_ERR_PARAM; *rounds = c->zdRounds; return GC_OK; }
 
 extern "C" int gc_zstd_decompress_host(gc_ctx* c, const void* src, size_t n, void* dst, size_t dstCap, size_t* outSize)
 {

@@ -49,6 +49,10 @@ struct GcZdBlock {
 // and puts the real values in.
 #define GC_ZD_SYM 0x80000000u
 
+// wide execution: where a block's content starts inside its frame, the repeat offsets it starts with, and whether the frame has already failed there
+struct GcZdPlace { uint64_t dst; uint32_t rep[3]; uint32_t skip; };
+#define GC_ZD_WIDE_MAX  0xFFF00000ull                 // content bytes of a batch the 32-bit positions of the wide path can address
+
 #define GC_ZD_T         1024u                         // execution kernel
 #define GC_ZD_MAX_WG    256u                          // frames in execution at a time (129 KB of LDS: one workgroup per CU)
 #define GC_ZD_CHUNK     1024u                         // bytes of the sequence bitstream staged in LDS at a time

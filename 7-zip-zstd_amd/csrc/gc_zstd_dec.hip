@@ -1003,6 +1003,225 @@ gc_zstd_dec_exec_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint8
     }
 }
 
+// =============================================================== wide execution ===============================================================
+// The execution kernel above copies one frame per workgroup, its blocks in order: the unit of parallelism is the frame, and a stream of few large
+// frames (what the reference's single-threaded encoder writes) leaves the machine empty.  The wide path executes ALL blocks of ALL frames at once.
+// A match byte cannot be copied before its source exists, so every content byte first gets a POINTER instead of a value:
+//   place   one wave per frame walks its blocks (sizes and repeat offsets behind every block are known from the entropy stage): where each block's
+//           content starts, which repeat offsets it starts with, whether the frame is still sound there;
+//   spread  one workgroup per block: literal bytes go to their place (they are final), every match byte p gets ptr[p] = p - offset; a final
+//           byte's entry is a MARK that carries the byte itself (0xFFFFFF00 | byte);
+//   chase   rounds over all bytes that are not final: w = ptr[ptr[p]]; if w is a mark, the byte is known: store it and take the mark over;
+//           else ptr[p] = w (pointer jumping: the distance to the literal at the end of the chain at least halves per round, so a chain of
+//           length L takes at most log2 L rounds; a byte follows up to GC_ZW_HOPS links per round, which saves passes over the array).
+//           Because a mark holds the value, whatever a lane reads is usable at once, also what another lane wrote a moment ago -- no ordering
+//           inside a launch is needed, stale reads only cost a round.  Each XCD sweeps its own contiguous eighth of the content in address
+//           order, so that a byte's source mostly lies where the same L2 has already seen it settle.  Pieces of 1 KiB that are final
+//           everywhere are skipped from then on;
+//   finish  per frame: size checks and the content checksum.
+// ptr entries are positions relative to the first content byte of the batch.
+#define GC_ZW_FINAL      0xFFFFFF00u              // ptr values from here on are marks: 0xFFFFFF00 | the byte
+#define GC_ZW_PIECE      1024u                    // bytes per "all final" flag
+#define GC_ZW_WG_BYTES   4096u                    // bytes per workgroup of the chase kernel
+#define GC_ZW_HOPS       12                       // links a byte follows per round (1 GB of text: 1 link 7 rounds 51.9 ms, 4 links 3 rounds 18.5 ms, 12 links 2 rounds 13.7 ms)
+#define GC_ZW_LANE_MAX   48u                      // literal runs / matches up to this length are written by the sequence's own lane
+
+extern "C" __global__ void __launch_bounds__(64)
+gc_zstd_dec_place_kernel(const GcZdFrame* __restrict__ frames, uint32_t nFrames, const GcZdBlock* __restrict__ blocks, uint64_t dstCap, GcZdPlace* __restrict__ place,
+                         uint64_t* __restrict__ result, uint32_t* __restrict__ ferr)
+{
+    __shared__ uint32_t sIn[64][8];               // type, status, litStatus, size, rep[3]
+    __shared__ GcZdPlace sOut[64];
+    const uint32_t f = blockIdx.x, lane = threadIdx.x;
+    if (f >= nFrames) return;
+    const GcZdFrame fr = frames[f];
+    const uint64_t cap = (fr.flags & GC_ZD_F_SIZE_KNOWN) ? fr.contentSize : (dstCap - fr.dstOff);
+    uint64_t produced = 0;
+    uint32_t r0 = 1, r1 = 4, r2 = 8, status = GC_ZD_OK;
+    for (uint32_t b0 = 0; b0 < fr.nBlocks; b0 += 64u) {
+        const uint32_t cnt = fr.nBlocks - b0 < 64u ? fr.nBlocks - b0 : 64u;
+        if (lane < cnt) {
+            const GcZdBlock* e = blocks + fr.blockBase + b0 + lane;
+            const uint32_t ty = e->type;
+            sIn[lane][0] = ty; sIn[lane][1] = e->status; sIn[lane][2] = e->litStatus; sIn[lane][3] = (ty & 3u) == 2u ? e->outSize : e->regen;
+            sIn[lane][4] = e->rep[0]; sIn[lane][5] = e->rep[1]; sIn[lane][6] = e->rep[2];
+        }
+        __syncthreads();
+        if (lane == 0) for (uint32_t k = 0; k < cnt; k++) {
+            const uint32_t ty = sIn[k][0], bt = ty & 3u, size = sIn[k][3];
+            if (!status) {
+                if (ty & GC_ZD_B_BAD) status = GC_ZD_CORRUPT;
+                else if (bt == 2u && (sIn[k][1] || sIn[k][2])) status = sIn[k][1] ? sIn[k][1] : sIn[k][2];
+                else if (produced + size > cap) status = GC_ZD_DST_SMALL;
+            }
+            GcZdPlace pl; pl.dst = produced; pl.rep[0] = r0; pl.rep[1] = r1; pl.rep[2] = r2; pl.skip = status ? 1u : 0u;
+            sOut[k] = pl;
+            if (!status) {
+                if (bt == 2u) {
+                    uint32_t out[3];
+                    for (int i = 0; i < 3; i++) {
+                        uint32_t v = sIn[k][4 + i];
+                        if (v & GC_ZD_SYM) { const uint32_t kk = v & 3u, delta = (v & 0x7FFFFFFFu) >> 2, in = kk == 0u ? r0 : (kk == 1u ? r1 : r2); v = in > delta ? in - delta : 1u; }
+                        out[i] = v;
+                    }
+                    r0 = out[0]; r1 = out[1]; r2 = out[2];
+                }
+                produced += size;
+            }
+        }
+        __syncthreads();
+        if (lane < cnt) place[fr.blockBase + b0 + lane] = sOut[lane];
+        __syncthreads();
+        status = gc_readlane(status, 0); r0 = gc_readlane(r0, 0); r1 = gc_readlane(r1, 0); r2 = gc_readlane(r2, 0);
+        produced = (uint64_t)gc_readlane((uint32_t)produced, 0) | ((uint64_t)gc_readlane((uint32_t)(produced >> 32), 0) << 32);
+    }
+    if (lane == 0) { result[f] = produced | ((uint64_t)status << 56); ferr[f] = 0; }
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+gc_zstd_dec_spread_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint8_t* __restrict__ dst, const GcZdFrame* __restrict__ frames, const GcZdBlock* __restrict__ blocks,
+                          const GcZdPlace* __restrict__ place, const uint8_t* __restrict__ litWork, uint64_t litWorkSize, const GcU4* __restrict__ seqWork,
+                          uint32_t* __restrict__ ptr, uint64_t batchBase, uint32_t* __restrict__ ferr)
+{
+    __shared__ uint32_t sList[256];
+    __shared__ uint32_t sCount;
+    const uint32_t t = threadIdx.x, b = blockIdx.x;
+    const GcZdPlace pl = place[b];
+    if (pl.skip) return;
+    const GcZdBlock e = blocks[b];
+    const GcZdFrame fr = frames[e.frame];
+    const uint32_t bt = e.type & 3u;
+    const uint8_t* const bsrc = src + e.srcOff;
+    uint8_t* const bdst = dst + fr.dstOff + pl.dst;
+    const uint32_t P = (uint32_t)(fr.dstOff - batchBase + pl.dst);                 // the block's first byte as a ptr index
+    uint32_t* const bptr = ptr + P;
+    if (bt == 0u) { for (uint32_t i = t; i < e.regen; i += 256u) { const uint8_t v = bsrc[i]; bdst[i] = v; bptr[i] = GC_ZW_FINAL | v; } return; }
+    if (bt == 1u) { const uint8_t v = bsrc[0]; for (uint32_t i = t; i < e.regen; i += 256u) { bdst[i] = v; bptr[i] = GC_ZW_FINAL | v; } return; }
+    const uint32_t nSeq = e.nSeq, lt = e.litInfo & 3u;
+    const uint8_t* const litSrc = lt >= 2u ? litWork + fr.litBase + e.litOff : bsrc + (e.litInfo >> 8);
+    const uint8_t rleByte = lt == 1u ? bsrc[e.litInfo >> 8] : (uint8_t)0;
+    const GcU4* const seq = seqWork + fr.seqBase + e.seqOff;
+    uint32_t bad = 0;
+    for (uint32_t j0 = 0; j0 < nSeq; j0 += 256u) {
+        if (t == 0) sCount = 0;
+        __syncthreads();
+        const uint32_t j = j0 + t;
+        if (j < nSeq) {
+            const GcU4 rec = seq[j];
+            const uint32_t ll = rec.x & 0x3FFFFu, ml = (rec.x >> 18) | ((rec.y & 15u) << 14), lp = rec.y >> 4, dp = rec.w;
+            uint32_t off = rec.z;
+            bool ok = true;
+            if (off & GC_ZD_SYM) {
+                const uint32_t k = off & 3u, delta = (off & 0x7FFFFFFFu) >> 2, in = pl.rep[k == 0u ? 0 : (k == 1u ? 1 : 2)];
+                if (in <= delta) ok = false; else off = in - delta;
+            }
+            const uint32_t d = dp + ll;
+            if (ok && (uint64_t)off > pl.dst + d) ok = false;
+            if (!ok) bad = 1;
+            else if (ll > GC_ZW_LANE_MAX || ml > GC_ZW_LANE_MAX) sList[atomicAdd(&sCount, 1u)] = j;
+            else {
+                for (uint32_t k = 0; k < ll; k++) { const uint8_t v = lt == 1u ? rleByte : litSrc[lp + k]; bdst[dp + k] = v; bptr[dp + k] = GC_ZW_FINAL | v; }
+                const uint32_t q0 = P + d - off;
+                for (uint32_t k = 0; k < ml; k++) bptr[d + k] = q0 + k;
+            }
+        }
+        __syncthreads();
+        const uint32_t nLong = sCount;
+        for (uint32_t i = 0; i < nLong; i++) {                                     // long runs: the whole workgroup
+            const GcU4 rec = seq[sList[i]];
+            const uint32_t ll = rec.x & 0x3FFFFu, ml = (rec.x >> 18) | ((rec.y & 15u) << 14), lp = rec.y >> 4, dp = rec.w;
+            uint32_t off = rec.z;
+            if (off & GC_ZD_SYM) { const uint32_t k = off & 3u, delta = (off & 0x7FFFFFFFu) >> 2; off = pl.rep[k == 0u ? 0 : (k == 1u ? 1 : 2)] - delta; }
+            const uint32_t d = dp + ll, q0 = P + d - off;
+            for (uint32_t k = t; k < ll; k += 256u) { const uint8_t v = lt == 1u ? rleByte : litSrc[lp + k]; bdst[dp + k] = v; bptr[dp + k] = GC_ZW_FINAL | v; }
+            for (uint32_t k = t; k < ml; k += 256u) bptr[d + k] = q0 + k;
+        }
+        __syncthreads();
+    }
+    {
+        const uint32_t lp = e.lposEnd, dp = e.dposEnd, rest = e.regen - lp;
+        for (uint32_t k = t; k < rest; k += 256u) { const uint8_t v = lt == 1u ? rleByte : litSrc[lp + k]; bdst[dp + k] = v; bptr[dp + k] = GC_ZW_FINAL | v; }
+    }
+    if (bad) atomicMax(&ferr[e.frame], (uint32_t)GC_ZD_CORRUPT);
+}
+
+extern "C" __global__ void __launch_bounds__(256)
+gc_zstd_dec_chase_kernel(uint8_t* dst /* first content byte of the batch */, uint32_t* ptr, uint32_t n, uint32_t groupsPerXcd, uint32_t hops, uint8_t* pieceDone, uint32_t* counter)
+{
+    __shared__ uint32_t sLeft;
+    const uint32_t t = threadIdx.x;
+    // workgroups go round the XCDs (blockIdx % 8): XCD x takes the groups [x * groupsPerXcd, (x + 1) * groupsPerXcd) in order
+    const uint32_t group = (blockIdx.x & 7u) * groupsPerXcd + (blockIdx.x >> 3);
+    for (uint32_t it = 0; it < GC_ZW_WG_BYTES / GC_ZW_PIECE; it++) {
+        const uint32_t piece = group * (GC_ZW_WG_BYTES / GC_ZW_PIECE) + it;
+        const uint32_t p = piece * GC_ZW_PIECE + t * 4u;
+        if ((uint64_t)piece * GC_ZW_PIECE >= n) break;
+        if (pieceDone[piece]) continue;
+        if (t == 0) sLeft = 0;
+        __syncthreads();
+        GcU4 v = *(const GcU4*)(ptr + p);                                          // (the array is padded with marks up to a whole workgroup)
+        uint32_t x[4] = { v.x, v.y, v.z, v.w };
+        uint32_t left = 0; bool changed = false;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            uint32_t w = x[i];
+            if (w >= GC_ZW_FINAL) continue;
+            for (uint32_t hop = 0; hop < hops && w < GC_ZW_FINAL; hop++) w = ptr[w];      // a few links per round: fewer passes over the array
+            x[i] = w; changed = true;
+            if (w >= GC_ZW_FINAL) dst[p + (uint32_t)i] = (uint8_t)w; else left++;
+        }
+        if (changed) { v.x = x[0]; v.y = x[1]; v.z = x[2]; v.w = x[3]; *(GcU4*)(ptr + p) = v; }
+        if (left) atomicAdd(&sLeft, left);
+        __syncthreads();
+        if (t == 0) { if (sLeft) atomicAdd(counter, sLeft); else pieceDone[piece] = 1; }
+        __syncthreads();
+    }
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+gc_zstd_dec_finish_kernel(const uint8_t* __restrict__ src, const uint8_t* __restrict__ dst, const GcZdFrame* __restrict__ frames, uint32_t nFrames, uint64_t* __restrict__ result,
+                          const uint32_t* __restrict__ ferr)
+{
+    __shared__ uint64_t sAcc[4];
+    const uint32_t f = blockIdx.x, t = threadIdx.x;
+    if (f >= nFrames) return;
+    const GcZdFrame fr = frames[f];
+    const uint64_t r = result[f], produced = r & 0x00FFFFFFFFFFFFFFull;
+    uint32_t status = (uint32_t)(r >> 56);
+    if (!status && ferr[f]) status = ferr[f];
+    if (!status && fr.nBlocks == 0u) status = GC_ZD_CORRUPT;
+    if (!status && (fr.flags & GC_ZD_F_SIZE_KNOWN) && produced != fr.contentSize) status = GC_ZD_SIZE;
+    if (!status && (fr.flags & GC_ZD_F_CHECKSUM)) {
+        const uint8_t* const fdst = dst + fr.dstOff;
+        const uint8_t* const fsrc = src + fr.srcOff;
+        const uint64_t srcEnd = fr.srcSize - 4u;
+        const uint64_t nStripes = produced >> 5;
+        if (t < 4u) {                                                              // XXH64, seed 0: lanes 0..3 are the four accumulators
+            uint64_t acc = t == 0u ? XP1 + XP2 : (t == 1u ? XP2 : (t == 2u ? 0ull : 0ull - XP1));
+            const uint8_t* q = fdst + 8u * t;
+            for (uint64_t s = 0; s < nStripes; s++) acc = zd_xround(acc, gc_ld64(q + (s << 5)));
+            sAcc[t] = acc;
+        }
+        __syncthreads();
+        if (t == 0) {
+            uint64_t h;
+            if (produced >= 32u) {
+                h = zd_rotl(sAcc[0], 1) + zd_rotl(sAcc[1], 7) + zd_rotl(sAcc[2], 12) + zd_rotl(sAcc[3], 18);
+                for (int k = 0; k < 4; k++) h = (h ^ zd_xround(0, sAcc[k])) * XP1 + XP4;
+            } else h = XP5;
+            h += produced;
+            uint64_t pos = nStripes << 5;
+            while (pos + 8u <= produced) { h ^= zd_xround(0, gc_ld64(fdst + pos)); h = zd_rotl(h, 27) * XP1 + XP4; pos += 8u; }
+            if (pos + 4u <= produced) { h ^= (uint64_t)gc_ld32(fdst + pos) * XP1; h = zd_rotl(h, 23) * XP2 + XP3; pos += 4u; }
+            while (pos < produced) { h ^= (uint64_t)fdst[pos] * XP5; h = zd_rotl(h, 11) * XP1; pos++; }
+            h ^= h >> 33; h *= XP2; h ^= h >> 29; h *= XP3; h ^= h >> 32;
+            const uint32_t want = (uint32_t)fsrc[srcEnd] | ((uint32_t)fsrc[srcEnd + 1] << 8) | ((uint32_t)fsrc[srcEnd + 2] << 16) | ((uint32_t)fsrc[srcEnd + 3] << 24);
+            if ((uint32_t)h != want) status = GC_ZD_CHECKSUM;
+        }
+    }
+    if (t == 0) result[f] = produced | ((uint64_t)status << 56);
+}
+
 // ---- host: frame scan (headers only) ----
 static uint32_t zd_le32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 
@@ -1110,4 +1329,24 @@ extern "C" void gc_zstd_dec_launch_exec(hipStream_t st, const uint8_t* src, uint
 {
     const uint32_t wg = nFrames < GC_ZD_MAX_WG ? nFrames : GC_ZD_MAX_WG;
     GC_LAUNCH(gc_zstd_dec_exec_kernel, wg, GC_ZD_T, st, src, srcSize, dst, dstCap, frames, nFrames, (const GcZdBlock*)blocks, ticket, (const uint8_t*)litWork, litWorkSize, (GcU4*)seqWork, result, prof, ready);
+}
+
+// ---- wide execution (all blocks of all frames at once; see the kernels) ----
+extern "C" void gc_zstd_dec_launch_place(hipStream_t st, const GcZdFrame* frames, uint32_t nFrames, const GcZdBlock* blocks, uint64_t dstCap, GcZdPlace* place, uint64_t* result, uint32_t* ferr)
+{
+    if (nFrames) GC_LAUNCH(gc_zstd_dec_place_kernel, nFrames, 64, st, frames, nFrames, blocks, dstCap, place, result, ferr);
+}
+extern "C" void gc_zstd_dec_launch_spread(hipStream_t st, const uint8_t* src, uint64_t srcSize, uint8_t* dst, const GcZdFrame* frames, const GcZdBlock* blocks, uint32_t nBlocks,
+                                          const GcZdPlace* place, const uint8_t* litWork, uint64_t litWorkSize, const void* seqWork, uint32_t* ptr, uint64_t batchBase, uint32_t* ferr)
+{
+    if (nBlocks) GC_LAUNCH(gc_zstd_dec_spread_kernel, nBlocks, 256, st, src, srcSize, dst, frames, blocks, place, litWork, litWorkSize, (const GcU4*)seqWork, ptr, batchBase, ferr);
+}
+extern "C" void gc_zstd_dec_launch_chase(hipStream_t st, uint8_t* dstBatch, uint32_t* ptr, uint32_t n, uint32_t hops, uint8_t* pieceDone, uint32_t* counter)
+{
+    const uint32_t groups = (uint32_t)(((uint64_t)n + GC_ZW_WG_BYTES - 1u) / GC_ZW_WG_BYTES), perXcd = (groups + 7u) / 8u;
+    if (groups) GC_LAUNCH(gc_zstd_dec_chase_kernel, perXcd * 8u, 256, st, dstBatch, ptr, n, perXcd, hops ? hops : (uint32_t)GC_ZW_HOPS, pieceDone, counter);
+}
+extern "C" void gc_zstd_dec_launch_finish(hipStream_t st, const uint8_t* src, const uint8_t* dst, const GcZdFrame* frames, uint32_t nFrames, uint64_t* result, const uint32_t* ferr)
+{
+    if (nFrames) GC_LAUNCH(gc_zstd_dec_finish_kernel, nFrames, 64, st, src, dst, frames, nFrames, result, ferr);
 }

@@ -225,6 +225,9 @@ int         gc_zstd_decompress_host(gc_ctx* ctx, const void* src, size_t n, void
 int         gc_zstd_decompress_timing(gc_ctx* ctx, float* ms);
 /* ... and of its kernels: ms[0] index, ms[1] literals (second stream, beside the sequences), ms[2] sequences, ms[3] execution */
 int         gc_zstd_decompress_kernel_timing(gc_ctx* ctx, float ms[4]);
+/* pointer-jumping rounds of the last call when it took the wide execution path (all blocks of all frames at once: batches of few frames),
+ * 0 when every batch went through the frame-per-workgroup execution kernel */
+int         gc_zstd_decompress_wide_rounds(gc_ctx* ctx, unsigned* rounds);
 
 /* raw stream handle (hipStream_t) so callers can order their own work against the context */
 void*       gc_ctx_stream(gc_ctx* ctx);

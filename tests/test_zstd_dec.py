@@ -143,7 +143,57 @@ def test_emu_damaged_streams_are_refused(pkg, O, emu_dec):
         emu_dec.code(b"\x00" * 16)                                             # not a zstd stream
 
 
+def _both_paths(pkg, O, lib_kw, monkeypatch, sizes, flips):
+    """The two execution stages (one workgroup per frame, blocks in order / all blocks at once through byte pointers and pointer jumping) must
+    give the same bytes and the same verdicts; by default frames of more than one block take the wide one (wide_rounds() says which ran)."""
+    x = _corpus(O, "silesia-like", sizes[0]).tobytes()
+    z = np.zeros(sizes[1], dtype=np.uint8); z[::4097] = 7; z = z.tobytes()                     # long chains: every match copies the one before
+    streams = [(O.ref_zstd_compress(x, 3).tobytes(), x), (O.ref_zstd_compress_opts(x, 19, checksum=True, streamed=True).tobytes(), x),
+               (O.ref_zstd_compress(x, 5, piece=len(x) // 5 + 1).tobytes(), x), (O.ref_zstd_compress_opts(z, 3, checksum=True).tobytes(), z)]
+    bad = bytearray(streams[1][0]); verdicts = []
+    for wide in ("0", "1"):
+        monkeypatch.setenv("GC_ZD_WIDE", wide)
+        dec = pkg.ZstdDecoder(**lib_kw)
+        try:
+            for comp, want in streams:
+                _check(dec, comp, want)
+                assert (dec.wide_rounds() > 0) == (wide == "1")
+            verdicts.append([])
+            for pos in range(len(bad) // 2, len(bad) // 2 + flips):                                # (the frame carries a checksum: refused or the same content)
+                bad[pos] ^= 0x10
+                try:
+                    assert dec.code(bytes(bad), capacity=len(x) + 64).tobytes() == x; verdicts[-1].append(0)
+                except pkg.GpuCodecError:
+                    verdicts[-1].append(1)
+                bad[pos] ^= 0x10
+            with pytest.raises(pkg.GpuCodecError):
+                dec.code(streams[1][0], capacity=len(x) - 1)                                    # (a frame that does not state its size)
+        finally:
+            dec.close()
+    assert verdicts[0] == verdicts[1] and sum(verdicts[0]) >= flips * 3 // 4
+    monkeypatch.delenv("GC_ZD_WIDE")
+    dec = pkg.ZstdDecoder(**lib_kw)
+    try:
+        _check(dec, streams[0][0], x); assert dec.wide_rounds() > 0                             # frames of several blocks: wide by default
+        _check(dec, streams[2][0], x); assert (dec.wide_rounds() > 0) == (len(x) // 5 > 131072)
+        ones = O.ref_zstd_compress(x[:1_000_000], 3, piece=100_000).tobytes()
+        _check(dec, ones, x[:1_000_000]); assert dec.wide_rounds() == 0                         # frames of one block each: one workgroup per frame
+        monkeypatch.setenv("GC_ZD_WIDE_NOMEM", "1")                                             # no room for the pointers: the frame kernel steps in
+        _check(dec, streams[1][0], x); assert dec.wide_rounds() == 0
+    finally:
+        dec.close()
+
+
+def test_emu_both_execution_paths(pkg, O, emu_lib_path, monkeypatch):
+    _both_paths(pkg, O, dict(lib_path=emu_lib_path), monkeypatch, (280_000, 150_000), 4)
+
+
 # ------------------------------------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_gpu_both_execution_paths(pkg, O, gpu_dec, monkeypatch):
+    _both_paths(pkg, O, dict(device=0), monkeypatch, (48 * MiB + 321, 32 * MiB), 24)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", KINDS)
 def test_gpu_reference_streams(O, gpu_dec, kind):
