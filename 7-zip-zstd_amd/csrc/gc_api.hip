@@ -898,7 +898,7 @@ extern "C" void gc_zstd_dec_launch_index(hipStream_t st, const uint8_t* src, con
 extern "C" void gc_zstd_dec_launch_literals(hipStream_t st, const uint8_t* src, uint64_t srcSize, const GcZdFrame* frames, GcZdBlock* blocks, uint32_t nBlocks, uint8_t* litWork,
                                             unsigned long long* prof, const uint32_t* order, uint32_t* ready);
 extern "C" void gc_zstd_dec_launch_sequences(hipStream_t st, const uint8_t* src, uint64_t srcSize, const GcZdFrame* frames, GcZdBlock* blocks, uint32_t nBlocks, void* seqWork,
-                                             unsigned long long* prof, const uint32_t* order, uint32_t* ready);
+                                             unsigned long long* prof, const uint32_t* order, uint32_t* ready, int several);
 extern "C" void gc_zstd_dec_launch_exec(hipStream_t st, const uint8_t* src, uint64_t srcSize, uint8_t* dst, uint64_t dstCap, const GcZdFrame* frames, uint32_t nFrames,
                                         GcZdBlock* blocks, uint32_t* ticket, uint8_t* litWork, uint64_t litWorkSize, void* seqWork, uint64_t* result, unsigned long long* prof,
                                         const uint32_t* ready);
@@ -937,11 +937,14 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
     { uint32_t v = 0; if (gc_env_u32("GC_ZD_PROF", 1, 1, &v) && hipMalloc((void**)&zdProf, 128) == hipSuccess) hipMemsetAsync(zdProf, 0, 128, c->stream); }
     uint64_t dstOff = 0;
     size_t i = 0;
+    uint64_t batchCap = GC_ZD_BATCH_BYTES;
+    { uint32_t v = 0; if (gc_env_u32("GC_ZD_BATCH_KIB", 1u, 4u << 20, &v)) batchCap = (uint64_t)v << 10; }       // test hook: small batches
     while (i < nFrames && rc == GC_OK) {
-        // a batch: frames that state their content size, closed by at most one that does not
+        // a batch: frames that state their content size (up to batchCap bytes of content, at least one frame), closed by at most one that does not
         size_t j = i; uint64_t off = dstOff, nBlocks = 0;
         for (; j < nFrames; j++) {
             const gc_zstd_frame& f = frames[j];
+            if (j > i && (f.flags & GC_ZD_F_SIZE_KNOWN) && off - dstOff + f.content_size > batchCap) break;       // the workspaces grow with the batch (≈ 7 bytes per content byte)
             if (f.src_off > n || f.src_size > n - f.src_off || f.header_size + 3ull > f.src_size || !f.n_blocks || (uint64_t)f.n_blocks * 3u > f.src_size || nBlocks + f.n_blocks > 0x7FFFFFFFull) { rc = GC_ERR_PARAM; break; }
             GcZdFrame& g = h[j];
             g.srcOff = f.src_off; g.srcSize = f.src_size; g.dstOff = off; g.contentSize = f.content_size; g.flags = f.flags; g.hdrSize = f.header_size;
@@ -991,12 +994,11 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
         // the frames are (one frame of 128 MiB: 4.7 against 460 ms).  It needs 4 bytes of workspace per content byte; frames of one block each stay
         // with the frame kernel (nothing to gain there).  Hook GC_ZD_WIDE = 0 / 1 forces the choice.
         bool wide = nBlocks >= 2u * cnt;
+        // the sequences kernel that takes several blocks per wave: less work per block, but a longer chain per sequence -- it wins once there are
+        // enough blocks to fill the machine (1 GB: 25.0 -> 16.0 ms; 256 blocks: 9.7 -> 12.0 ms).  Hook GC_ZD_SEQV = 0 / 1 forces the choice.
+        int seqSeveral = nBlocks >= 1024u ? 1 : 0;
+        { uint32_t v = 0; if (gc_env_u32("GC_ZD_SEQV", 0, 1, &v)) seqSeveral = (int)v; }
         { uint32_t v = 0; if (gc_env_u32("GC_ZD_WIDE", 0, 1, &v)) wide = v != 0u; }
-        {   // the 32-bit positions of the wide path must cover the batch (a frame of unknown size may grow up to the end of the destination)
-            const GcZdFrame& lastF = h[j - 1];
-            const uint64_t extentMax = (lastF.flags & GC_ZD_F_SIZE_KNOWN) ? off - h[i].dstOff : dstCap - h[i].dstOff;
-            if (extentMax > GC_ZD_WIDE_MAX) wide = false;
-        }
         if (wide) overlap = false;
         if ((rc = zd_grow(c, (void**)&c->zdOrder, &c->zdOrderCap, (size_t)nBlocks * 4u)) != GC_OK) break;
         if ((rc = zd_grow(c, (void**)&c->zdReady, &c->zdReadyCap, (size_t)nBlocks * 4u)) != GC_OK) break;
@@ -1022,7 +1024,7 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
         hipEventRecord(c->evPart[1][2], c->stream2);
         gc_zstd_dec_launch_literals(c->stream2, (const uint8_t*)d_src, n, c->zdFrames, c->zdBlocks, (uint32_t)nBlocks, c->zdLit, zdProf, c->zdOrder, c->zdReady);
         hipEventRecord(c->evPart[0][1], c->stream2);
-        gc_zstd_dec_launch_sequences(c->stream, (const uint8_t*)d_src, n, c->zdFrames, c->zdBlocks, (uint32_t)nBlocks, c->zdSeq, zdProf, c->zdOrder, c->zdReady);
+        gc_zstd_dec_launch_sequences(c->stream, (const uint8_t*)d_src, n, c->zdFrames, c->zdBlocks, (uint32_t)nBlocks, c->zdSeq, zdProf, c->zdOrder, c->zdReady, seqSeveral);
         hipEventRecord(c->evPart[1][1], c->stream);
         hipStreamWaitEvent(c->stream, c->evPart[0][1], 0);
         if (wide) {
@@ -1037,6 +1039,7 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
             for (size_t k = 0; k < cnt; k++) { const uint64_t e = h[i + k].dstOff - h[i].dstOff + (res[k] & 0x00FFFFFFFFFFFFFFull); if (e > extent) extent = e; }
             const uint64_t padded = (extent + 4095u) & ~4095ull;
             uint32_t noRoom = 0; gc_env_u32("GC_ZD_WIDE_NOMEM", 1u, 1u, &noRoom);               // test hook: as if the workspace could not be had
+            if (extent > GC_ZD_WIDE_MAX) noRoom = 1;               // (one frame beyond the reach of the 32-bit positions)
             if (noRoom || zd_grow(c, (void**)&c->zdPtr, &c->zdPtrCap, (size_t)padded * 4u + 16u) != GC_OK || zd_grow(c, (void**)&c->zdDone, &c->zdDoneCap, (size_t)(padded / 1024u) + 16u) != GC_OK) {
                 wide = false; c->err[0] = 0;                       // no room for the pointers: the frame kernel does it
             }
@@ -1096,7 +1099,8 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
     free(h); free(res);
     if (zdProf) {
         unsigned long long pv[16] = { 0 };
-        if (hipMemcpy(pv, zdProf, 128, hipMemcpyDeviceToHost) == hipSuccess && pv[3])
+        if (hipMemcpy(pv, zdProf, 128, hipMemcpyDeviceToHost) == hipSuccess && getenv("GC_ZD_SEQV_DBG")) { for (int q = 0; q < 16; q++) fprintf(stderr, "[dbg %2d] %016llx\n", q, pv[q]); }
+        else if (pv[3])
             fprintf(stderr, "[GC_ZD_PROF] compressed blocks %llu: cycles per block pass1 %.0f pass2 %.0f flush %.0f; pass 2: %.1f groups of 64 sequences per block, %.2f rounds per group of which %.2f for one special match\n", pv[3],
                     (double)pv[0] / pv[3], (double)pv[1] / pv[3], (double)pv[2] / pv[3], (double)pv[5] / pv[3], pv[5] ? (double)pv[4] / pv[5] : 0.0, pv[5] ? (double)pv[6] / pv[5] : 0.0);
         if (pv[12]) fprintf(stderr, "[GC_ZD_PROF] entropy kernel, cycles per block: sequences wave tables %.0f decode %.0f; literals wave tree %.0f streams %.0f\n",

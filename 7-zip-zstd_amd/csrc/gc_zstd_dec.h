@@ -51,6 +51,7 @@ struct GcZdBlock {
 
 // wide execution: where a block's content starts inside its frame, the repeat offsets it starts with, and whether the frame has already failed there
 struct GcZdPlace { uint64_t dst; uint32_t rep[3]; uint32_t skip; };
+#define GC_ZD_BATCH_BYTES (2ull << 30)                // content bytes decoded per batch of launches (a frame that is larger is a batch of its own)
 #define GC_ZD_WIDE_MAX  0xFFF00000ull                 // content bytes of a batch the 32-bit positions of the wide path can address
 
 #define GC_ZD_T         1024u                         // execution kernel

@@ -737,6 +737,233 @@ gc_zstd_dec_seq_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
     gc_signal_device(&ready[b]);
 }
 
+// ---- sequences, several blocks per wave ----
+// The kernel above spends a whole wave on one block and lets three of its 64 lanes decode, the wave's scalar unit doing the bookkeeping: with 22
+// waves per CU the kernel is bound by the ISSUE of those instructions (62 vector + 48 scalar per sequence, a vector instruction of a wave64 takes
+// four cycles whatever the number of live lanes; measured 2 000 cycles per sequence and wave).  Here a wave takes ZV_G blocks, four lanes each
+// (literal-length, match-length, offset state, one spare), and all bookkeeping is per lane: the same instructions now move ZV_G blocks on, and with
+// one wave per SIMD the kernel is bound by the latency of the chain of one sequence (state -> table -> bit counts -> bit positions -> bits -> state).
+// What the three lanes of a block tell each other travels through quad-permute DPP moves.  The bitstream pieces are still staged in LDS: when one
+// block has used up its piece the whole wave fetches its next one (one 16-byte load per lane), the other blocks carry on from where they were.
+#define ZV_G 6u
+struct ZvBlock {
+    uint32_t ll[512], ml[512], of[256];
+    __attribute__((aligned(16))) uint8_t buf[(GC_ZD_CHUNK + 64u) > 2u * (ZD_WIN_S + 16u) ? (GC_ZD_CHUNK + 64u) : 2u * (ZD_WIN_S + 16u)];
+    int16_t norm[64]; uint16_t next[64]; uint32_t v[16];                    // v: 0 error, 4 seq stream start, 5..7 table logs
+};
+// value of `v` in lane k of my group of four lanes
+template <int K> __device__ __forceinline__ uint32_t zv_quad(uint32_t v)
+{
+#ifdef HIPEMU
+    return __shfl(v, (int)((__lane_id() & 60u) + (unsigned)K));
+#else
+    // The move stays an instruction of its own: folded into the subtraction that uses it (v_subrev_u32_dpp ... quad_perm:[1,1,1,1], LLVM's DPP
+    // combiner at -O1 and above) the MI355X returned the other lane's value as 0 -- every match length with extra bits came out wrong while the
+    // emulator and the same code built with -mllvm -amdgpu-dpp-combine=false were right (tools/gpu_seqv_variants.py).  The empty asm is a use the
+    // combiner cannot see through.
+    uint32_t r = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, K * 0x55 /* quad_perm:[K,K,K,K] */, 0xF, 0xF, true);
+#ifndef ZV_KEEP_DPP_FOLD
+    asm volatile("" : "+v"(r));
+#endif
+    return r;
+#endif
+}
+
+#ifdef ZV_STRONG_SYNC
+#define ZV_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier(); } while (0)
+#else
+#define ZV_SYNC() gc_wave_sync()
+#endif
+extern "C" __global__ void __launch_bounds__(64)
+gc_zstd_dec_seqv_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const GcZdFrame* __restrict__ frames, GcZdBlock* blocks, GcU4* seqWork,
+                        const uint32_t* __restrict__ order, uint32_t nBlocks, uint32_t* ready, unsigned long long* dbg)
+{
+    __shared__ ZvBlock sB[ZV_G];
+    __shared__ ZdConst sK;
+#ifdef ZV_ZERO_LDS
+    for (uint32_t i = threadIdx.x; i < sizeof(sB) / 4u; i += 64u) ((uint32_t*)sB)[i] = 0;
+    gc_wave_sync();
+#endif
+    const uint32_t lane = threadIdx.x, role = lane & 3u, g = (lane >> 2) < ZV_G ? (lane >> 2) : 0u;
+    const uint32_t idx = blockIdx.x * ZV_G + (lane >> 2);
+    const bool have = (lane >> 2) < ZV_G && idx < nBlocks;
+    const uint32_t b = have ? order[idx] : 0u;
+    const uint32_t ty = have ? blocks[b].type : 0u;
+    const bool mine = have && (ty & 3u) == 2u && !(ty & GC_ZD_B_BAD);       // my group of four lanes has a compressed block
+    ZvBlock& M = sB[g];
+    for (uint32_t i = lane; i < 36u; i += 64u) { sK.llBase[i] = kZdLLBase[i]; sK.llBits[i] = kZdLLBits[i]; sK.llNorm[i] = kZdLLNorm[i]; }
+    for (uint32_t i = lane; i < 53u; i += 64u) { sK.mlBase[i] = kZdMLBase[i]; sK.mlBits[i] = kZdMLBits[i]; sK.mlNorm[i] = kZdMLNorm[i]; }
+    for (uint32_t i = lane; i < 29u; i += 64u) sK.ofNorm[i] = kZdOFNorm[i];
+    // block fields (every lane of the group holds them)
+    uint64_t eSrcOff = 0, eSeqOff = 0; uint32_t eSize = 0, eSeqPos = 0, eNSeq = 0, eModes = 0, eRegen = 0, eFrame = 0;
+    if (mine) { const GcZdBlock* e = blocks + b; eSrcOff = e->srcOff; eSeqOff = e->seqOff; eSize = e->size; eSeqPos = e->seqPos; eNSeq = e->nSeq; eModes = e->modes; eRegen = e->regen; eFrame = e->frame; }
+    for (uint32_t gg = 0; gg < ZV_G; gg++) {                               // header windows, the whole wave per block
+        if (!gc_readlane(mine ? 1u : 0u, gg * 4u)) continue;
+        const uint64_t so = (uint64_t)gc_readlane((uint32_t)eSrcOff, gg * 4u) | ((uint64_t)gc_readlane((uint32_t)(eSrcOff >> 32), gg * 4u) << 32);
+        const uint32_t sp0 = gc_readlane(eSeqPos, gg * 4u), bs0 = gc_readlane(eSize, gg * 4u);
+        for (uint32_t i = lane; i < ZD_WIN_S + 8u; i += 64u) sB[gg].buf[i] = sp0 + i < bs0 ? src[so + sp0 + i] : (uint8_t)0;
+        if (lane < 16u) sB[gg].v[lane] = 0;
+    }
+    ZV_SYNC();
+    const GcZdFrame fr = frames[eFrame];
+    const uint8_t* const bsrc = src + eSrcOff;
+    if (mine && role == 0u && eNSeq) {                                     // symbol tables: one lane per block (the blocks side by side)
+        uint8_t* const sWinS = M.buf; uint8_t* const sWinR = M.buf + ZD_WIN_S + 16u;
+        uint32_t err = 0, p = 1;
+        const int ord[3] = { ZT_LL, ZT_OF, ZT_ML };
+        for (int i = 0; i < 3 && !err; i++) {
+            const int which = ord[i];
+            uint32_t* const tab = which == ZT_LL ? M.ll : (which == ZT_OF ? M.of : M.ml);
+            const uint32_t mode = (eModes >> (which == ZT_LL ? 6u : (which == ZT_OF ? 4u : 2u))) & 3u;
+            if (mode != 3u) { p = zd_seq_table(mode, sWinS, ZD_WIN_S, p, tab, &M.v[5 + which], which, &sK, M.norm, M.next); if (!p) err = 1; }
+            else {
+                const uint32_t k = zd_find_table_source(blocks, fr.blockBase, b, which);
+                if (k == 0xFFFFFFFFu) { err = 1; break; }
+                const uint32_t m2 = blocks[k].modes;
+                const uint32_t mk = (m2 >> (which == ZT_LL ? 6u : (which == ZT_OF ? 4u : 2u))) & 3u;
+                uint32_t q = 1;
+                if (mk != 0u) {
+                    zd_load_window(sWinR, src, srcSize, blocks[k].srcOff + blocks[k].seqPos, ZD_WIN_S);
+                    for (int y = 0; y < 3 && ord[y] != which; y++) {
+                        const int w2 = ord[y];
+                        const int sk = zd_seq_table_skip((m2 >> (w2 == ZT_LL ? 6u : (w2 == ZT_OF ? 4u : 2u))) & 3u, sWinR, ZD_WIN_S, q, w2, M.norm);
+                        if (sk < 0) { err = 1; break; }
+                        q += (uint32_t)sk;
+                    }
+                }
+                if (!err && !zd_seq_table(mk, sWinR, ZD_WIN_S, q, tab, &M.v[5 + which], which, &sK, M.norm, M.next)) err = 1;
+            }
+        }
+        if (!err && (p > ZD_WIN_S || eSeqPos + p >= eSize)) err = 1;
+        M.v[4] = eSeqPos + p; if (err) M.v[0] = 1;
+    }
+    ZV_SYNC();
+    // ---- decode ----
+    const uint32_t nSeq = eNSeq;
+    uint32_t err = mine && nSeq ? M.v[0] : 0u;
+    const uint32_t seqStart = M.v[4];
+    const uint64_t spOff = eSrcOff + seqStart;                             // the bitstream of my block, absolute in the compressed stream
+    const uint32_t n = (mine && nSeq && !err) ? eSize - seqStart : 1u;
+    int32_t off = 0;
+    if (mine && nSeq && !err) {
+        const uint32_t last = src[spOff + n - 1u];
+        if (!last) err = 1; else off = (int32_t)((n - 1u) * 8u + gc_hibit32(last));
+    }
+    const uint32_t llLog = M.v[5 + ZT_LL], ofLog = M.v[5 + ZT_OF], mlLog = M.v[5 + ZT_ML];
+#ifndef ZV_DBG
+#define ZV_DBG 0
+#endif
+    const bool dq = ZV_DBG >= 1 && dbg && blockIdx.x == 0u && lane < 4u;
+    const bool dq2 = ZV_DBG >= 2 && dq;
+    if (dq2 && role == 0u) { dbg[0] = (unsigned long long)M.v[0] | ((unsigned long long)M.v[4] << 32); dbg[1] = llLog | (ofLog << 8) | (mlLog << 16) | ((unsigned long long)n << 32); dbg[2] = (uint32_t)off | ((unsigned long long)err << 32); dbg[10] = (unsigned long long)mine | ((unsigned long long)nSeq << 32); dbg[11] = eSize | ((unsigned long long)eSeqPos << 32); }
+    bool dfirst = true;
+    const uint32_t* const myTab = role == 1u ? M.ml : (role == 2u ? M.of : M.ll);
+    const uint32_t* const myBase = role == 1u ? sK.mlBase : sK.llBase;
+    GcU4* const seq = seqWork + fr.seqBase + eSeqOff;
+    uint32_t st = 0, j = 0, dpos = 0, lpos = 0, cLo = 0;
+    uint32_t rep0 = GC_ZD_SYM | 0u, rep1 = GC_ZD_SYM | 1u, rep2 = GC_ZD_SYM | 2u;
+    bool run = mine && nSeq && !err, staged = false, first = true;
+    for (;;) {
+        // the blocks whose piece is used up (or who have none yet): the whole wave stages the next piece of each
+        const bool want = run && !staged;
+        uint64_t m = __ballot(want && role == 0u);
+        while (m) {
+            const uint32_t L = gc_ctz64(m); m &= m - 1ull;
+            const uint32_t gg = L >> 2;
+            const int32_t offG = (int32_t)gc_readlane((uint32_t)off, L);
+            const uint32_t nG = gc_readlane(n, L);
+            const uint64_t spG = (uint64_t)gc_readlane((uint32_t)spOff, L) | ((uint64_t)gc_readlane((uint32_t)(spOff >> 32), L) << 32);
+            const uint8_t* const sp = src + spG;
+            const uint32_t hi = (uint32_t)(offG + 7) >> 3;
+            const uint32_t lo = hi > GC_ZD_CHUNK ? (hi - GC_ZD_CHUNK) & ~7u : 0u;
+            uint8_t* const buf = sB[gg].buf;
+            if (lane < 2u) { const uint64_t z = 0; __builtin_memcpy(buf + 8u * lane, &z, 8); }
+            for (uint32_t i = lane * 8u; i < hi + 8u - lo; i += 512u) {
+                uint64_t v = 0;
+                if (lo + i + 8u <= nG) v = gc_ld64(sp + lo + i);
+                else for (uint32_t k = 0; k < 8u && lo + i + k < nG; k++) v |= (uint64_t)sp[lo + i + k] << (8u * k);
+                __builtin_memcpy(buf + 16u + i, &v, 8);
+            }
+        }
+        ZV_SYNC();
+        if (want) { const uint32_t hi = (uint32_t)(off + 7) >> 3; cLo = hi > GC_ZD_CHUNK ? (hi - GC_ZD_CHUNK) & ~7u : 0u; staged = true; }
+#define ZV_RD64(p, c) (gc_ld64(M.buf + (((uint32_t)((p) + 128) >> 3) - (c))) >> ((uint32_t)(p) & 7u))
+#define ZV_RD32(p, c) (gc_ld32(M.buf + (((uint32_t)((p) + 128) >> 3) - (c))) >> ((uint32_t)(p) & 7u))
+        if (want && first) {                                               // the three initial states
+            const int32_t p1 = off - (int32_t)llLog, p2 = p1 - (int32_t)ofLog, p3 = p2 - (int32_t)mlLog;
+            if (p3 < 0) { err = 1; run = false; }
+            else {
+                const int32_t pm = role == 0u ? p1 : (role == 2u ? p2 : p3);
+                const uint32_t lg = role == 0u ? llLog : (role == 2u ? ofLog : mlLog);
+                st = role < 3u ? ZV_RD32(pm, cLo) & ((1u << lg) - 1u) : 0u;
+                off = p3;
+            }
+            first = false;
+            if (dq2 && role < 3u) dbg[3 + role] = st | ((unsigned long long)(uint32_t)off << 32);
+        }
+        for (;;) {
+            const bool can = run && (cLo == 0u || ((uint32_t)off >> 3) >= cLo + 16u);
+            if (__ballot(run && !can)) break;                              // somebody needs the next piece of its stream
+            if (!__ballot(can)) break;
+            const uint32_t en = myTab[can ? st : 0u];
+            const uint32_t more = j + 1u < nSeq ? 15u : 0u;                 // the last sequence does not move the states on
+            const uint32_t eb = (en >> 14) & 31u, nb = (en >> 10) & more;
+            const uint32_t llb = zv_quad<0>(eb), mlb = zv_quad<1>(eb), ofb = zv_quad<2>(eb);
+            const uint32_t nl = zv_quad<0>(nb), nm = zv_quad<1>(nb), no = zv_quad<2>(nb);
+            const int32_t p1 = off - (int32_t)ofb, p2 = p1 - (int32_t)mlb, p3 = p2 - (int32_t)llb;      // extra bits: offset, match length, literal length
+            const int32_t p4 = p3 - (int32_t)nl, p5 = p4 - (int32_t)nm, p6 = p5 - (int32_t)no;          // state bits: literal length, match length, offset
+            const int32_t pe = !can ? 0 : (role == 0u ? p3 : (role == 1u ? p2 : p1)), ps = !can ? 0 : (role == 0u ? p4 : (role == 1u ? p5 : p6));
+            const uint32_t cc = can ? cLo : 0u;
+            const uint64_t we = ZV_RD64(pe, cc);
+            const uint32_t ws = ZV_RD32(ps, cc);
+            const uint32_t base = role == 2u ? 1u << eb : myBase[role < 2u ? en >> 19 : 0u];
+            const uint32_t val = base + ((uint32_t)we & ((1u << eb) - 1u));
+            const uint32_t stNew = role < 3u ? (en & 0x3FFu) + (ws & ((1u << nb) - 1u)) : 0u;
+            const uint32_t ll = zv_quad<0>(val), ml = zv_quad<1>(val), ofv = zv_quad<2>(val);
+            if (dq2 && dfirst && can) { if (role < 3u) dbg[6 + role] = en | ((unsigned long long)val << 32); if (role == 0u) { dbg[9] = ll | ((unsigned long long)ml << 20) | ((unsigned long long)ofv << 40); dbg[12] = llb | (mlb << 8) | (ofb << 16) | ((unsigned long long)(nl | (nm << 8) | (no << 16)) << 32); dbg[13] = (uint32_t)p6 | ((unsigned long long)cLo << 32); } dfirst = false; }
+            if (can) {
+                st = stNew; off = p6;
+                // offset value 1..3 = one of the three last offsets (shifted by one when the sequence has no literals; "4" = the first minus 1)
+                const bool isRep = ofv <= 3u;
+                const uint32_t ix = ofv - 1u + (ll == 0u ? 1u : 0u);
+                const uint32_t r0m1 = (rep0 & GC_ZD_SYM) ? rep0 + 4u : rep0 - 1u;
+                const uint32_t o = !isRep ? ofv - 3u : (ix == 0u ? rep0 : (ix == 1u ? rep1 : (ix == 2u ? rep2 : r0m1)));
+                const bool shift3 = !isRep || ix >= 2u, shift2 = isRep && ix == 1u;
+                rep2 = shift3 ? rep1 : rep2;
+                rep1 = (shift3 || shift2) ? rep0 : rep1;
+                rep0 = o;
+                const bool bad = off < 0 || o == 0u || lpos + ll > eRegen || dpos + ll + ml > GC_ZSTD_BLOCK_MAX;
+                if (ofb > 30u) { err = GC_ZD_UNSUPPORTED; run = false; }
+                else if (bad) { err = 1; run = false; }
+                else {
+                    if (role == 0u) { GcU4 rec; rec.x = ll | (ml << 18); rec.y = (ml >> 14) | (lpos << 4); rec.z = o; rec.w = dpos; seq[j] = rec; }
+                    dpos += ll + ml; lpos += ll; j++;
+                    if (j >= nSeq) { run = false; if (off != 0) err = 1; }
+                }
+            }
+        }
+#undef ZV_RD64
+#undef ZV_RD32
+        if (run) { const bool can = cLo == 0u || ((uint32_t)off >> 3) >= cLo + 16u; if (!can) staged = false; }
+        if (!__ballot(run)) break;
+    }
+    if (dq && role == 0u) { dbg[14] = err | ((unsigned long long)j << 32); dbg[15] = (uint32_t)off | ((unsigned long long)dpos << 32); }
+    if (mine && role == 0u) {
+        uint32_t status = err ? (err == GC_ZD_UNSUPPORTED ? GC_ZD_UNSUPPORTED : GC_ZD_CORRUPT) : GC_ZD_OK;
+        const uint32_t outSize = dpos + (eRegen - lpos);
+        if (!status && outSize > GC_ZSTD_BLOCK_MAX) status = GC_ZD_CORRUPT;
+        blocks[b].status = status; blocks[b].outSize = outSize; blocks[b].lposEnd = lpos; blocks[b].dposEnd = dpos;
+        blocks[b].rep[0] = rep0; blocks[b].rep[1] = rep1; blocks[b].rep[2] = rep2;
+    }
+#ifdef HIPEMU
+    hipemu::wave_barrier();
+    if (mine && role == 0u) __atomic_fetch_add(&ready[b], 1u, __ATOMIC_RELEASE);
+#else
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (mine && role == 0u) __hip_atomic_fetch_add(&ready[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+}
+
 // =============================================================== execution kernel ===============================================================
 // byte `si` of the block image, or of the frame's output in front of the block when si < 0.  (The LDS read is unconditional and the HBM read sits in
 // its own branch: a select between an LDS and a global pointer makes this compiler emit an illegal compare against src_shared_base.)
@@ -1319,9 +1546,11 @@ extern "C" void gc_zstd_dec_launch_literals(hipStream_t st, const uint8_t* src, 
     if (nBlocks) GC_LAUNCH(gc_zstd_dec_lit_kernel, nBlocks, 64, st, src, srcSize, frames, blocks, litWork, prof, order, ready);
 }
 extern "C" void gc_zstd_dec_launch_sequences(hipStream_t st, const uint8_t* src, uint64_t srcSize, const GcZdFrame* frames, GcZdBlock* blocks, uint32_t nBlocks, void* seqWork,
-                                             unsigned long long* prof, const uint32_t* order, uint32_t* ready)
+                                             unsigned long long* prof, const uint32_t* order, uint32_t* ready, int several)
 {
-    if (nBlocks) GC_LAUNCH(gc_zstd_dec_seq_kernel, nBlocks, 64, st, src, srcSize, frames, blocks, (GcU4*)seqWork, prof, order, ready);
+    if (!nBlocks) return;
+    if (several) GC_LAUNCH(gc_zstd_dec_seqv_kernel, (nBlocks + ZV_G - 1u) / ZV_G, 64, st, src, srcSize, frames, blocks, (GcU4*)seqWork, order, nBlocks, ready, prof);
+    else GC_LAUNCH(gc_zstd_dec_seq_kernel, nBlocks, 64, st, src, srcSize, frames, blocks, (GcU4*)seqWork, prof, order, ready);
 }
 extern "C" void gc_zstd_dec_launch_exec(hipStream_t st, const uint8_t* src, uint64_t srcSize, uint8_t* dst, uint64_t dstCap, const GcZdFrame* frames, uint32_t nFrames,
                                         GcZdBlock* blocks, uint32_t* ticket, uint8_t* litWork, uint64_t litWorkSize, void* seqWork, uint64_t* result, unsigned long long* prof,

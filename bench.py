@@ -170,19 +170,22 @@ def run_codec(codec, level, corpus_name, total, args, env):
                         best, kms, rounds = ms, dec.kernel_timing_ms(), dec.wide_rounds()
                 same = bool(got == total and torch.equal(d_y[:total], d_src[:total]))
                 dom = max(kms, key=lambda k: kms[k])
+                nblk = sum(int(frames[i].n_blocks) for i in range(nf))
+                kname = {"execution": "gc_zstd_dec_chase_kernel" if rounds else "gc_zstd_dec_exec_kernel", "literals": "gc_zstd_dec_lit_kernel", "index": "gc_zstd_dec_index_kernel",
+                         "sequences": "gc_zstd_dec_seqv_kernel" if nblk >= 1024 else "gc_zstd_dec_seq_kernel"}[dom]      # (gc_api.hip: six blocks per wave from 1024 blocks on)
                 algo = total + int(stream.size)                      # compressed stream read once + content written once
                 dtraffic = None
                 try:
                     pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
                     if pm.get("_workload_bytes", {}).get("zstd_dec") == total:
-                        dtraffic = pm["zstd_dec"]["gc_zstd_dec_%s_kernel" % {"execution": "exec", "sequences": "seq", "literals": "lit", "index": "index"}[dom]]["hbm_bytes_per_launch"]
+                        dtraffic = pm["zstd_dec"][kname]["hbm_bytes_per_launch"]
                 except Exception:
                     dtraffic = None
                 gpu_decode = {"frames": nf, "content_bytes": total, "kernel_ms": round(best, 3), "value": round(total / best / 1e3, 1), "unit": "MB/s of content",
                               "bit_exact": same, "reference_decoder_1_core_MBps": round(total / td / 1e6, 1),
                               "kernels_ms": {k: round(v, 3) for k, v in kms.items()},
                               "execution": ("wide: place + spread + %d pointer-jumping rounds + finish over all blocks at once" % rounds) if rounds else "one workgroup per frame, blocks in order",
-                              "roofline": {"bound": "hbm", "kernel": "gc_zstd_dec_%s_kernel" % {"execution": "exec", "sequences": "seq", "literals": "lit", "index": "index"}[dom],
+                              "roofline": {"bound": "hbm", "kernel": kname,
                                            "achieved": round(algo / (kms[dom] * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                            "frac": round(algo / (kms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": dtraffic, "algorithmic_bytes_per_launch": algo}}
                 dec.close(); del d_c, d_y

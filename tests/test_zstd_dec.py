@@ -184,11 +184,63 @@ def _both_paths(pkg, O, lib_kw, monkeypatch, sizes, flips):
         dec.close()
 
 
+def _several_blocks_per_wave(pkg, O, lib_kw, monkeypatch, sizes):
+    """The sequences kernel that takes six blocks per wave (four lanes each, quad-permute moves between them; the default from 1024 blocks on) must
+    agree with the one-block-per-wave kernel: every kind of stream, long matches included (their extra bits were what a mis-folded DPP move lost on
+    the MI355X: tools/gpu_seqv_variants.py)."""
+    monkeypatch.setenv("GC_ZD_SEQV", "1")
+    dec = pkg.ZstdDecoder(**lib_kw)
+    try:
+        for kind in KINDS:
+            for n, level in sizes:
+                x = _corpus(O, kind, n).tobytes()
+                _check(dec, O.ref_zstd_compress(x, level).tobytes(), x)
+        x = _corpus(O, "silesia-like", sizes[-1][0]).tobytes()
+        _check(dec, O.ref_zstd_compress_opts(x, 5, checksum=True, streamed=True).tobytes(), x)
+        _check(dec, O.ref_zstd_compress(x, 3, piece=70_000).tobytes(), x)                        # frames of one block: several frames per wave
+        bad = bytearray(O.ref_zstd_compress_opts(x, 3, checksum=True).tobytes())
+        for pos in range(len(bad) // 3, len(bad) // 3 + 6):
+            bad[pos] ^= 0x04
+            try:
+                assert dec.code(bytes(bad), capacity=len(x) + 64).tobytes() == x
+            except pkg.GpuCodecError:
+                pass
+            bad[pos] ^= 0x04
+    finally:
+        dec.close()
+
+
+def test_emu_sequences_kernel_several_blocks_per_wave(pkg, O, emu_lib_path, monkeypatch):
+    _several_blocks_per_wave(pkg, O, dict(lib_path=emu_lib_path), monkeypatch, ((5000, 1), (300_000, 3), (200_000, 19)))
+
+
+def test_emu_small_batches(pkg, O, emu_lib_path, monkeypatch):
+    """The launches of a call cover at most GC_ZD_BATCH_BYTES of content at a time (workspaces grow with the batch); the test hook makes the batches
+    small: 7 frames in batches of one or two, a frame larger than the cap alone in its batch, both execution stages."""
+    x = _corpus(O, "text-zipf", 900_000).tobytes()
+    comp = O.ref_zstd_compress(x[:600_000], 3, piece=100_000).tobytes() + O.ref_zstd_compress_opts(x[600_000:], 3, checksum=True).tobytes()
+    monkeypatch.setenv("GC_ZD_BATCH_KIB", "150")
+    dec = pkg.ZstdDecoder(lib_path=emu_lib_path)
+    try:
+        _check(dec, comp, x)
+        assert dec.wide_rounds() > 0                       # (the last frame has three blocks)
+    finally:
+        dec.close()
+
+
 def test_emu_both_execution_paths(pkg, O, emu_lib_path, monkeypatch):
     _both_paths(pkg, O, dict(lib_path=emu_lib_path), monkeypatch, (280_000, 150_000), 4)
 
 
 # ------------------------------------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+def test_gpu_sequences_kernel_several_blocks_per_wave(pkg, O, gpu_dec, monkeypatch):
+    _several_blocks_per_wave(pkg, O, dict(device=0), monkeypatch, ((5000, 1), (3 * MiB + 17, 3), (4 * MiB, 19)))
+    monkeypatch.delenv("GC_ZD_SEQV")
+    x = _corpus(O, "silesia-like", 160 * MiB + 5).tobytes()                                      # 1281 blocks: the default takes this kernel
+    _check(gpu_dec, O.ref_zstd_compress(x, 1).tobytes(), x)
+
+
 @pytest.mark.gpu
 def test_gpu_both_execution_paths(pkg, O, gpu_dec, monkeypatch):
     _both_paths(pkg, O, dict(device=0), monkeypatch, (48 * MiB + 321, 32 * MiB), 24)
