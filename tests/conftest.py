@@ -26,7 +26,7 @@ def pytest_cmdline_main(config):
     emulator is slow and single-threaded.  GPU runs stay in one process (one device, and the driver records which libraries that
     process loads).  GC_TEST_WORKERS overrides (0 = off)."""
     want = os.environ.get("GC_TEST_WORKERS")
-    n = int(want) if want is not None else (4 if _no_gpu_here() else 0)
+    n = int(want) if want is not None else (max(2, min(6, (os.cpu_count() or 4) - 2)) if _no_gpu_here() else 0)
     if os.environ.get("PYTEST_XDIST_WORKER") or hasattr(config, "workerinput"):
         return                                     # inside a worker: never nest
     if n > 0 and getattr(config.option, "numprocesses", None) is None and config.pluginmanager.hasplugin("xdist"):
