@@ -22,7 +22,7 @@ def _no_gpu_here():
 
 @pytest.hookimpl(tryfirst=True)
 def pytest_cmdline_main(config):
-    """CPU runs (no GPU in the machine) spread the test FILES over a few worker processes (pytest-xdist, if installed): the SIMT
+    """CPU runs (no GPU in the machine) spread the tests over a few worker processes (pytest-xdist, if installed): the SIMT
     emulator is slow and single-threaded.  GPU runs stay in one process (one device, and the driver records which libraries that
     process loads).  GC_TEST_WORKERS overrides (0 = off)."""
     want = os.environ.get("GC_TEST_WORKERS")
@@ -31,7 +31,7 @@ def pytest_cmdline_main(config):
         return                                     # inside a worker: never nest
     if n > 0 and getattr(config.option, "numprocesses", None) is None and config.pluginmanager.hasplugin("xdist"):
         config.option.numprocesses = n
-        config.option.dist = "loadfile"
+        config.option.dist = "load"               # (per test: the slowest files would otherwise be the critical path; module fixtures are cheap)
         config.option.tx = ["popen"] * n          # (what -n would have filled in)
 
 
