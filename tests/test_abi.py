@@ -41,3 +41,24 @@ def test_emulator_library_has_same_surface(emu_lib_path):
     lib = ctypes.CDLL(emu_lib_path)
     for n in _declared_functions():
         assert hasattr(lib, n)
+
+
+def test_quad_permute_moves_of_the_sequences_kernel_stay_unfolded(graft, tmp_path):
+    """gc_zstd_dec_seqv_kernel passes values between the four lanes of a block with quad-permute DPP moves.  Folded into their users by the compiler's
+    DPP combiner (v_subrev_u32_dpp ... quad_perm:[1,1,1,1]) they read the neighbour lane as 0 on the MI355X (profiles/r02_dpp_combine.md), so the source
+    keeps every move an instruction of its own; this compiles the file for gfx950 (no GPU needed) and looks at the kernel's instructions."""
+    import re, shutil, subprocess
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else shutil.which("hipcc")
+    if not hipcc:
+        pytest.skip("no hipcc")
+    src = os.path.join(graft.CSRC, "gc_zstd_dec.hip")
+    out = str(tmp_path / "gc_zstd_dec.s")
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + graft.CSRC, "-I" + os.path.join(graft.ROOT, "include"), "-S", "--cuda-device-only", src, "-o", out],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    text = open(out).read()
+    m = re.search(r"^gc_zstd_dec_seqv_kernel:.*?s_endpgm", text, re.S | re.M)
+    assert m, "kernel not found in the assembly"
+    dpp = re.findall(r"\b(v_\w+_dpp)\b", m.group(0))
+    assert dpp and set(dpp) == {"v_mov_b32_dpp"}, sorted(set(dpp))
+    assert len(dpp) == 9                                           # 2 x 3 bit counts + 3 values per sequence step
