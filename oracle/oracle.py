@@ -58,7 +58,7 @@ class _Diag(C.Structure):
 
 
 def ref(name):
-    """name in {'zstd','flzma2','brotli','bra'}; returns CDLL or None when the prebuilt .so is absent."""
+    """name in {'zstd','flzma2','brotli','bra','lzfind'}; returns CDLL or None when the prebuilt .so is absent."""
     if name not in _ref:
         lib = _load(os.path.join(HERE, "_ref", "lib%s_ref.so" % name))
         if lib is not None:
@@ -83,6 +83,9 @@ def ref(name):
                 lib.ref_bra_x86_convert.restype = _SZ
                 lib.ref_delta_convert.argtypes = [_VP, _SZ, C.c_uint, C.c_int, _VP]
                 lib.ref_delta_convert.restype = None
+            elif name == "lzfind":
+                lib.ref_lzfind_matches.argtypes = [_VP, _SZ, C.c_uint, C.c_int, C.c_int, C.c_uint, C.c_uint, _VP, _VP, _SZ, C.POINTER(_SZ)]
+                lib.ref_lzfind_matches.restype = C.c_int
             elif name == "brotli":
                 lib.ref_brotli_compress.argtypes = [_VP, _SZ, _VP, _SZ, C.c_int, C.c_int]
                 lib.ref_brotli_decompress.argtypes = [_VP, _SZ, _VP, _SZ]
@@ -263,3 +266,28 @@ def ref_brotli_decompress(comp, cap):
     if r == _BAD:
         raise ValueError("reference brotli decoder rejected the stream")
     return out[:r]
+
+
+def _match_lists(fn, data, history, cut, nice, extra):
+    a = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data, dtype=np.uint8)
+    counts = np.zeros(max(a.size, 1), dtype=np.uint32)
+    cap = 2 * a.size * 8 + 64
+    pairs = np.zeros(cap, dtype=np.uint32)
+    used = _SZ(0)
+    rc = fn(a.ctypes.data if a.size else None, a.size, int(history), *extra, int(cut), int(nice), counts.ctypes.data, pairs.ctypes.data, cap, C.byref(used))
+    if rc != 0:
+        raise RuntimeError("match finder oracle failed: %d" % rc)
+    return counts[:a.size].copy(), pairs[:used.value].copy()
+
+
+def ref_lzfind_matches(data, history=1 << 20, bt=False, hash_bytes=4, cut=32, nice=64):
+    """The reference's mainline match finder (C/LzFind.c through ref_shim_lzfind.c): (values per position, all (length, distance - 1) values in order)."""
+    return _match_lists(ref("lzfind").ref_lzfind_matches, data, history, cut, nice, (1 if bt else 0, int(hash_bytes)))
+
+
+def port_hc4_matches(data, history=1 << 20, cut=32, nice=64):
+    """The restatement oracle/lzfind_hc4.c of Hc4_MatchFinder_GetMatches, same output layout."""
+    lib = port()
+    lib.gc_oracle_hc4_matches.argtypes = [_VP, _SZ, C.c_uint, C.c_uint, C.c_uint, _VP, _VP, _SZ, C.POINTER(_SZ)]
+    lib.gc_oracle_hc4_matches.restype = C.c_int
+    return _match_lists(lib.gc_oracle_hc4_matches, data, history, cut, nice, ())

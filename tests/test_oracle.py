@@ -92,3 +92,29 @@ def test_corpus_generators_are_deterministic(O):
         a2 = (18000 * (a2 & 0xffff) + (a2 >> 16)) & 0xFFFFFFFF
         r = (((a1 << 16) & 0xFFFFFFFF) + a2) & 0xFFFFFFFF
         assert a[i] == ((r >> 1) & 0xFF)
+
+
+# ---------------------------------------------------------------------------------------------- match finder oracle (the next row)
+def test_hc4_restatement_matches_the_golden_lists(O):
+    """oracle/lzfind_hc4.c (what Hc4_MatchFinder_GetMatches returns for every position, restated in data-parallel form) against lists the reference's
+    own C/LzFind.c produced (tests/golden/make_hc4_fixture.py)."""
+    g = np.load(os.path.join(GOLD, "hc4_matches.npz"))
+    for name in ("text", "lz", "sil"):
+        hist, cut, nice = (int(v) for v in g[name + "_params"])
+        counts, pairs = O.port_hc4_matches(g[name + "_input"], hist, cut, nice)
+        assert np.array_equal(counts, g[name + "_counts"].astype(np.uint32)), name
+        assert np.array_equal(pairs, g[name + "_pairs"]), name
+
+
+@pytest.mark.parametrize("kind", ["text-zipf", "lz-7zip", "silesia-like", "random", "zeros"])
+def test_hc4_restatement_matches_the_reference(O, kind):
+    if O.ref("lzfind") is None:
+        pytest.skip("oracle/_ref not built")
+    x = np.zeros(40_000, dtype=np.uint8) if kind == "zeros" else O.corpus(kind, 150_000)
+    for hist, cut, nice in ((1 << 20, 32, 64), (4096, 8, 273), (65536, 1, 32), (1 << 16, 48, 5), (300, 16, 128)):     # window wraps, cut 1, shortest / longest nice length
+        c1, p1 = O.ref_lzfind_matches(x, hist, False, 4, cut, nice)
+        c2, p2 = O.port_hc4_matches(x, hist, cut, nice)
+        assert np.array_equal(c1, c2) and np.array_equal(p1, p2), (kind, hist, cut, nice)
+    for n in (0, 1, 3, 4, 5, 9):
+        a, b = O.ref_lzfind_matches(x[:n], 1 << 16, False, 4, 32, 64), O.port_hc4_matches(x[:n], 1 << 16, 32, 64)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
