@@ -39,7 +39,7 @@ extern "C" __global__ void gc_zstd_emit_kernel(const uint8_t*, uint64_t, const u
 extern "C" __global__ void gc_mf_count_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
 extern "C" __global__ void gc_mf_scan_kernel(uint32_t*, uint32_t);
 extern "C" __global__ void gc_mf_scatter_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
-extern "C" __global__ void gc_mf_link_kernel(const uint32_t*, const GcMfEntry*, GcMfEntry*, uint32_t, uint64_t);
+extern "C" __global__ void gc_mf_link_kernel(const uint32_t*, const GcMfEntry*, GcMfEntry*, uint32_t, uint64_t, uint32_t, uint32_t*);
 extern "C" __global__ void gc_mf_verify_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
 extern "C" __global__ void gc_mf_count_half_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
 extern "C" __global__ void gc_mf_scatter_half_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
@@ -54,7 +54,7 @@ extern "C" __global__ void gc_mf_deepen_kernel(const uint8_t*, uint64_t, uint32_
 extern "C" __global__ void gc_mf_count_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
 extern "C" __global__ void gc_mf_scan_kernel_p8(uint32_t*, uint32_t);
 extern "C" __global__ void gc_mf_scatter_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
-extern "C" __global__ void gc_mf_link_kernel_p8(const uint32_t*, const GcMfEntry*, GcMfEntry*, uint32_t, uint64_t);
+extern "C" __global__ void gc_mf_link_kernel_p8(const uint32_t*, const GcMfEntry*, GcMfEntry*, uint32_t, uint64_t, uint32_t, uint32_t*);
 extern "C" __global__ void gc_mf_verify_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
 extern "C" __global__ void gc_mf_count_half_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
 extern "C" __global__ void gc_mf_scatter_half_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
@@ -66,6 +66,8 @@ extern "C" __global__ void gc_mf_count_far_kernel_p8(const uint8_t*, uint64_t, u
 extern "C" __global__ void gc_mf_scatter_far_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
 extern "C" __global__ void gc_mf_verify_far_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
 extern "C" __global__ void gc_mf_deepen_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, uint32_t*);
+extern "C" __global__ void gc_mf_vparse_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, GcSeqRaw*, uint8_t*, GcBlockMeta*, unsigned long long*);
+extern "C" __global__ void gc_mf_vparse_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, GcSeqRaw*, uint8_t*, GcBlockMeta*, unsigned long long*);
 extern "C" __global__ void gc_mf_parse_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcSeqRaw*, uint8_t*, GcBlockMeta*, uint16_t*, uint32_t);
 extern "C" __global__ void gc_mf_short_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint16_t*);
 extern "C" __global__ void gc_mf_dp2_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
@@ -113,6 +115,7 @@ struct gc_ctx {
     uint64_t* lzM; size_t lzMCap; uint8_t* lzRcOut; size_t lzRcOutCap;     // item lists, range-coder staging (allocated on the first FLZMA2 call)
     uint8_t* brStage; GcBrotliBlockInfo* brInfo; GcBrotliPlan* brPlan;    // BROTLI path
     // windowed match finder (gc_mf.h): counts/offsets, partition starts, entry lists; grown on demand
+    uint32_t nCU; uint32_t* mfTicket;      // compute units of the device; ticket counters of the persistent launches (4 per part)
     uint32_t* mfCnt; size_t mfCntCap; GcMfEntry* mfEnt; size_t mfEntCap; GcMfEntry* mfEnt2; size_t mfEnt2Cap; uint32_t* mfRec; size_t mfRecCap; uint32_t* mfRec2; size_t mfRec2Cap;
     uint16_t* mfRec3; size_t mfRec3Cap; uint32_t* mfDp; size_t mfDpCap; uint16_t* mfPrice; size_t mfPriceCap; uint32_t* mfWinCost; size_t mfWinCostCap; uint32_t* mfDpStat; size_t mfDpStatCap;      // W5s records, W7 records, price tables, W7 phase-A symbol counts
     hipEvent_t evMf[GC_MAX_PARTS][13];      // per part: W1 start, W1 end, W2 end, W3 end, W4 end, W5 end, W6 end; price-based parse: greedy W6 end, W5s end, W7 end;
@@ -178,6 +181,7 @@ extern "C" int gc_ctx_create(gc_ctx** out, int device)
     if (!c) return GC_ERR_NOMEM;
     memset(c, 0, sizeof(*c));
     c->device = device;
+    c->nCU = prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256u;
     // every failure below releases what has been created so far (ctx_release skips what is still null)
     int rc = GC_OK;
     if (hipStreamCreate(&c->stream) != hipSuccess || hipStreamCreate(&c->stream2) != hipSuccess || hipStreamCreate(&c->stream3) != hipSuccess) rc = GC_ERR_HIP;
@@ -187,6 +191,7 @@ extern "C" int gc_ctx_create(gc_ctx** out, int device)
         for (uint32_t i = 0; rc == GC_OK && i < GC_PART_EVENTS; i++) if (hipEventCreate(&c->evPart[p][i]) != hipSuccess) rc = GC_ERR_HIP;
     }
     if (rc == GC_OK && hipMalloc((void**)&c->prof, (GC_LZ_PHASES + GC_SEQ_PHASES) * sizeof(unsigned long long)) != hipSuccess) rc = GC_ERR_NOMEM;
+    if (rc == GC_OK && hipMalloc((void**)&c->mfTicket, GC_MAX_PARTS * 4u * sizeof(uint32_t)) != hipSuccess) rc = GC_ERR_NOMEM;
     if (rc == GC_OK && (hipMalloc((void**)&c->result, 16) != hipSuccess || hipHostMalloc((void**)&c->hostResult, 16) != hipSuccess)) rc = GC_ERR_NOMEM;
     if (rc != GC_OK) { ctx_release(c); return rc; }
     c->dbgFrameBlocks = 0; c->dbgPartFrames = 0;
@@ -212,7 +217,7 @@ static void ctx_release(gc_ctx* c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     free_workspace(c);
-    hipFree(c->prof); hipFree(c->result); if (c->hostResult) hipHostFree(c->hostResult); hipFree(c->dIn); hipFree(c->dOut);
+    hipFree(c->prof); hipFree(c->mfTicket); hipFree(c->result); if (c->hostResult) hipHostFree(c->hostResult); hipFree(c->dIn); hipFree(c->dOut);
     hipFree(c->zdLit); hipFree(c->zdSeq); hipFree(c->zdFrames); hipFree(c->zdResult); hipFree(c->zdTot); hipFree(c->zdBlocks); hipFree(c->zdOrder); hipFree(c->zdReady); hipFree(c->zdTicket); hipFree(c->zdPlace); hipFree(c->zdPtr); hipFree(c->zdDone); hipFree(c->zdFerr);
     for (int i = 0; i < 2; i++) if (c->zdEv[i]) hipEventDestroy(c->zdEv[i]);
     hipFree(c->mfCnt); hipFree(c->mfEnt); hipFree(c->mfEnt2); hipFree(c->mfRec); hipFree(c->mfRec2); hipFree(c->mfRec3); hipFree(c->mfDp); hipFree(c->mfPrice); hipFree(c->mfWinCost); hipFree(c->mfDpStat);
@@ -342,6 +347,13 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
     const bool fast = c->mfFast != 0u;
     const uint32_t nParts = 1u << g.partLog;
 #define MFSEL(k) (fast ? k##_p8 : k)          // the kernel of this geometry
+    // W4 is a persistent launch: one-wave workgroups, six per CU (24 KiB of LDS each), fed from a ticket counter (one counter per launch and part)
+    uint32_t linkLaunch = 0;
+    uint32_t linkWpc = 6u; gc_env_u32("GC_LINK_WPC", 1u, 32u, &linkWpc);         // test hook: one-wave workgroups per CU
+    const uint32_t nLists = g.nFrames * nParts, linkGrid = nLists * GC_MF_LINK_SEGS < c->nCU * linkWpc ? nLists * GC_MF_LINK_SEGS : c->nCU * linkWpc;
+    HIPCHK(c, hipMemsetAsync(c->mfTicket + part * 4u, 0, 4u * sizeof(uint32_t), st));
+#define MF_LINK(cnt_, ent_, ent2_) do { uint32_t* ticket_ = c->mfTicket + part * 4u + linkLaunch++; \
+        GC_LAUNCH(MFSEL(gc_mf_link_kernel), linkGrid, 64, st, (const uint32_t*)(cnt_), (const GcMfEntry*)(ent_), ent2_, g.tilesPerFrame, g.frameBytes, nLists, ticket_); } while (0)
     hipEvent_t* ev = c->evMf[part];
     HIPCHK(c, hipEventRecord(ev[0], st));
     if (c->halfList) GC_LAUNCH(MFSEL(gc_mf_count_half_kernel), perT * GC_XCDS, nParts, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, cnt);
@@ -352,8 +364,21 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
     if (c->halfList) GC_LAUNCH(MFSEL(gc_mf_scatter_half_kernel), perT * GC_XCDS, nParts, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt, ent);
     else GC_LAUNCH(MFSEL(gc_mf_scatter_kernel), perT * GC_XCDS, nParts, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt, ent);
     HIPCHK(c, hipEventRecord(ev[3], st));
-    GC_LAUNCH(MFSEL(gc_mf_link_kernel), g.nFrames * nParts * GC_MF_LINK_SEGS, 64, st, (const uint32_t*)cnt, (const GcMfEntry*)ent, ent2, g.tilesPerFrame, g.frameBytes);
+    MF_LINK(cnt, ent, ent2);
     HIPCHK(c, hipEventRecord(ev[4], st));
+    // the levels that parse the first pass's records as they are: verify + parse in one kernel, the records stay in LDS (W5 + W6 fused)
+    uint32_t fused = (!c->halfList && !c->farPass && !c->searchDepth && !c->priceParse && !c->shortPass) ? 1u : 0u;
+    gc_env_u32("GC_FUSED_PARSE", 0u, 1u, &fused);               // test hook: 0 = the two kernels
+    if (fused && (c->halfList || c->farPass || c->searchDepth || c->priceParse || c->shortPass)) fused = 0u;
+    if (fused) {
+        GC_LAUNCH(MFSEL(gc_mf_vparse_kernel), perB * GC_XCDS, g.verifyT, st, src, (uint64_t)n, frameBlocks, nBlocks, perB, c->lazyDepth, (const uint32_t*)cnt,
+                  (const GcMfEntry*)ent2, seqRaw, lit, meta, prof);
+        for (int i = 10; i <= 12; i++) HIPCHK(c, hipEventRecord(ev[i], st));
+        HIPCHK(c, hipEventRecord(ev[5], st));
+        HIPCHK(c, hipEventRecord(ev[6], st));
+        (void)prof;
+        return GC_OK;
+    }
     if (c->halfList) GC_LAUNCH(MFSEL(gc_mf_verify_half_kernel), perT * GC_XCDS, g.verifyT, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt,
                                (const GcMfEntry*)ent2, rec);
     else GC_LAUNCH(MFSEL(gc_mf_verify_kernel), perT * GC_XCDS, g.verifyT, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt,
@@ -363,7 +388,7 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
         GC_LAUNCH(MFSEL(gc_mf_count_far_kernel), perT * GC_XCDS, nParts, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, cnt);
         GC_LAUNCH(MFSEL(gc_mf_scan_kernel), g.nFrames, 1024, st, cnt, g.tilesPerFrame);
         GC_LAUNCH(MFSEL(gc_mf_scatter_far_kernel), perT * GC_XCDS, nParts, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt, ent);
-        GC_LAUNCH(MFSEL(gc_mf_link_kernel), g.nFrames * nParts * GC_MF_LINK_SEGS, 64, st, (const uint32_t*)cnt, (const GcMfEntry*)ent, ent2, g.tilesPerFrame, g.frameBytes);
+        MF_LINK(cnt, ent, ent2);
         GC_LAUNCH(MFSEL(gc_mf_verify_far_kernel), perT * GC_XCDS, g.verifyT, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt,
                   (const GcMfEntry*)ent2, rec);
     }
@@ -381,7 +406,7 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
         GC_LAUNCH(MFSEL(gc_mf_count_short_kernel), perT * GC_XCDS, nParts, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, cnt);
         GC_LAUNCH(MFSEL(gc_mf_scan_kernel), g.nFrames, 1024, st, cnt, g.tilesPerFrame);
         GC_LAUNCH(MFSEL(gc_mf_scatter_short_kernel), perT * GC_XCDS, nParts, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt, ent);
-        GC_LAUNCH(MFSEL(gc_mf_link_kernel), g.nFrames * nParts * GC_MF_LINK_SEGS, 64, st, (const uint32_t*)cnt, (const GcMfEntry*)ent, ent2, g.tilesPerFrame, g.frameBytes);
+        MF_LINK(cnt, ent, ent2);
         GC_LAUNCH(MFSEL(gc_mf_verify_short_kernel), perT * GC_XCDS, g.verifyT, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt,
                   (const GcMfEntry*)ent2, (const uint32_t*)rec, recN);
         recDp = recN;

@@ -273,10 +273,13 @@ __device__ __forceinline__ void mf_scatter_body(const uint8_t* __restrict__ src,
     uint32_t nEnt = 0;
     for (uint32_t w = 0; w < MF_WAVES; w++) nEnt += sWaveTot[w];
     // pass B: stable ranks -> permutation
+#ifdef MF_RANK_BALLOT
     const uint64_t lt = gc_lanemask_lt();
+#endif
     for (uint32_t r = 0; r < GC_MF_TILE / MF_T; r++) {
         const uint32_t q = qBase + r * 64u + lane;
         const MfKeys k = mf_keys<MODE>(sW, q, T);
+#ifdef MF_RANK_BALLOT
         uint64_t peers = __ballot(k.ok);
         if (peers != 0ull) {                                      // uniform
 #pragma unroll
@@ -294,6 +297,12 @@ __device__ __forceinline__ void mf_scatter_body(const uint8_t* __restrict__ src,
             }
             gc_wave_sync();
         }
+#else
+        // one returning ds_add per position: the LDS unit serves the lanes that hit one counter in lane order (the property W4's ds_max
+        // relies on), lanes are positions, rounds follow each other in program order -- so the value returned is the position's stable rank
+        if (k.ok) sPerm[atomicAdd(&sRun[wave][k.part], 1u)] = (uint16_t)q;
+        gc_wave_step();
+#endif
     }
     __syncthreads();
     // output: slot j of the sorted tile -> its partition's run in HBM
@@ -343,7 +352,9 @@ MFK(gc_mf_scatter_far_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize,
 // overwritten after ~4 Ki insertions on average, so the tables are then what the single walk would have left, up to slots not
 // touched for 16 Ki insertions (e^-4 of them), whose stale candidates are simply not offered.  Output goes to a second entry
 // array because the replay reads what the previous segment's wave is working on.
+#ifndef LINK_DEPTH
 #define LINK_DEPTH 8u                 // steps per register set
+#endif
 #ifdef GC_MF_FAST
 #define LINK_SEG   49152u             // entries per segment (1.5 x the mean list length of a full 8 MiB frame: 256 partitions)
 #else
@@ -384,7 +395,7 @@ __device__ __forceinline__ void mf_link_steps(const uint64_t q[LINK_DEPTH], uint
         const uint32_t kS = (uint32_t)(e >> (GC_MF_POS_BITS + GC_MF_KL_BITS)) & ((1u << GC_MF_KS_BITS) - 1u);
         mL[d] = ((pos[d] + 1u) << 8) | (kL & 0xFFu); mS[d] = ((pos[d] + 1u) << 8) | (kS & 0xFFu);
         rL[d] = 0; rS[d] = 0;
-        if (i < end) { rL[d] = atomicMax(&tabL[kL >> 8], mL[d]); rS[d] = atomicMax(&tabS[kS >> 8], mS[d]); }
+        if (i < end) { rL[d] = atomicMax(&tabL[kL >> (GC_MF_KL_BITS - GC_MF_LSLOT_LOG)], mL[d]); rS[d] = atomicMax(&tabS[kS >> (GC_MF_KS_BITS - GC_MF_SSLOT_LOG)], mS[d]); }
         gc_wave_step();
     }
 #pragma unroll
@@ -395,51 +406,59 @@ __device__ __forceinline__ void mf_link_steps(const uint64_t q[LINK_DEPTH], uint
     }
 }
 
+// The launch is PERSISTENT: as many one-wave workgroups as the chip holds at once (the tables of a wave take 24 KiB of LDS: six per CU), each
+// drawing work items (frame, partition, segment) from a ticket counter until none is left -- seven of eight items are segments that do not
+// exist, and a launch of one short-lived workgroup per item left the CUs a wave or two each (run 33: 1.6 resident waves per CU on average).
 extern "C" __global__ void __launch_bounds__(64)
 MFK(gc_mf_link_kernel)(const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, GcMfEntry* __restrict__ entOut, uint32_t tilesPerFrame,
-                  uint64_t frameBytes)
+                  uint64_t frameBytes, uint32_t nLists, uint32_t* __restrict__ ticket)
 {
     __shared__ uint32_t tabL[1u << GC_MF_LSLOT_LOG];
     __shared__ uint32_t tabS[1u << GC_MF_SSLOT_LOG];
     const uint32_t lane = threadIdx.x;
-    // segment-major, so that the live waves are dealt evenly to the XCDs (workgroup i runs on XCD i % 8), and HIGHEST segment
-    // first: most workgroups of the leading groups find no such segment and retire at once; the ones that do exist belong to
-    // the long lists and are the longest pieces of work (LINK_SEG + LINK_WARM entries), so they start first instead of forming
-    // the tail of the launch
-    const uint32_t nLists = gridDim.x / LINK_SEGS;
-    const uint32_t seg = LINK_SEGS - 1u - blockIdx.x / nLists, fg = blockIdx.x % nLists;
-    const uint32_t frame = fg >> GC_MF_PART_LOG, g = fg & (GC_MF_PARTS - 1u);
-    const uint32_t* row = offs + (uint64_t)frame * (tilesPerFrame + 1u) * GC_MF_PARTS;
-    const uint32_t listStart = row[g], listEnd = row[(uint64_t)tilesPerFrame * GC_MF_PARTS + g];
-    const uint32_t start = listStart + seg * LINK_SEG;
-    if (start >= listEnd) return;
-    const uint32_t end = (seg + 1u < LINK_SEGS && start + LINK_SEG < listEnd) ? start + LINK_SEG : listEnd;
-    const GcMfEntry* E = ent + (uint64_t)frame * frameBytes;
-    GcMfEntry* EO = entOut + (uint64_t)frame * frameBytes;
-    for (uint32_t i = lane; i < (1u << GC_MF_LSLOT_LOG); i += 64u) tabL[i] = 0;
-    for (uint32_t i = lane; i < (1u << GC_MF_SSLOT_LOG); i += 64u) tabS[i] = 0;
-    gc_wave_sync();
-    if (seg != 0u) {                                              // warm the tables: insert only (ds_max keeps the most recent)
-        for (uint32_t i = start - LINK_WARM + lane; i < start; i += 64u) {
-            const uint64_t e = E[i];
-            const uint32_t pos = (uint32_t)e & ((1u << GC_MF_POS_BITS) - 1u);
-            const uint32_t kL = (uint32_t)(e >> GC_MF_POS_BITS) & ((1u << GC_MF_KL_BITS) - 1u);
-            const uint32_t kS = (uint32_t)(e >> (GC_MF_POS_BITS + GC_MF_KL_BITS)) & ((1u << GC_MF_KS_BITS) - 1u);
-            atomicMax(&tabL[kL >> 8], ((pos + 1u) << 8) | (kL & 0xFFu));
-            atomicMax(&tabS[kS >> 8], ((pos + 1u) << 8) | (kS & 0xFFu));
-        }
+    const uint32_t nItems = nLists * LINK_SEGS;
+    for (;;) {
+        uint32_t item = 0;
+        if (lane == 0u) item = atomicAdd(ticket, 1u);
+        item = __shfl(item, 0);
+        if (item >= nItems) break;
+        // segment-major and HIGHEST segment first: the segments that exist beyond the first belong to the long lists and are the longest pieces
+        // of work (LINK_SEG + LINK_WARM entries), so they start first instead of forming the tail of the launch
+        const uint32_t seg = LINK_SEGS - 1u - item / nLists, fg = item % nLists;
+        const uint32_t frame = fg >> GC_MF_PART_LOG, g = fg & (GC_MF_PARTS - 1u);
+        const uint32_t* row = offs + (uint64_t)frame * (tilesPerFrame + 1u) * GC_MF_PARTS;
+        const uint32_t listStart = row[g], listEnd = row[(uint64_t)tilesPerFrame * GC_MF_PARTS + g];
+        const uint32_t start = listStart + seg * LINK_SEG;
+        if (start >= listEnd) continue;
+        const uint32_t end = (seg + 1u < LINK_SEGS && start + LINK_SEG < listEnd) ? start + LINK_SEG : listEnd;
+        const GcMfEntry* E = ent + (uint64_t)frame * frameBytes;
+        GcMfEntry* EO = entOut + (uint64_t)frame * frameBytes;
+        gc_wave_sync();                                           // (the previous item's table operations are done)
+        for (uint32_t i = lane; i < (1u << GC_MF_LSLOT_LOG); i += 64u) tabL[i] = 0;
+        for (uint32_t i = lane; i < (1u << GC_MF_SSLOT_LOG); i += 64u) tabS[i] = 0;
         gc_wave_sync();
-    }
-    // Two register sets of LINK_DEPTH steps each: while one set is linked, the loads of the other are in flight.  (The set is
-    // requested right after the previous one has been consumed, so every wait in the loop body is for loads that are one whole
-    // set old.)
-    uint64_t qa[LINK_DEPTH], qb[LINK_DEPTH];
-    mf_link_load(qa, E, start, end, lane);
-    for (uint32_t s0 = start; s0 < end; s0 += 2u * 64u * LINK_DEPTH) {
-        mf_link_load(qb, E, s0 + 64u * LINK_DEPTH, end, lane);
-        mf_link_steps(qa, tabL, tabS, EO, s0, end, lane);
-        mf_link_load(qa, E, s0 + 2u * 64u * LINK_DEPTH, end, lane);
-        mf_link_steps(qb, tabL, tabS, EO, s0 + 64u * LINK_DEPTH, end, lane);
+        if (seg != 0u) {                                          // warm the tables: insert only (ds_max keeps the most recent)
+            for (uint32_t i = start - LINK_WARM + lane; i < start; i += 64u) {
+                const uint64_t e = E[i];
+                const uint32_t pos = (uint32_t)e & ((1u << GC_MF_POS_BITS) - 1u);
+                const uint32_t kL = (uint32_t)(e >> GC_MF_POS_BITS) & ((1u << GC_MF_KL_BITS) - 1u);
+                const uint32_t kS = (uint32_t)(e >> (GC_MF_POS_BITS + GC_MF_KL_BITS)) & ((1u << GC_MF_KS_BITS) - 1u);
+                atomicMax(&tabL[kL >> (GC_MF_KL_BITS - GC_MF_LSLOT_LOG)], ((pos + 1u) << 8) | (kL & 0xFFu));
+                atomicMax(&tabS[kS >> (GC_MF_KS_BITS - GC_MF_SSLOT_LOG)], ((pos + 1u) << 8) | (kS & 0xFFu));
+            }
+            gc_wave_sync();
+        }
+        // Two register sets of LINK_DEPTH steps each: while one set is linked, the loads of the other are in flight.  (The set is
+        // requested right after the previous one has been consumed, so every wait in the loop body is for loads that are one whole
+        // set old.)
+        uint64_t qa[LINK_DEPTH], qb[LINK_DEPTH];
+        mf_link_load(qa, E, start, end, lane);
+        for (uint32_t s0 = start; s0 < end; s0 += 2u * 64u * LINK_DEPTH) {
+            mf_link_load(qb, E, s0 + 64u * LINK_DEPTH, end, lane);
+            mf_link_steps(qa, tabL, tabS, EO, s0, end, lane);
+            mf_link_load(qa, E, s0 + 2u * 64u * LINK_DEPTH, end, lane);
+            mf_link_steps(qb, tabL, tabS, EO, s0 + 64u * LINK_DEPTH, end, lane);
+        }
     }
 }
 
@@ -453,7 +472,9 @@ MFK(gc_mf_link_kernel)(const uint32_t* __restrict__ offs, const GcMfEntry* __res
 //   - the records are collected in LDS and leave as full lines (stores are written through the L2 at the granularity of the
 //     request: 4-byte stores in list order would reach HBM as 94 M partial-line writes)
 #define MFV_T GC_MF_VERIFY_T
+#ifndef MFV_B
 #define MFV_B 4u                      // listed positions per thread and round
+#endif
 #define MFV_PAD_AFTER (GC_MATCH_CAP + 32u)                        // staged bytes behind the tile: own side of every compare
 #define MFV_STAGE_WORDS ((MF_STAGE_PAD + GC_MF_TILE + MFV_PAD_AFTER) / 4u)
 
@@ -483,26 +504,22 @@ __device__ __forceinline__ uint32_t mfv_len13(const LzW16& me, const LzW16& cw, 
     return len >= GC_MIN_MATCH ? len : 0u;
 }
 
-// MF_FAR / MF_SHORT: the candidates come from a later pass; recIn holds the records so far and a position's record is replaced
-// only by a candidate of better gain (recIn == rec: in place; a workgroup reads and writes its own tile only).
+// optional phase profile (thread 0's shader-clock deltas, added to prof[i] as they are taken: no registers held across the kernel)
+#define VP_PHASE(prof, tprev, i) do { if ((prof) != nullptr && threadIdx.x == 0) { const unsigned long long now_ = gc_clock(); atomicAdd(&(prof)[i], now_ - (tprev)); (tprev) = now_; } } while (0)
+
+// The verification of ONE tile: fills sRec[0 .. T.len) (LDS) and ends with a workgroup barrier.  Shared by the stand-alone verify
+// kernels (records -> HBM) and the fused verify + parse kernel (records never leave the CU).  Called by all MFV_T threads.
 template <int MODE>
-__device__ __forceinline__ void mf_verify_body(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
-                    const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, const uint32_t* recIn, uint32_t* rec)
+__device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks,
+                    const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, const uint32_t* recIn,
+                    uint32_t* sW, uint32_t* sRec, uint8_t* sExt, uint32_t* sStart, uint32_t* sLocal, uint32_t* sWaveTot,
+                    unsigned long long* prof = nullptr, unsigned long long* tprev = nullptr)
 {
     constexpr bool FAR = MODE == MF_FAR || MODE == MF_SHORT;      // a merging pass
     constexpr bool HALF = MODE == MF_HALF;                        // even positions only; matches are extended one byte backwards
     constexpr uint32_t MINLEN = MODE == MF_SHORT ? 3u : GC_MIN_MATCH;
     constexpr uint32_t LONGLEN = MODE == MF_SHORT ? 4u : (MODE == MF_FAR ? 16u : 8u);   // a verified long candidate has this many bytes
-    __shared__ uint32_t sW[MFV_STAGE_WORDS];
-    __shared__ uint32_t sRec[GC_MF_TILE];
-    __shared__ uint8_t sExt[HALF ? GC_MF_TILE : 4u];              // MF_HALF: bytes in front of a listed position that its match covers as well
-    __shared__ uint32_t sStart[GC_MF_PARTS], sLocal[GC_MF_PARTS + 1u];
-    __shared__ uint32_t sWaveTot[GC_MF_PARTS / 64u];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const uint32_t tile = mf_item(blockIdx.x, per);
-    if (tile >= nTiles) return;
-    const MfTile T = mf_tile(tile, frameBlocks, srcSize);
-    if (T.len == 0u) return;
     const uint32_t TPF = frameBlocks * GC_MF_TILES_PER_BLOCK;
     uint32_t c = 0, incl = 0;
     if (t < GC_MF_PARTS) {
@@ -527,6 +544,7 @@ __device__ __forceinline__ void mf_verify_body(const uint8_t* __restrict__ src, 
         if (t == GC_MF_PARTS - 1u) sLocal[GC_MF_PARTS] = before + incl;
     }
     __syncthreads();
+    VP_PHASE(prof, *tprev, 0);                                     // stage + run offsets
     const uint32_t nEnt = sLocal[GC_MF_PARTS];
     const uint8_t* wsrc = src + T.frameStart;
     const GcMfEntry* E = ent + (uint64_t)T.frame * ((uint64_t)frameBlocks * GC_ZSTD_BLOCK_MAX);
@@ -619,6 +637,7 @@ __device__ __forceinline__ void mf_verify_body(const uint8_t* __restrict__ src, 
             }
         }
     }
+    VP_PHASE(prof, *tprev, 1);                                     // listed positions
     if (!FAR && !HALF) unlisted();
     if (HALF) {
         // positions without a record of their own take the match of the nearest listed position behind them that reaches back to them
@@ -636,6 +655,25 @@ __device__ __forceinline__ void mf_verify_body(const uint8_t* __restrict__ src, 
         }
     }
     __syncthreads();
+}
+
+// MF_FAR / MF_SHORT: the candidates come from a later pass; recIn holds the records so far and a position's record is replaced
+// only by a candidate of better gain (recIn == rec: in place; a workgroup reads and writes its own tile only).
+template <int MODE>
+__device__ __forceinline__ void mf_verify_body(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
+                    const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, const uint32_t* recIn, uint32_t* rec)
+{
+    __shared__ uint32_t sW[MFV_STAGE_WORDS];
+    __shared__ uint32_t sRec[GC_MF_TILE];
+    __shared__ uint8_t sExt[MODE == MF_HALF ? GC_MF_TILE : 4u];   // MF_HALF: bytes in front of a listed position that its match covers as well
+    __shared__ uint32_t sStart[GC_MF_PARTS], sLocal[GC_MF_PARTS + 1u];
+    __shared__ uint32_t sWaveTot[GC_MF_PARTS / 64u];
+    const uint32_t t = threadIdx.x;
+    const uint32_t tile = mf_item(blockIdx.x, per);
+    if (tile >= nTiles) return;
+    const MfTile T = mf_tile(tile, frameBlocks, srcSize);
+    if (T.len == 0u) return;
+    mf_verify_tile<MODE>(T, src, srcSize, frameBlocks, offs, ent, recIn, sW, sRec, sExt, sStart, sLocal, sWaveTot);
     // records out: 16 bytes per lane, full lines
     GcU4* R4 = (GcU4*)(rec + T.tileStart);
     const GcU4* S4 = (const GcU4*)sRec;
@@ -715,7 +753,6 @@ MFK(gc_mf_deepen_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint
     }
 }
 
-#ifndef GC_MF_FAST       // (W6 works on blocks, not tiles: one copy)
 // ------------------------------------------------------------------------------------------------ W6 parse
 // Greedy parse with one-step lazy evaluation: next(p) = p + len if the match at p is taken, else p + 1; the block's sequences
 // are the matches on the path from position 0.  The path is found without walking the block serially:
@@ -761,6 +798,127 @@ __device__ __forceinline__ uint32_t pz_exit(uint32_t nxt)
     return cur;                                                   // 64 .. 127
 }
 
+
+// ------------------------------------------------------------------------------------------------ W5 + W6 fused: verify + parse
+// The levels that parse the first pass's records as they are (no far pass, no link following, no price-based parse) never need the
+// records in HBM: one workgroup per BLOCK takes the block's tiles in order, verifies a tile into LDS (mf_verify_tile) and parses it
+// right there.  The parse of a tile is W6's scheme at tile scale -- every wave composes the exit maps of its 16 segments, the maps
+// are chained from the lane at which the path entered the tile, every wave walks its segments from its real entry -- and because the
+// tiles are taken in order the entry lane, the sequence count and the literal count simply carry over from tile to tile: no group
+// maps, no second reading of the records.  Literal bytes come from the staged tile.  The lazy look-ahead stops at the tile's end
+// (the records of the next tile do not exist yet): a position in the last two bytes of a tile takes its match as it is.
+// HBM traffic per input byte: 8 R (linked entries) + candidate windows + 1 R (tile) + sequences and literals out; W5's 4 W and W6's
+// 8-12 R of records are gone.
+#define VP_WAVES   (MFV_T / 64u)
+#define VP_SEGS    (GC_MF_TILE / 64u)                            // segments per tile
+#define VP_SPW     (VP_SEGS / VP_WAVES)                          // segments per wave (16 in both geometries)
+#ifdef VP_MIN_WAVES
+#elif defined(GC_MF_FAST)
+#define VP_MIN_WAVES 6                                           // three workgroups of 512 per CU (LDS allows three): <= 80 VGPRs
+#else
+#define VP_MIN_WAVES 4
+#endif
+extern "C" __global__ void __launch_bounds__(MFV_T, VP_MIN_WAVES)
+MFK(gc_mf_vparse_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nBlocks, uint32_t per, uint32_t lazy,
+                    const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent,
+                    GcSeqRaw* __restrict__ seqRaw, uint8_t* __restrict__ lit, GcBlockMeta* __restrict__ meta,
+                    unsigned long long* __restrict__ prof /* optional phase profile: slots 0 stage, 1 listed, 2 unlisted, 3 exit maps, 4 entry chain, 5 walk, 6 emit */)
+{
+    __shared__ uint32_t sW[MFV_STAGE_WORDS];
+    __shared__ uint32_t sRec[GC_MF_TILE + 4u];                    // (+ zeros behind the tile: the look-ahead of its last positions)
+    __shared__ uint8_t sExt[4u];
+    __shared__ uint32_t sStart[GC_MF_PARTS], sLocal[GC_MF_PARTS + 1u];
+    __shared__ uint32_t sWaveTot[GC_MF_PARTS / 64u];
+    __shared__ uint8_t  sExitW[VP_WAVES][64];                     // exit lane of a wave's 16 segments for every entry lane
+    __shared__ uint64_t sMaskSeq[VP_SEGS], sMaskLit[VP_SEGS];
+    __shared__ uint32_t sCntSeq[VP_WAVES], sCntLit[VP_WAVES];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    const uint32_t b = mf_item(blockIdx.x, per);
+    if (b >= nBlocks) return;
+    const uint64_t base = (uint64_t)b * GC_ZSTD_BLOCK_MAX;
+    GcSeqRaw* mySeq = seqRaw + (uint64_t)b * GC_MAX_SEQ_PER_BLOCK;
+    uint8_t* myLit = lit + (uint64_t)b * GC_ZSTD_BLOCK_MAX;
+    uint32_t entry = 0, seqRun = 0, litRun = 0;                   // carried from tile to tile (uniform)
+    const uint64_t lt = gc_lanemask_lt();
+    unsigned long long tprev = prof ? gc_clock() : 0ull;
+    for (uint32_t ti = 0; ti < GC_MF_TILES_PER_BLOCK; ti++) {
+        entry = gc_uniform(entry); seqRun = gc_uniform(seqRun); litRun = gc_uniform(litRun);      // (scalar registers)
+        const MfTile T = mf_tile(gc_uniform(b * GC_MF_TILES_PER_BLOCK + ti), frameBlocks, srcSize);
+        if (T.len == 0u) break;                                   // (uniform: the block ends here)
+        mf_verify_tile<MF_BASE>(T, src, srcSize, frameBlocks, offs, ent, nullptr, sW, sRec, sExt, sStart, sLocal, sWaveTot, prof, &tprev);
+        const uint32_t n = T.len;
+        VP_PHASE(prof, tprev, 2);
+        // ---- exit map of this wave's segments
+        const uint32_t seg0 = wave * VP_SPW;
+        {
+            uint32_t comp = lane;
+#pragma unroll 1
+            for (uint32_t k = 0; k < VP_SPW; k++) {
+                const uint32_t seg = seg0 + k;
+                if (seg * 64u >= n) break;                        // (uniform) past the end: the identity
+                const PzSeg s = pz_seg(sRec, seg * 64u + lane, n, lane, lazy);
+                const uint32_t ex = pz_exit(s.nxt) - 64u;
+                comp = __shfl(ex, (int)comp);
+            }
+            sExitW[wave][lane] = (uint8_t)comp;
+        }
+        __syncthreads();
+        VP_PHASE(prof, tprev, 3);
+        // ---- real entry lane of this wave: the tile's entry chained through the waves in front (every wave for itself: <= 15 LDS reads)
+        uint32_t e = entry;
+        for (uint32_t w = 0; w < wave; w++) e = sExitW[w][e];
+        e = gc_uniform(e);
+        uint32_t exitAll = e;                                     // ... and the lane at which the path enters the next tile
+        for (uint32_t w = wave; w < VP_WAVES; w++) exitAll = sExitW[w][exitAll];
+        VP_PHASE(prof, tprev, 4);
+        // ---- walk the segments from the real entry: path masks + counts
+        uint32_t nS = 0, nL = 0;
+#pragma unroll 1
+        for (uint32_t k = 0; k < VP_SPW; k++) {
+            const uint32_t seg = seg0 + k;
+            if (seg * 64u >= n) break;
+            const uint32_t p = seg * 64u + lane;
+            const PzSeg s = pz_seg(sRec, p, n, lane, lazy);
+            uint64_t path = 0;
+            uint32_t c = e;
+            while (c < 64u) { path |= 1ull << c; c = gc_readlane(s.nxt, c); }
+            e = c - 64u;
+            const uint64_t takeMask = __ballot(s.take), inMask = __ballot(p < n);
+            const uint64_t mS = path & takeMask, mL = path & ~takeMask & inMask;
+            if (lane == 0) { sMaskSeq[seg] = mS; sMaskLit[seg] = mL; }
+            nS += (uint32_t)__popcll(mS); nL += (uint32_t)__popcll(mL);
+        }
+        if (lane == 0) { sCntSeq[wave] = nS; sCntLit[wave] = nL; }
+        __syncthreads();
+        VP_PHASE(prof, tprev, 5);
+        uint32_t sBefore = 0, lBefore = 0, sAll = 0, lAll = 0;
+        for (uint32_t w = 0; w < VP_WAVES; w++) {
+            const uint32_t cs = sCntSeq[w], cl = sCntLit[w];
+            if (w < wave) { sBefore += cs; lBefore += cl; }
+            sAll += cs; lAll += cl;
+        }
+        // ---- emit
+        uint32_t sr = seqRun + sBefore, lr = litRun + lBefore;
+#pragma unroll 1
+        for (uint32_t k = 0; k < VP_SPW; k++) {
+            const uint32_t seg = seg0 + k;
+            if (seg * 64u >= n) break;
+            const uint64_t mS = sMaskSeq[seg], mL = sMaskLit[seg];
+            const uint32_t q = seg * 64u + lane;
+            const uint32_t myLitRank = lr + (uint32_t)__popcll(mL & lt);
+            if ((mS >> lane) & 1ull) { GcSeqRaw r; r.litRank = myLitRank; r.offml = sRec[q]; mySeq[sr + (uint32_t)__popcll(mS & lt)] = r; }
+            if ((mL >> lane) & 1ull) myLit[myLitRank] = (uint8_t)mf_lds_byte(sW, q + MF_STAGE_PAD);
+            sr += (uint32_t)__popcll(mS); lr += (uint32_t)__popcll(mL);
+        }
+        entry = exitAll; seqRun += sAll; litRun += lAll;
+        __syncthreads();                                          // the next tile overwrites sW / sRec / the masks
+        VP_PHASE(prof, tprev, 6);
+    }
+    if (t == 0) { GcBlockMeta m; m.nSeqRaw = seqRun; m.nLit = litRun; meta[b] = m; }
+    (void)base;
+}
+
+#ifndef GC_MF_FAST       // (W6 works on blocks, not tiles: one copy)
 extern "C" __global__ void __launch_bounds__(PZ_T)
 gc_mf_parse_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t lazy, const uint32_t* __restrict__ rec,
                    GcSeqRaw* __restrict__ seqRaw, uint8_t* __restrict__ lit, GcBlockMeta* __restrict__ meta, uint16_t* __restrict__ priceTab,

@@ -59,8 +59,12 @@ typedef uint64_t GcMfEntry;
 #define GC_MF_POS_BITS    23u
 #define GC_MF_KL_BITS     20u
 #define GC_MF_KS_BITS     19u
+#ifndef GC_MF_LSLOT_LOG
 #define GC_MF_LSLOT_LOG   12u                             // W4 long table: 2^12 slots per partition (2^20 per frame)
+#endif
+#ifndef GC_MF_SSLOT_LOG
 #define GC_MF_SSLOT_LOG   11u                             // W4 short table: 2^11 slots per partition (2^19 per frame)
+#endif
 
 #define GC_MF_PARSE_T     1024u                           // W6: threads per block
 #ifdef GC_MF_FAST

@@ -31,7 +31,11 @@
 #define SEQ_TILE_WORDS ((SEQ_T * 80u) / 32u + 8u)
 #define SEQ_CHAIN_TILE 4096u   // sequences per state-chain tile
 #define SEQ_CHAIN_SEG  64u     // sequences per lane and tile
+#define SEQ_TC(u) ((u) + ((u) >> 6))                     // index of tile element u in tCode (row stride 65 bytes)
+#define SEQ_TO(u) ((u) + 2u * ((u) >> 6))                // ... in tOut (row stride 66 half-words = 33 banks)
+#ifndef SEQ_WARM_SEGS
 #define SEQ_WARM_SEGS  4u      // a lane looks this many segments back for a point where all state walks meet
+#endif
 
 __constant__ uint8_t kLLCode[64] = { 0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,16,17,17,18,18,19,19,20,20,20,20,21,21,21,21,
                                      22,22,22,22,22,22,22,22,23,23,23,23,23,23,23,23,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24 };
@@ -59,8 +63,10 @@ struct SeqTab {              // one FSE table in LDS
     uint32_t descSize, mode, tableLog, maxSym, finalState;
     uint32_t tabMaxSym;      // last symbol described by norm[] (predefined: whole default table)
     // state-chain tile scratch (see "chains" in the kernel)
-    uint8_t  tCode[SEQ_CHAIN_TILE];
-    uint16_t tOut[SEQ_CHAIN_TILE];
+    // a lane walks ITS segment, i.e. the lanes of a wave touch elements SEQ_CHAIN_SEG apart: with a row length of exactly 64 all of them would
+    // fall into one or two LDS banks (a 32-way conflict per access); one element of padding per segment spreads them over all banks
+    uint8_t  tCode[SEQ_CHAIN_TILE + SEQ_CHAIN_TILE / SEQ_CHAIN_SEG + 3u];
+    uint16_t tOut[SEQ_CHAIN_TILE + 2u * (SEQ_CHAIN_TILE / SEQ_CHAIN_SEG)];
     uint64_t meet[SEQ_CHAIN_TILE / 64u];
 };
 
@@ -298,12 +304,12 @@ gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __res
                 // stage the codes (independent loads, eight in flight per lane), then per 64 sequences one mask of the positions
                 // that hold a count-1 symbol ("meeting points")
 #pragma unroll 8
-                for (uint32_t u = lane; u < tileLen; u += 64u) T.tCode[u] = C[nSeq - 1u - (tb + u)];
+                for (uint32_t u = lane; u < tileLen; u += 64u) T.tCode[SEQ_TC(u)] = C[nSeq - 1u - (tb + u)];
                 gc_wave_sync();
                 SEQ_SUB(5);
                 for (uint32_t k = 0; k < tileLen; k += 64u) {
                     const uint32_t u = k + lane;
-                    const bool isR = u < tileLen && ((resetMask >> T.tCode[u]) & 1ull) != 0ull;
+                    const bool isR = u < tileLen && ((resetMask >> T.tCode[SEQ_TC(u)]) & 1ull) != 0ull;
                     const uint64_t bal = __ballot(isR);
                     if (lane == 0u) T.meet[k >> 6] = bal;
                 }
@@ -313,7 +319,7 @@ gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __res
                 uint32_t first = u0;                          // first index of the segment that emits bits
                 uint32_t st0 = carry;
                 if (lane < nSegs) {
-                    if (tb + u0 == 0u) { st0 = gc_fse_init_state(T.state, T.tt[T.tCode[0]]); T.tOut[0] = 0; first = 1u; }   // FSE_initCState2: no bits
+                    if (tb + u0 == 0u) { st0 = gc_fse_init_state(T.state, T.tt[T.tCode[SEQ_TC(0)]]); T.tOut[SEQ_TO(0)] = 0; first = 1u; }   // FSE_initCState2: no bits
                     else if (lane != 0u) {
                         // run ahead from the nearest meeting point in the SEQ_WARM_SEGS segments before this one (from there the
                         // state is exact whatever it was before); if there is none, from SEQ_WARM_SEGS segments back (a guess)
@@ -322,12 +328,12 @@ gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __res
                             const uint64_t m = T.meet[c];
                             if (m) { w = c * 64u + 63u - (uint32_t)__clzll((long long)m); break; }
                         }
-                        if (tb + w == 0u) { st0 = gc_fse_init_state(T.state, T.tt[T.tCode[0]]); w = 1u; }                   // exact, not a guess
+                        if (tb + w == 0u) { st0 = gc_fse_init_state(T.state, T.tt[T.tCode[SEQ_TC(0)]]); w = 1u; }                   // exact, not a guess
                         else st0 = 1u << L;
                         if (w < u0) {                              // the symbol's table entry does not depend on the state: fetched one
-                            GcFseSym sy = T.tt[T.tCode[w]];          // step ahead, so a step costs one dependent LDS read, not three
+                            GcFseSym sy = T.tt[T.tCode[SEQ_TC(w)]];          // step ahead, so a step costs one dependent LDS read, not three
                             for (; w < u0; w++) {
-                                const GcFseSym nx = T.tt[T.tCode[w + 1u < u0 ? w + 1u : w]];
+                                const GcFseSym nx = T.tt[T.tCode[SEQ_TC(w + 1u < u0 ? w + 1u : w)]];
                                 const uint32_t nb = (st0 + sy.deltaNbBits) >> 16;
                                 st0 = T.state[(st0 >> nb) + (uint32_t)sy.deltaFindState];
                                 sy = nx;
@@ -347,12 +353,12 @@ gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __res
                 for (;;) {
                     if (redo) {
                         uint32_t state = st0, u = first;
-                        GcFseSym sy = T.tt[T.tCode[u < u1 ? u : u1 - 1u]];
+                        GcFseSym sy = T.tt[T.tCode[SEQ_TC(u < u1 ? u : u1 - 1u)]];
                         for (; u < u1; u++) {
-                            if (!firstPass && (T.tOut[u] & 0x3FFu) == (state & 0x3FFu)) break;
-                            const GcFseSym nx = T.tt[T.tCode[u + 1u < u1 ? u + 1u : u]];
+                            if (!firstPass && (T.tOut[SEQ_TO(u)] & 0x3FFu) == (state & 0x3FFu)) break;
+                            const GcFseSym nx = T.tt[T.tCode[SEQ_TC(u + 1u < u1 ? u + 1u : u)]];
                             const uint32_t nb = (state + sy.deltaNbBits) >> 16;
-                            T.tOut[u] = (uint16_t)((nb << 10) | (state & 0x3FFu));
+                            T.tOut[SEQ_TO(u)] = (uint16_t)((nb << 10) | (state & 0x3FFu));
                             state = T.state[(state >> nb) + (uint32_t)sy.deltaFindState];
                             sy = nx;
                         }
@@ -373,7 +379,7 @@ gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __res
                 carry = __shfl(fin, (int)(nSegs - 1u));
                 gc_wave_sync();
                 SEQ_SUB(7);
-                for (uint32_t u = lane; u < tileLen; u += 64u) S[nSeq - 1u - (tb + u)] = T.tOut[u];
+                for (uint32_t u = lane; u < tileLen; u += 64u) S[nSeq - 1u - (tb + u)] = T.tOut[SEQ_TO(u)];
                 gc_wave_sync();
                 SEQ_SUB(8);
             }

@@ -14,8 +14,9 @@ ap.add_argument("--corpus", default="text-zipf")
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--codec", default="zstd")
 ap.add_argument("--level", type=int, default=0)
+ap.add_argument("--lib", default=None, help="library variant (tools/_variants/lib_<name>.so)")
 a = ap.parse_args()
-g.build_hip()
+if not a.lib: g.build_hip()
 pkg = g.load_package()
 from importlib import util as _u
 spec = _u.spec_from_file_location("c", os.path.join(ROOT, "7-zip-zstd_amd", "corpus", "__init__.py"))
@@ -23,7 +24,7 @@ cm = _u.module_from_spec(spec); spec.loader.exec_module(cm)
 x = cm.corpus(a.corpus, a.bytes)
 fl2 = a.codec == "flzma2"
 br = a.codec == "brotli"
-enc = pkg.Flzma2Encoder(device=0, level=a.level or 5) if fl2 else (pkg.BrotliEncoder(device=0, level=a.level or 6) if br else pkg.ZstdEncoder(device=0, level=a.level or 3))
+enc = pkg.Flzma2Encoder(device=0, level=a.level or 5, lib_path=a.lib) if fl2 else (pkg.BrotliEncoder(device=0, level=a.level or 6, lib_path=a.lib) if br else pkg.ZstdEncoder(device=0, level=a.level or 3, lib_path=a.lib))
 d_src = torch.from_numpy(x).cuda(); cap = enc.compress_bound(x.size); d_dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
 def run():
     enc.code_device(d_src.data_ptr(), x.size, d_dst.data_ptr(), cap); return enc.finish()
