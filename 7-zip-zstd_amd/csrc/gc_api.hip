@@ -30,8 +30,10 @@ struct GcFramePlan { uint64_t off; uint32_t size; uint32_t compressed; };
 
 extern "C" __global__ void gc_zstd_lz_kernel(const uint8_t*, uint64_t, GcSeqRaw*, uint8_t*, GcBlockMeta*, unsigned long long*);
 extern "C" __global__ void gc_zstd_huf_kernel(const uint8_t*, const GcBlockMeta*, uint8_t*, GcSectionInfo*);
-extern "C" __global__ void gc_zstd_seq_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t*, uint32_t*, uint8_t*, uint16_t*,
-                                              uint8_t*, GcSectionInfo*, uint64_t, uint32_t, unsigned long long*);
+extern "C" __global__ void gc_zstd_seq_codes_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t*, uint32_t*, uint8_t*, GcSeqHist*, uint8_t*, GcSectionInfo*, uint32_t, unsigned long long*);
+extern "C" __global__ void gc_zstd_seq_tables_kernel(const GcSeqHist*, const GcSectionInfo*, GcSeqTabG*, unsigned long long*);
+extern "C" __global__ void gc_zstd_seq_chain_kernel(const uint8_t*, const GcSectionInfo*, GcSeqTabG*, uint16_t*, unsigned long long*);
+extern "C" __global__ void gc_zstd_seq_pack_kernel(const uint64_t*, const uint8_t*, const uint16_t*, const GcSeqTabG*, uint8_t*, GcSectionInfo*, uint64_t, unsigned long long*);
 extern "C" __global__ void gc_zstd_plan_kernel(const GcSectionInfo*, uint32_t, uint64_t, uint64_t, uint32_t, GcFramePlan*, uint64_t*, uint32_t);
 extern "C" __global__ void gc_zstd_emit_kernel(const uint8_t*, uint64_t, const uint8_t*, const uint8_t*, const GcSectionInfo*,
                                                const GcFramePlan*, const uint64_t*, uint32_t, uint32_t, uint8_t*);
@@ -68,6 +70,8 @@ extern "C" __global__ void gc_mf_verify_far_kernel_p8(const uint8_t*, uint64_t, 
 extern "C" __global__ void gc_mf_deepen_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, uint32_t*);
 extern "C" __global__ void gc_mf_vparse_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, GcSeqRaw*, uint8_t*, GcBlockMeta*, unsigned long long*);
 extern "C" __global__ void gc_mf_vparse_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, GcSeqRaw*, uint8_t*, GcBlockMeta*, unsigned long long*);
+extern "C" __global__ void gc_mf_vparse_tile_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, GcSeqRaw*, uint8_t*, GcBlockMeta*, uint32_t*, uint32_t*, unsigned long long*);
+extern "C" __global__ void gc_mf_vparse_tile_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, GcSeqRaw*, uint8_t*, GcBlockMeta*, uint32_t*, uint32_t*, unsigned long long*);
 extern "C" __global__ void gc_mf_parse_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcSeqRaw*, uint8_t*, GcBlockMeta*, uint16_t*, uint32_t);
 extern "C" __global__ void gc_mf_short_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint16_t*);
 extern "C" __global__ void gc_mf_dp2_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
@@ -109,12 +113,13 @@ struct gc_ctx {
     // workspace, grown on demand
     uint32_t capBlocks;
     GcSeqRaw* seqRaw; uint8_t* lit; GcBlockMeta* meta;
-    uint64_t* seqPacked; uint32_t* seqOff; uint8_t* codes; uint16_t* stOut;
+    uint64_t* seqPacked; uint32_t* seqOff; uint8_t* codes; uint16_t* stOut; GcSeqHist* seqHist; GcSeqTabG* seqTabs;
     uint8_t* litSec; uint8_t* seqSec; GcSectionInfo* info; GcFramePlan* plan; uint64_t* result;
     uint32_t* lzNM; GcLzmaChunkInfo* lzInfo; GcLzmaPlan* lzPlan; uint16_t* lzStream; size_t lzStreamCap;       // FLZMA2 path
     uint64_t* lzM; size_t lzMCap; uint8_t* lzRcOut; size_t lzRcOutCap;     // item lists, range-coder staging (allocated on the first FLZMA2 call)
     uint8_t* brStage; GcBrotliBlockInfo* brInfo; GcBrotliPlan* brPlan;    // BROTLI path
     // windowed match finder (gc_mf.h): counts/offsets, partition starts, entry lists; grown on demand
+    uint32_t* mfTileWord; size_t mfTileWordCap;   // fused verify + parse: one word of counts per tile
     uint32_t nCU; uint32_t* mfTicket;      // compute units of the device; ticket counters of the persistent launches (4 per part)
     uint32_t* mfCnt; size_t mfCntCap; GcMfEntry* mfEnt; size_t mfEntCap; GcMfEntry* mfEnt2; size_t mfEnt2Cap; uint32_t* mfRec; size_t mfRecCap; uint32_t* mfRec2; size_t mfRec2Cap;
     uint16_t* mfRec3; size_t mfRec3Cap; uint32_t* mfDp; size_t mfDpCap; uint16_t* mfPrice; size_t mfPriceCap; uint32_t* mfWinCost; size_t mfWinCostCap; uint32_t* mfDpStat; size_t mfDpStatCap;      // W5s records, W7 records, price tables, W7 phase-A symbol counts
@@ -191,7 +196,7 @@ extern "C" int gc_ctx_create(gc_ctx** out, int device)
         for (uint32_t i = 0; rc == GC_OK && i < GC_PART_EVENTS; i++) if (hipEventCreate(&c->evPart[p][i]) != hipSuccess) rc = GC_ERR_HIP;
     }
     if (rc == GC_OK && hipMalloc((void**)&c->prof, (GC_LZ_PHASES + GC_SEQ_PHASES) * sizeof(unsigned long long)) != hipSuccess) rc = GC_ERR_NOMEM;
-    if (rc == GC_OK && hipMalloc((void**)&c->mfTicket, GC_MAX_PARTS * 4u * sizeof(uint32_t)) != hipSuccess) rc = GC_ERR_NOMEM;
+    if (rc == GC_OK && hipMalloc((void**)&c->mfTicket, GC_MAX_PARTS * 16u * sizeof(uint32_t)) != hipSuccess) rc = GC_ERR_NOMEM;
     if (rc == GC_OK && (hipMalloc((void**)&c->result, 16) != hipSuccess || hipHostMalloc((void**)&c->hostResult, 16) != hipSuccess)) rc = GC_ERR_NOMEM;
     if (rc != GC_OK) { ctx_release(c); return rc; }
     c->dbgFrameBlocks = 0; c->dbgPartFrames = 0;
@@ -204,12 +209,12 @@ extern "C" int gc_ctx_create(gc_ctx** out, int device)
 static void free_workspace(gc_ctx* c)
 {
     hipFree(c->seqRaw); hipFree(c->lit); hipFree(c->meta); hipFree(c->seqPacked); hipFree(c->seqOff); hipFree(c->codes);
-    hipFree(c->stOut); hipFree(c->litSec); hipFree(c->seqSec); hipFree(c->info); hipFree(c->plan);
+    hipFree(c->stOut); hipFree(c->seqHist); hipFree(c->seqTabs); hipFree(c->litSec); hipFree(c->seqSec); hipFree(c->info); hipFree(c->plan);
     hipFree(c->brStage); hipFree(c->brInfo); hipFree(c->brPlan); c->brStage = nullptr; c->brInfo = nullptr; c->brPlan = nullptr;
     hipFree(c->lzNM); hipFree(c->lzInfo); hipFree(c->lzPlan); hipFree(c->lzStream); c->lzStream = nullptr; c->lzStreamCap = 0; c->lzNM = nullptr; c->lzInfo = nullptr; c->lzPlan = nullptr;
     hipFree(c->lzM); c->lzM = nullptr; c->lzMCap = 0; hipFree(c->lzRcOut); c->lzRcOut = nullptr; c->lzRcOutCap = 0;
     c->seqRaw = nullptr; c->lit = nullptr; c->meta = nullptr; c->seqPacked = nullptr; c->seqOff = nullptr; c->codes = nullptr;
-    c->stOut = nullptr; c->litSec = nullptr; c->seqSec = nullptr; c->info = nullptr; c->plan = nullptr; c->capBlocks = 0;
+    c->stOut = nullptr; c->seqHist = nullptr; c->seqTabs = nullptr; c->litSec = nullptr; c->seqSec = nullptr; c->info = nullptr; c->plan = nullptr; c->capBlocks = 0;
 }
 
 static void ctx_release(gc_ctx* c)
@@ -220,7 +225,7 @@ static void ctx_release(gc_ctx* c)
     hipFree(c->prof); hipFree(c->mfTicket); hipFree(c->result); if (c->hostResult) hipHostFree(c->hostResult); hipFree(c->dIn); hipFree(c->dOut);
     hipFree(c->zdLit); hipFree(c->zdSeq); hipFree(c->zdFrames); hipFree(c->zdResult); hipFree(c->zdTot); hipFree(c->zdBlocks); hipFree(c->zdOrder); hipFree(c->zdReady); hipFree(c->zdTicket); hipFree(c->zdPlace); hipFree(c->zdPtr); hipFree(c->zdDone); hipFree(c->zdFerr);
     for (int i = 0; i < 2; i++) if (c->zdEv[i]) hipEventDestroy(c->zdEv[i]);
-    hipFree(c->mfCnt); hipFree(c->mfEnt); hipFree(c->mfEnt2); hipFree(c->mfRec); hipFree(c->mfRec2); hipFree(c->mfRec3); hipFree(c->mfDp); hipFree(c->mfPrice); hipFree(c->mfWinCost); hipFree(c->mfDpStat);
+    hipFree(c->mfTileWord); hipFree(c->mfCnt); hipFree(c->mfEnt); hipFree(c->mfEnt2); hipFree(c->mfRec); hipFree(c->mfRec2); hipFree(c->mfRec3); hipFree(c->mfDp); hipFree(c->mfPrice); hipFree(c->mfWinCost); hipFree(c->mfDpStat);
     for (int i = 0; i < 8; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
     for (uint32_t p = 0; p < GC_MAX_PARTS; p++) {
         for (int i = 0; i < 13; i++) if (c->evMf[p][i]) hipEventDestroy(c->evMf[p][i]);
@@ -262,7 +267,9 @@ static int ensure_workspace(gc_ctx* c, uint32_t nBlocks)
         hipMalloc((void**)&c->seqPacked, nb * ms * sizeof(uint64_t)) != hipSuccess ||
         hipMalloc((void**)&c->seqOff, nb * ms * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void**)&c->codes, nb * ms * 3) != hipSuccess ||
-        hipMalloc((void**)&c->stOut, nb * ms * 3 * sizeof(uint16_t)) != hipSuccess ||
+        hipMalloc((void**)&c->stOut, nb * GC_SEQ_ST_STRIDE * 3 * sizeof(uint16_t)) != hipSuccess ||
+        hipMalloc((void**)&c->seqHist, nb * sizeof(GcSeqHist)) != hipSuccess ||
+        hipMalloc((void**)&c->seqTabs, nb * 3 * sizeof(GcSeqTabG)) != hipSuccess ||
         hipMalloc((void**)&c->litSec, nb * GC_LITSEC_STRIDE) != hipSuccess ||
         hipMalloc((void**)&c->seqSec, nb * GC_SEQSEC_STRIDE) != hipSuccess ||
         hipMalloc((void**)&c->info, nb * sizeof(GcSectionInfo)) != hipSuccess ||
@@ -305,10 +312,12 @@ static int ensure_finder_workspace(gc_ctx* c, size_t n, uint32_t frameBlocks)
     const size_t needCnt = g.cntWords * sizeof(uint32_t), needEnt = (size_t)g.nFrames * g.frameBytes * sizeof(GcMfEntry);
     const size_t needRec = (size_t)g.nBlocks * GC_ZSTD_BLOCK_MAX * sizeof(uint32_t);
     const size_t needPrice = (size_t)g.nBlocks * GC_PRICE_WORDS * sizeof(uint16_t);
-    if (needCnt > c->mfCntCap || needEnt > c->mfEntCap || needEnt > c->mfEnt2Cap || needRec > c->mfRecCap || ((c->searchDepth || c->shortPass) && needRec > c->mfRec2Cap) ||
+    const size_t needTileWord = ((size_t)g.nTiles + 64u) * sizeof(uint32_t);
+    if (needTileWord > c->mfTileWordCap || needCnt > c->mfCntCap || needEnt > c->mfEntCap || needEnt > c->mfEnt2Cap || needRec > c->mfRecCap || ((c->searchDepth || c->shortPass) && needRec > c->mfRec2Cap) ||
         (c->priceParse && (needRec / 2u > c->mfRec3Cap || needRec > c->mfDpCap || needPrice > c->mfPriceCap || (size_t)g.nBlocks * 128u > c->mfWinCostCap || (size_t)g.nBlocks * GC_DPS_WORDS * 4u > c->mfDpStatCap))) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         int rc;
+        if ((rc = mf_grow(c, (void**)&c->mfTileWord, &c->mfTileWordCap, needTileWord, "tile counts")) != GC_OK) return rc;
         if ((rc = mf_grow(c, (void**)&c->mfCnt, &c->mfCntCap, needCnt, "offsets")) != GC_OK) return rc;
         if ((rc = mf_grow(c, (void**)&c->mfEnt, &c->mfEntCap, needEnt, "entries")) != GC_OK) return rc;
         if ((rc = mf_grow(c, (void**)&c->mfEnt2, &c->mfEnt2Cap, needEnt, "linked entries")) != GC_OK) return rc;
@@ -351,8 +360,8 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
     uint32_t linkLaunch = 0;
     uint32_t linkWpc = 6u; gc_env_u32("GC_LINK_WPC", 1u, 32u, &linkWpc);         // test hook: one-wave workgroups per CU
     const uint32_t nLists = g.nFrames * nParts, linkGrid = nLists * GC_MF_LINK_SEGS < c->nCU * linkWpc ? nLists * GC_MF_LINK_SEGS : c->nCU * linkWpc;
-    HIPCHK(c, hipMemsetAsync(c->mfTicket + part * 4u, 0, 4u * sizeof(uint32_t), st));
-#define MF_LINK(cnt_, ent_, ent2_) do { uint32_t* ticket_ = c->mfTicket + part * 4u + linkLaunch++; \
+    HIPCHK(c, hipMemsetAsync(c->mfTicket + part * 16u, 0, 16u * sizeof(uint32_t), st));      // words 0..3: W4's launches, 8..15: the fused kernel's XCD classes
+#define MF_LINK(cnt_, ent_, ent2_) do { uint32_t* ticket_ = c->mfTicket + part * 16u + linkLaunch++; \
         GC_LAUNCH(MFSEL(gc_mf_link_kernel), linkGrid, 64, st, (const uint32_t*)(cnt_), (const GcMfEntry*)(ent_), ent2_, g.tilesPerFrame, g.frameBytes, nLists, ticket_); } while (0)
     hipEvent_t* ev = c->evMf[part];
     HIPCHK(c, hipEventRecord(ev[0], st));
@@ -371,6 +380,15 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
     gc_env_u32("GC_FUSED_PARSE", 0u, 1u, &fused);               // test hook: 0 = the two kernels
     if (fused && (c->halfList || c->farPass || c->searchDepth || c->priceParse || c->shortPass)) fused = 0u;
     if (fused) {
+        uint32_t mode = 2u; gc_env_u32("GC_FUSED_MODE", 1u, 2u, &mode);       // test hook: 1 = a workgroup per block (tiles in order), 2 = a workgroup per tile
+        if (mode == 2u) {
+            const uint32_t tpb = GC_ZSTD_BLOCK_MAX >> g.tileLog;
+            const uint32_t perV = ((gc_xcd_per(g.nTiles) + tpb - 1u) / tpb) * tpb;      // whole blocks per XCD class: a tile never waits for a tile of another class
+            uint32_t* tw = c->mfTileWord + (size_t)frame0 * g.tilesPerFrame;
+            HIPCHK(c, hipMemsetAsync(tw, 0, (size_t)g.nTiles * sizeof(uint32_t), st));
+            GC_LAUNCH(MFSEL(gc_mf_vparse_tile_kernel), perV * GC_XCDS, g.verifyT, st, src, (uint64_t)n, frameBlocks, g.nTiles, perV, c->lazyDepth, (const uint32_t*)cnt,
+                      (const GcMfEntry*)ent2, seqRaw, lit, meta, c->mfTicket + part * 16u + 8u, tw, prof);
+        } else
         GC_LAUNCH(MFSEL(gc_mf_vparse_kernel), perB * GC_XCDS, g.verifyT, st, src, (uint64_t)n, frameBlocks, nBlocks, perB, c->lazyDepth, (const uint32_t*)cnt,
                   (const GcMfEntry*)ent2, seqRaw, lit, meta, prof);
         for (int i = 10; i <= 12; i++) HIPCHK(c, hipEventRecord(ev[i], st));
@@ -537,17 +555,56 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
     c->priceParse = level >= 16 ? 1u : 0u;        // the reference's btopt / btultra strategies start at level 16 (clevels.h:44-47)
     gc_env_u32("GC_PRICE_PARSE", 0u, 1u, &c->priceParse);                                      // test hook
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
-    rc = launch_finder(c, src, n, frameBlocks, c->profOn ? c->prof : nullptr);
+    // The input can be taken in frame-aligned PARTS, the finder of part p + 1 (main stream) beside the entropy stage of part p (sequences on
+    // stream2, literals on stream3).  Measured on MI355X (run r3_g, 1 GB of text at level 3): 1 part 30.9 ms, 2 parts 32.2, 4 parts 32.0,
+    // 8 parts 35.2; 100 MB: 3.9 / 5.0 / 7.1 ms -- kernels that run beside each other take the CUs' LDS and wave slots from one another and
+    // every part pays its own launch tails.  One part it is; the hook keeps the path exercised.
+    const uint32_t nFrames = (nBlocks + frameBlocks - 1u) / frameBlocks;
+    uint32_t nParts = 1u;
+    gc_env_u32("GC_ZSTD_PARTS", 1u, GC_MAX_PARTS, &nParts);                                    // test hook
+    if (c->dbgPartFrames) nParts = nFrames / c->dbgPartFrames;
+    if (nParts > nFrames) nParts = nFrames;
+    if (nParts > GC_MAX_PARTS) nParts = GC_MAX_PARTS;
+    if (nParts < 1u) nParts = 1u;
+    c->mfTimed = false;
+    rc = ensure_finder_workspace(c, n, frameBlocks);
     if (rc != GC_OK) return rc;
-    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
-    // K2 (literals) and K3 (sequences) are independent consumers of K1: run them on two streams
-    HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev[1], 0));
-    HIPCHK(c, hipEventRecord(c->ev[3], c->stream2));
-    GC_LAUNCH(gc_zstd_seq_kernel, nBlocks, GC_SEQ_T, c->stream2, (const GcSeqRaw*)c->seqRaw, (const GcBlockMeta*)c->meta, c->seqPacked,
-              c->seqOff, c->codes, c->stOut, c->seqSec, c->info, (uint64_t)n, frameBlocks, c->profOn ? c->prof + GC_LZ_PHASES : nullptr);
+    const uint32_t framesPerPart = (nFrames + nParts - 1u) / nParts;
+    uint32_t usedParts = 0;
+    for (uint32_t p = 0; p < nParts; p++) {
+        const uint32_t blk0 = p * framesPerPart * frameBlocks;
+        if (blk0 >= nBlocks) break;
+        const size_t off = (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
+        const size_t len = (size_t)framesPerPart * frameBlocks * GC_ZSTD_BLOCK_MAX < n - off ? (size_t)framesPerPart * frameBlocks * GC_ZSTD_BLOCK_MAX : n - off;
+        const uint32_t pBlocks = gc_num_blocks(len);
+        rc = launch_finder_part(c, c->stream, p, src + off, len, frameBlocks, blk0, c->profOn ? c->prof : nullptr);
+        if (rc != GC_OK) return rc;
+        HIPCHK(c, hipEventRecord(c->evPart[p][0], c->stream));                                 // finder of this part done
+        if (p + 1u == nParts || blk0 + pBlocks >= nBlocks) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+        // K2 (literals) and K3 (sequences) are independent consumers of the finder: two more streams
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evPart[p][0], 0));
+        HIPCHK(c, hipStreamWaitEvent(c->stream3, c->evPart[p][0], 0));
+        if (p == 0u) HIPCHK(c, hipEventRecord(c->ev[3], c->stream2));
+        {   // K3: codes -> tables -> state chains -> pack (gc_zstd_seq.hip)
+            unsigned long long* sprof = c->profOn ? c->prof + GC_LZ_PHASES : nullptr;
+            uint8_t* codes = c->codes + (size_t)blk0 * 3u * GC_MAX_SEQ_PER_BLOCK;
+            uint64_t* packed = c->seqPacked + (size_t)blk0 * GC_MAX_SEQ_PER_BLOCK;
+            uint16_t* st = c->stOut + (size_t)blk0 * 3u * GC_SEQ_ST_STRIDE;
+            GC_LAUNCH(gc_zstd_seq_codes_kernel, pBlocks, GC_SEQ_T, c->stream2, (const GcSeqRaw*)(c->seqRaw + (size_t)blk0 * GC_MAX_SEQ_PER_BLOCK), (const GcBlockMeta*)(c->meta + blk0),
+                      packed, c->seqOff + (size_t)blk0 * GC_MAX_SEQ_PER_BLOCK, codes, c->seqHist + blk0, c->seqSec + (size_t)blk0 * GC_SEQSEC_STRIDE, c->info + blk0, frameBlocks, sprof);
+            GC_LAUNCH(gc_zstd_seq_tables_kernel, pBlocks * 3u, 64, c->stream2, (const GcSeqHist*)(c->seqHist + blk0), (const GcSectionInfo*)(c->info + blk0), c->seqTabs + (size_t)blk0 * 3u, sprof);
+            GC_LAUNCH(gc_zstd_seq_chain_kernel, pBlocks * 3u, 64, c->stream2, (const uint8_t*)codes, (const GcSectionInfo*)(c->info + blk0), c->seqTabs + (size_t)blk0 * 3u, st, sprof);
+            GC_LAUNCH(gc_zstd_seq_pack_kernel, pBlocks, GC_SEQ_T, c->stream2, (const uint64_t*)packed, (const uint8_t*)codes, (const uint16_t*)st, (const GcSeqTabG*)(c->seqTabs + (size_t)blk0 * 3u),
+                      c->seqSec + (size_t)blk0 * GC_SEQSEC_STRIDE, c->info + blk0, (uint64_t)len, sprof);
+        }
+        GC_LAUNCH(gc_zstd_huf_kernel, pBlocks, 256, c->stream3, (const uint8_t*)(c->lit + (size_t)blk0 * GC_ZSTD_BLOCK_MAX), (const GcBlockMeta*)(c->meta + blk0),
+                  c->litSec + (size_t)blk0 * GC_LITSEC_STRIDE, c->info + blk0);
+        usedParts = p + 1u;
+    }
+    c->mfTimed = frameBlocks > 1u; c->mfParts = usedParts; c->mfPriced = c->mfTimed && c->priceParse != 0u;
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream2));
-    GC_LAUNCH(gc_zstd_huf_kernel, nBlocks, 256, c->stream, (const uint8_t*)c->lit, (const GcBlockMeta*)c->meta, c->litSec, c->info);
-    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream3));
+    HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev[2], 0));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev[4], 0));
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     GC_LAUNCH(gc_zstd_plan_kernel, 1, 1024, c->stream, (const GcSectionInfo*)c->info, nBlocks, (uint64_t)n, (uint64_t)dstCap, frameBlocks, c->plan, c->result, c->optSeekTable);

@@ -47,8 +47,22 @@ struct GcSectionInfo {
 // worst-case frame: 4 magic + 1 FHD + 4 FCS + 3 block header + payload
 #define GC_FRAME_OVERHEAD 12u
 
-#define GC_SEQ_T      512u  // K3: threads per block
+#define GC_SEQ_T      256u  // K3a / K3d: threads per block
 #define GC_LZ_PHASES  7   // K1 phase profile slots: probe, insert, verify, double, chain, walk, emit
 #define GC_SEQ_PHASES 9   // K3 phase profile slots: merge, codes, tables, chains, pack + chain sub-phases: stage, warm-up, walk, copy-out
+
+// K3 between its kernels (gc_zstd_seq.hip)
+#define GC_SEQ_CHAIN_TILE 4096u                                   // sequences per state-chain tile (64 lanes x 64)
+#define GC_SEQ_ST_STRIDE  (((GC_MAX_SEQ_PER_BLOCK + GC_SEQ_CHAIN_TILE - 1u) / GC_SEQ_CHAIN_TILE) * GC_SEQ_CHAIN_TILE)   // states of one table of one block
+struct GcSeqHist { uint32_t count[3][64]; };                      // K3a -> K3b: code histograms (LL, OF, ML)
+struct GcSeqSymG { int32_t deltaFindState; uint32_t deltaNbBits; };
+struct GcSeqTabG {                                                // K3b -> K3c, K3d: one FSE table of one block
+    uint16_t state[512];
+    GcSeqSymG tt[64];
+    int16_t  norm[64];
+    uint8_t  desc[96];                                            // table description bytes for the section header
+    uint32_t descSize, mode, tableLog, maxSym, tabMaxSym, finalState;
+    uint32_t pad[2];
+};
 
 static inline uint32_t gc_num_blocks(uint64_t n) { return (uint32_t)((n + GC_ZSTD_BLOCK_MAX - 1) / GC_ZSTD_BLOCK_MAX); }

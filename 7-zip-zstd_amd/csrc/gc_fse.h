@@ -7,9 +7,10 @@
 // Free choice (any distribution summing to 2^tableLog is decodable; reference heuristic = FSE_normalizeCount,
 // fse_compress.c:465): fse_normalize below is a plain largest-remainder scaling.
 #pragma once
+#include "gc_common.h"
 #include "gc_device.h"
 
-struct GcFseSym { int32_t deltaFindState; uint32_t deltaNbBits; };
+typedef GcSeqSymG GcFseSym;       // { int32_t deltaFindState; uint32_t deltaNbBits; } -- also the element type of the tables that travel between K3's kernels
 
 // log2(x) in 1/256 bit units (piecewise linear; only used to compare table costs)
 __device__ __forceinline__ uint32_t gc_log2_q8(uint32_t x)

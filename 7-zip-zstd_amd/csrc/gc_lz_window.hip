@@ -475,6 +475,7 @@ MFK(gc_mf_link_kernel)(const uint32_t* __restrict__ offs, const GcMfEntry* __res
 #ifndef MFV_B
 #define MFV_B 4u                      // listed positions per thread and round
 #endif
+#define MFV_NONE 0xFFFFFFFFu             // sRec: no record written yet (a record's length byte never exceeds GC_MATCH_CAP)
 #define MFV_PAD_AFTER (GC_MATCH_CAP + 32u)                        // staged bytes behind the tile: own side of every compare
 #define MFV_STAGE_WORDS ((MF_STAGE_PAD + GC_MF_TILE + MFV_PAD_AFTER) / 4u)
 
@@ -509,7 +510,7 @@ __device__ __forceinline__ uint32_t mfv_len13(const LzW16& me, const LzW16& cw, 
 
 // The verification of ONE tile: fills sRec[0 .. T.len) (LDS) and ends with a workgroup barrier.  Shared by the stand-alone verify
 // kernels (records -> HBM) and the fused verify + parse kernel (records never leave the CU).  Called by all MFV_T threads.
-template <int MODE>
+template <int MODE, bool TILE_LIMIT = false>
 __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks,
                     const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, const uint32_t* recIn,
                     uint32_t* sW, uint32_t* sRec, uint8_t* sExt, uint32_t* sStart, uint32_t* sLocal, uint32_t* sWaveTot,
@@ -535,6 +536,10 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
         const GcU4* R4 = (const GcU4*)(recIn + T.tileStart);
         GcU4* S4 = (GcU4*)sRec;
         for (uint32_t i = t; i < (T.len + 3u) / 4u; i += MFV_T) S4[i] = R4[i];
+    } else if (!HALF) {                                           // "no record yet": what the listed positions leave behind is exactly the unlisted ones
+        GcU4 none; none.x = none.y = none.z = none.w = MFV_NONE;
+        GcU4* S4 = (GcU4*)sRec;
+        for (uint32_t i = t; i < GC_MF_TILE / 4u; i += MFV_T) S4[i] = none;
     }
     __syncthreads();
     if (t < GC_MF_PARTS) {
@@ -544,8 +549,8 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
         if (t == GC_MF_PARTS - 1u) sLocal[GC_MF_PARTS] = before + incl;
     }
     __syncthreads();
-    VP_PHASE(prof, *tprev, 0);                                     // stage + run offsets
     const uint32_t nEnt = sLocal[GC_MF_PARTS];
+    VP_PHASE(prof, *tprev, 0);                                     // stage + run offsets
     const uint8_t* wsrc = src + T.frameStart;
     const GcMfEntry* E = ent + (uint64_t)T.frame * ((uint64_t)frameBlocks * GC_ZSTD_BLOCK_MAX);
     const uint64_t blockBase = T.tileStart & ~(uint64_t)(GC_ZSTD_BLOCK_MAX - 1u);     // a tile never straddles blocks
@@ -556,6 +561,7 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
     // backward extension below finds every record that is not its own in place; odd positions without a run start out empty.)
     auto unlisted = [&]() {
         for (uint32_t q = t; q < T.len; q += MFV_T) {
+            if (!FAR && !HALF && sRec[q] != MFV_NONE) continue;     // a listed position: its record is in place (nineteen in twenty on text)
             const uint64_t x = mf_lds_ld64(sW, q + MF_STAGE_PAD);
             const bool run = T.tileStart + q > T.frameStart && ((x << 8) | (uint64_t)mf_lds_byte(sW, q + MF_STAGE_PAD - 1u)) == x;
             const bool windowed = T.tileStart + q + GC_MATCH_CAP + 16u <= T.frameEnd;
@@ -564,7 +570,8 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
             const uint32_t p = pTile + q;
             uint32_t len = 0;
             if (run && windowed && p + 8u <= nBlk) {              // both sides of the compare lie in the staged tile
-                const uint32_t maxLen = (nBlk - p) < GC_MATCH_CAP ? (nBlk - p) : GC_MATCH_CAP;
+                uint32_t maxLen = (nBlk - p) < GC_MATCH_CAP ? (nBlk - p) : GC_MATCH_CAP;
+                if (TILE_LIMIT && maxLen > T.len - q) maxLen = T.len - q;
                 while (len < maxLen) {
                     const uint32_t more = lz_cmp16(mf_lds_ld16(sW, q + MF_STAGE_PAD + len), mf_lds_ld16(sW, q + MF_STAGE_PAD - 1u + len));
                     len += more;
@@ -579,16 +586,29 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
     if (HALF) { unlisted(); __syncthreads(); }
     // listed positions, MFV_B per thread and round, stage by stage over small arrays so that the entry loads, then the long
     // candidates, then the short candidates that are still needed are in flight together
-    for (uint32_t j0 = t; j0 < nEnt; j0 += MFV_T * MFV_B) {
+    // Every wave takes a contiguous share of the tile's flat list of entries, 64 * MFV_B of them per round.  The run (= partition) of an index
+    // is found by walking the run starts from the run of the round's first index (a wave-uniform cursor that only moves forward: a run holds
+    // 32 entries on average, so a lane looks at two or three starts) -- not by a bisection per entry, which cost eight dependent LDS reads and
+    // two dozen vector instructions of a kernel that is bound by vector issue.
+    const uint32_t perWave = ((nEnt + MFV_T - 1u) / MFV_T) * 64u;
+    const uint32_t jBeg = wave * perWave, jEnd = jBeg + perWave < nEnt ? jBeg + perWave : nEnt;
+    uint32_t g0 = 0;                                              // run of index jBeg (largest g with sLocal[g] <= jBeg)
+    if (jBeg < jEnd) {
+#pragma unroll
+        for (uint32_t step = GC_MF_PARTS / 2u; step != 0u; step >>= 1) if (sLocal[g0 + step] <= jBeg) g0 += step;
+    }
+    for (uint32_t j0 = jBeg; j0 < jEnd; j0 += 64u * MFV_B) {
         uint64_t e[MFV_B];
+        bool live[MFV_B];
 #pragma unroll
         for (uint32_t k = 0; k < MFV_B; k++) {
-            const uint32_t j = j0 + k * MFV_T;
-            const uint32_t jj = j < nEnt ? j : nEnt - 1u;
-            uint32_t lo = 0;                                      // largest g with sLocal[g] <= jj (branch-free bisection)
-#pragma unroll
-            for (uint32_t step = GC_MF_PARTS / 2u; step != 0u; step >>= 1) if (sLocal[lo + step] <= jj) lo += step;
+            const uint32_t j = j0 + k * 64u + lane;
+            live[k] = j < jEnd;
+            const uint32_t jj = live[k] ? j : jEnd - 1u;
+            uint32_t lo = g0;
+            while (sLocal[lo + 1u] <= jj) lo++;                   // (jj < nEnt = sLocal[GC_MF_PARTS]: ends at a run that exists)
             e[k] = E[sStart[lo] + (jj - sLocal[lo])];
+            g0 = gc_readlane(lo, 63u);
         }
         uint32_t q[MFV_B], cS[MFV_B], maxLen[MFV_B], bestLen[MFV_B], bestC[MFV_B];
         uint32_t bestExt[MFV_B];
@@ -599,8 +619,9 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
             const uint32_t cL = (uint32_t)(e[k] >> GC_MF_TILE_LOG) & 0xFFFFFFu;
             cS[k] = (uint32_t)(e[k] >> (GC_MF_TILE_LOG + 24u)) & 0xFFFFFFu;
             const uint32_t p = pTile + q[k];                      // block-relative
-            const bool can = j0 + k * MFV_T < nEnt && p + 8u <= nBlk;
+            const bool can = live[k] && p + 8u <= nBlk;
             maxLen[k] = can ? ((nBlk - p) < GC_MATCH_CAP ? (nBlk - p) : GC_MATCH_CAP) : 0u;
+            if (TILE_LIMIT && maxLen[k] > T.len - q[k]) maxLen[k] = T.len - q[k];      // matches end with their tile (the parse of a tile starts at its first byte)
             if (cS[k] == cL) cS[k] = 0;
             bestC[k] = (can && cL) ? cL : 0u;
             bestExt[k] = 0;
@@ -629,7 +650,7 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
                 if (len > maxLen[k]) len = maxLen[k];
                 if (more < 16u) break;
             }
-            if (j0 + k * MFV_T < nEnt) {
+            if (live[k]) {
                 const uint32_t nr = len ? (((pw - (bestC[k] - 1u)) << 8) | len) : 0u;
                 if (HALF && nr != 0u) sExt[q[k]] = (uint8_t)bestExt[k];
                 if (!FAR) sRec[q[k]] = nr;
@@ -638,7 +659,7 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
         }
     }
     VP_PHASE(prof, *tprev, 1);                                     // listed positions
-    if (!FAR && !HALF) unlisted();
+    if (!FAR && !HALF) { __syncthreads(); unlisted(); }            // (the pass reads which records are in place)
     if (HALF) {
         // positions without a record of their own take the match of the nearest listed position behind them that reaches back to them
         // (only records of listed positions carry sExt > 0, and those are not written here: the result does not depend on thread order)
@@ -825,10 +846,14 @@ MFK(gc_mf_vparse_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint
                     unsigned long long* __restrict__ prof /* optional phase profile: slots 0 stage, 1 listed, 2 unlisted, 3 exit maps, 4 entry chain, 5 walk, 6 emit */)
 {
     __shared__ uint32_t sW[MFV_STAGE_WORDS];
-    __shared__ uint32_t sRec[GC_MF_TILE + 4u];                    // (+ zeros behind the tile: the look-ahead of its last positions)
+    __shared__ uint32_t sRec[GC_MF_TILE];
     __shared__ uint8_t sExt[4u];
-    __shared__ uint32_t sStart[GC_MF_PARTS], sLocal[GC_MF_PARTS + 1u];
-    __shared__ uint32_t sWaveTot[GC_MF_PARTS / 64u];
+    // verify: the tile's run table; parse: one byte per position, take << 7 | next position (segment-relative, <= 127).  (LDS is handed out in
+    // granules of 1280 bytes: three workgroups per CU need <= 53 760 bytes each, hence the shared space.)
+    __shared__ uint32_t sAux[GC_MF_TILE / 4u];
+    uint32_t* sStart = sAux; uint32_t* sLocal = sAux + GC_MF_PARTS; uint32_t* sWaveTot = sAux + 2u * GC_MF_PARTS + 1u;
+    uint8_t* sNxt = (uint8_t*)sAux;
+    static_assert((2u * GC_MF_PARTS + 1u + GC_MF_PARTS / 64u) * 4u <= GC_MF_TILE, "the run table fits the parse's byte array");
     __shared__ uint8_t  sExitW[VP_WAVES][64];                     // exit lane of a wave's 16 segments for every entry lane
     __shared__ uint64_t sMaskSeq[VP_SEGS], sMaskLit[VP_SEGS];
     __shared__ uint32_t sCntSeq[VP_WAVES], sCntLit[VP_WAVES];
@@ -857,6 +882,7 @@ MFK(gc_mf_vparse_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint
                 const uint32_t seg = seg0 + k;
                 if (seg * 64u >= n) break;                        // (uniform) past the end: the identity
                 const PzSeg s = pz_seg(sRec, seg * 64u + lane, n, lane, lazy);
+                sNxt[seg * 64u + lane] = (uint8_t)(s.nxt | (s.take ? 0x80u : 0u));      // (the walk below reads this instead of deciding again)
                 const uint32_t ex = pz_exit(s.nxt) - 64u;
                 comp = __shfl(ex, (int)comp);
             }
@@ -878,12 +904,12 @@ MFK(gc_mf_vparse_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint
             const uint32_t seg = seg0 + k;
             if (seg * 64u >= n) break;
             const uint32_t p = seg * 64u + lane;
-            const PzSeg s = pz_seg(sRec, p, n, lane, lazy);
+            const uint32_t nb = sNxt[p], nxt = nb & 0x7Fu;
             uint64_t path = 0;
             uint32_t c = e;
-            while (c < 64u) { path |= 1ull << c; c = gc_readlane(s.nxt, c); }
+            while (c < 64u) { path |= 1ull << c; c = gc_readlane(nxt, c); }
             e = c - 64u;
-            const uint64_t takeMask = __ballot(s.take), inMask = __ballot(p < n);
+            const uint64_t takeMask = __ballot((nb & 0x80u) != 0u), inMask = __ballot(p < n);
             const uint64_t mS = path & takeMask, mL = path & ~takeMask & inMask;
             if (lane == 0) { sMaskSeq[seg] = mS; sMaskLit[seg] = mL; }
             nS += (uint32_t)__popcll(mS); nL += (uint32_t)__popcll(mL);
@@ -916,6 +942,133 @@ MFK(gc_mf_vparse_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint
     }
     if (t == 0) { GcBlockMeta m; m.nSeqRaw = seqRun; m.nLit = litRun; meta[b] = m; }
     (void)base;
+}
+
+// ------------------------------------------------------------------------------------------------ W5 + W6 fused, one workgroup per TILE
+// The same two stages with the tiles of a block taken by different workgroups AT THE SAME TIME, as W5 takes them: neighbouring tiles run
+// on the same XCD at the same moment, so the candidate windows of one are the input the others have just staged (an L2 hit), where the
+// block-serial kernel above has every workgroup of an XCD in a block of its own (96 blocks = 12 MiB under a 4 MiB L2: its candidate reads
+// all go to HBM, 56 GB per GB of input by the counters).  What made the tiles of a block depend on each other is cut:
+//   - a match ends with its tile (TILE_LIMIT): every tile's path starts at its first byte.  The rest of a match that was cut is found
+//     again at the next tile's first position; if it comes back with the same offset the sequences kernel merges the two records
+//     (chains of records with equal offset and no literals between them are one sequence), so most cuts cost nothing;
+//   - where a tile's sequences and literals go in the block's arrays depends on the counts of the tiles in front: every tile publishes
+//     its counts in one word (ready << 31 | sequences << 14 | literals) as soon as its path is known, and reads the words of the (at most
+//     15) tiles in front of it.  No chain: each word is its tile's own count.  A workgroup draws its tile from a ticket counter of its XCD
+//     class (workgroup index mod 8), so the tiles it waits for have been drawn before it and are running or done whatever the dispatch order.
+extern "C" __global__ void __launch_bounds__(MFV_T, VP_MIN_WAVES)
+MFK(gc_mf_vparse_tile_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per /* a multiple of the tiles of a block */,
+                    uint32_t lazy, const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent,
+                    GcSeqRaw* __restrict__ seqRaw, uint8_t* __restrict__ lit, GcBlockMeta* __restrict__ meta,
+                    uint32_t* __restrict__ tickets /* 8, zeroed */, uint32_t* __restrict__ tileWord /* per tile, zeroed */,
+                    unsigned long long* __restrict__ prof)
+{
+    __shared__ uint32_t sW[MFV_STAGE_WORDS];
+    __shared__ uint32_t sRec[GC_MF_TILE];
+    __shared__ uint8_t sExt[4u];
+    __shared__ uint32_t sAux[GC_MF_TILE / 4u];                    // verify: the tile's run table; parse: take << 7 | next position, one byte per position
+    uint32_t* sStart = sAux; uint32_t* sLocal = sAux + GC_MF_PARTS; uint32_t* sWaveTot = sAux + 2u * GC_MF_PARTS + 1u;
+    uint8_t* sNxt = (uint8_t*)sAux;
+    __shared__ uint8_t  sExitW[VP_WAVES][64];
+    __shared__ uint64_t sMaskSeq[VP_SEGS], sMaskLit[VP_SEGS];
+    __shared__ uint32_t sCntSeq[VP_WAVES], sCntLit[VP_WAVES];
+    __shared__ uint32_t sTicket, sBase[2];
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    if (t == 0) sTicket = atomicAdd(&tickets[blockIdx.x & (GC_XCDS - 1u)], 1u);
+    __syncthreads();
+    const uint32_t tile = (blockIdx.x & (GC_XCDS - 1u)) * per + sTicket;
+    if (tile >= nTiles) return;
+    const MfTile T = mf_tile(tile, frameBlocks, srcSize);
+    if (T.len == 0u) return;                                      // (past the end of the input: nobody waits for such a tile)
+    unsigned long long tprev = prof ? gc_clock() : 0ull;
+    const uint32_t b = tile / GC_MF_TILES_PER_BLOCK, ti = tile % GC_MF_TILES_PER_BLOCK;
+    GcSeqRaw* mySeq = seqRaw + (uint64_t)b * GC_MAX_SEQ_PER_BLOCK;
+    uint8_t* myLit = lit + (uint64_t)b * GC_ZSTD_BLOCK_MAX;
+    const uint64_t lt = gc_lanemask_lt();
+    mf_verify_tile<MF_BASE, true>(T, src, srcSize, frameBlocks, offs, ent, nullptr, sW, sRec, sExt, sStart, sLocal, sWaveTot, prof, &tprev);
+    const uint32_t n = T.len;
+    VP_PHASE(prof, tprev, 2);
+    // ---- exit map of this wave's segments
+    const uint32_t seg0 = wave * VP_SPW;
+    {
+        uint32_t comp = lane;
+#pragma unroll 1
+        for (uint32_t k = 0; k < VP_SPW; k++) {
+            const uint32_t seg = seg0 + k;
+            if (seg * 64u >= n) break;                            // (uniform) past the end: the identity
+            const PzSeg s = pz_seg(sRec, seg * 64u + lane, n, lane, lazy);
+            sNxt[seg * 64u + lane] = (uint8_t)(s.nxt | (s.take ? 0x80u : 0u));
+            const uint32_t ex = pz_exit(s.nxt) - 64u;
+            comp = __shfl(ex, (int)comp);
+        }
+        sExitW[wave][lane] = (uint8_t)comp;
+    }
+    __syncthreads();
+    VP_PHASE(prof, tprev, 3);
+    // ---- real entry lane of this wave: lane 0 of the tile chained through the waves in front
+    uint32_t e = 0;
+    for (uint32_t w = 0; w < wave; w++) e = sExitW[w][e];
+    e = gc_uniform(e);
+    VP_PHASE(prof, tprev, 4);
+    // ---- walk the segments from the real entry: path masks + counts
+    uint32_t nS = 0, nL = 0;
+#pragma unroll 1
+    for (uint32_t k = 0; k < VP_SPW; k++) {
+        const uint32_t seg = seg0 + k;
+        if (seg * 64u >= n) break;
+        const uint32_t p = seg * 64u + lane;
+        const uint32_t nb = sNxt[p], nxt = nb & 0x7Fu;
+        uint64_t path = 0;
+        uint32_t c = e;
+        while (c < 64u) { path |= 1ull << c; c = gc_readlane(nxt, c); }
+        e = c - 64u;
+        const uint64_t takeMask = __ballot((nb & 0x80u) != 0u), inMask = __ballot(p < n);
+        const uint64_t mS = path & takeMask, mL = path & ~takeMask & inMask;
+        if (lane == 0) { sMaskSeq[seg] = mS; sMaskLit[seg] = mL; }
+        nS += (uint32_t)__popcll(mS); nL += (uint32_t)__popcll(mL);
+    }
+    if (lane == 0) { sCntSeq[wave] = nS; sCntLit[wave] = nL; }
+    __syncthreads();
+    uint32_t sBefore = 0, lBefore = 0, sAll = 0, lAll = 0;
+    for (uint32_t w = 0; w < VP_WAVES; w++) {
+        const uint32_t cs = sCntSeq[w], cl = sCntLit[w];
+        if (w < wave) { sBefore += cs; lBefore += cl; }
+        sAll += cs; lAll += cl;
+    }
+    // ---- this tile's counts out, the counts of the tiles in front of it in
+    if (wave == 0) {
+        if (lane == 0) {
+#ifdef HIPEMU
+            __atomic_store_n(&tileWord[tile], 0x80000000u | (sAll << 14) | lAll, __ATOMIC_RELEASE);
+#else
+            __hip_atomic_store(&tileWord[tile], 0x80000000u | (sAll << 14) | lAll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+        }
+        uint32_t w = 0x80000000u;
+        if (lane < ti) { do { w = gc_poll_device(&tileWord[tile - ti + lane]); if (!(w >> 31)) gc_nap(); } while (!(w >> 31)); }
+        const uint32_t sb = gc_wave_sum(lane < ti ? (w >> 14) & 0x1FFFFu : 0u), lb = gc_wave_sum(lane < ti ? w & 0x3FFFu : 0u);
+        if (lane == 0) { sBase[0] = sb; sBase[1] = lb; }
+    }
+    __syncthreads();
+    VP_PHASE(prof, tprev, 5);
+    const uint32_t seqBase = sBase[0], litBase = sBase[1];
+    // ---- emit
+    uint32_t sr = seqBase + sBefore, lr = litBase + lBefore;
+#pragma unroll 1
+    for (uint32_t k = 0; k < VP_SPW; k++) {
+        const uint32_t seg = seg0 + k;
+        if (seg * 64u >= n) break;
+        const uint64_t mS = sMaskSeq[seg], mL = sMaskLit[seg];
+        const uint32_t q = seg * 64u + lane;
+        const uint32_t myLitRank = lr + (uint32_t)__popcll(mL & lt);
+        if ((mS >> lane) & 1ull) { GcSeqRaw r; r.litRank = myLitRank; r.offml = sRec[q]; mySeq[sr + (uint32_t)__popcll(mS & lt)] = r; }
+        if ((mL >> lane) & 1ull) myLit[myLitRank] = (uint8_t)mf_lds_byte(sW, q + MF_STAGE_PAD);
+        sr += (uint32_t)__popcll(mS); lr += (uint32_t)__popcll(mL);
+    }
+    // the block's totals: the last tile of the block that exists
+    const bool lastOfBlock = ti + 1u == GC_MF_TILES_PER_BLOCK || T.tileStart + n >= T.frameEnd;
+    if (t == 0 && lastOfBlock) { GcBlockMeta m; m.nSeqRaw = seqBase + sAll; m.nLit = litBase + lAll; meta[b] = m; }
+    VP_PHASE(prof, tprev, 6);
 }
 
 #ifndef GC_MF_FAST       // (W6 works on blocks, not tiles: one copy)

@@ -1,21 +1,25 @@
-// gc_zstd_seq.hip -- K3: sequences section of one zstd block per workgroup (256 threads).
+// gc_zstd_seq.hip -- K3: the sequences section of every zstd block, as FOUR kernels of different shape.
 //
 // Replaces ZSTD_seqToCodes (C/zstd/zstd_compress.c:2693), ZSTD_updateRep (zstd_compress_internal.h:818),
 // ZSTD_buildSequencesStatistics (zstd_compress.c:2763: histograms, ZSTD_selectEncodingType, ZSTD_buildCTable ->
 // FSE_normalizeCount / FSE_writeNCount / FSE_buildCTable_wksp) and ZSTD_encodeSequences_body
 // (zstd_compress_sequences.c:291-383).
 //
-// Stages (S = serial per lane, P = parallel over sequences):
-//   P  merge   chains of capped matches (same offset, litLength 0) collapse into one sequence
-//   P  repcode repeat-offset history as a scan: rep1 = previous offset, rep2 = the offset before the current run
-//              of equal offsets.  Only codes whose meaning depends on (rep1, rep2) are emitted, so the decoder's
-//              third history slot never matters and the whole assignment is order-independent
-//   P  codes   LL/ML/OF code + extra bits, three LDS histograms
-//   S  tables  one wave per table: mode (predefined / RLE / FSE), normalisation, NCount header, CTable
-//   S  chains  one wave per table walks its FSE state backwards over all sequences: 64 segments at once, each lane finding
-//              its start state by running a few symbols ahead of its segment (FSE states forget their origin), checked and
-//              repaired against the predecessor's final state, so the result is exactly the serial walk
-//   P  pack    per-sequence bit counts -> block prefix sums -> fields OR-ed into an LDS tile -> bytes stream out
+//   K3a codes   workgroup of 256 per block, parallel over sequences:
+//                 merge    chains of capped matches (same offset, litLength 0) collapse into one sequence
+//                 repcode  repeat-offset history as a scan: rep1 = previous offset, rep2 = the offset before the current run
+//                          of equal offsets.  Only codes whose meaning depends on (rep1, rep2) are emitted, so the decoder's
+//                          third history slot never matters and the whole assignment is order-independent
+//                 codes    LL/ML/OF code + extra bits, three histograms
+//   K3b tables  ONE WAVE per (block, table): mode (predefined / RLE / FSE), normalisation, NCount header, CTable -- serial work of one lane
+//   K3c chains  ONE WAVE per (block, table) walks the table's FSE state backwards over all sequences: 64 segments at once, each lane
+//               finding its start state by running a few symbols ahead of its segment (FSE states forget their origin), checked and
+//               repaired against the predecessor's final state, so the result is exactly the serial walk
+//   K3d pack    workgroup of 256 per block: per-sequence bit counts -> prefix sums -> fields OR-ed into an LDS tile -> bytes stream out
+//
+// Why four: as one kernel (rounds 1-2) a block held 8 waves and 53 KB of LDS for the whole time while its serial middle (tables: three
+// lanes, chains: three waves; 70 % of the block's time) ran -- three blocks per CU, a machine mostly waiting.  Apart, the serial stages are
+// one-wave workgroups with 3-7 KB of LDS, a few thousand of them in flight, and the parallel stages are small workgroups that come and go.
 //
 // Bit order is normative (zstd_compress_sequences.c:311-376): last sequence first; per sequence OF-state,
 // ML-state, LL-state, LL extra, ML extra, OF extra; then final states ML, OF, LL and a closing 1 bit.
@@ -29,13 +33,14 @@
 
 #define SEQ_T GC_SEQ_T
 #define SEQ_TILE_WORDS ((SEQ_T * 80u) / 32u + 8u)
-#define SEQ_CHAIN_TILE 4096u   // sequences per state-chain tile
+#define SEQ_CHAIN_TILE GC_SEQ_CHAIN_TILE   // sequences per state-chain tile
 #define SEQ_CHAIN_SEG  64u     // sequences per lane and tile
-#define SEQ_TC(u) ((u) + ((u) >> 6))                     // index of tile element u in tCode (row stride 65 bytes)
-#define SEQ_TO(u) ((u) + 2u * ((u) >> 6))                // ... in tOut (row stride 66 half-words = 33 banks)
+#define SEQ_TC(u) ((u) + ((u) >> 6))                     // index of tile element u in tCode: row stride 65 bytes (a lane walks ITS segment, i.e.
+                                                         // the lanes of a wave touch elements 64 apart: unpadded they would share two LDS banks)
 #ifndef SEQ_WARM_SEGS
 #define SEQ_WARM_SEGS  4u      // a lane looks this many segments back for a point where all state walks meet
 #endif
+#define SEQ_CHK        8u      // the walk keeps its state at every 8th symbol of a segment: where a repair walk can tell that it has rejoined
 
 __constant__ uint8_t kLLCode[64] = { 0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,16,17,17,18,18,19,19,20,20,20,20,21,21,21,21,
                                      22,22,22,22,22,22,22,22,23,23,23,23,23,23,23,23,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24 };
@@ -52,7 +57,7 @@ __constant__ int16_t kOFDefNorm[29] = { 1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,
 __device__ __forceinline__ uint32_t seq_ll_code(uint32_t ll) { return ll > 63u ? gc_hibit32(ll) + 19u : kLLCode[ll]; }
 __device__ __forceinline__ uint32_t seq_ml_code(uint32_t mlBase) { return mlBase > 127u ? gc_hibit32(mlBase) + 36u : kMLCode[mlBase]; }
 
-struct SeqTab {              // one FSE table in LDS
+struct SeqTab {              // one FSE table in LDS (K3b builds it)
     uint16_t state[512];
     GcFseSym tt[64];
     int16_t  norm[64];
@@ -62,12 +67,6 @@ struct SeqTab {              // one FSE table in LDS
     uint8_t  desc[96];       // table description bytes for the section header
     uint32_t descSize, mode, tableLog, maxSym, finalState;
     uint32_t tabMaxSym;      // last symbol described by norm[] (predefined: whole default table)
-    // state-chain tile scratch (see "chains" in the kernel)
-    // a lane walks ITS segment, i.e. the lanes of a wave touch elements SEQ_CHAIN_SEG apart: with a row length of exactly 64 all of them would
-    // fall into one or two LDS banks (a 32-way conflict per access); one element of padding per segment spreads them over all banks
-    uint8_t  tCode[SEQ_CHAIN_TILE + SEQ_CHAIN_TILE / SEQ_CHAIN_SEG + 3u];
-    uint16_t tOut[SEQ_CHAIN_TILE + 2u * (SEQ_CHAIN_TILE / SEQ_CHAIN_SEG)];
-    uint64_t meet[SEQ_CHAIN_TILE / 64u];
 };
 
 // block-wide exclusive sum scan (SEQ_T threads)
@@ -163,43 +162,32 @@ __device__ inline void seq_build_table(SeqTab& T, int which, uint32_t nbSeq)
     }
 }
 
+#define SEQ_PHASE(i) do { if (prof && t == 0) { unsigned long long now_ = gc_clock(); atomicAdd(&prof[i], now_ - tprev); tprev = now_; } } while (0)
+
+// ------------------------------------------------------------------------------------------------ K3a codes
 extern "C" __global__ void __launch_bounds__(SEQ_T)
-gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __restrict__ meta,
-                   uint64_t* __restrict__ seqPacked,      // scratch: GC_MAX_SEQ_PER_BLOCK per block
-                   uint32_t* __restrict__ seqOff,         // scratch: GC_MAX_SEQ_PER_BLOCK per block (real offsets)
-                   uint8_t* __restrict__ codes,           // scratch: 3 * GC_MAX_SEQ_PER_BLOCK per block (LL, OF, ML)
-                   uint16_t* __restrict__ stOut,          // scratch: 3 * GC_MAX_SEQ_PER_BLOCK per block
-                   uint8_t* __restrict__ seqSec, GcSectionInfo* __restrict__ info, uint64_t srcSize,
+gc_zstd_seq_codes_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __restrict__ meta,
+                   uint64_t* __restrict__ seqPacked,      // out: ll | mlBase << 17 | offBase << 35 per merged sequence
+                   uint32_t* __restrict__ seqOff,         // scratch: real offsets
+                   uint8_t* __restrict__ codes,           // out: 3 * GC_MAX_SEQ_PER_BLOCK per block (LL, OF, ML)
+                   GcSeqHist* __restrict__ hist, uint8_t* __restrict__ seqSec, GcSectionInfo* __restrict__ info,
                    uint32_t frameBlocks,                  // blocks per zstd frame: repeat offsets carry over inside a frame
                    unsigned long long* __restrict__ prof /* optional per-phase cycle sums */)
 {
-    __shared__ SeqTab sTab[3];
+    __shared__ uint32_t sCount[3][64];
     __shared__ uint32_t sWave[SEQ_T / 64u];
     __shared__ uint32_t sRun[SEQ_T];
-    __shared__ uint32_t sTile[SEQ_TILE_WORDS];
-
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6, b = blockIdx.x;
+    const uint32_t t = threadIdx.x, b = blockIdx.x;
     const uint32_t nRaw = meta[b].nSeqRaw;
-    const uint64_t blockBase = (uint64_t)b * GC_ZSTD_BLOCK_MAX;
-    const uint32_t blockLen = (uint32_t)((srcSize - blockBase) < GC_ZSTD_BLOCK_MAX ? (srcSize - blockBase) : GC_ZSTD_BLOCK_MAX);
     const GcSeqRaw* R = seqRaw + (uint64_t)b * GC_MAX_SEQ_PER_BLOCK;
     uint64_t* P = seqPacked + (uint64_t)b * GC_MAX_SEQ_PER_BLOCK;
     uint32_t* O = seqOff + (uint64_t)b * GC_MAX_SEQ_PER_BLOCK;
     uint8_t* cLL = codes + (uint64_t)b * 3u * GC_MAX_SEQ_PER_BLOCK;
     uint8_t* cOF = cLL + GC_MAX_SEQ_PER_BLOCK;
     uint8_t* cML = cOF + GC_MAX_SEQ_PER_BLOCK;
-    uint16_t* stLL = stOut + (uint64_t)b * 3u * GC_MAX_SEQ_PER_BLOCK;
-    uint16_t* stOF = stLL + GC_MAX_SEQ_PER_BLOCK;
-    uint16_t* stML = stOF + GC_MAX_SEQ_PER_BLOCK;
-    uint8_t* out = seqSec + (uint64_t)b * GC_SEQSEC_STRIDE;
-
-    if (nRaw == 0) { if (t == 0) { out[0] = 0; info[b].seqSecSize = 1; info[b].nSeq = 0; } return; }
-
-    for (uint32_t i = t; i < 3u * 64u; i += SEQ_T) sTab[i >> 6].count[i & 63u] = 0;
+    if (nRaw == 0) { if (t == 0) { seqSec[(uint64_t)b * GC_SEQSEC_STRIDE] = 0; info[b].seqSecSize = 1; info[b].nSeq = 0; } return; }
+    for (uint32_t i = t; i < 3u * 64u; i += SEQ_T) sCount[i >> 6][i & 63u] = 0;
     unsigned long long tprev = prof ? gc_clock() : 0ull;
-#define SEQ_PHASE(i) do { if (prof && t == 0) { unsigned long long now_ = gc_clock(); atomicAdd(&prof[i], now_ - tprev); tprev = now_; } } while (0)
-    unsigned long long tsub = 0;
-#define SEQ_SUB(i) do { if (prof && t == 0) { unsigned long long now_ = gc_clock(); if (tsub) atomicAdd(&prof[i], now_ - tsub); tsub = now_; } } while (0)
 
     // ---- S1: merge chains of capped matches.  Head = first record of a run with equal offset and litLength 0.
     //      P[j] = ll(17) | ml(18)<<17 for merged sequence j, O[j] = its offset
@@ -261,7 +249,7 @@ gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __res
             const uint32_t mlBase = ml - 3u;
             const uint32_t llc = seq_ll_code(ll), mlc = seq_ml_code(mlBase), ofc = gc_hibit32(offBase);
             cLL[j] = (uint8_t)llc; cOF[j] = (uint8_t)ofc; cML[j] = (uint8_t)mlc;
-            atomicAdd(&sTab[0].count[llc], 1u); atomicAdd(&sTab[1].count[ofc], 1u); atomicAdd(&sTab[2].count[mlc], 1u);
+            atomicAdd(&sCount[0][llc], 1u); atomicAdd(&sCount[1][ofc], 1u); atomicAdd(&sCount[2][mlc], 1u);
             P[j] = (uint64_t)ll | ((uint64_t)mlBase << 17) | ((uint64_t)offBase << 35);   // ll, mlBase, offBase
 #ifdef HIPEMU
             if (getenv("GC_TRACE")) fprintf(stderr, "E %u ofv=%u ml=%u ll=%u off=%u rep1=%u rep2=%u\n", j, offBase, ml, ll, off, rep1, rep2);
@@ -270,139 +258,218 @@ gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __res
         carryRun = max(carryRun, tot);
         __syncthreads();
     }
-
+    for (uint32_t i = t; i < 3u * 64u; i += SEQ_T) hist[b].count[i >> 6][i & 63u] = sCount[i >> 6][i & 63u];
+    if (t == 0) info[b].nSeq = nSeq;
     SEQ_PHASE(1);         // repcodes + codes + histograms
-    // ---- tables: one lane per table
-    if (wave < 3u && lane == 0u) seq_build_table(sTab[wave], (int)wave, nSeq);
-    __syncthreads();
-    SEQ_PHASE(2);         // tables
+}
 
-    // ---- chains: wave w walks table w's FSE state backwards (last sequence first = processing index v 0).
-    //      The walk is serial through the state, but walks that started from different states meet at the next symbol whose
-    //      normalised count is 1 (every state has the same successor there; the table builder above makes sure such symbols
-    //      exist).  So the 64 lanes of the wave walk 64 consecutive segments of 64 sequences at once: a lane first runs
-    //      ahead of its segment from the nearest such meeting point before it (no output), then its own segment.  Afterwards every
-    //      segment's start state is compared with its predecessor's final state; a segment that started wrong is walked again
-    //      from the right state, only until it rejoins the states already stored, and this repeats until nothing changes
-    //      (each round settles at least one more segment, so the result is exactly the serial walk).
-    if (wave < 3u) {
-        SeqTab& T = sTab[wave];
-        const uint8_t* C = wave == 0u ? cLL : (wave == 1u ? cOF : cML);
-        uint16_t* S = wave == 0u ? stLL : (wave == 1u ? stOF : stML);
-        if (T.mode == 1u) {                                   // RLE table: no state bits at all
-            for (uint32_t j = lane; j < nSeq; j += 64u) S[j] = 0;
-            if (lane == 0u) T.finalState = 0;
-        } else {
-            const uint32_t L = T.tableLog;
-            int nv = 0;
-            if (lane <= T.tabMaxSym) nv = T.norm[lane];
-            const uint64_t resetMask = __ballot(nv == 1 || nv == -1);    // symbols that send every state to the same successor
-            uint32_t carry = 0;                               // state after the last sequence of the previous tile
-            for (uint32_t tb = 0; tb < nSeq; tb += SEQ_CHAIN_TILE) {
-                const uint32_t tileLen = min(SEQ_CHAIN_TILE, nSeq - tb);
-                if (prof && t == 0) tsub = gc_clock();
-                // stage the codes (independent loads, eight in flight per lane), then per 64 sequences one mask of the positions
-                // that hold a count-1 symbol ("meeting points")
-#pragma unroll 8
-                for (uint32_t u = lane; u < tileLen; u += 64u) T.tCode[SEQ_TC(u)] = C[nSeq - 1u - (tb + u)];
-                gc_wave_sync();
-                SEQ_SUB(5);
-                for (uint32_t k = 0; k < tileLen; k += 64u) {
-                    const uint32_t u = k + lane;
-                    const bool isR = u < tileLen && ((resetMask >> T.tCode[SEQ_TC(u)]) & 1ull) != 0ull;
-                    const uint64_t bal = __ballot(isR);
-                    if (lane == 0u) T.meet[k >> 6] = bal;
-                }
-                gc_wave_sync();
-                const uint32_t nSegs = (tileLen + SEQ_CHAIN_SEG - 1u) / SEQ_CHAIN_SEG;      // <= 64: lane i walks segment i
-                const uint32_t u0 = lane * SEQ_CHAIN_SEG, u1 = min(u0 + SEQ_CHAIN_SEG, tileLen);
-                uint32_t first = u0;                          // first index of the segment that emits bits
-                uint32_t st0 = carry;
-                if (lane < nSegs) {
-                    if (tb + u0 == 0u) { st0 = gc_fse_init_state(T.state, T.tt[T.tCode[SEQ_TC(0)]]); T.tOut[SEQ_TO(0)] = 0; first = 1u; }   // FSE_initCState2: no bits
-                    else if (lane != 0u) {
-                        // run ahead from the nearest meeting point in the SEQ_WARM_SEGS segments before this one (from there the
-                        // state is exact whatever it was before); if there is none, from SEQ_WARM_SEGS segments back (a guess)
-                        uint32_t w = lane > SEQ_WARM_SEGS ? (lane - SEQ_WARM_SEGS) * SEQ_CHAIN_SEG : 0u;
-                        for (uint32_t c = lane; c-- > 0u && c + SEQ_WARM_SEGS >= lane; ) {
-                            const uint64_t m = T.meet[c];
-                            if (m) { w = c * 64u + 63u - (uint32_t)__clzll((long long)m); break; }
-                        }
-                        if (tb + w == 0u) { st0 = gc_fse_init_state(T.state, T.tt[T.tCode[SEQ_TC(0)]]); w = 1u; }                   // exact, not a guess
-                        else st0 = 1u << L;
-                        if (w < u0) {                              // the symbol's table entry does not depend on the state: fetched one
-                            GcFseSym sy = T.tt[T.tCode[SEQ_TC(w)]];          // step ahead, so a step costs one dependent LDS read, not three
-                            for (; w < u0; w++) {
-                                const GcFseSym nx = T.tt[T.tCode[SEQ_TC(w + 1u < u0 ? w + 1u : w)]];
-                                const uint32_t nb = (st0 + sy.deltaNbBits) >> 16;
-                                st0 = T.state[(st0 >> nb) + (uint32_t)sy.deltaFindState];
-                                sy = nx;
-                            }
-                        }
-                    }
-                }
-                SEQ_SUB(6);
-                // tOut[u] = nbBits << 10 | state BEFORE symbol u (10 bits): the bits to emit are its low nbBits, and a repair walk
-                // can tell when it has rejoined the trajectory already stored (same state at the same u: the rest is unchanged)
-                uint32_t fin = st0;
-                bool redo = lane < nSegs;
-                bool firstPass = true;
-#ifdef HIPEMU
-                uint32_t dbgRounds = 0, dbgRedo = 0;
-#endif
-                for (;;) {
-                    if (redo) {
-                        uint32_t state = st0, u = first;
-                        GcFseSym sy = T.tt[T.tCode[SEQ_TC(u < u1 ? u : u1 - 1u)]];
-                        for (; u < u1; u++) {
-                            if (!firstPass && (T.tOut[SEQ_TO(u)] & 0x3FFu) == (state & 0x3FFu)) break;
-                            const GcFseSym nx = T.tt[T.tCode[SEQ_TC(u + 1u < u1 ? u + 1u : u)]];
-                            const uint32_t nb = (state + sy.deltaNbBits) >> 16;
-                            T.tOut[SEQ_TO(u)] = (uint16_t)((nb << 10) | (state & 0x3FFu));
-                            state = T.state[(state >> nb) + (uint32_t)sy.deltaFindState];
-                            sy = nx;
-                        }
-                        if (u == u1) fin = state;                 // walked to the end: the final state may have changed
-                    }
-                    firstPass = false;
-                    const uint32_t prevFin = __shfl_up(fin, 1);
-                    redo = lane != 0u && lane < nSegs && prevFin != st0;
-                    if (redo) st0 = prevFin;
-#ifdef HIPEMU
-                    dbgRounds++; dbgRedo += (uint32_t)__popcll(__ballot(redo));
-#endif
-                    if (!__any(redo)) break;
-                }
-#ifdef HIPEMU
-                if (getenv("GC_TRACE_CHAIN") && lane == 0) fprintf(stderr, "chain table=%u tile=%u len=%u L=%u rounds=%u redone=%u\n", wave, tb, tileLen, L, dbgRounds, dbgRedo);
-#endif
-                carry = __shfl(fin, (int)(nSegs - 1u));
-                gc_wave_sync();
-                SEQ_SUB(7);
-                for (uint32_t u = lane; u < tileLen; u += 64u) S[nSeq - 1u - (tb + u)] = T.tOut[SEQ_TO(u)];
-                gc_wave_sync();
-                SEQ_SUB(8);
-            }
-            if (lane == 0u) T.finalState = carry;
+// ------------------------------------------------------------------------------------------------ K3b tables
+// workgroup (one wave) bt = 3 * block + table; table 0 LL, 1 OF, 2 ML
+extern "C" __global__ void __launch_bounds__(64)
+gc_zstd_seq_tables_kernel(const GcSeqHist* __restrict__ hist, const GcSectionInfo* __restrict__ info, GcSeqTabG* __restrict__ tabs,
+                          unsigned long long* __restrict__ prof)
+{
+    __shared__ SeqTab T;
+    const uint32_t t = threadIdx.x, b = blockIdx.x / 3u, which = blockIdx.x % 3u;
+    const uint32_t nSeq = info[b].nSeq;
+    if (nSeq == 0u) return;
+    unsigned long long tprev = prof ? gc_clock() : 0ull;
+    T.count[t] = hist[b].count[which][t];
+    T.norm[t] = 0;
+    if (t == 0) T.finalState = 0;
+    gc_wave_sync();
+    if (t == 0) seq_build_table(T, (int)which, nSeq);
+    gc_wave_sync();
+    GcSeqTabG& G = tabs[blockIdx.x];
+    for (uint32_t i = t; i < 512u; i += 64u) G.state[i] = T.state[i];
+    G.tt[t] = T.tt[t];
+    G.norm[t] = T.norm[t];
+    for (uint32_t i = t; i < 96u; i += 64u) G.desc[i] = T.desc[i];
+    if (t == 0) { G.descSize = T.descSize; G.mode = T.mode; G.tableLog = T.tableLog; G.maxSym = T.maxSym; G.tabMaxSym = T.tabMaxSym; G.finalState = 0; }
+    SEQ_PHASE(2);         // tables
+}
+
+// ------------------------------------------------------------------------------------------------ K3c chains
+// One wave walks table `which`'s FSE state backwards over the block's sequences (last sequence first = processing index 0).
+//      The walk is serial through the state, but walks that started from different states meet at the next symbol whose
+//      normalised count is 1 (every state has the same successor there; the table builder makes sure such symbols
+//      exist).  So the 64 lanes of the wave walk 64 consecutive segments of 64 sequences at once: a lane first runs
+//      ahead of its segment from the nearest such meeting point before it (no output), then its own segment.  Afterwards every
+//      segment's start state is compared with its predecessor's final state; a segment that started wrong is walked again
+//      from the right state, only until it rejoins the states it went through before (kept at every 8th symbol), and this repeats until
+//      nothing changes (each round settles at least one more segment, so the result is exactly the serial walk).
+// Output: states[tile base + 64 * k + lane] = nbBits << 10 | state BEFORE symbol (64 * lane + k) of the tile (10 bits): the bits to emit are its
+// low nbBits.  Symbol k of all 64 segments leaves as ONE 128-byte store; the pack kernel reads through the same index (SEQ_ST_IDX).
+#define SEQ_ST_IDX(u) (((u) & ~(SEQ_CHAIN_TILE - 1u)) + (((u) & 63u) << 6) + (((u) & (SEQ_CHAIN_TILE - 1u)) >> 6))
+extern "C" __global__ void __launch_bounds__(64)
+gc_zstd_seq_chain_kernel(const uint8_t* __restrict__ codes, const GcSectionInfo* __restrict__ info, GcSeqTabG* __restrict__ tabs,
+                         uint16_t* __restrict__ states,   // out: 3 * GC_SEQ_ST_STRIDE per block (LL, OF, ML)
+                         unsigned long long* __restrict__ prof)
+{
+    __shared__ uint16_t sState[512];
+    __shared__ GcFseSym sTT[64];
+    __shared__ uint8_t  tCode[SEQ_CHAIN_TILE + SEQ_CHAIN_TILE / SEQ_CHAIN_SEG + 3u];
+    __shared__ uint64_t sMeet[SEQ_CHAIN_TILE / 64u];
+    __shared__ uint16_t sChk[64u * (SEQ_CHAIN_SEG / SEQ_CHK + 1u)];        // [lane][checkpoint], row stride 9 half-words
+    const uint32_t t = threadIdx.x, lane = t, b = blockIdx.x / 3u, which = blockIdx.x % 3u;
+    const uint32_t nSeq = info[b].nSeq;
+    if (nSeq == 0u) return;
+    GcSeqTabG& G = tabs[blockIdx.x];
+    if (G.mode == 1u) return;                                 // RLE table: no state bits at all (the pack kernel knows)
+    unsigned long long tprev = prof ? gc_clock() : 0ull;
+    unsigned long long tsub = 0;
+#define SEQ_SUB(i) do { if (prof && t == 0) { unsigned long long now_ = gc_clock(); if (tsub) atomicAdd(&prof[i], now_ - tsub); tsub = now_; } } while (0)
+    const uint8_t* C = codes + ((uint64_t)b * 3u + which) * GC_MAX_SEQ_PER_BLOCK;
+    uint16_t* S = states + ((uint64_t)b * 3u + which) * GC_SEQ_ST_STRIDE;
+    for (uint32_t i = lane; i < 512u; i += 64u) sState[i] = G.state[i];
+    sTT[lane] = G.tt[lane];
+    const uint32_t L = G.tableLog;
+    int nv = 0;
+    if (lane <= G.tabMaxSym) nv = G.norm[lane];
+    const uint64_t resetMask = __ballot(nv == 1 || nv == -1);    // symbols that send every state to the same successor
+    gc_wave_sync();
+    uint32_t carry = 0;                               // state after the last sequence of the previous tile
+    for (uint32_t tb = 0; tb < nSeq; tb += SEQ_CHAIN_TILE) {
+        const uint32_t tileLen = min(SEQ_CHAIN_TILE, nSeq - tb);
+        if (prof && t == 0) tsub = gc_clock();
+        // stage the codes (independent loads, eight in flight per lane), then per 64 sequences one mask of the positions
+        // that hold a count-1 symbol ("meeting points")
+        // (tile element u is sequence nSeq - 1 - (tb + u): sixteen elements per lane and load, read upwards in memory and stored back to front)
+        for (uint32_t u16 = lane * 16u; u16 < tileLen; u16 += 64u * 16u) {
+            const uint32_t jTop = nSeq - 1u - (tb + u16);         // sequence of element u16; the lane's elements are jTop, jTop - 1, ...
+            if (u16 + 16u <= tileLen) {
+                GcU4 v; __builtin_memcpy(&v, C + (jTop - 15u), 16);
+                const uint32_t w[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+                for (uint32_t i = 0; i < 16u; i++) tCode[SEQ_TC(u16 + i)] = (uint8_t)(w[(15u - i) >> 2] >> (((15u - i) & 3u) * 8u));
+            } else
+                for (uint32_t i = 0; u16 + i < tileLen; i++) tCode[SEQ_TC(u16 + i)] = C[jTop - i];
         }
+        gc_wave_sync();
+        SEQ_SUB(5);
+        for (uint32_t k = 0; k < tileLen; k += 64u) {
+            const uint32_t u = k + lane;
+            const bool isR = u < tileLen && ((resetMask >> tCode[SEQ_TC(u)]) & 1ull) != 0ull;
+            const uint64_t bal = __ballot(isR);
+            if (lane == 0u) sMeet[k >> 6] = bal;
+        }
+        gc_wave_sync();
+        const uint32_t nSegs = (tileLen + SEQ_CHAIN_SEG - 1u) / SEQ_CHAIN_SEG;      // <= 64: lane i walks segment i
+        const uint32_t u0 = lane * SEQ_CHAIN_SEG, u1 = min(u0 + SEQ_CHAIN_SEG, tileLen);
+        uint32_t first = u0;                          // first index of the segment that emits bits
+        uint32_t st0 = carry;
+        if (lane < nSegs) {
+            if (tb + u0 == 0u) { st0 = gc_fse_init_state(sState, sTT[tCode[SEQ_TC(0)]]); S[0] = 0; first = 1u; }   // FSE_initCState2: no bits
+            else if (lane != 0u) {
+                // run ahead from the nearest meeting point in the SEQ_WARM_SEGS segments before this one (from there the
+                // state is exact whatever it was before); if there is none, from SEQ_WARM_SEGS segments back (a guess)
+                uint32_t w = lane > SEQ_WARM_SEGS ? (lane - SEQ_WARM_SEGS) * SEQ_CHAIN_SEG : 0u;
+                for (uint32_t c = lane; c-- > 0u && c + SEQ_WARM_SEGS >= lane; ) {
+                    const uint64_t m = sMeet[c];
+                    if (m) { w = c * 64u + 63u - (uint32_t)__clzll((long long)m); break; }
+                }
+                if (tb + w == 0u) { st0 = gc_fse_init_state(sState, sTT[tCode[SEQ_TC(0)]]); w = 1u; }                   // exact, not a guess
+                else st0 = 1u << L;
+                if (w < u0) {                              // the symbol's table entry does not depend on the state: fetched one
+                    GcFseSym sy = sTT[tCode[SEQ_TC(w)]];      // step ahead, so a step costs one dependent LDS read, not three
+                    for (; w < u0; w++) {
+                        const GcFseSym nx = sTT[tCode[SEQ_TC(w + 1u < u0 ? w + 1u : w)]];
+                        const uint32_t nb = (st0 + sy.deltaNbBits) >> 16;
+                        st0 = sState[(st0 >> nb) + (uint32_t)sy.deltaFindState];
+                        sy = nx;
+                    }
+                }
+            }
+        }
+        SEQ_SUB(6);
+        uint32_t fin = st0;
+        bool redo = lane < nSegs;
+        bool firstPass = true;
+        uint16_t* chk = sChk + lane * (SEQ_CHAIN_SEG / SEQ_CHK + 1u);
+        uint16_t* Sk = S + tb + lane;                 // symbol k of this lane's segment -> Sk[64 * k]
+#ifdef HIPEMU
+        uint32_t dbgRounds = 0, dbgRedo = 0;
+#endif
+        for (;;) {
+            if (redo) {
+                uint32_t state = st0, u = first;
+                GcFseSym sy = sTT[tCode[SEQ_TC(u < u1 ? u : u1 - 1u)]];
+                for (; u < u1; u++) {
+                    const uint32_t k = u - u0;
+                    if ((k & (SEQ_CHK - 1u)) == 0u) {
+                        if (!firstPass && chk[k / SEQ_CHK] == (uint16_t)state) break;     // rejoined: the rest is what it was
+                        chk[k / SEQ_CHK] = (uint16_t)state;
+                    }
+                    const GcFseSym nx = sTT[tCode[SEQ_TC(u + 1u < u1 ? u + 1u : u)]];
+                    const uint32_t nb = (state + sy.deltaNbBits) >> 16;
+                    Sk[64u * k] = (uint16_t)((nb << 10) | (state & 0x3FFu));
+                    state = sState[(state >> nb) + (uint32_t)sy.deltaFindState];
+                    sy = nx;
+                }
+                if (u == u1) fin = state;                 // walked to the end: the final state may have changed
+            }
+            firstPass = false;
+            const uint32_t prevFin = __shfl_up(fin, 1);
+            redo = lane != 0u && lane < nSegs && prevFin != st0;
+            if (redo) st0 = prevFin;
+#ifdef HIPEMU
+            dbgRounds++; dbgRedo += (uint32_t)__popcll(__ballot(redo));
+#endif
+            if (!__any(redo)) break;
+        }
+#ifdef HIPEMU
+        if (getenv("GC_TRACE_CHAIN") && lane == 0) fprintf(stderr, "chain table=%u tile=%u len=%u L=%u rounds=%u redone=%u\n", which, tb, tileLen, L, dbgRounds, dbgRedo);
+#endif
+        carry = __shfl(fin, (int)(nSegs - 1u));
+        gc_wave_sync();
+        SEQ_SUB(7);
     }
-    __syncthreads();
+    if (lane == 0u) G.finalState = carry;
     SEQ_PHASE(3);         // state chains
+}
+
+// ------------------------------------------------------------------------------------------------ K3d pack
+extern "C" __global__ void __launch_bounds__(SEQ_T)
+gc_zstd_seq_pack_kernel(const uint64_t* __restrict__ seqPacked, const uint8_t* __restrict__ codes, const uint16_t* __restrict__ states,
+                        const GcSeqTabG* __restrict__ tabs, uint8_t* __restrict__ seqSec, GcSectionInfo* __restrict__ info, uint64_t srcSize,
+                        unsigned long long* __restrict__ prof)
+{
+    __shared__ uint32_t sWave[SEQ_T / 64u];
+    __shared__ uint32_t sTile[SEQ_TILE_WORDS];
+    __shared__ uint32_t sMode[3], sLog[3], sFinal[3], sDesc[3];
+    const uint32_t t = threadIdx.x, b = blockIdx.x;
+    const uint32_t nSeq = info[b].nSeq;
+    if (nSeq == 0u) return;                                   // (the codes kernel has written the one-byte section)
+    unsigned long long tprev = prof ? gc_clock() : 0ull;
+    const uint64_t blockBase = (uint64_t)b * GC_ZSTD_BLOCK_MAX;
+    const uint32_t blockLen = (uint32_t)((srcSize - blockBase) < GC_ZSTD_BLOCK_MAX ? (srcSize - blockBase) : GC_ZSTD_BLOCK_MAX);
+    const uint64_t* P = seqPacked + (uint64_t)b * GC_MAX_SEQ_PER_BLOCK;
+    const uint8_t* cLL = codes + (uint64_t)b * 3u * GC_MAX_SEQ_PER_BLOCK;
+    const uint8_t* cOF = cLL + GC_MAX_SEQ_PER_BLOCK;
+    const uint8_t* cML = cOF + GC_MAX_SEQ_PER_BLOCK;
+    const uint16_t* stLL = states + (uint64_t)b * 3u * GC_SEQ_ST_STRIDE;
+    const uint16_t* stOF = stLL + GC_SEQ_ST_STRIDE;
+    const uint16_t* stML = stOF + GC_SEQ_ST_STRIDE;
+    const GcSeqTabG* G = tabs + (uint64_t)b * 3u;
+    uint8_t* out = seqSec + (uint64_t)b * GC_SEQSEC_STRIDE;
+    if (t < 3u) { sMode[t] = G[t].mode; sLog[t] = G[t].tableLog; sFinal[t] = G[t].finalState; sDesc[t] = G[t].descSize; }
+    __syncthreads();
 
     // ---- section header (zstd_compress.c:2939-2953 nbSeq; modes byte; table descriptions LL, OF, ML)
     uint32_t hdrLen;
     {
         uint32_t h = nSeq < 128u ? 1u : (nSeq < 0x7F00u ? 2u : 3u);
-        hdrLen = h + 1u + sTab[0].descSize + sTab[1].descSize + sTab[2].descSize;
+        hdrLen = h + 1u + sDesc[0] + sDesc[1] + sDesc[2];
         if (t == 0) {
             if (h == 1u) out[0] = (uint8_t)nSeq;
             else if (h == 2u) { out[0] = (uint8_t)((nSeq >> 8) + 0x80u); out[1] = (uint8_t)nSeq; }
             else { out[0] = 0xFF; out[1] = (uint8_t)(nSeq - 0x7F00u); out[2] = (uint8_t)((nSeq - 0x7F00u) >> 8); }
-            out[h] = (uint8_t)((sTab[0].mode << 6) | (sTab[1].mode << 4) | (sTab[2].mode << 2));
+            out[h] = (uint8_t)((sMode[0] << 6) | (sMode[1] << 4) | (sMode[2] << 2));
             uint32_t p = h + 1u;
-            for (int k = 0; k < 3; k++) for (uint32_t i = 0; i < sTab[k].descSize; i++) out[p++] = sTab[k].desc[i];
+            for (int k = 0; k < 3; k++) for (uint32_t i = 0; i < sDesc[k]; i++) out[p++] = G[k].desc[i];
         }
     }
+    const bool rleLL = sMode[0] == 1u, rleOF = sMode[1] == 1u, rleML = sMode[2] == 1u;
 
     // ---- pack the bitstream, last sequence first
     const uint32_t limit = min(blockLen, (uint32_t)GC_SEQSEC_STRIDE - 64u);
@@ -419,7 +486,8 @@ gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __res
             const uint32_t ll = (uint32_t)(pk & 0x1FFFFu), mlBase = (uint32_t)((pk >> 17) & 0x3FFFFu), offBase = (uint32_t)(pk >> 35);
             const uint32_t llc = cLL[j], mlc = cML[j], ofc = cOF[j];
             if (u != 0u) {
-                uint32_t so_ = stOF[j], sm = stML[j], sl = stLL[j];
+                const uint32_t si = SEQ_ST_IDX(u);
+                const uint32_t so_ = rleOF ? 0u : stOF[si], sm = rleML ? 0u : stML[si], sl = rleLL ? 0u : stLL[si];
                 a |= (uint64_t)(so_ & ((1u << (so_ >> 10)) - 1u)) << na; na += so_ >> 10;     // low nbBits of the state (stored whole)
                 a |= (uint64_t)(sm & ((1u << (sm >> 10)) - 1u)) << na; na += sm >> 10;
                 a |= (uint64_t)(sl & ((1u << (sl >> 10)) - 1u)) << na; na += sl >> 10;
@@ -438,12 +506,12 @@ gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __res
         if (lastTile) {
             if (t == 0) {      // final states ML, OF, LL then the closing bit (zstd_compress_sequences.c:372-376)
                 uint32_t e = endBits;
-                seq_or_bits(sTile, e, sTab[2].finalState & ((1u << sTab[2].tableLog) - 1u), sTab[2].tableLog); e += sTab[2].tableLog;
-                seq_or_bits(sTile, e, sTab[1].finalState & ((1u << sTab[1].tableLog) - 1u), sTab[1].tableLog); e += sTab[1].tableLog;
-                seq_or_bits(sTile, e, sTab[0].finalState & ((1u << sTab[0].tableLog) - 1u), sTab[0].tableLog); e += sTab[0].tableLog;
+                seq_or_bits(sTile, e, sFinal[2] & ((1u << sLog[2]) - 1u), sLog[2]); e += sLog[2];
+                seq_or_bits(sTile, e, sFinal[1] & ((1u << sLog[1]) - 1u), sLog[1]); e += sLog[1];
+                seq_or_bits(sTile, e, sFinal[0] & ((1u << sLog[0]) - 1u), sLog[0]); e += sLog[0];
                 seq_or_bits(sTile, e, 1u, 1u);
             }
-            endBits += sTab[0].tableLog + sTab[1].tableLog + sTab[2].tableLog + 1u;
+            endBits += sLog[0] + sLog[1] + sLog[2] + 1u;
         }
         __syncthreads();
         const uint32_t flush = lastTile ? (endBits + 7u) >> 3 : endBits >> 3;
@@ -457,5 +525,5 @@ gc_zstd_seq_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __res
         __syncthreads();
     }
     SEQ_PHASE(4);         // pack
-    if (t == 0) { info[b].seqSecSize = overflow ? 0xFFFFFFFFu : hdrLen + outBytes; info[b].nSeq = nSeq; }
+    if (t == 0) info[b].seqSecSize = overflow ? 0xFFFFFFFFu : hdrLen + outBytes;
 }
