@@ -362,6 +362,7 @@ MFK(gc_mf_scatter_far_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize,
 #endif
 #define LINK_WARM  16384u             // entries replayed in front of a segment
 #define LINK_SEGS  GC_MF_LINK_SEGS                 // segments per list; the last one takes whatever is left
+#define LINK_BATCH 16u                             // items of the upper segments per ticket
 
 // what the table held when the entry arrived -> candidate position + 1, or 0
 __device__ __forceinline__ uint32_t mf_link_pick(uint32_t seen, uint32_t mine)
@@ -416,21 +417,39 @@ MFK(gc_mf_link_kernel)(const uint32_t* __restrict__ offs, const GcMfEntry* __res
     __shared__ uint32_t tabL[1u << GC_MF_LSLOT_LOG];
     __shared__ uint32_t tabS[1u << GC_MF_SSLOT_LOG];
     const uint32_t lane = threadIdx.x;
-    const uint32_t nItems = nLists * LINK_SEGS;
+    // Work items = (list, segment) pairs, highest segment first: the segments beyond the first belong to the long lists and are the longest
+    // pieces of work (LINK_SEG + LINK_WARM entries), so they start first instead of forming the tail of the launch.  Most of them do not
+    // exist: tickets of the upper segments stand for LINK_BATCH items each, which as many lanes test side by side (one trip to memory for the
+    // batch instead of one per item; a batch is small enough that the segments found in it are no tail of their own); the first segments, nearly all of which exist, are drawn one by one, so that the work stays evenly dealt.
+    const uint32_t nUpper = nLists * (LINK_SEGS - 1u), nBatches = (nUpper + LINK_BATCH - 1u) / LINK_BATCH, nTickets = nBatches + nLists;
     for (;;) {
-        uint32_t item = 0;
-        if (lane == 0u) item = atomicAdd(ticket, 1u);
-        item = __shfl(item, 0);
-        if (item >= nItems) break;
-        // segment-major and HIGHEST segment first: the segments that exist beyond the first belong to the long lists and are the longest pieces
-        // of work (LINK_SEG + LINK_WARM entries), so they start first instead of forming the tail of the launch
+        uint32_t tk = 0;
+        if (lane == 0u) tk = atomicAdd(ticket, 1u);
+        tk = __shfl(tk, 0);
+        if (tk >= nTickets) break;
+        uint64_t todo;                                            // lanes whose item exists
+        uint32_t myItem, myStart = 0, myEnd = 0;
+        {
+            myItem = tk < nBatches ? tk * LINK_BATCH + lane : nUpper + (tk - nBatches);
+            const bool inRange = tk < nBatches ? (lane < LINK_BATCH && myItem < nUpper) : lane == 0u;
+            bool exists = false;
+            if (inRange) {
+                const uint32_t seg = LINK_SEGS - 1u - myItem / nLists, fg = myItem % nLists;
+                const uint32_t frame = fg >> GC_MF_PART_LOG, g = fg & (GC_MF_PARTS - 1u);
+                const uint32_t* row = offs + (uint64_t)frame * (tilesPerFrame + 1u) * GC_MF_PARTS;
+                const uint32_t listStart = row[g], listEnd = row[(uint64_t)tilesPerFrame * GC_MF_PARTS + g];
+                myStart = listStart + seg * LINK_SEG;
+                exists = myStart < listEnd;
+                myEnd = (seg + 1u < LINK_SEGS && myStart + LINK_SEG < listEnd) ? myStart + LINK_SEG : listEnd;
+            }
+            todo = __ballot(exists);
+        }
+      while (todo != 0ull) {
+        const uint32_t src_ = gc_ctz64(todo);
+        todo &= todo - 1ull;
+        const uint32_t item = __shfl(myItem, (int)src_), start = __shfl(myStart, (int)src_), end = __shfl(myEnd, (int)src_);
         const uint32_t seg = LINK_SEGS - 1u - item / nLists, fg = item % nLists;
-        const uint32_t frame = fg >> GC_MF_PART_LOG, g = fg & (GC_MF_PARTS - 1u);
-        const uint32_t* row = offs + (uint64_t)frame * (tilesPerFrame + 1u) * GC_MF_PARTS;
-        const uint32_t listStart = row[g], listEnd = row[(uint64_t)tilesPerFrame * GC_MF_PARTS + g];
-        const uint32_t start = listStart + seg * LINK_SEG;
-        if (start >= listEnd) continue;
-        const uint32_t end = (seg + 1u < LINK_SEGS && start + LINK_SEG < listEnd) ? start + LINK_SEG : listEnd;
+        const uint32_t frame = fg >> GC_MF_PART_LOG;
         const GcMfEntry* E = ent + (uint64_t)frame * frameBytes;
         GcMfEntry* EO = entOut + (uint64_t)frame * frameBytes;
         gc_wave_sync();                                           // (the previous item's table operations are done)
@@ -459,6 +478,7 @@ MFK(gc_mf_link_kernel)(const uint32_t* __restrict__ offs, const GcMfEntry* __res
             mf_link_load(qa, E, s0 + 2u * 64u * LINK_DEPTH, end, lane);
             mf_link_steps(qb, tabL, tabS, EO, s0 + 64u * LINK_DEPTH, end, lane);
         }
+      }
     }
 }
 

@@ -298,9 +298,11 @@ gc_zstd_seq_tables_kernel(const GcSeqHist* __restrict__ hist, const GcSectionInf
 //      segment's start state is compared with its predecessor's final state; a segment that started wrong is walked again
 //      from the right state, only until it rejoins the states it went through before (kept at every 8th symbol), and this repeats until
 //      nothing changes (each round settles at least one more segment, so the result is exactly the serial walk).
-// Output: states[tile base + 64 * k + lane] = nbBits << 10 | state BEFORE symbol (64 * lane + k) of the tile (10 bits): the bits to emit are its
-// low nbBits.  Symbol k of all 64 segments leaves as ONE 128-byte store; the pack kernel reads through the same index (SEQ_ST_IDX).
-#define SEQ_ST_IDX(u) (((u) & ~(SEQ_CHAIN_TILE - 1u)) + (((u) & 63u) << 6) + (((u) & (SEQ_CHAIN_TILE - 1u)) >> 6))
+// Output: nbBits << 10 | state BEFORE the symbol (10 bits): the bits to emit are its low nbBits.  Symbol k of segment `lane` of a tile is processing
+// index u = 64 * lane + k; it is stored at SEQ_ST_IDX(u) = 256 * (lane / 4) + 4 * k + lane % 4, i.e. the 256 symbols of four neighbouring segments
+// share 512 bytes: a step of the walk writes 8 bytes per group of four lanes, sixteen steps fill a line, and the 256 sequences a pack
+// workgroup takes per round are four whole lines (in segment-major order the same round touched 64 lines: 3.7 GB fetched for 0.4 GB of states).
+#define SEQ_ST_IDX(u) (((u) & ~255u) + (((u) & 63u) << 2) + (((u) >> 6) & 3u))
 extern "C" __global__ void __launch_bounds__(64)
 gc_zstd_seq_chain_kernel(const uint8_t* __restrict__ codes, const GcSectionInfo* __restrict__ info, GcSeqTabG* __restrict__ tabs,
                          uint16_t* __restrict__ states,   // out: 3 * GC_SEQ_ST_STRIDE per block (LL, OF, ML)
@@ -386,7 +388,7 @@ gc_zstd_seq_chain_kernel(const uint8_t* __restrict__ codes, const GcSectionInfo*
         bool redo = lane < nSegs;
         bool firstPass = true;
         uint16_t* chk = sChk + lane * (SEQ_CHAIN_SEG / SEQ_CHK + 1u);
-        uint16_t* Sk = S + tb + lane;                 // symbol k of this lane's segment -> Sk[64 * k]
+        uint16_t* Sk = S + tb + ((lane >> 2) << 8) + (lane & 3u);      // symbol k of this lane's segment -> Sk[4 * k]
 #ifdef HIPEMU
         uint32_t dbgRounds = 0, dbgRedo = 0;
 #endif
@@ -402,7 +404,7 @@ gc_zstd_seq_chain_kernel(const uint8_t* __restrict__ codes, const GcSectionInfo*
                     }
                     const GcFseSym nx = sTT[tCode[SEQ_TC(u + 1u < u1 ? u + 1u : u)]];
                     const uint32_t nb = (state + sy.deltaNbBits) >> 16;
-                    Sk[64u * k] = (uint16_t)((nb << 10) | (state & 0x3FFu));
+                    Sk[4u * k] = (uint16_t)((nb << 10) | (state & 0x3FFu));
                     state = sState[(state >> nb) + (uint32_t)sy.deltaFindState];
                     sy = nx;
                 }
