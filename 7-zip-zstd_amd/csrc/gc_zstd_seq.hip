@@ -165,10 +165,31 @@ __device__ inline void seq_build_table(SeqTab& T, int which, uint32_t nbSeq)
 #define SEQ_PHASE(i) do { if (prof && t == 0) { unsigned long long now_ = gc_clock(); atomicAdd(&prof[i], now_ - tprev); tprev = now_; } } while (0)
 
 // ------------------------------------------------------------------------------------------------ K3a codes
+// block-wide inclusive max scan of 64-bit keys (SEQ_T threads)
+__device__ __forceinline__ uint64_t seq_incl_maxscan64(uint64_t v, uint64_t* sWave64, uint64_t* total)
+{
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t lo = __shfl_up((uint32_t)v, d), hi = __shfl_up((uint32_t)(v >> 32), d);
+        const uint64_t o = ((uint64_t)hi << 32) | lo;
+        if (lane >= (uint32_t)d && o > v) v = o;
+    }
+    if (lane == 63u) sWave64[wave] = v;
+    __syncthreads();
+    uint64_t before = 0, all = 0;
+    for (uint32_t w = 0; w < SEQ_T / 64u; w++) { const uint64_t c = sWave64[w]; if (w < wave && c > before) before = c; if (c > all) all = c; }
+    __syncthreads();
+    *total = all;
+    return before > v ? before : v;
+}
+
+// The raw records are taken SEQ_T at a time; merged sequences collect in an LDS ring and are coded SEQ_T at a time from there, so nothing this
+// kernel computes is written to memory and read back (rounds 1-2 wrote the merged sequences out, then read them and their neighbours again).
+#define SEQ_RING 1024u       // merged sequences the ring holds (>= 2 * SEQ_T + 1)
 extern "C" __global__ void __launch_bounds__(SEQ_T)
 gc_zstd_seq_codes_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta* __restrict__ meta,
                    uint64_t* __restrict__ seqPacked,      // out: ll | mlBase << 17 | offBase << 35 per merged sequence
-                   uint32_t* __restrict__ seqOff,         // scratch: real offsets
+                   uint32_t* __restrict__ seqOff,         // (unused since the ring; kept in the signature for the workspace's sake)
                    uint8_t* __restrict__ codes,           // out: 3 * GC_MAX_SEQ_PER_BLOCK per block (LL, OF, ML)
                    GcSeqHist* __restrict__ hist, uint8_t* __restrict__ seqSec, GcSectionInfo* __restrict__ info,
                    uint32_t frameBlocks,                  // blocks per zstd frame: repeat offsets carry over inside a frame
@@ -176,73 +197,51 @@ gc_zstd_seq_codes_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta*
 {
     __shared__ uint32_t sCount[3][64];
     __shared__ uint32_t sWave[SEQ_T / 64u];
-    __shared__ uint32_t sRun[SEQ_T];
+    __shared__ uint64_t sWave64[SEQ_T / 64u];
+    __shared__ uint64_t sPair[SEQ_T];
+    __shared__ uint32_t rLL[SEQ_RING], rML[SEQ_RING], rOFF[SEQ_RING];
     const uint32_t t = threadIdx.x, b = blockIdx.x;
     const uint32_t nRaw = meta[b].nSeqRaw;
     const GcSeqRaw* R = seqRaw + (uint64_t)b * GC_MAX_SEQ_PER_BLOCK;
     uint64_t* P = seqPacked + (uint64_t)b * GC_MAX_SEQ_PER_BLOCK;
-    uint32_t* O = seqOff + (uint64_t)b * GC_MAX_SEQ_PER_BLOCK;
     uint8_t* cLL = codes + (uint64_t)b * 3u * GC_MAX_SEQ_PER_BLOCK;
     uint8_t* cOF = cLL + GC_MAX_SEQ_PER_BLOCK;
     uint8_t* cML = cOF + GC_MAX_SEQ_PER_BLOCK;
+    (void)seqOff;
     if (nRaw == 0) { if (t == 0) { seqSec[(uint64_t)b * GC_SEQSEC_STRIDE] = 0; info[b].seqSecSize = 1; info[b].nSeq = 0; } return; }
     for (uint32_t i = t; i < 3u * 64u; i += SEQ_T) sCount[i >> 6][i & 63u] = 0;
     unsigned long long tprev = prof ? gc_clock() : 0ull;
 
-    // ---- S1: merge chains of capped matches.  Head = first record of a run with equal offset and litLength 0.
-    //      P[j] = ll(17) | ml(18)<<17 for merged sequence j, O[j] = its offset
-    uint32_t nSeq = 0;
-    for (uint32_t tb = 0; tb < nRaw; tb += SEQ_T) {
-        const uint32_t i = tb + t;
-        uint32_t head = 0, ll = 0, off = 0, ml = 0;
-        if (i < nRaw) {
-            GcSeqRaw r = R[i];
-            uint32_t prevRank = 0, prevOff = 0;
-            if (i) { GcSeqRaw q = R[i - 1u]; prevRank = q.litRank; prevOff = q.offml >> 8; }
-            ll = r.litRank - prevRank; off = r.offml >> 8; ml = r.offml & 0xFFu;
-            head = (i == 0u || ll != 0u || off != prevOff) ? 1u : 0u;
-            if (head) {
-                const uint32_t rank = r.litRank;
-                for (uint32_t k = i + 1u; k < nRaw; k++) {            // absorb the continuation records
-                    GcSeqRaw c = R[k];
-                    if (c.litRank != rank || (c.offml >> 8) != off) break;
-                    ml += c.offml & 0xFFu;
-                }
-            }
-        }
-        uint32_t tot;
-        const uint32_t j = nSeq + seq_excl_scan(head, sWave, &tot);
-        if (head) { P[j] = (uint64_t)ll | ((uint64_t)ml << 17); O[j] = off; }
-        nSeq += tot;
-    }
-    __syncthreads();      // P/O written by this workgroup are read back by other lanes below
-    SEQ_PHASE(0);         // merge
-
-    // ---- S2: repeat offsets as scans, then codes + histograms
-    //      virtual history: index -1 -> offset 1, -2 -> 4 (start state {1,4,8}, zstd_internal.h:65) in the first block of a
-    //      frame.  In later blocks the decoder arrives with the history the previous block left behind; this block is coded
-    //      without knowing it (blocks stay independent units of work): the virtual history is "unknown" (0, never equal to
-    //      an offset), so no repeat code refers to it.  rep1 = previous offset and rep2 = offset before the current run hold
-    //      for the decoder whatever the unknown part was, because every code emitted below moves exactly those two slots.
+    // virtual history of the repeat offsets: index -1 -> offset 1, -2 -> 4 (start state {1,4,8}, zstd_internal.h:65) in the first block of a
+    // frame.  In later blocks the decoder arrives with the history the previous block left behind; this block is coded
+    // without knowing it (blocks stay independent units of work): the virtual history is "unknown" (0, never equal to
+    // an offset), so no repeat code refers to it.  rep1 = previous offset and rep2 = offset before the current run hold
+    // for the decoder whatever the unknown part was, because every code emitted below moves exactly those two slots.
     const bool firstInFrame = (b % frameBlocks) == 0u;
     const uint32_t virt1 = firstInFrame ? 1u : 0u, virt2 = firstInFrame ? 4u : 0u;
-    uint32_t carryRun = 1u;      // (run start index + 2) of the run containing the last sequence of the previous tile
-    for (uint32_t tb = 0; tb < nSeq; tb += SEQ_T) {
-        const uint32_t j = tb + t;
-        uint32_t off = 0, prevOff = virt1;
-        if (j < nSeq) { off = O[j]; prevOff = j ? O[j - 1u] : virt1; }
-        const uint32_t v = (j < nSeq && off != prevOff) ? j + 2u : 0u;
-        uint32_t tot;
-        const uint32_t runIncl = max(seq_incl_maxscan(v, sWave, &tot), carryRun);  // run start (+2) of the run containing j
-        sRun[t] = runIncl;
+    uint32_t nMerged = 0, nCoded = 0;        // merged sequences in the ring so far / coded so far (uniform)
+    uint32_t carryOff = virt1;               // offset of the last coded sequence
+    uint64_t carryPair = (1ull << 32) | virt2;   // (start index + 2 of the run of equal offsets that holds the last coded sequence, offset in front of that run)
+
+    // S2 on the SEQ_T sequences from nCoded on (or the last few): repeat offsets as scans, codes, histograms
+    auto code_batch = [&](uint32_t count) {
+        const uint32_t j = nCoded + t;
+        const bool on = t < count;
+        uint32_t off = 0, prevOff = carryOff, ll = 0, ml = 0;
+        if (on) {
+            off = rOFF[j & (SEQ_RING - 1u)]; ll = rLL[j & (SEQ_RING - 1u)]; ml = rML[j & (SEQ_RING - 1u)];
+            if (t) prevOff = rOFF[(j - 1u) & (SEQ_RING - 1u)];
+        }
+        // a run of equal offsets starts at j: key = (j + 2, the offset in front of the run); the scan hands every j the key of its run
+        const uint64_t key = (on && off != prevOff) ? (((uint64_t)(j + 2u)) << 32) | prevOff : 0ull;
+        uint64_t tot;
+        uint64_t pair = seq_incl_maxscan64(key, sWave64, &tot);
+        if (carryPair > pair) pair = carryPair;
+        sPair[t] = pair;
         __syncthreads();
-        const uint32_t runPrev = t ? sRun[t - 1u] : carryRun;                      // ... of the run containing j-1
-        if (j < nSeq) {
-            const uint64_t pk = P[j];
-            const uint32_t ll = (uint32_t)(pk & 0x1FFFFu), ml = (uint32_t)((pk >> 17) & 0x3FFFFu);
-            const uint32_t rep1 = prevOff;
-            const int32_t before = (int32_t)runPrev - 3;             // index whose offset is rep2 (>= -2)
-            const uint32_t rep2 = before >= 0 ? O[before] : (before == -1 ? virt1 : virt2);
+        const uint64_t pairPrev = t ? sPair[t - 1u] : carryPair;                   // ... of the run that holds j - 1
+        if (on) {
+            const uint32_t rep1 = prevOff, rep2 = (uint32_t)pairPrev;
             uint32_t offBase;
             if (ll != 0u) offBase = (off == rep1) ? 1u : ((off == rep2) ? 2u : off + 3u);
             else offBase = (off == rep2) ? 1u : ((rep1 > 1u && off == rep1 - 1u) ? 3u : off + 3u);
@@ -255,11 +254,43 @@ gc_zstd_seq_codes_kernel(const GcSeqRaw* __restrict__ seqRaw, const GcBlockMeta*
             if (getenv("GC_TRACE")) fprintf(stderr, "E %u ofv=%u ml=%u ll=%u off=%u rep1=%u rep2=%u\n", j, offBase, ml, ll, off, rep1, rep2);
 #endif
         }
-        carryRun = max(carryRun, tot);
+        if (tot > carryPair) carryPair = tot;
+        carryOff = rOFF[(nCoded + count - 1u) & (SEQ_RING - 1u)];
+        nCoded += count;
         __syncthreads();
+    };
+
+    GcSeqRaw rNext, qNext;                   // this thread's record of the next round and the record in front of it (requested a round ahead)
+    rNext.litRank = rNext.offml = qNext.litRank = qNext.offml = 0;
+    if (t < nRaw) { rNext = R[t]; if (t) qNext = R[t - 1u]; }
+    for (uint32_t tb = 0; tb < nRaw; tb += SEQ_T) {
+        // ---- S1: merge chains of capped matches.  Head = first record of a run with equal offset and litLength 0; the records behind it
+        //      add their lengths to it (a chain may run on into the next SEQ_T records: the ring's last sequence stays open until then)
+        const uint32_t i = tb + t;
+        const GcSeqRaw r = rNext, q = qNext;
+        if (i + SEQ_T < nRaw) { rNext = R[i + SEQ_T]; qNext = R[i + SEQ_T - 1u]; }
+        uint32_t head = 0, ll = 0, off = 0, ml = 0;
+        if (i < nRaw) {
+            uint32_t prevRank = 0, prevOff = 0;
+            if (i) { prevRank = q.litRank; prevOff = q.offml >> 8; }
+            ll = r.litRank - prevRank; off = r.offml >> 8; ml = r.offml & 0xFFu;
+            head = (i == 0u || ll != 0u || off != prevOff) ? 1u : 0u;
+        }
+        uint32_t tot;
+        const uint32_t before = seq_excl_scan(head, sWave, &tot);
+        const uint32_t slot = (nMerged + before + head - 1u) & (SEQ_RING - 1u);      // (a record that is no head: the sequence of the head in front of it)
+        if (head) { rLL[slot] = ll; rML[slot] = ml; rOFF[slot] = off; }
+        __syncthreads();
+        if (i < nRaw && !head) atomicAdd(&rML[slot], ml);
+        nMerged += tot;
+        __syncthreads();
+        // ---- S2 whenever SEQ_T sequences are complete (the last one in the ring may still grow)
+        while (nMerged - nCoded > SEQ_T) code_batch(SEQ_T);
     }
+    SEQ_PHASE(0);         // merge (and the batches coded on the way)
+    while (nCoded < nMerged) code_batch(nMerged - nCoded < SEQ_T ? nMerged - nCoded : SEQ_T);
     for (uint32_t i = t; i < 3u * 64u; i += SEQ_T) hist[b].count[i >> 6][i & 63u] = sCount[i >> 6][i & 63u];
-    if (t == 0) info[b].nSeq = nSeq;
+    if (t == 0) info[b].nSeq = nMerged;
     SEQ_PHASE(1);         // repcodes + codes + histograms
 }
 
