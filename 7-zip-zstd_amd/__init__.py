@@ -17,11 +17,12 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "csrc", "libgpucodec.so")
+HOOKS_LIB_PATH = os.path.join(HERE, "csrc", "libgpucodec_hooks.so")     # test build: GC_* environment hooks compiled in (tests / tools only)
 
 GC_OK = 0
 _ERR = {-1: "GC_ERR_NO_DEVICE", -2: "GC_ERR_HIP", -3: "GC_ERR_NOMEM", -4: "GC_ERR_DST_SMALL", -5: "GC_ERR_PARAM", -6: "GC_ERR_CORRUPT"}
 
-EXPORTS = ["gc_device_count", "gc_ctx_create", "gc_ctx_destroy", "gc_last_error_message", "gc_zstd_compress_bound",
+EXPORTS = ["gc_test_hooks_enabled", "gc_device_count", "gc_ctx_create", "gc_ctx_destroy", "gc_last_error_message", "gc_zstd_compress_bound",
            "gc_zstd_compress_device", "gc_zstd_finish", "gc_zstd_compress_host", "gc_zstd_last_timing", "gc_ctx_stream",
            "gc_zstd_set_phase_profile", "gc_zstd_phase_profile", "gc_mf_last_timing", "gc_mf_price_timing", "gc_mf_pass_timing",
            "gc_flzma2_compress_bound", "gc_flzma2_dict_prop", "gc_flzma2_compress_device", "gc_flzma2_finish", "gc_flzma2_compress_host",
@@ -46,6 +47,7 @@ def load_library(path=None):
     if not os.path.exists(path):
         raise GpuCodecError("HIP extension %s is missing: run __graft_entry__.build()" % path)
     lib = C.CDLL(path)
+    lib.gc_test_hooks_enabled.restype = C.c_int
     lib.gc_device_count.restype = C.c_int
     lib.gc_ctx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
     lib.gc_ctx_create.restype = C.c_int

@@ -139,8 +139,11 @@ struct gc_ctx {
     bool profOn; uint32_t profBlocks;
 };
 
-// Test hooks (environment variables) are validated: a value outside [lo, hi] is ignored, so that no setting can push the kernels
-// outside the geometry their entry formats were sized for (23-bit frame-relative positions, 8 MiB dictionary property, ...).
+// Test hooks (environment variables) exist only in the TEST build of this file (-DGC_TEST_HOOKS: csrc/libgpucodec_hooks.so and the emulator
+// library of tests/emu); in the shipped library gc_env_u32 is the constant `false`, no getenv is compiled in, and the bytes a call produces
+// depend on its arguments alone.  Where a hook is read its value is validated: one outside [lo, hi] is ignored, so that no setting can push
+// the kernels outside the geometry their entry formats were sized for (23-bit frame-relative positions, 8 MiB dictionary property, ...).
+#ifdef GC_TEST_HOOKS
 static bool gc_env_u32(const char* name, uint32_t lo, uint32_t hi, uint32_t* out)
 {
     const char* e = getenv(name);
@@ -151,6 +154,11 @@ static bool gc_env_u32(const char* name, uint32_t lo, uint32_t hi, uint32_t* out
     *out = (uint32_t)v;
     return true;
 }
+extern "C" int gc_test_hooks_enabled(void) { return 1; }
+#else
+static inline bool gc_env_u32(const char*, uint32_t, uint32_t, uint32_t*) { return false; }
+extern "C" int gc_test_hooks_enabled(void) { return 0; }
+#endif
 
 #define HIPCHK(ctx, call)                                                                       \
     do { hipError_t e_ = (call);                                                                \
@@ -1181,7 +1189,8 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
     free(h); free(res);
     if (zdProf) {
         unsigned long long pv[16] = { 0 };
-        if (hipMemcpy(pv, zdProf, 128, hipMemcpyDeviceToHost) == hipSuccess && getenv("GC_ZD_SEQV_DBG")) { for (int q = 0; q < 16; q++) fprintf(stderr, "[dbg %2d] %016llx\n", q, pv[q]); }
+        uint32_t dbg_ = 0;
+        if (hipMemcpy(pv, zdProf, 128, hipMemcpyDeviceToHost) == hipSuccess && gc_env_u32("GC_ZD_SEQV_DBG", 1u, 1u, &dbg_)) { for (int q = 0; q < 16; q++) fprintf(stderr, "[dbg %2d] %016llx\n", q, pv[q]); }
         else if (pv[3])
             fprintf(stderr, "[GC_ZD_PROF] compressed blocks %llu: cycles per block pass1 %.0f pass2 %.0f flush %.0f; pass 2: %.1f groups of 64 sequences per block, %.2f rounds per group of which %.2f for one special match\n", pv[3],
                     (double)pv[0] / pv[3], (double)pv[1] / pv[3], (double)pv[2] / pv[3], (double)pv[5] / pv[3], pv[5] ? (double)pv[4] / pv[5] : 0.0, pv[5] ? (double)pv[6] / pv[5] : 0.0);

@@ -166,6 +166,9 @@ int         gc_multi_compress_host(gc_multi* m, int codec, const void* src, size
 #define GC_BROTLI_NOT_FIRST 2u      /* ... and not its first piece: no stream header */
 #define GC_BROTLI_NOT_LAST  4u      /* ... and not its last piece: no closing (ISLAST) meta-block */
 int         gc_ctx_set_option(gc_ctx* ctx, int option, int value);
+/* 1 in the test build of the library (csrc/libgpucodec_hooks.so: GC_* environment variables select code paths for the tests), 0 in the
+ * shipped one, which reads no environment variable at all */
+int         gc_test_hooks_enabled(void);
 
 /* ---- CRC-32 of data that lies in device memory (C/7zCrc.c CrcCalc: polynomial 0xEDB88320, init and final XOR 0xFFFFFFFF).
  * Synchronous, on the current device's default stream. */

@@ -90,3 +90,14 @@ def gpu_enc(pkg, graft):
     enc = pkg.ZstdEncoder(device=0)       # raises loudly if libgpucodec.so is missing or no gfx950 device opens
     yield enc
     enc.close()
+
+
+@pytest.fixture(scope="session")
+def gpu_hooks_kw(pkg, graft):
+    """Constructor arguments for GPU tests that steer the library through GC_* environment hooks: those exist only in the test build
+    (csrc/libgpucodec_hooks.so, the same objects with gc_api.hip compiled -DGC_TEST_HOOKS); the shipped library reads no environment."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    graft.build_hip()
+    return dict(device=0, lib_path=pkg.HOOKS_LIB_PATH)

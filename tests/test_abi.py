@@ -62,3 +62,16 @@ def test_quad_permute_moves_of_the_sequences_kernel_stay_unfolded(graft, tmp_pat
     dpp = re.findall(r"\b(v_\w+_dpp)\b", m.group(0))
     assert dpp and set(dpp) == {"v_mov_b32_dpp"}, sorted(set(dpp))
     assert len(dpp) == 9                                           # 2 x 3 bit counts + 3 values per sequence step
+
+
+def test_shipped_library_reads_no_environment(pkg, graft):
+    """The GC_* hooks are compiled into the test build only: the shipped library imports no getenv and says so."""
+    import subprocess
+    graft.build_hip()
+    syms = subprocess.run(["nm", "-D", "--undefined-only", graft.LIB], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in syms
+    hooks = subprocess.run(["nm", "-D", "--undefined-only", graft.LIB_HOOKS], capture_output=True, text=True, check=True).stdout
+    assert "getenv" in hooks
+    import ctypes
+    assert ctypes.CDLL(graft.LIB).gc_test_hooks_enabled() == 0
+    assert ctypes.CDLL(graft.LIB_HOOKS).gc_test_hooks_enabled() == 1

@@ -111,10 +111,10 @@ def test_gpu_bytes_equal_emulator_bytes_with_price_parse(O, pkg, emu_lib_path, g
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("codec,level,kind,n", [("flzma2", 5, "silesia-like", 32 << 20), ("zstd", 19, "text-zipf", 32 << 20), ("brotli", 9, "web-text", 32 << 20)])
-def test_gpu_price_parse_beats_greedy_at_size(O, pkg, gpu_ok, monkeypatch, codec, level, kind, n):
+def test_gpu_price_parse_beats_greedy_at_size(O, pkg, gpu_ok, gpu_hooks_kw, monkeypatch, codec, level, kind, n):
     x = O.corpus(kind, n)
-    greedy = _code(O, pkg, codec, level, x, monkeypatch, 0, device=0)
-    priced = _code(O, pkg, codec, level, x, monkeypatch, None, device=0)
+    greedy = _code(O, pkg, codec, level, x, monkeypatch, 0, **gpu_hooks_kw)
+    priced = _code(O, pkg, codec, level, x, monkeypatch, None, **gpu_hooks_kw)
     assert len(priced) < 0.995 * len(greedy), (len(priced), len(greedy))
 
 

@@ -234,16 +234,16 @@ def test_emu_both_execution_paths(pkg, O, emu_lib_path, monkeypatch):
 
 # ------------------------------------------------------------------------------------------------------------------------------- GPU
 @pytest.mark.gpu
-def test_gpu_sequences_kernel_several_blocks_per_wave(pkg, O, gpu_dec, monkeypatch):
-    _several_blocks_per_wave(pkg, O, dict(device=0), monkeypatch, ((5000, 1), (3 * MiB + 17, 3), (4 * MiB, 19)))
+def test_gpu_sequences_kernel_several_blocks_per_wave(pkg, O, gpu_dec, gpu_hooks_kw, monkeypatch):
+    _several_blocks_per_wave(pkg, O, gpu_hooks_kw, monkeypatch, ((5000, 1), (3 * MiB + 17, 3), (4 * MiB, 19)))
     monkeypatch.delenv("GC_ZD_SEQV")
     x = _corpus(O, "silesia-like", 160 * MiB + 5).tobytes()                                      # 1281 blocks: the default takes this kernel
     _check(gpu_dec, O.ref_zstd_compress(x, 1).tobytes(), x)
 
 
 @pytest.mark.gpu
-def test_gpu_both_execution_paths(pkg, O, gpu_dec, monkeypatch):
-    _both_paths(pkg, O, dict(device=0), monkeypatch, (48 * MiB + 321, 32 * MiB), 24)
+def test_gpu_both_execution_paths(pkg, O, gpu_dec, gpu_hooks_kw, monkeypatch):
+    _both_paths(pkg, O, gpu_hooks_kw, monkeypatch, (48 * MiB + 321, 32 * MiB), 24)
 
 
 @pytest.mark.gpu

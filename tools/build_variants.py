@@ -17,6 +17,7 @@ for spec in sys.argv[1:]:
         only[f] = [x for x in fl.split(",") if x]
         if f == "gc_lz_window.hip":                   # the fast geometry is a second compile of the same source
             only.setdefault("gc_lz_window_p8.hip", only[f])
+    only.setdefault("gc_api.hip", []).append("-DGC_TEST_HOOKS")       # variants are test builds: the GC_* hooks work in them
     base = g.compile_hip_objects(os.path.join(g.CSRC, "_obj"))
     objs = g.compile_hip_objects(os.path.join(ROOT, "tools", "_variants", "obj"), only=only) if only else base
     # objects of sources without flags of their own: the normal build's

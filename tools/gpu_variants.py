@@ -20,6 +20,7 @@ ap.add_argument("--phases", action="store_true")
 ap.add_argument("--check", action="store_true", help="decode every variant's stream under the reference decoder (zstd only)")
 ap.add_argument("specs", nargs="+")
 a = ap.parse_args()
+g.build_hip()
 pkg = g.load_package()
 from importlib import util as _u
 spec = _u.spec_from_file_location("c", os.path.join(ROOT, "7-zip-zstd_amd", "corpus", "__init__.py"))
@@ -29,6 +30,7 @@ d_src = torch.from_numpy(x).cuda()
 for sp in a.specs:
     name, _, envs = sp.partition("@")
     lib = None if name == "shipped" else os.path.join(ROOT, "tools", "_variants", "lib_%s.so" % name)
+    if name == "shipped" and envs: lib = pkg.HOOKS_LIB_PATH        # (the shipped library reads no environment: hooks live in the test build)
     saved = {}
     for kv in filter(None, envs.split(",")):
         k, _, v = kv.partition("="); saved[k] = os.environ.get(k); os.environ[k] = v
