@@ -22,7 +22,7 @@ HOOKS_LIB_PATH = os.path.join(HERE, "csrc", "libgpucodec_hooks.so")     # test b
 GC_OK = 0
 _ERR = {-1: "GC_ERR_NO_DEVICE", -2: "GC_ERR_HIP", -3: "GC_ERR_NOMEM", -4: "GC_ERR_DST_SMALL", -5: "GC_ERR_PARAM", -6: "GC_ERR_CORRUPT"}
 
-EXPORTS = ["gc_test_hooks_enabled", "gc_device_count", "gc_ctx_create", "gc_ctx_destroy", "gc_last_error_message", "gc_zstd_compress_bound",
+EXPORTS = ["gc_test_hooks_enabled", "gc_lzfind_get_matches_device", "gc_device_count", "gc_ctx_create", "gc_ctx_destroy", "gc_last_error_message", "gc_zstd_compress_bound",
            "gc_zstd_compress_device", "gc_zstd_finish", "gc_zstd_compress_host", "gc_zstd_last_timing", "gc_ctx_stream",
            "gc_zstd_set_phase_profile", "gc_zstd_phase_profile", "gc_mf_last_timing", "gc_mf_price_timing", "gc_mf_pass_timing",
            "gc_flzma2_compress_bound", "gc_flzma2_dict_prop", "gc_flzma2_compress_device", "gc_flzma2_finish", "gc_flzma2_compress_host",
@@ -48,6 +48,8 @@ def load_library(path=None):
         raise GpuCodecError("HIP extension %s is missing: run __graft_entry__.build()" % path)
     lib = C.CDLL(path)
     lib.gc_test_hooks_enabled.restype = C.c_int
+    lib.gc_lzfind_get_matches_device.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_uint, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p, C.c_uint]
+    lib.gc_lzfind_get_matches_device.restype = C.c_int
     lib.gc_device_count.restype = C.c_int
     lib.gc_ctx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int]
     lib.gc_ctx_create.restype = C.c_int
@@ -191,6 +193,37 @@ def crc32_device(ptr, n, lib_path=None):
     if rc != GC_OK:
         raise GpuCodecError("gc_crc32_device failed: %s" % _ERR.get(rc, rc))
     return v.value
+
+
+def lzfind_get_matches_device(src_ptr, n, counts_ptr, pairs_ptr, stride, history=1 << 20, bt=False, cut=32, nice=64, lib_path=None):
+    """IMatchFinder2::GetMatches of the reference's HC4 (bt=False) / BT4 (bt=True) for every position of n bytes at a device pointer (under the
+    emulator: host pointers): counts[i] uint32 values at pairs[i * stride ...] (length, distance - 1, ...).  (C/LzFind.c:1362, :1219)"""
+    rc = load_library(lib_path).gc_lzfind_get_matches_device(src_ptr, n, 1 if bt else 0, history, cut, nice, counts_ptr, pairs_ptr, stride)
+    if rc != GC_OK:
+        raise GpuCodecError("gc_lzfind_get_matches_device failed: %s" % _ERR.get(rc, rc))
+
+
+def lzfind_matches(data, history=1 << 20, bt=False, cut=32, nice=64, device=None, lib_path=None):
+    """Host convenience over lzfind_get_matches_device: (values per position, all values in order) -- the layout of the oracle's match lists.
+    device=None: the pointers are host pointers (emulator library); else the buffers go through torch on that device."""
+    import numpy as np
+    a = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data, dtype=np.uint8)
+    stride = 2 * (min(cut, nice) + 2)
+    if device is None:
+        counts = np.zeros(max(a.size, 1), dtype=np.uint32); pairs = np.zeros(max(a.size, 1) * stride, dtype=np.uint32)
+        lzfind_get_matches_device(a.ctypes.data, a.size, counts.ctypes.data, pairs.ctypes.data, stride, history, bt, cut, nice, lib_path)
+    else:
+        import torch
+        dev = "cuda:%d" % device
+        d = torch.from_numpy(a).to(dev) if a.size else torch.zeros(1, dtype=torch.uint8, device=dev)
+        dc = torch.zeros(max(a.size, 1), dtype=torch.int32, device=dev); dp = torch.zeros(max(a.size, 1) * stride, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        lzfind_get_matches_device(d.data_ptr(), a.size, dc.data_ptr(), dp.data_ptr(), stride, history, bt, cut, nice, lib_path)
+        counts = dc.cpu().numpy().view(np.uint32); pairs = dp.cpu().numpy().view(np.uint32)
+    counts = counts[:a.size]
+    p2 = pairs.reshape(-1, stride)[:a.size]
+    mask = np.arange(stride, dtype=np.uint32)[None, :] < counts[:, None]
+    return counts, p2[mask]
 
 
 def codec_grain(codec, level, lib_path=None):

@@ -195,6 +195,15 @@ int         gc_bra_x86_convert_device(const void* d_src, void* d_dst, size_t n, 
  * state[256] in/out as the reference keeps it (zeros at the start of a stream: Delta_Init); encoding is out of place only. */
 int         gc_delta_convert_device(const void* d_src, void* d_dst, size_t n, unsigned delta, int encoding, unsigned char state[256]);
 
+/* ---- The mainline LZMA match finders on data in device memory: IMatchFinder2::GetMatches (C/LzFind.h:127-140) for EVERY
+ * position of a buffer in one call -- exactly the values Hc4_MatchFinder_GetMatches (C/LzFind.c:1362) / Bt4_MatchFinder_GetMatches (:1219) write
+ * there when the reference runs over the same buffer (MatchFinder_Create(historySize, 0, niceLen, ...), cutValue = cut), position by position.
+ *   bt           0 = HC4 (hash chains), 1 = BT4 (binary trees)
+ *   d_counts[i]  number of uint32 values of position i (two per match: length, distance - 1), stored at d_pairs[i * stride ...]
+ * GC_ERR_DST_SMALL if a position has more than `stride` values (its list is cut).  n < 2^31 - 16; synchronous on the default stream. */
+int         gc_lzfind_get_matches_device(const void* d_src, size_t n, int bt, uint32_t historySize, uint32_t cut, uint32_t niceLen,
+                                         uint32_t* d_counts, uint32_t* d_pairs, uint32_t stride);
+
 /* ---- ZSTD decoding on the device.  Replaces the ZSTD_decompressStream loop of NCompress::NZSTD::CDecoder::CodeSpec
  * (CPP/7zip/Compress/ZstdDecoder.cpp:66-240; C/zstd/zstd_decompress.c:2086) for callers that hold a whole compressed stream.
  * Entropy decoding (Huffman literals, FSE sequences) runs per BLOCK (<= 128 KiB, one workgroup each, whatever the frame structure);
