@@ -1035,7 +1035,7 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
         for (; j < nFrames; j++) {
             const gc_zstd_frame& f = frames[j];
             if (j > i && (f.flags & GC_ZD_F_SIZE_KNOWN) && off - dstOff + f.content_size > batchCap) break;       // the workspaces grow with the batch (≈ 7 bytes per content byte)
-            if (f.src_off > n || f.src_size > n - f.src_off || f.header_size + 3ull > f.src_size || !f.n_blocks || (uint64_t)f.n_blocks * 3u > f.src_size || nBlocks + f.n_blocks > 0x7FFFFFFFull) { rc = GC_ERR_PARAM; break; }
+            if (f.src_off > n || f.src_size > n - f.src_off || f.header_size < 6u || f.header_size + 3ull + ((f.flags & GC_ZD_F_CHECKSUM) ? 4u : 0u) > f.src_size || !f.n_blocks || (uint64_t)f.n_blocks * 3u > f.src_size || nBlocks + f.n_blocks > 0x7FFFFFFFull) { rc = GC_ERR_PARAM; break; }
             GcZdFrame& g = h[j];
             g.srcOff = f.src_off; g.srcSize = f.src_size; g.dstOff = off; g.contentSize = f.content_size; g.flags = f.flags; g.hdrSize = f.header_size;
             g.nBlocks = f.n_blocks; g.blockBase = (uint32_t)nBlocks; g.litBase = 0; g.seqBase = 0;

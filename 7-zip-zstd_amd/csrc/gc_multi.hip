@@ -149,8 +149,13 @@ extern "C" int gc_multi_compress_host(gc_multi* m, int codec, const void* src, s
     Job j; j.m = m; j.codec = codec; j.level = level; j.flags = flags; j.src = (const uint8_t*)src; j.n = n; j.dst = (uint8_t*)dst; j.dstCap = dstCap;
     j.piece = piece; j.nPieces = (n + piece - 1u) / piece;
     const size_t nWorkers = j.nPieces < m->workerDevice.size() ? j.nPieces : m->workerDevice.size();
+    // Pieces are dealt from an atomic counter, so the job completes with however many helpers could be started: a std::thread that cannot be
+    // created (std::system_error) or a vector that cannot grow (std::bad_alloc) only costs parallelism -- no exception leaves this extern "C" call
     std::vector<std::thread> th;
-    for (size_t w = 1; w < nWorkers; w++) th.emplace_back(worker, std::ref(j), w);
+    try {
+        th.reserve(nWorkers);
+        for (size_t w = 1; w < nWorkers; w++) th.emplace_back(worker, std::ref(j), w);
+    } catch (...) {}
     worker(j, 0);                         // the calling thread is worker 0
     for (std::thread& t : th) t.join();
     if (j.rc != GC_OK) return j.rc;

@@ -300,7 +300,7 @@ __device__ uint32_t zd_find_table_source(const GcZdBlock* blocks, uint32_t first
 __device__ uint32_t zd_seq_table(uint32_t mode, const uint8_t* win, uint32_t winLen, uint32_t p, uint32_t* tab, uint32_t* logOut, int which,
                                  const ZdConst* k, int16_t* sNorm, uint16_t* sNext)
 {
-    const uint32_t maxSym = which == ZT_LL ? 35u : (which == ZT_OF ? 30u : 52u), maxLog = which == ZT_OF ? 8u : 9u;
+    const uint32_t maxSym = which == ZT_LL ? 35u : (which == ZT_OF ? 31u : 52u), maxLog = which == ZT_OF ? 8u : 9u;
     if (mode == 0u) {
         const int16_t* dn = which == ZT_LL ? k->llNorm : (which == ZT_OF ? k->ofNorm : k->mlNorm);
         const uint32_t dm = which == ZT_LL ? 35u : (which == ZT_OF ? 28u : 52u), dl = which == ZT_OF ? 5u : 6u;
@@ -328,7 +328,7 @@ __device__ int zd_seq_table_skip(uint32_t mode, const uint8_t* win, uint32_t win
 {
     if (mode == 0u || mode == 3u) return 0;
     if (mode == 1u) return 1;
-    const uint32_t maxSym = which == ZT_LL ? 35u : (which == ZT_OF ? 30u : 52u), maxLog = which == ZT_OF ? 8u : 9u;
+    const uint32_t maxSym = which == ZT_LL ? 35u : (which == ZT_OF ? 31u : 52u), maxLog = which == ZT_OF ? 8u : 9u;
     uint32_t ms = 0, log = 0;
     if (p >= winLen) return -1;
     const uint32_t h = zd_read_ncount(win + p, winLen - p, sNorm, maxSym, maxLog, &ms, &log);
@@ -540,7 +540,7 @@ gc_zstd_dec_lit_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
         const uint32_t G = nStreams == 4u ? 16u : 64u, q = nStreams == 4u ? lane >> 4 : 0u, li = lane & (G - 1u);
         uint32_t sOff = base, sLen = avail, cnt = e.regen, oOff = 0;
         if (nStreams == 4u) {
-            if (avail < 10u || e.regen < 4u) ok = false;
+            if (avail < 10u || e.regen < 6u) ok = false;       // four streams regenerate at least 6 bytes (huf_decompress.c: HUF_decompress4X1_usingDTable_internal_body, dstSize < 6)
             else {
                 const uint32_t s1 = (uint32_t)bsrc[base] | ((uint32_t)bsrc[base + 1] << 8), s2 = (uint32_t)bsrc[base + 2] | ((uint32_t)bsrc[base + 3] << 8),
                                s3 = (uint32_t)bsrc[base + 4] | ((uint32_t)bsrc[base + 5] << 8);

@@ -16,6 +16,7 @@
 // throws; allocations are checked.
 #include "gc_7z_abi.h"
 #include "gpucodec.h"
+#include <mutex>
 #include <new>
 #include <thread>
 #include <stdlib.h>
@@ -78,12 +79,77 @@ HRESULT hresult_of(int gcErr)
     }
 }
 
+// Process-wide state (round 3).  A 7z run creates one coder object per folder / archive member, and what is slow about the first one is not its
+// compression: opening the HIP runtime and the devices (about 0.2 s) and page-locking the staging buffers.  So the host scheduler, the decoder's
+// context and the pinned buffers belong to the PROCESS: created on first use, lent to the coder objects, never torn down (the HIP runtime's own
+// exit handlers run in an unspecified order against ours).  `gpu` is held for one batch on the devices at a time -- never across the host's
+// Read / Write calls, which may wait for another coder of the same folder (CoderMixerMT runs them as threads).
+struct BufSet { uint8_t* in[2] = { nullptr, nullptr }; size_t inCap[2] = { 0, 0 }; uint8_t* out = nullptr; size_t outCap = 0; };
+struct Shared {
+    std::mutex mu;                                    // guards multi / dec creation and the pool
+    std::mutex gpu;                                   // one batch on the devices at a time
+    gc_multi* multi = nullptr;                        // host scheduler over every visible GPU, two contexts each (csrc/gc_multi.hip)
+    gc_ctx* dec = nullptr;                            // the ZSTD decoder's context (device 0)
+    BufSet pool[4]; int nPool = 0;                    // buffer sets handed back by finished Code() calls
+};
+Shared* shared()
+{
+    static Shared* s = new (std::nothrow) Shared();   // leaked on purpose, see above
+    return s;
+}
+gc_multi* shared_multi(int* rcOut)
+{
+    Shared* s = shared();
+    if (!s) { *rcOut = GC_ERR_NOMEM; return nullptr; }
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (!s->multi) { const int rc = gc_multi_create(&s->multi, nullptr, 0, 2); if (rc != GC_OK) { s->multi = nullptr; *rcOut = rc; return nullptr; } }
+    *rcOut = GC_OK;
+    return s->multi;
+}
+gc_ctx* shared_dec_ctx()
+{
+    Shared* s = shared();
+    if (!s) return nullptr;
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (!s->dec && gc_ctx_create(&s->dec, 0) != GC_OK) s->dec = nullptr;
+    return s->dec;
+}
+void buf_acquire(BufSet* b)
+{
+    Shared* s = shared();
+    *b = BufSet();
+    if (!s) return;
+    std::lock_guard<std::mutex> lk(s->mu);
+    if (s->nPool) *b = s->pool[--s->nPool];
+}
+void buf_release(BufSet* b)
+{
+    Shared* s = shared();
+    bool kept = false;
+    if (s) { std::lock_guard<std::mutex> lk(s->mu); if (s->nPool < 4) { s->pool[s->nPool++] = *b; kept = true; } }
+    if (!kept) { gc_host_free(b->in[0]); gc_host_free(b->in[1]); gc_host_free(b->out); }
+    *b = BufSet();
+}
+// pinned buffer of at least `need` bytes; `keep` bytes of the old one survive a growth
+bool buf_grow(uint8_t** buf, size_t* cap, size_t need, size_t keep)
+{
+    if (need <= *cap) return true;
+    uint8_t* nb = (uint8_t*)gc_host_alloc(need);
+    if (!nb) return false;
+    if (keep) memcpy(nb, *buf, keep);
+    gc_host_free(*buf); *buf = nb; *cap = need;
+    return true;
+}
+struct BufLease {                                     // a Code() call's buffers go back to the pool however the call ends
+    BufSet b;
+    BufLease() { buf_acquire(&b); }
+    ~BufLease() { buf_release(&b); }
+};
+
 class CGpuEncoder final : public ICompressCoder, public ICompressSetCoderMt, public ICompressSetCoderProperties,
                               public ICompressSetCoderPropertiesOpt, public ICompressWriteCoderProperties {
     ULONG refs_ = 1;
     const int kind_;
-    gc_multi* multi_ = nullptr;                       // host scheduler over every visible GPU, two contexts each (csrc/gc_multi.hip)
-    uint8_t* inBuf_ = nullptr; uint8_t* inBuf2_ = nullptr; uint8_t* outBuf_ = nullptr; size_t inCap_ = 0, outCap_ = 0;     // pinned (gc_host_alloc)
     int level_;                                       // ZSTD_CLEVEL_DEFAULT 3 / FL2 default 5 (Lzma2Encoder.cpp:178-239 maps -mx to it)
     uint8_t props_[5] = { 1, 5, 3, 0, 0 };            // ZSTD: CProps{major, minor, level, reserved[2]}  ZstdEncoder.h:17-32
     uint64_t expected_ = 0;
@@ -93,7 +159,6 @@ class CGpuEncoder final : public ICompressCoder, public ICompressSetCoderMt, pub
 public:
     explicit CGpuEncoder(int kind) : kind_(kind), level_(default_level(kind)) {}
     static int default_level(int kind) { return kind == KIND_ZSTD ? 3 : (kind == KIND_FLZMA2 ? 5 : 3); }   // BrotliEncoder.h: _props._level = 3
-    ~CGpuEncoder() { if (multi_) gc_multi_destroy(multi_); gc_host_free(inBuf_); gc_host_free(inBuf2_); gc_host_free(outBuf_); }
 
     HRESULT QueryInterface(const GUID& iid, void** out) override
     {
@@ -154,20 +219,24 @@ public:
     HRESULT Code(ISequentialInStream* in, ISequentialOutStream* out, const uint64_t*, const uint64_t*, ICompressProgressInfo* progress) override
     {
         if (!in || !out) return E_INVALIDARG;
-        if (!multi_) { int rc = gc_multi_create(&multi_, nullptr, 0, 2); if (rc != GC_OK) { multi_ = nullptr; return hresult_of(rc); } }
+        int mrc = GC_OK;
+        gc_multi* const multi = shared_multi(&mrc);
+        if (!multi) return hresult_of(mrc);
+        // a batch = whole pieces, one per worker, but at most 1 GiB (and at least one piece): three pinned buffers of that size are all the
+        // host memory a coder takes, whatever the number of GPUs
         const size_t piece = gc_multi_piece_bytes(codec(), level_);
-        size_t batch = piece * (size_t)gc_multi_workers(multi_);
+        size_t perBatch = (size_t)gc_multi_workers(multi), most = ((size_t)1 << 30) / piece;
+        if (perBatch > most) perBatch = most;
+        if (perBatch < 1) perBatch = 1;
+        size_t batch = piece * perBatch;
         if (expected_ && expected_ < batch) batch = (size_t)((expected_ + 131071u) & ~(uint64_t)131071u);
         // two input buffers: while a helper thread compresses batch k on the GPUs and writes it out, this thread reads batch k + 1 (the host's
         // reader also computes its CRC there), so that the slower of the two sides sets the pace, not their sum
-        if (batch > inCap_) {
-            gc_host_free(inBuf_); gc_host_free(inBuf2_);
-            inBuf_ = (uint8_t*)gc_host_alloc(batch); inBuf2_ = (uint8_t*)gc_host_alloc(batch);
-            inCap_ = inBuf_ && inBuf2_ ? batch : 0;
-            if (!inCap_) { gc_host_free(inBuf_); gc_host_free(inBuf2_); inBuf_ = inBuf2_ = nullptr; return E_OUTOFMEMORY; }
-        }
-        const size_t bound = gc_codec_compress_bound(codec(), inCap_) + 1u;
-        if (bound > outCap_) { gc_host_free(outBuf_); outBuf_ = (uint8_t*)gc_host_alloc(bound); outCap_ = outBuf_ ? bound : 0; if (!outBuf_) return E_OUTOFMEMORY; }
+        BufLease lease; BufSet& B = lease.b;
+        if (!buf_grow(&B.in[0], &B.inCap[0], batch, 0) || !buf_grow(&B.in[1], &B.inCap[1], batch, 0)) return E_OUTOFMEMORY;
+        const size_t inCap = batch;
+        if (!buf_grow(&B.out, &B.outCap, gc_codec_compress_bound(codec(), inCap) + 1u, 0)) return E_OUTOFMEMORY;
+        uint8_t* const outBuf = B.out; const size_t outCap = B.outCap;
         uint64_t totalIn = 0, totalOut = 0;
         struct Job { std::thread th; HRESULT hr = S_OK; size_t got = 0, produced = 0; bool active = false; } job;
         auto finish = [&]() -> HRESULT {                      // wait for the batch in flight, account for it
@@ -179,8 +248,8 @@ public:
         };
         HRESULT res = S_OK;
         for (unsigned batchIdx = 0;; batchIdx++) {
-            uint8_t* const buf = (batchIdx & 1u) ? inBuf2_ : inBuf_;
-            size_t got = inCap_;
+            uint8_t* const buf = B.in[batchIdx & 1u];
+            size_t got = inCap;
             HRESULT r = read_full(in, buf, &got);
             HRESULT f = finish();
             if (r != S_OK) { res = r; break; }
@@ -191,11 +260,14 @@ public:
                               : plainBrotli_ ? (GC_BROTLI_PLAIN | GC_BROTLI_NOT_LAST | (batchIdx != 0 ? GC_BROTLI_NOT_FIRST : 0u)) : 0u;
             if (plainBrotli_ && got == 0) break;
             job.got = got; job.produced = 0; job.hr = S_OK; job.active = true;
-            job.th = std::thread([this, buf, got, fl, out, &job]() {
-                const int rc = gc_multi_compress_host(multi_, codec(), buf, got, outBuf_, outCap_, level_, fl, 0, &job.produced);
-                job.hr = rc != GC_OK ? hresult_of(rc) : write_all(out, outBuf_, job.produced);
-            });
-            if (got < inCap_) break;      // short read = end of stream
+            auto work = [this, multi, buf, got, fl, out, outBuf, outCap, &job]() {
+                int rc;
+                { std::lock_guard<std::mutex> g(shared()->gpu); rc = gc_multi_compress_host(multi, codec(), buf, got, outBuf, outCap, level_, fl, 0, &job.produced); }
+                job.hr = rc != GC_OK ? hresult_of(rc) : write_all(out, outBuf, job.produced);
+            };
+            try { job.th = std::thread(work); }
+            catch (...) { job.active = false; work(); if (job.hr != S_OK) { res = job.hr; break; } totalIn += got; totalOut += job.produced; }   // no helper thread to be had: this one does the batch
+            if (got < inCap) break;       // short read = end of stream
         }
         { const HRESULT f = finish(); if (res == S_OK) res = f; }
         if (res != S_OK) return res;
@@ -223,22 +295,10 @@ public:
 // unsupported frames (dictionary) E_NOTIMPL.
 class CGpuZstdDecoder final : public ICompressCoder, public ICompressSetDecoderProperties2, public ICompressSetCoderMt {
     ULONG refs_ = 1;
-    gc_ctx* ctx_ = nullptr;
-    uint8_t* inBuf_ = nullptr; uint8_t* outBuf_ = nullptr; size_t inCap_ = 0, outCap_ = 0;     // pinned (gc_host_alloc)
     gc_zstd_frame* frames_ = nullptr; size_t framesCap_ = 0;
 
-    bool grow(uint8_t** buf, size_t* cap, size_t need, size_t keep)
-    {
-        if (need <= *cap) return true;
-        uint8_t* nb = (uint8_t*)gc_host_alloc(need);
-        if (!nb) return false;
-        if (keep) memcpy(nb, *buf, keep);
-        gc_host_free(*buf); *buf = nb; *cap = need;
-        return true;
-    }
-
 public:
-    ~CGpuZstdDecoder() { if (ctx_) gc_ctx_destroy(ctx_); gc_host_free(inBuf_); gc_host_free(outBuf_); free(frames_); }
+    ~CGpuZstdDecoder() { free(frames_); }
 
     HRESULT QueryInterface(const GUID& iid, void** out) override
     {
@@ -261,9 +321,14 @@ public:
     HRESULT Code(ISequentialInStream* in, ISequentialOutStream* out, const uint64_t*, const uint64_t* outSize, ICompressProgressInfo* progress) override
     {
         if (!in || !out) return E_INVALIDARG;
-        if (!ctx_ && gc_ctx_create(&ctx_, 0) != GC_OK) { ctx_ = nullptr; return E_FAIL; }       // no gfx950 device: there is no CPU decoder behind this object
+        gc_ctx* const ctx = shared_dec_ctx();
+        if (!ctx) return E_FAIL;                                                               // no gfx950 device: there is no CPU decoder behind this object
+        BufLease lease;
+        uint8_t*& inBuf_ = lease.b.in[0]; size_t& inCap_ = lease.b.inCap[0]; uint8_t*& outBuf_ = lease.b.out; size_t& outCap_ = lease.b.outCap;
         const size_t kPiece = (size_t)64 << 20;
-        if (!grow(&inBuf_, &inCap_, kPiece, 0)) return E_OUTOFMEMORY;
+        const size_t kMaxFrameIn = (size_t)1 << 30;          // largest compressed frame buffered whole (pinned host memory)
+        const size_t kMaxContent = (size_t)4 << 30;          // largest content of one piece (pinned host + HBM, + 4 B per byte on the wide path)
+        if (!buf_grow(&inBuf_, &inCap_, kPiece, 0)) return E_OUTOFMEMORY;
         uint64_t totalIn = 0, totalOut = 0;
         size_t have = 0;
         bool eof = false;
@@ -282,7 +347,11 @@ public:
             if (rc != GC_OK) return rc == GC_ERR_PARAM ? E_NOTIMPL : E_FAIL;
             if (consumed == 0) {                                   // not even one whole frame in the buffer
                 if (eof) return E_FAIL;                            // the stream ends inside a frame
-                if (!grow(&inBuf_, &inCap_, inCap_ * 2u, have)) return E_OUTOFMEMORY;
+                // One frame is the unit this decoder works on, and it holds the frame (pinned) and its content (pinned + HBM): the buffer grows
+                // up to kMaxFrameIn and no further -- beyond it the object answers E_NOTIMPL ("unsupported") so that a host with another ZSTD
+                // decoder takes the stream there (the reference's decoder needs only a window, ZstdDecoder.cpp:66-240); INTEGRATION.md states the bound.
+                if (inCap_ >= kMaxFrameIn) return E_NOTIMPL;
+                if (!buf_grow(&inBuf_, &inCap_, inCap_ * 2u, have)) return E_OUTOFMEMORY;
                 continue;
             }
             if (nFrames > framesCap_) {
@@ -294,15 +363,19 @@ public:
             if (nFrames) {
                 rc = gc_zstd_scan_prefix(inBuf_, have, frames_, framesCap_, &nFrames, &content, &consumed);
                 if (rc != GC_OK) return E_FAIL;
-                // capacity: the content sizes the frames state; else what the host expects (outSize); else a guess that doubles until it fits
-                size_t cap = content != ~0ull ? (size_t)content : (outSize && *outSize > totalOut ? (size_t)(*outSize - totalOut) : consumed * 8u + ((size_t)1 << 20));
-                size_t produced = 0;
-                for (;;) {
-                    if (!grow(&outBuf_, &outCap_, cap ? cap : 1u, 0)) return E_OUTOFMEMORY;
-                    rc = gc_zstd_decompress_host(ctx_, inBuf_, consumed, outBuf_, cap, &produced);
-                    if (rc == GC_ERR_DST_SMALL && content == ~0ull && cap < ((size_t)1 << 40)) { cap *= 2u; continue; }
-                    break;
+                // capacity: the content sizes the frames state; a frame that does not state one regenerates at most 128 KiB per block
+                // (zstd_decompress_block.c: blockSizeMax), and the scan has counted its blocks -- no guessing, no second decode
+                // (a piece whose frames regenerate more than kMaxContent is decoded a run of frames at a time; one frame beyond it is refused)
+                size_t cap = 0;
+                for (size_t i = 0; i < nFrames; i++) {
+                    const uint64_t fc = (frames_[i].flags & 2u) ? frames_[i].content_size : (uint64_t)frames_[i].n_blocks * (128u << 10);
+                    if (fc > kMaxContent) return E_NOTIMPL;
+                    if (cap + fc > kMaxContent) { consumed = (size_t)frames_[i].src_off; break; }
+                    cap += (size_t)fc;
                 }
+                size_t produced = 0;
+                if (!buf_grow(&outBuf_, &outCap_, cap ? cap : 1u, 0)) return E_OUTOFMEMORY;
+                { std::lock_guard<std::mutex> g(shared()->gpu); rc = gc_zstd_decompress_host(ctx, inBuf_, consumed, outBuf_, cap, &produced); }
                 if (rc != GC_OK) return rc == GC_ERR_PARAM ? E_NOTIMPL : hresult_of(rc);
                 HRESULT r = write_all(out, outBuf_, produced);
                 if (r != S_OK) return r;

@@ -83,6 +83,8 @@ def ref(name):
                 lib.ref_bra_x86_convert.restype = _SZ
                 lib.ref_delta_convert.argtypes = [_VP, _SZ, C.c_uint, C.c_int, _VP]
                 lib.ref_delta_convert.restype = None
+                if hasattr(lib, "ref_crc32"):
+                    lib.ref_crc32.argtypes = [_VP, _SZ]; lib.ref_crc32.restype = C.c_uint
             elif name == "lzfind":
                 lib.ref_lzfind_matches.argtypes = [_VP, _SZ, C.c_uint, C.c_int, C.c_int, C.c_uint, C.c_uint, _VP, _VP, _SZ, C.POINTER(_SZ)]
                 lib.ref_lzfind_matches.restype = C.c_int
@@ -115,7 +117,10 @@ def corpus(kind, n, seed=20260921):
     if name not in sys.modules:
         spec = importlib.util.spec_from_file_location(name, os.path.join(os.path.dirname(HERE), "7-zip-zstd_amd", "corpus", "__init__.py"))
         mod = importlib.util.module_from_spec(spec); sys.modules[name] = mod; spec.loader.exec_module(mod)
-    return sys.modules[name].corpus(kind, n, seed)
+    mod = sys.modules[name]
+    if kind in mod.REAL_KINDS:                       # real bytes from the image (round 3): real-src / real-bin / real-py
+        return mod.real_corpus(kind, n)
+    return mod.corpus(kind, n, seed)
 
 
 # ----------------------------------------------------------------------------- zstd
@@ -163,6 +168,12 @@ def ref_bra_convert(kind, data, pc=0, encoding=True):
     view = buf[off:off + a.size]; view[:] = a
     done = ref("bra").ref_bra_convert(kind, view.ctypes.data, a.size, pc & 0xFFFFFFFF, 1 if encoding else 0)
     return view.copy(), int(done)
+
+
+def ref_crc32(data):
+    """The reference's CRC-32 (C/7zCrc.c CrcCalc) of data"""
+    a = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data)
+    return int(ref("bra").ref_crc32(a.ctypes.data if a.size else None, a.size)) & 0xFFFFFFFF
 
 
 def ref_delta_convert(data, delta, encoding=True, state=None):

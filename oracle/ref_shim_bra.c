@@ -4,6 +4,7 @@
 #include <stddef.h>
 #include "Bra.h"
 #include "Delta.h"
+#include "7zCrc.h"
 
 /* kind: 0 ARM64, 1 ARM, 2 ARMT, 3 PPC, 4 SPARC, 5 IA64, 6 RISCV; returns the processed byte count */
 size_t ref_bra_convert(int kind, unsigned char* data, size_t n, unsigned pc, int encoding)
@@ -35,4 +36,12 @@ size_t ref_bra_x86_convert(unsigned char* data, size_t n, unsigned pc, int encod
 void ref_delta_convert(unsigned char* data, size_t n, unsigned delta, int encoding, unsigned char* state)
 {
     if (encoding) Delta_Encode(state, delta, data, n); else Delta_Decode(state, delta, data, n);
+}
+
+/* CRC-32 as the 7z container computes it (C/7zCrc.c: CrcCalc after CrcGenerateTable) */
+unsigned ref_crc32(const unsigned char* data, size_t n)
+{
+    static int ready = 0;
+    if (!ready) { CrcGenerateTable(); ready = 1; }
+    return CrcCalc(data, n);
 }

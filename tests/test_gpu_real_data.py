@@ -1,0 +1,68 @@
+"""GPU size bars on REAL data (-m gpu; round 3).  The stand-in corpora are generators; these are real bytes that the image itself holds, the same
+on the build container and on the GPU box (7-zip-zstd_amd/corpus: real-src = C / C++ headers + Python sources, real-bin = the shared objects of
+/opt/rocm/lib incl. their gfx code objects, real-py = the standard library's .py + .pyc): the three BASELINE codecs at their BASELINE levels against
+the reference ENCODER (oracle/_ref) on the same bytes, band 2 %, each stream decoded by the reference decoder."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+MiB = 1024 * 1024
+THR = min(os.cpu_count() or 1, 64)
+CASES = [("real-src", 64 * MiB), ("real-bin", 211_900_000), ("real-py", 64 * MiB)]       # (real-py: all there is, 18.9 MB)
+# bars that are not met, with the measured figure (filled from tools/gpu_ratio.py on the MI355X; strict=False)
+NOT_YET = {}
+
+
+@pytest.fixture(scope="module")
+def gpu(pkg, graft):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    graft.build_hip()
+    return pkg
+
+
+def _corpus(O, kind, n):
+    x = O.corpus(kind, n)
+    if x.size < (1 << 20):
+        pytest.skip("the image holds no %s data" % kind)
+    return x
+
+
+def _bar(codec, kind, ours, ref):
+    if ours > 1.02 * ref and (codec, kind) in NOT_YET:
+        pytest.xfail("known gap: " + NOT_YET[(codec, kind)])
+    assert ours <= 1.02 * ref, (codec, kind, ours, ref, round(ours / ref, 4))
+
+
+@pytest.mark.parametrize("kind,n", CASES)
+def test_zstd_level3_real_data(O, gpu, kind, n):
+    if O.ref("zstd") is None:
+        pytest.skip("oracle/_ref did not travel")
+    x = _corpus(O, kind, min(n, 128 * MiB))
+    e = gpu.ZstdEncoder(level=3); c = e.code(x); e.close()
+    assert np.array_equal(O.ref_zstd_decompress(c, x.size), x)
+    _bar("zstd", kind, len(c), len(O.ref_zstd_compress(x, 3)))
+
+
+@pytest.mark.parametrize("kind,n", CASES)
+def test_flzma2_level5_real_data(O, gpu, kind, n):
+    if O.ref("flzma2") is None:
+        pytest.skip("oracle/_ref did not travel")
+    x = _corpus(O, kind, n)
+    e = gpu.Flzma2Encoder(level=5); c = e.code(x); prop = e.coder_props()[0]; e.close()
+    assert np.array_equal(O.ref_lzma2_decode(c, x.size, prop), x)
+    ref, _ = O.ref_fl2_compress(x, 5, threads=THR)
+    _bar("flzma2", kind, len(c), len(ref))
+
+
+@pytest.mark.parametrize("kind,n", CASES)
+def test_brotli_q6_real_data(O, gpu, kind, n):
+    if O.ref("brotli") is None:
+        pytest.skip("oracle/_ref did not travel")
+    x = _corpus(O, kind, min(n, 64 * MiB))
+    e = gpu.BrotliEncoder(level=6); c = e.code(x); e.close()
+    assert np.array_equal(O.ref_brotlimt_decompress(c, x.size, THR), x)
+    _bar("brotli", kind, len(c), len(O.ref_brotlimt_compress(x, 6, THR)))
