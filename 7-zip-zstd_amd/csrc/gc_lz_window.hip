@@ -696,6 +696,53 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
         }
     }
     __syncthreads();
+    // Continuation of capped matches (round 3).  A record holds at most GC_MATCH_CAP bytes; the parse goes on at the position behind it, whose own
+    // candidate -- the most recent earlier position with the same 8 (5, 16, 12) bytes -- is, in data with many copies of the same text (headers,
+    // generated code, archives of similar files), usually ANOTHER copy than the one the match came from: a match of 500 bytes was coded as eight
+    // sequences with eight offsets (on 8 MiB of C++ headers: 32 087 sequences of exactly 64 bytes against the reference's 414, the stream a third
+    // larger).  So the record GC_MATCH_CAP behind a capped one prefers that one's distance when the match goes on there at least as far (within two
+    // bytes): the pieces then share their offset and leave as one sequence / one LZMA match (K3a, L1 and W7 merge equal offsets).  A lane walks one
+    // residue class mod 64 of its wave's share of the tile upwards, so that the record it looks back at is final; the chain is cut where the shares
+    // meet (every 1 KiB), which keeps the result independent of the order in which the waves run.
+    if (MODE == MF_BASE || MODE == MF_FAR || MODE == MF_SHORT) {      // (every pass that merges candidates by gain may have replaced a continued record by a nearer one)
+        constexpr uint32_t NSUB = MFV_T / 64u;
+        const uint32_t subLen = ((T.len + NSUB * 64u - 1u) / (NSUB * 64u)) * 64u;
+        const uint32_t sBeg = wave * subLen, sEnd = sBeg + subLen < T.len ? sBeg + subLen : T.len;
+        // one position: true if its record was replaced
+        auto cont = [&](uint32_t q) -> bool {
+            const uint32_t prev = sRec[q - GC_MATCH_CAP];
+            if ((prev & 0xFFu) != GC_MATCH_CAP) return false;
+            const uint32_t d = prev >> 8, cur = sRec[q];
+            if ((cur >> 8) == d) return false;
+            if (T.tileStart + q + GC_MATCH_CAP + 16u > T.frameEnd) return false;     // (the compare windows must lie inside the frame)
+            const uint32_t p = pTile + q;
+            if (p + 8u > nBlk) return false;
+            uint32_t maxLen = (nBlk - p) < GC_MATCH_CAP ? (nBlk - p) : GC_MATCH_CAP;
+            if (TILE_LIMIT && maxLen > T.len - q) maxLen = T.len - q;
+            const uint64_t cpos = (uint64_t)(wTile + q) - d;       // frame-relative position of the continued source
+            uint32_t len = 0;
+            while (len < maxLen) {
+                const uint32_t more = lz_cmp16(mf_lds_ld16(sW, q + MF_STAGE_PAD + len), lz_ld16(wsrc, cpos + len));
+                len += more;
+                if (more < 16u) break;
+            }
+            if (len > maxLen) len = maxLen;
+            if (len < MINLEN || len + 2u < (cur & 0xFFu)) return false;
+            sRec[q] = (d << 8) | len;
+            return true;
+        };
+        // phase A: every wave inside its share, from the share's second row on (the first row looks back into the share in front)
+        for (uint32_t q = sBeg + GC_MATCH_CAP + lane; q < sEnd; q += 64u) cont(q);
+        __syncthreads();
+        // phase B: the first rows, share by share in order (what a share looks back at is final), followed down the share while records change
+        for (uint32_t sIdx = 1; sIdx < NSUB; sIdx++) {
+            if (wave == sIdx) {
+                uint32_t q = sBeg + lane;
+                while (q < sEnd && cont(q)) q += 64u;
+            }
+            __syncthreads();
+        }
+    }
 }
 
 // MF_FAR / MF_SHORT: the candidates come from a later pass; recIn holds the records so far and a position's record is replaced

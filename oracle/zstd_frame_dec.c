@@ -49,6 +49,11 @@ typedef struct {
 } gco_diag_t;
 
 static gco_diag_t g_diag;
+/* stream statistics of the last gco_zstd_decompress call (analysis aid: tools/zstd_stream_stats.py): [0] blocks with sequences, [1] sequences,
+ * [2] literal bytes, [3] bytes of literals sections, [4] bytes of sequences sections, [5] match bytes, [6] repeat-offset sequences,
+ * [7] sum of offset codes (~ offset bits), [8] raw / RLE blocks, [9] matches shorter than 8 bytes */
+static unsigned long long g_stats[16];
+void gco_zstd_stats(unsigned long long* out) { int i; for (i = 0; i < 16; i++) out[i] = g_stats[i]; }
 static int g_trace;   /* GCO_TRACE=1: print every decoded sequence (encoder bring-up aid) */
 #define FAIL(c) do { g_diag.code = (c); g_diag.line = __LINE__; return (c); } while (0)
 
@@ -354,6 +359,7 @@ static int decode_block(frame_ctx* fc, const uint8_t* src, size_t n, uint8_t* ds
             p += comp; litSize = regen;
         }
     }
+    g_stats[2] += litSize; g_stats[3] += (unsigned long long)(p - src); g_stats[4] += (unsigned long long)(end - p);
     /* ---- sequences section (zstd_decompress_block.c:697) */
     {
         size_t nbSeq, litPos = 0, out = dstPos;
@@ -376,6 +382,7 @@ static int decode_block(frame_ctx* fc, const uint8_t* src, size_t n, uint8_t* ds
         if (seq_table(&fc->of, &fc->of_valid, (modes >> 4) & 3, &p, end, OF_defaultNorm, 29, 5, 8, 31)) FAIL(GCO_ERR_CORRUPT);
         if (seq_table(&fc->ml, &fc->ml_valid, (modes >> 2) & 3, &p, end, ML_defaultNorm, 53, 6, 9, 52)) FAIL(GCO_ERR_CORRUPT);
         if (bb_init(&b, p, (size_t)(end - p))) FAIL(GCO_ERR_CORRUPT);
+        g_stats[0]++;
         sLL = (uint32_t)bb_read(&b, fc->ll.al); sOF = (uint32_t)bb_read(&b, fc->of.al); sML = (uint32_t)bb_read(&b, fc->ml.al);
         if (b.off < 0) FAIL(GCO_ERR_CORRUPT);
         for (i = 0; i < nbSeq; i++) {
@@ -387,6 +394,7 @@ static int decode_block(frame_ctx* fc, const uint8_t* src, size_t n, uint8_t* ds
             ll = LL_base[llc] + (uint32_t)bb_read(&b, LL_bits[llc]);
             /* repcode rules: zstd_decompress_block.c:1250-1290 */
             if (g_trace) fprintf(stderr, "D %zu ofv=%u ml=%u ll=%u\n", i, ofv, ml, ll);
+            g_stats[1]++; g_stats[5] += ml; g_stats[6] += ofv <= 3; g_stats[7] += ofc; g_stats[9] += ml < 8;
             if (ofv > 3) { offset = ofv - 3; fc->rep[2] = fc->rep[1]; fc->rep[1] = fc->rep[0]; fc->rep[0] = offset; }
             else {
                 uint32_t idx = ofv + (ll == 0 ? 1 : 0);
@@ -424,7 +432,7 @@ static int decode_block(frame_ctx* fc, const uint8_t* src, size_t n, uint8_t* ds
 int gco_zstd_decompress(uint8_t* dst, size_t cap, const uint8_t* src, size_t n, size_t* outLen)
 {
     size_t ip = 0, op = 0;
-    memset(&g_diag, 0, sizeof(g_diag));
+    memset(&g_diag, 0, sizeof(g_diag)); memset(g_stats, 0, sizeof(g_stats));
     g_trace = getenv("GCO_TRACE") != NULL;
     while (ip < n) {
         uint32_t magic; frame_ctx* fc; size_t frameStart = op;
