@@ -79,7 +79,8 @@ extern "C" __global__ void gc_mf_dp3_kernel(const uint8_t*, uint64_t, uint32_t, 
 
 extern "C" __global__ void gc_lzma2_prep_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t, uint64_t*, uint32_t*);
 extern "C" __global__ void gc_lzma2_model_kernel(const uint8_t*, uint64_t, const uint64_t*, const uint32_t*, uint32_t, uint32_t, uint16_t*, GcLzmaChunkInfo*, const uint32_t*, unsigned long long*, uint32_t, uint32_t);
-extern "C" __global__ void gc_lzma2_rc_kernel(const uint16_t*, uint32_t, uint32_t, uint8_t*, GcLzmaChunkInfo*);
+extern "C" __global__ void gc_lzma2_rc_kernel(uint16_t*, uint32_t, uint32_t, uint8_t*, GcLzmaChunkInfo*);
+extern "C" __global__ void gc_lzma2_rc_fin_kernel(const uint16_t*, uint32_t, uint32_t, uint8_t*, GcLzmaChunkInfo*);
 extern "C" __global__ void gc_lzma2_plan_kernel(const GcLzmaChunkInfo*, uint32_t, uint32_t, uint64_t, uint32_t, GcLzmaPlan*, uint64_t*);
 extern "C" __global__ void gc_lzma2_emit_kernel(const uint8_t*, uint32_t, const uint8_t*, const GcLzmaChunkInfo*, const GcLzmaPlan*, uint32_t,
                                                 uint32_t, const uint64_t*, uint8_t*);
@@ -520,7 +521,9 @@ extern "C" int gc_mf_pass_timing(gc_ctx* c, float ms[4])
 // zstd level -> blocks per frame.  Levels 1-2 (the reference's `fast` strategy, clevels.h:29-30) use the block-local finder and
 // one frame per block; level 3 and up (dfast and stronger, clevels.h:31-47, windowLog >= 21) use the windowed finder with
 // 8 MiB frames.
-static uint32_t zstd_frame_blocks(int level) { return level <= 2 ? 1u : GC_MF_MAX_FRAME_BLOCKS; }
+// level 1 = the block-local finder (the reference's `fast`, config C1); from level 2 on the windowed finder: the reference's level 2 has a window of
+// 1 MiB (clevels.h:27), and a finder that sees one 128 KiB block was 8 % behind it (run r03_levels: 1.085 / 1.078 on text / lz-7zip)
+static uint32_t zstd_frame_blocks(int level) { return level <= 1 ? 1u : GC_MF_MAX_FRAME_BLOCKS; }
 // zstd level -> match links followed per position (the reference's searchLog grows the same way: clevels.h:25-47)
 static uint32_t zstd_search_depth(int level) { return level < 6 ? 0u : (level < 10 ? 2u : (level < 16 ? 4u : 8u)); }
 
@@ -684,9 +687,9 @@ extern "C" size_t gc_flzma2_compress_bound(size_t n)
     return n + nChunks * 6u + 16u;
 }
 
-// level -> blocks per match-finder frame.  Levels 1-2: block-local finder (128 KiB window); level 3 and up: windowed finder,
-// 8 MiB frames = the dictionary size of the reference's level 5 (fl2_compress.c:37-104).
-static uint32_t flzma2_frame_blocks(int level) { return level <= 2 ? 1u : GC_MF_MAX_FRAME_BLOCKS; }
+// level -> blocks per match-finder frame.  Every level runs the windowed finder over 8 MiB frames (round 3; levels 1-2 used the block-local
+// finder before: a 128 KiB window against the reference's 1-2 MiB dictionaries, fl2_compress.c:52-63, was 12-24 % behind it, run r03_levels).
+static uint32_t flzma2_frame_blocks(int level) { (void)level; return GC_MF_MAX_FRAME_BLOCKS; }
 
 // dictionary-size property byte of the 7z coder (Lzma2Encoder.cpp:353-364): dict = (2|(p&1)) << (p/2+11).
 // Matches never reach back further than the start of their frame: 128 KiB (p = 10) or 8 MiB (p = 22).
@@ -783,7 +786,9 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
         // stage 3 (stream3): range coder
         HIPCHK(c, hipStreamWaitEvent(c->stream3, ev[4], 0));
         HIPCHK(c, hipEventRecord(ev[5], c->stream3));
-        GC_LAUNCH(gc_lzma2_rc_kernel, (pRc + 63u) / 64u, 64, c->stream3, (const uint16_t*)(c->lzStream + (size_t)blk0 * segPerBlock * GC_LZMA_STREAM_WORDS(segLog)),
+        GC_LAUNCH(gc_lzma2_rc_kernel, (pRc + 63u) / 64u, 64, c->stream3, c->lzStream + (size_t)blk0 * segPerBlock * GC_LZMA_STREAM_WORDS(segLog),
+                  segLog, pRc, c->lzRcOut + (size_t)blk0 * GC_LZMA_RC_PER_BLOCK * GC_LZMA_RC_STRIDE, c->lzInfo + (size_t)blk0 * GC_LZMA_RC_PER_BLOCK);
+        GC_LAUNCH(gc_lzma2_rc_fin_kernel, pRc, 64, c->stream3, (const uint16_t*)(c->lzStream + (size_t)blk0 * segPerBlock * GC_LZMA_STREAM_WORDS(segLog)),
                   segLog, pRc, c->lzRcOut + (size_t)blk0 * GC_LZMA_RC_PER_BLOCK * GC_LZMA_RC_STRIDE, c->lzInfo + (size_t)blk0 * GC_LZMA_RC_PER_BLOCK);
         HIPCHK(c, hipEventRecord(ev[6], c->stream3));
         f0 = f1;

@@ -61,7 +61,9 @@ __device__ __forceinline__ uint32_t br_rev(uint32_t code, uint32_t nbits) { retu
 struct BrCmd { uint32_t sym; uint32_t insExtraBits, insExtraVal, copyExtraBits, copyExtraVal; uint32_t dsym, dExtraBits, dExtraVal; bool hasDist; };
 // ll literals then a copy of ml bytes at distance off; ml == 0: trailing insert-only command.  useLast: off equals the
 // previous copy's distance of this meta-block
-__device__ __forceinline__ BrCmd br_command(uint32_t ll, uint32_t ml, uint32_t off, bool useLast)
+// rcode 1..15: the distance is one of the ring-buffer short codes (second / third / fourth last distance, last or second last -+ 1..3: RFC 7932
+// section 4, no extra bits), found by br_ring_code; 0: none
+__device__ __forceinline__ BrCmd br_command(uint32_t ll, uint32_t ml, uint32_t off, bool useLast, uint32_t rcode = 0u)
 {
     BrCmd c;
     const uint32_t ic = br_ins_code(ll), cc = ml ? br_copy_code(ml) : 0u;
@@ -72,11 +74,41 @@ __device__ __forceinline__ BrCmd br_command(uint32_t ll, uint32_t ml, uint32_t o
     if (implicitCell) { c.sym = low | (cc < 8u ? 0u : 64u); c.hasDist = false; }
     else { c.sym = kCellBase[(cc >> 3) + 3u * (ic >> 3)] | low; c.hasDist = ml != 0u; }
     c.dsym = 0; c.dExtraBits = 0; c.dExtraVal = 0;
-    if (c.hasDist && !useLast) {
+    if (c.hasDist && !useLast && rcode != 0u) c.dsym = rcode;
+    else if (c.hasDist && !useLast) {
         const uint32_t v = off + 3u, n = gc_hibit32(v) - 1u, b = (v >> n) & 1u;
         c.dsym = 16u + 2u * (n - 1u) + b; c.dExtraBits = n; c.dExtraVal = v - ((2u + b) << n);
     }
     return c;
+}
+
+// The short distance code of command j (a copy whose distance differs from the previous command's), 0 if none applies.  The decoder keeps the last
+// four distances that were NOT coded with symbol 0 (br_decode.c:2277, TakeDistanceFromRingBuffer :1690-1715); since every command here uses symbol
+// 0 whenever its distance equals the previous one, those are the distances of the last four "heads" -- commands whose distance differs from their
+// predecessor's -- in front of j.  They are found by walking back over the packed commands (at most BR_RING_WALK of them; heads that lie further
+// back, or in an earlier meta-block, are simply not used: an entry is only ever named when it is known exactly).
+#define BR_RING_WALK 24u
+__device__ __forceinline__ uint32_t br_ring_code(const uint64_t* P, uint32_t j, uint32_t off)
+{
+    uint32_t ring[4] = { 0u, 0u, 0u, 0u }, n = 0;
+    uint32_t cur = (uint32_t)(P[j - 1u] >> 36) & 0xFFFFFFu;          // (j >= 1) the previous command's distance = last distance
+    ring[n++] = cur;
+    for (uint32_t k = 1; k < BR_RING_WALK && n < 4u && k < j; k++) {
+        const uint32_t d = (uint32_t)(P[j - 1u - k] >> 36) & 0xFFFFFFu;
+        if (d != cur) { ring[n++] = d; cur = d; }                    // P[j - k] was a head: the distance in front of it is the next older entry
+    }
+    // the walk stopped inside a run of equal distances or at the meta-block start: the oldest entry found is exact only if its run was left,
+    // i.e. if it was recorded at a change -- entries are recorded at changes, except ring[0], which is always exact
+    if (n >= 2u && off == ring[1]) return 1u;
+    if (n >= 3u && off == ring[2]) return 2u;
+    if (n >= 4u && off == ring[3]) return 3u;
+    const int d0 = (int)off - (int)ring[0];
+    if (d0 >= -3 && d0 <= 3 && d0 != 0) return 4u + (uint32_t)(d0 < 0 ? 2 * (-d0 - 1) : 2 * (d0 - 1) + 1);      // 4: -1, 5: +1, 6: -2, 7: +2, 8: -3, 9: +3
+    if (n >= 2u) {
+        const int d1 = (int)off - (int)ring[1];
+        if (d1 >= -3 && d1 <= 3 && d1 != 0) return 10u + (uint32_t)(d1 < 0 ? 2 * (-d1 - 1) : 2 * (d1 - 1) + 1);
+    }
+    return 0u;
 }
 
 // OR up to 64 bits into the (zero-initialised) global bit buffer at absolute bit offset `pos`
@@ -330,6 +362,20 @@ gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
     if (t == 0 && tailLen) { P[nSeq] = (uint64_t)tailLen; LS[nSeq] = litBeforeTail; }
     __syncthreads();
 
+    // ---- short distance codes (round 3): bits 60..63 of a packed command (distances have 24 bits: WBITS = 24).  Computed a tile of commands at a
+    //      time -- all reads of the tile's walks, then the stores (a walk reads the distance fields only, which never change)
+    for (uint32_t tb = 0; tb < nSeq; tb += BR_T) {
+        const uint32_t j = tb + t;
+        uint32_t rcode = 0;
+        if (j >= 1u && j < nSeq) {
+            const uint32_t off = (uint32_t)(P[j] >> 36) & 0xFFFFFFu;
+            if (off != ((uint32_t)(P[j - 1u] >> 36) & 0xFFFFFFu)) rcode = br_ring_code(P, j, off);
+        }
+        __syncthreads();
+        if (rcode) P[j] |= (uint64_t)rcode << 60;
+        __syncthreads();
+    }
+
     // ---- histograms
     for (uint32_t i = t * 4u; i < nLit; i += BR_T * 4u) {
         if (i + 4u <= nLit) {
@@ -339,9 +385,9 @@ gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
     }
     for (uint32_t j = t; j < nCmd; j += BR_T) {
         const uint64_t pk = P[j];
-        const uint32_t ll = (uint32_t)(pk & 0x3FFFFu), ml = (uint32_t)((pk >> 18) & 0x3FFFFu), off = (uint32_t)(pk >> 36);
-        const bool useLast = j > 0u && ml != 0u && (uint32_t)(P[j - 1u] >> 36) == off;
-        const BrCmd c = br_command(ll, ml, off, useLast);
+        const uint32_t ll = (uint32_t)(pk & 0x3FFFFu), ml = (uint32_t)((pk >> 18) & 0x3FFFFu), off = (uint32_t)(pk >> 36) & 0xFFFFFFu;
+        const bool useLast = j > 0u && ml != 0u && ((uint32_t)(P[j - 1u] >> 36) & 0xFFFFFFu) == off;
+        const BrCmd c = br_command(ll, ml, off, useLast, (uint32_t)(pk >> 60));
         atomicAdd(&hCmd[c.sym], 1u);
         if (c.hasDist) atomicAdd(&hDist[c.dsym], 1u);
     }
@@ -392,9 +438,9 @@ gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
         BrCmd c; c.sym = 0; c.insExtraBits = c.insExtraVal = c.copyExtraBits = c.copyExtraVal = c.dsym = c.dExtraBits = c.dExtraVal = 0; c.hasDist = false;
         if (valid) {
             const uint64_t pk = P[j];
-            ll = (uint32_t)(pk & 0x3FFFFu); ml = (uint32_t)((pk >> 18) & 0x3FFFFu); off = (uint32_t)(pk >> 36); ls = LS[j];
-            useLast = j > 0u && ml != 0u && (uint32_t)(P[j - 1u] >> 36) == off;
-            c = br_command(ll, ml, off, useLast);
+            ll = (uint32_t)(pk & 0x3FFFFu); ml = (uint32_t)((pk >> 18) & 0x3FFFFu); off = (uint32_t)(pk >> 36) & 0xFFFFFFu; ls = LS[j];
+            useLast = j > 0u && ml != 0u && ((uint32_t)(P[j - 1u] >> 36) & 0xFFFFFFu) == off;
+            c = br_command(ll, ml, off, useLast, (uint32_t)(pk >> 60));
         }
         const uint32_t headBits = valid ? dCmd[c.sym] + c.insExtraBits + c.copyExtraBits : 0u;
         const uint32_t tailBits = (valid && c.hasDist) ? dDist[c.dsym] + c.dExtraBits : 0u;

@@ -540,155 +540,122 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
 }
 
 // ---------------------------------------------------------------------------------------------- L3: range coder
-// One rc chunk per LANE.  With the probabilities already resolved, what is left of LZMA's serial dependency is the range
-// recurrence itself -- bound = (range >> 11) * p; range = bit ? range - bound : bound; renormalise -- register-only work
-// (C/fast-lzma2/range_enc.h:62-152, RC_shiftLow range_enc.c:123-140).  All chunks of an input are coded at the same time, so
-// the kernel takes as long as ONE chunk's chain of ~4.5 coded bits per byte: what matters is the number of dependent cycles per
-// coded bit.  The step is therefore written without branches: every state update is a select, the output byte (if any) is
-// OR-ed into a 16-byte register window at a computed position, and only once per eight coded bits a lane with a complete
-// group of eight bytes stores it; the one rare case that needs a loop is a carry rippling through pending 0xFF bytes.
+// With the probabilities already resolved, what is left of LZMA's serial dependency is the range recurrence itself -- bound = (range >> 11) * p;
+// range = bit ? range - bound : bound; renormalise (C/fast-lzma2/range_enc.h:62-152) -- and all chunks of an input are coded at the same time, so
+// the kernel takes as long as ONE chunk's chain: what matters is the number of instructions per coded bit of a lane that has a SIMD to itself.
+// Round 3: two kernels.  What RC_shiftLow (range_enc.c:123-140) does with `cache` and `cacheSize` -- hold back the last byte and the 0xFF bytes
+// behind it until it is known whether a carry comes -- is a big-number addition done one digit at a time; it does not have to sit in the serial
+// loop.  Every shift step takes the 9-bit digit low >> 24 (a byte and the carry into the byte in front of it) out of low:
+//   L3a gc_lzma2_rc_kernel      one LANE per rc chunk (group of chunks): the recurrence, and one 16-bit store per shift step: the digit goes
+//                               back into the word stream the lane is reading, which it has consumed further than it has written (a step shifts at
+//                               most once: p >= 31).  No cache, no pending count, no byte window, no wave-level look at rare cases:
+//                               ~18 vector instructions per coded bit instead of ~40 (8.4 -> X ms on the Silesia stand-in).
+//   L3b gc_lzma2_rc_fin_kernel  one WAVE per chunk: output byte k = (digit[k-1] & 255) + (digit[k] >> 8) + the carry from byte k + 1; 64 bytes at
+//                               a time from the chunk's end, the carries of a tile resolved by one 64-bit addition of its generate / propagate masks.
+// The bytes are those of the reference's encoder for the same (probability, bit) sequence: n shift steps + 5 flush steps give n + 5 bytes.
+__device__ __forceinline__ uint32_t rc_mul24(uint32_t a, uint32_t b)       // a < 2^21, b < 2^11: the full-rate 24-bit multiply is exact
+{
+#ifdef HIPEMU
+    return a * b;
+#else
+    return __umul24(a, b);
+#endif
+}
 struct LzRc {
-    uint32_t low, carry;              // low 32 bits of `low` + its 33rd bit
-    uint32_t range, cache, pend;      // pend = cacheSize - 1: 0xFF bytes waiting behind `cache` for a possible carry
-    uint32_t outPos;                  // bytes produced so far
-    uint32_t putQ;                    // groups of eight bytes written to memory
-    uint64_t w0, w1;                  // bytes [8 * putQ, outPos): at most 15
-    uint64_t* out;
-    uint32_t capQ;                    // groups of eight bytes the staging area of this chunk (group of chunks) holds
-    bool act;                         // false while the lane only runs along (its state is thrown away): no memory side effects
+    uint64_t low;                     // < 2^33
+    uint32_t range;
+    uint32_t nDig;                    // digits written so far
+    uint16_t* dig;                    // where they go: the start of this chunk's words
 };
-
-__device__ __forceinline__ void rc_append(LzRc& rc, uint32_t v, bool on)          // byte v at position outPos, if `on`
-{
-    const uint32_t pos = rc.outPos - 8u * rc.putQ;                 // 0 .. 15
-    const uint64_t x = on ? (uint64_t)(v & 0xFFu) << ((pos & 7u) * 8u) : 0ull;
-    rc.w0 |= pos < 8u ? x : 0ull;
-    rc.w1 |= pos < 8u ? 0ull : x;
-    rc.outPos += on ? 1u : 0u;
-}
-// write a complete group of eight bytes (if there is one)
-__device__ __forceinline__ void rc_put_away(LzRc& rc)
-{
-    if (rc.outPos - 8u * rc.putQ >= 8u) {
-        if (rc.act && rc.putQ < rc.capQ) rc.out[rc.putQ] = rc.w0;
-        rc.w0 = rc.w1; rc.w1 = 0; rc.putQ++;
-    }
-}
-// one coded bit, branch-free except for the wave-level look at the rare case
+// one coded bit
 __device__ __forceinline__ void rc_word(LzRc& rc, uint32_t w)
 {
     const bool bit = (w & LZW_BIT) != 0u, direct = (w & LZW_DIRECT) != 0u;
-    const uint32_t bound = direct ? rc.range >> 1 : (rc.range >> 11) * (w & 0x7FFu);
-    const uint32_t add = bit ? bound : 0u;
-    const uint32_t sum = rc.low + add;
-    const uint32_t carry = rc.carry | (sum < add ? 1u : 0u);
-    const uint32_t range = (bit && !direct) ? rc.range - bound : bound;
-    const bool need = range < (1u << 24);                          // RC_shiftLow; one step always suffices (p >= 31)
-    const bool emit = need && (sum < 0xFF000000u || carry != 0u);
-    // emit: the delayed byte `cache` (+ carry), then the pending 0xFF bytes (+ carry: they turn into 0x00), then the top byte
-    // of low becomes the delayed byte.  !emit && need: the top byte is 0xFF and no carry is known yet -> one more pending byte
-    uint32_t extra = emit ? rc.pend : 0u;                          // almost always 0
-    rc_append(rc, rc.cache + carry, emit);
-    if (__any(extra != 0u)) {                                      // rare: a lane has pending bytes to emit
-        while (__any(extra != 0u)) { rc_put_away(rc); rc_append(rc, 0xFFu + carry, extra != 0u); extra -= extra ? 1u : 0u; }
+    const uint32_t bound = direct ? rc.range >> 1 : rc_mul24(rc.range >> 11, w & 0x7FFu);
+    rc.low += bit ? bound : 0u;
+    uint32_t range = (bit && !direct) ? rc.range - bound : bound;
+    if (range < (1u << 24)) {                                      // RC_shiftLow; one step always suffices (p >= 31)
+        rc.dig[rc.nDig++] = (uint16_t)(rc.low >> 24);
+        rc.low = (rc.low & 0xFFFFFFull) << 8;
+        range <<= 8;
     }
-    rc.cache = emit ? sum >> 24 : rc.cache;
-    rc.pend = need ? (emit ? 0u : rc.pend + 1u) : rc.pend;
-    rc.low = need ? sum << 8 : sum;
-    rc.carry = need ? 0u : carry;
-    rc.range = need ? range << 8 : range;
+    rc.range = range;
 }
 
 extern "C" __global__ void __launch_bounds__(64)
-gc_lzma2_rc_kernel(const uint16_t* __restrict__ stream, uint32_t segLog, uint32_t nRc, uint8_t* __restrict__ rcOut,
-                   GcLzmaChunkInfo* __restrict__ cinfo)
+gc_lzma2_rc_kernel(uint16_t* stream, uint32_t segLog, uint32_t nRc, uint8_t* __restrict__ rcOut, GcLzmaChunkInfo* __restrict__ cinfo)
 {
     const uint32_t lane = threadIdx.x;
     const uint32_t c = blockIdx.x * 64u + lane;
     GcLzmaChunkInfo ci; ci.usize = 0; ci.csize = 0; ci.wordStart = 0; ci.wordEnd = 0;
     if (c < nRc) ci = cinfo[c];
-    const bool live = ci.usize != 0u && ci.csize != 0xFFFFFFFFu;           // idle lanes run along without words
+    const bool live = ci.usize != 0u && ci.csize != 0xFFFFFFFFu;
+    if (!live) return;                                              // (nothing below is wave-synchronous)
     const uint32_t seg = c >> (segLog - GC_LZMA_RC_LOG);
-    const uint16_t* W = stream + (uint64_t)(live ? seg : 0u) * GC_LZMA_STREAM_WORDS(segLog);
-    LzRc rc; rc.low = 0; rc.carry = 0; rc.range = 0xFFFFFFFFu; rc.cache = 0; rc.pend = 0; rc.outPos = 0; rc.putQ = 0; rc.w0 = 0; rc.w1 = 0; rc.act = live;
-    rc.out = (uint64_t*)(rcOut + (uint64_t)(live ? c : 0u) * GC_LZMA_RC_STRIDE);
-    const uint32_t members = (ci.usize + GC_LZMA_RC_SIZE - 1u) >> GC_LZMA_RC_LOG;       // rc chunks coded as this one LZMA2 chunk
-    rc.capQ = members * (GC_LZMA_RC_STRIDE / 8u);
-    // words up to the next 16-byte boundary of the stream one by one (every lane of the wave takes part in each step, lanes
-    // without a word just do not advance), then eight at a time from one 16-byte load, then the rest one by one
-    uint32_t k = live ? ci.wordStart : 0u;
-    const uint32_t end = live ? ci.wordEnd : 0u;
-    while (__any(k < end && (k & 7u) != 0u)) {
-        const bool on = k < end && (k & 7u) != 0u;
-        const LzRc save = rc;
-        rc.act = on;
-        rc_word(rc, on ? W[k] : 0u);
-        if (!on) rc = save;
-        k += on ? 1u : 0u;
-        rc.act = live;
-        rc_put_away(rc);
-    }
+    uint16_t* W = stream + (uint64_t)seg * GC_LZMA_STREAM_WORDS(segLog);
+    LzRc rc; rc.low = 0; rc.range = 0xFFFFFFFFu; rc.nDig = 0; rc.dig = W + ci.wordStart;
+    uint32_t k = ci.wordStart;
+    const uint32_t end = ci.wordEnd;
+    // words up to the next 16-byte boundary of the stream one by one, then eight at a time from one 16-byte load (the next load is in
+    // flight while these are coded; digits land in front of word k, loads reach behind it), then the rest one by one
+    while (k < end && (k & 7u) != 0u) { rc_word(rc, W[k]); k++; }
     const uint32_t nVec = k + 8u <= end ? (end - k) >> 3 : 0u;
     const GcU4* V = (const GcU4*)(W + k);
     GcU4 nxt; nxt.x = nxt.y = nxt.z = nxt.w = 0;
     if (nVec) nxt = V[0];
-    for (uint32_t i = 0; __any(i < nVec); i++) {
-        if (__all(i < nVec)) {                              // every lane has a whole vector: nothing to mask
-            const GcU4 cur = nxt;
-            if (i + 1u < nVec) nxt = V[i + 1u];             // next load in flight while these are coded
-            rc_word(rc, cur.x & 0xFFFFu); rc_word(rc, cur.x >> 16); rc_word(rc, cur.y & 0xFFFFu); rc_word(rc, cur.y >> 16);
-            rc_word(rc, cur.z & 0xFFFFu); rc_word(rc, cur.z >> 16); rc_word(rc, cur.w & 0xFFFFu); rc_word(rc, cur.w >> 16);
-        } else {                                            // some lanes have run out of vectors: they run along
-            const bool on = i < nVec;
-            const GcU4 cur = nxt;
-            if (i + 1u < nVec) nxt = V[i + 1u];
-            const LzRc save = rc;
-            rc.act = on;
-            rc_word(rc, cur.x & 0xFFFFu); rc_word(rc, cur.x >> 16); rc_word(rc, cur.y & 0xFFFFu); rc_word(rc, cur.y >> 16);
-            rc_word(rc, cur.z & 0xFFFFu); rc_word(rc, cur.z >> 16); rc_word(rc, cur.w & 0xFFFFu); rc_word(rc, cur.w >> 16);
-            if (!on) rc = save;
-            rc.act = live;
-        }
-        rc_put_away(rc);
+    for (uint32_t i = 0; i < nVec; i++) {
+        const GcU4 cur = nxt;
+        if (i + 1u < nVec) nxt = V[i + 1u];
+        rc_word(rc, cur.x & 0xFFFFu); rc_word(rc, cur.x >> 16); rc_word(rc, cur.y & 0xFFFFu); rc_word(rc, cur.y >> 16);
+        rc_word(rc, cur.z & 0xFFFFu); rc_word(rc, cur.z >> 16); rc_word(rc, cur.w & 0xFFFFu); rc_word(rc, cur.w >> 16);
     }
     k += nVec << 3;
-    while (__any(k < end)) {
-        const bool on = k < end;
-        const LzRc save = rc;
-        rc.act = on;
-        rc_word(rc, on ? W[k] : 0u);
-        if (!on) rc = save;
-        k += on ? 1u : 0u;
-        rc.act = live;
-        rc_put_away(rc);
+    while (k < end) { rc_word(rc, W[k]); k++; }
+    // what is left of low leaves through the five flush steps, which L3b derives from it: the value travels in the chunk's staging area
+    *(uint64_t*)(rcOut + (uint64_t)c * GC_LZMA_RC_STRIDE) = rc.low;
+    cinfo[c].csize = rc.nDig;
+}
+
+__device__ __forceinline__ uint64_t rc_rev64(uint64_t v) { return ((uint64_t)__brev((uint32_t)v) << 32) | (uint64_t)__brev((uint32_t)(v >> 32)); }
+
+extern "C" __global__ void __launch_bounds__(64)
+gc_lzma2_rc_fin_kernel(const uint16_t* __restrict__ stream, uint32_t segLog, uint32_t nRc, uint8_t* __restrict__ rcOut, GcLzmaChunkInfo* __restrict__ cinfo)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t c = blockIdx.x;
+    if (c >= nRc) return;
+    const GcLzmaChunkInfo ci = cinfo[c];
+    if (ci.usize == 0u || ci.csize == 0xFFFFFFFFu) return;         // (uniform)
+    const uint32_t seg = c >> (segLog - GC_LZMA_RC_LOG);
+    const uint16_t* D = stream + (uint64_t)seg * GC_LZMA_STREAM_WORDS(segLog) + ci.wordStart;
+    uint8_t* out = rcOut + (uint64_t)c * GC_LZMA_RC_STRIDE;
+    const uint32_t nDig = ci.csize, n = nDig + 5u;                  // bytes of the chunk
+    const uint64_t low = *(const uint64_t*)out;                     // (read by every lane before any lane writes: the barrier below)
+    gc_wave_sync_global();
+    const uint32_t members = (ci.usize + GC_LZMA_RC_SIZE - 1u) >> GC_LZMA_RC_LOG;       // rc chunks coded as this one LZMA2 chunk
+    if (n > members * GC_LZMA_RC_STRIDE || n > 65536u) {            // did not fit the staging area / an LZMA2 chunk holds at most 64 KiB of coded bytes: the segment is stored
+        if (lane == 0u) cinfo[c].csize = 0xFFFFFFFFu;
+        return;
     }
-    rc.act = live;
-    if (live) {
-        for (int i = 0; i < 5; i++) {                                       // RC_flush: five shift steps
-            const uint32_t carry = rc.carry;
-            const bool emit = rc.low < 0xFF000000u || carry != 0u;
-            if (emit) {
-                uint8_t tmp = (uint8_t)(rc.cache + carry);
-                // (plain per-lane code: the tail is not performance relevant)
-                { const uint32_t pos = rc.outPos - 8u * rc.putQ; if (pos < 8u) rc.w0 |= (uint64_t)tmp << (pos * 8u); else rc.w1 |= (uint64_t)tmp << ((pos - 8u) * 8u); rc.outPos++; }
-                for (uint32_t e = rc.pend; e != 0u; e--) {
-                    rc_put_away(rc);
-                    const uint32_t pos = rc.outPos - 8u * rc.putQ; const uint64_t x = (uint64_t)((0xFFu + carry) & 0xFFu);
-                    if (pos < 8u) rc.w0 |= x << (pos * 8u); else rc.w1 |= x << ((pos - 8u) * 8u);
-                    rc.outPos++;
-                }
-                rc.cache = rc.low >> 24; rc.pend = 0;
-            } else rc.pend++;
-            rc.low <<= 8; rc.carry = 0;
-            rc_put_away(rc);
-        }
+    // digit k: a shift step's, or one of the five flush steps' (low >> 24 with its carry bit, then the three bytes below, then 0)
+    auto digit = [&](uint32_t kk) -> uint32_t {
+        if (kk < nDig) return D[kk];
+        const uint32_t f = kk - nDig;
+        return f == 0u ? (uint32_t)(low >> 24) & 0x1FFu : (f < 4u ? (uint32_t)(low >> (24u - 8u * f)) & 0xFFu : 0u);
+    };
+    uint32_t cin = 0;                                               // carry into the tile from the bytes behind it
+    for (uint32_t tb = ((n - 1u) >> 6) << 6;; tb -= 64u) {
+        const uint32_t kk = tb + lane;
+        uint32_t v = 0;
+        if (kk < n) v = (kk ? digit(kk - 1u) & 0xFFu : 0u) + (digit(kk) >> 8);          // 0 .. 256
+        // bit i of the masks = the byte of significance i inside the tile (lane 63 is the least significant)
+        const uint64_t G = rc_rev64(__ballot(v == 256u)), P = rc_rev64(__ballot(v == 255u));
+        const uint64_t X = G | P, s1 = X + G, s2 = s1 + cin;
+        const uint32_t cout = (s1 < X || s2 < s1) ? 1u : 0u;
+        const uint64_t carryIn = s2 ^ P;                            // bit i: the carry that enters byte i  (X ^ G = P)
+        if (kk < n) out[kk] = (uint8_t)(v + (uint32_t)((carryIn >> (63u - lane)) & 1ull));
+        cin = cout;
+        if (tb == 0u) break;
     }
-    if (live) {
-        const uint32_t n = rc.outPos;
-        if (n <= rc.capQ * 8u && n <= 65536u) {                // (an LZMA2 chunk holds at most 64 KiB of coded bytes)
-            uint8_t* o = (uint8_t*)rc.out;
-            for (uint32_t i = 8u * rc.putQ; i < n; i++) { const uint32_t pos = i - 8u * rc.putQ; o[i] = (uint8_t)((pos < 8u ? rc.w0 >> (pos * 8u) : rc.w1 >> ((pos - 8u) * 8u)) & 0xFFu); }
-            cinfo[c].csize = n;
-        } else cinfo[c].csize = 0xFFFFFFFFu;                 // did not fit the staging area: the segment is stored
-    }
+    if (lane == 0u) cinfo[c].csize = n;
 }
