@@ -1020,7 +1020,7 @@ MFK(gc_mf_vparse_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint
 //     again at the next tile's first position; if it comes back with the same offset the sequences kernel merges the two records
 //     (chains of records with equal offset and no literals between them are one sequence), so most cuts cost nothing;
 //   - where a tile's sequences and literals go in the block's arrays depends on the counts of the tiles in front: every tile publishes
-//     its counts in one word (ready << 31 | sequences << 14 | literals) as soon as its path is known, and reads the words of the (at most
+//     its counts in one word (ready << 31 | sequences << 15 | literals) as soon as its path is known, and reads the words of the (at most
 //     15) tiles in front of it.  No chain: each word is its tile's own count.  A workgroup draws its tile from a ticket counter of its XCD
 //     class (workgroup index mod 8), so the tiles it waits for have been drawn before it and are running or done whatever the dispatch order.
 extern "C" __global__ void __launch_bounds__(MFV_T, VP_MIN_WAVES)
@@ -1106,14 +1106,14 @@ MFK(gc_mf_vparse_tile_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize,
     if (wave == 0) {
         if (lane == 0) {
 #ifdef HIPEMU
-            __atomic_store_n(&tileWord[tile], 0x80000000u | (sAll << 14) | lAll, __ATOMIC_RELEASE);
+            __atomic_store_n(&tileWord[tile], 0x80000000u | (sAll << 15) | lAll, __ATOMIC_RELEASE);
 #else
-            __hip_atomic_store(&tileWord[tile], 0x80000000u | (sAll << 14) | lAll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&tileWord[tile], 0x80000000u | (sAll << 15) | lAll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #endif
         }
         uint32_t w = 0x80000000u;
         if (lane < ti) { do { w = gc_poll_device(&tileWord[tile - ti + lane]); if (!(w >> 31)) gc_nap(); } while (!(w >> 31)); }
-        const uint32_t sb = gc_wave_sum(lane < ti ? (w >> 14) & 0x1FFFFu : 0u), lb = gc_wave_sum(lane < ti ? w & 0x3FFFu : 0u);
+        const uint32_t sb = gc_wave_sum(lane < ti ? (w >> 15) & 0xFFFFu : 0u), lb = gc_wave_sum(lane < ti ? w & 0x7FFFu : 0u);      // (a 16 KiB tile of literals only has 2^14 of them: 15 bits)
         if (lane == 0) { sBase[0] = sb; sBase[1] = lb; }
     }
     __syncthreads();

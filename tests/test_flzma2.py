@@ -85,6 +85,15 @@ def test_emu_long_matches_and_patterns(O, emu_fl2):
     _roundtrip(O, emu_fl2[1], y)                                                         # dense rep0 / rep1 usage
 
 
+def test_emu_tile_of_literals_only_in_the_fused_parse(O, emu_fl2):
+    """Levels 1-2 run the windowed finder's fused verify + parse kernel on the wide geometry (16 KiB tiles).  A tile without a single match has 2^14
+    literals -- one more than the 14 bits its count had in the word the tiles publish (the sequence counts of the tiles behind it went wrong and
+    the later kernels never ended; found on the GPU in round 3 with the Silesia stand-in's random part)."""
+    t = O.corpus("text-zipf", 40_000)
+    x = np.concatenate([t, O.corpus("random", 3 * 16384 + 100), t, O.corpus("random", 16384), t[:5000]])
+    _roundtrip(O, emu_fl2[1], x)
+
+
 def test_emu_many_frames_and_parts(O, pkg, emu_lib_path, monkeypatch):
     """The multi-frame and multi-part paths on a small input: test hooks shrink the match-finder frame to one block and make every
     frame its own part (stages of different parts run on different streams; a later part's first literal has the last byte of
