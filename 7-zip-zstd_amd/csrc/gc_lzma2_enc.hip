@@ -573,13 +573,14 @@ __device__ __forceinline__ void rc_word(LzRc& rc, uint32_t w)
     const bool bit = (w & LZW_BIT) != 0u, direct = (w & LZW_DIRECT) != 0u;
     const uint32_t bound = direct ? rc.range >> 1 : rc_mul24(rc.range >> 11, w & 0x7FFu);
     rc.low += bit ? bound : 0u;
-    uint32_t range = (bit && !direct) ? rc.range - bound : bound;
-    if (range < (1u << 24)) {                                      // RC_shiftLow; one step always suffices (p >= 31)
-        rc.dig[rc.nDig++] = (uint16_t)(rc.low >> 24);
-        rc.low = (rc.low & 0xFFFFFFull) << 8;
-        range <<= 8;
-    }
-    rc.range = range;
+    const uint32_t range = (bit && !direct) ? rc.range - bound : bound;
+    const bool need = range < (1u << 24);                          // RC_shiftLow; one step always suffices (p >= 31)
+    // no branch: the digit is stored whether or not there is a shift step, and only a step moves the write position on (a slot that did not
+    // count is written again by the next word; the position never passes the word being coded, which is in a register already)
+    rc.dig[rc.nDig] = (uint16_t)(rc.low >> 24);
+    rc.nDig += need ? 1u : 0u;
+    rc.low = need ? (rc.low & 0xFFFFFFull) << 8 : rc.low;
+    rc.range = need ? range << 8 : range;
 }
 
 extern "C" __global__ void __launch_bounds__(64)
