@@ -521,9 +521,10 @@ extern "C" int gc_mf_pass_timing(gc_ctx* c, float ms[4])
 // zstd level -> blocks per frame.  Levels 1-2 (the reference's `fast` strategy, clevels.h:29-30) use the block-local finder and
 // one frame per block; level 3 and up (dfast and stronger, clevels.h:31-47, windowLog >= 21) use the windowed finder with
 // 8 MiB frames.
-// level 1 = the block-local finder (the reference's `fast`, config C1); from level 2 on the windowed finder: the reference's level 2 has a window of
-// 1 MiB (clevels.h:27), and a finder that sees one 128 KiB block was 8 % behind it (run r03_levels: 1.085 / 1.078 on text / lz-7zip)
-static uint32_t zstd_frame_blocks(int level) { return level <= 1 ? 1u : GC_MF_MAX_FRAME_BLOCKS; }
+// Every level runs the windowed finder over 8 MiB frames (round 3).  Levels 1-2 used the block-local finder before -- a 128 KiB window against the
+// 512 KiB / 1 MiB windows of the reference's levels 1 / 2 (clevels.h:26-27): 1.026 x its level 1 on text, 1.085 x its level 2 (run r03_levels).
+// The block-local kernel K1 still serves inputs of one block.
+static uint32_t zstd_frame_blocks(int level) { (void)level; return GC_MF_MAX_FRAME_BLOCKS; }
 // zstd level -> match links followed per position (the reference's searchLog grows the same way: clevels.h:25-47)
 static uint32_t zstd_search_depth(int level) { return level < 6 ? 0u : (level < 10 ? 2u : (level < 16 ? 4u : 8u)); }
 
@@ -836,12 +837,12 @@ extern "C" int gc_flzma2_compress_host(gc_ctx* c, const void* src, size_t n, voi
 // chunk = 1 MiB x level as in brotli-mt (C/zstdmt/brotli-mt_compress.c:115-118), in 128 KiB blocks
 static uint32_t brotli_blocks_per_chunk(int level) { if (level < 1) level = 1; if (level > 11) level = 11; return (uint32_t)level * 8u; }
 
-// quality -> blocks per match-finder frame.  Qualities 0-2: block-local finder.  Above: the windowed finder over frames that
+// quality -> blocks per match-finder frame.  Quality 0: block-local finder.  Above (from quality 1 since round 3: 1.04 x the reference before): the windowed finder over frames that
 // tile the chunk exactly (a copy must not reach into the previous chunk: every chunk is a brotli stream of its own), the whole
 // chunk when it is <= 8 MiB (qualities 3-8), half of it above (72/80/88 blocks -> 36/40/44).
 static uint32_t brotli_frame_blocks(int level, uint32_t bpc)
 {
-    if (level <= 2) return 1u;
+    if (level <= 0) return 1u;
     return bpc <= GC_MF_MAX_FRAME_BLOCKS ? bpc : bpc / 2u;
 }
 

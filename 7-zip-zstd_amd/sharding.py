@@ -3,8 +3,7 @@
 All three codecs produce streams that concatenate: zstd frames (the reference decoder accepts any number of them,
 CPP/7zip/Compress/ZstdDecoder.cpp:145-158), brotli-mt frames (C/zstdmt/brotli-mt_decompress.c:240-351) and runs of LZMA2
 chunks that start with a dictionary reset and share ONE end marker (C/Lzma2Dec.c:97).  So N ranks compress N contiguous ranges
-cut at multiples of the codec's independence grain (gc_codec_grain: 8 MiB match-finder frames for zstd level >= 2 and FLZMA2,
-128 KiB blocks for zstd level 1; the brotli-mt chunk of `level` MiB) with no data-path collective, and the host concatenates
+cut at multiples of the codec's independence grain (gc_codec_grain: 8 MiB match-finder frames for zstd and FLZMA2; the brotli-mt chunk of `level` MiB) with no data-path collective, and the host concatenates
 the compressed ranges in rank order.  This is the job split of the reference's own multi-threaded front ends (ZSTDMT jobs,
 C/zstd/zstdmt_compress.c:1184-1247; brotli-mt chunks, C/zstdmt/brotli-mt_compress.c:209-333) with GPUs in place of worker
 threads.  The in-process counterpart (several GPUs driven by one process, host threads) is gc_multi in csrc/gc_multi.hip.
@@ -14,7 +13,7 @@ torch.distributed is used for the gather of the compressed byte strings only (gl
 import numpy as np
 
 GRAIN_ZSTD = 128 * 1024
-FRAME_ZSTD = 64 * GRAIN_ZSTD      # level >= 2: 8 MiB frames (windowed match finder, csrc/gc_mf.h GC_MF_MAX_FRAME_BLOCKS)
+FRAME_ZSTD = 64 * GRAIN_ZSTD      # 8 MiB frames (windowed match finder, csrc/gc_mf.h GC_MF_MAX_FRAME_BLOCKS)
 FLZMA2_NO_END_MARK = 1            # include/gpucodec.h GC_FLZMA2_NO_END_MARK
 
 
@@ -31,16 +30,14 @@ def codec_grain(codec, level):
     """What gc_codec_grain returns (kept in Python too so that range planning needs no library handle)."""
     if codec == "brotli":
         return max(1, min(11, int(level))) * 8 * GRAIN_ZSTD
-    if codec == "zstd":
-        return GRAIN_ZSTD if int(level) <= 1 else FRAME_ZSTD      # (level 1: the block-local finder)
-    return FRAME_ZSTD                                             # FLZMA2: every level
+    return FRAME_ZSTD                                             # zstd and FLZMA2: the windowed finder at every level
 
 
 def zstd_grain(level, n, world):
-    """Grain used for a zstd input of n bytes on `world` ranks: a whole 8 MiB frame at level >= 2 when every rank gets at
+    """Grain used for a zstd input of n bytes on `world` ranks: a whole 8 MiB frame when every rank gets at
     least one; otherwise one block (a range that starts inside a frame only cuts that frame's window short, the stream stays
     valid)."""
-    if level >= 2 and n >= world * FRAME_ZSTD:
+    if n >= world * FRAME_ZSTD:
         return FRAME_ZSTD
     return GRAIN_ZSTD
 

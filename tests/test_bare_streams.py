@@ -30,7 +30,7 @@ def _check_seek_table(O, x, c, frame_bytes):
     assert off == t0 and dec == n
 
 
-@pytest.mark.parametrize("level,n,frame", [(1, 3 * BLK + 77, BLK), (3, 5 * BLK + 5, 2 * BLK)])
+@pytest.mark.parametrize("level,n,frame", [(1, 3 * BLK + 77, 2 * BLK), (3, 5 * BLK + 5, 2 * BLK)])       # (the windowed finder at every level: frames of GC_FRAME_BLOCKS blocks)
 def test_zstd_seek_table_emulator(pkg, O, emu_lib_path, monkeypatch, level, n, frame):
     monkeypatch.setenv("GC_FRAME_BLOCKS", "2")
     x = O.corpus("text-zipf", n)

@@ -122,15 +122,10 @@ def test_two_rank_gloo_equals_single_rank(graft, pkg, O, emu_lib_path, tmp_path,
     S = _sharding(graft)
     parts = [emu_enc.code(x[s:e]) for s, e in S.shard_ranges(n, 2) if e > s]
     assert np.array_equal(y, np.concatenate(parts))
-    # ... at levels 1-2 (one frame per block) it differs from the single-rank stream only in the last ~80 bytes before a
-    # range end, which the match finder leaves as literals because it never reads past the end of the buffer it was given;
-    # at level >= 2 every range starts its own frame (its window does not reach into the previous range), which costs ratio
-    # on inputs this small and nothing measurable at 8 MiB frames
+    # ... every range starts its own frame (its window does not reach into the previous range), which costs ratio on inputs this small and
+    # nothing measurable at 8 MiB frames
     whole = int(emu_enc.code(x).size)
-    if level <= 1:
-        assert abs(int(y.size) - whole) <= 64
-    else:
-        assert whole <= int(y.size) <= whole * 1.10
+    assert whole <= int(y.size) <= whole * 1.10
     assert np.array_equal(O.port_zstd_decompress(y, n), x)
     if O.ref("zstd") is not None:
         assert np.array_equal(O.ref_zstd_decompress(y, n), x)

@@ -114,7 +114,7 @@ def test_emu_own_encoder_roundtrip(pkg, O, emu_lib_path, emu_dec, level, monkeyp
     finally:
         enc.close()
     frames, n, total = emu_dec.scan(comp)
-    assert total == x.size and n >= (1 if level <= 1 else 2)
+    assert total == x.size and n >= 2
     _check(emu_dec, comp, x.tobytes())
     _check(emu_dec, comp2, x.tobytes())                                        # the seek table is a skippable frame
 
