@@ -94,6 +94,33 @@ def _pmc_lookup(section, n, kname):
     return None, None, kname
 
 
+def real_data_check(pkg, device):
+    """Outside every timed region, N = 1 only: the two codecs of the metric on REAL bytes from the image (7-zip-zstd_amd/corpus real_corpus: C / C++ / Python
+    sources, ROCm shared objects) against the reference encoders at the same levels -- the stand-in corpora above are generators.  Sizes only."""
+    import numpy as np
+    O = _oracle()
+    out = {"note": "64 MiB per corpus, the reference with up to 64 threads; ours_over_ref against the 2 % band", "corpora": {}}
+    try:
+        thr = min(os.cpu_count() or 1, 64)
+        for kind in ("real-src", "real-bin"):
+            x = O.corpus(kind, 64 << 20)
+            if x.size < (1 << 20):
+                continue
+            row = {"bytes": int(x.size)}
+            if O.ref("zstd") is not None:
+                e = pkg.ZstdEncoder(level=3, device=device); c = e.code(x); e.close()
+                r = O.ref_zstd_compress(x, 3)
+                row["zstd_l3"] = {"ours": int(len(c)), "ref": int(len(r)), "ours_over_ref": round(len(c) / len(r), 4), "decodes": bool(np.array_equal(O.ref_zstd_decompress(c, x.size), x))}
+            if O.ref("flzma2") is not None:
+                e = pkg.Flzma2Encoder(level=5, device=device); c = e.code(x); prop = e.coder_props()[0]; e.close()
+                r, _ = O.ref_fl2_compress(x, 5, threads=thr)
+                row["flzma2_l5"] = {"ours": int(len(c)), "ref": int(len(r)), "ours_over_ref": round(len(c) / len(r), 4), "decodes": bool(np.array_equal(O.ref_lzma2_decode(c, x.size, prop), x))}
+            out["corpora"][kind] = row
+    except Exception as ex:                      # (a report, never a reason for the bench line to be missing)
+        out["error"] = repr(ex)
+    return out
+
+
 def run_codec(codec, level, corpus_name, total, args, env):
     """K timed steps of one codec over this rank's range of the corpus; rank 0 returns the result object."""
     import numpy as np
@@ -325,6 +352,8 @@ def main():
         }
         if extra is not None:
             line["flzma2_l5_silesia"] = extra
+        if not args.codec and world == 1 and not args.no_cpu_baseline:
+            line["real_data"] = real_data_check(pkg, local_rank)
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
