@@ -102,3 +102,21 @@ def test_gpu_multi_pieces(pkg, O, graft, codec, level, kind, n):
     else:
         e = pkg.Flzma2Encoder(level=level); prop = e.coder_props()[0]; e.close()
         assert np.array_equal(O.ref_lzma2_decode(y, n, prop), x)
+
+
+@pytest.mark.gpu
+def test_gpu_multi_two_real_devices(pkg, O, graft):
+    """The host scheduler over TWO real GPUs (skipped on a one-GPU box: the first multi-GPU box that runs the suite exercises it): pieces dealt to
+    four contexts on two devices, the stream equal to the one-context stream and decodable by the reference."""
+    import torch
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    graft.build_hip()
+    x = O.corpus("text-zipf", 300_000_000)
+    m = pkg.MultiEncoder("zstd", 3)
+    assert m.workers() >= 4
+    y = m.code(x)
+    m.close()
+    e = pkg.ZstdEncoder(level=3); whole = e.code(x); e.close()
+    assert np.array_equal(y, whole)
+    assert np.array_equal(O.ref_zstd_decompress(y, x.size), x)
