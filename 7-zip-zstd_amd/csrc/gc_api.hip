@@ -561,10 +561,12 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
     c->searchDepth = zstd_search_depth(level);
     c->farPass = level >= 7 ? 1u : 0u;            // where the reference searches chains / trees (lazy2 and up).  Measured (run 29, 32 MiB): level 9
                                                   // 1.027 -> 0.984 x the reference on text, level 12 1.040 -> 1.001 x
-    c->shortPass = level >= 16 ? 1u : 0u;         // the reference's btopt strategies search 3-byte matches (minMatch 3, clevels.h:44-47)
+    c->shortPass = level >= 10 ? 1u : 0u;         // the reference's btopt strategies search 3-byte matches (minMatch 3, clevels.h:44-47); from level 10 since round 3, see priceParse
     gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass); gc_env_u32("GC_SHORT_PASS", 0u, 1u, &c->shortPass);   // test hooks
     c->priceMinLen = 3u; c->priceLitCtx = 0u;     // zstd: matches of >= 3 bytes, literals without context (one Huffman table per block)
-    c->priceParse = level >= 16 ? 1u : 0u;        // the reference's btopt / btultra strategies start at level 16 (clevels.h:44-47)
+    c->priceParse = level >= 10 ? 1u : 0u;        // the reference's btopt / btultra strategies start at level 16 (clevels.h:44-47), its levels 10-15 are lazy2 / btlazy2 over deep
+                                                  // chains and trees; the greedy / lazy2 parse over this finder's 3-6 candidates was 1.03 x them on lz-7zip (levels 10 and 12, run r03_z12),
+                                                  // the price-based parse 0.98 -- so it starts at level 10 here
     gc_env_u32("GC_PRICE_PARSE", 0u, 1u, &c->priceParse);                                      // test hook
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     // The input can be taken in frame-aligned PARTS, the finder of part p + 1 (main stream) beside the entropy stage of part p (sequences on
@@ -676,7 +678,8 @@ extern "C" int gc_zstd_phase_profile(gc_ctx* c, double cyclesPerBlock[GC_LZ_PHAS
 static uint32_t flzma2_seg_log(int level)
 {
     { uint32_t v = 0; if (gc_env_u32("GC_SEG_LOG", GC_LZMA_SEG_LOG_MIN, GC_LZMA_SEG_LOG_MAX, &v)) return v; }   // test hook
-    if (level <= 2) return 14u;
+    if (level <= 1) return 14u;
+    if (level == 2) return 17u;     // (run r03_fl2ab, silesia-like 32 MiB: 16 KiB segments 1.032 x the reference's level 2, 32 KiB 1.022, 128 KiB 1.012)
     if (level <= 4) return 15u;
     return 17u;                 // 128 KiB: what the reference's slices are (>= 112 KiB, lzma2_enc.h:22).  Measured (run r2_c, 64 MiB per corpus):
                                 // 32 KiB -> 128 KiB segments is worth 0.9-1.5 % of the level-5 size
@@ -734,11 +737,12 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     c->searchDepth = level >= 5 ? (level >= 8 ? 8u : 2u) : 0u;      // (with the far pass in, links beyond the second add < 0.1 %)
     c->farPass = level >= 3 ? 1u : 0u;            // the reference's match table resolves to depth 42 at level 5 (fl2_compress.c:37-104);
                                                   // level 3 (run 30x, 32 MiB): 1.071 -> 1.026 x the reference on text
-    c->shortPass = level >= 5 ? 1u : 0u;          // ... and holds the nearest match of >= 2 bytes for every position
+    c->shortPass = level >= 3 ? 1u : 0u;          // ... and holds the nearest match of >= 2 bytes for every position
     gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass); gc_env_u32("GC_SHORT_PASS", 0u, 1u, &c->shortPass);   // test hooks
     gc_env_u32("GC_SEARCH_DEPTH", 0u, 8u, &c->searchDepth);
     c->priceMinLen = 2u; c->priceLitCtx = 7u;
-    c->priceParse = level >= 5 ? 1u : 0u;         // the reference's FL2_opt / FL2_ultra strategies start at level 5 (fl2_compress.c:37-104)
+    c->priceParse = level >= 3 ? 1u : 0u;         // the reference's FL2_opt strategy starts at level 3 of its 7-Zip table (fl2_compress.c:52-63); round 3 (run r03_fl2ab): level 3 with
+                                                  // the greedy parse was 1.038 x the reference on silesia-like, with the price-based parse 1.002
     gc_env_u32("GC_PRICE_PARSE", 0u, 1u, &c->priceParse);                                      // test hook: 0 = greedy parse only
     if (frameBlocks > 1u && c->dbgFrameBlocks) frameBlocks = c->dbgFrameBlocks;
     if (frameBlocks > nBlocks) frameBlocks = nBlocks;

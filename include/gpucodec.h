@@ -49,7 +49,7 @@ size_t      gc_zstd_compress_bound(size_t n);
 /* Compress n bytes already resident in device memory into device memory.  Asynchronous on the context's
  * stream; call gc_zstd_finish to synchronise and fetch the size.  `level` follows the reference's -mx
  * scale (1..22) and selects the configuration of the GPU path: levels 1-5 the windowed finder over 8 MiB frames with a one-step lazy parse, 6+ lazy2 and link following, 7+ the far pass
- * (16- / 12-byte keys), 16+ the short pass and the price-based parse. */
+ * (16- / 12-byte keys), 10+ the short pass and the price-based parse. */
 int         gc_zstd_compress_device(gc_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t dstCapacity, int level);
 int         gc_zstd_finish(gc_ctx* ctx, size_t* compressedSize);
 

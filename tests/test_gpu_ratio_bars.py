@@ -29,14 +29,11 @@ def _need(O, name):
 
 # Bars that are NOT met yet are recorded as expected failures with the measured figure (MI355X, runs r03_levels / r03_q1 of round 3 unless a round is
 # named), so that the suite stays green and the gap stays visible; strict=False: the day a bar is met the test simply passes.
-NOT_YET = {("zstd", 12, "lz-7zip"): "1.030 x the reference's level 12 on lz-7zip (round 2; greedy / lazy2 parse over two passes of candidates; the reference searches a hash chain of depth 2^8)",
-           ("zstd", 16, "text-zipf"): "1.024 x btopt (one price-based pass over 3-6 candidates per position; the reference: all matches of a binary tree, adaptive prices)",
+NOT_YET = {("zstd", 16, "text-zipf"): "1.024 x btopt (one price-based pass over 3-6 candidates per position; the reference: all matches of a binary tree, adaptive prices)",
            ("zstd", 19, "text-zipf"): "1.063 x btultra2 (round 2; as level 16; the reference adds a second pass over the first block)",
            ("zstd", 19, "lz-7zip"): "1.059 x btultra2 (round 2)",
            ("zstd", 22, "text-zipf"): "1.076 x the reference's level 22 (btultra2, window 128 MiB; this engine's frames are 8 MiB and levels 16-22 run one configuration)",
            ("zstd", 22, "lz-7zip"): "1.076 x the reference's level 22",
-           ("flzma2", 2, "silesia-like"): "1.032 x the reference's level 2 (model segments of 16 KiB at levels 1-2)",
-           ("flzma2", 3, "silesia-like"): "1.038 x the reference's level 3 (greedy parse + far pass; the reference: FL2_opt)",
            ("flzma2", 7, "text-zipf"): "1.046 x the reference's level 7 (dictionary 64 MiB, FL2_ultra; this engine's frames are 8 MiB and levels 5-7 run one configuration)",
            ("flzma2", 7, "lz-7zip"): "1.079 x the reference's level 7", ("flzma2", 7, "silesia-like"): "1.027 x the reference's level 7",
            ("flzma2", 9, "text-zipf"): "1.047 x the reference's level 9 (dictionary 128 MiB, search depth 254)",
@@ -52,7 +49,7 @@ def _xfail_if_known(codec, level, kind):
         pytest.xfail("known gap: " + why)
 
 
-@pytest.mark.parametrize("level", [5, 7, 9, 12])
+@pytest.mark.parametrize("level", [5, 7, 9, 10, 12])
 @pytest.mark.parametrize("kind", ["text-zipf", "lz-7zip"])
 def test_zstd_lazy_levels_within_2_percent(O, gpu, level, kind):
     _need(O, "zstd")
