@@ -559,6 +559,7 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
                                                   // bound by what they do per tile and per list, not per entry.  The test hook keeps the path exercised.)
     gc_env_u32("GC_HALF_LIST", 0u, 1u, &c->halfList);
     c->searchDepth = zstd_search_depth(level);
+    gc_env_u32("GC_SEARCH_DEPTH", 0u, 64u, &c->searchDepth);                                  // test hook
     c->farPass = level >= 7 ? 1u : 0u;            // where the reference searches chains / trees (lazy2 and up).  Measured (run 29, 32 MiB): level 9
                                                   // 1.027 -> 0.984 x the reference on text, level 12 1.040 -> 1.001 x
     c->shortPass = level >= 10 ? 1u : 0u;         // the reference's btopt strategies search 3-byte matches (minMatch 3, clevels.h:44-47); from level 10 since round 3, see priceParse
@@ -734,12 +735,14 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     uint32_t frameBlocks = flzma2_frame_blocks(level);
     c->lazyDepth = level >= 5 ? 2u : 1u;
     c->halfList = 0; c->mfFast = 0;
-    c->searchDepth = level >= 5 ? (level >= 8 ? 8u : 2u) : 0u;      // (with the far pass in, links beyond the second add < 0.1 %)
+    c->searchDepth = level >= 5 ? (level >= 8 ? 12u : 6u) : 0u;     // links followed per position.  On the stand-in corpora links beyond the second add < 0.1 % (round 2: depth 2);
+                                                                    // on real source text (64 MiB, run r03_depth) depth 2 / 6 / 12 give 1.030 / 1.017 / 1.012 x the reference, on the Python
+                                                                    // library 1.021 / 1.017 / 1.015, for 3.7 / 10 / 18 ms of W5b per 212 MB: depth 6 puts both inside the 2 % band
     c->farPass = level >= 3 ? 1u : 0u;            // the reference's match table resolves to depth 42 at level 5 (fl2_compress.c:37-104);
                                                   // level 3 (run 30x, 32 MiB): 1.071 -> 1.026 x the reference on text
     c->shortPass = level >= 3 ? 1u : 0u;          // ... and holds the nearest match of >= 2 bytes for every position
     gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass); gc_env_u32("GC_SHORT_PASS", 0u, 1u, &c->shortPass);   // test hooks
-    gc_env_u32("GC_SEARCH_DEPTH", 0u, 8u, &c->searchDepth);
+    gc_env_u32("GC_SEARCH_DEPTH", 0u, 64u, &c->searchDepth);
     c->priceMinLen = 2u; c->priceLitCtx = 7u;
     c->priceParse = level >= 3 ? 1u : 0u;         // the reference's FL2_opt strategy starts at level 3 of its 7-Zip table (fl2_compress.c:52-63); round 3 (run r03_fl2ab): level 3 with
                                                   // the greedy parse was 1.038 x the reference on silesia-like, with the price-based parse 1.002
@@ -883,6 +886,7 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     c->lazyDepth = level >= 7 ? 2u : 1u;
     c->halfList = 0; c->mfFast = level <= 6 ? 1u : 0u;        // (qualities 5-6 run the far pass on the fast geometry: 0.97-0.99 x the reference at 15 % less time than on the wide one)
     c->searchDepth = level >= 7 ? (level >= 10 ? 8u : 4u) : 0u;
+    gc_env_u32("GC_SEARCH_DEPTH", 0u, 64u, &c->searchDepth);                                  // test hook
     c->farPass = level >= 5 ? 1u : 0u; c->shortPass = 0;      // longer matches stand in for the context modelling / block splitting B1 lacks
     gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass);                                            // test hook
     c->priceMinLen = 3u; c->priceLitCtx = 0u;     // copies of >= 3 bytes (a 2-byte copy at a fresh distance never pays in brotli), one literal code per meta-block

@@ -817,7 +817,8 @@ MFK(gc_mf_deepen_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint
         const uint32_t pw = wTile + q, p = pTile + q;
         const uint32_t r = RI[pw];
         uint32_t bestLen = r & 0xFFu, bestOff = r >> 8;
-        if (bestLen != 0u && T.tileStart + q + GC_MATCH_CAP + 16u <= T.frameEnd) {
+        // (a capped record cannot be beaten: the links lead to EARLIER positions, i.e. larger offsets at no more than the same length)
+        if (bestLen != 0u && bestLen < GC_MATCH_CAP && T.tileStart + q + GC_MATCH_CAP + 16u <= T.frameEnd) {
             const uint32_t maxLen = (nBlk - p) < GC_MATCH_CAP ? (nBlk - p) : GC_MATCH_CAP;
             const LzW16 me = lz_ld16(wsrc, pw);
             int bestGain = lz_gain(bestLen, bestOff);

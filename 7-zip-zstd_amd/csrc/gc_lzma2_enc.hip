@@ -548,8 +548,8 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
 // loop.  Every shift step takes the 9-bit digit low >> 24 (a byte and the carry into the byte in front of it) out of low:
 //   L3a gc_lzma2_rc_kernel      one LANE per rc chunk (group of chunks): the recurrence, and one 16-bit store per shift step: the digit goes
 //                               back into the word stream the lane is reading, which it has consumed further than it has written (a step shifts at
-//                               most once: p >= 31).  No cache, no pending count, no byte window, no wave-level look at rare cases:
-//                               ~18 vector instructions per coded bit instead of ~40 (8.4 -> X ms on the Silesia stand-in).
+//                               most once: p >= 31).  No cache, no pending count, no byte window, no wave-level look at rare cases
+//                               (8.4 -> 5.95 ms on the Silesia stand-in).
 //   L3b gc_lzma2_rc_fin_kernel  one WAVE per chunk: output byte k = (digit[k-1] & 255) + (digit[k] >> 8) + the carry from byte k + 1; 64 bytes at
 //                               a time from the chunk's end, the carries of a tile resolved by one 64-bit addition of its generate / propagate masks.
 // The bytes are those of the reference's encoder for the same (probability, bit) sequence: n shift steps + 5 flush steps give n + 5 bytes.
@@ -573,14 +573,13 @@ __device__ __forceinline__ void rc_word(LzRc& rc, uint32_t w)
     const bool bit = (w & LZW_BIT) != 0u, direct = (w & LZW_DIRECT) != 0u;
     const uint32_t bound = direct ? rc.range >> 1 : rc_mul24(rc.range >> 11, w & 0x7FFu);
     rc.low += bit ? bound : 0u;
-    const uint32_t range = (bit && !direct) ? rc.range - bound : bound;
-    const bool need = range < (1u << 24);                          // RC_shiftLow; one step always suffices (p >= 31)
-    // no branch: the digit is stored whether or not there is a shift step, and only a step moves the write position on (a slot that did not
-    // count is written again by the next word; the position never passes the word being coded, which is in a register already)
-    rc.dig[rc.nDig] = (uint16_t)(rc.low >> 24);
-    rc.nDig += need ? 1u : 0u;
-    rc.low = need ? (rc.low & 0xFFFFFFull) << 8 : rc.low;
-    rc.range = need ? range << 8 : range;
+    uint32_t range = (bit && !direct) ? rc.range - bound : bound;
+    if (range < (1u << 24)) {                                      // RC_shiftLow; one step always suffices (p >= 31)
+        rc.dig[rc.nDig++] = (uint16_t)(rc.low >> 24);              // (measured against a branch-free form that stores the digit at every bit and only counts it at a
+        rc.low = (rc.low & 0xFFFFFFull) << 8;                      //  shift step: 5.95 ms with the branch, 8.3 ms without -- a store per coded bit costs more than the branch)
+        range <<= 8;
+    }
+    rc.range = range;
 }
 
 extern "C" __global__ void __launch_bounds__(64)
