@@ -735,9 +735,8 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     uint32_t frameBlocks = flzma2_frame_blocks(level);
     c->lazyDepth = level >= 5 ? 2u : 1u;
     c->halfList = 0; c->mfFast = 0;
-    c->searchDepth = level >= 5 ? (level >= 8 ? 12u : 6u) : 0u;     // links followed per position.  On the stand-in corpora links beyond the second add < 0.1 % (round 2: depth 2);
-                                                                    // on real source text (64 MiB, run r03_depth) depth 2 / 6 / 12 give 1.030 / 1.017 / 1.012 x the reference, on the Python
-                                                                    // library 1.021 / 1.017 / 1.015, for 3.7 / 10 / 18 ms of W5b per 212 MB: depth 6 puts both inside the 2 % band
+    c->searchDepth = level >= 5 ? (level >= 8 ? 16u : 12u) : 0u;    // links followed where a tile has long matches, by the positions that start one (two links elsewhere: gc_mf_deepen_kernel).
+                                                                    // Real source text (64 MiB): two links everywhere 1.030 x the reference, six everywhere 1.017 (run r03_depth)
     c->farPass = level >= 3 ? 1u : 0u;            // the reference's match table resolves to depth 42 at level 5 (fl2_compress.c:37-104);
                                                   // level 3 (run 30x, 32 MiB): 1.071 -> 1.026 x the reference on text
     c->shortPass = level >= 3 ? 1u : 0u;          // ... and holds the nearest match of >= 2 bytes for every position

@@ -796,13 +796,23 @@ MFK(gc_mf_verify_short_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize
 // Higher levels search deeper, as the reference does with hash chains / binary trees of growing search depth
 // (ZSTD_HcFindBestMatch zstd_lazy.c:667, searchLog in clevels.h; RMF depth in fl2_compress.c:37-104).  Here the chain is implicit:
 // W5 left at every position p the offset of its best match, i.e. a link to an earlier position c with the same context; c's own
-// record links to a still earlier occurrence, and so on.  One thread per position follows `depth` such links and keeps the
+// record links to a still earlier occurrence, and so on.  One thread per position follows such links and keeps the
 // candidate with the best gain.  Reads the records of W5, writes a second record array (other threads still follow the old links).
+// How MANY links is decided per tile and per position (round 3; measured on the emulator, 4 MiB per corpus, FLZMA2 level 5, size against two
+// links everywhere / links followed):
+//   - the links pay where the data has long repeats with many earlier copies: C++ / Python sources -0.9 % at twelve links for starts and two inside
+//     matches (7.6 M links; six links everywhere: -0.8 % for 13.3 M), shared objects -0.5 %, the Python library -0.4 %; on data whose matches are
+//     short they buy nothing for three times the reads (text -0.18 %, the Silesia stand-in -0.04 %, lz-7zip -0.06 %).  So a tile goes deep
+//     (`depth` links) only if at least one position in 16 has a match of >= 32 bytes, and follows two links otherwise;
+//   - a position INSIDE a match (its record continues the record in front of it) follows two links: what the deeper ones find there, the
+//     match's start has found already, one byte earlier.
 #define MFD_T 256u
+#define MFD_LONG 32u
 extern "C" __global__ void __launch_bounds__(MFD_T)
 MFK(gc_mf_deepen_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per, uint32_t depth,
                     const uint32_t* __restrict__ recIn, uint32_t* __restrict__ recOut)
 {
+    __shared__ uint32_t sLong;
     const uint32_t t = threadIdx.x;
     const uint32_t tile = mf_item(blockIdx.x, per);
     if (tile >= nTiles) return;
@@ -813,17 +823,30 @@ MFK(gc_mf_deepen_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint
     const uint64_t blockBase = T.tileStart & ~(uint64_t)(GC_ZSTD_BLOCK_MAX - 1u);
     const uint32_t nBlk = (uint32_t)((srcSize - blockBase) < GC_ZSTD_BLOCK_MAX ? (srcSize - blockBase) : GC_ZSTD_BLOCK_MAX);
     const uint32_t pTile = (uint32_t)(T.tileStart - blockBase), wTile = (uint32_t)(T.tileStart - T.frameStart);
+    // does the tile have long matches?  (one coalesced pass over its records, which the loop below reads again from the cache)
+    if (t == 0u) sLong = 0;
+    __syncthreads();
+    uint32_t nLong = 0;
+    for (uint32_t q = t; q < T.len; q += MFD_T) nLong += (RI[wTile + q] & 0xFFu) >= MFD_LONG ? 1u : 0u;
+    nLong = gc_wave_sum(nLong);
+    if ((t & 63u) == 0u && nLong) atomicAdd(&sLong, nLong);
+    __syncthreads();
+    const uint32_t shallow = depth < 2u ? depth : 2u;
+    const uint32_t depthStart = sLong * 16u >= T.len ? depth : shallow;
     for (uint32_t q = t; q < T.len; q += MFD_T) {
         const uint32_t pw = wTile + q, p = pTile + q;
         const uint32_t r = RI[pw];
         uint32_t bestLen = r & 0xFFu, bestOff = r >> 8;
         // (a capped record cannot be beaten: the links lead to EARLIER positions, i.e. larger offsets at no more than the same length)
         if (bestLen != 0u && bestLen < GC_MATCH_CAP && T.tileStart + q + GC_MATCH_CAP + 16u <= T.frameEnd) {
+            const uint32_t rp = pw ? RI[pw - 1u] : 0u;
+            const bool inside = (rp >> 8) == bestOff && (rp & 0xFFu) > bestLen;        // the record in front covers this position with the same distance
+            const uint32_t nLinks = inside ? shallow : depthStart;
             const uint32_t maxLen = (nBlk - p) < GC_MATCH_CAP ? (nBlk - p) : GC_MATCH_CAP;
             const LzW16 me = lz_ld16(wsrc, pw);
             int bestGain = lz_gain(bestLen, bestOff);
             uint32_t c = pw - bestOff;
-            for (uint32_t d = 0; d < depth; d++) {
+            for (uint32_t d = 0; d < nLinks; d++) {
                 const uint32_t rc = RI[c];
                 if ((rc & 0xFFu) == 0u) break;
                 const uint32_t c2 = c - (rc >> 8);
