@@ -99,7 +99,8 @@ struct gc_ctx {
     hipEvent_t evPart[GC_MAX_PARTS][GC_PART_EVENTS];   // per input part: stage boundaries (see gc_flzma2_compress_device)
     uint32_t nParts;
     uint32_t lazyDepth;       // W6: 1 = one-step lazy, 2 = lazy2 (set per call from codec + level)
-    uint32_t searchDepth;     // W5b: match links followed per position (0 = W5's two candidates only)
+    uint32_t searchDepth;     // W5b: match links followed per position (0 = W5's two candidates only) -- by the starts of matches in tiles with long matches
+    uint32_t searchShallow;   // ... and everywhere else (gc_mf_deepen_kernel)
     uint32_t shortPass;       // third finder pass with 4- / 3-byte keys; its merged records feed the price-based parse only
     uint32_t farPass;         // second finder pass with 16- / 12-byte keys (longer matches), merged into the records by gain
     uint32_t optSeekTable, optBrotliPlain;   // gc_ctx_set_option
@@ -422,7 +423,7 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
     HIPCHK(c, hipEventRecord(ev[11], st));
     if (c->searchDepth) {                                       // W5b: follow match links (timed with W5)
         uint32_t* rec2 = c->mfRec2 + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
-        GC_LAUNCH(MFSEL(gc_mf_deepen_kernel), perT * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, c->searchDepth, (const uint32_t*)rec, rec2);
+        GC_LAUNCH(MFSEL(gc_mf_deepen_kernel), perT * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, c->searchDepth | (c->searchShallow << 8), (const uint32_t*)rec, rec2);
         rec = rec2;
     }
     HIPCHK(c, hipEventRecord(ev[12], st));
@@ -558,8 +559,8 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
                                                   // gc_lz_window.hip -- was measured at level 3 on 1 GB of text: 43.2 -> 39.0 ms for +3.5-4.5 % size.  Not taken: W3-W5 are
                                                   // bound by what they do per tile and per list, not per entry.  The test hook keeps the path exercised.)
     gc_env_u32("GC_HALF_LIST", 0u, 1u, &c->halfList);
-    c->searchDepth = zstd_search_depth(level);
-    gc_env_u32("GC_SEARCH_DEPTH", 0u, 64u, &c->searchDepth);                                  // test hook
+    c->searchDepth = zstd_search_depth(level); c->searchShallow = c->searchDepth < 2u ? c->searchDepth : 2u;
+    if (gc_env_u32("GC_SEARCH_DEPTH", 0u, 64u, &c->searchDepth)) c->searchShallow = c->searchDepth < 2u ? c->searchDepth : 2u;      // test hook
     c->farPass = level >= 7 ? 1u : 0u;            // where the reference searches chains / trees (lazy2 and up).  Measured (run 29, 32 MiB): level 9
                                                   // 1.027 -> 0.984 x the reference on text, level 12 1.040 -> 1.001 x
     c->shortPass = level >= 10 ? 1u : 0u;         // the reference's btopt strategies search 3-byte matches (minMatch 3, clevels.h:44-47); from level 10 since round 3, see priceParse
@@ -735,13 +736,14 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     uint32_t frameBlocks = flzma2_frame_blocks(level);
     c->lazyDepth = level >= 5 ? 2u : 1u;
     c->halfList = 0; c->mfFast = 0;
+    c->searchShallow = level >= 5 ? 2u : 0u;
     c->searchDepth = level >= 5 ? (level >= 8 ? 16u : 12u) : 0u;    // links followed where a tile has long matches, by the positions that start one (two links elsewhere: gc_mf_deepen_kernel).
                                                                     // Real source text (64 MiB): two links everywhere 1.030 x the reference, six everywhere 1.017 (run r03_depth)
     c->farPass = level >= 3 ? 1u : 0u;            // the reference's match table resolves to depth 42 at level 5 (fl2_compress.c:37-104);
                                                   // level 3 (run 30x, 32 MiB): 1.071 -> 1.026 x the reference on text
     c->shortPass = level >= 3 ? 1u : 0u;          // ... and holds the nearest match of >= 2 bytes for every position
     gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass); gc_env_u32("GC_SHORT_PASS", 0u, 1u, &c->shortPass);   // test hooks
-    gc_env_u32("GC_SEARCH_DEPTH", 0u, 64u, &c->searchDepth);
+    if (gc_env_u32("GC_SEARCH_DEPTH", 0u, 64u, &c->searchDepth)) c->searchShallow = c->searchDepth < 2u ? c->searchDepth : 2u;
     c->priceMinLen = 2u; c->priceLitCtx = 7u;
     c->priceParse = level >= 3 ? 1u : 0u;         // the reference's FL2_opt strategy starts at level 3 of its 7-Zip table (fl2_compress.c:52-63); round 3 (run r03_fl2ab): level 3 with
                                                   // the greedy parse was 1.038 x the reference on silesia-like, with the price-based parse 1.002
@@ -884,8 +886,11 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     uint32_t frameBlocks = brotli_frame_blocks(level, bpcFinder);
     c->lazyDepth = level >= 7 ? 2u : 1u;
     c->halfList = 0; c->mfFast = level <= 6 ? 1u : 0u;        // (qualities 5-6 run the far pass on the fast geometry: 0.97-0.99 x the reference at 15 % less time than on the wide one)
-    c->searchDepth = level >= 7 ? (level >= 10 ? 8u : 4u) : 0u;
-    gc_env_u32("GC_SEARCH_DEPTH", 0u, 64u, &c->searchDepth);                                  // test hook
+    // W5b: from quality 5 the starts of matches in tiles with long matches follow 8 links (12 from quality 10); everywhere else none at qualities 5-6 (the kernel then only
+    // reads a tile's records once: data with short matches pays nothing), two from quality 7.  Quality 6 on real data (run r03_brdepth, four links everywhere):
+    // sources 1.084 -> 1.056 x the reference, the Python library 1.024 -> 1.006
+    c->searchDepth = level >= 5 ? (level >= 10 ? 12u : 8u) : 0u; c->searchShallow = level >= 7 ? 2u : 0u;
+    if (gc_env_u32("GC_SEARCH_DEPTH", 0u, 64u, &c->searchDepth)) c->searchShallow = c->searchDepth < 2u ? c->searchDepth : 2u;      // test hook
     c->farPass = level >= 5 ? 1u : 0u; c->shortPass = 0;      // longer matches stand in for the context modelling / block splitting B1 lacks
     gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass);                                            // test hook
     c->priceMinLen = 3u; c->priceLitCtx = 0u;     // copies of >= 3 bytes (a 2-byte copy at a fresh distance never pays in brotli), one literal code per meta-block

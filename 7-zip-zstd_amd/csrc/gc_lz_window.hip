@@ -803,16 +803,17 @@ MFK(gc_mf_verify_short_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize
 //   - the links pay where the data has long repeats with many earlier copies: C++ / Python sources -0.9 % at twelve links for starts and two inside
 //     matches (7.6 M links; six links everywhere: -0.8 % for 13.3 M), shared objects -0.5 %, the Python library -0.4 %; on data whose matches are
 //     short they buy nothing for three times the reads (text -0.18 %, the Silesia stand-in -0.04 %, lz-7zip -0.06 %).  So a tile goes deep
-//     (`depth` links) only if at least one position in 16 has a match of >= 32 bytes, and follows two links otherwise;
-//   - a position INSIDE a match (its record continues the record in front of it) follows two links: what the deeper ones find there, the
+//     (`depth` links) only if at least one position in 16 has a match of >= 32 bytes, and follows `shallow` links (two; none at brotli 5-6) otherwise;
+//   - a position INSIDE a match (its record continues the record in front of it) follows `shallow` links: what the deeper ones find there, the
 //     match's start has found already, one byte earlier.
 #define MFD_T 256u
 #define MFD_LONG 32u
 extern "C" __global__ void __launch_bounds__(MFD_T)
-MFK(gc_mf_deepen_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per, uint32_t depth,
+MFK(gc_mf_deepen_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per, uint32_t depths /* deep | shallow << 8 */,
                     const uint32_t* __restrict__ recIn, uint32_t* __restrict__ recOut)
 {
     __shared__ uint32_t sLong;
+    const uint32_t depth = depths & 0xFFu, shallow = depths >> 8;
     const uint32_t t = threadIdx.x;
     const uint32_t tile = mf_item(blockIdx.x, per);
     if (tile >= nTiles) return;
@@ -831,7 +832,6 @@ MFK(gc_mf_deepen_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint
     nLong = gc_wave_sum(nLong);
     if ((t & 63u) == 0u && nLong) atomicAdd(&sLong, nLong);
     __syncthreads();
-    const uint32_t shallow = depth < 2u ? depth : 2u;
     const uint32_t depthStart = sLong * 16u >= T.len ? depth : shallow;
     for (uint32_t q = t; q < T.len; q += MFD_T) {
         const uint32_t pw = wTile + q, p = pTile + q;
