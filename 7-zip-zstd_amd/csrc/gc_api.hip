@@ -886,10 +886,10 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     uint32_t frameBlocks = brotli_frame_blocks(level, bpcFinder);
     c->lazyDepth = level >= 7 ? 2u : 1u;
     c->halfList = 0; c->mfFast = level <= 6 ? 1u : 0u;        // (qualities 5-6 run the far pass on the fast geometry: 0.97-0.99 x the reference at 15 % less time than on the wide one)
-    // W5b: from quality 5 the starts of matches in tiles with long matches follow 8 links (12 from quality 10); everywhere else none at qualities 5-6 (the kernel then only
-    // reads a tile's records once: data with short matches pays nothing), two from quality 7.  Quality 6 on real data (run r03_brdepth, four links everywhere):
-    // sources 1.084 -> 1.056 x the reference, the Python library 1.024 -> 1.006
-    c->searchDepth = level >= 5 ? (level >= 10 ? 12u : 8u) : 0u; c->searchShallow = level >= 7 ? 2u : 0u;
+    // W5b from quality 7: four links (eight from quality 10) for the starts of matches in tiles with long matches, two elsewhere.  Qualities 5-6 stay without it: measured
+    // at quality 6 with (8, 0) (run r03_q3): sources 1.084 -> 1.068 x the reference and the Python library 1.024 -> 1.015, but web-text -- config C5's data, whose boilerplate
+    // makes most tiles "long" -- 16.6 -> 9.4 GB/s for 0.3 % of its size
+    c->searchDepth = level >= 7 ? (level >= 10 ? 8u : 4u) : 0u; c->searchShallow = c->searchDepth < 2u ? c->searchDepth : 2u;
     if (gc_env_u32("GC_SEARCH_DEPTH", 0u, 64u, &c->searchDepth)) c->searchShallow = c->searchDepth < 2u ? c->searchDepth : 2u;      // test hook
     c->farPass = level >= 5 ? 1u : 0u; c->shortPass = 0;      // longer matches stand in for the context modelling / block splitting B1 lacks
     gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass);                                            // test hook
