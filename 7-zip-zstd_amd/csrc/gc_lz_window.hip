@@ -672,6 +672,7 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
             }
             if (live[k]) {
                 const uint32_t nr = len ? (((pw - (bestC[k] - 1u)) << 8) | len) : 0u;
+                if (MODE == MF_BASE && len == GC_MATCH_CAP) sWaveTot[1] = 0xFFFFFFFFu;      // "the tile has a capped record": the word held a count (dead since the run offsets were made), never this value
                 if (HALF && nr != 0u) sExt[q[k]] = (uint8_t)bestExt[k];
                 if (!FAR) sRec[q[k]] = nr;
                 else if (nr) { const uint32_t old = sRec[q[k]]; if (old == 0u || lz_gain(len, nr >> 8) > lz_gain(old & 0xFFu, old >> 8)) sRec[q[k]] = nr; }
@@ -704,7 +705,9 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
     // bytes): the pieces then share their offset and leave as one sequence / one LZMA match (K3a, L1 and W7 merge equal offsets).  A lane walks one
     // residue class mod 64 of its wave's share of the tile upwards, so that the record it looks back at is final; the chain is cut where the shares
     // meet (every 1 KiB), which keeps the result independent of the order in which the waves run.
-    if (MODE == MF_BASE || MODE == MF_FAR || MODE == MF_SHORT) {      // (every pass that merges candidates by gain may have replaced a continued record by a nearer one)
+    // (every pass that merges candidates by gain may have replaced a continued record by a nearer one; the first pass knows whether it wrote a capped record at all --
+    //  byte runs aside, which keep their distance 1 anyway -- and most tiles of ordinary text have none: they skip the nine barriers below)
+    if ((MODE == MF_BASE && sWaveTot[1] == 0xFFFFFFFFu) || MODE == MF_FAR || MODE == MF_SHORT) {
         constexpr uint32_t NSUB = MFV_T / 64u;
         const uint32_t subLen = ((T.len + NSUB * 64u - 1u) / (NSUB * 64u)) * 64u;
         const uint32_t sBeg = wave * subLen, sEnd = sBeg + subLen < T.len ? sBeg + subLen : T.len;
