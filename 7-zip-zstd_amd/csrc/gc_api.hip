@@ -136,7 +136,7 @@ struct gc_ctx {
     bool pending; bool timed;
     // zstd decoder (gc_zstd_dec.hip): per-workgroup literal / sequence workspace, frame table, per-frame results, ticket counter
     uint8_t* zdLit; size_t zdLitCap; void* zdSeq; size_t zdSeqCap; GcZdFrame* zdFrames; size_t zdFramesCap; uint64_t* zdResult; uint64_t* zdTot;
-    GcZdBlock* zdBlocks; size_t zdBlocksCap; uint32_t* zdOrder; size_t zdOrderCap; uint32_t* zdReady; size_t zdReadyCap; uint32_t* zdTicket; GcZdPlace* zdPlace; size_t zdPlaceCap; uint32_t* zdPtr; size_t zdPtrCap; uint8_t* zdDone; size_t zdDoneCap; uint32_t* zdFerr; size_t zdFerrCap; uint32_t zdRounds; hipEvent_t zdEv[2]; float zdMs; float zdKms[4];   // last call: whole, and index / literals / sequences / execution kernels
+    GcZdBlock* zdBlocks; size_t zdBlocksCap; uint32_t* zdOrder; size_t zdOrderCap; uint32_t* zdReady; size_t zdReadyCap; uint32_t* zdTicket; GcZdPlace* zdPlace; size_t zdPlaceCap; uint32_t* zdPtr; size_t zdPtrCap; uint8_t* zdDone; size_t zdDoneCap; uint32_t* zdFerr; size_t zdFerrCap; uint32_t zdRounds; hipEvent_t zdEv[2]; float zdMs; float zdKms[4]; int zdSeqvState /* 0 not checked yet, 1 verified on this device, -1 wrong: the one-block-per-wave kernel is used */; bool zdSelfTest;   // last call: whole, and index / literals / sequences / execution kernels
     unsigned long long* prof;  // device: GC_LZ_PHASES + GC_SEQ_PHASES cycle sums, only when profiling is on
     bool profOn; uint32_t profBlocks;
 };
@@ -1027,10 +1027,60 @@ static int zd_grow(gc_ctx* c, void** p, size_t* cap, size_t need)
     return GC_OK;
 }
 
+// Run-time check of the sequences kernel that takes six blocks per wave (gc_zstd_dec_seqv_kernel).  Its lanes exchange values through quad-permute DPP moves
+// which one compiler version folded into their users in a way the MI355X executed wrongly (every match length with extra bits off; right under the emulator
+// and with -amdgpu-dpp-combine=false: profiles/r02_dpp_combine.md).  The source keeps the moves apart with an empty asm and tests/test_abi.py reads the
+// compiled kernel, but the failure mode is SILENT wrong lengths, so every context decodes one known frame through that kernel before it trusts it: a frame
+// of the reference's encoder (level 3; 2475 bytes of content made by the generator below: literals, then matches of 3 .. 1000 bytes, i.e. match-length codes
+// with 0 .. 9 extra bits) -- if the content comes back wrong, the context uses the one-block-per-wave kernel from then on.  ROCm 7.2.0 / hipcc of this image: passes.
+static const uint8_t kZdSelfTestStream[377] = {
+    40,181,47,253,96,171,8,125,11,0,52,19,5,4,139,162,232,28,126,140,152,200,10,190,247,18,179,117,101,245,103,243,254,169,108,127,73,108,172,39,
+    22,218,79,1,118,74,146,246,3,199,77,82,244,139,170,168,159,41,237,196,117,185,84,182,147,194,113,52,116,171,133,223,100,236,190,36,175,89,91,203,
+    203,45,30,103,223,185,137,63,100,222,208,95,213,177,135,229,161,235,98,200,211,24,158,156,28,148,227,23,70,199,187,96,46,72,225,100,198,183,23,188,
+    215,143,54,231,102,52,173,210,255,0,168,5,90,27,130,233,252,77,86,238,231,47,185,154,107,88,250,197,167,115,122,125,95,90,241,98,29,160,171,114,
+    217,36,33,154,147,163,115,117,147,92,162,31,79,47,148,0,25,223,63,234,23,90,141,1,54,37,197,56,3,84,151,97,173,185,30,24,155,32,100,19,
+    69,197,68,134,81,105,187,190,32,165,253,23,61,98,222,238,106,151,106,56,52,182,187,218,79,107,100,247,38,136,252,185,75,83,175,99,213,133,213,164,
+    190,182,242,118,213,1,173,12,221,28,140,146,225,46,152,193,230,37,46,144,119,85,153,131,177,147,73,88,212,44,185,37,133,94,83,17,47,52,242,73,
+    69,228,205,221,78,41,223,155,237,26,39,34,105,132,72,174,86,216,109,110,94,141,1,54,14,117,90,88,51,198,218,45,120,86,180,45,227,192,16,15,
+    0,0,22,48,29,93,1,201,161,21,144,12,101,64,25,232,128,193,49,8,160,52,42,0,40,141,242,60,228,106,24,67,54,71,202,23,161,14,55,146,
+    140,191,227,82,3,208,178,212,152,132,69,135,1,6,207,154,2
+};
+static void zd_selftest_content(uint8_t* buf /* 2475 */)
+{
+    uint32_t s = 12345u, n = 0;
+    auto rnd = [&]() -> uint8_t { s = s * 1664525u + 1013904223u; return (uint8_t)(s >> 24); };
+    for (int i = 0; i < 256; i++) buf[n++] = rnd();
+    static const uint32_t lens[16] = { 37, 70, 131, 258, 19, 300, 45, 1000, 64, 65, 3, 4, 5, 35, 36, 99 };
+    for (uint32_t k = 0; k < 16u; k++) {
+        for (int j = 0; j < 3; j++) buf[n++] = rnd();
+        const uint32_t pos = (k * 37u) % 200u, n0 = n;
+        for (uint32_t i = 0; i < lens[k]; i++) buf[n++] = buf[pos + (i % (n0 - pos))];
+    }
+}
+static void zd_seqv_selftest(gc_ctx* c)
+{
+    c->zdSeqvState = -1;                                   // until proven right
+    c->zdSelfTest = true;
+    uint8_t want[2475], got[2475];
+    zd_selftest_content(want);
+    gc_zstd_frame fr; size_t nf = 0; uint64_t total = 0;
+    uint8_t* dIn = nullptr; uint8_t* dOut = nullptr; size_t produced = 0;
+    if (gc_zstd_scan_frames(kZdSelfTestStream, sizeof(kZdSelfTestStream), &fr, 1, &nf, &total) == GC_OK && nf == 1 && total == sizeof(want) &&
+        hipMalloc((void**)&dIn, sizeof(kZdSelfTestStream) + 64) == hipSuccess && hipMalloc((void**)&dOut, sizeof(want) + 64) == hipSuccess &&
+        hipMemcpy(dIn, kZdSelfTestStream, sizeof(kZdSelfTestStream), hipMemcpyHostToDevice) == hipSuccess &&
+        gc_zstd_decompress_device(c, dIn, sizeof(kZdSelfTestStream), dOut, sizeof(want), &fr, 1, &produced) == GC_OK && produced == sizeof(want) &&
+        hipMemcpy(got, dOut, sizeof(got), hipMemcpyDeviceToHost) == hipSuccess && memcmp(got, want, sizeof(want)) == 0)
+        c->zdSeqvState = 1;
+    hipFree(dIn); hipFree(dOut);
+    c->zdSelfTest = false;
+    c->err[0] = 0;                                          // (a failed check is not an error of the caller's stream)
+}
+
 extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n, void* d_dst, size_t dstCap, const gc_zstd_frame* frames, size_t nFrames, size_t* outSize)
 {
     if (!c || (!d_src && n) || (!d_dst && dstCap) || (!frames && nFrames)) return GC_ERR_PARAM;
     HIPCHK(c, hipSetDevice(c->device));
+    if (c->zdSeqvState == 0 && !c->zdSelfTest) zd_seqv_selftest(c);          // once per context: the six-blocks-per-wave kernel against a known frame
     c->zdMs = 0.f; c->zdKms[0] = c->zdKms[1] = c->zdKms[2] = c->zdKms[3] = 0.f; c->zdRounds = 0;
     if (outSize) *outSize = 0;
     if (!nFrames) return GC_OK;
@@ -1106,6 +1156,8 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
         // enough blocks to fill the machine (1 GB: 25.0 -> 16.0 ms; 256 blocks: 9.7 -> 12.0 ms).  Hook GC_ZD_SEQV = 0 / 1 forces the choice.
         int seqSeveral = nBlocks >= 1024u ? 1 : 0;
         { uint32_t v = 0; if (gc_env_u32("GC_ZD_SEQV", 0, 1, &v)) seqSeveral = (int)v; }
+        if (c->zdSelfTest) seqSeveral = 1;                       // the self-check is about that kernel
+        else if (c->zdSeqvState < 0) seqSeveral = 0;             // it decoded the known frame wrongly on this device / build: not used
         { uint32_t v = 0; if (gc_env_u32("GC_ZD_WIDE", 0, 1, &v)) wide = v != 0u; }
         if (wide) overlap = false;
         if ((rc = zd_grow(c, (void**)&c->zdOrder, &c->zdOrderCap, (size_t)nBlocks * 4u)) != GC_OK) break;
@@ -1220,6 +1272,14 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
     return rc;
 }
 
+extern "C" int gc_zstd_decompress_selfcheck(gc_ctx* c, int* state)
+{
+    if (!c || !state) return GC_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->zdSeqvState == 0) zd_seqv_selftest(c);
+    *state = c->zdSeqvState;
+    return GC_OK;
+}
 extern "C" int gc_zstd_decompress_timing(gc_ctx* c, float* ms) { if (!c || !ms) return GC_ERR_PARAM; *ms = c->zdMs; return GC_OK; }
 extern "C" int gc_zstd_decompress_kernel_timing(gc_ctx* c, float ms[4]) { if (!c || !ms) return GC_ERR_PARAM; for (int i = 0; i < 4; i++) ms[i] = c->zdKms[i]; return GC_OK; }
 

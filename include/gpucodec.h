@@ -232,6 +232,10 @@ int         gc_zstd_scan_prefix(const void* src, size_t n, gc_zstd_frame* frames
 int         gc_zstd_decompress_device(gc_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t dstCapacity,
                                       const gc_zstd_frame* frames, size_t nFrames, size_t* decompressedSize);
 int         gc_zstd_decompress_host(gc_ctx* ctx, const void* src, size_t n, void* dst, size_t dstCapacity, size_t* decompressedSize);
+/* The decoder's run-time self-check: every context decodes one known frame of the reference's encoder through the sequences kernel that takes six blocks
+ * per wave before it trusts that kernel (its lane-to-lane moves were once miscompiled into silently wrong match lengths; on a wrong result the context
+ * uses the one-block-per-wave kernel).  Runs the check if the context has not done so yet; *state = 1 verified, -1 wrong on this device / build. */
+int         gc_zstd_decompress_selfcheck(gc_ctx* ctx, int* state);
 /* HIP-event duration of the decode kernels of the last gc_zstd_decompress_* call */
 int         gc_zstd_decompress_timing(gc_ctx* ctx, float* ms);
 /* ... and of its kernels: ms[0] index, ms[1] literals (second stream, beside the sequences), ms[2] sequences, ms[3] execution */

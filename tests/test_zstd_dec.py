@@ -297,3 +297,22 @@ def test_gpu_damaged_streams_are_refused(pkg, O, gpu_dec):
             refused += 1
     assert refused >= 190
     _check(gpu_dec, bytes(comp), x)                                            # the context still works afterwards
+
+
+def test_emu_decoder_selfcheck(emu_dec):
+    """every context decodes a built-in frame of the reference's encoder through the six-blocks-per-wave sequences kernel before it trusts it"""
+    assert emu_dec.selfcheck() == 1
+
+
+@pytest.mark.gpu
+def test_gpu_decoder_selfcheck(pkg, graft):
+    """... and on the device the check must come back right: -1 would mean the lane-to-lane moves of that kernel were miscompiled again (profiles/r02_dpp_combine.md)"""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    graft.build_hip()
+    d = pkg.ZstdDecoder(device=0)
+    try:
+        assert d.selfcheck() == 1
+    finally:
+        d.close()
