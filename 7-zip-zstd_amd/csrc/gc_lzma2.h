@@ -40,7 +40,8 @@
 #define GC_LZMA_RC_SIZE     (1u << GC_LZMA_RC_LOG)
 #define GC_LZMA_RC_PER_BLOCK (GC_ZSTD_BLOCK_MAX >> GC_LZMA_RC_LOG)
 #define GC_LZMA_RC_STRIDE   (GC_LZMA_RC_SIZE + 1024u)     // bytes of range-coder output reserved per rc chunk (LZMA expands < 2 %)
-#define GC_LZMA_RC_GROUP_MAX 8u                           // rc chunks that may be coded as one LZMA2 chunk (32 KiB: below the 64 KiB of a stored chunk)
+#define GC_LZMA_RC_GROUP_MAX 32u                          // rc chunks that may be coded as one LZMA2 chunk: up to a whole 128 KiB segment where it compresses into GC_LZMA_RC_MERGE_WORDS coded bits
+                                                          // (round 3; 8 before: on data of ratio 12 a chunk header + range-coder flush per 32 KiB was 0.4 % of the stream).  An LZMA2 chunk holds 2 MiB / 64 KiB coded.
 #define GC_LZMA_RC_MERGE_WORDS 49152u                     // ... while their coded bits stay within this many words (4 KiB of literals cost 36864: 9 per byte)
 #define GC_LZMA_SEG_LOG_MIN 14u
 #define GC_LZMA_SEG_LOG_MAX 17u
