@@ -16,6 +16,8 @@
 // throws; allocations are checked.
 #include "gc_7z_abi.h"
 #include "gpucodec.h"
+#include <atomic>
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -89,6 +91,8 @@ struct Shared {
     std::mutex mu;                                    // guards multi / dec creation and the pool
     std::mutex gpu;                                   // one batch on the devices at a time
     gc_multi* multi = nullptr;                        // host scheduler over every visible GPU, two contexts each (csrc/gc_multi.hip)
+    std::atomic<int> multiState{0};                   // 0 not there yet, 1 ready, -1 could not be created
+    std::atomic<int> warm{0};                         // the warm-up thread has been started
     gc_ctx* dec = nullptr;                            // the ZSTD decoder's context (device 0)
     BufSet pool[4]; int nPool = 0;                    // buffer sets handed back by finished Code() calls
 };
@@ -102,9 +106,34 @@ gc_multi* shared_multi(int* rcOut)
     Shared* s = shared();
     if (!s) { *rcOut = GC_ERR_NOMEM; return nullptr; }
     std::lock_guard<std::mutex> lk(s->mu);
-    if (!s->multi) { const int rc = gc_multi_create(&s->multi, nullptr, 0, 2); if (rc != GC_OK) { s->multi = nullptr; *rcOut = rc; return nullptr; } }
+    if (!s->multi) { const int rc = gc_multi_create(&s->multi, nullptr, 0, 2); if (rc != GC_OK) { s->multi = nullptr; s->multiState.store(-1); *rcOut = rc; return nullptr; } }
+    s->multiState.store(1);
     *rcOut = GC_OK;
     return s->multi;
+}
+// Opening the HIP runtime and the devices takes about 0.2 s -- a third of what `7z a` needs for 1 GB.  It is started in the background as soon as the host asks for an
+// encoder object, and Code() spends the wait reading input (the host's reader computes its CRC there): a started `7z a` then pays max(start-up, reading), not their sum.
+unsigned test_env_u32(const char* name)                // test hooks of the plugin: compiled in only for the emulator module (tests/emu/Makefile)
+{
+#ifdef GC_PLUGIN_TEST_HOOKS
+    const char* v = getenv(name);
+    return v ? (unsigned)strtoul(v, nullptr, 10) : 0u;
+#else
+    (void)name; return 0u;
+#endif
+}
+void warm_up_async()
+{
+    Shared* s = shared();
+    int zero = 0;
+    if (!s || !s->warm.compare_exchange_strong(zero, 1)) return;
+    try {
+        std::thread([]() {
+            const unsigned delay = test_env_u32("GC_PLUGIN_WARM_DELAY_MS");        // (test hook: a slow start-up on a machine that has none)
+            if (delay) std::this_thread::sleep_for(std::chrono::milliseconds(delay));
+            int rc; shared_multi(&rc);
+        }).detach();
+    } catch (...) {}                                   // no thread to be had: Code() creates the scheduler itself
 }
 gc_ctx* shared_dec_ctx()
 {
@@ -219,12 +248,28 @@ public:
     HRESULT Code(ISequentialInStream* in, ISequentialOutStream* out, const uint64_t*, const uint64_t*, ICompressProgressInfo* progress) override
     {
         if (!in || !out) return E_INVALIDARG;
+        size_t piece = gc_multi_piece_bytes(codec(), level_);
+        { const unsigned kib = test_env_u32("GC_PLUGIN_PIECE_KIB"); if (kib) piece = (size_t)kib << 10; }       // (test hook: pieces an emulator can chew)
+        // While the scheduler is still being created (warm_up_async), read ahead: pieces into ordinary memory, at most 16 of them / 1 GiB.  They are
+        // compressed first, in order, by the helper thread, while this thread goes on reading into the pinned buffers.
+        warm_up_async();
+        struct Early { uint8_t* p; size_t n; } early[16]; unsigned nEarly = 0; size_t earlyBytes = 0; bool earlyEof = false;
+        struct EarlyFree { Early* e; unsigned* n; ~EarlyFree() { for (unsigned i = 0; i < *n; i++) free(e[i].p); } } earlyFree{ early, &nEarly };
+        while (shared() && shared()->multiState.load() == 0 && nEarly < 16u && earlyBytes + piece <= ((size_t)1 << 30) && !earlyEof) {
+            uint8_t* p = (uint8_t*)malloc(piece);
+            if (!p) break;
+            size_t got = piece;
+            const HRESULT r = read_full(in, p, &got);
+            if (r != S_OK) { free(p); return r; }
+            if (got == 0) { free(p); earlyEof = nEarly != 0u; break; }       // (an empty input goes through the loop below, which codes the empty stream)
+            early[nEarly].p = p; early[nEarly].n = got; nEarly++; earlyBytes += got;
+            if (got < piece) earlyEof = true;
+        }
         int mrc = GC_OK;
         gc_multi* const multi = shared_multi(&mrc);
         if (!multi) return hresult_of(mrc);
         // a batch = whole pieces, one per worker, but at most 1 GiB (and at least one piece): three pinned buffers of that size are all the
         // host memory a coder takes, whatever the number of GPUs
-        const size_t piece = gc_multi_piece_bytes(codec(), level_);
         size_t perBatch = (size_t)gc_multi_workers(multi), most = ((size_t)1 << 30) / piece;
         if (perBatch > most) perBatch = most;
         if (perBatch < 1) perBatch = 1;
@@ -247,18 +292,35 @@ public:
             return progress ? progress->SetRatioInfo(&totalIn, &totalOut) : S_OK;
         };
         HRESULT res = S_OK;
-        for (unsigned batchIdx = 0;; batchIdx++) {
-            uint8_t* const buf = B.in[batchIdx & 1u];
+        unsigned segIdx = 0;                                   // gc_multi calls handed out so far: the first one of a plain brotli stream carries the stream header
+        auto flags_of = [&](unsigned idx) -> unsigned {       // FLZMA2: one end marker behind the last call; plain brotli: the closing meta-block behind the last
+            return kind_ == KIND_FLZMA2 ? GC_FLZMA2_NO_END_MARK : plainBrotli_ ? (GC_BROTLI_PLAIN | GC_BROTLI_NOT_LAST | (idx != 0 ? GC_BROTLI_NOT_FIRST : 0u)) : 0u;
+        };
+        if (nEarly) {                                          // the pieces read ahead: one call each, in order, on the helper thread
+            job.got = earlyBytes; job.produced = 0; job.hr = S_OK; job.active = true;
+            const unsigned first = segIdx; segIdx += nEarly;
+            auto work = [this, multi, &early, nEarly, first, &flags_of, out, outBuf, outCap, &job]() {
+                for (unsigned i = 0; i < nEarly && job.hr == S_OK; i++) {
+                    size_t produced = 0; int rc;
+                    { std::lock_guard<std::mutex> g(shared()->gpu); rc = gc_multi_compress_host(multi, codec(), early[i].p, early[i].n, outBuf, outCap, level_, flags_of(first + i), 0, &produced); }
+                    job.hr = rc != GC_OK ? hresult_of(rc) : write_all(out, outBuf, produced);
+                    job.produced += produced;
+                }
+            };
+            try { job.th = std::thread(work); }
+            catch (...) { job.active = false; work(); if (job.hr != S_OK) return job.hr; totalIn += earlyBytes; totalOut += job.produced; }
+        }
+        for (; !earlyEof;) {
+            uint8_t* const buf = B.in[segIdx & 1u];
             size_t got = inCap;
             HRESULT r = read_full(in, buf, &got);
             HRESULT f = finish();
             if (r != S_OK) { res = r; break; }
             if (f != S_OK) { res = f; break; }
-            if (got == 0 && (batchIdx != 0 || kind_ == KIND_FLZMA2)) break;
-            // FLZMA2: one end marker behind the last batch; plain brotli: stream header in the first batch, the closing meta-block behind the last
-            const unsigned fl = kind_ == KIND_FLZMA2 ? GC_FLZMA2_NO_END_MARK
-                              : plainBrotli_ ? (GC_BROTLI_PLAIN | GC_BROTLI_NOT_LAST | (batchIdx != 0 ? GC_BROTLI_NOT_FIRST : 0u)) : 0u;
+            if (got == 0 && (segIdx != 0 || kind_ == KIND_FLZMA2)) break;
+            const unsigned fl = flags_of(segIdx);
             if (plainBrotli_ && got == 0) break;
+            segIdx++;
             job.got = got; job.produced = 0; job.hr = S_OK; job.active = true;
             auto work = [this, multi, buf, got, fl, out, outBuf, outCap, &job]() {
                 int rc;
@@ -413,6 +475,7 @@ HRESULT create_encoder(uint32_t index, const GUID* iid, void** out)
     *out = nullptr;
     if (index >= kNumMethods) return CLASS_E_CLASSNOTAVAILABLE;
     if (!iid || !(*iid == IID_ICompressCoder)) return E_NOINTERFACE;     // 1-stream, non-filter codecs only (CodecExports.cpp:127-150)
+    warm_up_async();                                       // the devices are opened while the host sets the coder up and reads its first input
     CGpuEncoder* e = new (std::nothrow) CGpuEncoder(kMethods[index].kind);
     IUnknown* obj = e ? static_cast<ICompressCoder*>(e) : nullptr;
     if (!obj) return E_OUTOFMEMORY;
