@@ -253,17 +253,16 @@ public:
         // While the scheduler is still being created (warm_up_async), read ahead: pieces into ordinary memory, at most 16 of them / 1 GiB.  They are
         // compressed first, in order, by the helper thread, while this thread goes on reading into the pinned buffers.
         warm_up_async();
-        // (one region, so that the helper thread can hand it to the scheduler in slices of a whole batch: every context works, as on the pinned path)
-        const size_t earlyCap = piece <= ((size_t)1 << 30) / 16u ? 16u * piece : (((size_t)1 << 30) / piece ? ((size_t)1 << 30) / piece * piece : piece);
-        uint8_t* early = nullptr; size_t earlyBytes = 0; bool earlyEof = false;
-        struct EarlyFree { uint8_t** p; ~EarlyFree() { free(*p); } } earlyFree{ &early };
-        while (shared() && shared()->multiState.load() == 0 && earlyBytes + piece <= earlyCap && !earlyEof) {
-            if (!early && !(early = (uint8_t*)malloc(earlyCap))) break;           // (address space; pages are touched as pieces arrive)
+        struct Early { uint8_t* p; size_t n; } early[16]; unsigned nEarly = 0; size_t earlyBytes = 0; bool earlyEof = false;
+        struct EarlyFree { Early* e; unsigned* n; ~EarlyFree() { for (unsigned i = 0; i < *n; i++) free(e[i].p); } } earlyFree{ early, &nEarly };
+        while (shared() && shared()->multiState.load() == 0 && nEarly < 16u && earlyBytes + piece <= ((size_t)1 << 30) && !earlyEof) {
+            uint8_t* p = (uint8_t*)malloc(piece);
+            if (!p) break;
             size_t got = piece;
-            const HRESULT r = read_full(in, early + earlyBytes, &got);
-            if (r != S_OK) return r;
-            if (got == 0) { earlyEof = earlyBytes != 0u; break; }                  // (an empty input goes through the loop below, which codes the empty stream)
-            earlyBytes += got;
+            const HRESULT r = read_full(in, p, &got);
+            if (r != S_OK) { free(p); return r; }
+            if (got == 0) { free(p); earlyEof = nEarly != 0u; break; }       // (an empty input goes through the loop below, which codes the empty stream)
+            early[nEarly].p = p; early[nEarly].n = got; nEarly++; earlyBytes += got;
             if (got < piece) earlyEof = true;
         }
         int mrc = GC_OK;
@@ -297,14 +296,13 @@ public:
         auto flags_of = [&](unsigned idx) -> unsigned {       // FLZMA2: one end marker behind the last call; plain brotli: the closing meta-block behind the last
             return kind_ == KIND_FLZMA2 ? GC_FLZMA2_NO_END_MARK : plainBrotli_ ? (GC_BROTLI_PLAIN | GC_BROTLI_NOT_LAST | (idx != 0 ? GC_BROTLI_NOT_FIRST : 0u)) : 0u;
         };
-        if (earlyBytes) {                                      // the pieces read ahead: slices of one batch each, in order, on the helper thread
+        if (nEarly) {                                          // the pieces read ahead: one call each, in order, on the helper thread
             job.got = earlyBytes; job.produced = 0; job.hr = S_OK; job.active = true;
-            const unsigned first = segIdx, nSlices = (unsigned)((earlyBytes + inCap - 1u) / inCap); segIdx += nSlices;
-            auto work = [this, multi, early, earlyBytes, inCap, nSlices, first, &flags_of, out, outBuf, outCap, &job]() {
-                for (unsigned i = 0; i < nSlices && job.hr == S_OK; i++) {
-                    const size_t off = (size_t)i * inCap, len = earlyBytes - off < inCap ? earlyBytes - off : inCap;
+            const unsigned first = segIdx; segIdx += nEarly;
+            auto work = [this, multi, &early, nEarly, first, &flags_of, out, outBuf, outCap, &job]() {
+                for (unsigned i = 0; i < nEarly && job.hr == S_OK; i++) {
                     size_t produced = 0; int rc;
-                    { std::lock_guard<std::mutex> g(shared()->gpu); rc = gc_multi_compress_host(multi, codec(), early + off, len, outBuf, outCap, level_, flags_of(first + i), 0, &produced); }
+                    { std::lock_guard<std::mutex> g(shared()->gpu); rc = gc_multi_compress_host(multi, codec(), early[i].p, early[i].n, outBuf, outCap, level_, flags_of(first + i), 0, &produced); }
                     job.hr = rc != GC_OK ? hresult_of(rc) : write_all(out, outBuf, produced);
                     job.produced += produced;
                 }
