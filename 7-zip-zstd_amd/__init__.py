@@ -31,7 +31,7 @@ EXPORTS = ["gc_test_hooks_enabled", "gc_lzfind_get_matches_device", "gc_device_c
            "gc_ctx_set_option", "gc_crc32_device", "gc_codec_grain", "gc_codec_compress_bound", "gc_host_begin", "gc_host_size", "gc_host_fetch", "gc_codec_compress_host",
            "gc_host_alloc", "gc_host_free", "gc_multi_create", "gc_multi_destroy", "gc_multi_workers", "gc_multi_last_error",
            "gc_multi_piece_bytes", "gc_multi_compress_host",
-           "gc_bra_convert_device", "gc_bra_x86_convert_device", "gc_delta_convert_device", "gc_zstd_scan_frames", "gc_zstd_scan_prefix", "gc_zstd_decompress_device", "gc_zstd_decompress_host", "gc_zstd_decompress_timing", "gc_zstd_decompress_kernel_timing", "gc_zstd_decompress_wide_rounds", "gc_zstd_decompress_selfcheck"]
+           "gc_bra_convert_device", "gc_bra_x86_convert_device", "gc_delta_convert_device", "gc_zstd_scan_frames", "gc_zstd_scan_prefix", "gc_zstd_decompress_device", "gc_zstd_decompress_host", "gc_zstd_decompress_timing", "gc_zstd_decompress_kernel_timing", "gc_zstd_decompress_wide_rounds", "gc_zstd_decompress_selfcheck", "gc_filter_host"]
 
 CODEC_ZSTD, CODEC_FLZMA2, CODEC_BROTLI = 0, 1, 2
 CODEC_IDS = {"zstd": CODEC_ZSTD, "flzma2": CODEC_FLZMA2, "brotli": CODEC_BROTLI}

@@ -1272,6 +1272,31 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
     return rc;
 }
 
+// One Filter() call of a 7-Zip pre-filter on a host buffer (include/gpucodec.h): the context's device buffers of the host-buffer decoder serve as staging.
+extern "C" int gc_filter_host(gc_ctx* c, int kind, void* data, size_t n, uint32_t pc, int encoding, unsigned delta, unsigned char* state, size_t* processed)
+{
+    if (processed) *processed = 0;
+    if (!c || (!data && n)) return GC_ERR_PARAM;
+    const bool x86 = kind == GC_FILTER_X86, dl = kind == GC_FILTER_DELTA;
+    if (!x86 && !dl && (kind < GC_BRA_ARM64 || kind > GC_BRA_RISCV)) return GC_ERR_PARAM;
+    if ((x86 || dl) && !state) return GC_ERR_PARAM;
+    if (dl && (delta < 1u || delta > 256u)) return GC_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!n) return GC_OK;
+    if (n > c->dInCap) { hipFree(c->dIn); c->dIn = nullptr; c->dInCap = 0; if (hipMalloc((void**)&c->dIn, n + 64) != hipSuccess) return GC_ERR_NOMEM; c->dInCap = n; }
+    if (n > c->dOutCap) { hipFree(c->dOut); c->dOut = nullptr; c->dOutCap = 0; if (hipMalloc((void**)&c->dOut, n + 64) != hipSuccess) return GC_ERR_NOMEM; c->dOutCap = n; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));                      // (the converters run on the default stream)
+    HIPCHK(c, hipMemcpy(c->dIn, data, n, hipMemcpyHostToDevice));
+    size_t done = 0; int rc;
+    if (x86) { uint32_t st; memcpy(&st, state, 4); rc = gc_bra_x86_convert_device(c->dIn, c->dOut, n, pc, encoding, &st, &done); memcpy(state, &st, 4); }
+    else if (dl) { rc = gc_delta_convert_device(c->dIn, c->dOut, n, delta, encoding, state); done = n; }
+    else rc = gc_bra_convert_device(kind, c->dIn, c->dOut, n, pc, encoding, &done);
+    if (rc != GC_OK) { snprintf(c->err, sizeof(c->err), "filter %d failed on the device", kind); return rc; }
+    HIPCHK(c, hipMemcpy(data, c->dOut, n, hipMemcpyDeviceToHost));   // (bytes behind `done` come back unchanged)
+    if (processed) *processed = done;
+    return GC_OK;
+}
+
 extern "C" int gc_zstd_decompress_selfcheck(gc_ctx* c, int* state)
 {
     if (!c || !state) return GC_ERR_PARAM;

@@ -81,6 +81,7 @@ static const GUID IID_ICompressSetCoderProperties    = GC_7Z_IID(4, 0x20);
 static const GUID IID_ICompressSetDecoderProperties2 = GC_7Z_IID(4, 0x22);
 static const GUID IID_ICompressWriteCoderProperties  = GC_7Z_IID(4, 0x23);
 static const GUID IID_ICompressSetCoderMt            = GC_7Z_IID(4, 0x25);
+static const GUID IID_ICompressFilter                = GC_7Z_IID(4, 0x40);      // ICoder.h:362-365
 
 // class ids: {23170F69-40C1-2791(encoder)/2790(decoder)-<method id as 8 little-endian bytes>}  CodecExports.cpp:44-52
 static inline GUID gc_codec_clsid(uint64_t methodId, bool encoder)
@@ -106,8 +107,9 @@ struct ICompressSetCoderPropertiesOpt : IUnknown { virtual HRESULT SetCoderPrope
 struct ICompressSetCoderProperties : IUnknown { virtual HRESULT SetCoderProperties(const PROPID* ids, const PROPVARIANT* props, uint32_t n) = 0; };
 struct ICompressWriteCoderProperties : IUnknown { virtual HRESULT WriteCoderProperties(ISequentialOutStream* out) = 0; };
 struct ICompressSetCoderMt : IUnknown { virtual HRESULT SetNumberOfThreads(uint32_t n) = 0; };
+struct ICompressFilter : IUnknown { virtual HRESULT Init() = 0; virtual uint32_t Filter(uint8_t* data, uint32_t size) = 0; };      // ICoder.h:320-365
 struct ICompressSetDecoderProperties2 : IUnknown { virtual HRESULT SetDecoderProperties2(const uint8_t* data, uint32_t size) = 0; };   // ICoder.h:187-189
 
-namespace NCoderPropID { enum { kDefaultProp = 0, kDictionarySize = 1, kNumThreads = 13, kLevel = 15, kReduceSize = 16, kExpectedDataSize = 17 }; }
+namespace NCoderPropID { enum { kDefaultProp = 0, kDictionarySize = 1, kNumThreads = 13, kLevel = 15, kReduceSize = 16, kExpectedDataSize = 17, kBranchOffset = 23 }; }
 namespace NMethodPropID { enum { kID = 0, kName, kDecoder, kEncoder, kPackStreams, kUnpackStreams, kDescription, kDecoderIsAssigned, kEncoderIsAssigned, kDigestSize, kIsFilter }; }
 namespace NModulePropID { enum { kInterfaceType = 0, kVersion = 1 }; }

@@ -28,20 +28,32 @@
 
 namespace {
 
-struct MethodInfo { uint64_t id; const char* name; int kind; };
-enum { KIND_ZSTD = 0, KIND_FLZMA2 = 1, KIND_BROTLI = 2 };
+struct MethodInfo { uint64_t id; const char* name; int kind; int filter; /* -1: a codec; else the gc_filter_host kind of a pre-filter (round 3) */ unsigned align; };
+enum { KIND_ZSTD = 0, KIND_FLZMA2 = 1, KIND_BROTLI = 2, KIND_FILTER = 3 };
 // Names and ids as registered by the reference (CPP/7zip/Compress/ZstdRegister.cpp:13-17, FastLzma2Register.cpp:13-18,
 // BrotliRegister.cpp:13-17).  A host that has these codecs built in (the reference's own 7z.so) resolves a method NAME to its
 // built-in encoder first (FindMethod_Index, CPP/7zip/Common/CreateCoder.cpp:160-204), so every method is registered a second
 // time under an alias with the SAME id -- the way FastLzma2Register.cpp:13-18 registers FLZMA2 beside LZMA2 under id 0x21:
 // `7z a -m0=ZSTDGPU` then runs this module's encoder, the archive records only the id, and any 7-Zip-zstd decodes it.
 const MethodInfo kMethods[] = {
-    { 0x4F71101, "ZSTD", KIND_ZSTD },
-    { 0x21, "FLZMA2", KIND_FLZMA2 },
-    { 0x4F71102, "BROTLI", KIND_BROTLI },
-    { 0x4F71101, "ZSTDGPU", KIND_ZSTD },
-    { 0x21, "FLZMA2GPU", KIND_FLZMA2 },
-    { 0x4F71102, "BROTLIGPU", KIND_BROTLI },
+    { 0x4F71101, "ZSTD", KIND_ZSTD, -1, 0 },
+    { 0x21, "FLZMA2", KIND_FLZMA2, -1, 0 },
+    { 0x4F71102, "BROTLI", KIND_BROTLI, -1, 0 },
+    { 0x4F71101, "ZSTDGPU", KIND_ZSTD, -1, 0 },
+    { 0x21, "FLZMA2GPU", KIND_FLZMA2, -1, 0 },
+    { 0x4F71102, "BROTLIGPU", KIND_BROTLI, -1, 0 },
+    // 7-Zip's pre-filters on the device, under names of their own with the reference's ids (BcjRegister.cpp:12-15, BranchRegister.cpp:33-57,
+    // DeltaFilter.cpp:121-124): `7z a -m0=BCJGPU -m1=ZSTDGPU` runs both on the GPU and any 7-Zip extracts the archive with its built-in filters;
+    // `align`: the alignment mask of the branch offset property (BranchRegister.cpp:56-57)
+    { 0x3030103, "BCJGPU", KIND_FILTER, GC_FILTER_X86, 0 },
+    { 0x3030205, "PPCGPU", KIND_FILTER, GC_BRA_PPC, 0 },
+    { 0x3030401, "IA64GPU", KIND_FILTER, GC_BRA_IA64, 0 },
+    { 0x3030501, "ARMGPU", KIND_FILTER, GC_BRA_ARM, 0 },
+    { 0x3030701, "ARMTGPU", KIND_FILTER, GC_BRA_ARMT, 0 },
+    { 0x3030805, "SPARCGPU", KIND_FILTER, GC_BRA_SPARC, 0 },
+    { 0xA, "ARM64GPU", KIND_FILTER, GC_BRA_ARM64, 3 },
+    { 0xB, "RISCVGPU", KIND_FILTER, GC_BRA_RISCV, 1 },
+    { 3, "DELTAGPU", KIND_FILTER, GC_FILTER_DELTA, 0 },
 };
 const uint32_t kNumMethods = sizeof(kMethods) / sizeof(kMethods[0]);
 
@@ -456,10 +468,94 @@ public:
     }
 };
 
+// A pre-filter object: NCompress::NBranch::CCoder / CEncoder / CDecoder (BranchMisc.cpp:14-118), NCompress::NBcj::CCoder2 (BcjCoder.cpp:10-22) and
+// NCompress::NDelta::CEncoder / CDecoder (DeltaFilter.cpp:28-119) over gc_filter_host: every Filter() call takes the host's buffer to the device, converts it
+// there and brings it back; the program counter, the x86 converter's state word and the Delta filter's 256 bytes of history are carried from call to call.
+class CGpuFilter final : public ICompressFilter, public ICompressSetCoderProperties, public ICompressWriteCoderProperties, public ICompressSetDecoderProperties2 {
+    ULONG refs_ = 1;
+    const int kind_; const bool encoding_; const unsigned align_;
+    uint32_t pc_ = 0, pcInit_ = 0;
+    unsigned delta_ = 1;
+    unsigned char state_[256];
+    bool hasPcProp() const { return kind_ == GC_BRA_ARM64 || kind_ == GC_BRA_RISCV; }
+public:
+    CGpuFilter(int kind, bool encoding, unsigned align) : kind_(kind), encoding_(encoding), align_(align) { memset(state_, 0, sizeof(state_)); }
+    HRESULT QueryInterface(const GUID& iid, void** out) override
+    {
+        if (!out) return E_INVALIDARG;
+        *out = nullptr;
+        if (iid == IID_IUnknown || iid == IID_ICompressFilter) *out = static_cast<ICompressFilter*>(this);
+        else if (encoding_ && (hasPcProp() || kind_ == GC_FILTER_DELTA) && iid == IID_ICompressSetCoderProperties) *out = static_cast<ICompressSetCoderProperties*>(this);
+        else if (encoding_ && (hasPcProp() || kind_ == GC_FILTER_DELTA) && iid == IID_ICompressWriteCoderProperties) *out = static_cast<ICompressWriteCoderProperties*>(this);
+        else if (!encoding_ && (hasPcProp() || kind_ == GC_FILTER_DELTA) && iid == IID_ICompressSetDecoderProperties2) *out = static_cast<ICompressSetDecoderProperties2*>(this);
+        else return E_NOINTERFACE;
+        ++refs_;
+        return S_OK;
+    }
+    ULONG AddRef() override { return ++refs_; }
+    ULONG Release() override { if (--refs_ != 0) return refs_; delete this; return 0; }
+
+    HRESULT Init() override { pc_ = pcInit_; memset(state_, 0, sizeof(state_)); return S_OK; }      // Z7_BRANCH_CONV_ST_X86_STATE_INIT_VAL = 0, Delta_Init: zeros
+    uint32_t Filter(uint8_t* data, uint32_t size) override
+    {
+        gc_ctx* const ctx = shared_dec_ctx();
+        if (!ctx || !size) return 0;                               // (no device: nothing is converted -- the host's coder then stops with its own error)
+        size_t done = 0; int rc;
+        { std::lock_guard<std::mutex> g(shared()->gpu); rc = gc_filter_host(ctx, kind_, data, size, pc_, encoding_ ? 1 : 0, delta_, state_, &done); }
+        if (rc != GC_OK) return 0;
+        pc_ += (uint32_t)done;
+        return (uint32_t)done;
+    }
+    HRESULT SetCoderProperties(const PROPID* ids, const PROPVARIANT* props, uint32_t n) override
+    {
+        uint32_t pc = 0; unsigned delta = delta_;
+        for (uint32_t i = 0; i < n; i++) {
+            if (kind_ == GC_FILTER_DELTA) {                        // DeltaFilter.cpp:53-80
+                if (ids[i] >= NCoderPropID::kReduceSize) continue;
+                if (props[i].vt != VT_UI4) return E_INVALIDARG;
+                if (ids[i] == NCoderPropID::kDefaultProp) { if (props[i].ulVal < 1 || props[i].ulVal > 256) return E_INVALIDARG; delta = props[i].ulVal; }
+                else if (ids[i] != NCoderPropID::kNumThreads && ids[i] != NCoderPropID::kLevel) return E_INVALIDARG;
+            } else if (ids[i] == NCoderPropID::kDefaultProp || ids[i] == NCoderPropID::kBranchOffset) {      // BranchMisc.cpp:44-63
+                if (props[i].vt != VT_UI4) return E_INVALIDARG;
+                pc = props[i].ulVal;
+                if (pc & align_) return E_INVALIDARG;
+            }
+        }
+        delta_ = delta; pcInit_ = pc;
+        return S_OK;
+    }
+    HRESULT WriteCoderProperties(ISequentialOutStream* out) override
+    {
+        if (kind_ == GC_FILTER_DELTA) { const uint8_t p = (uint8_t)(delta_ - 1u); return write_all(out, &p, 1); }       // DeltaFilter.cpp:82-86
+        if (pcInit_ == 0) return S_OK;                             // BranchMisc.cpp:66-73
+        const uint8_t b[4] = { (uint8_t)pcInit_, (uint8_t)(pcInit_ >> 8), (uint8_t)(pcInit_ >> 16), (uint8_t)(pcInit_ >> 24) };
+        return write_all(out, b, 4);
+    }
+    HRESULT SetDecoderProperties2(const uint8_t* p, uint32_t size) override
+    {
+        if (kind_ == GC_FILTER_DELTA) { if (size != 1) return E_INVALIDARG; delta_ = (unsigned)p[0] + 1u; return S_OK; }       // DeltaFilter.cpp:112-118
+        uint32_t v = 0;                                            // BranchMisc.cpp:103-116
+        if (size != 0) { if (size != 4) return E_NOTIMPL; v = (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); if (v & align_) return E_NOTIMPL; }
+        pcInit_ = v;
+        return S_OK;
+    }
+};
+
+HRESULT create_filter(uint32_t index, bool encoding, const GUID* iid, void** out)
+{
+    if (!iid || !(*iid == IID_ICompressFilter)) return E_NOINTERFACE;          // CodecExports.cpp:127-150: filters are created through ICompressFilter
+    CGpuFilter* f = new (std::nothrow) CGpuFilter(kMethods[index].filter, encoding, kMethods[index].align);
+    IUnknown* obj = f ? static_cast<ICompressFilter*>(f) : nullptr;
+    if (!obj) return E_OUTOFMEMORY;
+    *out = obj;
+    return S_OK;
+}
+
 HRESULT create_decoder(uint32_t index, const GUID* iid, void** out)
 {
     if (!out) return E_INVALIDARG;
     *out = nullptr;
+    if (index < kNumMethods && kMethods[index].kind == KIND_FILTER) return create_filter(index, false, iid, out);
     if (index >= kNumMethods || kMethods[index].kind != KIND_ZSTD) return CLASS_E_CLASSNOTAVAILABLE;
     if (!iid || !(*iid == IID_ICompressCoder)) return E_NOINTERFACE;
     CGpuZstdDecoder* d = new (std::nothrow) CGpuZstdDecoder();
@@ -474,7 +570,8 @@ HRESULT create_encoder(uint32_t index, const GUID* iid, void** out)
     if (!out) return E_INVALIDARG;
     *out = nullptr;
     if (index >= kNumMethods) return CLASS_E_CLASSNOTAVAILABLE;
-    if (!iid || !(*iid == IID_ICompressCoder)) return E_NOINTERFACE;     // 1-stream, non-filter codecs only (CodecExports.cpp:127-150)
+    if (kMethods[index].kind == KIND_FILTER) return create_filter(index, true, iid, out);
+    if (!iid || !(*iid == IID_ICompressCoder)) return E_NOINTERFACE;     // the 1-stream codecs (CodecExports.cpp:127-150)
     warm_up_async();                                       // the devices are opened while the host sets the coder up and reads its first input
     CGpuEncoder* e = new (std::nothrow) CGpuEncoder(kMethods[index].kind);
     IUnknown* obj = e ? static_cast<ICompressCoder*>(e) : nullptr;
@@ -502,13 +599,13 @@ GC_EXPORT HRESULT GetMethodProperty(uint32_t index, PROPID propID, PROPVARIANT* 
         }
         case NMethodPropID::kEncoderIsAssigned: value->vt = VT_BOOL; value->boolVal = -1; break;   // VARIANT_TRUE
         case NMethodPropID::kDecoder:
-            if (m.kind == KIND_ZSTD) {
+            if (m.kind == KIND_ZSTD || m.kind == KIND_FILTER) {
                 GUID g = gc_codec_clsid(m.id, false);
                 value->bstrVal = gc_bstr_bytes(&g, sizeof(g)); if (!value->bstrVal) return E_OUTOFMEMORY; value->vt = VT_BSTR;
             }
             break;
-        case NMethodPropID::kDecoderIsAssigned: value->vt = VT_BOOL; value->boolVal = m.kind == KIND_ZSTD ? -1 : 0; break;
-        case NMethodPropID::kIsFilter: value->vt = VT_BOOL; value->boolVal = 0; break;
+        case NMethodPropID::kDecoderIsAssigned: value->vt = VT_BOOL; value->boolVal = (m.kind == KIND_ZSTD || m.kind == KIND_FILTER) ? -1 : 0; break;
+        case NMethodPropID::kIsFilter: value->vt = VT_BOOL; value->boolVal = m.kind == KIND_FILTER ? -1 : 0; break;
         default: break;      // kPackStreams, ...: left VT_EMPTY
     }
     return S_OK;
@@ -526,7 +623,7 @@ GC_EXPORT HRESULT CreateObject(const GUID* clsid, const GUID* iid, void** out)
     for (uint32_t i = 0; i < kNumMethods; i++)
         if (*clsid == gc_codec_clsid(kMethods[i].id, true)) return create_encoder(i, iid, out);
     for (uint32_t i = 0; i < kNumMethods; i++)
-        if (kMethods[i].kind == KIND_ZSTD && *clsid == gc_codec_clsid(kMethods[i].id, false)) return create_decoder(i, iid, out);
+        if ((kMethods[i].kind == KIND_ZSTD || kMethods[i].kind == KIND_FILTER) && *clsid == gc_codec_clsid(kMethods[i].id, false)) return create_decoder(i, iid, out);
     return CLASS_E_CLASSNOTAVAILABLE;
 }
 

@@ -194,6 +194,16 @@ int         gc_bra_x86_convert_device(const void* d_src, void* d_dst, size_t n, 
  * state[256] in/out as the reference keeps it (zeros at the start of a stream: Delta_Init); encoding is out of place only. */
 int         gc_delta_convert_device(const void* d_src, void* d_dst, size_t n, unsigned delta, int encoding, unsigned char state[256]);
 
+/* One Filter() call of a 7-Zip pre-filter on a HOST buffer, in place -- what NCompress::NBranch::CCoder::Filter (CPP/7zip/Compress/BranchMisc.cpp:21-26),
+ * NCompress::NBcj::CCoder2::Filter (BcjCoder.cpp:17-22) and NCompress::NDelta::CEncoder / CDecoder::Filter (DeltaFilter.cpp:47-51, :106-110) do with their
+ * buffer: host -> device, the converter of gc_bra_* / gc_delta_* above, device -> host.  kind: a GC_BRA_* value, GC_FILTER_X86 or GC_FILTER_DELTA.
+ * pc as above; `delta` 1..256 (GC_FILTER_DELTA only); `state`: 4 bytes for GC_FILTER_X86 (the converter's state word, 0 at the start of a stream), 256 for
+ * GC_FILTER_DELTA, unused otherwise; *processed = the bytes converted (the caller presents the rest again with more data behind it, as 7-Zip's filter
+ * coder does).  This is the path the plugin's filter objects (BCJGPU, ARM64GPU, DELTAGPU, ...) run on. */
+#define GC_FILTER_X86   100
+#define GC_FILTER_DELTA 101
+int         gc_filter_host(gc_ctx* ctx, int kind, void* data, size_t n, uint32_t pc, int encoding, unsigned delta, unsigned char* state, size_t* processed);
+
 /* ---- The mainline LZMA match finders on data in device memory: IMatchFinder2::GetMatches (C/LzFind.h:127-140) for EVERY
  * position of a buffer in one call -- exactly the values Hc4_MatchFinder_GetMatches (C/LzFind.c:1362) / Bt4_MatchFinder_GetMatches (:1219) write
  * there when the reference runs over the same buffer (MatchFinder_Create(historySize, 0, niceLen, ...), cutValue = cut), position by position.

@@ -7,9 +7,14 @@
 //   plugin_host <module.so> list
 //   plugin_host <module.so> encode <method-name> <level> <in-file> <out-file> [props-out-file] [by-clsid]
 //   plugin_host <module.so> decode <method-name> <props-file|-> <in-file> <out-file> [by-clsid]     (what 7zDecode.cpp:260-420 does with a decoder)
+//   plugin_host <module.so> filter <method-name> <enc|dec> <prop|props-file|-> <in-file> <out-file> [buffer-bytes]
+//                 (what CFilterCoder does with a pre-filter, CPP/7zip/Common/FilterCoder.cpp: Init, then Filter() on a buffer that is refilled behind the bytes left over;
+//                  enc: <prop> = the number given as kDefaultProp / kBranchOffset, properties written to <out-file>.props; dec: <props-file> as written by enc)
 #include "../../7-zip-zstd_amd/plugin/gc_7z_abi.h"
 #include <dlfcn.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 #include <string>
 #include <vector>
 
@@ -88,9 +93,67 @@ int main(int argc, char** argv)
             memcpy(&encId, v.bstrVal, 16); gc_variant_clear(&v);
         }
         if (mode == "list") printf("%u %llX %s enc=%d dec=%d clsid=%08X-%04X-%04X\n", i, (unsigned long long)id, name.c_str(), enc, dec, encId.Data1, encId.Data2, encId.Data3);
-        if (argc > 3 && name == argv[3] && (mode == "decode" ? dec : enc)) { found = (int)i; foundId = id; }
+        const bool wantDec = mode == "decode" || (mode == "filter" && argc > 4 && std::string(argv[4]) == "dec");
+        if (argc > 3 && name == argv[3] && (wantDec ? dec : enc)) { found = (int)i; foundId = id; }
     }
     if (mode == "list") return 0;
+    if (mode == "filter") {
+        if (argc < 8 || found < 0) { fprintf(stderr, "method not found\n"); return 8; }
+        const bool encoding = std::string(argv[4]) == "enc";
+        memset(&v, 0, sizeof(v));
+        if (getProp((uint32_t)found, NMethodPropID::kIsFilter, &v) != S_OK || v.vt != VT_BOOL || v.boolVal == 0) { fprintf(stderr, "not a filter\n"); return 9; }
+        void* rawF = nullptr;
+        { void* bad = nullptr; if ((encoding ? createEnc : createDec)((uint32_t)found, &IID_ICompressCoder, &bad) != E_NOINTERFACE || bad) { fprintf(stderr, "iid check\n"); return 10; } }
+        HRESULT rf = (encoding ? createEnc : createDec)((uint32_t)found, &IID_ICompressFilter, &rawF);
+        if (rf != S_OK || !rawF) { fprintf(stderr, "Create filter failed: %08X\n", (unsigned)rf); return 9; }
+        ICompressFilter* flt = (ICompressFilter*)rawF;
+        const std::string prop = argv[5];
+        if (encoding) {
+            ICompressSetCoderProperties* sp = nullptr; ICompressWriteCoderProperties* wp = nullptr;
+            const bool hasProps = flt->QueryInterface(IID_ICompressSetCoderProperties, (void**)&sp) == S_OK;
+            if (prop != "-") {
+                if (!hasProps) { fprintf(stderr, "filter takes no properties\n"); return 11; }
+                PROPID id = foundId == 3 ? (PROPID)NCoderPropID::kDefaultProp : (PROPID)NCoderPropID::kBranchOffset; PROPVARIANT pv; memset(&pv, 0, sizeof(pv)); pv.vt = VT_UI4; pv.ulVal = (uint32_t)strtoul(prop.c_str(), nullptr, 0);
+                if (sp->SetCoderProperties(&id, &pv, 1) != S_OK) { fprintf(stderr, "SetCoderProperties refused\n"); return 12; }
+            }
+            if (hasProps) {
+                if (flt->QueryInterface(IID_ICompressWriteCoderProperties, (void**)&wp) != S_OK) return 11;
+                FileOut p; p.f = fopen((std::string(argv[7]) + ".props").c_str(), "wb"); if (!p.f || wp->WriteCoderProperties(&p) != S_OK) return 14; fclose(p.f);
+                wp->Release(); sp->Release();
+            }
+        } else if (prop != "-") {
+            ICompressSetDecoderProperties2* sp = nullptr;
+            if (flt->QueryInterface(IID_ICompressSetDecoderProperties2, (void**)&sp) != S_OK) return 11;
+            FILE* pf = fopen(prop.c_str(), "rb"); if (!pf) return 13;
+            uint8_t pb[16]; size_t pn = fread(pb, 1, sizeof(pb), pf); fclose(pf);
+            if (sp->SetDecoderProperties2(pb, (uint32_t)pn) != S_OK) { fprintf(stderr, "SetDecoderProperties2 refused %zu bytes\n", pn); return 12; }
+            sp->Release();
+        }
+        FILE* fi = fopen(argv[6], "rb"); FILE* fo = fopen(argv[7], "wb");
+        if (!fi || !fo) { fprintf(stderr, "file open\n"); return 13; }
+        const size_t cap = argc > 8 ? (size_t)strtoul(argv[8], nullptr, 0) : (size_t)1 << 20;
+        std::vector<uint8_t> buf(cap);
+        if (flt->Init() != S_OK) return 15;
+        size_t have = 0; bool eof = false; unsigned long long total = 0, calls = 0;
+        for (;;) {
+            while (!eof && have < cap) { const size_t got = fread(buf.data() + have, 1, cap - have, fi); if (got == 0) eof = true; have += got; }
+            if (have == 0) break;
+            uint32_t done = flt->Filter(buf.data(), (uint32_t)have); calls++;
+            if (done > have) { fprintf(stderr, "filter asked for more bytes than a branch converter may\n"); return 16; }
+            if (done == 0) {                                  // nothing more can be converted: the rest passes as it is (FilterCoder.cpp, end of stream)
+                if (!eof && have < cap) continue;
+                done = (uint32_t)have;
+                if (!eof) { fprintf(stderr, "no progress on a full buffer\n"); return 16; }
+            }
+            if (fwrite(buf.data(), 1, done, fo) != done) return 14;
+            total += done; have -= done;
+            if (have) memmove(buf.data(), buf.data() + done, have);
+        }
+        fclose(fi); fclose(fo);
+        if (flt->Release() != 0) { fprintf(stderr, "refcount leak\n"); return 18; }
+        printf("ok bytes=%llu calls=%llu\n", total, calls);
+        return 0;
+    }
     if (mode == "decode") {
         if (argc < 7 || found < 0) { fprintf(stderr, "method not found\n"); return 8; }
         const bool byClsidD = argc > 7 && std::string(argv[7]) == "by-clsid";

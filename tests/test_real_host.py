@@ -72,9 +72,11 @@ def _run(host_dir, env, *args):
 def _check_listing(out, module_name):
     assert module_name in out, out
     lines = [l.split() for l in out.splitlines()]
-    ours = [l for l in lines if len(l) == 4 and l[0] == "1" and l[1] in ("E", "ED")]   # "<lib index> E|ED <id> <name>" from library 1
+    ours = [l for l in lines if len(l) == 4 and l[0] == "1" and l[1] in ("E", "ED", "EDF")]   # "<lib index> E|ED|EDF <id> <name>" from library 1
     got = {(l[2], l[3]) for l in ours}
+    filters = {"BCJGPU", "PPCGPU", "IA64GPU", "ARMGPU", "ARMTGPU", "SPARCGPU", "ARM64GPU", "RISCVGPU", "DELTAGPU"}        # the pre-filters on the device (round 3)
     assert {l[3] for l in ours if l[1] == "ED"} == {"ZSTD", "ZSTDGPU"}               # encoder + decoder: ZSTD only
+    assert {l[3] for l in ours if l[1] == "EDF"} == filters                          # ... and the filters, which the host recognises as such
     for want in [("4F71101", "ZSTD"), ("21", "FLZMA2"), ("4F71102", "BROTLI"), ("4F71101", "ZSTDGPU"), ("21", "FLZMA2GPU"), ("4F71102", "BROTLIGPU")]:
         assert want in got, (want, out)
 
@@ -175,3 +177,45 @@ def test_gpu_real_host_archives_through_the_product_module(host_dir, graft, O):
     _roundtrip(host_dir, env, O, "ZSTDGPU", 3, "ZSTD", 150_000_000)                   # three pieces of 64 MiB over the host scheduler
     _roundtrip(host_dir, env, O, "FLZMA2GPU", 5, "LZMA2", 80_000_000, "silesia-like")        # (one piece: FLZMA2 pieces are 256 MiB)
     _roundtrip(host_dir, env, O, "BROTLIGPU", 6, "BROTLI", 80_000_000, "web-text")
+
+
+def _filter_chain(host_dir, env, O, n_bcj, n_delta):
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_bra import _x86_like
+    for tag, methods, x in (("bcj", ["-m0=BCJGPU", "-m1=ZSTDGPU", "-mx3"], _x86_like(n_bcj, 3)),
+                            ("delta", ["-m0=DELTAGPU:4", "-m1=ZSTDGPU", "-mx3"], O.corpus("silesia-like", n_delta))):
+        src = host_dir / ("flt_%s.bin" % tag); x.tofile(src)
+        arc = host_dir / ("flt_%s.7z" % tag)
+        if arc.exists():
+            arc.unlink()
+        r = _run(host_dir, env, "a", *methods, arc.name, src.name)
+        assert r.returncode == 0 and "Everything is Ok" in r.stdout, r.stdout + r.stderr
+        r = _run(host_dir, env, "l", "-slt", arc.name)
+        assert ("BCJ" if tag == "bcj" else "Delta:4") in r.stdout and "ZSTD" in r.stdout, r.stdout
+        r = _run(host_dir, env, "t", arc.name)                                        # built-in decoders first (CreateCoder.cpp:206-232)
+        assert r.returncode == 0 and "Everything is Ok" in r.stdout, r.stdout + r.stderr
+        out = host_dir / ("x_flt_" + tag)
+        if out.exists():
+            shutil.rmtree(out)
+        r = _run(host_dir, env, "x", "-o" + str(out), arc.name)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert np.array_equal(np.fromfile(out / src.name, dtype=np.uint8), x)
+
+
+@pytest.mark.gpu
+def test_gpu_real_host_filter_chain_through_the_product_module(host_dir, graft, O):
+    """the same chain on the device: 7-Zip's filter coder hands its buffer to gc_filter_host call by call"""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    graft.build_hip()
+    module = graft.build_plugin()
+    _filter_chain(host_dir, _install(host_dir, module, os.path.join(ROOT, "7-zip-zstd_amd", "csrc")), O, 40_000_000, 20_000_000)
+
+
+def test_real_host_filter_chain_through_the_emulator_module(host_dir, emu_lib_path, O):
+    """`7z a -m0=BCJGPU -m1=ZSTDGPU`: the reference's own host runs this module's x86 branch converter in front of this module's ZSTD encoder (7-Zip's filter
+    coder drives Filter() on its buffer), records the reference's method ids, and tests / extracts the archive with its BUILT-IN BCJ and ZSTD decoders;
+    the same with the Delta filter and its property."""
+    _filter_chain(host_dir, _install(host_dir, os.path.join(EMU, "lib7zgpucodec_emu.so"), EMU), O, 300_000, 200_000)
