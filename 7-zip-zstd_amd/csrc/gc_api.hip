@@ -78,7 +78,7 @@ extern "C" __global__ void gc_mf_dp2_kernel(const uint8_t*, uint64_t, uint32_t, 
 extern "C" __global__ void gc_mf_dp3_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
 
 extern "C" __global__ void gc_lzma2_prep_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t, uint64_t*, uint32_t*);
-extern "C" __global__ void gc_lzma2_model_kernel(const uint8_t*, uint64_t, const uint64_t*, const uint32_t*, uint32_t, uint32_t, uint16_t*, GcLzmaChunkInfo*, const uint32_t*, unsigned long long*, uint32_t, uint32_t);
+extern "C" __global__ void gc_lzma2_model_kernel(const uint8_t*, uint64_t, const uint64_t*, const uint32_t*, uint32_t, uint32_t, uint16_t*, GcLzmaChunkInfo*, const uint32_t*, unsigned long long*, uint32_t, uint32_t, uint32_t);
 extern "C" __global__ void gc_lzma2_rc_kernel(uint16_t*, uint32_t, uint32_t, uint8_t*, GcLzmaChunkInfo*);
 extern "C" __global__ void gc_lzma2_rc_fin_kernel(const uint16_t*, uint32_t, uint32_t, uint8_t*, GcLzmaChunkInfo*);
 extern "C" __global__ void gc_lzma2_plan_kernel(const GcLzmaChunkInfo*, uint32_t, uint32_t, uint64_t, uint32_t, GcLzmaPlan*, uint64_t*);
@@ -763,6 +763,8 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     const uint32_t segPerBlock = GC_ZSTD_BLOCK_MAX >> segLog;
     uint32_t mergeWords = GC_LZMA_RC_MERGE_WORDS;
     gc_env_u32("GC_RC_MERGE_WORDS", 0u, GC_LZMA_RC_MERGE_WORDS, &mergeWords);                  // test hook: 0 = one LZMA2 chunk per rc chunk
+    uint32_t rep4 = 0;                                                                         // rep2 / rep3 coding in L2: on the emulator only so far (test hook), see gc_lzma2_enc.hip LzLru
+    gc_env_u32("GC_L2_REP4", 0u, 1u, &rep4);
     uint32_t wordCap = GC_LZMA_STREAM_WORDS(segLog);                                           // words a segment may produce before it is stored instead
     gc_env_u32("GC_SEG_WORD_CAP", 1u, GC_LZMA_STREAM_WORDS(segLog), &wordCap);                  // test hook: a low cap sends ordinary segments down that path
     if (c->profOn) { HIPCHK(c, hipMemsetAsync(c->prof, 0, (GC_LZ_PHASES + GC_SEQ_PHASES) * sizeof(unsigned long long), c->stream)); c->profBlocks = 1u; }   // L2 phase sums (raw)
@@ -790,7 +792,7 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
                   (const uint32_t*)(c->lzNM + blk0), segLog, (uint32_t)(off != 0u ? 1u : 0u),
                   c->lzStream + (size_t)blk0 * segPerBlock * GC_LZMA_STREAM_WORDS(segLog), c->lzInfo + (size_t)blk0 * GC_LZMA_RC_PER_BLOCK,
                   (const uint32_t*)((c->priceParse && frameBlocks > 1u) ? c->mfWinCost + (size_t)blk0 * 32u : nullptr),
-                  c->profOn ? c->prof : nullptr, mergeWords, wordCap);
+                  c->profOn ? c->prof : nullptr, mergeWords, wordCap, rep4);
         HIPCHK(c, hipEventRecord(ev[4], c->stream2));
         // stage 3 (stream3): range coder
         HIPCHK(c, hipStreamWaitEvent(c->stream3, ev[4], 0));

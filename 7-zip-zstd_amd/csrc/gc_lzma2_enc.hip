@@ -192,7 +192,7 @@ __device__ __forceinline__ void lz_gen_len(LzEv& o, uint32_t base, uint32_t len,
     }
 }
 
-// one match-type symbol.  kind: 0 normal match, 1 rep0 (long), 2 rep1, 3 short rep (one byte at rep0: LzmaDec.c "IsRep0Long = 0").
+// one match-type symbol.  kind: 0 normal match, 1 rep0 (long), 2 rep1, 3 short rep (one byte at rep0: LzmaDec.c "IsRep0Long = 0"), 4 rep2, 5 rep3.
 // dist = distance-1.  At most 48 events.
 __device__ __forceinline__ void lz_gen_match(LzEv& o, uint32_t kind, uint32_t len, uint32_t dist, uint32_t state, uint32_t posState)
 {
@@ -221,7 +221,8 @@ __device__ __forceinline__ void lz_gen_match(LzEv& o, uint32_t kind, uint32_t le
     } else {
         ev_put(o, LZP_ISREP + state, 1);
         if (kind == 1u) { ev_put(o, LZP_ISREPG0 + state, 0); ev_put(o, LZP_ISREP0LONG + state * 4u + posState, 1); }
-        else { ev_put(o, LZP_ISREPG0 + state, 1); ev_put(o, LZP_ISREPG1 + state, 0); }
+        else if (kind == 2u) { ev_put(o, LZP_ISREPG0 + state, 1); ev_put(o, LZP_ISREPG1 + state, 0); }
+        else { ev_put(o, LZP_ISREPG0 + state, 1); ev_put(o, LZP_ISREPG1 + state, 1); ev_put(o, LZP_ISREPG2 + state, kind == 5u ? 1u : 0u); }       // LzmaDec.c: IsRepG2 picks rep2 / rep3
         lz_gen_len(o, LZP_REPLEN, len, posState);
     }
 }
@@ -279,6 +280,40 @@ __device__ __forceinline__ void lz_gen_item(LzEv& o, const uint8_t* S, uint64_t 
     if (it.len) lz_gen_match(o, kind, it.len, it.off - 1u, st, it.pos & 3u);
 }
 
+// The decoder's four repeat distances as an LRU list (rep4 mode, round 3: written and checked on the emulator, NOT enabled in the shipped library yet).
+// LZMA moves the distance a match uses to the front of (rep0..rep3) -- a new one pushes the last out -- so as long as the encoder codes EVERY match
+// whose distance is in the list as that repeat (first index), the list is "the four most recently used distances, most recent first".  A run of
+// accesses is summarised by its distinct distances in recency order (at most four), and two runs compose: S(AB) = S(B) ++ (S(A) without S(B)) -- an
+// associative operation, so a wave scan gives every item the summary of the items in front of it; the list in front of the tile (wave-uniform; it may
+// hold equal entries while the initial 1, 1, 1, 1 is still in it) follows with the first occurrence of every summarised distance taken out.
+struct LzLru { uint32_t v0, v1, v2, v3; };                         // 0 = empty (distances are >= 1)
+__device__ __forceinline__ void lru_put(LzLru& a, uint32_t x, bool dedupe)
+{
+    if (x == 0u || (dedupe && (x == a.v0 || x == a.v1 || x == a.v2 || x == a.v3))) return;
+    if (!a.v0) a.v0 = x; else if (!a.v1) a.v1 = x; else if (!a.v2) a.v2 = x; else if (!a.v3) a.v3 = x;
+}
+// later ++ (earlier without later's entries): both hold distinct entries
+__device__ __forceinline__ LzLru lru_join(const LzLru& later, const LzLru& earlier)
+{
+    LzLru r = later;
+    lru_put(r, earlier.v0, true); lru_put(r, earlier.v1, true); lru_put(r, earlier.v2, true); lru_put(r, earlier.v3, true);
+    return r;
+}
+// summary ++ (the decoder's list without the FIRST occurrence of every summarised distance)
+__device__ __forceinline__ LzLru lru_over(const LzLru& sum, LzLru dec)
+{
+    const uint32_t e[4] = { sum.v0, sum.v1, sum.v2, sum.v3 };
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint32_t x = e[j];
+        if (x == 0u) continue;
+        if (dec.v0 == x) dec.v0 = 0; else if (dec.v1 == x) dec.v1 = 0; else if (dec.v2 == x) dec.v2 = 0; else if (dec.v3 == x) dec.v3 = 0;
+    }
+    LzLru r = sum;
+    lru_put(r, dec.v0, false); lru_put(r, dec.v1, false); lru_put(r, dec.v2, false); lru_put(r, dec.v3, false);
+    return r;
+}
+
 extern "C" __global__ void __launch_bounds__(64)
 gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const uint64_t* __restrict__ Mall,
                       const uint32_t* __restrict__ nM, uint32_t segLog, uint32_t hasPrev /* the byte in front of src exists (src is a later part of a stream) */,
@@ -291,7 +326,8 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
                          within this many words (0 = never): a chunk costs 10 bytes (5 of header, 5 of range-coder start / flush), which
                          is 1 % of a well-compressed 4 KiB; the bound keeps the longest range-coder chain what it is for 4 KiB of
                          incompressible data */,
-                      uint32_t wordCap /* words the segment may produce (its reserved place, GC_LZMA_STREAM_WORDS); beyond that it is stored */)
+                      uint32_t wordCap /* words the segment may produce (its reserved place, GC_LZMA_STREAM_WORDS); beyond that it is stored */,
+                      uint32_t rep4 /* 1: matches whose distance is rep2 / rep3 of the decoder are coded as such (LzLru above); 0: rep0 / rep1 only */)
 {
     __shared__ uint16_t P[LZP_TOTAL];
     __shared__ uint32_t sTick[LZ2_TICKS / 4u];                    // ticket bytes (see LZ2_TICKS)
@@ -354,6 +390,7 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
     uint32_t cExit = 0;               // coder state after the last match item (0: state at segment start)
     uint32_t cLits = 0;               // literals coded since the last match item (in cut items)
     uint32_t wpos = 0;                // words written so far
+    LzLru cLru; cLru.v0 = cLru.v1 = cLru.v2 = cLru.v3 = 1u;                 // rep4: the decoder's repeat distances after a state reset (LzmaDec.c: reps = 1)
     bool overflow = false;            // the words of the segment outgrew their reserved place: the segment is stored
 
     unsigned long long tprev = prof ? gc_clock() : 0ull, pc0 = 0, pc1 = 0, pc2 = 0; uint32_t pSteps = 0, pRounds = 0;
@@ -396,6 +433,27 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
 #ifdef HIPEMU
         if (isM && it.len == 1u && kind != 3u) { fprintf(stderr, "L2: one-byte item at %u is not a repeat of the previous distance (%u vs %u)\n", it.pos, it.off, pOff); abort(); }
 #endif
+        LzLru lruIncl; lruIncl.v0 = lruIncl.v1 = lruIncl.v2 = lruIncl.v3 = 0;
+        if (rep4) {
+            LzLru a; a.v0 = isM ? it.off : 0u; a.v1 = a.v2 = a.v3 = 0;
+#pragma unroll
+            for (uint32_t d = 1; d < 64u; d <<= 1) {
+                LzLru b; b.v0 = __shfl_up(a.v0, d); b.v1 = __shfl_up(a.v1, d); b.v2 = __shfl_up(a.v2, d); b.v3 = __shfl_up(a.v3, d);
+                if (lane < d) b.v0 = b.v1 = b.v2 = b.v3 = 0;
+                a = lru_join(a, b);
+            }
+            lruIncl = a;
+            LzLru ex; ex.v0 = __shfl_up(a.v0, 1); ex.v1 = __shfl_up(a.v1, 1); ex.v2 = __shfl_up(a.v2, 1); ex.v3 = __shfl_up(a.v3, 1);
+            if (lane == 0u) ex.v0 = ex.v1 = ex.v2 = ex.v3 = 0;
+            const LzLru L4 = lru_over(ex, cLru);                             // the decoder's list in front of this item
+            if (isM) {
+                const uint32_t k4 = it.off == L4.v0 ? (it.len == 1u ? 3u : 1u) : (it.off == L4.v1 ? 2u : (it.off == L4.v2 ? 4u : (it.off == L4.v3 ? 5u : 0u)));
+#ifdef HIPEMU
+                if ((kind != 0u && k4 != kind) || (kind == 0u && k4 != 0u && k4 < 4u)) { fprintf(stderr, "L2 rep4: item at %u off %u: list %u %u %u %u says kind %u, the scans say %u\n", it.pos, it.off, L4.v0, L4.v1, L4.v2, L4.v3, k4, kind); abort(); }
+#endif
+                kind = k4;
+            }
+        }
         // coder state: literals of cut items since the last match, state after that match
         const uint32_t cl = (lane < cnt && !isM) ? ll : 0u;
         const uint32_t aIncl = gc_wave_incl_sum(cl), aExcl = aIncl - cl;
@@ -497,6 +555,10 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
             cLits = gc_readlane(aIncl, lastLane) - gc_readlane(aIncl, ml_);
         } else cLits += gc_readlane(aIncl, lastLane);
         cMatch = mLast;
+        if (rep4) {
+            LzLru t; t.v0 = gc_readlane(lruIncl.v0, lastLane); t.v1 = gc_readlane(lruIncl.v1, lastLane); t.v2 = gc_readlane(lruIncl.v2, lastLane); t.v3 = gc_readlane(lruIncl.v3, lastLane);
+            cLru = lru_over(t, cLru);
+        }
         gc_wave_sync();
     }
     gc_wave_sync();

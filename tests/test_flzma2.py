@@ -94,6 +94,23 @@ def test_emu_tile_of_literals_only_in_the_fused_parse(O, emu_fl2):
     _roundtrip(O, emu_fl2[1], x)
 
 
+def test_emu_rep2_rep3_coding_behind_its_hook(O, pkg, emu_lib_path, monkeypatch):
+    """L2 can code matches whose distance is the decoder's rep2 / rep3 as such (an LRU list of the four repeat distances from an associative wave scan,
+    gc_lzma2_enc.hip LzLru).  Round 3: written and checked here; the shipped library keeps it off until it has run on the device (test hook GC_L2_REP4).
+    Real binaries and sources gain 0.35 % (4 MiB each under the emulator); a match at rep2 / rep3 must then ALWAYS be coded as that repeat (the list is only the
+    decoder's while that holds), which on data where such repeats are rare can cost a few bytes -- the stream must decode and stay within 0.2 %."""
+    rng = np.random.default_rng(3)
+    rec = rng.integers(0, 256, size=(4000, 24), dtype=np.uint8)
+    rec[:, 0:4] = np.arange(4000, dtype="<u4").view(np.uint8).reshape(-1, 4)          # a counter, then fields that repeat at three strides
+    rec[:, 4:12] = rec[(np.arange(4000) // 3) * 3 % 4000, 4:12]
+    rec[:, 12:20] = rec[(np.arange(4000) // 7) * 7 % 4000, 12:20]
+    x = np.concatenate([rec.reshape(-1), O.corpus("lz-7zip", 200_000), O.corpus("real-bin", 400_000) if O.corpus("real-bin", 1).size else O.corpus("silesia-like", 400_000)])
+    plain = pkg.Flzma2Encoder(lib_path=emu_lib_path, level=5); c0 = _roundtrip(O, plain, x); plain.close()
+    monkeypatch.setenv("GC_L2_REP4", "1")
+    rep4 = pkg.Flzma2Encoder(lib_path=emu_lib_path, level=5); c1 = _roundtrip(O, rep4, x); rep4.close()
+    assert len(c1) <= 1.002 * len(c0)
+
+
 def test_emu_many_frames_and_parts(O, pkg, emu_lib_path, monkeypatch):
     """The multi-frame and multi-part paths on a small input: test hooks shrink the match-finder frame to one block and make every
     frame its own part (stages of different parts run on different streams; a later part's first literal has the last byte of
