@@ -76,6 +76,10 @@ extern "C" __global__ void gc_mf_parse_kernel(const uint8_t*, uint64_t, uint32_t
 extern "C" __global__ void gc_mf_short_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint16_t*);
 extern "C" __global__ void gc_mf_dp2_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
 extern "C" __global__ void gc_mf_dp3_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
+extern "C" __global__ void gc_mf_dpl2_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
+extern "C" __global__ void gc_mf_dpl2s_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
+extern "C" __global__ void gc_mf_dpl3_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
+extern "C" __global__ void gc_mf_dpl3s_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
 
 extern "C" __global__ void gc_lzma2_prep_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t, uint64_t*, uint32_t*);
 extern "C" __global__ void gc_lzma2_model_kernel(const uint8_t*, uint64_t, const uint64_t*, const uint32_t*, uint32_t, uint32_t, uint16_t*, GcLzmaChunkInfo*, const uint32_t*, unsigned long long*, uint32_t, uint32_t, uint32_t);
@@ -457,9 +461,21 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
         uint32_t* dps = c->mfDpStat + (size_t)blk0 * GC_DPS_WORDS;
         HIPCHK(c, hipMemsetAsync(dps, 0, (size_t)nBlocks * GC_DPS_WORDS * sizeof(uint32_t), st));
         uint32_t phase0 = 0; { uint32_t one = 0; if (gc_env_u32("GC_DP_PHASES", 1u, 2u, &one) && one == 1u) phase0 = 2u; }    // test hook: 1 = W6's prices only
+        // W7L (gc_lz_dpl.hip): one lane per window; LZMA with the four repeat distances at every node.  Test hook GC_DPL: 0 = W7 (a wave per window)
+        uint32_t laneDp = c->priceMinLen <= 2u ? 1u : 0u; gc_env_u32("GC_DPL", 0u, 1u, &laneDp);
         for (uint32_t phase = phase0; phase != 3u; phase = phase == 0u ? 1u : 3u) {
             const uint32_t nDpWg = nBlocks * (phase == 0u ? 1u : 8u), perD = gc_xcd_per(nDpWg);
             uint32_t* wcp = phase == 0u ? (uint32_t*)nullptr : wc;
+            if (laneDp) {
+                const uint32_t nItems = phase == 0u ? (nBlocks + 1u) / 2u : nBlocks, perL = gc_xcd_per(nItems);
+                if (c->priceMinLen <= 2u) {
+                    if (phase == 0u) GC_LAUNCH(gc_mf_dpl2s_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
+                    else GC_LAUNCH(gc_mf_dpl2_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
+                } else {
+                    if (phase == 0u) GC_LAUNCH(gc_mf_dpl3s_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
+                    else GC_LAUNCH(gc_mf_dpl3_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
+                }
+            } else
             if (c->priceMinLen <= 2u) GC_LAUNCH(gc_mf_dp2_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
             else GC_LAUNCH(gc_mf_dp3_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
         }
@@ -763,7 +779,7 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     const uint32_t segPerBlock = GC_ZSTD_BLOCK_MAX >> segLog;
     uint32_t mergeWords = GC_LZMA_RC_MERGE_WORDS;
     gc_env_u32("GC_RC_MERGE_WORDS", 0u, GC_LZMA_RC_MERGE_WORDS, &mergeWords);                  // test hook: 0 = one LZMA2 chunk per rc chunk
-    uint32_t rep4 = 0;                                                                         // rep2 / rep3 coding in L2: on the emulator only so far (test hook), see gc_lzma2_enc.hip LzLru
+    uint32_t rep4 = 1;                                                                         // rep2 / rep3 coding in L2 (gc_lzma2_enc.hip LzLru); test hook: 0 = rep0 / rep1 only
     gc_env_u32("GC_L2_REP4", 0u, 1u, &rep4);
     uint32_t wordCap = GC_LZMA_STREAM_WORDS(segLog);                                           // words a segment may produce before it is stored instead
     gc_env_u32("GC_SEG_WORD_CAP", 1u, GC_LZMA_STREAM_WORDS(segLog), &wordCap);                  // test hook: a low cap sends ordinary segments down that path

@@ -1,0 +1,464 @@
+// gc_lz_dpl.hip -- W7L: the price-based ("optimal") parse with one LANE per window (round 4).
+//
+// Same job as W7 of gc_lz_price.hip (LZMA_optimalParse, C/fast-lzma2/lzma2_enc.c:949-1440; ZSTD_compressBlock_opt_generic,
+// C/zstd/zstd_opt.c:1077): the cheapest way through a window of positions under static per-block prices, a step being a literal,
+// any prefix of a match candidate, or -- LZMA -- a repeat of one of the FOUR last distances of the path (rep0..rep3,
+// LZMA_getRepPrice lzma2_enc.c:289, the rep loop of the optimal parser :1090, four distances per node :990-998).
+//
+// W7 gave a window to a WAVE: the 64 open nodes in one VGPR, one node per ~45 instructions, i.e. 64 lanes busy with the edges of ONE
+// position, most of which do not exist.  The windows are independent and there are tens of thousands of them (211.9 MB = 103 000
+// windows of 2 KiB), so here a window is a LANE: every lane runs the textbook forward programme on its own window, the 64 lanes of a
+// wave step through their windows in lockstep (node i of all 64 windows at step i), and one vector instruction works on 64 positions.
+// What a lane needs per node lives in LDS columns of its own ([slot][lane]: no bank conflicts, no sharing, no barriers):
+//   sCost  ring of the DPL_M open nodes: 64-bit words cost | bytes left of a capped match | distance | class | length, relaxed with
+//          ds_min_u64 (fire and forget: the minimum carries its back pointer AND its distance)
+//   sReps  ring of the last DPL_M final nodes: the four repeat distances of the cheapest way to each (the programme compares distances, it
+//          never dereferences one: what a repeat matches comes from the hints below)
+// Edges are at most DPL_M = 16 bytes long: a longer match is a chain of pieces -- the head is priced with the length price of the
+// whole match, the rest of it travels with the node it reaches ("bytes left") and is offered there at DP_CONT_PRICE, any length --
+// which keeps both rings at 16 slots (24 KiB of LDS per wave with the price table: 5-6 waves per CU) and the relax loops short.
+//
+// Repeats at EVERY position without a dependent memory access in the node loop: which bytes repeat at position p at distance d is a
+// property of (p, d), not of the path.  The path only decides WHICH d are its repeats.  So the HINTS of a position are fixed a group of
+// four positions ahead of the programme: the four repeat distances of its newest final node (a path that only adds literals or repeats
+// keeps them; a new match pushes them down one place) plus the last two distances of a cheap "shadow" greedy parse of the finder's
+// records that runs along (the distance of a match the path is about to take).  For each hint 16 bytes at p - d are requested one group
+// early and compared with the window's own bytes when they have arrived.  At node i a hint becomes an edge (lengths 2..16, price of
+// rep k) iff its distance is rep k of THAT node; with rep0 and one byte equal it is LZMA's short repeat.
+// Windows start DPL_WARM positions early: the programme runs over the end of the window in front (clipping its edges at the window's
+// first node exactly as that window's own lane does) for nothing but the state it arrives with -- the repeat distances and the rest of
+// a match cut by the boundary -- which is what makes 2 KiB windows affordable on data that is coded with repeats (8 MiB of ROCm shared
+// objects: 4 096 windows that each re-establish four distances with full-price matches cost 2.5 % of the stream).
+//
+// The back pointers of a window go to the window's own slice of the record array (one word per node); the walk back from the last
+// node rewrites that slice in place, slot by slot in lockstep, into what W6 follows: (distance << 8 | length) where the path starts a
+// match, 0 elsewhere; neighbouring pieces with one distance leave as records of up to 64 bytes.
+#include "gc_mf.h"
+#include "gc_lz_parse.h"
+
+#define DPL_M        16u
+#define DPL_MMASK    (DPL_M - 1u)
+#define DPL_INF      0xFFFFFFFFFFFFFFFFull
+#define DPL_CONT     4u               // the rest of a capped match: a quarter of a bit (as DP_CONT_PRICE of W7)
+#define DPL_WARM     256              // positions in front of a window that the programme runs over for its state
+#define DPL_HCAP     16u              // bytes compared per hint
+#define DPL_NH       6u               // hints per position: rep0..rep3 of the newest final node + two of the shadow parse
+// class of an edge (bits 4..6 of the low word)
+#define DPL_LIT      0u
+#define DPL_NEW      1u               // a match at a distance that is no repeat of the node
+#define DPL_REP0     2u               // .. 5: rep0..rep3
+#define DPL_SREP     6u               // LZMA short repeat (one byte at rep0)
+#define DPL_CONTC    7u               // continuation of the capped piece in front of it
+#define DPL_SURE     0x80000000u      // in rep0 of a node: the distance is the decoder's rep0 for certain (a match of this window lies on the way)
+
+__device__ __forceinline__ uint32_t dpl_item(uint32_t bid, uint32_t per) { return (bid & (GC_XCDS - 1u)) * per + (bid >> 3); }
+
+struct DplReps { uint32_t r0 /* | DPL_SURE */, r1, r2, r3; };      // 0 = none
+__device__ __forceinline__ uint32_t dpl_which(const DplReps& s, uint32_t d)     // index of distance d among the node's four (4 = none)
+{
+    return (s.r0 & ~DPL_SURE) == d ? 0u : (s.r1 == d ? 1u : (s.r2 == d ? 2u : (s.r3 == d ? 3u : 4u)));
+}
+// distance d moves to the front (a new one pushes the last out): LzmaDec.c's rep0..rep3 update
+__device__ __forceinline__ void dpl_mtf(DplReps& s, uint32_t d, uint32_t sure)
+{
+    const uint32_t a = s.r0 & ~DPL_SURE;
+    if (a == d) { s.r0 = d | sure | (s.r0 & DPL_SURE); return; }
+    if (s.r1 == d) { s.r1 = a; }
+    else if (s.r2 == d) { s.r2 = s.r1; s.r1 = a; }
+    else { s.r3 = s.r2; s.r2 = s.r1; s.r1 = a; }
+    s.r0 = d | sure;
+}
+__device__ __forceinline__ void dpl_lru_put(uint32_t (&l)[2], uint32_t d) { if (l[0] != d) { l[1] = l[0]; l[0] = d; } }
+
+template <bool REPS, uint32_t MINLEN, uint32_t BPW /* blocks per wave: 1 = all windows of a block (64 x 2 KiB), 2 = a sample (32 x 512 B of each) */>
+__device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t frameBlocks, uint32_t phaseArg, uint32_t* __restrict__ dpStat,
+                                        uint32_t litCtxArg, const uint32_t* __restrict__ rec, const uint16_t* __restrict__ rec3, const uint16_t* __restrict__ priceTab,
+                                        uint32_t* __restrict__ recOut, uint32_t* __restrict__ winCost)
+{
+    __shared__ unsigned long long sCost[DPL_M][64];
+    __shared__ GcU4 sReps[REPS ? DPL_M : 1u][64];
+    __shared__ uint16_t sPrice[BPW][GC_PRICE_WORDS];
+    __shared__ uint32_t sCnt[BPW][GC_DPS_WORDS];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t litCtxMask = litCtxArg & 0xFFu, hasPrev = litCtxArg >> 31;
+    const bool phaseA = phaseArg == 0u, phaseB = phaseArg == 1u;
+    const uint32_t item = dpl_item(blockIdx.x, per);
+    if (item * BPW >= nBlocks) return;                            // (uniform)
+    // ---- this lane's window
+    const uint32_t lb = BPW == 1u ? 0u : lane >> 5;               // block of the wave
+    const uint32_t b = item * BPW + lb;
+    const bool blockLive = b < nBlocks;
+    const uint64_t base = (uint64_t)(blockLive ? b : 0u) * GC_ZSTD_BLOCK_MAX;
+    const uint32_t blockLen = blockLive ? (uint32_t)((srcSize - base) < GC_ZSTD_BLOCK_MAX ? (srcSize - base) : GC_ZSTD_BLOCK_MAX) : 0u;
+#ifdef HIPEMU
+    static const int xWin4k = getenv("GC_X_WIN4K") ? atoi(getenv("GC_X_WIN4K")) : 0, xNoHint = getenv("GC_X_NOHINT") ? atoi(getenv("GC_X_NOHINT")) : 0, xWarm = getenv("GC_X_WARM") ? atoi(getenv("GC_X_WARM")) : DPL_WARM;
+    static const int xHints = getenv("GC_X_HINTS") ? atoi(getenv("GC_X_HINTS")) : 63;
+    const uint32_t winLen = BPW == 1u ? (xWin4k ? 4096u : 2048u) : 512u;
+    const uint32_t w0 = BPW == 1u ? (xWin4k ? (lane < 32u ? lane << 12 : GC_ZSTD_BLOCK_MAX) : lane << 11) : ((lane & 31u) << 12) + 1536u;
+#else
+    const int xWarm = DPL_WARM;
+    const uint32_t winLen = BPW == 1u ? 2048u : 512u;
+    const uint32_t w0 = BPW == 1u ? lane << 11 : ((lane & 31u) << 12) + 1536u;
+#endif
+    const uint32_t n = w0 < blockLen ? ((blockLen - w0) < winLen ? (blockLen - w0) : winLen) : 0u;       // nodes 0 .. n
+    const uint32_t nMax = gc_wave_max(n);
+    // ---- price tables (as W7: W6's table, phase A with optimistic ceilings where the greedy parse found no matches, phase B from phase A's counts)
+    for (uint32_t q = 0; q < BPW; q++) {
+        const uint32_t bb = item * BPW + q;
+        if (bb < nBlocks) { const GcU4* T4 = (const GcU4*)(priceTab + (uint64_t)bb * GC_PRICE_WORDS); GcU4* S4 = (GcU4*)sPrice[q]; for (uint32_t i = lane; i < GC_PRICE_WORDS / 8u; i += 64u) S4[i] = T4[i]; }
+        if (phaseA) for (uint32_t i = lane; i < GC_DPS_WORDS; i += 64u) sCnt[q][i] = 0;
+    }
+    gc_wave_sync();
+    for (uint32_t q = 0; q < BPW; q++) {
+        const uint32_t bb = item * BPW + q;
+        if (bb >= nBlocks) continue;                              // (uniform)
+        uint16_t* P = sPrice[q];
+        if (lane == 0u) {                                         // before anything is known: repeats 3 / 3.5 / 4 / 5 / 5 bits on top of the match flag, "no repeat" free
+            P[GC_PRICE_FLAGS + 2u] = 48u; P[GC_PRICE_FLAGS + 3u] = 56u; P[GC_PRICE_FLAGS + 4u] = 64u; P[GC_PRICE_FLAGS + 5u] = 80u; P[GC_PRICE_FLAGS + 6u] = 80u; P[GC_PRICE_FLAGS + 7u] = 0u;
+        }
+        // lengths of repeats before anything is known: as those of matches, but the short ones (which hardly occur among the finder's matches) at 2.5 bits
+        for (uint32_t i = lane; i < GC_PRICE_NLEN; i += 64u) { const uint32_t v = P[GC_PRICE_LEN + i]; P[GC_PRICE_REPLEN + i] = (uint16_t)(i < 10u && v > 40u ? 40u : v); }
+        gc_wave_sync();
+        if (phaseA && P[GC_PRICE_FLAGS + 1u] >= 64u) {
+            for (uint32_t i = lane; i < GC_PRICE_NLEN + 64u + 1u; i += 64u) {
+                const uint32_t idx = i < GC_PRICE_NLEN ? GC_PRICE_LEN + i : (i < GC_PRICE_NLEN + 64u ? GC_PRICE_SLOT + (i - GC_PRICE_NLEN) : GC_PRICE_FLAGS + 1u);
+                const uint32_t cap = i < 10u ? 8u : (i < GC_PRICE_NLEN ? 0xFFFFu : (i < GC_PRICE_NLEN + 64u ? 48u : 16u));
+                if (P[idx] > cap) P[idx] = (uint16_t)cap;
+            }
+        }
+        if (phaseB) {
+            const uint32_t* C = dpStat + (uint64_t)bb * GC_DPS_WORDS;
+            const uint32_t nLit = C[GC_DPS_NLIT], nMat = C[GC_DPS_NMAT];
+            if (nLit + nMat != 0u) {
+                const uint32_t nRepAll = REPS ? C[GC_DPS_NREP] + C[GC_DPS_NSREP] + C[GC_DPS_NREP1] + C[GC_DPS_NREP2] + C[GC_DPS_NREP3] : 0u;
+                const uint32_t nNew = nMat > nRepAll ? nMat - nRepAll : 0u;      // matches at a new distance: what lengths (of the match coder) and slots are counted over
+                for (uint32_t i = lane; i < GC_PRICE_NLEN + 64u + 2u; i += 64u) {
+                    if (i < GC_PRICE_NLEN) P[GC_PRICE_LEN + i] = (uint16_t)pz_price(8u * C[GC_DPS_LEN + i] + 1u, 8u * nNew + 63u);
+                    else if (i < GC_PRICE_NLEN + 64u) P[GC_PRICE_SLOT + (i - GC_PRICE_NLEN)] = (uint16_t)pz_price(8u * C[GC_DPS_SLOT + (i - GC_PRICE_NLEN)] + 1u, 8u * nNew + 44u);
+                    else if (i == GC_PRICE_NLEN + 64u) P[GC_PRICE_FLAGS] = (uint16_t)pz_price(nLit + 1u, nLit + nMat + 2u);
+                    else P[GC_PRICE_FLAGS + 1u] = (uint16_t)pz_price(nMat + 1u, nLit + nMat + 2u);
+                }
+                if (REPS) {
+                    uint32_t nr = 0; for (uint32_t i = 0; i < GC_PRICE_NLEN; i++) nr += C[GC_DPS_REPLEN + i];
+                    if (nr >= 16u) for (uint32_t i = lane; i < GC_PRICE_NLEN; i += 64u) P[GC_PRICE_REPLEN + i] = (uint16_t)pz_price(8u * C[GC_DPS_REPLEN + i] + 1u, 8u * nr + 63u);
+                }
+                if (REPS && lane == 0u) {
+                    // IsRep, IsRepG0, IsRep0Long, IsRepG1, IsRepG2 (LzmaEnc.c / lzma2_enc.c:289 LZMA_getRepPrice) from how often phase A's paths used each
+                    const uint32_t n0 = C[GC_DPS_NREP], nS = C[GC_DPS_NSREP], n1 = C[GC_DPS_NREP1], n2 = C[GC_DPS_NREP2], n3 = C[GC_DPS_NREP3];
+                    const uint32_t all = n0 + nS + n1 + n2 + n3;
+                    const uint32_t isRep = pz_price(all + 1u, nMat + 2u), g0 = pz_price(n0 + nS + 1u, all + 2u), g0n = pz_price(n1 + n2 + n3 + 1u, all + 2u);
+                    P[GC_PRICE_FLAGS + 2u] = (uint16_t)(isRep + g0 + pz_price(n0 + 1u, n0 + nS + 2u));
+                    P[GC_PRICE_FLAGS + 3u] = (uint16_t)(isRep + g0 + pz_price(nS + 1u, n0 + nS + 2u));
+                    P[GC_PRICE_FLAGS + 4u] = (uint16_t)(isRep + g0n + pz_price(n1 + 1u, n1 + n2 + n3 + 2u));
+                    const uint32_t g1n = pz_price(n2 + n3 + 1u, n1 + n2 + n3 + 2u);
+                    P[GC_PRICE_FLAGS + 5u] = (uint16_t)(isRep + g0n + g1n + pz_price(n2 + 1u, n2 + n3 + 2u));
+                    P[GC_PRICE_FLAGS + 6u] = (uint16_t)(isRep + g0n + g1n + pz_price(n3 + 1u, n2 + n3 + 2u));
+                    P[GC_PRICE_FLAGS + 7u] = (uint16_t)pz_price(nNew + 1u, nMat + 2u);      // "no repeat"
+                }
+            }
+        }
+    }
+    gc_wave_sync();
+    const uint16_t* P = sPrice[lb];
+    const uint32_t flagLit = P[GC_PRICE_FLAGS], flagMat = P[GC_PRICE_FLAGS + 1u];
+    const uint32_t newAdd = flagMat + (REPS ? (uint32_t)P[GC_PRICE_FLAGS + 7u] : 0u);
+    const uint8_t* S = src + base + w0;                           // window-relative addressing (positions in front of the window are negative)
+    const uint32_t* R = rec + base + w0;
+    const uint16_t* R3 = rec3 + base + w0;
+    uint32_t* BP = recOut + base + w0;
+    const uint64_t absW = base + w0;
+    const uint64_t tailRoom = srcSize - absW;                     // bytes of the input from the window start on
+    // the programme starts `warm` positions in front of the window (a multiple of four, inside the window's frame)
+    int32_t warm = 0;
+    if (n != 0u) {
+        const uint64_t frameBytes = (uint64_t)frameBlocks * GC_ZSTD_BLOCK_MAX;
+        const uint64_t inFrame = absW % frameBytes;
+        warm = inFrame < (uint64_t)xWarm ? (int32_t)inFrame : xWarm;
+        warm &= ~3;
+    }
+    const int32_t warmMax = (int32_t)gc_wave_max((uint32_t)warm);
+    const int32_t N = (int32_t)n;
+
+    for (uint32_t s = 0; s < DPL_M; s++) sCost[s][lane] = DPL_INF;
+    sCost[(uint32_t)(-warm) & DPL_MMASK][lane] = 0ull;            // the first node: cost 0
+    if (REPS) { GcU4 v; v.x = v.y = v.z = v.w = 0u; for (uint32_t s = 0; s < DPL_M; s++) sReps[s][lane] = v; }
+    uint32_t lru[2] = { 0u, 0u };                                 // the shadow parse: the last two distances of a greedy walk over the finder's records
+    int32_t sNext = -warm;
+    DplReps st; st.r0 = st.r1 = st.r2 = st.r3 = 0u;               // repeat distances of the node being expanded
+
+    // ---- pipelines: records two groups of four positions ahead, hint bytes one group ahead
+    uint32_t recG[4], recN[4], r3G[4], r3N[4], byG, byN;
+    uint32_t hintG[4][DPL_NH];                                    // this group: distance << 8 | bytes that repeat there (0 = none)
+    uint32_t hdN[4][DPL_NH];                                      // next group: distances; bytes in flight
+    LzW16 hbN[4][DPL_NH], ownN[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4u; u++) {
+#pragma unroll
+        for (uint32_t k = 0; k < DPL_NH; k++) { hintG[u][k] = 0u; hdN[u][k] = 0u; hbN[u][k].a = hbN[u][k].b = 0ull; }
+        ownN[u].a = ownN[u].b = 0ull;
+    }
+    // group loader: records, short candidates and bytes of positions g4 .. g4 + 3 (g4 a multiple of four, possibly negative)
+    auto load_group = [&](int32_t g4, uint32_t (&rr)[4], uint32_t (&r3)[4], uint32_t& by) {
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) { rr[u] = 0u; r3[u] = GC_SHORT_NONE; }
+        by = 0u;
+        if (g4 >= -warm && g4 + 4 <= N) {
+            GcU4 v; __builtin_memcpy(&v, R + g4, 16); rr[0] = v.x; rr[1] = v.y; rr[2] = v.z; rr[3] = v.w;
+            uint64_t h; __builtin_memcpy(&h, R3 + g4, 8); r3[0] = (uint32_t)h & 0xFFFFu; r3[1] = (uint32_t)(h >> 16) & 0xFFFFu; r3[2] = (uint32_t)(h >> 32) & 0xFFFFu; r3[3] = (uint32_t)(h >> 48);
+            by = gc_ld32(S + g4);
+        } else if (g4 >= -warm) {
+#pragma unroll
+            for (int32_t u = 0; u < 4; u++) if (g4 + u < N) { rr[u] = R[g4 + u]; r3[u] = R3[g4 + u]; by |= (uint32_t)S[g4 + u] << (8 * u); }
+        }
+    };
+    // hint stage of positions g4 .. g4 + 3 (REPS): their hint distances are fixed and the bytes requested; the shadow parse moves over them
+    auto hint_stage = [&](int32_t g4, const uint32_t (&rr)[4]) {
+#pragma unroll
+        for (int32_t u = 0; u < 4; u++) {
+            const int32_t q = g4 + u;
+            uint32_t d[DPL_NH] = { st.r0 & ~DPL_SURE, st.r1, st.r2, st.r3, lru[0], lru[1] };
+            if (d[4] == d[0] || d[4] == d[1] || d[4] == d[2] || d[4] == d[3]) d[4] = 0u;
+            if (d[5] == d[0] || d[5] == d[1] || d[5] == d[2] || d[5] == d[3]) d[5] = 0u;
+            const bool ok = q >= -warm && q < N && (uint64_t)((int64_t)q + (int64_t)DPL_HCAP) <= tailRoom;
+            uint32_t any = 0u;
+#pragma unroll
+            for (uint32_t k = 0; k < DPL_NH; k++) {
+#ifdef HIPEMU
+                if (!((xHints >> k) & 1)) d[k] = 0u;
+#endif
+                hdN[u][k] = ok ? d[k] : 0u; any |= hdN[u][k];
+            }
+            if (any) ownN[u] = lz_ld16(S + q, 0);
+#pragma unroll
+            for (uint32_t k = 0; k < DPL_NH; k++) if (hdN[u][k]) hbN[u][k] = lz_ld16(S + (int64_t)q - (int64_t)hdN[u][k], 0);
+            if (q >= sNext && q < N) {                             // the shadow parse takes the record of q (or steps over a literal)
+                const uint32_t L = rr[u] & 0xFFu;
+                if (L >= 3u) { dpl_lru_put(lru, rr[u] >> 8); sNext = q + (int32_t)L; } else sNext = q + 1;
+            }
+        }
+    };
+    auto hints_arrive = [&]() {
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++)
+#pragma unroll
+            for (uint32_t k = 0; k < DPL_NH; k++) {
+                uint32_t l = hdN[u][k] ? lz_cmp16(ownN[u], hbN[u][k]) : 0u;
+#ifdef HIPEMU
+                if (xNoHint) l = 0;
+#endif
+                hintG[u][k] = l ? (hdN[u][k] << 8) | l : 0u;
+            }
+    };
+    load_group(-warmMax, recG, r3G, byG);
+    load_group(-warmMax + 4, recN, r3N, byN);
+    if (REPS) { hint_stage(-warmMax, recG); hints_arrive(); hint_stage(-warmMax + 4, recN); }
+    uint32_t prevByte = 0u;
+    if (n != 0u && (absW + hasPrev) > (uint64_t)warm) prevByte = (uint32_t)S[-warm - 1];
+    uint32_t contDist = 0u, contRem = 0u; bool contCapped = false;   // the node being expanded was reached by a capped piece
+    uint32_t c1 = 0u, c2 = 0u, c3 = 0u;                           // back pointers waiting to be stored (nodes 4g+1 .. 4g+3)
+    uint32_t cost0 = 0u, costN = 0u;                              // cost of the window's first / last node
+
+    // ---- the programme: node i = finalize (i > -warm) + expand (i < n); nodes below 0 are the warm-up
+    for (int32_t g4 = -warmMax; g4 < (int32_t)nMax + 4; g4 += 4) {
+        uint32_t recNN[4], r3NN[4], byNN;
+        load_group(g4 + 8, recNN, r3NN, byNN);
+#pragma unroll
+        for (int32_t u = 0; u < 4; u++) {
+            const int32_t i = g4 + u;
+            const uint32_t slot = (uint32_t)i & DPL_MMASK;
+            const unsigned long long w = sCost[slot][lane];
+            sCost[slot][lane] = DPL_INF;
+            const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+            const uint32_t c0 = hi >> 6;
+            const bool live = n != 0u && i >= -warm && i <= N;
+            if (live && i > -warm) {                               // ---- finalize node i
+                const uint32_t len = (lo & 15u) + 1u, cls = (lo >> 4) & 7u, dist = lo >> 8;
+                if (REPS) {
+                    const GcU4 pv = sReps[(uint32_t)(i - (int32_t)len) & DPL_MMASK][lane];
+                    st.r0 = pv.x; st.r1 = pv.y; st.r2 = pv.z; st.r3 = pv.w;
+                    if (cls != DPL_LIT && cls != DPL_SREP) dpl_mtf(st, dist, i - (int32_t)len >= 0 ? DPL_SURE : 0u);
+                    GcU4 nv; nv.x = st.r0; nv.y = st.r1; nv.z = st.r2; nv.w = st.r3; sReps[slot][lane] = nv;
+                }
+                contCapped = ((lo >> 7) & 1u) != 0u; contDist = dist; contRem = hi & 63u;
+                if (i == 0) cost0 = c0;
+                if (i == N) costN = c0;
+            }
+            // back pointers: node j lives in slot j - 1; nodes 4g-3 .. 4g leave together
+            if (u == 0) {
+                if (g4 >= 4 && g4 - 4 < N) {
+                    if (g4 <= N) { GcU4 v; v.x = c1; v.y = c2; v.z = c3; v.w = lo; __builtin_memcpy(BP + (g4 - 4), &v, 16); }
+                    else { BP[g4 - 4] = c1; if (g4 - 3 < N) BP[g4 - 3] = c2; if (g4 - 2 < N) BP[g4 - 2] = c3; }
+                }
+            } else if (u == 1) c1 = lo; else if (u == 2) c2 = lo; else c3 = lo;
+            {                                                      // ---- expand node i: every lane runs this (wave operations inside); room = 0 switches a lane off
+                // bytes up to the end of the window -- in the warm-up: up to the window's first node, where the lane of the window in front stops too
+                const uint32_t room = !live ? 0u : (i < 0 ? (uint32_t)(-i) : (uint32_t)(N - i));
+                const uint32_t byte = (byG >> (8 * u)) & 0xFFu;
+                // a continuation of one byte is only a match together with the piece in front of it: at the window's first node that piece is the warm-up's guess
+                const uint32_t contX0 = i == 0 ? 2u : 1u;
+                // literal
+                if (room != 0u) {
+                    const uint32_t pr = flagLit + P[GC_PRICE_LIT + (((prevByte >> 5) & litCtxMask) << 8) + byte];
+                    const unsigned long long word = ((unsigned long long)((c0 + pr) << 6) << 32);
+                    atomicMin(&sCost[(uint32_t)(i + 1) & DPL_MMASK][lane], word);
+                    prevByte = byte;
+                }
+                // one candidate (Lx bytes at distance Dx, clipped to `room` by the caller; Lx = 0: none) as pieces of <= DPL_M bytes.  The last piece carries
+                // the length price of the whole match and, as "bytes left", what lies behind it (`behind`: also what the end of the window cut off -- the
+                // next window's warm-up finds it there); `openEnd`: the bytes behind it were not compared (hints), it is offered again where it ends
+                auto relax_cand = [&](uint32_t Lx, uint32_t behind, uint32_t Dx, uint32_t cls, uint32_t add, uint32_t x0, bool openEnd) {
+                    const uint32_t Lm = Lx < DPL_M ? Lx : DPL_M;
+                    uint32_t left = Lx - Lm + behind; if (left > 63u) left = 63u;
+                    const uint32_t wholeLen = Lx + behind < GC_MATCH_CAP ? Lx + behind : GC_MATCH_CAP;
+                    const uint32_t low = (Dx << 8) | (cls << 4);
+                    const uint32_t top = gc_wave_max(Lm >= x0 ? Lm : 0u);
+                    for (uint32_t x = 1u; x <= top; x++) {
+                        if (x >= x0 && x <= Lm) {
+                            const bool last = x == Lm && (left != 0u || openEnd);
+                            const uint32_t lp = cls == DPL_CONTC ? 0u : (uint32_t)P[(cls >= DPL_REP0 ? GC_PRICE_REPLEN : GC_PRICE_LEN) + (x == Lm && left != 0u ? wholeLen : x)];
+                            atomicMin(&sCost[(uint32_t)(i + (int32_t)x) & DPL_MMASK][lane], ((unsigned long long)(((c0 + add + lp) << 6) | (x == Lm ? left : 0u)) << 32) | (low | (last ? 0x80u : 0u) | (x - 1u)));
+                        }
+                    }
+                };
+                // the rest of a capped match whose length is known
+                {
+                    uint32_t Lc = (room != 0u && contCapped) ? contRem : 0u;
+                    const uint32_t beh = Lc > room ? Lc - room : 0u;
+                    if (Lc > room) Lc = room;
+                    if (__any(Lc != 0u)) relax_cand(Lc, beh, contDist, DPL_CONTC, DPL_CONT, contX0, false);
+                }
+                // finder candidate, short candidate
+                const uint32_t r = recG[u], r3 = r3G[u];
+                uint32_t L = r & 0xFFu; const uint32_t D = r >> 8;
+                uint32_t behL = L > room ? L - room : 0u;
+                if (L > room) L = room;
+                uint32_t L3 = 0u, D3 = 0u;
+                if (r3 != GC_SHORT_NONE) { L3 = (r3 & 15u) + 2u; D3 = (r3 >> 4) + 1u; if (L3 > room) L3 = room; if (L3 > DPL_M) L3 = DPL_M; if (L3 < MINLEN || (L >= L3 && D <= D3)) L3 = 0u; }
+                if (L < MINLEN && !(contCapped && D == contDist && L != 0u)) { L = 0u; behL = 0u; }
+#pragma unroll
+                for (uint32_t cnd = 0; cnd < 2u; cnd++) {
+                    const uint32_t Lx = cnd ? L3 : L, Dx = cnd ? D3 : D;
+                    if (__any(Lx != 0u)) {
+                        uint32_t cls = DPL_NEW, add = 0u, x0 = MINLEN;
+                        if (Lx != 0u) {
+                            const uint32_t sl = gc_dist_slot(Dx - 1u);
+                            add = newAdd + P[GC_PRICE_SLOT + sl] + (sl >= 4u ? 16u * ((sl >> 1) - 1u) : 0u);
+                            if (REPS) { const uint32_t k = dpl_which(st, Dx); if (k < 4u) { cls = DPL_REP0 + k; add = flagMat + P[GC_PRICE_FLAGS + (k == 0u ? 2u : 3u + k)]; } }
+                            if (contCapped && Dx == contDist) { cls = DPL_CONTC; add = DPL_CONT; x0 = contX0; }
+                        }
+                        relax_cand(Lx, cnd ? 0u : behL, Dx, cls, add, x0, false);
+                    }
+                }
+                // hints: repeats of the node's own distances
+                if (REPS) {
+#pragma unroll
+                    for (uint32_t k = 0; k < DPL_NH; k++) {
+                        const uint32_t h = hintG[u][k];
+                        uint32_t hl = h & 0xFFu; const uint32_t hd = h >> 8;
+                        const bool open = hl >= DPL_HCAP;
+                        if (hl > room) hl = room;
+                        uint32_t cls = 0u, add = 0u, x0 = 2u;
+                        if (hl != 0u && st.r0 == (hd | DPL_SURE) && !(contCapped && hd == contDist)) {          // LZMA's short repeat: one byte at rep0, known for certain
+                            const uint32_t pr = flagMat + P[GC_PRICE_FLAGS + 3u];
+                            atomicMin(&sCost[(uint32_t)(i + 1) & DPL_MMASK][lane], ((unsigned long long)((c0 + pr) << 6) << 32) | ((hd << 8) | (DPL_SREP << 4)));
+                        }
+                        if (hl != 0u && (hd == D || hd == D3)) hl = (hd == D ? L : L3) >= hl ? 0u : hl;          // the candidate itself covers it
+                        if (hl != 0u) {
+                            const uint32_t kk = dpl_which(st, hd);
+                            if (contCapped && hd == contDist) { cls = DPL_CONTC; add = DPL_CONT; x0 = contX0; }
+                            else if (kk < 4u) { cls = DPL_REP0 + kk; add = flagMat + P[GC_PRICE_FLAGS + (kk == 0u ? 2u : 3u + kk)]; }
+                            else hl = 0u;
+                        }
+                        if (__any(hl >= x0)) relax_cand(hl >= x0 ? hl : 0u, 0u, hd, cls, add, x0, open);
+                    }
+                }
+            }
+        }
+        // ---- next group: hint bytes that have arrived -> lengths; new requests with the newest node's distances; the shadow parse moves on
+        if (REPS) { hints_arrive(); hint_stage(g4 + 8, recNN); }
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) { recG[u] = recN[u]; recN[u] = recNN[u]; r3G[u] = r3N[u]; r3N[u] = r3NN[u]; }
+        byG = byN; byN = byNN;
+    }
+    // back pointers of the last nodes (n not a multiple of four is covered above; n a multiple of four: nodes n-3 .. n left at g4 = n)
+    gc_wave_sync_global();
+    if (winCost != nullptr && BPW == 1u) {                        // estimate per 4 KiB range-coder chunk = two windows
+        costN -= cost0;
+        const uint32_t other = __shfl_xor(costN, 1);
+        if ((lane & 1u) == 0u && w0 < blockLen) winCost[(uint64_t)b * (GC_ZSTD_BLOCK_MAX >> 12) + (lane >> 1)] = costN + other;
+    }
+    // ---- walk back, slot by slot in lockstep: slot q holds the back pointer of node q + 1 and receives the record of position q
+    uint32_t j = n;                                               // end node of the edge the walk is inside of (slots s .. j - 1)
+    uint32_t s = n, eDist = 0u, eCls = 0u;                        // its start node, distance, class of its FIRST piece so far
+    uint32_t runEnd = 0u;                                         // end of the run of pieces with one distance that the edge belongs to
+    uint32_t nextLo = n ? BP[n - 1u] : 0u;                        // back pointer of node j (read one slot early)
+    uint32_t nRecs = 0u, nLitC = 0u;
+    for (uint32_t it = 0; it < nMax; it++) {
+        const uint32_t q = n - 1u - it;                           // (wraps for finished lanes)
+        if (it < n) {
+            if (q + 1u == j) {                                    // a new edge (walking backwards): ends at node j, starts at node s
+                const uint32_t len = (nextLo & 15u) + 1u;
+                const uint32_t dist = nextLo >> 8;
+                const bool joins = dist != 0u && dist == eDist && s == j;      // same distance as the piece behind it: one run
+                if (!joins) runEnd = j;
+                eDist = dist; eCls = (nextLo >> 4) & 7u; s = j - len;
+            }
+            uint32_t out = 0u;
+            if (q == s) {                                         // start of the edge: read the back pointer of node s now (slot s - 1)
+                nextLo = s ? BP[s - 1u] : 0u;
+                const bool runGoesOn = s != 0u && eDist != 0u && (nextLo >> 8) == eDist;
+                const uint32_t span = runEnd - q;                 // bytes from here to the end of the run
+                if (eDist != 0u) {
+                    if (!runGoesOn) {                             // first record of the run: what is left after the 64-byte records behind it
+                        out = (eDist << 8) | (span - ((span - 1u) & ~63u));
+                        if (phaseA) {
+                            atomicAdd(&sCnt[lb][((eCls >= DPL_REP0 && eCls <= DPL_REP0 + 3u) ? GC_DPS_REPLEN : GC_DPS_LEN) + (span < 64u ? span : 64u)], 1u);
+                            if (eCls == DPL_NEW) atomicAdd(&sCnt[lb][GC_DPS_SLOT + gc_dist_slot(eDist - 1u)], 1u);
+                            else if (eCls == DPL_SREP) atomicAdd(&sCnt[lb][GC_DPS_NSREP], 1u);
+                            else if (eCls == DPL_REP0) atomicAdd(&sCnt[lb][GC_DPS_NREP], 1u);
+                            else if (eCls >= DPL_REP0 + 1u && eCls <= DPL_REP0 + 3u) atomicAdd(&sCnt[lb][GC_DPS_NREP1 + (eCls - DPL_REP0 - 1u)], 1u);
+                            atomicAdd(&sCnt[lb][GC_DPS_NMAT], 1u);
+                        }
+                    } else if ((span & 63u) == 0u) out = (eDist << 8) | 64u;
+                } else nLitC++;
+                j = s;
+            } else if (eDist != 0u && ((runEnd - q) & 63u) == 0u) out = (eDist << 8) | 64u;
+            if (out != 0u) nRecs++;
+            if (!phaseA) BP[q] = out;
+        }
+    }
+    if (phaseA) {
+        if (n != 0u) atomicAdd(&sCnt[lb][GC_DPS_NLIT], nLitC);
+        gc_wave_sync();
+        for (uint32_t q = 0; q < BPW; q++) {
+            const uint32_t bb = item * BPW + q;
+            if (bb >= nBlocks) continue;
+            uint32_t* C = dpStat + (uint64_t)bb * GC_DPS_WORDS;
+            for (uint32_t i = lane; i < GC_DPS_WORDS; i += 64u) { const uint32_t v = sCnt[q][i]; if (v) atomicAdd(&C[i], v); }
+        }
+        return;
+    }
+    // The sequence arrays behind W6 hold GC_MAX_SEQ_PER_BLOCK = 128 KiB / 5 entries per block: a window whose path has more records than its
+    // share falls back to the finder's own records (followed from the window start they are matches of >= GC_MIN_MATCH bytes but the last one)
+    const bool fallback = nRecs > n / GC_MIN_MATCH;
+    if (__any(fallback)) {
+        gc_wave_sync_global();
+        if (fallback) for (uint32_t q = 0; q < n; q++) {          // (W6 follows them from the window start)
+            const uint32_t r = R[q];
+            uint32_t L = r & 0xFFu; if (L > n - q) L = n - q;
+            BP[q] = (L >= MINLEN && (r & 0xFFu) >= GC_MIN_MATCH) ? ((r & ~0xFFu) | L) : 0u;
+        }
+    }
+}
+
+// one kernel per codec family and grid shape (the shared arrays of dpl_run are per instantiation)
+#define DPL_KERNEL(name, REPS, MINLEN, BPW) \
+extern "C" __global__ void __launch_bounds__(64) \
+name(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t frameBlocks, uint32_t phase, uint32_t* __restrict__ dpStat, uint32_t litCtxMask, \
+     const uint32_t* __restrict__ rec, const uint16_t* __restrict__ rec3, const uint16_t* __restrict__ priceTab, uint32_t* __restrict__ recOut, uint32_t* __restrict__ winCost) \
+{ dpl_run<REPS, MINLEN, BPW>(src, srcSize, nBlocks, per, frameBlocks, phase, dpStat, litCtxMask, rec, rec3, priceTab, recOut, winCost); }
+
+DPL_KERNEL(gc_mf_dpl2_kernel,  true, 2u, 1u)      // LZMA: every window
+DPL_KERNEL(gc_mf_dpl2s_kernel, true, 2u, 2u)      // LZMA: the sample of phase A
+DPL_KERNEL(gc_mf_dpl3_kernel,  false, 3u, 1u)     // zstd, brotli
+DPL_KERNEL(gc_mf_dpl3s_kernel, false, 3u, 2u)

@@ -112,7 +112,8 @@ static inline GcMfGeom gc_mf_geom(uint64_t n, uint32_t frameBlocks, bool fast)
 #define GC_PRICE_NLEN   80u
 #define GC_PRICE_SLOT   (GC_PRICE_LEN + GC_PRICE_NLEN)            // [LZMA distance slot 0..63] (without the footer bits)
 #define GC_PRICE_FLAGS  (GC_PRICE_SLOT + 64u)                     // literal flag, match flag
-#define GC_PRICE_WORDS  (GC_PRICE_FLAGS + 8u)                     // 2200: a multiple of 8 (16-byte rows)
+#define GC_PRICE_REPLEN (GC_PRICE_FLAGS + 8u)                     // W7L: [length 0..79] of a repeat match (LZMA codes those with a coder of their own, LzmaEnc.c repLenEnc)
+#define GC_PRICE_WORDS  (GC_PRICE_REPLEN + GC_PRICE_NLEN)         // 2280: a multiple of 8 (16-byte rows)
 #define GC_PRICE_MAX    240u               // 15 bits: literal + flag of 4096 positions stay below 2^21 units (the cost field of a W7 node)
 // Symbol counts of the price-based parse's own path (W7 phase A, a sample of the windows of every block): what phase B prices
 // lengths, distance slots and the literal / match flag with.  uint32 per block.
@@ -122,7 +123,11 @@ static inline GcMfGeom gc_mf_geom(uint64_t n, uint32_t frameBlocks, bool fast)
 #define GC_DPS_NMAT     (GC_DPS_NLIT + 1u)
 #define GC_DPS_NREP      (GC_DPS_NLIT + 2u)     // repeats of >= 2 bytes found through the path's own distance
 #define GC_DPS_NSREP     (GC_DPS_NLIT + 3u)     // short repeats (one byte)
-#define GC_DPS_WORDS    160u
+#define GC_DPS_NREP1     (GC_DPS_NLIT + 4u)     // W7L: repeats of the second / third / fourth last distance (rep1, rep2, rep3: consecutive words)
+#define GC_DPS_NREP2     (GC_DPS_NLIT + 5u)
+#define GC_DPS_NREP3     (GC_DPS_NLIT + 6u)
+#define GC_DPS_REPLEN   160u               // [length 0..79] of the repeat matches
+#define GC_DPS_WORDS    240u
 #define GC_SHORT_NONE   0xFFFFu            // W5s -> W7: uint16 per position, (distance - 1) << 4 | (length - 2), or none
 
 // Workgroup index -> work item such that each of the 8 XCDs (workgroups are dealt round-robin to XCDs) owns one contiguous

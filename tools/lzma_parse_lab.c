@@ -423,6 +423,17 @@ static void parse_dp_gpu(DpCfg cfg, int greedyLazy)
     Sym* out = malloc(sizeof(Sym) * (N / 2 + 16)); u32 nOut = 0;
     Node2* nd = malloc(sizeof(Node2) * (cfg.win + 2));
     Enc pe; pe.update = 0;
+    /* repCompare >= 2: rep candidates only at distances named by HINTS = the last 4 distinct distances of the previous parse's matches that start before p
+     * (repCompare 3: matches that END at or before p) -- position-only data, computable in parallel before the DP */
+    u32* hint = NULL;
+    static Sym* gGreedy = NULL; static u32 nGreedy = 0;
+    if (!g_dpIter) { gGreedy = malloc(sizeof(Sym) * (nSyms + 1)); memcpy(gGreedy, syms, sizeof(Sym) * nSyms); nGreedy = nSyms; }
+    if (cfg.repCompare >= 2) { Sym* g = gGreedy && getenv("LAB_HINT_GREEDY") ? gGreedy : syms; u32 ng = gGreedy && getenv("LAB_HINT_GREEDY") ? nGreedy : nSyms;
+        hint = calloc((size_t)N * 4, 4); u32 lru[4] = {0,0,0,0}; u32 k = 0; int nh = getenv("LAB_NHINT") ? atoi(getenv("LAB_NHINT")) : 4;
+        for (u32 p = 0; p < N; p++) {
+            if (p % FRAME == 0) lru[0] = lru[1] = lru[2] = lru[3] = 0;
+            while (k < ng && (cfg.repCompare == 3 ? g[k].pos + g[k].len <= p : g[k].pos < p)) { u32 d = g[k].off; int j = 0; for (j = 0; j < 3; j++) if (lru[j] == d) break; for (; j > 0; j--) lru[j] = lru[j - 1]; lru[0] = d; k++; }
+            for (int j = 0; j < 4; j++) hint[(size_t)p * 4 + j] = j < nh ? lru[j] : 0; } }
     for (u32 b0 = 0; b0 < N; b0 += (128u << 10)) {
         u32 b1 = b0 + (128u << 10) < N ? b0 + (128u << 10) : N;
         memcpy(syms, g, sizeof(Sym) * ng); nSyms = ng;
@@ -431,16 +442,26 @@ static void parse_dp_gpu(DpCfg cfg, int greedyLazy)
             u32 w1 = w0 + cfg.win < b1 ? w0 + cfg.win : b1, n = w1 - w0;
             for (u32 i = 0; i <= n; i++) nd[i].cost = 1e30f;
             nd[0].cost = 0; nd[0].s.st = 0; nd[0].s.rep[0] = nd[0].s.rep[1] = nd[0].s.rep[2] = nd[0].s.rep[3] = 0;   /* 0 = unknown */
+            if (hint && getenv("LAB_INITREP")) for (int j = 0; j < 4; j++) nd[0].s.rep[j] = hint[(size_t)w0 * 4 + j];
+            u32 skipTo = 0; int nice = getenv("LAB_NICE2") ? atoi(getenv("LAB_NICE2")) : 0; int hcap = getenv("LAB_HCAP") ? atoi(getenv("LAB_HCAP")) : 273;
             for (u32 i = 0; i < n; i++) {
                 u32 p = w0 + i; St s = nd[i].s; u32 fs = p / FRAME * FRAME; float c0 = nd[i].cost;
+                if (i < skipTo || c0 > 1e29f) continue;
+                if (nice) { u32 d = recOff[p], l = recLen[p]; if (l) { u32 mx = n - i; l = full_len(p, d, l, mx < 64 ? mx : 64); if (l >= (u32)nice) {
+                    u32 kind = 1; for (u32 r = 0; r < (u32)cfg.repDetect; r++) if (s.rep[r] == d) { kind = 3 + r; break; }
+                    pe.bits = 0; St t = s; for (int q = 0; q < 4; q++) if (!t.rep[q]) t.rep[q] = 0xFFFFFFFFu; e_symbol(&pe, &t, p, kind, l, d); for (int q = 0; q < 4; q++) if (t.rep[q] == 0xFFFFFFFFu) t.rep[q] = 0;
+                    for (u32 x = i + 1; x <= n; x++) nd[x].cost = 1e30f;
+                    dp_relax(nd, i + l, c0 + (float)pe.bits, i, kind, l, d, 0, &t); skipTo = i + l; continue; } } }
                 if (cfg.simpleState) s.st = s.st >= 7 ? 7 : 0;
                 St sl = s; if (!sl.rep[0]) sl.rep[0] = 1;
                 { pe.bits = 0; St t = sl; if (cfg.litPlain && t.st >= 7) { u32 keep = t.st; t.st = 0; e_symbol(&pe, &t, p, 0, 0, 0); t.st = st_lit(keep); pe.bits += 0; } else e_symbol(&pe, &t, p, 0, 0, 0);
                   t.rep[0] = s.rep[0]; dp_relax(nd, i + 1, c0 + (float)pe.bits, i, 0, 0, 0, 0, &t); }
                 u32 maxl = n - i; if (maxl > 273) maxl = 273;
-                if (cfg.shortRep && s.rep[0] && p >= fs + s.rep[0] && S[p] == S[p - s.rep[0]]) { pe.bits = 0; St t = s; e_symbol(&pe, &t, p, 2, 1, 0); dp_relax(nd, i + 1, c0 + (float)pe.bits, i, 2, 1, 0, 0, &t); }
+                if (cfg.shortRep && s.rep[0] && p >= fs + s.rep[0] && S[p] == S[p - s.rep[0]] && (!hint || getenv("LAB_SREP_FREE") || hint[(size_t)p*4]==s.rep[0] || hint[(size_t)p*4+1]==s.rep[0] || hint[(size_t)p*4+2]==s.rep[0] || hint[(size_t)p*4+3]==s.rep[0])) { pe.bits = 0; St t = s; e_symbol(&pe, &t, p, 2, 1, 0); dp_relax(nd, i + 1, c0 + (float)pe.bits, i, 2, 1, 0, 0, &t); }
                 if (maxl < 2) continue;
-                if (cfg.repCompare) for (u32 r = 0; r < 4; r++) { u32 d = s.rep[r]; if (!d || p < fs + d) continue; u32 l = mlen(p, p - d, maxl); if (l < 2) continue;
+                if (cfg.repCompare) for (u32 r = 0; r < 4; r++) { u32 d = s.rep[r]; if (!d || p < fs + d) continue;
+                    if (hint) { int ok = 0; for (int j = 0; j < 4; j++) if (hint[(size_t)p * 4 + j] == d) ok = 1; if (!ok) continue; }
+                    u32 l = mlen(p, p - d, maxl < (u32)hcap ? maxl : (u32)hcap); if (l < 2) continue;
                     for (u32 x = 2; x <= l; x++) { pe.bits = 0; St t = s; e_symbol(&pe, &t, p, 3 + r, x, d); dp_relax(nd, i + x, c0 + (float)pe.bits, i, 3 + r, x, d, 0, &t); } }
                 for (int w = 0; w < 2; w++) {
                     u32 d = w ? rec3Off[p] : recOff[p], l = w ? rec3Len[p] : recLen[p];
@@ -459,7 +480,7 @@ static void parse_dp_gpu(DpCfg cfg, int greedyLazy)
                     }
                 }
             }
-            static u32 stack[8192]; u32 sp = 0; for (u32 i = n; i != 0; i = nd[i].prev) stack[sp++] = i;
+            static u32 stack[140000]; u32 sp = 0; for (u32 i = n; i != 0; i = nd[i].prev) stack[sp++] = i;
             u32 at = 0;
             while (sp) { u32 i = stack[--sp]; u32 p = w0 + at;
                 if (nd[i].kind == 9) { out[nOut].pos = p; out[nOut].len = nd[i].len; out[nOut].off = nd[i].off; nOut++; out[nOut].pos = p + nd[i].len + 1; out[nOut].len = nd[i].len2; out[nOut].off = nd[i].off; nOut++; }
