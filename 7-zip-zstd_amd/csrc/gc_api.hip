@@ -467,9 +467,10 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
             const uint32_t nDpWg = nBlocks * (phase == 0u ? 1u : 8u), perD = gc_xcd_per(nDpWg);
             uint32_t* wcp = phase == 0u ? (uint32_t*)nullptr : wc;
             if (laneDp) {
-                const uint32_t nItems = phase == 0u ? (nBlocks + 1u) / 2u : nBlocks, perL = gc_xcd_per(nItems);
+                uint32_t fullA = 0u; gc_env_u32("GC_DP_FULLA", 0u, 1u, &fullA);      // test hook: phase A over every window
+                const uint32_t nItems = (nBlocks + 1u) / 2u, perL = gc_xcd_per(nItems);     // a wave = two blocks
                 if (c->priceMinLen <= 2u) {
-                    if (phase == 0u) GC_LAUNCH(gc_mf_dpl2s_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
+                    if (phase == 0u && !fullA) GC_LAUNCH(gc_mf_dpl2s_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
                     else GC_LAUNCH(gc_mf_dpl2_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
                 } else {
                     if (phase == 0u) GC_LAUNCH(gc_mf_dpl3s_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);

@@ -36,8 +36,17 @@
 #include "gc_mf.h"
 #include "gc_lz_parse.h"
 
-#define DPL_M        16u
+#ifndef DPL_LENBITS
+#define DPL_LENBITS  5u
+#endif
+#define DPL_M        (1u << DPL_LENBITS)
 #define DPL_MMASK    (DPL_M - 1u)
+// low word of a node: distance | capped | class | length - 1
+#define DPL_LO_LEN(lo)   (((lo) & DPL_MMASK) + 1u)
+#define DPL_LO_CLS(lo)   (((lo) >> DPL_LENBITS) & 7u)
+#define DPL_LO_CAP(lo)   (((lo) >> (DPL_LENBITS + 3u)) & 1u)
+#define DPL_LO_DIST(lo)  ((lo) >> (DPL_LENBITS + 4u))
+#define DPL_LO(dist, cap, cls, len) (((dist) << (DPL_LENBITS + 4u)) | ((cap) ? 1u << (DPL_LENBITS + 3u) : 0u) | ((cls) << DPL_LENBITS) | ((len) - 1u))
 #define DPL_INF      0xFFFFFFFFFFFFFFFFull
 #define DPL_CONT     4u               // the rest of a capped match: a quarter of a bit (as DP_CONT_PRICE of W7)
 #define DPL_WARM     256              // positions in front of a window that the programme runs over for its state
@@ -70,22 +79,23 @@ __device__ __forceinline__ void dpl_mtf(DplReps& s, uint32_t d, uint32_t sure)
 }
 __device__ __forceinline__ void dpl_lru_put(uint32_t (&l)[2], uint32_t d) { if (l[0] != d) { l[1] = l[0]; l[0] = d; } }
 
-template <bool REPS, uint32_t MINLEN, uint32_t BPW /* blocks per wave: 1 = all windows of a block (64 x 2 KiB), 2 = a sample (32 x 512 B of each) */>
+template <bool REPS, uint32_t MINLEN, bool SAMPLE /* a wave = two blocks: false = all their windows (2 x 32 x 4 KiB), true = a sample (32 x 512 B of each, counted) */>
 __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t frameBlocks, uint32_t phaseArg, uint32_t* __restrict__ dpStat,
                                         uint32_t litCtxArg, const uint32_t* __restrict__ rec, const uint16_t* __restrict__ rec3, const uint16_t* __restrict__ priceTab,
                                         uint32_t* __restrict__ recOut, uint32_t* __restrict__ winCost)
 {
     __shared__ unsigned long long sCost[DPL_M][64];
     __shared__ GcU4 sReps[REPS ? DPL_M : 1u][64];
+    constexpr uint32_t BPW = 2u;
     __shared__ uint16_t sPrice[BPW][GC_PRICE_WORDS];
-    __shared__ uint32_t sCnt[BPW][GC_DPS_WORDS];
+    __shared__ uint32_t sCnt[SAMPLE ? BPW : 1u][SAMPLE ? GC_DPS_WORDS : 1u];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t litCtxMask = litCtxArg & 0xFFu, hasPrev = litCtxArg >> 31;
-    const bool phaseA = phaseArg == 0u, phaseB = phaseArg == 1u;
+    const bool phaseA = SAMPLE && phaseArg == 0u, phaseB = phaseArg == 1u;      // (the sample kernels count: phase A; the others run phase B, or phase 2 = W6's prices as they are)
     const uint32_t item = dpl_item(blockIdx.x, per);
     if (item * BPW >= nBlocks) return;                            // (uniform)
     // ---- this lane's window
-    const uint32_t lb = BPW == 1u ? 0u : lane >> 5;               // block of the wave
+    const uint32_t lb = lane >> 5;                                // block of the wave
     const uint32_t b = item * BPW + lb;
     const bool blockLive = b < nBlocks;
     const uint64_t base = (uint64_t)(blockLive ? b : 0u) * GC_ZSTD_BLOCK_MAX;
@@ -93,12 +103,13 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
 #ifdef HIPEMU
     static const int xWin4k = getenv("GC_X_WIN4K") ? atoi(getenv("GC_X_WIN4K")) : 0, xNoHint = getenv("GC_X_NOHINT") ? atoi(getenv("GC_X_NOHINT")) : 0, xWarm = getenv("GC_X_WARM") ? atoi(getenv("GC_X_WARM")) : DPL_WARM;
     static const int xHints = getenv("GC_X_HINTS") ? atoi(getenv("GC_X_HINTS")) : 63;
-    const uint32_t winLen = BPW == 1u ? (xWin4k ? 4096u : 2048u) : 512u;
-    const uint32_t w0 = BPW == 1u ? (xWin4k ? (lane < 32u ? lane << 12 : GC_ZSTD_BLOCK_MAX) : lane << 11) : ((lane & 31u) << 12) + 1536u;
+    (void)xWin4k;
+    const uint32_t winLen = SAMPLE ? 512u : 4096u;
+    const uint32_t w0 = ((lane & 31u) << 12) + (SAMPLE ? 1536u : 0u);
 #else
     const int xWarm = DPL_WARM;
-    const uint32_t winLen = BPW == 1u ? 2048u : 512u;
-    const uint32_t w0 = BPW == 1u ? lane << 11 : ((lane & 31u) << 12) + 1536u;
+    const uint32_t winLen = SAMPLE ? 512u : 4096u;
+    const uint32_t w0 = ((lane & 31u) << 12) + (SAMPLE ? 1536u : 0u);
 #endif
     const uint32_t n = w0 < blockLen ? ((blockLen - w0) < winLen ? (blockLen - w0) : winLen) : 0u;       // nodes 0 .. n
     const uint32_t nMax = gc_wave_max(n);
@@ -272,14 +283,14 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
             const uint32_t c0 = hi >> 6;
             const bool live = n != 0u && i >= -warm && i <= N;
             if (live && i > -warm) {                               // ---- finalize node i
-                const uint32_t len = (lo & 15u) + 1u, cls = (lo >> 4) & 7u, dist = lo >> 8;
+                const uint32_t len = DPL_LO_LEN(lo), cls = DPL_LO_CLS(lo), dist = DPL_LO_DIST(lo);
                 if (REPS) {
                     const GcU4 pv = sReps[(uint32_t)(i - (int32_t)len) & DPL_MMASK][lane];
                     st.r0 = pv.x; st.r1 = pv.y; st.r2 = pv.z; st.r3 = pv.w;
                     if (cls != DPL_LIT && cls != DPL_SREP) dpl_mtf(st, dist, i - (int32_t)len >= 0 ? DPL_SURE : 0u);
                     GcU4 nv; nv.x = st.r0; nv.y = st.r1; nv.z = st.r2; nv.w = st.r3; sReps[slot][lane] = nv;
                 }
-                contCapped = ((lo >> 7) & 1u) != 0u; contDist = dist; contRem = hi & 63u;
+                contCapped = DPL_LO_CAP(lo) != 0u; contDist = dist; contRem = hi & 63u;
                 if (i == 0) cost0 = c0;
                 if (i == N) costN = c0;
             }
@@ -290,7 +301,7 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
                     else { BP[g4 - 4] = c1; if (g4 - 3 < N) BP[g4 - 3] = c2; if (g4 - 2 < N) BP[g4 - 2] = c3; }
                 }
             } else if (u == 1) c1 = lo; else if (u == 2) c2 = lo; else c3 = lo;
-            {                                                      // ---- expand node i: every lane runs this (wave operations inside); room = 0 switches a lane off
+            {                                                      // ---- expand node i (room = 0: a lane without this node)
                 // bytes up to the end of the window -- in the warm-up: up to the window's first node, where the lane of the window in front stops too
                 const uint32_t room = !live ? 0u : (i < 0 ? (uint32_t)(-i) : (uint32_t)(N - i));
                 const uint32_t byte = (byG >> (8 * u)) & 0xFFu;
@@ -310,13 +321,11 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
                     const uint32_t Lm = Lx < DPL_M ? Lx : DPL_M;
                     uint32_t left = Lx - Lm + behind; if (left > 63u) left = 63u;
                     const uint32_t wholeLen = Lx + behind < GC_MATCH_CAP ? Lx + behind : GC_MATCH_CAP;
-                    const uint32_t low = (Dx << 8) | (cls << 4);
-                    const uint32_t top = gc_wave_max(Lm >= x0 ? Lm : 0u);
-                    for (uint32_t x = 1u; x <= top; x++) {
-                        if (x >= x0 && x <= Lm) {
+                    for (uint32_t x = x0; x <= Lm; x++) {                  // (a plain divergent loop: the lanes touch nothing but their own columns)
+                        {
                             const bool last = x == Lm && (left != 0u || openEnd);
                             const uint32_t lp = cls == DPL_CONTC ? 0u : (uint32_t)P[(cls >= DPL_REP0 ? GC_PRICE_REPLEN : GC_PRICE_LEN) + (x == Lm && left != 0u ? wholeLen : x)];
-                            atomicMin(&sCost[(uint32_t)(i + (int32_t)x) & DPL_MMASK][lane], ((unsigned long long)(((c0 + add + lp) << 6) | (x == Lm ? left : 0u)) << 32) | (low | (last ? 0x80u : 0u) | (x - 1u)));
+                            atomicMin(&sCost[(uint32_t)(i + (int32_t)x) & DPL_MMASK][lane], ((unsigned long long)(((c0 + add + lp) << 6) | (x == Lm ? left : 0u)) << 32) | DPL_LO(Dx, last, cls, x));
                         }
                     }
                 };
@@ -325,7 +334,7 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
                     uint32_t Lc = (room != 0u && contCapped) ? contRem : 0u;
                     const uint32_t beh = Lc > room ? Lc - room : 0u;
                     if (Lc > room) Lc = room;
-                    if (__any(Lc != 0u)) relax_cand(Lc, beh, contDist, DPL_CONTC, DPL_CONT, contX0, false);
+                    if (Lc != 0u) relax_cand(Lc, beh, contDist, DPL_CONTC, DPL_CONT, contX0, false);
                 }
                 // finder candidate, short candidate
                 const uint32_t r = recG[u], r3 = r3G[u];
@@ -338,15 +347,15 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
 #pragma unroll
                 for (uint32_t cnd = 0; cnd < 2u; cnd++) {
                     const uint32_t Lx = cnd ? L3 : L, Dx = cnd ? D3 : D;
-                    if (__any(Lx != 0u)) {
+                    if (Lx != 0u) {
                         uint32_t cls = DPL_NEW, add = 0u, x0 = MINLEN;
-                        if (Lx != 0u) {
+                        {
                             const uint32_t sl = gc_dist_slot(Dx - 1u);
                             add = newAdd + P[GC_PRICE_SLOT + sl] + (sl >= 4u ? 16u * ((sl >> 1) - 1u) : 0u);
                             if (REPS) { const uint32_t k = dpl_which(st, Dx); if (k < 4u) { cls = DPL_REP0 + k; add = flagMat + P[GC_PRICE_FLAGS + (k == 0u ? 2u : 3u + k)]; } }
                             if (contCapped && Dx == contDist) { cls = DPL_CONTC; add = DPL_CONT; x0 = contX0; }
                         }
-                        relax_cand(Lx, cnd ? 0u : behL, Dx, cls, add, x0, false);
+                        relax_cand(Lx, cnd ? 0u : behL, Dx, cls, add, x0, !cnd && (r & 0xFFu) == GC_MATCH_CAP);     // a capped record goes on in the record behind it
                     }
                 }
                 // hints: repeats of the node's own distances
@@ -360,7 +369,7 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
                         uint32_t cls = 0u, add = 0u, x0 = 2u;
                         if (hl != 0u && st.r0 == (hd | DPL_SURE) && !(contCapped && hd == contDist)) {          // LZMA's short repeat: one byte at rep0, known for certain
                             const uint32_t pr = flagMat + P[GC_PRICE_FLAGS + 3u];
-                            atomicMin(&sCost[(uint32_t)(i + 1) & DPL_MMASK][lane], ((unsigned long long)((c0 + pr) << 6) << 32) | ((hd << 8) | (DPL_SREP << 4)));
+                            atomicMin(&sCost[(uint32_t)(i + 1) & DPL_MMASK][lane], ((unsigned long long)((c0 + pr) << 6) << 32) | DPL_LO(hd, false, DPL_SREP, 1u));
                         }
                         if (hl != 0u && (hd == D || hd == D3)) hl = (hd == D ? L : L3) >= hl ? 0u : hl;          // the candidate itself covers it
                         if (hl != 0u) {
@@ -369,7 +378,7 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
                             else if (kk < 4u) { cls = DPL_REP0 + kk; add = flagMat + P[GC_PRICE_FLAGS + (kk == 0u ? 2u : 3u + kk)]; }
                             else hl = 0u;
                         }
-                        if (__any(hl >= x0)) relax_cand(hl >= x0 ? hl : 0u, 0u, hd, cls, add, x0, open);
+                        if (hl >= x0) relax_cand(hl, 0u, hd, cls, add, x0, open);
                     }
                 }
             }
@@ -382,11 +391,7 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
     }
     // back pointers of the last nodes (n not a multiple of four is covered above; n a multiple of four: nodes n-3 .. n left at g4 = n)
     gc_wave_sync_global();
-    if (winCost != nullptr && BPW == 1u) {                        // estimate per 4 KiB range-coder chunk = two windows
-        costN -= cost0;
-        const uint32_t other = __shfl_xor(costN, 1);
-        if ((lane & 1u) == 0u && w0 < blockLen) winCost[(uint64_t)b * (GC_ZSTD_BLOCK_MAX >> 12) + (lane >> 1)] = costN + other;
-    }
+    if (winCost != nullptr && !SAMPLE && w0 < blockLen) winCost[(uint64_t)b * (GC_ZSTD_BLOCK_MAX >> 12) + (lane & 31u)] = costN - cost0;     // estimate per 4 KiB range-coder chunk
     // ---- walk back, slot by slot in lockstep: slot q holds the back pointer of node q + 1 and receives the record of position q
     uint32_t j = n;                                               // end node of the edge the walk is inside of (slots s .. j - 1)
     uint32_t s = n, eDist = 0u, eCls = 0u;                        // its start node, distance, class of its FIRST piece so far
@@ -397,16 +402,16 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
         const uint32_t q = n - 1u - it;                           // (wraps for finished lanes)
         if (it < n) {
             if (q + 1u == j) {                                    // a new edge (walking backwards): ends at node j, starts at node s
-                const uint32_t len = (nextLo & 15u) + 1u;
-                const uint32_t dist = nextLo >> 8;
+                const uint32_t len = DPL_LO_LEN(nextLo);
+                const uint32_t dist = DPL_LO_DIST(nextLo);
                 const bool joins = dist != 0u && dist == eDist && s == j;      // same distance as the piece behind it: one run
                 if (!joins) runEnd = j;
-                eDist = dist; eCls = (nextLo >> 4) & 7u; s = j - len;
+                eDist = dist; eCls = DPL_LO_CLS(nextLo); s = j - len;
             }
             uint32_t out = 0u;
             if (q == s) {                                         // start of the edge: read the back pointer of node s now (slot s - 1)
                 nextLo = s ? BP[s - 1u] : 0u;
-                const bool runGoesOn = s != 0u && eDist != 0u && (nextLo >> 8) == eDist;
+                const bool runGoesOn = s != 0u && eDist != 0u && DPL_LO_DIST(nextLo) == eDist;
                 const uint32_t span = runEnd - q;                 // bytes from here to the end of the run
                 if (eDist != 0u) {
                     if (!runGoesOn) {                             // first record of the run: what is left after the 64-byte records behind it
@@ -452,13 +457,13 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
 }
 
 // one kernel per codec family and grid shape (the shared arrays of dpl_run are per instantiation)
-#define DPL_KERNEL(name, REPS, MINLEN, BPW) \
+#define DPL_KERNEL(name, REPS, MINLEN, SAMPLE) \
 extern "C" __global__ void __launch_bounds__(64) \
 name(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t frameBlocks, uint32_t phase, uint32_t* __restrict__ dpStat, uint32_t litCtxMask, \
      const uint32_t* __restrict__ rec, const uint16_t* __restrict__ rec3, const uint16_t* __restrict__ priceTab, uint32_t* __restrict__ recOut, uint32_t* __restrict__ winCost) \
-{ dpl_run<REPS, MINLEN, BPW>(src, srcSize, nBlocks, per, frameBlocks, phase, dpStat, litCtxMask, rec, rec3, priceTab, recOut, winCost); }
+{ dpl_run<REPS, MINLEN, SAMPLE>(src, srcSize, nBlocks, per, frameBlocks, phase, dpStat, litCtxMask, rec, rec3, priceTab, recOut, winCost); }
 
-DPL_KERNEL(gc_mf_dpl2_kernel,  true, 2u, 1u)      // LZMA: every window
-DPL_KERNEL(gc_mf_dpl2s_kernel, true, 2u, 2u)      // LZMA: the sample of phase A
-DPL_KERNEL(gc_mf_dpl3_kernel,  false, 3u, 1u)     // zstd, brotli
-DPL_KERNEL(gc_mf_dpl3s_kernel, false, 3u, 2u)
+DPL_KERNEL(gc_mf_dpl2_kernel,  true, 2u, false)   // LZMA: every window
+DPL_KERNEL(gc_mf_dpl2s_kernel, true, 2u, true)    // LZMA: the sample of phase A
+DPL_KERNEL(gc_mf_dpl3_kernel,  false, 3u, false)  // zstd, brotli
+DPL_KERNEL(gc_mf_dpl3s_kernel, false, 3u, true)

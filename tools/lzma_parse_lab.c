@@ -309,6 +309,9 @@ static void refine_records(void)
 /* ---------------------------------------------------------------- optimal parse (upper bound for these candidates) */
 typedef struct { float cost; u32 prev; u32 len; u32 off; u8 kind; St s; } Node;
 static u32 full_len(u32 p, u32 off, u32 have, u32 lim) { u32 l = have; while (l < lim && S[p + l] == S[p + l - off]) l++; return l; }
+static Sym* g_optG; static u32 g_optNG;      /* LAB_OPT_STATIC: a greedy parse whose block statistics price the optimal parse (instead of the live model) */
+static void count_block(u32 b0, u32 b1);
+static Model g_blockModel;
 static void parse_optimal(int segLog, int use3, int allLens)
 {
     static Model m; Enc pe; pe.m = &m; pe.update = 0;
@@ -320,6 +323,7 @@ static void parse_optimal(int segLog, int use3, int allLens)
     for (u32 ss = 0; ss < N; ss += segSize) {
         u32 se = ss + segSize < N ? ss + segSize : N;
         model_reset(&m);
+        if (g_optG) { Sym* keep = syms; u32 kn = nSyms; syms = g_optG; nSyms = g_optNG; count_block(ss, se); syms = keep; nSyms = kn; pe.m = &g_blockModel; }
         St cur; cur.st = 0; cur.rep[0] = cur.rep[1] = cur.rep[2] = cur.rep[3] = 1;
         u32 s0 = ss;
         while (s0 < se) {
@@ -383,7 +387,7 @@ static void parse_optimal(int segLog, int use3, int allLens)
  *     the precomputed continuation behind every record: match(d, L) + literal + rep0(d, c)
  *   - no short rep; matched literals priced exactly or as plain literals (flag) */
 typedef struct { int staticPrices, win, repCompare, composite, shortRep, litPlain, use3, maxLenCap, repDetect, d3max, simpleState; } DpCfg;
-static Model g_blockModel; static u32 g_blockModelFor = 0xFFFFFFFFu;
+static u32 g_blockModelFor = 0xFFFFFFFFu;
 typedef struct { Model* m; } CountSink;
 static void count_block(u32 b0, u32 b1)          /* events of the greedy symbols inside [b0, b1) -> static probabilities */
 {
@@ -434,10 +438,11 @@ static void parse_dp_gpu(DpCfg cfg, int greedyLazy)
             if (p % FRAME == 0) lru[0] = lru[1] = lru[2] = lru[3] = 0;
             while (k < ng && (cfg.repCompare == 3 ? g[k].pos + g[k].len <= p : g[k].pos < p)) { u32 d = g[k].off; int j = 0; for (j = 0; j < 3; j++) if (lru[j] == d) break; for (; j > 0; j--) lru[j] = lru[j - 1]; lru[0] = d; k++; }
             for (int j = 0; j < 4; j++) hint[(size_t)p * 4 + j] = j < nh ? lru[j] : 0; } }
-    for (u32 b0 = 0; b0 < N; b0 += (128u << 10)) {
-        u32 b1 = b0 + (128u << 10) < N ? b0 + (128u << 10) : N;
+    u32 pblk = getenv("LAB_PBLK") ? (u32)atoi(getenv("LAB_PBLK")) : (128u << 10), pctx = getenv("LAB_PCTX") ? (u32)atoi(getenv("LAB_PCTX")) : 0;
+    for (u32 b0 = 0; b0 < N; b0 += pblk) {
+        u32 b1 = b0 + pblk < N ? b0 + pblk : N;
         memcpy(syms, g, sizeof(Sym) * ng); nSyms = ng;
-        if (cfg.staticPrices) { count_block(b0, b1); pe.m = &g_blockModel; } else { model_reset(&madapt); pe.m = &madapt; }
+        if (cfg.staticPrices) { u32 c0 = b0 > pctx ? b0 - pctx : 0, c1 = b1 + pctx < N ? b1 + pctx : N; count_block(c0, c1); pe.m = &g_blockModel; } else { model_reset(&madapt); pe.m = &madapt; }
         for (u32 w0 = b0; w0 < b1; w0 += cfg.win) {
             u32 w1 = w0 + cfg.win < b1 ? w0 + cfg.win : b1, n = w1 - w0;
             for (u32 i = 0; i <= n; i++) nd[i].cost = 1e30f;
@@ -463,17 +468,17 @@ static void parse_dp_gpu(DpCfg cfg, int greedyLazy)
                     if (hint) { int ok = 0; for (int j = 0; j < 4; j++) if (hint[(size_t)p * 4 + j] == d) ok = 1; if (!ok) continue; }
                     u32 l = mlen(p, p - d, maxl < (u32)hcap ? maxl : (u32)hcap); if (l < 2) continue;
                     for (u32 x = 2; x <= l; x++) { pe.bits = 0; St t = s; e_symbol(&pe, &t, p, 3 + r, x, d); dp_relax(nd, i + x, c0 + (float)pe.bits, i, 3 + r, x, d, 0, &t); } }
-                for (int w = 0; w < 2; w++) {
-                    u32 d = w ? rec3Off[p] : recOff[p], l = w ? rec3Len[p] : recLen[p];
-                    if (w && !cfg.use3) break; if (!l) continue;
+                for (int w = 0; w < 3; w++) {
+                    u32 d = w == 2 ? rec2Off[p] : w ? rec3Off[p] : recOff[p], l = w == 2 ? rec2Len[p] : w ? rec3Len[p] : recLen[p];
+                    if (w == 1 && !cfg.use3) continue; if (w == 2 && !getenv("LAB_TWO")) continue; if (!l) continue;
                     u32 cap = cfg.maxLenCap ? (u32)cfg.maxLenCap : 273;
                     l = full_len(p, d, l, maxl < cap ? maxl : cap); if (l < 2) continue;
                     u32 kind = 1; for (u32 r = 0; r < (u32)cfg.repDetect; r++) if (s.rep[r] == d) { kind = 3 + r; break; }
-                    if (w && cfg.d3max && d > (u32)cfg.d3max) continue;
+                    if (w == 1 && cfg.d3max && d > (u32)cfg.d3max) continue;
                     St tl; float cl = 0;
                     for (u32 x = 2; x <= l; x++) { pe.bits = 0; St t = s; for (int q = 0; q < 4; q++) if (!t.rep[q]) t.rep[q] = 0xFFFFFFFFu; e_symbol(&pe, &t, p, kind, x, d); for (int q = 0; q < 4; q++) if (t.rep[q] == 0xFFFFFFFFu) t.rep[q] = 0;
                         dp_relax(nd, i + x, c0 + (float)pe.bits, i, kind, x, d, 0, &t); if (x == l) { tl = t; cl = c0 + (float)pe.bits; } }
-                    if (cfg.composite && !w && i + l + 3 <= n && l < 273) {   /* match + literal + rep0 */
+                    if (cfg.composite && w == 0 && i + l + 3 <= n && l < 273) {   /* match + literal + rep0 */
                         u32 q = p + l; u32 c = mlen(q + 1, q + 1 - d, (n - i - l - 1) < 273 ? (n - i - l - 1) : 273);
                         if (c >= 2) { pe.bits = 0; St t = tl; e_symbol(&pe, &t, q, 0, 0, 0); float c1 = cl + (float)pe.bits;
                             for (u32 x = 2; x <= c; x++) { pe.bits = 0; St t2 = t; e_symbol(&pe, &t2, q + 1, 3, x, d); dp_relax(nd, i + l + 1 + x, c1 + (float)pe.bits, i, 9, l, d, x, &t2); } }
@@ -564,7 +569,11 @@ int main(int argc, char** argv)
     finder(depth, getenv("LAB_MINMATCH") ? atoi(getenv("LAB_MINMATCH")) : 5, 1);
     if (getenv("LAB_HC")) finder_hc(atoi(getenv("LAB_HC")));
     if (getenv("LAB_LPM")) finder_lpm(atoi(getenv("LAB_LPM")));
-    if (getenv("LAB_OPT")) { parse_optimal(atoi(getenv("LAB_OPT")), 1, 1); return 0; }
+    if (getenv("LAB_OPT")) {
+        if (getenv("LAB_OPT_STATIC")) { parse_greedy(2); g_optG = malloc(sizeof(Sym) * (nSyms + 1)); memcpy(g_optG, syms, sizeof(Sym) * nSyms); g_optNG = nSyms; }
+        parse_optimal(atoi(getenv("LAB_OPT")), 1, 1);
+        for (int it = 0; it < (getenv("LAB_OPT_STATIC") ? atoi(getenv("LAB_OPT_STATIC")) - 1 : 0); it++) { free(g_optG); g_optG = malloc(sizeof(Sym) * (nSyms + 1)); memcpy(g_optG, syms, sizeof(Sym) * nSyms); g_optNG = nSyms; parse_optimal(atoi(getenv("LAB_OPT")), 1, 1); }
+        return 0; }
     if (getenv("LAB_DP")) {
         parse_greedy(2); double a0 = price_syms(segLog, 12, &h); printf("greedy-lazy2 seg %d: %.0f\n", segLog, a0);
         int v[11] = {1, 4096, 0, 1, 0, 0, 0, 0, 4, 0, 0}; const char* e = getenv("LAB_DP"); sscanf(e, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d", v, v+1, v+2, v+3, v+4, v+5, v+6, v+7, v+8, v+9, v+10);
