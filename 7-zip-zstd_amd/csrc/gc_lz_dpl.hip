@@ -35,12 +35,19 @@
 // match, 0 elsewhere; neighbouring pieces with one distance leave as records of up to 64 bytes.
 #include "gc_mf.h"
 #include "gc_lz_parse.h"
+#ifdef HIPEMU
+#include <stdio.h>
+#include <stdlib.h>
+#endif
 
 #ifndef DPL_LENBITS
 #define DPL_LENBITS  5u
 #endif
 #define DPL_M        (1u << DPL_LENBITS)
 #define DPL_MMASK    (DPL_M - 1u)
+#ifndef DPL_MR
+#define DPL_MR       16u              // final nodes whose repeat distances are kept: the node an edge of more than DPL_MR bytes comes from is
+#endif                                 // taken to have the distances of the oldest one (they differ only where the cheapest ways to the two differ)
 // low word of a node: distance | capped | class | length - 1
 #define DPL_LO_LEN(lo)   (((lo) & DPL_MMASK) + 1u)
 #define DPL_LO_CLS(lo)   (((lo) >> DPL_LENBITS) & 7u)
@@ -50,8 +57,8 @@
 #define DPL_INF      0xFFFFFFFFFFFFFFFFull
 #define DPL_CONT     4u               // the rest of a capped match: a quarter of a bit (as DP_CONT_PRICE of W7)
 #define DPL_WARM     256              // positions in front of a window that the programme runs over for its state
-#define DPL_HCAP     16u              // bytes compared per hint
-#define DPL_NH       6u               // hints per position: rep0..rep3 of the newest final node + two of the shadow parse
+#define DPL_NC       2u               // requests in flight per group of nodes: the last one for the shadow parse's distances
+#define DPL_NT       6u               // tracked distances: rep0..rep3 of the newest final node + the last two of the shadow parse
 // class of an edge (bits 4..6 of the low word)
 #define DPL_LIT      0u
 #define DPL_NEW      1u               // a match at a distance that is no repeat of the node
@@ -77,7 +84,6 @@ __device__ __forceinline__ void dpl_mtf(DplReps& s, uint32_t d, uint32_t sure)
     else { s.r3 = s.r2; s.r2 = s.r1; s.r1 = a; }
     s.r0 = d | sure;
 }
-__device__ __forceinline__ void dpl_lru_put(uint32_t (&l)[2], uint32_t d) { if (l[0] != d) { l[1] = l[0]; l[0] = d; } }
 
 template <bool REPS, uint32_t MINLEN, bool SAMPLE /* a wave = two blocks: false = all their windows (2 x 32 x 4 KiB), true = a sample (32 x 512 B of each, counted) */>
 __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t frameBlocks, uint32_t phaseArg, uint32_t* __restrict__ dpStat,
@@ -85,7 +91,7 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
                                         uint32_t* __restrict__ recOut, uint32_t* __restrict__ winCost)
 {
     __shared__ unsigned long long sCost[DPL_M][64];
-    __shared__ GcU4 sReps[REPS ? DPL_M : 1u][64];
+    __shared__ GcU4 sReps[REPS ? DPL_MR : 1u][64];
     constexpr uint32_t BPW = 2u;
     __shared__ uint16_t sPrice[BPW][GC_PRICE_WORDS];
     __shared__ uint32_t sCnt[SAMPLE ? BPW : 1u][SAMPLE ? GC_DPS_WORDS : 1u];
@@ -181,9 +187,11 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
     const uint64_t tailRoom = srcSize - absW;                     // bytes of the input from the window start on
     // the programme starts `warm` positions in front of the window (a multiple of four, inside the window's frame)
     int32_t warm = 0;
+    int64_t inFrameW = 0;                                         // bytes of the window's frame in front of the window: a distance d reaches them from position q iff q + inFrameW >= d
     if (n != 0u) {
         const uint64_t frameBytes = (uint64_t)frameBlocks * GC_ZSTD_BLOCK_MAX;
         const uint64_t inFrame = absW % frameBytes;
+        inFrameW = (int64_t)inFrame;
         warm = inFrame < (uint64_t)xWarm ? (int32_t)inFrame : xWarm;
         warm &= ~3;
     }
@@ -192,22 +200,22 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
 
     for (uint32_t s = 0; s < DPL_M; s++) sCost[s][lane] = DPL_INF;
     sCost[(uint32_t)(-warm) & DPL_MMASK][lane] = 0ull;            // the first node: cost 0
-    if (REPS) { GcU4 v; v.x = v.y = v.z = v.w = 0u; for (uint32_t s = 0; s < DPL_M; s++) sReps[s][lane] = v; }
-    uint32_t lru[2] = { 0u, 0u };                                 // the shadow parse: the last two distances of a greedy walk over the finder's records
-    int32_t sNext = -warm;
+    if (REPS) { GcU4 v; v.x = v.y = v.z = v.w = 0u; for (uint32_t s = 0; s < DPL_MR; s++) sReps[s][lane] = v; }
     DplReps st; st.r0 = st.r1 = st.r2 = st.r3 = 0u;               // repeat distances of the node being expanded
 
     // ---- pipelines: records two groups of four positions ahead, hint bytes one group ahead
     uint32_t recG[4], recN[4], r3G[4], r3N[4], byG, byN;
-    uint32_t hintG[4][DPL_NH];                                    // this group: distance << 8 | bytes that repeat there (0 = none)
-    uint32_t hdN[4][DPL_NH];                                      // next group: distances; bytes in flight
-    LzW16 hbN[4][DPL_NH], ownN[4];
+    // tracked distances (REPS): where the window's bytes repeat at distance tD[k] -- bit j of tM[k]: S[pb + j] == S[pb + j - tD[k]], known for
+    // positions below tE[k].  One slot is (re)filled per group of four nodes, 32 positions at a time, from two 32-byte reads issued a group earlier.
+    uint32_t tD[DPL_NT]; int32_t tE[DPL_NT]; unsigned long long tM[DPL_NT];
 #pragma unroll
-    for (uint32_t u = 0; u < 4u; u++) {
+    for (uint32_t k = 0; k < DPL_NT; k++) { tD[k] = 0u; tE[k] = 0; tM[k] = 0ull; }
+    uint32_t lru[2] = { 0u, 0u }; int32_t sNext = -warm;         // the shadow parse: the last two distances of a greedy walk over the finder's records
+    int32_t pb = 0;                                               // position of bit 0 of the masks (a multiple of four)
+    // in flight, one request for the node's distances (slots 0..3) and one for the shadow parse's (slots 4, 5): slot (DPL_NT = none), its distance, first position, the bytes
+    uint32_t fK[DPL_NC], fD[DPL_NC]; int32_t fQ[DPL_NC]; LzW16 fOwn[DPL_NC][2], fOth[DPL_NC][2];
 #pragma unroll
-        for (uint32_t k = 0; k < DPL_NH; k++) { hintG[u][k] = 0u; hdN[u][k] = 0u; hbN[u][k].a = hbN[u][k].b = 0ull; }
-        ownN[u].a = ownN[u].b = 0ull;
-    }
+    for (uint32_t c = 0; c < DPL_NC; c++) { fK[c] = DPL_NT; fD[c] = 0u; fQ[c] = 0; fOwn[c][0].a = fOwn[c][0].b = fOwn[c][1].a = fOwn[c][1].b = fOth[c][0].a = fOth[c][0].b = fOth[c][1].a = fOth[c][1].b = 0ull; }
     // group loader: records, short candidates and bytes of positions g4 .. g4 + 3 (g4 a multiple of four, possibly negative)
     auto load_group = [&](int32_t g4, uint32_t (&rr)[4], uint32_t (&r3)[4], uint32_t& by) {
 #pragma unroll
@@ -222,47 +230,97 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
             for (int32_t u = 0; u < 4; u++) if (g4 + u < N) { rr[u] = R[g4 + u]; r3[u] = R3[g4 + u]; by |= (uint32_t)S[g4 + u] << (8 * u); }
         }
     };
-    // hint stage of positions g4 .. g4 + 3 (REPS): their hint distances are fixed and the bytes requested; the shadow parse moves over them
-    auto hint_stage = [&](int32_t g4, const uint32_t (&rr)[4]) {
+    // bytes of x that are zero, as a mask of 4 bits / of two 16-byte strings that are equal, as a mask of 16 bits
+    auto zero4 = [](uint32_t x) -> uint32_t { uint32_t y = x | (x >> 4); y |= y >> 2; y |= y >> 1; y = ~y & 0x01010101u; return (y * 0x10204080u) >> 28; };
+    auto eq16 = [&](const LzW16& x, const LzW16& y) -> uint32_t {
+        const unsigned long long d0 = x.a ^ y.a, d1 = x.b ^ y.b;
+        return zero4((uint32_t)d0) | (zero4((uint32_t)(d0 >> 32)) << 4) | (zero4((uint32_t)d1) << 8) | (zero4((uint32_t)(d1 >> 32)) << 12);
+    };
+    // between two groups of nodes (q0 = first position of the next group): what was requested a group ago arrives, the masks move on, the distances of the
+    // newest final node that are not tracked yet take the slots of those that are none of its distances, and the slot that runs out first is refilled
+    // the shadow parse moves over the records rr of positions g .. g + 3
+    auto shadow_step = [&](int32_t g, const uint32_t (&rr)[4]) {
 #pragma unroll
         for (int32_t u = 0; u < 4; u++) {
-            const int32_t q = g4 + u;
-            uint32_t d[DPL_NH] = { st.r0 & ~DPL_SURE, st.r1, st.r2, st.r3, lru[0], lru[1] };
-            if (d[4] == d[0] || d[4] == d[1] || d[4] == d[2] || d[4] == d[3]) d[4] = 0u;
-            if (d[5] == d[0] || d[5] == d[1] || d[5] == d[2] || d[5] == d[3]) d[5] = 0u;
-            const bool ok = q >= -warm && q < N && (uint64_t)((int64_t)q + (int64_t)DPL_HCAP) <= tailRoom;
-            uint32_t any = 0u;
+            const int32_t q = g + u;
+            if (q >= sNext && q >= -warm && q < N) { const uint32_t L = rr[u] & 0xFFu; if (L >= 3u) { const uint32_t d = rr[u] >> 8; if (lru[0] != d) { lru[1] = lru[0]; lru[0] = d; } sNext = q + (int32_t)L; } else sNext = q + 1; }
+        }
+    };
+    // between two groups of nodes (q0 = first position of the next group): what was requested a group ago arrives, the masks move on, wanted distances
+    // that are not tracked take the slots of those nobody wants, and per request channel the slot that runs out first is refilled
+    auto track_step = [&](int32_t q0) {
 #pragma unroll
-            for (uint32_t k = 0; k < DPL_NH; k++) {
-#ifdef HIPEMU
-                if (!((xHints >> k) & 1)) d[k] = 0u;
-#endif
-                hdN[u][k] = ok ? d[k] : 0u; any |= hdN[u][k];
+        for (uint32_t c = 0; c < DPL_NC; c++) {
+            if (fK[c] < DPL_NT) {
+#pragma unroll
+                for (uint32_t k = 0; k < DPL_NT; k++) if (k == fK[c] && tD[k] == fD[c]) {
+                    const unsigned long long bits = (unsigned long long)(eq16(fOwn[c][0], fOth[c][0]) | (eq16(fOwn[c][1], fOth[c][1]) << 16));
+                    const uint32_t sh = (uint32_t)(fQ[c] - pb);
+                    tM[k] = (tM[k] & ((1ull << sh) - 1ull)) | (bits << sh);
+                    tE[k] = fQ[c] + 32;
+                }
+                fK[c] = DPL_NT;
             }
-            if (any) ownN[u] = lz_ld16(S + q, 0);
+        }
+        if (q0 - pb >= 32) {
+            pb += 32;
 #pragma unroll
-            for (uint32_t k = 0; k < DPL_NH; k++) if (hdN[u][k]) hbN[u][k] = lz_ld16(S + (int64_t)q - (int64_t)hdN[u][k], 0);
-            if (q >= sNext && q < N) {                             // the shadow parse takes the record of q (or steps over a literal)
-                const uint32_t L = rr[u] & 0xFFu;
-                if (L >= 3u) { dpl_lru_put(lru, rr[u] >> 8); sNext = q + (int32_t)L; } else sNext = q + 1;
+            for (uint32_t k = 0; k < DPL_NT; k++) tM[k] >>= 32;
+        }
+        const uint32_t want[DPL_NT] = { st.r0 & ~DPL_SURE, st.r1, st.r2, st.r3, lru[0], lru[1] };
+#pragma unroll
+        for (uint32_t j = 0; j < DPL_NT; j++) {
+            const uint32_t d = want[j];
+            bool have = d == 0u;
+#pragma unroll
+            for (uint32_t k = 0; k < DPL_NT; k++) have = have || tD[k] == d;
+            if (have) continue;
+            uint32_t v = DPL_NT;                                  // a slot of its kind whose distance nobody wants
+#pragma unroll
+            for (uint32_t k = 0; k < DPL_NT; k++) {
+                const uint32_t t = tD[k];
+                const bool mine = j < 4u ? k < 4u : k >= 4u;
+                if (mine && v == DPL_NT && t != want[0] && t != want[1] && t != want[2] && t != want[3] && t != want[4] && t != want[5]) v = k;
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < DPL_NT; k++) if (k == v) {
+                // a newly tracked distance is wanted NOW (the nodes that made it a repeat are the ones about to use it): its first 32 positions are read on
+                // the spot -- one exposed memory latency per new distance, a few per hundred nodes -- instead of leaving the next group of nodes without it
+                tD[k] = d; tM[k] = 0ull; tE[k] = q0;
+                if (q0 < N && q0 >= -warm && (uint64_t)((int64_t)q0 + 32) <= tailRoom && (int64_t)q0 + inFrameW >= (int64_t)d) {     // (a distance of the shadow parse comes from a record a few positions AHEAD)
+                    const LzW16 o0 = lz_ld16(S + q0, 0), o1 = lz_ld16(S + q0 + 16, 0);
+                    const LzW16 p0 = lz_ld16(S + (int64_t)q0 - (int64_t)d, 0), p1 = lz_ld16(S + (int64_t)q0 - (int64_t)d + 16, 0);
+                    tM[k] = (unsigned long long)(eq16(o0, p0) | (eq16(o1, p1) << 16)) << (uint32_t)(q0 - pb);
+                    tE[k] = q0 + 32;
+                }
+            }
+        }
+        uint32_t taken = DPL_NT;
+#pragma unroll
+        for (uint32_t c = 0; c < DPL_NC; c++) {
+            uint32_t pick = DPL_NT; int32_t best = 0x7FFFFFFF;
+#pragma unroll
+            for (uint32_t k = 0; k < DPL_NT; k++) if ((c + 1u < DPL_NC ? k < 4u : k >= 4u) && k != taken && tD[k] != 0u && tE[k] < best) { best = tE[k]; pick = k; }
+            if (c + 2u < DPL_NC) taken = pick;
+            if (pick < DPL_NT && best - q0 < 40 && q0 < N) {
+                const int32_t fq = best > q0 ? best : q0;
+                uint32_t dPick = 0u;
+#pragma unroll
+                for (uint32_t k = 0; k < DPL_NT; k++) if (k == pick) dPick = tD[k];
+                if (fq - pb <= 32 && (uint64_t)((int64_t)fq + 32) <= tailRoom && fq >= -warm && (int64_t)fq + inFrameW >= (int64_t)dPick) {
+                    fK[c] = pick; fQ[c] = fq; fD[c] = dPick;
+                    fOwn[c][0] = lz_ld16(S + fq, 0); fOwn[c][1] = lz_ld16(S + fq + 16, 0);
+                    fOth[c][0] = lz_ld16(S + (int64_t)fq - (int64_t)fD[c], 0); fOth[c][1] = lz_ld16(S + (int64_t)fq - (int64_t)fD[c] + 16, 0);
+#pragma unroll
+                    for (uint32_t k = 0; k < DPL_NT; k++) if (k == pick && tE[k] < q0) tE[k] = q0;      // (nothing known in between)
+                }
             }
         }
     };
-    auto hints_arrive = [&]() {
-#pragma unroll
-        for (uint32_t u = 0; u < 4u; u++)
-#pragma unroll
-            for (uint32_t k = 0; k < DPL_NH; k++) {
-                uint32_t l = hdN[u][k] ? lz_cmp16(ownN[u], hbN[u][k]) : 0u;
-#ifdef HIPEMU
-                if (xNoHint) l = 0;
-#endif
-                hintG[u][k] = l ? (hdN[u][k] << 8) | l : 0u;
-            }
-    };
     load_group(-warmMax, recG, r3G, byG);
     load_group(-warmMax + 4, recN, r3N, byN);
-    if (REPS) { hint_stage(-warmMax, recG); hints_arrive(); hint_stage(-warmMax + 4, recN); }
+    pb = -warmMax;
+    if (REPS) { shadow_step(-warmMax, recG); shadow_step(-warmMax + 4, recN); }
     uint32_t prevByte = 0u;
     if (n != 0u && (absW + hasPrev) > (uint64_t)warm) prevByte = (uint32_t)S[-warm - 1];
     uint32_t contDist = 0u, contRem = 0u; bool contCapped = false;   // the node being expanded was reached by a capped piece
@@ -285,10 +343,10 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
             if (live && i > -warm) {                               // ---- finalize node i
                 const uint32_t len = DPL_LO_LEN(lo), cls = DPL_LO_CLS(lo), dist = DPL_LO_DIST(lo);
                 if (REPS) {
-                    const GcU4 pv = sReps[(uint32_t)(i - (int32_t)len) & DPL_MMASK][lane];
+                    const GcU4 pv = sReps[(uint32_t)(i - (int32_t)(len < DPL_MR ? len : DPL_MR)) & (DPL_MR - 1u)][lane];      // (an edge longer than the ring: the oldest node it still holds)
                     st.r0 = pv.x; st.r1 = pv.y; st.r2 = pv.z; st.r3 = pv.w;
                     if (cls != DPL_LIT && cls != DPL_SREP) dpl_mtf(st, dist, i - (int32_t)len >= 0 ? DPL_SURE : 0u);
-                    GcU4 nv; nv.x = st.r0; nv.y = st.r1; nv.z = st.r2; nv.w = st.r3; sReps[slot][lane] = nv;
+                    GcU4 nv; nv.x = st.r0; nv.y = st.r1; nv.z = st.r2; nv.w = st.r3; sReps[slot & (DPL_MR - 1u)][lane] = nv;
                 }
                 contCapped = DPL_LO_CAP(lo) != 0u; contDist = dist; contRem = hi & 63u;
                 if (i == 0) cost0 = c0;
@@ -358,13 +416,26 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
                         relax_cand(Lx, cnd ? 0u : behL, Dx, cls, add, x0, !cnd && (r & 0xFFu) == GC_MATCH_CAP);     // a capped record goes on in the record behind it
                     }
                 }
-                // hints: repeats of the node's own distances
+                // repeats of the node's own distances, where those are tracked
                 if (REPS) {
 #pragma unroll
-                    for (uint32_t k = 0; k < DPL_NH; k++) {
-                        const uint32_t h = hintG[u][k];
-                        uint32_t hl = h & 0xFFu; const uint32_t hd = h >> 8;
-                        const bool open = hl >= DPL_HCAP;
+                    for (uint32_t k = 0; k < DPL_NT; k++) {
+                        const uint32_t hd = tD[k];
+                        const int32_t avail = tE[k] - i;                               // positions from here on that the mask knows
+                        uint32_t hl = 0u;
+                        if (hd != 0u && avail > 0 && room != 0u) {
+                            const unsigned long long run = ~(tM[k] >> (uint32_t)(i - pb));
+                            hl = run ? gc_ctz64(run) : 64u;
+                            if (hl > (uint32_t)avail) hl = (uint32_t)avail;
+                        }
+#ifdef HIPEMU
+                        static const int xPerfect = getenv("GC_X_PERFECT") ? atoi(getenv("GC_X_PERFECT")) : 0;
+                        if ((xPerfect == 1 || (xPerfect == 2 && avail <= 0) || (xPerfect == 3 && avail > 0 && hl == (uint32_t)avail)) && hd != 0u && room != 0u && (uint64_t)((int64_t)i + 40) <= tailRoom) { hl = 0u; while (hl < 32u && S[i + (int32_t)hl] == S[(int64_t)i + hl - (int64_t)hd]) hl++; }
+                        if (xNoHint) hl = 0u;
+                        for (uint32_t z = 0; z < hl; z++) if (S[i + (int32_t)z] != S[(int64_t)i + z - (int64_t)hd]) { fprintf(stderr, "W7L: mask of distance %u wrong at %d + %u\n", hd, i, z); abort(); }
+#endif
+                        const bool open = hl != 0u && ((avail > 0 && hl == (uint32_t)avail) || hl >= DPL_M) && hl <= room;      // the run may go on behind what is known / what an edge holds
+                        if (hl > DPL_M) hl = DPL_M;
                         if (hl > room) hl = room;
                         uint32_t cls = 0u, add = 0u, x0 = 2u;
                         if (hl != 0u && st.r0 == (hd | DPL_SURE) && !(contCapped && hd == contDist)) {          // LZMA's short repeat: one byte at rep0, known for certain
@@ -384,7 +455,7 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
             }
         }
         // ---- next group: hint bytes that have arrived -> lengths; new requests with the newest node's distances; the shadow parse moves on
-        if (REPS) { hints_arrive(); hint_stage(g4 + 8, recNN); }
+        if (REPS) { shadow_step(g4 + 8, recNN); track_step(g4 + 4); }
 #pragma unroll
         for (uint32_t u = 0; u < 4u; u++) { recG[u] = recN[u]; recN[u] = recNN[u]; r3G[u] = r3N[u]; r3N[u] = r3NN[u]; }
         byG = byN; byN = byNN;
