@@ -76,10 +76,11 @@ extern "C" __global__ void gc_mf_parse_kernel(const uint8_t*, uint64_t, uint32_t
 extern "C" __global__ void gc_mf_short_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint16_t*);
 extern "C" __global__ void gc_mf_dp2_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
 extern "C" __global__ void gc_mf_dp3_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
-extern "C" __global__ void gc_mf_dpl2_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
-extern "C" __global__ void gc_mf_dpl2s_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
-extern "C" __global__ void gc_mf_dpl3_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
-extern "C" __global__ void gc_mf_dpl3s_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
+extern "C" __global__ void gc_mf_litprice_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, const uint16_t*, uint32_t, uint8_t*);
+extern "C" __global__ void gc_mf_dpl2_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*);
+extern "C" __global__ void gc_mf_dpl2s_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*);
+extern "C" __global__ void gc_mf_dpl3_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*);
+extern "C" __global__ void gc_mf_dpl3s_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*);
 
 extern "C" __global__ void gc_lzma2_prep_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t, uint64_t*, uint32_t*);
 extern "C" __global__ void gc_lzma2_model_kernel(const uint8_t*, uint64_t, const uint64_t*, const uint32_t*, uint32_t, uint32_t, uint16_t*, GcLzmaChunkInfo*, const uint32_t*, unsigned long long*, uint32_t, uint32_t, uint32_t);
@@ -128,7 +129,7 @@ struct gc_ctx {
     uint32_t* mfTileWord; size_t mfTileWordCap;   // fused verify + parse: one word of counts per tile
     uint32_t nCU; uint32_t* mfTicket;      // compute units of the device; ticket counters of the persistent launches (4 per part)
     uint32_t* mfCnt; size_t mfCntCap; GcMfEntry* mfEnt; size_t mfEntCap; GcMfEntry* mfEnt2; size_t mfEnt2Cap; uint32_t* mfRec; size_t mfRecCap; uint32_t* mfRec2; size_t mfRec2Cap;
-    uint16_t* mfRec3; size_t mfRec3Cap; uint32_t* mfDp; size_t mfDpCap; uint16_t* mfPrice; size_t mfPriceCap; uint32_t* mfWinCost; size_t mfWinCostCap; uint32_t* mfDpStat; size_t mfDpStatCap;      // W5s records, W7 records, price tables, W7 phase-A symbol counts
+    uint16_t* mfRec3; size_t mfRec3Cap; uint32_t* mfDp; size_t mfDpCap; uint16_t* mfPrice; size_t mfPriceCap; uint32_t* mfWinCost; size_t mfWinCostCap; uint32_t* mfDpStat; size_t mfDpStatCap; uint8_t* mfLitPrice; size_t mfLitPriceCap;      // (+ W7L: literal price per position) W5s records, W7 records, price tables, W7 phase-A symbol counts
     hipEvent_t evMf[GC_MAX_PARTS][13];      // per part: W1 start, W1 end, W2 end, W3 end, W4 end, W5 end, W6 end; price-based parse: greedy W6 end, W5s end, W7 end;
                                             // inside W5: first verify end, far pass end, deepen end
     bool mfPriced;                          // the last call ran the price-based parse (events 7..9 are valid)
@@ -239,7 +240,7 @@ static void ctx_release(gc_ctx* c)
     hipFree(c->prof); hipFree(c->mfTicket); hipFree(c->result); if (c->hostResult) hipHostFree(c->hostResult); hipFree(c->dIn); hipFree(c->dOut);
     hipFree(c->zdLit); hipFree(c->zdSeq); hipFree(c->zdFrames); hipFree(c->zdResult); hipFree(c->zdTot); hipFree(c->zdBlocks); hipFree(c->zdOrder); hipFree(c->zdReady); hipFree(c->zdTicket); hipFree(c->zdPlace); hipFree(c->zdPtr); hipFree(c->zdDone); hipFree(c->zdFerr);
     for (int i = 0; i < 2; i++) if (c->zdEv[i]) hipEventDestroy(c->zdEv[i]);
-    hipFree(c->mfTileWord); hipFree(c->mfCnt); hipFree(c->mfEnt); hipFree(c->mfEnt2); hipFree(c->mfRec); hipFree(c->mfRec2); hipFree(c->mfRec3); hipFree(c->mfDp); hipFree(c->mfPrice); hipFree(c->mfWinCost); hipFree(c->mfDpStat);
+    hipFree(c->mfTileWord); hipFree(c->mfCnt); hipFree(c->mfEnt); hipFree(c->mfEnt2); hipFree(c->mfRec); hipFree(c->mfRec2); hipFree(c->mfRec3); hipFree(c->mfDp); hipFree(c->mfPrice); hipFree(c->mfWinCost); hipFree(c->mfDpStat); hipFree(c->mfLitPrice);
     for (int i = 0; i < 8; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
     for (uint32_t p = 0; p < GC_MAX_PARTS; p++) {
         for (int i = 0; i < 13; i++) if (c->evMf[p][i]) hipEventDestroy(c->evMf[p][i]);
@@ -328,7 +329,7 @@ static int ensure_finder_workspace(gc_ctx* c, size_t n, uint32_t frameBlocks)
     const size_t needPrice = (size_t)g.nBlocks * GC_PRICE_WORDS * sizeof(uint16_t);
     const size_t needTileWord = ((size_t)g.nTiles + 64u) * sizeof(uint32_t);
     if (needTileWord > c->mfTileWordCap || needCnt > c->mfCntCap || needEnt > c->mfEntCap || needEnt > c->mfEnt2Cap || needRec > c->mfRecCap || ((c->searchDepth || c->shortPass) && needRec > c->mfRec2Cap) ||
-        (c->priceParse && (needRec / 2u > c->mfRec3Cap || needRec > c->mfDpCap || needPrice > c->mfPriceCap || (size_t)g.nBlocks * 128u > c->mfWinCostCap || (size_t)g.nBlocks * GC_DPS_WORDS * 4u > c->mfDpStatCap))) {
+        (c->priceParse && (needRec / 2u > c->mfRec3Cap || needRec > c->mfDpCap || needPrice > c->mfPriceCap || (size_t)g.nBlocks * 128u > c->mfWinCostCap || (size_t)g.nBlocks * GC_DPS_WORDS * 4u > c->mfDpStatCap || needRec / 4u > c->mfLitPriceCap))) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         int rc;
         if ((rc = mf_grow(c, (void**)&c->mfTileWord, &c->mfTileWordCap, needTileWord, "tile counts")) != GC_OK) return rc;
@@ -343,6 +344,7 @@ static int ensure_finder_workspace(gc_ctx* c, size_t n, uint32_t frameBlocks)
             if ((rc = mf_grow(c, (void**)&c->mfPrice, &c->mfPriceCap, needPrice, "price tables")) != GC_OK) return rc;
             if ((rc = mf_grow(c, (void**)&c->mfWinCost, &c->mfWinCostCap, (size_t)g.nBlocks * 128u, "window costs")) != GC_OK) return rc;
             if ((rc = mf_grow(c, (void**)&c->mfDpStat, &c->mfDpStatCap, (size_t)g.nBlocks * GC_DPS_WORDS * 4u, "path symbol counts")) != GC_OK) return rc;
+            if ((rc = mf_grow(c, (void**)&c->mfLitPrice, &c->mfLitPriceCap, needRec / 4u, "literal prices")) != GC_OK) return rc;
         }
     }
     return GC_OK;
@@ -463,6 +465,8 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
         uint32_t phase0 = 0; { uint32_t one = 0; if (gc_env_u32("GC_DP_PHASES", 1u, 2u, &one) && one == 1u) phase0 = 2u; }    // test hook: 1 = W6's prices only
         // W7L (gc_lz_dpl.hip): one lane per window; LZMA with the four repeat distances at every node.  Test hook GC_DPL: 0 = W7 (a wave per window)
         uint32_t laneDp = c->priceMinLen <= 2u ? 1u : 0u; gc_env_u32("GC_DPL", 0u, 1u, &laneDp);
+        uint8_t* lpr = c->mfLitPrice + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
+        if (laneDp) GC_LAUNCH(gc_mf_litprice_kernel, perB * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perB, (const uint16_t*)price, litCtxArg, lpr);
         for (uint32_t phase = phase0; phase != 3u; phase = phase == 0u ? 1u : 3u) {
             const uint32_t nDpWg = nBlocks * (phase == 0u ? 1u : 8u), perD = gc_xcd_per(nDpWg);
             uint32_t* wcp = phase == 0u ? (uint32_t*)nullptr : wc;
@@ -470,11 +474,11 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
                 uint32_t fullA = 0u; gc_env_u32("GC_DP_FULLA", 0u, 1u, &fullA);      // test hook: phase A over every window
                 const uint32_t nItems = (nBlocks + 1u) / 2u, perL = gc_xcd_per(nItems);     // a wave = two blocks
                 if (c->priceMinLen <= 2u) {
-                    if (phase == 0u && !fullA) GC_LAUNCH(gc_mf_dpl2s_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
-                    else GC_LAUNCH(gc_mf_dpl2_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
+                    if (phase == 0u && !fullA) GC_LAUNCH(gc_mf_dpl2s_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
+                    else GC_LAUNCH(gc_mf_dpl2_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
                 } else {
-                    if (phase == 0u) GC_LAUNCH(gc_mf_dpl3s_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
-                    else GC_LAUNCH(gc_mf_dpl3_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
+                    if (phase == 0u) GC_LAUNCH(gc_mf_dpl3s_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
+                    else GC_LAUNCH(gc_mf_dpl3_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
                 }
             } else
             if (c->priceMinLen <= 2u) GC_LAUNCH(gc_mf_dp2_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);

@@ -58,6 +58,7 @@
 #define DPL_CONT     4u               // the rest of a capped match: a quarter of a bit (as DP_CONT_PRICE of W7)
 #define DPL_WARM     256              // positions in front of a window that the programme runs over for its state
 #define DPL_NC       2u               // requests in flight per group of nodes: the last one for the shadow parse's distances
+#define DPL_TABW     7u               // length prices kept in registers: lengths 0 .. 13, two per word (the static part of a relax loop ends at 12)
 #define DPL_NT       6u               // tracked distances: rep0..rep3 of the newest final node + the last two of the shadow parse
 // class of an edge (bits 4..6 of the low word)
 #define DPL_LIT      0u
@@ -85,15 +86,28 @@ __device__ __forceinline__ void dpl_mtf(DplReps& s, uint32_t d, uint32_t sure)
     s.r0 = d | sure;
 }
 
+#if defined(DPL_PROF) && !defined(HIPEMU)
+__device__ unsigned long long g_dplProf[16];
+extern "C" int gc_dpl_prof_read(unsigned long long* out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dplProf), sizeof(g_dplProf)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = { 0 }; if (hipMemcpyToSymbol(HIP_SYMBOL(g_dplProf), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#define DPL_T(k) do { const unsigned long long now_ = clock64(); pacc[k] += now_ - ptick; ptick = now_; } while (0)
+#else
+#define DPL_T(k) do { } while (0)
+#endif
+
 template <bool REPS, uint32_t MINLEN, bool SAMPLE /* a wave = two blocks: false = all their windows (2 x 32 x 4 KiB), true = a sample (32 x 512 B of each, counted) */>
 __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t frameBlocks, uint32_t phaseArg, uint32_t* __restrict__ dpStat,
                                         uint32_t litCtxArg, const uint32_t* __restrict__ rec, const uint16_t* __restrict__ rec3, const uint16_t* __restrict__ priceTab,
-                                        uint32_t* __restrict__ recOut, uint32_t* __restrict__ winCost)
+                                        uint32_t* __restrict__ recOut, uint32_t* __restrict__ winCost, const uint8_t* __restrict__ litPrice)
 {
     __shared__ unsigned long long sCost[DPL_M][64];
     __shared__ GcU4 sReps[REPS ? DPL_MR : 1u][64];
     constexpr uint32_t BPW = 2u;
-    __shared__ uint16_t sPrice[BPW][GC_PRICE_WORDS];
+    __shared__ uint16_t sPrice[BPW][GC_PRICE_WORDS - GC_PRICE_LEN];      // (the literal rows are not needed here: gc_mf_litprice_kernel has priced every position)
     __shared__ uint32_t sCnt[SAMPLE ? BPW : 1u][SAMPLE ? GC_DPS_WORDS : 1u];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t litCtxMask = litCtxArg & 0xFFu, hasPrev = litCtxArg >> 31;
@@ -108,12 +122,13 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
     const uint32_t blockLen = blockLive ? (uint32_t)((srcSize - base) < GC_ZSTD_BLOCK_MAX ? (srcSize - base) : GC_ZSTD_BLOCK_MAX) : 0u;
 #ifdef HIPEMU
     static const int xWin4k = getenv("GC_X_WIN4K") ? atoi(getenv("GC_X_WIN4K")) : 0, xNoHint = getenv("GC_X_NOHINT") ? atoi(getenv("GC_X_NOHINT")) : 0, xWarm = getenv("GC_X_WARM") ? atoi(getenv("GC_X_WARM")) : DPL_WARM;
+    static const int xSparse = getenv("GC_X_SPARSE") ? atoi(getenv("GC_X_SPARSE")) : 0;
     static const int xHints = getenv("GC_X_HINTS") ? atoi(getenv("GC_X_HINTS")) : 63;
     (void)xWin4k;
     const uint32_t winLen = SAMPLE ? 512u : 4096u;
     const uint32_t w0 = ((lane & 31u) << 12) + (SAMPLE ? 1536u : 0u);
 #else
-    const int xWarm = DPL_WARM;
+    const int xWarm = DPL_WARM; const int xSparse = 0;
     const uint32_t winLen = SAMPLE ? 512u : 4096u;
     const uint32_t w0 = ((lane & 31u) << 12) + (SAMPLE ? 1536u : 0u);
 #endif
@@ -122,14 +137,14 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
     // ---- price tables (as W7: W6's table, phase A with optimistic ceilings where the greedy parse found no matches, phase B from phase A's counts)
     for (uint32_t q = 0; q < BPW; q++) {
         const uint32_t bb = item * BPW + q;
-        if (bb < nBlocks) { const GcU4* T4 = (const GcU4*)(priceTab + (uint64_t)bb * GC_PRICE_WORDS); GcU4* S4 = (GcU4*)sPrice[q]; for (uint32_t i = lane; i < GC_PRICE_WORDS / 8u; i += 64u) S4[i] = T4[i]; }
+        if (bb < nBlocks) { const GcU4* T4 = (const GcU4*)(priceTab + (uint64_t)bb * GC_PRICE_WORDS + GC_PRICE_LEN); GcU4* S4 = (GcU4*)sPrice[q]; for (uint32_t i = lane; i < (GC_PRICE_WORDS - GC_PRICE_LEN) / 8u; i += 64u) S4[i] = T4[i]; }
         if (phaseA) for (uint32_t i = lane; i < GC_DPS_WORDS; i += 64u) sCnt[q][i] = 0;
     }
     gc_wave_sync();
     for (uint32_t q = 0; q < BPW; q++) {
         const uint32_t bb = item * BPW + q;
         if (bb >= nBlocks) continue;                              // (uniform)
-        uint16_t* P = sPrice[q];
+        uint16_t* P = sPrice[q] - GC_PRICE_LEN;                   // (indexed with the table's own offsets, all >= GC_PRICE_LEN)
         if (lane == 0u) {                                         // before anything is known: repeats 3 / 3.5 / 4 / 5 / 5 bits on top of the match flag, "no repeat" free
             P[GC_PRICE_FLAGS + 2u] = 48u; P[GC_PRICE_FLAGS + 3u] = 56u; P[GC_PRICE_FLAGS + 4u] = 64u; P[GC_PRICE_FLAGS + 5u] = 80u; P[GC_PRICE_FLAGS + 6u] = 80u; P[GC_PRICE_FLAGS + 7u] = 0u;
         }
@@ -176,9 +191,24 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
         }
     }
     gc_wave_sync();
-    const uint16_t* P = sPrice[lb];
+    const uint16_t* P = sPrice[lb] - GC_PRICE_LEN;
+    // Tracking the repeat distances is half of a node's work.  Where phase A's paths of BOTH blocks of the wave hardly ever repeated a distance (text: one
+    // match symbol in 30) phase B runs without it: repeats are then only found where a candidate of the finder has a repeat distance.
+    bool trackOn = REPS;
+    if (REPS && phaseB) {
+        uint32_t rich = 0u;
+        for (uint32_t q = 0; q < BPW; q++) {
+            const uint32_t bb = item * BPW + q;
+            if (bb >= nBlocks) continue;
+            const uint32_t* C = dpStat + (uint64_t)bb * GC_DPS_WORDS;
+            const uint32_t reps = C[GC_DPS_NREP] + C[GC_DPS_NSREP] + C[GC_DPS_NREP1] + C[GC_DPS_NREP2] + C[GC_DPS_NREP3];
+            if (reps * 20u >= C[GC_DPS_NMAT] || C[GC_DPS_NMAT] == 0u) rich = 1u;
+        }
+        trackOn = gc_uniform(rich) != 0u;
+    }
     const uint32_t flagLit = P[GC_PRICE_FLAGS], flagMat = P[GC_PRICE_FLAGS + 1u];
     const uint32_t newAdd = flagMat + (REPS ? (uint32_t)P[GC_PRICE_FLAGS + 7u] : 0u);
+    const uint32_t fRep0 = flagMat + P[GC_PRICE_FLAGS + 2u], fSrep = flagMat + P[GC_PRICE_FLAGS + 3u], fRep1 = flagMat + P[GC_PRICE_FLAGS + 4u], fRep2 = flagMat + P[GC_PRICE_FLAGS + 5u], fRep3 = flagMat + P[GC_PRICE_FLAGS + 6u];      // (in registers: an LDS read in the node loop is a stall of a lone wave)
     const uint8_t* S = src + base + w0;                           // window-relative addressing (positions in front of the window are negative)
     const uint32_t* R = rec + base + w0;
     const uint16_t* R3 = rec3 + base + w0;
@@ -203,8 +233,9 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
     if (REPS) { GcU4 v; v.x = v.y = v.z = v.w = 0u; for (uint32_t s = 0; s < DPL_MR; s++) sReps[s][lane] = v; }
     DplReps st; st.r0 = st.r1 = st.r2 = st.r3 = 0u;               // repeat distances of the node being expanded
 
-    // ---- pipelines: records two groups of four positions ahead, hint bytes one group ahead
-    uint32_t recG[4], recN[4], r3G[4], r3N[4], byG, byN;
+    // ---- pipelines: records, short candidates and literal prices two groups of four positions ahead
+    uint32_t recG[4], recN[4], recNN[4], r3G[4], r3N[4], r3NN[4], lpG, lpN, lpNN;
+    const uint8_t* LP = litPrice + base + w0;
     // tracked distances (REPS): where the window's bytes repeat at distance tD[k] -- bit j of tM[k]: S[pb + j] == S[pb + j - tD[k]], known for
     // positions below tE[k].  One slot is (re)filled per group of four nodes, 32 positions at a time, from two 32-byte reads issued a group earlier.
     uint32_t tD[DPL_NT]; int32_t tE[DPL_NT]; unsigned long long tM[DPL_NT];
@@ -224,10 +255,10 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
         if (g4 >= -warm && g4 + 4 <= N) {
             GcU4 v; __builtin_memcpy(&v, R + g4, 16); rr[0] = v.x; rr[1] = v.y; rr[2] = v.z; rr[3] = v.w;
             uint64_t h; __builtin_memcpy(&h, R3 + g4, 8); r3[0] = (uint32_t)h & 0xFFFFu; r3[1] = (uint32_t)(h >> 16) & 0xFFFFu; r3[2] = (uint32_t)(h >> 32) & 0xFFFFu; r3[3] = (uint32_t)(h >> 48);
-            by = gc_ld32(S + g4);
+            by = gc_ld32(LP + g4);
         } else if (g4 >= -warm) {
 #pragma unroll
-            for (int32_t u = 0; u < 4; u++) if (g4 + u < N) { rr[u] = R[g4 + u]; r3[u] = R3[g4 + u]; by |= (uint32_t)S[g4 + u] << (8 * u); }
+            for (int32_t u = 0; u < 4; u++) if (g4 + u < N) { rr[u] = R[g4 + u]; r3[u] = R3[g4 + u]; by |= (uint32_t)LP[g4 + u] << (8 * u); }
         }
     };
     // bytes of x that are zero, as a mask of 4 bits / of two 16-byte strings that are equal, as a mask of 16 bits
@@ -268,6 +299,7 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
             for (uint32_t k = 0; k < DPL_NT; k++) tM[k] >>= 32;
         }
         const uint32_t want[DPL_NT] = { st.r0 & ~DPL_SURE, st.r1, st.r2, st.r3, lru[0], lru[1] };
+        uint32_t fillD = 0u, fillK = DPL_NT;                      // a distance of the node that gets its first 32 positions on the spot (below)
 #pragma unroll
         for (uint32_t j = 0; j < DPL_NT; j++) {
             const uint32_t d = want[j];
@@ -283,17 +315,18 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
                 if (mine && v == DPL_NT && t != want[0] && t != want[1] && t != want[2] && t != want[3] && t != want[4] && t != want[5]) v = k;
             }
 #pragma unroll
-            for (uint32_t k = 0; k < DPL_NT; k++) if (k == v) {
-                // a newly tracked distance is wanted NOW (the nodes that made it a repeat are the ones about to use it): its first 32 positions are read on
-                // the spot -- one exposed memory latency per new distance, a few per hundred nodes -- instead of leaving the next group of nodes without it
-                tD[k] = d; tM[k] = 0ull; tE[k] = q0;
-                if (q0 < N && q0 >= -warm && (uint64_t)((int64_t)q0 + 32) <= tailRoom && (int64_t)q0 + inFrameW >= (int64_t)d) {     // (a distance of the shadow parse comes from a record a few positions AHEAD)
-                    const LzW16 o0 = lz_ld16(S + q0, 0), o1 = lz_ld16(S + q0 + 16, 0);
-                    const LzW16 p0 = lz_ld16(S + (int64_t)q0 - (int64_t)d, 0), p1 = lz_ld16(S + (int64_t)q0 - (int64_t)d + 16, 0);
-                    tM[k] = (unsigned long long)(eq16(o0, p0) | (eq16(o1, p1) << 16)) << (uint32_t)(q0 - pb);
-                    tE[k] = q0 + 32;
-                }
-            }
+            for (uint32_t k = 0; k < DPL_NT; k++) if (k == v) { tD[k] = d; tM[k] = 0ull; tE[k] = q0; }
+            if (j < 4u && v < DPL_NT && fillK == DPL_NT) { fillK = v; fillD = d; }
+        }
+        // A newly tracked distance of the NODE is wanted now (the nodes that made it a repeat are the ones about to use it): its first 32 positions are read on
+        // the spot -- an exposed memory latency, a few times per hundred nodes and lane -- instead of leaving the next group of nodes without it (the evaluation
+        // slices: ROCm shared objects +0.5 % without).  The shadow parse's distances come early; their request channel serves them.
+        if (fillK < DPL_NT && q0 < N && q0 >= -warm && (uint64_t)((int64_t)q0 + 32) <= tailRoom && (int64_t)q0 + inFrameW >= (int64_t)fillD) {
+            const LzW16 o0 = lz_ld16(S + q0, 0), o1 = lz_ld16(S + q0 + 16, 0);
+            const LzW16 p0 = lz_ld16(S + (int64_t)q0 - (int64_t)fillD, 0), p1 = lz_ld16(S + (int64_t)q0 - (int64_t)fillD + 16, 0);
+            const unsigned long long bits = (unsigned long long)(eq16(o0, p0) | (eq16(o1, p1) << 16)) << (uint32_t)(q0 - pb);
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; k++) if (k == fillK) { tM[k] = bits; tE[k] = q0 + 32; }
         }
         uint32_t taken = DPL_NT;
 #pragma unroll
@@ -317,149 +350,199 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
             }
         }
     };
-    load_group(-warmMax, recG, r3G, byG);
-    load_group(-warmMax + 4, recN, r3N, byN);
+    load_group(-warmMax, recG, r3G, lpG);
+    load_group(-warmMax + 4, recN, r3N, lpN);
     pb = -warmMax;
     if (REPS) { shadow_step(-warmMax, recG); shadow_step(-warmMax + 4, recN); }
-    uint32_t prevByte = 0u;
-    if (n != 0u && (absW + hasPrev) > (uint64_t)warm) prevByte = (uint32_t)S[-warm - 1];
     uint32_t contDist = 0u, contRem = 0u; bool contCapped = false;   // the node being expanded was reached by a capped piece
     uint32_t c1 = 0u, c2 = 0u, c3 = 0u;                           // back pointers waiting to be stored (nodes 4g+1 .. 4g+3)
     uint32_t cost0 = 0u, costN = 0u;                              // cost of the window's first / last node
+    // length prices of the lane's block in registers, two per word (the relax loops below run over static lengths)
+    uint32_t lenR[DPL_TABW], repR[DPL_TABW];
+#pragma unroll
+    for (uint32_t k = 0; k < DPL_TABW; k++) {
+        lenR[k] = (uint32_t)P[GC_PRICE_LEN + 2u * k] | ((uint32_t)P[GC_PRICE_LEN + 2u * k + 1u] << 16);
+        repR[k] = REPS ? (uint32_t)P[GC_PRICE_REPLEN + 2u * k] | ((uint32_t)P[GC_PRICE_REPLEN + 2u * k + 1u] << 16) : 0u;
+    }
+    unsigned long long* const myCost = &sCost[0][lane];           // this lane's column: slot s at myCost[s * 64]
 
-    // ---- the programme: node i = finalize (i > -warm) + expand (i < n); nodes below 0 are the warm-up
-    for (int32_t g4 = -warmMax; g4 < (int32_t)nMax + 4; g4 += 4) {
-        uint32_t recNN[4], r3NN[4], byNN;
-        load_group(g4 + 8, recNN, r3NN, byNN);
-#pragma unroll
-        for (int32_t u = 0; u < 4; u++) {
-            const int32_t i = g4 + u;
-            const uint32_t slot = (uint32_t)i & DPL_MMASK;
-            const unsigned long long w = sCost[slot][lane];
-            sCost[slot][lane] = DPL_INF;
-            const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
-            const uint32_t c0 = hi >> 6;
-            const bool live = n != 0u && i >= -warm && i <= N;
-            if (live && i > -warm) {                               // ---- finalize node i
-                const uint32_t len = DPL_LO_LEN(lo), cls = DPL_LO_CLS(lo), dist = DPL_LO_DIST(lo);
-                if (REPS) {
-                    const GcU4 pv = sReps[(uint32_t)(i - (int32_t)(len < DPL_MR ? len : DPL_MR)) & (DPL_MR - 1u)][lane];      // (an edge longer than the ring: the oldest node it still holds)
-                    st.r0 = pv.x; st.r1 = pv.y; st.r2 = pv.z; st.r3 = pv.w;
-                    if (cls != DPL_LIT && cls != DPL_SREP) dpl_mtf(st, dist, i - (int32_t)len >= 0 ? DPL_SURE : 0u);
-                    GcU4 nv; nv.x = st.r0; nv.y = st.r1; nv.z = st.r2; nv.w = st.r3; sReps[slot & (DPL_MR - 1u)][lane] = nv;
-                }
-                contCapped = DPL_LO_CAP(lo) != 0u; contDist = dist; contRem = hi & 63u;
-                if (i == 0) cost0 = c0;
-                if (i == N) costN = c0;
-            }
-            // back pointers: node j lives in slot j - 1; nodes 4g-3 .. 4g leave together
-            if (u == 0) {
-                if (g4 >= 4 && g4 - 4 < N) {
-                    if (g4 <= N) { GcU4 v; v.x = c1; v.y = c2; v.z = c3; v.w = lo; __builtin_memcpy(BP + (g4 - 4), &v, 16); }
-                    else { BP[g4 - 4] = c1; if (g4 - 3 < N) BP[g4 - 3] = c2; if (g4 - 2 < N) BP[g4 - 2] = c3; }
-                }
-            } else if (u == 1) c1 = lo; else if (u == 2) c2 = lo; else c3 = lo;
-            {                                                      // ---- expand node i (room = 0: a lane without this node)
-                // bytes up to the end of the window -- in the warm-up: up to the window's first node, where the lane of the window in front stops too
-                const uint32_t room = !live ? 0u : (i < 0 ? (uint32_t)(-i) : (uint32_t)(N - i));
-                const uint32_t byte = (byG >> (8 * u)) & 0xFFu;
-                // a continuation of one byte is only a match together with the piece in front of it: at the window's first node that piece is the warm-up's guess
-                const uint32_t contX0 = i == 0 ? 2u : 1u;
-                // literal
-                if (room != 0u) {
-                    const uint32_t pr = flagLit + P[GC_PRICE_LIT + (((prevByte >> 5) & litCtxMask) << 8) + byte];
-                    const unsigned long long word = ((unsigned long long)((c0 + pr) << 6) << 32);
-                    atomicMin(&sCost[(uint32_t)(i + 1) & DPL_MMASK][lane], word);
-                    prevByte = byte;
-                }
-                // one candidate (Lx bytes at distance Dx, clipped to `room` by the caller; Lx = 0: none) as pieces of <= DPL_M bytes.  The last piece carries
-                // the length price of the whole match and, as "bytes left", what lies behind it (`behind`: also what the end of the window cut off -- the
-                // next window's warm-up finds it there); `openEnd`: the bytes behind it were not compared (hints), it is offered again where it ends
-                auto relax_cand = [&](uint32_t Lx, uint32_t behind, uint32_t Dx, uint32_t cls, uint32_t add, uint32_t x0, bool openEnd) {
-                    const uint32_t Lm = Lx < DPL_M ? Lx : DPL_M;
-                    uint32_t left = Lx - Lm + behind; if (left > 63u) left = 63u;
-                    const uint32_t wholeLen = Lx + behind < GC_MATCH_CAP ? Lx + behind : GC_MATCH_CAP;
-                    for (uint32_t x = x0; x <= Lm; x++) {                  // (a plain divergent loop: the lanes touch nothing but their own columns)
-                        {
-                            const bool last = x == Lm && (left != 0u || openEnd);
-                            const uint32_t lp = cls == DPL_CONTC ? 0u : (uint32_t)P[(cls >= DPL_REP0 ? GC_PRICE_REPLEN : GC_PRICE_LEN) + (x == Lm && left != 0u ? wholeLen : x)];
-                            atomicMin(&sCost[(uint32_t)(i + (int32_t)x) & DPL_MMASK][lane], ((unsigned long long)(((c0 + add + lp) << 6) | (x == Lm ? left : 0u)) << 32) | DPL_LO(Dx, last, cls, x));
-                        }
-                    }
-                };
-                // the rest of a capped match whose length is known
-                {
-                    uint32_t Lc = (room != 0u && contCapped) ? contRem : 0u;
-                    const uint32_t beh = Lc > room ? Lc - room : 0u;
-                    if (Lc > room) Lc = room;
-                    if (Lc != 0u) relax_cand(Lc, beh, contDist, DPL_CONTC, DPL_CONT, contX0, false);
-                }
-                // finder candidate, short candidate
-                const uint32_t r = recG[u], r3 = r3G[u];
-                uint32_t L = r & 0xFFu; const uint32_t D = r >> 8;
-                uint32_t behL = L > room ? L - room : 0u;
-                if (L > room) L = room;
-                uint32_t L3 = 0u, D3 = 0u;
-                if (r3 != GC_SHORT_NONE) { L3 = (r3 & 15u) + 2u; D3 = (r3 >> 4) + 1u; if (L3 > room) L3 = room; if (L3 > DPL_M) L3 = DPL_M; if (L3 < MINLEN || (L >= L3 && D <= D3)) L3 = 0u; }
-                if (L < MINLEN && !(contCapped && D == contDist && L != 0u)) { L = 0u; behL = 0u; }
-#pragma unroll
-                for (uint32_t cnd = 0; cnd < 2u; cnd++) {
-                    const uint32_t Lx = cnd ? L3 : L, Dx = cnd ? D3 : D;
-                    if (Lx != 0u) {
-                        uint32_t cls = DPL_NEW, add = 0u, x0 = MINLEN;
-                        {
-                            const uint32_t sl = gc_dist_slot(Dx - 1u);
-                            add = newAdd + P[GC_PRICE_SLOT + sl] + (sl >= 4u ? 16u * ((sl >> 1) - 1u) : 0u);
-                            if (REPS) { const uint32_t k = dpl_which(st, Dx); if (k < 4u) { cls = DPL_REP0 + k; add = flagMat + P[GC_PRICE_FLAGS + (k == 0u ? 2u : 3u + k)]; } }
-                            if (contCapped && Dx == contDist) { cls = DPL_CONTC; add = DPL_CONT; x0 = contX0; }
-                        }
-                        relax_cand(Lx, cnd ? 0u : behL, Dx, cls, add, x0, !cnd && (r & 0xFFu) == GC_MATCH_CAP);     // a capped record goes on in the record behind it
-                    }
-                }
-                // repeats of the node's own distances, where those are tracked
-                if (REPS) {
-#pragma unroll
-                    for (uint32_t k = 0; k < DPL_NT; k++) {
-                        const uint32_t hd = tD[k];
-                        const int32_t avail = tE[k] - i;                               // positions from here on that the mask knows
-                        uint32_t hl = 0u;
-                        if (hd != 0u && avail > 0 && room != 0u) {
-                            const unsigned long long run = ~(tM[k] >> (uint32_t)(i - pb));
-                            hl = run ? gc_ctz64(run) : 64u;
-                            if (hl > (uint32_t)avail) hl = (uint32_t)avail;
-                        }
+    // One candidate as edges: Lm bytes (0: none) at a distance, lengths x0 .. Lm.  hiBase = (cost of the node + flags and distance) << 6; the edge of Lm bytes
+    // carries hiLast / loLast instead (length price of the whole match, bytes left, "capped").  Every lane runs the loop (static lengths, its own predicate);
+    // the wave leaves it once no lane has a longer candidate.
 #ifdef HIPEMU
-                        static const int xPerfect = getenv("GC_X_PERFECT") ? atoi(getenv("GC_X_PERFECT")) : 0;
-                        if ((xPerfect == 1 || (xPerfect == 2 && avail <= 0) || (xPerfect == 3 && avail > 0 && hl == (uint32_t)avail)) && hd != 0u && room != 0u && (uint64_t)((int64_t)i + 40) <= tailRoom) { hl = 0u; while (hl < 32u && S[i + (int32_t)hl] == S[(int64_t)i + hl - (int64_t)hd]) hl++; }
-                        if (xNoHint) hl = 0u;
-                        for (uint32_t z = 0; z < hl; z++) if (S[i + (int32_t)z] != S[(int64_t)i + z - (int64_t)hd]) { fprintf(stderr, "W7L: mask of distance %u wrong at %d + %u\n", hd, i, z); abort(); }
+#define DPL_NONE_LONGER(x, L) ((x) > (L))
+#else
+#define DPL_NONE_LONGER(x, L) (!__any((x) <= (L)))
 #endif
-                        const bool open = hl != 0u && ((avail > 0 && hl == (uint32_t)avail) || hl >= DPL_M) && hl <= room;      // the run may go on behind what is known / what an edge holds
-                        if (hl > DPL_M) hl = DPL_M;
-                        if (hl > room) hl = room;
-                        uint32_t cls = 0u, add = 0u, x0 = 2u;
-                        if (hl != 0u && st.r0 == (hd | DPL_SURE) && !(contCapped && hd == contDist)) {          // LZMA's short repeat: one byte at rep0, known for certain
-                            const uint32_t pr = flagMat + P[GC_PRICE_FLAGS + 3u];
-                            atomicMin(&sCost[(uint32_t)(i + 1) & DPL_MMASK][lane], ((unsigned long long)((c0 + pr) << 6) << 32) | DPL_LO(hd, false, DPL_SREP, 1u));
-                        }
-                        if (hl != 0u && (hd == D || hd == D3)) hl = (hd == D ? L : L3) >= hl ? 0u : hl;          // the candidate itself covers it
-                        if (hl != 0u) {
-                            const uint32_t kk = dpl_which(st, hd);
-                            if (contCapped && hd == contDist) { cls = DPL_CONTC; add = DPL_CONT; x0 = contX0; }
-                            else if (kk < 4u) { cls = DPL_REP0 + kk; add = flagMat + P[GC_PRICE_FLAGS + (kk == 0u ? 2u : 3u + kk)]; }
-                            else hl = 0u;
-                        }
-                        if (hl >= x0) relax_cand(hl, 0u, hd, cls, add, x0, open);
+    // The lengths tried are x0 .. LO and the last four (Lm - 3 .. Lm): what lies between are prefixes of a long candidate that end nowhere in particular
+    // (measured on the evaluation slices: all lengths against 2 .. 12 + the last four of the finder's candidates, 2 .. 4 + the last four of a repeat:
+    // +0.05 ... 0.2 % size for half the relax instructions).  tabBase: where the length prices lie in LDS (for the lengths that are not static).
+    auto relax = [&](int32_t i, uint32_t Lm, uint32_t x0, uint32_t hiBase, uint32_t loBase, uint32_t lastLen /* whose price the last edge carries */, uint32_t left, uint32_t loLast,
+                     const uint32_t (&tab)[DPL_TABW], uint32_t tabBase, bool flat, const uint32_t LO) {
+        if (DPL_NONE_LONGER(x0 > 1u ? x0 : 1u, Lm)) return;
+        // the four prices with a length of the lane's own: read together, used below
+        const uint32_t p3 = P[tabBase + (Lm > 3u ? Lm - 3u : 0u)], p2 = P[tabBase + (Lm > 2u ? Lm - 2u : 0u)], p1 = P[tabBase + (Lm > 1u ? Lm - 1u : 0u)], p0 = P[tabBase + lastLen];
+        const uint32_t pre = Lm > 4u ? (Lm - 4u < LO ? Lm - 4u : LO) : 0u;        // lengths up to here in the static loop
+#pragma unroll
+        for (uint32_t x = 1u; x <= LO; x++) {
+            if (x > 1u && (x & 3u) == 1u && DPL_NONE_LONGER(x, pre)) break;
+            if (x >= x0 && x <= pre) {
+                const uint32_t lp = flat ? 0u : ((tab[x >> 1] >> (16u * (x & 1u))) & 0xFFFFu);
+                atomicMin(&myCost[(((uint32_t)i + x) & DPL_MMASK) * 64u], ((unsigned long long)(hiBase + (lp << 6)) << 32) | (loBase | (x - 1u)));
+            }
+        }
+#pragma unroll
+        for (uint32_t t = 3u; t >= 1u; t--) {
+            const uint32_t x = Lm - t;                             // (per lane)
+            if (Lm > t && x >= x0 && x > pre) {
+                const uint32_t lp = flat ? 0u : (t == 3u ? p3 : (t == 2u ? p2 : p1));
+                atomicMin(&myCost[(((uint32_t)i + x) & DPL_MMASK) * 64u], ((unsigned long long)(hiBase + (lp << 6)) << 32) | (loBase | (x - 1u)));
+            }
+        }
+        if (Lm >= x0 && Lm != 0u) atomicMin(&myCost[(((uint32_t)i + Lm) & DPL_MMASK) * 64u], ((unsigned long long)((hiBase + ((flat ? 0u : p0) << 6)) | left) << 32) | loLast);
+    };
+
+    // ---- the programme: node i = finalize (i > -warm) + expand (i < n); nodes below 0 are the warm-up.  The records of the group of four positions
+    //      that holds i sit in recG / r3G / lpG and move down one place per node, so that the node's own are always in place 0
+#if defined(DPL_PROF) && !defined(HIPEMU)
+    unsigned long long pacc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, ptick = clock64();
+#endif
+    for (int32_t i = -warmMax; i < (int32_t)nMax + 4; i++) {
+        const uint32_t u = (uint32_t)i & 3u;
+        DPL_T(7);
+        if (u == 0u) load_group(i + 8, recNN, r3NN, lpNN);
+        const uint32_t slot = (uint32_t)i & DPL_MMASK;
+        const unsigned long long w = myCost[slot * 64u];
+        myCost[slot * 64u] = DPL_INF;
+        const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
+        const uint32_t c0 = hi >> 6;
+        const bool live = n != 0u && i >= -warm && i <= N;
+        if (live && i > -warm) {                                   // ---- finalize node i
+            const uint32_t len = DPL_LO_LEN(lo), cls = DPL_LO_CLS(lo), dist = DPL_LO_DIST(lo);
+            if (REPS) {
+                const GcU4 pv = sReps[(uint32_t)(i - (int32_t)(len < DPL_MR ? len : DPL_MR)) & (DPL_MR - 1u)][lane];      // (an edge longer than the ring: the oldest node it still holds)
+                st.r0 = pv.x; st.r1 = pv.y; st.r2 = pv.z; st.r3 = pv.w;
+                if (cls != DPL_LIT && cls != DPL_SREP) dpl_mtf(st, dist, i - (int32_t)len >= 0 ? DPL_SURE : 0u);
+                GcU4 nv; nv.x = st.r0; nv.y = st.r1; nv.z = st.r2; nv.w = st.r3; sReps[slot & (DPL_MR - 1u)][lane] = nv;
+            }
+            contCapped = DPL_LO_CAP(lo) != 0u; contDist = dist; contRem = hi & 63u;
+            if (i == 0) cost0 = c0;
+            if (i == N) costN = c0;
+        }
+        DPL_T(0);
+        // back pointers: node j lives in slot j - 1; nodes 4g-3 .. 4g leave together
+        if (u == 0u) {
+            if (i >= 4 && i - 4 < N) {
+                if (i <= N) { GcU4 v; v.x = c1; v.y = c2; v.z = c3; v.w = lo; __builtin_memcpy(BP + (i - 4), &v, 16); }
+                else { BP[i - 4] = c1; if (i - 3 < N) BP[i - 3] = c2; if (i - 2 < N) BP[i - 2] = c3; }
+            }
+        } else { c1 = u == 1u ? lo : c1; c2 = u == 2u ? lo : c2; c3 = u == 3u ? lo : c3; }
+        {                                                          // ---- expand node i (room = 0: a lane without this node)
+            // bytes up to the end of the window -- in the warm-up: up to the window's first node, where the lane of the window in front stops too
+            const uint32_t room = !live ? 0u : (i < 0 ? (uint32_t)(-i) : (uint32_t)(N - i));
+            // a continuation of one byte is only a match together with the piece in front of it: at the window's first node that piece is the warm-up's guess
+            const uint32_t contX0 = i == 0 ? 2u : 1u;
+            const uint32_t cbase = c0 << 6;
+            if (room != 0u) atomicMin(&myCost[(((uint32_t)i + 1u) & DPL_MMASK) * 64u], (unsigned long long)(cbase + ((flagLit + (lpG & 0xFFu)) << 6)) << 32);      // literal
+            // the rest of a capped match whose length is known
+            {
+                uint32_t Lc = (room != 0u && contCapped) ? contRem : 0u;
+                const uint32_t beh = Lc > room ? Lc - room : 0u;
+                if (Lc > room) Lc = room;
+                const uint32_t Lm = Lc < DPL_M ? Lc : DPL_M;
+                uint32_t left = Lc - Lm + beh; if (left > 63u) left = 63u;
+                const uint32_t hb = cbase + (DPL_CONT << 6);
+                relax(i, Lm, contX0, hb, DPL_LO(contDist, false, DPL_CONTC, 1u), 0u, left, DPL_LO(contDist, left != 0u, DPL_CONTC, Lm ? Lm : 1u), lenR, GC_PRICE_LEN, true, 4u);
+            }
+            DPL_T(1);
+            // finder candidate, short candidate
+            const uint32_t r = recG[0], r3 = r3G[0];
+            uint32_t L = r & 0xFFu; const uint32_t D = r >> 8;
+            uint32_t behL = L > room ? L - room : 0u;
+            if (L > room) L = room;
+            uint32_t L3 = 0u, D3 = 0u;
+            if (r3 != GC_SHORT_NONE) { L3 = (r3 & 15u) + 2u; D3 = (r3 >> 4) + 1u; if (L3 > room) L3 = room; if (L3 > DPL_M) L3 = DPL_M; if (L3 < MINLEN || (L >= L3 && D <= D3)) L3 = 0u; }
+            if (L < MINLEN && !(contCapped && D == contDist && L != 0u)) { L = 0u; behL = 0u; }
+#pragma unroll
+            for (uint32_t cnd = 0; cnd < 2u; cnd++) {
+                const uint32_t Lx = cnd ? L3 : L, Dx = cnd ? D3 : (D ? D : 1u), behind = cnd ? 0u : behL;
+                uint32_t cls = DPL_NEW, x0 = MINLEN;
+                const uint32_t sl = gc_dist_slot(Dx - 1u);
+                uint32_t add = newAdd + P[GC_PRICE_SLOT + sl] + (sl >= 4u ? 16u * ((sl >> 1) - 1u) : 0u);
+                if (REPS) { const uint32_t k = dpl_which(st, Dx); if (k < 4u) { cls = DPL_REP0 + k; add = k == 0u ? fRep0 : (k == 1u ? fRep1 : (k == 2u ? fRep2 : fRep3)); } }
+                const bool isCont = contCapped && Dx == contDist;
+                if (isCont) { cls = DPL_CONTC; add = DPL_CONT; x0 = contX0; }
+                const uint32_t Lm = Lx < DPL_M ? Lx : DPL_M;
+                uint32_t left = Lx - Lm + behind; if (left > 63u) left = 63u;
+                const bool openEnd = !cnd && (r & 0xFFu) == GC_MATCH_CAP;      // a capped record goes on in the record behind it
+                const uint32_t wholeLen = Lx + behind < GC_MATCH_CAP ? Lx + behind : GC_MATCH_CAP;
+                const bool repTab = REPS && cls >= DPL_REP0 && cls <= DPL_REP0 + 3u;
+                const uint32_t hb = cbase + (add << 6);
+                const uint32_t loLast = DPL_LO(Dx, left != 0u || openEnd, cls, Lm ? Lm : 1u), lastLen = left != 0u ? wholeLen : Lm;      // the last piece: the length price of the whole match
+                if (repTab) relax(i, Lm, x0, hb, DPL_LO(Dx, false, cls, 1u), lastLen, left, loLast, repR, GC_PRICE_REPLEN, isCont, cnd ? 8u : 12u);
+                else relax(i, Lm, x0, hb, DPL_LO(Dx, false, cls, 1u), lastLen, left, loLast, lenR, GC_PRICE_LEN, isCont, cnd ? 8u : 12u);
+            }
+            DPL_T(2);
+            // repeats of the node's own distances, where those are tracked.  Of the (up to four) that repeat here two become edges: the one with the
+            // lowest repeat index -- the cheapest flags -- and the longest one (evaluation slices: against all of them +0.0x % size, a third of the work)
+            if (REPS && trackOn) {
+                uint32_t bestK = 8u, bestL = 0u, bestD = 0u, longK = 8u, longL = 0u, longD = 0u; bool bestOpen = false, longOpen = false;
+                const uint32_t r0d = st.r0 & ~DPL_SURE;
+#pragma unroll
+                for (uint32_t k = 0; k < DPL_NT; k++) {
+                    const uint32_t hd = tD[k];
+                    const int32_t avail = tE[k] - i;                               // positions from here on that the mask knows
+                    uint32_t hl = 0u;
+                    if (hd != 0u && avail > 0 && room != 0u) {
+                        const unsigned long long run = ~(tM[k] >> (uint32_t)(i - pb));
+                        hl = run ? gc_ctz64(run) : 64u;
+                        if (hl > (uint32_t)avail) hl = (uint32_t)avail;
                     }
+#ifdef HIPEMU
+                    if (xNoHint) hl = 0u;
+                    for (uint32_t z = 0; z < hl; z++) if (S[i + (int32_t)z] != S[(int64_t)i + z - (int64_t)hd]) { fprintf(stderr, "W7L: mask of distance %u wrong at %d + %u\n", hd, i, z); abort(); }
+#endif
+                    const bool open = hl != 0u && ((avail > 0 && hl == (uint32_t)avail) || hl >= DPL_M) && hl <= room;      // the run may go on behind what is known / what an edge holds
+                    if (hl > DPL_M) hl = DPL_M;
+                    if (hl > room) hl = room;
+                    // which repeat of the node it is: 0..3; the continuation of a capped piece counts as the cheapest (index 0 - 1)
+                    uint32_t kk = hd == r0d ? 1u : (hd == st.r1 ? 2u : (hd == st.r2 ? 3u : (hd == st.r3 ? 4u : 8u)));
+                    if (contCapped && hd == contDist) kk = 0u;
+                    if (hl != 0u && kk == 1u && (st.r0 & DPL_SURE))               // LZMA's short repeat: one byte at rep0, known for certain
+                        atomicMin(&myCost[(((uint32_t)i + 1u) & DPL_MMASK) * 64u], ((unsigned long long)(cbase + (fSrep << 6)) << 32) | DPL_LO(hd, false, DPL_SREP, 1u));
+                    if (hl != 0u && (hd == D || hd == D3)) hl = (hd == D ? L : L3) >= hl ? 0u : hl;          // the candidate itself covers it
+                    if (hl < (kk == 0u ? contX0 : 2u) || kk == 8u) continue;
+                    if (kk < bestK) { bestK = kk; bestL = hl; bestD = hd; bestOpen = open; }
+                    if (hl > longL) { longK = kk; longL = hl; longD = hd; longOpen = open; }
+                }
+                if (longK == bestK) longL = 0u;
+#pragma unroll
+                for (uint32_t e = 0; e < 2u; e++) {
+                    const uint32_t kk = e ? longK : bestK, hl = e ? longL : bestL, hd = e ? longD : bestD; const bool open = e ? longOpen : bestOpen;
+                    const bool isCont = kk == 0u;
+                    const uint32_t ri = (kk - 1u) & 3u;                            // repeat index
+                    const uint32_t cls = isCont ? DPL_CONTC : DPL_REP0 + ri, add = isCont ? DPL_CONT : (ri == 0u ? fRep0 : (ri == 1u ? fRep1 : (ri == 2u ? fRep2 : fRep3)));
+                    const uint32_t hb = cbase + (add << 6);
+                    relax(i, hl, isCont ? contX0 : 2u, hb, DPL_LO(hd, false, cls, 1u), hl, 0u, DPL_LO(hd, open, cls, hl ? hl : 1u), repR, GC_PRICE_REPLEN, isCont, 4u);
                 }
             }
         }
-        // ---- next group: hint bytes that have arrived -> lengths; new requests with the newest node's distances; the shadow parse moves on
-        if (REPS) { shadow_step(g4 + 8, recNN); track_step(g4 + 4); }
+        DPL_T(3);
+        // the group's records move down one place
+        recG[0] = recG[1]; recG[1] = recG[2]; recG[2] = recG[3]; r3G[0] = r3G[1]; r3G[1] = r3G[2]; r3G[2] = r3G[3]; lpG >>= 8;
+        if (u == 3u) {                                             // ---- between two groups: the shadow parse and the tracked distances move on, the next group's records come in
+            if (REPS && trackOn) { shadow_step(i + 5, recNN); track_step(i + 1); }
 #pragma unroll
-        for (uint32_t u = 0; u < 4u; u++) { recG[u] = recN[u]; recN[u] = recNN[u]; r3G[u] = r3N[u]; r3N[u] = r3NN[u]; }
-        byG = byN; byN = byNN;
+            for (uint32_t q = 0; q < 4u; q++) { recG[q] = recN[q]; recN[q] = recNN[q]; r3G[q] = r3N[q]; r3N[q] = r3NN[q]; }
+            lpG = lpN; lpN = lpNN;
+            DPL_T(4);
+        }
     }
+#if defined(DPL_PROF) && !defined(HIPEMU)
+    if (lane == 0u && !SAMPLE) for (int k = 0; k < 8; k++) atomicAdd(&g_dplProf[k], pacc[k]);
+    ptick = clock64();
+#endif
+#undef DPL_NONE_LONGER
     // back pointers of the last nodes (n not a multiple of four is covered above; n a multiple of four: nodes n-3 .. n left at g4 = n)
     gc_wave_sync_global();
     if (winCost != nullptr && !SAMPLE && w0 < blockLen) winCost[(uint64_t)b * (GC_ZSTD_BLOCK_MAX >> 12) + (lane & 31u)] = costN - cost0;     // estimate per 4 KiB range-coder chunk
@@ -503,6 +586,9 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
             if (!phaseA) BP[q] = out;
         }
     }
+#if defined(DPL_PROF) && !defined(HIPEMU)
+    if (lane == 0u && !SAMPLE) atomicAdd(&g_dplProf[8], clock64() - ptick);
+#endif
     if (phaseA) {
         if (n != 0u) atomicAdd(&sCnt[lb][GC_DPS_NLIT], nLitC);
         gc_wave_sync();
@@ -531,10 +617,35 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
 #define DPL_KERNEL(name, REPS, MINLEN, SAMPLE) \
 extern "C" __global__ void __launch_bounds__(64) \
 name(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t frameBlocks, uint32_t phase, uint32_t* __restrict__ dpStat, uint32_t litCtxMask, \
-     const uint32_t* __restrict__ rec, const uint16_t* __restrict__ rec3, const uint16_t* __restrict__ priceTab, uint32_t* __restrict__ recOut, uint32_t* __restrict__ winCost) \
-{ dpl_run<REPS, MINLEN, SAMPLE>(src, srcSize, nBlocks, per, frameBlocks, phase, dpStat, litCtxMask, rec, rec3, priceTab, recOut, winCost); }
+     const uint32_t* __restrict__ rec, const uint16_t* __restrict__ rec3, const uint16_t* __restrict__ priceTab, uint32_t* __restrict__ recOut, uint32_t* __restrict__ winCost, \
+     const uint8_t* __restrict__ litPrice) \
+{ dpl_run<REPS, MINLEN, SAMPLE>(src, srcSize, nBlocks, per, frameBlocks, phase, dpStat, litCtxMask, rec, rec3, priceTab, recOut, winCost, litPrice); }
 
 DPL_KERNEL(gc_mf_dpl2_kernel,  true, 2u, false)   // LZMA: every window
 DPL_KERNEL(gc_mf_dpl2s_kernel, true, 2u, true)    // LZMA: the sample of phase A
 DPL_KERNEL(gc_mf_dpl3_kernel,  false, 3u, false)  // zstd, brotli
 DPL_KERNEL(gc_mf_dpl3s_kernel, false, 3u, true)
+
+// The literal price of every position under its block's table (W6's statistics: literal given the top bits of the byte in front of it), one byte each
+// (prices stop at GC_PRICE_MAX = 240): position-parallel, so the lanes of W7L read four prices per group of nodes instead of holding 4 KiB of table per
+// block in LDS.  One workgroup per block.
+extern "C" __global__ void __launch_bounds__(256)
+gc_mf_litprice_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, const uint16_t* __restrict__ priceTab, uint32_t litCtxArg, uint8_t* __restrict__ out)
+{
+    __shared__ uint16_t sLit[GC_PRICE_LEN];
+    const uint32_t t = threadIdx.x, b = dpl_item(blockIdx.x, per);
+    if (b >= nBlocks) return;
+    const uint32_t litCtxMask = litCtxArg & 0xFFu, hasPrev = litCtxArg >> 31;
+    { const GcU4* T4 = (const GcU4*)(priceTab + (uint64_t)b * GC_PRICE_WORDS); GcU4* S4 = (GcU4*)sLit; for (uint32_t i = t; i < GC_PRICE_LEN / 8u; i += 256u) S4[i] = T4[i]; }
+    __syncthreads();
+    const uint64_t base = (uint64_t)b * GC_ZSTD_BLOCK_MAX;
+    const uint32_t n = (uint32_t)((srcSize - base) < GC_ZSTD_BLOCK_MAX ? (srcSize - base) : GC_ZSTD_BLOCK_MAX);
+    for (uint32_t p = t * 16u; p < n; p += 256u * 16u) {
+        uint8_t in[17], o[16];
+        in[0] = (base + p + hasPrev) ? src[base + p - 1u] : (uint8_t)0;
+        if (p + 16u <= n) __builtin_memcpy(in + 1, src + base + p, 16); else for (uint32_t k = 0; k < 16u; k++) in[1 + k] = p + k < n ? src[base + p + k] : (uint8_t)0;
+#pragma unroll
+        for (uint32_t k = 0; k < 16u; k++) o[k] = (uint8_t)sLit[((((uint32_t)in[k] >> 5) & litCtxMask) << 8) + in[k + 1u]];
+        if (p + 16u <= n) __builtin_memcpy(out + base + p, o, 16); else for (uint32_t k = 0; k < 16u && p + k < n; k++) out[base + p + k] = o[k];
+    }
+}
