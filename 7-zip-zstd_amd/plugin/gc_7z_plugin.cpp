@@ -105,6 +105,7 @@ struct Shared {
     gc_multi* multi = nullptr;                        // host scheduler over every visible GPU, two contexts each (csrc/gc_multi.hip)
     std::atomic<int> multiState{0};                   // 0 not there yet, 1 ready, -1 could not be created
     std::atomic<int> warm{0};                         // the warm-up thread has been started
+    std::mutex warmMu; std::thread warmThread;        // ... and is joined before any coder object dies / the module is unloaded (warm_up_join)
     gc_ctx* dec = nullptr;                            // the ZSTD decoder's context (device 0)
     BufSet pool[4]; int nPool = 0;                    // buffer sets handed back by finished Code() calls
 };
@@ -140,13 +141,24 @@ void warm_up_async()
     int zero = 0;
     if (!s || !s->warm.compare_exchange_strong(zero, 1)) return;
     try {
-        std::thread([]() {
+        std::lock_guard<std::mutex> lk(s->warmMu);
+        s->warmThread = std::thread([]() {
             const unsigned delay = test_env_u32("GC_PLUGIN_WARM_DELAY_MS");        // (test hook: a slow start-up on a machine that has none)
             if (delay) std::this_thread::sleep_for(std::chrono::milliseconds(delay));
             int rc; shared_multi(&rc);
-        }).detach();
+        });
     } catch (...) {}                                   // no thread to be had: Code() creates the scheduler itself
 }
+// The warm-up thread is inside the HIP runtime's initialisation for ~0.2 s.  A host that creates an encoder and never reaches Code() (a rejected property, an
+// abort) must not get to exit() / static destruction while it is: every encoder object joins it when it dies, and so does the module when it is unloaded.
+void warm_up_join()
+{
+    Shared* s = shared();
+    if (!s) return;
+    std::lock_guard<std::mutex> lk(s->warmMu);
+    if (s->warmThread.joinable() && s->warmThread.get_id() != std::this_thread::get_id()) s->warmThread.join();
+}
+__attribute__((destructor)) static void plugin_unload() { warm_up_join(); }
 gc_ctx* shared_dec_ctx()
 {
     Shared* s = shared();
@@ -167,7 +179,9 @@ void buf_release(BufSet* b)
 {
     Shared* s = shared();
     bool kept = false;
-    if (s) { std::lock_guard<std::mutex> lk(s->mu); if (s->nPool < 4) { s->pool[s->nPool++] = *b; kept = true; } }
+    const size_t kKeep = (size_t)256 << 20;             // a long-lived host must not sit on gigabytes of page-locked memory after one large archive
+    const bool small = b->inCap[0] <= kKeep && b->inCap[1] <= kKeep && b->outCap <= kKeep;
+    if (s && small) { std::lock_guard<std::mutex> lk(s->mu); if (s->nPool < 4) { s->pool[s->nPool++] = *b; kept = true; } }
     if (!kept) { gc_host_free(b->in[0]); gc_host_free(b->in[1]); gc_host_free(b->out); }
     *b = BufSet();
 }
@@ -215,7 +229,7 @@ public:
         return S_OK;
     }
     ULONG AddRef() override { return ++refs_; }
-    ULONG Release() override { if (--refs_ != 0) return refs_; delete this; return 0; }      // non-atomic like MyCom.h:380-390
+    ULONG Release() override { if (--refs_ != 0) return refs_; warm_up_join(); delete this; return 0; }      // non-atomic like MyCom.h:380-390
 
     // the workers are GPU contexts, their number follows the devices; BROTLI with "0 threads" = a plain .br stream without brotli-mt
     // framing, which is how the reference's bare-file handler asks for it (BrotliHandler.cpp:286-291, BrotliEncoder.cpp:166-177)
@@ -495,14 +509,27 @@ public:
     ULONG AddRef() override { return ++refs_; }
     ULONG Release() override { if (--refs_ != 0) return refs_; delete this; return 0; }
 
-    HRESULT Init() override { pc_ = pcInit_; memset(state_, 0, sizeof(state_)); return S_OK; }      // Z7_BRANCH_CONV_ST_X86_STATE_INIT_VAL = 0, Delta_Init: zeros
+    // A return of 0 means "not enough data" to CFilterCoder, which then writes the bytes through UNFILTERED and reports S_OK (FilterCoder.cpp:172-174,
+    // :383-387): a failure must never look like that.  Init() is the call with an HRESULT (CFilterCoder RINOKs it): no device -> E_FAIL before a byte is
+    // read.  A failure in mid-stream is latched and answered with a size no buffer has: the host takes a return above what it handed over as "cannot
+    // convert this" and ends with E_FAIL / S_FALSE (FilterCoder.cpp:176-201, :248-262, :389-396), never with an archive that claims the filter.
+    bool failed_ = false;
+    static const uint32_t kFilterFailed = 0xFFFFFFFFu;
+    HRESULT Init() override
+    {
+        pc_ = pcInit_; memset(state_, 0, sizeof(state_)); failed_ = false;     // Z7_BRANCH_CONV_ST_X86_STATE_INIT_VAL = 0, Delta_Init: zeros
+        if (test_env_u32("GC_PLUGIN_FILTER_NO_DEVICE")) return E_FAIL;          // (test hook: as on a machine without a usable GPU)
+        return shared_dec_ctx() ? S_OK : E_FAIL;
+    }
     uint32_t Filter(uint8_t* data, uint32_t size) override
     {
-        gc_ctx* const ctx = shared_dec_ctx();
-        if (!ctx || !size) return 0;                               // (no device: nothing is converted -- the host's coder then stops with its own error)
+        if (!size) return 0;
+        gc_ctx* const ctx = failed_ ? nullptr : shared_dec_ctx();
+        if (!ctx) { failed_ = true; return kFilterFailed; }
+        const unsigned failAt = test_env_u32("GC_PLUGIN_FILTER_FAIL_AT_PC");     // (test hook: the device fails once the stream has got this far)
         size_t done = 0; int rc;
-        { std::lock_guard<std::mutex> g(shared()->gpu); rc = gc_filter_host(ctx, kind_, data, size, pc_, encoding_ ? 1 : 0, delta_, state_, &done); }
-        if (rc != GC_OK) return 0;
+        { std::lock_guard<std::mutex> g(shared()->gpu); rc = (failAt && pc_ - pcInit_ >= failAt) ? GC_ERR_HIP : gc_filter_host(ctx, kind_, data, size, pc_, encoding_ ? 1 : 0, delta_, state_, &done); }
+        if (rc != GC_OK) { failed_ = true; return kFilterFailed; }
         pc_ += (uint32_t)done;
         return (uint32_t)done;
     }

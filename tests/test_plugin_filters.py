@@ -77,3 +77,15 @@ def test_delta_filter_equals_the_reference(O, emu_module, tmp_path, delta):
     assert (tmp_path / "enc.bin.props").read_bytes() == bytes([delta - 1])           # DeltaFilter.cpp:82-86
     dec = _filter(emu_module, "DELTAGPU", "dec", tmp_path / "enc.bin.props", tmp_path / "enc.bin", tmp_path / "dec.bin", 77_777)
     assert np.array_equal(dec, x)
+
+
+@pytest.mark.parametrize("hook,code", [("GC_PLUGIN_FILTER_NO_DEVICE=1", 15), ("GC_PLUGIN_FILTER_FAIL_AT_PC=100000", 16)])
+def test_filter_failure_is_reported_not_passed_through(emu_module, tmp_path, hook, code):
+    """no device: Init() fails (the call CFilterCoder checks); a failure in mid-stream: Filter() answers with a size no buffer has -- never with 0, which the
+    filter coder reads as "pass the rest through unfiltered" (FilterCoder.cpp:172-174)"""
+    x = _x86_like(300_000, 7)
+    src = tmp_path / "in.bin"; x.tofile(src)
+    k, v = hook.split("=")
+    r = subprocess.run([os.path.join(EMU, "plugin_host"), emu_module, "filter", "BCJGPU", "enc", "-", str(src), str(tmp_path / "out.bin"), "65537"],
+                       capture_output=True, text=True, env=dict(os.environ, **{k: v}))
+    assert r.returncode == code, (r.returncode, r.stderr)

@@ -219,3 +219,24 @@ def test_real_host_filter_chain_through_the_emulator_module(host_dir, emu_lib_pa
     coder drives Filter() on its buffer), records the reference's method ids, and tests / extracts the archive with its BUILT-IN BCJ and ZSTD decoders;
     the same with the Delta filter and its property."""
     _filter_chain(host_dir, _install(host_dir, os.path.join(EMU, "lib7zgpucodec_emu.so"), EMU), O, 300_000, 200_000)
+
+
+@pytest.mark.parametrize("hook", ["GC_PLUGIN_FILTER_NO_DEVICE=1", "GC_PLUGIN_FILTER_FAIL_AT_PC=65536"])
+def test_real_host_filter_failure_is_an_error_not_an_unfiltered_archive(host_dir, emu_lib_path, hook):
+    """A filter that cannot run -- no device when the coder is set up, or a device failure in mid-stream -- must end `7z a` with an error: a return of 0
+    from Filter() would make CFilterCoder write the bytes through unfiltered into a folder that declares the filter (FilterCoder.cpp:172-174)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_bra import _x86_like
+    env = _install(host_dir, os.path.join(EMU, "lib7zgpucodec_emu.so"), EMU)
+    k, v = hook.split("="); env[k] = v
+    x = _x86_like(400_000, 5)
+    src = host_dir / "flt_fail.bin"; x.tofile(src)
+    arc = host_dir / "flt_fail.7z"
+    if arc.exists():
+        arc.unlink()
+    r = _run(host_dir, env, "a", "-m0=BCJGPU", "-m1=ZSTDGPU", "-mx3", arc.name, src.name)
+    assert r.returncode != 0 and "Everything is Ok" not in r.stdout, r.stdout + r.stderr
+    if arc.exists():                                                   # whatever was left behind must not pass as an archive of the file
+        t = _run(host_dir, dict(env, **{k: "0"}), "t", arc.name)
+        assert t.returncode != 0 or "flt_fail.bin" not in _run(host_dir, env, "l", arc.name).stdout
