@@ -211,8 +211,8 @@ extern "C" int gc_ctx_create(gc_ctx** out, int device)
         for (uint32_t i = 0; rc == GC_OK && i < GC_PART_EVENTS; i++) if (hipEventCreate(&c->evPart[p][i]) != hipSuccess) rc = GC_ERR_HIP;
     }
     if (rc == GC_OK && hipMalloc((void**)&c->prof, (GC_LZ_PHASES + GC_SEQ_PHASES) * sizeof(unsigned long long)) != hipSuccess) rc = GC_ERR_NOMEM;
-    if (rc == GC_OK && hipMalloc((void**)&c->mfTicket, GC_MAX_PARTS * 16u * sizeof(uint32_t)) != hipSuccess) rc = GC_ERR_NOMEM;
-    if (rc == GC_OK && (hipMalloc((void**)&c->result, 16) != hipSuccess || hipHostMalloc((void**)&c->hostResult, 16) != hipSuccess)) rc = GC_ERR_NOMEM;
+    if (rc == GC_OK && (hipMalloc((void**)&c->mfTicket, GC_MAX_PARTS * 16u * sizeof(uint32_t)) != hipSuccess || hipMemsetAsync(c->mfTicket, 0, GC_MAX_PARTS * 16u * sizeof(uint32_t), c->stream) != hipSuccess)) rc = GC_ERR_NOMEM;
+    if (rc == GC_OK && (hipMalloc((void**)&c->result, 16) != hipSuccess || hipHostMalloc((void**)&c->hostResult, 16 + GC_MAX_PARTS * 16u * sizeof(uint32_t)) != hipSuccess)) rc = GC_ERR_NOMEM;      // (+ a copy of the ticket / watchdog words)
     if (rc != GC_OK) { ctx_release(c); return rc; }
     c->dbgFrameBlocks = 0; c->dbgPartFrames = 0;
     gc_env_u32("GC_FRAME_BLOCKS", 1u, GC_MF_MAX_FRAME_BLOCKS, &c->dbgFrameBlocks);      // test hooks: small frames / parts
@@ -659,8 +659,13 @@ extern "C" int gc_zstd_finish(gc_ctx* c, size_t* compressedSize)
     if (!c || !c->pending) return GC_ERR_PARAM;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipMemcpyAsync(c->hostResult, c->result, 16, hipMemcpyDeviceToHost, c->stream));
+    uint32_t* const words = (uint32_t*)(c->hostResult + 2);          // word 7 of a part: a kernel's bounded wait for another workgroup ran out (gc_lz_window.hip, fused verify + parse)
+    HIPCHK(c, hipMemcpyAsync(words, c->mfTicket, GC_MAX_PARTS * 16u * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->pending = false;
+    { uint32_t trip = 0; gc_env_u32("GC_WATCHDOG_TRIP", 0u, 1u, &trip);       // test hook: as if a wait had run out
+      for (uint32_t p = 0; p < GC_MAX_PARTS; p++) trip |= words[p * 16u + 7u];
+      if (trip) { snprintf(c->err, sizeof(c->err), "a kernel gave up waiting for another workgroup (watchdog): the output of this call is not valid"); return GC_ERR_HIP; } }
     if (c->hostResult[1]) { snprintf(c->err, sizeof(c->err), "destination too small: need %llu bytes", (unsigned long long)c->hostResult[0]); return GC_ERR_DST_SMALL; }
     if (compressedSize) *compressedSize = (size_t)c->hostResult[0];
     return GC_OK;

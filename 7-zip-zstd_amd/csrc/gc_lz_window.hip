@@ -1139,7 +1139,9 @@ MFK(gc_mf_vparse_tile_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize,
 #endif
         }
         uint32_t w = 0x80000000u;
-        if (lane < ti) { do { w = gc_poll_device(&tileWord[tile - ti + lane]); if (!(w >> 31)) gc_nap(); } while (!(w >> 31)); }
+        // (bounded: tiles are drawn from a ticket counter, so whatever a tile waits for is running or done -- but if that ever fails to hold the call must end with
+        //  an error code, not hang: after ~4 s of polling the lane reports through the word in front of the ticket counters and goes on with empty counts)
+        if (lane < ti) { uint32_t spins = 0; do { w = gc_poll_device(&tileWord[tile - ti + lane]); if (!(w >> 31)) { gc_nap(); if (++spins > (1u << 22)) { atomicOr(tickets - 1, 1u); w = 0x80000000u; } } } while (!(w >> 31)); }
         const uint32_t sb = gc_wave_sum(lane < ti ? (w >> 15) & 0xFFFFu : 0u), lb = gc_wave_sum(lane < ti ? w & 0x7FFFu : 0u);      // (a 16 KiB tile of literals only has 2^14 of them: 15 bits)
         if (lane == 0) { sBase[0] = sb; sBase[1] = lb; }
     }

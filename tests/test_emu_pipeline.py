@@ -63,3 +63,17 @@ def test_binary_alphabet_over_128_symbols(O, emu_enc):
 def test_deterministic(O, emu_enc):
     x = O.corpus("silesia-like", BLK)
     assert np.array_equal(emu_enc.code(x), emu_enc.code(x))
+
+
+def test_watchdog_word_turns_into_an_error_code(pkg, emu_lib_path, O, monkeypatch):
+    """the inter-workgroup waits of the fused verify + parse kernel are bounded; a wait that runs out sets a word that the finish call turns into
+    GC_ERR_HIP (test hook GC_WATCHDOG_TRIP: as if that had happened) -- an error code, not a hang and not a stream"""
+    x = O.corpus("text-zipf", 300_000)
+    e = pkg.ZstdEncoder(level=3, lib_path=emu_lib_path)
+    assert len(e.code(x)) > 0
+    monkeypatch.setenv("GC_WATCHDOG_TRIP", "1")
+    with pytest.raises(pkg.GpuCodecError):
+        e.code(x)
+    monkeypatch.delenv("GC_WATCHDOG_TRIP")
+    assert len(e.code(x)) > 0
+    e.close()
