@@ -321,6 +321,9 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
         // A newly tracked distance of the NODE is wanted now (the nodes that made it a repeat are the ones about to use it): its first 32 positions are read on
         // the spot -- an exposed memory latency, a few times per hundred nodes and lane -- instead of leaving the next group of nodes without it (the evaluation
         // slices: ROCm shared objects +0.5 % without).  The shadow parse's distances come early; their request channel serves them.
+#ifdef DPL_NOSYNCFILL
+        fillK = DPL_NT;                                            // (experiment: what the fills on the spot cost)
+#endif
         if (fillK < DPL_NT && q0 < N && q0 >= -warm && (uint64_t)((int64_t)q0 + 32) <= tailRoom && (int64_t)q0 + inFrameW >= (int64_t)fillD) {
             const LzW16 o0 = lz_ld16(S + q0, 0), o1 = lz_ld16(S + q0 + 16, 0);
             const LzW16 p0 = lz_ld16(S + (int64_t)q0 - (int64_t)fillD, 0), p1 = lz_ld16(S + (int64_t)q0 - (int64_t)fillD + 16, 0);
