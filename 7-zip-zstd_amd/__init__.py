@@ -24,7 +24,7 @@ _ERR = {-1: "GC_ERR_NO_DEVICE", -2: "GC_ERR_HIP", -3: "GC_ERR_NOMEM", -4: "GC_ER
 
 EXPORTS = ["gc_test_hooks_enabled", "gc_lzfind_get_matches_device", "gc_device_count", "gc_ctx_create", "gc_ctx_destroy", "gc_last_error_message", "gc_zstd_compress_bound",
            "gc_zstd_compress_device", "gc_zstd_finish", "gc_zstd_compress_host", "gc_zstd_last_timing", "gc_ctx_stream",
-           "gc_zstd_set_phase_profile", "gc_zstd_phase_profile", "gc_mf_last_timing", "gc_mf_price_timing", "gc_mf_pass_timing",
+           "gc_zstd_set_phase_profile", "gc_zstd_phase_profile", "gc_mf_last_timing", "gc_mf_price_timing", "gc_mf_pass_timing", "gc_host_begin_pre", "gc_codec_compress_host_pre",
            "gc_flzma2_compress_bound", "gc_flzma2_dict_prop", "gc_flzma2_compress_device", "gc_flzma2_finish", "gc_flzma2_compress_host",
            "gc_flzma2_last_timing",
            "gc_brotli_compress_bound", "gc_brotli_compress_device", "gc_brotli_finish", "gc_brotli_compress_host", "gc_brotli_last_timing",
@@ -303,6 +303,27 @@ class _EncoderBase:
     def stream(self):
         return self._lib.gc_ctx_stream(self._ctx)
 
+    CODEC = None                      # GC_CODEC_* of the subclass (0 zstd, 1 flzma2, 2 brotli)
+    FILTER_X86, FILTER_DELTA = 100, 101
+
+    def code_pre(self, data, filter=0, pc=0, delta=1, want_crc=True, flags=0):
+        """gc_codec_compress_host_pre: one host buffer -> (compressed stream of the FILTERED bytes, CRC-32 of the raw bytes, bytes the converter converted).
+        What a 7z folder `filter -> coder` holds, with the reader's CRC, from one transfer (include/gpucodec.h gc_pre)."""
+        import numpy as np
+
+        class GcPre(C.Structure):
+            _fields_ = [("filter", C.c_int), ("pc", C.c_uint32), ("delta", C.c_uint), ("want_crc", C.c_int), ("state", C.c_ubyte * 256), ("crc", C.c_uint32), ("processed", C.c_uint64)]
+        x = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data)
+        pre = GcPre(); pre.filter = int(filter); pre.pc = int(pc); pre.delta = int(delta); pre.want_crc = 1 if want_crc else 0
+        self._lib.gc_codec_compress_bound.restype = C.c_size_t; self._lib.gc_codec_compress_bound.argtypes = [C.c_int, C.c_size_t]
+        cap = int(self._lib.gc_codec_compress_bound(self.CODEC, x.size))
+        out = np.empty(cap, dtype=np.uint8); n = C.c_size_t(0)
+        self._lib.gc_codec_compress_host_pre.restype = C.c_int
+        self._lib.gc_codec_compress_host_pre.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_int, C.c_uint, C.c_void_p, C.POINTER(C.c_size_t)]
+        self._check(self._lib.gc_codec_compress_host_pre(self._ctx, self.CODEC, x.ctypes.data_as(C.c_void_p), x.size, out.ctypes.data_as(C.c_void_p), cap, int(self.level), int(flags),
+                                                         C.byref(pre), C.byref(n)), "gc_codec_compress_host_pre")
+        return out[: n.value].copy(), int(pre.crc), int(pre.processed)
+
     MF_KERNELS = ("mf.count", "mf.scan", "mf.scatter", "mf.link", "mf.verify", "mf.parse")
 
     def mf_timing_ms(self):
@@ -326,6 +347,7 @@ class _EncoderBase:
 
 
 class Flzma2Encoder(_EncoderBase):
+    CODEC = 1
     L2_PHASES = ("l2.header_cycles", "l2.generate_cycles", "l2.apply_cycles", "l2.apply_steps", "l2.rounds", "l2.segments")
 
     def set_phase_profile(self, on=True):
@@ -377,6 +399,7 @@ class Flzma2Encoder(_EncoderBase):
 
 
 class BrotliEncoder(_EncoderBase):
+    CODEC = 2
     """Mirror of NCompress::NBROTLI::CEncoder (CPP/7zip/Compress/BrotliEncoder.h:35-70; Code() at BrotliEncoder.cpp:118-164):
     bytes -> brotli-mt framed chunks; `coder_props()` is the 3-byte blob {BROTLI_VERSION_MAJOR 1, BROTLI_VERSION_MINOR 2, level} of BrotliEncoder.h:18-32."""
 
@@ -481,6 +504,7 @@ class ZstdDecoder(_EncoderBase):
 
 
 class ZstdEncoder(_EncoderBase):
+    CODEC = 0
     """Mirror of NCompress::NZSTD::CEncoder for the compression hot path (one object per GPU)."""
 
     KERNELS = ("lz", "huf", "seq", "plan", "emit", "total")

@@ -137,7 +137,7 @@ struct gc_ctx {
     int lastCodec;            // 0 zstd, 1 flzma2, 2 brotli: which kernels the events of the last call bracket
     uint64_t* hostResult;     // pinned
     // staging for the host-buffer entry point
-    uint8_t* dIn; size_t dInCap; uint8_t* dOut; size_t dOutCap;
+    uint8_t* dIn; size_t dInCap; uint8_t* dOut; size_t dOutCap; uint8_t* dPre; size_t dPreCap;      // (dPre: the pre-filtered input of gc_host_begin_pre)
     bool pending; bool timed;
     // zstd decoder (gc_zstd_dec.hip): per-workgroup literal / sequence workspace, frame table, per-frame results, ticket counter
     uint8_t* zdLit; size_t zdLitCap; void* zdSeq; size_t zdSeqCap; GcZdFrame* zdFrames; size_t zdFramesCap; uint64_t* zdResult; uint64_t* zdTot;
@@ -237,7 +237,7 @@ static void ctx_release(gc_ctx* c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     free_workspace(c);
-    hipFree(c->prof); hipFree(c->mfTicket); hipFree(c->result); if (c->hostResult) hipHostFree(c->hostResult); hipFree(c->dIn); hipFree(c->dOut);
+    hipFree(c->prof); hipFree(c->mfTicket); hipFree(c->result); if (c->hostResult) hipHostFree(c->hostResult); hipFree(c->dIn); hipFree(c->dOut); hipFree(c->dPre);
     hipFree(c->zdLit); hipFree(c->zdSeq); hipFree(c->zdFrames); hipFree(c->zdResult); hipFree(c->zdTot); hipFree(c->zdBlocks); hipFree(c->zdOrder); hipFree(c->zdReady); hipFree(c->zdTicket); hipFree(c->zdPlace); hipFree(c->zdPtr); hipFree(c->zdDone); hipFree(c->zdFerr);
     for (int i = 0; i < 2; i++) if (c->zdEv[i]) hipEventDestroy(c->zdEv[i]);
     hipFree(c->mfTileWord); hipFree(c->mfCnt); hipFree(c->mfEnt); hipFree(c->mfEnt2); hipFree(c->mfRec); hipFree(c->mfRec2); hipFree(c->mfRec3); hipFree(c->mfDp); hipFree(c->mfPrice); hipFree(c->mfWinCost); hipFree(c->mfDpStat); hipFree(c->mfLitPrice);
@@ -969,25 +969,52 @@ extern "C" size_t gc_codec_compress_bound(int codec, size_t n)
     return codec == GC_CODEC_ZSTD ? gc_zstd_compress_bound(n) : (codec == GC_CODEC_FLZMA2 ? gc_flzma2_compress_bound(n) : gc_brotli_compress_bound(n));
 }
 
-extern "C" int gc_host_begin(gc_ctx* c, int codec, const void* src, size_t n, int level, unsigned flags)
+extern "C" int gc_crc32_device(const void* d_src, size_t n, uint32_t* crc);
+extern "C" int gc_bra_convert_device(int kind, const void* d_src, void* d_dst, size_t n, uint32_t pc, int encoding, size_t* processed);
+extern "C" int gc_bra_x86_convert_device(const void* d_src, void* d_dst, size_t n, uint32_t pc, int encoding, uint32_t* state, size_t* processed);
+extern "C" int gc_delta_convert_device(const void* d_src, void* d_dst, size_t n, unsigned delta, int encoding, unsigned char state[256]);
+
+// H2D + [CRC-32 of the raw bytes + pre-filter, both on the device: gpucodec.h gc_pre] + enqueue of the codec's kernels
+extern "C" int gc_host_begin_pre(gc_ctx* c, int codec, const void* src, size_t n, int level, unsigned flags, gc_pre* pre)
 {
     if (!c || (!src && n) || codec < GC_CODEC_ZSTD || codec > GC_CODEC_BROTLI) return GC_ERR_PARAM;
+    const int flt = pre ? pre->filter : 0;
+    const bool x86 = flt == GC_FILTER_X86, dl = flt == GC_FILTER_DELTA;
+    if (flt != 0 && !x86 && !dl && (flt < GC_BRA_ARM64 || flt > GC_BRA_RISCV)) return GC_ERR_PARAM;
+    if (dl && (pre->delta < 1u || pre->delta > 256u)) return GC_ERR_PARAM;
     HIPCHK(c, hipSetDevice(c->device));
     const size_t bound = gc_codec_compress_bound(codec, n);
     if (n > c->dInCap) { hipFree(c->dIn); c->dIn = nullptr; c->dInCap = 0; if (hipMalloc((void**)&c->dIn, n + 64) != hipSuccess) return GC_ERR_NOMEM; c->dInCap = n; }
     if (bound > c->dOutCap) { hipFree(c->dOut); c->dOut = nullptr; c->dOutCap = 0; if (hipMalloc((void**)&c->dOut, bound) != hipSuccess) return GC_ERR_NOMEM; c->dOutCap = bound; }
     if (n) HIPCHK(c, hipMemcpyAsync(c->dIn, src, n, hipMemcpyHostToDevice, c->stream));
+    const uint8_t* d_in = c->dIn;
+    if (pre) { pre->crc = 0; pre->processed = 0; }
+    if (pre && n && (pre->want_crc || flt)) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));                  // (the CRC and the converters run on the default stream and return values to the host)
+        if (pre->want_crc) { const int rc = gc_crc32_device(c->dIn, n, &pre->crc); if (rc != GC_OK) { snprintf(c->err, sizeof(c->err), "CRC of the input failed on the device"); return rc; } }
+        if (flt) {
+            if (n > c->dPreCap) { hipFree(c->dPre); c->dPre = nullptr; c->dPreCap = 0; if (hipMalloc((void**)&c->dPre, n + 64) != hipSuccess) return GC_ERR_NOMEM; c->dPreCap = n; }
+            size_t done = 0; int rc;
+            if (x86) { uint32_t st; memcpy(&st, pre->state, 4); rc = gc_bra_x86_convert_device(c->dIn, c->dPre, n, pre->pc, 1, &st, &done); memcpy(pre->state, &st, 4); }
+            else if (dl) { rc = gc_delta_convert_device(c->dIn, c->dPre, n, pre->delta, 1, pre->state); done = n; }
+            else rc = gc_bra_convert_device(flt, c->dIn, c->dPre, n, pre->pc, 1, &done);
+            if (rc != GC_OK) { snprintf(c->err, sizeof(c->err), "pre-filter %d failed on the device", flt); return rc; }
+            pre->processed = done;
+            d_in = c->dPre;
+        }
+    } else if (pre && pre->want_crc) pre->crc = 0u;                  // (CrcCalc of nothing)
     if (codec == GC_CODEC_BROTLI && (flags & GC_BROTLI_PLAIN)) {      // per-call form of GC_OPT_BROTLI_PLAIN (pieces of one stream); the context's own option comes back afterwards
         const uint32_t keep = c->optBrotliPlain;
         c->optBrotliPlain = (flags & 7u) | 1u;
-        const int rc = gc_brotli_compress_device(c, c->dIn, n, c->dOut, c->dOutCap, level);
+        const int rc = gc_brotli_compress_device(c, d_in, n, c->dOut, c->dOutCap, level);
         c->optBrotliPlain = keep;
         return rc;
     }
-    return codec == GC_CODEC_ZSTD ? gc_zstd_compress_device(c, c->dIn, n, c->dOut, c->dOutCap, level)
-         : codec == GC_CODEC_FLZMA2 ? gc_flzma2_compress_device(c, c->dIn, n, c->dOut, c->dOutCap, level, flags)
-                                    : gc_brotli_compress_device(c, c->dIn, n, c->dOut, c->dOutCap, level);
+    return codec == GC_CODEC_ZSTD ? gc_zstd_compress_device(c, d_in, n, c->dOut, c->dOutCap, level)
+         : codec == GC_CODEC_FLZMA2 ? gc_flzma2_compress_device(c, d_in, n, c->dOut, c->dOutCap, level, flags)
+                                    : gc_brotli_compress_device(c, d_in, n, c->dOut, c->dOutCap, level);
 }
+extern "C" int gc_host_begin(gc_ctx* c, int codec, const void* src, size_t n, int level, unsigned flags) { return gc_host_begin_pre(c, codec, src, n, level, flags, nullptr); }
 
 extern "C" int gc_host_size(gc_ctx* c, size_t* compressedSize) { return gc_zstd_finish(c, compressedSize); }
 
@@ -999,10 +1026,10 @@ extern "C" int gc_host_fetch(gc_ctx* c, void* dst, size_t size)
     return GC_OK;
 }
 
-extern "C" int gc_codec_compress_host(gc_ctx* c, int codec, const void* src, size_t n, void* dst, size_t dstCap, int level, unsigned flags, size_t* outSize)
+extern "C" int gc_codec_compress_host_pre(gc_ctx* c, int codec, const void* src, size_t n, void* dst, size_t dstCap, int level, unsigned flags, gc_pre* pre, size_t* outSize)
 {
     if (!c || (!src && n) || !dst) return GC_ERR_PARAM;
-    int rc = gc_host_begin(c, codec, src, n, level, flags);
+    int rc = gc_host_begin_pre(c, codec, src, n, level, flags, pre);
     if (rc != GC_OK) return rc;
     size_t sz = 0;
     rc = gc_host_size(c, &sz);
@@ -1012,6 +1039,10 @@ extern "C" int gc_codec_compress_host(gc_ctx* c, int codec, const void* src, siz
     if (rc != GC_OK) return rc;
     if (outSize) *outSize = sz;
     return GC_OK;
+}
+extern "C" int gc_codec_compress_host(gc_ctx* c, int codec, const void* src, size_t n, void* dst, size_t dstCap, int level, unsigned flags, size_t* outSize)
+{
+    return gc_codec_compress_host_pre(c, codec, src, n, dst, dstCap, level, flags, nullptr, outSize);
 }
 
 // pinned host memory for callers that want the copies of gc_host_begin / gc_host_fetch to run at link speed and asynchronously

@@ -135,6 +135,22 @@ int         gc_host_size(gc_ctx* ctx, size_t* compressedSize);
 int         gc_host_fetch(gc_ctx* ctx, void* dst, size_t size);
 int         gc_codec_compress_host(gc_ctx* ctx, int codec, const void* src, size_t n, void* dst, size_t dstCapacity, int level, unsigned flags,
                                    size_t* compressedSize);
+/* ---- pre-processing on the device INSIDE the compress call ("fused into the same H2D pass"): the CRC-32 of the raw input (C/7zCrc.c) and one
+ * of 7-Zip's pre-filters (C/Bra.c, C/Bra86.c, C/Delta.c) applied to the input where it lies in HBM, before the match finder -- ONE transfer for what the 7z
+ * folder pipeline does in three host passes (the CRC in the reader CPP/7zip/Common/InOutTempBuffer / CInStreamWithCRC, CFilterCoder CPP/7zip/Common/
+ * FilterCoder.cpp:160-262, then the coder; caller: CPP/7zip/Archive/7z/7zEncode.cpp:152-239).  The compressed stream is that of the FILTERED bytes: what a
+ * folder "filter -> coder" holds.
+ *   filter      0 = none, GC_BRA_* / GC_FILTER_X86 / GC_FILTER_DELTA as for gc_filter_host;  pc, delta, state: as there (state: 4 bytes x86, 256 Delta), in and out
+ *   want_crc    != 0: crc receives CrcCalc(src, n) (init / final XOR 0xFFFFFFFF, polynomial 0xEDB88320)
+ *   processed   out: bytes the converter has converted (the last few of a stream stay as they are, as at the end of CFilterCoder's stream) */
+typedef struct gc_pre {
+    int filter; uint32_t pc; unsigned delta; int want_crc;
+    unsigned char state[256];
+    uint32_t crc; uint64_t processed;
+} gc_pre;
+int         gc_host_begin_pre(gc_ctx* ctx, int codec, const void* src, size_t n, int level, unsigned flags, gc_pre* pre);
+int         gc_codec_compress_host_pre(gc_ctx* ctx, int codec, const void* src, size_t n, void* dst, size_t dstCapacity, int level, unsigned flags,
+                                       gc_pre* pre, size_t* compressedSize);
 void*       gc_host_alloc(size_t n);
 void        gc_host_free(void* p);
 
