@@ -111,12 +111,15 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
     __shared__ uint32_t sCnt[SAMPLE ? BPW : 1u][SAMPLE ? GC_DPS_WORDS : 1u];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t litCtxMask = litCtxArg & 0xFFu, hasPrev = litCtxArg >> 31;
+    const bool win2k = !SAMPLE && (phaseArg & 16u) != 0u;         // every window of ONE block per wave, 64 x 2 KiB (more, shorter waves: the launch ends with its slowest wave)
+    phaseArg &= 15u;
+    const uint32_t BPWr = win2k ? 1u : BPW;
     const bool phaseA = SAMPLE && phaseArg == 0u, phaseB = phaseArg == 1u;      // (the sample kernels count: phase A; the others run phase B, or phase 2 = W6's prices as they are)
     const uint32_t item = dpl_item(blockIdx.x, per);
-    if (item * BPW >= nBlocks) return;                            // (uniform)
+    if (item * BPWr >= nBlocks) return;                           // (uniform)
     // ---- this lane's window
-    const uint32_t lb = lane >> 5;                                // block of the wave
-    const uint32_t b = item * BPW + lb;
+    const uint32_t lb = win2k ? 0u : lane >> 5;                   // block of the wave
+    const uint32_t b = item * BPWr + lb;
     const bool blockLive = b < nBlocks;
     const uint64_t base = (uint64_t)(blockLive ? b : 0u) * GC_ZSTD_BLOCK_MAX;
     const uint32_t blockLen = blockLive ? (uint32_t)((srcSize - base) < GC_ZSTD_BLOCK_MAX ? (srcSize - base) : GC_ZSTD_BLOCK_MAX) : 0u;
@@ -125,24 +128,24 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
     static const int xSparse = getenv("GC_X_SPARSE") ? atoi(getenv("GC_X_SPARSE")) : 0;
     static const int xHints = getenv("GC_X_HINTS") ? atoi(getenv("GC_X_HINTS")) : 63;
     (void)xWin4k;
-    const uint32_t winLen = SAMPLE ? 512u : 4096u;
-    const uint32_t w0 = ((lane & 31u) << 12) + (SAMPLE ? 1536u : 0u);
+    const uint32_t winLen = SAMPLE ? 512u : (win2k ? 2048u : 4096u);
+    const uint32_t w0 = win2k ? lane << 11 : ((lane & 31u) << 12) + (SAMPLE ? 1536u : 0u);
 #else
     const int xWarm = DPL_WARM; const int xSparse = 0;
-    const uint32_t winLen = SAMPLE ? 512u : 4096u;
-    const uint32_t w0 = ((lane & 31u) << 12) + (SAMPLE ? 1536u : 0u);
+    const uint32_t winLen = SAMPLE ? 512u : (win2k ? 2048u : 4096u);
+    const uint32_t w0 = win2k ? lane << 11 : ((lane & 31u) << 12) + (SAMPLE ? 1536u : 0u);
 #endif
     const uint32_t n = w0 < blockLen ? ((blockLen - w0) < winLen ? (blockLen - w0) : winLen) : 0u;       // nodes 0 .. n
     const uint32_t nMax = gc_wave_max(n);
     // ---- price tables (as W7: W6's table, phase A with optimistic ceilings where the greedy parse found no matches, phase B from phase A's counts)
     for (uint32_t q = 0; q < BPW; q++) {
-        const uint32_t bb = item * BPW + q;
+        const uint32_t bb = q < BPWr ? item * BPWr + q : nBlocks;
         if (bb < nBlocks) { const GcU4* T4 = (const GcU4*)(priceTab + (uint64_t)bb * GC_PRICE_WORDS + GC_PRICE_LEN); GcU4* S4 = (GcU4*)sPrice[q]; for (uint32_t i = lane; i < (GC_PRICE_WORDS - GC_PRICE_LEN) / 8u; i += 64u) S4[i] = T4[i]; }
         if (phaseA) for (uint32_t i = lane; i < GC_DPS_WORDS; i += 64u) sCnt[q][i] = 0;
     }
     gc_wave_sync();
     for (uint32_t q = 0; q < BPW; q++) {
-        const uint32_t bb = item * BPW + q;
+        const uint32_t bb = q < BPWr ? item * BPWr + q : nBlocks;
         if (bb >= nBlocks) continue;                              // (uniform)
         uint16_t* P = sPrice[q] - GC_PRICE_LEN;                   // (indexed with the table's own offsets, all >= GC_PRICE_LEN)
         if (lane == 0u) {                                         // before anything is known: repeats 3 / 3.5 / 4 / 5 / 5 bits on top of the match flag, "no repeat" free
@@ -198,7 +201,7 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
     if (REPS && phaseB) {
         uint32_t rich = 0u;
         for (uint32_t q = 0; q < BPW; q++) {
-            const uint32_t bb = item * BPW + q;
+            const uint32_t bb = q < BPWr ? item * BPWr + q : nBlocks;
             if (bb >= nBlocks) continue;
             const uint32_t* C = dpStat + (uint64_t)bb * GC_DPS_WORDS;
             const uint32_t reps = C[GC_DPS_NREP] + C[GC_DPS_NSREP] + C[GC_DPS_NREP1] + C[GC_DPS_NREP2] + C[GC_DPS_NREP3];
@@ -386,23 +389,25 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
         // the four prices with a length of the lane's own: read together, used below
         const uint32_t p3 = P[tabBase + (Lm > 3u ? Lm - 3u : 0u)], p2 = P[tabBase + (Lm > 2u ? Lm - 2u : 0u)], p1 = P[tabBase + (Lm > 1u ? Lm - 1u : 0u)], p0 = P[tabBase + lastLen];
         const uint32_t pre = Lm > 4u ? (Lm - 4u < LO ? Lm - 4u : LO) : 0u;        // lengths up to here in the static loop
+        // (every lane issues every ds_min: a lane without that edge sends the neutral word -- a select instead of an exec-mask branch per edge)
 #pragma unroll
         for (uint32_t x = 1u; x <= LO; x++) {
             if (x > 1u && (x & 3u) == 1u && DPL_NONE_LONGER(x, pre)) break;
-            if (x >= x0 && x <= pre) {
-                const uint32_t lp = flat ? 0u : ((tab[x >> 1] >> (16u * (x & 1u))) & 0xFFFFu);
-                atomicMin(&myCost[(((uint32_t)i + x) & DPL_MMASK) * 64u], ((unsigned long long)(hiBase + (lp << 6)) << 32) | (loBase | (x - 1u)));
-            }
+            const uint32_t lp = flat ? 0u : ((tab[x >> 1] >> (16u * (x & 1u))) & 0xFFFFu);
+            const uint32_t hi = (x >= x0 && x <= pre) ? hiBase + (lp << 6) : 0xFFFFFFFFu;
+            atomicMin(&myCost[(((uint32_t)i + x) & DPL_MMASK) * 64u], ((unsigned long long)hi << 32) | (loBase | (x - 1u)));
         }
 #pragma unroll
         for (uint32_t t = 3u; t >= 1u; t--) {
             const uint32_t x = Lm - t;                             // (per lane)
-            if (Lm > t && x >= x0 && x > pre) {
-                const uint32_t lp = flat ? 0u : (t == 3u ? p3 : (t == 2u ? p2 : p1));
-                atomicMin(&myCost[(((uint32_t)i + x) & DPL_MMASK) * 64u], ((unsigned long long)(hiBase + (lp << 6)) << 32) | (loBase | (x - 1u)));
-            }
+            const uint32_t lp = flat ? 0u : (t == 3u ? p3 : (t == 2u ? p2 : p1));
+            const uint32_t hi = (Lm > t && x >= x0 && x > pre) ? hiBase + (lp << 6) : 0xFFFFFFFFu;
+            atomicMin(&myCost[(((uint32_t)i + x) & DPL_MMASK) * 64u], ((unsigned long long)hi << 32) | (loBase | ((x - 1u) & DPL_MMASK)));
         }
-        if (Lm >= x0 && Lm != 0u) atomicMin(&myCost[(((uint32_t)i + Lm) & DPL_MMASK) * 64u], ((unsigned long long)((hiBase + ((flat ? 0u : p0) << 6)) | left) << 32) | loLast);
+        {
+            const uint32_t hi = (Lm >= x0 && Lm != 0u) ? ((hiBase + ((flat ? 0u : p0) << 6)) | left) : 0xFFFFFFFFu;
+            atomicMin(&myCost[(((uint32_t)i + Lm) & DPL_MMASK) * 64u], ((unsigned long long)hi << 32) | loLast);
+        }
     };
 
     // ---- the programme: node i = finalize (i > -warm) + expand (i < n); nodes below 0 are the warm-up.  The records of the group of four positions
@@ -446,7 +451,7 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
             // a continuation of one byte is only a match together with the piece in front of it: at the window's first node that piece is the warm-up's guess
             const uint32_t contX0 = i == 0 ? 2u : 1u;
             const uint32_t cbase = c0 << 6;
-            if (room != 0u) atomicMin(&myCost[(((uint32_t)i + 1u) & DPL_MMASK) * 64u], (unsigned long long)(cbase + ((flagLit + (lpG & 0xFFu)) << 6)) << 32);      // literal
+            atomicMin(&myCost[(((uint32_t)i + 1u) & DPL_MMASK) * 64u], (unsigned long long)(room != 0u ? cbase + ((flagLit + (lpG & 0xFFu)) << 6) : 0xFFFFFFFFu) << 32);      // literal
             // the rest of a capped match whose length is known
             {
                 uint32_t Lc = (room != 0u && contCapped) ? contRem : 0u;
@@ -482,25 +487,24 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
                 const bool repTab = REPS && cls >= DPL_REP0 && cls <= DPL_REP0 + 3u;
                 const uint32_t hb = cbase + (add << 6);
                 const uint32_t loLast = DPL_LO(Dx, left != 0u || openEnd, cls, Lm ? Lm : 1u), lastLen = left != 0u ? wholeLen : Lm;      // the last piece: the length price of the whole match
-                if (repTab) relax(i, Lm, x0, hb, DPL_LO(Dx, false, cls, 1u), lastLen, left, loLast, repR, GC_PRICE_REPLEN, isCont, cnd ? 8u : 12u);
-                else relax(i, Lm, x0, hb, DPL_LO(Dx, false, cls, 1u), lastLen, left, loLast, lenR, GC_PRICE_LEN, isCont, cnd ? 8u : 12u);
+                if (repTab) relax(i, Lm, x0, hb, DPL_LO(Dx, false, cls, 1u), lastLen, left, loLast, repR, GC_PRICE_REPLEN, isCont, cnd ? 6u : 8u);
+                else relax(i, Lm, x0, hb, DPL_LO(Dx, false, cls, 1u), lastLen, left, loLast, lenR, GC_PRICE_LEN, isCont, cnd ? 6u : 8u);
             }
             DPL_T(2);
             // repeats of the node's own distances, where those are tracked.  Of the (up to four) that repeat here two become edges: the one with the
             // lowest repeat index -- the cheapest flags -- and the longest one (evaluation slices: against all of them +0.0x % size, a third of the work)
             if (REPS && trackOn) {
-                uint32_t bestK = 8u, bestL = 0u, bestD = 0u, longK = 8u, longL = 0u, longD = 0u; bool bestOpen = false, longOpen = false;
+                uint32_t bestK = 8u, bestL = 0u, bestD = 0u, longK = 8u, longL = 0u, longD = 0u, srepD = 0u; bool bestOpen = false, longOpen = false;
                 const uint32_t r0d = st.r0 & ~DPL_SURE;
 #pragma unroll
                 for (uint32_t k = 0; k < DPL_NT; k++) {
                     const uint32_t hd = tD[k];
                     const int32_t avail = tE[k] - i;                               // positions from here on that the mask knows
-                    uint32_t hl = 0u;
-                    if (hd != 0u && avail > 0 && room != 0u) {
-                        const unsigned long long run = ~(tM[k] >> (uint32_t)(i - pb));
-                        hl = run ? gc_ctz64(run) : 64u;
-                        if (hl > (uint32_t)avail) hl = (uint32_t)avail;
-                    }
+                    const uint32_t av = avail > 0 ? (uint32_t)avail : 0u;
+                    const unsigned long long run = ~(tM[k] >> (uint32_t)(i - pb)) | (1ull << 63);      // (straight-line: selects, no branch per slot)
+                    uint32_t hl = gc_ctz64(run);
+                    hl = hl > av ? av : hl;
+                    hl = (hd != 0u && room != 0u) ? hl : 0u;
 #ifdef HIPEMU
                     if (xNoHint) hl = 0u;
                     for (uint32_t z = 0; z < hl; z++) if (S[i + (int32_t)z] != S[(int64_t)i + z - (int64_t)hd]) { fprintf(stderr, "W7L: mask of distance %u wrong at %d + %u\n", hd, i, z); abort(); }
@@ -511,13 +515,14 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
                     // which repeat of the node it is: 0..3; the continuation of a capped piece counts as the cheapest (index 0 - 1)
                     uint32_t kk = hd == r0d ? 1u : (hd == st.r1 ? 2u : (hd == st.r2 ? 3u : (hd == st.r3 ? 4u : 8u)));
                     if (contCapped && hd == contDist) kk = 0u;
-                    if (hl != 0u && kk == 1u && (st.r0 & DPL_SURE))               // LZMA's short repeat: one byte at rep0, known for certain
-                        atomicMin(&myCost[(((uint32_t)i + 1u) & DPL_MMASK) * 64u], ((unsigned long long)(cbase + (fSrep << 6)) << 32) | DPL_LO(hd, false, DPL_SREP, 1u));
-                    if (hl != 0u && (hd == D || hd == D3)) hl = (hd == D ? L : L3) >= hl ? 0u : hl;          // the candidate itself covers it
-                    if (hl < (kk == 0u ? contX0 : 2u) || kk == 8u) continue;
-                    if (kk < bestK) { bestK = kk; bestL = hl; bestD = hd; bestOpen = open; }
-                    if (hl > longL) { longK = kk; longL = hl; longD = hd; longOpen = open; }
+                    if (hl != 0u && kk == 1u && (st.r0 & DPL_SURE)) srepD = hd;      // LZMA's short repeat: one byte at rep0, known for certain
+                    const uint32_t covered = hd == D ? L : (hd == D3 ? L3 : 0u);                                // the candidate itself covers it
+                    const bool use = hl >= (kk == 0u ? contX0 : 2u) && kk != 8u && covered < hl;
+                    const bool b1 = use && kk < bestK, b2 = use && hl > longL;
+                    bestK = b1 ? kk : bestK; bestL = b1 ? hl : bestL; bestD = b1 ? hd : bestD; bestOpen = b1 ? open : bestOpen;
+                    longK = b2 ? kk : longK; longL = b2 ? hl : longL; longD = b2 ? hd : longD; longOpen = b2 ? open : longOpen;
                 }
+                atomicMin(&myCost[(((uint32_t)i + 1u) & DPL_MMASK) * 64u], ((unsigned long long)(srepD ? cbase + (fSrep << 6) : 0xFFFFFFFFu) << 32) | DPL_LO(srepD, false, DPL_SREP, 1u));
                 if (longK == bestK) longL = 0u;
 #pragma unroll
                 for (uint32_t e = 0; e < 2u; e++) {
@@ -548,7 +553,11 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
 #undef DPL_NONE_LONGER
     // back pointers of the last nodes (n not a multiple of four is covered above; n a multiple of four: nodes n-3 .. n left at g4 = n)
     gc_wave_sync_global();
-    if (winCost != nullptr && !SAMPLE && w0 < blockLen) winCost[(uint64_t)b * (GC_ZSTD_BLOCK_MAX >> 12) + (lane & 31u)] = costN - cost0;     // estimate per 4 KiB range-coder chunk
+    if (winCost != nullptr && !SAMPLE) {                          // estimate per 4 KiB range-coder chunk
+        const uint32_t mine = costN - cost0, other = __shfl_xor(mine, 1);
+        if (!win2k) { if (w0 < blockLen) winCost[(uint64_t)b * (GC_ZSTD_BLOCK_MAX >> 12) + (lane & 31u)] = mine; }
+        else if ((lane & 1u) == 0u && w0 < blockLen) winCost[(uint64_t)b * (GC_ZSTD_BLOCK_MAX >> 12) + (lane >> 1)] = mine + other;
+    }
     // ---- walk back, slot by slot in lockstep: slot q holds the back pointer of node q + 1 and receives the record of position q
     uint32_t j = n;                                               // end node of the edge the walk is inside of (slots s .. j - 1)
     uint32_t s = n, eDist = 0u, eCls = 0u;                        // its start node, distance, class of its FIRST piece so far
@@ -596,7 +605,7 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
         if (n != 0u) atomicAdd(&sCnt[lb][GC_DPS_NLIT], nLitC);
         gc_wave_sync();
         for (uint32_t q = 0; q < BPW; q++) {
-            const uint32_t bb = item * BPW + q;
+            const uint32_t bb = q < BPWr ? item * BPWr + q : nBlocks;
             if (bb >= nBlocks) continue;
             uint32_t* C = dpStat + (uint64_t)bb * GC_DPS_WORDS;
             for (uint32_t i = lane; i < GC_DPS_WORDS; i += 64u) { const uint32_t v = sCnt[q][i]; if (v) atomicAdd(&C[i], v); }
