@@ -56,7 +56,7 @@
 #define DPL_LO(dist, cap, cls, len) (((dist) << (DPL_LENBITS + 4u)) | ((cap) ? 1u << (DPL_LENBITS + 3u) : 0u) | ((cls) << DPL_LENBITS) | ((len) - 1u))
 #define DPL_INF      0xFFFFFFFFFFFFFFFFull
 #define DPL_CONT     4u               // the rest of a capped match: a quarter of a bit (as DP_CONT_PRICE of W7)
-#define DPL_WARM     256              // positions in front of a window that the programme runs over for its state
+#define DPL_WARM     128              // positions in front of a window that the programme runs over for its state
 #define DPL_NC       2u               // requests in flight per group of nodes: the last one for the shadow parse's distances
 #define DPL_TABW     7u               // length prices kept in registers: lengths 0 .. 13, two per word (the static part of a relax loop ends at 12)
 #define DPL_NT       6u               // tracked distances: rep0..rep3 of the newest final node + the last two of the shadow parse
