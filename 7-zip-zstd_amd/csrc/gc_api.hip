@@ -79,6 +79,8 @@ extern "C" __global__ void gc_mf_dp3_kernel(const uint8_t*, uint64_t, uint32_t, 
 extern "C" __global__ void gc_mf_litprice_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, const uint16_t*, uint32_t, uint8_t*);
 extern "C" __global__ void gc_mf_dpl2_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*);
 extern "C" __global__ void gc_mf_dpl2s_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*);
+extern "C" __global__ void gc_mf_dplz_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*);
+extern "C" __global__ void gc_mf_dplzs_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*);
 extern "C" __global__ void gc_mf_dpl3_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*);
 extern "C" __global__ void gc_mf_dpl3s_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*);
 
@@ -113,6 +115,8 @@ struct gc_ctx {
     uint32_t halfList;        // first finder pass over the even positions only, matches extended one byte backwards (zstd levels 3-5)
     uint32_t priceParse;      // W5s + W7: price-based parse on top of the greedy one (gc_lz_price.hip)
     uint32_t priceMinLen, priceLitCtx;        // its shortest match and literal context bits (LZMA: 2, 7; zstd: 3, 0)
+    int lastCodecHint;        // codec of the call being enqueued (0 zstd, 1 flzma2, 2 brotli): which W7L kernels the finder launches
+    uint32_t laneParse;       // the price-based parse is W7L (a lane per window, repeat distances at every node) rather than W7
     uint32_t dbgFrameBlocks, dbgPartFrames;   // test hooks (env GC_FRAME_BLOCKS / GC_PART_FRAMES): small frames / parts so that
                                               // the multi-frame and multi-part paths can be exercised on small inputs
     hipEvent_t ev[8];         // 0 lz start, 1 lz end, 2 huf end, 3 seq start, 4 seq end, 5 plan start, 6 plan end, 7 emit end
@@ -464,7 +468,7 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
         HIPCHK(c, hipMemsetAsync(dps, 0, (size_t)nBlocks * GC_DPS_WORDS * sizeof(uint32_t), st));
         uint32_t phase0 = 0; { uint32_t one = 0; if (gc_env_u32("GC_DP_PHASES", 1u, 2u, &one) && one == 1u) phase0 = 2u; }    // test hook: 1 = W6's prices only
         // W7L (gc_lz_dpl.hip): one lane per window; LZMA with the four repeat distances at every node.  Test hook GC_DPL: 0 = W7 (a wave per window)
-        uint32_t laneDp = c->priceMinLen <= 2u ? 1u : 0u; gc_env_u32("GC_DPL", 0u, 1u, &laneDp);
+        uint32_t laneDp = c->laneParse; gc_env_u32("GC_DPL", 0u, 1u, &laneDp);
         uint8_t* lpr = c->mfLitPrice + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
         if (laneDp) GC_LAUNCH(gc_mf_litprice_kernel, perB * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perB, (const uint16_t*)price, litCtxArg, lpr);
         for (uint32_t phase = phase0; phase != 3u; phase = phase == 0u ? 1u : 3u) {
@@ -479,6 +483,9 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
                 if (c->priceMinLen <= 2u) {
                     if (phase == 0u && !fullA) GC_LAUNCH(gc_mf_dpl2s_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
                     else GC_LAUNCH(gc_mf_dpl2_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
+                } else if (c->lastCodecHint == 0) {
+                    if (phase == 0u && !fullA) GC_LAUNCH(gc_mf_dplzs_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
+                    else GC_LAUNCH(gc_mf_dplz_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
                 } else {
                     if (phase == 0u) GC_LAUNCH(gc_mf_dpl3s_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
                     else GC_LAUNCH(gc_mf_dpl3_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
@@ -589,7 +596,9 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
                                                   // 1.027 -> 0.984 x the reference on text, level 12 1.040 -> 1.001 x
     c->shortPass = level >= 10 ? 1u : 0u;         // the reference's btopt strategies search 3-byte matches (minMatch 3, clevels.h:44-47); from level 10 since round 3, see priceParse
     gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass); gc_env_u32("GC_SHORT_PASS", 0u, 1u, &c->shortPass);   // test hooks
-    c->priceMinLen = 3u; c->priceLitCtx = 0u;     // zstd: matches of >= 3 bytes, literals without context (one Huffman table per block)
+    c->laneParse = level >= 16 ? 1u : 0u;         // the reference's btopt .. btultra2 (clevels.h:44-50) price its three repeat offsets at every position; real sources / binaries at level 19
+                                                  // (emulator, 4 MiB): 1.109 / 1.124 x the reference with W7, 1.081 / 1.075 with W7L.  Levels 10-15 (the reference: lazy2 / btlazy2) keep W7
+    c->lastCodecHint = 0; c->priceMinLen = 3u; c->priceLitCtx = 0u;     // zstd: matches of >= 3 bytes, literals without context (one Huffman table per block)
     c->priceParse = level >= 10 ? 1u : 0u;        // the reference's btopt / btultra strategies start at level 16 (clevels.h:44-47), its levels 10-15 are lazy2 / btlazy2 over deep
                                                   // chains and trees; the greedy / lazy2 parse over this finder's 3-6 candidates was 1.03 x them on lz-7zip (levels 10 and 12, run r03_z12),
                                                   // the price-based parse 0.98 -- so it starts at level 10 here
@@ -773,7 +782,7 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     c->shortPass = level >= 3 ? 1u : 0u;          // ... and holds the nearest match of >= 2 bytes for every position
     gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass); gc_env_u32("GC_SHORT_PASS", 0u, 1u, &c->shortPass);   // test hooks
     if (gc_env_u32("GC_SEARCH_DEPTH", 0u, 64u, &c->searchDepth)) c->searchShallow = c->searchDepth < 2u ? c->searchDepth : 2u;
-    c->priceMinLen = 2u; c->priceLitCtx = 7u;
+    c->laneParse = 1u; c->lastCodecHint = 1; c->priceMinLen = 2u; c->priceLitCtx = 7u;
     c->priceParse = level >= 3 ? 1u : 0u;         // the reference's FL2_opt strategy starts at level 3 of its 7-Zip table (fl2_compress.c:52-63); round 3 (run r03_fl2ab): level 3 with
                                                   // the greedy parse was 1.038 x the reference on silesia-like, with the price-based parse 1.002
     gc_env_u32("GC_PRICE_PARSE", 0u, 1u, &c->priceParse);                                      // test hook: 0 = greedy parse only
@@ -924,7 +933,7 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     if (gc_env_u32("GC_SEARCH_DEPTH", 0u, 64u, &c->searchDepth)) c->searchShallow = c->searchDepth < 2u ? c->searchDepth : 2u;      // test hook
     c->farPass = level >= 5 ? 1u : 0u; c->shortPass = 0;      // longer matches stand in for the context modelling / block splitting B1 lacks
     gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass);                                            // test hook
-    c->priceMinLen = 3u; c->priceLitCtx = 0u;     // copies of >= 3 bytes (a 2-byte copy at a fresh distance never pays in brotli), one literal code per meta-block
+    c->laneParse = 0u; c->lastCodecHint = 2; c->priceMinLen = 3u; c->priceLitCtx = 0u;     // copies of >= 3 bytes (a 2-byte copy at a fresh distance never pays in brotli), one literal code per meta-block
     c->priceParse = level >= 8 ? 1u : 0u;         // the reference parses greedily up to quality 9 (zopfli from 10).  Measured at quality 6
                                                   // (run 28, 64 MiB per corpus): greedy + far pass 0.979-1.002 x the reference at 16.6 GB/s,
                                                   // price-based parse without far pass 0.983-1.012 x at 11.1 GB/s, both 0.93-0.98 x at 9.4 GB/s

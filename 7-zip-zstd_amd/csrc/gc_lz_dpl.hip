@@ -449,7 +449,7 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
             // bytes up to the end of the window -- in the warm-up: up to the window's first node, where the lane of the window in front stops too
             const uint32_t room = !live ? 0u : (i < 0 ? (uint32_t)(-i) : (uint32_t)(N - i));
             // a continuation of one byte is only a match together with the piece in front of it: at the window's first node that piece is the warm-up's guess
-            const uint32_t contX0 = i == 0 ? 2u : 1u;
+            const uint32_t contX0 = i == 0 ? (MINLEN > 2u ? MINLEN : 2u) : 1u;
             const uint32_t cbase = c0 << 6;
             atomicMin(&myCost[(((uint32_t)i + 1u) & DPL_MMASK) * 64u], (unsigned long long)(room != 0u ? cbase + ((flagLit + (lpG & 0xFFu)) << 6) : 0xFFFFFFFFu) << 32);      // literal
             // the rest of a capped match whose length is known
@@ -515,14 +515,14 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
                     // which repeat of the node it is: 0..3; the continuation of a capped piece counts as the cheapest (index 0 - 1)
                     uint32_t kk = hd == r0d ? 1u : (hd == st.r1 ? 2u : (hd == st.r2 ? 3u : (hd == st.r3 ? 4u : 8u)));
                     if (contCapped && hd == contDist) kk = 0u;
-                    if (hl != 0u && kk == 1u && (st.r0 & DPL_SURE)) srepD = hd;      // LZMA's short repeat: one byte at rep0, known for certain
+                    if (MINLEN == 2u && hl != 0u && kk == 1u && (st.r0 & DPL_SURE)) srepD = hd;      // LZMA's short repeat: one byte at rep0, known for certain
                     const uint32_t covered = hd == D ? L : (hd == D3 ? L3 : 0u);                                // the candidate itself covers it
-                    const bool use = hl >= (kk == 0u ? contX0 : 2u) && kk != 8u && covered < hl;
+                    const bool use = hl >= (kk == 0u ? contX0 : MINLEN) && kk != 8u && covered < hl;
                     const bool b1 = use && kk < bestK, b2 = use && hl > longL;
                     bestK = b1 ? kk : bestK; bestL = b1 ? hl : bestL; bestD = b1 ? hd : bestD; bestOpen = b1 ? open : bestOpen;
                     longK = b2 ? kk : longK; longL = b2 ? hl : longL; longD = b2 ? hd : longD; longOpen = b2 ? open : longOpen;
                 }
-                atomicMin(&myCost[(((uint32_t)i + 1u) & DPL_MMASK) * 64u], ((unsigned long long)(srepD ? cbase + (fSrep << 6) : 0xFFFFFFFFu) << 32) | DPL_LO(srepD, false, DPL_SREP, 1u));
+                if (MINLEN == 2u) atomicMin(&myCost[(((uint32_t)i + 1u) & DPL_MMASK) * 64u], ((unsigned long long)(srepD ? cbase + (fSrep << 6) : 0xFFFFFFFFu) << 32) | DPL_LO(srepD, false, DPL_SREP, 1u));
                 if (longK == bestK) longL = 0u;
 #pragma unroll
                 for (uint32_t e = 0; e < 2u; e++) {
@@ -531,7 +531,7 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
                     const uint32_t ri = (kk - 1u) & 3u;                            // repeat index
                     const uint32_t cls = isCont ? DPL_CONTC : DPL_REP0 + ri, add = isCont ? DPL_CONT : (ri == 0u ? fRep0 : (ri == 1u ? fRep1 : (ri == 2u ? fRep2 : fRep3)));
                     const uint32_t hb = cbase + (add << 6);
-                    relax(i, hl, isCont ? contX0 : 2u, hb, DPL_LO(hd, false, cls, 1u), hl, 0u, DPL_LO(hd, open, cls, hl ? hl : 1u), repR, GC_PRICE_REPLEN, isCont, 4u);
+                    relax(i, hl, isCont ? contX0 : MINLEN, hb, DPL_LO(hd, false, cls, 1u), hl, 0u, DPL_LO(hd, open, cls, hl ? hl : 1u), repR, GC_PRICE_REPLEN, isCont, 4u);
                 }
             }
         }
@@ -635,7 +635,9 @@ name(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32
 
 DPL_KERNEL(gc_mf_dpl2_kernel,  true, 2u, false)   // LZMA: every window
 DPL_KERNEL(gc_mf_dpl2s_kernel, true, 2u, true)    // LZMA: the sample of phase A
-DPL_KERNEL(gc_mf_dpl3_kernel,  false, 3u, false)  // zstd, brotli
+DPL_KERNEL(gc_mf_dplz_kernel,  true, 3u, false)   // zstd: its three repeat offsets are the first three of the four kept here (ZSTD_updateRep, zstd_compress_internal.h:818: the same move-to-front); no match below three bytes, no short repeat
+DPL_KERNEL(gc_mf_dplzs_kernel, true, 3u, true)
+DPL_KERNEL(gc_mf_dpl3_kernel,  false, 3u, false)  // brotli (no repeat distances in the programme yet)
 DPL_KERNEL(gc_mf_dpl3s_kernel, false, 3u, true)
 
 // The literal price of every position under its block's table (W6's statistics: literal given the top bits of the byte in front of it), one byte each

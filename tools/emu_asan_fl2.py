@@ -1,4 +1,4 @@
-"""CPU: the FLZMA2 encoder kernels (incl. the lane-per-window price parse) under the SIMT emulator built with AddressSanitizer (make -C tests/emu asan): every
+"""CPU: the FLZMA2 encoder kernels and the zstd ones of level 19 (both with the lane-per-window price parse) under the SIMT emulator built with AddressSanitizer (make -C tests/emu asan): every
 access to the input, the workspaces and the LDS arrays is checked; the streams must decode.
 usage: ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0 LD_PRELOAD=$(gcc -print-file-name=libasan.so) python tools/emu_asan_fl2.py [seed] [seconds]"""
 import sys, time, os
@@ -22,5 +22,7 @@ while time.time() - t0 < secs:
     for level in (5, 3):
         e = pkg.Flzma2Encoder(level=level, lib_path=lib); c = e.code(x); prop = e.coder_props()[0]; e.close()
         assert np.array_equal(O.ref_lzma2_decode(c, x.size, prop), x), ("decode", n, level)
+    e = pkg.ZstdEncoder(level=19, lib_path=lib); c = e.code(x); e.close()
+    assert np.array_equal(O.ref_zstd_decompress(c, x.size), x), ("zstd decode", n)
     it += 1
 print("iterations", it)
