@@ -20,6 +20,10 @@
 #include <stdlib.h>
 #include <string.h>
 #include <new>
+#ifdef GC_TEST_HOOKS
+#include <vector>
+#include <unistd.h>
+#endif
 
 struct GcFramePlan { uint64_t off; uint32_t size; uint32_t compressed; };
 
@@ -85,12 +89,12 @@ extern "C" __global__ void gc_mf_dpl3_kernel(const uint8_t*, uint64_t, uint32_t,
 extern "C" __global__ void gc_mf_dpl3s_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*);
 
 extern "C" __global__ void gc_lzma2_prep_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t, uint64_t*, uint32_t*);
-extern "C" __global__ void gc_lzma2_model_kernel(const uint8_t*, uint64_t, const uint64_t*, const uint32_t*, uint32_t, uint32_t, uint16_t*, GcLzmaChunkInfo*, const uint32_t*, unsigned long long*, uint32_t, uint32_t, uint32_t);
+extern "C" __global__ void gc_lzma2_model_kernel(const uint8_t*, uint64_t, const uint64_t*, const uint32_t*, uint32_t, uint32_t, uint16_t*, GcLzmaChunkInfo*, const uint32_t*, unsigned long long*, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t);
 extern "C" __global__ void gc_lzma2_rc_kernel(uint16_t*, uint32_t, uint32_t, uint8_t*, GcLzmaChunkInfo*);
 extern "C" __global__ void gc_lzma2_rc_fin_kernel(const uint16_t*, uint32_t, uint32_t, uint8_t*, GcLzmaChunkInfo*);
 extern "C" __global__ void gc_lzma2_plan_kernel(const GcLzmaChunkInfo*, uint32_t, uint32_t, uint64_t, uint32_t, GcLzmaPlan*, uint64_t*);
 extern "C" __global__ void gc_lzma2_emit_kernel(const uint8_t*, uint32_t, const uint8_t*, const GcLzmaChunkInfo*, const GcLzmaPlan*, uint32_t,
-                                                uint32_t, const uint64_t*, uint8_t*);
+                                                uint32_t, const uint64_t*, uint8_t*, const uint8_t*);
 
 extern "C" __global__ void gc_brotli_block_kernel(const uint8_t*, uint64_t, const GcSeqRaw*, const uint8_t*, const GcBlockMeta*, uint64_t*, uint32_t*,
                                                   uint32_t, uint32_t, uint32_t*, GcBrotliBlockInfo*);
@@ -126,6 +130,7 @@ struct gc_ctx {
     GcSeqRaw* seqRaw; uint8_t* lit; GcBlockMeta* meta;
     uint64_t* seqPacked; uint32_t* seqOff; uint8_t* codes; uint16_t* stOut; GcSeqHist* seqHist; GcSeqTabG* seqTabs;
     uint8_t* litSec; uint8_t* seqSec; GcSectionInfo* info; GcFramePlan* plan; uint64_t* result;
+    uint8_t* lzProps;         // FLZMA2: props byte per model segment (lc / lp chosen by L2), 128 KiB >> GC_LZMA_SEG_LOG_MIN of them per block
     uint32_t* lzNM; GcLzmaChunkInfo* lzInfo; GcLzmaPlan* lzPlan; uint16_t* lzStream; size_t lzStreamCap;       // FLZMA2 path
     uint64_t* lzM; size_t lzMCap; uint8_t* lzRcOut; size_t lzRcOutCap;     // item lists, range-coder staging (allocated on the first FLZMA2 call)
     uint8_t* brStage; GcBrotliBlockInfo* brInfo; GcBrotliPlan* brPlan;    // BROTLI path
@@ -230,7 +235,7 @@ static void free_workspace(gc_ctx* c)
     hipFree(c->seqRaw); hipFree(c->lit); hipFree(c->meta); hipFree(c->seqPacked); hipFree(c->seqOff); hipFree(c->codes);
     hipFree(c->stOut); hipFree(c->seqHist); hipFree(c->seqTabs); hipFree(c->litSec); hipFree(c->seqSec); hipFree(c->info); hipFree(c->plan);
     hipFree(c->brStage); hipFree(c->brInfo); hipFree(c->brPlan); c->brStage = nullptr; c->brInfo = nullptr; c->brPlan = nullptr;
-    hipFree(c->lzNM); hipFree(c->lzInfo); hipFree(c->lzPlan); hipFree(c->lzStream); c->lzStream = nullptr; c->lzStreamCap = 0; c->lzNM = nullptr; c->lzInfo = nullptr; c->lzPlan = nullptr;
+    hipFree(c->lzProps); c->lzProps = nullptr; hipFree(c->lzNM); hipFree(c->lzInfo); hipFree(c->lzPlan); hipFree(c->lzStream); c->lzStream = nullptr; c->lzStreamCap = 0; c->lzNM = nullptr; c->lzInfo = nullptr; c->lzPlan = nullptr;
     hipFree(c->lzM); c->lzM = nullptr; c->lzMCap = 0; hipFree(c->lzRcOut); c->lzRcOut = nullptr; c->lzRcOutCap = 0;
     c->seqRaw = nullptr; c->lit = nullptr; c->meta = nullptr; c->seqPacked = nullptr; c->seqOff = nullptr; c->codes = nullptr;
     c->stOut = nullptr; c->seqHist = nullptr; c->seqTabs = nullptr; c->litSec = nullptr; c->seqSec = nullptr; c->info = nullptr; c->plan = nullptr; c->capBlocks = 0;
@@ -296,6 +301,7 @@ static int ensure_workspace(gc_ctx* c, uint32_t nBlocks)
         hipMalloc((void**)&c->brStage, nb * GC_BR_STAGE_STRIDE) != hipSuccess ||
         hipMalloc((void**)&c->brInfo, nb * sizeof(GcBrotliBlockInfo)) != hipSuccess ||
         hipMalloc((void**)&c->brPlan, nb * sizeof(GcBrotliPlan)) != hipSuccess ||
+        hipMalloc((void**)&c->lzProps, nb * (GC_ZSTD_BLOCK_MAX >> GC_LZMA_SEG_LOG_MIN)) != hipSuccess ||
         hipMalloc((void**)&c->lzNM, nb * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void**)&c->lzInfo, nb * GC_LZMA_RC_PER_BLOCK * sizeof(GcLzmaChunkInfo)) != hipSuccess ||
         hipMalloc((void**)&c->lzPlan, nb * GC_LZMA_RC_PER_BLOCK * sizeof(GcLzmaPlan)) != hipSuccess) {
@@ -320,6 +326,8 @@ static int mf_grow(gc_ctx* c, void** p, size_t* cap, size_t needBytes, const cha
         if (hipMalloc(&np, needBytes) != hipSuccess) { snprintf(c->err, sizeof(c->err), "workspace (%s) of %zu bytes failed", what, needBytes); return GC_ERR_NOMEM; }
     }
     hipFree(*p); *p = np; *cap = needBytes;
+    { uint32_t poison = 0; if (gc_env_u32("GC_POISON_WORKSPACE", 0u, 255u, &poison) && hipMemsetAsync(np, (int)poison, needBytes, c->stream) != hipSuccess) return GC_ERR_HIP; }   // test hook: the
+                                                                   // finder's workspace starts filled with this byte -- what a recycled allocation holds is not zeros
     return GC_OK;
 }
 
@@ -678,6 +686,26 @@ extern "C" int gc_zstd_finish(gc_ctx* c, size_t* compressedSize)
     { uint32_t trip = 0; gc_env_u32("GC_WATCHDOG_TRIP", 0u, 1u, &trip);       // test hook: as if a wait had run out
       for (uint32_t p = 0; p < GC_MAX_PARTS; p++) trip |= words[p * 16u + 7u];
       if (trip) { snprintf(c->err, sizeof(c->err), "a kernel gave up waiting for another workgroup (watchdog): the output of this call is not valid"); return GC_ERR_HIP; } }
+#ifdef GC_TEST_HOOKS
+    if (const char* dir = getenv("GC_DUMP_STATE")) {               // test hook: the parse's intermediate state of this call, for comparing two runs offline
+        static int serial = 0;
+        char path[512]; snprintf(path, sizeof(path), "%s/state_%d_%d.bin", dir, (int)getpid(), serial++);
+        if (FILE* f = fopen(path, "wb")) {
+            const uint32_t nb = c->capBlocks;
+            struct { const char* name; const void* p; size_t bytes; } parts[] = {
+                { "wincost", c->mfWinCost, c->mfWinCost ? (size_t)nb * 128u : 0u }, { "dpstat", c->mfDpStat, c->mfDpStat ? (size_t)nb * GC_DPS_WORDS * 4u : 0u },
+                { "price", c->mfPrice, c->mfPrice ? (size_t)nb * GC_PRICE_WORDS * 2u : 0u }, { "lzinfo", c->lzInfo, c->lzInfo ? (size_t)nb * GC_LZMA_RC_PER_BLOCK * sizeof(GcLzmaChunkInfo) : 0u },
+                { "lznm", c->lzNM, c->lzNM ? (size_t)nb * 4u : 0u } };
+            for (auto& q : parts) {
+                std::vector<uint8_t> h(q.bytes);
+                if (q.bytes && hipMemcpy(h.data(), q.p, q.bytes, hipMemcpyDeviceToHost) != hipSuccess) h.assign(q.bytes, 0xEE);
+                char hdr[32] = { 0 }; snprintf(hdr, sizeof(hdr), "%s", q.name); fwrite(hdr, 1, 16, f);
+                const uint64_t nbytes = q.bytes; fwrite(&nbytes, 8, 1, f); fwrite(h.data(), 1, q.bytes, f);
+            }
+            fclose(f);
+        }
+    }
+#endif
     if (c->hostResult[1]) { snprintf(c->err, sizeof(c->err), "destination too small: need %llu bytes", (unsigned long long)c->hostResult[0]); return GC_ERR_DST_SMALL; }
     if (compressedSize) *compressedSize = (size_t)c->hostResult[0];
     return GC_OK;
@@ -803,6 +831,8 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     gc_env_u32("GC_RC_MERGE_WORDS", 0u, GC_LZMA_RC_MERGE_WORDS, &mergeWords);                  // test hook: 0 = one LZMA2 chunk per rc chunk
     uint32_t rep4 = 1;                                                                         // rep2 / rep3 coding in L2 (gc_lzma2_enc.hip LzLru); test hook: 0 = rep0 / rep1 only
     gc_env_u32("GC_L2_REP4", 0u, 1u, &rep4);
+    uint32_t litSel = 1;                                                                       // lc / lp per model segment (gc_lzma2_model_kernel); test hook: 0 = the reference's lc 3 / lp 0 everywhere
+    gc_env_u32("GC_L2_LITSEL", 0u, 1u, &litSel);
     uint32_t wordCap = GC_LZMA_STREAM_WORDS(segLog);                                           // words a segment may produce before it is stored instead
     gc_env_u32("GC_SEG_WORD_CAP", 1u, GC_LZMA_STREAM_WORDS(segLog), &wordCap);                  // test hook: a low cap sends ordinary segments down that path
     if (c->profOn) { HIPCHK(c, hipMemsetAsync(c->prof, 0, (GC_LZ_PHASES + GC_SEQ_PHASES) * sizeof(unsigned long long), c->stream)); c->profBlocks = 1u; }   // L2 phase sums (raw)
@@ -830,7 +860,7 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
                   (const uint32_t*)(c->lzNM + blk0), segLog, (uint32_t)(off != 0u ? 1u : 0u),
                   c->lzStream + (size_t)blk0 * segPerBlock * GC_LZMA_STREAM_WORDS(segLog), c->lzInfo + (size_t)blk0 * GC_LZMA_RC_PER_BLOCK,
                   (const uint32_t*)((c->priceParse && frameBlocks > 1u) ? c->mfWinCost + (size_t)blk0 * 32u : nullptr),
-                  c->profOn ? c->prof : nullptr, mergeWords, wordCap, rep4);
+                  c->profOn ? c->prof : nullptr, mergeWords, wordCap, rep4, c->lzProps + (size_t)blk0 * segPerBlock, litSel);
         HIPCHK(c, hipEventRecord(ev[4], c->stream2));
         // stage 3 (stream3): range coder
         HIPCHK(c, hipStreamWaitEvent(c->stream3, ev[4], 0));
@@ -850,7 +880,7 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     GC_LAUNCH(gc_lzma2_plan_kernel, 1, 1024, c->stream, (const GcLzmaChunkInfo*)c->lzInfo, nRc, segLog, (uint64_t)dstCap, (uint32_t)flags, c->lzPlan, c->result);
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
     GC_LAUNCH(gc_lzma2_emit_kernel, nRc + 1u, 256, c->stream, src, segLog, (const uint8_t*)c->lzRcOut, (const GcLzmaChunkInfo*)c->lzInfo,
-              (const GcLzmaPlan*)c->lzPlan, nRc, (uint32_t)flags, (const uint64_t*)c->result, (uint8_t*)d_dst);
+              (const GcLzmaPlan*)c->lzPlan, nRc, (uint32_t)flags, (const uint64_t*)c->result, (uint8_t*)d_dst, (const uint8_t*)c->lzProps);
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     HIPCHK(c, hipGetLastError());
     c->pending = true; c->timed = true; c->lastCodec = 1;

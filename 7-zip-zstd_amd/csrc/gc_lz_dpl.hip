@@ -553,10 +553,13 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
 #undef DPL_NONE_LONGER
     // back pointers of the last nodes (n not a multiple of four is covered above; n a multiple of four: nodes n-3 .. n left at g4 = n)
     gc_wave_sync_global();
-    if (winCost != nullptr && !SAMPLE) {                          // estimate per 4 KiB range-coder chunk
+    {                                                             // estimate per 4 KiB range-coder chunk (2 KiB windows: the sum of two lanes).
+        // Straight-line on purpose: as `if (!win2k) store A else store B` behind the shuffle, hipcc 7.2 emitted the two stores under each other's condition
+        // (seen in the ISA and in the output: half of the entries written, with the sum of two windows) -- L2 then stored segments by whatever the rest held
         const uint32_t mine = costN - cost0, other = __shfl_xor(mine, 1);
-        if (!win2k) { if (w0 < blockLen) winCost[(uint64_t)b * (GC_ZSTD_BLOCK_MAX >> 12) + (lane & 31u)] = mine; }
-        else if ((lane & 1u) == 0u && w0 < blockLen) winCost[(uint64_t)b * (GC_ZSTD_BLOCK_MAX >> 12) + (lane >> 1)] = mine + other;
+        const uint32_t idx = win2k ? lane >> 1 : lane & 31u, val = win2k ? mine + other : mine;
+        const bool wr = winCost != nullptr && !SAMPLE && w0 < blockLen && (!win2k || (lane & 1u) == 0u);
+        if (wr) winCost[(uint64_t)b * (GC_ZSTD_BLOCK_MAX >> 12) + idx] = val;
     }
     // ---- walk back, slot by slot in lockstep: slot q holds the back pointer of node q + 1 and receives the record of position q
     uint32_t j = n;                                               // end node of the edge the walk is inside of (slots s .. j - 1)

@@ -29,6 +29,8 @@
 #include "gc_common.h"
 #include "gc_device.h"
 #include "gc_lzma2.h"
+#include "gc_mf.h"
+#include "gc_lz_parse.h"      // pz_price
 #ifdef HIPEMU
 #include <stdio.h>
 #include <stdlib.h>
@@ -228,10 +230,10 @@ __device__ __forceinline__ void lz_gen_match(LzEv& o, uint32_t kind, uint32_t le
 }
 
 // one literal: isMatch=0 + 8 tree bits (plain, or "matched" after a match: LzmaDec.c MATCHED_LITER_DEC)
-__device__ __forceinline__ void lz_gen_literal(LzEv& o, uint32_t cur, uint32_t prev, uint32_t matchByte, uint32_t state, uint32_t posState)
+__device__ __forceinline__ void lz_gen_literal(LzEv& o, uint32_t cur, uint32_t prev, uint32_t matchByte, uint32_t state, uint32_t posState, uint32_t lc, uint32_t lpMask)
 {
     ev_put(o, LZP_ISMATCH + state * 4u + posState, 0);
-    const uint32_t pb = LZP_LITERAL + 0x300u * (prev >> (8u - GC_LZMA_LC));
+    const uint32_t pb = LZP_LITERAL + 0x300u * (((posState & lpMask) << lc) + (prev >> (8u - lc)));      // LzmaDec.c: ((processedPos & lpMask) << lc) + (prevByte >> (8 - lc)); lc + lp <= 3 here
     if (state < 7u) {
         uint32_t m = 1;
         for (int i = 7; i >= 0; i--) { const uint32_t bit = (cur >> i) & 1u; ev_put(o, pb + m, bit); m = (m << 1) | bit; }
@@ -257,7 +259,7 @@ __device__ __forceinline__ LzItem lz_item(const uint64_t* M, uint32_t idx)
 // distance (matched literal), S = block base (S[-1] exists iff blockBase > 0).  The literal bytes (<= GC_LZMA_LIT_CUT of them,
 // plus the byte in front) are fetched with three 8-byte loads up front instead of one dependent byte load per literal.
 __device__ __forceinline__ void lz_gen_item(LzEv& o, const uint8_t* S, uint64_t blockBase, uint64_t srcSize, uint32_t hasPrev, uint32_t lp, const LzItem& it,
-                                            uint32_t st0, uint32_t rep0, uint32_t kind)
+                                            uint32_t st0, uint32_t rep0, uint32_t kind, uint32_t lc, uint32_t lpMask)
 {
     uint32_t st = st0;
     const uint32_t ll = it.pos - lp;
@@ -272,7 +274,7 @@ __device__ __forceinline__ void lz_gen_item(LzEv& o, const uint8_t* S, uint64_t 
             uint32_t cur;
             if (fast) { const uint32_t j = i + 1u; const uint64_t x = j < 8u ? x0 : (j < 16u ? x1 : x2); cur = (uint32_t)(x >> ((j & 7u) * 8u)) & 0xFFu; }
             else cur = S[lp + i];
-            lz_gen_literal(o, cur, prev, i == 0u ? mb0 : 0u, st, (lp + i) & 3u);
+            lz_gen_literal(o, cur, prev, i == 0u ? mb0 : 0u, st, (lp + i) & 3u, lc, lpMask);
             st = st < 4u ? 0u : (st < 10u ? st - 3u : st - 6u);
             prev = cur;
         }
@@ -327,9 +329,11 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
                          is 1 % of a well-compressed 4 KiB; the bound keeps the longest range-coder chain what it is for 4 KiB of
                          incompressible data */,
                       uint32_t wordCap /* words the segment may produce (its reserved place, GC_LZMA_STREAM_WORDS); beyond that it is stored */,
-                      uint32_t rep4 /* 1: matches whose distance is rep2 / rep3 of the decoder are coded as such (LzLru above); 0: rep0 / rep1 only */)
+                      uint32_t rep4 /* 1: matches whose distance is rep2 / rep3 of the decoder are coded as such (LzLru above); 0: rep0 / rep1 only */,
+                      uint8_t* __restrict__ segProps /* out, per segment: the LZMA props byte its first chunk carries (lc / lp chosen per segment) */,
+                      uint32_t litSel /* 1: choose the literal context bits per segment; 0: the reference's lc = 3, lp = 0 */)
 {
-    __shared__ uint16_t P[LZP_TOTAL];
+    __shared__ __attribute__((aligned(16))) uint16_t P[LZP_TOTAL];
     __shared__ uint32_t sTick[LZ2_TICKS / 4u];                    // ticket bytes (see LZ2_TICKS)
     __shared__ uint16_t sEv[LZ2_EVCAP];
     __shared__ uint32_t sWordEnd[GC_LZMA_RC_PER_BLOCK];
@@ -354,6 +358,7 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
         const uint32_t segLen = (ss + segSize < blockLen ? ss + segSize : blockLen) - ss;
         hopeless = est >= segLen * 128u;                          // 8 bits per byte in 1/16 bit units
     }
+    if (lane == 0u) segProps[seg] = (uint8_t)GC_LZMA_PROPS;
     if (ss >= blockLen || nItems == 0xFFFFFFFFu || hopeless) {
         // no such segment -- or the item list overflowed (cannot happen for lists built by L1; kept as a guard): store it
         for (uint32_t c = lane; c < rcPerSeg; c += 64u) {
@@ -367,6 +372,55 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
     const uint8_t* S = src + blockBase;                   // block-relative addressing; S[-1] exists iff blockBase > 0
     const uint64_t* M = Mall + (uint64_t)b * GC_LZMA_MAX_ITEMS;
 
+    // ---- literal context bits of this segment.  Every model segment starts with a state reset and carries a props byte (gc_lzma2_frame.hip), so lc / lp
+    // are free per segment.  The reference codes everything with lc 3 / lp 0 (fl2_compress.c:116-138); machine code and tables of 2- / 4-byte fields code their
+    // literals better by POSITION (liblzma on ROCm shared objects: lc 0 / lp 2 -2.1 %, lc 2 / lp 1 -1.8 %; text +0.3-0.5 %).  Chosen by the order-0 cost of a
+    // quarter of the segment's bytes under each of three context functions (all with <= 8 contexts: the literal coder keeps its size), the reference's unless
+    // another is 1/64 cheaper.  Counters: two per 32-bit word in the (not yet initialised) probability array.
+    uint32_t litLc = GC_LZMA_LC, litLpMask = 0u;
+    if (litSel && se - ss >= 4096u) {
+        uint32_t* W = (uint32_t*)P;
+        constexpr uint32_t NCELL = 2048u + 2048u + 1024u;
+        for (uint32_t i = lane; i < NCELL / 2u; i += 64u) W[i] = 0u;
+        gc_wave_sync();
+        const uint32_t nGroups = (se - ss) >> 6;                  // one 16-byte piece out of every 64 bytes: <= 32 Ki samples, counters stay below 2^16
+        for (uint32_t g = lane; g < nGroups; g += 64u) {
+            const uint32_t o = ss + (g << 6);
+            uint8_t by[16]; __builtin_memcpy(by, S + o, 16);
+            uint32_t prev = (blockBase + o + hasPrev) != 0u ? S[(int64_t)o - 1] : 0u;
+#pragma unroll
+            for (uint32_t j = 0; j < 16u; j++) {
+                const uint32_t cur = by[j];
+                const uint32_t cA = ((prev >> 5) << 8) + cur, cB = 2048u + (((((j & 1u) << 2) + (prev >> 6))) << 8) + cur, cC = 4096u + ((j & 3u) << 8) + cur;
+                atomicAdd(&W[cA >> 1], 1u << ((cA & 1u) << 4)); atomicAdd(&W[cB >> 1], 1u << ((cB & 1u) << 4)); atomicAdd(&W[cC >> 1], 1u << ((cC & 1u) << 4));
+                prev = cur;
+            }
+        }
+        gc_wave_sync();
+        uint32_t cost[3] = { 0u, 0u, 0u };
+        for (uint32_t ctx = 0; ctx < 20u; ctx++) {                // 8 + 8 + 4 contexts of 256 cells
+            uint32_t n[4], tot = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 4u; q++) { const uint32_t cell = (ctx << 8) + (q << 6) + lane; n[q] = (W[cell >> 1] >> ((cell & 1u) << 4)) & 0xFFFFu; tot += n[q]; }
+            tot = gc_wave_sum(tot);
+            uint32_t part = 0;
+#pragma unroll
+            for (uint32_t q = 0; q < 4u; q++) if (n[q]) part += n[q] * pz_price(4u * n[q] + 1u, 4u * tot + 256u);
+            part = gc_wave_sum(part);
+            cost[ctx < 8u ? 0u : (ctx < 16u ? 1u : 2u)] += part >> 4;
+        }
+        uint32_t best = 0u;
+        if ((unsigned long long)cost[1] * 64u < (unsigned long long)cost[0] * 63u) best = 1u;
+        if ((unsigned long long)cost[2] * 64u < (unsigned long long)cost[0] * 63u && cost[2] < cost[best]) best = 2u;
+        best = gc_uniform(best);
+#ifdef HIPEMU
+        { static const int xf = getenv("GC_X_LITFORCE") ? atoi(getenv("GC_X_LITFORCE")) : -1; if (xf >= 0) best = (uint32_t)xf;
+          if (getenv("GC_X_LITSHOW") && lane == 0u) fprintf(stderr, "seg %u cost %u %u %u best %u\n", seg, cost[0], cost[1], cost[2], best); }
+#endif
+        if (best == 1u) { litLc = 2u; litLpMask = 1u; } else if (best == 2u) { litLc = 0u; litLpMask = 3u; }
+        if (lane == 0u) segProps[seg] = (uint8_t)((GC_LZMA_PB * 5u + (best == 1u ? 1u : (best == 2u ? 2u : 0u))) * 9u + litLc);
+        gc_wave_sync();
+    }
     for (uint32_t i = lane; i < LZP_TOTAL; i += 64u) P[i] = 1024u;
     for (uint32_t i = lane; i < LZ2_TICKS / 4u; i += 64u) sTick[i] = 0;
     if (lane < GC_LZMA_RC_PER_BLOCK) sWordEnd[lane] = 0;
@@ -495,7 +549,7 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
 #endif
             if (lane >= done && lane < upto) {
                 LzEv o; o.p = sEv + (evIncl - nEv - evDone); o.n = 0; o.store = true;
-                lz_gen_item(o, S, blockBase, srcSize, hasPrev, prevEnd, it, st0, pOff, kind);
+                lz_gen_item(o, S, blockBase, srcSize, hasPrev, prevEnd, it, st0, pOff, kind, litLc, litLpMask);
             }
             gc_wave_sync();
             L2_PHASE(pc1);

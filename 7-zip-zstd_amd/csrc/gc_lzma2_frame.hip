@@ -67,7 +67,7 @@ gc_lzma2_plan_kernel(const GcLzmaChunkInfo* __restrict__ cinfo, uint32_t nRc, ui
 extern "C" __global__ void __launch_bounds__(256)
 gc_lzma2_emit_kernel(const uint8_t* __restrict__ src, uint32_t segLog, const uint8_t* __restrict__ rcOut,
                      const GcLzmaChunkInfo* __restrict__ cinfo, const GcLzmaPlan* __restrict__ plan, uint32_t nRc,
-                     uint32_t flags, const uint64_t* __restrict__ result, uint8_t* __restrict__ dst)
+                     uint32_t flags, const uint64_t* __restrict__ result, uint8_t* __restrict__ dst, const uint8_t* __restrict__ segProps /* L2: props byte per model segment */)
 {
     if (result[1]) return;
     const uint32_t t = threadIdx.x, c = blockIdx.x;
@@ -85,7 +85,7 @@ gc_lzma2_emit_kernel(const uint8_t* __restrict__ src, uint32_t segLog, const uin
             const uint32_t c1 = ci.csize - 1u;
             o[0] = (uint8_t)(0x80u | ((segFirst ? (c == 0u ? 3u : 2u) : 0u) << 5) | (u1 >> 16));
             o[1] = (uint8_t)(u1 >> 8); o[2] = (uint8_t)u1; o[3] = (uint8_t)(c1 >> 8); o[4] = (uint8_t)c1;
-            if (segFirst) o[5] = (uint8_t)GC_LZMA_PROPS;
+            if (segFirst) o[5] = segProps[c / rcPerSeg];
         }
         const uint8_t* s = rcOut + (uint64_t)c * GC_LZMA_RC_STRIDE;
         for (uint32_t i = t; i < ci.csize; i += 256u) o[hdr + i] = s[i];

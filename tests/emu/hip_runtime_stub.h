@@ -19,7 +19,9 @@ struct hipDeviceProp_t { char gcnArchName[64]; int multiProcessorCount; };
 static inline hipError_t hipGetDeviceCount(int* n) { const char* e = getenv("HIPEMU_DEVICES"); const int v = e ? atoi(e) : 1; *n = v >= 1 && v <= 64 ? v : 1; return 0; }
 static inline hipError_t hipSetDevice(int) { return 0; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { strcpy(p->gcnArchName, "gfx950:emu"); p->multiProcessorCount = 256; return 0; }
-static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
+// GC_EMU_POISON=<byte>: every device allocation starts filled with that byte (a negative value: with random bytes of that seed) (what a recycled allocation of a long-lived process looks like on the device;
+// malloc's fresh pages are zero, which hides reads of words no kernel has written)
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); if (*p) { const char* e = getenv("GC_EMU_POISON"); if (e) { const int v = atoi(e); if (v >= 0) memset(*p, v, n ? n : 1); else { unsigned long long x = 0x9E3779B97F4A7C15ull * (unsigned long long)(-v); unsigned char* q = (unsigned char*)*p; for (size_t i = 0; i < n; i++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; q[i] = (unsigned char)(x >> 32); } } } } return *p ? 0 : 2; }
 static inline hipError_t hipFree(void* p) { free(p); return 0; }
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
 static inline hipError_t hipHostFree(void* p) { free(p); return 0; }

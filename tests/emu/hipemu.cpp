@@ -8,6 +8,9 @@
 #include <atomic>
 #include <mutex>
 
+extern "C" unsigned char __start_hipemu_lds[], __stop_hipemu_lds[];      // the section of all `__shared__` variables of the library (hipemu.h)
+static unsigned char hipemu_lds_anchor __attribute__((section("hipemu_lds"), used)) = 0;      // (the section exists even in a library without kernels)
+
 namespace hipemu {
 
 thread_local Fiber* cur = nullptr;
@@ -146,7 +149,12 @@ void launch(dim3 grid, dim3 block, kernel_thunk_t thunk, void* args, int)
     std::lock_guard<std::mutex> guard(launchMutex);
     unsigned nblocks = grid.x * grid.y * grid.z;
     static Pool pool;
-    for (unsigned i = 0; i < nblocks; i++) run_block(grid, block, i, thunk, args, pool);
+    static const char* poison = getenv("GC_EMU_POISON_LDS");
+    static unsigned long long px = poison ? 0x9E3779B97F4A7C15ull * (unsigned long long)(atoi(poison) + 1) : 0ull;
+    for (unsigned i = 0; i < nblocks; i++) {
+        if (poison) for (unsigned char* q = __start_hipemu_lds; q < __stop_hipemu_lds; q++) { px ^= px << 13; px ^= px >> 7; px ^= px << 17; *q = (unsigned char)(px >> 32); }
+        run_block(grid, block, i, thunk, args, pool);
+    }
 }
 
 }  // namespace hipemu

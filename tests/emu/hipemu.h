@@ -27,7 +27,9 @@
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
-#define __shared__ static
+// `__shared__`: a static in a section of its own, so that the launcher can fill ALL of it with garbage before every workgroup (GC_EMU_POISON_LDS=<seed>): on the
+// device a workgroup's LDS holds whatever the workgroups before it left there, a plain static would hold the previous workgroup's values of the SAME variable
+#define __shared__ static __attribute__((section("hipemu_lds")))
 #define __restrict__ __restrict
 #define __constant__ static const
 

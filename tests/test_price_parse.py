@@ -40,6 +40,21 @@ def _code(O, pkg, codec, level, x, monkeypatch, price, **kw):
     return c
 
 
+def _stored_chunks(c):
+    """(LZMA chunks, stored chunks, 4 KiB index of the first stored ones) of an LZMA2 stream: what a failure message should say"""
+    p = 0; raw = []; nl = 0; pos = 0
+    while p < len(c):
+        ctl = int(c[p])
+        if ctl == 0:
+            break
+        if ctl < 0x80:
+            u = (int(c[p + 1]) << 8 | int(c[p + 2])) + 1; raw.append(pos >> 12); p += 3 + u
+        else:
+            u = ((ctl & 31) << 16 | int(c[p + 1]) << 8 | int(c[p + 2])) + 1; p += 5 + (int(c[p + 3]) << 8 | int(c[p + 4])) + 1 + (1 if ctl >= 0xC0 else 0); nl += 1
+        pos += u
+    return nl, len(raw), raw[:40]
+
+
 CASES = [("flzma2", 5), ("zstd", 19), ("brotli", 9)]
 
 
@@ -115,7 +130,21 @@ def test_gpu_price_parse_beats_greedy_at_size(O, pkg, gpu_ok, gpu_hooks_kw, monk
     x = O.corpus(kind, n)
     greedy = _code(O, pkg, codec, level, x, monkeypatch, 0, **gpu_hooks_kw)
     priced = _code(O, pkg, codec, level, x, monkeypatch, None, **gpu_hooks_kw)
-    assert len(priced) < 0.995 * len(greedy), (len(priced), len(greedy))
+    assert len(priced) < 0.995 * len(greedy), (len(priced), len(greedy), _stored_chunks(priced) if codec == "flzma2" else None)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("codec,level", [("flzma2", 5), ("flzma2", 3), ("zstd", 19), ("brotli", 9)])
+def test_gpu_output_does_not_depend_on_what_the_workspace_held(O, pkg, gpu_ok, gpu_hooks_kw, monkeypatch, codec, level):
+    """Round 4: the window costs W7L hands to L2 were half written (a miscompiled if / else behind a shuffle: the ISA stored under the other branch's condition), so
+    L2 stored segments by what the allocation happened to hold -- zeros in a fresh process, the previous tests' data in a long one (+8 .. +60 % size, streams still
+    valid).  The hook fills the finder's workspace with a byte before its first use; the stream must not change."""
+    x = O.corpus("silesia-like", 8 << 20)
+    plain = _code(O, pkg, codec, level, x, monkeypatch, None, **gpu_hooks_kw)
+    for fill in (0xFF, 0x5A):
+        monkeypatch.setenv("GC_POISON_WORKSPACE", str(fill))
+        assert np.array_equal(_code(O, pkg, codec, level, x, monkeypatch, None, **gpu_hooks_kw), plain), (codec, level, fill)
+    monkeypatch.delenv("GC_POISON_WORKSPACE")
 
 
 @pytest.mark.gpu
