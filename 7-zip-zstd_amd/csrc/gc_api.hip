@@ -476,7 +476,7 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
         HIPCHK(c, hipMemsetAsync(dps, 0, (size_t)nBlocks * GC_DPS_WORDS * sizeof(uint32_t), st));
         uint32_t phase0 = 0; { uint32_t one = 0; if (gc_env_u32("GC_DP_PHASES", 1u, 2u, &one) && one == 1u) phase0 = 2u; }    // test hook: 1 = W6's prices only
         // W7L (gc_lz_dpl.hip): one lane per window; LZMA with the four repeat distances at every node.  Test hook GC_DPL: 0 = W7 (a wave per window)
-        uint32_t laneDp = c->laneParse; gc_env_u32("GC_DPL", 0u, 1u, &laneDp);
+        uint32_t laneDp = c->laneParse ? 2u : 0u; gc_env_u32("GC_DPL", 0u, 2u, &laneDp);      // 2: phase A in W7L, phase B per block in W7 or W7L by what phase A's paths did (gc_mf.h GC_DPS_RICH); test hook: 1 = W7L everywhere, 0 = W7
         uint8_t* lpr = c->mfLitPrice + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
         if (laneDp) GC_LAUNCH(gc_mf_litprice_kernel, perB * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perB, (const uint16_t*)price, litCtxArg, lpr);
         for (uint32_t phase = phase0; phase != 3u; phase = phase == 0u ? 1u : 3u) {
@@ -487,7 +487,12 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
                 uint32_t win2k = 0u; gc_env_u32("GC_DPL_WIN2K", 0u, 1u, &win2k);      // test hook: windows of 2 KiB, one block per wave, in the pass over every window
                 const bool w2 = win2k != 0u && (phase != 0u || fullA);
                 const uint32_t nItems = w2 ? nBlocks : (nBlocks + 1u) / 2u, perL = gc_xcd_per(nItems);     // a wave = two blocks (2 KiB windows: one)
-                const uint32_t phaseK = phase | (w2 ? 16u : 0u);
+                const bool select = laneDp == 2u && phase == 1u && !w2;
+                const uint32_t phaseK = phase | (w2 ? 16u : 0u) | (select ? GC_DP_SELECT : 0u);
+                if (select) {                                      // the blocks without repeats: W7
+                    if (c->priceMinLen <= 2u) GC_LAUNCH(gc_mf_dp2_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, frameBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
+                    else GC_LAUNCH(gc_mf_dp3_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, frameBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
+                }
                 if (c->priceMinLen <= 2u) {
                     if (phase == 0u && !fullA) GC_LAUNCH(gc_mf_dpl2s_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
                     else GC_LAUNCH(gc_mf_dpl2_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);

@@ -112,6 +112,7 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t litCtxMask = litCtxArg & 0xFFu, hasPrev = litCtxArg >> 31;
     const bool win2k = !SAMPLE && (phaseArg & 16u) != 0u;         // every window of ONE block per wave, 64 x 2 KiB (more, shorter waves: the launch ends with its slowest wave)
+    const bool selective = !SAMPLE && (phaseArg & GC_DP_SELECT) != 0u;      // phase B of the blocks whose sampled paths repeat distances; the others are W7's (gc_mf.h GC_DPS_RICH)
     phaseArg &= 15u;
     const uint32_t BPWr = win2k ? 1u : BPW;
     const bool phaseA = SAMPLE && phaseArg == 0u, phaseB = phaseArg == 1u;      // (the sample kernels count: phase A; the others run phase B, or phase 2 = W6's prices as they are)
@@ -120,7 +121,14 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
     // ---- this lane's window
     const uint32_t lb = win2k ? 0u : lane >> 5;                   // block of the wave
     const uint32_t b = item * BPWr + lb;
-    const bool blockLive = b < nBlocks;
+    bool mineSel = true;
+    if (selective) {                                              // (both blocks' counts are read by every lane: the wave's decisions are uniform)
+        const bool s0 = GC_DPS_RICH(dpStat + (uint64_t)(item * BPWr) * GC_DPS_WORDS);
+        const bool s1 = BPWr > 1u && item * BPWr + 1u < nBlocks && GC_DPS_RICH(dpStat + (uint64_t)(item * BPWr + 1u) * GC_DPS_WORDS);
+        if (!s0 && !s1) return;
+        mineSel = lb == 0u ? s0 : s1;
+    }
+    const bool blockLive = b < nBlocks && mineSel;
     const uint64_t base = (uint64_t)(blockLive ? b : 0u) * GC_ZSTD_BLOCK_MAX;
     const uint32_t blockLen = blockLive ? (uint32_t)((srcSize - base) < GC_ZSTD_BLOCK_MAX ? (srcSize - base) : GC_ZSTD_BLOCK_MAX) : 0u;
 #ifdef HIPEMU
@@ -198,7 +206,7 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
     // Tracking the repeat distances is half of a node's work.  Where phase A's paths of BOTH blocks of the wave hardly ever repeated a distance (text: one
     // match symbol in 30) phase B runs without it: repeats are then only found where a candidate of the finder has a repeat distance.
     bool trackOn = REPS;
-    if (REPS && phaseB) {
+    if (REPS && phaseB && !selective) {
         uint32_t rich = 0u;
         for (uint32_t q = 0; q < BPW; q++) {
             const uint32_t bb = q < BPWr ? item * BPWr + q : nBlocks;

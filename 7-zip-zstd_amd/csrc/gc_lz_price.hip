@@ -185,6 +185,8 @@ __device__ __forceinline__ void dp_window(const uint8_t* __restrict__ src, uint6
     __shared__ uint32_t sCnt[GC_DPS_WORDS];                       // phase A: symbol counts of this workgroup's paths
     constexpr bool REPS = minLen == 2u;                           // LZMA: the path carries its last match distance (rep0) and may repeat it
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = gc_uniform(t >> 6);        // (uniform: the node index i must live in an SGPR)
+    const bool selective = (phaseArg & GC_DP_SELECT) != 0u;       // phase B: blocks whose sampled paths repeat distances belong to W7L (gc_lz_dpl.hip)
+    phaseArg &= 15u;
     const bool phaseA = phaseArg == 0u, phaseB = phaseArg == 1u;
     bool useReps = REPS;                                          // (uniform per workgroup = per block)
     // a workgroup = DP_WAVES windows of one block: consecutive ones, or in phase A every eighth one (windows 3, 11, 19, 27)
@@ -192,6 +194,7 @@ __device__ __forceinline__ void dp_window(const uint8_t* __restrict__ src, uint6
     const uint32_t wgPerBlock = phaseA ? DP_WINS_PER_BLOCK / DP_WAVES / 8u : DP_WINS_PER_BLOCK / DP_WAVES;
     const uint32_t b = item / wgPerBlock;
     if (b >= nBlocks) return;
+    if (selective && phaseB && GC_DPS_RICH(dpStat + (uint64_t)b * GC_DPS_WORDS)) return;      // (uniform per workgroup)
     const uint32_t win = phaseA ? ((item % wgPerBlock) * DP_WAVES + wave) * 8u + 3u : (item % wgPerBlock) * DP_WAVES + wave;
     { const GcU4* T4 = (const GcU4*)(priceTab + (uint64_t)b * GC_PRICE_WORDS); GcU4* S4 = (GcU4*)sPrice;
       for (uint32_t i = t; i < GC_PRICE_WORDS / 8u; i += DP_T) S4[i] = T4[i]; }

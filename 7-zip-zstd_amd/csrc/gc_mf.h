@@ -128,6 +128,10 @@ static inline GcMfGeom gc_mf_geom(uint64_t n, uint32_t frameBlocks, bool fast)
 #define GC_DPS_NREP3     (GC_DPS_NLIT + 6u)
 #define GC_DPS_REPLEN   160u               // [length 0..79] of the repeat matches
 #define GC_DPS_WORDS    240u
+// Phase B of a block runs in W7L (a lane per window, the repeat distances at every node) where phase A's paths repeated a distance in at least one match symbol of
+// twenty, in W7 (a wave per window, a third of the time) elsewhere: bit 5 of both kernels' phase argument = "only my kind of block".  C = the block's counts.
+#define GC_DP_SELECT    32u
+#define GC_DPS_RICH(C)  ((C)[GC_DPS_NMAT] != 0u && ((C)[GC_DPS_NREP] + (C)[GC_DPS_NSREP] + (C)[GC_DPS_NREP1] + (C)[GC_DPS_NREP2] + (C)[GC_DPS_NREP3]) * 20u >= (C)[GC_DPS_NMAT])
 #define GC_SHORT_NONE   0xFFFFu            // W5s -> W7: uint16 per position, (distance - 1) << 4 | (length - 2), or none
 
 // Workgroup index -> work item such that each of the 8 XCDs (workgroups are dealt round-robin to XCDs) owns one contiguous
