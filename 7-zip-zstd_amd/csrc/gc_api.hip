@@ -476,7 +476,11 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
         HIPCHK(c, hipMemsetAsync(dps, 0, (size_t)nBlocks * GC_DPS_WORDS * sizeof(uint32_t), st));
         uint32_t phase0 = 0; { uint32_t one = 0; if (gc_env_u32("GC_DP_PHASES", 1u, 2u, &one) && one == 1u) phase0 = 2u; }    // test hook: 1 = W6's prices only
         // W7L (gc_lz_dpl.hip): one lane per window; LZMA with the four repeat distances at every node.  Test hook GC_DPL: 0 = W7 (a wave per window)
-        uint32_t laneDp = c->laneParse ? 2u : 0u; gc_env_u32("GC_DPL", 0u, 2u, &laneDp);      // 2: phase A in W7L, phase B per block in W7 or W7L by what phase A's paths did (gc_mf.h GC_DPS_RICH); test hook: 1 = W7L everywhere, 0 = W7
+        // 1: W7L everywhere (FLZMA2); 2: phase A in W7L, phase B per block in W7 or W7L by what phase A's paths did (gc_mf.h GC_DPS_RICH) -- zstd, where text repeats
+        // an offset in 1 % of its sequences and sources / binaries in 8-46 %: 125 MB of text at level 19 3.78 -> 4.75 GB/s (run r4s), the sizes of W7L where it matters.
+        // (FLZMA2 on the Silesia stand-in: half of the blocks sit right at the threshold, and a W7L launch takes as long for a few blocks as for all of them -- it ends with
+        // its slowest wave, and all of its waves fit the device at once -- so the two kernels' times add up: 40 -> 49 ms.)  Test hook GC_DPL: 0 = W7 with its own phase A
+        uint32_t laneDp = c->laneParse ? (c->lastCodecHint == 1 ? 1u : 2u) : 0u; gc_env_u32("GC_DPL", 0u, 2u, &laneDp);
         uint8_t* lpr = c->mfLitPrice + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
         if (laneDp) GC_LAUNCH(gc_mf_litprice_kernel, perB * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perB, (const uint16_t*)price, litCtxArg, lpr);
         for (uint32_t phase = phase0; phase != 3u; phase = phase == 0u ? 1u : 3u) {
