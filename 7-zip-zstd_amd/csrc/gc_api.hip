@@ -704,7 +704,8 @@ extern "C" int gc_zstd_finish(gc_ctx* c, size_t* compressedSize)
             struct { const char* name; const void* p; size_t bytes; } parts[] = {
                 { "wincost", c->mfWinCost, c->mfWinCost ? (size_t)nb * 128u : 0u }, { "dpstat", c->mfDpStat, c->mfDpStat ? (size_t)nb * GC_DPS_WORDS * 4u : 0u },
                 { "price", c->mfPrice, c->mfPrice ? (size_t)nb * GC_PRICE_WORDS * 2u : 0u }, { "lzinfo", c->lzInfo, c->lzInfo ? (size_t)nb * GC_LZMA_RC_PER_BLOCK * sizeof(GcLzmaChunkInfo) : 0u },
-                { "lznm", c->lzNM, c->lzNM ? (size_t)nb * 4u : 0u } };
+                { "lznm", c->lzNM, c->lzNM ? (size_t)nb * 4u : 0u },
+                { "dp", c->mfDp, (c->mfDp && nb <= 16u) ? (size_t)nb * GC_ZSTD_BLOCK_MAX * 4u : 0u } };      // (W7 / W7L records: small inputs only)
             for (auto& q : parts) {
                 std::vector<uint8_t> h(q.bytes);
                 if (q.bytes && hipMemcpy(h.data(), q.p, q.bytes, hipMemcpyDeviceToHost) != hipSuccess) h.assign(q.bytes, 0xEE);

@@ -162,7 +162,9 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
         // lengths of repeats before anything is known: as those of matches, but the short ones (which hardly occur among the finder's matches) at 2.5 bits
         for (uint32_t i = lane; i < GC_PRICE_NLEN; i += 64u) { const uint32_t v = P[GC_PRICE_LEN + i]; P[GC_PRICE_REPLEN + i] = (uint16_t)(i < 10u && v > 40u ? 40u : v); }
         gc_wave_sync();
-        if (phaseA && P[GC_PRICE_FLAGS + 1u] >= 64u) {
+        const bool ceilings = phaseA && P[GC_PRICE_FLAGS + 1u] >= 64u;      // (read by every lane BEFORE the loop below rewrites that entry: lanes that run one after
+        gc_wave_sync();                                                     //  another -- the emulator -- would otherwise stop capping from lane 17 on)
+        if (ceilings) {
             for (uint32_t i = lane; i < GC_PRICE_NLEN + 64u + 1u; i += 64u) {
                 const uint32_t idx = i < GC_PRICE_NLEN ? GC_PRICE_LEN + i : (i < GC_PRICE_NLEN + 64u ? GC_PRICE_SLOT + (i - GC_PRICE_NLEN) : GC_PRICE_FLAGS + 1u);
                 const uint32_t cap = i < 10u ? 8u : (i < GC_PRICE_NLEN ? 0xFFFFu : (i < GC_PRICE_NLEN + 64u ? 48u : 16u));

@@ -125,6 +125,21 @@ def test_gpu_bytes_equal_emulator_bytes_with_price_parse(O, pkg, emu_lib_path, g
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("codec,level", [("flzma2", 5), ("zstd", 19)])
+@pytest.mark.parametrize("kind,off", [("silesia-like", 40 * BLK), ("real-bin", 64 * BLK)])
+def test_gpu_bytes_equal_emulator_bytes_where_paths_repeat_distances(O, pkg, emu_lib_path, gpu_ok, monkeypatch, codec, level, kind, off):
+    """Round 4: on tables of small records (blocks 38.. of the Silesia stand-in) the device and the emulator disagreed -- phase A's price ceilings were switched on by
+    a table entry that the capping loop itself rewrites, which lanes running one after another saw half-way.  Data whose sampled paths repeat distances, two blocks."""
+    x = O.corpus(kind, off + 2 * BLK)
+    if x.size < off + 2 * BLK:
+        pytest.skip("the image holds too little %s data" % kind)
+    x = np.ascontiguousarray(x[off:off + 2 * BLK])
+    g = _code(O, pkg, codec, level, x, monkeypatch, None, device=0)
+    e = _code(O, pkg, codec, level, x, monkeypatch, None, lib_path=emu_lib_path)
+    assert np.array_equal(g, e)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("codec,level,kind,n", [("flzma2", 5, "silesia-like", 32 << 20), ("zstd", 19, "text-zipf", 32 << 20), ("brotli", 9, "web-text", 32 << 20)])
 def test_gpu_price_parse_beats_greedy_at_size(O, pkg, gpu_ok, gpu_hooks_kw, monkeypatch, codec, level, kind, n):
     x = O.corpus(kind, n)
