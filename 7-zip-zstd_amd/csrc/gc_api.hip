@@ -487,9 +487,8 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
             const uint32_t nDpWg = nBlocks * (phase == 0u ? 1u : 8u), perD = gc_xcd_per(nDpWg);
             uint32_t* wcp = phase == 0u ? (uint32_t*)nullptr : wc;
             if (laneDp) {
-                uint32_t fullA = 0u; gc_env_u32("GC_DP_FULLA", 0u, 1u, &fullA);      // test hook: phase A over every window
                 uint32_t win2k = 0u; gc_env_u32("GC_DPL_WIN2K", 0u, 1u, &win2k);      // test hook: windows of 2 KiB, one block per wave, in the pass over every window
-                const bool w2 = win2k != 0u && (phase != 0u || fullA);
+                const bool w2 = win2k != 0u && phase != 0u;
                 const uint32_t nItems = w2 ? nBlocks : (nBlocks + 1u) / 2u, perL = gc_xcd_per(nItems);     // a wave = two blocks (2 KiB windows: one)
                 const bool select = laneDp == 2u && phase == 1u && !w2;
                 const uint32_t phaseK = phase | (w2 ? 16u : 0u) | (select ? GC_DP_SELECT : 0u);
@@ -498,10 +497,10 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
                     else GC_LAUNCH(gc_mf_dp3_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, frameBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
                 }
                 if (c->priceMinLen <= 2u) {
-                    if (phase == 0u && !fullA) GC_LAUNCH(gc_mf_dpl2s_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
+                    if (phase == 0u) GC_LAUNCH(gc_mf_dpl2s_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
                     else GC_LAUNCH(gc_mf_dpl2_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
                 } else if (c->lastCodecHint == 0) {
-                    if (phase == 0u && !fullA) GC_LAUNCH(gc_mf_dplzs_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
+                    if (phase == 0u) GC_LAUNCH(gc_mf_dplzs_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
                     else GC_LAUNCH(gc_mf_dplz_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
                 } else {
                     if (phase == 0u) GC_LAUNCH(gc_mf_dpl3s_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
@@ -609,6 +608,7 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
     gc_env_u32("GC_HALF_LIST", 0u, 1u, &c->halfList);
     c->searchDepth = zstd_search_depth(level); c->searchShallow = c->searchDepth < 2u ? c->searchDepth : 2u;
     if (gc_env_u32("GC_SEARCH_DEPTH", 0u, 64u, &c->searchDepth)) c->searchShallow = c->searchDepth < 2u ? c->searchDepth : 2u;      // test hook
+    gc_env_u32("GC_SEARCH_SHALLOW", 0u, 64u, &c->searchShallow);                                // test hook: links followed by every position
     c->farPass = level >= 7 ? 1u : 0u;            // where the reference searches chains / trees (lazy2 and up).  Measured (run 29, 32 MiB): level 9
                                                   // 1.027 -> 0.984 x the reference on text, level 12 1.040 -> 1.001 x
     c->shortPass = level >= 10 ? 1u : 0u;         // the reference's btopt strategies search 3-byte matches (minMatch 3, clevels.h:44-47); from level 10 since round 3, see priceParse
