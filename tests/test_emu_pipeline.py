@@ -77,3 +77,32 @@ def test_watchdog_word_turns_into_an_error_code(pkg, emu_lib_path, O, monkeypatc
     monkeypatch.delenv("GC_WATCHDOG_TRIP")
     assert len(e.code(x)) > 0
     e.close()
+
+
+_GARBAGE_SCRIPT = r"""
+import sys, hashlib
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + '/oracle')
+import numpy as np
+import __graft_entry__ as g, oracle as O
+pkg = g.load_package()
+x = np.concatenate([O.corpus('silesia-like', 131072 + 4321), O.corpus('text-zipf', 30000)])
+for name, cls, level in (('zstd', pkg.ZstdEncoder, 3), ('zstd', pkg.ZstdEncoder, 19), ('flzma2', pkg.Flzma2Encoder, 5), ('brotli', pkg.BrotliEncoder, 6)):
+    e = cls(level=level, lib_path=sys.argv[2]); c = e.code(x); e.close()
+    print(name, level, len(c), hashlib.sha1(c.tobytes()).hexdigest())
+"""
+
+
+def test_streams_do_not_depend_on_what_memory_held(emu_lib_path, graft):
+    """Round 4 (profiles/r04_defects.md): on the device a fresh allocation and a workgroup's LDS hold whatever was there before; the emulator's malloc hands out zero
+    pages and its `__shared__` statics keep the previous workgroup's values.  With every allocation and all of LDS filled with garbage (GC_EMU_POISON, GC_EMU_POISON_LDS:
+    tests/emu/hip_runtime_stub.h, hipemu.cpp) the encoders must produce the same bytes."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    def run(extra):
+        env = dict(os.environ); env.update(extra)
+        r = subprocess.run([sys.executable, "-c", _GARBAGE_SCRIPT, root, emu_lib_path], capture_output=True, text=True, env=env, timeout=1500)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return r.stdout
+    plain = run({})
+    assert plain.count("\n") == 4
+    assert run({"GC_EMU_POISON": "-7", "GC_EMU_POISON_LDS": "3", "GC_POISON_WORKSPACE": "90"}) == plain
