@@ -497,14 +497,14 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
                     else GC_LAUNCH(gc_mf_dp3_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, frameBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
                 }
                 if (c->priceMinLen <= 2u) {
-                    if (phase == 0u) GC_LAUNCH(gc_mf_dpl2s_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
-                    else GC_LAUNCH(gc_mf_dpl2_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
+                    if (phase == 0u) GC_LAUNCH(gc_mf_dpl2s_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
+                    else GC_LAUNCH(gc_mf_dpl2_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
                 } else if (c->lastCodecHint == 0) {
-                    if (phase == 0u) GC_LAUNCH(gc_mf_dplzs_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
-                    else GC_LAUNCH(gc_mf_dplz_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
+                    if (phase == 0u) GC_LAUNCH(gc_mf_dplzs_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
+                    else GC_LAUNCH(gc_mf_dplz_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
                 } else {
-                    if (phase == 0u) GC_LAUNCH(gc_mf_dpl3s_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
-                    else GC_LAUNCH(gc_mf_dpl3_kernel, perL * GC_XCDS, 64, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
+                    if (phase == 0u) GC_LAUNCH(gc_mf_dpl3s_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
+                    else GC_LAUNCH(gc_mf_dpl3_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
                 }
             } else
             if (c->priceMinLen <= 2u) GC_LAUNCH(gc_mf_dp2_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);

@@ -55,6 +55,18 @@
 #define DPL_LO_DIST(lo)  ((lo) >> (DPL_LENBITS + 4u))
 #define DPL_LO(dist, cap, cls, len) (((dist) << (DPL_LENBITS + 4u)) | ((cap) ? 1u << (DPL_LENBITS + 3u) : 0u) | ((cls) << DPL_LENBITS) | ((len) - 1u))
 #define DPL_INF      0xFFFFFFFFFFFFFFFFull
+// Two waves per group of 64 windows (GC_DPL_THREADS = 128, gc_mf.h): both step through the nodes together, wave 0 expands a node's literal, finder candidates and
+// the rest of a capped match, stores back pointers and walks back; wave 1 keeps the tracked distances and expands the node's repeats.  One LDS barrier per node.
+// The rings are two slots longer than an edge / one longer than the reach of a repeat look-up, so that what one wave resets or rewrites during a step is nothing
+// the other wave can still read or already target in that step: slot of node i - 1 is cleared in step i (node i + DPL_RC - 1 is out of reach of an edge of <= DPL_M).
+#define DPL_RC       (DPL_M + 2u)     // cost ring
+#define DPL_RR       (DPL_MR + 1u)    // ring of repeat distances
+#define DPL_PAIR     (GC_DPL_THREADS == 128u)
+#if defined(HIPEMU)
+#define DPL_BARRIER() do { if (DPL_PAIR) __syncthreads(); } while (0)
+#else
+#define DPL_BARRIER() do { if (DPL_PAIR) { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } } while (0)      // (LDS only: the global loads in flight stay in flight)
+#endif
 #define DPL_CONT     4u               // the rest of a capped match: a quarter of a bit (as DP_CONT_PRICE of W7)
 #define DPL_WARM     128              // positions in front of a window that the programme runs over for its state
 #define DPL_NC       2u               // requests in flight per group of nodes: the last one for the shadow parse's distances
@@ -87,11 +99,11 @@ __device__ __forceinline__ void dpl_mtf(DplReps& s, uint32_t d, uint32_t sure)
 }
 
 #if defined(DPL_PROF) && !defined(HIPEMU)
-__device__ unsigned long long g_dplProf[16];
+__device__ unsigned long long g_dplProf[32];      // [0..15] wave 0 of a pair, [16..31] wave 1; per wave: sections 0..7 of a node step, 8 = walk back, 9 = waiting at the barrier
 extern "C" int gc_dpl_prof_read(unsigned long long* out, int reset)
 {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dplProf), sizeof(g_dplProf)) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[16] = { 0 }; if (hipMemcpyToSymbol(HIP_SYMBOL(g_dplProf), z, sizeof(z)) != hipSuccess) return -1; }
+    if (reset) { unsigned long long z[32] = { 0 }; if (hipMemcpyToSymbol(HIP_SYMBOL(g_dplProf), z, sizeof(z)) != hipSuccess) return -1; }
     return 0;
 }
 #define DPL_T(k) do { const unsigned long long now_ = clock64(); pacc[k] += now_ - ptick; ptick = now_; } while (0)
@@ -104,12 +116,14 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
                                         uint32_t litCtxArg, const uint32_t* __restrict__ rec, const uint16_t* __restrict__ rec3, const uint16_t* __restrict__ priceTab,
                                         uint32_t* __restrict__ recOut, uint32_t* __restrict__ winCost, const uint8_t* __restrict__ litPrice)
 {
-    __shared__ unsigned long long sCost[DPL_M][64];
-    __shared__ GcU4 sReps[REPS ? DPL_MR : 1u][64];
+    __shared__ unsigned long long sCost[DPL_RC][64];
+    __shared__ GcU4 sReps[REPS ? DPL_RR : 1u][64];
     constexpr uint32_t BPW = 2u;
     __shared__ uint16_t sPrice[BPW][GC_PRICE_WORDS - GC_PRICE_LEN];      // (the literal rows are not needed here: gc_mf_litprice_kernel has priced every position)
     __shared__ uint32_t sCnt[SAMPLE ? BPW : 1u][SAMPLE ? GC_DPS_WORDS : 1u];
     const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t role = DPL_PAIR ? gc_uniform(threadIdx.x >> 6) : 0u;
+    const bool isA = !DPL_PAIR || role == 0u, isB = !DPL_PAIR || role == 1u;      // wave 0 / wave 1 of the pair (one wave: both)
     const uint32_t litCtxMask = litCtxArg & 0xFFu, hasPrev = litCtxArg >> 31;
     const bool win2k = !SAMPLE && (phaseArg & 16u) != 0u;         // every window of ONE block per wave, 64 x 2 KiB (more, shorter waves: the launch ends with its slowest wave)
     const bool selective = !SAMPLE && (phaseArg & GC_DP_SELECT) != 0u;      // phase B of the blocks whose sampled paths repeat distances; the others are W7's (gc_mf.h GC_DPS_RICH)
@@ -145,7 +159,8 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
 #endif
     const uint32_t n = w0 < blockLen ? ((blockLen - w0) < winLen ? (blockLen - w0) : winLen) : 0u;       // nodes 0 .. n
     const uint32_t nMax = gc_wave_max(n);
-    // ---- price tables (as W7: W6's table, phase A with optimistic ceilings where the greedy parse found no matches, phase B from phase A's counts)
+    // ---- price tables (as W7: W6's table, phase A with optimistic ceilings where the greedy parse found no matches, phase B from phase A's counts); by wave 0
+    if (isA) {
     for (uint32_t q = 0; q < BPW; q++) {
         const uint32_t bb = q < BPWr ? item * BPWr + q : nBlocks;
         if (bb < nBlocks) { const GcU4* T4 = (const GcU4*)(priceTab + (uint64_t)bb * GC_PRICE_WORDS + GC_PRICE_LEN); GcU4* S4 = (GcU4*)sPrice[q]; for (uint32_t i = lane; i < (GC_PRICE_WORDS - GC_PRICE_LEN) / 8u; i += 64u) S4[i] = T4[i]; }
@@ -204,6 +219,8 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
         }
     }
     gc_wave_sync();
+    }
+    DPL_BARRIER();
     const uint16_t* P = sPrice[lb] - GC_PRICE_LEN;
     // Tracking the repeat distances is half of a node's work.  Where phase A's paths of BOTH blocks of the wave hardly ever repeated a distance (text: one
     // match symbol in 30) phase B runs without it: repeats are then only found where a candidate of the finder has a repeat distance.
@@ -241,9 +258,14 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
     const int32_t warmMax = (int32_t)gc_wave_max((uint32_t)warm);
     const int32_t N = (int32_t)n;
 
-    for (uint32_t s = 0; s < DPL_M; s++) sCost[s][lane] = DPL_INF;
-    sCost[(uint32_t)(-warm) & DPL_MMASK][lane] = 0ull;            // the first node: cost 0
-    if (REPS) { GcU4 v; v.x = v.y = v.z = v.w = 0u; for (uint32_t s = 0; s < DPL_MR; s++) sReps[s][lane] = v; }
+    // ring slots of node i: i mod DPL_RC / i mod DPL_RR, kept as counters of the (uniform) node loop
+    uint32_t si = (uint32_t)(((-warmMax) % (int32_t)DPL_RC + (int32_t)DPL_RC) % (int32_t)DPL_RC), sr = (uint32_t)(((-warmMax) % (int32_t)DPL_RR + (int32_t)DPL_RR) % (int32_t)DPL_RR);
+    if (isA) {
+        for (uint32_t s = 0; s < DPL_RC; s++) sCost[s][lane] = DPL_INF;
+        sCost[(si + (uint32_t)(warmMax - warm)) % DPL_RC][lane] = 0ull;          // the first node: cost 0
+        if (REPS) { GcU4 v; v.x = v.y = v.z = v.w = 0u; for (uint32_t s = 0; s < DPL_RR; s++) sReps[s][lane] = v; }
+    }
+    DPL_BARRIER();
     DplReps st; st.r0 = st.r1 = st.r2 = st.r3 = 0u;               // repeat distances of the node being expanded
 
     // ---- pipelines: records, short candidates and literal prices two groups of four positions ahead
@@ -393,7 +415,8 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
     // The lengths tried are x0 .. LO and the last four (Lm - 3 .. Lm): what lies between are prefixes of a long candidate that end nowhere in particular
     // (measured on the evaluation slices: all lengths against 2 .. 12 + the last four of the finder's candidates, 2 .. 4 + the last four of a repeat:
     // +0.05 ... 0.2 % size for half the relax instructions).  tabBase: where the length prices lie in LDS (for the lengths that are not static).
-    auto relax = [&](int32_t i, uint32_t Lm, uint32_t x0, uint32_t hiBase, uint32_t loBase, uint32_t lastLen /* whose price the last edge carries */, uint32_t left, uint32_t loLast,
+    auto slotOf = [&](uint32_t x) -> uint32_t { const uint32_t t = si + x; return t >= DPL_RC ? t - DPL_RC : t; };      // ring slot of node i + x, x <= DPL_M + 1 (si: the slot of node i)
+    auto relax = [&](int32_t, uint32_t Lm, uint32_t x0, uint32_t hiBase, uint32_t loBase, uint32_t lastLen /* whose price the last edge carries */, uint32_t left, uint32_t loLast,
                      const uint32_t (&tab)[DPL_TABW], uint32_t tabBase, bool flat, const uint32_t LO) {
         if (DPL_NONE_LONGER(x0 > 1u ? x0 : 1u, Lm)) return;
         // the four prices with a length of the lane's own: read together, used below
@@ -405,43 +428,43 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
             if (x > 1u && (x & 3u) == 1u && DPL_NONE_LONGER(x, pre)) break;
             const uint32_t lp = flat ? 0u : ((tab[x >> 1] >> (16u * (x & 1u))) & 0xFFFFu);
             const uint32_t hi = (x >= x0 && x <= pre) ? hiBase + (lp << 6) : 0xFFFFFFFFu;
-            atomicMin(&myCost[(((uint32_t)i + x) & DPL_MMASK) * 64u], ((unsigned long long)hi << 32) | (loBase | (x - 1u)));
+            atomicMin(&myCost[slotOf(x) * 64u], ((unsigned long long)hi << 32) | (loBase | (x - 1u)));
         }
 #pragma unroll
         for (uint32_t t = 3u; t >= 1u; t--) {
             const uint32_t x = Lm - t;                             // (per lane)
             const uint32_t lp = flat ? 0u : (t == 3u ? p3 : (t == 2u ? p2 : p1));
             const uint32_t hi = (Lm > t && x >= x0 && x > pre) ? hiBase + (lp << 6) : 0xFFFFFFFFu;
-            atomicMin(&myCost[(((uint32_t)i + x) & DPL_MMASK) * 64u], ((unsigned long long)hi << 32) | (loBase | ((x - 1u) & DPL_MMASK)));
+            atomicMin(&myCost[slotOf(Lm > t ? x : 1u) * 64u], ((unsigned long long)hi << 32) | (loBase | ((x - 1u) & DPL_MMASK)));
         }
         {
             const uint32_t hi = (Lm >= x0 && Lm != 0u) ? ((hiBase + ((flat ? 0u : p0) << 6)) | left) : 0xFFFFFFFFu;
-            atomicMin(&myCost[(((uint32_t)i + Lm) & DPL_MMASK) * 64u], ((unsigned long long)hi << 32) | loLast);
+            atomicMin(&myCost[slotOf(Lm) * 64u], ((unsigned long long)hi << 32) | loLast);
         }
     };
 
     // ---- the programme: node i = finalize (i > -warm) + expand (i < n); nodes below 0 are the warm-up.  The records of the group of four positions
     //      that holds i sit in recG / r3G / lpG and move down one place per node, so that the node's own are always in place 0
 #if defined(DPL_PROF) && !defined(HIPEMU)
-    unsigned long long pacc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, ptick = clock64();
+    unsigned long long pacc[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, ptick = clock64();
 #endif
     for (int32_t i = -warmMax; i < (int32_t)nMax + 4; i++) {
         const uint32_t u = (uint32_t)i & 3u;
         DPL_T(7);
         if (u == 0u) load_group(i + 8, recNN, r3NN, lpNN);
-        const uint32_t slot = (uint32_t)i & DPL_MMASK;
-        const unsigned long long w = myCost[slot * 64u];
-        myCost[slot * 64u] = DPL_INF;
+        const unsigned long long w = myCost[si * 64u];
+        if (isA && i != -warmMax) myCost[(si == 0u ? DPL_RC - 1u : si - 1u) * 64u] = DPL_INF;      // node i - 1's slot becomes node i + DPL_RC - 1's (both waves have read it: the barrier of step i - 1)
         const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
         const uint32_t c0 = hi >> 6;
         const bool live = n != 0u && i >= -warm && i <= N;
         if (live && i > -warm) {                                   // ---- finalize node i
             const uint32_t len = DPL_LO_LEN(lo), cls = DPL_LO_CLS(lo), dist = DPL_LO_DIST(lo);
             if (REPS) {
-                const GcU4 pv = sReps[(uint32_t)(i - (int32_t)(len < DPL_MR ? len : DPL_MR)) & (DPL_MR - 1u)][lane];      // (an edge longer than the ring: the oldest node it still holds)
+                uint32_t ps = sr + DPL_RR - (len < DPL_MR ? len : DPL_MR); ps = ps >= DPL_RR ? ps - DPL_RR : ps;
+                const GcU4 pv = sReps[ps][lane];                  // (an edge longer than the ring: the oldest node it still holds)
                 st.r0 = pv.x; st.r1 = pv.y; st.r2 = pv.z; st.r3 = pv.w;
                 if (cls != DPL_LIT && cls != DPL_SREP) dpl_mtf(st, dist, i - (int32_t)len >= 0 ? DPL_SURE : 0u);
-                GcU4 nv; nv.x = st.r0; nv.y = st.r1; nv.z = st.r2; nv.w = st.r3; sReps[slot & (DPL_MR - 1u)][lane] = nv;
+                if (isA) { GcU4 nv; nv.x = st.r0; nv.y = st.r1; nv.z = st.r2; nv.w = st.r3; sReps[sr][lane] = nv; }
             }
             contCapped = DPL_LO_CAP(lo) != 0u; contDist = dist; contRem = hi & 63u;
             if (i == 0) cost0 = c0;
@@ -449,7 +472,8 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
         }
         DPL_T(0);
         // back pointers: node j lives in slot j - 1; nodes 4g-3 .. 4g leave together
-        if (u == 0u) {
+        if (!isA) { }
+        else if (u == 0u) {
             if (i >= 4 && i - 4 < N) {
                 if (i <= N) { GcU4 v; v.x = c1; v.y = c2; v.z = c3; v.w = lo; __builtin_memcpy(BP + (i - 4), &v, 16); }
                 else { BP[i - 4] = c1; if (i - 3 < N) BP[i - 3] = c2; if (i - 2 < N) BP[i - 2] = c3; }
@@ -461,9 +485,9 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
             // a continuation of one byte is only a match together with the piece in front of it: at the window's first node that piece is the warm-up's guess
             const uint32_t contX0 = i == 0 ? (MINLEN > 2u ? MINLEN : 2u) : 1u;
             const uint32_t cbase = c0 << 6;
-            atomicMin(&myCost[(((uint32_t)i + 1u) & DPL_MMASK) * 64u], (unsigned long long)(room != 0u ? cbase + ((flagLit + (lpG & 0xFFu)) << 6) : 0xFFFFFFFFu) << 32);      // literal
-            // the rest of a capped match whose length is known
-            {
+            if (isA) atomicMin(&myCost[slotOf(1u) * 64u], (unsigned long long)(room != 0u ? cbase + ((flagLit + (lpG & 0xFFu)) << 6) : 0xFFFFFFFFu) << 32);      // literal
+            // the rest of a capped match whose length is known (handing these two to wave 1 as well -- 23.5 : 19.4 of the pair's work are wave 0's -- changed nothing: 23.85 -> 23.72 ms)
+            if (isA) {
                 uint32_t Lc = (room != 0u && contCapped) ? contRem : 0u;
                 const uint32_t beh = Lc > room ? Lc - room : 0u;
                 if (Lc > room) Lc = room;
@@ -481,6 +505,7 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
             uint32_t L3 = 0u, D3 = 0u;
             if (r3 != GC_SHORT_NONE) { L3 = (r3 & 15u) + 2u; D3 = (r3 >> 4) + 1u; if (L3 > room) L3 = room; if (L3 > DPL_M) L3 = DPL_M; if (L3 < MINLEN || (L >= L3 && D <= D3)) L3 = 0u; }
             if (L < MINLEN && !(contCapped && D == contDist && L != 0u)) { L = 0u; behL = 0u; }
+            if (isA) {
 #pragma unroll
             for (uint32_t cnd = 0; cnd < 2u; cnd++) {
                 const uint32_t Lx = cnd ? L3 : L, Dx = cnd ? D3 : (D ? D : 1u), behind = cnd ? 0u : behL;
@@ -500,10 +525,11 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
                 if (repTab) relax(i, Lm, x0, hb, DPL_LO(Dx, false, cls, 1u), lastLen, left, loLast, repR, GC_PRICE_REPLEN, isCont, cnd ? 6u : 8u);
                 else relax(i, Lm, x0, hb, DPL_LO(Dx, false, cls, 1u), lastLen, left, loLast, lenR, GC_PRICE_LEN, isCont, cnd ? 6u : 8u);
             }
+            }
             DPL_T(2);
             // repeats of the node's own distances, where those are tracked.  Of the (up to four) that repeat here two become edges: the one with the
             // lowest repeat index -- the cheapest flags -- and the longest one (evaluation slices: against all of them +0.0x % size, a third of the work)
-            if (REPS && trackOn) {
+            if (REPS && trackOn && isB) {
                 uint32_t bestK = 8u, bestL = 0u, bestD = 0u, longK = 8u, longL = 0u, longD = 0u, srepD = 0u; bool bestOpen = false, longOpen = false;
                 const uint32_t r0d = st.r0 & ~DPL_SURE;
 #pragma unroll
@@ -532,7 +558,7 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
                     bestK = b1 ? kk : bestK; bestL = b1 ? hl : bestL; bestD = b1 ? hd : bestD; bestOpen = b1 ? open : bestOpen;
                     longK = b2 ? kk : longK; longL = b2 ? hl : longL; longD = b2 ? hd : longD; longOpen = b2 ? open : longOpen;
                 }
-                if (MINLEN == 2u) atomicMin(&myCost[(((uint32_t)i + 1u) & DPL_MMASK) * 64u], ((unsigned long long)(srepD ? cbase + (fSrep << 6) : 0xFFFFFFFFu) << 32) | DPL_LO(srepD, false, DPL_SREP, 1u));
+                if (MINLEN == 2u) atomicMin(&myCost[slotOf(1u) * 64u], ((unsigned long long)(srepD ? cbase + (fSrep << 6) : 0xFFFFFFFFu) << 32) | DPL_LO(srepD, false, DPL_SREP, 1u));
                 if (longK == bestK) longL = 0u;
 #pragma unroll
                 for (uint32_t e = 0; e < 2u; e++) {
@@ -549,17 +575,22 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
         // the group's records move down one place
         recG[0] = recG[1]; recG[1] = recG[2]; recG[2] = recG[3]; r3G[0] = r3G[1]; r3G[1] = r3G[2]; r3G[2] = r3G[3]; lpG >>= 8;
         if (u == 3u) {                                             // ---- between two groups: the shadow parse and the tracked distances move on, the next group's records come in
-            if (REPS && trackOn) { shadow_step(i + 5, recNN); track_step(i + 1); }
+            if (REPS && trackOn && isB) { shadow_step(i + 5, recNN); track_step(i + 1); }
 #pragma unroll
             for (uint32_t q = 0; q < 4u; q++) { recG[q] = recN[q]; recN[q] = recNN[q]; r3G[q] = r3N[q]; r3N[q] = r3NN[q]; }
             lpG = lpN; lpN = lpNN;
             DPL_T(4);
         }
+        si = si + 1u == DPL_RC ? 0u : si + 1u; sr = sr + 1u == DPL_RR ? 0u : sr + 1u;
+        DPL_T(5);
+        DPL_BARRIER();                                             // every edge out of node i is in LDS before either wave reads node i + 1
+        DPL_T(9);
     }
 #if defined(DPL_PROF) && !defined(HIPEMU)
-    if (lane == 0u && !SAMPLE) for (int k = 0; k < 8; k++) atomicAdd(&g_dplProf[k], pacc[k]);
+    if (lane == 0u && !SAMPLE) for (int k = 0; k < 10; k++) atomicAdd(&g_dplProf[16u * role + k], pacc[k]);
     ptick = clock64();
 #endif
+    if (!isA) return;                                              // wave 1 is done: the rest (window costs, walk back, counts) is wave 0's
 #undef DPL_NONE_LONGER
     // back pointers of the last nodes (n not a multiple of four is covered above; n a multiple of four: nodes n-3 .. n left at g4 = n)
     gc_wave_sync_global();
@@ -640,7 +671,7 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
 
 // one kernel per codec family and grid shape (the shared arrays of dpl_run are per instantiation)
 #define DPL_KERNEL(name, REPS, MINLEN, SAMPLE) \
-extern "C" __global__ void __launch_bounds__(64) \
+extern "C" __global__ void __launch_bounds__(GC_DPL_THREADS) \
 name(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t frameBlocks, uint32_t phase, uint32_t* __restrict__ dpStat, uint32_t litCtxMask, \
      const uint32_t* __restrict__ rec, const uint16_t* __restrict__ rec3, const uint16_t* __restrict__ priceTab, uint32_t* __restrict__ recOut, uint32_t* __restrict__ winCost, \
      const uint8_t* __restrict__ litPrice) \

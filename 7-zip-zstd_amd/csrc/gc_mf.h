@@ -130,6 +130,9 @@ static inline GcMfGeom gc_mf_geom(uint64_t n, uint32_t frameBlocks, bool fast)
 #define GC_DPS_WORDS    240u
 // Phase B of a block runs in W7L (a lane per window, the repeat distances at every node) where phase A's paths repeated a distance in at least one match symbol of
 // twenty, in W7 (a wave per window, a third of the time) elsewhere: bit 5 of both kernels' phase argument = "only my kind of block".  C = the block's counts.
+#ifndef GC_DPL_THREADS
+#define GC_DPL_THREADS  128u              // W7L: two waves per group of 64 windows (gc_lz_dpl.hip; 64 = one wave does everything)
+#endif
 #define GC_DP_SELECT    32u
 #define GC_DPS_RICH(C)  ((C)[GC_DPS_NMAT] != 0u && ((C)[GC_DPS_NREP] + (C)[GC_DPS_NSREP] + (C)[GC_DPS_NREP1] + (C)[GC_DPS_NREP2] + (C)[GC_DPS_NREP3]) * 20u >= (C)[GC_DPS_NMAT])
 #define GC_SHORT_NONE   0xFFFFu            // W5s -> W7: uint16 per position, (distance - 1) << 4 | (length - 2), or none

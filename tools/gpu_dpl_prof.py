@@ -18,10 +18,12 @@ pkg = g.load_package()
 kind = sys.argv[1] if len(sys.argv) > 1 else 'silesia-like'; n = int(sys.argv[2]) if len(sys.argv) > 2 else 211_900_000
 x = O.corpus(kind, n)
 e = pkg.Flzma2Encoder(level=5, device=0, lib_path=lib); c = e.code(x)
-L = C.CDLL(lib); buf = (C.c_ulonglong * 16)()
+L = C.CDLL(lib); buf = (C.c_ulonglong * 32)()
 L.gc_dpl_prof_read(buf, 1); c = e.code(x); L.gc_dpl_prof_read(buf, 0); e.close()
-names = ['finalize', 'literal+cont', 'main+short', 'tracked repeats', 'between groups (track, shadow)', '-', '-', 'loop head + group load', 'walk back']
-tot = sum(buf[:9])
-for k, nm in enumerate(names):
-    if nm != '-': print('%-32s %6.2f %%  %.3e cycles' % (nm, 100.0 * buf[k] / tot, buf[k]))
-print('waves x cycles total %.3e' % tot, 'compressed', len(c))
+names = ['finalize', 'literal+cont', 'main+short', 'tracked repeats', 'between groups (track, shadow)', 'ring counters', '-', 'loop head + group load', 'walk back', 'waiting at the barrier']
+for role in (0, 1):
+    b = buf[16 * role:16 * role + 10]; tot = sum(b)
+    print('wave %d of the pair: %.3e cycles' % (role, tot))
+    for k, nm in enumerate(names):
+        if nm != '-' and tot: print('  %-32s %6.2f %%  %.3e cycles' % (nm, 100.0 * b[k] / tot, b[k]))
+print('compressed', len(c))
