@@ -61,7 +61,7 @@
 // the other wave can still read or already target in that step: slot of node i - 1 is cleared in step i (node i + DPL_RC - 1 is out of reach of an edge of <= DPL_M).
 #define DPL_RC       (DPL_M + 2u)     // cost ring
 #define DPL_RR       (DPL_MR + 1u)    // ring of repeat distances
-#define DPL_PAIR     (GC_DPL_THREADS == 128u)
+#define DPL_PAIR     (GC_DPL_THREADS > 64u)      // more than one wave per group
 #if defined(HIPEMU)
 #define DPL_BARRIER() do { if (DPL_PAIR) __syncthreads(); } while (0)
 #else
@@ -123,7 +123,8 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
     __shared__ uint32_t sCnt[SAMPLE ? BPW : 1u][SAMPLE ? GC_DPS_WORDS : 1u];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t role = DPL_PAIR ? gc_uniform(threadIdx.x >> 6) : 0u;
-    const bool isA = !DPL_PAIR || role == 0u, isB = !DPL_PAIR || role == 1u;      // wave 0 / wave 1 of the pair (one wave: both)
+    const bool isA = !DPL_PAIR || role == 0u, isB = !DPL_PAIR || role == 1u;      // wave 0 / wave 1 of the group (one wave: both)
+    const bool isC = GC_DPL_THREADS == 192u ? role == 2u : isA;   // a third wave takes the literal, the capped rest and the short candidate off wave 0
     const uint32_t litCtxMask = litCtxArg & 0xFFu, hasPrev = litCtxArg >> 31;
     const bool win2k = !SAMPLE && (phaseArg & 16u) != 0u;         // every window of ONE block per wave, 64 x 2 KiB (more, shorter waves: the launch ends with its slowest wave)
     const bool selective = !SAMPLE && (phaseArg & GC_DP_SELECT) != 0u;      // phase B of the blocks whose sampled paths repeat distances; the others are W7's (gc_mf.h GC_DPS_RICH)
@@ -485,9 +486,9 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
             // a continuation of one byte is only a match together with the piece in front of it: at the window's first node that piece is the warm-up's guess
             const uint32_t contX0 = i == 0 ? (MINLEN > 2u ? MINLEN : 2u) : 1u;
             const uint32_t cbase = c0 << 6;
-            if (isA) atomicMin(&myCost[slotOf(1u) * 64u], (unsigned long long)(room != 0u ? cbase + ((flagLit + (lpG & 0xFFu)) << 6) : 0xFFFFFFFFu) << 32);      // literal
+            if (isC) atomicMin(&myCost[slotOf(1u) * 64u], (unsigned long long)(room != 0u ? cbase + ((flagLit + (lpG & 0xFFu)) << 6) : 0xFFFFFFFFu) << 32);      // literal
             // the rest of a capped match whose length is known (handing these two to wave 1 as well -- 23.5 : 19.4 of the pair's work are wave 0's -- changed nothing: 23.85 -> 23.72 ms)
-            if (isA) {
+            if (isC) {
                 uint32_t Lc = (room != 0u && contCapped) ? contRem : 0u;
                 const uint32_t beh = Lc > room ? Lc - room : 0u;
                 if (Lc > room) Lc = room;
@@ -505,9 +506,10 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
             uint32_t L3 = 0u, D3 = 0u;
             if (r3 != GC_SHORT_NONE) { L3 = (r3 & 15u) + 2u; D3 = (r3 >> 4) + 1u; if (L3 > room) L3 = room; if (L3 > DPL_M) L3 = DPL_M; if (L3 < MINLEN || (L >= L3 && D <= D3)) L3 = 0u; }
             if (L < MINLEN && !(contCapped && D == contDist && L != 0u)) { L = 0u; behL = 0u; }
-            if (isA) {
+            {
 #pragma unroll
             for (uint32_t cnd = 0; cnd < 2u; cnd++) {
+                if (!(cnd ? isC : isA)) continue;
                 const uint32_t Lx = cnd ? L3 : L, Dx = cnd ? D3 : (D ? D : 1u), behind = cnd ? 0u : behL;
                 uint32_t cls = DPL_NEW, x0 = MINLEN;
                 const uint32_t sl = gc_dist_slot(Dx - 1u);

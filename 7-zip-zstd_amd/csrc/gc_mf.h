@@ -131,7 +131,8 @@ static inline GcMfGeom gc_mf_geom(uint64_t n, uint32_t frameBlocks, bool fast)
 // Phase B of a block runs in W7L (a lane per window, the repeat distances at every node) where phase A's paths repeated a distance in at least one match symbol of
 // twenty, in W7 (a wave per window, a third of the time) elsewhere: bit 5 of both kernels' phase argument = "only my kind of block".  C = the block's counts.
 #ifndef GC_DPL_THREADS
-#define GC_DPL_THREADS  128u              // W7L: two waves per group of 64 windows (gc_lz_dpl.hip; 64 = one wave does everything)
+#define GC_DPL_THREADS  128u              // W7L: two waves per group of 64 windows (gc_lz_dpl.hip; 64 = one wave does everything; 192 = a third wave for the literal, the
+                                           // capped rest and the short candidate: measured 39.2 ms against 23.9 -- the kernel then runs in two rounds, run r4k3)
 #endif
 #define GC_DP_SELECT    32u
 #define GC_DPS_RICH(C)  ((C)[GC_DPS_NMAT] != 0u && ((C)[GC_DPS_NREP] + (C)[GC_DPS_NSREP] + (C)[GC_DPS_NREP1] + (C)[GC_DPS_NREP2] + (C)[GC_DPS_NREP3]) * 20u >= (C)[GC_DPS_NMAT])
