@@ -274,7 +274,7 @@ def run_codec(codec, level, corpus_name, total, args, env):
     achieved = algo_bytes / (per_kernel[dom] * 1e-3) / 1e9
     mf_names = {"mf.count": "gc_mf_count_kernel", "mf.scan": "gc_mf_scan_kernel", "mf.scatter": "gc_mf_scatter_kernel",
                 "mf.link": "gc_mf_link_kernel", "mf.verify": "gc_mf_verify_kernel", "mf.parse": "gc_mf_parse_kernel",
-                "mf.short": "gc_mf_short_kernel", "mf.deepen": "gc_mf_deepen_kernel", "mf.dp": "gc_mf_dpl2_kernel" if fl2 else "gc_mf_dp3_kernel"}
+                "mf.short": "gc_mf_short_kernel", "mf.deepen": "gc_mf_deepen_kernel", "mf.dp": "gc_mf_dpl2_kernel" if fl2 else ("gc_mf_dp3_kernel + gc_mf_dplz_kernel (phase B per block in one of them)" if (not br and level >= 16) else "gc_mf_dp3_kernel")}
     kname = mf_names[dom] if dom in mf_names else \
         "gc_zstd_lz_kernel" if dom == "lz" else ("gc_lzma2_%s_kernel" if fl2 else ("gc_brotli_%s_kernel" if br else "gc_zstd_%s_kernel")) % dom
     # HBM bytes per launch of the dominant kernel from the committed PMC passes (tools/gpu_pmc.sh), same per-launch workload only; the section's
