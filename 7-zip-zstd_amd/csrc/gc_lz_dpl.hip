@@ -672,8 +672,14 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
 }
 
 // one kernel per codec family and grid shape (the shared arrays of dpl_run are per instantiation)
+// (experiment builds: -DDPL_WAVES_PER_EU=n caps the registers so that n waves fit a SIMD -- three waves per group need three)
+#if defined(DPL_WAVES_PER_EU) && !defined(HIPEMU)
+#define DPL_OCC __attribute__((amdgpu_waves_per_eu(DPL_WAVES_PER_EU)))
+#else
+#define DPL_OCC
+#endif
 #define DPL_KERNEL(name, REPS, MINLEN, SAMPLE) \
-extern "C" __global__ void __launch_bounds__(GC_DPL_THREADS) \
+extern "C" __global__ void __launch_bounds__(GC_DPL_THREADS) DPL_OCC \
 name(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t frameBlocks, uint32_t phase, uint32_t* __restrict__ dpStat, uint32_t litCtxMask, \
      const uint32_t* __restrict__ rec, const uint16_t* __restrict__ rec3, const uint16_t* __restrict__ priceTab, uint32_t* __restrict__ recOut, uint32_t* __restrict__ winCost, \
      const uint8_t* __restrict__ litPrice) \
