@@ -12,6 +12,7 @@ import oracle as O
 ap = argparse.ArgumentParser(); ap.add_argument("--seconds", type=float, default=60); ap.add_argument("--max-mib", type=float, default=24); ap.add_argument("--lib", default=""); ap.add_argument("--seed", type=int, default=7)
 a = ap.parse_args()
 pkg = g.load_package(); kw = {"lib_path": a.lib} if a.lib else {"device": 0}
+if a.lib and os.environ.get("GC_FUZZ_DEVICE"): kw["device"] = int(os.environ["GC_FUZZ_DEVICE"])      # a device library other than the shipped one (the hooks build)
 rng = np.random.default_rng(a.seed)
 text = O.corpus("text-zipf", 4 << 20); lz = O.corpus("lz-7zip", 4 << 20); sil = O.corpus("silesia-like", 211_900_000)[31_785_000:31_785_000 + (4 << 20)]   # PCM-like part
 os.makedirs(os.path.join(ROOT, "gpurun_out", "fuzz"), exist_ok=True)
