@@ -723,11 +723,20 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
             uint32_t maxLen = (nBlk - p) < GC_MATCH_CAP ? (nBlk - p) : GC_MATCH_CAP;
             if (TILE_LIMIT && maxLen > T.len - q) maxLen = T.len - q;
             const uint64_t cpos = (uint64_t)(wTile + q) - d;       // frame-relative position of the continued source
+            // (four 16-byte pieces of the source per round, not one: in phase B below ONE wave at a time walks a chain of these while the others wait at the barrier, and
+            //  a match that goes on for the whole cap was sixteen dependent loads -- on real sources this pass took as long as the whole entry loop.  A piece is read only
+            //  where the one-piece loop would have read it: offset < maxLen.)
             uint32_t len = 0;
             while (len < maxLen) {
-                const uint32_t more = lz_cmp16(mf_lds_ld16(sW, q + MF_STAGE_PAD + len), lz_ld16(wsrc, cpos + len));
+                const bool h1 = len + 16u < maxLen, h2 = len + 32u < maxLen, h3 = len + 48u < maxLen;
+                const LzW16 c0 = lz_ld16(wsrc, cpos + len), c1 = lz_ld16(wsrc, cpos + len + (h1 ? 16u : 0u)), c2 = lz_ld16(wsrc, cpos + len + (h2 ? 32u : 0u)), c3 = lz_ld16(wsrc, cpos + len + (h3 ? 48u : 0u));
+                uint32_t more = lz_cmp16(mf_lds_ld16(sW, q + MF_STAGE_PAD + len), c0);
+                bool full = more == 16u;
+                if (full && h1) { const uint32_t m = lz_cmp16(mf_lds_ld16(sW, q + MF_STAGE_PAD + len + 16u), c1); more += m; full = m == 16u; }
+                if (full && h2) { const uint32_t m = lz_cmp16(mf_lds_ld16(sW, q + MF_STAGE_PAD + len + 32u), c2); more += m; full = m == 16u; }
+                if (full && h3) { const uint32_t m = lz_cmp16(mf_lds_ld16(sW, q + MF_STAGE_PAD + len + 48u), c3); more += m; full = m == 16u; }
                 len += more;
-                if (more < 16u) break;
+                if (!full) break;
             }
             if (len > maxLen) len = maxLen;
             if (len < MINLEN || len + 2u < (cur & 0xFFu)) return false;

@@ -21,7 +21,8 @@ pkg = g.load_package()
 from importlib import util as _u
 spec = _u.spec_from_file_location("c", os.path.join(ROOT, "7-zip-zstd_amd", "corpus", "__init__.py"))
 cm = _u.module_from_spec(spec); spec.loader.exec_module(cm)
-x = cm.corpus(a.corpus, a.bytes)
+x = cm.real_corpus(a.corpus, a.bytes) if a.corpus in cm.REAL_KINDS else cm.corpus(a.corpus, a.bytes)
+if x.size < a.bytes: x = np.resize(x[:(x.size >> 23) << 23], a.bytes)      # real bytes tiled frame by frame to the size asked for
 fl2 = a.codec == "flzma2"
 br = a.codec == "brotli"
 enc = pkg.Flzma2Encoder(device=0, level=a.level or 5, lib_path=a.lib) if fl2 else (pkg.BrotliEncoder(device=0, level=a.level or 6, lib_path=a.lib) if br else pkg.ZstdEncoder(device=0, level=a.level or 3, lib_path=a.lib))
