@@ -276,19 +276,20 @@ public:
         if (!in || !out) return E_INVALIDARG;
         size_t piece = gc_multi_piece_bytes(codec(), level_);
         { const unsigned kib = test_env_u32("GC_PLUGIN_PIECE_KIB"); if (kib) piece = (size_t)kib << 10; }       // (test hook: pieces an emulator can chew)
-        // While the scheduler is still being created (warm_up_async), read ahead: pieces into ordinary memory, at most 16 of them / 1 GiB.  They are
-        // compressed first, in order, by the helper thread, while this thread goes on reading into the pinned buffers.
+        // While the scheduler is still being created (warm_up_async), read ahead: whole pieces back to back into ONE ordinary buffer, at most 16 of them /
+        // 1 GiB (reserved at once, touched as it fills).  They are compressed first by the helper thread -- a batch of pieces per call, so that every GPU
+        // context takes its piece as in the loop below -- while this thread goes on reading into the pinned buffers.
         warm_up_async();
-        struct Early { uint8_t* p; size_t n; } early[16]; unsigned nEarly = 0; size_t earlyBytes = 0; bool earlyEof = false;
-        struct EarlyFree { Early* e; unsigned* n; ~EarlyFree() { for (unsigned i = 0; i < *n; i++) free(e[i].p); } } earlyFree{ early, &nEarly };
-        while (shared() && shared()->multiState.load() == 0 && nEarly < 16u && earlyBytes + piece <= ((size_t)1 << 30) && !earlyEof) {
-            uint8_t* p = (uint8_t*)malloc(piece);
-            if (!p) break;
+        struct EarlyBuf { uint8_t* p = nullptr; ~EarlyBuf() { free(p); } } early;
+        size_t earlyBytes = 0; bool earlyEof = false;
+        size_t earlyMost = ((size_t)1 << 30) / piece; if (earlyMost > 16u) earlyMost = 16u; earlyMost *= piece;
+        while (shared() && shared()->multiState.load() == 0 && earlyBytes + piece <= earlyMost && !earlyEof) {
+            if (!early.p && !(early.p = (uint8_t*)malloc(earlyMost))) break;
             size_t got = piece;
-            const HRESULT r = read_full(in, p, &got);
-            if (r != S_OK) { free(p); return r; }
-            if (got == 0) { free(p); earlyEof = nEarly != 0u; break; }       // (an empty input goes through the loop below, which codes the empty stream)
-            early[nEarly].p = p; early[nEarly].n = got; nEarly++; earlyBytes += got;
+            const HRESULT r = read_full(in, early.p + earlyBytes, &got);
+            if (r != S_OK) return r;
+            if (got == 0) { earlyEof = earlyBytes != 0u; break; }             // (an empty input goes through the loop below, which codes the empty stream)
+            earlyBytes += got;
             if (got < piece) earlyEof = true;
         }
         int mrc = GC_OK;
@@ -306,7 +307,8 @@ public:
         BufLease lease; BufSet& B = lease.b;
         if (!buf_grow(&B.in[0], &B.inCap[0], batch, 0) || !buf_grow(&B.in[1], &B.inCap[1], batch, 0)) return E_OUTOFMEMORY;
         const size_t inCap = batch;
-        if (!buf_grow(&B.out, &B.outCap, gc_codec_compress_bound(codec(), inCap) + 1u, 0)) return E_OUTOFMEMORY;
+        const size_t earlyCall = earlyBytes < piece * perBatch ? earlyBytes : piece * perBatch;      // bytes of one call over the pieces read ahead
+        if (!buf_grow(&B.out, &B.outCap, gc_codec_compress_bound(codec(), inCap > earlyCall ? inCap : earlyCall) + 1u, 0)) return E_OUTOFMEMORY;
         uint8_t* const outBuf = B.out; const size_t outCap = B.outCap;
         uint64_t totalIn = 0, totalOut = 0;
         struct Job { std::thread th; HRESULT hr = S_OK; size_t got = 0, produced = 0; bool active = false; } job;
@@ -322,13 +324,16 @@ public:
         auto flags_of = [&](unsigned idx) -> unsigned {       // FLZMA2: one end marker behind the last call; plain brotli: the closing meta-block behind the last
             return kind_ == KIND_FLZMA2 ? GC_FLZMA2_NO_END_MARK : plainBrotli_ ? (GC_BROTLI_PLAIN | GC_BROTLI_NOT_LAST | (idx != 0 ? GC_BROTLI_NOT_FIRST : 0u)) : 0u;
         };
-        if (nEarly) {                                          // the pieces read ahead: one call each, in order, on the helper thread
+        if (earlyBytes) {                                      // the pieces read ahead: calls of one batch each, in order, on the helper thread
             job.got = earlyBytes; job.produced = 0; job.hr = S_OK; job.active = true;
-            const unsigned first = segIdx; segIdx += nEarly;
-            auto work = [this, multi, &early, nEarly, first, &flags_of, out, outBuf, outCap, &job]() {
-                for (unsigned i = 0; i < nEarly && job.hr == S_OK; i++) {
+            const unsigned first = segIdx; segIdx += (unsigned)((earlyBytes + earlyCall - 1u) / earlyCall);
+            const uint8_t* const ep = early.p;
+            auto work = [this, multi, ep, earlyBytes, earlyCall, first, &flags_of, out, outBuf, outCap, &job]() {
+                unsigned i = 0;
+                for (size_t off = 0; off < earlyBytes && job.hr == S_OK; off += earlyCall, i++) {
+                    const size_t n = earlyBytes - off < earlyCall ? earlyBytes - off : earlyCall;
                     size_t produced = 0; int rc;
-                    { std::lock_guard<std::mutex> g(shared()->gpu); rc = gc_multi_compress_host(multi, codec(), early[i].p, early[i].n, outBuf, outCap, level_, flags_of(first + i), 0, &produced); }
+                    { std::lock_guard<std::mutex> g(shared()->gpu); rc = gc_multi_compress_host(multi, codec(), ep + off, n, outBuf, outCap, level_, flags_of(first + i), 0, &produced); }
                     job.hr = rc != GC_OK ? hresult_of(rc) : write_all(out, outBuf, produced);
                     job.produced += produced;
                 }
@@ -456,7 +461,9 @@ public:
                 // (a piece whose frames regenerate more than kMaxContent is decoded a run of frames at a time; one frame beyond it is refused)
                 size_t cap = 0;
                 for (size_t i = 0; i < nFrames; i++) {
-                    const uint64_t fc = (frames_[i].flags & 2u) ? frames_[i].content_size : (uint64_t)frames_[i].n_blocks * (128u << 10);
+                    const uint64_t most = (uint64_t)frames_[i].n_blocks * (128u << 10);
+                    if ((frames_[i].flags & 2u) && frames_[i].content_size > most) return E_FAIL;      // a stated size the frame's blocks cannot regenerate: damaged (or forged to make this object pin gigabytes)
+                    const uint64_t fc = (frames_[i].flags & 2u) ? frames_[i].content_size : most;
                     if (fc > kMaxContent) return E_NOTIMPL;
                     if (cap + fc > kMaxContent) { consumed = (size_t)frames_[i].src_off; break; }
                     cap += (size_t)fc;

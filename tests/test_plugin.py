@@ -165,6 +165,20 @@ def test_zstd_decode_through_com_surface(O, emu_module, tmp_path, n):
     assert r.returncode == 15
 
 
+def test_zstd_decoder_refuses_a_forged_content_size(emu_module, tmp_path):
+    """A 17-byte stream whose frame header states 3.75 GiB of content over one 5-byte raw block: the decoder object must answer "damaged" (E_FAIL) from the
+    scan's block count -- a frame regenerates at most 128 KiB per block (zstd_decompress_block.c: blockSizeMax) -- and must not size (and pin) its output
+    buffer from the header first."""
+    forged = bytes([0x28, 0xB5, 0x2F, 0xFD, 0x80, 0x50]) + (0xF0000000).to_bytes(4, "little") + bytes([0x29, 0x00, 0x00]) + b"hello"
+    src = tmp_path / "forged.zst"; src.write_bytes(forged)
+    r = _host(emu_module, "decode", "ZSTD", "-", src, tmp_path / "forged.out")
+    assert r.returncode == 15 and "80004005" in r.stderr, r.stderr + r.stdout
+    honest = bytes([0x28, 0xB5, 0x2F, 0xFD, 0x80, 0x50]) + (5).to_bytes(4, "little") + bytes([0x29, 0x00, 0x00]) + b"hello"
+    src.write_bytes(honest)
+    r = _host(emu_module, "decode", "ZSTD", "-", src, tmp_path / "honest.out")
+    assert r.returncode == 0 and (tmp_path / "honest.out").read_bytes() == b"hello", r.stderr + r.stdout
+
+
 def test_zstd_encode_then_decode_through_com_surface(O, emu_module, tmp_path):
     x = O.corpus("text-zipf", 3 * BLK + 17)
     src, mid, props, dst = tmp_path / "in.bin", tmp_path / "mid.zst", tmp_path / "props.bin", tmp_path / "out.bin"
