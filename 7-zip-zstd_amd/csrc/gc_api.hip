@@ -1208,8 +1208,10 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
     size_t i = 0;
     uint64_t batchCap = GC_ZD_BATCH_BYTES;
     { uint32_t v = 0; if (gc_env_u32("GC_ZD_BATCH_KIB", 1u, 4u << 20, &v)) batchCap = (uint64_t)v << 10; }       // test hook: small batches
+    bool serialRetry = false;                                    // the batch at hand is being decoded a second time, the execution kernel behind the entropy kernels
     while (i < nFrames && rc == GC_OK) {
         // a batch: frames that state their content size (up to batchCap bytes of content, at least one frame), closed by at most one that does not
+        const uint64_t dstOffBatch = dstOff;
         size_t j = i; uint64_t off = dstOff, nBlocks = 0;
         for (; j < nFrames; j++) {
             const gc_zstd_frame& f = frames[j];
@@ -1258,6 +1260,7 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
         overlap = false;
 #endif
         { uint32_t v = 0; if (gc_env_u32("GC_ZD_OVERLAP", 0, 1, &v)) overlap = overlap && v != 0u; }
+        if (serialRetry) overlap = false;
         // The wide execution (all blocks of all frames at once through byte pointers and pointer jumping, see gc_zstd_dec.hip) instead of one workgroup
         // per frame that copies its blocks in order (~0.27 GB/s per frame): 1 GB in 120 frames 13.7 ms against 49 ms, and it does not care how few
         // the frames are (one frame of 128 MiB: 4.7 against 460 ms).  It needs 4 bytes of workspace per content byte; frames of one block each stay
@@ -1356,15 +1359,25 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
         if (hipEventElapsedTime(&ms, c->evPart[1][2], c->evPart[0][1]) == hipSuccess) c->zdKms[1] += ms;
         if (hipEventElapsedTime(&ms, c->evPart[0][0], c->evPart[1][1]) == hipSuccess) c->zdKms[2] += ms;
         if (hipEventElapsedTime(&ms, c->evPart[1][3], c->evPart[1][4]) == hipSuccess) c->zdKms[3] += ms;
+        bool retryNow = false;
+        uint32_t failFirst = 0; gc_env_u32("GC_ZD_FAIL_FIRST", 1u, 1u, &failFirst);            // test hook: the first pass over a batch reports its first frame as damaged
         for (size_t k = 0; k < cnt; k++) {
-            const uint32_t st = (uint32_t)(res[k] >> 56);
+            uint32_t st = (uint32_t)(res[k] >> 56);
+            if (failFirst && !serialRetry && k == 0u) st = GC_ZD_CORRUPT;
             const uint64_t produced = res[k] & 0x00FFFFFFFFFFFFFFull;
             if (st == GC_ZD_OK) { dstOff = h[i + k].dstOff + produced; continue; }
+            // The execution kernel that starts before the entropy kernels gives up (and reports its frame as damaged) when their blocks do not arrive --
+            // which is what happens to a sound stream where launches are serialised (rocprofv3 --pmc: run r4pmcdec, the self-check frame failed this
+            // way) or another process holds the device.  Such a batch is decoded once more with the kernels one after the other before it is
+            // called damaged; a damaged stream fails again, one pass later.
+            if (((overlap && !wide) || failFirst) && !serialRetry) { retryNow = true; break; }
             snprintf(c->err, sizeof(c->err), "frame %zu: %s", i + k, st == GC_ZD_DST_SMALL ? "destination too small" : st == GC_ZD_CHECKSUM ? "content checksum mismatch" :
                      st == GC_ZD_SIZE ? "content size field does not match" : st == GC_ZD_UNSUPPORTED ? "unsupported frame" : "corrupted data");
             rc = st == GC_ZD_DST_SMALL ? GC_ERR_DST_SMALL : (st == GC_ZD_UNSUPPORTED ? GC_ERR_PARAM : GC_ERR_CORRUPT);
             break;
         }
+        if (retryNow) { serialRetry = true; dstOff = dstOffBatch; continue; }               // the same frames again
+        serialRetry = false;
         i = j;
     }
     free(h); free(res);

@@ -299,6 +299,36 @@ def test_gpu_damaged_streams_are_refused(pkg, O, gpu_dec):
     _check(gpu_dec, bytes(comp), x)                                            # the context still works afterwards
 
 
+def _serial_retry(pkg, O, lib_kw, monkeypatch, n):
+    """A batch whose overlapped execution kernel reports a frame as damaged (it gives up when the entropy kernels' blocks do not arrive: serialised
+    launches under a profiler, a device shared with another process) is decoded once more with the kernels one after the other before the stream is
+    called damaged.  The hook makes the first pass over every batch fail: sound streams of every shape must still come out whole (frames of several
+    blocks, frames of one block, small batches -- the retry starts again at the batch's first output byte), a damaged one must still be refused."""
+    monkeypatch.setenv("GC_ZD_FAIL_FIRST", "1")
+    x = _corpus(O, "silesia-like", n).tobytes()
+    for batch_kib in (None, "256"):
+        if batch_kib: monkeypatch.setenv("GC_ZD_BATCH_KIB", batch_kib)
+        dec = pkg.ZstdDecoder(**lib_kw)
+        try:
+            _check(dec, O.ref_zstd_compress(x, 3).tobytes(), x)
+            _check(dec, O.ref_zstd_compress(x, 3, piece=100_000).tobytes(), x)
+            _check(dec, O.ref_zstd_compress_opts(x, 5, checksum=True, streamed=True).tobytes(), x)
+            bad = bytearray(O.ref_zstd_compress_opts(x, 3, checksum=True).tobytes()); bad[len(bad) // 2] ^= 0x10
+            with pytest.raises(pkg.GpuCodecError):
+                dec.code(bytes(bad), capacity=len(x) + 64)
+        finally:
+            dec.close()
+
+
+def test_emu_serial_retry_of_a_batch(pkg, O, emu_lib_path, monkeypatch):
+    _serial_retry(pkg, O, dict(lib_path=emu_lib_path), monkeypatch, 700_000)
+
+
+@pytest.mark.gpu
+def test_gpu_serial_retry_of_a_batch(pkg, O, gpu_dec, gpu_hooks_kw, monkeypatch):
+    _serial_retry(pkg, O, gpu_hooks_kw, monkeypatch, 5 * MiB + 11)
+
+
 def test_emu_decoder_selfcheck(emu_dec):
     """every context decodes a built-in frame of the reference's encoder through the six-blocks-per-wave sequences kernel before it trusts it"""
     assert emu_dec.selfcheck() == 1
