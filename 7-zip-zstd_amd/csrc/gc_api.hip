@@ -966,11 +966,15 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     uint32_t frameBlocks = brotli_frame_blocks(level, bpcFinder);
     c->lazyDepth = level >= 7 ? 2u : 1u;
     c->halfList = 0; c->mfFast = level <= 6 ? 1u : 0u;        // (qualities 5-6 run the far pass on the fast geometry: 0.97-0.99 x the reference at 15 % less time than on the wide one)
-    // W5b from quality 7: four links (eight from quality 10) for the starts of matches in tiles with long matches, two elsewhere.  Qualities 5-6 stay without it: measured
-    // at quality 6 with (8, 0) (run r03_q3): sources 1.084 -> 1.068 x the reference and the Python library 1.024 -> 1.015, but web-text -- config C5's data, whose boilerplate
+    // W5b from quality 7: four links (eight from quality 10) for the starts of matches in tiles with long matches, two elsewhere.  Quality 5 stays without it (round 3 measured
+    // quality 6 with (8, 0) (run r03_q3): sources 1.084 -> 1.068 x the reference and the Python library 1.024 -> 1.015, but web-text -- config C5's data, whose boilerplate
     // makes most tiles "long" -- 16.6 -> 9.4 GB/s for 0.3 % of its size
-    c->searchDepth = level >= 7 ? (level >= 10 ? 8u : 4u) : 0u; c->searchShallow = c->searchDepth < 2u ? c->searchDepth : 2u;
+    // Quality 6 follows ONE link everywhere since round 4 (run r4brd / r4brd3, 64 MiB per corpus, web-text 500 MB): real Python library 1.024 -> 1.015 x the reference (inside the
+    // band), real sources 1.084 -> 1.069, shared objects 1.106 -> 1.101, web-text 17.0 -> 14.5 GB/s (W5b 5.0 ms per 500 MB).  One link for the starts of matches only:
+    // 1.020 / 1.076 / 1.104 at 15.0 GB/s; two links: 1.010 / 1.062 / 1.099 at 12.9; four (starts only beyond two): 1.009 / 1.059 / 1.098 at 11.4.  Quality 5 stays without.
+    c->searchDepth = level >= 7 ? (level >= 10 ? 8u : 4u) : (level == 6 ? 1u : 0u); c->searchShallow = c->searchDepth < 2u ? c->searchDepth : 2u;
     if (gc_env_u32("GC_SEARCH_DEPTH", 0u, 64u, &c->searchDepth)) c->searchShallow = c->searchDepth < 2u ? c->searchDepth : 2u;      // test hook
+    gc_env_u32("GC_SEARCH_SHALLOW", 0u, 64u, &c->searchShallow);                                // test hook: links followed by the positions inside a match and in tiles without long matches
     c->farPass = level >= 5 ? 1u : 0u; c->shortPass = 0;      // longer matches stand in for the context modelling / block splitting B1 lacks
     gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass);                                            // test hook
     c->laneParse = 0u; c->lastCodecHint = 2; c->priceMinLen = 3u; c->priceLitCtx = 0u;     // copies of >= 3 bytes (a 2-byte copy at a fresh distance never pays in brotli), one literal code per meta-block

@@ -15,9 +15,9 @@ CASES = [("real-src", 64 * MiB), ("real-bin", 211_900_000), ("real-py", 64 * MiB
 NOT_YET = {("flzma2", "real-src"): "0.998 x the reference in round 4 (1.018 in round 3): inside the band, the entry stays as a guard",
            ("flzma2", "real-bin"): "1.026 x the reference on all 211.9 MB (1.020 on the first 64 MiB; round 4: the lane-per-window parse W7L carries four repeat distances per node, L2 codes rep0..rep3 and chooses lc / lp per segment; 1.054 in round 3).  What is left is static per-block prices against the reference's adaptive ones: tables of records 1.04-1.08, tools/lzma_parse_lab.c LAB_OPT_STATIC",
            ("flzma2", "real-py"): "1.008 x the reference in round 4 (1.017 in round 3): inside the band, the entry stays as a guard",
-           ("brotli", "real-src"): "1.084 x the reference (run r03_q1; 1.236 before the continuation of capped matches and the distance ring codes): one meta-block with its three prefix codes per 128 KiB of input, where the reference's meta-blocks grow to megabytes on data of ratio 10",
-           ("brotli", "real-bin"): "1.106 x the reference (its hasher tries the last distances first at every position; here they are only coded when the parse happens to repeat them)",
-           ("brotli", "real-py"): "1.024 x the reference"}
+           ("brotli", "real-src"): "1.069 x the reference (round 4, run r4brd: quality 6 follows one match link; 1.084 in round 3, 1.236 before the continuation of capped matches and the distance ring codes).  Meta-blocks over groups of blocks were built and measured: no gain (tools/experiments); the gap is in the matches and the literal contexts",
+           ("brotli", "real-bin"): "1.101 x the reference (round 4; 1.106 in round 3: its hasher tries the last distances first at every position; here they are only coded when the parse happens to repeat them)",
+           ("brotli", "real-py"): "1.015 x the reference in round 4 (1.024 in round 3): inside the band, the entry stays as a guard"}
 
 
 @pytest.fixture(scope="module")
