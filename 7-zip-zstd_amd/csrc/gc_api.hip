@@ -97,7 +97,7 @@ extern "C" __global__ void gc_lzma2_emit_kernel(const uint8_t*, uint32_t, const 
                                                 uint32_t, const uint64_t*, uint8_t*, const uint8_t*);
 
 extern "C" __global__ void gc_brotli_block_kernel(const uint8_t*, uint64_t, const GcSeqRaw*, const uint8_t*, const GcBlockMeta*, uint64_t*, uint32_t*,
-                                                  uint32_t, uint32_t, uint32_t*, GcBrotliBlockInfo*);
+                                                  uint32_t, uint32_t, uint32_t, uint32_t*, GcBrotliBlockInfo*);
 extern "C" __global__ void gc_brotli_plan_kernel(const GcBrotliBlockInfo*, uint32_t, uint32_t, uint64_t, GcBrotliPlan*, uint64_t*);
 extern "C" __global__ void gc_brotli_emit_kernel(const uint8_t*, uint64_t, const uint8_t*, const GcBrotliBlockInfo*, const GcBrotliPlan*, uint32_t,
                                                  uint32_t, uint32_t, const uint64_t*, uint8_t*);
@@ -987,8 +987,11 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     rc = launch_finder(c, src, n, frameBlocks, nullptr);
     if (rc != GC_OK) return rc;
     HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    uint32_t brRepSub = 1u;                                    // B1's last-distance substitution (gc_brotli.hip): one pass (emulator, 2 MiB, quality 6: shared objects 1.0925 -> 1.0788 x the reference,
+                                                               // sources 1.0499 -> 1.0461; a second pass: 1.0771 / 1.0455 for as much time again)
+    gc_env_u32("GC_BR_REPSUB", 0u, 4u, &brRepSub);                                             // test hook
     GC_LAUNCH(gc_brotli_block_kernel, nBlocks, 256, c->stream, src, (uint64_t)n, (const GcSeqRaw*)c->seqRaw, (const uint8_t*)c->lit,
-              (const GcBlockMeta*)c->meta, c->seqPacked, c->seqOff, bpc, c->optBrotliPlain, (uint32_t*)c->brStage, c->brInfo);
+              (const GcBlockMeta*)c->meta, c->seqPacked, c->seqOff, bpc, c->optBrotliPlain, brRepSub, (uint32_t*)c->brStage, c->brInfo);
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     GC_LAUNCH(gc_brotli_plan_kernel, 1, 1024, c->stream, (const GcBrotliBlockInfo*)c->brInfo, nBlocks, bpc, (uint64_t)dstCap, c->brPlan, c->result);
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));

@@ -111,6 +111,16 @@ __device__ __forceinline__ uint32_t br_ring_code(const uint64_t* P, uint32_t j, 
     return 0u;
 }
 
+// eight source bytes from any address; are two byte ranges of the source equal (8 bytes at a time, never a byte beyond n)
+__device__ __forceinline__ uint64_t br_ld8(const uint8_t* p) { uint64_t w; __builtin_memcpy(&w, p, 8); return w; }
+__device__ __forceinline__ bool br_same(const uint8_t* a, const uint8_t* c, uint32_t n)
+{
+    uint32_t i = 0;
+    for (; i + 8u <= n; i += 8u) if (br_ld8(a + i) != br_ld8(c + i)) return false;
+    for (; i < n; i++) if (a[i] != c[i]) return false;
+    return true;
+}
+
 // OR up to 64 bits into the (zero-initialised) global bit buffer at absolute bit offset `pos`
 __device__ __forceinline__ void br_or_bits(uint32_t* buf, uint64_t pos, uint64_t v, uint32_t nbits)
 {
@@ -300,7 +310,7 @@ gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
                        uint64_t* __restrict__ seqPacked /* scratch: GC_MAX_SEQ_PER_BLOCK per block */,
                        uint32_t* __restrict__ seqLitStart /* scratch: GC_MAX_SEQ_PER_BLOCK per block */,
                        uint32_t blocksPerChunk /* 0xFFFFFFFF: ONE plain stream (no brotli-mt chunks) */, uint32_t plainFlags /* plain stream: bit 1 = this call is
-                       not its first piece (no stream header), bit 2 = not its last (no closing meta-block) */,
+                       not its first piece (no stream header), bit 2 = not its last (no closing meta-block) */, uint32_t repSub /* passes of the last-distance substitution */,
                        uint32_t* __restrict__ stage /* zeroed, GC_BR_STAGE_STRIDE bytes per block */, GcBrotliBlockInfo* __restrict__ info)
 {
     __shared__ uint32_t hLit[256], hCmd[704], hDist[64];
@@ -361,6 +371,58 @@ gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
     const uint32_t nCmd = nSeq + (tailLen ? 1u : 0u);
     if (t == 0 && tailLen) { P[nSeq] = (uint64_t)tailLen; LS[nSeq] = litBeforeTail; }
     __syncthreads();
+
+    // ---- last-distance substitution (round 4; repSub passes): a copy of up to BR_SUB_MAX bytes whose bytes ALSO match at the previous command's distance
+    //      takes that distance -- the same bytes come out, the parse keeps its shape, and the distance costs symbol 0 (or an implicit cell) instead of a code with
+    //      extra bits.  The reference's hasher gets there by testing the last distances FIRST at every position (hash_longest_match64_inc.h:185); here the finder
+    //      knows no parse, so the test runs on the commands.  A command's copy starts at blockBase + LS[j] + ll_j + (sum of the copy lengths in front of it):
+    //      one scan per tile of commands.  Decisions of a pass use the distances as the pass found them (all reads of a tile, then its stores); any
+    //      distance whose bytes match is valid whatever the neighbours did, a second pass picks up runs.
+#define BR_SUB_MAX 512u
+    for (uint32_t pass = 0; pass < repSub; pass++) {
+        uint32_t carryM = 0;
+        for (uint32_t tb = 0; tb < nSeq; tb += BR_T) {
+            const uint32_t j = tb + t;
+            uint32_t ml = 0, ll = 0, off = 0, prevOff = 0;
+            if (j < nSeq) {
+                const uint64_t pk = P[j];
+                ll = (uint32_t)(pk & 0x3FFFFu); ml = (uint32_t)((pk >> 18) & 0x3FFFFu); off = (uint32_t)(pk >> 36) & 0xFFFFFFu;
+                if (j) prevOff = (uint32_t)(P[j - 1u] >> 36) & 0xFFFFFFu;
+            }
+            uint32_t totM;
+            const uint32_t before = carryM + br_excl_scan(ml, sWave, &totM);
+            uint32_t subOff = 0;
+            if (j >= 1u && j < nSeq && prevOff != off && ml <= BR_SUB_MAX) {
+                const uint64_t pos = blockBase + LS[j] + ll + before;
+                const uint8_t* a = src + pos;
+                // the distances of the three commands in front, nearest first (the second / third of them are ring entries 1 / 2 where they differ: br_ring_code);
+                // the walk ends at a command that is no copy or has this command's own distance (nothing to gain further back).  The first eight bytes of
+                // the three candidates are fetched together, the rest is compared for the first one that passes
+                uint32_t d[3] = { 0u, 0u, 0u };
+                for (uint32_t k = 1; k <= 3u && k <= j; k++) {
+                    const uint32_t dk = (uint32_t)(P[j - k] >> 36) & 0xFFFFFFu;
+                    if (dk == 0u || dk == off) break;
+                    d[k - 1u] = dk;
+                }
+                const bool wide = pos + 8u <= srcSize;                                 // (the copy may end with the input: no 8-byte read across that end)
+                const uint64_t mask = ml >= 8u ? ~0ull : ((1ull << (8u * ml)) - 1ull);
+                uint64_t wa = 0, wc[3] = { 0, 0, 0 };
+                if (wide) { wa = br_ld8(a); for (int k = 0; k < 3; k++) if (d[k]) wc[k] = br_ld8(a - d[k]); }
+                for (int k = 0; k < 3 && subOff == 0u; k++) {
+                    if (d[k] == 0u) break;
+                    const uint8_t* c = a - d[k];
+                    bool same;
+                    if (wide) same = ((wa ^ wc[k]) & mask) == 0ull && (ml <= 8u || br_same(a + 8, c + 8, ml - 8u));
+                    else same = br_same(a, c, ml);
+                    if (same) subOff = d[k];
+                }
+            }
+            __syncthreads();
+            if (subOff) P[j] = (P[j] & ~(0xFFFFFFull << 36)) | ((uint64_t)subOff << 36);
+            __syncthreads();
+            carryM += totM;
+        }
+    }
 
     // ---- short distance codes (round 3): bits 60..63 of a packed command (distances have 24 bits: WBITS = 24).  Computed a tile of commands at a
     //      time -- all reads of the tile's walks, then the stores (a walk reads the distance fields only, which never change)
