@@ -106,6 +106,33 @@ def test_emu_deterministic(O, emu_br):
     assert np.array_equal(emu_br[6].code(x), emu_br[6].code(x))
 
 
+def test_emu_last_distance_substitution(pkg, O, emu_lib_path, monkeypatch):
+    """B1 gives a copy the distance of one of the three commands in front when its bytes match there too (same bytes out, same parse, a cheaper distance code).  On
+    records of a fixed stride -- where the finder's nearest candidate and the parse's last distance differ all the time -- the stream must get smaller than with the
+    step switched off (hook GC_BR_REPSUB=0), on text it must stay where it was (within 0.05 %), and every stream must decode under the reference decoder."""
+    _need_ref(O)
+    rng = np.random.default_rng(5)
+    rec = rng.integers(0, 256, size=(6000, 24), dtype=np.uint8)
+    rec[:, :10] = rec[0, :10]; rec[:, 14:20] = (np.arange(6000)[:, None] >> np.array([0, 8, 16, 0, 8, 16])) & 0xFF      # tables of records: constant fields, counters, noise
+    cases = (("records", rec.reshape(-1).copy()), ("text", O.corpus("text-zipf", 3 * BLK + 5)), ("objects", O.corpus("real-bin", 4 * BLK)))
+    for name, x in cases:
+        if x.size < BLK:
+            continue                                                                                                        # (the image holds no such data)
+        sizes = {}
+        for passes in ("0", "1", "2"):
+            monkeypatch.setenv("GC_BR_REPSUB", passes)
+            e = pkg.BrotliEncoder(lib_path=emu_lib_path, level=6)
+            try:
+                c = e.code(x)
+            finally:
+                e.close()
+            assert np.array_equal(O.ref_brotlimt_decompress(c, x.size, 2), x), (name, passes)
+            sizes[passes] = len(c)
+        assert sizes["1"] <= sizes["0"] * 1.0005 and sizes["2"] <= sizes["0"] * 1.0005, (name, sizes)       # (the prefix codes move with the symbols: a few bytes either way where nothing is gained)
+        if name != "text":
+            assert sizes["1"] < sizes["0"], (name, sizes)
+
+
 def test_golden_fixtures_decode_under_reference(O):
     """the reference's own regression fixtures (tests/regr-arc/test.txt.br, .br-mt.br) pin the decoder side of the oracle"""
     _need_ref(O)
