@@ -990,7 +990,7 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     uint32_t brRepSub = 2u;                                    // B1's last-distance substitution (gc_brotli.hip): two passes.  Emulator, quality 6, x the reference, passes 0 / 1 / 2 / 3 / 4: shared objects
                                                                // 8 MiB 1.1262 / 1.1095 / 1.0969 / 1.0919 / 1.0888 (2 MiB: 1.0925 / 1.0788 / 1.0771), sources 8 MiB 1.1594 / 1.1439 / 1.1392; a pass carries a
                                                                // distance three commands further along a run of records and costs 0.86 ms per 500 MB on the device (B1 5.4 ms without)
-    gc_env_u32("GC_BR_REPSUB", 0u, 4u, &brRepSub);                                             // test hook
+    gc_env_u32("GC_BR_REPSUB", 0u, 64u, &brRepSub);                                             // test hook
     GC_LAUNCH(gc_brotli_block_kernel, nBlocks, 256, c->stream, src, (uint64_t)n, (const GcSeqRaw*)c->seqRaw, (const uint8_t*)c->lit,
               (const GcBlockMeta*)c->meta, c->seqPacked, c->seqOff, bpc, c->optBrotliPlain, brRepSub, (uint32_t*)c->brStage, c->brInfo);
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
