@@ -89,10 +89,11 @@ extern "C" __global__ void gc_mf_dpl3_kernel(const uint8_t*, uint64_t, uint32_t,
 extern "C" __global__ void gc_mf_dpl3s_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*);
 
 extern "C" __global__ void gc_lzma2_prep_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t, uint64_t*, uint32_t*);
-extern "C" __global__ void gc_lzma2_model_kernel(const uint8_t*, uint64_t, const uint64_t*, const uint32_t*, uint32_t, uint32_t, uint16_t*, GcLzmaChunkInfo*, const uint32_t*, unsigned long long*, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t);
+extern "C" __global__ void gc_lzma2_model_kernel(const uint8_t*, uint64_t, const uint64_t*, const uint32_t*, uint32_t, uint32_t, uint16_t*, GcLzmaChunkInfo*, const uint32_t*, unsigned long long*, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t, uint32_t, uint32_t);
+extern "C" __global__ void gc_lzma2_segkind_kernel(const GcLzmaChunkInfo*, const uint8_t*, uint32_t, uint32_t, uint8_t*);
 extern "C" __global__ void gc_lzma2_rc_kernel(uint16_t*, uint32_t, uint32_t, uint8_t*, GcLzmaChunkInfo*);
 extern "C" __global__ void gc_lzma2_rc_fin_kernel(const uint16_t*, uint32_t, uint32_t, uint8_t*, GcLzmaChunkInfo*);
-extern "C" __global__ void gc_lzma2_plan_kernel(const GcLzmaChunkInfo*, uint32_t, uint32_t, uint64_t, uint32_t, GcLzmaPlan*, uint64_t*);
+extern "C" __global__ void gc_lzma2_plan_kernel(const GcLzmaChunkInfo*, uint32_t, uint32_t, uint64_t, uint32_t, GcLzmaPlan*, uint64_t*, const uint8_t*, const uint8_t*);
 extern "C" __global__ void gc_lzma2_emit_kernel(const uint8_t*, uint32_t, const uint8_t*, const GcLzmaChunkInfo*, const GcLzmaPlan*, uint32_t,
                                                 uint32_t, const uint64_t*, uint8_t*, const uint8_t*);
 
@@ -301,7 +302,7 @@ static int ensure_workspace(gc_ctx* c, uint32_t nBlocks)
         hipMalloc((void**)&c->brStage, nb * GC_BR_STAGE_STRIDE) != hipSuccess ||
         hipMalloc((void**)&c->brInfo, nb * sizeof(GcBrotliBlockInfo)) != hipSuccess ||
         hipMalloc((void**)&c->brPlan, nb * sizeof(GcBrotliPlan)) != hipSuccess ||
-        hipMalloc((void**)&c->lzProps, nb * (GC_ZSTD_BLOCK_MAX >> GC_LZMA_SEG_LOG_MIN)) != hipSuccess ||
+        hipMalloc((void**)&c->lzProps, 2u * nb * (GC_ZSTD_BLOCK_MAX >> GC_LZMA_SEG_LOG_MIN)) != hipSuccess ||      // (second half: LZMA / stored per model segment, gc_lzma2_segkind_kernel)
         hipMalloc((void**)&c->lzNM, nb * sizeof(uint32_t)) != hipSuccess ||
         hipMalloc((void**)&c->lzInfo, nb * GC_LZMA_RC_PER_BLOCK * sizeof(GcLzmaChunkInfo)) != hipSuccess ||
         hipMalloc((void**)&c->lzPlan, nb * GC_LZMA_RC_PER_BLOCK * sizeof(GcLzmaPlan)) != hipSuccess) {
@@ -334,7 +335,7 @@ static int mf_grow(gc_ctx* c, void** p, size_t* cap, size_t needBytes, const cha
 // workspace of the windowed finder for n input bytes
 static int ensure_finder_workspace(gc_ctx* c, size_t n, uint32_t frameBlocks)
 {
-    if (frameBlocks <= 1u) return GC_OK;
+    if (MF_F(frameBlocks) <= 1u) return GC_OK;                  // (frameBlocks: F, or F | S << 8 | C << 16 -- overlapping frames, gc_mf.h)
     const GcMfGeom g = gc_mf_geom(n, frameBlocks, c->mfFast != 0u);
     const size_t needCnt = g.cntWords * sizeof(uint32_t), needEnt = (size_t)g.nFrames * g.frameBytes * sizeof(GcMfEntry);
     const size_t needRec = (size_t)g.nBlocks * GC_ZSTD_BLOCK_MAX * sizeof(uint32_t);
@@ -364,18 +365,20 @@ static int ensure_finder_workspace(gc_ctx* c, size_t n, uint32_t frameBlocks)
 
 // Match finder for one part of the input: `src` / `n` are the part, blk0 its first block (a multiple of frameBlocks: parts are
 // whole frames, so everything inside is relative to the part and only the workspace pointers are offset).
-static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const uint8_t* src, size_t n, uint32_t frameBlocks, uint32_t blk0, unsigned long long* prof)
+static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const uint8_t* src, size_t n, uint32_t frameArg /* F, or F | S << 8 | C << 16: overlapping frames (gc_mf.h) */, uint32_t blk0, unsigned long long* prof)
 {
+    const uint32_t frameBlocks = frameArg;                           // what W1..W5b take (they decode it: mf_tile)
+    const uint32_t groupBlocks = MF_C(frameArg);                     // what the stages behind the finder call a frame: matches reach back to the start of the GROUP
     const uint32_t nBlocks = gc_num_blocks(n);
     GcSeqRaw* seqRaw = c->seqRaw + (size_t)blk0 * GC_MAX_SEQ_PER_BLOCK;
     uint8_t* lit = c->lit + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
     GcBlockMeta* meta = c->meta + blk0;
-    if (frameBlocks <= 1u) {
+    if (MF_F(frameArg) <= 1u) {
         GC_LAUNCH(gc_zstd_lz_kernel, nBlocks, 1024, st, src, (uint64_t)n, seqRaw, lit, meta, prof);
         return GC_OK;
     }
     const GcMfGeom g = gc_mf_geom(n, frameBlocks, c->mfFast != 0u);
-    const uint32_t frame0 = blk0 / frameBlocks;
+    const uint32_t frame0 = (blk0 / groupBlocks) * MF_FPG(frameArg);       // (parts are whole groups)
     uint32_t* cnt = c->mfCnt + ((size_t)frame0 * (g.tilesPerFrame + 1u) << g.partLog);
     GcMfEntry* ent = c->mfEnt + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
     GcMfEntry* ent2 = c->mfEnt2 + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
@@ -406,7 +409,7 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
     // the levels that parse the first pass's records as they are: verify + parse in one kernel, the records stay in LDS (W5 + W6 fused)
     uint32_t fused = (!c->halfList && !c->farPass && !c->searchDepth && !c->priceParse && !c->shortPass) ? 1u : 0u;
     gc_env_u32("GC_FUSED_PARSE", 0u, 1u, &fused);               // test hook: 0 = the two kernels
-    if (fused && (c->halfList || c->farPass || c->searchDepth || c->priceParse || c->shortPass)) fused = 0u;
+    if (fused && (c->halfList || c->farPass || c->searchDepth || c->priceParse || c->shortPass || MF_C(frameArg) != MF_F(frameArg))) fused = 0u;
     if (fused) {
         uint32_t mode = 2u; gc_env_u32("GC_FUSED_MODE", 1u, 2u, &mode);       // test hook: 1 = a workgroup per block (tiles in order), 2 = a workgroup per tile
         if (mode == 2u) {
@@ -468,7 +471,7 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
         GC_LAUNCH(gc_mf_parse_kernel, perB * GC_XCDS, GC_MF_PARSE_T, st, src, (uint64_t)n, nBlocks, perB, c->lazyDepth, (const uint32_t*)rec, seqRaw, lit, meta, price, litCtxArg);
         HIPCHK(c, hipEventRecord(ev[7], st));
         const uint32_t nChunkWg = (uint32_t)(((n + 2047u) / 2048u + 3u) / 4u), perC = gc_xcd_per(nChunkWg);
-        GC_LAUNCH(gc_mf_short_kernel, perC * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, (uint32_t)((n + 2047u) / 2048u), perC, rec3);
+        GC_LAUNCH(gc_mf_short_kernel, perC * GC_XCDS, 256, st, src, (uint64_t)n, groupBlocks, (uint32_t)((n + 2047u) / 2048u), perC, rec3);
         HIPCHK(c, hipEventRecord(ev[8], st));
         // W7 in two phases: A = a sample of the windows (one workgroup of 4 windows per block) under optimistic prices, counting the symbols of its
         // paths; B = every window under prices made from those counts (gc_lz_price.hip)
@@ -493,22 +496,22 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
                 const bool select = laneDp == 2u && phase == 1u && !w2;
                 const uint32_t phaseK = phase | (w2 ? 16u : 0u) | (select ? GC_DP_SELECT : 0u);
                 if (select) {                                      // the blocks without repeats: W7
-                    if (c->priceMinLen <= 2u) GC_LAUNCH(gc_mf_dp2_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, frameBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
-                    else GC_LAUNCH(gc_mf_dp3_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, frameBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
+                    if (c->priceMinLen <= 2u) GC_LAUNCH(gc_mf_dp2_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, groupBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
+                    else GC_LAUNCH(gc_mf_dp3_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, groupBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
                 }
                 if (c->priceMinLen <= 2u) {
-                    if (phase == 0u) GC_LAUNCH(gc_mf_dpl2s_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
-                    else GC_LAUNCH(gc_mf_dpl2_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
+                    if (phase == 0u) GC_LAUNCH(gc_mf_dpl2s_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
+                    else GC_LAUNCH(gc_mf_dpl2_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
                 } else if (c->lastCodecHint == 0) {
-                    if (phase == 0u) GC_LAUNCH(gc_mf_dplzs_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
-                    else GC_LAUNCH(gc_mf_dplz_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
+                    if (phase == 0u) GC_LAUNCH(gc_mf_dplzs_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
+                    else GC_LAUNCH(gc_mf_dplz_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
                 } else {
-                    if (phase == 0u) GC_LAUNCH(gc_mf_dpl3s_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
-                    else GC_LAUNCH(gc_mf_dpl3_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, frameBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
+                    if (phase == 0u) GC_LAUNCH(gc_mf_dpl3s_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
+                    else GC_LAUNCH(gc_mf_dpl3_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
                 }
             } else
-            if (c->priceMinLen <= 2u) GC_LAUNCH(gc_mf_dp2_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
-            else GC_LAUNCH(gc_mf_dp3_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, frameBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
+            if (c->priceMinLen <= 2u) GC_LAUNCH(gc_mf_dp2_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, groupBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
+            else GC_LAUNCH(gc_mf_dp3_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, groupBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
         }
         HIPCHK(c, hipEventRecord(ev[9], st));
         GC_LAUNCH(gc_mf_parse_kernel, perB * GC_XCDS, GC_MF_PARSE_T, st, src, (uint64_t)n, nBlocks, perB, 0u, (const uint32_t*)dp, seqRaw, lit, meta, (uint16_t*)nullptr, 0u);
@@ -527,7 +530,7 @@ static int launch_finder(gc_ctx* c, const uint8_t* src, size_t n, uint32_t frame
     if (rc != GC_OK) return rc;
     rc = launch_finder_part(c, c->stream, 0, src, n, frameBlocks, 0, prof);
     if (rc != GC_OK) return rc;
-    c->mfTimed = frameBlocks > 1u; c->mfParts = 1; c->mfPriced = c->mfTimed && c->priceParse != 0u;
+    c->mfTimed = MF_F(frameBlocks) > 1u; c->mfParts = 1; c->mfPriced = c->mfTimed && c->priceParse != 0u;
     return GC_OK;
 }
 
@@ -573,6 +576,12 @@ extern "C" int gc_mf_pass_timing(gc_ctx* c, float ms[4])
 // 512 KiB / 1 MiB windows of the reference's levels 1 / 2 (clevels.h:26-27): 1.026 x its level 1 on text, 1.085 x its level 2 (run r03_levels).
 // The block-local kernel K1 still serves inputs of one block.
 static uint32_t zstd_frame_blocks(int level) { (void)level; return GC_MF_MAX_FRAME_BLOCKS; }
+// Levels 16-22: the finder's frames overlap (gc_mf.h "Overlapping frames") inside groups that are the zstd frames.  The reference: windowLog 22 at level 16-17, 23 at 18-19,
+// 25 / 26 / 27 at 20 / 21 / 22 (clevels.h:44-50), one frame, ZSTDMT jobs of four windows overlapping by one (zstdmt_compress.c:741-747).  Here the window stays 8 MiB
+// (23-bit positions); what the levels choose is how much of it a position is sure to have behind it: stride 4 MiB = 4-8 MiB of history at 16-19, stride 2 MiB = 6-8 MiB at
+// 20-22 (each halving of the stride lists and links every position once more: W1..W4 of the three passes).
+static uint32_t zstd_group_blocks(int level) { return level >= 16 ? 4u * GC_MF_MAX_FRAME_BLOCKS : GC_MF_MAX_FRAME_BLOCKS; }     // 32 MiB zstd frames (= shard grain) / 8 MiB
+static uint32_t zstd_stride_blocks(int level) { return level >= 20 ? GC_MF_MAX_FRAME_BLOCKS / 4u : GC_MF_MAX_FRAME_BLOCKS / 2u; }
 // zstd level -> match links followed per position (the reference's searchLog grows the same way: clevels.h:25-47)
 static uint32_t zstd_search_depth(int level) { return level < 6 ? 0u : (level < 10 ? 2u : (level < 16 ? 4u : 8u)); }
 
@@ -620,12 +629,20 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
                                                   // chains and trees; the greedy / lazy2 parse over this finder's 3-6 candidates was 1.03 x them on lz-7zip (levels 10 and 12, run r03_z12),
                                                   // the price-based parse 0.98 -- so it starts at level 10 here
     gc_env_u32("GC_PRICE_PARSE", 0u, 1u, &c->priceParse);                                      // test hook
+    // Overlapping finder frames (gc_mf.h) from level 16: the zstd frame becomes the GROUP (the reference's own frames are the whole input with a sliding window).
+    const uint32_t zGroup = zstd_group_blocks(level);
+    uint32_t zArg = frameBlocks;                                                               // what the finder takes
+    if (zGroup > frameBlocks && frameBlocks == GC_MF_MAX_FRAME_BLOCKS && nBlocks > frameBlocks) {
+        uint32_t stride = zstd_stride_blocks(level); gc_env_u32("GC_MF_STRIDE", 1u, GC_MF_MAX_FRAME_BLOCKS, &stride);      // test hook (blocks; 64 = no overlap)
+        if (stride < frameBlocks && (frameBlocks % stride) == 0u && ((zGroup - frameBlocks) % stride) == 0u) zArg = GC_MF_GEOM_ARG(frameBlocks, stride, zGroup);
+    }
+    const uint32_t zFrameBlocks = MF_C(zArg);                                                  // blocks per zstd frame
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     // The input can be taken in frame-aligned PARTS, the finder of part p + 1 (main stream) beside the entropy stage of part p (sequences on
     // stream2, literals on stream3).  Measured on MI355X (run r3_g, 1 GB of text at level 3): 1 part 30.9 ms, 2 parts 32.2, 4 parts 32.0,
     // 8 parts 35.2; 100 MB: 3.9 / 5.0 / 7.1 ms -- kernels that run beside each other take the CUs' LDS and wave slots from one another and
     // every part pays its own launch tails.  One part it is; the hook keeps the path exercised.
-    const uint32_t nFrames = (nBlocks + frameBlocks - 1u) / frameBlocks;
+    const uint32_t nFrames = (nBlocks + zFrameBlocks - 1u) / zFrameBlocks;                      // (zstd frames = the finder's groups)
     uint32_t nParts = 1u;
     gc_env_u32("GC_ZSTD_PARTS", 1u, GC_MAX_PARTS, &nParts);                                    // test hook
     if (c->dbgPartFrames) nParts = nFrames / c->dbgPartFrames;
@@ -633,17 +650,17 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
     if (nParts > GC_MAX_PARTS) nParts = GC_MAX_PARTS;
     if (nParts < 1u) nParts = 1u;
     c->mfTimed = false;
-    rc = ensure_finder_workspace(c, n, frameBlocks);
+    rc = ensure_finder_workspace(c, n, zArg);
     if (rc != GC_OK) return rc;
     const uint32_t framesPerPart = (nFrames + nParts - 1u) / nParts;
     uint32_t usedParts = 0;
     for (uint32_t p = 0; p < nParts; p++) {
-        const uint32_t blk0 = p * framesPerPart * frameBlocks;
+        const uint32_t blk0 = p * framesPerPart * zFrameBlocks;
         if (blk0 >= nBlocks) break;
         const size_t off = (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
-        const size_t len = (size_t)framesPerPart * frameBlocks * GC_ZSTD_BLOCK_MAX < n - off ? (size_t)framesPerPart * frameBlocks * GC_ZSTD_BLOCK_MAX : n - off;
+        const size_t len = (size_t)framesPerPart * zFrameBlocks * GC_ZSTD_BLOCK_MAX < n - off ? (size_t)framesPerPart * zFrameBlocks * GC_ZSTD_BLOCK_MAX : n - off;
         const uint32_t pBlocks = gc_num_blocks(len);
-        rc = launch_finder_part(c, c->stream, p, src + off, len, frameBlocks, blk0, c->profOn ? c->prof : nullptr);
+        rc = launch_finder_part(c, c->stream, p, src + off, len, zArg, blk0, c->profOn ? c->prof : nullptr);
         if (rc != GC_OK) return rc;
         HIPCHK(c, hipEventRecord(c->evPart[p][0], c->stream));                                 // finder of this part done
         if (p + 1u == nParts || blk0 + pBlocks >= nBlocks) HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
@@ -657,7 +674,7 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
             uint64_t* packed = c->seqPacked + (size_t)blk0 * GC_MAX_SEQ_PER_BLOCK;
             uint16_t* st = c->stOut + (size_t)blk0 * 3u * GC_SEQ_ST_STRIDE;
             GC_LAUNCH(gc_zstd_seq_codes_kernel, pBlocks, GC_SEQ_T, c->stream2, (const GcSeqRaw*)(c->seqRaw + (size_t)blk0 * GC_MAX_SEQ_PER_BLOCK), (const GcBlockMeta*)(c->meta + blk0),
-                      packed, c->seqOff + (size_t)blk0 * GC_MAX_SEQ_PER_BLOCK, codes, c->seqHist + blk0, c->seqSec + (size_t)blk0 * GC_SEQSEC_STRIDE, c->info + blk0, frameBlocks, sprof);
+                      packed, c->seqOff + (size_t)blk0 * GC_MAX_SEQ_PER_BLOCK, codes, c->seqHist + blk0, c->seqSec + (size_t)blk0 * GC_SEQSEC_STRIDE, c->info + blk0, zFrameBlocks, sprof);
             GC_LAUNCH(gc_zstd_seq_tables_kernel, pBlocks * 3u, 64, c->stream2, (const GcSeqHist*)(c->seqHist + blk0), (const GcSectionInfo*)(c->info + blk0), c->seqTabs + (size_t)blk0 * 3u, sprof);
             GC_LAUNCH(gc_zstd_seq_chain_kernel, pBlocks * 3u, 64, c->stream2, (const uint8_t*)codes, (const GcSectionInfo*)(c->info + blk0), c->seqTabs + (size_t)blk0 * 3u, st, sprof);
             GC_LAUNCH(gc_zstd_seq_pack_kernel, pBlocks, GC_SEQ_T, c->stream2, (const uint64_t*)packed, (const uint8_t*)codes, (const uint16_t*)st, (const GcSeqTabG*)(c->seqTabs + (size_t)blk0 * 3u),
@@ -673,10 +690,10 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev[2], 0));
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev[4], 0));
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
-    GC_LAUNCH(gc_zstd_plan_kernel, 1, 1024, c->stream, (const GcSectionInfo*)c->info, nBlocks, (uint64_t)n, (uint64_t)dstCap, frameBlocks, c->plan, c->result, c->optSeekTable);
+    GC_LAUNCH(gc_zstd_plan_kernel, 1, 1024, c->stream, (const GcSectionInfo*)c->info, nBlocks, (uint64_t)n, (uint64_t)dstCap, zFrameBlocks, c->plan, c->result, c->optSeekTable);
     HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     GC_LAUNCH(gc_zstd_emit_kernel, nBlocks + (c->optSeekTable ? 1u : 0u), 256, c->stream, src, (uint64_t)n, (const uint8_t*)c->litSec, (const uint8_t*)c->seqSec,
-              (const GcSectionInfo*)c->info, (const GcFramePlan*)c->plan, (const uint64_t*)c->result, nBlocks, frameBlocks, (uint8_t*)d_dst);
+              (const GcSectionInfo*)c->info, (const GcFramePlan*)c->plan, (const uint64_t*)c->result, nBlocks, zFrameBlocks, (uint8_t*)d_dst);
     HIPCHK(c, hipEventRecord(c->ev[7], c->stream));
     HIPCHK(c, hipGetLastError());
     c->pending = true; c->timed = true; c->lastCodec = 0;
@@ -694,7 +711,9 @@ extern "C" int gc_zstd_finish(gc_ctx* c, size_t* compressedSize)
     c->pending = false;
     { uint32_t trip = 0; gc_env_u32("GC_WATCHDOG_TRIP", 0u, 1u, &trip);       // test hook: as if a wait had run out
       for (uint32_t p = 0; p < GC_MAX_PARTS; p++) trip |= words[p * 16u + 7u];
-      if (trip) { snprintf(c->err, sizeof(c->err), "a kernel gave up waiting for another workgroup (watchdog): the output of this call is not valid"); return GC_ERR_HIP; } }
+      if (trip) {       // (a part's words are only zeroed when that part is launched again: clear them all, or a later call that uses fewer parts would report this trip for ever)
+          hipMemsetAsync(c->mfTicket, 0, GC_MAX_PARTS * 16u * sizeof(uint32_t), c->stream); hipStreamSynchronize(c->stream);
+          snprintf(c->err, sizeof(c->err), "a kernel gave up waiting for another workgroup (watchdog): the output of this call is not valid"); return GC_ERR_HIP; } }
 #ifdef GC_TEST_HOOKS
     if (const char* dir = getenv("GC_DUMP_STATE")) {               // test hook: the parse's intermediate state of this call, for comparing two runs offline
         static int serial = 0;
@@ -772,6 +791,10 @@ extern "C" size_t gc_flzma2_compress_bound(size_t n)
 // level -> blocks per match-finder frame.  Every level runs the windowed finder over 8 MiB frames (round 3; levels 1-2 used the block-local
 // finder before: a 128 KiB window against the reference's 1-2 MiB dictionaries, fl2_compress.c:52-63, was 12-24 % behind it, run r03_levels).
 static uint32_t flzma2_frame_blocks(int level) { (void)level; return GC_MF_MAX_FRAME_BLOCKS; }
+// Levels 7-9 (the reference: dictionaries of 64 / 64 / 128 MiB, fl2_compress.c:59-62): overlapping finder frames (gc_mf.h) in groups of 64 MiB, stride 4 MiB at 7, 2 MiB at 8-9
+// (a position is sure of 4 / 6 MiB of history; the window itself stays 8 MiB: 23-bit positions).  Levels 1-6: frames that tile the input.
+static uint32_t flzma2_group_blocks(int level) { return level >= 7 ? 8u * GC_MF_MAX_FRAME_BLOCKS : GC_MF_MAX_FRAME_BLOCKS; }
+static uint32_t flzma2_stride_blocks(int level) { return level >= 8 ? GC_MF_MAX_FRAME_BLOCKS / 4u : GC_MF_MAX_FRAME_BLOCKS / 2u; }
 
 // dictionary-size property byte of the 7z coder (Lzma2Encoder.cpp:353-364): dict = (2|(p&1)) << (p/2+11).
 // Matches never reach back further than the start of their frame: 128 KiB (p = 10) or 8 MiB (p = 22).
@@ -826,13 +849,20 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     gc_env_u32("GC_PRICE_PARSE", 0u, 1u, &c->priceParse);                                      // test hook: 0 = greedy parse only
     if (frameBlocks > 1u && c->dbgFrameBlocks) frameBlocks = c->dbgFrameBlocks;
     if (frameBlocks > nBlocks) frameBlocks = nBlocks;
-    rc = ensure_finder_workspace(c, n, frameBlocks);
+    uint32_t fArg = frameBlocks;                                                               // what the finder takes: overlapping frames from level 7 (gc_mf.h)
+    { const uint32_t grp = flzma2_group_blocks(level);
+      if (grp > frameBlocks && frameBlocks == GC_MF_MAX_FRAME_BLOCKS && nBlocks > frameBlocks) {
+          uint32_t stride = flzma2_stride_blocks(level); gc_env_u32("GC_MF_STRIDE", 1u, GC_MF_MAX_FRAME_BLOCKS, &stride);      // test hook (blocks; 64 = no overlap)
+          if (stride < frameBlocks && (frameBlocks % stride) == 0u && ((grp - frameBlocks) % stride) == 0u) fArg = GC_MF_GEOM_ARG(frameBlocks, stride, grp);
+      } }
+    const uint32_t groupBlocks = MF_C(fArg);
+    rc = ensure_finder_workspace(c, n, fArg);
     if (rc != GC_OK) return rc;
     // parts: ONE by default.  Overlapping the stages of several parts was measured and lost (212 MB: 33.9 ms with 4 parts against
     // 24.3 ms with one, profiles/r01_run8_flzma2_kernel_stats.md): model and range coder are chains whose duration is set by the
     // length of one segment / chunk, not by how many there are, so every part pays the full chain again, and the model kernel's
     // LDS footprint keeps the finder of the next part waiting.  GC_PART_FRAMES (test hook) still selects parts of that many frames.
-    const uint32_t nFrames = (nBlocks + frameBlocks - 1u) / frameBlocks;
+    const uint32_t nFrames = (nBlocks + groupBlocks - 1u) / groupBlocks;                       // (parts are whole groups; without overlap a group is a frame)
     uint32_t nParts = c->dbgPartFrames ? nFrames / c->dbgPartFrames : 1u; if (nParts < 1u) nParts = 1u; if (nParts > GC_MAX_PARTS) nParts = GC_MAX_PARTS;
     if (frameBlocks <= 1u) nParts = 1u;
     c->mfTimed = false; c->nParts = nParts;
@@ -845,19 +875,28 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     gc_env_u32("GC_L2_LITSEL", 0u, 1u, &litSel);
     uint32_t wordCap = GC_LZMA_STREAM_WORDS(segLog);                                           // words a segment may produce before it is stored instead
     gc_env_u32("GC_SEG_WORD_CAP", 1u, GC_LZMA_STREAM_WORDS(segLog), &wordCap);                  // test hook: a low cap sends ordinary segments down that path
+    // model segments over 2 / 4 / 8 blocks where the parse prices them within what one block of poorly compressible data costs (gc_lzma2_model_kernel): level >= 5.
+    // Parts (test hook) are whole frames, frames are multiples of eight blocks: a group never straddles a part.
+    uint32_t segMerge = (segLog == 17u && level >= 5 && rep4) ? 8u : 0u;
+    gc_env_u32("GC_SEG_MERGE", 0u, 8u, &segMerge);                                              // test hook: 0 = every block a segment of its own (round 4)
+    if (segMerge & (segMerge - 1u)) segMerge = 4u;
+    while (segMerge > 1u && nBlocks > groupBlocks && (groupBlocks % segMerge) != 0u) segMerge >>= 1;      // (groups are aligned to the input: they must not straddle frames, or a frame-aligned shard would differ from the whole input's bytes)
+    uint32_t mergeBudget = 16u * 917504u;                                                      // 896 Ki coded bits (1/16 bit units) = 7 bits per byte of ONE 128 KiB block, the longest chain the launch has anyway (PCM-like data; >= 8 bits per byte is stored unmodelled)
+    { uint32_t kbits = 0; if (gc_env_u32("GC_SEG_MERGE_KBITS", 1u, 4096u, &kbits)) mergeBudget = kbits * 16384u; }
+    uint8_t* const segKind = c->lzProps + (size_t)c->capBlocks * (GC_ZSTD_BLOCK_MAX >> GC_LZMA_SEG_LOG_MIN);
     if (c->profOn) { HIPCHK(c, hipMemsetAsync(c->prof, 0, (GC_LZ_PHASES + GC_SEQ_PHASES) * sizeof(unsigned long long), c->stream)); c->profBlocks = 1u; }   // L2 phase sums (raw)
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     uint32_t f0 = 0;
     for (uint32_t p = 0; p < nParts; p++) {
         const uint32_t f1 = (uint32_t)(((uint64_t)nFrames * (p + 1u)) / nParts);
-        const uint32_t blk0 = f0 * frameBlocks, blk1 = f1 * frameBlocks < nBlocks ? f1 * frameBlocks : nBlocks;
+        const uint32_t blk0 = f0 * groupBlocks, blk1 = f1 * groupBlocks < nBlocks ? f1 * groupBlocks : nBlocks;
         const uint64_t off = (uint64_t)blk0 * GC_ZSTD_BLOCK_MAX;
         const size_t pn = (size_t)(((uint64_t)blk1 * GC_ZSTD_BLOCK_MAX < n ? (uint64_t)blk1 * GC_ZSTD_BLOCK_MAX : (uint64_t)n) - off);
         const uint32_t pBlocks = blk1 - blk0, pSegs = pBlocks * segPerBlock, pRc = pBlocks * GC_LZMA_RC_PER_BLOCK;
         hipEvent_t* ev = c->evPart[p];
         // stage 1 (main stream): match finder + item lists
         HIPCHK(c, hipEventRecord(ev[0], c->stream));
-        rc = launch_finder_part(c, c->stream, p, src + off, pn, frameBlocks, blk0, nullptr);
+        rc = launch_finder_part(c, c->stream, p, src + off, pn, fArg, blk0, nullptr);
         if (rc != GC_OK) return rc;
         HIPCHK(c, hipEventRecord(ev[1], c->stream));
         GC_LAUNCH(gc_lzma2_prep_kernel, pBlocks, 256, c->stream, (const GcSeqRaw*)(c->seqRaw + (size_t)blk0 * GC_MAX_SEQ_PER_BLOCK),
@@ -870,7 +909,7 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
                   (const uint32_t*)(c->lzNM + blk0), segLog, (uint32_t)(off != 0u ? 1u : 0u),
                   c->lzStream + (size_t)blk0 * segPerBlock * GC_LZMA_STREAM_WORDS(segLog), c->lzInfo + (size_t)blk0 * GC_LZMA_RC_PER_BLOCK,
                   (const uint32_t*)((c->priceParse && frameBlocks > 1u) ? c->mfWinCost + (size_t)blk0 * 32u : nullptr),
-                  c->profOn ? c->prof : nullptr, mergeWords, wordCap, rep4, c->lzProps + (size_t)blk0 * segPerBlock, litSel);
+                  c->profOn ? c->prof : nullptr, mergeWords, wordCap, rep4, c->lzProps + (size_t)blk0 * segPerBlock, litSel, segMerge, mergeBudget);
         HIPCHK(c, hipEventRecord(ev[4], c->stream2));
         // stage 3 (stream3): range coder
         HIPCHK(c, hipStreamWaitEvent(c->stream3, ev[4], 0));
@@ -883,11 +922,12 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
         f0 = f1;
     }
     c->mfTimed = frameBlocks > 1u; c->mfParts = nParts; c->mfPriced = c->mfTimed && c->priceParse != 0u;
-    (void)nSegs;
     // all parts coded -> headers and assembly on the main stream
     HIPCHK(c, hipStreamWaitEvent(c->stream, c->evPart[nParts - 1u][6], 0));
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-    GC_LAUNCH(gc_lzma2_plan_kernel, 1, 1024, c->stream, (const GcLzmaChunkInfo*)c->lzInfo, nRc, segLog, (uint64_t)dstCap, (uint32_t)flags, c->lzPlan, c->result);
+    GC_LAUNCH(gc_lzma2_segkind_kernel, (nSegs + 255u) / 256u, 256, c->stream, (const GcLzmaChunkInfo*)c->lzInfo, (const uint8_t*)c->lzProps, nSegs, segLog, segKind);
+    GC_LAUNCH(gc_lzma2_plan_kernel, 1, 1024, c->stream, (const GcLzmaChunkInfo*)c->lzInfo, nRc, segLog, (uint64_t)dstCap, (uint32_t)flags, c->lzPlan, c->result,
+              (const uint8_t*)c->lzProps, (const uint8_t*)segKind);
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
     GC_LAUNCH(gc_lzma2_emit_kernel, nRc + 1u, 256, c->stream, src, segLog, (const uint8_t*)c->lzRcOut, (const GcLzmaChunkInfo*)c->lzInfo,
               (const GcLzmaPlan*)c->lzPlan, nRc, (uint32_t)flags, (const uint64_t*)c->result, (uint8_t*)d_dst, (const uint8_t*)c->lzProps);
@@ -1116,6 +1156,10 @@ extern "C" size_t gc_codec_grain(int codec, int level)
 {
     uint32_t fb = codec == GC_CODEC_ZSTD ? zstd_frame_blocks(level) : flzma2_frame_blocks(level);
     if (codec != GC_CODEC_BROTLI && fb > 1u) gc_env_u32("GC_FRAME_BLOCKS", 1u, GC_MF_MAX_FRAME_BLOCKS, &fb);     // test hook: small frames (as in gc_ctx_create)
+    if (codec != GC_CODEC_BROTLI && fb == GC_MF_MAX_FRAME_BLOCKS) {                                              // overlapping frames: the unit is the group (zstd 16-22: 32 MiB, FLZMA2 7-9: 64 MiB)
+        uint32_t stride = GC_MF_MAX_FRAME_BLOCKS; const bool hook = gc_env_u32("GC_MF_STRIDE", 1u, GC_MF_MAX_FRAME_BLOCKS, &stride);
+        if (!hook || stride < GC_MF_MAX_FRAME_BLOCKS) fb = codec == GC_CODEC_ZSTD ? zstd_group_blocks(level) : flzma2_group_blocks(level);
+    }
     if (codec != GC_CODEC_BROTLI) return (size_t)fb * GC_ZSTD_BLOCK_MAX;
     return (size_t)brotli_blocks_per_chunk(level) * GC_ZSTD_BLOCK_MAX;
 }
@@ -1378,7 +1422,8 @@ extern "C" int gc_zstd_decompress_device(gc_ctx* c, const void* d_src, size_t n,
             // which is what happens to a sound stream where launches are serialised (rocprofv3 --pmc: run r4pmcdec, the self-check frame failed this
             // way) or another process holds the device.  Such a batch is decoded once more with the kernels one after the other before it is
             // called damaged; a damaged stream fails again, one pass later.
-            if (((overlap && !wide) || failFirst) && !serialRetry) { retryNow = true; break; }
+            // (only GC_ZD_CORRUPT can come from a wait that ran out: a small destination, an unsupported frame, a checksum or a size mismatch would fail the same way again)
+            if ((overlap || failFirst) && st == GC_ZD_CORRUPT && !serialRetry) { retryNow = true; break; }
             snprintf(c->err, sizeof(c->err), "frame %zu: %s", i + k, st == GC_ZD_DST_SMALL ? "destination too small" : st == GC_ZD_CHECKSUM ? "content checksum mismatch" :
                      st == GC_ZD_SIZE ? "content size field does not match" : st == GC_ZD_UNSUPPORTED ? "unsupported frame" : "corrupted data");
             rc = st == GC_ZD_DST_SMALL ? GC_ERR_DST_SMALL : (st == GC_ZD_UNSUPPORTED ? GC_ERR_PARAM : GC_ERR_CORRUPT);

@@ -78,6 +78,9 @@
 #define DPL_REP0     2u               // .. 5: rep0..rep3
 #define DPL_SREP     6u               // LZMA short repeat (one byte at rep0)
 #define DPL_CONTC    7u               // continuation of the capped piece in front of it
+#ifndef DPL_SREP_ANY
+#define DPL_SREP_ANY 1               // 1: the short repeat is offered at the node's rep0 whether or not that is known for certain (L2 codes a wrong one as a literal); 0: round 4
+#endif
 #define DPL_SURE     0x80000000u      // in rep0 of a node: the distance is the decoder's rep0 for certain (a match of this window lies on the way)
 
 __device__ __forceinline__ uint32_t dpl_item(uint32_t bid, uint32_t per) { return (bid & (GC_XCDS - 1u)) * per + (bid >> 3); }
@@ -150,11 +153,12 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
     static const int xWin4k = getenv("GC_X_WIN4K") ? atoi(getenv("GC_X_WIN4K")) : 0, xNoHint = getenv("GC_X_NOHINT") ? atoi(getenv("GC_X_NOHINT")) : 0, xWarm = getenv("GC_X_WARM") ? atoi(getenv("GC_X_WARM")) : DPL_WARM;
     static const int xSparse = getenv("GC_X_SPARSE") ? atoi(getenv("GC_X_SPARSE")) : 0;
     static const int xHints = getenv("GC_X_HINTS") ? atoi(getenv("GC_X_HINTS")) : 63;
+    static const bool xSrepAny = getenv("GC_X_SREP_ANY") ? atoi(getenv("GC_X_SREP_ANY")) != 0 : DPL_SREP_ANY != 0;
     (void)xWin4k;
     const uint32_t winLen = SAMPLE ? 512u : (win2k ? 2048u : 4096u);
     const uint32_t w0 = win2k ? lane << 11 : ((lane & 31u) << 12) + (SAMPLE ? 1536u : 0u);
 #else
-    const int xWarm = DPL_WARM; const int xSparse = 0;
+    const int xWarm = DPL_WARM; const int xSparse = 0; const bool xSrepAny = DPL_SREP_ANY != 0;
     const uint32_t winLen = SAMPLE ? 512u : (win2k ? 2048u : 4096u);
     const uint32_t w0 = win2k ? lane << 11 : ((lane & 31u) << 12) + (SAMPLE ? 1536u : 0u);
 #endif
@@ -553,7 +557,8 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
                     // which repeat of the node it is: 0..3; the continuation of a capped piece counts as the cheapest (index 0 - 1)
                     uint32_t kk = hd == r0d ? 1u : (hd == st.r1 ? 2u : (hd == st.r2 ? 3u : (hd == st.r3 ? 4u : 8u)));
                     if (contCapped && hd == contDist) kk = 0u;
-                    if (MINLEN == 2u && hl != 0u && kk == 1u && (st.r0 & DPL_SURE)) srepD = hd;      // LZMA's short repeat: one byte at rep0, known for certain
+                    if (MINLEN == 2u && hl != 0u && kk == 1u && (xSrepAny || (st.r0 & DPL_SURE))) srepD = hd;      // LZMA's short repeat: one byte at rep0 (round 4: only where rep0 is known for certain -- a match of this window on
+                                                                                                                  // the way; round 5: L2 codes a short repeat that names another distance than its rep0 as a literal, so the distance the window arrived with will do)
                     const uint32_t covered = hd == D ? L : (hd == D3 ? L3 : 0u);                                // the candidate itself covers it
                     const bool use = hl >= (kk == 0u ? contX0 : MINLEN) && kk != 8u && covered < hl;
                     const bool b1 = use && kk < bestK, b2 = use && hl > longL;

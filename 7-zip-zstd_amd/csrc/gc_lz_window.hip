@@ -45,17 +45,24 @@ struct MfTile {
     uint64_t frameStart, frameEnd;    // absolute
     uint64_t tileStart;               // absolute
     uint32_t len;                     // positions of the tile that exist (0: the tile lies past the end of the input)
+    bool own;                         // the frame verifies this tile (overlapping frames, gc_mf.h: false = the tile is only listed and linked here, an earlier frame has its records)
 };
+// frameBlocks: F, or F | S << 8 | C << 16 (gc_mf.h GC_MF_GEOM_ARG)
 __device__ __forceinline__ MfTile mf_tile(uint32_t tile, uint32_t frameBlocks, uint64_t srcSize)
 {
     MfTile T;
-    const uint32_t TPF = frameBlocks * GC_MF_TILES_PER_BLOCK;
-    const uint64_t frameBytes = (uint64_t)frameBlocks * GC_ZSTD_BLOCK_MAX;
+    const uint32_t F = MF_F(frameBlocks), S = MF_S(frameBlocks), C = MF_C(frameBlocks), fpg = 1u + (C - F) / S;
+    const uint32_t TPF = F * GC_MF_TILES_PER_BLOCK;
+    const uint64_t frameBytes = (uint64_t)F * GC_ZSTD_BLOCK_MAX;
     T.frame = tile / TPF; T.tif = tile % TPF;
-    T.frameStart = (uint64_t)T.frame * frameBytes;
-    T.frameEnd = (T.frameStart + frameBytes) < srcSize ? (T.frameStart + frameBytes) : srcSize;
+    const uint32_t gi = T.frame / fpg, fi = T.frame % fpg;
+    const uint64_t groupStart = (uint64_t)gi * C * GC_ZSTD_BLOCK_MAX;
+    const uint64_t groupEnd = (groupStart + (uint64_t)C * GC_ZSTD_BLOCK_MAX) < srcSize ? (groupStart + (uint64_t)C * GC_ZSTD_BLOCK_MAX) : srcSize;
+    T.frameStart = groupStart + (uint64_t)fi * S * GC_ZSTD_BLOCK_MAX;
+    T.frameEnd = (T.frameStart + frameBytes) < groupEnd ? (T.frameStart + frameBytes) : groupEnd;
     T.tileStart = T.frameStart + (uint64_t)T.tif * GC_MF_TILE;
     T.len = T.tileStart < T.frameEnd ? (uint32_t)((T.frameEnd - T.tileStart) < GC_MF_TILE ? (T.frameEnd - T.tileStart) : GC_MF_TILE) : 0u;
+    T.own = fi == 0u || T.tif >= (F - S) * GC_MF_TILES_PER_BLOCK;
     return T;
 }
 
@@ -152,7 +159,7 @@ __device__ __forceinline__ void mf_count_body(const uint8_t* __restrict__ src, u
     const uint32_t tile = mf_item(blockIdx.x, per);
     if (tile >= nTiles) return;
     const MfTile T = mf_tile(tile, frameBlocks, srcSize);
-    const uint32_t TPF = frameBlocks * GC_MF_TILES_PER_BLOCK;
+    const uint32_t TPF = MF_F(frameBlocks) * GC_MF_TILES_PER_BLOCK;
     sHist[t] = 0;
     if (T.len) mf_stage(sW, MF_STAGE_WORDS, src, srcSize, T.tileStart, t, MF_T);
     __syncthreads();
@@ -244,7 +251,7 @@ __device__ __forceinline__ void mf_scatter_body(const uint8_t* __restrict__ src,
     if (tile >= nTiles) return;
     const MfTile T = mf_tile(tile, frameBlocks, srcSize);
     if (T.len == 0u) return;
-    const uint32_t TPF = frameBlocks * GC_MF_TILES_PER_BLOCK;
+    const uint32_t TPF = MF_F(frameBlocks) * GC_MF_TILES_PER_BLOCK;
     for (uint32_t w = 0; w < MF_WAVES; w++) sRun[w][t] = 0;
     mf_stage(sW, MF_STAGE_WORDS, src, srcSize, T.tileStart, t, MF_T);
     __syncthreads();
@@ -306,7 +313,7 @@ __device__ __forceinline__ void mf_scatter_body(const uint8_t* __restrict__ src,
     }
     __syncthreads();
     // output: slot j of the sorted tile -> its partition's run in HBM
-    GcMfEntry* E = ent + (uint64_t)T.frame * ((uint64_t)frameBlocks * GC_ZSTD_BLOCK_MAX);
+    GcMfEntry* E = ent + (uint64_t)T.frame * ((uint64_t)MF_F(frameBlocks) * GC_ZSTD_BLOCK_MAX);
     for (uint32_t j = t; j < nEnt; j += MF_T) {
         const MfKeys k = mf_keys<MODE>(sW, sPerm[j], T);
         E[sGlob[k.part] + (j - sLocal[k.part])] = k.entry;
@@ -541,7 +548,7 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
     constexpr uint32_t MINLEN = MODE == MF_SHORT ? 3u : GC_MIN_MATCH;
     constexpr uint32_t LONGLEN = MODE == MF_SHORT ? 4u : (MODE == MF_FAR ? 16u : 8u);   // a verified long candidate has this many bytes
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const uint32_t TPF = frameBlocks * GC_MF_TILES_PER_BLOCK;
+    const uint32_t TPF = MF_F(frameBlocks) * GC_MF_TILES_PER_BLOCK;
     uint32_t c = 0, incl = 0;
     if (t < GC_MF_PARTS) {
         const uint32_t* row = offs + ((uint64_t)T.frame * (TPF + 1u) + T.tif) * GC_MF_PARTS;
@@ -572,7 +579,7 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
     const uint32_t nEnt = sLocal[GC_MF_PARTS];
     VP_PHASE(prof, *tprev, 0);                                     // stage + run offsets
     const uint8_t* wsrc = src + T.frameStart;
-    const GcMfEntry* E = ent + (uint64_t)T.frame * ((uint64_t)frameBlocks * GC_ZSTD_BLOCK_MAX);
+    const GcMfEntry* E = ent + (uint64_t)T.frame * ((uint64_t)MF_F(frameBlocks) * GC_ZSTD_BLOCK_MAX);
     const uint64_t blockBase = T.tileStart & ~(uint64_t)(GC_ZSTD_BLOCK_MAX - 1u);     // a tile never straddles blocks
     const uint32_t nBlk = (uint32_t)((srcSize - blockBase) < GC_ZSTD_BLOCK_MAX ? (srcSize - blockBase) : GC_ZSTD_BLOCK_MAX);
     const uint32_t pTile = (uint32_t)(T.tileStart - blockBase);
@@ -772,7 +779,7 @@ __device__ __forceinline__ void mf_verify_body(const uint8_t* __restrict__ src, 
     const uint32_t tile = mf_item(blockIdx.x, per);
     if (tile >= nTiles) return;
     const MfTile T = mf_tile(tile, frameBlocks, srcSize);
-    if (T.len == 0u) return;
+    if (T.len == 0u || !T.own) return;                            // (overlapping frames: the tiles a frame shares with the one in front have their records from that one)
     mf_verify_tile<MODE>(T, src, srcSize, frameBlocks, offs, ent, recIn, sW, sRec, sExt, sStart, sLocal, sWaveTot);
     // records out: 16 bytes per lane, full lines
     GcU4* R4 = (GcU4*)(rec + T.tileStart);
@@ -830,7 +837,7 @@ MFK(gc_mf_deepen_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint
     const uint32_t tile = mf_item(blockIdx.x, per);
     if (tile >= nTiles) return;
     const MfTile T = mf_tile(tile, frameBlocks, srcSize);
-    if (T.len == 0u) return;
+    if (T.len == 0u || !T.own) return;
     const uint8_t* wsrc = src + T.frameStart;
     const uint32_t* RI = recIn + T.frameStart;                     // frame-relative indexing, like the candidates
     const uint64_t blockBase = T.tileStart & ~(uint64_t)(GC_ZSTD_BLOCK_MAX - 1u);
@@ -860,7 +867,7 @@ MFK(gc_mf_deepen_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint
             uint32_t c = pw - bestOff;
             for (uint32_t d = 0; d < nLinks; d++) {
                 const uint32_t rc = RI[c];
-                if ((rc & 0xFFu) == 0u) break;
+                if ((rc & 0xFFu) == 0u || (rc >> 8) > c) break;              // (overlapping frames: the record of a position this frame shares with the one in front may reach back beyond this frame's start)
                 const uint32_t c2 = c - (rc >> 8);
                 uint32_t len = lz_cmp16(me, lz_ld16(wsrc, c2));
                 while (len >= 16u && (len & 15u) == 0u && len < maxLen) {

@@ -331,7 +331,11 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
                       uint32_t wordCap /* words the segment may produce (its reserved place, GC_LZMA_STREAM_WORDS); beyond that it is stored */,
                       uint32_t rep4 /* 1: matches whose distance is rep2 / rep3 of the decoder are coded as such (LzLru above); 0: rep0 / rep1 only */,
                       uint8_t* __restrict__ segProps /* out, per segment: the LZMA props byte its first chunk carries (lc / lp chosen per segment) */,
-                      uint32_t litSel /* 1: choose the literal context bits per segment; 0: the reference's lc = 3, lp = 0 */)
+                      uint32_t litSel /* 1: choose the literal context bits per segment; 0: the reference's lc = 3, lp = 0 */,
+                      uint32_t segMerge /* round 5: 2 / 4 / 8 = a model segment may span that many 128 KiB blocks (aligned groups, power of two) where the parse prices
+                         them cheaply enough; 0 / 1 = off.  Needs segLog = 17, winCost and rep4 */,
+                      uint32_t mergeBudget /* ... while the blocks' estimated cost (winCost units, 1/16 bit) stays within this: the model chain of a merged
+                         segment is then no longer than that of ONE block of poorly compressible data, which is what the launch takes anyway */)
 {
     __shared__ __attribute__((aligned(16))) uint16_t P[LZP_TOTAL];
     __shared__ uint32_t sTick[LZ2_TICKS / 4u];                    // ticket bytes (see LZ2_TICKS)
@@ -339,8 +343,56 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
     __shared__ uint32_t sWordEnd[GC_LZMA_RC_PER_BLOCK];
 
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t seg = blockIdx.x;
     const uint32_t segSize = 1u << segLog, perBlock = GC_ZSTD_BLOCK_MAX >> segLog, rcPerSeg = segSize >> GC_LZMA_RC_LOG;
+    // ---- model segments over several blocks (round 5).  A state reset costs what the model needs to learn the data again, and that does not shrink with the
+    // data's size: on 8 MiB of ROCm shared objects that compress 9 : 1 an exact LZMA model prices the same parse 1.9 % / 3.1 % / 3.5 % smaller with resets every
+    // 256 KiB / 512 KiB / 1 MiB than every 128 KiB (tools/lzma_parse_lab.c), and the reference's own slices are >= 218 KiB at level 5 with 64 threads
+    // (fl2_compress.c:272-292: 14 MiB of new data per 16 MiB dictionary block / threads).  What a wave of this kernel costs is its coded bits, not its input bytes,
+    // so an aligned group of 2 / 4 / 8 blocks whose estimated cost (the parse's winCost) stays within what ONE poorly compressible block costs is modelled by ONE
+    // wave as ONE segment: the group's first block is the leader (state reset + props byte), the others continue its probabilities, coder state and repeat
+    // distances (props entry 0xFF; their first chunk is an ordinary 0x80 chunk).  Everything else stays per block: item list, word stream place, rc chunks.
+    uint32_t seg = blockIdx.x, nMember = 1u;
+    if (segMerge >= 2u && perBlock == 1u && winCost != nullptr && rep4 != 0u) {
+        const uint32_t nBlocksAll = (uint32_t)((srcSize + GC_ZSTD_BLOCK_MAX - 1u) / GC_ZSTD_BLOCK_MAX);
+        const uint32_t g0 = seg & ~(segMerge - 1u);
+        // lane j * 8 + k: (k-th group of four windows) of block g0 + j; est[j] = the block's estimate, 0xFFFFFFFF = absent or hopeless (never merged)
+        uint32_t e = 0;
+        { const uint32_t j = lane >> 3, bb = g0 + j;
+          if (j < segMerge && bb < nBlocksAll) { const uint32_t* wc = winCost + (uint64_t)bb * GC_LZMA_RC_PER_BLOCK + (lane & 7u) * 4u; e = wc[0] + wc[1] + wc[2] + wc[3]; }
+          e += __shfl_xor(e, 1); e += __shfl_xor(e, 2); e += __shfl_xor(e, 4); }
+        uint32_t est[8];
+#pragma unroll
+        for (uint32_t j = 0; j < 8u; j++) {
+            const uint32_t bb = g0 + j;
+            uint32_t v = __shfl(e, (int)(j * 8u));
+            if (j >= segMerge || bb >= nBlocksAll) v = 0xFFFFFFFFu;
+            else { const uint64_t bs = (uint64_t)bb * GC_ZSTD_BLOCK_MAX; const uint32_t bl = (uint32_t)((srcSize - bs) < GC_ZSTD_BLOCK_MAX ? (srcSize - bs) : GC_ZSTD_BLOCK_MAX);
+                   if (v >= bl * 128u || nM[bb] == 0xFFFFFFFFu) v = 0xFFFFFFFFu; }
+            est[j] = v;
+        }
+        const uint32_t me = seg - g0;
+        uint32_t lead = me; nMember = 1u;
+        for (uint32_t sz = segMerge; sz >= 2u; sz >>= 1) {           // the largest aligned group around this block that fits the budget
+            const uint32_t a = me & ~(sz - 1u);
+            uint64_t sum = 0; bool ok = true;
+#pragma unroll
+            for (uint32_t j = 0; j < 8u; j++) if (j >= a && j < a + sz) { if (est[j] == 0xFFFFFFFFu) ok = false; else sum += est[j]; }
+            if (ok && sum <= (uint64_t)mergeBudget) { lead = a; nMember = sz; break; }
+        }
+        if (lead != me) return;                                     // a member: its leader's wave does the work
+    }
+    bool overflow = false;            // the words of a block outgrew their reserved place: the whole segment is stored
+    uint32_t cOff = 1u;               // effective distance of the previous item (1 until the segment's first match)
+    uint32_t cExit = 0;               // coder state after the last match item (0: state at segment start)
+    uint32_t cLits = 0;               // literals coded since the last match item (in cut items)
+    bool segHasMatch = false;         // a match in an earlier block of this segment
+    bool anyDemoted = false;          // (wave-uniform) a one-byte item of this segment was coded as a literal: the rep0 / rep1 scans (a cross-check under the emulator) no longer apply
+    LzLru cLru; cLru.v0 = cLru.v1 = cLru.v2 = cLru.v3 = 1u;                 // rep4: the decoder's repeat distances after a state reset (LzmaDec.c: reps = 1)
+    uint32_t litLc = GC_LZMA_LC, litLpMask = 0u;
+    const uint32_t segLead = seg;
+    unsigned long long tprev = prof ? gc_clock() : 0ull, pc0 = 0, pc1 = 0, pc2 = 0; uint32_t pSteps = 0, pRounds = 0;
+  for (uint32_t bi = 0; bi < nMember; bi++) {
+    seg = segLead + bi;
     const uint32_t b = seg / perBlock, sInB = seg % perBlock;
     const uint64_t blockBase = (uint64_t)b * GC_ZSTD_BLOCK_MAX;
     const uint32_t blockLen = (uint32_t)((srcSize - blockBase) < GC_ZSTD_BLOCK_MAX ? (srcSize - blockBase) : GC_ZSTD_BLOCK_MAX);
@@ -358,8 +410,8 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
         const uint32_t segLen = (ss + segSize < blockLen ? ss + segSize : blockLen) - ss;
         hopeless = est >= segLen * 128u;                          // 8 bits per byte in 1/16 bit units
     }
-    if (lane == 0u) segProps[seg] = (uint8_t)GC_LZMA_PROPS;
-    if (ss >= blockLen || nItems == 0xFFFFFFFFu || hopeless) {
+    if (lane == 0u) segProps[seg] = bi == 0u ? (uint8_t)GC_LZMA_PROPS : (uint8_t)0xFFu;
+    if (ss >= blockLen || nItems == 0xFFFFFFFFu || hopeless) {                // (never a block of a merged segment: those exist, have a list and are not hopeless)
         // no such segment -- or the item list overflowed (cannot happen for lists built by L1; kept as a guard): store it
         for (uint32_t c = lane; c < rcPerSeg; c += 64u) {
             const uint32_t cs = ss + (c << GC_LZMA_RC_LOG);
@@ -377,7 +429,7 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
     // literals better by POSITION (liblzma on ROCm shared objects: lc 0 / lp 2 -2.1 %, lc 2 / lp 1 -1.8 %; text +0.3-0.5 %).  Chosen by the order-0 cost of a
     // quarter of the segment's bytes under each of three context functions (all with <= 8 contexts: the literal coder keeps its size), the reference's unless
     // another is 1/64 cheaper.  Counters: two per 32-bit word in the (not yet initialised) probability array.
-    uint32_t litLc = GC_LZMA_LC, litLpMask = 0u;
+    if (bi == 0u) {
     if (litSel && se - ss >= 4096u) {
         uint32_t* W = (uint32_t*)P;
         constexpr uint32_t NCELL = 2048u + 2048u + 1024u;
@@ -423,6 +475,7 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
     }
     for (uint32_t i = lane; i < LZP_TOTAL; i += 64u) P[i] = 1024u;
     for (uint32_t i = lane; i < LZ2_TICKS / 4u; i += 64u) sTick[i] = 0;
+    }
     if (lane < GC_LZMA_RC_PER_BLOCK) sWordEnd[lane] = 0;
 
     // items of this segment = items that END in (ss, se]  (a cut at position ss closes the previous segment)
@@ -437,17 +490,12 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
     gc_wave_sync();
 
     // carried across tiles of 64 items (all wave-uniform)
+    // (cOff, cExit, cLits, cLru live across the blocks of a merged segment: declared above)
     uint32_t cursor = ss;             // end of the previous item
-    uint32_t cOff = 1u;               // effective distance of the previous item (1 until the segment's first match)
     uint32_t cRun = 0;                // (k + 1) of the start of the run of equal distances containing the previous item; 0 = virtual
-    uint32_t cMatch = 0;              // (k + 1) of the last match item; 0 = none yet
-    uint32_t cExit = 0;               // coder state after the last match item (0: state at segment start)
-    uint32_t cLits = 0;               // literals coded since the last match item (in cut items)
-    uint32_t wpos = 0;                // words written so far
-    LzLru cLru; cLru.v0 = cLru.v1 = cLru.v2 = cLru.v3 = 1u;                 // rep4: the decoder's repeat distances after a state reset (LzmaDec.c: reps = 1)
-    bool overflow = false;            // the words of the segment outgrew their reserved place: the segment is stored
+    uint32_t cMatch = 0;              // (k + 1) of the last match item OF THIS BLOCK; 0 = none yet (segHasMatch: one in an earlier block of the segment)
+    uint32_t wpos = 0;                // words written so far (of this block: every block has its own place)
 
-    unsigned long long tprev = prof ? gc_clock() : 0ull, pc0 = 0, pc1 = 0, pc2 = 0; uint32_t pSteps = 0, pRounds = 0;
 #define L2_PHASE(acc) do { if (prof) { const unsigned long long now_ = gc_clock(); acc += now_ - tprev; tprev = now_; } } while (0)
     for (uint32_t base = first; base < last; base += 64u) {
         const uint32_t cnt = last - base < 64u ? last - base : 64u;
@@ -457,6 +505,29 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
         const uint32_t k = base - first + lane;                              // segment-relative item index
         LzItem it; it.pos = se; it.len = 0; it.off = 0;
         if (lane < cnt) it = lz_item(M, base + lane);
+        // rep4: the decoder's repeat distances in front of every item, first (an LRU list as a wave scan, LzLru above).  One-byte items are short repeats: they name
+        // rep0 and leave the list as it is, so they take no part in the scan -- and one whose distance is NOT the list's front (the parse offers the short repeat
+        // from the repeat distance its window ARRIVED with, which is the path of another lane: W7L, round 5) is coded as the literal it also is: the item becomes a
+        // cut one byte further on.  (Round 4 only let the parse name a short repeat behind a match of its own window: 14.5 K of them against the reference's 60 K
+        // on 4 MiB of tables of records.)
+        LzLru lruIncl; lruIncl.v0 = lruIncl.v1 = lruIncl.v2 = lruIncl.v3 = 0;
+        LzLru L4; L4.v0 = L4.v1 = L4.v2 = L4.v3 = 0;
+        if (rep4) {
+            LzLru a; a.v0 = (lane < cnt && it.len >= 2u) ? it.off : 0u; a.v1 = a.v2 = a.v3 = 0;
+#pragma unroll
+            for (uint32_t d = 1; d < 64u; d <<= 1) {
+                LzLru b; b.v0 = __shfl_up(a.v0, d); b.v1 = __shfl_up(a.v1, d); b.v2 = __shfl_up(a.v2, d); b.v3 = __shfl_up(a.v3, d);
+                if (lane < d) b.v0 = b.v1 = b.v2 = b.v3 = 0;
+                a = lru_join(a, b);
+            }
+            lruIncl = a;
+            LzLru ex; ex.v0 = __shfl_up(a.v0, 1); ex.v1 = __shfl_up(a.v1, 1); ex.v2 = __shfl_up(a.v2, 1); ex.v3 = __shfl_up(a.v3, 1);
+            if (lane == 0u) ex.v0 = ex.v1 = ex.v2 = ex.v3 = 0;
+            L4 = lru_over(ex, cLru);                                         // the decoder's list in front of this item
+            const bool demote = lane < cnt && it.len == 1u && it.off != L4.v0;
+            if (demote) { it.pos += 1u; it.len = 0u; it.off = 0u; }
+            if (__any(demote)) anyDemoted = true;
+        }
         const bool isM = lane < cnt && it.len != 0u;
         uint32_t prevEnd = __shfl_up(it.pos + it.len, 1); if (lane == 0) prevEnd = cursor;
         const uint32_t ll = lane < cnt ? it.pos - prevEnd : 0u;
@@ -466,7 +537,7 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
         // effective distance: a cut repeats the distance of the last match; before the segment's first match it is 1
         const bool mPrevInTile = mPrev != 0u && mPrev - 1u >= base - first;
         const uint32_t offAtMPrev = __shfl(it.off, (int)(mPrevInTile ? mPrev - 1u - (base - first) : 0u));
-        const uint32_t offE = isM ? it.off : (mPrev ? (mPrevInTile ? offAtMPrev : cOff) : 1u);
+        const uint32_t offE = isM ? it.off : (mPrevInTile ? offAtMPrev : cOff);       // (cOff is 1 until the segment's first match)
         uint32_t pOff = __shfl_up(offE, 1); if (lane == 0) pOff = cOff;
         // repeat-distance history as scans: rep0 = previous distance, rep1 = distance before the current run of equal ones
         const uint32_t v = (lane < cnt && offE != pOff) ? k + 1u : 0u;
@@ -485,25 +556,13 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
         uint32_t kind = 0;
         if (isM) kind = it.off == pOff ? (it.len == 1u ? 3u : 1u) : (it.off == rep1 ? 2u : 0u);
 #ifdef HIPEMU
-        if (isM && it.len == 1u && kind != 3u) { fprintf(stderr, "L2: one-byte item at %u is not a repeat of the previous distance (%u vs %u)\n", it.pos, it.off, pOff); abort(); }
+        if (bi == 0u && !anyDemoted && isM && it.len == 1u && kind != 3u) { fprintf(stderr, "L2: one-byte item at %u is not a repeat of the previous distance (%u vs %u)\n", it.pos, it.off, pOff); abort(); }
 #endif
-        LzLru lruIncl; lruIncl.v0 = lruIncl.v1 = lruIncl.v2 = lruIncl.v3 = 0;
         if (rep4) {
-            LzLru a; a.v0 = isM ? it.off : 0u; a.v1 = a.v2 = a.v3 = 0;
-#pragma unroll
-            for (uint32_t d = 1; d < 64u; d <<= 1) {
-                LzLru b; b.v0 = __shfl_up(a.v0, d); b.v1 = __shfl_up(a.v1, d); b.v2 = __shfl_up(a.v2, d); b.v3 = __shfl_up(a.v3, d);
-                if (lane < d) b.v0 = b.v1 = b.v2 = b.v3 = 0;
-                a = lru_join(a, b);
-            }
-            lruIncl = a;
-            LzLru ex; ex.v0 = __shfl_up(a.v0, 1); ex.v1 = __shfl_up(a.v1, 1); ex.v2 = __shfl_up(a.v2, 1); ex.v3 = __shfl_up(a.v3, 1);
-            if (lane == 0u) ex.v0 = ex.v1 = ex.v2 = ex.v3 = 0;
-            const LzLru L4 = lru_over(ex, cLru);                             // the decoder's list in front of this item
             if (isM) {
                 const uint32_t k4 = it.off == L4.v0 ? (it.len == 1u ? 3u : 1u) : (it.off == L4.v1 ? 2u : (it.off == L4.v2 ? 4u : (it.off == L4.v3 ? 5u : 0u)));
 #ifdef HIPEMU
-                if ((kind != 0u && k4 != kind) || (kind == 0u && k4 != 0u && k4 < 4u)) { fprintf(stderr, "L2 rep4: item at %u off %u: list %u %u %u %u says kind %u, the scans say %u\n", it.pos, it.off, L4.v0, L4.v1, L4.v2, L4.v3, k4, kind); abort(); }
+                if (bi == 0u && !anyDemoted && ((kind != 0u && k4 != kind) || (kind == 0u && k4 != 0u && k4 < 4u))) { fprintf(stderr, "L2 rep4: item at %u off %u: list %u %u %u %u says kind %u, the scans say %u\n", it.pos, it.off, L4.v0, L4.v1, L4.v2, L4.v3, k4, kind); abort(); }
 #endif
                 kind = k4;
             }
@@ -515,7 +574,7 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
         const uint32_t mLane = mInTile ? mPrev - 1u - (base - first) : 0u;
         const uint32_t aAtM = __shfl(aExcl, (int)mLane);
         const uint32_t L = mInTile ? aExcl - aAtM : cLits + aExcl;           // literals between the last match and this item
-        const bool litBefore = (L + ll) != 0u || mPrev == 0u;                // <=> coder state before the match is a literal state
+        const bool litBefore = (L + ll) != 0u || (mPrev == 0u && !segHasMatch);      // <=> coder state before the match is a literal state
         const uint32_t stAfter = kind == 0u ? (litBefore ? 7u : 10u) : (kind == 3u ? (litBefore ? 9u : 11u) : (litBefore ? 8u : 11u));   // LzmaDec.c state updates
         const uint32_t exAtM = __shfl(stAfter, (int)mLane);
         const uint32_t exM = mInTile ? exAtM : cExit;                        // state after the last match before this item
@@ -616,18 +675,8 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
         gc_wave_sync();
     }
     gc_wave_sync();
-    if (prof && lane == 0u) {
-        atomicAdd(&prof[0], pc0); atomicAdd(&prof[1], pc1); atomicAdd(&prof[2], pc2);
-        atomicAdd(&prof[3], (unsigned long long)pSteps); atomicAdd(&prof[4], (unsigned long long)pRounds); atomicAdd(&prof[5], 1ull);
-    }
-    if (overflow) {                                                          // (wave-uniform) same marking as for a segment that is not modelled at all
-        for (uint32_t c = lane; c < rcPerSeg; c += 64u) {
-            const uint32_t cs = ss + (c << GC_LZMA_RC_LOG);
-            GcLzmaChunkInfo ci; ci.usize = cs < blockLen ? ((blockLen - cs) < GC_LZMA_RC_SIZE ? (blockLen - cs) : GC_LZMA_RC_SIZE) : 0u;
-            ci.csize = 0xFFFFFFFFu; ci.wordStart = 0; ci.wordEnd = 0; CI[c] = ci;
-        }
-        return;
-    }
+    if (overflow) break;
+    segHasMatch = segHasMatch || cMatch != 0u;                               // (the next block of a merged segment starts from cOff / cExit / cLits / cLru as they are)
     // rc chunks -> LZMA2 chunks: greedy groups of neighbours (one lane; at most 32 chunks).  The leader carries the group (its
     // uncompressed size, the word range of all members), the other members are marked absent (usize 0), which is what every
     // later stage already skips; the group's range-coder output lies in the members' staging areas, which are contiguous.
@@ -651,6 +700,26 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
             GcLzmaChunkInfo none; none.usize = 0; none.csize = 0; none.wordStart = 0; none.wordEnd = 0;
             for (uint32_t j = 1; j < k; j++) CI[c + j] = none;
             c += k;
+        }
+    }
+    gc_wave_sync();                                                          // (lane 0 has read sWordEnd: the next block may clear it)
+  }
+    if (prof && lane == 0u) {
+        atomicAdd(&prof[0], pc0); atomicAdd(&prof[1], pc1); atomicAdd(&prof[2], pc2);
+        atomicAdd(&prof[3], (unsigned long long)pSteps); atomicAdd(&prof[4], (unsigned long long)pRounds); atomicAdd(&prof[5], 1ull);
+    }
+    if (overflow) {                                                          // (wave-uniform) same marking as for a segment that is not modelled at all -- for EVERY block of the segment:
+        for (uint32_t bi = 0; bi < nMember; bi++) {                          // the blocks behind the one that overflowed continue a model that was never coded, the ones in front go with them (the plan stores a segment whole)
+            const uint32_t sg = segLead + bi, b = sg / perBlock, ss = (sg % perBlock) << segLog;
+            const uint64_t blockBase = (uint64_t)b * GC_ZSTD_BLOCK_MAX;
+            const uint32_t blockLen = (uint32_t)((srcSize - blockBase) < GC_ZSTD_BLOCK_MAX ? (srcSize - blockBase) : GC_ZSTD_BLOCK_MAX);
+            GcLzmaChunkInfo* CI = cinfo + (uint64_t)b * GC_LZMA_RC_PER_BLOCK + (ss >> GC_LZMA_RC_LOG);
+            if (lane == 0u) segProps[sg] = bi == 0u ? (uint8_t)GC_LZMA_PROPS : (uint8_t)0xFFu;
+            for (uint32_t c = lane; c < rcPerSeg; c += 64u) {
+                const uint32_t cs = ss + (c << GC_LZMA_RC_LOG);
+                GcLzmaChunkInfo ci; ci.usize = cs < blockLen ? ((blockLen - cs) < GC_LZMA_RC_SIZE ? (blockLen - cs) : GC_LZMA_RC_SIZE) : 0u;
+                ci.csize = 0xFFFFFFFFu; ci.wordStart = 0; ci.wordEnd = 0; CI[c] = ci;
+            }
         }
     }
 }

@@ -10,29 +10,39 @@
 // carries the group, the other members are marked absent) -- becomes one LZMA2 chunk.  The first chunk of a model segment resets the
 // coder state (0xC0; 0xE0 for the first chunk of the stream) and carries the props byte, the others continue (0x80).  A segment whose
 // LZMA chunks would not be smaller than the data is stored whole (one stored chunk per rc chunk); the segment behind it starts with a state reset like
-// every segment, which is also what the decoder demands after a dictionary-resetting stored chunk.
+// every segment, which is also what the decoder demands after a dictionary-resetting stored chunk.  Round 5: a model segment may span several 128 KiB blocks
+// (segProps entry 0xFF = "continues the block in front"): only its first chunk resets, and it is stored or coded as a whole (gc_lzma2_segkind_kernel).
 #include "gc_common.h"
 #include "gc_device.h"
 #include "gc_lzma2.h"
 
-// bytes of the chunks of the segment that contains rc chunk c, as LZMA chunks; 0xFFFFFFFF if one of them overflowed its staging
-__device__ __forceinline__ bool lzma2_seg_is_lzma(const GcLzmaChunkInfo* __restrict__ cinfo, uint32_t c, uint32_t rcPerSeg)
+// Is a model segment coded as LZMA chunks, or stored?  One thread per segment ENTRY (props[sg]: the props byte of a segment's first block, 0xFF = the block
+// continues the model of the block in front -- a segment over several blocks, gc_lzma2_model_kernel, round 5); the leader's thread decides for the whole segment:
+// stored if one of its chunks overflowed its staging (or was never modelled), or if the LZMA chunks are not smaller than stored ones.  kind[sg] = 1 LZMA, 0 stored.
+extern "C" __global__ void __launch_bounds__(256)
+gc_lzma2_segkind_kernel(const GcLzmaChunkInfo* __restrict__ cinfo, const uint8_t* __restrict__ props, uint32_t nSegs, uint32_t segLog, uint8_t* __restrict__ kind)
 {
-    const uint32_t s0 = c & ~(rcPerSeg - 1u);
-    uint32_t lz = 0, raw = 0;
-    for (uint32_t k = 0; k < rcPerSeg; k++) {
-        const GcLzmaChunkInfo ci = cinfo[s0 + k];
+    const uint32_t sg = blockIdx.x * 256u + threadIdx.x;
+    if (sg >= nSegs || props[sg] == 0xFFu) return;
+    const uint32_t rcPerSeg = 1u << (segLog - GC_LZMA_RC_LOG);
+    uint32_t end = sg + 1u;
+    while (end < nSegs && props[end] == 0xFFu) end++;
+    uint32_t lz = 0, raw = 0; bool ok = true;
+    for (uint32_t c = sg * rcPerSeg; c < end * rcPerSeg && ok; c++) {
+        const GcLzmaChunkInfo ci = cinfo[c];
         if (ci.usize == 0u) continue;
-        if (ci.csize == 0xFFFFFFFFu || ci.csize == 0u) return false;
-        lz += (k == 0u ? 6u : 5u) + ci.csize; raw += 3u + ci.usize;
+        if (ci.csize == 0xFFFFFFFFu || ci.csize == 0u) { ok = false; break; }
+        lz += (c == sg * rcPerSeg ? 6u : 5u) + ci.csize; raw += 3u + ci.usize;
     }
-    return lz < raw;
+    const uint8_t k = (ok && lz < raw) ? 1u : 0u;
+    for (uint32_t q = sg; q < end; q++) kind[q] = k;
 }
 
 // L4: one workgroup; exclusive scan of chunk sizes.  flags bit0: no end marker (more shards follow)
 extern "C" __global__ void __launch_bounds__(1024)
 gc_lzma2_plan_kernel(const GcLzmaChunkInfo* __restrict__ cinfo, uint32_t nRc, uint32_t segLog, uint64_t dstCap, uint32_t flags,
-                     GcLzmaPlan* __restrict__ plan, uint64_t* __restrict__ result /* [0]=total bytes, [1]=error */)
+                     GcLzmaPlan* __restrict__ plan, uint64_t* __restrict__ result /* [0]=total bytes, [1]=error */,
+                     const uint8_t* __restrict__ segProps, const uint8_t* __restrict__ segKind)
 {
     __shared__ uint32_t sWave[16];
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
@@ -44,8 +54,8 @@ gc_lzma2_plan_kernel(const GcLzmaChunkInfo* __restrict__ cinfo, uint32_t nRc, ui
         if (c < nRc) {
             const GcLzmaChunkInfo ci = cinfo[c];
             if (ci.usize) {
-                kind = lzma2_seg_is_lzma(cinfo, c, rcPerSeg) ? 1u : 2u;
-                size = kind == 1u ? ((c & (rcPerSeg - 1u)) == 0u ? 6u : 5u) + ci.csize : 3u + ci.usize;
+                kind = segKind[c / rcPerSeg] ? 1u : 2u;
+                size = kind == 1u ? (((c & (rcPerSeg - 1u)) == 0u && segProps[c / rcPerSeg] != 0xFFu) ? 6u : 5u) + ci.csize : 3u + ci.usize;
             }
         }
         uint32_t incl = gc_wave_incl_sum(size);
@@ -79,7 +89,7 @@ gc_lzma2_emit_kernel(const uint8_t* __restrict__ src, uint32_t segLog, const uin
     const uint32_t u1 = ci.usize - 1u;
     const uint32_t rcPerSeg = 1u << (segLog - GC_LZMA_RC_LOG);
     if (p.kind == 1u) {
-        const bool segFirst = (c & (rcPerSeg - 1u)) == 0u;
+        const bool segFirst = (c & (rcPerSeg - 1u)) == 0u && segProps[c / rcPerSeg] != 0xFFu;       // (0xFF: the block continues the segment of the block in front -- an ordinary 0x80 chunk)
         const uint32_t hdr = segFirst ? 6u : 5u;
         if (t == 0) {
             const uint32_t c1 = ci.csize - 1u;

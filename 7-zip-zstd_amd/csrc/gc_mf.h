@@ -74,6 +74,20 @@ typedef uint64_t GcMfEntry;
 #endif
 #define GC_MF_LINK_SEGS   8u                              // W4: waves per (frame, partition): long lists are linked in segments
 
+// Overlapping frames (round 5).  A frame is the finder's WINDOW: F blocks whose positions are numbered with 23 bits.  Without overlap the frames tile the input and a
+// position's history is what lies between it and its frame's start -- 4 MiB on average of an 8 MiB frame, where the reference's window slides (zstd level 19: windowLog 23,
+// clevels.h:47; ZSTDMT jobs overlap by a whole window at the btultra levels, zstdmt_compress.c:741-747; Fast-LZMA2 level 7: 64 MiB dictionaries, fl2_compress.c:52-63).
+// Measured on the reference itself: zstd 19 on independent 8 MiB pieces against one stream, 32 MiB: text 1.030, lz-7zip 1.053, real sources 1.043 x.
+// With a stride S < F the frames of a GROUP of C = F + k S blocks overlap: frame i of a group is the window [i S, i S + F) of the group's blocks; it lists and links all
+// of its positions (W1..W4) but only VERIFIES the ones no earlier frame has (its last S blocks; frame 0: all F).  A position then sees between F - S and F blocks of
+// history (from the group's first F blocks on).  Groups are independent of each other (the unit of sharding and, for zstd, the zstd frame).
+// The kernels take the three numbers as ONE 32-bit argument (the old `frameBlocks`: a plain F means S = C = F):
+#define GC_MF_GEOM_ARG(F, S, C) ((uint32_t)(F) | ((uint32_t)(S) << 8) | ((uint32_t)(C) << 16))
+#define MF_F(a) ((a) & 0xFFu)
+#define MF_S(a) ((((a) >> 8) & 0xFFu) ? (((a) >> 8) & 0xFFu) : MF_F(a))
+#define MF_C(a) (((a) >> 16) ? ((a) >> 16) : MF_F(a))
+#define MF_FPG(a) (1u + (MF_C(a) - MF_F(a)) / MF_S(a))          // frames per group
+
 // W5 -> W6: one 32-bit match record per input position, (offset << 8) | length; 0 = no match
 struct GcMfGeom {
     uint32_t tileLog, partLog, verifyT;    // which geometry (wide / fast)
@@ -86,14 +100,15 @@ struct GcMfGeom {
     uint64_t cntWords;        // nFrames * (tilesPerFrame + 1) * GC_MF_PARTS
 };
 
-static inline GcMfGeom gc_mf_geom(uint64_t n, uint32_t frameBlocks, bool fast)
+static inline GcMfGeom gc_mf_geom(uint64_t n, uint32_t frameArg, bool fast)
 {
     GcMfGeom g;
+    const uint32_t frameBlocks = MF_F(frameArg);
     g.tileLog = fast ? GC_MF_FAST_TILE_LOG : GC_MF_WIDE_TILE_LOG; g.partLog = fast ? GC_MF_FAST_PART_LOG : GC_MF_WIDE_PART_LOG;
     g.verifyT = fast ? GC_MF_FAST_VERIFY_T : GC_MF_WIDE_VERIFY_T;
     g.frameBlocks = frameBlocks;
     g.nBlocks = gc_num_blocks(n);
-    g.nFrames = (g.nBlocks + frameBlocks - 1u) / frameBlocks;
+    g.nFrames = ((g.nBlocks + MF_C(frameArg) - 1u) / MF_C(frameArg)) * MF_FPG(frameArg);      // (no overlap: C = F, one frame per group)
     g.tilesPerFrame = frameBlocks * (GC_ZSTD_BLOCK_MAX >> g.tileLog);
     g.nTiles = g.nFrames * g.tilesPerFrame;
     g.frameBytes = (uint64_t)frameBlocks * GC_ZSTD_BLOCK_MAX;

@@ -30,6 +30,10 @@ def codec_grain(codec, level):
     """What gc_codec_grain returns (kept in Python too so that range planning needs no library handle)."""
     if codec == "brotli":
         return max(1, min(11, int(level))) * 8 * GRAIN_ZSTD
+    if codec == "zstd" and int(level) >= 16:
+        return 4 * FRAME_ZSTD                                     # overlapping finder frames inside 32 MiB zstd frames (csrc/gc_api.hip zstd_group_blocks)
+    if codec == "flzma2" and int(level) >= 7:
+        return 8 * FRAME_ZSTD                                     # ... inside groups of 64 MiB (flzma2_group_blocks)
     return FRAME_ZSTD                                             # zstd and FLZMA2: the windowed finder at every level
 
 
