@@ -358,7 +358,12 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
         // lane j * 8 + k: (k-th group of four windows) of block g0 + j; est[j] = the block's estimate, 0xFFFFFFFF = absent or hopeless (never merged)
         uint32_t e = 0;
         { const uint32_t j = lane >> 3, bb = g0 + j;
-          if (j < segMerge && bb < nBlocksAll) { const uint32_t* wc = winCost + (uint64_t)bb * GC_LZMA_RC_PER_BLOCK + (lane & 7u) * 4u; e = wc[0] + wc[1] + wc[2] + wc[3]; }
+          if (j < segMerge && bb < nBlocksAll) {
+              const uint64_t bs = (uint64_t)bb * GC_ZSTD_BLOCK_MAX; const uint32_t bl = (uint32_t)((srcSize - bs) < GC_ZSTD_BLOCK_MAX ? (srcSize - bs) : GC_ZSTD_BLOCK_MAX);
+              const uint32_t w0 = (lane & 7u) * 4u; const uint32_t* wc = winCost + (uint64_t)bb * GC_LZMA_RC_PER_BLOCK + w0;
+#pragma unroll
+              for (uint32_t q = 0; q < 4u; q++) if (((w0 + q) << GC_LZMA_RC_LOG) < bl) e += wc[q];      // (windows behind the end of a short last block were never written)
+          }
           e += __shfl_xor(e, 1); e += __shfl_xor(e, 2); e += __shfl_xor(e, 4); }
         uint32_t est[8];
 #pragma unroll

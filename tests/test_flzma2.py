@@ -131,11 +131,26 @@ def test_emu_segment_whose_words_outgrow_their_place_is_stored(O, pkg, emu_lib_p
     stored.  The test hook lowers the cap so that ordinary text takes that path: segments above the cap are stored, the others stay LZMA, and the
     stream decodes."""
     x = O.corpus("text-zipf", BLK + 40_000)
+    monkeypatch.setenv("GC_SEG_MERGE", "0")                        # every block a model segment of its own (round 5 merges cheap neighbours: the case below)
     plain = pkg.Flzma2Encoder(lib_path=emu_lib_path, level=5); c0 = _roundtrip(O, plain, x); plain.close()
     monkeypatch.setenv("GC_SEG_WORD_CAP", "300000")                # a 128 KiB segment of this text needs ~350 000 words, the short last one far fewer
     capped = pkg.Flzma2Encoder(lib_path=emu_lib_path, level=5); c1 = _roundtrip(O, capped, x); capped.close()
     assert len(c1) > len(c0) + BLK // 2                             # the whole first segment went out stored ...
     assert len(c1) < x.size + 64                                   # ... but not everything (the short last segment is still LZMA)
+
+
+def test_emu_merged_segment_one_of_whose_blocks_outgrows_its_place_is_stored_whole(O, pkg, emu_lib_path, monkeypatch):
+    """Round 5: cheap neighbouring blocks share one model segment (gc_lzma2_model_kernel `segMerge`).  When the words of ONE block of such a segment outgrow their
+    place the whole segment is stored -- the blocks behind continue a model that was never coded, the blocks in front share the segment's fate in the plan."""
+    x = O.corpus("text-zipf", BLK + 40_000)
+    merged = pkg.Flzma2Encoder(lib_path=emu_lib_path, level=5); c0 = _roundtrip(O, merged, x); merged.close()
+    monkeypatch.setenv("GC_SEG_MERGE", "0")
+    single = pkg.Flzma2Encoder(lib_path=emu_lib_path, level=5); c1 = _roundtrip(O, single, x); single.close()
+    assert len(c0) < len(c1)                                        # the two blocks as one segment: one state reset fewer
+    monkeypatch.delenv("GC_SEG_MERGE")
+    monkeypatch.setenv("GC_SEG_WORD_CAP", "300000")
+    capped = pkg.Flzma2Encoder(lib_path=emu_lib_path, level=5); c2 = _roundtrip(O, capped, x); capped.close()
+    assert x.size < len(c2) < x.size + 256                          # both blocks stored
 
 
 def test_emu_shards_concatenate(O, emu_fl2):
