@@ -630,7 +630,7 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
                                                   // the price-based parse 0.98 -- so it starts at level 10 here
     gc_env_u32("GC_PRICE_PARSE", 0u, 1u, &c->priceParse);                                      // test hook
     // Overlapping finder frames (gc_mf.h) from level 16: the zstd frame becomes the GROUP (the reference's own frames are the whole input with a sliding window).
-    const uint32_t zGroup = zstd_group_blocks(level);
+    uint32_t zGroup = zstd_group_blocks(level); gc_env_u32("GC_MF_GROUP", 1u, 65535u, &zGroup);                            // test hook: blocks per group
     uint32_t zArg = frameBlocks;                                                               // what the finder takes
     if (zGroup > frameBlocks && frameBlocks == GC_MF_MAX_FRAME_BLOCKS && nBlocks > frameBlocks) {
         uint32_t stride = zstd_stride_blocks(level); gc_env_u32("GC_MF_STRIDE", 1u, GC_MF_MAX_FRAME_BLOCKS, &stride);      // test hook (blocks; 64 = no overlap)
@@ -850,7 +850,7 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     if (frameBlocks > 1u && c->dbgFrameBlocks) frameBlocks = c->dbgFrameBlocks;
     if (frameBlocks > nBlocks) frameBlocks = nBlocks;
     uint32_t fArg = frameBlocks;                                                               // what the finder takes: overlapping frames from level 7 (gc_mf.h)
-    { const uint32_t grp = flzma2_group_blocks(level);
+    { uint32_t grp = flzma2_group_blocks(level); gc_env_u32("GC_MF_GROUP", 1u, 65535u, &grp);                            // test hook: blocks per group
       if (grp > frameBlocks && frameBlocks == GC_MF_MAX_FRAME_BLOCKS && nBlocks > frameBlocks) {
           uint32_t stride = flzma2_stride_blocks(level); gc_env_u32("GC_MF_STRIDE", 1u, GC_MF_MAX_FRAME_BLOCKS, &stride);      // test hook (blocks; 64 = no overlap)
           if (stride < frameBlocks && (frameBlocks % stride) == 0u && ((grp - frameBlocks) % stride) == 0u) fArg = GC_MF_GEOM_ARG(frameBlocks, stride, grp);
