@@ -56,6 +56,9 @@ extern "C" __global__ void gc_mf_verify_short_kernel(const uint8_t*, uint64_t, u
 extern "C" __global__ void gc_mf_count_far_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
 extern "C" __global__ void gc_mf_scatter_far_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
 extern "C" __global__ void gc_mf_verify_far_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
+extern "C" __global__ void gc_mf_count_far2_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
+extern "C" __global__ void gc_mf_scatter_far2_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
+extern "C" __global__ void gc_mf_verify_far2_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
 extern "C" __global__ void gc_mf_deepen_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, uint32_t*);
 extern "C" __global__ void gc_mf_count_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
 extern "C" __global__ void gc_mf_scan_kernel_p8(uint32_t*, uint32_t);
@@ -71,6 +74,9 @@ extern "C" __global__ void gc_mf_verify_short_kernel_p8(const uint8_t*, uint64_t
 extern "C" __global__ void gc_mf_count_far_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
 extern "C" __global__ void gc_mf_scatter_far_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
 extern "C" __global__ void gc_mf_verify_far_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
+extern "C" __global__ void gc_mf_count_far2_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
+extern "C" __global__ void gc_mf_scatter_far2_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
+extern "C" __global__ void gc_mf_verify_far2_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
 extern "C" __global__ void gc_mf_deepen_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, uint32_t*);
 extern "C" __global__ void gc_mf_vparse_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, GcSeqRaw*, uint8_t*, GcBlockMeta*, unsigned long long*);
 extern "C" __global__ void gc_mf_vparse_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, GcSeqRaw*, uint8_t*, GcBlockMeta*, unsigned long long*);
@@ -81,12 +87,12 @@ extern "C" __global__ void gc_mf_short_kernel(const uint8_t*, uint64_t, uint32_t
 extern "C" __global__ void gc_mf_dp2_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
 extern "C" __global__ void gc_mf_dp3_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
 extern "C" __global__ void gc_mf_litprice_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, const uint16_t*, uint32_t, uint8_t*);
-extern "C" __global__ void gc_mf_dpl2_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*);
-extern "C" __global__ void gc_mf_dpl2s_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*);
-extern "C" __global__ void gc_mf_dplz_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*);
-extern "C" __global__ void gc_mf_dplzs_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*);
-extern "C" __global__ void gc_mf_dpl3_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*);
-extern "C" __global__ void gc_mf_dpl3s_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*);
+extern "C" __global__ void gc_mf_dpl2_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*, uint32_t*);
+extern "C" __global__ void gc_mf_dpl2s_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*, uint32_t*);
+extern "C" __global__ void gc_mf_dplz_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*, uint32_t*);
+extern "C" __global__ void gc_mf_dplzs_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*, uint32_t*);
+extern "C" __global__ void gc_mf_dpl3_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*, uint32_t*);
+extern "C" __global__ void gc_mf_dpl3s_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*, uint32_t*);
 
 extern "C" __global__ void gc_lzma2_prep_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t, uint64_t*, uint32_t*);
 extern "C" __global__ void gc_lzma2_model_kernel(const uint8_t*, uint64_t, const uint64_t*, const uint32_t*, uint32_t, uint32_t, uint16_t*, GcLzmaChunkInfo*, const uint32_t*, unsigned long long*, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t, uint32_t, uint32_t);
@@ -121,6 +127,9 @@ struct gc_ctx {
     uint32_t priceParse;      // W5s + W7: price-based parse on top of the greedy one (gc_lz_price.hip)
     uint32_t priceMinLen, priceLitCtx;        // its shortest match and literal context bits (LZMA: 2, 7; zstd: 3, 0)
     int lastCodecHint;        // codec of the call being enqueued (0 zstd, 1 flzma2, 2 brotli): which W7L kernels the finder launches
+    uint32_t shortPlain;      // overlapping frames: the pass with 4- / 3-byte keys runs over frames that tile the input (launch_finder_part)
+    uint32_t farPass2;        // one more pass of the far kind with keys of 32 / 24 bytes (gc_lz_window.hip MF_FAR2)
+    uint32_t reParse;         // W7L runs a second full pass under prices made from the first one's own paths (launch_finder_part)
     uint32_t laneParse;       // the price-based parse is W7L (a lane per window, repeat distances at every node) rather than W7
     uint32_t dbgFrameBlocks, dbgPartFrames;   // test hooks (env GC_FRAME_BLOCKS / GC_PART_FRAMES): small frames / parts so that
                                               // the multi-frame and multi-part paths can be exercised on small inputs
@@ -342,7 +351,7 @@ static int ensure_finder_workspace(gc_ctx* c, size_t n, uint32_t frameBlocks)
     const size_t needPrice = (size_t)g.nBlocks * GC_PRICE_WORDS * sizeof(uint16_t);
     const size_t needTileWord = ((size_t)g.nTiles + 64u) * sizeof(uint32_t);
     if (needTileWord > c->mfTileWordCap || needCnt > c->mfCntCap || needEnt > c->mfEntCap || needEnt > c->mfEnt2Cap || needRec > c->mfRecCap || ((c->searchDepth || c->shortPass) && needRec > c->mfRec2Cap) ||
-        (c->priceParse && (needRec / 2u > c->mfRec3Cap || needRec > c->mfDpCap || needPrice > c->mfPriceCap || (size_t)g.nBlocks * 128u > c->mfWinCostCap || (size_t)g.nBlocks * GC_DPS_WORDS * 4u > c->mfDpStatCap || needRec / 4u > c->mfLitPriceCap))) {
+        (c->priceParse && (needRec / 2u > c->mfRec3Cap || needRec > c->mfDpCap || needPrice > c->mfPriceCap || (size_t)g.nBlocks * 128u > c->mfWinCostCap || (size_t)g.nBlocks * GC_DPS_WORDS * 8u > c->mfDpStatCap || needRec / 4u > c->mfLitPriceCap))) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         int rc;
         if ((rc = mf_grow(c, (void**)&c->mfTileWord, &c->mfTileWordCap, needTileWord, "tile counts")) != GC_OK) return rc;
@@ -356,7 +365,7 @@ static int ensure_finder_workspace(gc_ctx* c, size_t n, uint32_t frameBlocks)
             if ((rc = mf_grow(c, (void**)&c->mfDp, &c->mfDpCap, needRec, "price-parse records")) != GC_OK) return rc;
             if ((rc = mf_grow(c, (void**)&c->mfPrice, &c->mfPriceCap, needPrice, "price tables")) != GC_OK) return rc;
             if ((rc = mf_grow(c, (void**)&c->mfWinCost, &c->mfWinCostCap, (size_t)g.nBlocks * 128u, "window costs")) != GC_OK) return rc;
-            if ((rc = mf_grow(c, (void**)&c->mfDpStat, &c->mfDpStatCap, (size_t)g.nBlocks * GC_DPS_WORDS * 4u, "path symbol counts")) != GC_OK) return rc;
+            if ((rc = mf_grow(c, (void**)&c->mfDpStat, &c->mfDpStatCap, (size_t)g.nBlocks * GC_DPS_WORDS * 8u, "path symbol counts (two sets: the sample's and the first full pass's)")) != GC_OK) return rc;
             if ((rc = mf_grow(c, (void**)&c->mfLitPrice, &c->mfLitPriceCap, needRec / 4u, "literal prices")) != GC_OK) return rc;
         }
     }
@@ -407,9 +416,9 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
     MF_LINK(cnt, ent, ent2);
     HIPCHK(c, hipEventRecord(ev[4], st));
     // the levels that parse the first pass's records as they are: verify + parse in one kernel, the records stay in LDS (W5 + W6 fused)
-    uint32_t fused = (!c->halfList && !c->farPass && !c->searchDepth && !c->priceParse && !c->shortPass) ? 1u : 0u;
+    uint32_t fused = (!c->halfList && !c->farPass && !c->farPass2 && !c->searchDepth && !c->priceParse && !c->shortPass) ? 1u : 0u;
     gc_env_u32("GC_FUSED_PARSE", 0u, 1u, &fused);               // test hook: 0 = the two kernels
-    if (fused && (c->halfList || c->farPass || c->searchDepth || c->priceParse || c->shortPass || MF_C(frameArg) != MF_F(frameArg))) fused = 0u;
+    if (fused && (c->halfList || c->farPass || c->farPass2 || c->searchDepth || c->priceParse || c->shortPass || MF_C(frameArg) != MF_F(frameArg))) fused = 0u;
     if (fused) {
         uint32_t mode = 2u; gc_env_u32("GC_FUSED_MODE", 1u, 2u, &mode);       // test hook: 1 = a workgroup per block (tiles in order), 2 = a workgroup per tile
         if (mode == 2u) {
@@ -441,6 +450,14 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
         GC_LAUNCH(MFSEL(gc_mf_verify_far_kernel), perT * GC_XCDS, g.verifyT, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt,
                   (const GcMfEntry*)ent2, rec);
     }
+    if (c->farPass2) {                                          // third pass of the far kind: keys of 32 / 24 bytes, capped records ranked by what lies behind the cap (gc_lz_window.hip MF_FAR2; timed with W5)
+        GC_LAUNCH(MFSEL(gc_mf_count_far2_kernel), perT * GC_XCDS, nParts, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, cnt);
+        GC_LAUNCH(MFSEL(gc_mf_scan_kernel), g.nFrames, 1024, st, cnt, g.tilesPerFrame);
+        GC_LAUNCH(MFSEL(gc_mf_scatter_far2_kernel), perT * GC_XCDS, nParts, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt, ent);
+        MF_LINK(cnt, ent, ent2);
+        GC_LAUNCH(MFSEL(gc_mf_verify_far2_kernel), perT * GC_XCDS, g.verifyT, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt,
+                  (const GcMfEntry*)ent2, rec);
+    }
     HIPCHK(c, hipEventRecord(ev[11], st));
     if (c->searchDepth) {                                       // W5b: follow match links (timed with W5)
         uint32_t* rec2 = c->mfRec2 + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
@@ -452,11 +469,19 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
     const uint32_t* recDp = rec;                                // what W7 reads: the records, or the records + short candidates
     if (c->priceParse && c->shortPass) {                        // third pass with 4- / 3-byte keys (timed with W5)
         uint32_t* recN = rec == c->mfRec + (size_t)blk0 * GC_ZSTD_BLOCK_MAX ? c->mfRec2 + (size_t)blk0 * GC_ZSTD_BLOCK_MAX : c->mfRec + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
-        GC_LAUNCH(MFSEL(gc_mf_count_short_kernel), perT * GC_XCDS, nParts, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, cnt);
-        GC_LAUNCH(MFSEL(gc_mf_scan_kernel), g.nFrames, 1024, st, cnt, g.tilesPerFrame);
-        GC_LAUNCH(MFSEL(gc_mf_scatter_short_kernel), perT * GC_XCDS, nParts, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt, ent);
-        MF_LINK(cnt, ent, ent2);
-        GC_LAUNCH(MFSEL(gc_mf_verify_short_kernel), perT * GC_XCDS, g.verifyT, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt,
+        // Overlapping frames list and link every position once per frame that holds it.  A match of 3-4 bytes MiBs back is never worth its distance, so this pass runs
+        // over frames that tile the input (the plain geometry F: a frame then lies inside its group, whose start is as far back as the stages behind the finder let a match reach)
+        const uint32_t fbS = c->shortPlain ? MF_F(frameArg) : frameArg;                 // (the levels that are not after speed keep the overlap: the generator of lz-7zip copies 3-4 bytes from anywhere in its window, 32 MiB at FLZMA2 level 7: +0.26 % without)
+        const GcMfGeom gs = gc_mf_geom(n, fbS, c->mfFast != 0u);
+        const uint32_t perTs = gc_xcd_per(gs.nTiles), nListsS = gs.nFrames * nParts;
+        uint32_t* cntS = c->mfCnt + ((size_t)((blk0 / MF_C(fbS)) * MF_FPG(fbS)) * (gs.tilesPerFrame + 1u) << gs.partLog);
+        GC_LAUNCH(MFSEL(gc_mf_count_short_kernel), perTs * GC_XCDS, nParts, st, src, (uint64_t)n, fbS, gs.nTiles, perTs, cntS);
+        GC_LAUNCH(MFSEL(gc_mf_scan_kernel), gs.nFrames, 1024, st, cntS, gs.tilesPerFrame);
+        GC_LAUNCH(MFSEL(gc_mf_scatter_short_kernel), perTs * GC_XCDS, nParts, st, src, (uint64_t)n, fbS, gs.nTiles, perTs, (const uint32_t*)cntS, ent);
+        {   uint32_t* ticket_ = c->mfTicket + part * 16u + linkLaunch++;
+            const uint32_t gridS = nListsS * GC_MF_LINK_SEGS < c->nCU * linkWpc ? nListsS * GC_MF_LINK_SEGS : c->nCU * linkWpc;
+            GC_LAUNCH(MFSEL(gc_mf_link_kernel), gridS, 64, st, (const uint32_t*)cntS, (const GcMfEntry*)ent, ent2, gs.tilesPerFrame, gs.frameBytes, nListsS, ticket_); }
+        GC_LAUNCH(MFSEL(gc_mf_verify_short_kernel), perTs * GC_XCDS, gs.verifyT, st, src, (uint64_t)n, fbS, gs.nTiles, perTs, (const uint32_t*)cntS,
                   (const GcMfEntry*)ent2, (const uint32_t*)rec, recN);
         recDp = recN;
     }
@@ -486,7 +511,19 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
         uint32_t laneDp = c->laneParse ? (c->lastCodecHint == 1 ? 1u : 2u) : 0u; gc_env_u32("GC_DPL", 0u, 2u, &laneDp);
         uint8_t* lpr = c->mfLitPrice + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
         if (laneDp) GC_LAUNCH(gc_mf_litprice_kernel, perB * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perB, (const uint16_t*)price, litCtxArg, lpr);
-        for (uint32_t phase = phase0; phase != 3u; phase = phase == 0u ? 1u : 3u) {
+        // Round 5: a re-priced SECOND pass over every window (W7L only): the first full pass counts the symbols of its own paths per block (all 32 windows, not the
+        // sample's 32 x 512 bytes), the second prices lengths, distance slots and the repeat / literal flags from those counts -- the static counterpart of the reference's
+        // statistics that follow its own parse (ZSTD_updateStats / ZSTD_rescaleFreqs zstd_opt.c:356,141; LZMA's prices refreshed from the live model lzma2_enc.c:1651-1682).
+        uint32_t reparse = c->reParse; gc_env_u32("GC_DP_REPARSE", 0u, 1u, &reparse);          // test hook
+        if (!laneDp || phase0 == 2u) reparse = 0u;
+        if (reparse) laneDp = 1u;                                    // (every block in W7L: the counts come from its walk back)
+        uint32_t* const dps2 = c->mfDpStat + c->mfDpStatCap / 8u + (size_t)blk0 * GC_DPS_WORDS;        // second half of the allocation
+        if (reparse) HIPCHK(c, hipMemsetAsync(dps2, 0, (size_t)nBlocks * GC_DPS_WORDS * sizeof(uint32_t), st));
+        uint32_t* const dpsA = dps;
+        for (uint32_t pass = phase0 == 2u ? 1u : 0u; pass < (reparse ? 3u : 2u); pass++) {
+            const uint32_t phase = phase0 == 2u ? 2u : (pass == 0u ? 0u : 1u);
+            uint32_t* const dps = pass == 2u ? dps2 : dpsA;          // the counts this pass prices from (pass 0 writes them)
+            uint32_t* const DPS_OUT = (pass == 1u && reparse) ? dps2 : (uint32_t*)nullptr;
             const uint32_t nDpWg = nBlocks * (phase == 0u ? 1u : 8u), perD = gc_xcd_per(nDpWg);
             uint32_t* wcp = phase == 0u ? (uint32_t*)nullptr : wc;
             if (laneDp) {
@@ -494,20 +531,20 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
                 const bool w2 = win2k != 0u && phase != 0u;
                 const uint32_t nItems = w2 ? nBlocks : (nBlocks + 1u) / 2u, perL = gc_xcd_per(nItems);     // a wave = two blocks (2 KiB windows: one)
                 const bool select = laneDp == 2u && phase == 1u && !w2;
-                const uint32_t phaseK = phase | (w2 ? 16u : 0u) | (select ? GC_DP_SELECT : 0u);
+                const uint32_t phaseK = phase | (w2 ? 16u : 0u) | (select ? GC_DP_SELECT : 0u) | (DPS_OUT ? GC_DP_COUNT : 0u);
                 if (select) {                                      // the blocks without repeats: W7
                     if (c->priceMinLen <= 2u) GC_LAUNCH(gc_mf_dp2_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, groupBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
                     else GC_LAUNCH(gc_mf_dp3_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, groupBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
                 }
                 if (c->priceMinLen <= 2u) {
-                    if (phase == 0u) GC_LAUNCH(gc_mf_dpl2s_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
-                    else GC_LAUNCH(gc_mf_dpl2_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
+                    if (phase == 0u) GC_LAUNCH(gc_mf_dpl2s_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr, DPS_OUT);
+                    else GC_LAUNCH(gc_mf_dpl2_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr, DPS_OUT);
                 } else if (c->lastCodecHint == 0) {
-                    if (phase == 0u) GC_LAUNCH(gc_mf_dplzs_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
-                    else GC_LAUNCH(gc_mf_dplz_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
+                    if (phase == 0u) GC_LAUNCH(gc_mf_dplzs_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr, DPS_OUT);
+                    else GC_LAUNCH(gc_mf_dplz_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr, DPS_OUT);
                 } else {
-                    if (phase == 0u) GC_LAUNCH(gc_mf_dpl3s_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
-                    else GC_LAUNCH(gc_mf_dpl3_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
+                    if (phase == 0u) GC_LAUNCH(gc_mf_dpl3s_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr, DPS_OUT);
+                    else GC_LAUNCH(gc_mf_dpl3_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr, DPS_OUT);
                 }
             } else
             if (c->priceMinLen <= 2u) GC_LAUNCH(gc_mf_dp2_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, groupBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
@@ -622,6 +659,10 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
                                                   // 1.027 -> 0.984 x the reference on text, level 12 1.040 -> 1.001 x
     c->shortPass = level >= 10 ? 1u : 0u;         // the reference's btopt strategies search 3-byte matches (minMatch 3, clevels.h:44-47); from level 10 since round 3, see priceParse
     gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass); gc_env_u32("GC_SHORT_PASS", 0u, 1u, &c->shortPass);   // test hooks
+    c->shortPlain = 0u;
+    c->farPass2 = level >= 7 ? 1u : 0u; gc_env_u32("GC_FAR2_PASS", 0u, 1u, &c->farPass2);      // keys of 32 / 24 bytes where the reference searches chains / trees for the LONGEST match: real sources, emulator, 8 MiB:
+                                                                                              // level 9 1.118 -> 1.050 x the reference, level 19 1.115 -> 1.097
+    c->reParse = 0u;
     c->laneParse = level >= 16 ? 1u : 0u;         // the reference's btopt .. btultra2 (clevels.h:44-50) price its three repeat offsets at every position; real sources / binaries at level 19
                                                   // (emulator, 4 MiB): 1.109 / 1.124 x the reference with W7, 1.081 / 1.075 with W7L.  Levels 10-15 (the reference: lazy2 / btlazy2) keep W7
     c->lastCodecHint = 0; c->priceMinLen = 3u; c->priceLitCtx = 0u;     // zstd: matches of >= 3 bytes, literals without context (one Huffman table per block)
@@ -630,9 +671,9 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
                                                   // the price-based parse 0.98 -- so it starts at level 10 here
     gc_env_u32("GC_PRICE_PARSE", 0u, 1u, &c->priceParse);                                      // test hook
     // Overlapping finder frames (gc_mf.h) from level 16: the zstd frame becomes the GROUP (the reference's own frames are the whole input with a sliding window).
-    uint32_t zGroup = zstd_group_blocks(level); gc_env_u32("GC_MF_GROUP", 1u, 65535u, &zGroup);                            // test hook: blocks per group
+    uint32_t zGroup = zstd_group_blocks(level); const bool grpHook = gc_env_u32("GC_MF_GROUP", 1u, 65535u, &zGroup);      // test hook: blocks per group (with GC_FRAME_BLOCKS and GC_MF_STRIDE: overlapping frames of a few blocks)
     uint32_t zArg = frameBlocks;                                                               // what the finder takes
-    if (zGroup > frameBlocks && frameBlocks == GC_MF_MAX_FRAME_BLOCKS && nBlocks > frameBlocks) {
+    if (zGroup > frameBlocks && (frameBlocks == GC_MF_MAX_FRAME_BLOCKS || grpHook) && nBlocks > frameBlocks) {
         uint32_t stride = zstd_stride_blocks(level); gc_env_u32("GC_MF_STRIDE", 1u, GC_MF_MAX_FRAME_BLOCKS, &stride);      // test hook (blocks; 64 = no overlap)
         if (stride < frameBlocks && (frameBlocks % stride) == 0u && ((zGroup - frameBlocks) % stride) == 0u) zArg = GC_MF_GEOM_ARG(frameBlocks, stride, zGroup);
     }
@@ -793,7 +834,8 @@ extern "C" size_t gc_flzma2_compress_bound(size_t n)
 static uint32_t flzma2_frame_blocks(int level) { (void)level; return GC_MF_MAX_FRAME_BLOCKS; }
 // Levels 7-9 (the reference: dictionaries of 64 / 64 / 128 MiB, fl2_compress.c:59-62): overlapping finder frames (gc_mf.h) in groups of 64 MiB, stride 4 MiB at 7, 2 MiB at 8-9
 // (a position is sure of 4 / 6 MiB of history; the window itself stays 8 MiB: 23-bit positions).  Levels 1-6: frames that tile the input.
-static uint32_t flzma2_group_blocks(int level) { return level >= 7 ? 8u * GC_MF_MAX_FRAME_BLOCKS : GC_MF_MAX_FRAME_BLOCKS; }
+// Levels 5-6 (round 5; the reference: 16 / 32 MiB dictionaries): groups of 16 MiB, stride 4 MiB -- real shared objects, 32 MiB at level 5 on the emulator: 1.0186 -> 1.0148 x the reference
+static uint32_t flzma2_group_blocks(int level) { return level >= 7 ? 8u * GC_MF_MAX_FRAME_BLOCKS : (level >= 5 ? 2u * GC_MF_MAX_FRAME_BLOCKS : GC_MF_MAX_FRAME_BLOCKS); }
 static uint32_t flzma2_stride_blocks(int level) { return level >= 8 ? GC_MF_MAX_FRAME_BLOCKS / 4u : GC_MF_MAX_FRAME_BLOCKS / 2u; }
 
 // dictionary-size property byte of the 7z coder (Lzma2Encoder.cpp:353-364): dict = (2|(p&1)) << (p/2+11).
@@ -843,6 +885,9 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     c->shortPass = level >= 3 ? 1u : 0u;          // ... and holds the nearest match of >= 2 bytes for every position
     gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass); gc_env_u32("GC_SHORT_PASS", 0u, 1u, &c->shortPass);   // test hooks
     if (gc_env_u32("GC_SEARCH_DEPTH", 0u, 64u, &c->searchDepth)) c->searchShallow = c->searchDepth < 2u ? c->searchDepth : 2u;
+    c->shortPlain = level < 7 ? 1u : 0u;
+    c->farPass2 = level >= 7 ? 1u : 0u; gc_env_u32("GC_FAR2_PASS", 0u, 1u, &c->farPass2);      // keys of 32 / 24 bytes (gc_lz_window.hip MF_FAR2) at the ultra levels
+    c->reParse = 0u;
     c->laneParse = 1u; c->lastCodecHint = 1; c->priceMinLen = 2u; c->priceLitCtx = 7u;
     c->priceParse = level >= 3 ? 1u : 0u;         // the reference's FL2_opt strategy starts at level 3 of its 7-Zip table (fl2_compress.c:52-63); round 3 (run r03_fl2ab): level 3 with
                                                   // the greedy parse was 1.038 x the reference on silesia-like, with the price-based parse 1.002
@@ -850,8 +895,8 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     if (frameBlocks > 1u && c->dbgFrameBlocks) frameBlocks = c->dbgFrameBlocks;
     if (frameBlocks > nBlocks) frameBlocks = nBlocks;
     uint32_t fArg = frameBlocks;                                                               // what the finder takes: overlapping frames from level 7 (gc_mf.h)
-    { uint32_t grp = flzma2_group_blocks(level); gc_env_u32("GC_MF_GROUP", 1u, 65535u, &grp);                            // test hook: blocks per group
-      if (grp > frameBlocks && frameBlocks == GC_MF_MAX_FRAME_BLOCKS && nBlocks > frameBlocks) {
+    { uint32_t grp = flzma2_group_blocks(level); const bool grpHook = gc_env_u32("GC_MF_GROUP", 1u, 65535u, &grp);      // test hook: blocks per group (with GC_FRAME_BLOCKS and GC_MF_STRIDE: overlapping frames of a few blocks)
+      if (grp > frameBlocks && (frameBlocks == GC_MF_MAX_FRAME_BLOCKS || grpHook) && nBlocks > frameBlocks) {
           uint32_t stride = flzma2_stride_blocks(level); gc_env_u32("GC_MF_STRIDE", 1u, GC_MF_MAX_FRAME_BLOCKS, &stride);      // test hook (blocks; 64 = no overlap)
           if (stride < frameBlocks && (frameBlocks % stride) == 0u && ((grp - frameBlocks) % stride) == 0u) fArg = GC_MF_GEOM_ARG(frameBlocks, stride, grp);
       } }
@@ -1017,6 +1062,9 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     gc_env_u32("GC_SEARCH_SHALLOW", 0u, 64u, &c->searchShallow);                                // test hook: links followed by the positions inside a match and in tiles without long matches
     c->farPass = level >= 5 ? 1u : 0u; c->shortPass = 0;      // longer matches stand in for the context modelling / block splitting B1 lacks
     gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass);                                            // test hook
+    c->shortPlain = 0u;
+    c->farPass2 = 0u; gc_env_u32("GC_FAR2_PASS", 0u, 1u, &c->farPass2);
+    c->reParse = 0u;
     c->laneParse = 0u; c->lastCodecHint = 2; c->priceMinLen = 3u; c->priceLitCtx = 0u;     // copies of >= 3 bytes (a 2-byte copy at a fresh distance never pays in brotli), one literal code per meta-block
     c->priceParse = level >= 8 ? 1u : 0u;         // the reference parses greedily up to quality 9 (zopfli from 10).  Measured at quality 6
                                                   // (run 28, 64 MiB per corpus): greedy + far pass 0.979-1.002 x the reference at 16.6 GB/s,

@@ -81,6 +81,9 @@
 #ifndef DPL_SREP_ANY
 #define DPL_SREP_ANY 1               // 1: the short repeat is offered at the node's rep0 whether or not that is known for certain (L2 codes a wrong one as a literal); 0: round 4
 #endif
+#ifndef DPL_ALL_LENGTHS
+#define DPL_ALL_LENGTHS (MINLEN == 3u && REPS)      // zstd's W7L: every length of a candidate is an edge (relax())
+#endif
 #define DPL_SURE     0x80000000u      // in rep0 of a node: the distance is the decoder's rep0 for certain (a match of this window lies on the way)
 
 __device__ __forceinline__ uint32_t dpl_item(uint32_t bid, uint32_t per) { return (bid & (GC_XCDS - 1u)) * per + (bid >> 3); }
@@ -117,19 +120,21 @@ extern "C" int gc_dpl_prof_read(unsigned long long* out, int reset)
 template <bool REPS, uint32_t MINLEN, bool SAMPLE /* a wave = two blocks: false = all their windows (2 x 32 x 4 KiB), true = a sample (32 x 512 B of each, counted) */>
 __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t frameBlocks, uint32_t phaseArg, uint32_t* __restrict__ dpStat,
                                         uint32_t litCtxArg, const uint32_t* __restrict__ rec, const uint16_t* __restrict__ rec3, const uint16_t* __restrict__ priceTab,
-                                        uint32_t* __restrict__ recOut, uint32_t* __restrict__ winCost, const uint8_t* __restrict__ litPrice)
+                                        uint32_t* __restrict__ recOut, uint32_t* __restrict__ winCost, const uint8_t* __restrict__ litPrice,
+                                        uint32_t* __restrict__ dpStatOut /* phase bit 6 (a pass over every window): the symbol counts of THIS pass's paths, per block, for one more pass under prices made from them */)
 {
     __shared__ unsigned long long sCost[DPL_RC][64];
     __shared__ GcU4 sReps[REPS ? DPL_RR : 1u][64];
     constexpr uint32_t BPW = 2u;
     __shared__ uint16_t sPrice[BPW][GC_PRICE_WORDS - GC_PRICE_LEN];      // (the literal rows are not needed here: gc_mf_litprice_kernel has priced every position)
-    __shared__ uint32_t sCnt[SAMPLE ? BPW : 1u][SAMPLE ? GC_DPS_WORDS : 1u];
+    __shared__ uint32_t sCnt[BPW][GC_DPS_WORDS];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t role = DPL_PAIR ? gc_uniform(threadIdx.x >> 6) : 0u;
     const bool isA = !DPL_PAIR || role == 0u, isB = !DPL_PAIR || role == 1u;      // wave 0 / wave 1 of the group (one wave: both)
     const bool isC = GC_DPL_THREADS == 192u ? role == 2u : isA;   // a third wave takes the literal, the capped rest and the short candidate off wave 0
     const uint32_t litCtxMask = litCtxArg & 0xFFu, hasPrev = litCtxArg >> 31;
     const bool win2k = !SAMPLE && (phaseArg & 16u) != 0u;         // every window of ONE block per wave, 64 x 2 KiB (more, shorter waves: the launch ends with its slowest wave)
+    const bool countB = !SAMPLE && (phaseArg & GC_DP_COUNT) != 0u && dpStatOut != nullptr;      // count the paths of this pass as phase A counts its sample (round 5: the re-priced second pass)
     const bool selective = !SAMPLE && (phaseArg & GC_DP_SELECT) != 0u;      // phase B of the blocks whose sampled paths repeat distances; the others are W7's (gc_mf.h GC_DPS_RICH)
     phaseArg &= 15u;
     const uint32_t BPWr = win2k ? 1u : BPW;
@@ -155,10 +160,12 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
     static const int xHints = getenv("GC_X_HINTS") ? atoi(getenv("GC_X_HINTS")) : 63;
     static const bool xSrepAny = getenv("GC_X_SREP_ANY") ? atoi(getenv("GC_X_SREP_ANY")) != 0 : DPL_SREP_ANY != 0;
     (void)xWin4k;
+    static const bool allLen = getenv("GC_X_ALL_LEN") ? atoi(getenv("GC_X_ALL_LEN")) != 0 : DPL_ALL_LENGTHS != 0;
     const uint32_t winLen = SAMPLE ? 512u : (win2k ? 2048u : 4096u);
     const uint32_t w0 = win2k ? lane << 11 : ((lane & 31u) << 12) + (SAMPLE ? 1536u : 0u);
 #else
     const int xWarm = DPL_WARM; const int xSparse = 0; const bool xSrepAny = DPL_SREP_ANY != 0;
+    const bool allLen = DPL_ALL_LENGTHS != 0;
     const uint32_t winLen = SAMPLE ? 512u : (win2k ? 2048u : 4096u);
     const uint32_t w0 = win2k ? lane << 11 : ((lane & 31u) << 12) + (SAMPLE ? 1536u : 0u);
 #endif
@@ -169,7 +176,7 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
     for (uint32_t q = 0; q < BPW; q++) {
         const uint32_t bb = q < BPWr ? item * BPWr + q : nBlocks;
         if (bb < nBlocks) { const GcU4* T4 = (const GcU4*)(priceTab + (uint64_t)bb * GC_PRICE_WORDS + GC_PRICE_LEN); GcU4* S4 = (GcU4*)sPrice[q]; for (uint32_t i = lane; i < (GC_PRICE_WORDS - GC_PRICE_LEN) / 8u; i += 64u) S4[i] = T4[i]; }
-        if (phaseA) for (uint32_t i = lane; i < GC_DPS_WORDS; i += 64u) sCnt[q][i] = 0;
+        if (phaseA || countB) for (uint32_t i = lane; i < GC_DPS_WORDS; i += 64u) sCnt[q][i] = 0;
     }
     gc_wave_sync();
     for (uint32_t q = 0; q < BPW; q++) {
@@ -435,6 +442,13 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
             const uint32_t hi = (x >= x0 && x <= pre) ? hiBase + (lp << 6) : 0xFFFFFFFFu;
             atomicMin(&myCost[slotOf(x) * 64u], ((unsigned long long)hi << 32) | (loBase | (x - 1u)));
         }
+        if (allLen) {                                              // every length between the static ones and the last four (zstd levels >= 16: ZSTD_compressBlock_opt_generic prices every length of every match, zstd_opt.c:1230-1250)
+            for (uint32_t x = LO + 1u; !DPL_NONE_LONGER(x + 4u, Lm); x++) {
+                const uint32_t lp = flat ? 0u : (uint32_t)P[tabBase + x];
+                const uint32_t hi = (x >= x0 && x + 4u <= Lm) ? hiBase + (lp << 6) : 0xFFFFFFFFu;
+                atomicMin(&myCost[slotOf(x <= DPL_M ? x : 1u) * 64u], ((unsigned long long)hi << 32) | (loBase | ((x - 1u) & DPL_MMASK)));
+            }
+        }
 #pragma unroll
         for (uint32_t t = 3u; t >= 1u; t--) {
             const uint32_t x = Lm - t;                             // (per lane)
@@ -633,7 +647,7 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
                 if (eDist != 0u) {
                     if (!runGoesOn) {                             // first record of the run: what is left after the 64-byte records behind it
                         out = (eDist << 8) | (span - ((span - 1u) & ~63u));
-                        if (phaseA) {
+                        if (phaseA || countB) {
                             atomicAdd(&sCnt[lb][((eCls >= DPL_REP0 && eCls <= DPL_REP0 + 3u) ? GC_DPS_REPLEN : GC_DPS_LEN) + (span < 64u ? span : 64u)], 1u);
                             if (eCls == DPL_NEW) atomicAdd(&sCnt[lb][GC_DPS_SLOT + gc_dist_slot(eDist - 1u)], 1u);
                             else if (eCls == DPL_SREP) atomicAdd(&sCnt[lb][GC_DPS_NSREP], 1u);
@@ -674,6 +688,16 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
             BP[q] = (L >= MINLEN && (r & 0xFFu) >= GC_MIN_MATCH) ? ((r & ~0xFFu) | L) : 0u;
         }
     }
+    if (countB) {                                                  // this pass's counts out (the paths of windows that fell back are counted as they were: a handful)
+        if (n != 0u) atomicAdd(&sCnt[lb][GC_DPS_NLIT], nLitC);
+        gc_wave_sync();
+        for (uint32_t q = 0; q < BPW; q++) {
+            const uint32_t bb = q < BPWr ? item * BPWr + q : nBlocks;
+            if (bb >= nBlocks) continue;
+            uint32_t* C = dpStatOut + (uint64_t)bb * GC_DPS_WORDS;
+            for (uint32_t i = lane; i < GC_DPS_WORDS; i += 64u) { const uint32_t v = sCnt[q][i]; if (v) atomicAdd(&C[i], v); }
+        }
+    }
 }
 
 // one kernel per codec family and grid shape (the shared arrays of dpl_run are per instantiation)
@@ -687,8 +711,8 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
 extern "C" __global__ void __launch_bounds__(GC_DPL_THREADS) DPL_OCC \
 name(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t frameBlocks, uint32_t phase, uint32_t* __restrict__ dpStat, uint32_t litCtxMask, \
      const uint32_t* __restrict__ rec, const uint16_t* __restrict__ rec3, const uint16_t* __restrict__ priceTab, uint32_t* __restrict__ recOut, uint32_t* __restrict__ winCost, \
-     const uint8_t* __restrict__ litPrice) \
-{ dpl_run<REPS, MINLEN, SAMPLE>(src, srcSize, nBlocks, per, frameBlocks, phase, dpStat, litCtxMask, rec, rec3, priceTab, recOut, winCost, litPrice); }
+     const uint8_t* __restrict__ litPrice, uint32_t* __restrict__ dpStatOut) \
+{ dpl_run<REPS, MINLEN, SAMPLE>(src, srcSize, nBlocks, per, frameBlocks, phase, dpStat, litCtxMask, rec, rec3, priceTab, recOut, winCost, litPrice, dpStatOut); }
 
 DPL_KERNEL(gc_mf_dpl2_kernel,  true, 2u, false)   // LZMA: every window
 DPL_KERNEL(gc_mf_dpl2s_kernel, true, 2u, true)    // LZMA: the sample of phase A

@@ -36,7 +36,7 @@ namespace MFK(gc_mf_ns) {
 #define MF_WAVES     (MF_T / 64u)
 static_assert(MF_T == GC_MF_PARTS, "W1/W3 use one thread per partition for the histogram rows");
 #define MF_STAGE_PAD 16u              // bytes staged in front of / behind the tile
-#define MF_STAGE_WORDS ((GC_MF_TILE + 2u * MF_STAGE_PAD) / 4u)
+#define MF_STAGE_WORDS ((GC_MF_TILE + 2u * MF_STAGE_PAD + 32u) / 4u)     // (+ 32: the keys of MF_FAR2 read 32 bytes from a position)
 
 __device__ __forceinline__ uint32_t mf_item(uint32_t bid, uint32_t per) { return (bid & (GC_XCDS - 1u)) * per + (bid >> 3); }
 
@@ -116,6 +116,10 @@ __device__ __forceinline__ uint32_t mf_lds_byte(const uint32_t* sW, uint32_t i) 
 // partly taken back in W5: a verified candidate is extended one byte BACKWARDS and the longer match is recorded at the position in
 // front if that has no record of its own.
 #define MF_HALF  3
+// MF_FAR2 = one more pass of the far kind with keys of 32 ("long") and 24 ("short") bytes (round 5, zstd levels >= 9 and FLZMA2 levels >= 7): in data made of many near-copies of
+// the same text (source trees, archives of similar files) the most recent position with the same 16 bytes is often a copy that diverges a few dozen bytes later, where the
+// reference's chains and trees return the LONGEST match (real sources, zstd level 9 and 19: 1.12 x the reference with 10 % more sequences of the same cost each).
+#define MF_FAR2  4
 struct MfKeys { bool ok, run; uint32_t part; uint64_t entry; };
 template <int MODE>
 __device__ __forceinline__ MfKeys mf_keys(const uint32_t* sW, uint32_t q, const MfTile& T)
@@ -131,6 +135,17 @@ __device__ __forceinline__ MfKeys mf_keys(const uint32_t* sW, uint32_t q, const 
         if (MODE == MF_SHORT) {
             hS = (lo & 0xFFFFFFu) * 0x9E3779B1u; hS ^= hS >> 15; hS *= 0x2C1B3C6Du;     // bytes 0..2
             hL = lo * 0x9E3779B1u; hL ^= hL >> 15; hL *= 0x85EBCA77u;                   // bytes 0..3
+        }
+        if (MODE == MF_FAR2) {
+            const uint64_t y = mf_lds_ld64(sW, q + MF_STAGE_PAD + 8u), z = mf_lds_ld64(sW, q + MF_STAGE_PAD + 16u), w = mf_lds_ld64(sW, q + MF_STAGE_PAD + 24u);
+            uint32_t h = hL + (uint32_t)y * 0xC2B2AE3Du; h ^= h >> 15; h *= 0x2C1B3C6Du;
+            h += (uint32_t)(y >> 32) * 0x27D4EB2Fu; h ^= h >> 13; h *= 0x165667B1u;
+            h += (uint32_t)z * 0x9E3779B1u; h ^= h >> 16; h *= 0x85EBCA6Bu;
+            hS = h + (uint32_t)(z >> 32) * 0xC2B2AE35u;           // bytes 0..23
+            hS ^= hS >> 15; hS *= 0x2C1B3C6Du;
+            hL = hS + (uint32_t)w * 0x27D4EB2Fu; hL ^= hL >> 13; hL *= 0x165667B1u;
+            hL += (uint32_t)(w >> 32) * 0x9E3779B1u;              // bytes 0..31
+            hL ^= hL >> 16; hL *= 0x85EBCA77u;
         }
         if (MODE == MF_FAR) {
             const uint64_t y = mf_lds_ld64(sW, q + MF_STAGE_PAD + 8u);
@@ -189,6 +204,11 @@ extern "C" __global__ void __launch_bounds__(MF_T)
 MFK(gc_mf_count_far_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per, uint32_t* __restrict__ cnt)
 {
     mf_count_body<MF_FAR>(src, srcSize, frameBlocks, nTiles, per, cnt);
+}
+extern "C" __global__ void __launch_bounds__(MF_T)
+MFK(gc_mf_count_far2_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per, uint32_t* __restrict__ cnt)
+{
+    mf_count_body<MF_FAR2>(src, srcSize, frameBlocks, nTiles, per, cnt);
 }
 
 // ------------------------------------------------------------------------------------------------ W2 scan
@@ -342,6 +362,12 @@ MFK(gc_mf_scatter_far_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize,
                          const uint32_t* __restrict__ offs, GcMfEntry* __restrict__ ent)
 {
     mf_scatter_body<MF_FAR>(src, srcSize, frameBlocks, nTiles, per, offs, ent);
+}
+extern "C" __global__ void __launch_bounds__(MF_T)
+MFK(gc_mf_scatter_far2_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
+                         const uint32_t* __restrict__ offs, GcMfEntry* __restrict__ ent)
+{
+    mf_scatter_body<MF_FAR2>(src, srcSize, frameBlocks, nTiles, per, offs, ent);
 }
 
 // ------------------------------------------------------------------------------------------------ W4 link
@@ -502,6 +528,9 @@ MFK(gc_mf_link_kernel)(const uint32_t* __restrict__ offs, const GcMfEntry* __res
 #ifndef MFV_B
 #define MFV_B 4u                      // listed positions per thread and round
 #endif
+#ifndef MFV_FAR_TIE
+#define MFV_FAR_TIE 1                 // the far pass too ranks two capped records by what lies behind the cap (round 5; 0 = by the distances alone, as rounds 2-4)
+#endif
 #define MFV_NONE 0xFFFFFFFFu             // sRec: no record written yet (a record's length byte never exceeds GC_MATCH_CAP)
 #define MFV_PAD_AFTER (GC_MATCH_CAP + 32u)                        // staged bytes behind the tile: own side of every compare
 #define MFV_STAGE_WORDS ((MF_STAGE_PAD + GC_MF_TILE + MFV_PAD_AFTER) / 4u)
@@ -543,10 +572,10 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
                     uint32_t* sW, uint32_t* sRec, uint8_t* sExt, uint32_t* sStart, uint32_t* sLocal, uint32_t* sWaveTot,
                     unsigned long long* prof = nullptr, unsigned long long* tprev = nullptr)
 {
-    constexpr bool FAR = MODE == MF_FAR || MODE == MF_SHORT;      // a merging pass
+    constexpr bool FAR = MODE == MF_FAR || MODE == MF_FAR2 || MODE == MF_SHORT;      // a merging pass
     constexpr bool HALF = MODE == MF_HALF;                        // even positions only; matches are extended one byte backwards
     constexpr uint32_t MINLEN = MODE == MF_SHORT ? 3u : GC_MIN_MATCH;
-    constexpr uint32_t LONGLEN = MODE == MF_SHORT ? 4u : (MODE == MF_FAR ? 16u : 8u);   // a verified long candidate has this many bytes
+    constexpr uint32_t LONGLEN = MODE == MF_SHORT ? 4u : ((MODE == MF_FAR || MODE == MF_FAR2) ? 16u : 8u);   // a verified long candidate has this many bytes
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
     const uint32_t TPF = MF_F(frameBlocks) * GC_MF_TILES_PER_BLOCK;
     uint32_t c = 0, incl = 0;
@@ -682,7 +711,24 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
                 if (MODE == MF_BASE && len == GC_MATCH_CAP) sWaveTot[1] = 0xFFFFFFFFu;      // "the tile has a capped record": the word held a count (dead since the run offsets were made), never this value
                 if (HALF && nr != 0u) sExt[q[k]] = (uint8_t)bestExt[k];
                 if (!FAR) sRec[q[k]] = nr;
-                else if (nr) { const uint32_t old = sRec[q[k]]; if (old == 0u || lz_gain(len, nr >> 8) > lz_gain(old & 0xFFu, old >> 8)) sRec[q[k]] = nr; }
+                else if (nr) {
+                    const uint32_t old = sRec[q[k]];
+                    bool take = old == 0u || lz_gain(len, nr >> 8) > lz_gain(old & 0xFFu, old >> 8);
+                    if ((MODE == MF_FAR2 || (MODE == MF_FAR && MFV_FAR_TIE)) && old != 0u && len == GC_MATCH_CAP && (old & 0xFFu) == GC_MATCH_CAP && (old >> 8) != (nr >> 8)) {
+                        // both records fill the cap: the gain only sees the distances, and the nearer copy is the one that diverges first in a tree of near-copies.  Compare up to
+                        // 64 bytes BEHIND the cap at both distances (inside the frame) and keep the one that goes on further (the nearer one if both go on as far).
+                        const uint64_t frameLen = T.frameEnd - T.frameStart;
+                        const uint64_t room = frameLen - ((uint64_t)pw + GC_MATCH_CAP);           // (listed positions have CAP + 16 bytes of frame behind them)
+                        const uint32_t lim = room < 80u ? (room < 16u ? 0u : (uint32_t)room - 16u) : 64u;
+                        uint32_t eN = 0, eO = 0;
+                        const uint64_t own = (uint64_t)pw + GC_MATCH_CAP;
+                        while (eN < lim) { const uint32_t m = lz_cmp16(lz_ld16(wsrc, own + eN), lz_ld16(wsrc, own - (nr >> 8) + eN)); eN += m; if (m < 16u) break; }
+                        while (eO < lim) { const uint32_t m = lz_cmp16(lz_ld16(wsrc, own + eO), lz_ld16(wsrc, own - (old >> 8) + eO)); eO += m; if (m < 16u) break; }
+                        if (eN > lim) eN = lim; if (eO > lim) eO = lim;
+                        take = eN > eO || (eN == eO && (nr >> 8) < (old >> 8));
+                    }
+                    if (take) sRec[q[k]] = nr;
+                }
             }
         }
     }
@@ -714,53 +760,103 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
     // meet (every 1 KiB), which keeps the result independent of the order in which the waves run.
     // (every pass that merges candidates by gain may have replaced a continued record by a nearer one; the first pass knows whether it wrote a capped record at all --
     //  byte runs aside, which keep their distance 1 anyway -- and most tiles of ordinary text have none: they skip the nine barriers below)
-    if ((MODE == MF_BASE && sWaveTot[1] == 0xFFFFFFFFu) || MODE == MF_FAR || MODE == MF_SHORT) {
+#ifdef MFV_CONT_OFF
+    if (false) {
+#else
+    if ((MODE == MF_BASE && sWaveTot[1] == 0xFFFFFFFFu) || MODE == MF_FAR || MODE == MF_FAR2 || MODE == MF_SHORT) {
+#endif
         constexpr uint32_t NSUB = MFV_T / 64u;
         const uint32_t subLen = ((T.len + NSUB * 64u - 1u) / (NSUB * 64u)) * 64u;
         const uint32_t sBeg = wave * subLen, sEnd = sBeg + subLen < T.len ? sBeg + subLen : T.len;
-        // one position: true if its record was replaced
+        // The walk down one residue class mod 64 (a lane's column of the share): row q looks at the record GC_MATCH_CAP in front of it; where that one is capped at a distance d
+        // other than q's own, the match at d is measured from q (<= four 16-byte pieces of the source, one round trip) and q's record takes d if that goes on at least as far
+        // (within two bytes).  follow: stop at the first row that does not change (phase B).
+        // Round 5: a chain of such rows was one memory round trip PER ROW, and on real sources / binaries the pass took as long as the whole entry loop (zstd level 3 on
+        // 1 GB: 30.5 / 31.3 GB/s against 44.7 on text; without phase B 36.1 / 35.4, run s4).  When row q is about to be measured over a full 64 bytes the source of row
+        // q + 64 at the same distance (the next 64 bytes) is requested in the same round: if q comes out capped at d -- the match goes on -- row q + 64 is decided from
+        // what has arrived already.  Two rows per round trip; the records are those of the row-by-row walk (same reads, same tests, same order per column).
+        auto piece4 = [&](uint32_t q, uint64_t cpos, uint32_t maxLen, const LzW16& c0, const LzW16& c1, const LzW16& c2, const LzW16& c3) -> uint32_t {
+            const bool h1 = 16u < maxLen, h2 = 32u < maxLen, h3 = 48u < maxLen;
+            uint32_t more = lz_cmp16(mf_lds_ld16(sW, q + MF_STAGE_PAD), c0);
+            bool full = more == 16u;
+            if (full && h1) { const uint32_t m = lz_cmp16(mf_lds_ld16(sW, q + MF_STAGE_PAD + 16u), c1); more += m; full = m == 16u; }
+            if (full && h2) { const uint32_t m = lz_cmp16(mf_lds_ld16(sW, q + MF_STAGE_PAD + 32u), c2); more += m; full = m == 16u; }
+            if (full && h3) { const uint32_t m = lz_cmp16(mf_lds_ld16(sW, q + MF_STAGE_PAD + 48u), c3); more += m; full = m == 16u; }
+            (void)cpos;
+            return more > maxLen ? maxLen : more;
+        };
+        auto walk = [&](uint32_t q, const uint32_t qEnd, const bool follow) {
+            while (q < qEnd) {
+                const uint32_t prev = sRec[q - GC_MATCH_CAP];
+                const uint32_t d = prev >> 8, cur = sRec[q];
+                const uint32_t p = pTile + q;
+                const bool need0 = (prev & 0xFFu) == GC_MATCH_CAP && (cur >> 8) != d && T.tileStart + q + GC_MATCH_CAP + 16u <= T.frameEnd && p + 8u <= nBlk;
+                if (!need0) { if (follow) return; q += 64u; continue; }
+                uint32_t max0 = (nBlk - p) < GC_MATCH_CAP ? (nBlk - p) : GC_MATCH_CAP;
+                if (TILE_LIMIT && max0 > T.len - q) max0 = T.len - q;
+                const uint64_t cpos = (uint64_t)(wTile + q) - d;   // frame-relative position of the continued source
+                // row q + 64, ahead of time: only a full row, and only if it would be measured at all
+                const uint32_t q1 = q + 64u;
+                uint32_t cur1 = 0u;
+                bool spec = max0 == GC_MATCH_CAP && q1 < qEnd;
+                if (spec) {
+                    cur1 = sRec[q1];
+                    spec = (cur1 >> 8) != d && T.tileStart + q1 + GC_MATCH_CAP + 16u <= T.frameEnd && p + 64u + GC_MATCH_CAP <= nBlk && (!TILE_LIMIT || q1 + GC_MATCH_CAP <= T.len);
+                }
+                const bool h1 = 16u < max0, h2 = 32u < max0, h3 = 48u < max0;       // (a piece is read only where the match can still go on: offset < maxLen)
+                const LzW16 c0 = lz_ld16(wsrc, cpos), c1 = lz_ld16(wsrc, cpos + (h1 ? 16u : 0u)), c2 = lz_ld16(wsrc, cpos + (h2 ? 32u : 0u)), c3 = lz_ld16(wsrc, cpos + (h3 ? 48u : 0u));
+                LzW16 e0 = c0, e1 = c0, e2 = c0, e3 = c0;
+                if (spec) { e0 = lz_ld16(wsrc, cpos + 64u); e1 = lz_ld16(wsrc, cpos + 80u); e2 = lz_ld16(wsrc, cpos + 96u); e3 = lz_ld16(wsrc, cpos + 112u); }
+                const uint32_t len0 = piece4(q, cpos, max0, c0, c1, c2, c3);
+                if (len0 < MINLEN || len0 + 2u < (cur & 0xFFu)) { if (follow) return; q += 64u; continue; }
+                sRec[q] = (d << 8) | len0;
+                if (!(spec && len0 == GC_MATCH_CAP)) { q += 64u; continue; }          // (the row below is looked at in the next round, the ordinary way)
+                const uint32_t len1 = piece4(q1, cpos + 64u, GC_MATCH_CAP, e0, e1, e2, e3);
+                if (len1 < MINLEN || len1 + 2u < (cur1 & 0xFFu)) { if (follow) return; q += 128u; continue; }
+                sRec[q1] = (d << 8) | len1;
+                q += 128u;
+            }
+        };
+#ifdef MFV_CONT_ROWWISE                // (check builds: the row-by-row walk of rounds 3-4 -- one round trip per row -- must give the same records)
         auto cont = [&](uint32_t q) -> bool {
             const uint32_t prev = sRec[q - GC_MATCH_CAP];
             if ((prev & 0xFFu) != GC_MATCH_CAP) return false;
             const uint32_t d = prev >> 8, cur = sRec[q];
             if ((cur >> 8) == d) return false;
-            if (T.tileStart + q + GC_MATCH_CAP + 16u > T.frameEnd) return false;     // (the compare windows must lie inside the frame)
+            if (T.tileStart + q + GC_MATCH_CAP + 16u > T.frameEnd) return false;
             const uint32_t p = pTile + q;
             if (p + 8u > nBlk) return false;
             uint32_t maxLen = (nBlk - p) < GC_MATCH_CAP ? (nBlk - p) : GC_MATCH_CAP;
             if (TILE_LIMIT && maxLen > T.len - q) maxLen = T.len - q;
-            const uint64_t cpos = (uint64_t)(wTile + q) - d;       // frame-relative position of the continued source
-            // (four 16-byte pieces of the source per round, not one: in phase B below ONE wave at a time walks a chain of these while the others wait at the barrier, and
-            //  a match that goes on for the whole cap was sixteen dependent loads -- on real sources this pass took as long as the whole entry loop.  A piece is read only
-            //  where the one-piece loop would have read it: offset < maxLen.)
-            uint32_t len = 0;
-            while (len < maxLen) {
-                const bool h1 = len + 16u < maxLen, h2 = len + 32u < maxLen, h3 = len + 48u < maxLen;
-                const LzW16 c0 = lz_ld16(wsrc, cpos + len), c1 = lz_ld16(wsrc, cpos + len + (h1 ? 16u : 0u)), c2 = lz_ld16(wsrc, cpos + len + (h2 ? 32u : 0u)), c3 = lz_ld16(wsrc, cpos + len + (h3 ? 48u : 0u));
-                uint32_t more = lz_cmp16(mf_lds_ld16(sW, q + MF_STAGE_PAD + len), c0);
-                bool full = more == 16u;
-                if (full && h1) { const uint32_t m = lz_cmp16(mf_lds_ld16(sW, q + MF_STAGE_PAD + len + 16u), c1); more += m; full = m == 16u; }
-                if (full && h2) { const uint32_t m = lz_cmp16(mf_lds_ld16(sW, q + MF_STAGE_PAD + len + 32u), c2); more += m; full = m == 16u; }
-                if (full && h3) { const uint32_t m = lz_cmp16(mf_lds_ld16(sW, q + MF_STAGE_PAD + len + 48u), c3); more += m; full = m == 16u; }
-                len += more;
-                if (!full) break;
-            }
-            if (len > maxLen) len = maxLen;
+            const uint64_t cpos = (uint64_t)(wTile + q) - d;
+            const bool h1 = 16u < maxLen, h2 = 32u < maxLen, h3 = 48u < maxLen;
+            const uint32_t len = piece4(q, cpos, maxLen, lz_ld16(wsrc, cpos), lz_ld16(wsrc, cpos + (h1 ? 16u : 0u)), lz_ld16(wsrc, cpos + (h2 ? 32u : 0u)), lz_ld16(wsrc, cpos + (h3 ? 48u : 0u)));
             if (len < MINLEN || len + 2u < (cur & 0xFFu)) return false;
             sRec[q] = (d << 8) | len;
             return true;
         };
-        // phase A: every wave inside its share, from the share's second row on (the first row looks back into the share in front)
         for (uint32_t q = sBeg + GC_MATCH_CAP + lane; q < sEnd; q += 64u) cont(q);
         __syncthreads();
-        // phase B: the first rows, share by share in order (what a share looks back at is final), followed down the share while records change
         for (uint32_t sIdx = 1; sIdx < NSUB; sIdx++) {
-            if (wave == sIdx) {
-                uint32_t q = sBeg + lane;
-                while (q < sEnd && cont(q)) q += 64u;
-            }
+            if (wave == sIdx) { uint32_t q = sBeg + lane; while (q < sEnd && cont(q)) q += 64u; }
             __syncthreads();
         }
+        (void)walk;
+        if (false) {
+#endif
+        // phase A: every wave inside its share, from the share's second row on (the first row looks back into the share in front)
+        walk(sBeg + GC_MATCH_CAP + lane, sEnd, false);
+        __syncthreads();
+        // phase B: the first rows, share by share in order (what a share looks back at is final), followed down the share while records change
+#ifndef MFV_CONT_NO_B                 // (experiment builds, tools/build_variants.py: chains cut where the shares meet)
+        for (uint32_t sIdx = 1; sIdx < NSUB; sIdx++) {
+            if (wave == sIdx) walk(sBeg + lane, sEnd, true);
+            __syncthreads();
+        }
+#endif
+#ifdef MFV_CONT_ROWWISE
+        }
+#endif
     }
 }
 
@@ -803,6 +899,12 @@ MFK(gc_mf_verify_far_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, 
                         const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, uint32_t* __restrict__ rec)
 {
     mf_verify_body<MF_FAR>(src, srcSize, frameBlocks, nTiles, per, offs, ent, rec, rec);
+}
+extern "C" __global__ void __launch_bounds__(MFV_T)
+MFK(gc_mf_verify_far2_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
+                        const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, uint32_t* __restrict__ rec)
+{
+    mf_verify_body<MF_FAR2>(src, srcSize, frameBlocks, nTiles, per, offs, ent, rec, rec);
 }
 extern "C" __global__ void __launch_bounds__(MFV_T)
 MFK(gc_mf_verify_short_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,

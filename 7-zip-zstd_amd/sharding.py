@@ -34,6 +34,8 @@ def codec_grain(codec, level):
         return 4 * FRAME_ZSTD                                     # overlapping finder frames inside 32 MiB zstd frames (csrc/gc_api.hip zstd_group_blocks)
     if codec == "flzma2" and int(level) >= 7:
         return 8 * FRAME_ZSTD                                     # ... inside groups of 64 MiB (flzma2_group_blocks)
+    if codec == "flzma2" and int(level) >= 5:
+        return 2 * FRAME_ZSTD                                     # ... of 16 MiB at levels 5-6 (round 5)
     return FRAME_ZSTD                                             # zstd and FLZMA2: the windowed finder at every level
 
 

@@ -26,7 +26,7 @@ def test_exports_declared_in_header_exist(pkg, emu_lib_path):
 def test_grain_and_piece_sizes(pkg, emu_lib_path):
     lib = pkg.load_library(emu_lib_path)
     assert lib.gc_codec_grain(pkg.CODEC_ZSTD, 1) == 64 * BLK and lib.gc_codec_grain(pkg.CODEC_ZSTD, 3) == 64 * BLK      # (the windowed finder at every level)
-    assert lib.gc_codec_grain(pkg.CODEC_FLZMA2, 1) == 64 * BLK and lib.gc_codec_grain(pkg.CODEC_FLZMA2, 5) == 64 * BLK      # (FLZMA2: the windowed finder at every level)
+    assert lib.gc_codec_grain(pkg.CODEC_FLZMA2, 1) == 64 * BLK and lib.gc_codec_grain(pkg.CODEC_FLZMA2, 5) == 128 * BLK     # (FLZMA2: the windowed finder at every level; level 5: overlapping frames in groups of 16 MiB)
     for q in range(0, 12):
         g = lib.gc_codec_grain(pkg.CODEC_BROTLI, q)
         assert g == max(q, 1) * 8 * BLK                      # the brotli-mt chunk (C/zstdmt/brotli-mt_compress.c:115-118)

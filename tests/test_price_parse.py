@@ -172,3 +172,69 @@ def test_gpu_brotli_q6_within_2_percent_of_reference_on_text(O, pkg, gpu_ok, mon
         c = _code(O, pkg, "brotli", 6, x, monkeypatch, None, device=0)
         ref = O.ref_brotlimt_compress(x, 6, 8)
         assert len(c) <= 1.02 * len(ref), (kind, len(c), len(ref))
+
+
+# ---- round 5: overlapping finder frames, the 32 / 24-byte pass, the re-priced second pass
+def _repeat_far_back(n_blocks, period_blocks, seed=7):
+    """text whose second half repeats the first with small changes: matches that reach `period_blocks` blocks back"""
+    rng = np.random.default_rng(seed)
+    base = np.frombuffer(bytes(rng.integers(97, 123, period_blocks * BLK, dtype=np.uint8)), dtype=np.uint8).copy()
+    out = np.tile(base, (n_blocks + period_blocks - 1) // period_blocks)[: n_blocks * BLK].copy()
+    out[rng.integers(0, out.size, out.size // 300)] = 32          # a changed byte every ~300
+    return out
+
+
+@pytest.mark.parametrize("codec,level", [("flzma2", 5), ("zstd", 19)])
+def test_emu_overlapping_frames_reach_further_back(O, pkg, emu_lib_path, monkeypatch, codec, level):
+    """gc_mf.h "Overlapping frames": frames of F blocks that start every S blocks inside a group of C.  With frames that tile the input (S = F) a position of a frame's first
+    block has nothing behind it; with S = F / 2 it has at least half a frame.  Hooks make the frames small: F = 4, S = 2, C = 8 on ten blocks whose content comes back
+    every three blocks -- the stream decodes, and it is smaller than with frames that tile."""
+    x = _repeat_far_back(10, 3)
+    monkeypatch.setenv("GC_FRAME_BLOCKS", "4"); monkeypatch.setenv("GC_MF_GROUP", "8"); monkeypatch.setenv("GC_MF_STRIDE", "4")
+    tiled = _code(O, pkg, codec, level, x, monkeypatch, None, lib_path=emu_lib_path)
+    monkeypatch.setenv("GC_MF_STRIDE", "2")
+    lapped = _code(O, pkg, codec, level, x, monkeypatch, None, lib_path=emu_lib_path)
+    assert len(lapped) < len(tiled), (len(lapped), len(tiled))
+
+
+@pytest.mark.parametrize("codec,level", [("zstd", 9), ("zstd", 19), ("flzma2", 7)])
+def test_emu_long_key_pass_decodes_and_does_not_lose(O, pkg, emu_lib_path, monkeypatch, codec, level):
+    """MF_FAR2 (gc_lz_window.hip): one more pass of the finder with keys of 32 / 24 bytes, on at zstd >= 7 and FLZMA2 >= 7; hook GC_FAR2_PASS=0 is the finder of round 4."""
+    x = np.concatenate([O.corpus("real-src", 3 * BLK), O.corpus("lz-7zip", 2 * BLK + 777)])
+    if x.size < 5 * BLK:
+        pytest.skip("the image holds no real-src data")
+    on = _code(O, pkg, codec, level, x, monkeypatch, None, lib_path=emu_lib_path)
+    monkeypatch.setenv("GC_FAR2_PASS", "0")
+    off = _code(O, pkg, codec, level, x, monkeypatch, None, lib_path=emu_lib_path)
+    assert len(on) <= len(off) + len(off) // 400, (len(on), len(off))
+
+
+@pytest.mark.parametrize("codec,level", [("flzma2", 5), ("zstd", 19)])
+def test_emu_repriced_second_pass_decodes(O, pkg, emu_lib_path, monkeypatch, codec, level):
+    """Hook GC_DP_REPARSE=1: W7L's pass over every window counts its own paths and runs once more under prices made from them (measured in round 5: nothing to gain, so it
+    is off; the path stays exercised)."""
+    x = np.concatenate([O.corpus("silesia-like", 2 * BLK + 999), O.corpus("text-zipf", BLK)])
+    plain = _code(O, pkg, codec, level, x, monkeypatch, None, lib_path=emu_lib_path)
+    monkeypatch.setenv("GC_DP_REPARSE", "1")
+    again = _code(O, pkg, codec, level, x, monkeypatch, None, lib_path=emu_lib_path)
+    assert abs(len(again) - len(plain)) < len(plain) // 50
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("codec,level", [("flzma2", 5), ("zstd", 19)])
+def test_gpu_bytes_equal_emulator_bytes_with_overlapping_frames(O, pkg, emu_lib_path, gpu_ok, gpu_hooks_kw, monkeypatch, codec, level):
+    x = _repeat_far_back(10, 3)
+    monkeypatch.setenv("GC_FRAME_BLOCKS", "4"); monkeypatch.setenv("GC_MF_GROUP", "8"); monkeypatch.setenv("GC_MF_STRIDE", "2")
+    g = _code(O, pkg, codec, level, x, monkeypatch, None, **gpu_hooks_kw)
+    e = _code(O, pkg, codec, level, x, monkeypatch, None, lib_path=emu_lib_path)
+    assert np.array_equal(g, e)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("codec,level", [("flzma2", 5), ("zstd", 19)])
+def test_gpu_bytes_equal_emulator_bytes_with_the_repriced_second_pass(O, pkg, emu_lib_path, gpu_ok, gpu_hooks_kw, monkeypatch, codec, level):
+    x = np.concatenate([O.corpus("silesia-like", 2 * BLK + 999), O.corpus("text-zipf", BLK)])
+    monkeypatch.setenv("GC_DP_REPARSE", "1")
+    g = _code(O, pkg, codec, level, x, monkeypatch, None, **gpu_hooks_kw)
+    e = _code(O, pkg, codec, level, x, monkeypatch, None, lib_path=emu_lib_path)
+    assert np.array_equal(g, e)

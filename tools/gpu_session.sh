@@ -58,7 +58,7 @@ PY
              rm -rf $OUT/pmc_$ctr
            done
            head -60 $OUT/pmc$k.md ;;
-    py)    s=${rest%%:*}; a=""; [ "$rest" != "$s" ] && a=$(echo "${rest#*:}" | tr ',' ' ')
+    py)    s=${rest%%:*}; a=""; [ "$rest" != "$s" ] && { a="${rest#*:}"; case "$a" in *\;*) a=$(echo "$a" | tr ';' ' ');; *) a=$(echo "$a" | tr ',' ' ');; esac; }      # (";" separates the arguments when they hold commas themselves)
            timeout 900 python tools/$s $a > $OUT/py$k.log 2>&1; tail -40 $OUT/py$k.log ;;
     *) echo "unknown step $step" ;;
   esac

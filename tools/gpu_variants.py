@@ -25,7 +25,11 @@ pkg = g.load_package()
 from importlib import util as _u
 spec = _u.spec_from_file_location("c", os.path.join(ROOT, "7-zip-zstd_amd", "corpus", "__init__.py"))
 cm = _u.module_from_spec(spec); spec.loader.exec_module(cm)
-x = cm.corpus(a.corpus, a.bytes)
+if a.corpus in cm.REAL_KINDS:                          # real bytes tiled to the size asked for (whole 8 MiB frames repeated), as tools/gpu_real_rate.py does
+    full = cm.real_corpus(a.corpus, 211_900_000)
+    x = np.ascontiguousarray(np.resize(full[: full.size - full.size % (8 << 20)], a.bytes))
+else:
+    x = cm.corpus(a.corpus, a.bytes)
 d_src = torch.from_numpy(x).cuda()
 for sp in a.specs:
     name, _, envs = sp.partition("@")
