@@ -127,6 +127,7 @@ struct gc_ctx {
     uint32_t priceParse;      // W5s + W7: price-based parse on top of the greedy one (gc_lz_price.hip)
     uint32_t priceMinLen, priceLitCtx;        // its shortest match and literal context bits (LZMA: 2, 7; zstd: 3, 0)
     int lastCodecHint;        // codec of the call being enqueued (0 zstd, 1 flzma2, 2 brotli): which W7L kernels the finder launches
+    uint32_t smallWin2k;      // W7L: windows of 2 KiB in calls of <= 1 024 blocks (launch_finder_part)
     uint32_t shortPlain;      // overlapping frames: the pass with 4- / 3-byte keys runs over frames that tile the input (launch_finder_part)
     uint32_t farPass2;        // one more pass of the far kind with keys of 32 / 24 bytes (gc_lz_window.hip MF_FAR2)
     uint32_t reParse;         // W7L runs a second full pass under prices made from the first one's own paths (launch_finder_part)
@@ -527,7 +528,11 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
             const uint32_t nDpWg = nBlocks * (phase == 0u ? 1u : 8u), perD = gc_xcd_per(nDpWg);
             uint32_t* wcp = phase == 0u ? (uint32_t*)nullptr : wc;
             if (laneDp) {
-                uint32_t win2k = 0u; gc_env_u32("GC_DPL_WIN2K", 0u, 1u, &win2k);      // test hook: windows of 2 KiB, one block per wave, in the pass over every window
+                // Windows of 2 KiB (one block per wave) where the 4 KiB ones leave the device half empty: W7L takes as long as ONE wave needs for its window, whatever the
+                // number of waves, as long as they are all resident (1 024 groups of 64 windows); a call of <= 1 024 blocks (128 MiB) has at most 512 groups of 4 KiB
+                // windows.  Round 4 measured 32 MiB 23.5 -> 13.6 ms and 128 MiB 25.4 -> 15.7 ms for +0.02 % (the Silesia stand-in) ... +0.36 % (shared objects) and left it
+                // off because the size bars sat at the band's edge; round 5 (merged model segments, overlapping frames) moved them: on at FLZMA2 levels 5-6.
+                uint32_t win2k = (c->smallWin2k && nBlocks <= 1024u) ? 1u : 0u; gc_env_u32("GC_DPL_WIN2K", 0u, 1u, &win2k);      // test hook
                 const bool w2 = win2k != 0u && phase != 0u;
                 const uint32_t nItems = w2 ? nBlocks : (nBlocks + 1u) / 2u, perL = gc_xcd_per(nItems);     // a wave = two blocks (2 KiB windows: one)
                 const bool select = laneDp == 2u && phase == 1u && !w2;
@@ -659,7 +664,7 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
                                                   // 1.027 -> 0.984 x the reference on text, level 12 1.040 -> 1.001 x
     c->shortPass = level >= 10 ? 1u : 0u;         // the reference's btopt strategies search 3-byte matches (minMatch 3, clevels.h:44-47); from level 10 since round 3, see priceParse
     gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass); gc_env_u32("GC_SHORT_PASS", 0u, 1u, &c->shortPass);   // test hooks
-    c->shortPlain = 0u;
+    c->shortPlain = 0u; c->smallWin2k = 0u;
     c->farPass2 = level >= 7 ? 1u : 0u; gc_env_u32("GC_FAR2_PASS", 0u, 1u, &c->farPass2);      // keys of 32 / 24 bytes where the reference searches chains / trees for the LONGEST match: real sources, emulator, 8 MiB:
                                                                                               // level 9 1.118 -> 1.050 x the reference, level 19 1.115 -> 1.097
     c->reParse = 0u;
@@ -886,6 +891,7 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass); gc_env_u32("GC_SHORT_PASS", 0u, 1u, &c->shortPass);   // test hooks
     if (gc_env_u32("GC_SEARCH_DEPTH", 0u, 64u, &c->searchDepth)) c->searchShallow = c->searchDepth < 2u ? c->searchDepth : 2u;
     c->shortPlain = level < 7 ? 1u : 0u;
+    c->smallWin2k = (level == 5 || level == 6) ? 1u : 0u;
     c->farPass2 = level >= 7 ? 1u : 0u; gc_env_u32("GC_FAR2_PASS", 0u, 1u, &c->farPass2);      // keys of 32 / 24 bytes (gc_lz_window.hip MF_FAR2) at the ultra levels
     c->reParse = 0u;
     c->laneParse = 1u; c->lastCodecHint = 1; c->priceMinLen = 2u; c->priceLitCtx = 7u;
@@ -1062,7 +1068,7 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     gc_env_u32("GC_SEARCH_SHALLOW", 0u, 64u, &c->searchShallow);                                // test hook: links followed by the positions inside a match and in tiles without long matches
     c->farPass = level >= 5 ? 1u : 0u; c->shortPass = 0;      // longer matches stand in for the context modelling / block splitting B1 lacks
     gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass);                                            // test hook
-    c->shortPlain = 0u;
+    c->shortPlain = 0u; c->smallWin2k = 0u;
     c->farPass2 = 0u; gc_env_u32("GC_FAR2_PASS", 0u, 1u, &c->farPass2);
     c->reParse = 0u;
     c->laneParse = 0u; c->lastCodecHint = 2; c->priceMinLen = 3u; c->priceLitCtx = 0u;     // copies of >= 3 bytes (a 2-byte copy at a fresh distance never pays in brotli), one literal code per meta-block

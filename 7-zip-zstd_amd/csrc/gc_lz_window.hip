@@ -849,8 +849,17 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
         __syncthreads();
         // phase B: the first rows, share by share in order (what a share looks back at is final), followed down the share while records change
 #ifndef MFV_CONT_NO_B                 // (experiment builds, tools/build_variants.py: chains cut where the shares meet)
-        for (uint32_t sIdx = 1; sIdx < NSUB; sIdx++) {
-            if (wave == sIdx) walk(sBeg + lane, sEnd, true);
+        // Round 5: one share at a time meant seven memory round trips one after the other with seven of the eight waves waiting (real sources: 37 K of the tile's ~150 K
+        // cycles, run s7) although a share's first row hardly ever depends on the repair of the share above: that needs a chain that runs through ALL of that share.
+        // So every share first repairs its first row (and what follows from it) AT THE SAME TIME, from the record above as phase A left it -- read before anybody writes --
+        // and the pass in order that makes it exact only looks again where the record above has changed since (no memory access anywhere else).
+        const uint32_t qFirst = sBeg + lane;
+        const uint32_t prevA = (wave != 0u && qFirst < sEnd) ? sRec[qFirst - GC_MATCH_CAP] : 0u;
+        __syncthreads();
+        if (wave != 0u) walk(qFirst, sEnd, true);
+        __syncthreads();
+        for (uint32_t sIdx = 2; sIdx < NSUB; sIdx++) {             // (share 1 looked at share 0, which phase B never touches)
+            if (wave == sIdx && qFirst < sEnd && sRec[qFirst - GC_MATCH_CAP] != prevA) walk(qFirst, sEnd, true);
             __syncthreads();
         }
 #endif
