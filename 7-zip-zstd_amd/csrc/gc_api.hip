@@ -127,6 +127,7 @@ struct gc_ctx {
     uint32_t priceParse;      // W5s + W7: price-based parse on top of the greedy one (gc_lz_price.hip)
     uint32_t priceMinLen, priceLitCtx;        // its shortest match and literal context bits (LZMA: 2, 7; zstd: 3, 0)
     int lastCodecHint;        // codec of the call being enqueued (0 zstd, 1 flzma2, 2 brotli): which W7L kernels the finder launches
+    uint32_t allLengths;      // W7L (zstd): every length of a candidate is an edge
     uint32_t smallWin2k;      // W7L: windows of 2 KiB in calls of <= 1 024 blocks (launch_finder_part)
     uint32_t shortPlain;      // overlapping frames: the pass with 4- / 3-byte keys runs over frames that tile the input (launch_finder_part)
     uint32_t farPass2;        // one more pass of the far kind with keys of 32 / 24 bytes (gc_lz_window.hip MF_FAR2)
@@ -536,19 +537,19 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
                 const bool w2 = win2k != 0u && phase != 0u;
                 const uint32_t nItems = w2 ? nBlocks : (nBlocks + 1u) / 2u, perL = gc_xcd_per(nItems);     // a wave = two blocks (2 KiB windows: one)
                 const bool select = laneDp == 2u && phase == 1u && !w2;
-                const uint32_t phaseK = phase | (w2 ? 16u : 0u) | (select ? GC_DP_SELECT : 0u) | (DPS_OUT ? GC_DP_COUNT : 0u);
+                const uint32_t phaseK = phase | (w2 ? 16u : 0u) | (select ? GC_DP_SELECT : 0u) | (DPS_OUT ? GC_DP_COUNT : 0u) | (c->allLengths ? GC_DP_ALLLEN : 0u);
                 if (select) {                                      // the blocks without repeats: W7
                     if (c->priceMinLen <= 2u) GC_LAUNCH(gc_mf_dp2_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, groupBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
                     else GC_LAUNCH(gc_mf_dp3_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, groupBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
                 }
                 if (c->priceMinLen <= 2u) {
-                    if (phase == 0u) GC_LAUNCH(gc_mf_dpl2s_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr, DPS_OUT);
+                    if (phase == 0u) GC_LAUNCH(gc_mf_dpl2s_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phase | (c->allLengths ? GC_DP_ALLLEN : 0u), dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr, DPS_OUT);
                     else GC_LAUNCH(gc_mf_dpl2_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr, DPS_OUT);
                 } else if (c->lastCodecHint == 0) {
-                    if (phase == 0u) GC_LAUNCH(gc_mf_dplzs_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr, DPS_OUT);
+                    if (phase == 0u) GC_LAUNCH(gc_mf_dplzs_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phase | (c->allLengths ? GC_DP_ALLLEN : 0u), dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr, DPS_OUT);
                     else GC_LAUNCH(gc_mf_dplz_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr, DPS_OUT);
                 } else {
-                    if (phase == 0u) GC_LAUNCH(gc_mf_dpl3s_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr, DPS_OUT);
+                    if (phase == 0u) GC_LAUNCH(gc_mf_dpl3s_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phase | (c->allLengths ? GC_DP_ALLLEN : 0u), dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr, DPS_OUT);
                     else GC_LAUNCH(gc_mf_dpl3_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr, DPS_OUT);
                 }
             } else
@@ -625,7 +626,7 @@ static uint32_t zstd_frame_blocks(int level) { (void)level; return GC_MF_MAX_FRA
 static uint32_t zstd_group_blocks(int level) { return level >= 16 ? 4u * GC_MF_MAX_FRAME_BLOCKS : GC_MF_MAX_FRAME_BLOCKS; }     // 32 MiB zstd frames (= shard grain) / 8 MiB
 static uint32_t zstd_stride_blocks(int level) { return level >= 20 ? GC_MF_MAX_FRAME_BLOCKS / 4u : GC_MF_MAX_FRAME_BLOCKS / 2u; }
 // zstd level -> match links followed per position (the reference's searchLog grows the same way: clevels.h:25-47)
-static uint32_t zstd_search_depth(int level) { return level < 6 ? 0u : (level < 10 ? 2u : (level < 16 ? 4u : 8u)); }
+static uint32_t zstd_search_depth(int level) { return level < 6 ? 0u : (level < 10 ? 2u : (level < 16 ? 4u : (level < 18 ? 8u : 16u))); }
 
 extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, void* d_dst, size_t dstCap, int level)
 {
@@ -665,7 +666,8 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
     c->shortPass = level >= 10 ? 1u : 0u;         // the reference's btopt strategies search 3-byte matches (minMatch 3, clevels.h:44-47); from level 10 since round 3, see priceParse
     gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass); gc_env_u32("GC_SHORT_PASS", 0u, 1u, &c->shortPass);   // test hooks
     c->shortPlain = 0u; c->smallWin2k = 0u;
-    c->farPass2 = level >= 7 ? 1u : 0u; gc_env_u32("GC_FAR2_PASS", 0u, 1u, &c->farPass2);      // keys of 32 / 24 bytes where the reference searches chains / trees for the LONGEST match: real sources, emulator, 8 MiB:
+    c->allLengths = level >= 18 ? 1u : 0u;        // levels 16-17 (the reference: btopt / btultra with searchLog 5) keep the sparse lengths and the two far passes; 18-22 (btultra / btultra2, searchLog 6-9) price every length
+    c->farPass2 = (level >= 7 && level != 16 && level != 17) ? 1u : 0u; gc_env_u32("GC_FAR2_PASS", 0u, 1u, &c->farPass2);      // keys of 32 / 24 bytes where the reference searches chains / trees for the LONGEST match: real sources, emulator, 8 MiB:
                                                                                               // level 9 1.118 -> 1.050 x the reference, level 19 1.115 -> 1.097
     c->reParse = 0u;
     c->laneParse = level >= 16 ? 1u : 0u;         // the reference's btopt .. btultra2 (clevels.h:44-50) price its three repeat offsets at every position; real sources / binaries at level 19
@@ -890,7 +892,7 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     c->shortPass = level >= 3 ? 1u : 0u;          // ... and holds the nearest match of >= 2 bytes for every position
     gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass); gc_env_u32("GC_SHORT_PASS", 0u, 1u, &c->shortPass);   // test hooks
     if (gc_env_u32("GC_SEARCH_DEPTH", 0u, 64u, &c->searchDepth)) c->searchShallow = c->searchDepth < 2u ? c->searchDepth : 2u;
-    c->shortPlain = level < 7 ? 1u : 0u;
+    c->shortPlain = level < 7 ? 1u : 0u; c->allLengths = 0u;
     c->smallWin2k = (level == 5 || level == 6) ? 1u : 0u;
     c->farPass2 = level >= 7 ? 1u : 0u; gc_env_u32("GC_FAR2_PASS", 0u, 1u, &c->farPass2);      // keys of 32 / 24 bytes (gc_lz_window.hip MF_FAR2) at the ultra levels
     c->reParse = 0u;
@@ -1068,7 +1070,7 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     gc_env_u32("GC_SEARCH_SHALLOW", 0u, 64u, &c->searchShallow);                                // test hook: links followed by the positions inside a match and in tiles without long matches
     c->farPass = level >= 5 ? 1u : 0u; c->shortPass = 0;      // longer matches stand in for the context modelling / block splitting B1 lacks
     gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass);                                            // test hook
-    c->shortPlain = 0u; c->smallWin2k = 0u;
+    c->shortPlain = 0u; c->smallWin2k = 0u; c->allLengths = 0u;
     c->farPass2 = 0u; gc_env_u32("GC_FAR2_PASS", 0u, 1u, &c->farPass2);
     c->reParse = 0u;
     c->laneParse = 0u; c->lastCodecHint = 2; c->priceMinLen = 3u; c->priceLitCtx = 0u;     // copies of >= 3 bytes (a 2-byte copy at a fresh distance never pays in brotli), one literal code per meta-block

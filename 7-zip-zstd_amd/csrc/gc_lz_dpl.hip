@@ -135,6 +135,7 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
     const uint32_t litCtxMask = litCtxArg & 0xFFu, hasPrev = litCtxArg >> 31;
     const bool win2k = !SAMPLE && (phaseArg & 16u) != 0u;         // every window of ONE block per wave, 64 x 2 KiB (more, shorter waves: the launch ends with its slowest wave)
     const bool countB = !SAMPLE && (phaseArg & GC_DP_COUNT) != 0u && dpStatOut != nullptr;      // count the paths of this pass as phase A counts its sample (round 5: the re-priced second pass)
+    const bool allLenArg = (phaseArg & GC_DP_ALLLEN) != 0u;       // every length of a candidate is an edge (zstd levels >= 18)
     const bool selective = !SAMPLE && (phaseArg & GC_DP_SELECT) != 0u;      // phase B of the blocks whose sampled paths repeat distances; the others are W7's (gc_mf.h GC_DPS_RICH)
     phaseArg &= 15u;
     const uint32_t BPWr = win2k ? 1u : BPW;
@@ -160,12 +161,13 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
     static const int xHints = getenv("GC_X_HINTS") ? atoi(getenv("GC_X_HINTS")) : 63;
     static const bool xSrepAny = getenv("GC_X_SREP_ANY") ? atoi(getenv("GC_X_SREP_ANY")) != 0 : DPL_SREP_ANY != 0;
     (void)xWin4k;
-    static const bool allLen = getenv("GC_X_ALL_LEN") ? atoi(getenv("GC_X_ALL_LEN")) != 0 : DPL_ALL_LENGTHS != 0;
+    static const bool allLenEnv = getenv("GC_X_ALL_LEN") ? atoi(getenv("GC_X_ALL_LEN")) != 0 : true;
+    const bool allLen = DPL_ALL_LENGTHS != 0 && allLenArg && allLenEnv;
     const uint32_t winLen = SAMPLE ? 512u : (win2k ? 2048u : 4096u);
     const uint32_t w0 = win2k ? lane << 11 : ((lane & 31u) << 12) + (SAMPLE ? 1536u : 0u);
 #else
     const int xWarm = DPL_WARM; const int xSparse = 0; const bool xSrepAny = DPL_SREP_ANY != 0;
-    const bool allLen = DPL_ALL_LENGTHS != 0;
+    const bool allLen = DPL_ALL_LENGTHS != 0 && allLenArg;
     const uint32_t winLen = SAMPLE ? 512u : (win2k ? 2048u : 4096u);
     const uint32_t w0 = win2k ? lane << 11 : ((lane & 31u) << 12) + (SAMPLE ? 1536u : 0u);
 #endif
