@@ -52,14 +52,14 @@ extern "C" __global__ void gc_mf_scatter_half_kernel(const uint8_t*, uint64_t, u
 extern "C" __global__ void gc_mf_verify_half_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
 extern "C" __global__ void gc_mf_count_short_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
 extern "C" __global__ void gc_mf_scatter_short_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
-extern "C" __global__ void gc_mf_verify_short_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, const uint32_t*, uint32_t*);
+extern "C" __global__ void gc_mf_verify_short_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, const uint32_t*, uint32_t*, const uint32_t*);
 extern "C" __global__ void gc_mf_count_far_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
 extern "C" __global__ void gc_mf_scatter_far_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
 extern "C" __global__ void gc_mf_verify_far_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
 extern "C" __global__ void gc_mf_count_far2_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
 extern "C" __global__ void gc_mf_scatter_far2_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
 extern "C" __global__ void gc_mf_verify_far2_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
-extern "C" __global__ void gc_mf_deepen_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, uint32_t*);
+extern "C" __global__ void gc_mf_deepen_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, uint32_t*, uint32_t*);
 extern "C" __global__ void gc_mf_count_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
 extern "C" __global__ void gc_mf_scan_kernel_p8(uint32_t*, uint32_t);
 extern "C" __global__ void gc_mf_scatter_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
@@ -70,14 +70,14 @@ extern "C" __global__ void gc_mf_scatter_half_kernel_p8(const uint8_t*, uint64_t
 extern "C" __global__ void gc_mf_verify_half_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
 extern "C" __global__ void gc_mf_count_short_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
 extern "C" __global__ void gc_mf_scatter_short_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
-extern "C" __global__ void gc_mf_verify_short_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, const uint32_t*, uint32_t*);
+extern "C" __global__ void gc_mf_verify_short_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, const uint32_t*, uint32_t*, const uint32_t*);
 extern "C" __global__ void gc_mf_count_far_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
 extern "C" __global__ void gc_mf_scatter_far_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
 extern "C" __global__ void gc_mf_verify_far_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
 extern "C" __global__ void gc_mf_count_far2_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
 extern "C" __global__ void gc_mf_scatter_far2_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
 extern "C" __global__ void gc_mf_verify_far2_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
-extern "C" __global__ void gc_mf_deepen_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, uint32_t*);
+extern "C" __global__ void gc_mf_deepen_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, uint32_t*, uint32_t*);
 extern "C" __global__ void gc_mf_vparse_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, GcSeqRaw*, uint8_t*, GcBlockMeta*, unsigned long long*);
 extern "C" __global__ void gc_mf_vparse_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, GcSeqRaw*, uint8_t*, GcBlockMeta*, unsigned long long*);
 extern "C" __global__ void gc_mf_vparse_tile_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, GcSeqRaw*, uint8_t*, GcBlockMeta*, uint32_t*, uint32_t*, unsigned long long*);
@@ -149,7 +149,7 @@ struct gc_ctx {
     // windowed match finder (gc_mf.h): counts/offsets, partition starts, entry lists; grown on demand
     uint32_t* mfTileWord; size_t mfTileWordCap;   // fused verify + parse: one word of counts per tile
     uint32_t nCU; uint32_t* mfTicket;      // compute units of the device; ticket counters of the persistent launches (4 per part)
-    uint32_t* mfCnt; size_t mfCntCap; GcMfEntry* mfEnt; size_t mfEntCap; GcMfEntry* mfEnt2; size_t mfEnt2Cap; uint32_t* mfRec; size_t mfRecCap; uint32_t* mfRec2; size_t mfRec2Cap;
+    uint32_t* mfCnt; size_t mfCntCap; GcMfEntry* mfEnt; size_t mfEntCap; GcMfEntry* mfEnt2; size_t mfEnt2Cap; uint32_t* mfRec; size_t mfRecCap; uint32_t* mfRec2; size_t mfRec2Cap; uint32_t* mfChanged; size_t mfChangedCap;
     uint16_t* mfRec3; size_t mfRec3Cap; uint32_t* mfDp; size_t mfDpCap; uint16_t* mfPrice; size_t mfPriceCap; uint32_t* mfWinCost; size_t mfWinCostCap; uint32_t* mfDpStat; size_t mfDpStatCap; uint8_t* mfLitPrice; size_t mfLitPriceCap;      // (+ W7L: literal price per position) W5s records, W7 records, price tables, W7 phase-A symbol counts
     hipEvent_t evMf[GC_MAX_PARTS][13];      // per part: W1 start, W1 end, W2 end, W3 end, W4 end, W5 end, W6 end; price-based parse: greedy W6 end, W5s end, W7 end;
                                             // inside W5: first verify end, far pass end, deepen end
@@ -261,7 +261,7 @@ static void ctx_release(gc_ctx* c)
     hipFree(c->prof); hipFree(c->mfTicket); hipFree(c->result); if (c->hostResult) hipHostFree(c->hostResult); hipFree(c->dIn); hipFree(c->dOut); hipFree(c->dPre);
     hipFree(c->zdLit); hipFree(c->zdSeq); hipFree(c->zdFrames); hipFree(c->zdResult); hipFree(c->zdTot); hipFree(c->zdBlocks); hipFree(c->zdOrder); hipFree(c->zdReady); hipFree(c->zdTicket); hipFree(c->zdPlace); hipFree(c->zdPtr); hipFree(c->zdDone); hipFree(c->zdFerr);
     for (int i = 0; i < 2; i++) if (c->zdEv[i]) hipEventDestroy(c->zdEv[i]);
-    hipFree(c->mfTileWord); hipFree(c->mfCnt); hipFree(c->mfEnt); hipFree(c->mfEnt2); hipFree(c->mfRec); hipFree(c->mfRec2); hipFree(c->mfRec3); hipFree(c->mfDp); hipFree(c->mfPrice); hipFree(c->mfWinCost); hipFree(c->mfDpStat); hipFree(c->mfLitPrice);
+    hipFree(c->mfTileWord); hipFree(c->mfCnt); hipFree(c->mfEnt); hipFree(c->mfEnt2); hipFree(c->mfRec); hipFree(c->mfRec2); hipFree(c->mfChanged); hipFree(c->mfRec3); hipFree(c->mfDp); hipFree(c->mfPrice); hipFree(c->mfWinCost); hipFree(c->mfDpStat); hipFree(c->mfLitPrice);
     for (int i = 0; i < 8; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
     for (uint32_t p = 0; p < GC_MAX_PARTS; p++) {
         for (int i = 0; i < 13; i++) if (c->evMf[p][i]) hipEventDestroy(c->evMf[p][i]);
@@ -352,7 +352,7 @@ static int ensure_finder_workspace(gc_ctx* c, size_t n, uint32_t frameBlocks)
     const size_t needRec = (size_t)g.nBlocks * GC_ZSTD_BLOCK_MAX * sizeof(uint32_t);
     const size_t needPrice = (size_t)g.nBlocks * GC_PRICE_WORDS * sizeof(uint16_t);
     const size_t needTileWord = ((size_t)g.nTiles + 64u) * sizeof(uint32_t);
-    if (needTileWord > c->mfTileWordCap || needCnt > c->mfCntCap || needEnt > c->mfEntCap || needEnt > c->mfEnt2Cap || needRec > c->mfRecCap || ((c->searchDepth || c->shortPass) && needRec > c->mfRec2Cap) ||
+    if (needTileWord > c->mfTileWordCap || needCnt > c->mfCntCap || needEnt > c->mfEntCap || needEnt > c->mfEnt2Cap || needRec > c->mfRecCap || ((c->searchDepth || c->shortPass) && (needRec > c->mfRec2Cap || needRec / 32u + 64u > c->mfChangedCap)) ||
         (c->priceParse && (needRec / 2u > c->mfRec3Cap || needRec > c->mfDpCap || needPrice > c->mfPriceCap || (size_t)g.nBlocks * 128u > c->mfWinCostCap || (size_t)g.nBlocks * GC_DPS_WORDS * 8u > c->mfDpStatCap || needRec / 4u > c->mfLitPriceCap))) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         int rc;
@@ -362,6 +362,7 @@ static int ensure_finder_workspace(gc_ctx* c, size_t n, uint32_t frameBlocks)
         if ((rc = mf_grow(c, (void**)&c->mfEnt2, &c->mfEnt2Cap, needEnt, "linked entries")) != GC_OK) return rc;
         if ((rc = mf_grow(c, (void**)&c->mfRec, &c->mfRecCap, needRec, "records")) != GC_OK) return rc;
         if ((c->searchDepth || c->shortPass) && (rc = mf_grow(c, (void**)&c->mfRec2, &c->mfRec2Cap, needRec, "deepened records")) != GC_OK) return rc;
+        if ((c->searchDepth || c->shortPass) && (rc = mf_grow(c, (void**)&c->mfChanged, &c->mfChangedCap, needRec / 32u + 64u, "changed-record bitmap")) != GC_OK) return rc;
         if (c->priceParse) {
             if ((rc = mf_grow(c, (void**)&c->mfRec3, &c->mfRec3Cap, needRec / 2u, "short candidates")) != GC_OK) return rc;
             if ((rc = mf_grow(c, (void**)&c->mfDp, &c->mfDpCap, needRec, "price-parse records")) != GC_OK) return rc;
@@ -461,9 +462,10 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
                   (const GcMfEntry*)ent2, rec);
     }
     HIPCHK(c, hipEventRecord(ev[11], st));
+    uint32_t* const chg = (c->searchDepth && c->shortPass && c->priceParse) ? c->mfChanged + (size_t)blk0 * (GC_ZSTD_BLOCK_MAX / 32u) : (uint32_t*)nullptr;      // which records W5b changes: what the pass with 4- / 3-byte keys looks at again (gc_lz_window.hip "continuation")
     if (c->searchDepth) {                                       // W5b: follow match links (timed with W5)
         uint32_t* rec2 = c->mfRec2 + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
-        GC_LAUNCH(MFSEL(gc_mf_deepen_kernel), perT * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, c->searchDepth | (c->searchShallow << 8), (const uint32_t*)rec, rec2);
+        GC_LAUNCH(MFSEL(gc_mf_deepen_kernel), perT * GC_XCDS, 256, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, c->searchDepth | (c->searchShallow << 8), (const uint32_t*)rec, rec2, chg);
         rec = rec2;
     }
     HIPCHK(c, hipEventRecord(ev[12], st));
@@ -484,7 +486,7 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
             const uint32_t gridS = nListsS * GC_MF_LINK_SEGS < c->nCU * linkWpc ? nListsS * GC_MF_LINK_SEGS : c->nCU * linkWpc;
             GC_LAUNCH(MFSEL(gc_mf_link_kernel), gridS, 64, st, (const uint32_t*)cntS, (const GcMfEntry*)ent, ent2, gs.tilesPerFrame, gs.frameBytes, nListsS, ticket_); }
         GC_LAUNCH(MFSEL(gc_mf_verify_short_kernel), perTs * GC_XCDS, gs.verifyT, st, src, (uint64_t)n, fbS, gs.nTiles, perTs, (const uint32_t*)cntS,
-                  (const GcMfEntry*)ent2, (const uint32_t*)rec, recN);
+                  (const GcMfEntry*)ent2, (const uint32_t*)rec, recN, (const uint32_t*)chg);
         recDp = recN;
     }
     HIPCHK(c, hipEventRecord(ev[5], st));
@@ -934,7 +936,9 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     gc_env_u32("GC_SEG_MERGE", 0u, 8u, &segMerge);                                              // test hook: 0 = every block a segment of its own (round 4)
     if (segMerge & (segMerge - 1u)) segMerge = 4u;
     while (segMerge > 1u && nBlocks > groupBlocks && (groupBlocks % segMerge) != 0u) segMerge >>= 1;      // (groups are aligned to the input: they must not straddle frames, or a frame-aligned shard would differ from the whole input's bytes)
-    uint32_t mergeBudget = 16u * 917504u;                                                      // 896 Ki coded bits (1/16 bit units) = 7 bits per byte of ONE 128 KiB block, the longest chain the launch has anyway (PCM-like data; >= 8 bits per byte is stored unmodelled)
+    uint32_t mergeBudget = 16u * 655360u;                                                      // 640 Ki coded bits (1/16 bit units) = 5 bits per byte of ONE 128 KiB block.  Measured on 211.9 MB (run s9, model kernel / size):
+                                                                                               // 896 Ki -- the longest chain the launch has anyway, PCM-like data -- 17.0 ms on the Silesia stand-in and 21.5 ms on shared objects
+                                                                                               // (the estimate is the PARSE's: the model's chain comes out longer); 640 Ki 14.4 / 14.5 ms, as without merging, for +0.01 / +0.05 % size
     { uint32_t kbits = 0; if (gc_env_u32("GC_SEG_MERGE_KBITS", 1u, 4096u, &kbits)) mergeBudget = kbits * 16384u; }
     uint8_t* const segKind = c->lzProps + (size_t)c->capBlocks * (GC_ZSTD_BLOCK_MAX >> GC_LZMA_SEG_LOG_MIN);
     if (c->profOn) { HIPCHK(c, hipMemsetAsync(c->prof, 0, (GC_LZ_PHASES + GC_SEQ_PHASES) * sizeof(unsigned long long), c->stream)); c->profBlocks = 1u; }   // L2 phase sums (raw)
