@@ -142,7 +142,11 @@ int         gc_codec_compress_host(gc_ctx* ctx, int codec, const void* src, size
  * folder "filter -> coder" holds.
  *   filter      0 = none, GC_BRA_* / GC_FILTER_X86 / GC_FILTER_DELTA as for gc_filter_host;  pc, delta, state: as there (state: 4 bytes x86, 256 Delta), in and out
  *   want_crc    != 0: crc receives CrcCalc(src, n) (init / final XOR 0xFFFFFFFF, polynomial 0xEDB88320)
- *   processed   out: bytes the converter has converted (the last few of a stream stay as they are, as at the end of CFilterCoder's stream) */
+ *   processed   out: bytes the converter has converted (the last few of a stream stay as they are, as at the end of CFilterCoder's stream)
+ * ONE CALL = ONE WHOLE STREAM.  All n bytes of the call are compressed, the unconverted tail included, and nothing is carried into a next call: a branch instruction
+ * that straddles the end of the call stays as it is, which is right at the end of a stream and WRONG in the middle of one (a decoder's filter converts across the seam).
+ * The CRC is not resumable either.  A caller that cuts a stream into pieces must filter / sum on its side (gc_filter_host carries pc and state from call to call) and
+ * use the plain entry points for the pieces; pc / state are "in" for streams that do not start at offset 0, "out" for inspection only. */
 typedef struct gc_pre {
     int filter; uint32_t pc; unsigned delta; int want_crc;
     unsigned char state[256];
