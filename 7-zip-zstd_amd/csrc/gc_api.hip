@@ -151,6 +151,7 @@ struct gc_ctx {
     uint32_t nCU; uint32_t* mfTicket;      // compute units of the device; ticket counters of the persistent launches (4 per part)
     uint32_t* mfCnt; size_t mfCntCap; GcMfEntry* mfEnt; size_t mfEntCap; GcMfEntry* mfEnt2; size_t mfEnt2Cap; uint32_t* mfRec; size_t mfRecCap; uint32_t* mfRec2; size_t mfRec2Cap; uint32_t* mfChanged; size_t mfChangedCap;
     uint16_t* mfRec3; size_t mfRec3Cap; uint32_t* mfDp; size_t mfDpCap; uint16_t* mfPrice; size_t mfPriceCap; uint32_t* mfWinCost; size_t mfWinCostCap; uint32_t* mfDpStat; size_t mfDpStatCap; uint8_t* mfLitPrice; size_t mfLitPriceCap;      // (+ W7L: literal price per position) W5s records, W7 records, price tables, W7 phase-A symbol counts
+    hipEvent_t evShort[GC_MAX_PARTS];       // W5s (near 2-3 byte candidates) runs beside the finder on stream2: done
     hipEvent_t evMf[GC_MAX_PARTS][13];      // per part: W1 start, W1 end, W2 end, W3 end, W4 end, W5 end, W6 end; price-based parse: greedy W6 end, W5s end, W7 end;
                                             // inside W5: first verify end, far pass end, deepen end
     bool mfPriced;                          // the last call ran the price-based parse (events 7..9 are valid)
@@ -229,6 +230,7 @@ extern "C" int gc_ctx_create(gc_ctx** out, int device)
     for (int i = 0; rc == GC_OK && i < 8; i++) if (hipEventCreate(&c->ev[i]) != hipSuccess) rc = GC_ERR_HIP;
     for (uint32_t p = 0; rc == GC_OK && p < GC_MAX_PARTS; p++) {
         for (int i = 0; rc == GC_OK && i < 13; i++) if (hipEventCreate(&c->evMf[p][i]) != hipSuccess) rc = GC_ERR_HIP;
+        if (rc == GC_OK && hipEventCreate(&c->evShort[p]) != hipSuccess) rc = GC_ERR_HIP;
         for (uint32_t i = 0; rc == GC_OK && i < GC_PART_EVENTS; i++) if (hipEventCreate(&c->evPart[p][i]) != hipSuccess) rc = GC_ERR_HIP;
     }
     if (rc == GC_OK && hipMalloc((void**)&c->prof, (GC_LZ_PHASES + GC_SEQ_PHASES) * sizeof(unsigned long long)) != hipSuccess) rc = GC_ERR_NOMEM;
@@ -265,6 +267,7 @@ static void ctx_release(gc_ctx* c)
     for (int i = 0; i < 8; i++) if (c->ev[i]) hipEventDestroy(c->ev[i]);
     for (uint32_t p = 0; p < GC_MAX_PARTS; p++) {
         for (int i = 0; i < 13; i++) if (c->evMf[p][i]) hipEventDestroy(c->evMf[p][i]);
+        if (c->evShort[p]) hipEventDestroy(c->evShort[p]);
         for (uint32_t i = 0; i < GC_PART_EVENTS; i++) if (c->evPart[p][i]) hipEventDestroy(c->evPart[p][i]);
     }
     if (c->stream3) hipStreamDestroy(c->stream3);
@@ -408,6 +411,15 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
         GC_LAUNCH(MFSEL(gc_mf_link_kernel), linkGrid, 64, st, (const uint32_t*)(cnt_), (const GcMfEntry*)(ent_), ent2_, g.tilesPerFrame, g.frameBytes, nLists, ticket_); } while (0)
     hipEvent_t* ev = c->evMf[part];
     HIPCHK(c, hipEventRecord(ev[0], st));
+    // W5s reads nothing but the input: it runs beside the finder's passes on the context's second stream (round 5; it was 1.5 ms of the main stream's chain per 212 MB).  stream2 is
+    // also where the stages behind the finder run, later in the same call: stream order keeps them apart.
+    const bool shortBeside = c->priceParse && st == c->stream;
+    if (shortBeside) {
+        HIPCHK(c, hipEventRecord(c->evShort[part], st)); HIPCHK(c, hipStreamWaitEvent(c->stream2, c->evShort[part], 0));        // (the input and the workspace are ready where `st` stands now)
+        const uint32_t nChunkWg = (uint32_t)(((n + 2047u) / 2048u + 3u) / 4u), perC = gc_xcd_per(nChunkWg);
+        GC_LAUNCH(gc_mf_short_kernel, perC * GC_XCDS, 256, c->stream2, src, (uint64_t)n, groupBlocks, (uint32_t)((n + 2047u) / 2048u), perC, c->mfRec3 + (size_t)blk0 * GC_ZSTD_BLOCK_MAX);
+        HIPCHK(c, hipEventRecord(c->evShort[part], c->stream2));
+    }
     if (c->halfList) GC_LAUNCH(MFSEL(gc_mf_count_half_kernel), perT * GC_XCDS, nParts, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, cnt);
     else GC_LAUNCH(MFSEL(gc_mf_count_kernel), perT * GC_XCDS, nParts, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, cnt);
     HIPCHK(c, hipEventRecord(ev[1], st));
@@ -500,7 +512,8 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
         GC_LAUNCH(gc_mf_parse_kernel, perB * GC_XCDS, GC_MF_PARSE_T, st, src, (uint64_t)n, nBlocks, perB, c->lazyDepth, (const uint32_t*)rec, seqRaw, lit, meta, price, litCtxArg);
         HIPCHK(c, hipEventRecord(ev[7], st));
         const uint32_t nChunkWg = (uint32_t)(((n + 2047u) / 2048u + 3u) / 4u), perC = gc_xcd_per(nChunkWg);
-        GC_LAUNCH(gc_mf_short_kernel, perC * GC_XCDS, 256, st, src, (uint64_t)n, groupBlocks, (uint32_t)((n + 2047u) / 2048u), perC, rec3);
+        if (shortBeside) HIPCHK(c, hipStreamWaitEvent(st, c->evShort[part], 0));
+        else GC_LAUNCH(gc_mf_short_kernel, perC * GC_XCDS, 256, st, src, (uint64_t)n, groupBlocks, (uint32_t)((n + 2047u) / 2048u), perC, rec3);
         HIPCHK(c, hipEventRecord(ev[8], st));
         // W7 in two phases: A = a sample of the windows (one workgroup of 4 windows per block) under optimistic prices, counting the symbols of its
         // paths; B = every window under prices made from those counts (gc_lz_price.hip)
@@ -922,7 +935,8 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     if (frameBlocks <= 1u) nParts = 1u;
     c->mfTimed = false; c->nParts = nParts;
     const uint32_t segPerBlock = GC_ZSTD_BLOCK_MAX >> segLog;
-    uint32_t mergeWords = GC_LZMA_RC_MERGE_WORDS;
+    uint32_t mergeWords = level <= 6 ? 32768u : GC_LZMA_RC_MERGE_WORDS;                        // coded bits of one LZMA2 chunk = the chain of ONE lane of L3.  Levels <= 6 (run s9, 211.9 MB): 49 152 -> 32 768 words takes 1.65 ms off L3
+                                                                                               // (5.98 -> 4.33) for +0.06 % size (10 bytes of header and coder flush per chunk)
     gc_env_u32("GC_RC_MERGE_WORDS", 0u, GC_LZMA_RC_MERGE_WORDS, &mergeWords);                  // test hook: 0 = one LZMA2 chunk per rc chunk
     uint32_t rep4 = 1;                                                                         // rep2 / rep3 coding in L2 (gc_lzma2_enc.hip LzLru); test hook: 0 = rep0 / rep1 only
     gc_env_u32("GC_L2_REP4", 0u, 1u, &rep4);
