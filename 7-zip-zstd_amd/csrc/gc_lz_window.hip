@@ -655,6 +655,13 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
     // is found by walking the run starts from the run of the round's first index (a wave-uniform cursor that only moves forward: a run holds
     // 32 entries on average, so a lane looks at two or three starts) -- not by a bisection per entry, which cost eight dependent LDS reads and
     // two dozen vector instructions of a kernel that is bound by vector issue.
+    // 16 bytes at frame-relative position c: from the staged tile where they lie inside it (a candidate a few KiB back is the common case on text, and what this kernel is
+    // bound by is the rate of scattered 16-byte requests to the L1: two per listed position), from memory otherwise.  Same bytes either way (round 5).
+    const uint32_t stagedLo = wTile >= MF_STAGE_PAD ? wTile - MF_STAGE_PAD : wTile + 0xFFFFFFFFu /* never */, stagedHi = wTile + (MFV_STAGE_WORDS * 4u - MF_STAGE_PAD);
+    auto ld16c = [&](uint64_t c) -> LzW16 {
+        if (wTile >= MF_STAGE_PAD && c >= stagedLo && c + 20u <= stagedHi) return mf_lds_ld16(sW, (uint32_t)(c - stagedLo));      // (+ 4: the three-word reads of mf_lds_ld64 stay inside the array)
+        return lz_ld16(wsrc, c);
+    };
     const uint32_t perWave = ((nEnt + MFV_T - 1u) / MFV_T) * 64u;
     const uint32_t jBeg = wave * perWave, jEnd = jBeg + perWave < nEnt ? jBeg + perWave : nEnt;
     uint32_t g0 = 0;                                              // run of index jBeg (largest g with sLocal[g] <= jBeg)
@@ -691,14 +698,14 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
             bestC[k] = (can && cL) ? cL : 0u;
             bestExt[k] = 0;
             if (HALF) { if (bestC[k] <= MFV_BACK) bestC[k] = 0; if (cS[k] <= MFV_BACK) cS[k] = 0; }      // (a candidate at the very frame start has no bytes in front of it)
-            if (bestC[k]) cw[k] = lz_ld16(wsrc, bestC[k] - 1u - (HALF ? MFV_BACK : 0u));
+            if (bestC[k]) cw[k] = ld16c(bestC[k] - 1u - (HALF ? MFV_BACK : 0u));
         }
 #pragma unroll
         for (uint32_t k = 0; k < MFV_B; k++) {
             if (HALF) { uint32_t x = 0; bestLen[k] = bestC[k] ? mfv_len13(mf_lds_ld16(sW, q[k] + MF_STAGE_PAD - MFV_BACK), cw[k], maxLen[k], x) : 0u; bestExt[k] = x; }
             else bestLen[k] = bestC[k] ? mfv_len16(mf_lds_ld16(sW, q[k] + MF_STAGE_PAD), cw[k], maxLen[k], MINLEN) : 0u;
             if (bestLen[k] >= LONGLEN || maxLen[k] == 0u) cS[k] = 0;  // verified long candidate: the short one is not needed
-            if (cS[k]) cw[k] = lz_ld16(wsrc, cS[k] - 1u - (HALF ? MFV_BACK : 0u));
+            if (cS[k]) cw[k] = ld16c(cS[k] - 1u - (HALF ? MFV_BACK : 0u));
         }
 #pragma unroll
         for (uint32_t k = 0; k < MFV_B; k++) {
@@ -710,7 +717,7 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
             }
             uint32_t len = bestLen[k];
             while ((HALF ? (len & 15u) == 13u : (len >= 16u && (len & 15u) == 0u)) && len < maxLen[k]) {      // saturated: extend 16 bytes per round (own side from LDS)
-                const uint32_t more = lz_cmp16(mf_lds_ld16(sW, q[k] + MF_STAGE_PAD + len), lz_ld16(wsrc, (uint64_t)(bestC[k] - 1u) + len));
+                const uint32_t more = lz_cmp16(mf_lds_ld16(sW, q[k] + MF_STAGE_PAD + len), ld16c((uint64_t)(bestC[k] - 1u) + len));
                 len += more;
                 if (len > maxLen[k]) len = maxLen[k];
                 if (more < 16u) break;
