@@ -13,7 +13,7 @@ THR = min(os.cpu_count() or 1, 64)
 CASES = [("real-src", 64 * MiB), ("real-bin", 211_900_000), ("real-py", 64 * MiB)]       # (real-py: all there is, 18.9 MB)
 # bars that are not met, with the measured figure (filled from tools/gpu_ratio.py on the MI355X; strict=False)
 NOT_YET = {("flzma2", "real-src"): "0.998 x the reference in round 4 (1.018 in round 3): inside the band, the entry stays as a guard",
-           ("flzma2", "real-bin"): "met in round 5: 1.017 x the reference on all 211.9 MB (model segments over cheap neighbouring blocks, level 5 in overlapping finder frames of 16 MiB groups -- the reference's dictionary at this level; 1.026 in round 4, 1.054 in round 3): the entry stays as a guard",
+           ("flzma2", "real-bin"): "met in round 5: 1.018 x the reference on all 211.9 MB (model segments over cheap neighbouring blocks, level 5 in overlapping finder frames of 16 MiB groups -- the reference's dictionary at this level; 1.026 in round 4, 1.054 in round 3): the entry stays as a guard",
            ("flzma2", "real-py"): "1.008 x the reference in round 4 (1.017 in round 3): inside the band, the entry stays as a guard",
            ("brotli", "real-src"): "1.058 x the reference (round 5, run s3, with B1's last-distance substitution in two passes; 1.069 in round 4 before it, 1.084 in round 3).  What is left needs the ring distances INSIDE the parse and literal context modelling with clustered block types (DESIGN section 8)",
            ("brotli", "real-bin"): "1.085 x the reference (round 5, run s3, with the substitution; 1.101 in round 4 before it, 1.106 in round 3: its hasher tries the last distances first at every position)",
