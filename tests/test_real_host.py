@@ -179,6 +179,53 @@ def test_gpu_real_host_archives_through_the_product_module(host_dir, graft, O):
     _roundtrip(host_dir, env, O, "BROTLIGPU", 6, "BROTLI", 80_000_000, "web-text")
 
 
+# The reference's own regression archives (tests/regr-arc, fixtures of tests/regression.test:66-88,153-173; committed as data under tests/golden/): written by the
+# reference's ZSTD encoder at level 17 / max, solid and non-solid.  The host WITHOUT a ZSTD codec of its own resolves method id 4F71101 to this module, so `7z t` / `7z x`
+# run the plugin's decoder; the pinned results are the CRCs (the host checks them itself: "Everything is Ok") and the SHA-256 of the decoded data.
+REGR_ARCS = [("test.txt.zstd.7z", {"test.txt": (1000000, "C601982A", "aeda0f81c8376d1678af53927a08cf641cafab8b68aef509c881eb0be0bc3c97")}),
+             ("test-sol.zstd.7z", {"test.txt": (1000000, "C601982A", "aeda0f81c8376d1678af53927a08cf641cafab8b68aef509c881eb0be0bc3c97"), "tesx.txt": (100000, "7ECE9EBC", None)}),
+             ("test-sol.zstd.max.7z", {"test.txt": (1000000, "C601982A", "aeda0f81c8376d1678af53927a08cf641cafab8b68aef509c881eb0be0bc3c97"), "tesx.txt": (100000, "7ECE9EBC", None)})]
+
+
+def _regression_archives(host_dir_nozstd, env):
+    import hashlib
+    import zlib
+    r = _run(host_dir_nozstd, env, "i")
+    assert r.returncode == 0 and "4F71101 ZSTD" in r.stdout, r.stdout                 # the only ZSTD decoder this host has is the module's
+    for name, files in REGR_ARCS:
+        arc = os.path.join(ROOT, "tests", "golden", name)
+        r = _run(host_dir_nozstd, env, "t", arc)
+        assert r.returncode == 0 and "Everything is Ok" in r.stdout, name + "\n" + r.stdout + r.stderr
+        r = _run(host_dir_nozstd, env, "l", "-slt", arc)
+        for fn, (size, crc, _) in files.items():
+            assert ("Path = " + fn) in r.stdout and ("CRC = " + crc) in r.stdout and ("Size = %d" % size) in r.stdout, r.stdout
+        assert "Method = ZSTD" in r.stdout, r.stdout
+        out = host_dir_nozstd / ("x_regr_" + name)
+        if out.exists():
+            shutil.rmtree(out)
+        r = _run(host_dir_nozstd, env, "x", "-o" + str(out), arc)
+        assert r.returncode == 0 and "Everything is Ok" in r.stdout, name + "\n" + r.stdout + r.stderr
+        for fn, (size, crc, sha) in files.items():
+            data = (out / fn).read_bytes()
+            assert len(data) == size and ("%08X" % (zlib.crc32(data) & 0xFFFFFFFF)) == crc, (name, fn)
+            if sha is not None:
+                assert hashlib.sha256(data).hexdigest() == sha, (name, fn)
+
+
+def test_real_host_extracts_the_reference_regression_archives_through_the_emulator_module(host_dir_nozstd, emu_lib_path):
+    _regression_archives(host_dir_nozstd, _install(host_dir_nozstd, os.path.join(EMU, "lib7zgpucodec_emu.so"), EMU))
+
+
+@pytest.mark.gpu
+def test_gpu_real_host_extracts_the_reference_regression_archives(host_dir_nozstd, graft):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    graft.build_hip()
+    module = graft.build_plugin()
+    _regression_archives(host_dir_nozstd, _install(host_dir_nozstd, module, os.path.join(ROOT, "7-zip-zstd_amd", "csrc")))
+
+
 def _filter_chain(host_dir, env, O, n_bcj, n_delta):
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tests"))
