@@ -50,7 +50,8 @@ __device__ __forceinline__ uint32_t ps_item(uint32_t bid, uint32_t per) { return
 
 __device__ __forceinline__ uint32_t sh_lds_ld32(const uint32_t* sW, uint32_t i)     // bytes i .. i+3 of the staged window
 {
-    uint32_t v; __builtin_memcpy(&v, (const uint8_t*)sW + i, 4); return v;     // (one ds_read_b32 at a byte address: gfx950 reads LDS unaligned, gc_lz_window.hip mf_lds_ld64)
+    const uint32_t w = i >> 2, sh = (i & 3u) * 8u;
+    return (uint32_t)((((uint64_t)sW[w + 1u] << 32) | sW[w]) >> sh);
 }
 
 extern "C" __global__ void __launch_bounds__(SH_T)

@@ -80,13 +80,19 @@ __device__ __forceinline__ void mf_stage(uint32_t* sW, uint32_t nWords, const ui
         sW[4u * c] = v.x; sW[4u * c + 1u] = v.y; sW[4u * c + 2u] = v.z; sW[4u * c + 3u] = v.w;
     }
 }
-// bytes i .. i+7 of the staged tile.  gfx950 reads LDS at any byte address (the target has unaligned-ds-access and the runtime enables the unaligned mode), so this is ONE
-// ds_read_b64 -- rounds 1-5 assembled it from three aligned words and two funnel shifts: 19 % of the fused verify + parse kernel's instructions (round 6)
+// bytes i .. i+7 of the staged tile: three aligned LDS words + two funnel shifts (v_alignbit).  (Round 6 measured the obvious alternative: gfx950 accepts LDS reads at
+// any byte address and hipcc turns an unaligned 8-byte memcpy into ONE ds_read_b64 -- 19 % fewer instructions in the fused verify + parse kernel, the same bytes
+// out -- but the hardware serves a misaligned ds_read_b64 several times slower than three aligned words: W1 0.66 -> 1.97 ms, W3 3.25 -> 6.23 ms, the fused kernel
+// unchanged, zstd-L3 on 1 GB 45.3 -> 37.7 GB/s, run s1.  Aligned words it is.)
 __device__ __forceinline__ uint64_t mf_lds_ld64(const uint32_t* sW, uint32_t i)
 {
-    uint64_t v; __builtin_memcpy(&v, (const uint8_t*)sW + i, 8); return v;
+    const uint32_t w = i >> 2, sh = (i & 3u) * 8u;
+    const uint32_t w0 = sW[w], w1 = sW[w + 1u], w2 = sW[w + 2u];
+    const uint32_t lo = (uint32_t)((((uint64_t)w1 << 32) | w0) >> sh);
+    const uint32_t hi = (uint32_t)((((uint64_t)w2 << 32) | w1) >> sh);
+    return ((uint64_t)hi << 32) | lo;
 }
-__device__ __forceinline__ uint32_t mf_lds_byte(const uint32_t* sW, uint32_t i) { return ((const uint8_t*)sW)[i]; }
+__device__ __forceinline__ uint32_t mf_lds_byte(const uint32_t* sW, uint32_t i) { return (sW[i >> 2] >> ((i & 3u) * 8u)) & 0xFFu; }
 
 // Is tile position q listed, and with which keys?  Not listed:
 //   - no full compare window (GC_MATCH_CAP + 16 bytes) left in the FRAME: such positions never match.  The limit is the frame
@@ -538,7 +544,7 @@ MFK(gc_mf_link_kernel)(const uint32_t* __restrict__ offs, const GcMfEntry* __res
 
 __device__ __forceinline__ LzW16 mf_lds_ld16(const uint32_t* sW, uint32_t i)
 {
-    LzW16 w; __builtin_memcpy(&w, (const uint8_t*)sW + i, 16); return w;
+    LzW16 w; w.a = mf_lds_ld64(sW, i); w.b = mf_lds_ld64(sW, i + 8u); return w;
 }
 // first 16 bytes of candidate c (frame-relative position + 1) against the own window; 0 if shorter than GC_MIN_MATCH
 __device__ __forceinline__ uint32_t mfv_len16(const LzW16& me, const LzW16& cw, uint32_t maxLen, uint32_t minLen = GC_MIN_MATCH)
