@@ -13,8 +13,11 @@
 // variable-length code, zero-run symbol 17, "stop when the Kraft sum is full"), canonical code assignment with bits sent
 // least-significant-first (so code words are stored bit-reversed), the 704-cell insert&copy alphabet, distance codes
 // (16 ring-buffer codes + 48 direct codes at NPOSTFIX = NDIRECT = 0) and the order cmd code, insert extra, copy extra,
-// literals, distance code, distance extra.  Free choices made here: one block type per category, one literal / distance
-// tree (no context modelling yet), NPOSTFIX = NDIRECT = 0, ring-buffer code 0 ("same distance as the previous copy") only.
+// literals, distance code, distance extra.  Free choices made here: one block type per category, one distance tree, NPOSTFIX = NDIRECT = 0.
+// Literal context modelling (round 6, quality >= 5 as in the reference, MIN_QUALITY_FOR_CONTEXT_MODELING): per meta-block either ONE literal tree or THIRTEEN, the
+// literal's context id taken from its two predecessors in CONTEXT_UTF8 mode (RFC 7932 section 7.1, br_utf8_lut0 / br_utf8_lut1 below) and mapped to a tree by the static map
+// of the reference's ShouldUseComplexStaticContextMap (C/brotli/br_encode.c:328-405: no clustering); the choice is made from the meta-block's own literal histograms (the
+// reference samples 64 bytes in every 4 KiB of input, :358-375), context map coded per RFC 7932 section 7.3 (C/brotli/br_brotli_bit_stream.c:592-735) without run lengths.
 //
 // Every meta-block is followed by an empty metadata meta-block (6 bits + padding, RFC 7932 section 9.2), which byte-aligns
 // the next one: meta-blocks are therefore independent byte strings that L-emit concatenates, and a 128 KiB block is one
@@ -28,6 +31,7 @@
 #include "gc_device.h"
 #include "gc_fse.h"
 #include "gc_brotli.h"
+#include "gc_lz_parse.h"       // pz_log2_q8: integer logarithm (the same on the device and under the emulator)
 
 #define BR_T 256u
 #define BR_WIN_WORDS 2048u     // 8 KiB: the bits of one tile of 256 commands are assembled in LDS and leave as full words
@@ -303,6 +307,71 @@ __device__ __forceinline__ uint32_t br_excl_scan(uint32_t v, uint32_t* sWave, ui
     *total = all;
     return before + incl - v;
 }
+
+// ---- literal context modelling: CONTEXT_UTF8 (RFC 7932 section 7.1; the reference holds the same function as a table, C/brotli/br_context.c:79-120).
+// context id = lut0(last byte) | lut1(second last byte): for two ASCII bytes 4 * class(last) + class2(second last)
+#define BR_NT 13u                      // literal trees of the static map (BROTLI_MAX_STATIC_CONTEXTS, C/brotli/enc/quality.h)
+__device__ __forceinline__ uint32_t br_utf8_lut0(uint32_t b)
+{
+    if (b >= 192u) return 2u + (b & 1u);                                  // UTF-8 lead byte
+    if (b >= 128u) return b & 1u;                                         // continuation byte
+    const bool up = b >= 'A' && b <= 'Z', lo = b >= 'a' && b <= 'z';
+    const uint32_t l = b | 0x20u;
+    const bool vowel = l == 'a' || l == 'e' || l == 'i' || l == 'o' || l == 'u';
+    uint32_t k = 3u;                                                      // other punctuation
+    if (b == 9u || b == 10u || b == 13u) k = 1u;
+    else if (b < 32u || b == 127u) k = 0u;
+    else if (b == ' ') k = 2u;
+    else if (b == '"' || b == '\'') k = 4u;
+    else if (b == '%') k = 5u;
+    else if (b == '(' || b == '<' || b == '[' || b == '{') k = 6u;
+    else if (b == ')' || b == '>' || b == ']' || b == '}') k = 7u;
+    else if (b == ',' || b == ';' || b == ':') k = 8u;
+    else if (b == '.') k = 9u;
+    else if (b == '=') k = 10u;
+    else if (b >= '0' && b <= '9') k = 11u;
+    else if (up) k = vowel ? 12u : 13u;
+    else if (lo) k = vowel ? 14u : 15u;
+    return 4u * k;
+}
+__device__ __forceinline__ uint32_t br_utf8_lut1(uint32_t b)
+{
+    if (b >= 208u) return 2u;
+    if (b >= 128u) return 0u;
+    if (b <= 32u || b == 127u) return 0u;                                 // control, space
+    if ((b >= '0' && b <= '9') || (b >= 'A' && b <= 'Z')) return 2u;
+    if (b >= 'a' && b <= 'z') return 3u;
+    return 1u;                                                            // punctuation
+}
+// context id (0..63) -> literal tree (0..12): what follows a line feed, a space, an opening / closing bracket, a digit, an upper- / lower-case letter ... each gets a code of its
+// own (the grouping of kStaticContextMapComplexUTF8, C/brotli/br_encode.c:330-347, written as the rule it encodes)
+__device__ __forceinline__ uint32_t br_static_tree(uint32_t ctx)
+{
+    const uint32_t c1 = ctx >> 2, c2 = ctx & 3u;
+    switch (c1) {
+    case 0:  return c2 < 2u ? 11u : 12u;          // after a non-ASCII byte
+    case 1:  return 0u;                            // line feed, tab
+    case 2:  return c2 < 2u ? 1u : 9u;             // space: start of a word after punctuation / after a word
+    case 3:  return 2u;
+    case 4:  return 1u;                            // quotes
+    case 5:  return c2 == 0u ? 8u : 3u;            // %
+    case 6:  return 1u;                            // opening brackets
+    case 7:  return 2u;                            // closing brackets
+    case 8:  return c2 == 0u ? 8u : 4u;            // , ; :
+    case 9:  return c2 == 0u ? 8u : (c2 == 1u ? 7u : 4u);      // .
+    case 10: return c2 == 0u ? 8u : 0u;            // =
+    case 11: return 3u;                            // digits
+    case 12: case 13: return c2 == 2u ? 10u : 5u;  // upper case: inside an upper-case word / at the start of one
+    default: return 6u;                            // lower case
+    }
+}
+extern "C" void gc_brotli_context_tables(uint8_t lut[512], uint8_t map[64])      // (tests: the restated tables against the reference's, tests/test_brotli.py)
+{
+    for (uint32_t b = 0; b < 256u; b++) { lut[b] = (uint8_t)br_utf8_lut0(b); lut[256u + b] = (uint8_t)br_utf8_lut1(b); }
+    for (uint32_t c = 0; c < 64u; c++) map[c] = (uint8_t)br_static_tree(c);
+}
+// VarLenUint8 + 1 (NBLTYPES, NTREES: RFC 7932 section 9.2): v = value - 1
+__device__ __forceinline__ void bw_put(struct BrBW& w, uint32_t v, uint32_t nb);
 
 extern "C" __global__ void __launch_bounds__(BR_T)
 gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const GcSeqRaw* __restrict__ seqRaw,

@@ -557,7 +557,7 @@ __device__ __forceinline__ uint32_t mfv_len16(const LzW16& me, const LzW16& cw, 
 // MF_HALF: the 16-byte windows start MFV_BACK bytes IN FRONT of the position and of the candidate.  Returns the common prefix of the bytes
 // from the position on (0..13; 0 if below GC_MIN_MATCH or maxLen == 0) and how many of the bytes in front agree as well (0..3, counted backwards).
 #define MFV_BACK 3u
-__device__ __forceinline__ uint32_t mfv_len13(const LzW16& me, const LzW16& cw, uint32_t maxLen, uint32_t& ext)
+__device__ __forceinline__ uint32_t mfv_len13(const LzW16& me, const LzW16& cw, uint32_t maxLen, uint32_t& ext, uint32_t minLen = GC_MIN_MATCH)
 {
     const uint64_t d0 = me.a ^ cw.a, d1 = me.b ^ cw.b;
     const bool b2 = ((d0 >> 16) & 0xFFull) == 0ull, b1 = ((d0 >> 8) & 0xFFull) == 0ull, b0 = (d0 & 0xFFull) == 0ull;
@@ -565,7 +565,7 @@ __device__ __forceinline__ uint32_t mfv_len13(const LzW16& me, const LzW16& cw, 
     const uint64_t e0 = (d0 >> 24) | (d1 << 40), e1 = (d1 >> 24) | (1ull << 40);
     uint32_t len = e0 ? gc_ctz64(e0) >> 3 : 8u + (gc_ctz64(e1) >> 3);
     if (len > maxLen) len = maxLen;
-    return len >= GC_MIN_MATCH ? len : 0u;
+    return len >= minLen ? len : 0u;
 }
 
 // optional phase profile (thread 0's shader-clock deltas, added to prof[i] as they are taken: no registers held across the kernel)
@@ -573,7 +573,17 @@ __device__ __forceinline__ uint32_t mfv_len13(const LzW16& me, const LzW16& cw, 
 
 // The verification of ONE tile: fills sRec[0 .. T.len) (LDS) and ends with a workgroup barrier.  Shared by the stand-alone verify
 // kernels (records -> HBM) and the fused verify + parse kernel (records never leave the CU).  Called by all MFV_T threads.
-template <int MODE, bool TILE_LIMIT = false>
+// BACK (round 6) = "catch-up": a verified candidate is also compared over the (up to MFV_CATCH = 3) bytes IN FRONT of the position and of the candidate (the 16-byte windows of
+// both start three bytes early, as MF_HALF's do: no extra memory request -- a second, 4-byte read per candidate cost brotli quality 6 on web-text 14.5 -> 12.1 GB/s, run s2), and the positions
+// in front that the match covers as well take it over, lengthened, if that beats their own record by gain -- ZSTD_compressBlock_doubleFast's and the lazy matchers' catch-up
+// loop (`while (ip > anchor && match > lowest && ip[-1] == match[-1]) { ip--; match--; mLength++; }`, C/zstd/zstd_double_fast.c:255-262, zstd_lazy.c:1640-1646), which here has
+// to be a property of the RECORDS because the parse does not exist yet: the most recent earlier position with the same 5 / 8 bytes is often a short match that the greedy parse
+// takes one or two bytes in front of a long one (and the one-step lazy look-ahead only sees one position on).  tools/zstd_parse_lab.c (32 MiB each, estimate, first pass + lazy 1):
+// text -4.0 %, web-text -4.6 %, real sources -6.1 %, shared objects -1.3 %, lz-7zip -2.0 %, the Silesia stand-in -1.4 %.  How many bytes in front agree travels in two free bits of the
+// record while it is in LDS (bit 7: lengths end at 64; bit 31: distances have 23 bits) and is taken out again before the records are read by anything else.
+#define MFV_CATCH 3u
+#define MFV_XBITS 0x80000080u
+template <int MODE, bool TILE_LIMIT = false, bool BACK = false>
 __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks,
                     const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, const uint32_t* recIn,
                     uint32_t* sW, uint32_t* sRec, uint8_t* sExt, uint32_t* sStart, uint32_t* sLocal, uint32_t* sWaveTot,
@@ -582,6 +592,7 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
 {
     constexpr bool FAR = MODE == MF_FAR || MODE == MF_FAR2 || MODE == MF_SHORT;      // a merging pass
     constexpr bool HALF = MODE == MF_HALF;                        // even positions only; matches are extended one byte backwards
+    constexpr bool SHIFT = HALF || BACK;                          // the 16-byte compare windows start MFV_BACK bytes in front of the position and of the candidate (mfv_len13)
     constexpr uint32_t MINLEN = MODE == MF_SHORT ? 3u : GC_MIN_MATCH;
     constexpr uint32_t LONGLEN = MODE == MF_SHORT ? 4u : ((MODE == MF_FAR || MODE == MF_FAR2) ? 16u : 8u);   // a verified long candidate has this many bytes
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
@@ -700,26 +711,27 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
             if (cS[k] == cL) cS[k] = 0;
             bestC[k] = (can && cL) ? cL : 0u;
             bestExt[k] = 0;
-            if (HALF) { if (bestC[k] <= MFV_BACK) bestC[k] = 0; if (cS[k] <= MFV_BACK) cS[k] = 0; }      // (a candidate at the very frame start has no bytes in front of it)
-            if (bestC[k]) cw[k] = ld16c(bestC[k] - 1u - (HALF ? MFV_BACK : 0u));
+            if (SHIFT) { if (bestC[k] <= MFV_BACK) bestC[k] = 0; if (cS[k] <= MFV_BACK) cS[k] = 0; }      // (a candidate at the very frame start has no bytes in front of it)
+            if (bestC[k]) cw[k] = ld16c(bestC[k] - 1u - (SHIFT ? MFV_BACK : 0u));
         }
 #pragma unroll
         for (uint32_t k = 0; k < MFV_B; k++) {
-            if (HALF) { uint32_t x = 0; bestLen[k] = bestC[k] ? mfv_len13(mf_lds_ld16(sW, q[k] + MF_STAGE_PAD - MFV_BACK), cw[k], maxLen[k], x) : 0u; bestExt[k] = x; }
+            if (SHIFT) { uint32_t x = 0; bestLen[k] = bestC[k] ? mfv_len13(mf_lds_ld16(sW, q[k] + MF_STAGE_PAD - MFV_BACK), cw[k], maxLen[k], x, MINLEN) : 0u; bestExt[k] = (BACK && x > q[k]) ? q[k] : x; }
             else bestLen[k] = bestC[k] ? mfv_len16(mf_lds_ld16(sW, q[k] + MF_STAGE_PAD), cw[k], maxLen[k], MINLEN) : 0u;
-            if (bestLen[k] >= LONGLEN || maxLen[k] == 0u) cS[k] = 0;  // verified long candidate: the short one is not needed
-            if (cS[k]) cw[k] = ld16c(cS[k] - 1u - (HALF ? MFV_BACK : 0u));
+            if (bestLen[k] >= (SHIFT && LONGLEN > 13u ? 13u : LONGLEN) || maxLen[k] == 0u) cS[k] = 0;  // verified long candidate: the short one is not needed (shifted windows hold 13 bytes from the position on)
+            if (cS[k]) cw[k] = ld16c(cS[k] - 1u - (SHIFT ? MFV_BACK : 0u));
         }
 #pragma unroll
         for (uint32_t k = 0; k < MFV_B; k++) {
             const uint32_t pw = wTile + q[k];
             if (cS[k]) {
                 uint32_t x = 0;
-                const uint32_t len = HALF ? mfv_len13(mf_lds_ld16(sW, q[k] + MF_STAGE_PAD - MFV_BACK), cw[k], maxLen[k], x) : mfv_len16(mf_lds_ld16(sW, q[k] + MF_STAGE_PAD), cw[k], maxLen[k], MINLEN);
+                const uint32_t len = SHIFT ? mfv_len13(mf_lds_ld16(sW, q[k] + MF_STAGE_PAD - MFV_BACK), cw[k], maxLen[k], x, MINLEN) : mfv_len16(mf_lds_ld16(sW, q[k] + MF_STAGE_PAD), cw[k], maxLen[k], MINLEN);
+                if (BACK && x > q[k]) x = q[k];                   // (never beyond the tile's first position: the positions in front belong to another workgroup)
                 if (len && (bestLen[k] == 0u || lz_gain(len, pw - (cS[k] - 1u)) > lz_gain(bestLen[k], pw - (bestC[k] - 1u)))) { bestLen[k] = len; bestC[k] = cS[k]; bestExt[k] = x; }
             }
             uint32_t len = bestLen[k];
-            while ((HALF ? (len & 15u) == 13u : (len >= 16u && (len & 15u) == 0u)) && len < maxLen[k]) {      // saturated: extend 16 bytes per round (own side from LDS)
+            while ((SHIFT ? (len & 15u) == 13u : (len >= 16u && (len & 15u) == 0u)) && len < maxLen[k]) {      // saturated: extend 16 bytes per round (own side from LDS)
                 const uint32_t more = lz_cmp16(mf_lds_ld16(sW, q[k] + MF_STAGE_PAD + len), ld16c((uint64_t)(bestC[k] - 1u) + len));
                 len += more;
                 if (len > maxLen[k]) len = maxLen[k];
@@ -729,7 +741,8 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
                 const uint32_t nr = len ? (((pw - (bestC[k] - 1u)) << 8) | len) : 0u;
                 if (MODE == MF_BASE && len == GC_MATCH_CAP) sWaveTot[1] = 0xFFFFFFFFu;      // "the tile has a capped record": the word held a count (dead since the run offsets were made), never this value
                 if (HALF && nr != 0u) sExt[q[k]] = (uint8_t)bestExt[k];
-                if (!FAR) sRec[q[k]] = nr;
+                const uint32_t xb = (BACK && nr != 0u) ? (((bestExt[k] & 1u) << 7) | ((bestExt[k] & 2u) << 30)) : 0u;      // how far the match reaches in front of the position (taken out again below)
+                if (!FAR) sRec[q[k]] = nr | xb;
                 else if (nr) {
                     const uint32_t old = sRec[q[k]];
                     bool take = old == 0u || lz_gain(len, nr >> 8) > lz_gain(old & 0xFFu, old >> 8);
@@ -747,7 +760,7 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
                         take = eN > eO || (eN == eO && (nr >> 8) < (old >> 8));
                     }
                     if (take) {                                   // the continuation below looks again at this row and at the one 64 behind it (nowhere else: what has not changed was decided in the pass before)
-                        sRec[q[k]] = nr;
+                        sRec[q[k]] = nr | xb;
                         atomicOr(&sDirty[q[k] >> 5], 1u << (q[k] & 31u)); atomicOr(&sDirty[(q[k] + GC_MATCH_CAP) >> 5], 1u << ((q[k] + GC_MATCH_CAP) & 31u));
                     }
                 }
@@ -769,6 +782,48 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
                 if (y < T.len && sExt[y] >= j) { const uint32_t r = sRec[y], l = (r & 0xFFu) + j; nr = (r & ~0xFFu) | (l < GC_MATCH_CAP ? l : GC_MATCH_CAP); }   // (the nearest one is visited last and wins)
             }
             if (nr != 0u) sRec[x] = nr;
+        }
+    }
+    if (BACK) {
+        // catch-up: position x takes over the record of x + j (j <= 3) lengthened by j where that record reaches back to x and beats x's own by gain.  Every decision is taken
+        // from the records as the passes above left them: a wave walks its share of the tile upwards, 64 positions per step (what a step looks at beyond its own 64 positions the
+        // wave has not rewritten yet; the three records beyond the share's end are read before anybody writes), so the result does not depend on the order in which the waves run.
+        // The two marker bits go.
+        __syncthreads();
+        constexpr uint32_t NSUBC = MFV_T / 64u;
+        const uint32_t shareLen = GC_MF_TILE / NSUBC, cBeg = wave * shareLen, cEnd = cBeg + shareLen;
+        uint32_t beyond[MFV_CATCH];
+#pragma unroll
+        for (uint32_t j = 0; j < MFV_CATCH; j++) beyond[j] = cEnd + j < T.len ? sRec[cEnd + j] : 0u;
+        __syncthreads();
+        for (uint32_t x0 = cBeg; x0 < cEnd && x0 < T.len; x0 += 64u) {
+            const uint32_t x = x0 + lane;
+            const uint32_t old = x < T.len ? sRec[x] : 0u;
+            const uint32_t own = old & ~MFV_XBITS;
+            uint32_t best = own;
+            int bg = (own & 0xFFu) ? lz_gain(own & 0xFFu, own >> 8) : -100000;
+#pragma unroll
+            for (uint32_t j = 1; j <= MFV_CATCH; j++) {
+                const uint32_t y = x + j;
+                uint32_t ry = (y < cEnd && y < T.len) ? sRec[y] : 0u;
+                if (y >= cEnd) ry = y - cEnd == 0u ? beyond[0] : (y - cEnd == 1u ? beyond[1] : beyond[2]);
+                const uint32_t e = ((ry >> 7) & 1u) | ((ry >> 30) & 2u);
+                if (e >= j) {
+                    uint32_t l = (ry & 0x7Fu) + j; if (l > GC_MATCH_CAP) l = GC_MATCH_CAP;
+                    const uint32_t off = (ry & 0x7FFFFFFFu) >> 8;
+                    const int g = lz_gain(l, off);
+                    if (g > bg) { bg = g; best = (off << 8) | l; }
+                }
+            }
+            gc_wave_sync();                                       // (every lane has read what it needs of this step's records)
+            if (x < T.len && old != best) {
+                sRec[x] = best;
+                if (own != best) {                                // a record of another match, not just the markers taken out
+                    if (FAR) { atomicOr(&sDirty[x >> 5], 1u << (x & 31u)); atomicOr(&sDirty[(x + GC_MATCH_CAP) >> 5], 1u << ((x + GC_MATCH_CAP) & 31u)); }
+                    if (MODE == MF_BASE && (best & 0xFFu) == GC_MATCH_CAP) sWaveTot[1] = 0xFFFFFFFFu;
+                }
+            }
+            gc_wave_sync();
         }
     }
     __syncthreads();
@@ -913,7 +968,7 @@ __device__ __forceinline__ void mf_verify_body(const uint8_t* __restrict__ src, 
     if (tile >= nTiles) return;
     const MfTile T = mf_tile(tile, frameBlocks, srcSize);
     if (T.len == 0u || !T.own) return;                            // (overlapping frames: the tiles a frame shares with the one in front have their records from that one)
-    mf_verify_tile<MODE>(T, src, srcSize, frameBlocks, offs, ent, recIn, sW, sRec, sExt, sStart, sLocal, sWaveTot, nullptr, nullptr, changedIn);
+    mf_verify_tile<MODE, false, MODE != MF_HALF>(T, src, srcSize, frameBlocks, offs, ent, recIn, sW, sRec, sExt, sStart, sLocal, sWaveTot, nullptr, nullptr, changedIn);
     // records out: 16 bytes per lane, full lines
     GcU4* R4 = (GcU4*)(rec + T.tileStart);
     const GcU4* S4 = (const GcU4*)sRec;
