@@ -104,7 +104,7 @@ extern "C" __global__ void gc_lzma2_emit_kernel(const uint8_t*, uint32_t, const 
                                                 uint32_t, const uint64_t*, uint8_t*, const uint8_t*);
 
 extern "C" __global__ void gc_brotli_block_kernel(const uint8_t*, uint64_t, const GcSeqRaw*, const uint8_t*, const GcBlockMeta*, uint64_t*, uint32_t*,
-                                                  uint32_t, uint32_t, uint32_t, uint32_t*, GcBrotliBlockInfo*);
+                                                  uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, GcBrotliBlockInfo*);
 extern "C" __global__ void gc_brotli_plan_kernel(const GcBrotliBlockInfo*, uint32_t, uint32_t, uint64_t, GcBrotliPlan*, uint64_t*);
 extern "C" __global__ void gc_brotli_emit_kernel(const uint8_t*, uint64_t, const uint8_t*, const GcBrotliBlockInfo*, const GcBrotliPlan*, uint32_t,
                                                  uint32_t, uint32_t, const uint64_t*, uint8_t*);
@@ -1108,8 +1108,10 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
                                                                // 8 MiB 1.1262 / 1.1095 / 1.0969 / 1.0919 / 1.0888 (2 MiB: 1.0925 / 1.0788 / 1.0771), sources 8 MiB 1.1594 / 1.1439 / 1.1392; a pass carries a
                                                                // distance three commands further along a run of records and costs 0.86 ms per 500 MB on the device (B1 5.4 ms without)
     gc_env_u32("GC_BR_REPSUB", 0u, 64u, &brRepSub);                                             // test hook
+    uint32_t brCtx = level >= 5 ? 1u : 0u;                     // literal context modelling from quality 5 (the reference: MIN_QUALITY_FOR_CONTEXT_MODELING, C/brotli/enc/quality.h): B1 chooses one tree or thirteen per meta-block
+    gc_env_u32("GC_BR_CTX", 0u, 1u, &brCtx);                                                    // test hook
     GC_LAUNCH(gc_brotli_block_kernel, nBlocks, 256, c->stream, src, (uint64_t)n, (const GcSeqRaw*)c->seqRaw, (const uint8_t*)c->lit,
-              (const GcBlockMeta*)c->meta, c->seqPacked, c->seqOff, bpc, c->optBrotliPlain, brRepSub, (uint32_t*)c->brStage, c->brInfo);
+              (const GcBlockMeta*)c->meta, c->seqPacked, c->seqOff, bpc, c->optBrotliPlain, brRepSub, brCtx, (uint32_t*)c->brStage, c->brInfo);
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     GC_LAUNCH(gc_brotli_plan_kernel, 1, 1024, c->stream, (const GcBrotliBlockInfo*)c->brInfo, nBlocks, bpc, (uint64_t)dstCap, c->brPlan, c->result);
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));

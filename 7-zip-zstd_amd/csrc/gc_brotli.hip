@@ -31,6 +31,10 @@
 #include "gc_device.h"
 #include "gc_fse.h"
 #include "gc_brotli.h"
+#ifdef HIPEMU
+#include <stdio.h>
+#include <stdlib.h>
+#endif
 #include "gc_lz_parse.h"       // pz_log2_q8: integer logarithm (the same on the device and under the emulator)
 
 #define BR_T 256u
@@ -223,6 +227,13 @@ __device__ __forceinline__ void bw_put(BrBW& w, uint32_t v, uint32_t nb)
     while (w.nbits >= 8u) { w.out[w.bytes++] = (uint8_t)w.acc; w.acc >>= 8; w.nbits -= 8u; }
 }
 __device__ __forceinline__ uint32_t bw_bits(const BrBW& w) { return w.bytes * 8u + w.nbits; }
+// VarLenUint8 (NBLTYPES - 1, NTREES - 1: RFC 7932 section 9.2; StoreVarLenUint8, C/brotli/br_brotli_bit_stream.c:96-110)
+__device__ __forceinline__ void bw_varlen8(BrBW& w, uint32_t v)
+{
+    if (v == 0u) { bw_put(w, 0u, 1); return; }
+    const uint32_t nb = gc_hibit32(v);
+    bw_put(w, 1u, 1); bw_put(w, nb, 3); bw_put(w, v - (1u << nb), nb);
+}
 
 // prefix code description (single lane).  alphaBits = ceil(log2(alphabet size)).  scratch: n + 32 uint16 entries.
 __device__ void br_store_code(BrBW& w, const uint8_t* depth, uint32_t n, uint32_t alphaBits, uint32_t nsym, uint16_t* seq)
@@ -311,7 +322,7 @@ __device__ __forceinline__ uint32_t br_excl_scan(uint32_t v, uint32_t* sWave, ui
 // ---- literal context modelling: CONTEXT_UTF8 (RFC 7932 section 7.1; the reference holds the same function as a table, C/brotli/br_context.c:79-120).
 // context id = lut0(last byte) | lut1(second last byte): for two ASCII bytes 4 * class(last) + class2(second last)
 #define BR_NT 13u                      // literal trees of the static map (BROTLI_MAX_STATIC_CONTEXTS, C/brotli/enc/quality.h)
-__device__ __forceinline__ uint32_t br_utf8_lut0(uint32_t b)
+__host__ __device__ __forceinline__ uint32_t br_utf8_lut0(uint32_t b)
 {
     if (b >= 192u) return 2u + (b & 1u);                                  // UTF-8 lead byte
     if (b >= 128u) return b & 1u;                                         // continuation byte
@@ -334,9 +345,9 @@ __device__ __forceinline__ uint32_t br_utf8_lut0(uint32_t b)
     else if (lo) k = vowel ? 14u : 15u;
     return 4u * k;
 }
-__device__ __forceinline__ uint32_t br_utf8_lut1(uint32_t b)
+__host__ __device__ __forceinline__ uint32_t br_utf8_lut1(uint32_t b)
 {
-    if (b >= 208u) return 2u;
+    if (b >= 224u) return 2u;                                             // (lead bytes of three- and four-byte sequences; the table of RFC 7932 section 7.1 has 0 for 128 .. 223)
     if (b >= 128u) return 0u;
     if (b <= 32u || b == 127u) return 0u;                                 // control, space
     if ((b >= '0' && b <= '9') || (b >= 'A' && b <= 'Z')) return 2u;
@@ -345,7 +356,7 @@ __device__ __forceinline__ uint32_t br_utf8_lut1(uint32_t b)
 }
 // context id (0..63) -> literal tree (0..12): what follows a line feed, a space, an opening / closing bracket, a digit, an upper- / lower-case letter ... each gets a code of its
 // own (the grouping of kStaticContextMapComplexUTF8, C/brotli/br_encode.c:330-347, written as the rule it encodes)
-__device__ __forceinline__ uint32_t br_static_tree(uint32_t ctx)
+__host__ __device__ __forceinline__ uint32_t br_static_tree(uint32_t ctx)
 {
     const uint32_t c1 = ctx >> 2, c2 = ctx & 3u;
     switch (c1) {
@@ -370,9 +381,6 @@ extern "C" void gc_brotli_context_tables(uint8_t lut[512], uint8_t map[64])     
     for (uint32_t b = 0; b < 256u; b++) { lut[b] = (uint8_t)br_utf8_lut0(b); lut[256u + b] = (uint8_t)br_utf8_lut1(b); }
     for (uint32_t c = 0; c < 64u; c++) map[c] = (uint8_t)br_static_tree(c);
 }
-// VarLenUint8 + 1 (NBLTYPES, NTREES: RFC 7932 section 9.2): v = value - 1
-__device__ __forceinline__ void bw_put(struct BrBW& w, uint32_t v, uint32_t nb);
-
 extern "C" __global__ void __launch_bounds__(BR_T)
 gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const GcSeqRaw* __restrict__ seqRaw,
                        const uint8_t* __restrict__ lit, const GcBlockMeta* __restrict__ meta,
@@ -380,16 +388,21 @@ gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
                        uint32_t* __restrict__ seqLitStart /* scratch: GC_MAX_SEQ_PER_BLOCK per block */,
                        uint32_t blocksPerChunk /* 0xFFFFFFFF: ONE plain stream (no brotli-mt chunks) */, uint32_t plainFlags /* plain stream: bit 1 = this call is
                        not its first piece (no stream header), bit 2 = not its last (no closing meta-block) */, uint32_t repSub /* passes of the last-distance substitution */,
+                       uint32_t ctxModel /* 1: literal context modelling may be chosen per meta-block (quality >= 5) */,
                        uint32_t* __restrict__ stage /* zeroed, GC_BR_STAGE_STRIDE bytes per block */, GcBrotliBlockInfo* __restrict__ info)
 {
-    __shared__ uint32_t hLit[256], hCmd[704], hDist[64];
-    __shared__ uint8_t  dLit[256], dCmd[704], dDist[64];
-    __shared__ uint16_t cLit[256], cCmd[704], cDist[64];
+    __shared__ uint32_t hLit[BR_NT][256], hCmd[704], hDist[64], hMap[16];      // literal histograms per tree of the static context map (one tree: row 0)
+    __shared__ uint8_t  dLit[BR_NT][256], dCmd[704], dDist[64], dMap[16];
+    __shared__ uint16_t cLit[BR_NT][256], cCmd[704], cDist[64], cMap[16];
+    __shared__ uint8_t  sLut[512], sMap[64];                               // CONTEXT_UTF8 lookup (last byte, second last byte); context id -> literal tree
+    __shared__ uint32_t sNs[BR_NT], sOne[BR_NT];                           // per literal tree: symbols in use, the lone symbol
+    __shared__ unsigned long long sAcc[BR_NT + 1u];                        // sum of h log2 h per tree / of the pooled histogram (units of 1/256 bit)
+    __shared__ uint32_t sTot[BR_NT], sUsed[BR_NT + 1u];
     __shared__ BrHufScratch S;
     __shared__ uint16_t sSeq[704 + 32];
-    __shared__ uint8_t  sHdr[1024];
+    __shared__ uint8_t  sHdr[4096];
     __shared__ uint32_t sWave[8];
-    __shared__ uint32_t sMisc[8];
+    __shared__ uint32_t sMisc[12];
     __shared__ uint32_t sBits[BR_WIN_WORDS];                               // bit window of one tile of commands (see below)
 
     const uint32_t t = threadIdx.x, b = blockIdx.x;
@@ -405,9 +418,17 @@ gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
     const bool firstInChunk = plain ? (b == 0u && !(plainFlags & 2u)) : (b % blocksPerChunk) == 0u;
     const bool lastInChunk = plain ? (blockBase + blockLen >= srcSize && !(plainFlags & 4u)) : (((b + 1u) % blocksPerChunk) == 0u || blockBase + blockLen >= srcSize);
 
-    for (uint32_t i = t; i < 256u; i += BR_T) hLit[i] = 0;
+    for (uint32_t i = t; i < BR_NT * 256u; i += BR_T) (&hLit[0][0])[i] = 0;
     for (uint32_t i = t; i < 704u; i += BR_T) hCmd[i] = 0;
     for (uint32_t i = t; i < 64u; i += BR_T) hDist[i] = 0;
+    // The decoder's context of a literal is made of the two bytes in front of it IN ITS STREAM: none in front of a brotli-mt chunk's first byte.  A later piece of a plain
+    // stream does not see the bytes in front of itself here: its first meta-block keeps one tree.
+    const uint64_t chunkStart = plain ? 0ull : blockBase - (uint64_t)(b % blocksPerChunk) * GC_ZSTD_BLOCK_MAX;
+    const bool ctxOk = ctxModel != 0u && !(plain && (plainFlags & 2u) != 0u && b == 0u);
+    for (uint32_t i = t; i < 256u; i += BR_T) { sLut[i] = (uint8_t)br_utf8_lut0(i); sLut[256u + i] = (uint8_t)br_utf8_lut1(i); }
+    if (t < 64u) sMap[t] = ctxOk ? (uint8_t)br_static_tree(t) : (uint8_t)0;
+    if (t < 16u) hMap[t] = 0;
+    if (t <= BR_NT) { sAcc[t] = 0ull; sUsed[t] = 0u; if (t < BR_NT) sTot[t] = 0u; }
     __syncthreads();
 
     // ---- merge chains of capped records (same offset, no literals in between) into commands: P[j] = ll | ml<<18 | off<<36,
@@ -508,11 +529,54 @@ gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
     }
 
     // ---- histograms
-    for (uint32_t i = t * 4u; i < nLit; i += BR_T * 4u) {
-        if (i + 4u <= nLit) {
-            const uint32_t v = *(const uint32_t*)(L + i);
-            atomicAdd(&hLit[v & 0xFFu], 1u); atomicAdd(&hLit[(v >> 8) & 0xFFu], 1u); atomicAdd(&hLit[(v >> 16) & 0xFFu], 1u); atomicAdd(&hLit[v >> 24], 1u);
-        } else for (uint32_t k = i; k < nLit; k++) atomicAdd(&hLit[L[k]], 1u);
+    if (!ctxOk) {
+        for (uint32_t i = t * 4u; i < nLit; i += BR_T * 4u) {
+            if (i + 4u <= nLit) {
+                const uint32_t v = *(const uint32_t*)(L + i);
+                atomicAdd(&hLit[0][v & 0xFFu], 1u); atomicAdd(&hLit[0][(v >> 8) & 0xFFu], 1u); atomicAdd(&hLit[0][(v >> 16) & 0xFFu], 1u); atomicAdd(&hLit[0][v >> 24], 1u);
+            } else for (uint32_t k = i; k < nLit; k++) atomicAdd(&hLit[0][L[k]], 1u);
+        }
+    } else {
+        // literal histograms per tree of the static map.  Where a literal stands in the INPUT: a command's first literal at block start + its literal rank + the copy lengths in
+        // front of it (one scan per tile of commands, as the substitution above); its context: the two input bytes in front of it
+        uint32_t carryM = 0;
+        for (uint32_t tb = 0; tb < nCmd; tb += BR_T) {
+            const uint32_t j = tb + t;
+            uint32_t ll = 0, ml = 0, ls = 0;
+            if (j < nCmd) { const uint64_t pk = P[j]; ll = (uint32_t)(pk & 0x3FFFFu); ml = (uint32_t)((pk >> 18) & 0x3FFFFu); ls = LS[j]; }
+            uint32_t totM;
+            const uint64_t cs = blockBase + ls + carryM + br_excl_scan(ml, sWave, &totM);
+            const bool isLong = ll > BR_LONG;
+            if (ll != 0u && !isLong) {
+                uint32_t p1 = cs > chunkStart ? src[cs - 1u] : 0u, p2 = cs > chunkStart + 1u ? src[cs - 2u] : 0u;
+                for (uint32_t i = 0; i < ll; i++) { const uint32_t by = src[cs + i];
+#ifdef HIPEMU
+                    if (by != L[ls + i]) { fprintf(stderr, "B1: literal %u of command %u: input %u, literal stream %u\n", i, j, by, (uint32_t)L[ls + i]); abort(); }
+#endif
+                    atomicAdd(&hLit[sMap[sLut[p1] | sLut[256u + p2]]][by], 1u); p2 = p1; p1 = by; }
+            }
+            for (uint32_t w0 = 0; w0 < BR_T / 64u; w0++) {         // long runs: the whole workgroup, one after the other
+                __syncthreads();
+                if ((t >> 6) == w0) { const uint64_t m = __ballot(isLong); if ((t & 63u) == 0u) { sMisc[2] = (uint32_t)m; sMisc[3] = (uint32_t)(m >> 32); } }
+                __syncthreads();
+                uint64_t mask = (uint64_t)sMisc[2] | ((uint64_t)sMisc[3] << 32);
+                while (mask) {
+                    const uint32_t ln = gc_ctz64(mask); mask &= mask - 1ull;
+                    const uint32_t jj = tb + w0 * 64u + ln;
+                    if (j == jj) { sMisc[4] = (uint32_t)cs; sMisc[5] = (uint32_t)(cs >> 32); }
+                    __syncthreads();
+                    const uint64_t pos = (uint64_t)sMisc[4] | ((uint64_t)sMisc[5] << 32);
+                    const uint32_t rl = (uint32_t)(P[jj] & 0x3FFFFu);
+                    for (uint32_t i = t; i < rl; i += BR_T) {
+                        const uint64_t q = pos + i;
+                        const uint32_t p1 = q > chunkStart ? src[q - 1u] : 0u, p2 = q > chunkStart + 1u ? src[q - 2u] : 0u;
+                        atomicAdd(&hLit[sMap[sLut[p1] | sLut[256u + p2]]][src[q]], 1u);
+                    }
+                    __syncthreads();
+                }
+            }
+            carryM += totM;
+        }
     }
     for (uint32_t j = t; j < nCmd; j += BR_T) {
         const uint64_t pk = P[j];
@@ -524,10 +588,57 @@ gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
     }
     __syncthreads();
 
+    // ---- one literal tree or thirteen?  The cost of the literals under each choice from the histograms themselves: sum over trees of T log2 T - sum h log2 h (integer
+    //      logarithm: the same choice on the device and under the emulator), plus what the tree descriptions and the context map cost (about 7 bits per symbol in use,
+    //      48 per tree, 360 for the map).  The reference decides from 5-bit histograms of a sample and wants 0.2 bits per literal (br_encode.c:377-399); here the estimate is exact
+    //      enough to take whatever is cheaper.
+    uint32_t nTrees = 1u;
+    if (ctxOk) {
+        uint32_t H = 0;
+        for (uint32_t tr = 0; tr < BR_NT; tr++) {
+            const uint32_t h = hLit[tr][t];                        // (BR_T = 256: thread t = literal value t)
+            if (h) { atomicAdd(&sAcc[tr], (unsigned long long)h * pz_log2_q8(h)); atomicAdd(&sTot[tr], h); atomicAdd(&sUsed[tr], 1u); }
+            H += h;
+        }
+        if (H) { atomicAdd(&sAcc[BR_NT], (unsigned long long)H * pz_log2_q8(H)); atomicAdd(&sUsed[BR_NT], 1u); }
+        __syncthreads();
+        if (t == 0) {
+            unsigned long long c13 = 0, T = 0, d13 = 0;
+            for (uint32_t tr = 0; tr < BR_NT; tr++) {
+                const uint32_t tt = sTot[tr];
+                if (tt) c13 += (unsigned long long)tt * pz_log2_q8(tt) - sAcc[tr];
+                T += tt;
+                d13 += sUsed[tr] ? 48u + 7u * sUsed[tr] : 8u;
+            }
+            const unsigned long long c1 = T ? T * pz_log2_q8((uint32_t)T) - sAcc[BR_NT] : 0ull, d1 = 48u + 7u * sUsed[BR_NT];
+            sMisc[6] = (T >= 512u && c13 + ((d13 + 360u) << 8) + (c1 >> 6) < c1 + (d1 << 8)) ? 1u : 0u;      // (a margin of 1.5 %: thirteen small codes lose more to whole-bit lengths than one large code)
+        }
+        __syncthreads();
+        if (sMisc[6]) nTrees = BR_NT;
+        else {                                                     // one tree: pool the histograms, every context id maps to tree 0
+            uint32_t H1 = 0;
+            for (uint32_t tr = 0; tr < BR_NT; tr++) H1 += hLit[tr][t];
+            hLit[0][t] = H1;
+            if (t < 64u) sMap[t] = 0;
+        }
+        __syncthreads();
+    }
     // ---- prefix codes
     bool ok = true;
-    const uint32_t nsLit = br_build_code(hLit, 256u, 15u, dLit, cLit, S, &ok);
-    uint32_t oneLit = 0;  if (nsLit == 1u) { for (uint32_t s = 0; s < 256u; s++) if (hLit[s]) oneLit = s; }
+    for (uint32_t tr = 0; tr < nTrees; tr++) {
+        const uint32_t ns = br_build_code(hLit[tr], 256u, 15u, dLit[tr], cLit[tr], S, &ok);
+        if (t == 0) { uint32_t one = 0; if (ns == 1u) { for (uint32_t s = 0; s < 256u; s++) if (hLit[tr][s]) one = s; } sNs[tr] = ns; sOne[tr] = one; }
+    }
+    uint32_t nsMap = 0, oneMap = 0;
+    if (nTrees > 1u) {                                             // the context map's own prefix code: 64 entries over the alphabet of trees
+        if (t < 64u) atomicAdd(&hMap[sMap[t]], 1u);
+        __syncthreads();
+        nsMap = br_build_code(hMap, BR_NT, 15u, dMap, cMap, S, &ok);
+        if (nsMap == 1u) { for (uint32_t s = 0; s < BR_NT; s++) if (hMap[s]) oneMap = s; }
+    }
+#ifdef HIPEMU
+    if (t == 0 && getenv("GC_BR_DEBUG")) { fprintf(stderr, "B1 block %u: nCmd %u nLit %u trees %u ok %d ns:", b, nCmd, nLit, nTrees, (int)ok); for (uint32_t tr = 0; tr < nTrees; tr++) fprintf(stderr, " %u", sNs[tr]); fprintf(stderr, "\n"); }
+#endif
     const uint32_t nsCmd = br_build_code(hCmd, 704u, 15u, dCmd, cCmd, S, &ok);
     uint32_t oneCmd = 0;  if (nsCmd == 1u) { for (uint32_t s = 0; s < 704u; s++) if (hCmd[s]) oneCmd = s; }
     const uint32_t nsDist = br_build_code(hDist, 64u, 15u, dDist, cDist, S, &ok);
@@ -545,9 +656,16 @@ gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
         sMisc[1] = bw_bits(w);                                             // bits before ISUNCOMPRESSED + 1: reused by the stored fallback
         bw_put(w, 0u, 1); bw_put(w, 0u, 1); bw_put(w, 0u, 1);              // NBLTYPESL = NBLTYPESI = NBLTYPESD = 1
         bw_put(w, 0u, 2); bw_put(w, 0u, 4);                                // NPOSTFIX = 0, NDIRECT = 0
-        bw_put(w, 0u, 2);                                                  // context mode of the single literal block type (LSB6; unused with one tree)
-        bw_put(w, 0u, 1); bw_put(w, 0u, 1);                                // NTREESL = 1, NTREESD = 1
-        sSeq[0] = (uint16_t)oneLit;  br_store_code(w, dLit, 256u, 8u, nsLit, sSeq);
+        bw_put(w, nTrees > 1u ? 2u : 0u, 2);                               // context mode of the single literal block type: 2 = UTF8 (0 = LSB6: unused with one tree)
+        bw_varlen8(w, nTrees - 1u);                                        // NTREESL
+        if (nTrees > 1u) {                                                 // literal context map (RFC 7932 section 7.3): no run-length codes, the 64 entries, no inverse move-to-front
+            bw_put(w, 0u, 1);                                              // RLEMAX = 0
+            sSeq[0] = (uint16_t)oneMap; br_store_code(w, dMap, BR_NT, 4u, nsMap, sSeq);
+            for (uint32_t c = 0; c < 64u; c++) bw_put(w, cMap[sMap[c]], dMap[sMap[c]]);
+            bw_put(w, 0u, 1);                                              // IMTF = 0
+        }
+        bw_put(w, 0u, 1);                                                  // NTREESD = 1
+        for (uint32_t tr = 0; tr < nTrees; tr++) { sSeq[0] = (uint16_t)sOne[tr]; br_store_code(w, dLit[tr], 256u, 8u, sNs[tr], sSeq); }
         sSeq[0] = (uint16_t)oneCmd;  br_store_code(w, dCmd, 704u, 10u, nsCmd, sSeq);
         sSeq[0] = (uint16_t)oneDist; br_store_code(w, dDist, 64u, 6u, nsDist, sSeq);
         const uint32_t hb = bw_bits(w);
@@ -556,6 +674,9 @@ gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
     }
     __syncthreads();
     const uint32_t hdrBits = sMisc[0];
+#ifdef HIPEMU
+    if (t == 0 && getenv("GC_BR_DEBUG")) fprintf(stderr, "B1 block %u: header %u bits\n", b, hdrBits);
+#endif
     for (uint32_t i = t; i < (hdrBits + 31u) / 32u; i += BR_T) {
         uint32_t v = 0; for (uint32_t k = 0; k < 4u; k++) { const uint32_t bi = i * 4u + k; if (bi * 8u < hdrBits) v |= (uint32_t)sHdr[bi] << (8u * k); }
         if (v) atomicOr(&out[i], v);
@@ -563,6 +684,8 @@ gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
 
     // ---- commands: bit counts -> offsets -> bits.  A command's literals are walked by its own lane unless the run is long.
     uint64_t bitBase = hdrBits;                                            // uniform running bit offset
+    uint32_t carryC = 0;                                                   // copy lengths of the commands in front of the tile (several trees: where a command's literals stand in the input)
+    const bool ctx = nTrees > 1u;                                          // uniform
     for (uint32_t tb = 0; tb < nCmd; tb += BR_T) {
         const uint32_t j = tb + t;
         uint32_t ll = 0, ml = 0, off = 0, ls = 0; bool valid = j < nCmd, useLast = false;
@@ -577,7 +700,14 @@ gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
         const uint32_t tailBits = (valid && c.hasDist) ? dDist[c.dsym] + c.dExtraBits : 0u;
         uint32_t litBits = 0;
         const bool isLong = valid && ll > BR_LONG;
-        if (valid && !isLong) for (uint32_t i = 0; i < ll; i++) litBits += dLit[L[ls + i]];
+        uint64_t cs = 0;                                                   // absolute position of the command's first literal
+        if (ctx) { uint32_t totM; cs = blockBase + ls + carryC + br_excl_scan(valid ? ml : 0u, sWave, &totM); carryC += totM; }
+        uint32_t c1 = 0, c2 = 0;                                           // the two bytes in front of it
+        if (ctx && valid && ll != 0u) { c1 = cs > chunkStart ? src[cs - 1u] : 0u; c2 = cs > chunkStart + 1u ? src[cs - 2u] : 0u; }
+        if (valid && !isLong) {
+            if (!ctx) for (uint32_t i = 0; i < ll; i++) litBits += dLit[0][L[ls + i]];
+            else { uint32_t p1 = c1, p2 = c2; for (uint32_t i = 0; i < ll; i++) { const uint32_t by = L[ls + i]; litBits += dLit[sMap[sLut[p1] | sLut[256u + p2]]][by]; p2 = p1; p1 = by; } }
+        }
         // long runs of this tile: summed by the whole workgroup, one after the other
         for (uint32_t w0 = 0; w0 < BR_T / 64u; w0++) {
             __syncthreads();
@@ -589,7 +719,17 @@ gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
                 const uint32_t jj = tb + w0 * 64u + ln;
                 const uint32_t rl = (uint32_t)(P[jj] & 0x3FFFFu), rs = LS[jj];
                 uint32_t part = 0;
-                for (uint32_t i = t; i < rl; i += BR_T) part += dLit[L[rs + i]];
+                if (!ctx) for (uint32_t i = t; i < rl; i += BR_T) part += dLit[0][L[rs + i]];
+                else {
+                    if (j == jj) { sMisc[8] = (uint32_t)cs; sMisc[9] = (uint32_t)(cs >> 32); }
+                    __syncthreads();
+                    const uint64_t pos0 = (uint64_t)sMisc[8] | ((uint64_t)sMisc[9] << 32);
+                    for (uint32_t i = t; i < rl; i += BR_T) {
+                        const uint64_t q = pos0 + i;
+                        const uint32_t p1 = q > chunkStart ? src[q - 1u] : 0u, p2 = q > chunkStart + 1u ? src[q - 2u] : 0u;
+                        part += dLit[sMap[sLut[p1] | sLut[256u + p2]]][L[rs + i]];
+                    }
+                }
                 uint32_t tot; br_excl_scan(part, sWave, &tot);
                 if (j == jj) litBits = tot;
             }
@@ -614,11 +754,13 @@ gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
             if (useWin) {
                 const uint32_t rq = (uint32_t)(q - (word0 << 5));
                 br_or_bits_lds(sBits, rq, hv, hn);
-                { uint32_t pos = rq + headBits; for (uint32_t i = 0; i < ll; i++) { const uint32_t sy = L[ls + i]; br_or_bits_lds(sBits, pos, cLit[sy], dLit[sy]); pos += dLit[sy]; } }
+                { uint32_t pos = rq + headBits, p1 = c1, p2 = c2;
+                  for (uint32_t i = 0; i < ll; i++) { const uint32_t sy = L[ls + i], tr = ctx ? sMap[sLut[p1] | sLut[256u + p2]] : 0u; br_or_bits_lds(sBits, pos, cLit[tr][sy], dLit[tr][sy]); pos += dLit[tr][sy]; p2 = p1; p1 = sy; } }
                 if (c.hasDist) br_or_bits_lds(sBits, rq + headBits + litBits, (uint64_t)cDist[c.dsym] | ((uint64_t)c.dExtraVal << dDist[c.dsym]), dDist[c.dsym] + c.dExtraBits);
             } else {
                 br_or_bits(out, q, hv, hn);
-                if (!isLong) { uint64_t pos = q + headBits; for (uint32_t i = 0; i < ll; i++) { const uint32_t sy = L[ls + i]; br_or_bits(out, pos, cLit[sy], dLit[sy]); pos += dLit[sy]; } }
+                if (!isLong) { uint64_t pos = q + headBits; uint32_t p1 = c1, p2 = c2;
+                               for (uint32_t i = 0; i < ll; i++) { const uint32_t sy = L[ls + i], tr = ctx ? sMap[sLut[p1] | sLut[256u + p2]] : 0u; br_or_bits(out, pos, cLit[tr][sy], dLit[tr][sy]); pos += dLit[tr][sy]; p2 = p1; p1 = sy; } }
                 if (c.hasDist) br_or_bits(out, q + headBits + litBits, (uint64_t)cDist[c.dsym] | ((uint64_t)c.dExtraVal << dDist[c.dsym]), dDist[c.dsym] + c.dExtraBits);
             }
         }
@@ -638,17 +780,22 @@ gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
             while (mask) {
                 const uint32_t ln = gc_ctz64(mask); mask &= mask - 1ull;
                 const uint32_t jj = tb + w0 * 64u + ln;
-                if (j == jj) { sMisc[4] = (uint32_t)(q + headBits); sMisc[5] = (uint32_t)((q + headBits) >> 32); }
+                if (j == jj) { sMisc[4] = (uint32_t)(q + headBits); sMisc[5] = (uint32_t)((q + headBits) >> 32); sMisc[8] = (uint32_t)cs; sMisc[9] = (uint32_t)(cs >> 32); }
                 __syncthreads();
                 uint64_t pos = (uint64_t)sMisc[4] | ((uint64_t)sMisc[5] << 32);
+                const uint64_t pos0 = (uint64_t)sMisc[8] | ((uint64_t)sMisc[9] << 32);
                 const uint32_t rl = (uint32_t)(P[jj] & 0x3FFFFu), rs = LS[jj];
                 for (uint32_t i0 = 0; i0 < rl; i0 += BR_T) {
                     const uint32_t i = i0 + t;
-                    uint32_t sy = 0, nb = 0;
-                    if (i < rl) { sy = L[rs + i]; nb = dLit[sy]; }
+                    uint32_t sy = 0, nb = 0, tr = 0;
+                    if (i < rl) {
+                        sy = L[rs + i];
+                        if (ctx) { const uint64_t qq = pos0 + i; const uint32_t p1 = qq > chunkStart ? src[qq - 1u] : 0u, p2 = qq > chunkStart + 1u ? src[qq - 2u] : 0u; tr = sMap[sLut[p1] | sLut[256u + p2]]; }
+                        nb = dLit[tr][sy];
+                    }
                     uint32_t tot;
                     const uint32_t at = br_excl_scan(nb, sWave, &tot);
-                    if (i < rl) br_or_bits(out, pos + at, cLit[sy], nb);
+                    if (i < rl) br_or_bits(out, pos + at, cLit[tr][sy], nb);
                     pos += tot;
                 }
             }

@@ -133,6 +133,55 @@ def test_emu_last_distance_substitution(pkg, O, emu_lib_path, monkeypatch):
             assert sizes["1"] < sizes["0"], (name, sizes)
 
 
+def test_context_tables_equal_the_reference_tables(O, emu_lib_path):
+    """B1 computes the CONTEXT_UTF8 lookup of RFC 7932 section 7.1 from the rule it encodes; the reference holds it as a table that its library exports
+    (_kBrotliContextLookupTable, C/brotli/common/context.h:99, br_context.c:79-120).  Value for value."""
+    import ctypes
+    _need_ref(O)
+    emu = ctypes.CDLL(emu_lib_path)
+    lut = (ctypes.c_uint8 * 512)(); tree = (ctypes.c_uint8 * 64)()
+    emu.gc_brotli_context_tables(lut, tree)
+    ref = (ctypes.c_uint8 * 2048).in_dll(O.ref("brotli"), "_kBrotliContextLookupTable")
+    assert bytes(lut) == bytes(ref)[2 * 512:3 * 512]                                  # CONTEXT_UTF8 = 2
+    assert max(tree) == 12 and set(tree) == set(range(13))                           # thirteen trees, every one of them reachable
+
+
+def test_emu_literal_context_modelling(pkg, O, emu_lib_path, monkeypatch):
+    """From quality 5 B1 may code a meta-block's literals with thirteen trees chosen by the two bytes in front (CONTEXT_UTF8 + a static context map).  Every stream must decode
+    under the reference decoder -- incl. multi-byte UTF-8 (context ids 0-3), the first bytes of a brotli-mt chunk (no bytes in front), a later piece of a plain stream -- and data
+    with context structure must get smaller than with the hook GC_BR_CTX=0 (one tree)."""
+    _need_ref(O)
+    rng = np.random.default_rng(11)
+    words = ["der", "die", "und", "Größe", "Straße", "naïve", "日本語", "текст", "für", "zwölf", "Äpfel", "0123", "x = y;", "\n\t", "{", "}", "(a, b)", "E=mc²", "…"]
+    utf8 = np.frombuffer(" ".join(words[i] for i in rng.integers(0, len(words), size=60_000)).encode("utf-8"), dtype=np.uint8).copy()
+    # text whose letters depend on what stands in front of them: a word per line, capitals after full stops, digits after '=': what the static map separates
+    struct_txt = np.frombuffer("".join("Key%d = %d. Next line follows here\n" % (i % 97, (i * 7919) % 100003) for i in range(40_000)).encode(), dtype=np.uint8).copy()
+    cases = (("utf8", utf8), ("structured", struct_txt[:9 * BLK + 77]), ("silesia", O.corpus("silesia-like", 3 * BLK + 5)), ("text", O.corpus("text-zipf", 2 * BLK)))
+    for name, x in cases:
+        sizes = {}
+        for ctx in ("0", "1"):
+            monkeypatch.setenv("GC_BR_CTX", ctx)
+            e = pkg.BrotliEncoder(lib_path=emu_lib_path, level=1 if name == "structured" else 6)      # (level 1: chunks of 8 blocks, so the nine blocks hold a chunk boundary; the hook switches the modelling on below quality 5 too)
+            try:
+                c = e.code(x)
+            finally:
+                e.close()
+            assert np.array_equal(O.ref_brotlimt_decompress(c, x.size, 2), x), (name, ctx)
+            sizes[ctx] = len(c)
+        assert sizes["1"] <= sizes["0"] * 1.001, (name, sizes)                          # (one tree is always among the choices; the choice is made from an estimate)
+        if name == "silesia":
+            assert sizes["1"] < sizes["0"] * 0.995, (name, sizes)
+    # plain stream in pieces: the first meta-block of a later piece keeps one tree (the bytes in front of it are another call's)
+    monkeypatch.setenv("GC_BR_CTX", "1"); monkeypatch.setenv("HIPEMU_DEVICES", "2")
+    x = struct_txt[:2 * 8 * BLK + 4321]                                    # three pieces at quality 1 (chunk = 1 MiB) through the host scheduler
+    m = pkg.MultiEncoder("brotli", 1, lib_path=emu_lib_path)
+    try:
+        c = m.code(x, flags=1)                                              # GC_BROTLI_PLAIN
+    finally:
+        m.close()
+    assert np.array_equal(O.ref_brotli_decompress(c, x.size), x)
+
+
 def test_golden_fixtures_decode_under_reference(O):
     """the reference's own regression fixtures (tests/regr-arc/test.txt.br, .br-mt.br) pin the decoder side of the oracle"""
     _need_ref(O)

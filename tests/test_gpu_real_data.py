@@ -52,6 +52,32 @@ def test_zstd_level3_real_data(O, gpu, kind, n):
     _bar("zstd", kind, len(c), len(O.ref_zstd_compress(x, 3)))
 
 
+# The levels between the BASELINE ones on real bytes (round 6; the review of round 5 found zstd 9 on shared objects at 1.060 with no test looking): the lazy range (9, 12), C4's
+# level (19) and FLZMA2's first ultra level, 32 MiB each, level L against the reference's level L.  Figures: MI355X, run s2 of round 6 (tools/gpu_sizes.py).
+LEVEL_CASES = [("zstd", 9, "real-src"), ("zstd", 9, "real-bin"), ("zstd", 12, "real-src"), ("zstd", 12, "real-bin"), ("zstd", 19, "real-src"), ("zstd", 19, "real-bin"), ("flzma2", 7, "real-bin")]
+NOT_YET_LEVELS = {("zstd", 19, "real-src"): "1.092 x btultra2 on real sources (round 6; 1.095 in round 5, 1.152 in round 4): one merged record per position against the binary tree's list of matches, static prices, no block splitter",
+                  ("zstd", 19, "real-bin"): "1.044 x btultra2 on shared objects (round 6; 1.043 in round 5)",
+                  ("flzma2", 7, "real-bin"): "not measured before round 6's last session: the entry only turns a miss into an expected failure"}
+
+
+@pytest.mark.parametrize("codec,level,kind", LEVEL_CASES)
+def test_levels_between_the_baseline_ones_on_real_data(O, gpu, codec, level, kind):
+    if O.ref(codec) is None:
+        pytest.skip("oracle/_ref did not travel")
+    x = _corpus(O, kind, 32 * MiB)
+    if codec == "zstd":
+        e = gpu.ZstdEncoder(level=level); c = e.code(x); e.close()
+        assert np.array_equal(O.ref_zstd_decompress(c, x.size), x)
+        ref = len(O.ref_zstd_compress(x, level))
+    else:
+        e = gpu.Flzma2Encoder(level=level); c = e.code(x); prop = e.coder_props()[0]; e.close()
+        assert np.array_equal(O.ref_lzma2_decode(c, x.size, prop), x)
+        ref = len(O.ref_fl2_compress(x, level, threads=THR)[0])
+    if len(c) > 1.02 * ref and (codec, level, kind) in NOT_YET_LEVELS:
+        pytest.xfail("known gap: " + NOT_YET_LEVELS[(codec, level, kind)])
+    assert len(c) <= 1.02 * ref, (codec, level, kind, len(c), ref, round(len(c) / ref, 4))
+
+
 @pytest.mark.parametrize("kind,n", CASES)
 def test_flzma2_level5_real_data(O, gpu, kind, n):
     if O.ref("flzma2") is None:
