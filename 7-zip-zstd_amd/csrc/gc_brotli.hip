@@ -400,10 +400,13 @@ gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
     __shared__ uint32_t sTot[BR_NT], sUsed[BR_NT + 1u];
     __shared__ BrHufScratch S;
     __shared__ uint16_t sSeq[704 + 32];
-    __shared__ uint8_t  sHdr[4096];
     __shared__ uint32_t sWave[8];
     __shared__ uint32_t sMisc[12];
-    __shared__ uint32_t sBits[BR_WIN_WORDS];                               // bit window of one tile of commands (see below)
+    // two arrays live in space that is free by the time they are needed (55 KB would leave two workgroups per CU, 43 KB leaves three): the header bytes in the scratch of the code
+    // construction (all codes are built before the header is written), the bit window of the command tiles in the literal histograms (dead once the codes exist)
+    uint8_t* const sHdr = (uint8_t*)&S;
+    uint32_t* const sBits = &hLit[0][0];
+    static_assert(sizeof(BrHufScratch) >= 4096u && BR_NT * 256u >= BR_WIN_WORDS, "aliased arrays fit");
 
     const uint32_t t = threadIdx.x, b = blockIdx.x;
     const uint64_t blockBase = (uint64_t)b * GC_ZSTD_BLOCK_MAX;
@@ -529,31 +532,32 @@ gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
     }
 
     // ---- histograms
-    if (!ctxOk) {
+    auto histFlat = [&]() {                                        // one tree: the literal stream as the parse wrote it
         for (uint32_t i = t * 4u; i < nLit; i += BR_T * 4u) {
             if (i + 4u <= nLit) {
                 const uint32_t v = *(const uint32_t*)(L + i);
                 atomicAdd(&hLit[0][v & 0xFFu], 1u); atomicAdd(&hLit[0][(v >> 8) & 0xFFu], 1u); atomicAdd(&hLit[0][(v >> 16) & 0xFFu], 1u); atomicAdd(&hLit[0][v >> 24], 1u);
             } else for (uint32_t k = i; k < nLit; k++) atomicAdd(&hLit[0][L[k]], 1u);
         }
-    } else {
-        // literal histograms per tree of the static map.  Where a literal stands in the INPUT: a command's first literal at block start + its literal rank + the copy lengths in
-        // front of it (one scan per tile of commands, as the substitution above); its context: the two input bytes in front of it
+    };
+    // literal histograms per tree of the static map.  Where a literal stands in the INPUT: a command's first literal at block start + its literal rank + the copy lengths in
+    // front of it (one scan per tile of commands, as the substitution above); its context: the two input bytes in front of it.  every: the literals of every n-th tile of
+    // commands only (a sample for the decision below)
+    auto histCtx = [&](uint32_t every) {
         uint32_t carryM = 0;
         for (uint32_t tb = 0; tb < nCmd; tb += BR_T) {
             const uint32_t j = tb + t;
+            const bool sampled = ((tb / BR_T) % every) == 0u;      // uniform
             uint32_t ll = 0, ml = 0, ls = 0;
             if (j < nCmd) { const uint64_t pk = P[j]; ll = (uint32_t)(pk & 0x3FFFFu); ml = (uint32_t)((pk >> 18) & 0x3FFFFu); ls = LS[j]; }
             uint32_t totM;
             const uint64_t cs = blockBase + ls + carryM + br_excl_scan(ml, sWave, &totM);
+            carryM += totM;
+            if (!sampled) continue;
             const bool isLong = ll > BR_LONG;
             if (ll != 0u && !isLong) {
                 uint32_t p1 = cs > chunkStart ? src[cs - 1u] : 0u, p2 = cs > chunkStart + 1u ? src[cs - 2u] : 0u;
-                for (uint32_t i = 0; i < ll; i++) { const uint32_t by = src[cs + i];
-#ifdef HIPEMU
-                    if (by != L[ls + i]) { fprintf(stderr, "B1: literal %u of command %u: input %u, literal stream %u\n", i, j, by, (uint32_t)L[ls + i]); abort(); }
-#endif
-                    atomicAdd(&hLit[sMap[sLut[p1] | sLut[256u + p2]]][by], 1u); p2 = p1; p1 = by; }
+                for (uint32_t i = 0; i < ll; i++) { const uint32_t by = src[cs + i]; atomicAdd(&hLit[sMap[sLut[p1] | sLut[256u + p2]]][by], 1u); p2 = p1; p1 = by; }
             }
             for (uint32_t w0 = 0; w0 < BR_T / 64u; w0++) {         // long runs: the whole workgroup, one after the other
                 __syncthreads();
@@ -575,25 +579,17 @@ gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
                     __syncthreads();
                 }
             }
-            carryM += totM;
         }
-    }
-    for (uint32_t j = t; j < nCmd; j += BR_T) {
-        const uint64_t pk = P[j];
-        const uint32_t ll = (uint32_t)(pk & 0x3FFFFu), ml = (uint32_t)((pk >> 18) & 0x3FFFFu), off = (uint32_t)(pk >> 36) & 0xFFFFFFu;
-        const bool useLast = j > 0u && ml != 0u && ((uint32_t)(P[j - 1u] >> 36) & 0xFFFFFFu) == off;
-        const BrCmd c = br_command(ll, ml, off, useLast, (uint32_t)(pk >> 60));
-        atomicAdd(&hCmd[c.sym], 1u);
-        if (c.hasDist) atomicAdd(&hDist[c.dsym], 1u);
-    }
-    __syncthreads();
-
-    // ---- one literal tree or thirteen?  The cost of the literals under each choice from the histograms themselves: sum over trees of T log2 T - sum h log2 h (integer
-    //      logarithm: the same choice on the device and under the emulator), plus what the tree descriptions and the context map cost (about 7 bits per symbol in use,
-    //      48 per tree, 360 for the map).  The reference decides from 5-bit histograms of a sample and wants 0.2 bits per literal (br_encode.c:377-399); here the estimate is exact
-    //      enough to take whatever is cheaper.
+    };
+    // ---- one literal tree or thirteen?  Decided on a SAMPLE -- the literals of every fourth tile of 256 commands -- so that a meta-block that stays with one tree (web-text: all
+    //      of them) pays a quarter of the walk; the reference samples 64 bytes in every 4 KiB (br_encode.c:358-375).  The cost of the literals under each choice from the sampled
+    //      histograms: sum over trees of T log2 T - sum h log2 h (integer logarithm: the same choice on the device and under the emulator), plus what the tree descriptions and
+    //      the context map cost (about 7 bits per symbol in use, 48 per tree, 360 for the map) and a margin of 1.5 % (thirteen small codes lose more to whole-bit lengths).
     uint32_t nTrees = 1u;
     if (ctxOk) {
+        constexpr uint32_t EVERY = 4u;
+        histCtx(EVERY);
+        __syncthreads();
         uint32_t H = 0;
         for (uint32_t tr = 0; tr < BR_NT; tr++) {
             const uint32_t h = hLit[tr][t];                        // (BR_T = 256: thread t = literal value t)
@@ -611,18 +607,26 @@ gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
                 d13 += sUsed[tr] ? 48u + 7u * sUsed[tr] : 8u;
             }
             const unsigned long long c1 = T ? T * pz_log2_q8((uint32_t)T) - sAcc[BR_NT] : 0ull, d1 = 48u + 7u * sUsed[BR_NT];
-            sMisc[6] = (T >= 512u && c13 + ((d13 + 360u) << 8) + (c1 >> 6) < c1 + (d1 << 8)) ? 1u : 0u;      // (a margin of 1.5 %: thirteen small codes lose more to whole-bit lengths than one large code)
+            const uint32_t scale = nCmd > BR_T ? EVERY : 1u;       // (what the sample stands for)
+            sMisc[6] = (T * scale >= 512u && scale * (c13 + (c1 >> 6)) + ((d13 + 360u) << 8) < scale * c1 + (d1 << 8)) ? 1u : 0u;
         }
         __syncthreads();
-        if (sMisc[6]) nTrees = BR_NT;
-        else {                                                     // one tree: pool the histograms, every context id maps to tree 0
-            uint32_t H1 = 0;
-            for (uint32_t tr = 0; tr < BR_NT; tr++) H1 += hLit[tr][t];
-            hLit[0][t] = H1;
-            if (t < 64u) sMap[t] = 0;
-        }
+        const bool use13 = sMisc[6] != 0u;
+        for (uint32_t i = t; i < BR_NT * 256u; i += BR_T) (&hLit[0][0])[i] = 0;
+        if (!use13 && t < 64u) sMap[t] = 0;                        // one tree: every context id maps to tree 0
         __syncthreads();
+        if (use13) { nTrees = BR_NT; histCtx(1u); } else histFlat();
+    } else histFlat();
+    for (uint32_t j = t; j < nCmd; j += BR_T) {
+        const uint64_t pk = P[j];
+        const uint32_t ll = (uint32_t)(pk & 0x3FFFFu), ml = (uint32_t)((pk >> 18) & 0x3FFFFu), off = (uint32_t)(pk >> 36) & 0xFFFFFFu;
+        const bool useLast = j > 0u && ml != 0u && ((uint32_t)(P[j - 1u] >> 36) & 0xFFFFFFu) == off;
+        const BrCmd c = br_command(ll, ml, off, useLast, (uint32_t)(pk >> 60));
+        atomicAdd(&hCmd[c.sym], 1u);
+        if (c.hasDist) atomicAdd(&hDist[c.dsym], 1u);
     }
+    __syncthreads();
+
     // ---- prefix codes
     bool ok = true;
     for (uint32_t tr = 0; tr < nTrees; tr++) {
