@@ -676,24 +676,28 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
     c->searchDepth = zstd_search_depth(level); c->searchShallow = c->searchDepth < 2u ? c->searchDepth : 2u;
     if (gc_env_u32("GC_SEARCH_DEPTH", 0u, 64u, &c->searchDepth)) c->searchShallow = c->searchDepth < 2u ? c->searchDepth : 2u;      // test hook
     gc_env_u32("GC_SEARCH_SHALLOW", 0u, 64u, &c->searchShallow);                                // test hook: links followed by every position
-    c->farPass = level >= 7 ? 1u : 0u;            // where the reference searches chains / trees (lazy2 and up).  Measured (run 29, 32 MiB): level 9
-                                                  // 1.027 -> 0.984 x the reference on text, level 12 1.040 -> 1.001 x
-    c->shortPass = level >= 7 ? 1u : 0u;          // the reference's btopt strategies search 3-byte matches (minMatch 3, clevels.h:44-47); from level 10 since round 3, from level 7 since round 6, see priceParse
+    c->farPass = level >= 5 ? 1u : 0u;            // where the reference searches chains / trees (lazy2 and up).  Measured (run 29, 32 MiB): level 9
+                                                  // 1.027 -> 0.984 x the reference on text, level 12 1.040 -> 1.001 x.  Round 6: from level 5 (was 7) -- the reference's greedy / lazy
+                                                  // strategies at 5-6 walk hash chains (zstd_lazy.c:667, searchLog 3: clevels.h:33-34), and on real sources the first pass alone was
+                                                  // 1.135 x its level 5 and 1.136 x its level 6 (32 / 8 MiB, run s4: nobody had looked); with the two far passes 0.932 / 0.984 (emulator, 8 MiB)
+    c->shortPass = level >= 5 ? 1u : 0u;          // the reference's btopt strategies search 3-byte matches (minMatch 3, clevels.h:44-47); from level 10 since round 3, from level 7 since round 6, see priceParse
     gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass); gc_env_u32("GC_SHORT_PASS", 0u, 1u, &c->shortPass);   // test hooks
     c->shortPlain = 0u; c->smallWin2k = 0u;
     c->allLengths = level >= 18 ? 1u : 0u;        // levels 16-17 (the reference: btopt / btultra with searchLog 5) keep the sparse lengths and the two far passes; 18-22 (btultra / btultra2, searchLog 6-9) price every length
-    c->farPass2 = (level >= 7 && level != 16 && level != 17) ? 1u : 0u; gc_env_u32("GC_FAR2_PASS", 0u, 1u, &c->farPass2);      // keys of 32 / 24 bytes where the reference searches chains / trees for the LONGEST match: real sources, emulator, 8 MiB:
+    c->farPass2 = (level >= 5 && level != 16 && level != 17) ? 1u : 0u; gc_env_u32("GC_FAR2_PASS", 0u, 1u, &c->farPass2);      // keys of 32 / 24 bytes where the reference searches chains / trees for the LONGEST match: real sources, emulator, 8 MiB:
                                                                                               // level 9 1.118 -> 1.050 x the reference, level 19 1.115 -> 1.097
     c->reParse = 0u;
     c->laneParse = level >= 16 ? 1u : 0u;         // the reference's btopt .. btultra2 (clevels.h:44-50) price its three repeat offsets at every position; real sources / binaries at level 19
                                                   // (emulator, 4 MiB): 1.109 / 1.124 x the reference with W7, 1.081 / 1.075 with W7L.  Levels 10-15 (the reference: lazy2 / btlazy2) keep W7
     c->lastCodecHint = 0; c->priceMinLen = 3u; c->priceLitCtx = 0u;     // zstd: matches of >= 3 bytes, literals without context (one Huffman table per block)
-    c->priceParse = level >= 7 ? 1u : 0u;         // the reference's btopt / btultra strategies start at level 16 (clevels.h:44-47), its levels 10-15 are lazy2 / btlazy2 over deep
+    c->priceParse = level >= 5 ? 1u : 0u;         // the reference's btopt / btultra strategies start at level 16 (clevels.h:44-47), its levels 10-15 are lazy2 / btlazy2 over deep
                                                   // chains and trees; the greedy / lazy2 parse over this finder's 3-6 candidates was 1.03 x them on lz-7zip (levels 10 and 12, run r03_z12),
                                                   // the price-based parse 0.98 -- so it started at level 10 in round 3.  Round 6: from level 7, where the far passes start.  The reference's
                                                   // lazy2 at 7-9 picks the longest of 16-32 tagged row candidates (zstd_lazy.c:1141); the lazy parse over this finder's gain-merged record was
                                                   // 1.058-1.062 x it on real shared objects (level 7 LARGER than level 5: a far match that wins by `4 len - log2 offset` is often dearer than the
-                                                  // near one it replaces); with the short pass + the price-based parse 1.026 / 1.028 (emulator, 8 MiB; real sources 1.038 -> 0.978, text 0.942 -> 0.909)
+                                                  // near one it replaces); with the short pass + the price-based parse 1.026 / 1.028 (emulator, 8 MiB; real sources 1.038 -> 0.978, text 0.942 -> 0.909).
+                                                  // And from level 5 once the far passes start there: levels 5 / 6 on shared objects 1.043 / 1.048 with the lazy parse over the merged records, 1.014 / 1.017 with
+                                                  // this one (real sources 0.891).  Levels 5-12 now differ in the geometry (5-6: the fast one), the links followed (0 / 2 / 4) and nothing else
     gc_env_u32("GC_PRICE_PARSE", 0u, 1u, &c->priceParse);                                      // test hook
     // Overlapping finder frames (gc_mf.h) from level 16: the zstd frame becomes the GROUP (the reference's own frames are the whole input with a sliding window).
     uint32_t zGroup = zstd_group_blocks(level); const bool grpHook = gc_env_u32("GC_MF_GROUP", 1u, 65535u, &zGroup);      // test hook: blocks per group (with GC_FRAME_BLOCKS and GC_MF_STRIDE: overlapping frames of a few blocks)

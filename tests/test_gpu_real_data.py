@@ -54,7 +54,7 @@ def test_zstd_level3_real_data(O, gpu, kind, n):
 
 # The levels between the BASELINE ones on real bytes (round 6; the review of round 5 found zstd 9 on shared objects at 1.060 with no test looking): the lazy range (9, 12), C4's
 # level (19) and FLZMA2's first ultra level, 32 MiB each, level L against the reference's level L.  Figures: MI355X, run s2 of round 6 (tools/gpu_sizes.py).
-LEVEL_CASES = [("zstd", 9, "real-src"), ("zstd", 9, "real-bin"), ("zstd", 12, "real-src"), ("zstd", 12, "real-bin"), ("zstd", 19, "real-src"), ("zstd", 19, "real-bin"), ("flzma2", 7, "real-bin")]
+LEVEL_CASES = [("zstd", 5, "real-src"), ("zstd", 5, "real-bin"), ("zstd", 6, "real-src"), ("zstd", 9, "real-src"), ("zstd", 9, "real-bin"), ("zstd", 12, "real-src"), ("zstd", 12, "real-bin"), ("zstd", 19, "real-src"), ("zstd", 19, "real-bin"), ("flzma2", 7, "real-bin")]
 NOT_YET_LEVELS = {("zstd", 19, "real-src"): "1.092 x btultra2 on real sources (round 6; 1.095 in round 5, 1.152 in round 4): one merged record per position against the binary tree's list of matches, static prices, no block splitter",
                   ("zstd", 19, "real-bin"): "1.044 x btultra2 on shared objects (round 6; 1.043 in round 5)",
                   ("flzma2", 7, "real-bin"): "not measured before round 6's last session: the entry only turns a miss into an expected failure"}
