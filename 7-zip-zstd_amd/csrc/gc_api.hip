@@ -20,6 +20,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <new>
+#include "gc_host_stream.h"
 #ifdef GC_TEST_HOOKS
 #include <vector>
 #include <unistd.h>
@@ -347,11 +348,27 @@ static int mf_grow(gc_ctx* c, void** p, size_t* cap, size_t needBytes, const cha
 }
 
 // workspace of the windowed finder for n input bytes
-static int ensure_finder_workspace(gc_ctx* c, size_t n, uint32_t frameBlocks)
+// The two entry lists (8 bytes per LISTED position each -- with overlapping frames a position is listed once per frame that holds it: FLZMA2 levels 8-9 list 29 frames of 8 MiB per
+// 64 MiB group, 29 GiB per GiB of input and list) and the count table are what the finder's passes W1..W5 hand to each other and nothing behind the finder reads, and the parts of
+// a call run their finder passes one after the other on the main stream: they are sized for the LARGEST PART and every part uses them from their start.  A call whose lists would
+// exceed GC_MF_ENT_BUDGET is taken in as many parts as it needs (mf_auto_parts; parts never change the bytes), so the workspace of a direct call of any size is bounded by the
+// per-position arrays (records, sequences, literals: ~35 bytes per input byte, + 20 for FLZMA2) plus this budget.
+#define GC_MF_ENT_BUDGET ((size_t)24u << 30)                  // bytes per entry list and part
+static uint32_t mf_auto_parts(size_t n, uint32_t frameArg)
+{
+    if (MF_F(frameArg) <= 1u) return 1u;
+    const size_t perGroup = (size_t)MF_FPG(frameArg) * MF_F(frameArg) * GC_ZSTD_BLOCK_MAX * sizeof(GcMfEntry);
+    const size_t nGroups = (gc_num_blocks(n) + MF_C(frameArg) - 1u) / MF_C(frameArg);
+    size_t perPart = GC_MF_ENT_BUDGET / perGroup; if (perPart < 1u) perPart = 1u;
+    size_t parts = (nGroups + perPart - 1u) / perPart;
+    return (uint32_t)(parts < 1u ? 1u : (parts > GC_MAX_PARTS ? GC_MAX_PARTS : parts));
+}
+static int ensure_finder_workspace(gc_ctx* c, size_t n, uint32_t frameBlocks, size_t maxPartBytes = 0 /* bytes of the largest part; 0: one part */)
 {
     if (MF_F(frameBlocks) <= 1u) return GC_OK;                  // (frameBlocks: F, or F | S << 8 | C << 16 -- overlapping frames, gc_mf.h)
     const GcMfGeom g = gc_mf_geom(n, frameBlocks, c->mfFast != 0u);
-    const size_t needCnt = g.cntWords * sizeof(uint32_t), needEnt = (size_t)g.nFrames * g.frameBytes * sizeof(GcMfEntry);
+    const GcMfGeom gp = gc_mf_geom(maxPartBytes && maxPartBytes < n ? maxPartBytes : n, frameBlocks, c->mfFast != 0u);
+    const size_t needCnt = gp.cntWords * sizeof(uint32_t), needEnt = (size_t)gp.nFrames * gp.frameBytes * sizeof(GcMfEntry);
     const size_t needRec = (size_t)g.nBlocks * GC_ZSTD_BLOCK_MAX * sizeof(uint32_t);
     const size_t needPrice = (size_t)g.nBlocks * GC_PRICE_WORDS * sizeof(uint16_t);
     const size_t needTileWord = ((size_t)g.nTiles + 64u) * sizeof(uint32_t);
@@ -394,9 +411,9 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
     }
     const GcMfGeom g = gc_mf_geom(n, frameBlocks, c->mfFast != 0u);
     const uint32_t frame0 = (blk0 / groupBlocks) * MF_FPG(frameArg);       // (parts are whole groups)
-    uint32_t* cnt = c->mfCnt + ((size_t)frame0 * (g.tilesPerFrame + 1u) << g.partLog);
-    GcMfEntry* ent = c->mfEnt + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
-    GcMfEntry* ent2 = c->mfEnt2 + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
+    uint32_t* cnt = c->mfCnt;                                              // count table and entry lists: every part from their start (ensure_finder_workspace)
+    GcMfEntry* ent = c->mfEnt;
+    GcMfEntry* ent2 = c->mfEnt2;
     uint32_t* rec = c->mfRec + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
     const uint32_t perT = gc_xcd_per(g.nTiles), perB = gc_xcd_per(nBlocks);
     const bool fast = c->mfFast != 0u;
@@ -490,7 +507,7 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
         const uint32_t fbS = c->shortPlain ? MF_F(frameArg) : frameArg;                 // (the levels that are not after speed keep the overlap: the generator of lz-7zip copies 3-4 bytes from anywhere in its window, 32 MiB at FLZMA2 level 7: +0.26 % without)
         const GcMfGeom gs = gc_mf_geom(n, fbS, c->mfFast != 0u);
         const uint32_t perTs = gc_xcd_per(gs.nTiles), nListsS = gs.nFrames * nParts;
-        uint32_t* cntS = c->mfCnt + ((size_t)((blk0 / MF_C(fbS)) * MF_FPG(fbS)) * (gs.tilesPerFrame + 1u) << gs.partLog);
+        uint32_t* cntS = c->mfCnt;
         GC_LAUNCH(MFSEL(gc_mf_count_short_kernel), perTs * GC_XCDS, nParts, st, src, (uint64_t)n, fbS, gs.nTiles, perTs, cntS);
         GC_LAUNCH(MFSEL(gc_mf_scan_kernel), gs.nFrames, 1024, st, cntS, gs.tilesPerFrame);
         GC_LAUNCH(MFSEL(gc_mf_scatter_short_kernel), perTs * GC_XCDS, nParts, st, src, (uint64_t)n, fbS, gs.nTiles, perTs, (const uint32_t*)cntS, ent);
@@ -716,13 +733,14 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
     uint32_t nParts = 1u;
     gc_env_u32("GC_ZSTD_PARTS", 1u, GC_MAX_PARTS, &nParts);                                    // test hook
     if (c->dbgPartFrames) nParts = nFrames / c->dbgPartFrames;
+    { const uint32_t autoParts = mf_auto_parts(n, zArg); if (nParts < autoParts) nParts = autoParts; }      // (entry lists beyond the budget: ensure_finder_workspace)
     if (nParts > nFrames) nParts = nFrames;
     if (nParts > GC_MAX_PARTS) nParts = GC_MAX_PARTS;
     if (nParts < 1u) nParts = 1u;
     c->mfTimed = false;
-    rc = ensure_finder_workspace(c, n, zArg);
-    if (rc != GC_OK) return rc;
     const uint32_t framesPerPart = (nFrames + nParts - 1u) / nParts;
+    rc = ensure_finder_workspace(c, n, zArg, (size_t)framesPerPart * zFrameBlocks * GC_ZSTD_BLOCK_MAX);
+    if (rc != GC_OK) return rc;
     uint32_t usedParts = 0;
     for (uint32_t p = 0; p < nParts; p++) {
         const uint32_t blk0 = p * framesPerPart * zFrameBlocks;
@@ -931,15 +949,22 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
           if (stride < frameBlocks && (frameBlocks % stride) == 0u && ((grp - frameBlocks) % stride) == 0u) fArg = GC_MF_GEOM_ARG(frameBlocks, stride, grp);
       } }
     const uint32_t groupBlocks = MF_C(fArg);
-    rc = ensure_finder_workspace(c, n, fArg);
-    if (rc != GC_OK) return rc;
     // parts: ONE by default.  Overlapping the stages of several parts was measured and lost (212 MB: 33.9 ms with 4 parts against
     // 24.3 ms with one, profiles/r01_run8_flzma2_kernel_stats.md): model and range coder are chains whose duration is set by the
     // length of one segment / chunk, not by how many there are, so every part pays the full chain again, and the model kernel's
     // LDS footprint keeps the finder of the next part waiting.  GC_PART_FRAMES (test hook) still selects parts of that many frames.
     const uint32_t nFrames = (nBlocks + groupBlocks - 1u) / groupBlocks;                       // (parts are whole groups; without overlap a group is a frame)
-    uint32_t nParts = c->dbgPartFrames ? nFrames / c->dbgPartFrames : 1u; if (nParts < 1u) nParts = 1u; if (nParts > GC_MAX_PARTS) nParts = GC_MAX_PARTS;
+    uint32_t nParts = c->dbgPartFrames ? nFrames / c->dbgPartFrames : 1u; if (nParts < 1u) nParts = 1u;
+    { const uint32_t autoParts = mf_auto_parts(n, fArg); if (nParts < autoParts) nParts = autoParts; }      // (entry lists beyond the budget: ensure_finder_workspace)
+    if (nParts > GC_MAX_PARTS) nParts = GC_MAX_PARTS;
+    if (nParts > nFrames) nParts = nFrames;
     if (frameBlocks <= 1u) nParts = 1u;
+    {   // the largest part (parts are whole groups: the split below)
+        uint32_t maxGroups = 0, g0 = 0;
+        for (uint32_t p = 0; p < nParts; p++) { const uint32_t g1 = (uint32_t)(((uint64_t)nFrames * (p + 1u)) / nParts); if (g1 - g0 > maxGroups) maxGroups = g1 - g0; g0 = g1; }
+        rc = ensure_finder_workspace(c, n, fArg, (size_t)maxGroups * groupBlocks * GC_ZSTD_BLOCK_MAX);
+        if (rc != GC_OK) return rc;
+    }
     c->mfTimed = false; c->nParts = nParts;
     const uint32_t segPerBlock = GC_ZSTD_BLOCK_MAX >> segLog;
     uint32_t mergeWords = level <= 6 ? 32768u : GC_LZMA_RC_MERGE_WORDS;                        // coded bits of one LZMA2 chunk = the chain of ONE lane of L3.  Levels <= 6 (run s9, 211.9 MB): 49 152 -> 32 768 words takes 1.65 ms off L3
@@ -1152,6 +1177,7 @@ extern "C" size_t gc_codec_compress_bound(int codec, size_t n)
     return codec == GC_CODEC_ZSTD ? gc_zstd_compress_bound(n) : (codec == GC_CODEC_FLZMA2 ? gc_flzma2_compress_bound(n) : gc_brotli_compress_bound(n));
 }
 
+struct GcStreamScope { hipStream_t prev; explicit GcStreamScope(hipStream_t st) : prev(gc_tls_stream) { gc_tls_stream = st; } ~GcStreamScope() { gc_tls_stream = prev; } };      // (gc_host_stream.h: the stand-alone entry points run on this context's stream while in scope)
 extern "C" int gc_crc32_device(const void* d_src, size_t n, uint32_t* crc);
 extern "C" int gc_bra_convert_device(int kind, const void* d_src, void* d_dst, size_t n, uint32_t pc, int encoding, size_t* processed);
 extern "C" int gc_bra_x86_convert_device(const void* d_src, void* d_dst, size_t n, uint32_t pc, int encoding, uint32_t* state, size_t* processed);
@@ -1173,7 +1199,7 @@ extern "C" int gc_host_begin_pre(gc_ctx* c, int codec, const void* src, size_t n
     const uint8_t* d_in = c->dIn;
     if (pre) { pre->crc = 0; pre->processed = 0; }
     if (pre && n && (pre->want_crc || flt)) {
-        HIPCHK(c, hipStreamSynchronize(c->stream));                  // (the CRC and the converters run on the default stream and return values to the host)
+        const GcStreamScope onMine(c->stream);                       // the CRC and the converters run on this context's stream (round 6: they used the null stream and waited for the whole device), in order behind the copy above
         if (pre->want_crc) { const int rc = gc_crc32_device(c->dIn, n, &pre->crc); if (rc != GC_OK) { snprintf(c->err, sizeof(c->err), "CRC of the input failed on the device"); return rc; } }
         if (flt) {
             if (n > c->dPreCap) { hipFree(c->dPre); c->dPre = nullptr; c->dPreCap = 0; if (hipMalloc((void**)&c->dPre, n + 64) != hipSuccess) return GC_ERR_NOMEM; c->dPreCap = n; }
@@ -1239,9 +1265,11 @@ extern "C" size_t gc_codec_grain(int codec, int level)
 {
     uint32_t fb = codec == GC_CODEC_ZSTD ? zstd_frame_blocks(level) : flzma2_frame_blocks(level);
     if (codec != GC_CODEC_BROTLI && fb > 1u) gc_env_u32("GC_FRAME_BLOCKS", 1u, GC_MF_MAX_FRAME_BLOCKS, &fb);     // test hook: small frames (as in gc_ctx_create)
-    if (codec != GC_CODEC_BROTLI && fb == GC_MF_MAX_FRAME_BLOCKS) {                                              // overlapping frames: the unit is the group (zstd 16-22: 32 MiB, FLZMA2 7-9: 64 MiB)
-        uint32_t stride = GC_MF_MAX_FRAME_BLOCKS; const bool hook = gc_env_u32("GC_MF_STRIDE", 1u, GC_MF_MAX_FRAME_BLOCKS, &stride);
-        if (!hook || stride < GC_MF_MAX_FRAME_BLOCKS) fb = codec == GC_CODEC_ZSTD ? zstd_group_blocks(level) : flzma2_group_blocks(level);
+    if (codec != GC_CODEC_BROTLI && fb > 1u) {                                                                   // overlapping frames: the unit is the group (zstd 16-22: 32 MiB, FLZMA2 5-6: 16 MiB, 7-9: 64 MiB)
+        uint32_t grp = codec == GC_CODEC_ZSTD ? zstd_group_blocks(level) : flzma2_group_blocks(level);
+        const bool grpHook = gc_env_u32("GC_MF_GROUP", 1u, 65535u, &grp);                                        // test hooks, read as the compress paths read them (small overlapping frames: shards must not cut a group)
+        uint32_t stride = codec == GC_CODEC_ZSTD ? zstd_stride_blocks(level) : flzma2_stride_blocks(level); gc_env_u32("GC_MF_STRIDE", 1u, GC_MF_MAX_FRAME_BLOCKS, &stride);
+        if (grp > fb && (fb == GC_MF_MAX_FRAME_BLOCKS || grpHook) && stride < fb && (fb % stride) == 0u && ((grp - fb) % stride) == 0u) fb = grp;
     }
     if (codec != GC_CODEC_BROTLI) return (size_t)fb * GC_ZSTD_BLOCK_MAX;
     return (size_t)brotli_blocks_per_chunk(level) * GC_ZSTD_BLOCK_MAX;
@@ -1545,14 +1573,15 @@ extern "C" int gc_filter_host(gc_ctx* c, int kind, void* data, size_t n, uint32_
     if (!n) return GC_OK;
     if (n > c->dInCap) { hipFree(c->dIn); c->dIn = nullptr; c->dInCap = 0; if (hipMalloc((void**)&c->dIn, n + 64) != hipSuccess) return GC_ERR_NOMEM; c->dInCap = n; }
     if (n > c->dOutCap) { hipFree(c->dOut); c->dOut = nullptr; c->dOutCap = 0; if (hipMalloc((void**)&c->dOut, n + 64) != hipSuccess) return GC_ERR_NOMEM; c->dOutCap = n; }
-    HIPCHK(c, hipStreamSynchronize(c->stream));                      // (the converters run on the default stream)
-    HIPCHK(c, hipMemcpy(c->dIn, data, n, hipMemcpyHostToDevice));
+    const GcStreamScope onMine(c->stream);                           // (the converters run on this context's stream, in order with the copies)
+    HIPCHK(c, hipMemcpyAsync(c->dIn, data, n, hipMemcpyHostToDevice, c->stream));
     size_t done = 0; int rc;
     if (x86) { uint32_t st; memcpy(&st, state, 4); rc = gc_bra_x86_convert_device(c->dIn, c->dOut, n, pc, encoding, &st, &done); memcpy(state, &st, 4); }
     else if (dl) { rc = gc_delta_convert_device(c->dIn, c->dOut, n, delta, encoding, state); done = n; }
     else rc = gc_bra_convert_device(kind, c->dIn, c->dOut, n, pc, encoding, &done);
     if (rc != GC_OK) { snprintf(c->err, sizeof(c->err), "filter %d failed on the device", kind); return rc; }
-    HIPCHK(c, hipMemcpy(data, c->dOut, n, hipMemcpyDeviceToHost));   // (bytes behind `done` come back unchanged)
+    HIPCHK(c, hipMemcpyAsync(data, c->dOut, n, hipMemcpyDeviceToHost, c->stream));   // (bytes behind `done` come back unchanged)
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     if (processed) *processed = done;
     return GC_OK;
 }

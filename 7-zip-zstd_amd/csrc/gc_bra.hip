@@ -25,6 +25,7 @@
 #include <hip/hip_runtime.h>
 #define GC_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
 #endif
+#include "gc_host_stream.h"
 
 #define BRA86_CHUNK 512u           // bytes per lane of the two converters that run a state machine (X86, RISCV)
 
@@ -309,14 +310,14 @@ static int bra_riscv(const void* d_src, void* d_dst, size_t n, uint32_t pc, int 
 {
     if (processed) *processed = 0;
     if (!n) return GC_OK;
-    if (hipMemcpy(d_dst, d_src, n, hipMemcpyDeviceToDevice) != hipSuccess) return GC_ERR_HIP;
+    if (gc_copy_sync(d_dst, d_src, n, hipMemcpyDeviceToDevice) != hipSuccess) return GC_ERR_HIP;
     if ((n & ~(size_t)1) <= 6u) return GC_OK;
     uint64_t* dRes = nullptr; uint64_t res = 0;
-    if (hipMalloc((void**)&dRes, 8) != hipSuccess) return GC_ERR_NOMEM;
+    if (gc_scratch_alloc((void**)&dRes, 8) != hipSuccess) return GC_ERR_NOMEM;
     const uint64_t lanes = (((uint64_t)n & ~1ull) - 6u + BRA86_CHUNK - 1u) / BRA86_CHUNK;
-    GC_LAUNCH(gc_bra_riscv_kernel, (uint32_t)((lanes + 255u) / 256u), 256, (hipStream_t)0, (const uint8_t*)d_src, (uint8_t*)d_dst, (uint64_t)n, pc, (uint32_t)(encoding != 0), dRes);
-    const bool ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(&res, dRes, 8, hipMemcpyDeviceToHost) == hipSuccess;
-    hipFree(dRes);
+    GC_LAUNCH(gc_bra_riscv_kernel, (uint32_t)((lanes + 255u) / 256u), 256, gc_tls_stream, (const uint8_t*)d_src, (uint8_t*)d_dst, (uint64_t)n, pc, (uint32_t)(encoding != 0), dRes);
+    const bool ok = hipStreamSynchronize(gc_tls_stream) == hipSuccess && gc_copy_sync(&res, dRes, 8, hipMemcpyDeviceToHost) == hipSuccess;
+    gc_scratch_free(dRes);
     if (!ok) return GC_ERR_HIP;
     if (processed) *processed = (size_t)res;
     return GC_OK;
@@ -332,14 +333,14 @@ extern "C" int gc_bra_convert_device(int kind, const void* d_src, void* d_dst, s
     uint32_t* dFlag = nullptr;
     uint32_t flag = 0;
     if (kind == GC_BRA_ARMT) {
-        if (hipMalloc((void**)&dFlag, 4) != hipSuccess) return GC_ERR_NOMEM;
-        if (hipMemcpy(dFlag, &flag, 4, hipMemcpyHostToDevice) != hipSuccess) { hipFree(dFlag); return GC_ERR_HIP; }
+        if (gc_scratch_alloc((void**)&dFlag, 4) != hipSuccess) return GC_ERR_NOMEM;
+        if (gc_copy_sync(dFlag, &flag, 4, hipMemcpyHostToDevice) != hipSuccess) { gc_scratch_free(dFlag); return GC_ERR_HIP; }
     }
     const uint64_t chunks = ((uint64_t)n + 15u) / 16u;
-    GC_LAUNCH(gc_bra_kernel, (uint32_t)((chunks + 255u) / 256u), 256, (hipStream_t)0, (const uint8_t*)d_src, (uint8_t*)d_dst, (uint64_t)n, pc, (uint32_t)kind,
+    GC_LAUNCH(gc_bra_kernel, (uint32_t)((chunks + 255u) / 256u), 256, gc_tls_stream, (const uint8_t*)d_src, (uint8_t*)d_dst, (uint64_t)n, pc, (uint32_t)kind,
               (uint32_t)(encoding != 0), dFlag);
-    bool ok = hipDeviceSynchronize() == hipSuccess;
-    if (dFlag) { ok = ok && hipMemcpy(&flag, dFlag, 4, hipMemcpyDeviceToHost) == hipSuccess; hipFree(dFlag); }
+    bool ok = hipStreamSynchronize(gc_tls_stream) == hipSuccess;
+    if (dFlag) { ok = ok && gc_copy_sync(&flag, dFlag, 4, hipMemcpyDeviceToHost) == hipSuccess; gc_scratch_free(dFlag); }
     if (!ok) return GC_ERR_HIP;
     if (processed) {
         // what the reference's converter returns for one call on the whole buffer (the tail it leaves to the next call)
@@ -461,14 +462,14 @@ extern "C" int gc_bra_x86_convert_device(const void* d_src, void* d_dst, size_t 
     if ((!d_src && n) || (!d_dst && n) || !state || (d_src == d_dst && n)) return GC_ERR_PARAM;
     if (processed) *processed = 0;
     if (!n) return GC_OK;
-    if (hipMemcpy(d_dst, d_src, n, hipMemcpyDeviceToDevice) != hipSuccess) return GC_ERR_HIP;
+    if (gc_copy_sync(d_dst, d_src, n, hipMemcpyDeviceToDevice) != hipSuccess) return GC_ERR_HIP;
     if (n < 5u) return GC_OK;                                // Bra86.c:52: nothing is processed, the state stays
     uint64_t* dRes = nullptr; uint64_t res[2] = { 0, 0 };
-    if (hipMalloc((void**)&dRes, 16) != hipSuccess) return GC_ERR_NOMEM;
+    if (gc_scratch_alloc((void**)&dRes, 16) != hipSuccess) return GC_ERR_NOMEM;
     const uint64_t lanes = ((uint64_t)n - 4u + BRA86_CHUNK - 1u) / BRA86_CHUNK;
-    GC_LAUNCH(gc_bra86_kernel, (uint32_t)((lanes + 255u) / 256u), 256, (hipStream_t)0, (const uint8_t*)d_src, (uint8_t*)d_dst, (uint64_t)n, pc, (uint32_t)(encoding != 0), *state, dRes);
-    const bool ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(res, dRes, 16, hipMemcpyDeviceToHost) == hipSuccess;
-    hipFree(dRes);
+    GC_LAUNCH(gc_bra86_kernel, (uint32_t)((lanes + 255u) / 256u), 256, gc_tls_stream, (const uint8_t*)d_src, (uint8_t*)d_dst, (uint64_t)n, pc, (uint32_t)(encoding != 0), *state, dRes);
+    const bool ok = hipStreamSynchronize(gc_tls_stream) == hipSuccess && gc_copy_sync(res, dRes, 16, hipMemcpyDeviceToHost) == hipSuccess;
+    gc_scratch_free(dRes);
     if (!ok) return GC_ERR_HIP;
     *state = (uint32_t)res[1];
     if (processed) *processed = (size_t)res[0];

@@ -18,6 +18,7 @@
 #endif
 #include <stdlib.h>
 #include <string.h>
+#include "gc_host_stream.h"
 
 #define CRC_SLICE 4096u
 #define CRC_T     256u                 // slices per chunk
@@ -72,6 +73,9 @@ gc_crc32_chunk_kernel(const uint8_t* __restrict__ src, uint32_t nChunks, const G
 }
 
 // ---------------------------------------------------------------------------------------------------- host side
+#ifndef __HIP_DEVICE_COMPILE__
+thread_local hipStream_t gc_tls_stream = nullptr;          // (gc_device.h)
+#endif
 static uint32_t crc_byte_table_entry(uint32_t i) { uint32_t r = i; for (int k = 0; k < 8; k++) r = (r >> 1) ^ (0xEDB88320u & (0u - (r & 1u))); return r; }
 static uint32_t crc_mat_apply(const uint32_t m[32], uint32_t v) { uint32_t r = 0; for (int i = 0; i < 32; i++) if ((v >> i) & 1u) r ^= m[i]; return r; }
 static void crc_mat_square(uint32_t out[32], const uint32_t m[32]) { for (int i = 0; i < 32; i++) out[i] = crc_mat_apply(m, m[i]); }
@@ -87,7 +91,7 @@ static void crc_shift_op(uint32_t out[32], uint64_t n)
     memcpy(out, acc, sizeof(acc));
 }
 
-// CRC-32 of n bytes in device memory; uses the default stream of the current device.  0 on success.
+// CRC-32 of n bytes in device memory; on the calling thread's stream (gc_device.h: the null stream unless a context set its own).  0 on success.
 extern "C" int gc_crc32_device(const void* d_src, size_t n, uint32_t* crc)
 {
     if ((!d_src && n) || !crc) return GC_ERR_PARAM;
@@ -105,18 +109,18 @@ extern "C" int gc_crc32_device(const void* d_src, size_t n, uint32_t* crc)
     if (nChunks) {
         GcCrcOps* dOps = nullptr; uint32_t* dOut = nullptr;
         uint32_t* hOut = (uint32_t*)malloc((size_t)nChunks * 4u);
-        if (!hOut || hipMalloc((void**)&dOps, sizeof(GcCrcOps)) != hipSuccess || hipMalloc((void**)&dOut, (size_t)nChunks * 4u) != hipSuccess) { free(hOut); free(tailBytes); hipFree(dOps); hipFree(dOut); return GC_ERR_NOMEM; }
-        bool ok = hipMemcpy(dOps, &hostOps, sizeof(GcCrcOps), hipMemcpyHostToDevice) == hipSuccess;
-        if (ok) { GC_LAUNCH(gc_crc32_chunk_kernel, nChunks, CRC_T, (hipStream_t)0, (const uint8_t*)d_src, nChunks, (const GcCrcOps*)dOps, dOut); }
-        ok = ok && hipMemcpy(hOut, dOut, (size_t)nChunks * 4u, hipMemcpyDeviceToHost) == hipSuccess;
-        hipFree(dOps); hipFree(dOut);
+        if (!hOut || gc_scratch_alloc((void**)&dOps, sizeof(GcCrcOps)) != hipSuccess || gc_scratch_alloc((void**)&dOut, (size_t)nChunks * 4u) != hipSuccess) { free(hOut); free(tailBytes); gc_scratch_free(dOps); gc_scratch_free(dOut); return GC_ERR_NOMEM; }
+        bool ok = gc_copy_sync(dOps, &hostOps, sizeof(GcCrcOps), hipMemcpyHostToDevice) == hipSuccess;
+        if (ok) { GC_LAUNCH(gc_crc32_chunk_kernel, nChunks, CRC_T, gc_tls_stream, (const uint8_t*)d_src, nChunks, (const GcCrcOps*)dOps, dOut); }
+        ok = ok && gc_copy_sync(hOut, dOut, (size_t)nChunks * 4u, hipMemcpyDeviceToHost) == hipSuccess;
+        gc_scratch_free(dOps); gc_scratch_free(dOut);
         if (!ok) { free(hOut); free(tailBytes); return GC_ERR_HIP; }
         uint32_t chunkOp[32]; crc_shift_op(chunkOp, CRC_CHUNK);
         for (uint32_t c = 0; c < nChunks; c++) reg = crc_mat_apply(chunkOp, reg) ^ hOut[c];
         free(hOut);
     }
     if (tail) {
-        if (hipMemcpy(tailBytes, (const uint8_t*)d_src + (size_t)nChunks * CRC_CHUNK, tail, hipMemcpyDeviceToHost) != hipSuccess) { free(tailBytes); return GC_ERR_HIP; }
+        if (gc_copy_sync(tailBytes, (const uint8_t*)d_src + (size_t)nChunks * CRC_CHUNK, tail, hipMemcpyDeviceToHost) != hipSuccess) { free(tailBytes); return GC_ERR_HIP; }
         for (size_t i = 0; i < tail; i++) reg = hostOps.table[(reg ^ tailBytes[i]) & 0xFFu] ^ (reg >> 8);
     }
     free(tailBytes);

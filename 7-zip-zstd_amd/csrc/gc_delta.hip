@@ -13,6 +13,7 @@
 #define GC_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
 #endif
 #include <string.h>
+#include "gc_host_stream.h"
 
 #define DL_CHUNK 65536u
 #define DL_T     256u
@@ -125,17 +126,17 @@ extern "C" int gc_delta_convert_device(const void* d_src, void* d_dst, size_t n,
     GcDeltaState st; memcpy(st.b, state, 256);
     uint8_t tail[256]; const size_t tl = n < delta ? n : delta;
     if (encoding) {
-        GC_LAUNCH(gc_delta_enc_kernel, (uint32_t)(((n + 7u) / 8u + 255u) / 256u), 256, (hipStream_t)0, (const uint8_t*)d_src, (uint8_t*)d_dst, (uint64_t)n, (uint32_t)delta, st);
-        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(tail, (const uint8_t*)d_src + n - tl, tl, hipMemcpyDeviceToHost) != hipSuccess) return GC_ERR_HIP;
+        GC_LAUNCH(gc_delta_enc_kernel, (uint32_t)(((n + 7u) / 8u + 255u) / 256u), 256, gc_tls_stream, (const uint8_t*)d_src, (uint8_t*)d_dst, (uint64_t)n, (uint32_t)delta, st);
+        if (hipStreamSynchronize(gc_tls_stream) != hipSuccess || gc_copy_sync(tail, (const uint8_t*)d_src + n - tl, tl, hipMemcpyDeviceToHost) != hipSuccess) return GC_ERR_HIP;
     } else {
         const uint32_t nChunks = (uint32_t)((n + DL_CHUNK - 1u) / DL_CHUNK);
         uint8_t* dTot = nullptr;
-        if (hipMalloc((void**)&dTot, (size_t)nChunks * 256u) != hipSuccess) return GC_ERR_NOMEM;
-        GC_LAUNCH(gc_delta_totals_kernel, nChunks, DL_T, (hipStream_t)0, (const uint8_t*)d_src, (uint64_t)n, (uint32_t)delta, dTot);
-        GC_LAUNCH(gc_delta_scan_kernel, 1, 256, (hipStream_t)0, dTot, nChunks, (uint32_t)delta, st);
-        GC_LAUNCH(gc_delta_dec_kernel, nChunks, DL_T, (hipStream_t)0, (const uint8_t*)d_src, (uint8_t*)d_dst, (uint64_t)n, (uint32_t)delta, (const uint8_t*)dTot);
-        const bool ok = hipDeviceSynchronize() == hipSuccess && hipMemcpy(tail, (const uint8_t*)d_dst + n - tl, tl, hipMemcpyDeviceToHost) == hipSuccess;
-        hipFree(dTot);
+        if (gc_scratch_alloc((void**)&dTot, (size_t)nChunks * 256u) != hipSuccess) return GC_ERR_NOMEM;
+        GC_LAUNCH(gc_delta_totals_kernel, nChunks, DL_T, gc_tls_stream, (const uint8_t*)d_src, (uint64_t)n, (uint32_t)delta, dTot);
+        GC_LAUNCH(gc_delta_scan_kernel, 1, 256, gc_tls_stream, dTot, nChunks, (uint32_t)delta, st);
+        GC_LAUNCH(gc_delta_dec_kernel, nChunks, DL_T, gc_tls_stream, (const uint8_t*)d_src, (uint8_t*)d_dst, (uint64_t)n, (uint32_t)delta, (const uint8_t*)dTot);
+        const bool ok = hipStreamSynchronize(gc_tls_stream) == hipSuccess && gc_copy_sync(tail, (const uint8_t*)d_dst + n - tl, tl, hipMemcpyDeviceToHost) == hipSuccess;
+        gc_scratch_free(dTot);
         if (!ok) return GC_ERR_HIP;
     }
     // the state behind the buffer: the last `delta` original bytes (older ones shift down when the buffer is shorter than delta)

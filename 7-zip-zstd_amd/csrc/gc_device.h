@@ -210,3 +210,4 @@ struct GcPub { uint32_t mine; };
 __device__ __forceinline__ void gc_publish(GcPub& pub, uint32_t mine) { pub.mine = mine; }
 __device__ __forceinline__ uint32_t gc_peek(const GcPub& pub, uint32_t lane) { return gc_readlane(pub.mine, lane); }
 #endif
+

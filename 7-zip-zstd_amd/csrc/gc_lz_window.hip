@@ -119,7 +119,7 @@ __device__ __forceinline__ uint32_t mf_lds_byte(const uint32_t* sW, uint32_t i) 
 // partly taken back in W5: a verified candidate is extended one byte BACKWARDS and the longer match is recorded at the position in
 // front if that has no record of its own.
 #define MF_HALF  3
-// MF_FAR2 = one more pass of the far kind with keys of 32 ("long") and 24 ("short") bytes (round 5, zstd levels >= 9 and FLZMA2 levels >= 7): in data made of many near-copies of
+// MF_FAR2 = one more pass of the far kind with keys of 32 ("long") and 24 ("short") bytes (round 5: zstd levels >= 7; round 6: >= 5; FLZMA2 levels >= 7): in data made of many near-copies of
 // the same text (source trees, archives of similar files) the most recent position with the same 16 bytes is often a copy that diverges a few dozen bytes later, where the
 // reference's chains and trees return the LONGEST match (real sources, zstd level 9 and 19: 1.12 x the reference with 10 % more sequences of the same cost each).
 #define MF_FAR2  4
@@ -871,7 +871,8 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
                 const uint32_t d = prev >> 8, cur = sRec[q];
                 const uint32_t p = pTile + q;
                 const bool fresh = !FAR || ((sDirty[q >> 5] >> (q & 31u)) & 1u) != 0u;
-                const bool need0 = fresh && (prev & 0xFFu) == GC_MATCH_CAP && (cur >> 8) != d && T.tileStart + q + GC_MATCH_CAP + 16u <= T.frameEnd && p + 8u <= nBlk;
+                const bool need0 = fresh && (prev & 0xFFu) == GC_MATCH_CAP && (cur >> 8) != d && d <= wTile + q      // (a record taken over from an overlapping frame may reach in front of THIS frame: the pass with 4- / 3-byte keys over frames that tile)
+                                   && T.tileStart + q + GC_MATCH_CAP + 16u <= T.frameEnd && p + 8u <= nBlk;
                 if (!need0) { if (follow) return; q += 64u; continue; }
                 uint32_t max0 = (nBlk - p) < GC_MATCH_CAP ? (nBlk - p) : GC_MATCH_CAP;
                 if (TILE_LIMIT && max0 > T.len - q) max0 = T.len - q;
@@ -905,7 +906,7 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
             const uint32_t prev = sRec[q - GC_MATCH_CAP];
             if ((prev & 0xFFu) != GC_MATCH_CAP) return false;
             const uint32_t d = prev >> 8, cur = sRec[q];
-            if ((cur >> 8) == d) return false;
+            if ((cur >> 8) == d || d > wTile + q) return false;
             if (T.tileStart + q + GC_MATCH_CAP + 16u > T.frameEnd) return false;
             const uint32_t p = pTile + q;
             if (p + 8u > nBlk) return false;

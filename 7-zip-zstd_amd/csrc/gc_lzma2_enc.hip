@@ -517,7 +517,8 @@ gc_lzma2_model_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const u
         // on 4 MiB of tables of records.)
         LzLru lruIncl; lruIncl.v0 = lruIncl.v1 = lruIncl.v2 = lruIncl.v3 = 0;
         LzLru L4; L4.v0 = L4.v1 = L4.v2 = L4.v3 = 0;
-        if (rep4) {
+        {   // (always: with the hook GC_L2_REP4=0 the list is not used for rep2 / rep3, but a one-byte item that names another distance than the decoder's rep0 must still
+            //  become the literal it also is -- W7L offers short repeats at distances it does not know for certain)
             LzLru a; a.v0 = (lane < cnt && it.len >= 2u) ? it.off : 0u; a.v1 = a.v2 = a.v3 = 0;
 #pragma unroll
             for (uint32_t d = 1; d < 64u; d <<= 1) {

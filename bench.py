@@ -297,7 +297,7 @@ def run_codec(codec, level, corpus_name, total, args, env):
         ours = enc.finish()
         ratio_vs_ref = {"note": "both encoders on the first sample_bytes of the corpus", "sample_bytes": ref[1], "ref_bytes": ref[0], "ours_bytes": ours,
                         "ours_over_ref": round(ours / ref[0], 4), "pass_le_1.02": bool(ours <= 1.02 * ref[0])}
-    frames = ("8 MiB match-finder frames" + (", overlapping (stride 4 MiB) in groups of %d MiB" % (grain >> 20) if grain > (8 << 20) else "")) if mf_ms else "block-local match finder"
+    frames = ("8 MiB match-finder frames" + (", overlapping (stride %d MiB) in groups of %d MiB" % ((2 if (codec == "zstd" and level >= 20) or (codec == "flzma2" and level >= 8) else 4), grain >> 20) if grain > (8 << 20) else "")) if mf_ms else "block-local match finder"
     res = {
         "metric": ("brotli-q%d (brotli-mt framed)" % level if br else "flzma2-L%d" % level if fl2 else "zstd-L%d" % level) + " compression throughput (input MB/s)",
         "value": round(value, 1), "unit": "MB/s", "ms_per_step": round(elapsed / args.steps * 1e3, 4),

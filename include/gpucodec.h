@@ -83,6 +83,12 @@ int         gc_mf_pass_timing(gc_ctx* ctx, float ms[4]);
 int         gc_zstd_set_phase_profile(gc_ctx* ctx, int enable);
 int         gc_zstd_phase_profile(gc_ctx* ctx, double cyclesPerBlock[16]);
 
+/* Workspace of a *_compress_device call (HBM, owned by the context, grown on demand and kept): the per-position arrays -- match records, sequences, literals, entropy-stage
+ * staging -- take about 35 bytes per input byte (zstd, brotli; + 20 for FLZMA2); the finder's two entry lists take 8 bytes per LISTED position each (levels whose finder frames
+ * overlap list a position once per frame that holds it: zstd 16-19 x 1.75, 20-22 x 3.25, FLZMA2 5-6 x 1.5, 7 x 1.9, 8-9 x 3.6) but never more than 24 GiB per list: a call
+ * whose lists would be larger runs its match finder in up to eight parts, one after the other over the same lists (same bytes out).  Callers that want less go through
+ * gc_multi_compress_host, whose pieces are 64 MiB (FLZMA2: 256 MiB) per context. */
+
 /* ---- FLZMA2 (7-Zip method id 0x21): an LZMA2 chunk stream that the stock decoder NCompress::NLzma2::CDecoder
  * (C/Lzma2Dec.c; registered for FLZMA2 at CPP/7zip/Compress/FastLzma2Register.cpp:15) regenerates bit-exactly.
  *   gc_flzma2_compress_host   <->  the FL2_compressStream loop of NCompress::NLzma2::CFastEncoder::Code

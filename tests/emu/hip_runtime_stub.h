@@ -23,6 +23,9 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { strcp
 // malloc's fresh pages are zero, which hides reads of words no kernel has written)
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); if (*p) { const char* e = getenv("GC_EMU_POISON"); if (e) { const int v = atoi(e); if (v >= 0) memset(*p, v, n ? n : 1); else { unsigned long long x = 0x9E3779B97F4A7C15ull * (unsigned long long)(-v); unsigned char* q = (unsigned char*)*p; for (size_t i = 0; i < n; i++) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; q[i] = (unsigned char)(x >> 32); } } } } return *p ? 0 : 2; }
 static inline hipError_t hipFree(void* p) { free(p); return 0; }
+typedef int hipMemcpyKind;
+static inline hipError_t hipMallocAsync(void** p, size_t n, hipStream_t) { return hipMalloc(p, n); }
+static inline hipError_t hipFreeAsync(void* p, hipStream_t) { free(p); return 0; }
 static inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { *p = malloc(n ? n : 1); return *p ? 0 : 2; }
 static inline hipError_t hipHostFree(void* p) { free(p); return 0; }
 static inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return 0; }

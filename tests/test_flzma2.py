@@ -105,6 +105,7 @@ def test_emu_rep2_rep3_coding_behind_its_hook(O, pkg, emu_lib_path, monkeypatch)
     rec[:, 4:12] = rec[(np.arange(4000) // 3) * 3 % 4000, 4:12]
     rec[:, 12:20] = rec[(np.arange(4000) // 7) * 7 % 4000, 12:20]
     x = np.concatenate([rec.reshape(-1), O.corpus("lz-7zip", 200_000), O.corpus("real-bin", 400_000) if O.corpus("real-bin", 1).size else O.corpus("silesia-like", 400_000)])
+    monkeypatch.setenv("GC_L2_REP4", "0")                                             # (on in the shipped library since round 4: the baseline is the hook's OFF path)
     plain = pkg.Flzma2Encoder(lib_path=emu_lib_path, level=5); c0 = _roundtrip(O, plain, x); plain.close()
     monkeypatch.setenv("GC_L2_REP4", "1")
     rep4 = pkg.Flzma2Encoder(lib_path=emu_lib_path, level=5); c1 = _roundtrip(O, rep4, x); rep4.close()
