@@ -48,9 +48,6 @@ extern "C" __global__ void gc_mf_scan_kernel(uint32_t*, uint32_t);
 extern "C" __global__ void gc_mf_scatter_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
 extern "C" __global__ void gc_mf_link_kernel(const uint32_t*, const GcMfEntry*, GcMfEntry*, uint32_t, uint64_t, uint32_t, uint32_t*);
 extern "C" __global__ void gc_mf_verify_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
-extern "C" __global__ void gc_mf_count_half_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
-extern "C" __global__ void gc_mf_scatter_half_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
-extern "C" __global__ void gc_mf_verify_half_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
 extern "C" __global__ void gc_mf_count_short_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
 extern "C" __global__ void gc_mf_scatter_short_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
 extern "C" __global__ void gc_mf_verify_short_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, const uint32_t*, uint32_t*, const uint32_t*);
@@ -66,9 +63,6 @@ extern "C" __global__ void gc_mf_scan_kernel_p8(uint32_t*, uint32_t);
 extern "C" __global__ void gc_mf_scatter_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
 extern "C" __global__ void gc_mf_link_kernel_p8(const uint32_t*, const GcMfEntry*, GcMfEntry*, uint32_t, uint64_t, uint32_t, uint32_t*);
 extern "C" __global__ void gc_mf_verify_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
-extern "C" __global__ void gc_mf_count_half_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
-extern "C" __global__ void gc_mf_scatter_half_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
-extern "C" __global__ void gc_mf_verify_half_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
 extern "C" __global__ void gc_mf_count_short_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
 extern "C" __global__ void gc_mf_scatter_short_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
 extern "C" __global__ void gc_mf_verify_short_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, const uint32_t*, uint32_t*, const uint32_t*);
@@ -79,8 +73,6 @@ extern "C" __global__ void gc_mf_count_far2_kernel_p8(const uint8_t*, uint64_t, 
 extern "C" __global__ void gc_mf_scatter_far2_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
 extern "C" __global__ void gc_mf_verify_far2_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
 extern "C" __global__ void gc_mf_deepen_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, uint32_t*, uint32_t*);
-extern "C" __global__ void gc_mf_vparse_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, GcSeqRaw*, uint8_t*, GcBlockMeta*, unsigned long long*);
-extern "C" __global__ void gc_mf_vparse_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, GcSeqRaw*, uint8_t*, GcBlockMeta*, unsigned long long*);
 extern "C" __global__ void gc_mf_vparse_tile_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, GcSeqRaw*, uint8_t*, GcBlockMeta*, uint32_t*, uint32_t*, unsigned long long*);
 extern "C" __global__ void gc_mf_vparse_tile_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, GcSeqRaw*, uint8_t*, GcBlockMeta*, uint32_t*, uint32_t*, unsigned long long*);
 extern "C" __global__ void gc_mf_parse_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcSeqRaw*, uint8_t*, GcBlockMeta*, uint16_t*, uint32_t);
@@ -88,12 +80,10 @@ extern "C" __global__ void gc_mf_short_kernel(const uint8_t*, uint64_t, uint32_t
 extern "C" __global__ void gc_mf_dp2_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
 extern "C" __global__ void gc_mf_dp3_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
 extern "C" __global__ void gc_mf_litprice_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, const uint16_t*, uint32_t, uint8_t*);
-extern "C" __global__ void gc_mf_dpl2_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*, uint32_t*);
-extern "C" __global__ void gc_mf_dpl2s_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*, uint32_t*);
-extern "C" __global__ void gc_mf_dplz_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*, uint32_t*);
-extern "C" __global__ void gc_mf_dplzs_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*, uint32_t*);
-extern "C" __global__ void gc_mf_dpl3_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*, uint32_t*);
-extern "C" __global__ void gc_mf_dpl3s_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*, uint32_t*);
+extern "C" __global__ void gc_mf_dpl2_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*);
+extern "C" __global__ void gc_mf_dpl2s_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*);
+extern "C" __global__ void gc_mf_dplz_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*);
+extern "C" __global__ void gc_mf_dplzs_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*, const uint8_t*);
 
 extern "C" __global__ void gc_lzma2_prep_kernel(const GcSeqRaw*, const GcBlockMeta*, uint64_t, uint64_t*, uint32_t*);
 extern "C" __global__ void gc_lzma2_model_kernel(const uint8_t*, uint64_t, const uint64_t*, const uint32_t*, uint32_t, uint32_t, uint16_t*, GcLzmaChunkInfo*, const uint32_t*, unsigned long long*, uint32_t, uint32_t, uint32_t, uint8_t*, uint32_t, uint32_t, uint32_t);
@@ -124,7 +114,6 @@ struct gc_ctx {
     uint32_t farPass;         // second finder pass with 16- / 12-byte keys (longer matches), merged into the records by gain
     uint32_t optSeekTable, optBrotliPlain;   // gc_ctx_set_option
     uint32_t mfFast;          // geometry of the windowed finder (gc_mf.h): 1 = 256 partitions / 8 KiB tiles, 0 = 1024 partitions / 16 KiB tiles
-    uint32_t halfList;        // first finder pass over the even positions only, matches extended one byte backwards (zstd levels 3-5)
     uint32_t priceParse;      // W5s + W7: price-based parse on top of the greedy one (gc_lz_price.hip)
     uint32_t priceMinLen, priceLitCtx;        // its shortest match and literal context bits (LZMA: 2, 7; zstd: 3, 0)
     int lastCodecHint;        // codec of the call being enqueued (0 zstd, 1 flzma2, 2 brotli): which W7L kernels the finder launches
@@ -132,7 +121,6 @@ struct gc_ctx {
     uint32_t smallWin2k;      // W7L: windows of 2 KiB in calls of <= 1 024 blocks (launch_finder_part)
     uint32_t shortPlain;      // overlapping frames: the pass with 4- / 3-byte keys runs over frames that tile the input (launch_finder_part)
     uint32_t farPass2;        // one more pass of the far kind with keys of 32 / 24 bytes (gc_lz_window.hip MF_FAR2)
-    uint32_t reParse;         // W7L runs a second full pass under prices made from the first one's own paths (launch_finder_part)
     uint32_t laneParse;       // the price-based parse is W7L (a lane per window, repeat distances at every node) rather than W7
     uint32_t dbgFrameBlocks, dbgPartFrames;   // test hooks (env GC_FRAME_BLOCKS / GC_PART_FRAMES): small frames / parts so that
                                               // the multi-frame and multi-part paths can be exercised on small inputs
@@ -373,7 +361,7 @@ static int ensure_finder_workspace(gc_ctx* c, size_t n, uint32_t frameBlocks, si
     const size_t needPrice = (size_t)g.nBlocks * GC_PRICE_WORDS * sizeof(uint16_t);
     const size_t needTileWord = ((size_t)g.nTiles + 64u) * sizeof(uint32_t);
     if (needTileWord > c->mfTileWordCap || needCnt > c->mfCntCap || needEnt > c->mfEntCap || needEnt > c->mfEnt2Cap || needRec > c->mfRecCap || ((c->searchDepth || c->shortPass) && (needRec > c->mfRec2Cap || needRec / 32u + 64u > c->mfChangedCap)) ||
-        (c->priceParse && (needRec / 2u > c->mfRec3Cap || needRec > c->mfDpCap || needPrice > c->mfPriceCap || (size_t)g.nBlocks * 128u > c->mfWinCostCap || (size_t)g.nBlocks * GC_DPS_WORDS * 8u > c->mfDpStatCap || needRec / 4u > c->mfLitPriceCap))) {
+        (c->priceParse && (needRec / 2u > c->mfRec3Cap || needRec > c->mfDpCap || needPrice > c->mfPriceCap || (size_t)g.nBlocks * 128u > c->mfWinCostCap || (size_t)g.nBlocks * GC_DPS_WORDS * 4u > c->mfDpStatCap || needRec / 4u > c->mfLitPriceCap))) {
         HIPCHK(c, hipStreamSynchronize(c->stream));
         int rc;
         if ((rc = mf_grow(c, (void**)&c->mfTileWord, &c->mfTileWordCap, needTileWord, "tile counts")) != GC_OK) return rc;
@@ -388,7 +376,7 @@ static int ensure_finder_workspace(gc_ctx* c, size_t n, uint32_t frameBlocks, si
             if ((rc = mf_grow(c, (void**)&c->mfDp, &c->mfDpCap, needRec, "price-parse records")) != GC_OK) return rc;
             if ((rc = mf_grow(c, (void**)&c->mfPrice, &c->mfPriceCap, needPrice, "price tables")) != GC_OK) return rc;
             if ((rc = mf_grow(c, (void**)&c->mfWinCost, &c->mfWinCostCap, (size_t)g.nBlocks * 128u, "window costs")) != GC_OK) return rc;
-            if ((rc = mf_grow(c, (void**)&c->mfDpStat, &c->mfDpStatCap, (size_t)g.nBlocks * GC_DPS_WORDS * 8u, "path symbol counts (two sets: the sample's and the first full pass's)")) != GC_OK) return rc;
+            if ((rc = mf_grow(c, (void**)&c->mfDpStat, &c->mfDpStatCap, (size_t)g.nBlocks * GC_DPS_WORDS * 4u, "path symbol counts")) != GC_OK) return rc;
             if ((rc = mf_grow(c, (void**)&c->mfLitPrice, &c->mfLitPriceCap, needRec / 4u, "literal prices")) != GC_OK) return rc;
         }
     }
@@ -437,41 +425,34 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
         GC_LAUNCH(gc_mf_short_kernel, perC * GC_XCDS, 256, c->stream2, src, (uint64_t)n, groupBlocks, (uint32_t)((n + 2047u) / 2048u), perC, c->mfRec3 + (size_t)blk0 * GC_ZSTD_BLOCK_MAX);
         HIPCHK(c, hipEventRecord(c->evShort[part], c->stream2));
     }
-    if (c->halfList) GC_LAUNCH(MFSEL(gc_mf_count_half_kernel), perT * GC_XCDS, nParts, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, cnt);
-    else GC_LAUNCH(MFSEL(gc_mf_count_kernel), perT * GC_XCDS, nParts, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, cnt);
+    GC_LAUNCH(MFSEL(gc_mf_count_kernel), perT * GC_XCDS, nParts, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, cnt);
     HIPCHK(c, hipEventRecord(ev[1], st));
     GC_LAUNCH(MFSEL(gc_mf_scan_kernel), g.nFrames, 1024, st, cnt, g.tilesPerFrame);
     HIPCHK(c, hipEventRecord(ev[2], st));
-    if (c->halfList) GC_LAUNCH(MFSEL(gc_mf_scatter_half_kernel), perT * GC_XCDS, nParts, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt, ent);
-    else GC_LAUNCH(MFSEL(gc_mf_scatter_kernel), perT * GC_XCDS, nParts, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt, ent);
+    GC_LAUNCH(MFSEL(gc_mf_scatter_kernel), perT * GC_XCDS, nParts, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt, ent);
     HIPCHK(c, hipEventRecord(ev[3], st));
     MF_LINK(cnt, ent, ent2);
     HIPCHK(c, hipEventRecord(ev[4], st));
     // the levels that parse the first pass's records as they are: verify + parse in one kernel, the records stay in LDS (W5 + W6 fused)
-    uint32_t fused = (!c->halfList && !c->farPass && !c->farPass2 && !c->searchDepth && !c->priceParse && !c->shortPass) ? 1u : 0u;
+    uint32_t fused = (!c->farPass && !c->farPass2 && !c->searchDepth && !c->priceParse && !c->shortPass) ? 1u : 0u;
     gc_env_u32("GC_FUSED_PARSE", 0u, 1u, &fused);               // test hook: 0 = the two kernels
-    if (fused && (c->halfList || c->farPass || c->farPass2 || c->searchDepth || c->priceParse || c->shortPass || MF_C(frameArg) != MF_F(frameArg))) fused = 0u;
+    if (fused && (c->farPass || c->farPass2 || c->searchDepth || c->priceParse || c->shortPass || MF_C(frameArg) != MF_F(frameArg))) fused = 0u;
     if (fused) {
-        uint32_t mode = 2u; gc_env_u32("GC_FUSED_MODE", 1u, 2u, &mode);       // test hook: 1 = a workgroup per block (tiles in order), 2 = a workgroup per tile
-        if (mode == 2u) {
+        {
             const uint32_t tpb = GC_ZSTD_BLOCK_MAX >> g.tileLog;
             const uint32_t perV = ((gc_xcd_per(g.nTiles) + tpb - 1u) / tpb) * tpb;      // whole blocks per XCD class: a tile never waits for a tile of another class
             uint32_t* tw = c->mfTileWord + (size_t)frame0 * g.tilesPerFrame;
             HIPCHK(c, hipMemsetAsync(tw, 0, (size_t)g.nTiles * sizeof(uint32_t), st));
             GC_LAUNCH(MFSEL(gc_mf_vparse_tile_kernel), perV * GC_XCDS, g.verifyT, st, src, (uint64_t)n, frameBlocks, g.nTiles, perV, c->lazyDepth, (const uint32_t*)cnt,
                       (const GcMfEntry*)ent2, seqRaw, lit, meta, c->mfTicket + part * 16u + 8u, tw, prof);
-        } else
-        GC_LAUNCH(MFSEL(gc_mf_vparse_kernel), perB * GC_XCDS, g.verifyT, st, src, (uint64_t)n, frameBlocks, nBlocks, perB, c->lazyDepth, (const uint32_t*)cnt,
-                  (const GcMfEntry*)ent2, seqRaw, lit, meta, prof);
+        }
         for (int i = 10; i <= 12; i++) HIPCHK(c, hipEventRecord(ev[i], st));
         HIPCHK(c, hipEventRecord(ev[5], st));
         HIPCHK(c, hipEventRecord(ev[6], st));
         (void)prof;
         return GC_OK;
     }
-    if (c->halfList) GC_LAUNCH(MFSEL(gc_mf_verify_half_kernel), perT * GC_XCDS, g.verifyT, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt,
-                               (const GcMfEntry*)ent2, rec);
-    else GC_LAUNCH(MFSEL(gc_mf_verify_kernel), perT * GC_XCDS, g.verifyT, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt,
+    GC_LAUNCH(MFSEL(gc_mf_verify_kernel), perT * GC_XCDS, g.verifyT, st, src, (uint64_t)n, frameBlocks, g.nTiles, perT, (const uint32_t*)cnt,
                    (const GcMfEntry*)ent2, rec);
     HIPCHK(c, hipEventRecord(ev[10], st));
     if (c->farPass) {                                           // second pass with 16- / 12-byte keys, merged into rec (timed with W5)
@@ -543,21 +524,13 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
         // (FLZMA2 on the Silesia stand-in: half of the blocks sit right at the threshold, and a W7L launch takes as long for a few blocks as for all of them -- it ends with
         // its slowest wave, and all of its waves fit the device at once -- so the two kernels' times add up: 40 -> 49 ms.)  Test hook GC_DPL: 0 = W7 with its own phase A
         uint32_t laneDp = c->laneParse ? (c->lastCodecHint == 1 ? 1u : 2u) : 0u; gc_env_u32("GC_DPL", 0u, 2u, &laneDp);
+        if (c->lastCodecHint == 2) laneDp = 0u;                        // (brotli: W7 only -- a lane-per-window programme with the distance ring as its repeat set was compiled in rounds 4-5 and never switched on)
         uint8_t* lpr = c->mfLitPrice + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
         if (laneDp) GC_LAUNCH(gc_mf_litprice_kernel, perB * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perB, (const uint16_t*)price, litCtxArg, lpr);
-        // Round 5: a re-priced SECOND pass over every window (W7L only): the first full pass counts the symbols of its own paths per block (all 32 windows, not the
-        // sample's 32 x 512 bytes), the second prices lengths, distance slots and the repeat / literal flags from those counts -- the static counterpart of the reference's
-        // statistics that follow its own parse (ZSTD_updateStats / ZSTD_rescaleFreqs zstd_opt.c:356,141; LZMA's prices refreshed from the live model lzma2_enc.c:1651-1682).
-        uint32_t reparse = c->reParse; gc_env_u32("GC_DP_REPARSE", 0u, 1u, &reparse);          // test hook
-        if (!laneDp || phase0 == 2u) reparse = 0u;
-        if (reparse) laneDp = 1u;                                    // (every block in W7L: the counts come from its walk back)
-        uint32_t* const dps2 = c->mfDpStat + c->mfDpStatCap / 8u + (size_t)blk0 * GC_DPS_WORDS;        // second half of the allocation
-        if (reparse) HIPCHK(c, hipMemsetAsync(dps2, 0, (size_t)nBlocks * GC_DPS_WORDS * sizeof(uint32_t), st));
-        uint32_t* const dpsA = dps;
-        for (uint32_t pass = phase0 == 2u ? 1u : 0u; pass < (reparse ? 3u : 2u); pass++) {
+        // (Round 5 built a re-priced SECOND pass over every window -- the first full pass counts its own paths, the second prices from those counts -- behind a hook: text -0.14 .. -0.25 %,
+        //  real sources +1.6 %, FLZMA2 on shared objects -0.04 %, profiles/r05_zstd19.md.  Measured, not taken; removed in round 6.)
+        for (uint32_t pass = phase0 == 2u ? 1u : 0u; pass < 2u; pass++) {
             const uint32_t phase = phase0 == 2u ? 2u : (pass == 0u ? 0u : 1u);
-            uint32_t* const dps = pass == 2u ? dps2 : dpsA;          // the counts this pass prices from (pass 0 writes them)
-            uint32_t* const DPS_OUT = (pass == 1u && reparse) ? dps2 : (uint32_t*)nullptr;
             const uint32_t nDpWg = nBlocks * (phase == 0u ? 1u : 8u), perD = gc_xcd_per(nDpWg);
             uint32_t* wcp = phase == 0u ? (uint32_t*)nullptr : wc;
             if (laneDp) {
@@ -569,20 +542,17 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
                 const bool w2 = win2k != 0u && phase != 0u;
                 const uint32_t nItems = w2 ? nBlocks : (nBlocks + 1u) / 2u, perL = gc_xcd_per(nItems);     // a wave = two blocks (2 KiB windows: one)
                 const bool select = laneDp == 2u && phase == 1u && !w2;
-                const uint32_t phaseK = phase | (w2 ? 16u : 0u) | (select ? GC_DP_SELECT : 0u) | (DPS_OUT ? GC_DP_COUNT : 0u) | (c->allLengths ? GC_DP_ALLLEN : 0u);
+                const uint32_t phaseK = phase | (w2 ? 16u : 0u) | (select ? GC_DP_SELECT : 0u) | (c->allLengths ? GC_DP_ALLLEN : 0u);
                 if (select) {                                      // the blocks without repeats: W7
                     if (c->priceMinLen <= 2u) GC_LAUNCH(gc_mf_dp2_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, groupBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
                     else GC_LAUNCH(gc_mf_dp3_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, groupBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
                 }
                 if (c->priceMinLen <= 2u) {
-                    if (phase == 0u) GC_LAUNCH(gc_mf_dpl2s_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phase | (c->allLengths ? GC_DP_ALLLEN : 0u), dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr, DPS_OUT);
-                    else GC_LAUNCH(gc_mf_dpl2_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr, DPS_OUT);
+                    if (phase == 0u) GC_LAUNCH(gc_mf_dpl2s_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phase | (c->allLengths ? GC_DP_ALLLEN : 0u), dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
+                    else GC_LAUNCH(gc_mf_dpl2_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
                 } else if (c->lastCodecHint == 0) {
-                    if (phase == 0u) GC_LAUNCH(gc_mf_dplzs_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phase | (c->allLengths ? GC_DP_ALLLEN : 0u), dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr, DPS_OUT);
-                    else GC_LAUNCH(gc_mf_dplz_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr, DPS_OUT);
-                } else {
-                    if (phase == 0u) GC_LAUNCH(gc_mf_dpl3s_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phase | (c->allLengths ? GC_DP_ALLLEN : 0u), dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr, DPS_OUT);
-                    else GC_LAUNCH(gc_mf_dpl3_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr, DPS_OUT);
+                    if (phase == 0u) GC_LAUNCH(gc_mf_dplzs_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phase | (c->allLengths ? GC_DP_ALLLEN : 0u), dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
+                    else GC_LAUNCH(gc_mf_dplz_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
                 }
             } else
             if (c->priceMinLen <= 2u) GC_LAUNCH(gc_mf_dp2_kernel, perD * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perD, groupBlocks, phase, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp);
@@ -686,10 +656,8 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
     c->lazyDepth = level >= 6 ? 2u : 1u;          // the reference's lazy2 begins at level 8 of its table; deeper look-ahead from 6 here
     c->mfFast = level <= 6 ? 1u : 0u;             // no far pass below level 7: the fast geometry (gc_mf.h)
     gc_env_u32("GC_MF_FAST", 0u, 1u, &c->mfFast);                                              // test hook
-    c->halfList = 0u;                             // (listing half of the positions, chosen by content, with matches extended up to 3 bytes backwards -- MF_HALF in
-                                                  // gc_lz_window.hip -- was measured at level 3 on 1 GB of text: 43.2 -> 39.0 ms for +3.5-4.5 % size.  Not taken: W3-W5 are
-                                                  // bound by what they do per tile and per list, not per entry.  The test hook keeps the path exercised.)
-    gc_env_u32("GC_HALF_LIST", 0u, 1u, &c->halfList);
+    // (Listing half of the positions, chosen by content, was measured at level 3 in rounds 2 and 5 -- 1 GB of text 43.2 -> 39.0 ms for +3.5-4.5 % size, real sources 0.949 -> 1.158 x
+    //  the reference -- and again in round 6's lab with the catch-up in place (tools/zstd_parse_lab.c policy 4: shared objects +10 %): not taken, its kernels are gone.)
     c->searchDepth = zstd_search_depth(level); c->searchShallow = c->searchDepth < 2u ? c->searchDepth : 2u;
     if (gc_env_u32("GC_SEARCH_DEPTH", 0u, 64u, &c->searchDepth)) c->searchShallow = c->searchDepth < 2u ? c->searchDepth : 2u;      // test hook
     gc_env_u32("GC_SEARCH_SHALLOW", 0u, 64u, &c->searchShallow);                                // test hook: links followed by every position
@@ -703,7 +671,6 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
     c->allLengths = level >= 18 ? 1u : 0u;        // levels 16-17 (the reference: btopt / btultra with searchLog 5) keep the sparse lengths and the two far passes; 18-22 (btultra / btultra2, searchLog 6-9) price every length
     c->farPass2 = (level >= 5 && level != 16 && level != 17) ? 1u : 0u; gc_env_u32("GC_FAR2_PASS", 0u, 1u, &c->farPass2);      // keys of 32 / 24 bytes where the reference searches chains / trees for the LONGEST match: real sources, emulator, 8 MiB:
                                                                                               // level 9 1.118 -> 1.050 x the reference, level 19 1.115 -> 1.097
-    c->reParse = 0u;
     c->laneParse = level >= 16 ? 1u : 0u;         // the reference's btopt .. btultra2 (clevels.h:44-50) price its three repeat offsets at every position; real sources / binaries at level 19
                                                   // (emulator, 4 MiB): 1.109 / 1.124 x the reference with W7, 1.081 / 1.075 with W7L.  Levels 10-15 (the reference: lazy2 / btlazy2) keep W7
     c->lastCodecHint = 0; c->priceMinLen = 3u; c->priceLitCtx = 0u;     // zstd: matches of >= 3 bytes, literals without context (one Huffman table per block)
@@ -923,7 +890,7 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     }
     uint32_t frameBlocks = flzma2_frame_blocks(level);
     c->lazyDepth = level >= 5 ? 2u : 1u;
-    c->halfList = 0; c->mfFast = 0;
+    c->mfFast = 0;
     c->searchShallow = level >= 5 ? 2u : 0u;
     c->searchDepth = level >= 5 ? (level >= 8 ? 16u : 12u) : 0u;    // links followed where a tile has long matches, by the positions that start one (two links elsewhere: gc_mf_deepen_kernel).
                                                                     // Real source text (64 MiB): two links everywhere 1.030 x the reference, six everywhere 1.017 (run r03_depth)
@@ -935,7 +902,6 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     c->shortPlain = level < 7 ? 1u : 0u; c->allLengths = 0u;
     c->smallWin2k = (level == 5 || level == 6) ? 1u : 0u;
     c->farPass2 = level >= 7 ? 1u : 0u; gc_env_u32("GC_FAR2_PASS", 0u, 1u, &c->farPass2);      // keys of 32 / 24 bytes (gc_lz_window.hip MF_FAR2) at the ultra levels
-    c->reParse = 0u;
     c->laneParse = 1u; c->lastCodecHint = 1; c->priceMinLen = 2u; c->priceLitCtx = 7u;
     c->priceParse = level >= 3 ? 1u : 0u;         // the reference's FL2_opt strategy starts at level 3 of its 7-Zip table (fl2_compress.c:52-63); round 3 (run r03_fl2ab): level 3 with
                                                   // the greedy parse was 1.038 x the reference on silesia-like, with the price-based parse 1.002
@@ -1108,7 +1074,7 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     HIPCHK(c, hipMemsetAsync(c->brStage, 0, (size_t)nBlocks * GC_BR_STAGE_STRIDE, c->stream));
     uint32_t frameBlocks = brotli_frame_blocks(level, bpcFinder);
     c->lazyDepth = level >= 7 ? 2u : 1u;
-    c->halfList = 0; c->mfFast = level <= 6 ? 1u : 0u;        // (qualities 5-6 run the far pass on the fast geometry: 0.97-0.99 x the reference at 15 % less time than on the wide one)
+    c->mfFast = level <= 6 ? 1u : 0u;        // (qualities 5-6 run the far pass on the fast geometry: 0.97-0.99 x the reference at 15 % less time than on the wide one)
     // W5b from quality 7: four links (eight from quality 10) for the starts of matches in tiles with long matches, two elsewhere.  Quality 5 stays without it (round 3 measured
     // quality 6 with (8, 0) (run r03_q3): sources 1.084 -> 1.068 x the reference and the Python library 1.024 -> 1.015, but web-text -- config C5's data, whose boilerplate
     // makes most tiles "long" -- 16.6 -> 9.4 GB/s for 0.3 % of its size
@@ -1122,7 +1088,6 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass);                                            // test hook
     c->shortPlain = 0u; c->smallWin2k = 0u; c->allLengths = 0u;
     c->farPass2 = 0u; gc_env_u32("GC_FAR2_PASS", 0u, 1u, &c->farPass2);
-    c->reParse = 0u;
     c->laneParse = 0u; c->lastCodecHint = 2; c->priceMinLen = 3u; c->priceLitCtx = 0u;     // copies of >= 3 bytes (a 2-byte copy at a fresh distance never pays in brotli), one literal code per meta-block
     c->priceParse = level >= 8 ? 1u : 0u;         // the reference parses greedily up to quality 9 (zopfli from 10).  Measured at quality 6
                                                   // (run 28, 64 MiB per corpus): greedy + far pass 0.979-1.002 x the reference at 16.6 GB/s,

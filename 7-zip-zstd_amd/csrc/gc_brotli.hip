@@ -581,13 +581,13 @@ gc_brotli_block_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, const 
             }
         }
     };
-    // ---- one literal tree or thirteen?  Decided on a SAMPLE -- the literals of every fourth tile of 256 commands -- so that a meta-block that stays with one tree (web-text: all
-    //      of them) pays a quarter of the walk; the reference samples 64 bytes in every 4 KiB (br_encode.c:358-375).  The cost of the literals under each choice from the sampled
+    // ---- one literal tree or thirteen?  Decided on a SAMPLE -- the literals of every eighth tile of 256 commands -- so that a meta-block that stays with one tree (web-text: all
+    //      of them) pays an eighth of the walk; the reference samples 64 bytes in every 4 KiB (br_encode.c:358-375).  The cost of the literals under each choice from the sampled
     //      histograms: sum over trees of T log2 T - sum h log2 h (integer logarithm: the same choice on the device and under the emulator), plus what the tree descriptions and
     //      the context map cost (about 7 bits per symbol in use, 48 per tree, 360 for the map) and a margin of 1.5 % (thirteen small codes lose more to whole-bit lengths).
     uint32_t nTrees = 1u;
     if (ctxOk) {
-        constexpr uint32_t EVERY = 4u;
+        constexpr uint32_t EVERY = 8u;
         histCtx(EVERY);
         __syncthreads();
         uint32_t H = 0;

@@ -120,8 +120,7 @@ extern "C" int gc_dpl_prof_read(unsigned long long* out, int reset)
 template <bool REPS, uint32_t MINLEN, bool SAMPLE /* a wave = two blocks: false = all their windows (2 x 32 x 4 KiB), true = a sample (32 x 512 B of each, counted) */>
 __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t frameBlocks, uint32_t phaseArg, uint32_t* __restrict__ dpStat,
                                         uint32_t litCtxArg, const uint32_t* __restrict__ rec, const uint16_t* __restrict__ rec3, const uint16_t* __restrict__ priceTab,
-                                        uint32_t* __restrict__ recOut, uint32_t* __restrict__ winCost, const uint8_t* __restrict__ litPrice,
-                                        uint32_t* __restrict__ dpStatOut /* phase bit 6 (a pass over every window): the symbol counts of THIS pass's paths, per block, for one more pass under prices made from them */)
+                                        uint32_t* __restrict__ recOut, uint32_t* __restrict__ winCost, const uint8_t* __restrict__ litPrice)
 {
     __shared__ unsigned long long sCost[DPL_RC][64];
     __shared__ GcU4 sReps[REPS ? DPL_RR : 1u][64];
@@ -134,7 +133,6 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
     const bool isC = GC_DPL_THREADS == 192u ? role == 2u : isA;   // a third wave takes the literal, the capped rest and the short candidate off wave 0
     const uint32_t litCtxMask = litCtxArg & 0xFFu, hasPrev = litCtxArg >> 31;
     const bool win2k = !SAMPLE && (phaseArg & 16u) != 0u;         // every window of ONE block per wave, 64 x 2 KiB (more, shorter waves: the launch ends with its slowest wave)
-    const bool countB = !SAMPLE && (phaseArg & GC_DP_COUNT) != 0u && dpStatOut != nullptr;      // count the paths of this pass as phase A counts its sample (round 5: the re-priced second pass)
     const bool allLenArg = (phaseArg & GC_DP_ALLLEN) != 0u;       // every length of a candidate is an edge (zstd levels >= 18)
     const bool selective = !SAMPLE && (phaseArg & GC_DP_SELECT) != 0u;      // phase B of the blocks whose sampled paths repeat distances; the others are W7's (gc_mf.h GC_DPS_RICH)
     phaseArg &= 15u;
@@ -178,7 +176,7 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
     for (uint32_t q = 0; q < BPW; q++) {
         const uint32_t bb = q < BPWr ? item * BPWr + q : nBlocks;
         if (bb < nBlocks) { const GcU4* T4 = (const GcU4*)(priceTab + (uint64_t)bb * GC_PRICE_WORDS + GC_PRICE_LEN); GcU4* S4 = (GcU4*)sPrice[q]; for (uint32_t i = lane; i < (GC_PRICE_WORDS - GC_PRICE_LEN) / 8u; i += 64u) S4[i] = T4[i]; }
-        if (phaseA || countB) for (uint32_t i = lane; i < GC_DPS_WORDS; i += 64u) sCnt[q][i] = 0;
+        if (phaseA) for (uint32_t i = lane; i < GC_DPS_WORDS; i += 64u) sCnt[q][i] = 0;
     }
     gc_wave_sync();
     for (uint32_t q = 0; q < BPW; q++) {
@@ -370,9 +368,6 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
         // A newly tracked distance of the NODE is wanted now (the nodes that made it a repeat are the ones about to use it): its first 32 positions are read on
         // the spot -- an exposed memory latency, a few times per hundred nodes and lane -- instead of leaving the next group of nodes without it (the evaluation
         // slices: ROCm shared objects +0.5 % without).  The shadow parse's distances come early; their request channel serves them.
-#ifdef DPL_NOSYNCFILL
-        fillK = DPL_NT;                                            // (experiment: what the fills on the spot cost)
-#endif
         if (fillK < DPL_NT && q0 < N && q0 >= -warm && (uint64_t)((int64_t)q0 + 32) <= tailRoom && (int64_t)q0 + inFrameW >= (int64_t)fillD) {
             const LzW16 o0 = lz_ld16(S + q0, 0), o1 = lz_ld16(S + q0 + 16, 0);
             const LzW16 p0 = lz_ld16(S + (int64_t)q0 - (int64_t)fillD, 0), p1 = lz_ld16(S + (int64_t)q0 - (int64_t)fillD + 16, 0);
@@ -649,7 +644,7 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
                 if (eDist != 0u) {
                     if (!runGoesOn) {                             // first record of the run: what is left after the 64-byte records behind it
                         out = (eDist << 8) | (span - ((span - 1u) & ~63u));
-                        if (phaseA || countB) {
+                        if (phaseA) {
                             atomicAdd(&sCnt[lb][((eCls >= DPL_REP0 && eCls <= DPL_REP0 + 3u) ? GC_DPS_REPLEN : GC_DPS_LEN) + (span < 64u ? span : 64u)], 1u);
                             if (eCls == DPL_NEW) atomicAdd(&sCnt[lb][GC_DPS_SLOT + gc_dist_slot(eDist - 1u)], 1u);
                             else if (eCls == DPL_SREP) atomicAdd(&sCnt[lb][GC_DPS_NSREP], 1u);
@@ -690,38 +685,20 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
             BP[q] = (L >= MINLEN && (r & 0xFFu) >= GC_MIN_MATCH) ? ((r & ~0xFFu) | L) : 0u;
         }
     }
-    if (countB) {                                                  // this pass's counts out (the paths of windows that fell back are counted as they were: a handful)
-        if (n != 0u) atomicAdd(&sCnt[lb][GC_DPS_NLIT], nLitC);
-        gc_wave_sync();
-        for (uint32_t q = 0; q < BPW; q++) {
-            const uint32_t bb = q < BPWr ? item * BPWr + q : nBlocks;
-            if (bb >= nBlocks) continue;
-            uint32_t* C = dpStatOut + (uint64_t)bb * GC_DPS_WORDS;
-            for (uint32_t i = lane; i < GC_DPS_WORDS; i += 64u) { const uint32_t v = sCnt[q][i]; if (v) atomicAdd(&C[i], v); }
-        }
-    }
 }
 
 // one kernel per codec family and grid shape (the shared arrays of dpl_run are per instantiation)
-// (experiment builds: -DDPL_WAVES_PER_EU=n caps the registers so that n waves fit a SIMD -- three waves per group need three)
-#if defined(DPL_WAVES_PER_EU) && !defined(HIPEMU)
-#define DPL_OCC __attribute__((amdgpu_waves_per_eu(DPL_WAVES_PER_EU)))
-#else
-#define DPL_OCC
-#endif
 #define DPL_KERNEL(name, REPS, MINLEN, SAMPLE) \
-extern "C" __global__ void __launch_bounds__(GC_DPL_THREADS) DPL_OCC \
+extern "C" __global__ void __launch_bounds__(GC_DPL_THREADS) \
 name(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t frameBlocks, uint32_t phase, uint32_t* __restrict__ dpStat, uint32_t litCtxMask, \
      const uint32_t* __restrict__ rec, const uint16_t* __restrict__ rec3, const uint16_t* __restrict__ priceTab, uint32_t* __restrict__ recOut, uint32_t* __restrict__ winCost, \
-     const uint8_t* __restrict__ litPrice, uint32_t* __restrict__ dpStatOut) \
-{ dpl_run<REPS, MINLEN, SAMPLE>(src, srcSize, nBlocks, per, frameBlocks, phase, dpStat, litCtxMask, rec, rec3, priceTab, recOut, winCost, litPrice, dpStatOut); }
+     const uint8_t* __restrict__ litPrice) \
+{ dpl_run<REPS, MINLEN, SAMPLE>(src, srcSize, nBlocks, per, frameBlocks, phase, dpStat, litCtxMask, rec, rec3, priceTab, recOut, winCost, litPrice); }
 
 DPL_KERNEL(gc_mf_dpl2_kernel,  true, 2u, false)   // LZMA: every window
 DPL_KERNEL(gc_mf_dpl2s_kernel, true, 2u, true)    // LZMA: the sample of phase A
 DPL_KERNEL(gc_mf_dplz_kernel,  true, 3u, false)   // zstd: its three repeat offsets are the first three of the four kept here (ZSTD_updateRep, zstd_compress_internal.h:818: the same move-to-front); no match below three bytes, no short repeat
 DPL_KERNEL(gc_mf_dplzs_kernel, true, 3u, true)
-DPL_KERNEL(gc_mf_dpl3_kernel,  false, 3u, false)  // brotli (no repeat distances in the programme yet)
-DPL_KERNEL(gc_mf_dpl3s_kernel, false, 3u, true)
 
 // The literal price of every position under its block's table (W6's statistics: literal given the top bits of the byte in front of it), one byte each
 // (prices stop at GC_PRICE_MAX = 240): position-parallel, so the lanes of W7L read four prices per group of nodes instead of holding 4 KiB of table per

@@ -112,13 +112,6 @@ __device__ __forceinline__ uint32_t mf_lds_byte(const uint32_t* sW, uint32_t i) 
 #define MF_BASE  0
 #define MF_FAR   1
 #define MF_SHORT 2
-// MF_HALF = MF_BASE over HALF of the positions, chosen by content (one bit of a hash of the position's 5 bytes, so that both ends of a
-// repeat are listed or neither is) -- zstd levels 3-5: the reference's dfast itself steps over positions once a literal run is under
-// way (zstd_double_fast.c:169-190), and its level-3 tables are 8 x smaller than the ones here.  Half the entries means half of W3's
-// stores and of W4's and W5's work; what it costs -- a match whose first position is not listed is seen a byte or two late -- is
-// partly taken back in W5: a verified candidate is extended one byte BACKWARDS and the longer match is recorded at the position in
-// front if that has no record of its own.
-#define MF_HALF  3
 // MF_FAR2 = one more pass of the far kind with keys of 32 ("long") and 24 ("short") bytes (round 5: zstd levels >= 7; round 6: >= 5; FLZMA2 levels >= 7): in data made of many near-copies of
 // the same text (source trees, archives of similar files) the most recent position with the same 16 bytes is often a copy that diverges a few dozen bytes later, where the
 // reference's chains and trees return the LONGEST match (real sources, zstd level 9 and 19: 1.12 x the reference with 10 % more sequences of the same cost each).
@@ -134,7 +127,6 @@ __device__ __forceinline__ MfKeys mf_keys(const uint32_t* sW, uint32_t q, const 
     if (q < T.len && P + GC_MATCH_CAP + 16u <= T.frameEnd && !r.run) {
         const uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
         uint32_t hL = lz_hash_long(lo, hi), hS = lz_hash_short(lo, hi);
-        if (MODE == MF_HALF && (((hS ^ (hS >> 16)) * 0x85EBCA6Bu) >> 31) != 0u) return r;        // half of the 5-byte contexts, chosen by content: both ends of a repeat are listed or neither
         if (MODE == MF_SHORT) {
             // three equal bytes are not listed in this pass (round 5): the hottest 3-byte keys of machine code and tables (00 00 00, FF FF FF, CC CC CC) sit in ONE partition each,
             // whose last list segment then is the tail of W4 -- 211.9 MB of shared objects at FLZMA2 level 5: this pass 16.5 -> 8.5 ms (the call 103.7 -> 95.5 ms) for +0.003 % size;
@@ -201,11 +193,6 @@ extern "C" __global__ void __launch_bounds__(MF_T)
 MFK(gc_mf_count_short_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per, uint32_t* __restrict__ cnt)
 {
     mf_count_body<MF_SHORT>(src, srcSize, frameBlocks, nTiles, per, cnt);
-}
-extern "C" __global__ void __launch_bounds__(MF_T)
-MFK(gc_mf_count_half_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per, uint32_t* __restrict__ cnt)
-{
-    mf_count_body<MF_HALF>(src, srcSize, frameBlocks, nTiles, per, cnt);
 }
 extern "C" __global__ void __launch_bounds__(MF_T)
 MFK(gc_mf_count_far_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per, uint32_t* __restrict__ cnt)
@@ -307,36 +294,13 @@ __device__ __forceinline__ void mf_scatter_body(const uint8_t* __restrict__ src,
     uint32_t nEnt = 0;
     for (uint32_t w = 0; w < MF_WAVES; w++) nEnt += sWaveTot[w];
     // pass B: stable ranks -> permutation
-#ifdef MF_RANK_BALLOT
-    const uint64_t lt = gc_lanemask_lt();
-#endif
     for (uint32_t r = 0; r < GC_MF_TILE / MF_T; r++) {
         const uint32_t q = qBase + r * 64u + lane;
         const MfKeys k = mf_keys<MODE>(sW, q, T);
-#ifdef MF_RANK_BALLOT
-        uint64_t peers = __ballot(k.ok);
-        if (peers != 0ull) {                                      // uniform
-#pragma unroll
-            for (uint32_t b = 0; b < GC_MF_PART_LOG; b++) {
-                const bool bit = ((k.part >> b) & 1u) != 0u;
-                const uint64_t bal = __ballot(k.ok && bit);
-                peers &= bit ? bal : ~bal;
-            }
-            const uint32_t rank = (uint32_t)__popcll(peers & lt);
-            const uint32_t base = k.ok ? sRun[wave][k.part] : 0u;
-            gc_wave_sync();
-            if (k.ok) {
-                if (rank == 0u) sRun[wave][k.part] = base + (uint32_t)__popcll(peers);
-                sPerm[base + rank] = (uint16_t)q;
-            }
-            gc_wave_sync();
-        }
-#else
         // one returning ds_add per position: the LDS unit serves the lanes that hit one counter in lane order (the property W4's ds_max
         // relies on), lanes are positions, rounds follow each other in program order -- so the value returned is the position's stable rank
         if (k.ok) sPerm[atomicAdd(&sRun[wave][k.part], 1u)] = (uint16_t)q;
         gc_wave_step();
-#endif
     }
     __syncthreads();
     // output: slot j of the sorted tile -> its partition's run in HBM
@@ -357,12 +321,6 @@ MFK(gc_mf_scatter_short_kernel)(const uint8_t* __restrict__ src, uint64_t srcSiz
                            const uint32_t* __restrict__ offs, GcMfEntry* __restrict__ ent)
 {
     mf_scatter_body<MF_SHORT>(src, srcSize, frameBlocks, nTiles, per, offs, ent);
-}
-extern "C" __global__ void __launch_bounds__(MF_T)
-MFK(gc_mf_scatter_half_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
-                          const uint32_t* __restrict__ offs, GcMfEntry* __restrict__ ent)
-{
-    mf_scatter_body<MF_HALF>(src, srcSize, frameBlocks, nTiles, per, offs, ent);
 }
 extern "C" __global__ void __launch_bounds__(MF_T)
 MFK(gc_mf_scatter_far_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
@@ -535,9 +493,6 @@ MFK(gc_mf_link_kernel)(const uint32_t* __restrict__ offs, const GcMfEntry* __res
 #ifndef MFV_B
 #define MFV_B 4u                      // listed positions per thread and round
 #endif
-#ifndef MFV_FAR_TIE
-#define MFV_FAR_TIE 0                 // 1: the far pass too ranks two capped records by what lies behind the cap -- measured (run s13): no size effect, +6 ms on 1 GB of web-text at brotli quality 6; the 32-byte pass keeps the rule
-#endif
 #define MFV_NONE 0xFFFFFFFFu             // sRec: no record written yet (a record's length byte never exceeds GC_MATCH_CAP)
 #define MFV_PAD_AFTER (GC_MATCH_CAP + 32u)                        // staged bytes behind the tile: own side of every compare
 #define MFV_STAGE_WORDS ((MF_STAGE_PAD + GC_MF_TILE + MFV_PAD_AFTER) / 4u)
@@ -554,8 +509,8 @@ __device__ __forceinline__ uint32_t mfv_len16(const LzW16& me, const LzW16& cw, 
     return len >= minLen ? len : 0u;
 }
 
-// MF_HALF: the 16-byte windows start MFV_BACK bytes IN FRONT of the position and of the candidate.  Returns the common prefix of the bytes
-// from the position on (0..13; 0 if below GC_MIN_MATCH or maxLen == 0) and how many of the bytes in front agree as well (0..3, counted backwards).
+// Catch-up (BACK): the 16-byte windows start MFV_BACK bytes IN FRONT of the position and of the candidate.  Returns the common prefix of the bytes
+// from the position on (0..13; 0 if below minLen or maxLen == 0) and how many of the bytes in front agree as well (0..3, counted backwards).
 #define MFV_BACK 3u
 __device__ __forceinline__ uint32_t mfv_len13(const LzW16& me, const LzW16& cw, uint32_t maxLen, uint32_t& ext, uint32_t minLen = GC_MIN_MATCH)
 {
@@ -574,7 +529,7 @@ __device__ __forceinline__ uint32_t mfv_len13(const LzW16& me, const LzW16& cw, 
 // The verification of ONE tile: fills sRec[0 .. T.len) (LDS) and ends with a workgroup barrier.  Shared by the stand-alone verify
 // kernels (records -> HBM) and the fused verify + parse kernel (records never leave the CU).  Called by all MFV_T threads.
 // BACK (round 6) = "catch-up": a verified candidate is also compared over the (up to MFV_CATCH = 3) bytes IN FRONT of the position and of the candidate (the 16-byte windows of
-// both start three bytes early, as MF_HALF's do: no extra memory request -- a second, 4-byte read per candidate cost brotli quality 6 on web-text 14.5 -> 12.1 GB/s, run s2), and the positions
+// both start three bytes early: no extra memory request -- a second, 4-byte read per candidate cost brotli quality 6 on web-text 14.5 -> 12.1 GB/s, run s2), and the positions
 // in front that the match covers as well take it over, lengthened, if that beats their own record by gain -- ZSTD_compressBlock_doubleFast's and the lazy matchers' catch-up
 // loop (`while (ip > anchor && match > lowest && ip[-1] == match[-1]) { ip--; match--; mLength++; }`, C/zstd/zstd_double_fast.c:255-262, zstd_lazy.c:1640-1646), which here has
 // to be a property of the RECORDS because the parse does not exist yet: the most recent earlier position with the same 5 / 8 bytes is often a short match that the greedy parse
@@ -591,8 +546,7 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
                     const uint32_t* __restrict__ changedIn = nullptr /* merging passes: bitmap of the positions whose record a kernel between the passes has changed (W5b) */)
 {
     constexpr bool FAR = MODE == MF_FAR || MODE == MF_FAR2 || MODE == MF_SHORT;      // a merging pass
-    constexpr bool HALF = MODE == MF_HALF;                        // even positions only; matches are extended one byte backwards
-    constexpr bool SHIFT = HALF || BACK;                          // the 16-byte compare windows start MFV_BACK bytes in front of the position and of the candidate (mfv_len13)
+    constexpr bool SHIFT = BACK;                                  // the 16-byte compare windows start MFV_BACK bytes in front of the position and of the candidate (mfv_len13)
     constexpr uint32_t MINLEN = MODE == MF_SHORT ? 3u : GC_MIN_MATCH;
     constexpr uint32_t LONGLEN = MODE == MF_SHORT ? 4u : ((MODE == MF_FAR || MODE == MF_FAR2) ? 16u : 8u);   // a verified long candidate has this many bytes
     const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
@@ -615,7 +569,7 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
         const uint32_t* D = changedIn != nullptr ? changedIn + (T.tileStart >> 5) : (const uint32_t*)nullptr;      // (a changed record concerns its own row and the one 64 behind it: two words on)
         const uint32_t nW = (T.len + 31u) / 32u;
         for (uint32_t i = t; i < GC_MF_TILE / 32u + 4u; i += MFV_T) sDirty[i] = D != nullptr ? ((i < nW ? D[i] : 0u) | ((i >= 2u && i - 2u < nW) ? D[i - 2u] : 0u)) : 0u;
-    } else if (!HALF) {                                           // "no record yet": what the listed positions leave behind is exactly the unlisted ones
+    } else {                                                      // "no record yet": what the listed positions leave behind is exactly the unlisted ones
         GcU4 none; none.x = none.y = none.z = none.w = MFV_NONE;
         GcU4* S4 = (GcU4*)sRec;
         for (uint32_t i = t; i < GC_MF_TILE / 4u; i += MFV_T) S4[i] = none;
@@ -636,16 +590,14 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
     const uint32_t nBlk = (uint32_t)((srcSize - blockBase) < GC_ZSTD_BLOCK_MAX ? (srcSize - blockBase) : GC_ZSTD_BLOCK_MAX);
     const uint32_t pTile = (uint32_t)(T.tileStart - blockBase);
     const uint32_t wTile = (uint32_t)(T.tileStart - T.frameStart);
-    // unlisted positions: byte runs match at distance 1, the tail of the frame does not match at all.  (MF_HALF: first, so that the
-    // backward extension below finds every record that is not its own in place; odd positions without a run start out empty.)
+    // unlisted positions: byte runs match at distance 1, the tail of the frame does not match at all
     auto unlisted = [&]() {
         for (uint32_t q = t; q < T.len; q += MFV_T) {
-            if (!FAR && !HALF && sRec[q] != MFV_NONE) continue;     // a listed position: its record is in place (nineteen in twenty on text)
+            if (!FAR && sRec[q] != MFV_NONE) continue;              // a listed position: its record is in place (nineteen in twenty on text)
             const uint64_t x = mf_lds_ld64(sW, q + MF_STAGE_PAD);
             const bool run = T.tileStart + q > T.frameStart && ((x << 8) | (uint64_t)mf_lds_byte(sW, q + MF_STAGE_PAD - 1u)) == x;
             const bool windowed = T.tileStart + q + GC_MATCH_CAP + 16u <= T.frameEnd;
-            if (HALF) sExt[q] = 0;
-            if (windowed && !run) { if (HALF) sRec[q] = 0u; continue; }      // listed (MF_HALF: or not; a listed position overwrites this)
+            if (windowed && !run) continue;                       // listed
             const uint32_t p = pTile + q;
             uint32_t len = 0;
             if (run && windowed && p + 8u <= nBlk) {              // both sides of the compare lie in the staged tile
@@ -662,7 +614,6 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
             sRec[q] = len ? ((1u << 8) | len) : 0u;
         }
     };
-    if (HALF) { unlisted(); __syncthreads(); }
     // listed positions, MFV_B per thread and round, stage by stage over small arrays so that the entry loads, then the long
     // candidates, then the short candidates that are still needed are in flight together
     // Every wave takes a contiguous share of the tile's flat list of entries, 64 * MFV_B of them per round.  The run (= partition) of an index
@@ -740,13 +691,12 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
             if (live[k]) {
                 const uint32_t nr = len ? (((pw - (bestC[k] - 1u)) << 8) | len) : 0u;
                 if (MODE == MF_BASE && len == GC_MATCH_CAP) sWaveTot[1] = 0xFFFFFFFFu;      // "the tile has a capped record": the word held a count (dead since the run offsets were made), never this value
-                if (HALF && nr != 0u) sExt[q[k]] = (uint8_t)bestExt[k];
                 const uint32_t xb = (BACK && nr != 0u) ? (((bestExt[k] & 1u) << 7) | ((bestExt[k] & 2u) << 30)) : 0u;      // how far the match reaches in front of the position (taken out again below)
                 if (!FAR) sRec[q[k]] = nr | xb;
                 else if (nr) {
                     const uint32_t old = sRec[q[k]];
                     bool take = old == 0u || lz_gain(len, nr >> 8) > lz_gain(old & 0xFFu, old >> 8);
-                    if ((MODE == MF_FAR2 || (MODE == MF_FAR && MFV_FAR_TIE)) && old != 0u && len == GC_MATCH_CAP && (old & 0xFFu) == GC_MATCH_CAP && (old >> 8) != (nr >> 8)) {
+                    if (MODE == MF_FAR2 && old != 0u && len == GC_MATCH_CAP && (old & 0xFFu) == GC_MATCH_CAP && (old >> 8) != (nr >> 8)) {
                         // both records fill the cap: the gain only sees the distances, and the nearer copy is the one that diverges first in a tree of near-copies.  Compare up to
                         // 64 bytes BEHIND the cap at both distances (inside the frame) and keep the one that goes on further (the nearer one if both go on as far).
                         const uint64_t frameLen = T.frameEnd - T.frameStart;
@@ -768,22 +718,7 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
         }
     }
     VP_PHASE(prof, *tprev, 1);                                     // listed positions
-    if (!FAR && !HALF) { __syncthreads(); unlisted(); }            // (the pass reads which records are in place)
-    if (HALF) {
-        // positions without a record of their own take the match of the nearest listed position behind them that reaches back to them
-        // (only records of listed positions carry sExt > 0, and those are not written here: the result does not depend on thread order)
-        __syncthreads();
-        for (uint32_t x = t; x < T.len; x += MFV_T) {
-            if (sRec[x] != 0u) continue;
-            uint32_t nr = 0;
-#pragma unroll
-            for (uint32_t j = MFV_BACK; j >= 1u; j--) {
-                const uint32_t y = x + j;
-                if (y < T.len && sExt[y] >= j) { const uint32_t r = sRec[y], l = (r & 0xFFu) + j; nr = (r & ~0xFFu) | (l < GC_MATCH_CAP ? l : GC_MATCH_CAP); }   // (the nearest one is visited last and wins)
-            }
-            if (nr != 0u) sRec[x] = nr;
-        }
-    }
+    if (!FAR) { __syncthreads(); unlisted(); }                     // (the pass reads which records are in place)
     if (BACK) {
         // catch-up: position x takes over the record of x + j (j <= 3) lengthened by j where that record reaches back to x and beats x's own by gain.  Every decision is taken
         // from the records as the passes above left them: a wave walks its share of the tile upwards, 64 positions per step (what a step looks at beyond its own 64 positions the
@@ -837,14 +772,10 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
     // meet (every 1 KiB), which keeps the result independent of the order in which the waves run.
     // (every pass that merges candidates by gain may have replaced a continued record by a nearer one; the first pass knows whether it wrote a capped record at all --
     //  byte runs aside, which keep their distance 1 anyway -- and most tiles of ordinary text have none: they skip the nine barriers below)
-#ifdef MFV_CONT_OFF
-    if (false) {
-#else
     // (round 5: a merging pass only looks again at rows whose record, or the record 64 in front, CHANGED in this pass -- one bit per position.  What the walk found again and
     //  again in every pass were the rows whose continuation FAILS: the same compares, the same memory round trips as in the pass before.  FLZMA2 level 5 on 211.9 MB of shared
     //  objects spent 17.8 ms in the pass with 4- / 3-byte keys against 4.8 ms on the Silesia stand-in; without the continuation there real sources come out 1.6 % larger.)
     if ((MODE == MF_BASE && sWaveTot[1] == 0xFFFFFFFFu) || MODE == MF_FAR || MODE == MF_FAR2 || MODE == MF_SHORT) {
-#endif
         constexpr uint32_t NSUB = MFV_T / 64u;
         const uint32_t subLen = ((T.len + NSUB * 64u - 1u) / (NSUB * 64u)) * 64u;
         const uint32_t sBeg = wave * subLen, sEnd = sBeg + subLen < T.len ? sBeg + subLen : T.len;
@@ -901,38 +832,10 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
                 q += 128u;
             }
         };
-#ifdef MFV_CONT_ROWWISE                // (check builds: the row-by-row walk of rounds 3-4 -- one round trip per row -- must give the same records)
-        auto cont = [&](uint32_t q) -> bool {
-            const uint32_t prev = sRec[q - GC_MATCH_CAP];
-            if ((prev & 0xFFu) != GC_MATCH_CAP) return false;
-            const uint32_t d = prev >> 8, cur = sRec[q];
-            if ((cur >> 8) == d || d > wTile + q) return false;
-            if (T.tileStart + q + GC_MATCH_CAP + 16u > T.frameEnd) return false;
-            const uint32_t p = pTile + q;
-            if (p + 8u > nBlk) return false;
-            uint32_t maxLen = (nBlk - p) < GC_MATCH_CAP ? (nBlk - p) : GC_MATCH_CAP;
-            if (TILE_LIMIT && maxLen > T.len - q) maxLen = T.len - q;
-            const uint64_t cpos = (uint64_t)(wTile + q) - d;
-            const bool h1 = 16u < maxLen, h2 = 32u < maxLen, h3 = 48u < maxLen;
-            const uint32_t len = piece4(q, cpos, maxLen, lz_ld16(wsrc, cpos), lz_ld16(wsrc, cpos + (h1 ? 16u : 0u)), lz_ld16(wsrc, cpos + (h2 ? 32u : 0u)), lz_ld16(wsrc, cpos + (h3 ? 48u : 0u)));
-            if (len < MINLEN || len + 2u < (cur & 0xFFu)) return false;
-            sRec[q] = (d << 8) | len;
-            return true;
-        };
-        for (uint32_t q = sBeg + GC_MATCH_CAP + lane; q < sEnd; q += 64u) cont(q);
-        __syncthreads();
-        for (uint32_t sIdx = 1; sIdx < NSUB; sIdx++) {
-            if (wave == sIdx) { uint32_t q = sBeg + lane; while (q < sEnd && cont(q)) q += 64u; }
-            __syncthreads();
-        }
-        (void)walk;
-        if (false) {
-#endif
         // phase A: every wave inside its share, from the share's second row on (the first row looks back into the share in front)
         walk(sBeg + GC_MATCH_CAP + lane, sEnd, false);
         __syncthreads();
         // phase B: the first rows, share by share in order (what a share looks back at is final), followed down the share while records change
-#ifndef MFV_CONT_NO_B                 // (experiment builds, tools/build_variants.py: chains cut where the shares meet)
         // Round 5: one share at a time meant seven memory round trips one after the other with seven of the eight waves waiting (real sources: 37 K of the tile's ~150 K
         // cycles, run s7) although a share's first row hardly ever depends on the repair of the share above: that needs a chain that runs through ALL of that share.
         // So every share first repairs its first row (and what follows from it) AT THE SAME TIME, from the record above as phase A left it -- read before anybody writes --
@@ -946,10 +849,6 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
             if (wave == sIdx && qFirst < sEnd && sRec[qFirst - GC_MATCH_CAP] != prevA) walk(qFirst, sEnd, true);
             __syncthreads();
         }
-#endif
-#ifdef MFV_CONT_ROWWISE
-        }
-#endif
     }
 }
 
@@ -961,7 +860,7 @@ __device__ __forceinline__ void mf_verify_body(const uint8_t* __restrict__ src, 
 {
     __shared__ uint32_t sW[MFV_STAGE_WORDS];
     __shared__ uint32_t sRec[GC_MF_TILE];
-    __shared__ __attribute__((aligned(16))) uint8_t sExt[MODE == MF_HALF ? GC_MF_TILE : ((MODE == MF_FAR || MODE == MF_FAR2 || MODE == MF_SHORT) ? GC_MF_TILE / 8u + 16u : 4u)];   // MF_HALF: bytes in front of a listed position that its match covers as well; merging passes: one bit per position, "its record or the one 64 in front changed in this pass"
+    __shared__ __attribute__((aligned(16))) uint8_t sExt[(MODE == MF_FAR || MODE == MF_FAR2 || MODE == MF_SHORT) ? GC_MF_TILE / 8u + 16u : 4u];   // merging passes: one bit per position, "its record or the one 64 in front changed in this pass"
     __shared__ uint32_t sStart[GC_MF_PARTS], sLocal[GC_MF_PARTS + 1u];
     __shared__ uint32_t sWaveTot[GC_MF_PARTS / 64u];
     const uint32_t t = threadIdx.x;
@@ -969,7 +868,7 @@ __device__ __forceinline__ void mf_verify_body(const uint8_t* __restrict__ src, 
     if (tile >= nTiles) return;
     const MfTile T = mf_tile(tile, frameBlocks, srcSize);
     if (T.len == 0u || !T.own) return;                            // (overlapping frames: the tiles a frame shares with the one in front have their records from that one)
-    mf_verify_tile<MODE, false, MODE != MF_HALF>(T, src, srcSize, frameBlocks, offs, ent, recIn, sW, sRec, sExt, sStart, sLocal, sWaveTot, nullptr, nullptr, changedIn);
+    mf_verify_tile<MODE, false, true>(T, src, srcSize, frameBlocks, offs, ent, recIn, sW, sRec, sExt, sStart, sLocal, sWaveTot, nullptr, nullptr, changedIn);
     // records out: 16 bytes per lane, full lines
     GcU4* R4 = (GcU4*)(rec + T.tileStart);
     const GcU4* S4 = (const GcU4*)sRec;
@@ -980,12 +879,6 @@ MFK(gc_mf_verify_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint
                     const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, uint32_t* __restrict__ rec)
 {
     mf_verify_body<MF_BASE>(src, srcSize, frameBlocks, nTiles, per, offs, ent, rec, rec);
-}
-extern "C" __global__ void __launch_bounds__(MFV_T)
-MFK(gc_mf_verify_half_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
-                         const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, uint32_t* __restrict__ rec)
-{
-    mf_verify_body<MF_HALF>(src, srcSize, frameBlocks, nTiles, per, offs, ent, rec, rec);
 }
 extern "C" __global__ void __launch_bounds__(MFV_T)
 MFK(gc_mf_verify_far_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
@@ -1136,8 +1029,8 @@ __device__ __forceinline__ uint32_t pz_exit(uint32_t nxt)
 
 // ------------------------------------------------------------------------------------------------ W5 + W6 fused: verify + parse
 // The levels that parse the first pass's records as they are (no far pass, no link following, no price-based parse) never need the
-// records in HBM: one workgroup per BLOCK takes the block's tiles in order, verifies a tile into LDS (mf_verify_tile) and parses it
-// right there.  The parse of a tile is W6's scheme at tile scale -- every wave composes the exit maps of its 16 segments, the maps
+// records in HBM: a tile is verified into LDS (mf_verify_tile) and parsed right there (rounds 2-3 had one workgroup per BLOCK take the block's
+// tiles in order; since round 3 every tile has a workgroup of its own, below).  The parse of a tile is W6's scheme at tile scale -- every wave composes the exit maps of its 16 segments, the maps
 // are chained from the lane at which the path entered the tile, every wave walks its segments from its real entry -- and because the
 // tiles are taken in order the entry lane, the sequence count and the literal count simply carry over from tile to tile: no group
 // maps, no second reading of the records.  Literal bytes come from the staged tile.  The lazy look-ahead stops at the tile's end
@@ -1147,117 +1040,11 @@ __device__ __forceinline__ uint32_t pz_exit(uint32_t nxt)
 #define VP_WAVES   (MFV_T / 64u)
 #define VP_SEGS    (GC_MF_TILE / 64u)                            // segments per tile
 #define VP_SPW     (VP_SEGS / VP_WAVES)                          // segments per wave (16 in both geometries)
-#ifdef VP_MIN_WAVES
-#elif defined(GC_MF_FAST)
+#if defined(GC_MF_FAST)
 #define VP_MIN_WAVES 6                                           // three workgroups of 512 per CU (LDS allows three): <= 80 VGPRs
 #else
 #define VP_MIN_WAVES 4
 #endif
-extern "C" __global__ void __launch_bounds__(MFV_T, VP_MIN_WAVES)
-MFK(gc_mf_vparse_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nBlocks, uint32_t per, uint32_t lazy,
-                    const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent,
-                    GcSeqRaw* __restrict__ seqRaw, uint8_t* __restrict__ lit, GcBlockMeta* __restrict__ meta,
-                    unsigned long long* __restrict__ prof /* optional phase profile: slots 0 stage, 1 listed, 2 unlisted, 3 exit maps, 4 entry chain, 5 walk, 6 emit */)
-{
-    __shared__ uint32_t sW[MFV_STAGE_WORDS];
-    __shared__ uint32_t sRec[GC_MF_TILE];
-    __shared__ uint8_t sExt[4u];
-    // verify: the tile's run table; parse: one byte per position, take << 7 | next position (segment-relative, <= 127).  (LDS is handed out in
-    // granules of 1280 bytes: three workgroups per CU need <= 53 760 bytes each, hence the shared space.)
-    __shared__ uint32_t sAux[GC_MF_TILE / 4u];
-    uint32_t* sStart = sAux; uint32_t* sLocal = sAux + GC_MF_PARTS; uint32_t* sWaveTot = sAux + 2u * GC_MF_PARTS + 1u;
-    uint8_t* sNxt = (uint8_t*)sAux;
-    static_assert((2u * GC_MF_PARTS + 1u + GC_MF_PARTS / 64u) * 4u <= GC_MF_TILE, "the run table fits the parse's byte array");
-    __shared__ uint8_t  sExitW[VP_WAVES][64];                     // exit lane of a wave's 16 segments for every entry lane
-    __shared__ uint64_t sMaskSeq[VP_SEGS], sMaskLit[VP_SEGS];
-    __shared__ uint32_t sCntSeq[VP_WAVES], sCntLit[VP_WAVES];
-    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
-    const uint32_t b = mf_item(blockIdx.x, per);
-    if (b >= nBlocks) return;
-    const uint64_t base = (uint64_t)b * GC_ZSTD_BLOCK_MAX;
-    GcSeqRaw* mySeq = seqRaw + (uint64_t)b * GC_MAX_SEQ_PER_BLOCK;
-    uint8_t* myLit = lit + (uint64_t)b * GC_ZSTD_BLOCK_MAX;
-    uint32_t entry = 0, seqRun = 0, litRun = 0;                   // carried from tile to tile (uniform)
-    const uint64_t lt = gc_lanemask_lt();
-    unsigned long long tprev = prof ? gc_clock() : 0ull;
-    for (uint32_t ti = 0; ti < GC_MF_TILES_PER_BLOCK; ti++) {
-        entry = gc_uniform(entry); seqRun = gc_uniform(seqRun); litRun = gc_uniform(litRun);      // (scalar registers)
-        const MfTile T = mf_tile(gc_uniform(b * GC_MF_TILES_PER_BLOCK + ti), frameBlocks, srcSize);
-        if (T.len == 0u) break;                                   // (uniform: the block ends here)
-        mf_verify_tile<MF_BASE>(T, src, srcSize, frameBlocks, offs, ent, nullptr, sW, sRec, sExt, sStart, sLocal, sWaveTot, prof, &tprev);
-        const uint32_t n = T.len;
-        VP_PHASE(prof, tprev, 2);
-        // ---- exit map of this wave's segments
-        const uint32_t seg0 = wave * VP_SPW;
-        {
-            uint32_t comp = lane;
-#pragma unroll 1
-            for (uint32_t k = 0; k < VP_SPW; k++) {
-                const uint32_t seg = seg0 + k;
-                if (seg * 64u >= n) break;                        // (uniform) past the end: the identity
-                const PzSeg s = pz_seg(sRec, seg * 64u + lane, n, lane, lazy);
-                sNxt[seg * 64u + lane] = (uint8_t)(s.nxt | (s.take ? 0x80u : 0u));      // (the walk below reads this instead of deciding again)
-                const uint32_t ex = pz_exit(s.nxt) - 64u;
-                comp = __shfl(ex, (int)comp);
-            }
-            sExitW[wave][lane] = (uint8_t)comp;
-        }
-        __syncthreads();
-        VP_PHASE(prof, tprev, 3);
-        // ---- real entry lane of this wave: the tile's entry chained through the waves in front (every wave for itself: <= 15 LDS reads)
-        uint32_t e = entry;
-        for (uint32_t w = 0; w < wave; w++) e = sExitW[w][e];
-        e = gc_uniform(e);
-        uint32_t exitAll = e;                                     // ... and the lane at which the path enters the next tile
-        for (uint32_t w = wave; w < VP_WAVES; w++) exitAll = sExitW[w][exitAll];
-        VP_PHASE(prof, tprev, 4);
-        // ---- walk the segments from the real entry: path masks + counts
-        uint32_t nS = 0, nL = 0;
-#pragma unroll 1
-        for (uint32_t k = 0; k < VP_SPW; k++) {
-            const uint32_t seg = seg0 + k;
-            if (seg * 64u >= n) break;
-            const uint32_t p = seg * 64u + lane;
-            const uint32_t nb = sNxt[p], nxt = nb & 0x7Fu;
-            uint64_t path = 0;
-            uint32_t c = e;
-            while (c < 64u) { path |= 1ull << c; c = gc_readlane(nxt, c); }
-            e = c - 64u;
-            const uint64_t takeMask = __ballot((nb & 0x80u) != 0u), inMask = __ballot(p < n);
-            const uint64_t mS = path & takeMask, mL = path & ~takeMask & inMask;
-            if (lane == 0) { sMaskSeq[seg] = mS; sMaskLit[seg] = mL; }
-            nS += (uint32_t)__popcll(mS); nL += (uint32_t)__popcll(mL);
-        }
-        if (lane == 0) { sCntSeq[wave] = nS; sCntLit[wave] = nL; }
-        __syncthreads();
-        VP_PHASE(prof, tprev, 5);
-        uint32_t sBefore = 0, lBefore = 0, sAll = 0, lAll = 0;
-        for (uint32_t w = 0; w < VP_WAVES; w++) {
-            const uint32_t cs = sCntSeq[w], cl = sCntLit[w];
-            if (w < wave) { sBefore += cs; lBefore += cl; }
-            sAll += cs; lAll += cl;
-        }
-        // ---- emit
-        uint32_t sr = seqRun + sBefore, lr = litRun + lBefore;
-#pragma unroll 1
-        for (uint32_t k = 0; k < VP_SPW; k++) {
-            const uint32_t seg = seg0 + k;
-            if (seg * 64u >= n) break;
-            const uint64_t mS = sMaskSeq[seg], mL = sMaskLit[seg];
-            const uint32_t q = seg * 64u + lane;
-            const uint32_t myLitRank = lr + (uint32_t)__popcll(mL & lt);
-            if ((mS >> lane) & 1ull) { GcSeqRaw r; r.litRank = myLitRank; r.offml = sRec[q]; mySeq[sr + (uint32_t)__popcll(mS & lt)] = r; }
-            if ((mL >> lane) & 1ull) myLit[myLitRank] = (uint8_t)mf_lds_byte(sW, q + MF_STAGE_PAD);
-            sr += (uint32_t)__popcll(mS); lr += (uint32_t)__popcll(mL);
-        }
-        entry = exitAll; seqRun += sAll; litRun += lAll;
-        __syncthreads();                                          // the next tile overwrites sW / sRec / the masks
-        VP_PHASE(prof, tprev, 6);
-    }
-    if (t == 0) { GcBlockMeta m; m.nSeqRaw = seqRun; m.nLit = litRun; meta[b] = m; }
-    (void)base;
-}
-
 // ------------------------------------------------------------------------------------------------ W5 + W6 fused, one workgroup per TILE
 // The same two stages with the tiles of a block taken by different workgroups AT THE SAME TIME, as W5 takes them: neighbouring tiles run
 // on the same XCD at the same moment, so the candidate windows of one are the input the others have just staged (an L2 hit), where the

@@ -151,7 +151,6 @@ static inline GcMfGeom gc_mf_geom(uint64_t n, uint32_t frameArg, bool fast)
 #endif
 #define GC_DP_SELECT    32u
 #define GC_DP_ALLLEN    128u              // W7L (zstd): every length of a candidate is an edge, not only the short ones and the last four (gc_lz_dpl.hip relax())
-#define GC_DP_COUNT     64u               // W7L, a pass over every window: count the symbols of its paths (per block) for one more pass under prices made from them
 #define GC_DPS_RICH(C)  ((C)[GC_DPS_NMAT] != 0u && ((C)[GC_DPS_NREP] + (C)[GC_DPS_NSREP] + (C)[GC_DPS_NREP1] + (C)[GC_DPS_NREP2] + (C)[GC_DPS_NREP3]) * 20u >= (C)[GC_DPS_NMAT])
 #define GC_SHORT_NONE   0xFFFFu            // W5s -> W7: uint16 per position, (distance - 1) << 4 | (length - 2), or none
 

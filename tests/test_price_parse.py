@@ -209,17 +209,6 @@ def test_emu_long_key_pass_decodes_and_does_not_lose(O, pkg, emu_lib_path, monke
     assert len(on) <= len(off) + len(off) // 400, (len(on), len(off))
 
 
-@pytest.mark.parametrize("codec,level", [("flzma2", 5), ("zstd", 19)])
-def test_emu_repriced_second_pass_decodes(O, pkg, emu_lib_path, monkeypatch, codec, level):
-    """Hook GC_DP_REPARSE=1: W7L's pass over every window counts its own paths and runs once more under prices made from them (measured in round 5: nothing to gain, so it
-    is off; the path stays exercised)."""
-    x = np.concatenate([O.corpus("silesia-like", 2 * BLK + 999), O.corpus("text-zipf", BLK)])
-    plain = _code(O, pkg, codec, level, x, monkeypatch, None, lib_path=emu_lib_path)
-    monkeypatch.setenv("GC_DP_REPARSE", "1")
-    again = _code(O, pkg, codec, level, x, monkeypatch, None, lib_path=emu_lib_path)
-    assert abs(len(again) - len(plain)) < len(plain) // 50
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize("codec,level", [("flzma2", 5), ("zstd", 19)])
 def test_gpu_bytes_equal_emulator_bytes_with_overlapping_frames(O, pkg, emu_lib_path, gpu_ok, gpu_hooks_kw, monkeypatch, codec, level):
@@ -230,11 +219,3 @@ def test_gpu_bytes_equal_emulator_bytes_with_overlapping_frames(O, pkg, emu_lib_
     assert np.array_equal(g, e)
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("codec,level", [("flzma2", 5), ("zstd", 19)])
-def test_gpu_bytes_equal_emulator_bytes_with_the_repriced_second_pass(O, pkg, emu_lib_path, gpu_ok, gpu_hooks_kw, monkeypatch, codec, level):
-    x = np.concatenate([O.corpus("silesia-like", 2 * BLK + 999), O.corpus("text-zipf", BLK)])
-    monkeypatch.setenv("GC_DP_REPARSE", "1")
-    g = _code(O, pkg, codec, level, x, monkeypatch, None, **gpu_hooks_kw)
-    e = _code(O, pkg, codec, level, x, monkeypatch, None, lib_path=emu_lib_path)
-    assert np.array_equal(g, e)
