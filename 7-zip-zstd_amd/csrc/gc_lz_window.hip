@@ -868,7 +868,8 @@ __device__ __forceinline__ void mf_verify_body(const uint8_t* __restrict__ src, 
     if (tile >= nTiles) return;
     const MfTile T = mf_tile(tile, frameBlocks, srcSize);
     if (T.len == 0u || !T.own) return;                            // (overlapping frames: the tiles a frame shares with the one in front have their records from that one)
-    mf_verify_tile<MODE, false, true>(T, src, srcSize, frameBlocks, offs, ent, recIn, sW, sRec, sExt, sStart, sLocal, sWaveTot, nullptr, nullptr, changedIn);
+    // (catch-up in every pass but the one with 4- / 3-byte keys: there it bought < 0.01 % -- FLZMA2 5 / 7 on the Silesia stand-in, shared objects, text, emulator -- for a millisecond per 212 MB)
+    mf_verify_tile<MODE, false, MODE != MF_SHORT>(T, src, srcSize, frameBlocks, offs, ent, recIn, sW, sRec, sExt, sStart, sLocal, sWaveTot, nullptr, nullptr, changedIn);
     // records out: 16 bytes per lane, full lines
     GcU4* R4 = (GcU4*)(rec + T.tileStart);
     const GcU4* S4 = (const GcU4*)sRec;
