@@ -51,6 +51,7 @@ extern "C" __global__ void gc_mf_verify_kernel(const uint8_t*, uint64_t, uint32_
 extern "C" __global__ void gc_mf_count_short_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
 extern "C" __global__ void gc_mf_scatter_short_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
 extern "C" __global__ void gc_mf_verify_short_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, const uint32_t*, uint32_t*, const uint32_t*);
+extern "C" __global__ void gc_mf_verify_shortb_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, const uint32_t*, uint32_t*, const uint32_t*);
 extern "C" __global__ void gc_mf_count_far_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
 extern "C" __global__ void gc_mf_scatter_far_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
 extern "C" __global__ void gc_mf_verify_far_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
@@ -66,6 +67,7 @@ extern "C" __global__ void gc_mf_verify_kernel_p8(const uint8_t*, uint64_t, uint
 extern "C" __global__ void gc_mf_count_short_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
 extern "C" __global__ void gc_mf_scatter_short_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
 extern "C" __global__ void gc_mf_verify_short_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, const uint32_t*, uint32_t*, const uint32_t*);
+extern "C" __global__ void gc_mf_verify_shortb_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, const uint32_t*, uint32_t*, const uint32_t*);
 extern "C" __global__ void gc_mf_count_far_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t*);
 extern "C" __global__ void gc_mf_scatter_far_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcMfEntry*);
 extern "C" __global__ void gc_mf_verify_far_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, uint32_t*);
@@ -495,8 +497,10 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
         {   uint32_t* ticket_ = c->mfTicket + part * 16u + linkLaunch++;
             const uint32_t gridS = nListsS * GC_MF_LINK_SEGS < c->nCU * linkWpc ? nListsS * GC_MF_LINK_SEGS : c->nCU * linkWpc;
             GC_LAUNCH(MFSEL(gc_mf_link_kernel), gridS, 64, st, (const uint32_t*)cntS, (const GcMfEntry*)ent, ent2, gs.tilesPerFrame, gs.frameBytes, nListsS, ticket_); }
-        GC_LAUNCH(MFSEL(gc_mf_verify_short_kernel), perTs * GC_XCDS, gs.verifyT, st, src, (uint64_t)n, fbS, gs.nTiles, perTs, (const uint32_t*)cntS,
+        if (c->shortPlain) GC_LAUNCH(MFSEL(gc_mf_verify_short_kernel), perTs * GC_XCDS, gs.verifyT, st, src, (uint64_t)n, fbS, gs.nTiles, perTs, (const uint32_t*)cntS,
                   (const GcMfEntry*)ent2, (const uint32_t*)rec, recN, (const uint32_t*)chg);
+        else GC_LAUNCH(MFSEL(gc_mf_verify_shortb_kernel), perTs * GC_XCDS, gs.verifyT, st, src, (uint64_t)n, fbS, gs.nTiles, perTs, (const uint32_t*)cntS,
+                  (const GcMfEntry*)ent2, (const uint32_t*)rec, recN, (const uint32_t*)chg);      // (with the catch-up: gc_lz_window.hip)
         recDp = recN;
     }
     HIPCHK(c, hipEventRecord(ev[5], st));
@@ -620,13 +624,13 @@ extern "C" int gc_mf_pass_timing(gc_ctx* c, float ms[4])
 // Every level runs the windowed finder over 8 MiB frames (round 3).  Levels 1-2 used the block-local finder before -- a 128 KiB window against the
 // 512 KiB / 1 MiB windows of the reference's levels 1 / 2 (clevels.h:26-27): 1.026 x its level 1 on text, 1.085 x its level 2 (run r03_levels).
 // The block-local kernel K1 still serves inputs of one block.
-static uint32_t zstd_frame_blocks(int level) { (void)level; return GC_MF_MAX_FRAME_BLOCKS; }
+static uint32_t zstd_frame_blocks(int level) { return level >= 20 ? GC_MF_WIDE_MAX_FRAME_BLOCKS : GC_MF_MAX_FRAME_BLOCKS; }       // (round 6: 16 MiB windows at 20-22 -- the reference: windowLog 25-27, clevels.h:48-50)
 // Levels 16-22: the finder's frames overlap (gc_mf.h "Overlapping frames") inside groups that are the zstd frames.  The reference: windowLog 22 at level 16-17, 23 at 18-19,
 // 25 / 26 / 27 at 20 / 21 / 22 (clevels.h:44-50), one frame, ZSTDMT jobs of four windows overlapping by one (zstdmt_compress.c:741-747).  Here the window stays 8 MiB
 // (23-bit positions); what the levels choose is how much of it a position is sure to have behind it: stride 4 MiB = 4-8 MiB of history at 16-19, stride 2 MiB = 6-8 MiB at
 // 20-22 (each halving of the stride lists and links every position once more: W1..W4 of the three passes).
 static uint32_t zstd_group_blocks(int level) { return level >= 16 ? 4u * GC_MF_MAX_FRAME_BLOCKS : GC_MF_MAX_FRAME_BLOCKS; }     // 32 MiB zstd frames (= shard grain) / 8 MiB
-static uint32_t zstd_stride_blocks(int level) { return level >= 20 ? GC_MF_MAX_FRAME_BLOCKS / 4u : GC_MF_MAX_FRAME_BLOCKS / 2u; }
+static uint32_t zstd_stride_blocks(int level) { (void)level; return GC_MF_MAX_FRAME_BLOCKS / 2u; }      // 4 MiB: a position is sure of 4 MiB of history at 16-19 (8 MiB windows), of 12 MiB at 20-22 (16 MiB windows; round 5: 8 MiB windows every 2 MiB)
 // zstd level -> match links followed per position (the reference's searchLog grows the same way: clevels.h:25-47)
 static uint32_t zstd_search_depth(int level) { return level < 6 ? 0u : (level < 10 ? 2u : (level < 16 ? 4u : (level < 18 ? 8u : 16u))); }
 
@@ -686,7 +690,7 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
     // Overlapping finder frames (gc_mf.h) from level 16: the zstd frame becomes the GROUP (the reference's own frames are the whole input with a sliding window).
     uint32_t zGroup = zstd_group_blocks(level); const bool grpHook = gc_env_u32("GC_MF_GROUP", 1u, 65535u, &zGroup);      // test hook: blocks per group (with GC_FRAME_BLOCKS and GC_MF_STRIDE: overlapping frames of a few blocks)
     uint32_t zArg = frameBlocks;                                                               // what the finder takes
-    if (zGroup > frameBlocks && (frameBlocks == GC_MF_MAX_FRAME_BLOCKS || grpHook) && nBlocks > frameBlocks) {
+    if (zGroup > frameBlocks && (frameBlocks == zstd_frame_blocks(level) || grpHook) && nBlocks > frameBlocks) {
         uint32_t stride = zstd_stride_blocks(level); gc_env_u32("GC_MF_STRIDE", 1u, GC_MF_MAX_FRAME_BLOCKS, &stride);      // test hook (blocks; 64 = no overlap)
         if (stride < frameBlocks && (frameBlocks % stride) == 0u && ((zGroup - frameBlocks) % stride) == 0u) zArg = GC_MF_GEOM_ARG(frameBlocks, stride, zGroup);
     }
@@ -845,16 +849,16 @@ extern "C" size_t gc_flzma2_compress_bound(size_t n)
 
 // level -> blocks per match-finder frame.  Every level runs the windowed finder over 8 MiB frames (round 3; levels 1-2 used the block-local
 // finder before: a 128 KiB window against the reference's 1-2 MiB dictionaries, fl2_compress.c:52-63, was 12-24 % behind it, run r03_levels).
-static uint32_t flzma2_frame_blocks(int level) { (void)level; return GC_MF_MAX_FRAME_BLOCKS; }
+static uint32_t flzma2_frame_blocks(int level) { return level >= 7 ? GC_MF_WIDE_MAX_FRAME_BLOCKS : GC_MF_MAX_FRAME_BLOCKS; }     // (round 6: 16 MiB windows at 7-9 -- the reference: dictionaries of 32 / 64 / 64 MiB, fl2_compress.c:74-86)
 // Levels 7-9 (the reference: dictionaries of 64 / 64 / 128 MiB, fl2_compress.c:59-62): overlapping finder frames (gc_mf.h) in groups of 64 MiB, stride 4 MiB at 7, 2 MiB at 8-9
 // (a position is sure of 4 / 6 MiB of history; the window itself stays 8 MiB: 23-bit positions).  Levels 1-6: frames that tile the input.
 // Levels 5-6 (round 5; the reference: 16 / 32 MiB dictionaries): groups of 16 MiB, stride 4 MiB -- real shared objects, 32 MiB at level 5 on the emulator: 1.0186 -> 1.0148 x the reference
 static uint32_t flzma2_group_blocks(int level) { return level >= 7 ? 8u * GC_MF_MAX_FRAME_BLOCKS : (level >= 5 ? 2u * GC_MF_MAX_FRAME_BLOCKS : GC_MF_MAX_FRAME_BLOCKS); }
-static uint32_t flzma2_stride_blocks(int level) { return level >= 8 ? GC_MF_MAX_FRAME_BLOCKS / 4u : GC_MF_MAX_FRAME_BLOCKS / 2u; }
+static uint32_t flzma2_stride_blocks(int level) { return level >= 8 ? GC_MF_MAX_FRAME_BLOCKS / 2u : (level >= 7 ? GC_MF_MAX_FRAME_BLOCKS : GC_MF_MAX_FRAME_BLOCKS / 2u); }      // 5-6: 4 MiB (8 MiB windows); 7: 8 MiB, 8-9: 4 MiB (16 MiB windows: 8-16 / 12-16 MiB of history)
 
 // dictionary-size property byte of the 7z coder (Lzma2Encoder.cpp:353-364): dict = (2|(p&1)) << (p/2+11).
 // Matches never reach back further than the start of their frame: 128 KiB (p = 10) or 8 MiB (p = 22).
-extern "C" unsigned char gc_flzma2_dict_prop(int level) { return flzma2_frame_blocks(level) == 1u ? 10 : 22; }
+extern "C" unsigned char gc_flzma2_dict_prop(int level) { const uint32_t f = flzma2_frame_blocks(level); return f == 1u ? 10 : (f > GC_MF_MAX_FRAME_BLOCKS ? 24 : 22); }      // 128 KiB / 8 MiB / 16 MiB
 
 extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n, void* d_dst, size_t dstCap, int level, unsigned flags)
 {
@@ -910,7 +914,7 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     if (frameBlocks > nBlocks) frameBlocks = nBlocks;
     uint32_t fArg = frameBlocks;                                                               // what the finder takes: overlapping frames from level 7 (gc_mf.h)
     { uint32_t grp = flzma2_group_blocks(level); const bool grpHook = gc_env_u32("GC_MF_GROUP", 1u, 65535u, &grp);      // test hook: blocks per group (with GC_FRAME_BLOCKS and GC_MF_STRIDE: overlapping frames of a few blocks)
-      if (grp > frameBlocks && (frameBlocks == GC_MF_MAX_FRAME_BLOCKS || grpHook) && nBlocks > frameBlocks) {
+      if (grp > frameBlocks && (frameBlocks == flzma2_frame_blocks(level) || grpHook) && nBlocks > frameBlocks) {
           uint32_t stride = flzma2_stride_blocks(level); gc_env_u32("GC_MF_STRIDE", 1u, GC_MF_MAX_FRAME_BLOCKS, &stride);      // test hook (blocks; 64 = no overlap)
           if (stride < frameBlocks && (frameBlocks % stride) == 0u && ((grp - frameBlocks) % stride) == 0u) fArg = GC_MF_GEOM_ARG(frameBlocks, stride, grp);
       } }
@@ -1040,7 +1044,8 @@ static uint32_t brotli_blocks_per_chunk(int level) { if (level < 1) level = 1; i
 static uint32_t brotli_frame_blocks(int level, uint32_t bpc)
 {
     if (level <= 0) return 1u;
-    return bpc <= GC_MF_MAX_FRAME_BLOCKS ? bpc : bpc / 2u;
+    const uint32_t cap = level >= 7 ? GC_MF_WIDE_MAX_FRAME_BLOCKS : GC_MF_MAX_FRAME_BLOCKS;       // (qualities >= 7 run the wide geometry: 16 MiB of positions, so the 9 / 10 / 11 MiB chunks of qualities 9-11 are ONE frame since round 6)
+    return bpc <= cap ? bpc : bpc / 2u;
 }
 
 extern "C" size_t gc_brotli_compress_bound(size_t n)
@@ -1234,7 +1239,8 @@ extern "C" size_t gc_codec_grain(int codec, int level)
         uint32_t grp = codec == GC_CODEC_ZSTD ? zstd_group_blocks(level) : flzma2_group_blocks(level);
         const bool grpHook = gc_env_u32("GC_MF_GROUP", 1u, 65535u, &grp);                                        // test hooks, read as the compress paths read them (small overlapping frames: shards must not cut a group)
         uint32_t stride = codec == GC_CODEC_ZSTD ? zstd_stride_blocks(level) : flzma2_stride_blocks(level); gc_env_u32("GC_MF_STRIDE", 1u, GC_MF_MAX_FRAME_BLOCKS, &stride);
-        if (grp > fb && (fb == GC_MF_MAX_FRAME_BLOCKS || grpHook) && stride < fb && (fb % stride) == 0u && ((grp - fb) % stride) == 0u) fb = grp;
+        const uint32_t fbDefault = codec == GC_CODEC_ZSTD ? zstd_frame_blocks(level) : flzma2_frame_blocks(level);
+        if (grp > fb && (fb == fbDefault || grpHook) && stride < fb && (fb % stride) == 0u && ((grp - fb) % stride) == 0u) fb = grp;
     }
     if (codec != GC_CODEC_BROTLI) return (size_t)fb * GC_ZSTD_BLOCK_MAX;
     return (size_t)brotli_blocks_per_chunk(level) * GC_ZSTD_BLOCK_MAX;

@@ -48,12 +48,14 @@
 #ifndef DPL_MR
 #define DPL_MR       16u              // final nodes whose repeat distances are kept: the node an edge of more than DPL_MR bytes comes from is
 #endif                                 // taken to have the distances of the oldest one (they differ only where the cheapest ways to the two differ)
-// low word of a node: distance | capped | class | length - 1
+// low word of a node: distance | class | length - 1
 #define DPL_LO_LEN(lo)   (((lo) & DPL_MMASK) + 1u)
 #define DPL_LO_CLS(lo)   (((lo) >> DPL_LENBITS) & 7u)
-#define DPL_LO_CAP(lo)   (((lo) >> (DPL_LENBITS + 3u)) & 1u)
-#define DPL_LO_DIST(lo)  ((lo) >> (DPL_LENBITS + 4u))
-#define DPL_LO(dist, cap, cls, len) (((dist) << (DPL_LENBITS + 4u)) | ((cap) ? 1u << (DPL_LENBITS + 3u) : 0u) | ((cls) << DPL_LENBITS) | ((len) - 1u))
+#define DPL_LO_DIST(lo)  ((lo) >> (DPL_LENBITS + 3u))          // 24 bits (round 6: 16 MiB frames; the "capped" flag moved to the high word)
+#define DPL_LO(dist, cls, len) (((dist) << (DPL_LENBITS + 3u)) | ((cls) << DPL_LENBITS) | ((len) - 1u))
+// high word of a node: cost << 7 | capped << 6 | bytes left of a capped match (0..63)
+#define DPL_CSH          7u
+#define DPL_HI_CAP       64u
 #define DPL_INF      0xFFFFFFFFFFFFFFFFull
 // Two waves per group of 64 windows (GC_DPL_THREADS = 128, gc_mf.h): both step through the nodes together, wave 0 expands a node's literal, finder candidates and
 // the rest of a capped match, stores back pointers and walks back; wave 1 keeps the tracked distances and expands the node's repeats.  One LDS barrier per node.
@@ -413,7 +415,7 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
     }
     unsigned long long* const myCost = &sCost[0][lane];           // this lane's column: slot s at myCost[s * 64]
 
-    // One candidate as edges: Lm bytes (0: none) at a distance, lengths x0 .. Lm.  hiBase = (cost of the node + flags and distance) << 6; the edge of Lm bytes
+    // One candidate as edges: Lm bytes (0: none) at a distance, lengths x0 .. Lm.  hiBase = (cost of the node + flags and distance) << 7; the edge of Lm bytes
     // carries hiLast / loLast instead (length price of the whole match, bytes left, "capped").  Every lane runs the loop (static lengths, its own predicate);
     // the wave leaves it once no lane has a longer candidate.
 #ifdef HIPEMU
@@ -425,7 +427,7 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
     // (measured on the evaluation slices: all lengths against 2 .. 12 + the last four of the finder's candidates, 2 .. 4 + the last four of a repeat:
     // +0.05 ... 0.2 % size for half the relax instructions).  tabBase: where the length prices lie in LDS (for the lengths that are not static).
     auto slotOf = [&](uint32_t x) -> uint32_t { const uint32_t t = si + x; return t >= DPL_RC ? t - DPL_RC : t; };      // ring slot of node i + x, x <= DPL_M + 1 (si: the slot of node i)
-    auto relax = [&](int32_t, uint32_t Lm, uint32_t x0, uint32_t hiBase, uint32_t loBase, uint32_t lastLen /* whose price the last edge carries */, uint32_t left, uint32_t loLast,
+    auto relax = [&](int32_t, uint32_t Lm, uint32_t x0, uint32_t hiBase, uint32_t loBase, uint32_t lastLen /* whose price the last edge carries */, uint32_t left, bool capLast, uint32_t loLast,
                      const uint32_t (&tab)[DPL_TABW], uint32_t tabBase, bool flat, const uint32_t LO) {
         if (DPL_NONE_LONGER(x0 > 1u ? x0 : 1u, Lm)) return;
         // the four prices with a length of the lane's own: read together, used below
@@ -436,13 +438,13 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
         for (uint32_t x = 1u; x <= LO; x++) {
             if (x > 1u && (x & 3u) == 1u && DPL_NONE_LONGER(x, pre)) break;
             const uint32_t lp = flat ? 0u : ((tab[x >> 1] >> (16u * (x & 1u))) & 0xFFFFu);
-            const uint32_t hi = (x >= x0 && x <= pre) ? hiBase + (lp << 6) : 0xFFFFFFFFu;
+            const uint32_t hi = (x >= x0 && x <= pre) ? hiBase + (lp << DPL_CSH) : 0xFFFFFFFFu;
             atomicMin(&myCost[slotOf(x) * 64u], ((unsigned long long)hi << 32) | (loBase | (x - 1u)));
         }
         if (allLen) {                                              // every length between the static ones and the last four (zstd levels >= 16: ZSTD_compressBlock_opt_generic prices every length of every match, zstd_opt.c:1230-1250)
             for (uint32_t x = LO + 1u; !DPL_NONE_LONGER(x + 4u, Lm); x++) {
                 const uint32_t lp = flat ? 0u : (uint32_t)P[tabBase + x];
-                const uint32_t hi = (x >= x0 && x + 4u <= Lm) ? hiBase + (lp << 6) : 0xFFFFFFFFu;
+                const uint32_t hi = (x >= x0 && x + 4u <= Lm) ? hiBase + (lp << DPL_CSH) : 0xFFFFFFFFu;
                 atomicMin(&myCost[slotOf(x <= DPL_M ? x : 1u) * 64u], ((unsigned long long)hi << 32) | (loBase | ((x - 1u) & DPL_MMASK)));
             }
         }
@@ -450,11 +452,11 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
         for (uint32_t t = 3u; t >= 1u; t--) {
             const uint32_t x = Lm - t;                             // (per lane)
             const uint32_t lp = flat ? 0u : (t == 3u ? p3 : (t == 2u ? p2 : p1));
-            const uint32_t hi = (Lm > t && x >= x0 && x > pre) ? hiBase + (lp << 6) : 0xFFFFFFFFu;
+            const uint32_t hi = (Lm > t && x >= x0 && x > pre) ? hiBase + (lp << DPL_CSH) : 0xFFFFFFFFu;
             atomicMin(&myCost[slotOf(Lm > t ? x : 1u) * 64u], ((unsigned long long)hi << 32) | (loBase | ((x - 1u) & DPL_MMASK)));
         }
         {
-            const uint32_t hi = (Lm >= x0 && Lm != 0u) ? ((hiBase + ((flat ? 0u : p0) << 6)) | left) : 0xFFFFFFFFu;
+            const uint32_t hi = (Lm >= x0 && Lm != 0u) ? ((hiBase + ((flat ? 0u : p0) << DPL_CSH)) | left | (capLast ? DPL_HI_CAP : 0u)) : 0xFFFFFFFFu;
             atomicMin(&myCost[slotOf(Lm) * 64u], ((unsigned long long)hi << 32) | loLast);
         }
     };
@@ -471,7 +473,7 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
         const unsigned long long w = myCost[si * 64u];
         if (isA && i != -warmMax) myCost[(si == 0u ? DPL_RC - 1u : si - 1u) * 64u] = DPL_INF;      // node i - 1's slot becomes node i + DPL_RC - 1's (both waves have read it: the barrier of step i - 1)
         const uint32_t lo = (uint32_t)w, hi = (uint32_t)(w >> 32);
-        const uint32_t c0 = hi >> 6;
+        const uint32_t c0 = hi >> DPL_CSH;
         const bool live = n != 0u && i >= -warm && i <= N;
         if (live && i > -warm) {                                   // ---- finalize node i
             const uint32_t len = DPL_LO_LEN(lo), cls = DPL_LO_CLS(lo), dist = DPL_LO_DIST(lo);
@@ -482,7 +484,7 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
                 if (cls != DPL_LIT && cls != DPL_SREP) dpl_mtf(st, dist, i - (int32_t)len >= 0 ? DPL_SURE : 0u);
                 if (isA) { GcU4 nv; nv.x = st.r0; nv.y = st.r1; nv.z = st.r2; nv.w = st.r3; sReps[sr][lane] = nv; }
             }
-            contCapped = DPL_LO_CAP(lo) != 0u; contDist = dist; contRem = hi & 63u;
+            contCapped = (hi & DPL_HI_CAP) != 0u; contDist = dist; contRem = hi & 63u;
             if (i == 0) cost0 = c0;
             if (i == N) costN = c0;
         }
@@ -500,8 +502,8 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
             const uint32_t room = !live ? 0u : (i < 0 ? (uint32_t)(-i) : (uint32_t)(N - i));
             // a continuation of one byte is only a match together with the piece in front of it: at the window's first node that piece is the warm-up's guess
             const uint32_t contX0 = i == 0 ? (MINLEN > 2u ? MINLEN : 2u) : 1u;
-            const uint32_t cbase = c0 << 6;
-            if (isC) atomicMin(&myCost[slotOf(1u) * 64u], (unsigned long long)(room != 0u ? cbase + ((flagLit + (lpG & 0xFFu)) << 6) : 0xFFFFFFFFu) << 32);      // literal
+            const uint32_t cbase = c0 << DPL_CSH;
+            if (isC) atomicMin(&myCost[slotOf(1u) * 64u], (unsigned long long)(room != 0u ? cbase + ((flagLit + (lpG & 0xFFu)) << DPL_CSH) : 0xFFFFFFFFu) << 32);      // literal
             // the rest of a capped match whose length is known (handing these two to wave 1 as well -- 23.5 : 19.4 of the pair's work are wave 0's -- changed nothing: 23.85 -> 23.72 ms)
             if (isC) {
                 uint32_t Lc = (room != 0u && contCapped) ? contRem : 0u;
@@ -509,8 +511,8 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
                 if (Lc > room) Lc = room;
                 const uint32_t Lm = Lc < DPL_M ? Lc : DPL_M;
                 uint32_t left = Lc - Lm + beh; if (left > 63u) left = 63u;
-                const uint32_t hb = cbase + (DPL_CONT << 6);
-                relax(i, Lm, contX0, hb, DPL_LO(contDist, false, DPL_CONTC, 1u), 0u, left, DPL_LO(contDist, left != 0u, DPL_CONTC, Lm ? Lm : 1u), lenR, GC_PRICE_LEN, true, 4u);
+                const uint32_t hb = cbase + (DPL_CONT << DPL_CSH);
+                relax(i, Lm, contX0, hb, DPL_LO(contDist, DPL_CONTC, 1u), 0u, left, left != 0u, DPL_LO(contDist, DPL_CONTC, Lm ? Lm : 1u), lenR, GC_PRICE_LEN, true, 4u);
             }
             DPL_T(1);
             // finder candidate, short candidate
@@ -537,10 +539,11 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
                 const bool openEnd = !cnd && (r & 0xFFu) == GC_MATCH_CAP;      // a capped record goes on in the record behind it
                 const uint32_t wholeLen = Lx + behind < GC_MATCH_CAP ? Lx + behind : GC_MATCH_CAP;
                 const bool repTab = REPS && cls >= DPL_REP0 && cls <= DPL_REP0 + 3u;
-                const uint32_t hb = cbase + (add << 6);
-                const uint32_t loLast = DPL_LO(Dx, left != 0u || openEnd, cls, Lm ? Lm : 1u), lastLen = left != 0u ? wholeLen : Lm;      // the last piece: the length price of the whole match
-                if (repTab) relax(i, Lm, x0, hb, DPL_LO(Dx, false, cls, 1u), lastLen, left, loLast, repR, GC_PRICE_REPLEN, isCont, cnd ? 6u : 8u);
-                else relax(i, Lm, x0, hb, DPL_LO(Dx, false, cls, 1u), lastLen, left, loLast, lenR, GC_PRICE_LEN, isCont, cnd ? 6u : 8u);
+                const uint32_t hb = cbase + (add << DPL_CSH);
+                const uint32_t loLast = DPL_LO(Dx, cls, Lm ? Lm : 1u), lastLen = left != 0u ? wholeLen : Lm;      // the last piece: the length price of the whole match
+                const bool capLast = left != 0u || openEnd;
+                if (repTab) relax(i, Lm, x0, hb, DPL_LO(Dx, cls, 1u), lastLen, left, capLast, loLast, repR, GC_PRICE_REPLEN, isCont, cnd ? 6u : 8u);
+                else relax(i, Lm, x0, hb, DPL_LO(Dx, cls, 1u), lastLen, left, capLast, loLast, lenR, GC_PRICE_LEN, isCont, cnd ? 6u : 8u);
             }
             }
             DPL_T(2);
@@ -576,7 +579,7 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
                     bestK = b1 ? kk : bestK; bestL = b1 ? hl : bestL; bestD = b1 ? hd : bestD; bestOpen = b1 ? open : bestOpen;
                     longK = b2 ? kk : longK; longL = b2 ? hl : longL; longD = b2 ? hd : longD; longOpen = b2 ? open : longOpen;
                 }
-                if (MINLEN == 2u) atomicMin(&myCost[slotOf(1u) * 64u], ((unsigned long long)(srepD ? cbase + (fSrep << 6) : 0xFFFFFFFFu) << 32) | DPL_LO(srepD, false, DPL_SREP, 1u));
+                if (MINLEN == 2u) atomicMin(&myCost[slotOf(1u) * 64u], ((unsigned long long)(srepD ? cbase + (fSrep << DPL_CSH) : 0xFFFFFFFFu) << 32) | DPL_LO(srepD, DPL_SREP, 1u));
                 if (longK == bestK) longL = 0u;
 #pragma unroll
                 for (uint32_t e = 0; e < 2u; e++) {
@@ -584,8 +587,8 @@ __device__ __forceinline__ void dpl_run(const uint8_t* __restrict__ src, uint64_
                     const bool isCont = kk == 0u;
                     const uint32_t ri = (kk - 1u) & 3u;                            // repeat index
                     const uint32_t cls = isCont ? DPL_CONTC : DPL_REP0 + ri, add = isCont ? DPL_CONT : (ri == 0u ? fRep0 : (ri == 1u ? fRep1 : (ri == 2u ? fRep2 : fRep3)));
-                    const uint32_t hb = cbase + (add << 6);
-                    relax(i, hl, isCont ? contX0 : MINLEN, hb, DPL_LO(hd, false, cls, 1u), hl, 0u, DPL_LO(hd, open, cls, hl ? hl : 1u), repR, GC_PRICE_REPLEN, isCont, 4u);
+                    const uint32_t hb = cbase + (add << DPL_CSH);
+                    relax(i, hl, isCont ? contX0 : MINLEN, hb, DPL_LO(hd, cls, 1u), hl, 0u, open, DPL_LO(hd, cls, hl ? hl : 1u), repR, GC_PRICE_REPLEN, isCont, 4u);
                 }
             }
         }

@@ -365,7 +365,7 @@ MFK(gc_mf_scatter_far2_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize
 // what the table held when the entry arrived -> candidate position + 1, or 0
 __device__ __forceinline__ uint32_t mf_link_pick(uint32_t seen, uint32_t mine)
 {
-    return (seen != 0u && seen < mine && ((seen ^ mine) & 0xFFu) == 0u) ? (seen >> 8) : 0u;
+    return (seen != 0u && seen < mine && ((seen ^ mine) & ((1u << GC_MF_TAG_BITS) - 1u)) == 0u) ? (seen >> GC_MF_TAG_BITS) : 0u;
 }
 
 __device__ __forceinline__ void mf_link_load(uint64_t q[LINK_DEPTH], const GcMfEntry* __restrict__ E, uint32_t s0, uint32_t end, uint32_t lane)
@@ -392,7 +392,7 @@ __device__ __forceinline__ void mf_link_steps(const uint64_t q[LINK_DEPTH], uint
         pos[d] = (uint32_t)e & ((1u << GC_MF_POS_BITS) - 1u);
         const uint32_t kL = (uint32_t)(e >> GC_MF_POS_BITS) & ((1u << GC_MF_KL_BITS) - 1u);
         const uint32_t kS = (uint32_t)(e >> (GC_MF_POS_BITS + GC_MF_KL_BITS)) & ((1u << GC_MF_KS_BITS) - 1u);
-        mL[d] = ((pos[d] + 1u) << 8) | (kL & 0xFFu); mS[d] = ((pos[d] + 1u) << 8) | (kS & 0xFFu);
+        mL[d] = ((pos[d] + 1u) << GC_MF_TAG_BITS) | (kL & ((1u << GC_MF_TAG_BITS) - 1u)); mS[d] = ((pos[d] + 1u) << GC_MF_TAG_BITS) | (kS & ((1u << GC_MF_TAG_BITS) - 1u));
         rL[d] = 0; rS[d] = 0;
         if (i < end) { rL[d] = atomicMax(&tabL[kL >> (GC_MF_KL_BITS - GC_MF_LSLOT_LOG)], mL[d]); rS[d] = atomicMax(&tabS[kS >> (GC_MF_KS_BITS - GC_MF_SSLOT_LOG)], mS[d]); }
         gc_wave_step();
@@ -401,7 +401,7 @@ __device__ __forceinline__ void mf_link_steps(const uint64_t q[LINK_DEPTH], uint
     for (uint32_t d = 0; d < LINK_DEPTH; d++) {
         const uint32_t i = s0 + d * 64u + lane;
         const uint32_t cL = mf_link_pick(rL[d], mL[d]), cS = mf_link_pick(rS[d], mS[d]);
-        if (i < end) EO[i] = (uint64_t)(pos[d] & (GC_MF_TILE - 1u)) | ((uint64_t)cL << GC_MF_TILE_LOG) | ((uint64_t)cS << (GC_MF_TILE_LOG + 24u));
+        if (i < end) EO[i] = (uint64_t)(pos[d] & (GC_MF_TILE - 1u)) | ((uint64_t)cL << GC_MF_TILE_LOG) | ((uint64_t)cS << (GC_MF_TILE_LOG + GC_MF_CAND_BITS));
     }
 }
 
@@ -460,8 +460,8 @@ MFK(gc_mf_link_kernel)(const uint32_t* __restrict__ offs, const GcMfEntry* __res
                 const uint32_t pos = (uint32_t)e & ((1u << GC_MF_POS_BITS) - 1u);
                 const uint32_t kL = (uint32_t)(e >> GC_MF_POS_BITS) & ((1u << GC_MF_KL_BITS) - 1u);
                 const uint32_t kS = (uint32_t)(e >> (GC_MF_POS_BITS + GC_MF_KL_BITS)) & ((1u << GC_MF_KS_BITS) - 1u);
-                atomicMax(&tabL[kL >> (GC_MF_KL_BITS - GC_MF_LSLOT_LOG)], ((pos + 1u) << 8) | (kL & 0xFFu));
-                atomicMax(&tabS[kS >> (GC_MF_KS_BITS - GC_MF_SSLOT_LOG)], ((pos + 1u) << 8) | (kS & 0xFFu));
+                atomicMax(&tabL[kL >> (GC_MF_KL_BITS - GC_MF_LSLOT_LOG)], ((pos + 1u) << GC_MF_TAG_BITS) | (kL & ((1u << GC_MF_TAG_BITS) - 1u)));
+                atomicMax(&tabS[kS >> (GC_MF_KS_BITS - GC_MF_SSLOT_LOG)], ((pos + 1u) << GC_MF_TAG_BITS) | (kS & ((1u << GC_MF_TAG_BITS) - 1u)));
             }
             gc_wave_sync();
         }
@@ -535,9 +535,10 @@ __device__ __forceinline__ uint32_t mfv_len13(const LzW16& me, const LzW16& cw, 
 // to be a property of the RECORDS because the parse does not exist yet: the most recent earlier position with the same 5 / 8 bytes is often a short match that the greedy parse
 // takes one or two bytes in front of a long one (and the one-step lazy look-ahead only sees one position on).  tools/zstd_parse_lab.c (32 MiB each, estimate, first pass + lazy 1):
 // text -4.0 %, web-text -4.6 %, real sources -6.1 %, shared objects -1.3 %, lz-7zip -2.0 %, the Silesia stand-in -1.4 %.  How many bytes in front agree travels in two free bits of the
-// record while it is in LDS (bit 7: lengths end at 64; bit 31: distances have 23 bits) and is taken out again before the records are read by anything else.
+// record while it is in LDS -- bit 7: lengths end at 64 -- plus one bit of a bitmap of the tile (the wide geometry's distances fill the other 24 bits), and is taken out again
+// before the records are read by anything else.
 #define MFV_CATCH 3u
-#define MFV_XBITS 0x80000080u
+#define MFV_XBITS 0x80u
 template <int MODE, bool TILE_LIMIT = false, bool BACK = false>
 __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks,
                     const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, const uint32_t* recIn,
@@ -562,6 +563,8 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
     }
     mf_stage(sW, MFV_STAGE_WORDS, src, srcSize, T.tileStart, t, MFV_T);
     uint32_t* const sDirty = (uint32_t*)sExt;                     // (merging passes only)
+    uint32_t* const sBack2 = (uint32_t*)(sExt + GC_MF_TILE / 8u + 16u);      // (BACK only) bit q: the match recorded at q also covers two or three bytes in front of it
+    if (BACK) { for (uint32_t i = t; i < GC_MF_TILE / 32u; i += MFV_T) sBack2[i] = 0u; }      // (before the barrier below)
     if (FAR) {                                                    // records of the first pass
         const GcU4* R4 = (const GcU4*)(recIn + T.tileStart);
         GcU4* S4 = (GcU4*)sRec;
@@ -653,8 +656,8 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
 #pragma unroll
         for (uint32_t k = 0; k < MFV_B; k++) {                    // long candidates
             q[k] = (uint32_t)e[k] & (GC_MF_TILE - 1u);
-            const uint32_t cL = (uint32_t)(e[k] >> GC_MF_TILE_LOG) & 0xFFFFFFu;
-            cS[k] = (uint32_t)(e[k] >> (GC_MF_TILE_LOG + 24u)) & 0xFFFFFFu;
+            const uint32_t cL = (uint32_t)(e[k] >> GC_MF_TILE_LOG) & ((1u << GC_MF_CAND_BITS) - 1u);
+            cS[k] = (uint32_t)(e[k] >> (GC_MF_TILE_LOG + GC_MF_CAND_BITS)) & ((1u << GC_MF_CAND_BITS) - 1u);
             const uint32_t p = pTile + q[k];                      // block-relative
             const bool can = live[k] && p + 8u <= nBlk;
             maxLen[k] = can ? ((nBlk - p) < GC_MATCH_CAP ? (nBlk - p) : GC_MATCH_CAP) : 0u;
@@ -691,8 +694,9 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
             if (live[k]) {
                 const uint32_t nr = len ? (((pw - (bestC[k] - 1u)) << 8) | len) : 0u;
                 if (MODE == MF_BASE && len == GC_MATCH_CAP) sWaveTot[1] = 0xFFFFFFFFu;      // "the tile has a capped record": the word held a count (dead since the run offsets were made), never this value
-                const uint32_t xb = (BACK && nr != 0u) ? (((bestExt[k] & 1u) << 7) | ((bestExt[k] & 2u) << 30)) : 0u;      // how far the match reaches in front of the position (taken out again below)
-                if (!FAR) sRec[q[k]] = nr | xb;
+                const uint32_t xb = (BACK && nr != 0u) ? ((bestExt[k] & 1u) << 7) : 0u;      // how far the match reaches in front of the position (taken out again below)
+                const bool x2 = BACK && nr != 0u && (bestExt[k] & 2u) != 0u;
+                if (!FAR) { sRec[q[k]] = nr | xb; if (x2) atomicOr(&sBack2[q[k] >> 5], 1u << (q[k] & 31u)); }
                 else if (nr) {
                     const uint32_t old = sRec[q[k]];
                     bool take = old == 0u || lz_gain(len, nr >> 8) > lz_gain(old & 0xFFu, old >> 8);
@@ -710,7 +714,7 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
                         take = eN > eO || (eN == eO && (nr >> 8) < (old >> 8));
                     }
                     if (take) {                                   // the continuation below looks again at this row and at the one 64 behind it (nowhere else: what has not changed was decided in the pass before)
-                        sRec[q[k]] = nr | xb;
+                        sRec[q[k]] = nr | xb; if (x2) atomicOr(&sBack2[q[k] >> 5], 1u << (q[k] & 31u));
                         atomicOr(&sDirty[q[k] >> 5], 1u << (q[k] & 31u)); atomicOr(&sDirty[(q[k] + GC_MATCH_CAP) >> 5], 1u << ((q[k] + GC_MATCH_CAP) & 31u));
                     }
                 }
@@ -742,10 +746,10 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
                 const uint32_t y = x + j;
                 uint32_t ry = (y < cEnd && y < T.len) ? sRec[y] : 0u;
                 if (y >= cEnd) ry = y - cEnd == 0u ? beyond[0] : (y - cEnd == 1u ? beyond[1] : beyond[2]);
-                const uint32_t e = ((ry >> 7) & 1u) | ((ry >> 30) & 2u);
+                const uint32_t e = (ry & 0x7Fu) == 0u ? 0u : (((ry >> 7) & 1u) | (((sBack2[(y & (GC_MF_TILE - 1u)) >> 5] >> (y & 31u)) & 1u) << 1));      // (ry != 0: y lies inside the tile)
                 if (e >= j) {
                     uint32_t l = (ry & 0x7Fu) + j; if (l > GC_MATCH_CAP) l = GC_MATCH_CAP;
-                    const uint32_t off = (ry & 0x7FFFFFFFu) >> 8;
+                    const uint32_t off = ry >> 8;
                     const int g = lz_gain(l, off);
                     if (g > bg) { bg = g; best = (off << 8) | l; }
                 }
@@ -854,13 +858,13 @@ __device__ __forceinline__ void mf_verify_tile(const MfTile& T, const uint8_t* _
 
 // MF_FAR / MF_SHORT: the candidates come from a later pass; recIn holds the records so far and a position's record is replaced
 // only by a candidate of better gain (recIn == rec: in place; a workgroup reads and writes its own tile only).
-template <int MODE>
+template <int MODE, bool BACK = true>
 __device__ __forceinline__ void mf_verify_body(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
                     const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, const uint32_t* recIn, uint32_t* rec, const uint32_t* __restrict__ changedIn = nullptr)
 {
     __shared__ uint32_t sW[MFV_STAGE_WORDS];
     __shared__ uint32_t sRec[GC_MF_TILE];
-    __shared__ __attribute__((aligned(16))) uint8_t sExt[(MODE == MF_FAR || MODE == MF_FAR2 || MODE == MF_SHORT) ? GC_MF_TILE / 8u + 16u : 4u];   // merging passes: one bit per position, "its record or the one 64 in front changed in this pass"
+    __shared__ __attribute__((aligned(16))) uint8_t sExt[2u * (GC_MF_TILE / 8u + 16u)];   // merging passes: one bit per position, "its record or the one 64 in front changed in this pass"; behind it the catch-up's bitmap
     __shared__ uint32_t sStart[GC_MF_PARTS], sLocal[GC_MF_PARTS + 1u];
     __shared__ uint32_t sWaveTot[GC_MF_PARTS / 64u];
     const uint32_t t = threadIdx.x;
@@ -868,8 +872,7 @@ __device__ __forceinline__ void mf_verify_body(const uint8_t* __restrict__ src, 
     if (tile >= nTiles) return;
     const MfTile T = mf_tile(tile, frameBlocks, srcSize);
     if (T.len == 0u || !T.own) return;                            // (overlapping frames: the tiles a frame shares with the one in front have their records from that one)
-    // (catch-up in every pass but the one with 4- / 3-byte keys: there it bought < 0.01 % -- FLZMA2 5 / 7 on the Silesia stand-in, shared objects, text, emulator -- for a millisecond per 212 MB)
-    mf_verify_tile<MODE, false, MODE != MF_SHORT>(T, src, srcSize, frameBlocks, offs, ent, recIn, sW, sRec, sExt, sStart, sLocal, sWaveTot, nullptr, nullptr, changedIn);
+    mf_verify_tile<MODE, false, BACK>(T, src, srcSize, frameBlocks, offs, ent, recIn, sW, sRec, sExt, sStart, sLocal, sWaveTot, nullptr, nullptr, changedIn);
     // records out: 16 bytes per lane, full lines
     GcU4* R4 = (GcU4*)(rec + T.tileStart);
     const GcU4* S4 = (const GcU4*)sRec;
@@ -898,7 +901,17 @@ MFK(gc_mf_verify_short_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize
                           const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, const uint32_t* __restrict__ recIn, uint32_t* __restrict__ recOut,
                           const uint32_t* __restrict__ changedIn)
 {
-    mf_verify_body<MF_SHORT>(src, srcSize, frameBlocks, nTiles, per, offs, ent, recIn, recOut, changedIn);
+    mf_verify_body<MF_SHORT, false>(src, srcSize, frameBlocks, nTiles, per, offs, ent, recIn, recOut, changedIn);
+}
+// The same pass WITH the catch-up.  Where the pass runs over frames that tile the input (FLZMA2 5-6) the catch-up bought < 0.01 % for a millisecond per 212 MB (the Silesia
+// stand-in, shared objects, text); where it keeps the overlapping frames -- zstd, FLZMA2 7-9: data whose short matches come from far away, lz-7zip -- it is what puts zstd 19 on
+// lz-7zip inside the band (1.0193 with, 1.0206 without, 32 MiB on the device).
+extern "C" __global__ void __launch_bounds__(MFV_T)
+MFK(gc_mf_verify_shortb_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t frameBlocks, uint32_t nTiles, uint32_t per,
+                          const uint32_t* __restrict__ offs, const GcMfEntry* __restrict__ ent, const uint32_t* __restrict__ recIn, uint32_t* __restrict__ recOut,
+                          const uint32_t* __restrict__ changedIn)
+{
+    mf_verify_body<MF_SHORT, true>(src, srcSize, frameBlocks, nTiles, per, offs, ent, recIn, recOut, changedIn);
 }
 
 // ------------------------------------------------------------------------------------------------ W5b deepen

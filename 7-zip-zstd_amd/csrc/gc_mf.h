@@ -50,13 +50,23 @@
 #define GC_MF_TILE        (1u << GC_MF_TILE_LOG)          // positions per tile
 #define GC_MF_TILES_PER_BLOCK (GC_ZSTD_BLOCK_MAX >> GC_MF_TILE_LOG)
 #define GC_MF_PARTS       (1u << GC_MF_PART_LOG)
-#define GC_MF_MAX_FRAME_BLOCKS 64u                        // 8 MiB: frame-relative positions fit 23 bits
+#define GC_MF_MAX_FRAME_BLOCKS 64u                        // 8 MiB: frame-relative positions fit 23 bits (the fast geometry, and the default of the wide one)
+#define GC_MF_WIDE_MAX_FRAME_BLOCKS 128u                  // 16 MiB: the wide geometry numbers positions with 24 bits (round 6: FLZMA2 7-9, zstd 20-22, brotli 9-11)
 
-// W3 -> W4 entry (64 bit):  pos[0..22] | long key[23..42] (12-bit slot, 8-bit tag) | short key[43..61] (11-bit slot, 8-bit tag)
-// W4 -> W5 entry (64 bit):  position in tile[0..13] | (long candidate + 1)[14..37] | (short candidate + 1)[38..61]   (0 = none;
-//                           candidates are frame-relative)
+// W3 -> W4 entry (64 bit), fast geometry:  pos[0..22] | long key[23..42] (12-bit slot, 8-bit tag) | short key[43..61] (11-bit slot, 8-bit tag)
+// W4 -> W5 entry (64 bit), fast geometry:  position in tile[0..12] | (long candidate + 1)[13..36] | (short candidate + 1)[37..60]   (0 = none;
+//                           candidates are frame-relative).  The wide geometry: one more bit per position (below)
 typedef uint64_t GcMfEntry;
+// Round 6: the wide geometry has 24-bit positions (16 MiB frames).  W3 -> W4: pos[24] | long key[20] | short key[19] = 63 bits; W4's table words (position + 1) << 7 | tag[7]
+// (25 + 7 = 32 bits: one tag bit less than the fast geometry's (position + 1) << 8 | tag[8]); W4 -> W5: position in tile[14] | (long candidate + 1)[25] | (short candidate + 1)[25] = 64 bits.
+#ifdef GC_MF_FAST
 #define GC_MF_POS_BITS    23u
+#define GC_MF_TAG_BITS    8u
+#else
+#define GC_MF_POS_BITS    24u
+#define GC_MF_TAG_BITS    7u
+#endif
+#define GC_MF_CAND_BITS   (GC_MF_POS_BITS + 1u)           // candidate + 1 (0 = none)
 #define GC_MF_KL_BITS     20u
 #define GC_MF_KS_BITS     19u
 #ifndef GC_MF_LSLOT_LOG
