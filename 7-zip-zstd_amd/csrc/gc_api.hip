@@ -624,13 +624,13 @@ extern "C" int gc_mf_pass_timing(gc_ctx* c, float ms[4])
 // Every level runs the windowed finder over 8 MiB frames (round 3).  Levels 1-2 used the block-local finder before -- a 128 KiB window against the
 // 512 KiB / 1 MiB windows of the reference's levels 1 / 2 (clevels.h:26-27): 1.026 x its level 1 on text, 1.085 x its level 2 (run r03_levels).
 // The block-local kernel K1 still serves inputs of one block.
-static uint32_t zstd_frame_blocks(int level) { return level >= 20 ? GC_MF_WIDE_MAX_FRAME_BLOCKS : GC_MF_MAX_FRAME_BLOCKS; }       // (round 6: 16 MiB windows at 20-22 -- the reference: windowLog 25-27, clevels.h:48-50)
+static uint32_t zstd_frame_blocks(int level) { return level >= 18 ? GC_MF_WIDE_MAX_FRAME_BLOCKS : GC_MF_MAX_FRAME_BLOCKS; }       // (round 6: 16 MiB windows at 18-22 -- the reference: windowLog 23 at 18-19, 25-27 at 20-22, clevels.h:46-50)
 // Levels 16-22: the finder's frames overlap (gc_mf.h "Overlapping frames") inside groups that are the zstd frames.  The reference: windowLog 22 at level 16-17, 23 at 18-19,
 // 25 / 26 / 27 at 20 / 21 / 22 (clevels.h:44-50), one frame, ZSTDMT jobs of four windows overlapping by one (zstdmt_compress.c:741-747).  Here the window stays 8 MiB
 // (23-bit positions); what the levels choose is how much of it a position is sure to have behind it: stride 4 MiB = 4-8 MiB of history at 16-19, stride 2 MiB = 6-8 MiB at
 // 20-22 (each halving of the stride lists and links every position once more: W1..W4 of the three passes).
 static uint32_t zstd_group_blocks(int level) { return level >= 16 ? 4u * GC_MF_MAX_FRAME_BLOCKS : GC_MF_MAX_FRAME_BLOCKS; }     // 32 MiB zstd frames (= shard grain) / 8 MiB
-static uint32_t zstd_stride_blocks(int level) { (void)level; return GC_MF_MAX_FRAME_BLOCKS / 2u; }      // 4 MiB: a position is sure of 4 MiB of history at 16-19 (8 MiB windows), of 12 MiB at 20-22 (16 MiB windows; round 5: 8 MiB windows every 2 MiB)
+static uint32_t zstd_stride_blocks(int level) { return (level == 18 || level == 19) ? GC_MF_MAX_FRAME_BLOCKS : GC_MF_MAX_FRAME_BLOCKS / 2u; }      // a position is sure of 4 MiB of history at 16-17 (8 MiB windows every 4 MiB), of 8 MiB -- the reference's whole window -- at 18-19 (16 MiB windows every 8 MiB), of 12 MiB at 20-22 (every 4 MiB; round 5: 8 MiB windows every 2 MiB)
 // zstd level -> match links followed per position (the reference's searchLog grows the same way: clevels.h:25-47)
 static uint32_t zstd_search_depth(int level) { return level < 6 ? 0u : (level < 10 ? 2u : (level < 16 ? 4u : (level < 18 ? 8u : 16u))); }
 

@@ -29,18 +29,18 @@ def _need(O, name):
 
 # Bars that are NOT met yet are recorded as expected failures with the measured figure (MI355X, runs r03_levels / r03_q1 of round 3 unless a round is
 # named), so that the suite stays green and the gap stays visible; strict=False: the day a bar is met the test simply passes.
-NOT_YET = {("zstd", 16, "text-zipf"): "met in round 5 (1.008 x btopt with overlapping finder frames; 1.027 in round 4): the entry stays as a guard",
-           ("zstd", 19, "text-zipf"): "1.046 x btultra2 (round 5, run s5: overlapping frames, the 32-byte pass, every length an edge; 1.066 in round 4).  On the reference itself (8 MiB): btopt 1.013, searchLog 3 1.071 x its level 19 -- what is left is the number of candidates per position and its accurate prices, profiles/r05_zstd19.md",
-           ("zstd", 19, "lz-7zip"): "1.023 x btultra2 (round 5; 1.059 in round 4)",
-           ("zstd", 22, "text-zipf"): "1.056 x the reference's level 22 (round 5; 1.076 in round 4; btultra2, window 128 MiB against overlapping 8 MiB frames in groups of 32 MiB)",
-           ("zstd", 22, "lz-7zip"): "1.033 x the reference's level 22 (round 5; 1.076 in round 4)",
-           ("flzma2", 7, "text-zipf"): "1.025 x the reference's level 7 (round 5: overlapping frames in groups of 64 MiB; 1.046 in round 4; dictionary 64 MiB, FL2_ultra)",
-           ("flzma2", 7, "lz-7zip"): "1.041 x the reference's level 7 (round 5; 1.079 in round 4)", ("flzma2", 7, "silesia-like"): "met in round 5 (1.020; 1.027 in round 4): a guard",
-           ("flzma2", 9, "text-zipf"): "1.024 x the reference's level 9 (round 5; 1.047 in round 4; dictionary 128 MiB, search depth 254)",
-           ("flzma2", 9, "lz-7zip"): "1.034 x the reference's level 9 (round 5; 1.079 in round 4)", ("flzma2", 9, "silesia-like"): "met in round 5 (1.019; 1.027 in round 4): a guard",
-           ("brotli", 9, "lz-7zip"): "1.027 x the reference's quality 9",
-           ("brotli", 11, "text-zipf"): "1.058 x the reference's quality 11 (zopfli-style parse, context modelling, block splitting: B1 has one tree per alphabet)",
-           ("brotli", 11, "lz-7zip"): "1.071 x the reference's quality 11", ("brotli", 11, "web-text"): "1.067 x the reference's quality 11"}
+NOT_YET = {("zstd", 16, "text-zipf"): "met since round 5 (1.003 x btopt in round 6): the entry stays as a guard",
+           ("zstd", 19, "text-zipf"): "1.030 x btultra2 (round 6, run s9: the catch-up, 16 MiB finder frames every 8 MiB; 1.046 in round 5, 1.066 in round 4).  What is left is not the candidates (more key classes, 64 links: nothing, DESIGN section 4) but its accurate, adaptive prices (1.024 at 4 MiB, where the window plays no part)",
+           ("zstd", 19, "lz-7zip"): "met in round 6 (0.997 x btultra2: the catch-up + 16 MiB finder frames; 1.023 in round 5): the entry stays as a guard",
+           ("zstd", 22, "text-zipf"): "1.042 x the reference's level 22 (round 6: 16 MiB finder frames + the catch-up; 1.056 in round 5; btultra2, window 128 MiB)",
+           ("zstd", 22, "lz-7zip"): "met in round 6 (1.010: 16 MiB finder frames, 24-bit positions; 1.033 in round 5): the entry stays as a guard",
+           ("flzma2", 7, "text-zipf"): "met in round 6 (1.010; 1.025 in round 5): a guard", ("flzma2", 7, "lz-7zip"): "met in round 6 (1.013 with 16 MiB finder frames; 1.041 in round 5): a guard",
+           ("flzma2", 7, "silesia-like"): "met since round 5 (1.015 in round 6): a guard",
+           ("flzma2", 9, "text-zipf"): "met in round 6 (1.012; 1.024 in round 5): a guard", ("flzma2", 9, "lz-7zip"): "met in round 6 (1.010; 1.034 in round 5): a guard",
+           ("flzma2", 9, "silesia-like"): "met since round 5 (1.015 in round 6): a guard",
+           ("brotli", 9, "lz-7zip"): "met in round 6 (0.992: the 9 MiB chunk is ONE finder frame since positions have 24 bits; 1.027 before): a guard",
+           ("brotli", 11, "text-zipf"): "1.058 x the reference's quality 11 in round 5 (zopfli-style parse, context clustering, block splitting; B1 chooses between one literal tree and a static map of thirteen, one block type per category)",
+           ("brotli", 11, "lz-7zip"): "1.071 x the reference's quality 11 in round 5", ("brotli", 11, "web-text"): "1.067 x the reference's quality 11 in round 5"}
 
 
 def _xfail_if_known(codec, level, kind):

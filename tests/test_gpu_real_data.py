@@ -15,8 +15,8 @@ CASES = [("real-src", 64 * MiB), ("real-bin", 211_900_000), ("real-py", 64 * MiB
 NOT_YET = {("flzma2", "real-src"): "0.998 x the reference in round 4 (1.018 in round 3): inside the band, the entry stays as a guard",
            ("flzma2", "real-bin"): "met in round 5: 1.018 x the reference on all 211.9 MB (model segments over cheap neighbouring blocks, level 5 in overlapping finder frames of 16 MiB groups -- the reference's dictionary at this level; 1.026 in round 4, 1.054 in round 3): the entry stays as a guard",
            ("flzma2", "real-py"): "1.008 x the reference in round 4 (1.017 in round 3): inside the band, the entry stays as a guard",
-           ("brotli", "real-src"): "1.058 x the reference (round 5, run s3, with B1's last-distance substitution in two passes; 1.069 in round 4 before it, 1.084 in round 3).  What is left needs the ring distances INSIDE the parse and literal context modelling with clustered block types (DESIGN section 8)",
-           ("brotli", "real-bin"): "1.085 x the reference (round 5, run s3, with the substitution; 1.101 in round 4 before it, 1.106 in round 3: its hasher tries the last distances first at every position)",
+           ("brotli", "real-src"): "1.041 x the reference (round 6, 64 MiB: the catch-up, literal context modelling; 1.058 in round 5, 1.084 in round 3).  What is left: the ring distances INSIDE the parse, block splitting, the static dictionary",
+           ("brotli", "real-bin"): "1.073 x the reference (round 6; 1.085 in round 5, 1.106 in round 3: its hasher tries the last distances first at every position)",
            ("brotli", "real-py"): "1.015 x the reference in round 4 (1.024 in round 3): inside the band, the entry stays as a guard"}
 
 
@@ -55,9 +55,9 @@ def test_zstd_level3_real_data(O, gpu, kind, n):
 # The levels between the BASELINE ones on real bytes (round 6; the review of round 5 found zstd 9 on shared objects at 1.060 with no test looking): the lazy range (9, 12), C4's
 # level (19) and FLZMA2's first ultra level, 32 MiB each, level L against the reference's level L.  Figures: MI355X, run s2 of round 6 (tools/gpu_sizes.py).
 LEVEL_CASES = [("zstd", 5, "real-src"), ("zstd", 5, "real-bin"), ("zstd", 6, "real-src"), ("zstd", 9, "real-src"), ("zstd", 9, "real-bin"), ("zstd", 12, "real-src"), ("zstd", 12, "real-bin"), ("zstd", 19, "real-src"), ("zstd", 19, "real-bin"), ("flzma2", 7, "real-bin")]
-NOT_YET_LEVELS = {("zstd", 19, "real-src"): "1.092 x btultra2 on real sources (round 6; 1.095 in round 5, 1.152 in round 4): one merged record per position against the binary tree's list of matches, static prices, no block splitter",
+NOT_YET_LEVELS = {("zstd", 19, "real-src"): "1.077 x btultra2 on real sources (round 6: 16 MiB finder frames; 1.095 in round 5, 1.152 in round 4): one merged record per position against the binary tree's list of matches, static prices, no block splitter",
                   ("zstd", 19, "real-bin"): "1.044 x btultra2 on shared objects (round 6; 1.043 in round 5)",
-                  ("flzma2", 7, "real-bin"): "not measured before round 6's last session: the entry only turns a miss into an expected failure"}
+                  ("flzma2", 7, "real-bin"): "1.041 x the reference's level 7 on shared objects (round 6, first measurement; real sources 1.019)"}
 
 
 @pytest.mark.parametrize("codec,level,kind", LEVEL_CASES)
