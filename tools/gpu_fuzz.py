@@ -33,7 +33,7 @@ while time.time() - t0 < a.seconds:
         parts.append(np.ascontiguousarray(p)); n += L
     x = np.ascontiguousarray(np.concatenate(parts)) if parts else np.empty(0, dtype=np.uint8); n = x.size
     codec = ["zstd", "flzma2", "brotli"][it % 3]
-    level = int(rng.choice({"zstd": [1, 2, 3, 5, 7, 9, 10, 12, 16, 19], "flzma2": [1, 2, 3, 4, 5, 7, 9], "brotli": [1, 2, 3, 4, 5, 6, 8, 10]}[codec]))
+    level = int(rng.choice({"zstd": [1, 2, 3, 5, 6, 7, 9, 10, 12, 16, 18, 19, 22], "flzma2": [1, 2, 3, 4, 5, 7, 9], "brotli": [1, 2, 3, 4, 5, 6, 8, 9, 10, 11]}[codec]))
     key = (codec, level)
     if key not in encs:
         encs[key] = {"zstd": pkg.ZstdEncoder, "flzma2": pkg.Flzma2Encoder, "brotli": pkg.BrotliEncoder}[codec](level=level, **kw)
