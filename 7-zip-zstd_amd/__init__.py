@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(HERE, "csrc", "libgpucodec.so")
 HOOKS_LIB_PATH = os.path.join(HERE, "csrc", "libgpucodec_hooks.so")     # test build: GC_* environment hooks compiled in (tests / tools only)
 
 GC_OK = 0
-_ERR = {-1: "GC_ERR_NO_DEVICE", -2: "GC_ERR_HIP", -3: "GC_ERR_NOMEM", -4: "GC_ERR_DST_SMALL", -5: "GC_ERR_PARAM", -6: "GC_ERR_CORRUPT"}
+_ERR = {-1: "GC_ERR_NO_DEVICE", -2: "GC_ERR_HIP", -3: "GC_ERR_NOMEM", -4: "GC_ERR_DST_SMALL", -5: "GC_ERR_PARAM", -6: "GC_ERR_CORRUPT", -7: "GC_ERR_UNSUPPORTED"}
 
 EXPORTS = ["gc_test_hooks_enabled", "gc_lzfind_get_matches_device", "gc_device_count", "gc_ctx_create", "gc_ctx_destroy", "gc_last_error_message", "gc_zstd_compress_bound",
            "gc_zstd_compress_device", "gc_zstd_finish", "gc_zstd_compress_host", "gc_zstd_last_timing", "gc_ctx_stream",
@@ -31,7 +31,8 @@ EXPORTS = ["gc_test_hooks_enabled", "gc_lzfind_get_matches_device", "gc_device_c
            "gc_ctx_set_option", "gc_crc32_device", "gc_codec_grain", "gc_codec_compress_bound", "gc_host_begin", "gc_host_size", "gc_host_fetch", "gc_codec_compress_host",
            "gc_host_alloc", "gc_host_free", "gc_multi_create", "gc_multi_destroy", "gc_multi_workers", "gc_multi_last_error",
            "gc_multi_piece_bytes", "gc_multi_compress_host",
-           "gc_bra_convert_device", "gc_bra_x86_convert_device", "gc_delta_convert_device", "gc_zstd_scan_frames", "gc_zstd_scan_prefix", "gc_zstd_decompress_device", "gc_zstd_decompress_host", "gc_zstd_decompress_timing", "gc_zstd_decompress_kernel_timing", "gc_zstd_decompress_wide_rounds", "gc_zstd_decompress_selfcheck", "gc_filter_host"]
+           "gc_bra_convert_device", "gc_bra_x86_convert_device", "gc_delta_convert_device", "gc_zstd_scan_frames", "gc_zstd_scan_prefix", "gc_zstd_decompress_device", "gc_zstd_decompress_host", "gc_zstd_decompress_timing", "gc_zstd_decompress_kernel_timing", "gc_zstd_decompress_wide_rounds", "gc_zstd_decompress_selfcheck", "gc_filter_host",
+           "gc_brotli_scan_prefix", "gc_brotli_dec_set_dictionary", "gc_brotli_dec_has_dictionary", "gc_brotli_decompress_device", "gc_brotli_decompress_host", "gc_brotli_decompress_timing"]
 
 CODEC_ZSTD, CODEC_FLZMA2, CODEC_BROTLI = 0, 1, 2
 CODEC_IDS = {"zstd": CODEC_ZSTD, "flzma2": CODEC_FLZMA2, "brotli": CODEC_BROTLI}
@@ -141,6 +142,18 @@ def load_library(path=None):
     lib.gc_zstd_decompress_host.restype = C.c_int
     lib.gc_zstd_decompress_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
     lib.gc_zstd_decompress_timing.restype = C.c_int
+    lib.gc_brotli_scan_prefix.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.POINTER(C.c_size_t)]
+    lib.gc_brotli_scan_prefix.restype = C.c_int
+    lib.gc_brotli_dec_set_dictionary.argtypes = [C.c_void_p, C.c_size_t]
+    lib.gc_brotli_dec_set_dictionary.restype = C.c_int
+    lib.gc_brotli_dec_has_dictionary.argtypes = []
+    lib.gc_brotli_dec_has_dictionary.restype = C.c_int
+    lib.gc_brotli_decompress_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.gc_brotli_decompress_device.restype = C.c_int
+    lib.gc_brotli_decompress_host.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.gc_brotli_decompress_host.restype = C.c_int
+    lib.gc_brotli_decompress_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    lib.gc_brotli_decompress_timing.restype = C.c_int
     return lib
 
 
@@ -184,6 +197,11 @@ class ZstdFrame(C.Structure):
     """gc_zstd_frame of include/gpucodec.h"""
     _fields_ = [("src_off", C.c_uint64), ("src_size", C.c_uint64), ("dst_off", C.c_uint64), ("content_size", C.c_uint64),
                 ("flags", C.c_uint32), ("header_size", C.c_uint32), ("n_blocks", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class BrotliChunk(C.Structure):
+    """gc_brotli_chunk of include/gpucodec.h"""
+    _fields_ = [("src_off", C.c_uint64), ("src_size", C.c_uint32), ("capacity", C.c_uint32)]
 
 
 def crc32_device(ptr, n, lib_path=None):
@@ -436,6 +454,57 @@ class BrotliEncoder(_EncoderBase):
         ms = (C.c_float * 5)()
         self._check(self._lib.gc_brotli_last_timing(self._ctx, ms), "gc_brotli_last_timing")
         return dict(zip(self.KERNELS, [float(x) for x in ms]))
+
+
+class BrotliDecoder(_EncoderBase):
+    """Mirror of NCompress::NBROTLI::CDecoder (CPP/7zip/Compress/BrotliDecoder.cpp:124) for whole brotli-mt streams: one wave per chunk on the GPU.  A stream that refers to
+    the static dictionary of RFC 7932 needs set_dictionary() first (the library does not carry the 122 784 bytes; a host with a brotli of its own has them)."""
+
+    def set_dictionary(self, data):
+        import numpy as np
+        a = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data, dtype=np.uint8)
+        rc = self._lib.gc_brotli_dec_set_dictionary(a.ctypes.data if a.size else None, a.size)
+        if rc != GC_OK:
+            raise GpuCodecError("gc_brotli_dec_set_dictionary: %s (not the dictionary of RFC 7932 Appendix A)" % _ERR.get(rc, rc))
+
+    def has_dictionary(self):
+        return bool(self._lib.gc_brotli_dec_has_dictionary())
+
+    def scan(self, data):
+        """-> (array of BrotliChunk, their number, the sum of their capacities, bytes of whole frames)"""
+        import numpy as np
+        a = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data, dtype=np.uint8)
+        n = C.c_size_t(0); used = C.c_size_t(0); cap = C.c_uint64(0)
+        rc = self._lib.gc_brotli_scan_prefix(a.ctypes.data, a.size, None, 0, C.byref(n), None, None)
+        if rc != GC_OK:
+            raise GpuCodecError("gc_brotli_scan_prefix failed: %s" % _ERR.get(rc, rc))
+        chunks = (BrotliChunk * max(1, n.value))()
+        rc = self._lib.gc_brotli_scan_prefix(a.ctypes.data, a.size, chunks, n.value, C.byref(n), C.byref(cap), C.byref(used))
+        if rc != GC_OK:
+            raise GpuCodecError("gc_brotli_scan_prefix failed: %s" % _ERR.get(rc, rc))
+        return chunks, n.value, cap.value, used.value
+
+    def code(self, data, capacity=None):
+        """brotli-mt stream (or a bare RFC 7932 stream, then capacity is needed) -> numpy uint8 content (host buffers; includes PCIe copies)"""
+        import numpy as np
+        a = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data, dtype=np.uint8)
+        if capacity is None:
+            framed = a.size >= 4 and int.from_bytes(a[:4].tobytes(), "little") == 0x184D2A50
+            capacity = self.scan(a)[2] if framed else max(1 << 20, 64 * a.size)
+        out = np.empty(max(1, capacity), dtype=np.uint8)
+        n = C.c_size_t(0)
+        self._check(self._lib.gc_brotli_decompress_host(self._ctx, a.ctypes.data, a.size, out.ctypes.data, capacity, C.byref(n)), "gc_brotli_decompress_host")
+        return out[:n.value]
+
+    def code_device(self, d_src_ptr, n, d_dst_ptr, dst_cap, chunks, n_chunks):
+        size = C.c_size_t(0)
+        self._check(self._lib.gc_brotli_decompress_device(self._ctx, d_src_ptr, n, d_dst_ptr, dst_cap, chunks, n_chunks, C.byref(size)), "gc_brotli_decompress_device")
+        return size.value
+
+    def last_timing_ms(self):
+        ms = C.c_float(0)
+        self._check(self._lib.gc_brotli_decompress_timing(self._ctx, C.byref(ms)), "gc_brotli_decompress_timing")
+        return float(ms.value)
 
 
 class ZstdDecoder(_EncoderBase):

@@ -10,6 +10,7 @@
 #include "gc_brotli.h"
 #include "gc_mf.h"
 #include "gc_zstd_dec.h"
+#include "gc_brotli_dec.h"
 #ifdef HIPEMU
 #include "hip_runtime_stub.h"
 #else
@@ -150,6 +151,7 @@ struct gc_ctx {
     int lastCodec;            // 0 zstd, 1 flzma2, 2 brotli: which kernels the events of the last call bracket
     uint64_t* hostResult;     // pinned
     // staging for the host-buffer entry point
+    GcBrDecWork brd;          // BROTLI decoder (gc_brotli_dec.hip)
     uint8_t* dIn; size_t dInCap; uint8_t* dOut; size_t dOutCap; uint8_t* dPre; size_t dPreCap;      // (dPre: the pre-filtered input of gc_host_begin_pre)
     bool pending; bool timed;
     // zstd decoder (gc_zstd_dec.hip): per-workgroup literal / sequence workspace, frame table, per-frame results, ticket counter
@@ -198,6 +200,8 @@ extern "C" size_t gc_zstd_compress_bound(size_t n)
 }
 
 static void free_workspace(gc_ctx* c);
+void gc_brd_release(GcBrDecWork* w);
+int gc_brd_decode(hipStream_t st, GcBrDecWork* w, const uint8_t* d_src, const gc_brotli_chunk* chunks, size_t nChunks, uint8_t* d_dst, size_t dstCap, size_t* produced, char* err, size_t errCap);
 static void ctx_release(gc_ctx* c);
 
 extern "C" int gc_ctx_create(gc_ctx** out, int device)
@@ -252,6 +256,7 @@ static void ctx_release(gc_ctx* c)
     if (c->stream) hipStreamSynchronize(c->stream);
     free_workspace(c);
     hipFree(c->prof); hipFree(c->mfTicket); hipFree(c->result); if (c->hostResult) hipHostFree(c->hostResult); hipFree(c->dIn); hipFree(c->dOut); hipFree(c->dPre);
+    gc_brd_release(&c->brd);
     hipFree(c->zdLit); hipFree(c->zdSeq); hipFree(c->zdFrames); hipFree(c->zdResult); hipFree(c->zdTot); hipFree(c->zdBlocks); hipFree(c->zdOrder); hipFree(c->zdReady); hipFree(c->zdTicket); hipFree(c->zdPlace); hipFree(c->zdPtr); hipFree(c->zdDone); hipFree(c->zdFerr);
     for (int i = 0; i < 2; i++) if (c->zdEv[i]) hipEventDestroy(c->zdEv[i]);
     hipFree(c->mfTileWord); hipFree(c->mfCnt); hipFree(c->mfEnt); hipFree(c->mfEnt2); hipFree(c->mfRec); hipFree(c->mfRec2); hipFree(c->mfChanged); hipFree(c->mfRec3); hipFree(c->mfDp); hipFree(c->mfPrice); hipFree(c->mfWinCost); hipFree(c->mfDpStat); hipFree(c->mfLitPrice);
@@ -1595,3 +1600,52 @@ extern "C" int gc_zstd_decompress_host(gc_ctx* c, const void* src, size_t n, voi
     if (rc == GC_OK && outSize) *outSize = produced;
     return rc;
 }
+
+// ---- BROTLI decoder (gc_brotli_dec.hip): the context's stream and buffers around gc_brd_decode
+extern "C" int gc_brotli_decompress_device(gc_ctx* c, const void* d_src, size_t n, void* d_dst, size_t dstCap, const gc_brotli_chunk* chunks, size_t nChunks, size_t* outSize)
+{
+    if (!c || (!d_src && n) || (!chunks && nChunks) || !outSize) return GC_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    *outSize = 0;
+#ifdef GC_TEST_HOOKS
+    { const char* e = getenv("GC_BRD_LDS"); c->brd.ldsCap = e ? (uint32_t)atoi(e) : 0u; }
+#endif
+    for (size_t i = 0; i < nChunks; i++) if (chunks[i].src_off > n || chunks[i].src_size > n - chunks[i].src_off) { snprintf(c->err, sizeof(c->err), "brotli chunk %zu lies outside the %zu input bytes", i, n); return GC_ERR_PARAM; }
+    return gc_brd_decode(c->stream, &c->brd, (const uint8_t*)d_src, chunks, nChunks, (uint8_t*)d_dst, dstCap, outSize, c->err, sizeof(c->err));
+}
+extern "C" int gc_brotli_decompress_host(gc_ctx* c, const void* src, size_t n, void* dst, size_t dstCap, size_t* outSize)
+{
+    if (!c || (!src && n) || (!dst && dstCap)) return GC_ERR_PARAM;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (outSize) *outSize = 0;
+    if (n == 0) return GC_OK;
+    size_t nChunks = 0, consumed = 0;
+    gc_brotli_chunk one; gc_brotli_chunk* ch = nullptr;
+    uint32_t magic = 0; if (n >= 4) memcpy(&magic, src, 4);
+    int rc = GC_OK;
+    if (magic != 0x184D2A50u) {                                   // a bare RFC 7932 stream: one chunk
+        one.src_off = 0; one.src_size = (uint32_t)n; one.capacity = (uint32_t)(dstCap < 0xFFFF0000u ? dstCap : 0xFFFF0000u);
+        if (n > 0xFFFFFFFFu) return GC_ERR_PARAM;
+        ch = &one; nChunks = 1;
+    } else {
+        rc = gc_brotli_scan_prefix(src, n, nullptr, 0, &nChunks, nullptr, &consumed);
+        if (rc == GC_OK && consumed != n) rc = GC_ERR_CORRUPT;   // the input ends inside a frame
+        if (rc != GC_OK) { snprintf(c->err, sizeof(c->err), "not a whole brotli-mt stream (frame scan failed)"); return rc; }
+        ch = (gc_brotli_chunk*)malloc((nChunks ? nChunks : 1) * sizeof(gc_brotli_chunk));
+        if (!ch) return GC_ERR_NOMEM;
+        rc = gc_brotli_scan_prefix(src, n, ch, nChunks, &nChunks, nullptr, &consumed);
+    }
+    if (rc == GC_OK && n > c->dInCap) { hipFree(c->dIn); c->dIn = nullptr; c->dInCap = 0; if (hipMalloc((void**)&c->dIn, n + 64) != hipSuccess) rc = GC_ERR_NOMEM; else c->dInCap = n; }
+    if (rc == GC_OK && dstCap > c->dOutCap) { hipFree(c->dOut); c->dOut = nullptr; c->dOutCap = 0; if (hipMalloc((void**)&c->dOut, dstCap + 64) != hipSuccess) rc = GC_ERR_NOMEM; else c->dOutCap = dstCap; }
+    size_t produced = 0;
+    if (rc == GC_OK && hipMemcpyAsync(c->dIn, src, n, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = GC_ERR_HIP;
+#ifdef GC_TEST_HOOKS
+    { const char* e = getenv("GC_BRD_LDS"); c->brd.ldsCap = e ? (uint32_t)atoi(e) : 0u; }
+#endif
+    if (rc == GC_OK) rc = gc_brd_decode(c->stream, &c->brd, c->dIn, ch, nChunks, c->dOut, dstCap, &produced, c->err, sizeof(c->err));
+    if (rc == GC_OK && produced && (hipMemcpyAsync(dst, c->dOut, produced, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)) rc = GC_ERR_HIP;
+    if (ch != &one) free(ch);
+    if (rc == GC_OK && outSize) *outSize = produced;
+    return rc;
+}
+extern "C" int gc_brotli_decompress_timing(gc_ctx* c, float* ms) { if (!c || !ms) return GC_ERR_PARAM; *ms = c->brd.ms; return GC_OK; }

@@ -1,0 +1,731 @@
+// gc_brotli_dec.hip -- BROTLI decoder (7-Zip method id 0x4F71102): the decoding half of what NCompress::NBROTLI::CDecoder
+// (CPP/7zip/Compress/BrotliDecoder.cpp:124) runs through BROTLIMT_decompressDCtx (C/zstdmt/brotli-mt_decompress.c:191-288: 16-byte frame headers
+// 0x184D2A50, 8, compressed size, 0x5242, hint in 64 KiB units -- each followed by a complete RFC 7932 stream) and BrotliDecoderDecompressStream
+// (C/brotli/br_decode.c).
+//
+// Brotli's literal trees are chosen by the bytes just produced and its copies reach back over everything the stream has produced, so INSIDE a stream the
+// entropy decoder cannot run ahead of the output the way the zstd decoder's stages do.  What is independent are the brotli-mt chunks:
+// config C5 is 1 590 of them.  One WAVE per chunk: lane 0 runs the stream's state machine (bit reader, prefix codes, context maps, block switches, the
+// insert-and-copy commands), all 64 lanes move the bytes of a copy that is longer than a few bytes and does not overlap itself.  Every chunk decodes into a
+// slot of its hint size; a scan over the chunks' real sizes and a copy kernel pack the content (brotli-mt's hint is an upper bound, not the size).
+//
+// Prefix codes are kept CANONICAL (RFC 7932 section 3.2): per code the count, the first code and the first symbol index of every length (96 bytes) + the symbols in
+// code order, in an LDS arena of the wave; a meta-block of the reference's quality 10-11 can hold up to 256 literal and 256 distance trees: what does not fit LDS
+// goes to a page in HBM (same code, flat addresses).  A symbol is decoded by the WAVE: lane l tests whether the next l bits are a code of length l (canonical
+// codes: exactly one length answers), a ballot names the length -- no tables to build, which is what a meta-block header with 13-256 trees would spend its time on.
+// The stream's state machine (bit reader, block switches, commands, distance ring) runs in all lanes alike; headers (prefix codes, context maps) are read by lane
+// 0; copies are done by the wave (lane i writes byte i: a copy that overlaps itself reads `i mod distance`).
+//
+// The static dictionary of RFC 7932 Appendix A (122 784 bytes, CRC-32 0x5136cb04 as the RFC states it) is NORMATIVE DATA that this repository does not hold: the
+// host hands it over once (gc_brotli_dec_set_dictionary: the plugin built inside the reference tree passes BrotliGetDictionary()->data of the host's own
+// C/brotli/br_dictionary.c); without it a stream that refers to the dictionary is answered with GC_ERR_UNSUPPORTED -- this engine's own
+// streams never do.  The 121 transforms of Appendix B are in gc_brotli_transforms.h.
+#include "gpucodec.h"
+#include "gc_common.h"
+#include "gc_device.h"
+#include "gc_brotli.h"
+#include "gc_brotli_dec.h"
+#ifdef HIPEMU
+#include "hip_runtime_stub.h"
+#include <stdio.h>
+#else
+#include <hip/hip_runtime.h>
+#define GC_LAUNCH(kernel, grid, block, stream, ...) hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, stream, __VA_ARGS__)
+#endif
+#include <stdlib.h>
+#include <string.h>
+#include "gc_host_stream.h"
+#include "gc_brotli_transforms.h"
+
+// status of one chunk
+#define BRD_OK          0u
+#define BRD_CORRUPT     1u
+#define BRD_DST_SMALL   2u
+#define BRD_DICTIONARY  3u            // the stream refers to the static dictionary and none is loaded
+#define BRD_LIMIT       4u            // more trees / block types than the arenas hold
+
+#define BRD_LDS_ARENA   18432u        // bytes of prefix codes per wave in LDS
+#define BRD_CMAP_LDS    2560u         // context map bytes per wave in LDS (64 per literal block type + 4 per distance block type)
+#define BRD_PAGE        (800u * 1024u)      // what a chunk takes in HBM when LDS does not hold its meta-block (256 literal + 256 command + 256 distance trees at their largest: 0.77 MB)
+#define BRD_MAX_WAVES   1792u         // 7 waves per CU (LDS) x 256 CUs: the launch's width; chunks beyond it are taken in turns
+
+struct GcBrDecChunk { uint64_t srcOff; uint64_t stageOff; uint32_t srcSize; uint32_t hintBytes; };      // payload of one brotli-mt frame (or a whole plain stream)
+struct GcBrDecResult { uint32_t size; uint32_t status; };
+struct GcBrDict { const uint8_t* words; };                                                               // RFC 7932 Appendix A, or null
+
+// ---- format tables (RFC 7932): insert / copy length codes (section 5), block counts (section 6), code length code order (section 3.5), dictionary buckets (section 8)
+__constant__ uint16_t kdInsBase[24] = { 0,1,2,3,4,5,6,8,10,14,18,26,34,50,66,98,130,194,322,578,1090,2114,6210,22594 };
+__constant__ uint8_t  kdInsExtra[24] = { 0,0,0,0,0,0,1,1,2,2,3,3,4,4,5,5,6,7,8,9,10,12,14,24 };
+__constant__ uint16_t kdCopyBase[24] = { 2,3,4,5,6,7,8,9,10,12,14,18,22,30,38,54,70,102,134,198,326,582,1094,2118 };
+__constant__ uint8_t  kdCopyExtra[24] = { 0,0,0,0,0,0,0,0,1,1,2,2,3,3,4,4,5,5,6,7,8,9,10,24 };
+__constant__ uint8_t  kdCellIns[11] = { 0, 0, 0, 0, 8, 8, 0, 16, 8, 16, 16 };
+__constant__ uint8_t  kdCellCopy[11] = { 0, 8, 0, 8, 0, 8, 16, 0, 16, 8, 16 };
+__constant__ uint16_t kdBlockBase[26] = { 1,5,9,13,17,25,33,41,49,65,81,97,113,145,177,209,241,305,369,497,753,1265,2289,4337,8433,16625 };
+__constant__ uint8_t  kdBlockExtra[26] = { 2,2,2,2,3,3,3,3,4,4,4,4,5,5,5,5,6,6,7,8,9,10,11,12,13,24 };
+__constant__ uint8_t  kdClcOrder[18] = { 1, 2, 3, 4, 0, 5, 17, 6, 16, 7, 8, 9, 10, 11, 12, 13, 14, 15 };
+__constant__ uint8_t  kdDictBits[25] = { 0,0,0,0,10,10,11,11,10,10,10,10,10,9,9,8,7,7,8,7,7,6,6,5,5 };
+__constant__ uint32_t kdDictOff[25] = { 0,0,0,0,0,4096,9216,21504,35840,44032,53248,63488,74752,87040,93696,100864,104704,106752,108928,113536,115968,118528,119872,121280,122016 };
+
+struct BrdBits {                      // LSB-first bit reader over the chunk's bytes; identical in every lane
+    const uint8_t* p; uint64_t acc; uint32_t n; uint32_t pos, end; uint32_t over;
+};
+__device__ __forceinline__ void brd_fill(BrdBits& b)               // afterwards n >= 33
+{
+    if (b.pos + 4u <= b.end) { uint32_t v; __builtin_memcpy(&v, b.p + b.pos, 4); b.acc |= (uint64_t)v << b.n; b.n += 32u; b.pos += 4u; return; }
+    while (b.n <= 56u) { const uint64_t v = b.pos < b.end ? b.p[b.pos] : 0ull; if (b.pos >= b.end + 16u) b.over = 1u; b.acc |= v << b.n; b.n += 8u; b.pos++; }
+}
+__device__ __forceinline__ uint32_t brd_take(BrdBits& b, uint32_t k)      // k <= 32
+{
+    if (b.n <= 32u) brd_fill(b);
+    const uint32_t v = (uint32_t)(b.acc & ((1ull << k) - 1ull));
+    b.acc >>= k; b.n -= k;
+    return v;
+}
+__device__ __forceinline__ uint32_t brd_consumed(const BrdBits& b) { return b.pos - (b.n >> 3); }      // bytes whose bits have been taken (rounded up)
+
+// a canonical prefix code: t[0..15] codes per length (t[0] = 1: ONE symbol, coded in zero bits), t[16..31] first code of the length, t[32..47] index of its first symbol
+struct BrdTree { const uint16_t* t; const uint8_t* sym8; const uint16_t* sym16; };
+__device__ __forceinline__ uint32_t brd_tree_sym(const BrdTree& t, uint32_t i) { return t.sym16 ? t.sym16[i] : t.sym8[i]; }
+// one lane on its own (headers)
+__device__ uint32_t brd_sym(BrdBits& b, const BrdTree& t)
+{
+    if (t.t[0]) return brd_tree_sym(t, 0);
+    if (b.n <= 32u) brd_fill(b);
+    const uint32_t rev = __brev((uint32_t)b.acc);
+#pragma unroll 1
+    for (uint32_t len = 1; len <= 15u; len++) {
+        const uint32_t c = rev >> (32u - len);
+        if (c - t.t[16u + len] < t.t[len]) { b.acc >>= len; b.n -= len; return brd_tree_sym(t, t.t[32u + len] + c - t.t[16u + len]); }
+    }
+    b.over = 1u;                                                  // not a code word: the code is incomplete (damaged)
+    return 0;
+}
+// the wave together (commands, literals, distances, block switches): every lane holds the same reader and gets the same symbol
+__device__ __forceinline__ uint32_t brd_sym_w(BrdBits& b, const BrdTree& t, uint32_t lane)
+{
+    if (t.t[0]) return brd_tree_sym(t, 0);
+    if (b.n <= 32u) brd_fill(b);
+    const uint32_t rev = __brev((uint32_t)b.acc), l = lane & 15u;
+    const uint32_t c = l ? rev >> (32u - l) : 0u;
+    const bool hit = l != 0u && c - t.t[16u + l] < t.t[l];
+    const uint64_t m = __ballot(hit) & 0xFFFEull;
+    if (m == 0ull) { b.over = 1u; return 0; }
+    const uint32_t len = (uint32_t)__ffsll((long long)m) - 1u;
+    const uint32_t i = t.t[32u + len] + (rev >> (32u - len)) - t.t[16u + len];
+    b.acc >>= len; b.n -= len;
+    return brd_tree_sym(t, i);
+}
+
+struct BrdArena { uint8_t* lds; uint32_t ldsCap, ldsUsed; uint8_t* hbm; uint32_t hbmCap, hbmUsed; };
+__device__ __forceinline__ uint8_t* brd_alloc(BrdArena& a, uint32_t bytes)
+{
+    bytes = (bytes + 7u) & ~7u;
+    if (a.ldsUsed + bytes <= a.ldsCap) { uint8_t* p = a.lds + a.ldsUsed; a.ldsUsed += bytes; return p; }
+    if (a.hbm && a.hbmUsed + bytes <= a.hbmCap) { uint8_t* p = a.hbm + a.hbmUsed; a.hbmUsed += bytes; return p; }
+    return nullptr;
+}
+// lengths (0..15) of `alpha` symbols -> the canonical code in the arena
+__device__ bool brd_build(const uint8_t* len, uint32_t alpha, BrdArena& A, BrdTree& out)
+{
+    const bool wide = alpha > 256u;
+    uint32_t cnt[16]; for (uint32_t k = 0; k < 16u; k++) cnt[k] = 0;
+    for (uint32_t sy = 0; sy < alpha; sy++) cnt[len[sy]]++;
+    const uint32_t nUsed = alpha - cnt[0];
+    uint8_t* mem = brd_alloc(A, 96u + (nUsed ? nUsed : 1u) * (wide ? 2u : 1u));
+    if (!mem) return false;
+    uint16_t* T = (uint16_t*)mem;
+    uint32_t code = 0, index = 0, off[16];
+    T[0] = 0; T[16] = 0; T[32] = 0;
+    for (uint32_t L = 1; L <= 15u; L++) { T[L] = (uint16_t)cnt[L]; T[16u + L] = (uint16_t)code; T[32u + L] = (uint16_t)index; off[L] = index; index += cnt[L]; code = (code + cnt[L]) << 1; }
+    for (uint32_t sy = 0; sy < alpha; sy++) { const uint32_t L = len[sy]; if (L) { const uint32_t k = off[L]++; if (wide) ((uint16_t*)(mem + 96u))[k] = (uint16_t)sy; else mem[96u + k] = (uint8_t)sy; } }
+    out.t = T; out.sym8 = wide ? nullptr : mem + 96u; out.sym16 = wide ? (const uint16_t*)(mem + 96u) : nullptr;
+    return true;
+}
+__device__ bool brd_build_single(uint32_t sym, bool wide, BrdArena& A, BrdTree& out)
+{
+    uint8_t* mem = brd_alloc(A, 96u + 2u);
+    if (!mem) return false;
+    uint16_t* T = (uint16_t*)mem; for (uint32_t k = 0; k < 48u; k++) T[k] = 0;
+    T[0] = 1;
+    if (wide) ((uint16_t*)(mem + 96u))[0] = (uint16_t)sym; else mem[96] = (uint8_t)sym;
+    out.t = T; out.sym8 = wide ? nullptr : mem + 96u; out.sym16 = wide ? (const uint16_t*)(mem + 96u) : nullptr;
+    return true;
+}
+
+// Reads one prefix code over an alphabet of `alpha` symbols (RFC 7932 sections 3.4 / 3.5) into the arena.  len[] = scratch of alpha bytes.  One lane.
+__device__ bool brd_read_code(BrdBits& b, uint32_t alpha, BrdArena& A, uint8_t* len, BrdTree& out, uint32_t& status)
+{
+    const uint32_t hskip = brd_take(b, 2);
+    if (hskip == 1u) {                                            // simple code: 1..4 symbols
+        const uint32_t nsym = brd_take(b, 2) + 1u;
+        uint32_t abits = 0; while ((1u << abits) < alpha) abits++;
+        uint32_t s[4] = { 0, 0, 0, 0 };
+        for (uint32_t i = 0; i < nsym; i++) { s[i] = brd_take(b, abits); if (s[i] >= alpha) { status = BRD_CORRUPT; return false; } }
+        for (uint32_t i = 0; i < nsym; i++) for (uint32_t j = i + 1u; j < nsym; j++) if (s[i] == s[j]) { status = BRD_CORRUPT; return false; }
+        if (nsym == 1u) { if (!brd_build_single(s[0], alpha > 256u, A, out)) { status = BRD_LIMIT; return false; } return true; }
+        for (uint32_t i = 0; i < alpha; i++) len[i] = 0;
+        if (nsym == 2u) { len[s[0]] = 1; len[s[1]] = 1; }
+        else if (nsym == 3u) { len[s[0]] = 1; len[s[1]] = 2; len[s[2]] = 2; }
+        else if (brd_take(b, 1)) { len[s[0]] = 1; len[s[1]] = 2; len[s[2]] = 3; len[s[3]] = 3; }
+        else { len[s[0]] = 2; len[s[1]] = 2; len[s[2]] = 2; len[s[3]] = 2; }
+        if (!brd_build(len, alpha, A, out)) { status = BRD_LIMIT; return false; }
+        return true;
+    }
+    // complex code: the lengths of the 18 code length symbols (a fixed code of 2-4 bits each), then the symbols' lengths under that code
+    uint8_t cl[18]; for (uint32_t i = 0; i < 18u; i++) cl[i] = 0;
+    int space = 32; uint32_t numCodes = 0;
+    for (uint32_t i = hskip; i < 18u && space > 0; i++) {
+        if (b.n <= 32u) brd_fill(b);
+        const uint32_t p = (uint32_t)b.acc & 15u;
+        uint32_t v, nb;
+        if ((p & 3u) == 0u) { v = 0; nb = 2; } else if ((p & 3u) == 2u) { v = 3; nb = 2; } else if ((p & 3u) == 1u) { v = 4; nb = 2; }
+        else if ((p & 4u) == 0u) { v = 2; nb = 3; } else if ((p & 8u) == 0u) { v = 1; nb = 4; } else { v = 5; nb = 4; }
+        b.acc >>= nb; b.n -= nb;
+        cl[kdClcOrder[i]] = (uint8_t)v;
+        if (v) { space -= 32 >> v; numCodes++; }
+    }
+    if (!(numCodes == 1u || space == 0)) { status = BRD_CORRUPT; return false; }
+    uint16_t ct[48]; uint8_t csym[18];
+    for (uint32_t i = 0; i < 48u; i++) ct[i] = 0;
+    if (numCodes == 1u) { ct[0] = 1; for (uint32_t sy = 0; sy < 18u; sy++) if (cl[sy]) csym[0] = (uint8_t)sy; }
+    else { uint32_t code = 0, k = 0; for (uint32_t L = 1; L <= 5u; L++) { ct[16u + L] = (uint16_t)code; ct[32u + L] = (uint16_t)k; for (uint32_t sy = 0; sy < 18u; sy++) if (cl[sy] == L) { csym[k++] = (uint8_t)sy; ct[L]++; } code = (code + ct[L]) << 1; } }
+    BrdTree cT; cT.t = ct; cT.sym8 = csym; cT.sym16 = nullptr;
+    uint32_t i = 0, prev = 8, rep = 0, repLen = 0;
+    int sp = 32768;
+    while (i < alpha && sp > 0) {
+        const uint32_t v = brd_sym(b, cT);
+        if (b.over) { status = BRD_CORRUPT; return false; }
+        if (v < 16u) {
+            len[i++] = (uint8_t)v; rep = 0;
+            if (v) { prev = v; sp -= 32768 >> v; }
+        } else {
+            const uint32_t extra = v == 16u ? 2u : 3u, newLen = v == 16u ? prev : 0u;
+            if (repLen != newLen) { rep = 0; repLen = newLen; }
+            const uint32_t old = rep;
+            if (rep > 0u) rep = (rep - 2u) << extra;
+            rep += brd_take(b, extra) + 3u;
+            const uint32_t delta = rep - old;
+            if (i + delta > alpha) { status = BRD_CORRUPT; return false; }
+            for (uint32_t k = 0; k < delta; k++) len[i + k] = (uint8_t)newLen;
+            i += delta;
+            if (newLen) sp -= (int)(delta << (15u - newLen));
+        }
+    }
+    if (sp != 0) { status = BRD_CORRUPT; return false; }
+    for (; i < alpha; i++) len[i] = 0;
+    if (!brd_build(len, alpha, A, out)) { status = BRD_LIMIT; return false; }
+    return true;
+}
+
+__device__ __forceinline__ uint32_t brd_varlen8(BrdBits& b)     // VarLenUint8: 0..255
+{
+    if (!brd_take(b, 1)) return 0u;
+    const uint32_t nb = brd_take(b, 3);
+    return nb ? (1u << nb) + brd_take(b, nb) : 1u;
+}
+
+// context ids of the four literal context modes (RFC 7932 section 7.1): lut[0..255] for the last byte, lut[256..511] for the one before (their OR for UTF8 and SIGNED)
+__device__ __forceinline__ uint32_t brd_utf8_0(uint32_t b)
+{
+    if (b >= 192u) return 2u + (b & 1u);
+    if (b >= 128u) return b & 1u;
+    const uint32_t l = b | 0x20u; const bool letter = l >= 'a' && l <= 'z';
+    const bool vowel = l == 'a' || l == 'e' || l == 'i' || l == 'o' || l == 'u';
+    uint32_t k = 3u;
+    if (b == 9u || b == 10u || b == 13u) k = 1u;
+    else if (b < 32u || b == 127u) k = 0u;
+    else if (b == ' ') k = 2u;
+    else if (b == '"' || b == '\'') k = 4u;
+    else if (b == '%') k = 5u;
+    else if (b == '(' || b == '<' || b == '[' || b == '{') k = 6u;
+    else if (b == ')' || b == '>' || b == ']' || b == '}') k = 7u;
+    else if (b == ',' || b == ';' || b == ':') k = 8u;
+    else if (b == '.') k = 9u;
+    else if (b == '=') k = 10u;
+    else if (b >= '0' && b <= '9') k = 11u;
+    else if (letter) k = (b < 'a' ? 12u : 14u) + (vowel ? 0u : 1u);
+    return 4u * k;
+}
+__device__ __forceinline__ uint32_t brd_utf8_1(uint32_t b)
+{
+    if (b >= 224u) return 2u;
+    if (b >= 128u) return 0u;
+    if (b <= 32u || b == 127u) return 0u;
+    if ((b >= '0' && b <= '9') || (b >= 'A' && b <= 'Z')) return 2u;
+    if (b >= 'a' && b <= 'z') return 3u;
+    return 1u;
+}
+__device__ __forceinline__ uint32_t brd_signed(uint32_t b) { return b == 0u ? 0u : (b < 16u ? 1u : (b < 64u ? 2u : (b < 128u ? 3u : (b < 192u ? 4u : (b < 240u ? 5u : (b < 255u ? 6u : 7u)))))); }
+
+// one category of block types (literals, insert-and-copy, distances): RFC 7932 section 6
+struct BrdBlocks { uint32_t n, type, prev, left; BrdTree typeCode, countCode; };
+__device__ __forceinline__ uint32_t brd_block_count(BrdBits& b, const BrdTree& t)
+{
+    const uint32_t s = brd_sym(b, t);
+    return s < 26u ? kdBlockBase[s] + brd_take(b, kdBlockExtra[s]) : 0u;
+}
+__device__ __forceinline__ void brd_switch_w(BrdBits& b, BrdBlocks& B, uint32_t lane)
+{
+    const uint32_t s = brd_sym_w(b, B.typeCode, lane);
+    uint32_t t = s == 0u ? B.prev : (s == 1u ? B.type + 1u : s - 2u);
+    if (t >= B.n) t -= B.n;
+    B.prev = B.type; B.type = t;
+    const uint32_t cs = brd_sym_w(b, B.countCode, lane);
+    B.left = cs < 26u ? kdBlockBase[cs] + brd_take(b, kdBlockExtra[cs]) : 0u;
+}
+
+// context map (RFC 7932 section 7.3): `size` entries in out[].  One lane.
+__device__ bool brd_context_map(BrdBits& b, uint32_t size, uint32_t& nTrees, uint8_t* out, BrdArena& A, uint8_t* lenScratch, uint32_t& status)
+{
+    nTrees = brd_varlen8(b) + 1u;
+    if (nTrees == 1u) { for (uint32_t i = 0; i < size; i++) out[i] = 0; return true; }
+    uint32_t rleMax = 0;
+    if (brd_take(b, 1)) rleMax = brd_take(b, 4) + 1u;
+    BrdArena tmp = A;                                             // the map's own code is only needed here: its arena space is given back
+    BrdTree t;
+    if (!brd_read_code(b, nTrees + rleMax, tmp, lenScratch, t, status)) return false;
+    for (uint32_t i = 0; i < size;) {
+        const uint32_t s = brd_sym(b, t);
+        if (b.over) { status = BRD_CORRUPT; return false; }
+        if (s == 0u) out[i++] = 0;
+        else if (s <= rleMax) { const uint32_t run = (1u << s) + brd_take(b, s); if (i + run > size) { status = BRD_CORRUPT; return false; } for (uint32_t k = 0; k < run; k++) out[i++] = 0; }
+        else out[i++] = (uint8_t)(s - rleMax);
+    }
+    if (brd_take(b, 1)) {                                         // inverse move-to-front
+        uint8_t mtf[256]; for (uint32_t i = 0; i < 256u; i++) mtf[i] = (uint8_t)i;
+        for (uint32_t i = 0; i < size; i++) { const uint32_t idx = out[i]; const uint8_t v = mtf[idx]; out[i] = v; for (uint32_t k = idx; k > 0u; k--) mtf[k] = mtf[k - 1u]; mtf[0] = v; }
+    }
+    for (uint32_t i = 0; i < size; i++) if (out[i] >= nTrees) { status = BRD_CORRUPT; return false; }
+    return true;
+}
+
+// what lane 0 read from a meta-block's header, for the wave (LDS)
+struct BrdMeta {
+    uint64_t acc; uint32_t n, pos, over, status;
+    uint32_t kind;                        // 0 compressed, 1 uncompressed (copy `mlen` bytes from srcAt), 2 nothing to produce, 3 the stream has ended
+    uint32_t mlen, last, srcAt;
+    uint32_t nTypes[3], left[3];
+    uint32_t npostfix, ndirect;
+    BrdTree typeCode[3], countCode[3];
+    BrdTree *TL, *TI, *TD; uint8_t *cmapL, *cmapD, *modes;
+};
+
+// ------------------------------------------------------------------------------------------------ one wave per chunk
+extern "C" __global__ void __launch_bounds__(64)
+gc_brotli_dec_kernel(const uint8_t* __restrict__ src, const GcBrDecChunk* __restrict__ chunks, uint32_t nChunks, uint8_t* __restrict__ stage,
+                     uint8_t* __restrict__ pages, uint32_t nPages, uint32_t* __restrict__ pageCursor, GcBrDecResult* __restrict__ result, GcBrDict dict, uint32_t ldsCap)
+{
+    __shared__ __attribute__((aligned(8))) uint8_t sArena[BRD_LDS_ARENA];
+    __shared__ uint8_t sCmap[BRD_CMAP_LDS];
+    __shared__ uint8_t sLut[512];                                 // UTF8 context ids (mode 2), the mode of every stream this engine writes and of nearly every one of the reference
+    __shared__ uint8_t sLen[704];
+    __shared__ BrdMeta sMeta;
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t i = lane; i < 256u; i += 64u) { sLut[i] = (uint8_t)brd_utf8_0(i); sLut[256u + i] = (uint8_t)brd_utf8_1(i); }
+    gc_wave_sync();
+    for (uint32_t c = blockIdx.x; c < nChunks; c += gridDim.x) {
+        const GcBrDecChunk ck = chunks[c];
+        uint8_t* const out = stage + ck.stageOff;
+        const uint32_t cap = ck.hintBytes;
+        uint8_t* myPage = nullptr;                                // taken from the pool when a meta-block needs it, kept for the chunk
+        uint32_t status = BRD_OK, pos = 0;
+        BrdBits b; b.p = src + ck.srcOff; b.acc = 0; b.n = 0; b.pos = 0; b.end = ck.srcSize; b.over = 0u;
+        // stream header: WBITS (RFC 7932 section 9.1)
+        uint32_t wbits = 16;
+        if (brd_take(b, 1)) { const uint32_t n = brd_take(b, 3); if (n) wbits = 17u + n; else { const uint32_t m = brd_take(b, 3); if (m == 1u) status = BRD_CORRUPT; else wbits = m ? 8u + m : 17u; } }
+        const uint32_t maxBack = (1u << wbits) - 16u;
+        int ring[4] = { 16, 15, 11, 4 }; uint32_t ringIdx = 0;  // the last distance is ring[(ringIdx - 1) & 3]
+        bool last = false;
+        while (!last && status == BRD_OK) {
+            // ---- meta-block header: lane 0 reads it (prefix codes and context maps are serial work), the wave takes over what it found
+            if (lane == 0u) {
+                BrdMeta M; M.kind = 2; M.mlen = 0; M.srcAt = 0;
+                uint32_t st = BRD_OK;
+                M.last = brd_take(b, 1);
+                if (M.last && brd_take(b, 1)) M.kind = 3;         // ISLASTEMPTY
+                else {
+                    const uint32_t nibCode = brd_take(b, 2);
+                    if (nibCode == 3u) {                          // metadata: skipped
+                        if (brd_take(b, 1)) st = BRD_CORRUPT;
+                        const uint32_t sb = brd_take(b, 2);
+                        uint32_t skip = 0;
+                        if (sb && st == BRD_OK) { skip = brd_take(b, 8u * sb); if (sb > 1u && (skip >> (8u * (sb - 1u))) == 0u) st = BRD_CORRUPT; skip += 1u; }
+                        if (brd_take(b, b.n & 7u) != 0u) st = BRD_CORRUPT;
+                        const uint32_t at = brd_consumed(b);
+                        if (at + skip > b.end) st = BRD_CORRUPT;
+                        b.acc = 0; b.n = 0; b.pos = at + skip;
+                    } else {
+                        const uint32_t nib = 4u + nibCode;
+                        uint32_t mlen = 0;
+                        for (uint32_t i = 0; i < nib; i++) { const uint32_t v = brd_take(b, 4); if (i + 1u == nib && nib > 4u && v == 0u) st = BRD_CORRUPT; mlen |= v << (4u * i); }
+                        M.mlen = mlen + 1u;
+                        if (st == BRD_OK && (uint64_t)pos + M.mlen > cap) st = BRD_DST_SMALL;
+                        if (st == BRD_OK && !M.last && brd_take(b, 1)) {      // uncompressed: the bytes follow at the next byte boundary
+                            if (brd_take(b, b.n & 7u) != 0u) st = BRD_CORRUPT;
+                            M.srcAt = brd_consumed(b); M.kind = 1;
+                            if (M.srcAt + M.mlen > b.end) st = BRD_CORRUPT;
+                            b.acc = 0; b.n = 0; b.pos = M.srcAt + M.mlen;
+                        } else if (st == BRD_OK) {
+                            M.kind = 0;
+                            // two passes at most: the second with a page in HBM behind the LDS arena
+                            const BrdBits b0 = b;
+                            for (uint32_t attempt = 0; attempt < 2u; attempt++) {
+                                b = b0; st = BRD_OK;
+                                BrdArena A; A.lds = sArena; A.ldsCap = ldsCap; A.ldsUsed = 0; A.hbm = myPage; A.hbmCap = BRD_PAGE; A.hbmUsed = 0;
+                                BrdBlocks BL[3];
+                                for (uint32_t k = 0; k < 3u && st == BRD_OK; k++) {
+                                    BL[k].n = brd_varlen8(b) + 1u; BL[k].left = 1u << 24;
+                                    BL[k].typeCode.t = nullptr; BL[k].typeCode.sym8 = nullptr; BL[k].typeCode.sym16 = nullptr; BL[k].countCode = BL[k].typeCode;
+                                    if (BL[k].n >= 2u) {
+                                        if (!brd_read_code(b, BL[k].n + 2u, A, sLen, BL[k].typeCode, st)) break;
+                                        if (!brd_read_code(b, 26u, A, sLen, BL[k].countCode, st)) break;
+                                        BL[k].left = brd_block_count(b, BL[k].countCode);
+                                    }
+                                    M.nTypes[k] = BL[k].n; M.left[k] = BL[k].left; M.typeCode[k] = BL[k].typeCode; M.countCode[k] = BL[k].countCode;
+                                }
+                                if (st == BRD_OK) {
+                                    M.npostfix = brd_take(b, 2); M.ndirect = brd_take(b, 4) << M.npostfix;
+                                    M.modes = brd_alloc(A, BL[0].n);
+                                    if (!M.modes) st = BRD_LIMIT;
+                                    else for (uint32_t i = 0; i < BL[0].n; i++) M.modes[i] = (uint8_t)brd_take(b, 2);
+                                }
+                                uint32_t nTreesL = 1, nTreesD = 1;
+                                if (st == BRD_OK) {
+                                    const uint32_t sl = 64u * BL[0].n, sd = 4u * BL[2].n;
+                                    if (sl + sd <= BRD_CMAP_LDS && ldsCap == BRD_LDS_ARENA) { M.cmapL = sCmap; M.cmapD = sCmap + sl; }
+                                    else if (A.hbm && A.hbmUsed + sl + sd <= A.hbmCap) { M.cmapL = A.hbm + A.hbmUsed; M.cmapD = M.cmapL + sl; A.hbmUsed += (sl + sd + 7u) & ~7u; }
+                                    else st = BRD_LIMIT;
+                                    if (st == BRD_OK) brd_context_map(b, sl, nTreesL, M.cmapL, A, sLen, st);
+                                    if (st == BRD_OK) brd_context_map(b, sd, nTreesD, M.cmapD, A, sLen, st);
+                                }
+                                if (st == BRD_OK) {
+                                    const uint32_t nTreesI = BL[1].n;
+                                    M.TL = (BrdTree*)brd_alloc(A, (nTreesL + nTreesI + nTreesD) * (uint32_t)sizeof(BrdTree));
+                                    if (!M.TL) st = BRD_LIMIT;
+                                    else {
+                                        M.TI = M.TL + nTreesL; M.TD = M.TI + nTreesI;
+                                        // the command trees first: every command reads one, and what is allocated first stays in LDS
+                                        // (the stream's order is literals, commands, distances: the codes are READ in that order, so the arena is filled in it as well --
+                                        //  a meta-block whose literal trees alone overflow LDS keeps its first trees there)
+                                        for (uint32_t i = 0; i < nTreesL && st == BRD_OK; i++) brd_read_code(b, 256u, A, sLen, M.TL[i], st);
+                                        for (uint32_t i = 0; i < nTreesI && st == BRD_OK; i++) brd_read_code(b, 704u, A, sLen, M.TI[i], st);
+                                        const uint32_t alphaD = 16u + M.ndirect + (48u << M.npostfix);
+                                        for (uint32_t i = 0; i < nTreesD && st == BRD_OK; i++) brd_read_code(b, alphaD, A, sLen, M.TD[i], st);
+                                    }
+                                }
+                                if (st != BRD_LIMIT || myPage) break;
+                                // LDS does not hold this meta-block: take a page of the pool and read the header again
+                                const uint32_t pg = atomicAdd(pageCursor, 1u);
+                                if (pg >= nPages) break;
+                                myPage = pages + (uint64_t)pg * BRD_PAGE;
+                            }
+                        }
+                    }
+                }
+                if (b.over && st == BRD_OK) st = BRD_CORRUPT;
+                M.acc = b.acc; M.n = b.n; M.pos = b.pos; M.over = b.over; M.status = st;
+                sMeta = M;
+            }
+            gc_wave_sync_global();
+            const uint32_t kind = sMeta.kind, mlen = sMeta.mlen;
+            status = sMeta.status; last = sMeta.last != 0u;
+            b.acc = sMeta.acc; b.n = sMeta.n; b.pos = sMeta.pos; b.over = sMeta.over;
+            if (status != BRD_OK || kind == 3u) { gc_wave_sync(); break; }
+            if (kind == 2u) { gc_wave_sync(); continue; }
+            if (kind == 1u) {
+                const uint8_t* s = b.p + sMeta.srcAt;
+                for (uint32_t i = lane; i < mlen; i += 64u) out[pos + i] = s[i];
+                pos += mlen;
+                gc_wave_sync_global();
+                continue;
+            }
+            // ---- commands: every lane runs the same state machine
+            BrdBlocks BL[3];
+            for (uint32_t k = 0; k < 3u; k++) { BL[k].n = sMeta.nTypes[k]; BL[k].type = 0; BL[k].prev = 1; BL[k].left = sMeta.left[k]; BL[k].typeCode = sMeta.typeCode[k]; BL[k].countCode = sMeta.countCode[k]; }
+            const uint32_t npostfix = sMeta.npostfix, ndirect = sMeta.ndirect;
+            const BrdTree* const TL = sMeta.TL; const BrdTree* const TI = sMeta.TI; const BrdTree* const TD = sMeta.TD;
+            const uint8_t* const cmapL = sMeta.cmapL; const uint8_t* const cmapD = sMeta.cmapD; const uint8_t* const modes = sMeta.modes;
+            gc_wave_sync();                                       // (sMeta is lane 0's to write again from here)
+            const uint32_t mEnd = pos + mlen;
+            uint32_t p1 = pos ? out[pos - 1u] : 0u, p2 = pos > 1u ? out[pos - 2u] : 0u;
+            uint32_t mode = modes[0];
+            const uint8_t* cmRow = cmapL;
+            BrdTree tCmd = TI[0];
+            while (pos < mEnd && status == BRD_OK) {
+                if (BL[1].left == 0u) { brd_switch_w(b, BL[1], lane); tCmd = TI[BL[1].type]; }
+                BL[1].left--;
+                const uint32_t cs = brd_sym_w(b, tCmd, lane);
+                const uint32_t cell = cs >> 6;
+                if (cell > 10u) { status = BRD_CORRUPT; break; }
+                const uint32_t ic = kdCellIns[cell] + ((cs >> 3) & 7u), cc = kdCellCopy[cell] + (cs & 7u);
+                uint32_t ins = kdInsBase[ic] + brd_take(b, kdInsExtra[ic]);
+                const uint32_t cplen = kdCopyBase[cc] + brd_take(b, kdCopyExtra[cc]);
+                if (pos + ins > mEnd) { status = BRD_CORRUPT; break; }
+                for (; ins != 0u; ins--) {
+                    if (BL[0].left == 0u) { brd_switch_w(b, BL[0], lane); mode = modes[BL[0].type]; cmRow = cmapL + 64u * BL[0].type; }
+                    BL[0].left--;
+                    uint32_t ctx;
+                    if (mode == 2u) ctx = sLut[p1] | sLut[256u + p2];
+                    else if (mode == 0u) ctx = p1 & 63u;
+                    else if (mode == 1u) ctx = p1 >> 2;
+                    else ctx = (brd_signed(p1) << 3) | brd_signed(p2);
+                    const uint32_t lit = brd_sym_w(b, TL[cmRow[ctx]], lane);
+                    if (lane == 0u) out[pos] = (uint8_t)lit;
+                    pos++; p2 = p1; p1 = lit;
+                }
+                if (b.over) { status = BRD_CORRUPT; break; }
+                if (pos == mEnd) break;                           // the meta-block ends behind the literals: no copy
+                int dist;
+                uint32_t dcode = 0;
+                if (cs >= 128u) {
+                    if (BL[2].left == 0u) brd_switch_w(b, BL[2], lane);
+                    BL[2].left--;
+                    const uint32_t dctx = cplen > 4u ? 3u : cplen - 2u;
+                    dcode = brd_sym_w(b, TD[cmapD[4u * BL[2].type + dctx]], lane);
+                }
+                const uint32_t maxDist = pos < maxBack ? pos : maxBack;
+                bool push = true;
+                if (dcode < 16u) {
+                    const int l1 = ring[(ringIdx + 3u) & 3u], l2 = ring[(ringIdx + 2u) & 3u], l3 = ring[(ringIdx + 1u) & 3u], l4 = ring[ringIdx & 3u];
+                    if (dcode == 0u) { dist = l1; push = false; }
+                    else if (dcode == 1u) dist = l2; else if (dcode == 2u) dist = l3; else if (dcode == 3u) dist = l4;
+                    else if (dcode < 10u) { const int d = (int)((dcode - 4u) >> 1) + 1; dist = l1 + (((dcode - 4u) & 1u) ? d : -d); }
+                    else { const int d = (int)((dcode - 10u) >> 1) + 1; dist = l2 + (((dcode - 10u) & 1u) ? d : -d); }
+                    if (dist <= 0) { status = BRD_CORRUPT; break; }
+                } else if (dcode < 16u + ndirect) dist = (int)(dcode - 15u);
+                else {
+                    const uint32_t v = dcode - ndirect - 16u, hcode = v >> npostfix, lcode = v & ((1u << npostfix) - 1u), nb = 1u + (hcode >> 1);
+                    const uint32_t off = ((2u + (hcode & 1u)) << nb) - 4u;
+                    dist = (int)(((off + brd_take(b, nb)) << npostfix) + lcode + ndirect + 1u);
+                    if (dist <= 0) { status = BRD_CORRUPT; break; }
+                }
+                if (b.over) { status = BRD_CORRUPT; break; }
+                gc_wave_sync_global();                            // lane 0's literals, for the lanes that copy
+                if ((uint32_t)dist > maxDist) {
+                    // ---- static dictionary reference (RFC 7932 section 8): the word of `cplen` bytes with one of the 121 transforms; it does not enter the ring
+                    if (cplen < 4u || cplen > 24u) { status = BRD_CORRUPT; break; }
+                    if (dict.words == nullptr) { status = BRD_DICTIONARY; break; }
+                    const uint32_t id = (uint32_t)dist - maxDist - 1u, nbits = kdDictBits[cplen];
+                    const uint32_t widx = id & ((1u << nbits) - 1u), tidx = id >> nbits;
+                    if (tidx >= GC_BR_NUM_TRANSFORMS) { status = BRD_CORRUPT; break; }
+                    const uint8_t* w = dict.words + kdDictOff[cplen] + widx * cplen;
+                    const uint32_t type = kdTransforms[tidx][1];
+                    const uint8_t* pre = kdAffixPool + kdTransforms[tidx][0]; const uint8_t* suf = kdAffixPool + kdTransforms[tidx][2];
+                    uint32_t wl = cplen, skip = 0;
+                    if (type >= 12u && type <= 20u) { skip = type - 11u; if (skip > wl) skip = wl; }            // omit the first n
+                    else if (type >= 1u && type <= 9u) wl = wl > type ? wl - type : 0u;                        // omit the last n
+                    const uint32_t body = wl - skip, total = pre[0] + body + suf[0];
+                    if (pos + total > mEnd) { status = BRD_CORRUPT; break; }
+                    if (lane == 0u) {
+                        uint8_t* o = out + pos;
+                        for (uint32_t i = 0; i < pre[0]; i++) *o++ = pre[1u + i];
+                        uint8_t* const w0 = o;
+                        for (uint32_t i = skip; i < wl; i++) *o++ = w[i];
+                        if (type == 10u || type == 11u) {         // uppercase the first / every character (UTF-8 aware as the RFC defines it)
+                            uint8_t* q = w0;
+                            while (q < o) {
+                                uint32_t step;
+                                if (q[0] < 192u) { if (q[0] >= 'a' && q[0] <= 'z') q[0] ^= 32u; step = 1; }
+                                else if (q[0] < 224u) { if (q + 1 < o) q[1] ^= 32u; step = 2; }
+                                else { if (q + 2 < o) q[2] ^= 5u; step = 3; }
+                                if (type == 10u) break;
+                                q += step;
+                            }
+                        }
+                        for (uint32_t i = 0; i < suf[0]; i++) *o++ = suf[1u + i];
+                    }
+                    pos += total;
+                    gc_wave_sync_global();
+                    p1 = out[pos - 1u]; p2 = pos > 1u ? out[pos - 2u] : 0u;
+                    continue;
+                }
+                if (push) { ring[ringIdx & 3u] = dist; ringIdx++; }
+                if (pos + cplen > mEnd) { status = BRD_CORRUPT; break; }
+                {
+                    const uint32_t d = (uint32_t)dist;
+                    uint8_t* const o = out + pos; const uint8_t* const s = o - d;
+                    if (d >= cplen) { for (uint32_t i = lane; i < cplen; i += 64u) o[i] = s[i]; }
+                    else if (d == 1u) { const uint8_t v = s[0]; for (uint32_t i = lane; i < cplen; i += 64u) o[i] = v; }
+                    else { for (uint32_t i = lane; i < cplen; i += 64u) o[i] = s[i % d]; }
+                }
+                pos += cplen;
+                gc_wave_sync_global();
+                p1 = out[pos - 1u]; p2 = out[pos - 2u];
+            }
+            if (b.over && status == BRD_OK) status = BRD_CORRUPT;
+            gc_wave_sync_global();
+        }
+        if (status == BRD_OK && brd_consumed(b) > ck.srcSize) status = BRD_CORRUPT;
+        if (lane == 0u) { GcBrDecResult r; r.size = pos; r.status = status; result[c] = r; }
+        gc_wave_sync();
+    }
+}
+
+// sizes -> offsets (one workgroup), then the packed copy (a workgroup per 64 KiB of a chunk)
+extern "C" __global__ void __launch_bounds__(1024)
+gc_brotli_dec_plan_kernel(const GcBrDecResult* __restrict__ result, uint32_t nChunks, uint64_t dstCap, uint64_t* __restrict__ offs, uint64_t* __restrict__ total /* [0] bytes, [1] status */)
+{
+    __shared__ uint64_t sWave[16];
+    __shared__ uint32_t sBad;
+    const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+    if (t == 0) sBad = 0;
+    __syncthreads();
+    uint64_t carry = 0; uint32_t bad = 0;
+    for (uint32_t tb = 0; tb < nChunks; tb += 1024u) {
+        const uint32_t i = tb + t;
+        uint64_t v = 0;
+        if (i < nChunks) { v = result[i].size; if (result[i].status > bad) bad = result[i].status; }
+        uint64_t incl = v;
+        for (uint32_t d = 1; d < 64u; d <<= 1) { const uint64_t o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+        if (lane == 63u) sWave[wave] = incl;
+        __syncthreads();
+        uint64_t before = 0, all = 0;
+        for (uint32_t w = 0; w < 16u; w++) { if (w < wave) before += sWave[w]; all += sWave[w]; }
+        __syncthreads();
+        if (i < nChunks) offs[i] = carry + before + incl - v;
+        carry += all;
+    }
+    if (bad) atomicMax(&sBad, bad);                               // any chunk's failure is the call's
+    __syncthreads();
+    if (t == 0) { total[0] = carry; total[1] = sBad ? sBad : (carry > dstCap ? BRD_DST_SMALL + 16u : 0u); }
+}
+extern "C" __global__ void __launch_bounds__(256)
+gc_brotli_dec_pack_kernel(const uint8_t* __restrict__ stage, const GcBrDecChunk* __restrict__ chunks, const GcBrDecResult* __restrict__ result, const uint64_t* __restrict__ offs,
+                          const uint64_t* __restrict__ total, uint32_t piecesPerChunk, uint8_t* __restrict__ dst)
+{
+    if (total[1]) return;
+    const uint32_t c = blockIdx.x / piecesPerChunk, piece = blockIdx.x % piecesPerChunk;
+    const uint64_t n = result[c].size, p0 = (uint64_t)piece << 16;
+    if (p0 >= n) return;
+    const uint32_t len = (uint32_t)(n - p0 < 65536u ? n - p0 : 65536u);
+    const uint8_t* s = stage + chunks[c].stageOff + p0;
+    uint8_t* d = dst + offs[c] + p0;
+    if ((((uintptr_t)s | (uintptr_t)d) & 15u) == 0u) {
+        struct alignas(16) V16 { uint64_t a, b; };
+        const uint32_t n16 = len >> 4;
+        for (uint32_t i = threadIdx.x; i < n16; i += 256u) ((V16*)d)[i] = ((const V16*)s)[i];
+        for (uint32_t i = (n16 << 4) + threadIdx.x; i < len; i += 256u) d[i] = s[i];
+    } else for (uint32_t i = threadIdx.x; i < len; i += 256u) d[i] = s[i];
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+// Walks the brotli-mt frames of a buffer (brotli-mt_decompress.c:191-288).  chunks may be null (count only).  *consumed = bytes of the whole frames.
+extern "C" int gc_brotli_scan_prefix(const void* src, size_t n, gc_brotli_chunk* chunks, size_t maxChunks, size_t* nChunks, uint64_t* capacityTotal, size_t* consumed)
+{
+    if ((!src && n) || !nChunks) return GC_ERR_PARAM;
+    const uint8_t* p = (const uint8_t*)src;
+    size_t off = 0, k = 0; uint64_t cap = 0;
+    while (off + 16u <= n) {
+        uint32_t magic, eight, csize; uint16_t br, hint;
+        memcpy(&magic, p + off, 4); memcpy(&eight, p + off + 4, 4); memcpy(&csize, p + off + 8, 4); memcpy(&br, p + off + 12, 2); memcpy(&hint, p + off + 14, 2);
+        if (magic != 0x184D2A50u || eight != 8u || br != 0x5242u) return GC_ERR_CORRUPT;
+        if (off + 16u + (size_t)csize > n) break;                 // the frame is not whole yet
+        if (chunks) { if (k >= maxChunks) return GC_ERR_PARAM; chunks[k].src_off = off + 16u; chunks[k].src_size = csize; chunks[k].capacity = (uint32_t)hint << 16; }
+        cap += (uint64_t)hint << 16; k++;
+        off += 16u + (size_t)csize;
+    }
+    *nChunks = k;
+    if (capacityTotal) *capacityTotal = cap;
+    if (consumed) *consumed = off;
+    return GC_OK;
+}
+
+// the process's copy of the static dictionary (RFC 7932 Appendix A); every device uploads it on its first use
+static uint8_t* gBrDict = nullptr;
+static uint64_t gBrDictStamp = 0;
+static uint32_t brd_crc32(const uint8_t* p, size_t n)
+{
+    uint32_t c = 0xFFFFFFFFu;
+    for (size_t i = 0; i < n; i++) { c ^= p[i]; for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1u))); }
+    return ~c;
+}
+extern "C" int gc_brotli_dec_set_dictionary(const void* data, size_t n)
+{
+    if (!data && n == 0) { free(gBrDict); gBrDict = nullptr; gBrDictStamp++; return GC_OK; }       // (forget it: tests)
+    if (!data || n != 122784u || brd_crc32((const uint8_t*)data, n) != 0x5136CB04u) return GC_ERR_PARAM;   // the CRC-32 RFC 7932 Appendix A states
+    uint8_t* copy = (uint8_t*)malloc(n);
+    if (!copy) return GC_ERR_NOMEM;
+    memcpy(copy, data, n);
+    free(gBrDict); gBrDict = copy; gBrDictStamp++;
+    return GC_OK;
+}
+extern "C" int gc_brotli_dec_has_dictionary(void) { return gBrDict != nullptr; }
+
+static bool brd_grow(uint8_t** p, size_t* cap, size_t need)
+{
+    if (need <= *cap) return true;
+    if (*p) hipFree(*p);
+    *p = nullptr; *cap = 0;
+    if (hipMalloc((void**)p, need + 64) != hipSuccess) return false;
+    *cap = need;
+    return true;
+}
+void gc_brd_release(GcBrDecWork* w)
+{
+    if (w->stage) hipFree(w->stage);
+    if (w->pages) hipFree(w->pages);
+    if (w->meta) hipFree(w->meta);
+    if (w->dict) hipFree(w->dict);
+    if (w->ev0) hipEventDestroy((hipEvent_t)w->ev0);
+    if (w->ev1) hipEventDestroy((hipEvent_t)w->ev1);
+    memset(w, 0, sizeof(*w));
+}
+// d_src / d_dst: device memory; chunks: host memory (as the scan returned them).  Synchronous (the sizes are read back).
+int gc_brd_decode(hipStream_t st, GcBrDecWork* w, const uint8_t* d_src, const gc_brotli_chunk* chunks, size_t nChunks, uint8_t* d_dst, size_t dstCap, size_t* produced, char* err, size_t errCap)
+{
+    *produced = 0;
+    if (nChunks == 0) return GC_OK;
+    if (nChunks > 0x7FFFFFFFu / 16u) return GC_ERR_PARAM;
+    GcBrDecChunk* hc = (GcBrDecChunk*)malloc(nChunks * sizeof(GcBrDecChunk));
+    if (!hc) return GC_ERR_NOMEM;
+    uint64_t stageBytes = 0; uint32_t maxHint = 0;
+    for (size_t i = 0; i < nChunks; i++) {
+        hc[i].srcOff = chunks[i].src_off; hc[i].srcSize = chunks[i].src_size; hc[i].hintBytes = chunks[i].capacity; hc[i].stageOff = stageBytes;
+        stageBytes += ((uint64_t)chunks[i].capacity + 63u) & ~63ull;
+        if (chunks[i].capacity > maxHint) maxHint = chunks[i].capacity;
+    }
+    const size_t oChunks = 0, oRes = (nChunks * sizeof(GcBrDecChunk) + 63u) & ~(size_t)63u, oOffs = oRes + ((nChunks * sizeof(GcBrDecResult) + 63u) & ~(size_t)63u),
+                 oTot = oOffs + ((nChunks * 8u + 63u) & ~(size_t)63u), oCur = oTot + 64u, metaBytes = oCur + 64u;
+    int rc = GC_OK;
+    if (!brd_grow(&w->stage, &w->stageCap, (size_t)stageBytes + 64u) || !brd_grow(&w->meta, &w->metaCap, metaBytes)) rc = GC_ERR_NOMEM;
+    if (rc == GC_OK && gBrDict && (!w->dict || w->dictStamp != gBrDictStamp)) {
+        if (!w->dict && hipMalloc((void**)&w->dict, 122784u + 64u) != hipSuccess) rc = GC_ERR_NOMEM;
+        else if (hipMemcpyAsync(w->dict, gBrDict, 122784u, hipMemcpyHostToDevice, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = GC_ERR_HIP;
+        w->dictStamp = gBrDictStamp;
+    }
+    if (rc == GC_OK && !w->ev0 && (hipEventCreate((hipEvent_t*)&w->ev0) != hipSuccess || hipEventCreate((hipEvent_t*)&w->ev1) != hipSuccess)) rc = GC_ERR_HIP;
+    uint64_t tot[2] = { 0, 0 };
+    for (int attempt = 0; attempt < 2 && rc == GC_OK; attempt++) {
+        // pages: a chunk whose meta-block does not fit LDS takes one; few streams need any (the reference's qualities 10-11), so the pool starts small
+        const uint32_t wantPages = attempt == 0 ? (uint32_t)(nChunks < 64u ? nChunks : 64u) : (uint32_t)nChunks;
+        if (w->nPages < wantPages) {
+            if (w->pages) hipFree(w->pages);
+            w->pages = nullptr; w->nPages = 0;
+            if (hipMalloc((void**)&w->pages, (size_t)wantPages * BRD_PAGE) != hipSuccess) { rc = GC_ERR_NOMEM; break; }
+            w->nPages = wantPages;
+        }
+        if (hipMemcpyAsync(w->meta + oChunks, hc, nChunks * sizeof(GcBrDecChunk), hipMemcpyHostToDevice, st) != hipSuccess || hipMemsetAsync(w->meta + oCur, 0, 64, st) != hipSuccess) { rc = GC_ERR_HIP; break; }
+        GcBrDict dict; dict.words = gBrDict ? w->dict : nullptr;
+        const uint32_t grid = (uint32_t)(nChunks < BRD_MAX_WAVES ? nChunks : BRD_MAX_WAVES);
+        hipEventRecord((hipEvent_t)w->ev0, st);
+        GC_LAUNCH(gc_brotli_dec_kernel, grid, 64, st, d_src, (const GcBrDecChunk*)(w->meta + oChunks), (uint32_t)nChunks, w->stage, w->pages, w->nPages, (uint32_t*)(w->meta + oCur),
+                  (GcBrDecResult*)(w->meta + oRes), dict, w->ldsCap && w->ldsCap < BRD_LDS_ARENA ? w->ldsCap : BRD_LDS_ARENA);
+        GC_LAUNCH(gc_brotli_dec_plan_kernel, 1, 1024, st, (const GcBrDecResult*)(w->meta + oRes), (uint32_t)nChunks, (uint64_t)dstCap, (uint64_t*)(w->meta + oOffs), (uint64_t*)(w->meta + oTot));
+        const uint32_t pieces = (maxHint + 65535u) >> 16;
+        if (pieces) GC_LAUNCH(gc_brotli_dec_pack_kernel, (uint32_t)nChunks * pieces, 256, st, w->stage, (const GcBrDecChunk*)(w->meta + oChunks), (const GcBrDecResult*)(w->meta + oRes),
+                              (const uint64_t*)(w->meta + oOffs), (const uint64_t*)(w->meta + oTot), pieces, d_dst);
+        hipEventRecord((hipEvent_t)w->ev1, st);
+        if (hipMemcpyAsync(tot, w->meta + oTot, 16, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = GC_ERR_HIP; break; }
+        hipEventElapsedTime(&w->ms, (hipEvent_t)w->ev0, (hipEvent_t)w->ev1);
+        if (tot[1] != BRD_LIMIT || w->nPages >= nChunks) break;   // (a second round with a page for every chunk)
+    }
+    free(hc);
+    if (rc != GC_OK) return rc;
+    switch (tot[1]) {
+        case 0: *produced = (size_t)tot[0]; return GC_OK;
+        case BRD_DST_SMALL + 16u: if (err) snprintf(err, errCap, "destination too small: need %llu bytes", (unsigned long long)tot[0]); return GC_ERR_DST_SMALL;
+        case BRD_DICTIONARY: if (err) snprintf(err, errCap, "the brotli stream refers to the static dictionary of RFC 7932 and the host has not handed it over (gc_brotli_dec_set_dictionary)"); return GC_ERR_UNSUPPORTED;
+        case BRD_LIMIT: if (err) snprintf(err, errCap, "a meta-block of the brotli stream holds more prefix codes than this decoder's arenas take"); return GC_ERR_UNSUPPORTED;
+        default: if (err) snprintf(err, errCap, "damaged brotli stream (chunk status %u)", (unsigned)tot[1]); return GC_ERR_CORRUPT;   // (a chunk that outgrows its brotli-mt hint is one, brotli-mt_decompress.c:243)
+    }
+}

@@ -35,6 +35,7 @@ extern "C" {
 #define GC_ERR_DST_SMALL   -4   /* dstCapacity < compressed size (cf. ZSTD_error_dstSize_tooSmall) */
 #define GC_ERR_PARAM       -5
 #define GC_ERR_CORRUPT     -6   /* decoder: the compressed data is damaged (cf. ZSTD_error_corruption_detected, checksum_wrong) */
+#define GC_ERR_UNSUPPORTED -7   /* decoder: a valid stream that needs what this decoder does not hold (brotli: the static dictionary has not been handed over) */
 
 typedef struct gc_ctx gc_ctx;
 
@@ -279,6 +280,33 @@ int         gc_zstd_decompress_kernel_timing(gc_ctx* ctx, float ms[4]);
 /* pointer-jumping rounds of the last call when it took the wide execution path (all blocks of all frames at once: batches of few frames),
  * 0 when every batch went through the frame-per-workgroup execution kernel */
 int         gc_zstd_decompress_wide_rounds(gc_ctx* ctx, unsigned* rounds);
+
+/* ---- BROTLI decoding on the device.  Replaces BROTLIMT_decompressDCtx (C/zstdmt/brotli-mt_decompress.c:191-288, pt_read / pt_decompress) and the
+ * BrotliDecoderDecompressStream loop under it (C/brotli/br_decode.c) as NCompress::NBROTLI::CDecoder::CodeSpec drives them (CPP/7zip/Compress/BrotliDecoder.cpp:124)
+ * for callers that hold whole brotli-mt frames.  One wave per brotli-mt chunk (the format's unit of independence: inside a stream every literal's prefix code
+ * depends on the two bytes in front of it); a bare RFC 7932 stream is ONE chunk and runs on one wave.
+ *   gc_brotli_scan_prefix         host: walks the 16-byte frame headers {0x184D2A50, 8, compressed size, 0x5242, hint}; an input that ends inside a frame is not an
+ *                                 error, *consumed = the bytes of the whole frames.  chunks may be NULL to count.  capacity = hint << 16 (the reference's output buffer).
+ *   gc_brotli_decompress_device   chunks as the scan returned them (host memory), d_src / d_dst device memory; the content of the chunks in order, packed.
+ *   gc_brotli_decompress_host     scan + H2D + decode + D2H; an input that does not start with a brotli-mt header is taken as one bare stream of at most dstCapacity bytes
+ *                                 (brotli-mt_decompress.c:573, st_decompress).
+ *   gc_brotli_dec_set_dictionary  the static dictionary of RFC 7932 Appendix A (122 784 bytes; checked against the CRC-32 the RFC states, 0x5136cb04), process-wide, copied.
+ *                                 This library does not carry it: a host that has a brotli of its own passes BrotliGetDictionary()->data (C/brotli/common/dictionary.h).
+ *                                 Without it a stream that refers to the dictionary gives GC_ERR_UNSUPPORTED; streams of this engine's encoder never refer to it.
+ * GC_ERR_CORRUPT: damaged stream, or a chunk longer than its hint (brotli-mt_decompress.c:243 sizes the output buffer by it). */
+typedef struct gc_brotli_chunk {
+    uint64_t src_off;                /* the RFC 7932 stream of the chunk inside the compressed buffer (behind its 16-byte header) */
+    uint32_t src_size;
+    uint32_t capacity;               /* upper bound of its content in bytes */
+} gc_brotli_chunk;
+int         gc_brotli_scan_prefix(const void* src, size_t n, gc_brotli_chunk* chunks, size_t maxChunks, size_t* nChunks, uint64_t* capacityTotal, size_t* consumed);
+int         gc_brotli_dec_set_dictionary(const void* data, size_t n);
+int         gc_brotli_dec_has_dictionary(void);
+int         gc_brotli_decompress_device(gc_ctx* ctx, const void* d_src, size_t n, void* d_dst, size_t dstCapacity,
+                                        const gc_brotli_chunk* chunks, size_t nChunks, size_t* decompressedSize);
+int         gc_brotli_decompress_host(gc_ctx* ctx, const void* src, size_t n, void* dst, size_t dstCapacity, size_t* decompressedSize);
+/* HIP-event duration of the decode kernels of the last gc_brotli_decompress_* call */
+int         gc_brotli_decompress_timing(gc_ctx* ctx, float* ms);
 
 /* raw stream handle (hipStream_t) so callers can order their own work against the context */
 void*       gc_ctx_stream(gc_ctx* ctx);

@@ -279,6 +279,27 @@ def ref_brotli_decompress(comp, cap):
     return out[:r]
 
 
+def ref_brotli_compress(data, level=6, lgwin=22):
+    """one bare RFC 7932 stream of the reference encoder (BrotliEncoderCompress)"""
+    a, ap = _buf(data)
+    cap = a.size + a.size // 4 + 4096
+    out = np.empty(cap, dtype=np.uint8)
+    r = ref("brotli").ref_brotli_compress(out.ctypes.data, cap, ap, a.size, level, lgwin)
+    if r == _BAD:
+        raise RuntimeError("reference brotli compress failed")
+    return out[:r].copy()
+
+
+def ref_brotli_dictionary():
+    """the static dictionary of RFC 7932 Appendix A as the reference holds it (C/brotli/common/dictionary.h: BrotliGetDictionary()->data, 122 784 bytes)"""
+    class _D(C.Structure):
+        _fields_ = [("size_bits_by_length", C.c_uint8 * 32), ("offsets_by_length", C.c_uint32 * 32), ("data_size", C.c_size_t), ("data", C.POINTER(C.c_uint8))]
+    lib = ref("brotli")
+    lib.BrotliGetDictionary.restype = C.POINTER(_D)
+    d = lib.BrotliGetDictionary().contents
+    return np.frombuffer(C.string_at(d.data, d.data_size), dtype=np.uint8).copy()
+
+
 def _match_lists(fn, data, history, cut, nice, extra):
     a = np.ascontiguousarray(np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data, dtype=np.uint8)
     counts = np.zeros(max(a.size, 1), dtype=np.uint32)
