@@ -21,8 +21,12 @@
 #include <mutex>
 #include <new>
 #include <thread>
+#include <vector>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <dlfcn.h>
+#include <link.h>
 
 #define GC_EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -489,6 +493,151 @@ public:
     }
 };
 
+// BROTLI decoder (NCompress::NBROTLI::CDecoder, BrotliDecoder.cpp:124; brotli-mt_decompress.c:191-288): the input is read in large pieces, every piece is cut at the end of its
+// last whole brotli-mt frame (gc_brotli_scan_prefix), the chunks are decoded on the GPU (one wave per chunk), the content is written out, the tail moves to the front.
+// An input that does not start with a brotli-mt header is a bare RFC 7932 stream (what the reference writes with "0 threads", brotli-mt_decompress.c:573): one chunk, read whole;
+// the host must have told its size (SetOutStreamSize / Code's outSize), else E_NOTIMPL.
+// The static dictionary of RFC 7932 is not in this module: the first decoder takes it from the host process -- a host built from the reference tree carries the brotli library,
+// whose BrotliGetDictionary (C/brotli/common/dictionary.h) is looked up among the loaded objects -- or from the file named by GPUCODEC_BROTLI_DICTIONARY (the 122 784 bytes).
+// Without it a stream that refers to the dictionary ends with E_NOTIMPL ("unsupported"), as the ZSTD decoder does with dictionary frames.
+void brotli_dictionary_once()
+{
+    static std::once_flag once;
+    std::call_once(once, [] {
+        if (gc_brotli_dec_has_dictionary()) return;
+        struct Found { const void* fn; } found = { nullptr };
+        dl_iterate_phdr([](struct dl_phdr_info* info, size_t, void* arg) -> int {
+            void* h = dlopen(info->dlpi_name && info->dlpi_name[0] ? info->dlpi_name : nullptr, RTLD_NOLOAD | RTLD_LAZY);
+            if (!h) return 0;
+            void* f = dlsym(h, "BrotliGetDictionary");
+            dlclose(h);
+            if (f) { ((Found*)arg)->fn = f; return 1; }
+            return 0;
+        }, &found);
+        if (found.fn) {
+            // struct BrotliDictionary { uint8_t size_bits_by_length[32]; uint32_t offsets_by_length[32]; size_t data_size; const uint8_t* data; ... } (common/dictionary.h:18-62);
+            // gc_brotli_dec_set_dictionary checks size and the CRC-32 the RFC states, so another layout cannot get wrong bytes in
+            struct Head { uint8_t bits[32]; uint32_t offs[32]; size_t dataSize; const uint8_t* data; };
+            const Head* d = ((const Head* (*)(void))found.fn)();
+            if (d && d->data && d->dataSize == 122784u && gc_brotli_dec_set_dictionary(d->data, d->dataSize) == GC_OK) return;
+        }
+        if (const char* path = getenv("GPUCODEC_BROTLI_DICTIONARY")) {
+            if (FILE* f = fopen(path, "rb")) {
+                std::vector<uint8_t> b(122784u + 1u);
+                const size_t n = fread(b.data(), 1, b.size(), f);
+                fclose(f);
+                gc_brotli_dec_set_dictionary(b.data(), n);
+            }
+        }
+    });
+}
+
+class CGpuBrotliDecoder final : public ICompressCoder, public ICompressSetDecoderProperties2, public ICompressSetCoderMt {
+    ULONG refs_ = 1;
+    gc_brotli_chunk* chunks_ = nullptr; size_t chunksCap_ = 0;
+
+public:
+    ~CGpuBrotliDecoder() { free(chunks_); }
+
+    HRESULT QueryInterface(const GUID& iid, void** out) override
+    {
+        if (!out) return E_INVALIDARG;
+        *out = nullptr;
+        if (iid == IID_IUnknown || iid == IID_ICompressCoder) *out = static_cast<ICompressCoder*>(this);
+        else if (iid == IID_ICompressSetDecoderProperties2) *out = static_cast<ICompressSetDecoderProperties2*>(this);
+        else if (iid == IID_ICompressSetCoderMt) *out = static_cast<ICompressSetCoderMt*>(this);
+        else return E_NOINTERFACE;
+        ++refs_;
+        return S_OK;
+    }
+    ULONG AddRef() override { return ++refs_; }
+    ULONG Release() override { if (--refs_ != 0) return refs_; delete this; return 0; }
+
+    HRESULT SetNumberOfThreads(uint32_t) override { return S_OK; }
+    HRESULT SetDecoderProperties2(const uint8_t*, uint32_t size) override { return size == 3 ? S_OK : E_NOTIMPL; }     // {major, minor, level}: BrotliDecoder.cpp:86-96
+
+    HRESULT Code(ISequentialInStream* in, ISequentialOutStream* out, const uint64_t*, const uint64_t* outSize, ICompressProgressInfo* progress) override
+    {
+        if (!in || !out) return E_INVALIDARG;
+        gc_ctx* const ctx = shared_dec_ctx();
+        if (!ctx) return E_FAIL;                                                               // no gfx950 device: there is no CPU decoder behind this object
+        brotli_dictionary_once();
+        BufLease lease;
+        uint8_t*& inBuf_ = lease.b.in[0]; size_t& inCap_ = lease.b.inCap[0]; uint8_t*& outBuf_ = lease.b.out; size_t& outCap_ = lease.b.outCap;
+        const size_t kPiece = (size_t)64 << 20;
+        const size_t kMaxIn = (size_t)1 << 30;               // largest compressed frame (or bare stream) buffered whole
+        const size_t kMaxContent = (size_t)4 << 30;          // largest content of one piece
+        if (!buf_grow(&inBuf_, &inCap_, kPiece, 0)) return E_OUTOFMEMORY;
+        uint64_t totalIn = 0, totalOut = 0;
+        size_t have = 0;
+        bool eof = false, bare = false, first = true;
+        for (;;) {
+            while (!eof && have < inCap_) {
+                const size_t want = inCap_ - have;
+                size_t got = want;
+                HRESULT r = read_full(in, inBuf_ + have, &got);
+                if (r != S_OK) return r;
+                have += got; totalIn += got;
+                if (got < want) eof = true;
+            }
+            if (have == 0) break;
+            if (first && have >= 4) { uint32_t magic; memcpy(&magic, inBuf_, 4); bare = magic != 0x184D2A50u; }
+            first = false;
+            size_t consumed = 0, produced = 0;
+            int rc;
+            if (bare) {
+                // a bare stream is one chunk: all of it has to be here, and the host has to have said how much it holds
+                if (!eof) { if (inCap_ >= kMaxIn) return E_NOTIMPL; if (!buf_grow(&inBuf_, &inCap_, inCap_ * 2u, have)) return E_OUTOFMEMORY; continue; }
+                if (!outSize || *outSize > 0xFFFF0000ull) return E_NOTIMPL;
+                const size_t cap = (size_t)*outSize;
+                if (!buf_grow(&outBuf_, &outCap_, cap ? cap : 1u, 0)) return E_OUTOFMEMORY;
+                { std::lock_guard<std::mutex> g(shared()->gpu); rc = gc_brotli_decompress_host(ctx, inBuf_, have, outBuf_, cap, &produced); }
+                consumed = have;
+            } else {
+                size_t nChunks = 0;
+                rc = gc_brotli_scan_prefix(inBuf_, have, nullptr, 0, &nChunks, nullptr, &consumed);
+                if (rc != GC_OK) return E_FAIL;
+                if (consumed == 0) {                               // not even one whole frame in the buffer
+                    if (eof) return E_FAIL;                        // the stream ends inside a frame
+                    if (inCap_ >= kMaxIn) return E_NOTIMPL;
+                    if (!buf_grow(&inBuf_, &inCap_, inCap_ * 2u, have)) return E_OUTOFMEMORY;
+                    continue;
+                }
+                if (nChunks > chunksCap_) {
+                    free(chunks_); chunksCap_ = 0;
+                    chunks_ = (gc_brotli_chunk*)malloc((nChunks + 64u) * sizeof(gc_brotli_chunk));
+                    if (!chunks_) return E_OUTOFMEMORY;
+                    chunksCap_ = nChunks + 64u;
+                }
+                uint64_t capTotal = 0;
+                rc = gc_brotli_scan_prefix(inBuf_, have, chunks_, chunksCap_, &nChunks, &capTotal, &consumed);
+                if (rc != GC_OK) return E_FAIL;
+                // the hints bound the content (brotli-mt_decompress.c:243); a piece whose chunks may regenerate more than kMaxContent is decoded a run of chunks at a time
+                size_t cap = 0;
+                for (size_t i = 0; i < nChunks; i++) {
+                    if (cap + chunks_[i].capacity > kMaxContent) { if (i == 0) return E_NOTIMPL; consumed = (size_t)chunks_[i].src_off - 16u; break; }
+                    cap += chunks_[i].capacity;
+                }
+                if (!buf_grow(&outBuf_, &outCap_, cap ? cap : 1u, 0)) return E_OUTOFMEMORY;
+                { std::lock_guard<std::mutex> g(shared()->gpu); rc = gc_brotli_decompress_host(ctx, inBuf_, consumed, outBuf_, cap, &produced); }
+            }
+            if (rc != GC_OK) return rc == GC_ERR_UNSUPPORTED ? E_NOTIMPL : hresult_of(rc);
+            HRESULT r = write_all(out, outBuf_, produced);
+            if (r != S_OK) return r;
+            totalOut += produced;
+            have -= consumed;
+            if (have) memmove(inBuf_, inBuf_ + consumed, have);
+            if (progress) {
+                const uint64_t pin = totalIn - have;
+                r = progress->SetRatioInfo(&pin, &totalOut);
+                if (r != S_OK) return r;
+            }
+            if (eof && have == 0) break;
+        }
+        return S_OK;
+    }
+};
+
 // A pre-filter object: NCompress::NBranch::CCoder / CEncoder / CDecoder (BranchMisc.cpp:14-118), NCompress::NBcj::CCoder2 (BcjCoder.cpp:10-22) and
 // NCompress::NDelta::CEncoder / CDecoder (DeltaFilter.cpp:28-119) over gc_filter_host: every Filter() call takes the host's buffer to the device, converts it
 // there and brings it back; the program counter, the x86 converter's state word and the Delta filter's 256 bytes of history are carried from call to call.
@@ -590,10 +739,11 @@ HRESULT create_decoder(uint32_t index, const GUID* iid, void** out)
     if (!out) return E_INVALIDARG;
     *out = nullptr;
     if (index < kNumMethods && kMethods[index].kind == KIND_FILTER) return create_filter(index, false, iid, out);
-    if (index >= kNumMethods || kMethods[index].kind != KIND_ZSTD) return CLASS_E_CLASSNOTAVAILABLE;
+    if (index >= kNumMethods || (kMethods[index].kind != KIND_ZSTD && kMethods[index].kind != KIND_BROTLI)) return CLASS_E_CLASSNOTAVAILABLE;     // (FLZMA2: the host's LZMA2 decoder)
     if (!iid || !(*iid == IID_ICompressCoder)) return E_NOINTERFACE;
-    CGpuZstdDecoder* d = new (std::nothrow) CGpuZstdDecoder();
-    IUnknown* obj = d ? static_cast<ICompressCoder*>(d) : nullptr;
+    IUnknown* obj = nullptr;
+    if (kMethods[index].kind == KIND_BROTLI) { CGpuBrotliDecoder* d = new (std::nothrow) CGpuBrotliDecoder(); obj = d ? static_cast<ICompressCoder*>(d) : nullptr; }
+    else { CGpuZstdDecoder* d = new (std::nothrow) CGpuZstdDecoder(); obj = d ? static_cast<ICompressCoder*>(d) : nullptr; }
     if (!obj) return E_OUTOFMEMORY;
     *out = obj;
     return S_OK;
@@ -633,12 +783,12 @@ GC_EXPORT HRESULT GetMethodProperty(uint32_t index, PROPID propID, PROPVARIANT* 
         }
         case NMethodPropID::kEncoderIsAssigned: value->vt = VT_BOOL; value->boolVal = -1; break;   // VARIANT_TRUE
         case NMethodPropID::kDecoder:
-            if (m.kind == KIND_ZSTD || m.kind == KIND_FILTER) {
+            if (m.kind == KIND_ZSTD || m.kind == KIND_BROTLI || m.kind == KIND_FILTER) {
                 GUID g = gc_codec_clsid(m.id, false);
                 value->bstrVal = gc_bstr_bytes(&g, sizeof(g)); if (!value->bstrVal) return E_OUTOFMEMORY; value->vt = VT_BSTR;
             }
             break;
-        case NMethodPropID::kDecoderIsAssigned: value->vt = VT_BOOL; value->boolVal = (m.kind == KIND_ZSTD || m.kind == KIND_FILTER) ? -1 : 0; break;
+        case NMethodPropID::kDecoderIsAssigned: value->vt = VT_BOOL; value->boolVal = (m.kind == KIND_ZSTD || m.kind == KIND_BROTLI || m.kind == KIND_FILTER) ? -1 : 0; break;
         case NMethodPropID::kIsFilter: value->vt = VT_BOOL; value->boolVal = m.kind == KIND_FILTER ? -1 : 0; break;
         default: break;      // kPackStreams, ...: left VT_EMPTY
     }
@@ -657,7 +807,7 @@ GC_EXPORT HRESULT CreateObject(const GUID* clsid, const GUID* iid, void** out)
     for (uint32_t i = 0; i < kNumMethods; i++)
         if (*clsid == gc_codec_clsid(kMethods[i].id, true)) return create_encoder(i, iid, out);
     for (uint32_t i = 0; i < kNumMethods; i++)
-        if ((kMethods[i].kind == KIND_ZSTD || kMethods[i].kind == KIND_FILTER) && *clsid == gc_codec_clsid(kMethods[i].id, false)) return create_decoder(i, iid, out);
+        if ((kMethods[i].kind == KIND_ZSTD || kMethods[i].kind == KIND_BROTLI || kMethods[i].kind == KIND_FILTER) && *clsid == gc_codec_clsid(kMethods[i].id, false)) return create_decoder(i, iid, out);
     return CLASS_E_CLASSNOTAVAILABLE;
 }
 

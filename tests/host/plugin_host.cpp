@@ -156,7 +156,8 @@ int main(int argc, char** argv)
     }
     if (mode == "decode") {
         if (argc < 7 || found < 0) { fprintf(stderr, "method not found\n"); return 8; }
-        const bool byClsidD = argc > 7 && std::string(argv[7]) == "by-clsid";
+        bool byClsidD = false; unsigned long long statedSize = 0; bool haveSize = false;      // [by-clsid] [size=<bytes>]: the unpack size a 7z folder knows (7zDecode.cpp hands it to Code())
+        for (int i = 7; i < argc; i++) { const std::string a = argv[i]; if (a == "by-clsid") byClsidD = true; else if (a.rfind("size=", 0) == 0) { statedSize = strtoull(a.c_str() + 5, nullptr, 10); haveSize = true; } }
         void* rawD = nullptr; HRESULT rd;
         if (byClsidD) { GUID c = gc_codec_clsid(foundId, false); rd = createObj(&c, &IID_ICompressCoder, &rawD); }
         else rd = createDec((uint32_t)found, &IID_ICompressCoder, &rawD);
@@ -173,7 +174,8 @@ int main(int argc, char** argv)
         FileIn in; in.f = fopen(argv[5], "rb"); FileOut out; out.f = fopen(argv[6], "wb");
         if (!in.f || !out.f) { fprintf(stderr, "file open\n"); return 13; }
         Progress prog;
-        HRESULT r2 = dec->Code(&in, &out, nullptr, nullptr, &prog);
+        const uint64_t outSizeArg = statedSize;
+        HRESULT r2 = dec->Code(&in, &out, nullptr, haveSize ? &outSizeArg : nullptr, &prog);
         fclose(in.f); fclose(out.f);
         if (r2 != S_OK) { fprintf(stderr, "Code failed: %08X\n", (unsigned)r2); return 15; }
         if (prog.out != out.total) { fprintf(stderr, "progress accounting\n"); return 16; }
@@ -190,9 +192,9 @@ int main(int argc, char** argv)
     if (byClsid) { GUID c = gc_codec_clsid(foundId, true); r = createObj(&c, &IID_ICompressCoder, &raw); }
     else r = createEnc((uint32_t)found, &IID_ICompressCoder, &raw);
     if (r != S_OK || !raw) { fprintf(stderr, "CreateEncoder failed: %08X\n", (unsigned)r); return 9; }
-    // wrong interface id must be refused, decoders are not provided
+    // wrong interface id must be refused, decoders exist for ZSTD and BROTLI only
     { void* bad = nullptr; if (createEnc((uint32_t)found, &IID_ISequentialInStream, &bad) != E_NOINTERFACE || bad) { fprintf(stderr, "iid check\n"); return 10; }
-      if (foundId != 0x4F71101 && (createDec((uint32_t)found, &IID_ICompressCoder, &bad) != CLASS_E_CLASSNOTAVAILABLE || bad)) { fprintf(stderr, "decoder check\n"); return 10; } }
+      if (foundId != 0x4F71101 && foundId != 0x4F71102 && (createDec((uint32_t)found, &IID_ICompressCoder, &bad) != CLASS_E_CLASSNOTAVAILABLE || bad)) { fprintf(stderr, "decoder check\n"); return 10; } }
     ICompressCoder* coder = (ICompressCoder*)raw;
     ICompressSetCoderProperties* setProps = nullptr; ICompressWriteCoderProperties* writeProps = nullptr;
     ICompressSetCoderMt* mt = nullptr; ICompressSetCoderPropertiesOpt* opt = nullptr; IUnknown* unk = nullptr; void* none = nullptr;

@@ -28,7 +28,7 @@ def test_exports_and_method_listing(emu_module):
     lines = r.stdout.strip().splitlines()
     assert lines[0].split()[1:3] == ["4F71101", "ZSTD"]            # id and name of ZstdRegister.cpp:13-17
     assert "enc=1 dec=1" in lines[0] and "clsid=23170F69-40C1-2791" in lines[0]      # ZSTD: encoder and decoder
-    assert "enc=1 dec=0" in lines[1] and "enc=1 dec=0" in lines[2]
+    assert "enc=1 dec=0" in lines[1] and "enc=1 dec=1" in lines[2]                   # FLZMA2: the host's LZMA2 decoder; BROTLI: encoder and decoder (round 6)
     assert lines[1].split()[1:3] == ["21", "FLZMA2"]               # FastLzma2Register.cpp:13-18
     assert lines[2].split()[1:3] == ["4F71102", "BROTLI"]          # BrotliRegister.cpp:13-17
     import ctypes
@@ -188,6 +188,87 @@ def test_zstd_encode_then_decode_through_com_surface(O, emu_module, tmp_path):
     r = _host(emu_module, "decode", "ZSTDGPU", props, mid, dst)
     assert r.returncode == 0, r.stderr + r.stdout
     assert dst.read_bytes() == x.tobytes()
+
+
+def _brotli_dictionary_env(O, tmp_path):
+    """the stand-in host has no brotli of its own: the plugin reads the RFC's dictionary from the file this variable names"""
+    f = tmp_path / "rfc7932_dictionary.bin"
+    O.ref_brotli_dictionary().tofile(f)
+    return {"GPUCODEC_BROTLI_DICTIONARY": str(f)}
+
+
+@pytest.mark.parametrize("n", [0, 1, 9 * BLK + 333])
+def test_brotli_decode_through_com_surface(O, emu_module, tmp_path, n):
+    """CreateDecoder / CreateObject(decoder class id) -> SetDecoderProperties2 (3 bytes, BrotliDecoder.cpp:86-96) -> Code(): brotli-mt streams of the reference encoder
+    (several frames; with references to the static dictionary), a bare stream with the size the folder states, damaged and cut streams."""
+    if O.ref("brotli") is None:
+        pytest.skip("oracle/_ref not built")
+    env = _brotli_dictionary_env(O, tmp_path)
+    x = O.corpus("real-src", n) if n > 1 else O.corpus("text-zipf", n)
+    if x.size < n:
+        x = O.corpus("text-zipf", n)
+    props = tmp_path / "props.bin"
+    props.write_bytes(bytes([1, 2, 6]))
+    streams = [("q6 x3", O.ref_brotlimt_compress(x, 6, 3)), ("q1", O.ref_brotlimt_compress(x, 1, 2)), ("q11 by class id", O.ref_brotlimt_compress(x, 11, 1))]
+    for i, (name, comp) in enumerate(streams):
+        src, dst = tmp_path / ("c%d.br" % i), tmp_path / ("d%d.bin" % i)
+        src.write_bytes(comp.tobytes())
+        r = _host(emu_module, "decode", "BROTLI", props if i != 1 else "-", src, dst, *(["by-clsid"] if i == 2 else []), env=env)
+        assert r.returncode == 0, name + ": " + r.stderr + r.stdout
+        assert dst.read_bytes() == x.tobytes(), name
+    if n > 1:
+        bare = tmp_path / "bare.br"; bare.write_bytes(O.ref_brotli_compress(x, 5, 22).tobytes())
+        r = _host(emu_module, "decode", "BROTLIGPU", props, bare, tmp_path / "bare.out", "size=%d" % n, env=env)
+        assert r.returncode == 0 and (tmp_path / "bare.out").read_bytes() == x.tobytes(), r.stderr + r.stdout
+        r = _host(emu_module, "decode", "BROTLI", props, bare, tmp_path / "bare2.out", env=env)          # no size stated: this decoder cannot size the one chunk
+        assert r.returncode == 15 and "80004001" in r.stderr                                             # E_NOTIMPL
+        # without the dictionary a stream that refers to it is "unsupported", not "damaged"
+        r = _host(emu_module, "decode", "BROTLI", props, tmp_path / "c0.br", tmp_path / "nodict.out")
+        assert r.returncode == 15 and "80004001" in r.stderr, r.stderr + r.stdout
+        comp = bytearray(streams[0][1].tobytes())
+        cut = tmp_path / "cut.br"; cut.write_bytes(bytes(comp[: len(comp) - 3]))
+        r = _host(emu_module, "decode", "BROTLI", "-", cut, tmp_path / "cut.out", env=env)
+        assert r.returncode == 15 and "80004005" in r.stderr                                             # E_FAIL: the stream ends inside a frame
+        comp[4] ^= 1                                                                                     # the frame header's "8"
+        bad = tmp_path / "bad.br"; bad.write_bytes(bytes(comp))
+        r = _host(emu_module, "decode", "BROTLI", "-", bad, tmp_path / "bad.out", env=env)
+        assert r.returncode == 15 and "80004005" in r.stderr
+
+
+def test_brotli_encode_then_decode_through_com_surface(O, emu_module, tmp_path):
+    x = O.corpus("silesia-like", 9 * BLK + 17)
+    src, mid, props, dst = tmp_path / "in.bin", tmp_path / "mid.br", tmp_path / "props.bin", tmp_path / "out.bin"
+    x.tofile(src)
+    r = _host(emu_module, "encode", "BROTLI", 1, src, mid, props)
+    assert r.returncode == 0, r.stderr + r.stdout
+    r = _host(emu_module, "decode", "BROTLIGPU", props, mid, dst)         # this engine's streams never refer to the dictionary: none handed over
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert dst.read_bytes() == x.tobytes()
+
+
+@pytest.mark.gpu
+def test_product_plugin_brotli_decoder_on_gpu(O, graft, tmp_path):
+    graft.build_hip()
+    module = graft.build_plugin()
+    subprocess.run(["make", "-C", os.path.join(ROOT, "tests", "emu"), "_build/plugin_host"], check=True, capture_output=True)
+    n = 300 * 1024 * 1024 + 4321                                   # the compressed stream exceeds one 64 MiB read piece of the decoder
+    x = O.corpus("web-text", n)
+    src, mid, props, dst = tmp_path / "in.bin", tmp_path / "mid.br", tmp_path / "props.bin", tmp_path / "out.bin"
+    x.tofile(src)
+    r = _host(module, "encode", "BROTLI", 6, src, mid, props)
+    assert r.returncode == 0, r.stderr + r.stdout
+    r = _host(module, "decode", "BROTLI", props, mid, dst)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert np.array_equal(np.fromfile(dst, dtype=np.uint8), x)
+    if O.ref("brotli") is not None:
+        env = _brotli_dictionary_env(O, tmp_path)
+        y = O.corpus("real-src", 40 * 1024 * 1024)
+        for q in (1, 6, 11):
+            s2, d2 = tmp_path / ("c%d.br" % q), tmp_path / ("d%d.bin" % q)
+            s2.write_bytes(O.ref_brotlimt_compress(y[: (8 if q == 11 else 40) * 1024 * 1024], q, min(os.cpu_count() or 1, 64)).tobytes())
+            r = _host(module, "decode", "BROTLI", "-", s2, d2, env=env)
+            assert r.returncode == 0, str(q) + ": " + r.stderr + r.stdout
+            assert d2.read_bytes() == y[: (8 if q == 11 else 40) * 1024 * 1024].tobytes(), q
 
 
 @pytest.mark.gpu

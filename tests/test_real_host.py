@@ -56,6 +56,22 @@ def host_dir_nozstd(tmp_path_factory, host_dir):
     return d
 
 
+@pytest.fixture(scope="module")
+def host_dir_nobrotli(tmp_path_factory, host_dir):
+    """The host with a bundle that has no BROTLI codec of its own (linked without BrotliRegister.o; the brotli library itself stays inside): method id 4F71102 resolves to the
+    plugin for encoding AND decoding, and the plugin finds the RFC's static dictionary in the host (BrotliGetDictionary of its 7z.so)."""
+    if not os.path.exists(os.path.join(HOST, "7z_nobrotli.so")):
+        if os.path.isdir("/root/reference/CPP"):
+            subprocess.run(["bash", os.path.join(ROOT, "oracle", "build_ref_7z.sh"), HOST], check=True, capture_output=True, env=dict(os.environ, REF_ROOT="/root/reference"))
+        if not os.path.exists(os.path.join(HOST, "7z_nobrotli.so")):
+            pytest.skip("reference host without brotli not built (oracle/_ref/host7z/7z_nobrotli.so)")
+    d = tmp_path_factory.mktemp("host7z_nobrotli")
+    shutil.copy2(os.path.join(HOST, "7z"), d / "7z")
+    shutil.copy2(os.path.join(HOST, "7z_nobrotli.so"), d / "7z.so")
+    (d / "Codecs").mkdir()
+    return d
+
+
 def _install(host_dir, module, libdir):
     for f in os.listdir(host_dir / "Codecs"):
         os.remove(host_dir / "Codecs" / f)
@@ -75,7 +91,7 @@ def _check_listing(out, module_name):
     ours = [l for l in lines if len(l) == 4 and l[0] == "1" and l[1] in ("E", "ED", "EDF")]   # "<lib index> E|ED|EDF <id> <name>" from library 1
     got = {(l[2], l[3]) for l in ours}
     filters = {"BCJGPU", "PPCGPU", "IA64GPU", "ARMGPU", "ARMTGPU", "SPARCGPU", "ARM64GPU", "RISCVGPU", "DELTAGPU"}        # the pre-filters on the device (round 3)
-    assert {l[3] for l in ours if l[1] == "ED"} == {"ZSTD", "ZSTDGPU"}               # encoder + decoder: ZSTD only
+    assert {l[3] for l in ours if l[1] == "ED"} == {"ZSTD", "ZSTDGPU", "BROTLI", "BROTLIGPU"}     # encoder + decoder: ZSTD and (round 6) BROTLI
     assert {l[3] for l in ours if l[1] == "EDF"} == filters                          # ... and the filters, which the host recognises as such
     for want in [("4F71101", "ZSTD"), ("21", "FLZMA2"), ("4F71102", "BROTLI"), ("4F71101", "ZSTDGPU"), ("21", "FLZMA2GPU"), ("4F71102", "BROTLIGPU")]:
         assert want in got, (want, out)
@@ -144,6 +160,52 @@ def _decoder_under_real_host(host_dir, host_dir_nozstd, env_full, env_nozstd, O,
     assert np.array_equal(np.fromfile(out / src.name, dtype=np.uint8), x)
     r = _run(host_dir, env_full, "t", str(host_dir_nozstd / ("a_ZSTD_%d.7z" % n)))                        # the plugin's archive under the reference's decoder
     assert r.returncode == 0 and "Everything is Ok" in r.stdout, r.stdout + r.stderr
+
+
+def _brotli_decoder_under_real_host(host_dir, host_dir_nobrotli, env_full, env_nob, O, n, level, kind):
+    """(1) the host without its own BROTLI codec archives with -m0=BROTLI (the plugin's encoder) and tests / extracts with the plugin's DECODER; (2) an archive written by the
+    reference's own CPU encoder (brotli-mt frames, references to the static dictionary) is extracted by the plugin's decoder, which takes the dictionary from the host's
+    BrotliGetDictionary; (3) the plugin's archive under the reference's decoder."""
+    r = _run(host_dir_nobrotli, env_nob, "i")
+    assert r.returncode == 0 and "4F71102 BROTLI" in r.stdout, r.stdout
+    assert [l for l in r.stdout.splitlines() if l.split()[-2:] == ["4F71102", "BROTLI"] and " ED " in l], r.stdout
+    _roundtrip(host_dir_nobrotli, env_nob, O, "BROTLI", level, "BROTLI", n)
+    x = O.corpus(kind, n)
+    src = host_dir / "cpu_src_br.bin"
+    x.tofile(src)
+    for lv in sorted({level, 6, 11} if n <= 2_000_000 else {level, 6}):
+        arc = host_dir / ("cpu_br%d.7z" % lv)
+        if arc.exists():
+            arc.unlink()
+        r = _run(host_dir, env_full, "a", "-m0=brotli", "-mx%d" % lv, arc.name, src.name)                # the reference's built-in encoder
+        assert r.returncode == 0 and "Everything is Ok" in r.stdout, r.stdout + r.stderr
+        shutil.copy2(arc, host_dir_nobrotli / arc.name)
+        out = host_dir_nobrotli / "x_cpu_br"
+        if out.exists():
+            shutil.rmtree(out)
+        r = _run(host_dir_nobrotli, env_nob, "x", "-o" + str(out), arc.name)                              # ... decoded by the plugin
+        assert r.returncode == 0 and "Everything is Ok" in r.stdout, r.stdout + r.stderr
+        assert np.array_equal(np.fromfile(out / src.name, dtype=np.uint8), x)
+    r = _run(host_dir, env_full, "t", str(host_dir_nobrotli / ("a_BROTLI_%d.7z" % n)))                   # the plugin's archive under the reference's decoder
+    assert r.returncode == 0 and "Everything is Ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_real_host_decodes_brotli_through_the_emulator_module(host_dir, host_dir_nobrotli, emu_lib_path, O):
+    module = os.path.join(EMU, "lib7zgpucodec_emu.so")
+    kind = "real-src" if O.corpus("real-src", 1 << 20).size >= (1 << 20) else "text-zipf"
+    _brotli_decoder_under_real_host(host_dir, host_dir_nobrotli, _install(host_dir, module, EMU), _install(host_dir_nobrotli, module, EMU), O, 300_000, 1, kind)
+
+
+@pytest.mark.gpu
+def test_gpu_real_host_decodes_brotli_through_the_product_module(host_dir, host_dir_nobrotli, graft, O):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    graft.build_hip()
+    module = graft.build_plugin()
+    libdir = os.path.join(ROOT, "7-zip-zstd_amd", "csrc")
+    kind = "real-src" if O.corpus("real-src", 1 << 20).size >= (1 << 20) else "text-zipf"
+    _brotli_decoder_under_real_host(host_dir, host_dir_nobrotli, _install(host_dir, module, libdir), _install(host_dir_nobrotli, module, libdir), O, 100_000_000, 6, kind)
 
 
 def test_real_host_decodes_through_the_emulator_module(host_dir, host_dir_nozstd, emu_lib_path, O):
