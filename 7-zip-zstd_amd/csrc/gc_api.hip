@@ -1608,7 +1608,7 @@ extern "C" int gc_brotli_decompress_device(gc_ctx* c, const void* d_src, size_t 
     HIPCHK(c, hipSetDevice(c->device));
     *outSize = 0;
 #ifdef GC_TEST_HOOKS
-    { const char* e = getenv("GC_BRD_LDS"); c->brd.ldsCap = e ? (uint32_t)atoi(e) : 0u; }
+    { const char* e = getenv("GC_BRD_LDS"); c->brd.ldsCap = e ? (uint32_t)atoi(e) : 0u; e = getenv("GC_BRD_INSTANCE"); c->brd.instance = e ? (uint32_t)atoi(e) : 0u; }
 #endif
     for (size_t i = 0; i < nChunks; i++) if (chunks[i].src_off > n || chunks[i].src_size > n - chunks[i].src_off) { snprintf(c->err, sizeof(c->err), "brotli chunk %zu lies outside the %zu input bytes", i, n); return GC_ERR_PARAM; }
     return gc_brd_decode(c->stream, &c->brd, (const uint8_t*)d_src, chunks, nChunks, (uint8_t*)d_dst, dstCap, outSize, c->err, sizeof(c->err));
@@ -1640,7 +1640,7 @@ extern "C" int gc_brotli_decompress_host(gc_ctx* c, const void* src, size_t n, v
     size_t produced = 0;
     if (rc == GC_OK && hipMemcpyAsync(c->dIn, src, n, hipMemcpyHostToDevice, c->stream) != hipSuccess) rc = GC_ERR_HIP;
 #ifdef GC_TEST_HOOKS
-    { const char* e = getenv("GC_BRD_LDS"); c->brd.ldsCap = e ? (uint32_t)atoi(e) : 0u; }
+    { const char* e = getenv("GC_BRD_LDS"); c->brd.ldsCap = e ? (uint32_t)atoi(e) : 0u; e = getenv("GC_BRD_INSTANCE"); c->brd.instance = e ? (uint32_t)atoi(e) : 0u; }
 #endif
     if (rc == GC_OK) rc = gc_brd_decode(c->stream, &c->brd, c->dIn, ch, nChunks, c->dOut, dstCap, &produced, c->err, sizeof(c->err));
     if (rc == GC_OK && produced && (hipMemcpyAsync(dst, c->dOut, produced, hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)) rc = GC_ERR_HIP;

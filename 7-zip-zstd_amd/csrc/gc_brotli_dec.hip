@@ -44,8 +44,6 @@
 #define BRD_DICTIONARY  3u            // the stream refers to the static dictionary and none is loaded
 #define BRD_LIMIT       4u            // more trees / block types than the arenas hold
 
-#define BRD_LDS_ARENA   18432u        // bytes of prefix codes per wave in LDS
-#define BRD_CMAP_LDS    2560u         // context map bytes per wave in LDS (64 per literal block type + 4 per distance block type)
 #define BRD_PAGE        (800u * 1024u)      // what a chunk takes in HBM when LDS does not hold its meta-block (256 literal + 256 command + 256 distance trees at their largest: 0.77 MB)
 #define BRD_MAX_WAVES   1792u         // 7 waves per CU (LDS) x 256 CUs: the launch's width; chunks beyond it are taken in turns
 
@@ -66,12 +64,14 @@ __constant__ uint8_t  kdClcOrder[18] = { 1, 2, 3, 4, 0, 5, 17, 6, 16, 7, 8, 9, 1
 __constant__ uint8_t  kdDictBits[25] = { 0,0,0,0,10,10,11,11,10,10,10,10,10,9,9,8,7,7,8,7,7,6,6,5,5 };
 __constant__ uint32_t kdDictOff[25] = { 0,0,0,0,0,4096,9216,21504,35840,44032,53248,63488,74752,87040,93696,100864,104704,106752,108928,113536,115968,118528,119872,121280,122016 };
 
-struct BrdBits {                      // LSB-first bit reader over the chunk's bytes; identical in every lane
-    const uint8_t* p; uint64_t acc; uint32_t n; uint32_t pos, end; uint32_t over;
+struct BrdBits {                      // LSB-first bit reader over the chunk's bytes; identical in every lane.  `next` = the four bytes at `pos`, loaded one refill ahead
+    const uint8_t* p; uint64_t acc; uint32_t n; uint32_t pos, end; uint32_t over; uint32_t next;
 };
+__device__ __forceinline__ uint32_t brd_load32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ void brd_prime(BrdBits& b) { b.next = b.pos + 4u <= b.end ? brd_load32(b.p + b.pos) : 0u; }      // after pos has been set
 __device__ __forceinline__ void brd_fill(BrdBits& b)               // afterwards n >= 33
 {
-    if (b.pos + 4u <= b.end) { uint32_t v; __builtin_memcpy(&v, b.p + b.pos, 4); b.acc |= (uint64_t)v << b.n; b.n += 32u; b.pos += 4u; return; }
+    if (b.pos + 4u <= b.end) { b.acc |= (uint64_t)b.next << b.n; b.n += 32u; b.pos += 4u; brd_prime(b); return; }
     while (b.n <= 56u) { const uint64_t v = b.pos < b.end ? b.p[b.pos] : 0ull; if (b.pos >= b.end + 16u) b.over = 1u; b.acc |= v << b.n; b.n += 8u; b.pos++; }
 }
 __device__ __forceinline__ uint32_t brd_take(BrdBits& b, uint32_t k)      // k <= 32
@@ -83,93 +83,145 @@ __device__ __forceinline__ uint32_t brd_take(BrdBits& b, uint32_t k)      // k <
 }
 __device__ __forceinline__ uint32_t brd_consumed(const BrdBits& b) { return b.pos - (b.n >> 3); }      // bytes whose bits have been taken (rounded up)
 
-// a canonical prefix code: t[0..15] codes per length (t[0] = 1: ONE symbol, coded in zero bits), t[16..31] first code of the length, t[32..47] index of its first symbol
-struct BrdTree { const uint16_t* t; const uint8_t* sym8; const uint16_t* sym16; };
-__device__ __forceinline__ uint32_t brd_tree_sym(const BrdTree& t, uint32_t i) { return t.sym16 ? t.sym16[i] : t.sym8[i]; }
-// one lane on its own (headers)
-__device__ uint32_t brd_sym(BrdBits& b, const BrdTree& t)
+// Where a meta-block's tables live: the wave's LDS arena, and a page of HBM behind it for meta-blocks with hundreds of codes.  A HANDLE is a byte offset with
+// bit 31 = "in the page" and bit 30 = "symbols are 16 bits wide" (alphabets above 256).
+// A canonical prefix code at a handle: uint16 t[48] -- t[0..15] codes per length (t[0] = 1: ONE symbol, coded in zero bits), t[16..31] the first code of the length,
+// t[32..47] the index of its first symbol -- then the symbols in code order.
+#define BRD_H_HBM   0x80000000u
+#define BRD_H_WIDE  0x40000000u
+#define BRD_H_OFF   0x3FFFFFFFu
+struct BrdMem { uint8_t* lds; uint8_t* hbm; };
+__device__ __forceinline__ const uint8_t* brd_at(const BrdMem& m, uint32_t h) { return (h & BRD_H_HBM) ? m.hbm + (h & BRD_H_OFF) : m.lds + (h & BRD_H_OFF); }
+__device__ __forceinline__ uint32_t brd_t(const BrdMem& m, uint32_t h, uint32_t i)
 {
-    if (t.t[0]) return brd_tree_sym(t, 0);
+    return (h & BRD_H_HBM) ? ((const uint16_t*)(m.hbm + (h & BRD_H_OFF)))[i] : ((const uint16_t*)(m.lds + (h & BRD_H_OFF)))[i];
+}
+__device__ __forceinline__ uint32_t brd_symbol(const BrdMem& m, uint32_t h, uint32_t i)
+{
+    const uint8_t* s = brd_at(m, h) + 96u;
+    return (h & BRD_H_WIDE) ? ((const uint16_t*)s)[i] : s[i];
+}
+// one lane on its own (headers)
+__device__ __noinline__ uint32_t brd_sym(BrdBits& b, const BrdMem m, uint32_t h)
+{
+    if (brd_t(m, h, 0)) return brd_symbol(m, h, 0);
     if (b.n <= 32u) brd_fill(b);
     const uint32_t rev = __brev((uint32_t)b.acc);
 #pragma unroll 1
     for (uint32_t len = 1; len <= 15u; len++) {
-        const uint32_t c = rev >> (32u - len);
-        if (c - t.t[16u + len] < t.t[len]) { b.acc >>= len; b.n -= len; return brd_tree_sym(t, t.t[32u + len] + c - t.t[16u + len]); }
+        const uint32_t c = rev >> (32u - len), first = brd_t(m, h, 16u + len);
+        if (c - first < brd_t(m, h, len)) { b.acc >>= len; b.n -= len; return brd_symbol(m, h, brd_t(m, h, 32u + len) + c - first); }
     }
     b.over = 1u;                                                  // not a code word: the code is incomplete (damaged)
     return 0;
 }
-// the wave together (commands, literals, distances, block switches): every lane holds the same reader and gets the same symbol
-__device__ __forceinline__ uint32_t brd_sym_w(BrdBits& b, const BrdTree& t, uint32_t lane)
+// the wave together: lane l tests whether the next l bits are a code of length l (canonical codes: one length answers); every lane gets the symbol
+__device__ __forceinline__ uint32_t brd_sym_w(BrdBits& b, const BrdMem& m, uint32_t h, uint32_t lane)
 {
-    if (t.t[0]) return brd_tree_sym(t, 0);
+    if (brd_t(m, h, 0)) return brd_symbol(m, h, 0);
     if (b.n <= 32u) brd_fill(b);
     const uint32_t rev = __brev((uint32_t)b.acc), l = lane & 15u;
     const uint32_t c = l ? rev >> (32u - l) : 0u;
-    const bool hit = l != 0u && c - t.t[16u + l] < t.t[l];
-    const uint64_t m = __ballot(hit) & 0xFFFEull;
-    if (m == 0ull) { b.over = 1u; return 0; }
-    const uint32_t len = (uint32_t)__ffsll((long long)m) - 1u;
-    const uint32_t i = t.t[32u + len] + (rev >> (32u - len)) - t.t[16u + len];
+    const bool hit = l != 0u && c - brd_t(m, h, 16u + l) < brd_t(m, h, l);
+    const uint64_t mk = __ballot(hit) & 0xFFFEull;
+    if (mk == 0ull) { b.over = 1u; return 0; }
+    const uint32_t len = (uint32_t)__ffsll((long long)mk) - 1u;
+    const uint32_t i = brd_t(m, h, 32u + len) + (rev >> (32u - len)) - brd_t(m, h, 16u + len);
     b.acc >>= len; b.n -= len;
-    return brd_tree_sym(t, i);
+    return brd_symbol(m, h, i);
+}
+// ... through a table of 2^BITS entries in LDS (0x8000 | symbol << 4 | length; 0: the code is longer than BITS, the wave decodes it)
+template <uint32_t BITS>
+__device__ __forceinline__ uint32_t brd_sym_t(BrdBits& b, const uint16_t* tabs, uint32_t nTab, const uint32_t* dir, uint32_t tree, const BrdMem& m, uint32_t lane)
+{
+    if (tree < nTab) {
+        if (b.n <= 32u) brd_fill(b);
+        const uint32_t e = tabs[(tree << BITS) + ((uint32_t)b.acc & ((1u << BITS) - 1u))];
+        if (e & 0x8000u) { const uint32_t len = e & 15u; b.acc >>= len; b.n -= len; return (e >> 4) & 0x7FFu; }
+    }
+    return brd_sym_w(b, m, dir[tree], lane);
+}
+// the wave fills the table of one code
+__device__ __noinline__ void brd_table_w(const BrdMem m, uint32_t h, uint32_t bits, uint16_t* tab, uint32_t lane)
+{
+    const uint32_t entries = 1u << bits;
+    if (brd_t(m, h, 0)) { const uint16_t e = (uint16_t)(0x8000u | (brd_symbol(m, h, 0) << 4)); for (uint32_t i = lane; i < entries; i += 64u) tab[i] = e; return; }
+    for (uint32_t i = lane; i < entries; i += 64u) tab[i] = 0;
+    gc_wave_sync();
+    const uint32_t nShort = brd_t(m, h, 32u + bits) + brd_t(m, h, bits);      // the symbols with codes of at most `bits` bits come first in code order
+    for (uint32_t i = lane; i < nShort; i += 64u) {
+        uint32_t L = 1;
+        while (L < bits && i >= brd_t(m, h, 32u + L) + brd_t(m, h, L)) L++;
+        const uint32_t code = brd_t(m, h, 16u + L) + i - brd_t(m, h, 32u + L);
+        const uint16_t e = (uint16_t)(0x8000u | (brd_symbol(m, h, i) << 4) | L);
+        for (uint32_t k = __brev(code) >> (32u - L); k < entries; k += 1u << L) tab[k] = e;
+    }
 }
 
-struct BrdArena { uint8_t* lds; uint32_t ldsCap, ldsUsed; uint8_t* hbm; uint32_t hbmCap, hbmUsed; };
-__device__ __forceinline__ uint8_t* brd_alloc(BrdArena& a, uint32_t bytes)
+struct BrdArena { BrdMem m; uint32_t ldsCap, ldsUsed; uint32_t hbmCap, hbmUsed; };
+__device__ __forceinline__ uint32_t brd_alloc(BrdArena& a, uint32_t bytes)      // -> handle, or ~0u
 {
     bytes = (bytes + 7u) & ~7u;
-    if (a.ldsUsed + bytes <= a.ldsCap) { uint8_t* p = a.lds + a.ldsUsed; a.ldsUsed += bytes; return p; }
-    if (a.hbm && a.hbmUsed + bytes <= a.hbmCap) { uint8_t* p = a.hbm + a.hbmUsed; a.hbmUsed += bytes; return p; }
-    return nullptr;
+    if (a.ldsUsed + bytes <= a.ldsCap) { const uint32_t h = a.ldsUsed; a.ldsUsed += bytes; return h; }
+    if (a.m.hbm && a.hbmUsed + bytes <= a.hbmCap) { const uint32_t h = a.hbmUsed | BRD_H_HBM; a.hbmUsed += bytes; return h; }
+    return ~0u;
+}
+__device__ __forceinline__ uint32_t brd_alloc_lds(BrdArena& a, uint32_t bytes)  // maps, modes, directories: read per symbol, so LDS or nothing
+{
+    bytes = (bytes + 7u) & ~7u;
+    if (a.ldsUsed + bytes <= a.ldsCap) { const uint32_t h = a.ldsUsed; a.ldsUsed += bytes; return h; }
+    return ~0u;
 }
 // lengths (0..15) of `alpha` symbols -> the canonical code in the arena
-__device__ bool brd_build(const uint8_t* len, uint32_t alpha, BrdArena& A, BrdTree& out)
+__device__ __noinline__ uint32_t brd_build(const uint8_t* len, uint32_t alpha, BrdArena& A)
 {
     const bool wide = alpha > 256u;
     uint32_t cnt[16]; for (uint32_t k = 0; k < 16u; k++) cnt[k] = 0;
     for (uint32_t sy = 0; sy < alpha; sy++) cnt[len[sy]]++;
     const uint32_t nUsed = alpha - cnt[0];
-    uint8_t* mem = brd_alloc(A, 96u + (nUsed ? nUsed : 1u) * (wide ? 2u : 1u));
-    if (!mem) return false;
+    const uint32_t h = brd_alloc(A, 96u + (nUsed ? nUsed : 1u) * (wide ? 2u : 1u));
+    if (h == ~0u) return h;
+    uint8_t* mem = (uint8_t*)brd_at(A.m, h);
     uint16_t* T = (uint16_t*)mem;
     uint32_t code = 0, index = 0, off[16];
     T[0] = 0; T[16] = 0; T[32] = 0;
     for (uint32_t L = 1; L <= 15u; L++) { T[L] = (uint16_t)cnt[L]; T[16u + L] = (uint16_t)code; T[32u + L] = (uint16_t)index; off[L] = index; index += cnt[L]; code = (code + cnt[L]) << 1; }
     for (uint32_t sy = 0; sy < alpha; sy++) { const uint32_t L = len[sy]; if (L) { const uint32_t k = off[L]++; if (wide) ((uint16_t*)(mem + 96u))[k] = (uint16_t)sy; else mem[96u + k] = (uint8_t)sy; } }
-    out.t = T; out.sym8 = wide ? nullptr : mem + 96u; out.sym16 = wide ? (const uint16_t*)(mem + 96u) : nullptr;
-    return true;
+    return h | (wide ? BRD_H_WIDE : 0u);
 }
-__device__ bool brd_build_single(uint32_t sym, bool wide, BrdArena& A, BrdTree& out)
+__device__ __noinline__ uint32_t brd_build_single(uint32_t sym, bool wide, BrdArena& A)
 {
-    uint8_t* mem = brd_alloc(A, 96u + 2u);
-    if (!mem) return false;
+    const uint32_t h = brd_alloc(A, 96u + 2u);
+    if (h == ~0u) return h;
+    uint8_t* mem = (uint8_t*)brd_at(A.m, h);
     uint16_t* T = (uint16_t*)mem; for (uint32_t k = 0; k < 48u; k++) T[k] = 0;
     T[0] = 1;
     if (wide) ((uint16_t*)(mem + 96u))[0] = (uint16_t)sym; else mem[96] = (uint8_t)sym;
-    out.t = T; out.sym8 = wide ? nullptr : mem + 96u; out.sym16 = wide ? (const uint16_t*)(mem + 96u) : nullptr;
-    return true;
+    return h | (wide ? BRD_H_WIDE : 0u);
 }
 
-// Reads one prefix code over an alphabet of `alpha` symbols (RFC 7932 sections 3.4 / 3.5) into the arena.  len[] = scratch of alpha bytes.  One lane.
-__device__ bool brd_read_code(BrdBits& b, uint32_t alpha, BrdArena& A, uint8_t* len, BrdTree& out, uint32_t& status)
+// Reads one prefix code over an alphabet of `alpha` symbols (RFC 7932 sections 3.4 / 3.5) into the arena.  len[] = scratch of alpha bytes.  One lane.  -> handle
+__device__ __noinline__ uint32_t brd_read_code(BrdBits& b, uint32_t alpha, BrdArena& A, uint8_t* len, uint32_t& status)
 {
     const uint32_t hskip = brd_take(b, 2);
+    uint32_t h;
     if (hskip == 1u) {                                            // simple code: 1..4 symbols
         const uint32_t nsym = brd_take(b, 2) + 1u;
         uint32_t abits = 0; while ((1u << abits) < alpha) abits++;
         uint32_t s[4] = { 0, 0, 0, 0 };
-        for (uint32_t i = 0; i < nsym; i++) { s[i] = brd_take(b, abits); if (s[i] >= alpha) { status = BRD_CORRUPT; return false; } }
-        for (uint32_t i = 0; i < nsym; i++) for (uint32_t j = i + 1u; j < nsym; j++) if (s[i] == s[j]) { status = BRD_CORRUPT; return false; }
-        if (nsym == 1u) { if (!brd_build_single(s[0], alpha > 256u, A, out)) { status = BRD_LIMIT; return false; } return true; }
-        for (uint32_t i = 0; i < alpha; i++) len[i] = 0;
-        if (nsym == 2u) { len[s[0]] = 1; len[s[1]] = 1; }
-        else if (nsym == 3u) { len[s[0]] = 1; len[s[1]] = 2; len[s[2]] = 2; }
-        else if (brd_take(b, 1)) { len[s[0]] = 1; len[s[1]] = 2; len[s[2]] = 3; len[s[3]] = 3; }
-        else { len[s[0]] = 2; len[s[1]] = 2; len[s[2]] = 2; len[s[3]] = 2; }
-        if (!brd_build(len, alpha, A, out)) { status = BRD_LIMIT; return false; }
-        return true;
+        for (uint32_t i = 0; i < nsym; i++) { s[i] = brd_take(b, abits); if (s[i] >= alpha) { status = BRD_CORRUPT; return ~0u; } }
+        for (uint32_t i = 0; i < nsym; i++) for (uint32_t j = i + 1u; j < nsym; j++) if (s[i] == s[j]) { status = BRD_CORRUPT; return ~0u; }
+        if (nsym == 1u) h = brd_build_single(s[0], alpha > 256u, A);
+        else {
+            for (uint32_t i = 0; i < alpha; i++) len[i] = 0;
+            if (nsym == 2u) { len[s[0]] = 1; len[s[1]] = 1; }
+            else if (nsym == 3u) { len[s[0]] = 1; len[s[1]] = 2; len[s[2]] = 2; }
+            else if (brd_take(b, 1)) { len[s[0]] = 1; len[s[1]] = 2; len[s[2]] = 3; len[s[3]] = 3; }
+            else { len[s[0]] = 2; len[s[1]] = 2; len[s[2]] = 2; len[s[3]] = 2; }
+            h = brd_build(len, alpha, A);
+        }
+        if (h == ~0u) status = BRD_LIMIT;
+        return h;
     }
     // complex code: the lengths of the 18 code length symbols (a fixed code of 2-4 bits each), then the symbols' lengths under that code
     uint8_t cl[18]; for (uint32_t i = 0; i < 18u; i++) cl[i] = 0;
@@ -184,17 +236,25 @@ __device__ bool brd_read_code(BrdBits& b, uint32_t alpha, BrdArena& A, uint8_t* 
         cl[kdClcOrder[i]] = (uint8_t)v;
         if (v) { space -= 32 >> v; numCodes++; }
     }
-    if (!(numCodes == 1u || space == 0)) { status = BRD_CORRUPT; return false; }
-    uint16_t ct[48]; uint8_t csym[18];
-    for (uint32_t i = 0; i < 48u; i++) ct[i] = 0;
-    if (numCodes == 1u) { ct[0] = 1; for (uint32_t sy = 0; sy < 18u; sy++) if (cl[sy]) csym[0] = (uint8_t)sy; }
-    else { uint32_t code = 0, k = 0; for (uint32_t L = 1; L <= 5u; L++) { ct[16u + L] = (uint16_t)code; ct[32u + L] = (uint16_t)k; for (uint32_t sy = 0; sy < 18u; sy++) if (cl[sy] == L) { csym[k++] = (uint8_t)sy; ct[L]++; } code = (code + ct[L]) << 1; } }
-    BrdTree cT; cT.t = ct; cT.sym8 = csym; cT.sym16 = nullptr;
+    if (!(numCodes == 1u || space == 0)) { status = BRD_CORRUPT; return ~0u; }
+    // the code length code itself: a small canonical code in registers / private memory
+    uint32_t cCnt[6], cFirst[6], cBase[6]; uint8_t csym[18]; uint32_t single = 0;
+    for (uint32_t i = 0; i < 6u; i++) { cCnt[i] = 0; cFirst[i] = 0; cBase[i] = 0; }
+    if (numCodes == 1u) { for (uint32_t sy = 0; sy < 18u; sy++) if (cl[sy]) single = sy; }
+    else { uint32_t code = 0, k = 0; for (uint32_t L = 1; L <= 5u; L++) { cFirst[L] = code; cBase[L] = k; for (uint32_t sy = 0; sy < 18u; sy++) if (cl[sy] == L) { csym[k++] = (uint8_t)sy; cCnt[L]++; } code = (code + cCnt[L]) << 1; } }
     uint32_t i = 0, prev = 8, rep = 0, repLen = 0;
     int sp = 32768;
     while (i < alpha && sp > 0) {
-        const uint32_t v = brd_sym(b, cT);
-        if (b.over) { status = BRD_CORRUPT; return false; }
+        uint32_t v = single;
+        if (numCodes != 1u) {
+            if (b.n <= 32u) brd_fill(b);
+            const uint32_t rev = __brev((uint32_t)b.acc);
+            uint32_t L = 1;
+            for (; L <= 5u; L++) { const uint32_t c = rev >> (32u - L); if (c - cFirst[L] < cCnt[L]) { v = csym[cBase[L] + c - cFirst[L]]; break; } }
+            if (L > 5u) { status = BRD_CORRUPT; return ~0u; }
+            b.acc >>= L; b.n -= L;
+        }
+        if (b.over) { status = BRD_CORRUPT; return ~0u; }
         if (v < 16u) {
             len[i++] = (uint8_t)v; rep = 0;
             if (v) { prev = v; sp -= 32768 >> v; }
@@ -205,16 +265,17 @@ __device__ bool brd_read_code(BrdBits& b, uint32_t alpha, BrdArena& A, uint8_t* 
             if (rep > 0u) rep = (rep - 2u) << extra;
             rep += brd_take(b, extra) + 3u;
             const uint32_t delta = rep - old;
-            if (i + delta > alpha) { status = BRD_CORRUPT; return false; }
+            if (i + delta > alpha) { status = BRD_CORRUPT; return ~0u; }
             for (uint32_t k = 0; k < delta; k++) len[i + k] = (uint8_t)newLen;
             i += delta;
             if (newLen) sp -= (int)(delta << (15u - newLen));
         }
     }
-    if (sp != 0) { status = BRD_CORRUPT; return false; }
+    if (sp != 0) { status = BRD_CORRUPT; return ~0u; }
     for (; i < alpha; i++) len[i] = 0;
-    if (!brd_build(len, alpha, A, out)) { status = BRD_LIMIT; return false; }
-    return true;
+    h = brd_build(len, alpha, A);
+    if (h == ~0u) status = BRD_LIMIT;
+    return h;
 }
 
 __device__ __forceinline__ uint32_t brd_varlen8(BrdBits& b)     // VarLenUint8: 0..255
@@ -224,7 +285,7 @@ __device__ __forceinline__ uint32_t brd_varlen8(BrdBits& b)     // VarLenUint8: 
     return nb ? (1u << nb) + brd_take(b, nb) : 1u;
 }
 
-// context ids of the four literal context modes (RFC 7932 section 7.1): lut[0..255] for the last byte, lut[256..511] for the one before (their OR for UTF8 and SIGNED)
+// context ids of the literal context modes (RFC 7932 section 7.1): for UTF8 lut[0..255] of the last byte | lut[256..511] of the one before
 __device__ __forceinline__ uint32_t brd_utf8_0(uint32_t b)
 {
     if (b >= 192u) return 2u + (b & 1u);
@@ -257,35 +318,33 @@ __device__ __forceinline__ uint32_t brd_utf8_1(uint32_t b)
 }
 __device__ __forceinline__ uint32_t brd_signed(uint32_t b) { return b == 0u ? 0u : (b < 16u ? 1u : (b < 64u ? 2u : (b < 128u ? 3u : (b < 192u ? 4u : (b < 240u ? 5u : (b < 255u ? 6u : 7u)))))); }
 
+// the format's small tables, copied to LDS once per wave (a read of __constant__ memory with a computed index is a trip to the scalar cache per symbol)
+struct BrdConst { uint16_t insBase[24], copyBase[24], blockBase[26]; uint8_t insExtra[24], copyExtra[24], blockExtra[26], cellIns[12], cellCopy[12]; };
+
 // one category of block types (literals, insert-and-copy, distances): RFC 7932 section 6
-struct BrdBlocks { uint32_t n, type, prev, left; BrdTree typeCode, countCode; };
-__device__ __forceinline__ uint32_t brd_block_count(BrdBits& b, const BrdTree& t)
+struct BrdBlocks { uint32_t n, type, prev, left, typeCode, countCode; };
+__device__ __forceinline__ void brd_switch_w(BrdBits& b, BrdBlocks& B, const BrdMem& m, const BrdConst& K, uint32_t lane)
 {
-    const uint32_t s = brd_sym(b, t);
-    return s < 26u ? kdBlockBase[s] + brd_take(b, kdBlockExtra[s]) : 0u;
-}
-__device__ __forceinline__ void brd_switch_w(BrdBits& b, BrdBlocks& B, uint32_t lane)
-{
-    const uint32_t s = brd_sym_w(b, B.typeCode, lane);
+    const uint32_t s = brd_sym_w(b, m, B.typeCode, lane);
     uint32_t t = s == 0u ? B.prev : (s == 1u ? B.type + 1u : s - 2u);
     if (t >= B.n) t -= B.n;
     B.prev = B.type; B.type = t;
-    const uint32_t cs = brd_sym_w(b, B.countCode, lane);
-    B.left = cs < 26u ? kdBlockBase[cs] + brd_take(b, kdBlockExtra[cs]) : 0u;
+    const uint32_t cs = brd_sym_w(b, m, B.countCode, lane);
+    B.left = cs < 26u ? K.blockBase[cs] + brd_take(b, K.blockExtra[cs]) : 0u;
 }
 
 // context map (RFC 7932 section 7.3): `size` entries in out[].  One lane.
-__device__ bool brd_context_map(BrdBits& b, uint32_t size, uint32_t& nTrees, uint8_t* out, BrdArena& A, uint8_t* lenScratch, uint32_t& status)
+__device__ __noinline__ bool brd_context_map(BrdBits& b, uint32_t size, uint32_t& nTrees, uint8_t* out, BrdArena& A, uint8_t* lenScratch, uint32_t& status)
 {
     nTrees = brd_varlen8(b) + 1u;
     if (nTrees == 1u) { for (uint32_t i = 0; i < size; i++) out[i] = 0; return true; }
     uint32_t rleMax = 0;
     if (brd_take(b, 1)) rleMax = brd_take(b, 4) + 1u;
     BrdArena tmp = A;                                             // the map's own code is only needed here: its arena space is given back
-    BrdTree t;
-    if (!brd_read_code(b, nTrees + rleMax, tmp, lenScratch, t, status)) return false;
+    const uint32_t h = brd_read_code(b, nTrees + rleMax, tmp, lenScratch, status);
+    if (h == ~0u) return false;
     for (uint32_t i = 0; i < size;) {
-        const uint32_t s = brd_sym(b, t);
+        const uint32_t s = brd_sym(b, tmp.m, h);
         if (b.over) { status = BRD_CORRUPT; return false; }
         if (s == 0u) out[i++] = 0;
         else if (s <= rleMax) { const uint32_t run = (1u << s) + brd_take(b, s); if (i + run > size) { status = BRD_CORRUPT; return false; } for (uint32_t k = 0; k < run; k++) out[i++] = 0; }
@@ -304,37 +363,49 @@ struct BrdMeta {
     uint64_t acc; uint32_t n, pos, over, status;
     uint32_t kind;                        // 0 compressed, 1 uncompressed (copy `mlen` bytes from srcAt), 2 nothing to produce, 3 the stream has ended
     uint32_t mlen, last, srcAt;
-    uint32_t nTypes[3], left[3];
+    uint32_t nTypes[3], left[3], typeCode[3], countCode[3];
     uint32_t npostfix, ndirect;
-    BrdTree typeCode[3], countCode[3];
-    BrdTree *TL, *TI, *TD; uint8_t *cmapL, *cmapD, *modes;
+    uint32_t nTrees[3];                   // literal, insert-and-copy, distance codes
+    uint32_t dir[3];                      // handles of the three directories (uint32 handles of the codes)
+    uint32_t cmapL, cmapD, modes;         // handles
+    uint32_t tab[3], nTab[3];             // LDS offset of the decoding tables of the first nTab codes of each kind (512 / 2048 / 512 bytes each)
+    uint32_t ldsUsed;
 };
 
 // ------------------------------------------------------------------------------------------------ one wave per chunk
-extern "C" __global__ void __launch_bounds__(64)
-gc_brotli_dec_kernel(const uint8_t* __restrict__ src, const GcBrDecChunk* __restrict__ chunks, uint32_t nChunks, uint8_t* __restrict__ stage,
-                     uint8_t* __restrict__ pages, uint32_t nPages, uint32_t* __restrict__ pageCursor, GcBrDecResult* __restrict__ result, GcBrDict dict, uint32_t ldsCap)
+// ARENA: bytes of LDS for a meta-block's codes, maps and decoding tables; RING: the last RING bytes of output, so that near copies read LDS (0: none).  The host picks the
+// instance by the number of chunks: few chunks get the LDS of a whole CU each.
+template <uint32_t ARENA, uint32_t RING>
+__device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src, const GcBrDecChunk* __restrict__ chunks, uint32_t nChunks, uint8_t* __restrict__ stage,
+                                                uint8_t* __restrict__ pages, uint32_t nPages, uint32_t* __restrict__ pageCursor, GcBrDecResult* __restrict__ result, GcBrDict dict, uint32_t ldsCap)
 {
-    __shared__ __attribute__((aligned(8))) uint8_t sArena[BRD_LDS_ARENA];
-    __shared__ uint8_t sCmap[BRD_CMAP_LDS];
+    __shared__ __attribute__((aligned(8))) uint8_t sArena[ARENA];
+    __shared__ uint8_t sRing[RING ? RING : 8u];
     __shared__ uint8_t sLut[512];                                 // UTF8 context ids (mode 2), the mode of every stream this engine writes and of nearly every one of the reference
     __shared__ uint8_t sLen[704];
     __shared__ BrdMeta sMeta;
+    __shared__ BrdConst sK;
     const uint32_t lane = threadIdx.x;
+    constexpr uint32_t RMASK = RING ? RING - 1u : 0u;
     for (uint32_t i = lane; i < 256u; i += 64u) { sLut[i] = (uint8_t)brd_utf8_0(i); sLut[256u + i] = (uint8_t)brd_utf8_1(i); }
+    if (lane < 24u) { sK.insBase[lane] = kdInsBase[lane]; sK.copyBase[lane] = kdCopyBase[lane]; sK.insExtra[lane] = kdInsExtra[lane]; sK.copyExtra[lane] = kdCopyExtra[lane]; }
+    if (lane < 26u) { sK.blockBase[lane] = kdBlockBase[lane]; sK.blockExtra[lane] = kdBlockExtra[lane]; }
+    if (lane < 11u) { sK.cellIns[lane] = kdCellIns[lane]; sK.cellCopy[lane] = kdCellCopy[lane]; }
     gc_wave_sync();
+    const BrdConst& K = sK;
     for (uint32_t c = blockIdx.x; c < nChunks; c += gridDim.x) {
         const GcBrDecChunk ck = chunks[c];
         uint8_t* const out = stage + ck.stageOff;
         const uint32_t cap = ck.hintBytes;
-        uint8_t* myPage = nullptr;                                // taken from the pool when a meta-block needs it, kept for the chunk
+        BrdMem mem; mem.lds = sArena; mem.hbm = nullptr;          // (the page is taken from the pool when a meta-block needs it, kept for the chunk)
         uint32_t status = BRD_OK, pos = 0;
-        BrdBits b; b.p = src + ck.srcOff; b.acc = 0; b.n = 0; b.pos = 0; b.end = ck.srcSize; b.over = 0u;
+        BrdBits b; b.p = src + ck.srcOff; b.acc = 0; b.n = 0; b.pos = 0; b.end = ck.srcSize; b.over = 0u; brd_prime(b);
         // stream header: WBITS (RFC 7932 section 9.1)
         uint32_t wbits = 16;
         if (brd_take(b, 1)) { const uint32_t n = brd_take(b, 3); if (n) wbits = 17u + n; else { const uint32_t m = brd_take(b, 3); if (m == 1u) status = BRD_CORRUPT; else wbits = m ? 8u + m : 17u; } }
         const uint32_t maxBack = (1u << wbits) - 16u;
-        int ring[4] = { 16, 15, 11, 4 }; uint32_t ringIdx = 0;  // the last distance is ring[(ringIdx - 1) & 3]
+        int r1 = 4, r2 = 11, r3 = 15, r4 = 16;                    // the last four distances, r1 the most recent
+        uint32_t p1 = 0, p2 = 0;                                  // the last two bytes of the output
         bool last = false;
         while (!last && status == BRD_OK) {
             // ---- meta-block header: lane 0 reads it (prefix codes and context maps are serial work), the wave takes over what it found
@@ -353,7 +424,7 @@ gc_brotli_dec_kernel(const uint8_t* __restrict__ src, const GcBrDecChunk* __rest
                         if (brd_take(b, b.n & 7u) != 0u) st = BRD_CORRUPT;
                         const uint32_t at = brd_consumed(b);
                         if (at + skip > b.end) st = BRD_CORRUPT;
-                        b.acc = 0; b.n = 0; b.pos = at + skip;
+                        b.acc = 0; b.n = 0; b.pos = at + skip; brd_prime(b);
                     } else {
                         const uint32_t nib = 4u + nibCode;
                         uint32_t mlen = 0;
@@ -364,60 +435,66 @@ gc_brotli_dec_kernel(const uint8_t* __restrict__ src, const GcBrDecChunk* __rest
                             if (brd_take(b, b.n & 7u) != 0u) st = BRD_CORRUPT;
                             M.srcAt = brd_consumed(b); M.kind = 1;
                             if (M.srcAt + M.mlen > b.end) st = BRD_CORRUPT;
-                            b.acc = 0; b.n = 0; b.pos = M.srcAt + M.mlen;
+                            b.acc = 0; b.n = 0; b.pos = M.srcAt + M.mlen; brd_prime(b);
                         } else if (st == BRD_OK) {
                             M.kind = 0;
-                            // two passes at most: the second with a page in HBM behind the LDS arena
+                            // two passes at most: the second with a page of HBM behind the LDS arena
                             const BrdBits b0 = b;
                             for (uint32_t attempt = 0; attempt < 2u; attempt++) {
                                 b = b0; st = BRD_OK;
-                                BrdArena A; A.lds = sArena; A.ldsCap = ldsCap; A.ldsUsed = 0; A.hbm = myPage; A.hbmCap = BRD_PAGE; A.hbmUsed = 0;
-                                BrdBlocks BL[3];
+                                BrdArena A; A.m = mem; A.ldsCap = ldsCap < ARENA ? ldsCap : ARENA; A.ldsUsed = 0; A.hbmCap = BRD_PAGE; A.hbmUsed = 0;
                                 for (uint32_t k = 0; k < 3u && st == BRD_OK; k++) {
-                                    BL[k].n = brd_varlen8(b) + 1u; BL[k].left = 1u << 24;
-                                    BL[k].typeCode.t = nullptr; BL[k].typeCode.sym8 = nullptr; BL[k].typeCode.sym16 = nullptr; BL[k].countCode = BL[k].typeCode;
-                                    if (BL[k].n >= 2u) {
-                                        if (!brd_read_code(b, BL[k].n + 2u, A, sLen, BL[k].typeCode, st)) break;
-                                        if (!brd_read_code(b, 26u, A, sLen, BL[k].countCode, st)) break;
-                                        BL[k].left = brd_block_count(b, BL[k].countCode);
+                                    M.nTypes[k] = brd_varlen8(b) + 1u; M.left[k] = ~0u; M.typeCode[k] = 0; M.countCode[k] = 0;
+                                    if (M.nTypes[k] >= 2u) {
+                                        M.typeCode[k] = brd_read_code(b, M.nTypes[k] + 2u, A, sLen, st); if (st != BRD_OK) break;
+                                        M.countCode[k] = brd_read_code(b, 26u, A, sLen, st); if (st != BRD_OK) break;
+                                        const uint32_t cs = brd_sym(b, A.m, M.countCode[k]);
+                                        M.left[k] = cs < 26u ? kdBlockBase[cs] + brd_take(b, kdBlockExtra[cs]) : 0u;
                                     }
-                                    M.nTypes[k] = BL[k].n; M.left[k] = BL[k].left; M.typeCode[k] = BL[k].typeCode; M.countCode[k] = BL[k].countCode;
                                 }
                                 if (st == BRD_OK) {
                                     M.npostfix = brd_take(b, 2); M.ndirect = brd_take(b, 4) << M.npostfix;
-                                    M.modes = brd_alloc(A, BL[0].n);
-                                    if (!M.modes) st = BRD_LIMIT;
-                                    else for (uint32_t i = 0; i < BL[0].n; i++) M.modes[i] = (uint8_t)brd_take(b, 2);
+                                    M.modes = brd_alloc_lds(A, M.nTypes[0]);
+                                    if (M.modes == ~0u) st = BRD_LIMIT;
+                                    else { uint8_t* md = sArena + M.modes; for (uint32_t i = 0; i < M.nTypes[0]; i++) md[i] = (uint8_t)brd_take(b, 2); }
                                 }
-                                uint32_t nTreesL = 1, nTreesD = 1;
+                                M.nTrees[0] = 1; M.nTrees[1] = M.nTypes[1]; M.nTrees[2] = 1;
                                 if (st == BRD_OK) {
-                                    const uint32_t sl = 64u * BL[0].n, sd = 4u * BL[2].n;
-                                    if (sl + sd <= BRD_CMAP_LDS && ldsCap == BRD_LDS_ARENA) { M.cmapL = sCmap; M.cmapD = sCmap + sl; }
-                                    else if (A.hbm && A.hbmUsed + sl + sd <= A.hbmCap) { M.cmapL = A.hbm + A.hbmUsed; M.cmapD = M.cmapL + sl; A.hbmUsed += (sl + sd + 7u) & ~7u; }
-                                    else st = BRD_LIMIT;
-                                    if (st == BRD_OK) brd_context_map(b, sl, nTreesL, M.cmapL, A, sLen, st);
-                                    if (st == BRD_OK) brd_context_map(b, sd, nTreesD, M.cmapD, A, sLen, st);
+                                    const uint32_t sl = 64u * M.nTypes[0], sd = 4u * M.nTypes[2];
+                                    M.cmapL = brd_alloc_lds(A, sl + sd); M.cmapD = M.cmapL + sl;
+                                    if (M.cmapL == ~0u) st = BRD_LIMIT;
+                                    if (st == BRD_OK) brd_context_map(b, sl, M.nTrees[0], sArena + M.cmapL, A, sLen, st);
+                                    if (st == BRD_OK) brd_context_map(b, sd, M.nTrees[2], sArena + M.cmapD, A, sLen, st);
                                 }
                                 if (st == BRD_OK) {
-                                    const uint32_t nTreesI = BL[1].n;
-                                    M.TL = (BrdTree*)brd_alloc(A, (nTreesL + nTreesI + nTreesD) * (uint32_t)sizeof(BrdTree));
-                                    if (!M.TL) st = BRD_LIMIT;
+                                    const uint32_t d0 = brd_alloc_lds(A, (M.nTrees[0] + M.nTrees[1] + M.nTrees[2]) * 4u);
+                                    if (d0 == ~0u) st = BRD_LIMIT;
                                     else {
-                                        M.TI = M.TL + nTreesL; M.TD = M.TI + nTreesI;
-                                        // the command trees first: every command reads one, and what is allocated first stays in LDS
-                                        // (the stream's order is literals, commands, distances: the codes are READ in that order, so the arena is filled in it as well --
-                                        //  a meta-block whose literal trees alone overflow LDS keeps its first trees there)
-                                        for (uint32_t i = 0; i < nTreesL && st == BRD_OK; i++) brd_read_code(b, 256u, A, sLen, M.TL[i], st);
-                                        for (uint32_t i = 0; i < nTreesI && st == BRD_OK; i++) brd_read_code(b, 704u, A, sLen, M.TI[i], st);
-                                        const uint32_t alphaD = 16u + M.ndirect + (48u << M.npostfix);
-                                        for (uint32_t i = 0; i < nTreesD && st == BRD_OK; i++) brd_read_code(b, alphaD, A, sLen, M.TD[i], st);
+                                        M.dir[0] = d0; M.dir[1] = d0 + 4u * M.nTrees[0]; M.dir[2] = M.dir[1] + 4u * M.nTrees[1];
+                                        const uint32_t alpha[3] = { 256u, 704u, 16u + M.ndirect + (48u << M.npostfix) };
+                                        for (uint32_t k = 0; k < 3u && st == BRD_OK; k++) {
+                                            uint32_t* dir = (uint32_t*)(sArena + M.dir[k]);
+                                            for (uint32_t i = 0; i < M.nTrees[k] && st == BRD_OK; i++) dir[i] = brd_read_code(b, alpha[k], A, sLen, st);
+                                        }
                                     }
                                 }
-                                if (st != BRD_LIMIT || myPage) break;
+                                M.ldsUsed = A.ldsUsed;
+                                if (st != BRD_LIMIT || mem.hbm) break;
                                 // LDS does not hold this meta-block: take a page of the pool and read the header again
                                 const uint32_t pg = atomicAdd(pageCursor, 1u);
                                 if (pg >= nPages) break;
-                                myPage = pages + (uint64_t)pg * BRD_PAGE;
+                                mem.hbm = pages + (uint64_t)pg * BRD_PAGE;
+                            }
+                            // decoding tables in what the arena has left: literal codes first (one lookup per byte), then the command codes, then the distance codes
+                            if (st == BRD_OK) {
+                                uint32_t at = (M.ldsUsed + 7u) & ~7u;
+                                const uint32_t capT = ldsCap < ARENA ? ldsCap : ARENA;
+                                const uint32_t bytesOf[3] = { 512u, 2048u, 512u };
+                                for (uint32_t k = 0; k < 3u; k++) {
+                                    const uint32_t room = capT > at ? (capT - at) / bytesOf[k] : 0u;
+                                    M.tab[k] = at; M.nTab[k] = room < M.nTrees[k] ? room : M.nTrees[k];
+                                    at += M.nTab[k] * bytesOf[k];
+                                }
                             }
                         }
                     }
@@ -429,78 +506,88 @@ gc_brotli_dec_kernel(const uint8_t* __restrict__ src, const GcBrDecChunk* __rest
             gc_wave_sync_global();
             const uint32_t kind = sMeta.kind, mlen = sMeta.mlen;
             status = sMeta.status; last = sMeta.last != 0u;
-            b.acc = sMeta.acc; b.n = sMeta.n; b.pos = sMeta.pos; b.over = sMeta.over;
+            b.acc = sMeta.acc; b.n = sMeta.n; b.pos = sMeta.pos; b.over = sMeta.over; brd_prime(b);
             if (status != BRD_OK || kind == 3u) { gc_wave_sync(); break; }
             if (kind == 2u) { gc_wave_sync(); continue; }
             if (kind == 1u) {
                 const uint8_t* s = b.p + sMeta.srcAt;
-                for (uint32_t i = lane; i < mlen; i += 64u) out[pos + i] = s[i];
+                for (uint32_t i = lane; i < mlen; i += 64u) { const uint8_t v = s[i]; out[pos + i] = v; if (RING) sRing[(pos + i) & RMASK] = v; }
+                p2 = mlen > 1u ? s[mlen - 2u] : p1; p1 = s[mlen - 1u];
                 pos += mlen;
                 gc_wave_sync_global();
                 continue;
             }
+            // (the reader of the commands is a value of its own: the header code above hands its reader to functions, which pins that one to memory)
+            BrdBits hb; hb.p = src + ck.srcOff; hb.end = ck.srcSize; hb.acc = sMeta.acc; hb.n = sMeta.n; hb.pos = sMeta.pos; hb.over = sMeta.over; brd_prime(hb);
+            // ---- the page, if lane 0 took one: its address travels as the pool index
+            { uint64_t hp = (uint64_t)(uintptr_t)mem.hbm; hp = __shfl(hp, 0); mem.hbm = (uint8_t*)(uintptr_t)hp; }
+            // ---- decoding tables
+            const uint32_t nTabL = sMeta.nTab[0], nTabI = sMeta.nTab[1], nTabD = sMeta.nTab[2];
+            const uint16_t* const tabL = (const uint16_t*)(sArena + sMeta.tab[0]); const uint16_t* const tabI = (const uint16_t*)(sArena + sMeta.tab[1]); const uint16_t* const tabD = (const uint16_t*)(sArena + sMeta.tab[2]);
+            const uint32_t* const dirL = (const uint32_t*)(sArena + sMeta.dir[0]); const uint32_t* const dirI = (const uint32_t*)(sArena + sMeta.dir[1]); const uint32_t* const dirD = (const uint32_t*)(sArena + sMeta.dir[2]);
+            for (uint32_t i = 0; i < nTabL; i++) brd_table_w(mem, dirL[i], 8u, (uint16_t*)tabL + 256u * i, lane);
+            for (uint32_t i = 0; i < nTabI; i++) brd_table_w(mem, dirI[i], 10u, (uint16_t*)tabI + 1024u * i, lane);
+            for (uint32_t i = 0; i < nTabD; i++) brd_table_w(mem, dirD[i], 8u, (uint16_t*)tabD + 256u * i, lane);
             // ---- commands: every lane runs the same state machine
             BrdBlocks BL[3];
             for (uint32_t k = 0; k < 3u; k++) { BL[k].n = sMeta.nTypes[k]; BL[k].type = 0; BL[k].prev = 1; BL[k].left = sMeta.left[k]; BL[k].typeCode = sMeta.typeCode[k]; BL[k].countCode = sMeta.countCode[k]; }
             const uint32_t npostfix = sMeta.npostfix, ndirect = sMeta.ndirect;
-            const BrdTree* const TL = sMeta.TL; const BrdTree* const TI = sMeta.TI; const BrdTree* const TD = sMeta.TD;
-            const uint8_t* const cmapL = sMeta.cmapL; const uint8_t* const cmapD = sMeta.cmapD; const uint8_t* const modes = sMeta.modes;
-            gc_wave_sync();                                       // (sMeta is lane 0's to write again from here)
+            const uint8_t* const cmapL = sArena + sMeta.cmapL; const uint8_t* const cmapD = sArena + sMeta.cmapD; const uint8_t* const modes = sArena + sMeta.modes;
+            gc_wave_sync();                                       // (sMeta is lane 0's to write again from here; the tables are whole)
             const uint32_t mEnd = pos + mlen;
-            uint32_t p1 = pos ? out[pos - 1u] : 0u, p2 = pos > 1u ? out[pos - 2u] : 0u;
             uint32_t mode = modes[0];
             const uint8_t* cmRow = cmapL;
-            BrdTree tCmd = TI[0];
             while (pos < mEnd && status == BRD_OK) {
-                if (BL[1].left == 0u) { brd_switch_w(b, BL[1], lane); tCmd = TI[BL[1].type]; }
+                if (BL[1].left == 0u) brd_switch_w(hb, BL[1], mem, K, lane);
                 BL[1].left--;
-                const uint32_t cs = brd_sym_w(b, tCmd, lane);
+                const uint32_t ti = BL[1].type;
+                const uint32_t cs = brd_sym_t<10>(hb, tabI, nTabI, dirI, ti, mem, lane);
                 const uint32_t cell = cs >> 6;
                 if (cell > 10u) { status = BRD_CORRUPT; break; }
-                const uint32_t ic = kdCellIns[cell] + ((cs >> 3) & 7u), cc = kdCellCopy[cell] + (cs & 7u);
-                uint32_t ins = kdInsBase[ic] + brd_take(b, kdInsExtra[ic]);
-                const uint32_t cplen = kdCopyBase[cc] + brd_take(b, kdCopyExtra[cc]);
+                const uint32_t ic = K.cellIns[cell] + ((cs >> 3) & 7u), cc = K.cellCopy[cell] + (cs & 7u);
+                uint32_t ins = K.insBase[ic] + brd_take(hb, K.insExtra[ic]);
+                const uint32_t cplen = K.copyBase[cc] + brd_take(hb, K.copyExtra[cc]);
                 if (pos + ins > mEnd) { status = BRD_CORRUPT; break; }
                 for (; ins != 0u; ins--) {
-                    if (BL[0].left == 0u) { brd_switch_w(b, BL[0], lane); mode = modes[BL[0].type]; cmRow = cmapL + 64u * BL[0].type; }
+                    if (BL[0].left == 0u) { brd_switch_w(hb, BL[0], mem, K, lane); mode = modes[BL[0].type]; cmRow = cmapL + 64u * BL[0].type; }
                     BL[0].left--;
                     uint32_t ctx;
                     if (mode == 2u) ctx = sLut[p1] | sLut[256u + p2];
                     else if (mode == 0u) ctx = p1 & 63u;
                     else if (mode == 1u) ctx = p1 >> 2;
                     else ctx = (brd_signed(p1) << 3) | brd_signed(p2);
-                    const uint32_t lit = brd_sym_w(b, TL[cmRow[ctx]], lane);
-                    if (lane == 0u) out[pos] = (uint8_t)lit;
+                    const uint32_t tl = cmRow[ctx];
+                    const uint32_t lit = brd_sym_t<8>(hb, tabL, nTabL, dirL, tl, mem, lane);
+                    if (lane == 0u) { out[pos] = (uint8_t)lit; if (RING) sRing[pos & RMASK] = (uint8_t)lit; }
                     pos++; p2 = p1; p1 = lit;
                 }
-                if (b.over) { status = BRD_CORRUPT; break; }
+                if (hb.over) { status = BRD_CORRUPT; break; }
                 if (pos == mEnd) break;                           // the meta-block ends behind the literals: no copy
                 int dist;
                 uint32_t dcode = 0;
                 if (cs >= 128u) {
-                    if (BL[2].left == 0u) brd_switch_w(b, BL[2], lane);
+                    if (BL[2].left == 0u) brd_switch_w(hb, BL[2], mem, K, lane);
                     BL[2].left--;
                     const uint32_t dctx = cplen > 4u ? 3u : cplen - 2u;
-                    dcode = brd_sym_w(b, TD[cmapD[4u * BL[2].type + dctx]], lane);
+                    const uint32_t td = cmapD[4u * BL[2].type + dctx];
+                    dcode = brd_sym_t<8>(hb, tabD, nTabD, dirD, td, mem, lane);
                 }
                 const uint32_t maxDist = pos < maxBack ? pos : maxBack;
                 bool push = true;
                 if (dcode < 16u) {
-                    const int l1 = ring[(ringIdx + 3u) & 3u], l2 = ring[(ringIdx + 2u) & 3u], l3 = ring[(ringIdx + 1u) & 3u], l4 = ring[ringIdx & 3u];
-                    if (dcode == 0u) { dist = l1; push = false; }
-                    else if (dcode == 1u) dist = l2; else if (dcode == 2u) dist = l3; else if (dcode == 3u) dist = l4;
-                    else if (dcode < 10u) { const int d = (int)((dcode - 4u) >> 1) + 1; dist = l1 + (((dcode - 4u) & 1u) ? d : -d); }
-                    else { const int d = (int)((dcode - 10u) >> 1) + 1; dist = l2 + (((dcode - 10u) & 1u) ? d : -d); }
+                    if (dcode == 0u) { dist = r1; push = false; }
+                    else if (dcode == 1u) dist = r2; else if (dcode == 2u) dist = r3; else if (dcode == 3u) dist = r4;
+                    else if (dcode < 10u) { const int d = (int)((dcode - 4u) >> 1) + 1; dist = r1 + (((dcode - 4u) & 1u) ? d : -d); }
+                    else { const int d = (int)((dcode - 10u) >> 1) + 1; dist = r2 + (((dcode - 10u) & 1u) ? d : -d); }
                     if (dist <= 0) { status = BRD_CORRUPT; break; }
                 } else if (dcode < 16u + ndirect) dist = (int)(dcode - 15u);
                 else {
                     const uint32_t v = dcode - ndirect - 16u, hcode = v >> npostfix, lcode = v & ((1u << npostfix) - 1u), nb = 1u + (hcode >> 1);
                     const uint32_t off = ((2u + (hcode & 1u)) << nb) - 4u;
-                    dist = (int)(((off + brd_take(b, nb)) << npostfix) + lcode + ndirect + 1u);
+                    dist = (int)(((off + brd_take(hb, nb)) << npostfix) + lcode + ndirect + 1u);
                     if (dist <= 0) { status = BRD_CORRUPT; break; }
                 }
-                if (b.over) { status = BRD_CORRUPT; break; }
-                gc_wave_sync_global();                            // lane 0's literals, for the lanes that copy
+                if (hb.over) { status = BRD_CORRUPT; break; }
                 if ((uint32_t)dist > maxDist) {
                     // ---- static dictionary reference (RFC 7932 section 8): the word of `cplen` bytes with one of the 121 transforms; it does not enter the ring
                     if (cplen < 4u || cplen > 24u) { status = BRD_CORRUPT; break; }
@@ -534,32 +621,52 @@ gc_brotli_dec_kernel(const uint8_t* __restrict__ src, const GcBrDecChunk* __rest
                         }
                         for (uint32_t i = 0; i < suf[0]; i++) *o++ = suf[1u + i];
                     }
-                    pos += total;
                     gc_wave_sync_global();
-                    p1 = out[pos - 1u]; p2 = pos > 1u ? out[pos - 2u] : 0u;
+                    if (total) {
+                        if (RING) for (uint32_t i = lane; i < total; i += 64u) sRing[(pos + i) & RMASK] = out[pos + i];
+                        p2 = total > 1u ? out[pos + total - 2u] : p1; p1 = out[pos + total - 1u];
+                    }
+                    pos += total;
+                    gc_wave_sync();
                     continue;
                 }
-                if (push) { ring[ringIdx & 3u] = dist; ringIdx++; }
+                if (push) { r4 = r3; r3 = r2; r2 = r1; r1 = dist; }
                 if (pos + cplen > mEnd) { status = BRD_CORRUPT; break; }
                 {
                     const uint32_t d = (uint32_t)dist;
-                    uint8_t* const o = out + pos; const uint8_t* const s = o - d;
-                    if (d >= cplen) { for (uint32_t i = lane; i < cplen; i += 64u) o[i] = s[i]; }
-                    else if (d == 1u) { const uint8_t v = s[0]; for (uint32_t i = lane; i < cplen; i += 64u) o[i] = v; }
-                    else { for (uint32_t i = lane; i < cplen; i += 64u) o[i] = s[i % d]; }
+                    uint32_t v = 0;                               // the byte of this lane's last turn
+                    if (RING && d + cplen + 64u <= RING) {
+                        // distance + length + 64 <= RING: no slot this copy writes holds a byte it still reads, in whatever order the lanes run
+                        gc_wave_sync();                           // lane 0's literals in the ring
+                        for (uint32_t i = lane; i < cplen; i += 64u) { v = sRing[(pos - d + (d < cplen ? i % d : i)) & RMASK]; out[pos + i] = (uint8_t)v; sRing[(pos + i) & RMASK] = (uint8_t)v; }
+                    } else {
+                        gc_wave_sync_global();                    // lane 0's literals in the output
+                        uint8_t* const o = out + pos; const uint8_t* const s = o - d;
+                        if (d >= cplen) { for (uint32_t i = lane; i < cplen; i += 64u) { v = s[i]; o[i] = (uint8_t)v; if (RING) sRing[(pos + i) & RMASK] = (uint8_t)v; } }
+                        else { for (uint32_t i = lane; i < cplen; i += 64u) { v = s[i % d]; o[i] = (uint8_t)v; if (RING) sRing[(pos + i) & RMASK] = (uint8_t)v; } }
+                    }
+                    p1 = __shfl(v, (int)((cplen - 1u) & 63u)); p2 = __shfl(v, (int)((cplen - 2u) & 63u));
                 }
                 pos += cplen;
-                gc_wave_sync_global();
-                p1 = out[pos - 1u]; p2 = out[pos - 2u];
+                gc_wave_sync();
             }
+            b.acc = hb.acc; b.n = hb.n; b.pos = hb.pos; b.over = hb.over; b.next = hb.next;
             if (b.over && status == BRD_OK) status = BRD_CORRUPT;
             gc_wave_sync_global();
         }
         if (status == BRD_OK && brd_consumed(b) > ck.srcSize) status = BRD_CORRUPT;
         if (lane == 0u) { GcBrDecResult r; r.size = pos; r.status = status; result[c] = r; }
-        gc_wave_sync();
+        gc_wave_sync_global();
     }
 }
+#define BRD_INSTANCE(NAME, ARENA, RING) \
+extern "C" __global__ void __launch_bounds__(64) NAME(const uint8_t* __restrict__ src, const GcBrDecChunk* __restrict__ chunks, uint32_t nChunks, uint8_t* __restrict__ stage, \
+    uint8_t* __restrict__ pages, uint32_t nPages, uint32_t* __restrict__ pageCursor, GcBrDecResult* __restrict__ result, GcBrDict dict, uint32_t ldsCap) \
+{ brd_kernel_body<ARENA, RING>(src, chunks, nChunks, stage, pages, nPages, pageCursor, result, dict, ldsCap); }
+BRD_INSTANCE(gc_brotli_dec_kernel_a, 81920u, 65536u)      // up to 256 chunks: a CU's LDS per wave
+BRD_INSTANCE(gc_brotli_dec_kernel_b, 45056u, 32768u)      // up to 512: two waves per CU
+BRD_INSTANCE(gc_brotli_dec_kernel_c, 20480u, 16384u)      // up to 1024: four
+BRD_INSTANCE(gc_brotli_dec_kernel_d, 18432u, 0u)          // more: seven, no ring
 
 // sizes -> offsets (one workgroup), then the packed copy (a workgroup per 64 KiB of a chunk)
 extern "C" __global__ void __launch_bounds__(1024)
@@ -708,8 +815,13 @@ int gc_brd_decode(hipStream_t st, GcBrDecWork* w, const uint8_t* d_src, const gc
         GcBrDict dict; dict.words = gBrDict ? w->dict : nullptr;
         const uint32_t grid = (uint32_t)(nChunks < BRD_MAX_WAVES ? nChunks : BRD_MAX_WAVES);
         hipEventRecord((hipEvent_t)w->ev0, st);
-        GC_LAUNCH(gc_brotli_dec_kernel, grid, 64, st, d_src, (const GcBrDecChunk*)(w->meta + oChunks), (uint32_t)nChunks, w->stage, w->pages, w->nPages, (uint32_t*)(w->meta + oCur),
-                  (GcBrDecResult*)(w->meta + oRes), dict, w->ldsCap && w->ldsCap < BRD_LDS_ARENA ? w->ldsCap : BRD_LDS_ARENA);
+        const GcBrDecChunk* dc = (const GcBrDecChunk*)(w->meta + oChunks); uint32_t* cur = (uint32_t*)(w->meta + oCur); GcBrDecResult* res = (GcBrDecResult*)(w->meta + oRes);
+        const uint32_t inst = w->instance ? w->instance : (nChunks <= 256u ? 1u : (nChunks <= 512u ? 2u : (nChunks <= 1024u ? 3u : 4u)));
+        const uint32_t lc = w->ldsCap ? w->ldsCap : ~0u;
+        if (inst == 1u) GC_LAUNCH(gc_brotli_dec_kernel_a, grid, 64, st, d_src, dc, (uint32_t)nChunks, w->stage, w->pages, w->nPages, cur, res, dict, lc);
+        else if (inst == 2u) GC_LAUNCH(gc_brotli_dec_kernel_b, grid, 64, st, d_src, dc, (uint32_t)nChunks, w->stage, w->pages, w->nPages, cur, res, dict, lc);
+        else if (inst == 3u) GC_LAUNCH(gc_brotli_dec_kernel_c, grid, 64, st, d_src, dc, (uint32_t)nChunks, w->stage, w->pages, w->nPages, cur, res, dict, lc);
+        else GC_LAUNCH(gc_brotli_dec_kernel_d, grid, 64, st, d_src, dc, (uint32_t)nChunks, w->stage, w->pages, w->nPages, cur, res, dict, lc);
         GC_LAUNCH(gc_brotli_dec_plan_kernel, 1, 1024, st, (const GcBrDecResult*)(w->meta + oRes), (uint32_t)nChunks, (uint64_t)dstCap, (uint64_t*)(w->meta + oOffs), (uint64_t*)(w->meta + oTot));
         const uint32_t pieces = (maxHint + 65535u) >> 16;
         if (pieces) GC_LAUNCH(gc_brotli_dec_pack_kernel, (uint32_t)nChunks * pieces, 256, st, w->stage, (const GcBrDecChunk*)(w->meta + oChunks), (const GcBrDecResult*)(w->meta + oRes),

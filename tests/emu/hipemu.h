@@ -26,6 +26,7 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
+#define __noinline__ __attribute__((noinline))
 #define __launch_bounds__(...)
 // `__shared__`: a static in a section of its own, so that the launcher can fill ALL of it with garbage before every workgroup (GC_EMU_POISON_LDS=<seed>): on the
 // device a workgroup's LDS holds whatever the workgroups before it left there, a plain static would hold the previous workgroup's values of the SAME variable

@@ -129,7 +129,7 @@ def test_emu_reference_streams(O, emu_dec, kind, q, n):
 def test_emu_meta_blocks_that_outgrow_lds_take_hbm_pages(O, emu_dec, monkeypatch):
     """A meta-block with more prefix codes than the wave's LDS arena holds (the reference's qualities 10-11 write up to 256 literal and distance trees) has its header read again
     with a page of HBM behind the arena.  The hook shrinks the arena so that small inputs get there; 70 chunks that all need a page outgrow the first pool of 64 (second round)."""
-    monkeypatch.setenv("GC_BRD_LDS", "1536")
+    monkeypatch.setenv("GC_BRD_LDS", "3072")                     # (context maps, modes and directories stay in LDS: they are read per symbol)
     x = np.concatenate([O.corpus(k, 130_000) for k in ("silesia-like", "real-src", "lz-7zip", "web-text")])
     _check(emu_dec, O.ref_brotlimt_compress(x, 11, 1), x)
     y = O.corpus("text-zipf", 70 * 6000)
