@@ -68,11 +68,11 @@ struct BrdBits {                      // LSB-first bit reader over the chunk's b
     const uint8_t* p; uint64_t acc; uint32_t n; uint32_t pos, end; uint32_t over; uint32_t next;
 };
 __device__ __forceinline__ uint32_t brd_load32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
-__device__ __forceinline__ void brd_prime(BrdBits& b) { b.next = b.pos + 4u <= b.end ? brd_load32(b.p + b.pos) : 0u; }      // after pos has been set
+__device__ __forceinline__ void brd_prime(BrdBits& b) { b.next = b.pos + 4u <= b.end ? gc_uniform(brd_load32(b.p + b.pos)) : 0u; }      // after pos has been set
 __device__ __forceinline__ void brd_fill(BrdBits& b)               // afterwards n >= 33
 {
     if (b.pos + 4u <= b.end) { b.acc |= (uint64_t)b.next << b.n; b.n += 32u; b.pos += 4u; brd_prime(b); return; }
-    while (b.n <= 56u) { const uint64_t v = b.pos < b.end ? b.p[b.pos] : 0ull; if (b.pos >= b.end + 16u) b.over = 1u; b.acc |= v << b.n; b.n += 8u; b.pos++; }
+    while (b.n <= 56u) { const uint64_t v = b.pos < b.end ? gc_uniform(b.p[b.pos]) : 0u; if (b.pos >= b.end + 16u) b.over = 1u; b.acc |= v << b.n; b.n += 8u; b.pos++; }
 }
 __device__ __forceinline__ uint32_t brd_take(BrdBits& b, uint32_t k)      // k <= 32
 {
@@ -118,7 +118,8 @@ __device__ __noinline__ uint32_t brd_sym(BrdBits& b, const BrdMem m, uint32_t h)
 // the wave together: lane l tests whether the next l bits are a code of length l (canonical codes: one length answers); every lane gets the symbol
 __device__ __forceinline__ uint32_t brd_sym_w(BrdBits& b, const BrdMem& m, uint32_t h, uint32_t lane)
 {
-    if (brd_t(m, h, 0)) return brd_symbol(m, h, 0);
+    h = gc_uniform(h);
+    if (gc_uniform(brd_t(m, h, 0))) return gc_uniform(brd_symbol(m, h, 0));
     if (b.n <= 32u) brd_fill(b);
     const uint32_t rev = __brev((uint32_t)b.acc), l = lane & 15u;
     const uint32_t c = l ? rev >> (32u - l) : 0u;
@@ -126,9 +127,9 @@ __device__ __forceinline__ uint32_t brd_sym_w(BrdBits& b, const BrdMem& m, uint3
     const uint64_t mk = __ballot(hit) & 0xFFFEull;
     if (mk == 0ull) { b.over = 1u; return 0; }
     const uint32_t len = (uint32_t)__ffsll((long long)mk) - 1u;
-    const uint32_t i = brd_t(m, h, 32u + len) + (rev >> (32u - len)) - brd_t(m, h, 16u + len);
+    const uint32_t i = gc_uniform(brd_t(m, h, 32u + len) + (rev >> (32u - len)) - brd_t(m, h, 16u + len));
     b.acc >>= len; b.n -= len;
-    return brd_symbol(m, h, i);
+    return gc_uniform(brd_symbol(m, h, i));
 }
 // ... through a table of 2^BITS entries in LDS (0x8000 | symbol << 4 | length; 0: the code is longer than BITS, the wave decodes it)
 template <uint32_t BITS>
@@ -136,7 +137,7 @@ __device__ __forceinline__ uint32_t brd_sym_t(BrdBits& b, const uint16_t* tabs, 
 {
     if (tree < nTab) {
         if (b.n <= 32u) brd_fill(b);
-        const uint32_t e = tabs[(tree << BITS) + ((uint32_t)b.acc & ((1u << BITS) - 1u))];
+        const uint32_t e = gc_uniform(tabs[(tree << BITS) + ((uint32_t)b.acc & ((1u << BITS) - 1u))]);
         if (e & 0x8000u) { const uint32_t len = e & 15u; b.acc >>= len; b.n -= len; return (e >> 4) & 0x7FFu; }
     }
     return brd_sym_w(b, m, dir[tree], lane);
@@ -330,7 +331,7 @@ __device__ __forceinline__ void brd_switch_w(BrdBits& b, BrdBlocks& B, const Brd
     if (t >= B.n) t -= B.n;
     B.prev = B.type; B.type = t;
     const uint32_t cs = brd_sym_w(b, m, B.countCode, lane);
-    B.left = cs < 26u ? K.blockBase[cs] + brd_take(b, K.blockExtra[cs]) : 0u;
+    B.left = cs < 26u ? gc_uniform(K.blockBase[cs]) + brd_take(b, gc_uniform(K.blockExtra[cs])) : 0u;
 }
 
 // context map (RFC 7932 section 7.3): `size` entries in out[].  One lane.
@@ -372,6 +373,23 @@ struct BrdMeta {
     uint32_t ldsUsed;
 };
 
+// The output goes to the ring first and to HBM in bursts: a byte store per literal keeps the wave's memory counter busy (every wait for the bit reader's next word then
+// also waits for the stores in front of it).  flush: bytes [from, upto) of the output from the ring to HBM, 16 bytes per lane where the position is aligned.
+template <uint32_t RING>
+__device__ __forceinline__ void brd_flush(const uint8_t* ring, uint8_t* __restrict__ out, uint32_t from, uint32_t upto, uint32_t lane)
+{
+    constexpr uint32_t RMASK = RING - 1u;
+    uint32_t a = from;
+    const uint32_t head = (16u - (a & 15u)) & 15u, h = head < upto - a ? head : upto - a;
+    if (lane < h) out[a + lane] = ring[(a + lane) & RMASK];
+    a += h;
+    const uint32_t n16 = (upto - a) >> 4;
+    struct alignas(16) V16 { uint64_t x, y; };
+    for (uint32_t k = lane; k < n16; k += 64u) *(V16*)(out + a + 16u * k) = *(const V16*)(ring + ((a + 16u * k) & RMASK));
+    a += n16 << 4;
+    if (lane < upto - a) out[a + lane] = ring[(a + lane) & RMASK];
+}
+
 // ------------------------------------------------------------------------------------------------ one wave per chunk
 // ARENA: bytes of LDS for a meta-block's codes, maps and decoding tables; RING: the last RING bytes of output, so that near copies read LDS (0: none).  The host picks the
 // instance by the number of chunks: few chunks get the LDS of a whole CU each.
@@ -380,13 +398,14 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
                                                 uint8_t* __restrict__ pages, uint32_t nPages, uint32_t* __restrict__ pageCursor, GcBrDecResult* __restrict__ result, GcBrDict dict, uint32_t ldsCap)
 {
     __shared__ __attribute__((aligned(8))) uint8_t sArena[ARENA];
-    __shared__ uint8_t sRing[RING ? RING : 8u];
+    __shared__ __attribute__((aligned(16))) uint8_t sRing[RING];
+    static_assert(RING >= 4096u && (RING & (RING - 1u)) == 0u, "the ring holds the output before it goes to HBM");
     __shared__ uint8_t sLut[512];                                 // UTF8 context ids (mode 2), the mode of every stream this engine writes and of nearly every one of the reference
     __shared__ uint8_t sLen[704];
     __shared__ BrdMeta sMeta;
     __shared__ BrdConst sK;
     const uint32_t lane = threadIdx.x;
-    constexpr uint32_t RMASK = RING ? RING - 1u : 0u;
+    constexpr uint32_t RMASK = RING - 1u;
     for (uint32_t i = lane; i < 256u; i += 64u) { sLut[i] = (uint8_t)brd_utf8_0(i); sLut[256u + i] = (uint8_t)brd_utf8_1(i); }
     if (lane < 24u) { sK.insBase[lane] = kdInsBase[lane]; sK.copyBase[lane] = kdCopyBase[lane]; sK.insExtra[lane] = kdInsExtra[lane]; sK.copyExtra[lane] = kdCopyExtra[lane]; }
     if (lane < 26u) { sK.blockBase[lane] = kdBlockBase[lane]; sK.blockExtra[lane] = kdBlockExtra[lane]; }
@@ -398,7 +417,8 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
         uint8_t* const out = stage + ck.stageOff;
         const uint32_t cap = ck.hintBytes;
         BrdMem mem; mem.lds = sArena; mem.hbm = nullptr;          // (the page is taken from the pool when a meta-block needs it, kept for the chunk)
-        uint32_t status = BRD_OK, pos = 0;
+        uint32_t status = BRD_OK, pos = 0, flushed = 0;             // output [flushed, pos) is in the ring only
+        bool unfenced = false;                                    // a flush has stored to HBM since the wave last waited for its stores
         BrdBits b; b.p = src + ck.srcOff; b.acc = 0; b.n = 0; b.pos = 0; b.end = ck.srcSize; b.over = 0u; brd_prime(b);
         // stream header: WBITS (RFC 7932 section 9.1)
         uint32_t wbits = 16;
@@ -504,25 +524,27 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
                 sMeta = M;
             }
             gc_wave_sync_global();
-            const uint32_t kind = sMeta.kind, mlen = sMeta.mlen;
-            status = sMeta.status; last = sMeta.last != 0u;
+            const uint32_t kind = gc_uniform(sMeta.kind), mlen = gc_uniform(sMeta.mlen);
+            status = gc_uniform(sMeta.status); last = gc_uniform(sMeta.last) != 0u;
             b.acc = sMeta.acc; b.n = sMeta.n; b.pos = sMeta.pos; b.over = sMeta.over; brd_prime(b);
             if (status != BRD_OK || kind == 3u) { gc_wave_sync(); break; }
             if (kind == 2u) { gc_wave_sync(); continue; }
             if (kind == 1u) {
-                const uint8_t* s = b.p + sMeta.srcAt;
-                for (uint32_t i = lane; i < mlen; i += 64u) { const uint8_t v = s[i]; out[pos + i] = v; if (RING) sRing[(pos + i) & RMASK] = v; }
-                p2 = mlen > 1u ? s[mlen - 2u] : p1; p1 = s[mlen - 1u];
-                pos += mlen;
-                gc_wave_sync_global();
+                const uint8_t* s = src + ck.srcOff + gc_uniform(sMeta.srcAt);
+                gc_wave_sync();
+                brd_flush<RING>(sRing, out, flushed, pos, lane);
+                for (uint32_t i = lane; i < mlen; i += 64u) { const uint8_t v = s[i]; out[pos + i] = v; sRing[(pos + i) & RMASK] = v; }
+                p2 = mlen > 1u ? gc_uniform(s[mlen - 2u]) : p1; p1 = gc_uniform(s[mlen - 1u]);
+                pos += mlen; flushed = pos;
+                gc_wave_sync();
                 continue;
             }
             // (the reader of the commands is a value of its own: the header code above hands its reader to functions, which pins that one to memory)
-            BrdBits hb; hb.p = src + ck.srcOff; hb.end = ck.srcSize; hb.acc = sMeta.acc; hb.n = sMeta.n; hb.pos = sMeta.pos; hb.over = sMeta.over; brd_prime(hb);
+            BrdBits hb; hb.p = src + ck.srcOff; hb.end = ck.srcSize; { const uint64_t a = sMeta.acc; hb.acc = (uint64_t)gc_uniform((uint32_t)a) | ((uint64_t)gc_uniform((uint32_t)(a >> 32)) << 32); } hb.n = gc_uniform(sMeta.n); hb.pos = gc_uniform(sMeta.pos); hb.over = gc_uniform(sMeta.over); brd_prime(hb);
             // ---- the page, if lane 0 took one: its address travels as the pool index
             { uint64_t hp = (uint64_t)(uintptr_t)mem.hbm; hp = __shfl(hp, 0); mem.hbm = (uint8_t*)(uintptr_t)hp; }
             // ---- decoding tables
-            const uint32_t nTabL = sMeta.nTab[0], nTabI = sMeta.nTab[1], nTabD = sMeta.nTab[2];
+            const uint32_t nTabL = gc_uniform(sMeta.nTab[0]), nTabI = gc_uniform(sMeta.nTab[1]), nTabD = gc_uniform(sMeta.nTab[2]);
             const uint16_t* const tabL = (const uint16_t*)(sArena + sMeta.tab[0]); const uint16_t* const tabI = (const uint16_t*)(sArena + sMeta.tab[1]); const uint16_t* const tabD = (const uint16_t*)(sArena + sMeta.tab[2]);
             const uint32_t* const dirL = (const uint32_t*)(sArena + sMeta.dir[0]); const uint32_t* const dirI = (const uint32_t*)(sArena + sMeta.dir[1]); const uint32_t* const dirD = (const uint32_t*)(sArena + sMeta.dir[2]);
             for (uint32_t i = 0; i < nTabL; i++) brd_table_w(mem, dirL[i], 8u, (uint16_t*)tabL + 256u * i, lane);
@@ -530,12 +552,12 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
             for (uint32_t i = 0; i < nTabD; i++) brd_table_w(mem, dirD[i], 8u, (uint16_t*)tabD + 256u * i, lane);
             // ---- commands: every lane runs the same state machine
             BrdBlocks BL[3];
-            for (uint32_t k = 0; k < 3u; k++) { BL[k].n = sMeta.nTypes[k]; BL[k].type = 0; BL[k].prev = 1; BL[k].left = sMeta.left[k]; BL[k].typeCode = sMeta.typeCode[k]; BL[k].countCode = sMeta.countCode[k]; }
-            const uint32_t npostfix = sMeta.npostfix, ndirect = sMeta.ndirect;
+            for (uint32_t k = 0; k < 3u; k++) { BL[k].n = gc_uniform(sMeta.nTypes[k]); BL[k].type = 0; BL[k].prev = 1; BL[k].left = gc_uniform(sMeta.left[k]); BL[k].typeCode = gc_uniform(sMeta.typeCode[k]); BL[k].countCode = gc_uniform(sMeta.countCode[k]); }
+            const uint32_t npostfix = gc_uniform(sMeta.npostfix), ndirect = gc_uniform(sMeta.ndirect);
             const uint8_t* const cmapL = sArena + sMeta.cmapL; const uint8_t* const cmapD = sArena + sMeta.cmapD; const uint8_t* const modes = sArena + sMeta.modes;
             gc_wave_sync();                                       // (sMeta is lane 0's to write again from here; the tables are whole)
             const uint32_t mEnd = pos + mlen;
-            uint32_t mode = modes[0];
+            uint32_t mode = gc_uniform(modes[0]);
             const uint8_t* cmRow = cmapL;
             while (pos < mEnd && status == BRD_OK) {
                 if (BL[1].left == 0u) brd_switch_w(hb, BL[1], mem, K, lane);
@@ -544,21 +566,22 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
                 const uint32_t cs = brd_sym_t<10>(hb, tabI, nTabI, dirI, ti, mem, lane);
                 const uint32_t cell = cs >> 6;
                 if (cell > 10u) { status = BRD_CORRUPT; break; }
-                const uint32_t ic = K.cellIns[cell] + ((cs >> 3) & 7u), cc = K.cellCopy[cell] + (cs & 7u);
-                uint32_t ins = K.insBase[ic] + brd_take(hb, K.insExtra[ic]);
-                const uint32_t cplen = K.copyBase[cc] + brd_take(hb, K.copyExtra[cc]);
+                const uint32_t ic = gc_uniform(K.cellIns[cell]) + ((cs >> 3) & 7u), cc = gc_uniform(K.cellCopy[cell]) + (cs & 7u);
+                uint32_t ins = gc_uniform(K.insBase[ic]) + brd_take(hb, gc_uniform(K.insExtra[ic]));
+                const uint32_t cplen = gc_uniform(K.copyBase[cc]) + brd_take(hb, gc_uniform(K.copyExtra[cc]));
                 if (pos + ins > mEnd) { status = BRD_CORRUPT; break; }
                 for (; ins != 0u; ins--) {
-                    if (BL[0].left == 0u) { brd_switch_w(hb, BL[0], mem, K, lane); mode = modes[BL[0].type]; cmRow = cmapL + 64u * BL[0].type; }
+                    if (BL[0].left == 0u) { brd_switch_w(hb, BL[0], mem, K, lane); mode = gc_uniform(modes[BL[0].type]); cmRow = cmapL + 64u * BL[0].type; }
                     BL[0].left--;
                     uint32_t ctx;
-                    if (mode == 2u) ctx = sLut[p1] | sLut[256u + p2];
+                    if (mode == 2u) ctx = gc_uniform(sLut[p1] | sLut[256u + p2]);
                     else if (mode == 0u) ctx = p1 & 63u;
                     else if (mode == 1u) ctx = p1 >> 2;
                     else ctx = (brd_signed(p1) << 3) | brd_signed(p2);
-                    const uint32_t tl = cmRow[ctx];
+                    const uint32_t tl = gc_uniform(cmRow[ctx]);
                     const uint32_t lit = brd_sym_t<8>(hb, tabL, nTabL, dirL, tl, mem, lane);
-                    if (lane == 0u) { out[pos] = (uint8_t)lit; if (RING) sRing[pos & RMASK] = (uint8_t)lit; }
+                    if (pos - flushed >= RING - 64u) { gc_wave_sync(); brd_flush<RING>(sRing, out, flushed, pos, lane); flushed = pos; unfenced = true; gc_wave_sync(); }
+                    if (lane == 0u) sRing[pos & RMASK] = (uint8_t)lit;
                     pos++; p2 = p1; p1 = lit;
                 }
                 if (hb.over) { status = BRD_CORRUPT; break; }
@@ -569,7 +592,7 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
                     if (BL[2].left == 0u) brd_switch_w(hb, BL[2], mem, K, lane);
                     BL[2].left--;
                     const uint32_t dctx = cplen > 4u ? 3u : cplen - 2u;
-                    const uint32_t td = cmapD[4u * BL[2].type + dctx];
+                    const uint32_t td = gc_uniform(cmapD[4u * BL[2].type + dctx]);
                     dcode = brd_sym_t<8>(hb, tabD, nTabD, dirD, td, mem, lane);
                 }
                 const uint32_t maxDist = pos < maxBack ? pos : maxBack;
@@ -603,29 +626,28 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
                     else if (type >= 1u && type <= 9u) wl = wl > type ? wl - type : 0u;                        // omit the last n
                     const uint32_t body = wl - skip, total = pre[0] + body + suf[0];
                     if (pos + total > mEnd) { status = BRD_CORRUPT; break; }
+                    if (pos - flushed + total + 64u > RING) { gc_wave_sync(); brd_flush<RING>(sRing, out, flushed, pos, lane); flushed = pos; unfenced = true; gc_wave_sync(); }
                     if (lane == 0u) {
-                        uint8_t* o = out + pos;
-                        for (uint32_t i = 0; i < pre[0]; i++) *o++ = pre[1u + i];
-                        uint8_t* const w0 = o;
-                        for (uint32_t i = skip; i < wl; i++) *o++ = w[i];
+                        uint8_t word[40]; uint32_t o = 0;         // (prefix <= 8, word <= 24, suffix <= 8 bytes: RFC 7932 Appendix B)
+                        for (uint32_t i = 0; i < pre[0]; i++) word[o++] = pre[1u + i];
+                        const uint32_t w0 = o;
+                        for (uint32_t i = skip; i < wl; i++) word[o++] = w[i];
                         if (type == 10u || type == 11u) {         // uppercase the first / every character (UTF-8 aware as the RFC defines it)
-                            uint8_t* q = w0;
+                            uint32_t q = w0;
                             while (q < o) {
                                 uint32_t step;
-                                if (q[0] < 192u) { if (q[0] >= 'a' && q[0] <= 'z') q[0] ^= 32u; step = 1; }
-                                else if (q[0] < 224u) { if (q + 1 < o) q[1] ^= 32u; step = 2; }
-                                else { if (q + 2 < o) q[2] ^= 5u; step = 3; }
+                                if (word[q] < 192u) { if (word[q] >= 'a' && word[q] <= 'z') word[q] ^= 32u; step = 1; }
+                                else if (word[q] < 224u) { if (q + 1u < o) word[q + 1u] ^= 32u; step = 2; }
+                                else { if (q + 2u < o) word[q + 2u] ^= 5u; step = 3; }
                                 if (type == 10u) break;
                                 q += step;
                             }
                         }
-                        for (uint32_t i = 0; i < suf[0]; i++) *o++ = suf[1u + i];
+                        for (uint32_t i = 0; i < suf[0]; i++) word[o++] = suf[1u + i];
+                        for (uint32_t i = 0; i < o; i++) sRing[(pos + i) & RMASK] = word[i];
                     }
-                    gc_wave_sync_global();
-                    if (total) {
-                        if (RING) for (uint32_t i = lane; i < total; i += 64u) sRing[(pos + i) & RMASK] = out[pos + i];
-                        p2 = total > 1u ? out[pos + total - 2u] : p1; p1 = out[pos + total - 1u];
-                    }
+                    gc_wave_sync();
+                    if (total) { p2 = total > 1u ? gc_uniform(sRing[(pos + total - 2u) & RMASK]) : p1; p1 = gc_uniform(sRing[(pos + total - 1u) & RMASK]); }
                     pos += total;
                     gc_wave_sync();
                     continue;
@@ -635,17 +657,27 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
                 {
                     const uint32_t d = (uint32_t)dist;
                     uint32_t v = 0;                               // the byte of this lane's last turn
-                    if (RING && d + cplen + 64u <= RING) {
-                        // distance + length + 64 <= RING: no slot this copy writes holds a byte it still reads, in whatever order the lanes run
-                        gc_wave_sync();                           // lane 0's literals in the ring
-                        for (uint32_t i = lane; i < cplen; i += 64u) { v = sRing[(pos - d + (d < cplen ? i % d : i)) & RMASK]; out[pos + i] = (uint8_t)v; sRing[(pos + i) & RMASK] = (uint8_t)v; }
-                    } else {
-                        gc_wave_sync_global();                    // lane 0's literals in the output
+                    gc_wave_sync();                               // lane 0's literals in the ring
+                    // (gc_wave_step: the hardware runs a wave's LDS operations in program order; the emulator's lanes must not write the ring before the others have read it)
+                    if (pos - flushed + cplen + 64u > RING) { brd_flush<RING>(sRing, out, flushed, pos, lane); flushed = pos; unfenced = true; gc_wave_step(); }
+                    if (cplen + 64u > RING / 2u) {
+                        // a copy the ring does not take beside what it holds: HBM to HBM (everything in front of it is there now), the ring follows
+                        if (flushed != pos) { brd_flush<RING>(sRing, out, flushed, pos, lane); flushed = pos; }
+                        gc_wave_sync_global(); unfenced = false;
                         uint8_t* const o = out + pos; const uint8_t* const s = o - d;
-                        if (d >= cplen) { for (uint32_t i = lane; i < cplen; i += 64u) { v = s[i]; o[i] = (uint8_t)v; if (RING) sRing[(pos + i) & RMASK] = (uint8_t)v; } }
-                        else { for (uint32_t i = lane; i < cplen; i += 64u) { v = s[i % d]; o[i] = (uint8_t)v; if (RING) sRing[(pos + i) & RMASK] = (uint8_t)v; } }
+                        for (uint32_t i = lane; i < cplen; i += 64u) { v = s[d < cplen ? i % d : i]; o[i] = (uint8_t)v; sRing[(pos + i) & RMASK] = (uint8_t)v; }
+                        flushed = pos + cplen;
+                    } else if (d + cplen + 64u <= RING) {
+                        // near: distance + length + 64 <= RING, so no slot this copy writes holds a byte it still reads, in whatever order the lanes run
+                        for (uint32_t i = lane; i < cplen; i += 64u) { v = sRing[(pos - d + (d < cplen ? i % d : i)) & RMASK]; sRing[(pos + i) & RMASK] = (uint8_t)v; }
+                    } else {
+                        // far: the source is in HBM unless it reaches into what the ring has not handed over yet
+                        if (pos - d + cplen > flushed) { brd_flush<RING>(sRing, out, flushed, pos, lane); flushed = pos; unfenced = true; }
+                        if (unfenced) { gc_wave_sync_global(); unfenced = false; }
+                        const uint8_t* const s = out + pos - d;
+                        for (uint32_t i = lane; i < cplen; i += 64u) { v = s[d < cplen ? i % d : i]; sRing[(pos + i) & RMASK] = (uint8_t)v; }
                     }
-                    p1 = __shfl(v, (int)((cplen - 1u) & 63u)); p2 = __shfl(v, (int)((cplen - 2u) & 63u));
+                    p1 = gc_readlane(v, (cplen - 1u) & 63u); p2 = gc_readlane(v, (cplen - 2u) & 63u);
                 }
                 pos += cplen;
                 gc_wave_sync();
@@ -654,6 +686,8 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
             if (b.over && status == BRD_OK) status = BRD_CORRUPT;
             gc_wave_sync_global();
         }
+        gc_wave_sync();
+        brd_flush<RING>(sRing, out, flushed, pos, lane);
         if (status == BRD_OK && brd_consumed(b) > ck.srcSize) status = BRD_CORRUPT;
         if (lane == 0u) { GcBrDecResult r; r.size = pos; r.status = status; result[c] = r; }
         gc_wave_sync_global();
@@ -666,7 +700,7 @@ extern "C" __global__ void __launch_bounds__(64) NAME(const uint8_t* __restrict_
 BRD_INSTANCE(gc_brotli_dec_kernel_a, 81920u, 65536u)      // up to 256 chunks: a CU's LDS per wave
 BRD_INSTANCE(gc_brotli_dec_kernel_b, 45056u, 32768u)      // up to 512: two waves per CU
 BRD_INSTANCE(gc_brotli_dec_kernel_c, 20480u, 16384u)      // up to 1024: four
-BRD_INSTANCE(gc_brotli_dec_kernel_d, 18432u, 0u)          // more: seven, no ring
+BRD_INSTANCE(gc_brotli_dec_kernel_d, 14336u, 4096u)       // more: seven
 
 // sizes -> offsets (one workgroup), then the packed copy (a workgroup per 64 KiB of a chunk)
 extern "C" __global__ void __launch_bounds__(1024)

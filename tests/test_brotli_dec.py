@@ -138,6 +138,21 @@ def test_emu_meta_blocks_that_outgrow_lds_take_hbm_pages(O, emu_dec, monkeypatch
     _check(emu_dec, c, y)
 
 
+@pytest.mark.parametrize("instance", [1, 2, 3, 4])
+def test_emu_every_kernel_instance(O, emu_dec, monkeypatch, instance):
+    """The decoder has four instances of its kernel (LDS arena / output ring of 64, 32, 16, 4 KiB), chosen by the number of chunks; the hook forces one.  Inputs that take every
+    way a copy can go: near (out of the ring), far (out of HBM, behind what the ring has handed over), longer than half the ring (HBM to HBM), reaching into itself at every size
+    (runs of one byte, a period of 3 and of 70 000), literal runs longer than the ring (random bytes), the dictionary."""
+    monkeypatch.setenv("GC_BRD_INSTANCE", str(instance))
+    rng = np.random.default_rng(instance)
+    block = O.corpus("text-zipf", 70_000)
+    x = np.concatenate([O.corpus("real-src", 120_000), np.zeros(150_000, dtype=np.uint8), np.tile(np.frombuffer(b"abc", dtype=np.uint8), 30_000), block, block, block[:50_000],
+                        rng.integers(0, 256, size=80_000, dtype=np.uint8), O.corpus("lz-7zip", 150_000), block[10_000:30_000]])
+    for q in (1, 5, 9, 11):
+        _check(emu_dec, O.ref_brotlimt_compress(x, q, 1), x)
+    _check(emu_dec, O.ref_brotli_compress(x, 6, 16), x, capacity=x.size)        # a window of 64 KiB: every distance is near
+
+
 def test_emu_bare_streams_and_windows(O, emu_dec):
     x = O.corpus("text-zipf", 180_000)
     for q, lgwin in ((1, 10), (5, 16), (6, 22), (9, 24), (11, 18)):
