@@ -64,14 +64,37 @@ __constant__ uint8_t  kdClcOrder[18] = { 1, 2, 3, 4, 0, 5, 17, 6, 16, 7, 8, 9, 1
 __constant__ uint8_t  kdDictBits[25] = { 0,0,0,0,10,10,11,11,10,10,10,10,10,9,9,8,7,7,8,7,7,6,6,5,5 };
 __constant__ uint32_t kdDictOff[25] = { 0,0,0,0,0,4096,9216,21504,35840,44032,53248,63488,74752,87040,93696,100864,104704,106752,108928,113536,115968,118528,119872,121280,122016 };
 
-struct BrdBits {                      // LSB-first bit reader over the chunk's bytes; identical in every lane.  `next` = the four bytes at `pos`, loaded one refill ahead
-    const uint8_t* p; uint64_t acc; uint32_t n; uint32_t pos, end; uint32_t over; uint32_t next;
+struct BrdQuad { uint32_t x, y, z, w; };
+// LSB-first bit reader over the chunk's bytes; identical in every lane.  The stream arrives 16 bytes at a time: `q` (four words in scalar registers) feeds the accumulator, `pend`
+// (the 16 bytes behind them, a load in flight in vector registers) becomes q when q is empty and the next load is issued then -- four refills ahead, which covers a trip to HBM;
+// a word that is looked at the moment it is loaded (one refill ahead, `readfirstlane` on the spot) makes every refill wait for its load.
+struct BrdBits {
+    const uint8_t* p; uint64_t acc; uint32_t n; uint32_t pos, end; uint32_t over;      // pos: the next byte that enters acc
+    uint64_t qlo, qhi; uint32_t qn;                                                     // qn words at pos, pos + 4, ...
+    BrdQuad pend; uint32_t pendOk;                                                      // the 16 bytes at pos + 4 * qn
 };
-__device__ __forceinline__ uint32_t brd_load32(const uint8_t* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
-__device__ __forceinline__ void brd_prime(BrdBits& b) { b.next = b.pos + 4u <= b.end ? gc_uniform(brd_load32(b.p + b.pos)) : 0u; }      // after pos has been set
+__device__ __forceinline__ BrdQuad brd_load128(const uint8_t* p) { BrdQuad v; __builtin_memcpy(&v, p, 16); return v; }
+__device__ __forceinline__ void brd_next_quad(BrdBits& b)          // q is empty: pend -> q, the load behind it goes out
+{
+    if (!b.pendOk) return;
+    b.qlo = (uint64_t)gc_uniform(b.pend.x) | ((uint64_t)gc_uniform(b.pend.y) << 32); b.qhi = (uint64_t)gc_uniform(b.pend.z) | ((uint64_t)gc_uniform(b.pend.w) << 32); b.qn = 4u;
+    b.pendOk = b.pos + 32u <= b.end;
+    if (b.pendOk) b.pend = brd_load128(b.p + b.pos + 16u);
+}
+__device__ __forceinline__ void brd_prime(BrdBits& b)              // after pos has been set
+{
+    b.qn = 0u; b.qlo = 0; b.qhi = 0; b.pend.x = b.pend.y = b.pend.z = b.pend.w = 0u;
+    b.pendOk = b.pos + 16u <= b.end;
+    if (b.pendOk) { b.pend = brd_load128(b.p + b.pos); brd_next_quad(b); }
+}
 __device__ __forceinline__ void brd_fill(BrdBits& b)               // afterwards n >= 33
 {
-    if (b.pos + 4u <= b.end) { b.acc |= (uint64_t)b.next << b.n; b.n += 32u; b.pos += 4u; brd_prime(b); return; }
+    if (b.qn) {
+        b.acc |= (uint64_t)(uint32_t)b.qlo << b.n; b.n += 32u; b.pos += 4u;
+        b.qlo = (b.qlo >> 32) | (b.qhi << 32); b.qhi >>= 32; b.qn--;
+        if (b.qn == 0u) brd_next_quad(b);
+        return;
+    }
     while (b.n <= 56u) { const uint64_t v = b.pos < b.end ? gc_uniform(b.p[b.pos]) : 0u; if (b.pos >= b.end + 16u) b.over = 1u; b.acc |= v << b.n; b.n += 8u; b.pos++; }
 }
 __device__ __forceinline__ uint32_t brd_take(BrdBits& b, uint32_t k)      // k <= 32
@@ -102,7 +125,7 @@ __device__ __forceinline__ uint32_t brd_symbol(const BrdMem& m, uint32_t h, uint
     return (h & BRD_H_WIDE) ? ((const uint16_t*)s)[i] : s[i];
 }
 // one lane on its own (headers)
-__device__ __noinline__ uint32_t brd_sym(BrdBits& b, const BrdMem m, uint32_t h)
+__device__ __forceinline__ uint32_t brd_sym(BrdBits& b, const BrdMem& m, uint32_t h)
 {
     if (brd_t(m, h, 0)) return brd_symbol(m, h, 0);
     if (b.n <= 32u) brd_fill(b);
@@ -159,6 +182,8 @@ __device__ __noinline__ void brd_table_w(const BrdMem m, uint32_t h, uint32_t bi
     }
 }
 
+// lane 0's work space while it reads a meta-block's header, in LDS (private arrays indexed by data live in scratch memory, a trip to HBM per access)
+struct BrdScratch { uint8_t len[704]; uint32_t cnt[16], off[16], cc[18]; uint8_t cl[18], csym[18], mtf[256]; };
 struct BrdArena { BrdMem m; uint32_t ldsCap, ldsUsed; uint32_t hbmCap, hbmUsed; };
 __device__ __forceinline__ uint32_t brd_alloc(BrdArena& a, uint32_t bytes)      // -> handle, or ~0u
 {
@@ -174,23 +199,24 @@ __device__ __forceinline__ uint32_t brd_alloc_lds(BrdArena& a, uint32_t bytes)  
     return ~0u;
 }
 // lengths (0..15) of `alpha` symbols -> the canonical code in the arena
-__device__ __noinline__ uint32_t brd_build(const uint8_t* len, uint32_t alpha, BrdArena& A)
+__device__ __forceinline__ uint32_t brd_build(BrdScratch* S, uint32_t alpha, BrdArena& A)
 {
     const bool wide = alpha > 256u;
-    uint32_t cnt[16]; for (uint32_t k = 0; k < 16u; k++) cnt[k] = 0;
+    const uint8_t* len = S->len; uint32_t* cnt = S->cnt; uint32_t* off = S->off;
+    for (uint32_t k = 0; k < 16u; k++) cnt[k] = 0;
     for (uint32_t sy = 0; sy < alpha; sy++) cnt[len[sy]]++;
     const uint32_t nUsed = alpha - cnt[0];
     const uint32_t h = brd_alloc(A, 96u + (nUsed ? nUsed : 1u) * (wide ? 2u : 1u));
     if (h == ~0u) return h;
     uint8_t* mem = (uint8_t*)brd_at(A.m, h);
     uint16_t* T = (uint16_t*)mem;
-    uint32_t code = 0, index = 0, off[16];
+    uint32_t code = 0, index = 0;
     T[0] = 0; T[16] = 0; T[32] = 0;
     for (uint32_t L = 1; L <= 15u; L++) { T[L] = (uint16_t)cnt[L]; T[16u + L] = (uint16_t)code; T[32u + L] = (uint16_t)index; off[L] = index; index += cnt[L]; code = (code + cnt[L]) << 1; }
     for (uint32_t sy = 0; sy < alpha; sy++) { const uint32_t L = len[sy]; if (L) { const uint32_t k = off[L]++; if (wide) ((uint16_t*)(mem + 96u))[k] = (uint16_t)sy; else mem[96u + k] = (uint8_t)sy; } }
     return h | (wide ? BRD_H_WIDE : 0u);
 }
-__device__ __noinline__ uint32_t brd_build_single(uint32_t sym, bool wide, BrdArena& A)
+__device__ __forceinline__ uint32_t brd_build_single(uint32_t sym, bool wide, BrdArena& A)
 {
     const uint32_t h = brd_alloc(A, 96u + 2u);
     if (h == ~0u) return h;
@@ -202,8 +228,9 @@ __device__ __noinline__ uint32_t brd_build_single(uint32_t sym, bool wide, BrdAr
 }
 
 // Reads one prefix code over an alphabet of `alpha` symbols (RFC 7932 sections 3.4 / 3.5) into the arena.  len[] = scratch of alpha bytes.  One lane.  -> handle
-__device__ __noinline__ uint32_t brd_read_code(BrdBits& b, uint32_t alpha, BrdArena& A, uint8_t* len, uint32_t& status)
+__device__ __forceinline__ uint32_t brd_read_code(BrdBits& b, uint32_t alpha, BrdArena& A, BrdScratch* S, uint32_t& status)
 {
+    uint8_t* const len = S->len;
     const uint32_t hskip = brd_take(b, 2);
     uint32_t h;
     if (hskip == 1u) {                                            // simple code: 1..4 symbols
@@ -219,13 +246,13 @@ __device__ __noinline__ uint32_t brd_read_code(BrdBits& b, uint32_t alpha, BrdAr
             else if (nsym == 3u) { len[s[0]] = 1; len[s[1]] = 2; len[s[2]] = 2; }
             else if (brd_take(b, 1)) { len[s[0]] = 1; len[s[1]] = 2; len[s[2]] = 3; len[s[3]] = 3; }
             else { len[s[0]] = 2; len[s[1]] = 2; len[s[2]] = 2; len[s[3]] = 2; }
-            h = brd_build(len, alpha, A);
+            h = brd_build(S, alpha, A);
         }
         if (h == ~0u) status = BRD_LIMIT;
         return h;
     }
     // complex code: the lengths of the 18 code length symbols (a fixed code of 2-4 bits each), then the symbols' lengths under that code
-    uint8_t cl[18]; for (uint32_t i = 0; i < 18u; i++) cl[i] = 0;
+    uint8_t* const cl = S->cl; for (uint32_t i = 0; i < 18u; i++) cl[i] = 0;
     int space = 32; uint32_t numCodes = 0;
     for (uint32_t i = hskip; i < 18u && space > 0; i++) {
         if (b.n <= 32u) brd_fill(b);
@@ -239,7 +266,7 @@ __device__ __noinline__ uint32_t brd_read_code(BrdBits& b, uint32_t alpha, BrdAr
     }
     if (!(numCodes == 1u || space == 0)) { status = BRD_CORRUPT; return ~0u; }
     // the code length code itself: a small canonical code in registers / private memory
-    uint32_t cCnt[6], cFirst[6], cBase[6]; uint8_t csym[18]; uint32_t single = 0;
+    uint32_t* const cCnt = S->cc; uint32_t* const cFirst = S->cc + 6; uint32_t* const cBase = S->cc + 12; uint8_t* const csym = S->csym; uint32_t single = 0;
     for (uint32_t i = 0; i < 6u; i++) { cCnt[i] = 0; cFirst[i] = 0; cBase[i] = 0; }
     if (numCodes == 1u) { for (uint32_t sy = 0; sy < 18u; sy++) if (cl[sy]) single = sy; }
     else { uint32_t code = 0, k = 0; for (uint32_t L = 1; L <= 5u; L++) { cFirst[L] = code; cBase[L] = k; for (uint32_t sy = 0; sy < 18u; sy++) if (cl[sy] == L) { csym[k++] = (uint8_t)sy; cCnt[L]++; } code = (code + cCnt[L]) << 1; } }
@@ -274,7 +301,7 @@ __device__ __noinline__ uint32_t brd_read_code(BrdBits& b, uint32_t alpha, BrdAr
     }
     if (sp != 0) { status = BRD_CORRUPT; return ~0u; }
     for (; i < alpha; i++) len[i] = 0;
-    h = brd_build(len, alpha, A);
+    h = brd_build(S, alpha, A);
     if (h == ~0u) status = BRD_LIMIT;
     return h;
 }
@@ -320,6 +347,7 @@ __device__ __forceinline__ uint32_t brd_utf8_1(uint32_t b)
 __device__ __forceinline__ uint32_t brd_signed(uint32_t b) { return b == 0u ? 0u : (b < 16u ? 1u : (b < 64u ? 2u : (b < 128u ? 3u : (b < 192u ? 4u : (b < 240u ? 5u : (b < 255u ? 6u : 7u)))))); }
 
 // the format's small tables, copied to LDS once per wave (a read of __constant__ memory with a computed index is a trip to the scalar cache per symbol)
+struct alignas(8) BrdCmd { uint32_t x, y; };
 struct BrdConst { uint16_t insBase[24], copyBase[24], blockBase[26]; uint8_t insExtra[24], copyExtra[24], blockExtra[26], cellIns[12], cellCopy[12]; };
 
 // one category of block types (literals, insert-and-copy, distances): RFC 7932 section 6
@@ -335,7 +363,7 @@ __device__ __forceinline__ void brd_switch_w(BrdBits& b, BrdBlocks& B, const Brd
 }
 
 // context map (RFC 7932 section 7.3): `size` entries in out[].  One lane.
-__device__ __noinline__ bool brd_context_map(BrdBits& b, uint32_t size, uint32_t& nTrees, uint8_t* out, BrdArena& A, uint8_t* lenScratch, uint32_t& status)
+__device__ __forceinline__ bool brd_context_map(BrdBits& b, uint32_t size, uint32_t& nTrees, uint8_t* out, BrdArena& A, BrdScratch* lenScratch, uint32_t& status)
 {
     nTrees = brd_varlen8(b) + 1u;
     if (nTrees == 1u) { for (uint32_t i = 0; i < size; i++) out[i] = 0; return true; }
@@ -352,7 +380,7 @@ __device__ __noinline__ bool brd_context_map(BrdBits& b, uint32_t size, uint32_t
         else out[i++] = (uint8_t)(s - rleMax);
     }
     if (brd_take(b, 1)) {                                         // inverse move-to-front
-        uint8_t mtf[256]; for (uint32_t i = 0; i < 256u; i++) mtf[i] = (uint8_t)i;
+        uint8_t* const mtf = lenScratch->mtf; for (uint32_t i = 0; i < 256u; i++) mtf[i] = (uint8_t)i;
         for (uint32_t i = 0; i < size; i++) { const uint32_t idx = out[i]; const uint8_t v = mtf[idx]; out[i] = v; for (uint32_t k = idx; k > 0u; k--) mtf[k] = mtf[k - 1u]; mtf[0] = v; }
     }
     for (uint32_t i = 0; i < size; i++) if (out[i] >= nTrees) { status = BRD_CORRUPT; return false; }
@@ -369,6 +397,7 @@ struct BrdMeta {
     uint32_t nTrees[3];                   // literal, insert-and-copy, distance codes
     uint32_t dir[3];                      // handles of the three directories (uint32 handles of the codes)
     uint32_t cmapL, cmapD, modes;         // handles
+    uint32_t ctxTab, nCtxTab;             // LDS offset of the context tables (2 KiB per literal block type: tree of (last byte, class of the byte before)), and for how many types
     uint32_t tab[3], nTab[3];             // LDS offset of the decoding tables of the first nTab codes of each kind (512 / 2048 / 512 bytes each)
     uint32_t ldsUsed;
 };
@@ -390,6 +419,32 @@ __device__ __forceinline__ void brd_flush(const uint8_t* ring, uint8_t* __restri
     if (lane < upto - a) out[a + lane] = ring[(a + lane) & RMASK];
 }
 
+// m literals in a row whose trees all have tables and whose context comes from one table (CLS 0: one tree; 2: UTF8 classes from the LUT; 3: the mode decides): the loop the
+// decoder spends its time in on data that does not compress well -- no block-type, flush or table-presence checks inside (the caller has sized m by them)
+template <uint32_t RING, uint32_t CLS>
+__device__ __forceinline__ void brd_literals(BrdBits& hb, uint32_t m, const uint16_t* tabL, const uint8_t* ctRow, const uint8_t* lut, uint8_t* ring, uint32_t& pos, uint32_t& p1, uint32_t& p2,
+                                             uint32_t& g1, uint32_t& g2, uint32_t mode, const uint32_t* dirL, const BrdMem& mem, uint32_t lane)
+{
+    for (; m != 0u; m--) {
+        if (hb.n <= 32u) brd_fill(hb);
+        const uint32_t tl = CLS ? gc_uniform(ctRow[(p1 << 3) | g2]) : 0u;
+        const uint32_t e = gc_uniform(tabL[(tl << 8) + ((uint32_t)hb.acc & 255u)]);
+        uint32_t lit;
+        if (e & 0x8000u) { const uint32_t len = e & 15u; hb.acc >>= len; hb.n -= len; lit = (e >> 4) & 0xFFu; }
+        else lit = brd_sym_w(hb, mem, dirL[tl], lane);
+        if (lane == 0u) ring[pos & (RING - 1u)] = (uint8_t)lit;
+        pos++; p2 = p1; p1 = lit;
+        if (CLS == 2u) { g2 = g1; g1 = gc_uniform(lut[256u + lit]); }
+        else if (CLS == 3u) { g2 = g1; g1 = mode == 3u ? brd_signed(lit) : 0u; }
+    }
+}
+
+// (check build -DBRD_PROFILE: chunk 0 prints the clock ticks it spent per section)
+#ifdef BRD_PROFILE
+#define BRD_T(k) { const uint64_t tNow = wall_clock64(); prof[k] += tNow - tLast; tLast = tNow; }
+#else
+#define BRD_T(k)
+#endif
 // ------------------------------------------------------------------------------------------------ one wave per chunk
 // ARENA: bytes of LDS for a meta-block's codes, maps and decoding tables; RING: the last RING bytes of output, so that near copies read LDS (0: none).  The host picks the
 // instance by the number of chunks: few chunks get the LDS of a whole CU each.
@@ -401,15 +456,21 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
     __shared__ __attribute__((aligned(16))) uint8_t sRing[RING];
     static_assert(RING >= 4096u && (RING & (RING - 1u)) == 0u, "the ring holds the output before it goes to HBM");
     __shared__ uint8_t sLut[512];                                 // UTF8 context ids (mode 2), the mode of every stream this engine writes and of nearly every one of the reference
-    __shared__ uint8_t sLen[704];
+    __shared__ BrdScratch sScratch;
     __shared__ BrdMeta sMeta;
     __shared__ BrdConst sK;
+    __shared__ BrdCmd sCmd[704];                                   // per insert-and-copy symbol: {insert base | extra bits << 16, copy base | extra bits << 16} (RFC 7932 section 5): one read per command
     const uint32_t lane = threadIdx.x;
     constexpr uint32_t RMASK = RING - 1u;
     for (uint32_t i = lane; i < 256u; i += 64u) { sLut[i] = (uint8_t)brd_utf8_0(i); sLut[256u + i] = (uint8_t)brd_utf8_1(i); }
     if (lane < 24u) { sK.insBase[lane] = kdInsBase[lane]; sK.copyBase[lane] = kdCopyBase[lane]; sK.insExtra[lane] = kdInsExtra[lane]; sK.copyExtra[lane] = kdCopyExtra[lane]; }
     if (lane < 26u) { sK.blockBase[lane] = kdBlockBase[lane]; sK.blockExtra[lane] = kdBlockExtra[lane]; }
     if (lane < 11u) { sK.cellIns[lane] = kdCellIns[lane]; sK.cellCopy[lane] = kdCellCopy[lane]; }
+    for (uint32_t cs = lane; cs < 704u; cs += 64u) {
+        const uint32_t cell = cs >> 6, ic = kdCellIns[cell] + ((cs >> 3) & 7u), cc = kdCellCopy[cell] + (cs & 7u);
+        BrdCmd e; e.x = kdInsBase[ic] | ((uint32_t)kdInsExtra[ic] << 16); e.y = kdCopyBase[cc] | ((uint32_t)kdCopyExtra[cc] << 16);
+        sCmd[cs] = e;
+    }
     gc_wave_sync();
     const BrdConst& K = sK;
     for (uint32_t c = blockIdx.x; c < nChunks; c += gridDim.x) {
@@ -417,6 +478,9 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
         uint8_t* const out = stage + ck.stageOff;
         const uint32_t cap = ck.hintBytes;
         BrdMem mem; mem.lds = sArena; mem.hbm = nullptr;          // (the page is taken from the pool when a meta-block needs it, kept for the chunk)
+#ifdef BRD_PROFILE
+        uint64_t prof[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tLast = wall_clock64(); uint32_t nCmd = 0, nLit = 0, nMeta = 0;
+#endif
         uint32_t status = BRD_OK, pos = 0, flushed = 0;             // output [flushed, pos) is in the ring only
         bool unfenced = false;                                    // a flush has stored to HBM since the wave last waited for its stores
         BrdBits b; b.p = src + ck.srcOff; b.acc = 0; b.n = 0; b.pos = 0; b.end = ck.srcSize; b.over = 0u; brd_prime(b);
@@ -430,7 +494,7 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
         while (!last && status == BRD_OK) {
             // ---- meta-block header: lane 0 reads it (prefix codes and context maps are serial work), the wave takes over what it found
             if (lane == 0u) {
-                BrdMeta M; M.kind = 2; M.mlen = 0; M.srcAt = 0;
+                BrdMeta& M = sMeta; M.kind = 2; M.mlen = 0; M.srcAt = 0;
                 uint32_t st = BRD_OK;
                 M.last = brd_take(b, 1);
                 if (M.last && brd_take(b, 1)) M.kind = 3;         // ISLASTEMPTY
@@ -466,8 +530,8 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
                                 for (uint32_t k = 0; k < 3u && st == BRD_OK; k++) {
                                     M.nTypes[k] = brd_varlen8(b) + 1u; M.left[k] = ~0u; M.typeCode[k] = 0; M.countCode[k] = 0;
                                     if (M.nTypes[k] >= 2u) {
-                                        M.typeCode[k] = brd_read_code(b, M.nTypes[k] + 2u, A, sLen, st); if (st != BRD_OK) break;
-                                        M.countCode[k] = brd_read_code(b, 26u, A, sLen, st); if (st != BRD_OK) break;
+                                        M.typeCode[k] = brd_read_code(b, M.nTypes[k] + 2u, A, &sScratch, st); if (st != BRD_OK) break;
+                                        M.countCode[k] = brd_read_code(b, 26u, A, &sScratch, st); if (st != BRD_OK) break;
                                         const uint32_t cs = brd_sym(b, A.m, M.countCode[k]);
                                         M.left[k] = cs < 26u ? kdBlockBase[cs] + brd_take(b, kdBlockExtra[cs]) : 0u;
                                     }
@@ -483,8 +547,8 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
                                     const uint32_t sl = 64u * M.nTypes[0], sd = 4u * M.nTypes[2];
                                     M.cmapL = brd_alloc_lds(A, sl + sd); M.cmapD = M.cmapL + sl;
                                     if (M.cmapL == ~0u) st = BRD_LIMIT;
-                                    if (st == BRD_OK) brd_context_map(b, sl, M.nTrees[0], sArena + M.cmapL, A, sLen, st);
-                                    if (st == BRD_OK) brd_context_map(b, sd, M.nTrees[2], sArena + M.cmapD, A, sLen, st);
+                                    if (st == BRD_OK) brd_context_map(b, sl, M.nTrees[0], sArena + M.cmapL, A, &sScratch, st);
+                                    if (st == BRD_OK) brd_context_map(b, sd, M.nTrees[2], sArena + M.cmapD, A, &sScratch, st);
                                 }
                                 if (st == BRD_OK) {
                                     const uint32_t d0 = brd_alloc_lds(A, (M.nTrees[0] + M.nTrees[1] + M.nTrees[2]) * 4u);
@@ -494,7 +558,7 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
                                         const uint32_t alpha[3] = { 256u, 704u, 16u + M.ndirect + (48u << M.npostfix) };
                                         for (uint32_t k = 0; k < 3u && st == BRD_OK; k++) {
                                             uint32_t* dir = (uint32_t*)(sArena + M.dir[k]);
-                                            for (uint32_t i = 0; i < M.nTrees[k] && st == BRD_OK; i++) dir[i] = brd_read_code(b, alpha[k], A, sLen, st);
+                                            for (uint32_t i = 0; i < M.nTrees[k] && st == BRD_OK; i++) dir[i] = brd_read_code(b, alpha[k], A, &sScratch, st);
                                         }
                                     }
                                 }
@@ -515,15 +579,17 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
                                     M.tab[k] = at; M.nTab[k] = room < M.nTrees[k] ? room : M.nTrees[k];
                                     at += M.nTab[k] * bytesOf[k];
                                 }
+                                M.ctxTab = at; M.nCtxTab = 0;
+                                if (M.nTrees[0] > 1u && M.nTab[0] == M.nTrees[0] && capT > at && (capT - at) / 2048u >= M.nTypes[0]) M.nCtxTab = M.nTypes[0];
                             }
                         }
                     }
                 }
                 if (b.over && st == BRD_OK) st = BRD_CORRUPT;
                 M.acc = b.acc; M.n = b.n; M.pos = b.pos; M.over = b.over; M.status = st;
-                sMeta = M;
             }
             gc_wave_sync_global();
+            BRD_T(0)
             const uint32_t kind = gc_uniform(sMeta.kind), mlen = gc_uniform(sMeta.mlen);
             status = gc_uniform(sMeta.status); last = gc_uniform(sMeta.last) != 0u;
             b.acc = sMeta.acc; b.n = sMeta.n; b.pos = sMeta.pos; b.over = sMeta.over; brd_prime(b);
@@ -550,40 +616,86 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
             for (uint32_t i = 0; i < nTabL; i++) brd_table_w(mem, dirL[i], 8u, (uint16_t*)tabL + 256u * i, lane);
             for (uint32_t i = 0; i < nTabI; i++) brd_table_w(mem, dirI[i], 10u, (uint16_t*)tabI + 1024u * i, lane);
             for (uint32_t i = 0; i < nTabD; i++) brd_table_w(mem, dirD[i], 8u, (uint16_t*)tabD + 256u * i, lane);
+            // ---- context tables: the literal's tree from the last byte and the class of the byte before it in ONE read (context id, then context map, are two)
+            const uint32_t nCtxTab = gc_uniform(sMeta.nCtxTab), nTreesL = gc_uniform(sMeta.nTrees[0]), nTreesD = gc_uniform(sMeta.nTrees[2]);
+            uint8_t* const ctxTab = sArena + sMeta.ctxTab;
+            for (uint32_t t = 0; t < nCtxTab; t++) {
+                const uint32_t md = (sArena + sMeta.modes)[t]; const uint8_t* row = sArena + sMeta.cmapL + 64u * t;
+                for (uint32_t e = lane; e < 2048u; e += 64u) {
+                    const uint32_t a = e >> 3, j = e & 7u;
+                    const uint32_t ctx = md == 2u ? (sLut[a] | (j & 3u)) : (md == 0u ? (a & 63u) : (md == 1u ? a >> 2 : ((brd_signed(a) << 3) | j)));
+                    ctxTab[2048u * t + e] = row[ctx];
+                }
+            }
             // ---- commands: every lane runs the same state machine
             BrdBlocks BL[3];
             for (uint32_t k = 0; k < 3u; k++) { BL[k].n = gc_uniform(sMeta.nTypes[k]); BL[k].type = 0; BL[k].prev = 1; BL[k].left = gc_uniform(sMeta.left[k]); BL[k].typeCode = gc_uniform(sMeta.typeCode[k]); BL[k].countCode = gc_uniform(sMeta.countCode[k]); }
             const uint32_t npostfix = gc_uniform(sMeta.npostfix), ndirect = gc_uniform(sMeta.ndirect);
             const uint8_t* const cmapL = sArena + sMeta.cmapL; const uint8_t* const cmapD = sArena + sMeta.cmapD; const uint8_t* const modes = sArena + sMeta.modes;
             gc_wave_sync();                                       // (sMeta is lane 0's to write again from here; the tables are whole)
+            BRD_T(1)
             const uint32_t mEnd = pos + mlen;
             uint32_t mode = gc_uniform(modes[0]);
             const uint8_t* cmRow = cmapL;
+            const uint8_t* ctRow = ctxTab;
+            // class of a byte as the byte BEFORE the last one (UTF8: 2 bits, SIGNED: 3 bits, the other modes do not look at it)
+            #define BRD_CLASS(x) (mode == 2u ? (uint32_t)sLut[256u + (x)] : (mode == 3u ? brd_signed(x) : 0u))
+            uint32_t g2 = nCtxTab ? gc_uniform(BRD_CLASS(p2)) : 0u, g1 = nCtxTab ? gc_uniform(BRD_CLASS(p1)) : 0u;
+            const bool fastLit = nTabL == nTreesL && (nTreesL == 1u || nCtxTab != 0u);
+            bool gStale = false;                                  // g1 / g2 are behind p1 / p2 (a copy has run: they are looked up when the next literal needs them)
             while (pos < mEnd && status == BRD_OK) {
                 if (BL[1].left == 0u) brd_switch_w(hb, BL[1], mem, K, lane);
                 BL[1].left--;
                 const uint32_t ti = BL[1].type;
                 const uint32_t cs = brd_sym_t<10>(hb, tabI, nTabI, dirI, ti, mem, lane);
-                const uint32_t cell = cs >> 6;
-                if (cell > 10u) { status = BRD_CORRUPT; break; }
-                const uint32_t ic = gc_uniform(K.cellIns[cell]) + ((cs >> 3) & 7u), cc = gc_uniform(K.cellCopy[cell]) + (cs & 7u);
-                uint32_t ins = gc_uniform(K.insBase[ic]) + brd_take(hb, gc_uniform(K.insExtra[ic]));
-                const uint32_t cplen = gc_uniform(K.copyBase[cc]) + brd_take(hb, gc_uniform(K.copyExtra[cc]));
+                if (cs >= 704u) { status = BRD_CORRUPT; break; }
+                const BrdCmd ci = sCmd[cs];
+                const uint32_t ciI = gc_uniform(ci.x), ciC = gc_uniform(ci.y);
+                uint32_t ins = ciI & 0xFFFFu; if (ciI >> 16) ins += brd_take(hb, ciI >> 16);
+                uint32_t cplen = ciC & 0xFFFFu; if (ciC >> 16) cplen += brd_take(hb, ciC >> 16);
                 if (pos + ins > mEnd) { status = BRD_CORRUPT; break; }
+                BRD_T(2)
+#ifdef BRD_PROFILE
+                nCmd++; nLit += ins;
+#endif
+                if (gStale && ins != 0u) { g2 = gc_uniform(BRD_CLASS(p2)); g1 = gc_uniform(BRD_CLASS(p1)); gStale = false; }
+                while (fastLit && ins != 0u) {
+                    if (BL[0].left == 0u) {
+                        brd_switch_w(hb, BL[0], mem, K, lane); mode = gc_uniform(modes[BL[0].type]); ctRow = ctxTab + 2048u * BL[0].type;
+                        if (nCtxTab) { g2 = gc_uniform(BRD_CLASS(p2)); g1 = gc_uniform(BRD_CLASS(p1)); }
+                    }
+                    uint32_t room = RING - 64u - (pos - flushed);
+                    if (room == 0u) { gc_wave_sync(); brd_flush<RING>(sRing, out, flushed, pos, lane); flushed = pos; unfenced = true; gc_wave_sync(); room = RING - 64u; }
+                    uint32_t m = ins < BL[0].left ? ins : BL[0].left;
+                    if (room < m) m = room;
+                    ins -= m; BL[0].left -= m;
+                    if (nTreesL == 1u) brd_literals<RING, 0u>(hb, m, tabL, ctRow, sLut, sRing, pos, p1, p2, g1, g2, mode, dirL, mem, lane);
+                    else if (mode == 2u) brd_literals<RING, 2u>(hb, m, tabL, ctRow, sLut, sRing, pos, p1, p2, g1, g2, mode, dirL, mem, lane);
+                    else brd_literals<RING, 3u>(hb, m, tabL, ctRow, sLut, sRing, pos, p1, p2, g1, g2, mode, dirL, mem, lane);
+                }
                 for (; ins != 0u; ins--) {
-                    if (BL[0].left == 0u) { brd_switch_w(hb, BL[0], mem, K, lane); mode = gc_uniform(modes[BL[0].type]); cmRow = cmapL + 64u * BL[0].type; }
+                    if (BL[0].left == 0u) {
+                        brd_switch_w(hb, BL[0], mem, K, lane); mode = gc_uniform(modes[BL[0].type]); cmRow = cmapL + 64u * BL[0].type; ctRow = ctxTab + 2048u * BL[0].type;
+                        if (nCtxTab) { g2 = gc_uniform(BRD_CLASS(p2)); g1 = gc_uniform(BRD_CLASS(p1)); }
+                    }
                     BL[0].left--;
-                    uint32_t ctx;
-                    if (mode == 2u) ctx = gc_uniform(sLut[p1] | sLut[256u + p2]);
-                    else if (mode == 0u) ctx = p1 & 63u;
-                    else if (mode == 1u) ctx = p1 >> 2;
-                    else ctx = (brd_signed(p1) << 3) | brd_signed(p2);
-                    const uint32_t tl = gc_uniform(cmRow[ctx]);
+                    uint32_t tl = 0;
+                    if (nCtxTab) tl = gc_uniform(ctRow[(p1 << 3) | g2]);
+                    else if (nTreesL > 1u) {
+                        uint32_t ctx;
+                        if (mode == 2u) ctx = gc_uniform(sLut[p1] | sLut[256u + p2]);
+                        else if (mode == 0u) ctx = p1 & 63u;
+                        else if (mode == 1u) ctx = p1 >> 2;
+                        else ctx = (brd_signed(p1) << 3) | brd_signed(p2);
+                        tl = gc_uniform(cmRow[ctx]);
+                    }
                     const uint32_t lit = brd_sym_t<8>(hb, tabL, nTabL, dirL, tl, mem, lane);
                     if (pos - flushed >= RING - 64u) { gc_wave_sync(); brd_flush<RING>(sRing, out, flushed, pos, lane); flushed = pos; unfenced = true; gc_wave_sync(); }
                     if (lane == 0u) sRing[pos & RMASK] = (uint8_t)lit;
                     pos++; p2 = p1; p1 = lit;
+                    if (nCtxTab) { g2 = g1; g1 = gc_uniform(BRD_CLASS(lit)); }
                 }
+                BRD_T(3)
                 if (hb.over) { status = BRD_CORRUPT; break; }
                 if (pos == mEnd) break;                           // the meta-block ends behind the literals: no copy
                 int dist;
@@ -592,24 +704,23 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
                     if (BL[2].left == 0u) brd_switch_w(hb, BL[2], mem, K, lane);
                     BL[2].left--;
                     const uint32_t dctx = cplen > 4u ? 3u : cplen - 2u;
-                    const uint32_t td = gc_uniform(cmapD[4u * BL[2].type + dctx]);
+                    const uint32_t td = nTreesD > 1u ? gc_uniform(cmapD[4u * BL[2].type + dctx]) : 0u;
                     dcode = brd_sym_t<8>(hb, tabD, nTabD, dirD, td, mem, lane);
                 }
                 const uint32_t maxDist = pos < maxBack ? pos : maxBack;
                 bool push = true;
-                if (dcode < 16u) {
+                if (dcode >= 16u + ndirect) {
+                    const uint32_t v = dcode - ndirect - 16u, hcode = v >> npostfix, lcode = v & ((1u << npostfix) - 1u), nb = 1u + (hcode >> 1);
+                    const uint32_t off = ((2u + (hcode & 1u)) << nb) - 4u;
+                    dist = (int)(((off + brd_take(hb, nb)) << npostfix) + lcode + ndirect + 1u);
+                    if (dist <= 0) { status = BRD_CORRUPT; break; }
+                } else if (dcode < 16u) {
                     if (dcode == 0u) { dist = r1; push = false; }
                     else if (dcode == 1u) dist = r2; else if (dcode == 2u) dist = r3; else if (dcode == 3u) dist = r4;
                     else if (dcode < 10u) { const int d = (int)((dcode - 4u) >> 1) + 1; dist = r1 + (((dcode - 4u) & 1u) ? d : -d); }
                     else { const int d = (int)((dcode - 10u) >> 1) + 1; dist = r2 + (((dcode - 10u) & 1u) ? d : -d); }
                     if (dist <= 0) { status = BRD_CORRUPT; break; }
-                } else if (dcode < 16u + ndirect) dist = (int)(dcode - 15u);
-                else {
-                    const uint32_t v = dcode - ndirect - 16u, hcode = v >> npostfix, lcode = v & ((1u << npostfix) - 1u), nb = 1u + (hcode >> 1);
-                    const uint32_t off = ((2u + (hcode & 1u)) << nb) - 4u;
-                    dist = (int)(((off + brd_take(hb, nb)) << npostfix) + lcode + ndirect + 1u);
-                    if (dist <= 0) { status = BRD_CORRUPT; break; }
-                }
+                } else dist = (int)(dcode - 15u);
                 if (hb.over) { status = BRD_CORRUPT; break; }
                 if ((uint32_t)dist > maxDist) {
                     // ---- static dictionary reference (RFC 7932 section 8): the word of `cplen` bytes with one of the 121 transforms; it does not enter the ring
@@ -648,12 +759,14 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
                     }
                     gc_wave_sync();
                     if (total) { p2 = total > 1u ? gc_uniform(sRing[(pos + total - 2u) & RMASK]) : p1; p1 = gc_uniform(sRing[(pos + total - 1u) & RMASK]); }
+                    gStale = nCtxTab != 0u;
                     pos += total;
                     gc_wave_sync();
                     continue;
                 }
                 if (push) { r4 = r3; r3 = r2; r2 = r1; r1 = dist; }
                 if (pos + cplen > mEnd) { status = BRD_CORRUPT; break; }
+                BRD_T(4)
                 {
                     const uint32_t d = (uint32_t)dist;
                     uint32_t v = 0;                               // the byte of this lane's last turn
@@ -669,7 +782,8 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
                         flushed = pos + cplen;
                     } else if (d + cplen + 64u <= RING) {
                         // near: distance + length + 64 <= RING, so no slot this copy writes holds a byte it still reads, in whatever order the lanes run
-                        for (uint32_t i = lane; i < cplen; i += 64u) { v = sRing[(pos - d + (d < cplen ? i % d : i)) & RMASK]; sRing[(pos + i) & RMASK] = (uint8_t)v; }
+                        if (cplen <= 64u && d >= cplen) { if (lane < cplen) { v = sRing[(pos - d + lane) & RMASK]; sRing[(pos + lane) & RMASK] = (uint8_t)v; } }
+                        else for (uint32_t i = lane; i < cplen; i += 64u) { v = sRing[(pos - d + (d < cplen ? i % d : i)) & RMASK]; sRing[(pos + i) & RMASK] = (uint8_t)v; }
                     } else {
                         // far: the source is in HBM unless it reaches into what the ring has not handed over yet
                         if (pos - d + cplen > flushed) { brd_flush<RING>(sRing, out, flushed, pos, lane); flushed = pos; unfenced = true; }
@@ -678,16 +792,24 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
                         for (uint32_t i = lane; i < cplen; i += 64u) { v = s[d < cplen ? i % d : i]; sRing[(pos + i) & RMASK] = (uint8_t)v; }
                     }
                     p1 = gc_readlane(v, (cplen - 1u) & 63u); p2 = gc_readlane(v, (cplen - 2u) & 63u);
+                    gStale = nCtxTab != 0u;
                 }
                 pos += cplen;
                 gc_wave_sync();
+                BRD_T(5)
             }
-            b.acc = hb.acc; b.n = hb.n; b.pos = hb.pos; b.over = hb.over; b.next = hb.next;
+            #undef BRD_CLASS
+            b = hb;
             if (b.over && status == BRD_OK) status = BRD_CORRUPT;
             gc_wave_sync_global();
         }
         gc_wave_sync();
         brd_flush<RING>(sRing, out, flushed, pos, lane);
+#ifdef BRD_PROFILE
+        BRD_T(6)
+        if (c == 0u && lane == 0u) printf("brd profile chunk 0: bytes %u commands %u literals %u | ticks (100 MHz): header %llu tables %llu command %llu literals %llu distance %llu copy %llu rest %llu\n", pos, nCmd, nLit,
+            (unsigned long long)prof[0], (unsigned long long)prof[1], (unsigned long long)prof[2], (unsigned long long)prof[3], (unsigned long long)prof[4], (unsigned long long)prof[5], (unsigned long long)prof[6]);
+#endif
         if (status == BRD_OK && brd_consumed(b) > ck.srcSize) status = BRD_CORRUPT;
         if (lane == 0u) { GcBrDecResult r; r.size = pos; r.status = status; result[c] = r; }
         gc_wave_sync_global();

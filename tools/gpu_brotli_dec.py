@@ -12,15 +12,16 @@ import __graft_entry__ as g
 pkg = g.load_package()
 import oracle as O
 
-ap = argparse.ArgumentParser(); ap.add_argument("--bytes", type=int, default=1_000_000_000); ap.add_argument("--ref-bytes", type=int, default=256 << 20); ap.add_argument("--corpus", default="web-text")
+ap = argparse.ArgumentParser(); ap.add_argument("--bytes", type=int, default=1_000_000_000); ap.add_argument("--ref-bytes", type=int, default=256 << 20); ap.add_argument("--corpus", default="web-text"); ap.add_argument("--only-own", action="store_true"); ap.add_argument("--reps", type=int, default=5); ap.add_argument("--lib", default=None)
 a = ap.parse_args()
 THR = min(os.cpu_count() or 1, 64)
-dec = pkg.BrotliDecoder(device=0)
+dec = pkg.BrotliDecoder(device=0, lib_path=a.lib)
 have_ref = O.ref("brotli") is not None
 if have_ref:
     dec.set_dictionary(O.ref_brotli_dictionary())
 
-def run(label, comp, x, reps=5):
+def run(label, comp, x, reps=None):
+    reps = reps or a.reps
     chunks, n, cap, used = dec.scan(comp)
     d_c = torch.from_numpy(np.ascontiguousarray(comp)).cuda(); d_x = torch.from_numpy(x).cuda(); d_y = torch.empty(x.size + 64, dtype=torch.uint8, device="cuda")
     got = dec.code_device(d_c.data_ptr(), int(comp.size), d_y.data_ptr(), x.size, chunks, n)      # warm-up (workspace)
@@ -46,12 +47,12 @@ def run(label, comp, x, reps=5):
 x = O.corpus(a.corpus, a.bytes)
 e = pkg.BrotliEncoder(level=6); c = e.code(x); e.close()
 run("this engine, quality 6, %s" % a.corpus, c, x)
-for kind in ("real-src", "real-bin"):
+for kind in (() if a.only_own else ("real-src", "real-bin")):
     xr = O.corpus(kind, 256 << 20)
     if xr.size >= (1 << 20):
         e = pkg.BrotliEncoder(level=6); c = e.code(xr); e.close()
         run("this engine, quality 6, %s" % kind, c, xr)
-if have_ref:
+if have_ref and not a.only_own:
     for q, nb in ((1, a.ref_bytes), (6, a.ref_bytes), (9, a.ref_bytes), (11, min(a.ref_bytes, 32 << 20))):
         xr = x[:nb]
         c = O.ref_brotlimt_compress(xr, q, THR)
