@@ -258,6 +258,27 @@ def run_codec(codec, level, corpus_name, total, args, env):
                                            "achieved": round(algo / (kms[dom] * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                            "frac": round(algo / (kms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": dtraffic, "traffic_measured_at_commit": dcommit, "algorithmic_bytes_per_launch": algo}}
                 dec.close(); del d_c, d_y
+            if br and world == 1:
+                # the same for BROTLI (gc_brotli_dec.hip: one wave per brotli-mt chunk; this engine's streams never refer to the static dictionary)
+                dec = pkg.BrotliDecoder(device=env["local_rank"])
+                chunks, nch, _, _ = dec.scan(stream)
+                d_c = torch.from_numpy(np.ascontiguousarray(stream)).to(dev)
+                d_y = torch.empty(total + 64, dtype=torch.uint8, device=dev)
+                DEC_RUNS = 3
+                best = 0.0
+                for it in range(DEC_RUNS + 1):
+                    got = dec.code_device(d_c.data_ptr(), int(stream.size), d_y.data_ptr(), total, chunks, nch)
+                    if it:
+                        best += dec.last_timing_ms() / DEC_RUNS
+                same = bool(got == total and torch.equal(d_y[:total], d_src[:total]))
+                algo = total + int(stream.size)
+                gpu_decode = {"chunks": nch, "content_bytes": total, "timing": "mean of %d decodes after one warm-up" % DEC_RUNS, "kernel_ms": round(best, 3), "value": round(total / best / 1e3, 1), "unit": "MB/s of content",
+                              "bit_exact": same, "reference_decoder_%d_threads_MBps" % thr: round(total / td / 1e6, 1),
+                              "parallelism": "one wave per brotli-mt chunk (%d chunks): inside a chunk the stream is serial by format" % nch,
+                              "roofline": {"bound": "hbm", "kernel": "gc_brotli_dec_kernel_" + ("a" if nch <= 256 else "b" if nch <= 512 else "c" if nch <= 1024 else "d"),
+                                           "achieved": round(algo / (best * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(algo / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                           "traffic": None, "algorithmic_bytes_per_launch": algo}}
+                dec.close(); del d_c, d_y
     value = total * args.steps / elapsed / 1e6
     ratio = total / total_csize
     # dominant kernel of rank 0 = the longest single kernel by live HIP-event timing; algorithmic bytes per launch =

@@ -28,7 +28,7 @@ try:
     f = d.get('flzma2_l5_silesia')
     if f: print('flzma2', f['value'], f['ms_per_step'], (f.get('ratio_vs_ref') or {}).get('ours_over_ref'), f['roofline']['kernel_ms'])
     if d.get('real_data'): print('real', json.dumps(d['real_data']['corpora'])[:1500])
-    if d.get('gpu_decode'): print('decode', d['gpu_decode']['value'], d['gpu_decode']['kernels_ms'])
+    if d.get('gpu_decode'): print('decode', d['gpu_decode']['value'], d['gpu_decode'].get('kernels_ms'))
 except Exception as e: print('bench line unreadable', e)
 PY
            ;;
