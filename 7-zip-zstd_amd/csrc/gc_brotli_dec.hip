@@ -642,6 +642,7 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
             #define BRD_CLASS(x) (mode == 2u ? (uint32_t)sLut[256u + (x)] : (mode == 3u ? brd_signed(x) : 0u))
             uint32_t g2 = nCtxTab ? gc_uniform(BRD_CLASS(p2)) : 0u, g1 = nCtxTab ? gc_uniform(BRD_CLASS(p1)) : 0u;
             const bool fastLit = nTabL == nTreesL && (nTreesL == 1u || nCtxTab != 0u);
+            uint32_t stalled = 0;
             bool gStale = false;                                  // g1 / g2 are behind p1 / p2 (a copy has run: they are looked up when the next literal needs them)
             while (pos < mEnd && status == BRD_OK) {
                 if (BL[1].left == 0u) brd_switch_w(hb, BL[1], mem, K, lane);
@@ -737,6 +738,8 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
                     else if (type >= 1u && type <= 9u) wl = wl > type ? wl - type : 0u;                        // omit the last n
                     const uint32_t body = wl - skip, total = pre[0] + body + suf[0];
                     if (pos + total > mEnd) { status = BRD_CORRUPT; break; }
+                    // (a transform may leave nothing of a word; a damaged stream whose codes all have one symbol could ask for that forever without spending a bit)
+                    if (total == 0u && ++stalled > 4096u) { status = BRD_CORRUPT; break; }
                     if (pos - flushed + total + 64u > RING) { gc_wave_sync(); brd_flush<RING>(sRing, out, flushed, pos, lane); flushed = pos; unfenced = true; gc_wave_sync(); }
                     if (lane == 0u) {
                         uint8_t word[40]; uint32_t o = 0;         // (prefix <= 8, word <= 24, suffix <= 8 bytes: RFC 7932 Appendix B)
