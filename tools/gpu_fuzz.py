@@ -17,6 +17,8 @@ rng = np.random.default_rng(a.seed)
 text = O.corpus("text-zipf", 4 << 20); lz = O.corpus("lz-7zip", 4 << 20); sil = O.corpus("silesia-like", 211_900_000)[31_785_000:31_785_000 + (4 << 20)]   # PCM-like part
 os.makedirs(os.path.join(ROOT, "gpurun_out", "fuzz"), exist_ok=True)
 t0 = time.time(); it = bad = 0; encs = {}; total = 0; dec = pkg.ZstdDecoder(**kw); ndec = nrefused = 0
+bdec = pkg.BrotliDecoder(**kw); nbdec = nbref = 0
+if O.ref("brotli") is not None: bdec.set_dictionary(O.ref_brotli_dictionary())
 while time.time() - t0 < a.seconds:
     target = int(min(a.max_mib * (1 << 20), 2 ** rng.uniform(3, 25)))
     parts, n = [], 0
@@ -56,9 +58,27 @@ while time.time() - t0 < a.seconds:
                         ok = (not opts["checksum"]) or np.array_equal(w, x)     # without a checksum a flip may go unnoticed by the format
                     except pkg.GpuCodecError:
                         nrefused += 1
+        if ok and codec == "brotli":
+            # ... and BROTLI streams through the GPU decoder: this engine's, a reference-encoder stream of a random quality (with its references to the static dictionary), damaged copies
+            ok = np.array_equal(bdec.code(y), x)
+            if ok and n <= (8 << 20):
+                r = O.ref_brotlimt_compress(x, int(rng.choice([0, 1, 2, 4, 5, 6, 9, 10, 11])) if n <= (1 << 20) else int(rng.choice([1, 5, 6])), int(rng.integers(1, 5)))
+                ok = np.array_equal(bdec.code(r), x)
+                nbdec += 1
+                for src_stream in (r, y):
+                    if ok and src_stream.size > 20:
+                        badr = src_stream.copy(); k = int(rng.integers(0, 3))
+                        if k == 0: badr[int(rng.integers(16, badr.size))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+                        elif k == 1: i = int(rng.integers(16, badr.size)); badr[i:i + 8] = rng.integers(0, 256, size=badr[i:i + 8].size, dtype=np.uint8)
+                        else: badr = badr[:int(rng.integers(17, badr.size))]
+                        try:
+                            bdec.code(badr)                                   # brotli carries no checksum: other content is not a failure, a crash or a hang is
+                        except pkg.GpuCodecError:
+                            nbref += 1
+                        ok = np.array_equal(bdec.code(y), x)                   # the context still works
     except Exception as ex:
         ok = False; print("EXC", codec, level, n, repr(ex)[:200], flush=True)
     if not ok:
         bad += 1; print("FAIL", codec, level, n, flush=True); np.save(os.path.join(ROOT, "gpurun_out", "fuzz", "fail_%s_%d_%d.npy" % (codec, level, n)), x)
     it += 1; total += n
-print("iterations", it, "bytes", total, "failures", bad, "| reference streams through the GPU decoder", ndec, "damaged copies refused", nrefused)
+print("iterations", it, "bytes", total, "failures", bad, "| reference streams through the GPU decoder", ndec, "damaged copies refused", nrefused, "| brotli: reference streams through the GPU decoder", nbdec, "damaged copies refused", nbref)
