@@ -440,6 +440,13 @@ __device__ __forceinline__ void brd_literals(BrdBits& hb, uint32_t m, const uint
 }
 
 // (check build -DBRD_PROFILE: chunk 0 prints the clock ticks it spent per section)
+// (check build -DBRD_STATS, emulator: chunk 0 prints where the stream's bits go -- header, command symbols + extra bits, literals, distances)
+#ifdef BRD_STATS
+#define BRD_BITS(hbv) ((uint64_t)(hbv).pos * 8u - (hbv).n)
+#define BRD_S(k, hbv) { const uint64_t bNow = BRD_BITS(hbv); stat[k] += bNow - bLast; bLast = bNow; }
+#else
+#define BRD_S(k, hbv)
+#endif
 #ifdef BRD_PROFILE
 #define BRD_T(k) { const uint64_t tNow = wall_clock64(); prof[k] += tNow - tLast; tLast = tNow; }
 #else
@@ -480,6 +487,9 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
         BrdMem mem; mem.lds = sArena; mem.hbm = nullptr;          // (the page is taken from the pool when a meta-block needs it, kept for the chunk)
 #ifdef BRD_PROFILE
         uint64_t prof[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tLast = wall_clock64(); uint32_t nCmd = 0, nLit = 0, nMeta = 0;
+#endif
+#ifdef BRD_STATS
+        uint64_t stat[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, bLast = 0; uint32_t sCmdN = 0, sLitN = 0, sDistN = 0, sMetaN = 0, sCtxN = 0, sRingN = 0, sImplN = 0; uint64_t sCopyBytes = 0;
 #endif
         uint32_t status = BRD_OK, pos = 0, flushed = 0;             // output [flushed, pos) is in the ring only
         bool unfenced = false;                                    // a flush has stored to HBM since the wave last waited for its stores
@@ -634,6 +644,10 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
             const uint8_t* const cmapL = sArena + sMeta.cmapL; const uint8_t* const cmapD = sArena + sMeta.cmapD; const uint8_t* const modes = sArena + sMeta.modes;
             gc_wave_sync();                                       // (sMeta is lane 0's to write again from here; the tables are whole)
             BRD_T(1)
+            BRD_S(0, hb)
+#ifdef BRD_STATS
+            sMetaN++; if (nTreesL > 1u) sCtxN++;
+#endif
             const uint32_t mEnd = pos + mlen;
             uint32_t mode = gc_uniform(modes[0]);
             const uint8_t* cmRow = cmapL;
@@ -656,6 +670,10 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
                 uint32_t cplen = ciC & 0xFFFFu; if (ciC >> 16) cplen += brd_take(hb, ciC >> 16);
                 if (pos + ins > mEnd) { status = BRD_CORRUPT; break; }
                 BRD_T(2)
+                BRD_S(1, hb)
+#ifdef BRD_STATS
+                sCmdN++; sLitN += ins; sCopyBytes += cplen; if (cs < 128u) sImplN++;
+#endif
 #ifdef BRD_PROFILE
                 nCmd++; nLit += ins;
 #endif
@@ -697,6 +715,7 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
                     if (nCtxTab) { g2 = g1; g1 = gc_uniform(BRD_CLASS(lit)); }
                 }
                 BRD_T(3)
+                BRD_S(2, hb)
                 if (hb.over) { status = BRD_CORRUPT; break; }
                 if (pos == mEnd) break;                           // the meta-block ends behind the literals: no copy
                 int dist;
@@ -770,6 +789,13 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
                 if (push) { r4 = r3; r3 = r2; r2 = r1; r1 = dist; }
                 if (pos + cplen > mEnd) { status = BRD_CORRUPT; break; }
                 BRD_T(4)
+                BRD_S(3, hb)
+#ifdef BRD_STATS
+                if (cs >= 128u) { sDistN++; if (dcode < 16u) sRingN++; }
+#ifdef BRD_DUMP
+                if (c == 0u && lane == 0u) printf("C %u %u %d %u\n", pos, cplen, dist, cs < 128u ? 0u : (dcode < 16u ? 1u : 2u));
+#endif
+#endif
                 {
                     const uint32_t d = (uint32_t)dist;
                     uint32_t v = 0;                               // the byte of this lane's last turn
@@ -808,6 +834,10 @@ __device__ __forceinline__ void brd_kernel_body(const uint8_t* __restrict__ src,
         }
         gc_wave_sync();
         brd_flush<RING>(sRing, out, flushed, pos, lane);
+#ifdef BRD_STATS
+        if (c == 0u && lane == 0u) printf("brd stats chunk 0: bytes %u meta-blocks %u (with context maps %u) commands %u (implicit distance %u) literals %u distance symbols %u (ring codes %u) copy bytes %llu | bits: header %llu command %llu literal %llu distance %llu\n",
+            pos, sMetaN, sCtxN, sCmdN, sImplN, sLitN, sDistN, sRingN, (unsigned long long)sCopyBytes, (unsigned long long)stat[0], (unsigned long long)stat[1], (unsigned long long)stat[2], (unsigned long long)stat[3]);
+#endif
 #ifdef BRD_PROFILE
         BRD_T(6)
         if (c == 0u && lane == 0u) printf("brd profile chunk 0: bytes %u commands %u literals %u | ticks (100 MHz): header %llu tables %llu command %llu literals %llu distance %llu copy %llu rest %llu\n", pos, nCmd, nLit,
