@@ -78,6 +78,7 @@ extern "C" __global__ void gc_mf_verify_far2_kernel_p8(const uint8_t*, uint64_t,
 extern "C" __global__ void gc_mf_deepen_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, uint32_t*, uint32_t*);
 extern "C" __global__ void gc_mf_vparse_tile_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, GcSeqRaw*, uint8_t*, GcBlockMeta*, uint32_t*, uint32_t*, unsigned long long*);
 extern "C" __global__ void gc_mf_vparse_tile_kernel_p8(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, const GcMfEntry*, GcSeqRaw*, uint8_t*, GcBlockMeta*, uint32_t*, uint32_t*, unsigned long long*);
+extern "C" __global__ void gc_mf_ringparse_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcSeqRaw*, uint8_t*, GcBlockMeta*);
 extern "C" __global__ void gc_mf_parse_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, const uint32_t*, GcSeqRaw*, uint8_t*, GcBlockMeta*, uint16_t*, uint32_t);
 extern "C" __global__ void gc_mf_short_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint16_t*);
 extern "C" __global__ void gc_mf_dp2_kernel(const uint8_t*, uint64_t, uint32_t, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t, const uint32_t*, const uint16_t*, const uint16_t*, uint32_t*, uint32_t*);
@@ -125,6 +126,8 @@ struct gc_ctx {
     uint32_t shortPlain;      // overlapping frames: the pass with 4- / 3-byte keys runs over frames that tile the input (launch_finder_part)
     uint32_t farPass2;        // one more pass of the far kind with keys of 32 / 24 bytes (gc_lz_window.hip MF_FAR2)
     uint32_t laneParse;       // the price-based parse is W7L (a lane per window, repeat distances at every node) rather than W7
+    uint32_t ringGeom;        // W6r: threads per block (16 per sub-block)
+    uint32_t ringParse;       // W6r (brotli qualities 5-7): the parse walks the records in order with the last four distances as candidates; the value = shortest copy at a ring distance, 0 = W6
     uint32_t dbgFrameBlocks, dbgPartFrames;   // test hooks (env GC_FRAME_BLOCKS / GC_PART_FRAMES): small frames / parts so that
                                               // the multi-frame and multi-part paths can be exercised on small inputs
     hipEvent_t ev[8];         // 0 lz start, 1 lz end, 2 huf end, 3 seq start, 4 seq end, 5 plan start, 6 plan end, 7 emit end
@@ -171,8 +174,8 @@ static bool gc_env_u32(const char* name, uint32_t lo, uint32_t hi, uint32_t* out
     const char* e = getenv(name);
     if (!e || !*e) return false;
     char* end = nullptr;
-    const long v = strtol(e, &end, 10);
-    if (end == e || v < (long)lo || v > (long)hi) return false;
+    const long long v = strtoll(e, &end, 10);
+    if (end == e || v < (long long)lo || v > (long long)hi) return false;
     *out = (uint32_t)v;
     return true;
 }
@@ -569,7 +572,12 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
         }
         HIPCHK(c, hipEventRecord(ev[9], st));
         GC_LAUNCH(gc_mf_parse_kernel, perB * GC_XCDS, GC_MF_PARSE_T, st, src, (uint64_t)n, nBlocks, perB, 0u, (const uint32_t*)dp, seqRaw, lit, meta, (uint16_t*)nullptr, 0u);
-    } else
+    } else if (c->ringParse) {
+        if ((c->ringParse >> 8) & 0xFFu)                               // W6r on the blocks that W6's parse shows to come back to their last distances
+            GC_LAUNCH(gc_mf_parse_kernel, perB * GC_XCDS, GC_MF_PARSE_T, st, src, (uint64_t)n, nBlocks, perB, c->lazyDepth, (const uint32_t*)rec, seqRaw, lit, meta, (uint16_t*)nullptr, 0u);
+        GC_LAUNCH(gc_mf_ringparse_kernel, perB * GC_XCDS, c->ringGeom, st, src, (uint64_t)n, nBlocks, perB, c->lazyDepth, c->ringParse, (const uint32_t*)rec, seqRaw, lit, meta);
+    }
+    else
         GC_LAUNCH(gc_mf_parse_kernel, perB * GC_XCDS, GC_MF_PARSE_T, st, src, (uint64_t)n, nBlocks, perB, c->lazyDepth, (const uint32_t*)rec, seqRaw, lit, meta, (uint16_t*)nullptr, 0u);
     HIPCHK(c, hipEventRecord(ev[6], st));
     (void)prof;
@@ -670,6 +678,7 @@ extern "C" int gc_zstd_compress_device(gc_ctx* c, const void* d_src, size_t n, v
     c->searchDepth = zstd_search_depth(level); c->searchShallow = c->searchDepth < 2u ? c->searchDepth : 2u;
     if (gc_env_u32("GC_SEARCH_DEPTH", 0u, 64u, &c->searchDepth)) c->searchShallow = c->searchDepth < 2u ? c->searchDepth : 2u;      // test hook
     gc_env_u32("GC_SEARCH_SHALLOW", 0u, 64u, &c->searchShallow);                                // test hook: links followed by every position
+    c->ringParse = 0u;
     c->farPass = level >= 5 ? 1u : 0u;            // where the reference searches chains / trees (lazy2 and up).  Measured (run 29, 32 MiB): level 9
                                                   // 1.027 -> 0.984 x the reference on text, level 12 1.040 -> 1.001 x.  Round 6: from level 5 (was 7) -- the reference's greedy / lazy
                                                   // strategies at 5-6 walk hash chains (zstd_lazy.c:667, searchLog 3: clevels.h:33-34), and on real sources the first pass alone was
@@ -903,6 +912,7 @@ extern "C" int gc_flzma2_compress_device(gc_ctx* c, const void* d_src, size_t n,
     c->searchShallow = level >= 5 ? 2u : 0u;
     c->searchDepth = level >= 5 ? (level >= 8 ? 16u : 12u) : 0u;    // links followed where a tile has long matches, by the positions that start one (two links elsewhere: gc_mf_deepen_kernel).
                                                                     // Real source text (64 MiB): two links everywhere 1.030 x the reference, six everywhere 1.017 (run r03_depth)
+    c->ringParse = 0u;
     c->farPass = level >= 3 ? 1u : 0u;            // the reference's match table resolves to depth 42 at level 5 (fl2_compress.c:37-104);
                                                   // level 3 (run 30x, 32 MiB): 1.071 -> 1.026 x the reference on text
     c->shortPass = level >= 3 ? 1u : 0u;          // ... and holds the nearest match of >= 2 bytes for every position
@@ -1098,6 +1108,8 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass);                                            // test hook
     c->shortPlain = 0u; c->smallWin2k = 0u; c->allLengths = 0u;
     c->farPass2 = 0u; gc_env_u32("GC_FAR2_PASS", 0u, 1u, &c->farPass2);
+    c->ringParse = level >= 5 ? (2u | (7u << 8) | (4u << 16) | (16u << 24)) : 0u; gc_env_u32("GC_BR_RING", 0u, 0xFFFFFFFFu, &c->ringParse);
+    c->ringGeom = 256u; { uint32_t g = 0; if (gc_env_u32("GC_BR_RING_GEOM", 64u, 256u, &g) && (g & 63u) == 0u) c->ringGeom = g; }     // test hook: 64 / 128 / 256 threads = 4 / 8 / 16 sub-blocks
     c->laneParse = 0u; c->lastCodecHint = 2; c->priceMinLen = 3u; c->priceLitCtx = 0u;     // copies of >= 3 bytes (a 2-byte copy at a fresh distance never pays in brotli), one literal code per meta-block
     c->priceParse = level >= 8 ? 1u : 0u;         // the reference parses greedily up to quality 9 (zopfli from 10).  Measured at quality 6
                                                   // (run 28, 64 MiB per corpus): greedy + far pass 0.979-1.002 x the reference at 16.6 GB/s,

@@ -21,6 +21,10 @@
 // W6 8 R (records, twice) + sequences and literals out.
 #include "gc_mf.h"
 #include "gc_lz_parse.h"
+#ifdef HIPEMU
+#include <stdio.h>
+#include <stdlib.h>
+#endif
 
 // kernel names of this geometry (gc_mf.h: the fast geometry is compiled from gc_lz_window_p8.hip with the suffix _p8)
 #ifdef GC_MF_FAST
@@ -1189,6 +1193,184 @@ MFK(gc_mf_vparse_tile_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize,
 }
 
 #ifndef GC_MF_FAST       // (W6 works on blocks, not tiles: one copy)
+// ------------------------------------------------------------------------------------------------ W6r ring-aware parse (BROTLI qualities 5-7, round 6)
+// The reference's hasher tries the LAST DISTANCES first at every position and scores them without their distance bits (C/brotli/enc/hash_longest_match64_inc.h:185-222,
+// BackwardReferenceScoreUsingLastDistance / ...PenaltyUsingLastDistance enc/hash.h:113-131), inside the greedy loop with one-step look-ahead of
+// enc/backward_references_inc.h:38-140.  On data that repeats with small differences -- machine code, tables of records -- it stays at one distance from copy to copy:
+// on ROCm shared objects 45 K of its 120 K commands per 4 MiB reuse the last distance against 25 K of this engine's with W6 + B1's substitution, and those distance
+// bits were the whole difference in size (tests/emu -DBRD_STATS).  Which distances are "last" is a property of the PARSE, so this cannot be a finder pass: W6r walks
+// the finder's records in order and knows its own ring.  To keep the walk short a block is cut into sub-blocks ("streams", 16 of 8 KiB with 256 threads) that are
+// walked at the same time, each by 16 lanes: lane (k, c) of a stream compares chunk c (16 bytes) behind position p with the bytes ring distance k in front of them; the
+// four chunks' byte-equality masks side by side (two shuffles) give the length at p and, shifted by one, the length at p + 1 -- one memory round trip per step tests four
+// distances over 64 bytes at both positions (a longer copy goes on in the next step: its distance is the ring's first then).  A stream starts 256 positions in front of
+// its sub-block and stores nothing there, so that it arrives with the ring of the data in front; it clips its copies at its end (B1 joins pieces of one distance that
+// touch).  Where neither p nor p + 1 has a candidate and four positions behind the last copy have been looked at one by one, the walk jumps to the next position with a
+// record (16 records are read per step).  Sub-blocks write sequences and literals to their own share of the block's arrays; the
+// workgroup closes the gaps at the end.  Scores in W6's units (lz_gain: 4 per byte, 1 per distance bit): last distance 4 len + 4, ring entries 1-3 4 len + 1, the
+// position behind wins with 7 more (the reference: + 15 and - 24 ... - 28 on a scale of 135 per byte and 30 per distance bit, cost_diff_lazy 175 = 2 / -1 / 5 in these
+// units; emulator, 4 MiB of shared objects: 1.0409 x the reference with those, 1.0351 with 4 / 1 / 7; real sources and lz-7zip do not care).
+#define PZR_G0   4                    // score of a copy at the last distance: 4 per byte + this (W6's lz_gain: 4 per byte - 1 per distance bit)
+#define PZR_GK   1                    // ... at ring entries 1-3
+#define PZR_LAZY 7                    // the position behind wins with this much more
+#define PZR_LPS 16u                   // lanes per sub-block: 4 ring distances x 4 chunks of 16 bytes
+#define PZR_MAX_STREAMS 16u           // 256 threads
+// bit i of the result: byte i of the two 16-byte windows is the same
+__device__ __forceinline__ uint32_t pzr_eq16(LzW16 x, LzW16 y)
+{
+    uint32_t m = 0;
+    const uint32_t d[4] = { (uint32_t)(x.a ^ y.a), (uint32_t)((x.a ^ y.a) >> 32), (uint32_t)(x.b ^ y.b), (uint32_t)((x.b ^ y.b) >> 32) };
+#pragma unroll
+    for (uint32_t i = 0; i < 4u; i++) {
+        const uint32_t nzb = (((d[i] & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | d[i]) & 0x80808080u;       // bit 7 of every byte that differs
+        const uint32_t eq = (~nzb & 0x80808080u) >> 7;                                           // bit 0 of every byte that is the same
+        m |= (((eq * 0x00204081u) >> 21) & 0xFu) << (4u * i);                                    // (bits 0 / 8 / 16 / 24 -> bits 21..24 of the product)
+    }
+    return m;
+}
+extern "C" __global__ void __launch_bounds__(256)
+gc_mf_ringparse_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t lazy, uint32_t ringMin, const uint32_t* __restrict__ rec,
+                       GcSeqRaw* __restrict__ seqRaw, uint8_t* __restrict__ lit, GcBlockMeta* __restrict__ meta)
+{
+    __shared__ uint32_t sCntS[PZR_MAX_STREAMS], sCntL[PZR_MAX_STREAMS];
+    const uint32_t t = threadIdx.x, lane = t & 63u, T = blockDim.x, nStreams = T / PZR_LPS;
+    const uint32_t b = mf_item(blockIdx.x, per);
+    if (b >= nBlocks) return;
+    const uint64_t base = (uint64_t)b * GC_ZSTD_BLOCK_MAX;
+    const uint32_t n = (uint32_t)((srcSize - base) < GC_ZSTD_BLOCK_MAX ? (srcSize - base) : GC_ZSTD_BLOCK_MAX);
+    const uint32_t* R = rec + base;
+    GcSeqRaw* mySeq = seqRaw + (uint64_t)b * GC_MAX_SEQ_PER_BLOCK;
+    uint8_t* myLit = lit + (uint64_t)b * GC_ZSTD_BLOCK_MAX;
+    const uint8_t* bsrc = src + base;
+    const uint32_t st = t / PZR_LPS, j = t % PZR_LPS, k = j >> 2, ch = j & 3u, g0 = lane & ~(PZR_LPS - 1u);
+    const uint32_t sub = ((n + nStreams * 64u - 1u) / (nStreams * 64u)) * 64u;
+    const uint32_t seqCap = GC_MAX_SEQ_PER_BLOCK / nStreams;
+    const uint32_t p0 = st * sub, pEnd = p0 < n ? (n - p0 < sub ? n : p0 + sub) : p0;
+    const uint32_t ringLim = (srcSize - base) >= 96u ? (uint32_t)((srcSize - base - 96u) < n ? (srcSize - base - 96u) : n) : 0u;   // (16-byte reads up to 80 bytes behind p)
+    GcSeqRaw* sq = mySeq + st * seqCap;
+    uint8_t* lq = myLit + p0;
+    const uint32_t quietMin = (ringMin >> 16) & 0xFFu, warm = (ringMin >> 24) * 16u, selShift = (ringMin >> 8) & 0xFFu;
+    ringMin &= 0xFFu;
+    // ---- which blocks: W6 has parsed the block already; only where its sequences come back to a distance of the three in front of them (one in 2^selShift or more: sources,
+    //      machine code, tables; text does it once in a thousand) is the block walked again -- elsewhere W6r's result is W6's (measured: web-text, text 0.0 / + 0.1 %)
+    if (selShift) {
+        __shared__ uint32_t sSel;
+        if (t == 0u) sSel = 0u;
+        __syncthreads();
+        const uint32_t nRaw = meta[b].nSeqRaw, nScan = nRaw < 4096u ? nRaw : 4096u;
+        uint32_t cnt = 0;
+        for (uint32_t i = 3u + t; i < nScan; i += T) {
+            const GcSeqRaw a = mySeq[i], a1 = mySeq[i - 1u], a2 = mySeq[i - 2u], a3 = mySeq[i - 3u];
+            const uint32_t o = a.offml >> 8, o1 = a1.offml >> 8;
+            if (o == o1 ? a.litRank != a1.litRank : (o == (a2.offml >> 8) || o == (a3.offml >> 8))) cnt++;        // (same distance without literals in between: pieces of one copy)
+        }
+        cnt = gc_wave_sum(cnt);
+        if (lane == 0u && cnt) atomicAdd(&sSel, cnt);
+        __syncthreads();
+        if ((sSel << selShift) < nScan) return;
+    }
+    // the walk starts `warm` positions in front of the sub-block and stores nothing there: it arrives with the ring (and the copy that is under way) of the data in front
+    uint32_t p = p0 < pEnd ? (p0 > warm ? p0 - warm : 0u) : p0, nS = 0, nL = 0, r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    uint32_t quiet = 0;                                           // positions without a candidate since the last copy
+    const uint32_t nm1 = n - 1u;
+    for (;;) {
+        const bool act = p < pEnd;
+        if (!__any(act)) break;
+        // the records of p .. p + 15 (lane j: p + j) and the bytes of p .. p + 63 (lane j: p + 4 j ..): candidates of this step, and where to go if there are none.
+        // ALL loads of the step are issued together from addresses that are valid in every lane (clamped; what a lane may not use is zeroed afterwards): a load behind
+        // a per-lane condition is waited for on the spot (hipcc 7.2 put seven round trips into the step that way)
+        const bool wide = act && p < ringLim;                                  // (80 bytes behind p can be read)
+        const uint32_t dk = k == 0u ? r0 : (k == 1u ? r1 : (k == 2u ? r2 : r3));
+        const bool tst = wide && dk != 0u;
+        const uint32_t q = p + j;
+        uint32_t rw = R[q < nm1 ? q : nm1];
+        uint32_t lw = bsrc[p < nm1 ? p : nm1];
+        uint32_t eq = 0;                                                       // bit i: byte p + 16 ch + i equals the byte dk in front of it
+        if (ringLim) {                                                         // (uniform: the input has 96 bytes behind the block's first position)
+            uint32_t lw4; __builtin_memcpy(&lw4, bsrc + (wide ? p + 4u * j : 0u), 4);
+            const uint64_t a = base + (tst ? p : 0u) + 16u * ch; const uint32_t dd = tst ? dk : 0u;
+            LzW16 xa = lz_ld16(src, a), ya = lz_ld16(src, a - dd);
+#ifndef HIPEMU
+            asm volatile("" : "+v"(xa.a), "+v"(xa.b), "+v"(ya.a), "+v"(ya.b), "+v"(lw4), "+v"(rw), "+v"(lw));
+#endif
+            if (wide) lw = lw4;
+            if (tst) eq = pzr_eq16(xa, ya);
+        }
+        if (!act || q >= pEnd) rw = 0u;
+        // the four chunks of a distance side by side: 64 bits, from which the length at p and the length at p + 1 are read (the second without loads of its own)
+        const uint32_t e1 = __shfl_xor(eq, 1), pair = (ch & 1u) ? (e1 | (eq << 16)) : (eq | (e1 << 16));
+        const uint32_t e2 = __shfl_xor(pair, 2);
+        const uint64_t M = (ch & 2u) ? ((uint64_t)e2 | ((uint64_t)pair << 32)) : ((uint64_t)pair | ((uint64_t)e2 << 32));
+        const uint32_t lenA = ~M ? gc_ctz64(~M) : 64u, lenB = ~(M >> 1) ? gc_ctz64(~(M >> 1)) : 64u;              // (lenB <= 63: M >> 1 has a zero on top)
+        const uint32_t lenAB = lenA | (lenB << 8);
+        const uint32_t q0 = __shfl(lenAB, (int)g0), q1 = __shfl(lenAB, (int)(g0 + 4u)), q2 = __shfl(lenAB, (int)(g0 + 8u)), q3 = __shfl(lenAB, (int)(g0 + 12u));
+        const uint32_t rec0 = __shfl(rw, (int)g0), rec1 = __shfl(rw, (int)(g0 + 1u)), rec2 = __shfl(rw, (int)(g0 + 2u));
+        const uint64_t bz = __ballot(rw != 0u);
+        const uint32_t nz = (uint32_t)(bz >> g0) & 0xFFFFu;                    // bit i: position p + i has a record
+        if (!act) continue;
+        // ---- the best candidate at p and at p + 1 (identical in the lanes of the stream)
+        const bool em = p >= p0;                                              // (false: still in front of the sub-block)
+        const uint32_t room = (em ? pEnd : p0) - p;
+        uint32_t bLen = 0, bOff = 0; int bG = -1000;
+        uint32_t cLen = 0; int cG = -1000;
+        {
+            uint32_t l = rec0 & 0xFFu; if (l > room) l = room;
+            if (l >= 2u) { bLen = l; bOff = rec0 >> 8; bG = lz_gain(l, bOff); }
+            l = rec1 & 0xFFu; if (l + 1u > room) l = room - 1u;
+            if (l >= 2u) { cLen = l; cG = lz_gain(l, rec1 >> 8); }
+        }
+#define PZR_TRY(qq, d, kk) { uint32_t l = (qq) & 0xFFu; if (l > room) l = room; int g = (int)(4u * l) + ((kk) == 0u ? PZR_G0 : PZR_GK); \
+                            if ((d) != 0u && l >= ringMin + ((kk) >= 2u ? 1u : 0u) && g > bG) { bLen = l; bOff = (d); bG = g; } \
+                            l = (qq) >> 8; if (l + 1u > room) l = room - 1u; g = (int)(4u * l) + ((kk) == 0u ? PZR_G0 : PZR_GK); \
+                            if ((d) != 0u && l >= ringMin + ((kk) >= 2u ? 1u : 0u) && g > cG) { cLen = l; cG = g; } }
+        PZR_TRY(q0, r0, 0u) PZR_TRY(q1, r1, 1u) PZR_TRY(q2, r2, 2u) PZR_TRY(q3, r3, 3u)
+#undef PZR_TRY
+        bool take = bLen != 0u && nS < seqCap;
+        if (take && lazy >= 1u && cLen != 0u && cG >= bG + PZR_LAZY) take = false;
+        if (take && lazy >= 2u) { const uint32_t l2 = rec2 & 0xFFu; if (l2 > bLen + 1u && l2 + 2u <= room && lz_gain(l2, rec2 >> 8) > bG + 8) take = false; }
+        if (take) {
+            if (em && j == 0u) { GcSeqRaw r; r.litRank = nL; r.offml = (bOff << 8) | bLen; sq[nS] = r; }
+            nS += em ? 1u : 0u; p += bLen; quiet = 0;
+            if (bOff != r0) { r3 = r2; r2 = r1; r1 = r0; r0 = bOff; }
+        } else {
+            // literals: one -- or, where neither p nor p + 1 has a candidate and the positions just behind a copy have been looked at, all up to the next position with a
+            // record (the ring distances are not tried in between: what ends a copy is a few differing bytes, and the finder lists the continuation behind them itself)
+            uint32_t run = 1u;
+            if (wide && bLen == 0u && cLen == 0u && quiet >= quietMin) { const uint32_t m = nz & ~3u; run = m ? (uint32_t)__builtin_ctz(m) : PZR_LPS; if (run > room) run = room; }
+            if (em && 4u * j < run) {
+                lq[nL + 4u * j] = (uint8_t)lw;
+                if (4u * j + 1u < run) lq[nL + 4u * j + 1u] = (uint8_t)(lw >> 8);
+                if (4u * j + 2u < run) lq[nL + 4u * j + 2u] = (uint8_t)(lw >> 16);
+                if (4u * j + 3u < run) lq[nL + 4u * j + 3u] = (uint8_t)(lw >> 24);
+            }
+            nL += em ? run : 0u; p += run; quiet += run;
+        }
+    }
+    if (j == 0u) { sCntS[st] = nS; sCntL[st] = nL; }
+    __syncthreads();
+    // ---- close the gaps between the sub-blocks' shares (every move goes towards the front: a share is read T entries at a time, then stored)
+    uint32_t preS = sCntS[0], preL = sCntL[0];
+    for (uint32_t s = 1; s < nStreams; s++) {
+        const uint32_t cS = sCntS[s], cL = sCntL[s];
+        const GcSeqRaw* fromS = mySeq + s * seqCap; const uint8_t* fromL = myLit + s * sub;
+        for (uint32_t i0 = 0; i0 < cS; i0 += T) {
+            GcSeqRaw r; r.litRank = 0; r.offml = 0;
+            if (i0 + t < cS) r = fromS[i0 + t];
+            __syncthreads();
+            if (i0 + t < cS) { r.litRank += preL; mySeq[preS + i0 + t] = r; }
+            __syncthreads();
+        }
+        for (uint32_t i0 = 0; i0 < cL; i0 += T) {
+            uint8_t v = 0;
+            if (i0 + t < cL) v = fromL[i0 + t];
+            __syncthreads();
+            if (i0 + t < cL) myLit[preL + i0 + t] = v;
+            __syncthreads();
+        }
+        preS += cS; preL += cL;
+    }
+    if (t == 0u) { GcBlockMeta m; m.nSeqRaw = preS; m.nLit = preL; meta[b] = m; }
+}
+
 extern "C" __global__ void __launch_bounds__(PZ_T)
 gc_mf_parse_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32_t nBlocks, uint32_t per, uint32_t lazy, const uint32_t* __restrict__ rec,
                    GcSeqRaw* __restrict__ seqRaw, uint8_t* __restrict__ lit, GcBlockMeta* __restrict__ meta, uint16_t* __restrict__ priceTab,

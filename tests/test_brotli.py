@@ -119,6 +119,7 @@ def test_emu_last_distance_substitution(pkg, O, emu_lib_path, monkeypatch):
         if x.size < BLK:
             continue                                                                                                        # (the image holds no such data)
         sizes = {}
+        monkeypatch.setenv("GC_BR_RING", "0")            # W6's parse (W6r tries the ring distances itself: behind it the step finds nothing on these inputs)
         for passes in ("0", "1", "2"):
             monkeypatch.setenv("GC_BR_REPSUB", passes)
             e = pkg.BrotliEncoder(lib_path=emu_lib_path, level=6)
@@ -131,6 +132,77 @@ def test_emu_last_distance_substitution(pkg, O, emu_lib_path, monkeypatch):
         assert sizes["1"] <= sizes["0"] * 1.0005 and sizes["2"] <= sizes["0"] * 1.0005, (name, sizes)       # (the prefix codes move with the symbols: a few bytes either way where nothing is gained)
         if name != "text":
             assert sizes["1"] < sizes["0"], (name, sizes)
+
+
+def _ring_word(ring_min=2, select=7, quiet=4, warm16=16):
+    """hook GC_BR_RING as gc_api.hip reads it: shortest copy at a ring distance | block selection (1 in 2^select sequences of W6's parse, 0 = every block) << 8 |
+    single steps behind a copy << 16 | warm-up positions / 16 << 24; 0 = W6 alone"""
+    return str(ring_min | (select << 8) | (quiet << 16) | (warm16 << 24))
+
+
+def _code_with(pkg, emu_lib_path, monkeypatch, x, level=6, **env):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    e = pkg.BrotliEncoder(lib_path=emu_lib_path, level=level)
+    try:
+        return e.code(x)
+    finally:
+        e.close()
+        for k in env:
+            monkeypatch.delenv(k, raising=False)
+
+
+def test_emu_ring_parse_on_tables_and_machine_code(pkg, O, emu_lib_path, monkeypatch):
+    """W6r (gc_lz_window.hip, qualities 5-7): the parse walks the finder's records in order and tries its own last four distances first, as the reference's hasher does
+    (hash_longest_match64_inc.h:185-222).  Tables of records and machine code must get clearly smaller than with W6 alone (hook GC_BR_RING=0), text must come out as W6
+    left it (the block selection finds no block that returns to its distances), and every stream decodes under the reference decoder."""
+    _need_ref(O)
+    rng = np.random.default_rng(11)
+    rec = rng.integers(0, 256, size=(12000, 24), dtype=np.uint8)
+    rec[:, :10] = rec[0, :10]; rec[:, 14:20] = (np.arange(12000)[:, None] >> np.array([0, 8, 16, 0, 8, 16])) & 0xFF
+    cases = [("records", rec.reshape(-1).copy(), 0.97), ("text", O.corpus("text-zipf", 3 * BLK + 5), None)]
+    obj = O.corpus("real-bin", 8 * BLK)
+    if obj.size >= 8 * BLK:
+        cases.append(("objects", obj, 0.975))
+    for name, x, bar in cases:
+        w6 = _code_with(pkg, emu_lib_path, monkeypatch, x, GC_BR_RING="0")
+        ring = _code_with(pkg, emu_lib_path, monkeypatch, x)
+        forced = _code_with(pkg, emu_lib_path, monkeypatch, x, GC_BR_RING=_ring_word(select=0))
+        for c in (w6, ring, forced):
+            assert np.array_equal(O.ref_brotlimt_decompress(c, x.size, 2), x), name
+        if bar is None:
+            assert np.array_equal(ring, w6), name                       # no block selected: W6's parse, byte for byte
+            assert len(forced) <= 1.005 * len(w6), (name, len(forced), len(w6))
+        else:
+            assert len(ring) <= bar * len(w6), (name, len(ring), len(w6))
+            assert len(forced) <= 1.001 * len(ring), (name, len(forced), len(ring))     # (the selection reads W6's parse: a block whose W6 parse never returns to a distance is left alone although W6r would gain there)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 95, 96, 97, 160, 1000, 4097, BLK - 1, BLK, BLK + 1, 2 * BLK + 12345])
+def test_emu_ring_parse_edge_sizes(pkg, O, emu_lib_path, monkeypatch, n):
+    """W6r forced on every block (selection off) at the sizes where its sub-blocks are ragged or empty, the input ends inside the 96 bytes in which no ring distance is
+    tried, or a block has one position; the three workgroup sizes (4 / 8 / 16 sub-blocks) and no warm-up / no single steps."""
+    _need_ref(O)
+    rng = np.random.default_rng(n)
+    rec = rng.integers(0, 256, size=(n // 12 + 2, 12), dtype=np.uint8); rec[:, :7] = rec[0, :7]
+    x = rec.reshape(-1)[:n].copy()
+    for geom, word in (("256", _ring_word(select=0)), ("128", _ring_word(select=0, warm16=0)), ("64", _ring_word(select=0, quiet=0, ring_min=3))):
+        for level in (5, 7):
+            c = _code_with(pkg, emu_lib_path, monkeypatch, x, level=level, GC_BR_RING=word, GC_BR_RING_GEOM=geom)
+            assert np.array_equal(O.ref_brotlimt_decompress(c, x.size, 2), x), (n, geom, level)
+
+
+def test_emu_ring_parse_literal_runs_and_long_copies(pkg, O, emu_lib_path, monkeypatch):
+    """runs of literals longer than a step sees (random bytes between repeats), copies longer than a step compares (64 bytes) at one distance, a sub-block that is all
+    literals beside one that is one copy, and a share of the sequence array that fills up (copies of two bytes at the last distance)"""
+    _need_ref(O)
+    rng = np.random.default_rng(3)
+    r = rng.integers(0, 256, size=40_000, dtype=np.uint8)
+    parts = [r, r[:30_000], np.zeros(20_000, dtype=np.uint8), r[5_000:9_000], rng.integers(0, 256, size=25_000, dtype=np.uint8), r[100:30_100]]
+    two = np.tile(np.array([1, 2, 0, 0], dtype=np.uint8), 12_000); two[2::4] = rng.integers(0, 256, size=12_000); two[3::4] = rng.integers(0, 256, size=12_000)    # "ab??" repeated: two-byte copies at distance 4
+    for x in (np.concatenate(parts), two, np.concatenate([two, r, two])):
+        c = _code_with(pkg, emu_lib_path, monkeypatch, x, GC_BR_RING=_ring_word(select=0))
+        assert np.array_equal(O.ref_brotlimt_decompress(c, x.size, 2), x)
 
 
 def test_context_tables_equal_the_reference_tables(O, emu_lib_path):
