@@ -1108,7 +1108,7 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     gc_env_u32("GC_FAR_PASS", 0u, 1u, &c->farPass);                                            // test hook
     c->shortPlain = 0u; c->smallWin2k = 0u; c->allLengths = 0u;
     c->farPass2 = 0u; gc_env_u32("GC_FAR2_PASS", 0u, 1u, &c->farPass2);
-    c->ringParse = level >= 5 ? (2u | (7u << 8) | (4u << 16) | (16u << 24)) : 0u; gc_env_u32("GC_BR_RING", 0u, 0xFFFFFFFFu, &c->ringParse);
+    c->ringParse = level >= 5 ? (2u | (8u << 8) | (4u << 16) | (16u << 24)) : 0u; gc_env_u32("GC_BR_RING", 0u, 0xFFFFFFFFu, &c->ringParse);
     c->ringGeom = 256u; { uint32_t g = 0; if (gc_env_u32("GC_BR_RING_GEOM", 64u, 256u, &g) && (g & 63u) == 0u) c->ringGeom = g; }     // test hook: 64 / 128 / 256 threads = 4 / 8 / 16 sub-blocks
     c->laneParse = 0u; c->lastCodecHint = 2; c->priceMinLen = 3u; c->priceLitCtx = 0u;     // copies of >= 3 bytes (a 2-byte copy at a fresh distance never pays in brotli), one literal code per meta-block
     c->priceParse = level >= 8 ? 1u : 0u;         // the reference parses greedily up to quality 9 (zopfli from 10).  Measured at quality 6

@@ -1265,8 +1265,31 @@ gc_mf_ringparse_kernel(const uint8_t* __restrict__ src, uint64_t srcSize, uint32
         }
         cnt = gc_wave_sum(cnt);
         if (lane == 0u && cnt) atomicAdd(&sSel, cnt);
+        // ... or where the NEXT copy could use the distance of the one in front (W6 takes whatever the finder lists there, so its parse need not show it): a sample of T
+        // records -- the first one at or behind position t n / T, and at the first record behind its end three bytes against the bytes the first one's distance in front
+        __shared__ uint32_t sGo, sSeen;
+        if (t == 0u) { sGo = 0u; sSeen = 0u; }
         __syncthreads();
-        if ((sSel << selShift) < nScan) return;
+        uint32_t go = 0, seen = 0;
+        {
+            uint32_t q = (uint32_t)(((uint64_t)t * n) / T), r = 0;
+            for (uint32_t i = 0; i < 32u && q < n; i++, q++) { r = R[q]; if (r) break; }
+            const uint32_t len = r & 0xFFu, off = r >> 8;
+            uint32_t e = q + len, r2 = 0;
+            if (r != 0u && len < GC_MATCH_CAP) for (uint32_t i = 0; i < 32u && e < n; i++, e++) { r2 = R[e]; if (r2) break; }
+            if (r2 != 0u && e + 8u < ringLim) {
+                seen = 1u;
+                const uint8_t* a = bsrc + e; const uint8_t* c = a - off;
+                if (a[0] == c[0] && a[1] == c[1] && a[2] == c[2]) go = 1u;
+            }
+        }
+        go = gc_wave_sum(go); seen = gc_wave_sum(seen);
+        if (lane == 0u) { if (go) atomicAdd(&sGo, go); if (seen) atomicAdd(&sSeen, seen); }
+        __syncthreads();
+#ifdef HIPEMU
+        if (t == 0u && getenv("PZR_COUNT")) printf("PZR block %u: %u of %u sequences return to a distance, %u of %u sampled copies go on\n", b, sSel, nScan, sGo, sSeen);
+#endif
+        if ((sSel << selShift) < nScan && sGo * 16u < sSeen) return;
     }
     // the walk starts `warm` positions in front of the sub-block and stores nothing there: it arrives with the ring (and the copy that is under way) of the data in front
     uint32_t p = p0 < pEnd ? (p0 > warm ? p0 - warm : 0u) : p0, nS = 0, nL = 0, r0 = 0, r1 = 0, r2 = 0, r3 = 0;

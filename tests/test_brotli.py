@@ -134,7 +134,7 @@ def test_emu_last_distance_substitution(pkg, O, emu_lib_path, monkeypatch):
             assert sizes["1"] < sizes["0"], (name, sizes)
 
 
-def _ring_word(ring_min=2, select=7, quiet=4, warm16=16):
+def _ring_word(ring_min=2, select=8, quiet=4, warm16=16):
     """hook GC_BR_RING as gc_api.hip reads it: shortest copy at a ring distance | block selection (1 in 2^select sequences of W6's parse, 0 = every block) << 8 |
     single steps behind a copy << 16 | warm-up positions / 16 << 24; 0 = W6 alone"""
     return str(ring_min | (select << 8) | (quiet << 16) | (warm16 << 24))
