@@ -15,8 +15,8 @@ CASES = [("real-src", 64 * MiB), ("real-bin", 211_900_000), ("real-py", 64 * MiB
 NOT_YET = {("flzma2", "real-src"): "0.998 x the reference in round 4 (1.018 in round 3): inside the band, the entry stays as a guard",
            ("flzma2", "real-bin"): "met in round 5: 1.018 x the reference on all 211.9 MB (model segments over cheap neighbouring blocks, level 5 in overlapping finder frames of 16 MiB groups -- the reference's dictionary at this level; 1.026 in round 4, 1.054 in round 3): the entry stays as a guard",
            ("flzma2", "real-py"): "1.008 x the reference in round 4 (1.017 in round 3): inside the band, the entry stays as a guard",
-           ("brotli", "real-src"): "1.041 x the reference (round 6, 64 MiB: the catch-up, literal context modelling; 1.058 in round 5, 1.084 in round 3).  What is left: the ring distances INSIDE the parse, block splitting, the static dictionary",
-           ("brotli", "real-bin"): "1.073 x the reference (round 6; 1.085 in round 5, 1.106 in round 3: its hasher tries the last distances first at every position)",
+           ("brotli", "real-src"): "1.0205 x the reference (round 6, 64 MiB, run final4: the ring-aware parse W6r; 1.041 before it, 1.058 in round 5, 1.084 in round 3).  What is left: 32 meta-blocks' worth of prefix-code descriptions where the reference writes one meta-block with block types (1 % of the stream), block splitting, the static dictionary",
+           ("brotli", "real-bin"): "met in round 6: 1.012 x the reference (W6r: the parse tries its own last four distances first, as the reference's hasher does; 1.073 before it, 1.085 in round 5, 1.106 in round 3); the entry stays as a guard",
            ("brotli", "real-py"): "1.015 x the reference in round 4 (1.024 in round 3): inside the band, the entry stays as a guard"}
 
 
@@ -54,10 +54,14 @@ def test_zstd_level3_real_data(O, gpu, kind, n):
 
 # The levels between the BASELINE ones on real bytes (round 6; the review of round 5 found zstd 9 on shared objects at 1.060 with no test looking): the lazy range (9, 12), C4's
 # level (19) and FLZMA2's first ultra level, 32 MiB each, level L against the reference's level L.  Figures: MI355X, run s2 of round 6 (tools/gpu_sizes.py).
-LEVEL_CASES = [("zstd", 5, "real-src"), ("zstd", 5, "real-bin"), ("zstd", 6, "real-src"), ("zstd", 9, "real-src"), ("zstd", 9, "real-bin"), ("zstd", 12, "real-src"), ("zstd", 12, "real-bin"), ("zstd", 19, "real-src"), ("zstd", 19, "real-bin"), ("flzma2", 7, "real-bin")]
+LEVEL_CASES = [("zstd", 5, "real-src"), ("zstd", 5, "real-bin"), ("zstd", 6, "real-src"), ("zstd", 9, "real-src"), ("zstd", 9, "real-bin"), ("zstd", 12, "real-src"), ("zstd", 12, "real-bin"), ("zstd", 19, "real-src"), ("zstd", 19, "real-bin"), ("flzma2", 7, "real-bin"),
+               ("brotli", 5, "real-bin"), ("brotli", 7, "real-bin"), ("brotli", 5, "real-src"), ("brotli", 7, "real-src"), ("brotli", 9, "real-bin")]      # (brotli 5 / 7: the ring-aware parse W6r, run final4)
 NOT_YET_LEVELS = {("zstd", 19, "real-src"): "1.077 x btultra2 on real sources (round 6: 16 MiB finder frames; 1.095 in round 5, 1.152 in round 4): one merged record per position against the binary tree's list of matches, static prices, no block splitter",
                   ("zstd", 19, "real-bin"): "1.044 x btultra2 on shared objects (round 6; 1.043 in round 5)",
-                  ("flzma2", 7, "real-bin"): "1.041 x the reference's level 7 on shared objects (round 6, first measurement; real sources 1.019)"}
+                  ("flzma2", 7, "real-bin"): "1.041 x the reference's level 7 on shared objects (round 6, first measurement; real sources 1.019)",
+                  ("brotli", 5, "real-src"): "1.038 x the reference's quality 5 on 32 MiB of real sources (round 6, run final4; shared objects 1.001)",
+                  ("brotli", 7, "real-src"): "1.060 x the reference's quality 7 on 32 MiB of real sources (round 6, run final4; shared objects 1.009): its hasher keeps 2^6 candidates per bucket at this quality",
+                  ("brotli", 9, "real-bin"): "1.023 x the reference's quality 9 on shared objects (round 6): the price-based parse W7 without ring distances at its nodes"}
 
 
 @pytest.mark.parametrize("codec,level,kind", LEVEL_CASES)
@@ -69,6 +73,10 @@ def test_levels_between_the_baseline_ones_on_real_data(O, gpu, codec, level, kin
         e = gpu.ZstdEncoder(level=level); c = e.code(x); e.close()
         assert np.array_equal(O.ref_zstd_decompress(c, x.size), x)
         ref = len(O.ref_zstd_compress(x, level))
+    elif codec == "brotli":
+        e = gpu.BrotliEncoder(level=level); c = e.code(x); e.close()
+        assert np.array_equal(O.ref_brotlimt_decompress(c, x.size, THR), x)
+        ref = len(O.ref_brotlimt_compress(x, level, THR))
     else:
         e = gpu.Flzma2Encoder(level=level); c = e.code(x); prop = e.coder_props()[0]; e.close()
         assert np.array_equal(O.ref_lzma2_decode(c, x.size, prop), x)
