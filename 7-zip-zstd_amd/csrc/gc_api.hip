@@ -536,7 +536,8 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
         // (FLZMA2 on the Silesia stand-in: half of the blocks sit right at the threshold, and a W7L launch takes as long for a few blocks as for all of them -- it ends with
         // its slowest wave, and all of its waves fit the device at once -- so the two kernels' times add up: 40 -> 49 ms.)  Test hook GC_DPL: 0 = W7 with its own phase A
         uint32_t laneDp = c->laneParse ? (c->lastCodecHint == 1 ? 1u : 2u) : 0u; gc_env_u32("GC_DPL", 0u, 2u, &laneDp);
-        if (c->lastCodecHint == 2) laneDp = 0u;                        // (brotli: W7 only -- a lane-per-window programme with the distance ring as its repeat set was compiled in rounds 4-5 and never switched on)
+        if (c->lastCodecHint == 2 && !c->laneParse) laneDp = 0u;                        // (brotli, hook GC_BR_LANE=0: W7 only.  Qualities 8-11 run zstd's W7L kernels since round 6: the parse's last distances at every node, which B1 then codes as ring
+                                                                                        //  entries; 32 MiB at quality 9: shared objects 1.023 -> 0.980 x the reference, real sources 1.092 -> 1.038, text / web-text / lz-7zip as before -- phase B goes to W7 there)
         uint8_t* lpr = c->mfLitPrice + (size_t)blk0 * GC_ZSTD_BLOCK_MAX;
         if (laneDp) GC_LAUNCH(gc_mf_litprice_kernel, perB * GC_XCDS, 256, st, src, (uint64_t)n, nBlocks, perB, (const uint16_t*)price, litCtxArg, lpr);
         // (Round 5 built a re-priced SECOND pass over every window -- the first full pass counts its own paths, the second prices from those counts -- behind a hook: text -0.14 .. -0.25 %,
@@ -562,7 +563,7 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
                 if (c->priceMinLen <= 2u) {
                     if (phase == 0u) GC_LAUNCH(gc_mf_dpl2s_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phase | (c->allLengths ? GC_DP_ALLLEN : 0u), dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
                     else GC_LAUNCH(gc_mf_dpl2_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
-                } else if (c->lastCodecHint == 0) {
+                } else {                                           // zstd, and brotli with the ring's first entries standing in for zstd's repeat offsets
                     if (phase == 0u) GC_LAUNCH(gc_mf_dplzs_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phase | (c->allLengths ? GC_DP_ALLLEN : 0u), dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
                     else GC_LAUNCH(gc_mf_dplz_kernel, perL * GC_XCDS, GC_DPL_THREADS, st, src, (uint64_t)n, nBlocks, perL, groupBlocks, phaseK, dps, litCtxArg, recDp, (const uint16_t*)rec3, (const uint16_t*)price, dp, wcp, (const uint8_t*)lpr);
                 }
@@ -1110,7 +1111,8 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     c->farPass2 = 0u; gc_env_u32("GC_FAR2_PASS", 0u, 1u, &c->farPass2);
     c->ringParse = level >= 5 ? (2u | (8u << 8) | (4u << 16) | (16u << 24)) : 0u; gc_env_u32("GC_BR_RING", 0u, 0xFFFFFFFFu, &c->ringParse);
     c->ringGeom = 256u; { uint32_t g = 0; if (gc_env_u32("GC_BR_RING_GEOM", 64u, 256u, &g) && (g & 63u) == 0u) c->ringGeom = g; }     // test hook: 64 / 128 / 256 threads = 4 / 8 / 16 sub-blocks
-    c->laneParse = 0u; c->lastCodecHint = 2; c->priceMinLen = 3u; c->priceLitCtx = 0u;     // copies of >= 3 bytes (a 2-byte copy at a fresh distance never pays in brotli), one literal code per meta-block
+    c->laneParse = level >= 8 ? 1u : 0u; gc_env_u32("GC_BR_LANE", 0u, 1u, &c->laneParse);      // qualities 8-11: W7L with the ring's first entries as its repeat distances, per block where phase A's paths repeat (launch_finder_part)
+    c->lastCodecHint = 2; c->priceMinLen = 3u; c->priceLitCtx = 0u;     // copies of >= 3 bytes (a 2-byte copy at a fresh distance never pays in brotli), one literal code per meta-block
     c->priceParse = level >= 8 ? 1u : 0u;         // the reference parses greedily up to quality 9 (zopfli from 10).  Measured at quality 6
                                                   // (run 28, 64 MiB per corpus): greedy + far pass 0.979-1.002 x the reference at 16.6 GB/s,
                                                   // price-based parse without far pass 0.983-1.012 x at 11.1 GB/s, both 0.93-0.98 x at 9.4 GB/s

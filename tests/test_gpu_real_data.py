@@ -55,13 +55,14 @@ def test_zstd_level3_real_data(O, gpu, kind, n):
 # The levels between the BASELINE ones on real bytes (round 6; the review of round 5 found zstd 9 on shared objects at 1.060 with no test looking): the lazy range (9, 12), C4's
 # level (19) and FLZMA2's first ultra level, 32 MiB each, level L against the reference's level L.  Figures: MI355X, run s2 of round 6 (tools/gpu_sizes.py).
 LEVEL_CASES = [("zstd", 5, "real-src"), ("zstd", 5, "real-bin"), ("zstd", 6, "real-src"), ("zstd", 9, "real-src"), ("zstd", 9, "real-bin"), ("zstd", 12, "real-src"), ("zstd", 12, "real-bin"), ("zstd", 19, "real-src"), ("zstd", 19, "real-bin"), ("flzma2", 7, "real-bin"),
-               ("brotli", 5, "real-bin"), ("brotli", 7, "real-bin"), ("brotli", 5, "real-src"), ("brotli", 7, "real-src"), ("brotli", 9, "real-bin")]      # (brotli 5 / 7: the ring-aware parse W6r, run final4)
+               ("brotli", 5, "real-bin"), ("brotli", 7, "real-bin"), ("brotli", 5, "real-src"), ("brotli", 7, "real-src"), ("brotli", 9, "real-bin"), ("brotli", 9, "real-src")]      # (brotli 5 / 7: the ring-aware parse W6r, run final4)
 NOT_YET_LEVELS = {("zstd", 19, "real-src"): "1.077 x btultra2 on real sources (round 6: 16 MiB finder frames; 1.095 in round 5, 1.152 in round 4): one merged record per position against the binary tree's list of matches, static prices, no block splitter",
                   ("zstd", 19, "real-bin"): "1.044 x btultra2 on shared objects (round 6; 1.043 in round 5)",
                   ("flzma2", 7, "real-bin"): "1.041 x the reference's level 7 on shared objects (round 6, first measurement; real sources 1.019)",
                   ("brotli", 5, "real-src"): "1.038 x the reference's quality 5 on 32 MiB of real sources (round 6, run final4; shared objects 1.001)",
                   ("brotli", 7, "real-src"): "1.060 x the reference's quality 7 on 32 MiB of real sources (round 6, run final4; shared objects 1.009): its hasher keeps 2^6 candidates per bucket at this quality",
-                  ("brotli", 9, "real-bin"): "1.023 x the reference's quality 9 on shared objects (round 6): the price-based parse W7 without ring distances at its nodes"}
+                  ("brotli", 9, "real-bin"): "met in round 6: 0.980 x the reference's quality 9 on shared objects (qualities 8-11 run W7L, the lane-per-window parse with the last distances at every node; 1.023 with W7); a guard",
+                  ("brotli", 9, "real-src"): "1.038 x the reference's quality 9 on 32 MiB of real sources (round 6, W7L; 1.092 with W7)"}
 
 
 @pytest.mark.parametrize("codec,level,kind", LEVEL_CASES)
