@@ -127,7 +127,7 @@ struct gc_ctx {
     uint32_t farPass2;        // one more pass of the far kind with keys of 32 / 24 bytes (gc_lz_window.hip MF_FAR2)
     uint32_t laneParse;       // the price-based parse is W7L (a lane per window, repeat distances at every node) rather than W7
     uint32_t ringGeom;        // W6r: threads per block (16 per sub-block)
-    uint32_t ringParse;       // W6r (brotli qualities 5-7): the parse walks the records in order with the last four distances as candidates; the value = shortest copy at a ring distance, 0 = W6
+    uint32_t ringParse;       // W6r (brotli qualities 5-6): the parse walks the records in order with the last four distances as candidates; the value = shortest copy at a ring distance, 0 = W6
     uint32_t dbgFrameBlocks, dbgPartFrames;   // test hooks (env GC_FRAME_BLOCKS / GC_PART_FRAMES): small frames / parts so that
                                               // the multi-frame and multi-part paths can be exercised on small inputs
     hipEvent_t ev[8];         // 0 lz start, 1 lz end, 2 huf end, 3 seq start, 4 seq end, 5 plan start, 6 plan end, 7 emit end
@@ -1111,9 +1111,10 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     c->farPass2 = 0u; gc_env_u32("GC_FAR2_PASS", 0u, 1u, &c->farPass2);
     c->ringParse = level >= 5 ? (2u | (8u << 8) | (4u << 16) | (16u << 24)) : 0u; gc_env_u32("GC_BR_RING", 0u, 0xFFFFFFFFu, &c->ringParse);
     c->ringGeom = 256u; { uint32_t g = 0; if (gc_env_u32("GC_BR_RING_GEOM", 64u, 256u, &g) && (g & 63u) == 0u) c->ringGeom = g; }     // test hook: 64 / 128 / 256 threads = 4 / 8 / 16 sub-blocks
-    c->laneParse = level >= 8 ? 1u : 0u; gc_env_u32("GC_BR_LANE", 0u, 1u, &c->laneParse);      // qualities 8-11: W7L with the ring's first entries as its repeat distances, per block where phase A's paths repeat (launch_finder_part)
+    c->laneParse = level >= 7 ? 1u : 0u; gc_env_u32("GC_BR_LANE", 0u, 1u, &c->laneParse);      // qualities 7-11: W7L with the ring's first entries as its repeat distances, per block where phase A's paths repeat (launch_finder_part)
     c->lastCodecHint = 2; c->priceMinLen = 3u; c->priceLitCtx = 0u;     // copies of >= 3 bytes (a 2-byte copy at a fresh distance never pays in brotli), one literal code per meta-block
-    c->priceParse = level >= 8 ? 1u : 0u;         // the reference parses greedily up to quality 9 (zopfli from 10).  Measured at quality 6
+    c->priceParse = level >= 7 ? 1u : 0u;         // (quality 7 since round 6 -- emulator, 2 MiB, with W7L: real sources 1.018 -> 0.980 x the reference, shared objects 1.040 -> 1.026, text 0.963 -> 0.939.)
+                                                  // The reference parses greedily up to quality 9 (zopfli from 10).  Measured at quality 6
                                                   // (run 28, 64 MiB per corpus): greedy + far pass 0.979-1.002 x the reference at 16.6 GB/s,
                                                   // price-based parse without far pass 0.983-1.012 x at 11.1 GB/s, both 0.93-0.98 x at 9.4 GB/s
     gc_env_u32("GC_PRICE_PARSE", 0u, 1u, &c->priceParse);                                      // test hook

@@ -1193,7 +1193,7 @@ MFK(gc_mf_vparse_tile_kernel)(const uint8_t* __restrict__ src, uint64_t srcSize,
 }
 
 #ifndef GC_MF_FAST       // (W6 works on blocks, not tiles: one copy)
-// ------------------------------------------------------------------------------------------------ W6r ring-aware parse (BROTLI qualities 5-7, round 6)
+// ------------------------------------------------------------------------------------------------ W6r ring-aware parse (BROTLI qualities 5-6, round 6)
 // The reference's hasher tries the LAST DISTANCES first at every position and scores them without their distance bits (C/brotli/enc/hash_longest_match64_inc.h:185-222,
 // BackwardReferenceScoreUsingLastDistance / ...PenaltyUsingLastDistance enc/hash.h:113-131), inside the greedy loop with one-step look-ahead of
 // enc/backward_references_inc.h:38-140.  On data that repeats with small differences -- machine code, tables of records -- it stays at one distance from copy to copy:

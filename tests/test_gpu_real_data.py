@@ -60,7 +60,7 @@ NOT_YET_LEVELS = {("zstd", 19, "real-src"): "1.077 x btultra2 on real sources (r
                   ("zstd", 19, "real-bin"): "1.044 x btultra2 on shared objects (round 6; 1.043 in round 5)",
                   ("flzma2", 7, "real-bin"): "1.041 x the reference's level 7 on shared objects (round 6, first measurement; real sources 1.019)",
                   ("brotli", 5, "real-src"): "1.038 x the reference's quality 5 on 32 MiB of real sources (round 6, run final4; shared objects 1.001)",
-                  ("brotli", 7, "real-src"): "1.060 x the reference's quality 7 on 32 MiB of real sources (round 6, run final4; shared objects 1.009): its hasher keeps 2^6 candidates per bucket at this quality",
+                  ("brotli", 7, "real-src"): "met in round 6: 1.004 x the reference's quality 7 on 32 MiB of real sources (quality 7 on the price-based parse with W7L; 1.060 with the greedy parse); a guard",
                   ("brotli", 9, "real-bin"): "met in round 6: 0.980 x the reference's quality 9 on shared objects (qualities 8-11 run W7L, the lane-per-window parse with the last distances at every node; 1.023 with W7); a guard",
                   ("brotli", 9, "real-src"): "1.038 x the reference's quality 9 on 32 MiB of real sources (round 6, W7L; 1.092 with W7)"}
 
