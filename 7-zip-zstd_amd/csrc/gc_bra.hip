@@ -314,11 +314,12 @@ static int bra_riscv(const void* d_src, void* d_dst, size_t n, uint32_t pc, int 
     if ((n & ~(size_t)1) <= 6u) return GC_OK;
     uint64_t* dRes = nullptr; uint64_t res = 0;
     if (gc_scratch_alloc((void**)&dRes, 8) != hipSuccess) return GC_ERR_NOMEM;
+    if (hipMemsetAsync(dRes, 0xFF, 8, gc_tls_stream) != hipSuccess) { gc_scratch_free(dRes); return GC_ERR_HIP; }       // a mark the kernel must overwrite
     const uint64_t lanes = (((uint64_t)n & ~1ull) - 6u + BRA86_CHUNK - 1u) / BRA86_CHUNK;
     GC_LAUNCH(gc_bra_riscv_kernel, (uint32_t)((lanes + 255u) / 256u), 256, gc_tls_stream, (const uint8_t*)d_src, (uint8_t*)d_dst, (uint64_t)n, pc, (uint32_t)(encoding != 0), dRes);
     const bool ok = hipStreamSynchronize(gc_tls_stream) == hipSuccess && gc_copy_sync(&res, dRes, 8, hipMemcpyDeviceToHost) == hipSuccess;
     gc_scratch_free(dRes);
-    if (!ok) return GC_ERR_HIP;
+    if (!ok || res > (uint64_t)n) return GC_ERR_HIP;
     if (processed) *processed = (size_t)res;
     return GC_OK;
 }
@@ -466,11 +467,12 @@ extern "C" int gc_bra_x86_convert_device(const void* d_src, void* d_dst, size_t 
     if (n < 5u) return GC_OK;                                // Bra86.c:52: nothing is processed, the state stays
     uint64_t* dRes = nullptr; uint64_t res[2] = { 0, 0 };
     if (gc_scratch_alloc((void**)&dRes, 16) != hipSuccess) return GC_ERR_NOMEM;
+    if (hipMemsetAsync(dRes, 0xFF, 16, gc_tls_stream) != hipSuccess) { gc_scratch_free(dRes); return GC_ERR_HIP; }      // a mark the kernel must overwrite (the lane that reaches the end stores position and state)
     const uint64_t lanes = ((uint64_t)n - 4u + BRA86_CHUNK - 1u) / BRA86_CHUNK;
     GC_LAUNCH(gc_bra86_kernel, (uint32_t)((lanes + 255u) / 256u), 256, gc_tls_stream, (const uint8_t*)d_src, (uint8_t*)d_dst, (uint64_t)n, pc, (uint32_t)(encoding != 0), *state, dRes);
     const bool ok = hipStreamSynchronize(gc_tls_stream) == hipSuccess && gc_copy_sync(res, dRes, 16, hipMemcpyDeviceToHost) == hipSuccess;
     gc_scratch_free(dRes);
-    if (!ok) return GC_ERR_HIP;
+    if (!ok || res[0] > (uint64_t)n) return GC_ERR_HIP;             // (the mark is still there, or a position behind the buffer: never report bytes as converted on such a result)
     *state = (uint32_t)res[1];
     if (processed) *processed = (size_t)res[0];
     return GC_OK;

@@ -75,6 +75,7 @@ gc_crc32_chunk_kernel(const uint8_t* __restrict__ src, uint32_t nChunks, const G
 // ---------------------------------------------------------------------------------------------------- host side
 #ifndef __HIP_DEVICE_COMPILE__
 thread_local hipStream_t gc_tls_stream = nullptr;          // (gc_device.h)
+thread_local GcScratchSlot gc_tls_scratch[4] = { { nullptr, 0, false }, { nullptr, 0, false }, { nullptr, 0, false }, { nullptr, 0, false } };   // (gc_host_stream.h)
 #endif
 static uint32_t crc_byte_table_entry(uint32_t i) { uint32_t r = i; for (int k = 0; k < 8; k++) r = (r >> 1) ^ (0xEDB88320u & (0u - (r & 1u))); return r; }
 static uint32_t crc_mat_apply(const uint32_t m[32], uint32_t v) { uint32_t r = 0; for (int i = 0; i < 32; i++) if ((v >> i) & 1u) r ^= m[i]; return r; }

@@ -190,3 +190,28 @@ def test_gpu_x86_converter_matches_the_reference(pkg, O, graft):
                 got, gdone, gst = _x86_gpu(pkg, None, x, pc, enc, st, dev=True)
                 assert np.array_equal(got, want), (dense, n, enc)
                 assert (gdone, gst) == (wdone, wst)
+
+
+@pytest.mark.gpu
+def test_gpu_x86_converter_results_of_calls_in_a_row(pkg, O, graft):
+    """Round 6: `7z a -m0=BCJGPU` wrote a wrong archive about once in ten runs -- a call on 155 KB right behind calls on 2 MiB and on 3 bytes came back with the 2 MiB
+    call's `processed` (the 16-byte result was read back from stream-ordered pool memory; gc_host_stream.h).  The pattern of 7-Zip's filter coder, many times: every
+    call's position and state against the reference converter's."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    if O.ref("bra") is None:
+        pytest.skip("oracle/_ref did not travel")
+    graft.build_hip()
+    sizes = [2_097_089, 3, 155_267, 1, 2_097_092, 4, 70_001]
+    xs = [_x86_like(n, 700 + i) for i, n in enumerate(sizes)]
+    want = [O.ref_bra_x86_convert(x, 0x1000 * i, True, 0) for i, x in enumerate(xs)]
+    d_in = [torch.from_numpy(x).cuda() for x in xs]
+    d_out = [torch.empty(max(1, x.size), dtype=torch.uint8, device="cuda") for x in xs]
+    torch.cuda.synchronize()
+    for rep in range(150):
+        for i, x in enumerate(xs):
+            done, st = pkg.bra_x86_convert_device(d_in[i].data_ptr(), d_out[i].data_ptr(), x.size, 0x1000 * i, True, 0)
+            assert (done, st) == (want[i][1], want[i][2]), (rep, i, x.size, done, want[i][1])
+    for i, x in enumerate(xs):
+        assert np.array_equal(d_out[i][: x.size].cpu().numpy(), want[i][0]), i
