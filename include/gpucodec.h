@@ -66,7 +66,7 @@ int         gc_zstd_last_timing(gc_ctx* ctx, float ms[6]);
  * HIP-event durations in the last call (any codec).  GC_ERR_PARAM if the last call used the block-local finder. */
 int         gc_mf_last_timing(gc_ctx* ctx, float ms[6]);
 
-/* The price-based parse (FLZMA2 level >= 5, zstd level >= 16, brotli quality >= 8: the counterpart of LZMA_optimalParse
+/* The price-based parse (FLZMA2 level >= 3, zstd level >= 5, brotli quality >= 7: the counterpart of LZMA_optimalParse
  * C/fast-lzma2/lzma2_enc.c:949 and ZSTD_compressBlock_opt_generic C/zstd/zstd_opt.c:1077) runs four kernels inside the "parse"
  * entry above; ms[0..3] = greedy parse + statistics, short candidates, shortest path, second parse pass.  GC_ERR_PARAM if the
  * last call did not run it. */
