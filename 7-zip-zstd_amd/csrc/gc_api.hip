@@ -576,7 +576,7 @@ static int launch_finder_part(gc_ctx* c, hipStream_t st, uint32_t part, const ui
     } else if (c->ringParse) {
         if ((c->ringParse >> 8) & 0xFFu)                               // W6r on the blocks that W6's parse shows to come back to their last distances
             GC_LAUNCH(gc_mf_parse_kernel, perB * GC_XCDS, GC_MF_PARSE_T, st, src, (uint64_t)n, nBlocks, perB, c->lazyDepth, (const uint32_t*)rec, seqRaw, lit, meta, (uint16_t*)nullptr, 0u);
-        GC_LAUNCH(gc_mf_ringparse_kernel, perB * GC_XCDS, c->ringGeom, st, src, (uint64_t)n, nBlocks, perB, c->lazyDepth, c->ringParse, (const uint32_t*)rec, seqRaw, lit, meta);
+        GC_LAUNCH(gc_mf_ringparse_kernel, perB * GC_XCDS, c->ringGeom, st, src, (uint64_t)n, nBlocks, perB, c->lazyDepth < 1u ? c->lazyDepth : 1u, c->ringParse, (const uint32_t*)rec, seqRaw, lit, meta);
     }
     else
         GC_LAUNCH(gc_mf_parse_kernel, perB * GC_XCDS, GC_MF_PARSE_T, st, src, (uint64_t)n, nBlocks, perB, c->lazyDepth, (const uint32_t*)rec, seqRaw, lit, meta, (uint16_t*)nullptr, 0u);
@@ -1094,7 +1094,8 @@ extern "C" int gc_brotli_compress_device(gc_ctx* c, const void* d_src, size_t n,
     const uint8_t* src = (const uint8_t*)d_src;
     HIPCHK(c, hipMemsetAsync(c->brStage, 0, (size_t)nBlocks * GC_BR_STAGE_STRIDE, c->stream));
     uint32_t frameBlocks = brotli_frame_blocks(level, bpcFinder);
-    c->lazyDepth = level >= 7 ? 2u : 1u;
+    c->lazyDepth = level >= 5 ? 2u : 1u; gc_env_u32("GC_BR_LAZY", 0u, 2u, &c->lazyDepth);        // W6 looks two positions ahead from quality 5 (round 6, emulator, 4 MiB at quality 6: web-text 0.960 -> 0.950 x the reference;
+                                                                                                  // it was 7).  W6r keeps one position (two: shared objects 1.035 -> 1.039).  Test hook
     c->mfFast = level <= 6 ? 1u : 0u;        // (qualities 5-6 run the far pass on the fast geometry: 0.97-0.99 x the reference at 15 % less time than on the wide one)
     // W5b from quality 7: four links (eight from quality 10) for the starts of matches in tiles with long matches, two elsewhere.  Quality 5 stays without it (round 3 measured
     // quality 6 with (8, 0) (run r03_q3): sources 1.084 -> 1.068 x the reference and the Python library 1.024 -> 1.015, but web-text -- config C5's data, whose boilerplate
