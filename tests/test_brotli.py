@@ -172,7 +172,7 @@ def test_emu_ring_parse_on_tables_and_machine_code(pkg, O, emu_lib_path, monkeyp
             assert np.array_equal(O.ref_brotlimt_decompress(c, x.size, 2), x), name
         if bar is None:
             assert np.array_equal(ring, w6), name                       # no block selected: W6's parse, byte for byte
-            assert len(forced) <= 1.005 * len(w6), (name, len(forced), len(w6))
+            assert len(forced) <= 1.02 * len(w6), (name, len(forced), len(w6))        # (W6 looks two positions ahead at this quality, W6r one: 1 % on text -- which is why text stays with W6)
         else:
             assert len(ring) <= bar * len(w6), (name, len(ring), len(w6))
             assert len(forced) <= 1.001 * len(ring), (name, len(forced), len(ring))     # (the selection reads W6's parse: a block whose W6 parse never returns to a distance is left alone although W6r would gain there)
